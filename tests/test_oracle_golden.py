@@ -1,0 +1,112 @@
+"""Pin the oracle (oracle/envelope_oracle.py) against the reference-generated golden fixtures.
+
+The fixtures under tests/golden/ were produced by the unmodified reference ``Envelope.update()`` (see
+tests/golden/make_golden.py).  On CPU, with one intra-op thread, the oracle must reproduce them bit-for-bit.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch as th
+
+import envelope_oracle as orc
+from cases import CASES, make_inputs, pareto_sets
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _run_oracle(c, dedup):
+    th.set_num_threads(1)
+    inp = make_inputs(c)
+    online = [th.tensor(a) for a in inp["online"]]
+    target = [th.tensor(a) for a in inp["target"]]
+    m = [th.tensor(a) for a in inp["exp_avg"]]
+    v = [th.tensor(a) for a in inp["exp_avg_sq"]]
+    batch = tuple(th.tensor(inp[k]) for k in ("obs", "actions", "rewards", "next_obs", "dones"))
+    sw = th.tensor(inp["sampled_w"]).float()
+    out = orc.envelope_update(online, target, m, v, c.step, batch, sw, n_actions=c.A, reward_dim=c.R,
+                              gamma=c.gamma, lr=c.lr, max_grad_norm=c.max_grad_norm, envelope=c.envelope,
+                              homotopy_lambda=c.homotopy_lambda, dedup=dedup)
+    return out, online, m, v
+
+
+@pytest.mark.parametrize("c", CASES, ids=lambda c: c.name)
+@pytest.mark.parametrize("dedup", [False, True])
+def test_envelope_update_matches_reference(c, dedup):
+    if dedup and not c.envelope:
+        pytest.skip("dedup only applies to the envelope target")
+    g = np.load(os.path.join(GOLD, f"envelope_{c.name}.npz"))
+    out, online, m, v = _run_oracle(c, dedup)
+    s = c.subsample
+    assert np.array_equal(out["target"].numpy(), g["target"])
+    assert np.float32(out["loss"].item()) == g["loss"]
+    if c.max_grad_norm is not None:
+        assert np.float32(out["grad_norm"].item()) == g["grad_norm"]
+    for i in range(len(online)):
+        assert np.array_equal(out["grads"][i].numpy().reshape(-1)[::s], g[f"grad_{i}"]), f"grad {i}"
+        assert np.array_equal(online[i].numpy().reshape(-1)[::s], g[f"param_after_{i}"]), f"param {i}"
+        assert np.array_equal(m[i].numpy().reshape(-1)[::s], g[f"exp_avg_{i}"])
+        assert np.array_equal(v[i].numpy().reshape(-1)[::s], g[f"exp_avg_sq_{i}"])
+        if c.max_grad_norm is not None:
+            assert np.array_equal(out["grads_raw"][i].numpy().reshape(-1)[::s], g[f"grad_raw_{i}"])
+    # PER priority: (|td . w| + min_priority) ** alpha on the host, envelope.py:331-333
+    pr = (out["priority_raw"].numpy().flatten() + 0.125) ** 0.6
+    assert np.array_equal(pr.astype(np.float64), g["priority_final"])
+
+
+def test_dedup_indices_consistent():
+    c = [c for c in CASES if c.name == "dup_weights"][0]
+    a, *_ = _run_oracle(c, False)
+    b, *_ = _run_oracle(c, True)
+    assert th.equal(a["pref"], b["pref"]) and th.equal(a["ac"], b["ac"])
+    # duplicated weights => exact ties across j; first index must win (never 3 or 4 when 1 / 0 tie with them)
+    assert not bool(((b["pref"] == 3) | (b["pref"] == 4)).any())
+
+
+def test_pareto_masks_match_reference():
+    g = np.load(os.path.join(GOLD, "pareto_masks.npz"))
+    for name, pts in pareto_sets().items():
+        for rd in (True, False):
+            want = g[f"{name}__rd{int(rd)}"].astype(bool)
+            got = orc.pareto_mask(pts, remove_duplicates=rd)
+            assert np.array_equal(got, want), (name, rd)
+
+
+def test_sumtree_trace_matches_reference():
+    g = np.load(os.path.join(GOLD, "per_trace.npz"))
+    rng = np.random.default_rng(5)
+    tree = orc.SumTree(50)
+    minp, ptr = 1e-5, 0
+    for t in range(70):
+        for _ in range(4):  # consume the same generator draws the buffer contents used
+            pass
+        rng.standard_normal(3); rng.integers(4); rng.standard_normal(2); rng.standard_normal(3)
+        tree.set(ptr, minp)
+        ptr = (ptr + 1) % 50
+        if t % 10 == 9:
+            idx = tree.sample_from_uniforms(g[f"u_{t}"])
+            assert np.array_equal(idx, g[f"idx_{t}"])
+            pr = (rng.random(16) + 0.01) ** 0.6
+            assert np.array_equal(pr, g[f"pr_{t}"])
+            minp = max(minp, pr.max())
+            tree.batch_set(idx, pr)
+            assert tree.nodes[0][0] == g[f"root_{t}"]
+            assert minp == g[f"minp_{t}"]
+    assert np.array_equal(tree.nodes[-1], g["leaves"])
+    assert np.array_equal(tree.nodes[3], g["level3"])
+
+
+def test_misc_known_answers():
+    g = np.load(os.path.join(GOLD, "misc.npz"))
+    got = np.array([orc.linearly_decaying_value(1.0, 50000, s, 100, 0.05) for s in (0, 100, 101, 25000, 50100, 90000)])
+    assert np.array_equal(got, g["lin_decay"])
+    assert np.float32(orc.huber(th.tensor(g["huber_x"]), 0.01).item()) == g["huber"]
+
+
+def test_uniform_stream_equivalence():
+    """np.random.uniform(0, T, n) == 0 + (T - 0) * np.random.random_sample(n), draw for draw."""
+    np.random.seed(7)
+    a = np.random.uniform(0, 3.7, size=100)
+    np.random.seed(7)
+    b = 0.0 + (3.7 - 0.0) * np.random.random_sample(100)
+    assert np.array_equal(a, b)
