@@ -1,0 +1,153 @@
+/*
+ * morl_hip.h -- C ABI of libmorl_hip.so: the MI355X (gfx950) native hot path of the
+ * multi-objective TD update of LucasAlegre/morl-baselines.
+ *
+ * The reference has no FFI/plugin boundary (it is 100 % Python on PyTorch); the boundary it does
+ * have is the Python class API (MOPolicy.update / Envelope.envelope_target / ReplayBuffer.sample,
+ * common/pareto.py functions).  Each entry point below replaces the arithmetic of one of those
+ * reference call sites (cited per function as path:line under /root/reference/morl_baselines)
+ * and is bound from Python with ctypes (INTEGRATION.md shows the stub a maintainer would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative morl_status otherwise; the message of the
+ *     last failure on the calling thread is available from morl_last_error().
+ *   - every pointer marked "device" is caller-owned device memory (e.g. a torch tensor's
+ *     data_ptr()); the library never frees or retains it beyond the call.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it, no
+ *     call synchronises the host unless stated.
+ *   - plain C types only: no torch / HIP types in any signature.
+ *   - a morl_ctx owns only scratch workspace (activations, split-K slabs); one ctx per agent,
+ *     not thread-safe per ctx.
+ */
+#ifndef MORL_HIP_H
+#define MORL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MORL_MAX_LAYERS 8   /* linear layers per network */
+#define MORL_MAX_OBJ 8      /* reward dimension R */
+#define MORL_ABI_VERSION 1
+
+typedef enum morl_status {
+    MORL_OK = 0,
+    MORL_ERR_ARG = -1,      /* bad argument (shape, alignment, null) */
+    MORL_ERR_HIP = -2,      /* a HIP runtime call failed */
+    MORL_ERR_STATE = -3,    /* ctx too small for the request */
+    MORL_ERR_ALLOC = -4
+} morl_status;
+
+typedef struct morl_ctx morl_ctx;
+
+/* Weight-conditioned Q network: cat(obs, w) -> [Linear, ReLU] * (n_layers-1) -> Linear -> (A, R).
+ * dims[0] = D + R, dims[n_layers] = A * R.  Flat parameter layout (what the torch nn.Parameters
+ * are views of): for l = 0..n_layers-1: W_l (dims[l+1] x dims[l], row-major = nn.Linear.weight),
+ * then b_l (dims[l+1]).  Replaces QNet / mlp: multi_policy/envelope/envelope.py:33-77,
+ * common/networks.py:10-48. */
+typedef struct morl_net_desc {
+    int32_t n_layers;
+    int32_t dims[MORL_MAX_LAYERS + 1];
+    int32_t obs_dim;     /* D */
+    int32_t reward_dim;  /* R */
+    int32_t n_actions;   /* A */
+} morl_net_desc;
+
+/* Hyper-parameters of one Envelope gradient step (envelope.py:88-118 constructor arguments). */
+typedef struct morl_update_cfg {
+    float gamma;
+    float homotopy_lambda;   /* 0 => plain MSE (envelope.py:309) */
+    float max_grad_norm;     /* < 0 => no clipping (max_grad_norm=None) */
+    double lr, beta1, beta2, eps; /* float64 like torch's Python-side scalars (adam.py) */
+    int32_t adam_step;       /* 1-based index of the step being taken */
+    int32_t envelope;        /* 1: envelope target (envelope.py:404-440), 0: DDQN target (:442-463) */
+    int32_t apply_step;      /* 0: stop after gradients (parity tests) */
+} morl_update_cfg;
+
+/* Optional device outputs of morl_envelope_update (any may be NULL). */
+typedef struct morl_update_out {
+    float* loss;          /* [1]   critic loss (envelope.py:307-313)                               */
+    float* grad_norm;     /* [1]   total L2 norm before clipping (envelope.py:324-325)               */
+    float* priority;      /* [B]   |td . w| of the weight-0 rows (envelope.py:330-331)               */
+    float* target;        /* [W*B][R] envelope / DDQN target, row r = i*B + b (envelope.py:293-297)  */
+    int32_t* pref;        /* [W*B] arg-max weight index j* (envelope.py:426), envelope only          */
+    int32_t* ac;          /* [W*B] arg-max action a* (envelope.py:424 / :455)                        */
+    float* q_online_next; /* [B][W][A][R] Q_online(s'_b, w_j)  (de-duplicated rows)                  */
+    float* q_target_next; /* [B][W][A][R] Q_target(s'_b, w_j)                                        */
+    float* q_values;      /* [W*B][A][R] Q_online(s_b, w_i), row r = i*B + b (envelope.py:300)       */
+} morl_update_out;
+
+const char* morl_last_error(void);
+int morl_abi_version(void);
+/* 1 when the library was built by hipcc for gfx950, 0 for the host-emulated test build (tests/hipsim). */
+int morl_is_device_build(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max_batch, int max_weights);
+int morl_ctx_destroy(morl_ctx* ctx);
+/* number of float parameters of `net` in the flat layout */
+int64_t morl_param_count(const morl_net_desc* net);
+
+/* ---- replay buffer: common/buffer.py:68-96 (gather part of ReplayBuffer.sample) -------------
+ * records: device, row-major [capacity][record_floats] with one transition per row laid out as
+ *   obs[D] | next_obs[D] | reward[R] | done[1] | action[1] (action stored as float)
+ * idx: device int64 [B].  Outputs are device arrays shaped as the reference returns them. */
+int morl_gather_batch(const float* records, int record_floats, int64_t capacity, const int64_t* idx, int B,
+                      int D, int R, float* obs, float* next_obs, float* rewards, float* dones,
+                      int32_t* actions, void* stream);
+
+/* ---- QNet.forward: envelope.py:60-77 ----------------------------------------------------------
+ * Evaluates Q(obs_b, w_k) for all B x W pairs.  row_order 0: row = b*W + k ("next-state slab"
+ * [B][W][A][R]); row_order 1: row = k*B + b (the reference's tiled TD-row order, envelope.py:284-291).
+ * q_out: device [B*W][A*R]. */
+int morl_qnet_forward(morl_ctx* ctx, const float* params, const float* obs, const float* weights, int B, int W,
+                      int row_order, float* q_out, void* stream);
+
+/* ---- envelope arg-max: envelope.py:422-439 (and DDQN :454-462 when diag_only) -----------------
+ * qo, qt: device [B][W][A][R]; weights: device [W][R].  For TD row (i, b):
+ * (j*, a*) = first arg-max over (j, a) of w_i . qo[b][j][a][:] (products and sums separately rounded in
+ * objective order, as the reference's batched einsum); target[i*B+b][:] = qt[b][j*][a*][:].
+ * diag_only = 1 restricts j to i (DDQN).  pref / ac may be NULL. */
+int morl_envelope_reduce(const float* qo, const float* qt, const float* weights, int B, int W, int A, int R,
+                         int diag_only, float* target, int32_t* pref, int32_t* ac, void* stream);
+
+/* ---- one Envelope gradient step: envelope.py:269-334 -------------------------------------------
+ * All arrays device.  params_online / grads / exp_avg / exp_avg_sq: flat [P]; params_target: flat [P]
+ * (read-only).  obs/next_obs [B][D], actions int32 [B], rewards [B][R], dones [B], weights [W][R].
+ * Computes targets with the de-duplicated B*W-row formulation (bit-identical to the reference's
+ * W^2*B-row formulation, SURVEY.md headline fact 3), MSE (+ homotopy) loss, gradients (written to
+ * `grads`, post-clip as torch leaves them), clip_grad_norm_ and torch's single-tensor Adam. */
+int morl_envelope_update(morl_ctx* ctx, float* params_online, const float* params_target, float* grads,
+                         float* exp_avg, float* exp_avg_sq, const float* obs, const float* next_obs,
+                         const int32_t* actions, const float* rewards, const float* dones, const float* weights,
+                         int B, int W, const morl_update_cfg* cfg, const morl_update_out* out, void* stream);
+
+/* ---- polyak_update: common/networks.py:120-139 ------------------------------------------------- */
+int morl_polyak(const float* src, float* dst, float tau, int64_t n, void* stream);
+
+/* ---- get_non_pareto_dominated_inds: common/pareto.py:34-57 --------------------------------------
+ * points: device float64 [N][R]; mask_out: device uint8 [N] (1 = keep).  Bit-exact boolean result. */
+int morl_pareto_mask(const double* points, int N, int R, int remove_duplicates, uint8_t* mask_out, void* stream);
+
+/* ---- PER sum-tree: common/prioritized_buffer.py:12-82 (device-resident) -------------------------
+ * tree: device float64, levels concatenated root first; level l has 2^l nodes and starts at offset
+ * 2^l - 1; n_levels = ceil(log2(capacity)) + 1.
+ * sample:  idx[k] = descent for query 0 + (root - 0) * u01[k]          (SumTree.sample :30-54)
+ * set:     sequential tree.set(ptr[k], value[k]) (value < 0 => use *running_max)  (SumTree.set :56-67,
+ *          PrioritizedReplayBuffer.add :126-147)
+ * update:  running_max = max(running_max, max(pr)); batch_set(idx, pr) keeping the first occurrence of
+ *          duplicated indices and adding in ascending index order (:69-82, :187-195).
+ *          pr[k] = (raw[k] + running_max_before) ** alpha when `raw` is given (envelope.py:333). */
+int morl_sumtree_sample(const double* tree, int n_levels, const double* u01, int B, int64_t* idx, void* stream);
+int morl_sumtree_set(double* tree, int n_levels, const int64_t* ptr, const double* value, int n,
+                     double* running_max, void* stream);
+int morl_sumtree_update(double* tree, int n_levels, const int64_t* idx, const float* raw, int B, double alpha,
+                        double* running_max, double* pr_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MORL_HIP_H */

@@ -1,0 +1,179 @@
+// Envelope-Q specific kernels: network-input assembly, the envelope arg-max + TD epilogue.
+#pragma once
+#include "morl_device.h"
+#include "morl_hip.h"
+
+namespace morl {
+
+// ----------------------------------------------------------------------------------------------
+// X0[row][0:D] = obs[b][:], X0[row][D:D+R] = weights[k][:], zero padding up to ldx.
+// row_order 0: row = b*W + k (next-state slab order); 1: row = k*B + b (reference TD-row order,
+// envelope.py:284-291).  Replaces th.cat((obs, w)) of QNet.forward (envelope.py:75) together with the
+// repeat / repeat_interleave tiling (envelope.py:284-291, 416-418) -- the tiled batch is never built.
+// HBM-bound: writes rows*ldx*4 bytes, reads are L2 hits.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_input_kernel(const float* __restrict__ obs,
+                                                          const float* __restrict__ weights, float* __restrict__ x0,
+                                                          int B, int W, int D, int R, int ldx, int row_order) {
+    const long long total = (long long)B * W * ldx;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(e / ldx), c = (int)(e % ldx);
+        int b, k;
+        if (row_order == 0) { b = row / W; k = row % W; } else { k = row / B; b = row % B; }
+        float v = 0.f;
+        if (c < D) v = obs[(size_t)b * D + c];
+        else if (c < D + R) v = weights[(size_t)k * R + (c - D)];
+        x0[e] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Envelope arg-max + TD target + loss gradient, one workgroup per transition b (4 waves).
+//
+//   scal(i; j, a) = w_i . Qo[b][j][a][:]   -- products and sums separately rounded, objective order
+//                                            (bit-identical to th.einsum("br,bwar->bwa"), envelope.py:422)
+//   (j*, a*) = first arg-max over the flattened (j, a) index  (== max over a then arg-max over j with
+//              torch's first-max tie-break, envelope.py:424-426)
+//   target[i,b,:] = Qt[b][j*][a*][:]                                      (envelope.py:429-439)
+//   tq = r_b + ((1 - done_b) * gamma) * target                             (envelope.py:298)
+//   td = Q[i,b,action_b,:] - tq ; dQ = dLoss/dQ for MSE (+ homotopy term)  (envelope.py:300-313)
+//
+// The Qo[b] slab (W*A*R floats) and the weight vectors are staged in LDS once and shared by the W
+// rows of this transition; each wave owns rows i = wave, wave+4, ...; the 64 lanes split the W*A
+// candidates and reduce (value, index) with wave shuffles, lowest index winning ties.
+// diag_only restricts j to i (DDQN target, envelope.py:442-463).
+// HBM-bound and tiny: reads 2*B*W*A*R*4 bytes once.
+// ----------------------------------------------------------------------------------------------
+constexpr int ENV_MAX_SLAB = 6144;   // floats of LDS for one Qo[b] slab (W*A*R)
+constexpr int ENV_MAX_WR = 1024;     // floats of LDS for the weight vectors (W*R)
+
+struct EnvelopeTdArgs {
+    const float* qo;        // [B][W][A][R]
+    const float* qt;        // [B][W][A][R]
+    const float* weights;   // [W][R]
+    const float* q_main;    // [W*B][ldq]  Q_online(s_b, w_i), row i*B+b ; may be NULL (reduce only)
+    const int32_t* actions; // [B]
+    const float* rewards;   // [B][R]
+    const float* dones;     // [B]
+    float* target;          // [W*B][R] or NULL
+    int32_t* pref;          // [W*B] or NULL
+    int32_t* ac;            // [W*B] or NULL
+    float* dq;              // [W*B][ldq] gradient wrt Q (zero outside the taken action) or NULL
+    double* loss_part;      // [B][2]  sum td^2, sum (wQ - wTQ)^2 over this transition's W rows, or NULL
+    float* priority;        // [B] |td . w| of the i = 0 row, or NULL
+    int B, W, A, R, ldq;
+    int diag_only;
+    float gamma;
+    float c_mse;            // (1 - lambda) * 2 / (W*B*R)
+    float c_aux;            // lambda * 2 / (W*B)
+};
+
+__global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
+    __shared__ float s_q[ENV_MAX_SLAB];
+    __shared__ float s_w[ENV_MAX_WR];
+    __shared__ double s_red[4][2];
+    const int b = (int)blockIdx.x;
+    const int lane = lane_id(), wave = wave_id();
+    const int W = p.W, A = p.A, R = p.R;
+    const int slab = W * A * R;
+    for (int e = (int)threadIdx.x; e < slab; e += (int)blockDim.x) s_q[e] = p.qo[(size_t)b * slab + e];
+    for (int e = (int)threadIdx.x; e < W * R; e += (int)blockDim.x) s_w[e] = p.weights[e];
+    __syncthreads();
+
+    double acc_mse = 0.0, acc_aux = 0.0;
+    const float not_done_gamma =
+        (p.q_main != nullptr) ? __fmul_rn(__fsub_rn(1.0f, p.dones[b]), p.gamma) : 0.f;  // (1 - d) * gamma
+    const int act = (p.q_main != nullptr) ? p.actions[b] : 0;
+
+    for (int i = wave; i < W; i += 4) {
+        float wi[MORL_MAX_OBJ];
+#pragma unroll
+        for (int r = 0; r < MORL_MAX_OBJ; ++r) wi[r] = (r < R) ? s_w[i * R + r] : 0.f;
+        const int c_begin = p.diag_only ? i * A : 0;
+        const int c_end = p.diag_only ? (i + 1) * A : W * A;
+        float best = -INFINITY;
+        int best_c = 0x7fffffff;
+        for (int c = c_begin + lane; c < c_end; c += kWave) {
+            const float* q = s_q + c * R;
+            float s = __fmul_rn(wi[0], q[0]);
+#pragma unroll
+            for (int r = 1; r < MORL_MAX_OBJ; ++r)
+                if (r < R) s = __fadd_rn(s, __fmul_rn(wi[r], q[r]));
+            if (s > best || best_c == 0x7fffffff) { best = s; best_c = c; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off);
+            const int oc = __shfl_xor(best_c, off);
+            if (oc != 0x7fffffff && (best_c == 0x7fffffff || ov > best || (ov == best && oc < best_c))) {
+                best = ov;
+                best_c = oc;
+            }
+        }
+        const int jstar = best_c / A, astar = best_c % A;
+        const size_t row = (size_t)i * p.B + b;
+        const float* qt = p.qt + ((size_t)b * W * A + best_c) * R;
+        if (lane == 0) {
+            if (p.pref) p.pref[row] = jstar;
+            if (p.ac) p.ac[row] = astar;
+        }
+        if (p.target && lane < R) p.target[row * R + lane] = qt[lane];
+        if (p.q_main == nullptr) continue;
+
+        // every lane evaluates the R-vector redundantly (broadcast loads), lanes then split the dQ row
+        float td[MORL_MAX_OBJ];
+        float wq = 0.f, wtq = 0.f;
+#pragma unroll
+        for (int r = 0; r < MORL_MAX_OBJ; ++r) {
+            td[r] = 0.f;
+            if (r < R) {
+                const float tq = __fadd_rn(p.rewards[(size_t)b * R + r], __fmul_rn(not_done_gamma, qt[r]));
+                const float qv = p.q_main[row * p.ldq + act * R + r];
+                td[r] = __fsub_rn(qv, tq);
+                wq = (r == 0) ? __fmul_rn(qv, wi[0]) : __fadd_rn(wq, __fmul_rn(qv, wi[r]));
+                wtq = (r == 0) ? __fmul_rn(tq, wi[0]) : __fadd_rn(wtq, __fmul_rn(tq, wi[r]));
+            }
+        }
+        const float daux = __fsub_rn(wq, wtq);
+        if (p.dq) {
+            for (int e = lane; e < p.ldq; e += kWave) {
+                float g = 0.f;
+                const int r = e - act * R;
+                if (r >= 0 && r < R) {
+                    float tdr = 0.f, wr = 0.f;
+#pragma unroll
+                    for (int rr = 0; rr < MORL_MAX_OBJ; ++rr)
+                        if (rr == r) { tdr = td[rr]; wr = wi[rr]; }
+                    g = p.c_mse * tdr + p.c_aux * daux * wr;
+                }
+                p.dq[row * p.ldq + e] = g;
+            }
+        }
+        if (lane == 0) {
+            double m = 0.0;
+#pragma unroll
+            for (int r = 0; r < MORL_MAX_OBJ; ++r)
+                if (r < R) m += (double)td[r] * (double)td[r];
+            acc_mse += m;
+            acc_aux += (double)daux * (double)daux;
+            if (i == 0 && p.priority) {
+                float pr = __fmul_rn(td[0], wi[0]);
+#pragma unroll
+                for (int r = 1; r < MORL_MAX_OBJ; ++r)
+                    if (r < R) pr = __fadd_rn(pr, __fmul_rn(td[r], wi[r]));
+                p.priority[b] = fabsf(pr);
+            }
+        }
+    }
+    if (p.loss_part) {
+        if (lane == 0) { s_red[wave][0] = acc_mse; s_red[wave][1] = acc_aux; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            p.loss_part[(size_t)b * 2 + 0] = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
+            p.loss_part[(size_t)b * 2 + 1] = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
+        }
+    }
+}
+
+}  // namespace morl

@@ -1,0 +1,48 @@
+// Shared device helpers for the gfx950 kernels of libmorl_hip (wave64 everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace morl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWave = 64;
+
+// Exact-f32 matrix core op: D(32x32) = A(32x2) * B(2x32) + C, one f32 per lane for A and B.
+// Lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; D register r of lane l is
+// row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), column l & 31.  v_mfma_f32_32x32x2_f32: 64 cycles / SIMD.
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+// Deterministic butterfly sums (same order on every run; all lanes end with the total).
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// XCD-aware block id: the dispatcher places block b on XCD b % 8; remap so that consecutive logical
+// tiles (which share an operand panel) land on one XCD's L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+}  // namespace morl

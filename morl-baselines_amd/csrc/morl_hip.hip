@@ -1,0 +1,523 @@
+// libmorl_hip.so -- C ABI over the gfx950 kernels (see include/morl_hip.h for the contract).
+// Host side is plain C++: it validates arguments, owns the scratch workspace and enqueues kernels on the
+// caller's stream.  Nothing here synchronises the host.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "morl_hip.h"
+#include "morl_device.h"
+#include "gemm_f32.h"
+#include "envelope_kernels.h"
+#include "optim_kernels.h"
+#include "replay_kernels.h"
+#include "pareto_kernels.h"
+
+using namespace morl;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(MORL_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define LAUNCH_CHECK(name)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = hipGetLastError();                                                          \
+        if (e_ != hipSuccess) return fail(MORL_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char* morl_last_error(void) { return g_err; }
+extern "C" int morl_abi_version(void) { return MORL_ABI_VERSION; }
+extern "C" int morl_is_device_build(void) {
+#ifdef HIPSIM_EMULATED  // defined only by tests/hipsim/hip/hip_runtime.h (host-emulated test build)
+    return 0;
+#else
+    return 1;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels that need the tile engine
+// ------------------------------------------------------------------------------------------------
+namespace morl {
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmProblem g) {
+    const int id = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    gemm_tile<A_KC, B_KC, EPI>(g, id / g.tiles_n, id % g.tiles_n, (int)blockIdx.y);
+}
+
+struct GemmGroup {
+    GemmProblem p[MORL_MAX_LAYERS];
+    int tile_start[MORL_MAX_LAYERS + 1];
+    int n;
+};
+
+// All weight-gradient GEMMs of one backward pass in a single launch (split-K over the batch rows):
+// dW_l[o][i] = sum_m g_l[m][o] * h_l[m][i], db_l[o] = sum_m g_l[m][o].
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_grouped_tn_kernel(GemmGroup grp) {
+    const int id = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int q = 0;
+    while (q + 1 < grp.n && id >= grp.tile_start[q + 1]) ++q;
+    const int local = id - grp.tile_start[q];
+    const GemmProblem& g = grp.p[q];
+    gemm_tile<false, false, EPI_STORE>(g, local / g.tiles_n, local % g.tiles_n, (int)blockIdx.y);
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst,
+                                                        int ldd, long long rows, int cols) {
+    const long long total = rows * cols;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / cols;
+        const int c = (int)(e % cols);
+        dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+
+}  // namespace morl
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct morl_ctx {
+    morl_net_desc net;
+    int L;
+    int64_t P;
+    int64_t offW[MORL_MAX_LAYERS], offB[MORL_MAX_LAYERS];
+    int max_batch, max_weights;
+    int64_t max_rows;
+    int ld0, ldq, max_h;
+    int dw_tiles;
+    // workspace (device)
+    float* x0n = nullptr;   // [rows][ld0]  cat(next_obs_b, w_j), row b*W+j
+    float* x0m = nullptr;   // [rows][ld0]  cat(obs_b, w_i),      row i*B+b
+    float* ping = nullptr;  // [rows][max_h] no-grad activations
+    float* pong = nullptr;
+    float* h[MORL_MAX_LAYERS] = {};   // h[l], l = 1..L-1: saved post-ReLU activations of the training pass
+    float* g[MORL_MAX_LAYERS] = {};   // g[l], l = 0..L-2: dLoss/dz_l ; g[L-1] aliases dq
+    float* qo = nullptr;    // [rows][A*R]
+    float* qt = nullptr;
+    float* qm = nullptr;    // [rows][ldq]
+    float* dq = nullptr;    // [rows][ldq]
+    float* slabs = nullptr; // [max_splits][P]
+    int max_splits;
+    double* sumsq_part = nullptr;  // [OPT_MAX_BLOCKS]
+    double* loss_part = nullptr;   // [max_batch][2]
+};
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int64_t morl_param_count(const morl_net_desc* net) {
+    if (!net || net->n_layers < 1 || net->n_layers > MORL_MAX_LAYERS) return -1;
+    int64_t p = 0;
+    for (int l = 0; l < net->n_layers; ++l) p += (int64_t)net->dims[l + 1] * net->dims[l] + net->dims[l + 1];
+    return p;
+}
+
+static int validate_net(const morl_net_desc* net) {
+    if (!net) return fail(MORL_ERR_ARG, "net is NULL");
+    if (net->n_layers < 1 || net->n_layers > MORL_MAX_LAYERS)
+        return fail(MORL_ERR_ARG, "n_layers=%d outside [1,%d]", net->n_layers, MORL_MAX_LAYERS);
+    if (net->reward_dim < 1 || net->reward_dim > MORL_MAX_OBJ)
+        return fail(MORL_ERR_ARG, "reward_dim=%d outside [1,%d]", net->reward_dim, MORL_MAX_OBJ);
+    if (net->obs_dim < 1 || net->n_actions < 1) return fail(MORL_ERR_ARG, "obs_dim / n_actions must be >= 1");
+    if (net->dims[0] != net->obs_dim + net->reward_dim)
+        return fail(MORL_ERR_ARG, "dims[0]=%d != obs_dim+reward_dim=%d", net->dims[0], net->obs_dim + net->reward_dim);
+    if (net->dims[net->n_layers] != net->n_actions * net->reward_dim)
+        return fail(MORL_ERR_ARG, "dims[last]=%d != n_actions*reward_dim=%d", net->dims[net->n_layers],
+                    net->n_actions * net->reward_dim);
+    for (int l = 0; l <= net->n_layers; ++l)
+        if (net->dims[l] < 1) return fail(MORL_ERR_ARG, "dims[%d]=%d", l, net->dims[l]);
+    return MORL_OK;
+}
+
+extern "C" int morl_ctx_destroy(morl_ctx* c) {
+    if (!c) return MORL_OK;
+    float* fl[] = {c->x0n, c->x0m, c->ping, c->pong, c->qo, c->qt, c->qm, c->dq, c->slabs};
+    for (float* p : fl)
+        if (p) (void)hipFree(p);
+    for (int l = 0; l < MORL_MAX_LAYERS; ++l) {
+        if (c->h[l]) (void)hipFree(c->h[l]);
+        if (c->g[l] && c->g[l] != c->dq) (void)hipFree(c->g[l]);
+    }
+    if (c->sumsq_part) (void)hipFree(c->sumsq_part);
+    if (c->loss_part) (void)hipFree(c->loss_part);
+    delete c;
+    return MORL_OK;
+}
+
+static int dmalloc(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail(MORL_ERR_ALLOC, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return MORL_OK;
+}
+
+extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max_batch, int max_weights) {
+    if (!out) return fail(MORL_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int rc = validate_net(net);
+    if (rc) return rc;
+    if (max_batch < 1 || max_weights < 1) return fail(MORL_ERR_ARG, "max_batch / max_weights must be >= 1");
+    if ((int64_t)max_weights * net->n_actions * net->reward_dim > ENV_MAX_SLAB)
+        return fail(MORL_ERR_ARG, "W*A*R=%lld exceeds the LDS slab of the envelope kernel (%d floats)",
+                    (long long)max_weights * net->n_actions * net->reward_dim, ENV_MAX_SLAB);
+    if (max_weights * net->reward_dim > ENV_MAX_WR) return fail(MORL_ERR_ARG, "W*R exceeds %d", ENV_MAX_WR);
+    morl_ctx* c = new (std::nothrow) morl_ctx();
+    if (!c) return fail(MORL_ERR_ALLOC, "out of host memory");
+    c->net = *net;
+    c->L = net->n_layers;
+    c->P = morl_param_count(net);
+    int64_t off = 0;
+    c->max_h = 1;
+    c->dw_tiles = 0;
+    for (int l = 0; l < c->L; ++l) {
+        c->offW[l] = off;
+        off += (int64_t)net->dims[l + 1] * net->dims[l];
+        c->offB[l] = off;
+        off += net->dims[l + 1];
+        c->max_h = std::max(c->max_h, net->dims[l + 1]);
+        c->dw_tiles += ((net->dims[l + 1] + GEMM_BM - 1) / GEMM_BM) * ((net->dims[l] + GEMM_BN - 1) / GEMM_BN);
+    }
+    c->max_batch = max_batch;
+    c->max_weights = max_weights;
+    c->max_rows = (int64_t)max_batch * max_weights;
+    c->ld0 = round_up(net->dims[0], 4);
+    c->ldq = round_up(net->dims[c->L], 4);
+    c->max_splits = 64;
+    const size_t rows = (size_t)c->max_rows;
+#define ALLOC(field, count)                                                        \
+    do {                                                                           \
+        rc = dmalloc((void**)&c->field, (size_t)(count) * sizeof(*c->field));      \
+        if (rc) { morl_ctx_destroy(c); return rc; }                                \
+    } while (0)
+    ALLOC(x0n, rows * c->ld0);
+    ALLOC(x0m, rows * c->ld0);
+    ALLOC(ping, rows * c->max_h);
+    ALLOC(pong, rows * c->max_h);
+    ALLOC(qo, rows * net->dims[c->L]);
+    ALLOC(qt, rows * net->dims[c->L]);
+    ALLOC(qm, rows * c->ldq);
+    ALLOC(dq, rows * c->ldq);
+    for (int l = 1; l < c->L; ++l) ALLOC(h[l], rows * net->dims[l]);
+    for (int l = 0; l + 1 < c->L; ++l) ALLOC(g[l], rows * net->dims[l + 1]);
+    c->g[c->L - 1] = c->dq;
+    ALLOC(slabs, (size_t)c->max_splits * c->P);
+    ALLOC(sumsq_part, OPT_MAX_BLOCKS);
+    ALLOC(loss_part, (size_t)max_batch * 2);
+#undef ALLOC
+    *out = c;
+    return MORL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+static int vec_ok(const void* p, int ld) { return (((uintptr_t)p & 15u) == 0 && (ld & 3) == 0) ? 1 : 0; }
+
+static int stream_grid(long long n, int threads, int cap = 2048) {
+    long long b = (n + threads - 1) / threads;
+    return (int)std::max(1ll, std::min<long long>(b, cap));
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+static int launch_gemm(GemmProblem g, hipStream_t s, const char* name) {
+    g.tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
+    g.tiles_n = (g.N + GEMM_BN - 1) / GEMM_BN;
+    g.a_vec = vec_ok(g.A, g.lda);
+    g.b_vec = vec_ok(g.B, g.ldb);
+    if (g.k_per_split <= 0) g.k_per_split = round_up(g.K, GEMM_BK);
+    const int splits = (g.K + g.k_per_split - 1) / g.k_per_split;
+    hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, EPI>), dim3(g.tiles_m * g.tiles_n, splits), dim3(GEMM_THREADS), 0, s, g);
+    LAUNCH_CHECK(name);
+    return MORL_OK;
+}
+
+// Q-network forward over `rows` assembled input rows x0 [rows][ld0].
+// save = true keeps the post-ReLU activations in ctx->h[1..L-1] (training pass).
+static int net_forward(morl_ctx* c, const float* params, const float* x0, int rows, bool save, float* q_out,
+                       int ldq_out, hipStream_t s) {
+    const float* in = x0;
+    int ld_in = c->ld0;
+    for (int l = 0; l < c->L; ++l) {
+        const bool last = (l == c->L - 1);
+        GemmProblem g{};
+        g.A = in;
+        g.lda = ld_in;
+        g.B = params + c->offW[l];
+        g.ldb = c->net.dims[l];
+        g.bias = params + c->offB[l];
+        g.M = rows;
+        g.N = c->net.dims[l + 1];
+        g.K = c->net.dims[l];
+        float* outp;
+        if (last) { outp = q_out; g.ldc = ldq_out; }
+        else {
+            outp = save ? c->h[l + 1] : ((l & 1) ? c->pong : c->ping);
+            g.ldc = c->net.dims[l + 1];
+        }
+        g.C = outp;
+        int rc = last ? launch_gemm<true, true, EPI_BIAS>(g, s, "gemm_fwd_out")
+                      : launch_gemm<true, true, EPI_BIAS_RELU>(g, s, "gemm_fwd_hidden");
+        if (rc) return rc;
+        in = outp;
+        ld_in = g.ldc;
+    }
+    return MORL_OK;
+}
+
+static int build_input(const float* obs, const float* weights, float* x0, int B, int W, int D, int R, int ldx,
+                       int row_order, hipStream_t s) {
+    const long long total = (long long)B * W * ldx;
+    hipLaunchKernelGGL(build_input_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, s, obs, weights, x0, B, W, D, R,
+                       ldx, row_order);
+    LAUNCH_CHECK("build_input");
+    return MORL_OK;
+}
+
+static int check_bw(const morl_ctx* c, int B, int W) {
+    if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
+    if (B < 1 || W < 1) return fail(MORL_ERR_ARG, "B=%d W=%d must be >= 1", B, W);
+    if (B > c->max_batch || W > c->max_weights)
+        return fail(MORL_ERR_STATE, "B=%d W=%d exceed ctx capacity (%d, %d)", B, W, c->max_batch, c->max_weights);
+    return MORL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// public entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int morl_gather_batch(const float* records, int record_floats, int64_t capacity, const int64_t* idx, int B,
+                                 int D, int R, float* obs, float* next_obs, float* rewards, float* dones,
+                                 int32_t* actions, void* stream) {
+    if (!records || !idx || !obs || !next_obs || !rewards || !dones || !actions) return fail(MORL_ERR_ARG, "NULL array");
+    if (B < 1 || D < 1 || R < 1 || capacity < 1) return fail(MORL_ERR_ARG, "bad sizes B=%d D=%d R=%d", B, D, R);
+    if (record_floats != 2 * D + R + 2)
+        return fail(MORL_ERR_ARG, "record_floats=%d != 2*D+R+2=%d", record_floats, 2 * D + R + 2);
+    const int blocks = std::min(1024, (B + 3) / 4);
+    hipLaunchKernelGGL(gather_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, records, record_floats,
+                       (long long)capacity, idx, B, D, R, obs, next_obs, rewards, dones, actions);
+    LAUNCH_CHECK("gather_batch");
+    return MORL_OK;
+}
+
+extern "C" int morl_qnet_forward(morl_ctx* c, const float* params, const float* obs, const float* weights, int B, int W,
+                                 int row_order, float* q_out, void* stream) {
+    int rc = check_bw(c, B, W);
+    if (rc) return rc;
+    if (!params || !obs || !weights || !q_out) return fail(MORL_ERR_ARG, "NULL array");
+    if (row_order != 0 && row_order != 1) return fail(MORL_ERR_ARG, "row_order must be 0 or 1");
+    hipStream_t s = (hipStream_t)stream;
+    rc = build_input(obs, weights, c->x0n, B, W, c->net.obs_dim, c->net.reward_dim, c->ld0, row_order, s);
+    if (rc) return rc;
+    return net_forward(c, params, c->x0n, B * W, false, q_out, c->net.dims[c->L], s);
+}
+
+extern "C" int morl_envelope_reduce(const float* qo, const float* qt, const float* weights, int B, int W, int A, int R,
+                                    int diag_only, float* target, int32_t* pref, int32_t* ac, void* stream) {
+    if (!qo || !qt || !weights || !target) return fail(MORL_ERR_ARG, "NULL array");
+    if (B < 1 || W < 1 || A < 1 || R < 1 || R > MORL_MAX_OBJ) return fail(MORL_ERR_ARG, "bad sizes");
+    if ((long long)W * A * R > ENV_MAX_SLAB || W * R > ENV_MAX_WR)
+        return fail(MORL_ERR_ARG, "W*A*R=%lld exceeds the LDS slab (%d floats)", (long long)W * A * R, ENV_MAX_SLAB);
+    EnvelopeTdArgs p{};
+    p.qo = qo; p.qt = qt; p.weights = weights;
+    p.target = target; p.pref = pref; p.ac = ac;
+    p.B = B; p.W = W; p.A = A; p.R = R; p.diag_only = diag_only;
+    hipLaunchKernelGGL(envelope_td_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
+    LAUNCH_CHECK("envelope_td(reduce)");
+    return MORL_OK;
+}
+
+extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const float* params_target, float* grads,
+                                    float* exp_avg, float* exp_avg_sq, const float* obs, const float* next_obs,
+                                    const int32_t* actions, const float* rewards, const float* dones,
+                                    const float* weights, int B, int W, const morl_update_cfg* cfg,
+                                    const morl_update_out* out, void* stream) {
+    int rc = check_bw(c, B, W);
+    if (rc) return rc;
+    if (!params_online || !params_target || !grads || !obs || !next_obs || !actions || !rewards || !dones || !weights ||
+        !cfg)
+        return fail(MORL_ERR_ARG, "NULL array");
+    if (cfg->apply_step && (!exp_avg || !exp_avg_sq)) return fail(MORL_ERR_ARG, "Adam state is NULL");
+    if (cfg->apply_step && cfg->adam_step < 1) return fail(MORL_ERR_ARG, "adam_step must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    const morl_net_desc& n = c->net;
+    const int D = n.obs_dim, R = n.reward_dim, A = n.n_actions, L = c->L;
+    const int rows = B * W, AR = A * R;
+    static const morl_update_out no_out = {};
+    if (!out) out = &no_out;
+
+    // 1. inputs of the three passes (the W-tiled batch of envelope.py:284-291 is never materialised wider than this)
+    if ((rc = build_input(next_obs, weights, c->x0n, B, W, D, R, c->ld0, 0, s))) return rc;
+    if ((rc = build_input(obs, weights, c->x0m, B, W, D, R, c->ld0, 1, s))) return rc;
+    // 2. no-grad next-state slabs Qo, Qt [B][W][A][R] (B*W distinct rows instead of the reference's W^2*B)
+    if ((rc = net_forward(c, params_online, c->x0n, rows, false, c->qo, AR, s))) return rc;
+    if ((rc = net_forward(c, params_target, c->x0n, rows, false, c->qt, AR, s))) return rc;
+    // 3. training forward, activations saved
+    if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
+    // 4. envelope arg-max + TD target + dLoss/dQ
+    {
+        EnvelopeTdArgs p{};
+        p.qo = c->qo; p.qt = c->qt; p.weights = weights; p.q_main = c->qm;
+        p.actions = actions; p.rewards = rewards; p.dones = dones;
+        p.target = out->target; p.pref = out->pref; p.ac = out->ac;
+        p.dq = c->dq; p.loss_part = c->loss_part; p.priority = out->priority;
+        p.B = B; p.W = W; p.A = A; p.R = R; p.ldq = c->ldq;
+        p.diag_only = cfg->envelope ? 0 : 1;
+        p.gamma = cfg->gamma;
+        const float lam = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
+        p.c_mse = (float)((1.0 - (double)lam) * 2.0 / ((double)rows * R));
+        p.c_aux = (float)((double)lam * 2.0 / (double)rows);
+        hipLaunchKernelGGL(envelope_td_kernel, dim3(B), dim3(256), 0, s, p);
+        LAUNCH_CHECK("envelope_td");
+    }
+    // 5. backward through the hidden layers: g[l-1] = (g[l] @ W_l) * (h[l] > 0)
+    for (int l = L - 1; l >= 1; --l) {
+        GemmProblem g{};
+        g.A = c->g[l];
+        g.lda = (l == L - 1) ? c->ldq : n.dims[l + 1];
+        g.B = params_online + c->offW[l];
+        g.ldb = n.dims[l];
+        g.C = c->g[l - 1];
+        g.ldc = n.dims[l];
+        g.mask = c->h[l];
+        g.ldmask = n.dims[l];
+        g.M = rows; g.N = n.dims[l]; g.K = n.dims[l + 1];
+        if ((rc = launch_gemm<true, false, EPI_RELU_MASK>(g, s, "gemm_dx"))) return rc;
+    }
+    // 6. all dW / db in one grouped split-K launch
+    int splits = std::max(1, std::min(c->max_splits, (256 + c->dw_tiles - 1) / c->dw_tiles));
+    int kps = round_up((rows + splits - 1) / splits, GEMM_BK);
+    splits = (rows + kps - 1) / kps;
+    {
+        GemmGroup grp{};
+        grp.n = L;
+        int t = 0;
+        for (int l = 0; l < L; ++l) {
+            GemmProblem& g = grp.p[l];
+            g.A = c->g[l];
+            g.lda = (l == L - 1) ? c->ldq : n.dims[l + 1];
+            g.B = (l == 0) ? c->x0m : c->h[l];
+            g.ldb = (l == 0) ? c->ld0 : n.dims[l];
+            g.C = c->slabs + c->offW[l];
+            g.ldc = n.dims[l];
+            g.colsum = c->slabs + c->offB[l];
+            g.M = n.dims[l + 1]; g.N = n.dims[l]; g.K = rows;
+            g.k_per_split = kps;
+            g.c_split_stride = c->P;
+            g.colsum_stride = c->P;
+            g.tiles_m = (g.M + GEMM_BM - 1) / GEMM_BM;
+            g.tiles_n = (g.N + GEMM_BN - 1) / GEMM_BN;
+            g.a_vec = vec_ok(g.A, g.lda);
+            g.b_vec = vec_ok(g.B, g.ldb);
+            grp.tile_start[l] = t;
+            t += g.tiles_m * g.tiles_n;
+        }
+        grp.tile_start[L] = t;
+        hipLaunchKernelGGL(gemm_grouped_tn_kernel, dim3(t, splits), dim3(GEMM_THREADS), 0, s, grp);
+        LAUNCH_CHECK("gemm_grouped_dw");
+    }
+    // 7. reduce the split-K slabs into the caller's grad buffer (+ norm partials, loss)
+    const int nblk = std::min(OPT_MAX_BLOCKS, stream_grid(c->P, OPT_THREADS));
+    {
+        const float lam = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
+        hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)c->slabs, splits,
+                           (long long)c->P, grads, (long long)c->P, c->sumsq_part, (const double*)c->loss_part, B,
+                           1.0 / ((double)rows * R), 1.0 / (double)rows, lam, out->loss);
+        LAUNCH_CHECK("grad_reduce");
+    }
+    // 8. clip + Adam
+    {
+        const double b1 = cfg->beta1, b2 = cfg->beta2;
+        const int t = std::max(1, cfg->adam_step);
+        const double bc1 = 1.0 - std::pow(b1, (double)t);
+        const double bc2 = 1.0 - std::pow(b2, (double)t);
+        const double step_size = (double)cfg->lr / bc1;
+        const double bc2_sqrt = std::sqrt(bc2);
+        hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, params_online, grads, exp_avg,
+                           exp_avg_sq, (long long)c->P, (const double*)c->sumsq_part, nblk, cfg->max_grad_norm,
+                           (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(-step_size), (float)bc2_sqrt,
+                           (float)cfg->eps, cfg->apply_step, out->grad_norm);
+        LAUNCH_CHECK("clip_adam");
+    }
+    // optional debug / parity outputs
+    if (out->q_online_next) HIP_TRY(hipMemcpyAsync(out->q_online_next, c->qo, (size_t)rows * AR * 4, hipMemcpyDeviceToDevice, s));
+    if (out->q_target_next) HIP_TRY(hipMemcpyAsync(out->q_target_next, c->qt, (size_t)rows * AR * 4, hipMemcpyDeviceToDevice, s));
+    if (out->q_values) {
+        hipLaunchKernelGGL(copy_rows_kernel, dim3(stream_grid((long long)rows * AR, 256)), dim3(256), 0, s,
+                           (const float*)c->qm, c->ldq, out->q_values, AR, (long long)rows, AR);
+        LAUNCH_CHECK("copy_rows");
+    }
+    return MORL_OK;
+}
+
+extern "C" int morl_polyak(const float* src, float* dst, float tau, int64_t n, void* stream) {
+    if (!src || !dst) return fail(MORL_ERR_ARG, "NULL array");
+    if (n < 0) return fail(MORL_ERR_ARG, "n < 0");
+    if (n == 0) return MORL_OK;
+    hipLaunchKernelGGL(polyak_kernel, dim3(stream_grid(n, OPT_THREADS)), dim3(OPT_THREADS), 0, (hipStream_t)stream, src,
+                       dst, (long long)n, tau, (float)(1.0 - (double)tau));
+    LAUNCH_CHECK("polyak");
+    return MORL_OK;
+}
+
+extern "C" int morl_pareto_mask(const double* points, int N, int R, int remove_duplicates, uint8_t* mask_out,
+                                void* stream) {
+    if (N == 0) return MORL_OK;
+    if (!points || !mask_out) return fail(MORL_ERR_ARG, "NULL array");
+    if (N < 0 || R < 1 || R > MORL_MAX_OBJ) return fail(MORL_ERR_ARG, "bad sizes N=%d R=%d (R <= %d)", N, R, MORL_MAX_OBJ);
+    hipLaunchKernelGGL(pareto_mask_kernel, dim3((N + PARETO_THREADS - 1) / PARETO_THREADS), dim3(PARETO_THREADS), 0,
+                       (hipStream_t)stream, points, N, R, remove_duplicates, mask_out);
+    LAUNCH_CHECK("pareto_mask");
+    return MORL_OK;
+}
+
+extern "C" int morl_sumtree_sample(const double* tree, int n_levels, const double* u01, int B, int64_t* idx,
+                                   void* stream) {
+    if (!tree || !u01 || !idx) return fail(MORL_ERR_ARG, "NULL array");
+    if (n_levels < 1 || n_levels > 40 || B < 1) return fail(MORL_ERR_ARG, "bad sizes");
+    hipLaunchKernelGGL(sumtree_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, tree, n_levels,
+                       u01, B, idx);
+    LAUNCH_CHECK("sumtree_sample");
+    return MORL_OK;
+}
+
+extern "C" int morl_sumtree_set(double* tree, int n_levels, const int64_t* ptr, const double* value, int n,
+                                double* running_max, void* stream) {
+    if (!tree || !ptr || !running_max) return fail(MORL_ERR_ARG, "NULL array");
+    if (n_levels < 1 || n_levels > 40 || n < 0) return fail(MORL_ERR_ARG, "bad sizes");
+    if (n == 0) return MORL_OK;
+    hipLaunchKernelGGL(sumtree_set_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tree, n_levels, ptr, value, n,
+                       (const double*)running_max);
+    LAUNCH_CHECK("sumtree_set");
+    return MORL_OK;
+}
+
+extern "C" int morl_sumtree_update(double* tree, int n_levels, const int64_t* idx, const float* raw, int B,
+                                   double alpha, double* running_max, double* pr_out, void* stream) {
+    if (!tree || !idx || !raw || !running_max) return fail(MORL_ERR_ARG, "NULL array");
+    if (n_levels < 1 || n_levels > 40) return fail(MORL_ERR_ARG, "bad n_levels");
+    if (B < 1 || B > ST_MAX_B) return fail(MORL_ERR_ARG, "B=%d outside [1,%d]", B, ST_MAX_B);
+    hipLaunchKernelGGL(sumtree_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tree, n_levels, idx, raw, B,
+                       (float)alpha, running_max, pr_out);
+    LAUNCH_CHECK("sumtree_update");
+    return MORL_OK;
+}

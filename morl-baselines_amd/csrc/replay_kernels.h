@@ -1,0 +1,180 @@
+// Device-resident replay storage: batch gather and the prioritized-replay sum tree.
+#pragma once
+#include "morl_device.h"
+
+namespace morl {
+
+// ----------------------------------------------------------------------------------------------
+// Batch gather (ReplayBuffer.sample's five fancy-index gathers, common/buffer.py:82-91).
+// Device storage is one AoS record per transition:  obs[D] | next_obs[D] | reward[R] | done | action
+// (all fp32; record_floats = 2D+R+2) so that add() is ONE contiguous H2D copy and a sampled transition
+// is ONE contiguous read.  One wave per sampled transition, lanes stride the record (coalesced 4-B
+// loads; 272 B per record at D=32, R=3).  HBM-bound: B * record_floats * 4 bytes in, the same out.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_batch_kernel(const float* __restrict__ records, int record_floats,
+                                                           long long capacity, const int64_t* __restrict__ idx, int B,
+                                                           int D, int R, float* __restrict__ obs,
+                                                           float* __restrict__ next_obs, float* __restrict__ rewards,
+                                                           float* __restrict__ dones, int32_t* __restrict__ actions) {
+    const int waves_per_block = (int)blockDim.x / kWave;
+    const int lane = lane_id();
+    for (int b = (int)blockIdx.x * waves_per_block + wave_id(); b < B; b += (int)gridDim.x * waves_per_block) {
+        long long t = idx[b];
+        if (t < 0) t = 0;
+        if (t >= capacity) t = capacity - 1;
+        const float* rec = records + (size_t)t * record_floats;
+        for (int e = lane; e < record_floats; e += kWave) {
+            const float v = rec[e];
+            if (e < D) obs[(size_t)b * D + e] = v;
+            else if (e < 2 * D) next_obs[(size_t)b * D + (e - D)] = v;
+            else if (e < 2 * D + R) rewards[(size_t)b * R + (e - 2 * D)] = v;
+            else if (e == 2 * D + R) dones[b] = v;
+            else actions[b] = (int32_t)v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Sum tree (common/prioritized_buffer.py:12-82), float64 levels concatenated root first: level l has
+// 2^l nodes at offset 2^l - 1.  All arithmetic is IEEE float64 in the reference's order, so indices and
+// node values are bit-exact.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long level_off(int l) { return (1ll << l) - 1; }
+
+// SumTree.sample (:30-54): query = 0 + (root - 0) * u ; per level: go right iff query > left_sum.
+__global__ __launch_bounds__(256) void sumtree_sample_kernel(const double* __restrict__ tree, int n_levels,
+                                                             const double* __restrict__ u01, int B,
+                                                             int64_t* __restrict__ idx) {
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k >= B) return;
+    double q = __dadd_rn(0.0, __dmul_rn(__dsub_rn(tree[0], 0.0), u01[k]));
+    long long node = 0;
+    for (int l = 1; l < n_levels; ++l) {
+        node *= 2;
+        const double left = tree[level_off(l) + node];
+        const bool gt = q > left;
+        node += gt ? 1 : 0;
+        q = __dsub_rn(q, __dmul_rn(left, gt ? 1.0 : 0.0));
+    }
+    idx[k] = node;
+}
+
+// Sequential SumTree.set (:56-67) for the transitions appended since the last sample.  value < 0 means
+// "the running max priority" (PrioritizedReplayBuffer.add uses self.min_priority, :143).
+// One wave; lane l owns level (n_levels-1-l): the n sets are applied in order, each lane adding the same
+// diff to its level's ancestor -- exactly np.add.at(nodes, node_index, diff) per level.
+__global__ __launch_bounds__(64) void sumtree_set_kernel(double* __restrict__ tree, int n_levels,
+                                                         const int64_t* __restrict__ ptr,
+                                                         const double* __restrict__ value, int n,
+                                                         const double* __restrict__ running_max) {
+    const int lane = lane_id();
+    const int leaf_level = n_levels - 1;
+    for (int k = 0; k < n; ++k) {
+        const long long leaf = ptr[k];
+        const double newp = (value == nullptr || value[k] < 0.0) ? *running_max : value[k];
+        const double diff = __dsub_rn(newp, tree[level_off(leaf_level) + leaf]);
+        // all lanes read the leaf before any lane writes it
+        const double d = __shfl(diff, 0);
+        if (lane < n_levels) {
+            const int l = leaf_level - lane;
+            const long long node = leaf >> lane;
+            tree[level_off(l) + node] = __dadd_rn(tree[level_off(l) + node], d);
+        }
+    }
+}
+
+// PrioritizedReplayBuffer.update_priorities (:187-195) + SumTree.batch_set (:69-82), one workgroup.
+//   pr[k]  = powf(raw[k] + (float)running_max, alpha)     (envelope.py:333, numpy float32 arithmetic)
+//   running_max = max(running_max, max_k pr[k])
+//   unique indices ascending, first occurrence's priority; diff = pr - leaf; per level add diffs of the
+//   children in ascending index order (np.add.at order) -> bit-exact float64 tree.
+constexpr int ST_MAX_B = 1024;
+__global__ __launch_bounds__(256) void sumtree_update_kernel(double* __restrict__ tree, int n_levels,
+                                                             const int64_t* __restrict__ idx,
+                                                             const float* __restrict__ raw, int B, float alpha,
+                                                             double* __restrict__ running_max,
+                                                             double* __restrict__ pr_out) {
+    __shared__ long long s_key[ST_MAX_B];   // (index << 11) | position  -> sort gives ascending index, first position first
+    __shared__ double s_diff[ST_MAX_B];
+    __shared__ long long s_node[ST_MAX_B];
+    __shared__ float s_pr[ST_MAX_B];
+    __shared__ float s_max[4];
+    const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+    const float rmax = (float)(*running_max);
+    float lmax = -INFINITY;
+    int npad = 1;
+    while (npad < B) npad <<= 1;
+    for (int k = tid; k < npad; k += nt) {
+        if (k < B) {
+            const float p = powf(__fadd_rn(raw[k], rmax), alpha);
+            s_pr[k] = p;
+            if (pr_out) pr_out[k] = (double)p;
+            lmax = fmaxf(lmax, p);
+            s_key[k] = (idx[k] << 11) | (long long)k;
+        } else {
+            s_key[k] = 0x7fffffffffffffffll;
+        }
+    }
+    lmax = wave_max(lmax);
+    if (lane_id() == 0) s_max[wave_id()] = lmax;
+    __syncthreads();
+    if (tid == 0) {
+        const float m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        // python max(self.min_priority, priorities.max()): keeps the old value unless the new one is larger
+        if ((double)m > *running_max) *running_max = (double)m;
+    }
+    // bitonic sort of the keys (ascending)
+    for (int size = 2; size <= npad; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int k = tid; k < npad; k += nt) {
+                const int partner = k ^ stride;
+                if (partner > k) {
+                    const bool up = ((k & size) == 0);
+                    const long long a = s_key[k], c = s_key[partner];
+                    if ((a > c) == up) { s_key[k] = c; s_key[partner] = a; }
+                }
+            }
+        }
+    __syncthreads();
+    // unique (first occurrence), leaf diffs
+    const int leaf_level = n_levels - 1;
+    for (int k = tid; k < npad; k += nt) {
+        long long node = -1;
+        double diff = 0.0;
+        if (k < B) {
+            const long long id = s_key[k] >> 11;
+            const bool first = (k == 0) || ((s_key[k - 1] >> 11) != id);
+            if (first) {
+                node = id;
+                diff = __dsub_rn((double)s_pr[(int)(s_key[k] & 2047)], tree[level_off(leaf_level) + id]);
+            }
+        }
+        s_node[k] = node;
+        s_diff[k] = diff;
+    }
+    __syncthreads();
+    // per level: the head of each run of equal ancestors adds that run's diffs in order
+    for (int up = 0; up < n_levels; ++up) {
+        const int l = leaf_level - up;
+        for (int k = tid; k < B; k += nt) {
+            if (s_node[k] < 0) continue;
+            const long long anc = s_node[k] >> up;
+            // previous valid entry
+            int j = k - 1;
+            while (j >= 0 && s_node[j] < 0) --j;
+            const bool head = (j < 0) || ((s_node[j] >> up) != anc);
+            if (!head) continue;
+            double acc = tree[level_off(l) + anc];
+            for (int e = k; e < B; ++e) {
+                if (s_node[e] < 0) continue;
+                if ((s_node[e] >> up) != anc) break;
+                acc = __dadd_rn(acc, s_diff[e]);
+            }
+            tree[level_off(l) + anc] = acc;
+        }
+        // levels are disjoint memory; no barrier needed between them
+    }
+}
+
+}  // namespace morl

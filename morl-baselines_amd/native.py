@@ -1,0 +1,153 @@
+"""ctypes binding of libmorl_hip.so (the C ABI declared in include/morl_hip.h).
+
+The product path has NO fallback: if the gfx950 library is missing or fails to load, ``load_library()``
+raises.  Tensors cross the boundary as raw device pointers (``tensor.data_ptr()``) plus explicit sizes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch as th
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
+
+MORL_MAX_LAYERS = 8
+MORL_MAX_OBJ = 8
+ABI_VERSION = 1
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("dims", C.c_int32 * (MORL_MAX_LAYERS + 1)), ("obs_dim", C.c_int32),
+                ("reward_dim", C.c_int32), ("n_actions", C.c_int32)]
+
+
+class UpdateCfg(C.Structure):
+    _fields_ = [("gamma", C.c_float), ("homotopy_lambda", C.c_float), ("max_grad_norm", C.c_float),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("adam_step", C.c_int32), ("envelope", C.c_int32), ("apply_step", C.c_int32)]
+
+
+class UpdateOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("loss", "grad_norm", "priority", "target", "pref", "ac", "q_online_next",
+                                          "q_target_next", "q_values")]
+
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "morl_last_error": (C.c_char_p, []),
+    "morl_abi_version": (C.c_int, []),
+    "morl_is_device_build": (C.c_int, []),
+    "morl_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(NetDesc), C.c_int, C.c_int]),
+    "morl_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "morl_param_count": (C.c_int64, [C.POINTER(NetDesc)]),
+    "morl_gather_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int] +
+                          [C.c_void_p] * 5 + [C.c_void_p]),
+    "morl_qnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p]),
+    "morl_envelope_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "morl_envelope_update": (C.c_int, [C.c_void_p] * 12 + [C.c_int, C.c_int, C.POINTER(UpdateCfg),
+                                                           C.POINTER(UpdateOut), C.c_void_p]),
+    "morl_polyak": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
+    "morl_pareto_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "morl_sumtree_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "morl_sumtree_set": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "morl_sumtree_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def _ptr(t: Optional[th.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: th.Tensor, dtype, name: str) -> th.Tensor:
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+class NativeLib:
+    """One loaded instance of the C ABI."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: build it with `python morl-baselines_amd/build.py` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        self.path = path
+        self.lib = C.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(self.lib, name)  # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if self.lib.morl_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{path}: ABI version {self.lib.morl_abi_version()} != {ABI_VERSION}")
+        self.is_device_build = bool(self.lib.morl_is_device_build())
+
+    # -- helpers --------------------------------------------------------------------------------
+    def check(self, rc: int) -> None:
+        if rc != 0:
+            raise RuntimeError(f"libmorl_hip error {rc}: {self.lib.morl_last_error().decode()}")
+
+    def check_device(self, *tensors: Optional[th.Tensor]) -> None:
+        """A gfx950 build only accepts device memory; the emulated test build only host memory."""
+        for t in tensors:
+            if t is None:
+                continue
+            if self.is_device_build and t.device.type != "cuda":
+                raise RuntimeError("libmorl_hip (gfx950 build) was handed a CPU tensor; no CPU fallback exists")
+            if not self.is_device_build and t.device.type != "cpu":
+                raise RuntimeError("emulated test build was handed a device tensor")
+
+    @staticmethod
+    def stream_of(t: th.Tensor) -> int:
+        if t.device.type == "cuda":
+            return th.cuda.current_stream(t.device).cuda_stream
+        return 0
+
+    # -- thin wrappers (argument order == header) -----------------------------------------------------
+    def ctx_create(self, desc: NetDesc, max_batch: int, max_weights: int) -> int:
+        h = C.c_void_p()
+        self.check(self.lib.morl_ctx_create(C.byref(h), C.byref(desc), max_batch, max_weights))
+        return h.value
+
+    def ctx_destroy(self, h: int) -> None:
+        if h:
+            self.lib.morl_ctx_destroy(h)
+
+    def param_count(self, desc: NetDesc) -> int:
+        return int(self.lib.morl_param_count(C.byref(desc)))
+
+
+def make_net_desc(obs_dim: int, reward_dim: int, n_actions: int, net_arch: Sequence[int]) -> NetDesc:
+    dims = [obs_dim + reward_dim] + [int(h) for h in net_arch] + [n_actions * reward_dim]
+    if len(dims) - 1 > MORL_MAX_LAYERS:
+        raise ValueError(f"at most {MORL_MAX_LAYERS} linear layers are supported, got {len(dims) - 1}")
+    if reward_dim > MORL_MAX_OBJ:
+        raise ValueError(f"reward_dim <= {MORL_MAX_OBJ} supported")
+    d = NetDesc()
+    d.n_layers = len(dims) - 1
+    for i, v in enumerate(dims):
+        d.dims[i] = v
+    d.obs_dim, d.reward_dim, d.n_actions = obs_dim, reward_dim, n_actions
+    return d
+
+
+_default: Optional[NativeLib] = None
+
+
+def load_library(path: Optional[str] = None) -> NativeLib:
+    """Load (once) the gfx950 library.  Raises if it is absent -- there is deliberately no fallback."""
+    global _default
+    if path is not None:
+        return NativeLib(path)
+    if _default is None:
+        _default = NativeLib(os.environ.get("MORL_HIP_LIB", DEFAULT_LIB))
+    return _default

@@ -1,0 +1,181 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/morl_hip.h).
+
+Every function takes torch tensors that live in device memory, passes raw pointers + sizes through
+ctypes and enqueues work on the current torch stream; nothing here computes on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import torch as th
+
+from .native import NativeLib, NetDesc, UpdateCfg, UpdateOut, _chk, _ptr, load_library, make_net_desc
+
+
+class QNetContext:
+    """Owns a ``morl_ctx`` (scratch workspace for a Q-network of fixed architecture)."""
+
+    def __init__(self, obs_dim: int, reward_dim: int, n_actions: int, net_arch: Sequence[int], max_batch: int,
+                 max_weights: int, lib: Optional[NativeLib] = None):
+        self.lib = lib or load_library()
+        self.desc: NetDesc = make_net_desc(obs_dim, reward_dim, n_actions, net_arch)
+        self.obs_dim, self.reward_dim, self.n_actions = obs_dim, reward_dim, n_actions
+        self.net_arch = list(net_arch)
+        self.max_batch, self.max_weights = int(max_batch), int(max_weights)
+        self.n_params = self.lib.param_count(self.desc)
+        self.handle = self.lib.ctx_create(self.desc, self.max_batch, self.max_weights)
+
+    def layer_slices(self):
+        """[(w_offset, (out, in), b_offset, out)] of the flat parameter layout."""
+        out, off = [], 0
+        d = list(self.desc.dims)[: self.desc.n_layers + 1]
+        for l in range(self.desc.n_layers):
+            o, i = d[l + 1], d[l]
+            out.append((off, (o, i), off + o * i, o))
+            off += o * i + o
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gather_batch(lib: NativeLib, records: th.Tensor, idx: th.Tensor, D: int, R: int):
+    """ReplayBuffer.sample gather (common/buffer.py:82-91) from the device record store."""
+    _chk(records, th.float32, "records")
+    _chk(idx, th.int64, "idx")
+    lib.check_device(records, idx)
+    B = idx.numel()
+    dev = records.device
+    obs = th.empty((B, D), dtype=th.float32, device=dev)
+    nobs = th.empty((B, D), dtype=th.float32, device=dev)
+    rew = th.empty((B, R), dtype=th.float32, device=dev)
+    done = th.empty((B, 1), dtype=th.float32, device=dev)
+    act = th.empty((B,), dtype=th.int32, device=dev)
+    lib.check(lib.lib.morl_gather_batch(_ptr(records), records.shape[1], records.shape[0], _ptr(idx), B, D, R,
+                                        _ptr(obs), _ptr(nobs), _ptr(rew), _ptr(done), _ptr(act),
+                                        lib.stream_of(records)))
+    return obs, act, rew, nobs, done
+
+
+def qnet_forward(ctx: QNetContext, params: th.Tensor, obs: th.Tensor, weights: th.Tensor, row_order: int = 0):
+    """Q(obs_b, w_k) for all pairs -> (B*W, A, R); row = b*W+k (row_order 0) or k*B+b (row_order 1)."""
+    lib = ctx.lib
+    _chk(params, th.float32, "params"); _chk(obs, th.float32, "obs"); _chk(weights, th.float32, "weights")
+    lib.check_device(params, obs, weights)
+    B, W = obs.shape[0], weights.shape[0]
+    q = th.empty((B * W, ctx.n_actions, ctx.reward_dim), dtype=th.float32, device=obs.device)
+    lib.check(lib.lib.morl_qnet_forward(ctx.handle, _ptr(params), _ptr(obs), _ptr(weights), B, W, row_order, _ptr(q),
+                                        lib.stream_of(obs)))
+    return q
+
+
+def envelope_reduce(lib: NativeLib, qo: th.Tensor, qt: th.Tensor, weights: th.Tensor, diag_only: bool = False):
+    """envelope.py:422-439 on de-duplicated slabs qo/qt (B, W, A, R) -> target (W*B, R), pref, ac (W*B,)."""
+    _chk(qo, th.float32, "qo"); _chk(qt, th.float32, "qt"); _chk(weights, th.float32, "weights")
+    lib.check_device(qo, qt, weights)
+    B, W, A, R = qo.shape
+    dev = qo.device
+    target = th.empty((W * B, R), dtype=th.float32, device=dev)
+    pref = th.empty((W * B,), dtype=th.int32, device=dev)
+    ac = th.empty((W * B,), dtype=th.int32, device=dev)
+    lib.check(lib.lib.morl_envelope_reduce(_ptr(qo), _ptr(qt), _ptr(weights), B, W, A, R, int(diag_only), _ptr(target),
+                                           _ptr(pref), _ptr(ac), lib.stream_of(qo)))
+    return target, pref, ac
+
+
+def envelope_update(ctx: QNetContext, params_online: th.Tensor, params_target: th.Tensor, grads: th.Tensor,
+                    exp_avg: Optional[th.Tensor], exp_avg_sq: Optional[th.Tensor], obs: th.Tensor,
+                    next_obs: th.Tensor, actions: th.Tensor, rewards: th.Tensor, dones: th.Tensor,
+                    weights: th.Tensor, *, gamma: float, lr: float, adam_step: int, max_grad_norm: Optional[float],
+                    homotopy_lambda: float = 0.0, envelope: bool = True, beta1: float = 0.9, beta2: float = 0.999,
+                    eps: float = 1e-8, apply_step: bool = True, outputs: Optional[Dict[str, th.Tensor]] = None,
+                    debug: bool = False) -> Dict[str, th.Tensor]:
+    """One Envelope gradient step (envelope.py:269-334) entirely on the device."""
+    lib = ctx.lib
+    for t, dt, n in ((params_online, th.float32, "params_online"), (params_target, th.float32, "params_target"),
+                     (grads, th.float32, "grads"), (obs, th.float32, "obs"), (next_obs, th.float32, "next_obs"),
+                     (actions, th.int32, "actions"), (rewards, th.float32, "rewards"), (dones, th.float32, "dones"),
+                     (weights, th.float32, "weights")):
+        _chk(t, dt, n)
+    lib.check_device(params_online, params_target, grads, exp_avg, exp_avg_sq, obs, next_obs, actions, rewards, dones,
+                     weights)
+    B, W = obs.shape[0], weights.shape[0]
+    A, R = ctx.n_actions, ctx.reward_dim
+    dev = obs.device
+    res = outputs if outputs is not None else {}
+    if "loss" not in res:
+        res["loss"] = th.empty((), dtype=th.float32, device=dev)
+        res["grad_norm"] = th.empty((), dtype=th.float32, device=dev)
+        res["priority"] = th.empty((B,), dtype=th.float32, device=dev)
+    if debug:
+        res["target"] = th.empty((W * B, R), dtype=th.float32, device=dev)
+        res["pref"] = th.empty((W * B,), dtype=th.int32, device=dev)
+        res["ac"] = th.empty((W * B,), dtype=th.int32, device=dev)
+        res["q_online_next"] = th.empty((B, W, A, R), dtype=th.float32, device=dev)
+        res["q_target_next"] = th.empty((B, W, A, R), dtype=th.float32, device=dev)
+        res["q_values"] = th.empty((W * B, A, R), dtype=th.float32, device=dev)
+    cfg = UpdateCfg(gamma=gamma, homotopy_lambda=homotopy_lambda,
+                    max_grad_norm=-1.0 if max_grad_norm is None else float(max_grad_norm), lr=lr, beta1=beta1,
+                    beta2=beta2, eps=eps, adam_step=int(adam_step), envelope=int(bool(envelope)),
+                    apply_step=int(bool(apply_step)))
+    out = UpdateOut(**{k: _ptr(res.get(k)) for k, _ in UpdateOut._fields_})
+    lib.check(lib.lib.morl_envelope_update(
+        ctx.handle, _ptr(params_online), _ptr(params_target), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(obs),
+        _ptr(next_obs), _ptr(actions), _ptr(rewards), _ptr(dones), _ptr(weights), B, W, C.byref(cfg), C.byref(out),
+        lib.stream_of(obs)))
+    return res
+
+
+def polyak(lib: NativeLib, src: th.Tensor, dst: th.Tensor, tau: float) -> None:
+    """polyak_update (common/networks.py:120-139) on flat parameter buffers."""
+    _chk(src, th.float32, "src"); _chk(dst, th.float32, "dst")
+    lib.check_device(src, dst)
+    if src.numel() != dst.numel():
+        raise ValueError("polyak: size mismatch")
+    lib.check(lib.lib.morl_polyak(_ptr(src), _ptr(dst), float(tau), src.numel(), lib.stream_of(src)))
+
+
+def pareto_mask(lib: NativeLib, points: th.Tensor, remove_duplicates: bool = True) -> th.Tensor:
+    """get_non_pareto_dominated_inds (common/pareto.py:34-57): points (N, R) float64 -> uint8 mask (N,)."""
+    _chk(points, th.float64, "points")
+    lib.check_device(points)
+    N, R = points.shape
+    mask = th.empty((N,), dtype=th.uint8, device=points.device)
+    lib.check(lib.lib.morl_pareto_mask(_ptr(points), N, R, int(remove_duplicates), _ptr(mask), lib.stream_of(points)))
+    return mask
+
+
+def sumtree_sample(lib: NativeLib, tree: th.Tensor, n_levels: int, u01: th.Tensor) -> th.Tensor:
+    _chk(tree, th.float64, "tree"); _chk(u01, th.float64, "u01")
+    lib.check_device(tree, u01)
+    idx = th.empty((u01.numel(),), dtype=th.int64, device=tree.device)
+    lib.check(lib.lib.morl_sumtree_sample(_ptr(tree), n_levels, _ptr(u01), u01.numel(), _ptr(idx), lib.stream_of(tree)))
+    return idx
+
+
+def sumtree_set(lib: NativeLib, tree: th.Tensor, n_levels: int, ptr: th.Tensor, value: Optional[th.Tensor],
+                running_max: th.Tensor) -> None:
+    _chk(tree, th.float64, "tree"); _chk(ptr, th.int64, "ptr"); _chk(running_max, th.float64, "running_max")
+    if value is not None:
+        _chk(value, th.float64, "value")
+    lib.check_device(tree, ptr, value, running_max)
+    lib.check(lib.lib.morl_sumtree_set(_ptr(tree), n_levels, _ptr(ptr), _ptr(value), ptr.numel(), _ptr(running_max),
+                                       lib.stream_of(tree)))
+
+
+def sumtree_update(lib: NativeLib, tree: th.Tensor, n_levels: int, idx: th.Tensor, raw: th.Tensor, alpha: float,
+                   running_max: th.Tensor, pr_out: Optional[th.Tensor] = None) -> None:
+    _chk(tree, th.float64, "tree"); _chk(idx, th.int64, "idx"); _chk(raw, th.float32, "raw")
+    _chk(running_max, th.float64, "running_max")
+    lib.check_device(tree, idx, raw, running_max, pr_out)
+    lib.check(lib.lib.morl_sumtree_update(_ptr(tree), n_levels, _ptr(idx), _ptr(raw), idx.numel(), float(alpha),
+                                          _ptr(running_max), _ptr(pr_out), lib.stream_of(tree)))

@@ -1,0 +1,164 @@
+// hipsim -- TEST INFRASTRUCTURE ONLY.
+//
+// A tiny wave-level SIMT emulator that lets the *unmodified* kernel sources under
+// morl-baselines_amd/csrc/ be compiled for the x86 host (clang++ -x c++ -I tests/hipsim ...) so
+// that their index arithmetic, LDS tiling, MFMA fragment maps and cross-lane reductions can be
+// checked against the oracle in the GPU-less build container (pytest -m "not gpu").
+//
+// It is NOT a product path: the shipped library is built by hipcc for gfx950 only, nothing in
+// morl-baselines_amd/ loads the emulated build by default, and bench.py / smoke() never do.
+//
+// Model: one OS thread; every work-item of a workgroup is a fiber (ucontext).  Blocks run one
+// after another.  __syncthreads() and the wave collectives (__shfl*, __ballot, __all, __any,
+// MFMA) are rendezvous points: a fiber yields until all work-items of its block / wave arrived.
+// Wave size is 64.  The f32 MFMA fragment maps are the gfx950 ones
+// (guide: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D row=(r&3)+8*(r>>2)+4*(l>>5), col=l&31).
+#pragma once
+#define HIPSIM_EMULATED 1
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct uint3 { unsigned x, y, z; };
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) double2 { double x, y; };
+struct int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2,
+                     hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+static inline const char* hipGetErrorString(hipError_t) { return "hipsim error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+
+namespace hipsim {
+struct LaneCtx {
+    uint3 tid, bid;
+    int lane, wave;
+};
+struct CollIn { float f[18]; double d; unsigned long long u; int i; };
+struct CollOut { float f[16]; double d; unsigned long long u; int i; };
+extern LaneCtx* cur;
+extern dim3 cur_block_dim, cur_grid_dim;
+void run_grid(dim3 grid, dim3 block, const std::function<void()>& body);
+void block_barrier();
+// generic wave rendezvous: every lane deposits `in`, the last arriver runs `fn(in[64], out[64], nlanes)`
+CollOut wave_collective(const CollIn& in, void (*fn)(const CollIn*, CollOut*, int));
+}  // namespace hipsim
+
+#define threadIdx (hipsim::cur->tid)
+#define blockIdx (hipsim::cur->bid)
+#define blockDim (hipsim::cur_block_dim)
+#define gridDim (hipsim::cur_grid_dim)
+#define warpSize 64
+
+static inline void __syncthreads() { hipsim::block_barrier(); }
+
+template <typename K, typename... Args>
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
+    hipsim::run_grid(grid, block, [&]() { kernel(args...); });
+}
+
+// ---- cross-lane ------------------------------------------------------------------------------
+namespace hipsim {
+static void fn_shfl_xor_f(const CollIn* in, CollOut* out, int n) {
+    for (int l = 0; l < n; ++l) { int s = l ^ in[l].i; out[l].f[0] = (s < n) ? in[s].f[0] : in[l].f[0]; }
+}
+static void fn_shfl_xor_i(const CollIn* in, CollOut* out, int n) {
+    for (int l = 0; l < n; ++l) { int s = l ^ in[l].i; out[l].u = (s < n) ? in[s].u : in[l].u; }
+}
+static void fn_shfl_xor_d(const CollIn* in, CollOut* out, int n) {
+    for (int l = 0; l < n; ++l) { int s = l ^ in[l].i; out[l].d = (s < n) ? in[s].d : in[l].d; }
+}
+static void fn_shfl_idx_f(const CollIn* in, CollOut* out, int n) {
+    for (int l = 0; l < n; ++l) { int s = in[l].i & 63; out[l].f[0] = (s < n) ? in[s].f[0] : in[l].f[0]; }
+}
+static void fn_shfl_idx_i(const CollIn* in, CollOut* out, int n) {
+    for (int l = 0; l < n; ++l) { int s = in[l].i & 63; out[l].u = (s < n) ? in[s].u : in[l].u; }
+}
+static void fn_shfl_idx_d(const CollIn* in, CollOut* out, int n) {
+    for (int l = 0; l < n; ++l) { int s = in[l].i & 63; out[l].d = (s < n) ? in[s].d : in[l].d; }
+}
+static void fn_ballot(const CollIn* in, CollOut* out, int n) {
+    unsigned long long m = 0;
+    for (int l = 0; l < n; ++l) if (in[l].i) m |= 1ull << l;
+    for (int l = 0; l < n; ++l) out[l].u = m;
+}
+static void fn_mfma_32x32x2(const CollIn* in, CollOut* out, int n) {
+    if (n != 64) { std::fprintf(stderr, "hipsim: MFMA needs a full wave (got %d lanes)\n", n); std::abort(); }
+    for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+            float acc = in[l].f[2 + r];
+            for (int k = 0; k < 2; ++k) acc = std::fmaf(in[row + 32 * k].f[0], in[col + 32 * k].f[1], acc);
+            out[l].f[r] = acc;
+        }
+}
+}  // namespace hipsim
+
+static inline float __shfl_xor(float v, int m, int = 64) { hipsim::CollIn in{}; in.f[0] = v; in.i = m; return hipsim::wave_collective(in, hipsim::fn_shfl_xor_f).f[0]; }
+static inline int __shfl_xor(int v, int m, int = 64) { hipsim::CollIn in{}; in.u = (unsigned)v; in.i = m; return (int)hipsim::wave_collective(in, hipsim::fn_shfl_xor_i).u; }
+static inline unsigned __shfl_xor(unsigned v, int m, int = 64) { hipsim::CollIn in{}; in.u = v; in.i = m; return (unsigned)hipsim::wave_collective(in, hipsim::fn_shfl_xor_i).u; }
+static inline double __shfl_xor(double v, int m, int = 64) { hipsim::CollIn in{}; in.d = v; in.i = m; return hipsim::wave_collective(in, hipsim::fn_shfl_xor_d).d; }
+static inline float __shfl(float v, int s, int = 64) { hipsim::CollIn in{}; in.f[0] = v; in.i = s; return hipsim::wave_collective(in, hipsim::fn_shfl_idx_f).f[0]; }
+static inline int __shfl(int v, int s, int = 64) { hipsim::CollIn in{}; in.u = (unsigned)v; in.i = s; return (int)hipsim::wave_collective(in, hipsim::fn_shfl_idx_i).u; }
+static inline double __shfl(double v, int s, int = 64) { hipsim::CollIn in{}; in.d = v; in.i = s; return hipsim::wave_collective(in, hipsim::fn_shfl_idx_d).d; }
+static inline unsigned long long __ballot(int p) { hipsim::CollIn in{}; in.i = p != 0; return hipsim::wave_collective(in, hipsim::fn_ballot).u; }
+static inline int __all(int p) { return __ballot(!p) == 0ull; }
+static inline int __any(int p) { return __ballot(p) != 0ull; }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+
+typedef float hipsim_f32x16 __attribute__((ext_vector_type(16)));
+static inline hipsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipsim_f32x16 c, int, int, int) {
+    hipsim::CollIn in{};
+    in.f[0] = a; in.f[1] = b;
+    for (int r = 0; r < 16; ++r) in.f[2 + r] = c[r];
+    hipsim::CollOut o = hipsim::wave_collective(in, hipsim::fn_mfma_32x32x2);
+    hipsim_f32x16 d;
+    for (int r = 0; r < 16; ++r) d[r] = o.f[r];
+    return d;
+}
+
+// ---- math that hipcc provides as builtins -------------------------------------------------------
+// Compile the emulated build with -ffp-contract=off so these stay separately rounded.
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+static inline float __fsqrt_rn(float a) { return std::sqrt(a); }
+static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
+static inline double __dsub_rn(double a, double b) { volatile double r = a - b; return r; }
