@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmorl_hip.so")
 SOURCES = ["morl_hip.hip"]
-HEADERS = ["morl_device.h", "gemm_f32.h", "envelope_kernels.h", "optim_kernels.h", "replay_kernels.h",
+HEADERS = ["morl_device.h", "gemm_f32.h", "envelope_kernels.h", "mlp_chain.h", "optim_kernels.h", "replay_kernels.h",
            "pareto_kernels.h"]
 
 
@@ -42,6 +42,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           # rounding contract: a*b+c is never fused behind our back (the envelope scalarisation must round every
+           # product and sum separately, as torch's einsum does); FMAs are written explicitly as fmaf()
+           "-ffp-contract=off",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB_PATH + ".tmp"]

@@ -45,13 +45,15 @@ __global__ __launch_bounds__(256) void build_input_kernel(const float* __restric
 // diag_only restricts j to i (DDQN target, envelope.py:442-463).
 // HBM-bound and tiny: reads 2*B*W*A*R*4 bytes once.
 // ----------------------------------------------------------------------------------------------
-constexpr int ENV_MAX_SLAB = 6144;   // floats of LDS for one Qo[b] slab (W*A*R)
+constexpr int ENV_MAX_SLAB = 6144;   // floats of LDS for one Qo[b] / Qt[b] slab (W*A*R)
 constexpr int ENV_MAX_WR = 1024;     // floats of LDS for the weight vectors (W*R)
 
 struct EnvelopeTdArgs {
     const float* qo;        // [B][W][A][R]
     const float* qt;        // [B][W][A][R]
     const float* weights;   // [W][R]
+    const float* row_weights;  // optional [B][R]: generic mode, ONE scalarisation vector per row b (W_i = 1);
+                               // reproduces Envelope.envelope_target(obs, w, sampled_w) for arbitrary rows
     const float* q_main;    // [W*B][ldq]  Q_online(s_b, w_i), row i*B+b ; may be NULL (reduce only)
     const int32_t* actions; // [B]
     const float* rewards;   // [B][R]
@@ -69,24 +71,43 @@ struct EnvelopeTdArgs {
     float c_aux;            // lambda * 2 / (W*B)
 };
 
+// LDS-resident throughout: phase 1 stages Qo[b], Qt[b], the weight vectors and the W taken-action Q entries of
+// this transition with coalesced / parallel loads; phase 2 (arg-max + TD per row) touches LDS only, so the 16
+// rows a wave owns are not serialised behind dependent global loads; phase 3 writes all outputs in bulk.
 __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
-    __shared__ float s_q[ENV_MAX_SLAB];
+    __shared__ float s_qo[ENV_MAX_SLAB];
+    __shared__ float s_qt[ENV_MAX_SLAB];
     __shared__ float s_w[ENV_MAX_WR];
+    __shared__ float s_qm[ENV_MAX_WR];    // Q_online(s_b, w_i)[action_b][r]
+    __shared__ float s_tgt[ENV_MAX_WR];   // selected target vectors
+    __shared__ float s_g[ENV_MAX_WR];     // dLoss/dQ of the taken action
+    __shared__ int s_best[ENV_MAX_WR];    // flattened (j*, a*)
     __shared__ double s_red[4][2];
     const int b = (int)blockIdx.x;
     const int lane = lane_id(), wave = wave_id();
     const int W = p.W, A = p.A, R = p.R;
     const int slab = W * A * R;
-    for (int e = (int)threadIdx.x; e < slab; e += (int)blockDim.x) s_q[e] = p.qo[(size_t)b * slab + e];
-    for (int e = (int)threadIdx.x; e < W * R; e += (int)blockDim.x) s_w[e] = p.weights[e];
+    const bool generic = p.row_weights != nullptr;
+    const int nI = generic ? 1 : W;          // scalarisation vectors handled by this workgroup
+    const bool train = p.q_main != nullptr;
+    const int act = train ? p.actions[b] : 0;
+    for (int e = (int)threadIdx.x; e < slab; e += (int)blockDim.x) {
+        s_qo[e] = p.qo[(size_t)b * slab + e];
+        s_qt[e] = p.qt[(size_t)b * slab + e];
+    }
+    for (int e = (int)threadIdx.x; e < nI * R; e += (int)blockDim.x) {
+        s_w[e] = generic ? p.row_weights[(size_t)b * R + e] : p.weights[e];
+        if (train) s_qm[e] = p.q_main[((size_t)(e / R) * p.B + b) * p.ldq + act * R + (e % R)];
+    }
     __syncthreads();
 
     double acc_mse = 0.0, acc_aux = 0.0;
-    const float not_done_gamma =
-        (p.q_main != nullptr) ? __fmul_rn(__fsub_rn(1.0f, p.dones[b]), p.gamma) : 0.f;  // (1 - d) * gamma
-    const int act = (p.q_main != nullptr) ? p.actions[b] : 0;
+    const float not_done_gamma = train ? __fmul_rn(__fsub_rn(1.0f, p.dones[b]), p.gamma) : 0.f;  // (1 - d) * gamma
+    float rew[MORL_MAX_OBJ];
+#pragma unroll
+    for (int r = 0; r < MORL_MAX_OBJ; ++r) rew[r] = (train && r < R) ? p.rewards[(size_t)b * R + r] : 0.f;
 
-    for (int i = wave; i < W; i += 4) {
+    for (int i = wave; i < nI; i += 4) {
         float wi[MORL_MAX_OBJ];
 #pragma unroll
         for (int r = 0; r < MORL_MAX_OBJ; ++r) wi[r] = (r < R) ? s_w[i * R + r] : 0.f;
@@ -95,7 +116,7 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
         float best = -INFINITY;
         int best_c = 0x7fffffff;
         for (int c = c_begin + lane; c < c_end; c += kWave) {
-            const float* q = s_q + c * R;
+            const float* q = s_qo + c * R;
             float s = __fmul_rn(wi[0], q[0]);
 #pragma unroll
             for (int r = 1; r < MORL_MAX_OBJ; ++r)
@@ -111,44 +132,32 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
                 best_c = oc;
             }
         }
-        const int jstar = best_c / A, astar = best_c % A;
-        const size_t row = (size_t)i * p.B + b;
-        const float* qt = p.qt + ((size_t)b * W * A + best_c) * R;
-        if (lane == 0) {
-            if (p.pref) p.pref[row] = jstar;
-            if (p.ac) p.ac[row] = astar;
-        }
-        if (p.target && lane < R) p.target[row * R + lane] = qt[lane];
-        if (p.q_main == nullptr) continue;
+        const float* qt = s_qt + best_c * R;
+        if (lane == 0) s_best[i] = best_c;
+        if (lane < R) s_tgt[i * R + lane] = qt[lane];
+        if (!train) continue;
 
-        // every lane evaluates the R-vector redundantly (broadcast loads), lanes then split the dQ row
+        // every lane evaluates the R-vector redundantly (LDS broadcasts)
         float td[MORL_MAX_OBJ];
         float wq = 0.f, wtq = 0.f;
 #pragma unroll
         for (int r = 0; r < MORL_MAX_OBJ; ++r) {
             td[r] = 0.f;
             if (r < R) {
-                const float tq = __fadd_rn(p.rewards[(size_t)b * R + r], __fmul_rn(not_done_gamma, qt[r]));
-                const float qv = p.q_main[row * p.ldq + act * R + r];
+                const float tq = __fadd_rn(rew[r], __fmul_rn(not_done_gamma, qt[r]));
+                const float qv = s_qm[i * R + r];
                 td[r] = __fsub_rn(qv, tq);
                 wq = (r == 0) ? __fmul_rn(qv, wi[0]) : __fadd_rn(wq, __fmul_rn(qv, wi[r]));
                 wtq = (r == 0) ? __fmul_rn(tq, wi[0]) : __fadd_rn(wtq, __fmul_rn(tq, wi[r]));
             }
         }
         const float daux = __fsub_rn(wq, wtq);
-        if (p.dq) {
-            for (int e = lane; e < p.ldq; e += kWave) {
-                float g = 0.f;
-                const int r = e - act * R;
-                if (r >= 0 && r < R) {
-                    float tdr = 0.f, wr = 0.f;
+        if (lane < R) {
+            float tdr = 0.f, wr = 0.f;
 #pragma unroll
-                    for (int rr = 0; rr < MORL_MAX_OBJ; ++rr)
-                        if (rr == r) { tdr = td[rr]; wr = wi[rr]; }
-                    g = p.c_mse * tdr + p.c_aux * daux * wr;
-                }
-                p.dq[row * p.ldq + e] = g;
-            }
+            for (int rr = 0; rr < MORL_MAX_OBJ; ++rr)
+                if (rr == lane) { tdr = td[rr]; wr = wi[rr]; }
+            s_g[i * R + lane] = p.c_mse * tdr + p.c_aux * daux * wr;
         }
         if (lane == 0) {
             double m = 0.0;
@@ -166,13 +175,31 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
             }
         }
     }
-    if (p.loss_part) {
-        if (lane == 0) { s_red[wave][0] = acc_mse; s_red[wave][1] = acc_aux; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            p.loss_part[(size_t)b * 2 + 0] = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
-            p.loss_part[(size_t)b * 2 + 1] = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
+    if (lane == 0) { s_red[wave][0] = acc_mse; s_red[wave][1] = acc_aux; }
+    __syncthreads();
+
+    // phase 3: bulk outputs.  Output row of (i, b) is i*B + b (generic mode: b).
+    const int nB = p.B;
+    for (int e = (int)threadIdx.x; e < nI * R; e += (int)blockDim.x) {
+        const int i = e / R;
+        const size_t row = generic ? (size_t)b : (size_t)i * nB + b;
+        if (p.target) p.target[row * R + (e % R)] = s_tgt[e];
+    }
+    for (int i = (int)threadIdx.x; i < nI; i += (int)blockDim.x) {
+        const size_t row = generic ? (size_t)b : (size_t)i * nB + b;
+        if (p.pref) p.pref[row] = s_best[i] / A;
+        if (p.ac) p.ac[row] = s_best[i] % A;
+    }
+    if (train && p.dq) {
+        for (int e = (int)threadIdx.x; e < nI * p.ldq; e += (int)blockDim.x) {
+            const int i = e / p.ldq, c = e % p.ldq;
+            const int r = c - act * R;
+            p.dq[((size_t)i * nB + b) * p.ldq + c] = (r >= 0 && r < R) ? s_g[i * R + r] : 0.f;
         }
+    }
+    if (p.loss_part && threadIdx.x == 0) {
+        p.loss_part[(size_t)b * 2 + 0] = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
+        p.loss_part[(size_t)b * 2 + 1] = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
     }
 }
 

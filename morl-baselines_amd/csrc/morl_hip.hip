@@ -14,6 +14,7 @@
 #include "morl_device.h"
 #include "gemm_f32.h"
 #include "envelope_kernels.h"
+#include "mlp_chain.h"
 #include "optim_kernels.h"
 #include "replay_kernels.h"
 #include "pareto_kernels.h"
@@ -123,6 +124,14 @@ struct morl_ctx {
     int max_splits;
     double* sumsq_part = nullptr;  // [OPT_MAX_BLOCKS]
     double* loss_part = nullptr;   // [max_batch][2]
+    // layer-fused path (mlp_chain.h): K-major transposed weight copies, refreshed at the start of every call
+    float* wt_online = nullptr;
+    float* wt_target = nullptr;
+    int64_t wt_count = 0;
+    int64_t offWt[MORL_MAX_LAYERS];
+    int ldn[MORL_MAX_LAYERS];
+    bool fused_ok = false;   // architecture fits the fused engine
+    bool use_fused = false;  // fused_ok and not disabled by morl_ctx_set_fused
 };
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -162,6 +171,8 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     }
     if (c->sumsq_part) (void)hipFree(c->sumsq_part);
     if (c->loss_part) (void)hipFree(c->loss_part);
+    if (c->wt_online) (void)hipFree(c->wt_online);
+    if (c->wt_target) (void)hipFree(c->wt_target);
     delete c;
     return MORL_OK;
 }
@@ -224,6 +235,18 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     ALLOC(slabs, (size_t)c->max_splits * c->P);
     ALLOC(sumsq_part, OPT_MAX_BLOCKS);
     ALLOC(loss_part, (size_t)max_batch * 2);
+    c->fused_ok = true;
+    c->wt_count = 0;
+    for (int l = 0; l < c->L; ++l) {
+        c->ldn[l] = round_up(net->dims[l + 1], 4);
+        c->offWt[l] = c->wt_count;
+        c->wt_count += (int64_t)net->dims[l] * c->ldn[l];
+        if (net->dims[l] > CH_MAXW || net->dims[l + 1] > CH_MAXW) c->fused_ok = false;
+        if (l >= 1 && (net->dims[l] & 3)) c->fused_ok = false;   // backward streams W_l rows with 16-byte loads
+    }
+    ALLOC(wt_online, c->wt_count);
+    ALLOC(wt_target, c->wt_count);
+    c->use_fused = c->fused_ok;
 #undef ALLOC
     *out = c;
     return MORL_OK;
@@ -294,6 +317,83 @@ static int build_input(const float* obs, const float* weights, float* x0, int B,
     return MORL_OK;
 }
 
+// ---- layer-fused path --------------------------------------------------------------------------
+static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipStream_t s) {
+    TransposeArgs t{};
+    t.n = c->L;
+    long long e = 0;
+    for (int l = 0; l < c->L; ++l) {
+        t.src_off[l] = c->offW[l];
+        t.dst_off[l] = c->offWt[l];
+        t.K[l] = c->net.dims[l];
+        t.N[l] = c->net.dims[l + 1];
+        t.ldn[l] = c->ldn[l];
+        t.elem_start[l] = e;
+        e += (long long)t.K[l] * t.ldn[l];
+    }
+    t.elem_start[c->L] = e;
+    hipLaunchKernelGGL(transpose_params_kernel, dim3(stream_grid(e, 256)), dim3(256), 0, s, params, wt, t);
+    LAUNCH_CHECK("transpose_params");
+    return MORL_OK;
+}
+
+// forward chain over rows assembled on the fly from (obs, weights); save => hidden activations to ctx->h[]
+static int chain_forward(morl_ctx* c, const float* params, const float* wt, const float* obs, const float* weights,
+                         int B, int W, int row_order, int rows, bool save, float* q_out, int ldq_out, hipStream_t s) {
+    ChainArgs a{};
+    a.n_steps = c->L;
+    a.rows = rows;
+    a.in_mode = 0;
+    a.obs = obs; a.weights = weights;
+    a.B = B; a.W = W; a.D = c->net.obs_dim; a.R = c->net.reward_dim; a.row_order = row_order;
+    for (int l = 0; l < c->L; ++l) {
+        ChainStep& st = a.step[l];
+        const bool last = (l == c->L - 1);
+        st.Bmat = wt + c->offWt[l];
+        st.ldb = c->ldn[l];
+        st.K = c->net.dims[l];
+        st.N = c->net.dims[l + 1];
+        st.bias = params + c->offB[l];
+        st.relu = last ? 0 : 1;
+        if (last) { st.out = q_out; st.ldout = ldq_out; }
+        else if (save) { st.out = c->h[l + 1]; st.ldout = c->net.dims[l + 1]; }
+    }
+    hipLaunchKernelGGL(mlp_chain_kernel, dim3((rows + CH_TM - 1) / CH_TM), dim3(CH_THREADS), 0, s, a);
+    LAUNCH_CHECK("mlp_chain(fwd)");
+    return MORL_OK;
+}
+
+// backward chain: g[L-1] = dq  ->  g[l-1] = (g[l] @ W_l) * (h[l] > 0), every g[l-1] written to ctx->g[]
+static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_t s) {
+    const int L = c->L;
+    if (L < 2) return MORL_OK;
+    ChainArgs a{};
+    a.n_steps = L - 1;
+    a.rows = rows;
+    a.in_mode = 1;
+    a.src = c->dq; a.ldsrc = c->ldq; a.K0 = c->net.dims[L];
+    for (int l = L - 1, k = 0; l >= 1; --l, ++k) {
+        ChainStep& st = a.step[k];
+        st.Bmat = params + c->offW[l];
+        st.ldb = c->net.dims[l];
+        st.K = c->net.dims[l + 1];
+        st.N = c->net.dims[l];
+        st.mask = c->h[l];
+        st.ldmask = c->net.dims[l];
+        st.out = c->g[l - 1];
+        st.ldout = c->net.dims[l];
+    }
+    hipLaunchKernelGGL(mlp_chain_kernel, dim3((rows + CH_TM - 1) / CH_TM), dim3(CH_THREADS), 0, s, a);
+    LAUNCH_CHECK("mlp_chain(bwd)");
+    return MORL_OK;
+}
+
+extern "C" int morl_ctx_set_fused(morl_ctx* c, int enable) {
+    if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
+    c->use_fused = enable && c->fused_ok;
+    return c->use_fused ? 1 : 0;
+}
+
 static int check_bw(const morl_ctx* c, int B, int W) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     if (B < 1 || W < 1) return fail(MORL_ERR_ARG, "B=%d W=%d must be >= 1", B, W);
@@ -324,11 +424,18 @@ extern "C" int morl_qnet_forward(morl_ctx* c, const float* params, const float* 
     int rc = check_bw(c, B, W);
     if (rc) return rc;
     if (!params || !obs || !weights || !q_out) return fail(MORL_ERR_ARG, "NULL array");
-    if (row_order != 0 && row_order != 1) return fail(MORL_ERR_ARG, "row_order must be 0 or 1");
+    if (row_order < 0 || row_order > 2) return fail(MORL_ERR_ARG, "row_order must be 0, 1 or 2");
+    if (row_order == 2 && W != 1) return fail(MORL_ERR_ARG, "row_order 2 (paired rows) takes W = 1 and weights [B][R]");
     hipStream_t s = (hipStream_t)stream;
+    const int rows = (row_order == 2) ? B : B * W;
+    if (c->use_fused) {
+        if ((rc = refresh_transposed(c, params, c->wt_online, s))) return rc;
+        return chain_forward(c, params, c->wt_online, obs, weights, B, W, row_order, rows, false, q_out,
+                             c->net.dims[c->L], s);
+    }
     rc = build_input(obs, weights, c->x0n, B, W, c->net.obs_dim, c->net.reward_dim, c->ld0, row_order, s);
     if (rc) return rc;
-    return net_forward(c, params, c->x0n, B * W, false, q_out, c->net.dims[c->L], s);
+    return net_forward(c, params, c->x0n, rows, false, q_out, c->net.dims[c->L], s);
 }
 
 extern "C" int morl_envelope_reduce(const float* qo, const float* qt, const float* weights, int B, int W, int A, int R,
@@ -365,14 +472,24 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     static const morl_update_out no_out = {};
     if (!out) out = &no_out;
 
-    // 1. inputs of the three passes (the W-tiled batch of envelope.py:284-291 is never materialised wider than this)
-    if ((rc = build_input(next_obs, weights, c->x0n, B, W, D, R, c->ld0, 0, s))) return rc;
+    // 1. the dW GEMM reads the training pass's layer-0 input from HBM (the W-tiled batch of envelope.py:284-291 is
+    //    never materialised wider than this [rows][D+R] block)
     if ((rc = build_input(obs, weights, c->x0m, B, W, D, R, c->ld0, 1, s))) return rc;
-    // 2. no-grad next-state slabs Qo, Qt [B][W][A][R] (B*W distinct rows instead of the reference's W^2*B)
-    if ((rc = net_forward(c, params_online, c->x0n, rows, false, c->qo, AR, s))) return rc;
-    if ((rc = net_forward(c, params_target, c->x0n, rows, false, c->qt, AR, s))) return rc;
-    // 3. training forward, activations saved
-    if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
+    if (c->use_fused) {
+        // 2./3. layer-fused passes: activations stay in LDS; rows assembled from (obs, weights) inside the kernel
+        if ((rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
+        if ((rc = refresh_transposed(c, params_target, c->wt_target, s))) return rc;
+        if ((rc = chain_forward(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR, s))) return rc;
+        if ((rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
+        if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm, c->ldq, s))) return rc;
+    } else {
+        if ((rc = build_input(next_obs, weights, c->x0n, B, W, D, R, c->ld0, 0, s))) return rc;
+        // 2. no-grad next-state slabs Qo, Qt [B][W][A][R] (B*W distinct rows instead of the reference's W^2*B)
+        if ((rc = net_forward(c, params_online, c->x0n, rows, false, c->qo, AR, s))) return rc;
+        if ((rc = net_forward(c, params_target, c->x0n, rows, false, c->qt, AR, s))) return rc;
+        // 3. training forward, activations saved
+        if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
+    }
     // 4. envelope arg-max + TD target + dLoss/dQ
     {
         EnvelopeTdArgs p{};
@@ -390,6 +507,9 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         LAUNCH_CHECK("envelope_td");
     }
     // 5. backward through the hidden layers: g[l-1] = (g[l] @ W_l) * (h[l] > 0)
+    if (c->use_fused) {
+        if ((rc = chain_backward(c, params_online, rows, s))) return rc;
+    } else
     for (int l = L - 1; l >= 1; --l) {
         GemmProblem g{};
         g.A = c->g[l];

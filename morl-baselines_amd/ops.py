@@ -17,7 +17,7 @@ class QNetContext:
     """Owns a ``morl_ctx`` (scratch workspace for a Q-network of fixed architecture)."""
 
     def __init__(self, obs_dim: int, reward_dim: int, n_actions: int, net_arch: Sequence[int], max_batch: int,
-                 max_weights: int, lib: Optional[NativeLib] = None):
+                 max_weights: int, lib: Optional[NativeLib] = None, fused: Optional[bool] = None):
         self.lib = lib or load_library()
         self.desc: NetDesc = make_net_desc(obs_dim, reward_dim, n_actions, net_arch)
         self.obs_dim, self.reward_dim, self.n_actions = obs_dim, reward_dim, n_actions
@@ -25,6 +25,8 @@ class QNetContext:
         self.max_batch, self.max_weights = int(max_batch), int(max_weights)
         self.n_params = self.lib.param_count(self.desc)
         self.handle = self.lib.ctx_create(self.desc, self.max_batch, self.max_weights)
+        # layer-fused MLP engine is the default whenever the architecture fits; fused=False forces per-layer GEMMs
+        self.fused = bool(self.lib.lib.morl_ctx_set_fused(self.handle, 1 if fused is None else int(fused)))
 
     def layer_slices(self):
         """[(w_offset, (out, in), b_offset, out)] of the flat parameter layout."""

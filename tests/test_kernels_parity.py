@@ -42,8 +42,8 @@ def relmax(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def run_update(lib, dev, c, inp, apply_step=True, debug=True):
-    ctx = ops.QNetContext(c.D, c.R, c.A, c.arch, c.B, c.W, lib=lib)
+def run_update(lib, dev, c, inp, apply_step=True, debug=True, fused=None):
+    ctx = ops.QNetContext(c.D, c.R, c.A, c.arch, c.B, c.W, lib=lib, fused=fused)
     t = dict(
         po=flat(inp["online"]).to(dev), pt=flat(inp["target"]).to(dev), m=flat(inp["exp_avg"]).to(dev),
         v=flat(inp["exp_avg_sq"]).to(dev), obs=th.tensor(inp["obs"]).to(dev), nobs=th.tensor(inp["next_obs"]).to(dev),
@@ -100,11 +100,12 @@ def check_update(res, t, o, online, m, v, c):
     assert float((t["po"].cpu() - flat(online)).abs().max()) <= 0.02 * c.lr
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "perlayer"])
 @pytest.mark.parametrize("c", CASES, ids=lambda c: c.name)
-def test_envelope_update_vs_oracle(be, c):
+def test_envelope_update_vs_oracle(be, c, fused):
     lib, dev, is_sim = be
     inp = make_inputs(c)
-    res, t = run_update(lib, dev, c, inp)
+    res, t = run_update(lib, dev, c, inp, fused=fused)
     o, online, m, v = run_oracle(c, inp)
     check_update(res, t, o, online, m, v, c)
 
@@ -167,8 +168,9 @@ def test_envelope_reduce_ties_bit_exact(be):
             assert th.equal(tg.cpu(), tg_o.reshape(-1, R))
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "perlayer"])
 @pytest.mark.parametrize("dims", [(6, 5, 3, 2, (16, 16)), (9, 4, 4, 3, (40,)), (130, 3, 5, 3, (200, 72, 136))])
-def test_qnet_forward_row_orders(be, dims):
+def test_qnet_forward_row_orders(be, dims, fused):
     lib, dev, _ = be
     B, W, A, R, arch = dims
     D = 11
@@ -177,7 +179,8 @@ def test_qnet_forward_row_orders(be, dims):
     params = [p + 0.01 * th.randn(p.shape, generator=th.Generator().manual_seed(1)) for p in params]
     obs = th.tensor(rng.standard_normal((B, D)), dtype=th.float32)
     sw = th.tensor(orc.random_weights(R, W, "gaussian", rng=rng), dtype=th.float32).reshape(W, R)
-    ctx = ops.QNetContext(D, R, A, arch, B, W, lib=lib)
+    ctx = ops.QNetContext(D, R, A, arch, B, W, lib=lib, fused=fused)
+    assert ctx.fused == fused
     pf = flat(params).to(dev)
     q0 = ops.qnet_forward(ctx, pf, obs.to(dev), sw.to(dev), row_order=0).cpu()
     q1 = ops.qnet_forward(ctx, pf, obs.to(dev), sw.to(dev), row_order=1).cpu()
