@@ -17,7 +17,8 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
-__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+// wave index as a scalar (SGPR) value so that wave-dependent loop bounds / branches stay scalar
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // Deterministic butterfly sums (same order on every run; all lanes end with the total).
 __device__ __forceinline__ double wave_sum(double v) {

@@ -132,6 +132,7 @@ struct morl_ctx {
     int ldn[MORL_MAX_LAYERS];
     bool fused_ok = false;   // architecture fits the fused engine
     bool use_fused = false;  // fused_ok and not disabled by morl_ctx_set_fused
+    bool use_dma = false;    // weight chunks via LDS-DMA (global_load_lds) instead of register staging
 };
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -358,7 +359,8 @@ static int chain_forward(morl_ctx* c, const float* params, const float* wt, cons
         if (last) { st.out = q_out; st.ldout = ldq_out; }
         else if (save) { st.out = c->h[l + 1]; st.ldout = c->net.dims[l + 1]; }
     }
-    hipLaunchKernelGGL(mlp_chain_kernel, dim3((rows + CH_TM - 1) / CH_TM), dim3(CH_THREADS), 0, s, a);
+    if (c->use_dma) hipLaunchKernelGGL(mlp_chain_dma_kernel, dim3((rows + CH_TM - 1) / CH_TM), dim3(CH_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(mlp_chain_kernel, dim3((rows + CH_TM - 1) / CH_TM), dim3(CH_THREADS), 0, s, a);
     LAUNCH_CHECK("mlp_chain(fwd)");
     return MORL_OK;
 }
@@ -383,7 +385,8 @@ static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_
         st.out = c->g[l - 1];
         st.ldout = c->net.dims[l];
     }
-    hipLaunchKernelGGL(mlp_chain_kernel, dim3((rows + CH_TM - 1) / CH_TM), dim3(CH_THREADS), 0, s, a);
+    if (c->use_dma) hipLaunchKernelGGL(mlp_chain_dma_kernel, dim3((rows + CH_TM - 1) / CH_TM), dim3(CH_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(mlp_chain_kernel, dim3((rows + CH_TM - 1) / CH_TM), dim3(CH_THREADS), 0, s, a);
     LAUNCH_CHECK("mlp_chain(bwd)");
     return MORL_OK;
 }
@@ -391,7 +394,8 @@ static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_
 extern "C" int morl_ctx_set_fused(morl_ctx* c, int enable) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     c->use_fused = enable && c->fused_ok;
-    return c->use_fused ? 1 : 0;
+    c->use_dma = c->use_fused && enable >= 2;
+    return c->use_fused ? (c->use_dma ? 2 : 1) : 0;
 }
 
 static int check_bw(const morl_ctx* c, int B, int W) {

@@ -13,11 +13,14 @@ import torch as th
 from .native import NativeLib, NetDesc, UpdateCfg, UpdateOut, _chk, _ptr, load_library, make_net_desc
 
 
+DEFAULT_ENGINE = 1
+
+
 class QNetContext:
     """Owns a ``morl_ctx`` (scratch workspace for a Q-network of fixed architecture)."""
 
     def __init__(self, obs_dim: int, reward_dim: int, n_actions: int, net_arch: Sequence[int], max_batch: int,
-                 max_weights: int, lib: Optional[NativeLib] = None, fused: Optional[bool] = None):
+                 max_weights: int, lib: Optional[NativeLib] = None, fused: Optional[int] = None):
         self.lib = lib or load_library()
         self.desc: NetDesc = make_net_desc(obs_dim, reward_dim, n_actions, net_arch)
         self.obs_dim, self.reward_dim, self.n_actions = obs_dim, reward_dim, n_actions
@@ -25,8 +28,10 @@ class QNetContext:
         self.max_batch, self.max_weights = int(max_batch), int(max_weights)
         self.n_params = self.lib.param_count(self.desc)
         self.handle = self.lib.ctx_create(self.desc, self.max_batch, self.max_weights)
-        # layer-fused MLP engine is the default whenever the architecture fits; fused=False forces per-layer GEMMs
-        self.fused = bool(self.lib.lib.morl_ctx_set_fused(self.handle, 1 if fused is None else int(fused)))
+        # engine: 0 per-layer GEMMs, 1 layer-fused (register-staged weights), 2 layer-fused (LDS-DMA weights);
+        # default = the fastest the architecture admits
+        self.engine = int(self.lib.lib.morl_ctx_set_fused(self.handle, DEFAULT_ENGINE if fused is None else int(fused)))
+        self.fused = self.engine > 0
 
     def layer_slices(self):
         """[(w_offset, (out, in), b_offset, out)] of the flat parameter layout."""

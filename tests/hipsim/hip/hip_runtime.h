@@ -44,6 +44,8 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 
+static inline long long clock64() { return 0; }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // only used on wave-uniform values
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 
@@ -150,6 +152,19 @@ static inline hipsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float 
     hipsim_f32x16 d;
     for (int r = 0; r < 16; ++r) d[r] = o.f[r];
     return d;
+}
+
+// LDS-DMA: lane l copies `size` bytes from its own global address to (first lane's LDS pointer) + l*size
+namespace hipsim {
+static void fn_first_ptr(const CollIn* in, CollOut* out, int n) { for (int l = 0; l < n; ++l) out[l].u = in[0].u; }
+}
+static inline void __builtin_amdgcn_global_load_lds(const __attribute__((address_space(1))) void* src,
+                                                    __attribute__((address_space(3))) void* dst, unsigned size, int offset,
+                                                    unsigned) {
+    hipsim::CollIn in{};
+    in.u = (unsigned long long)(uintptr_t)dst;
+    char* base = (char*)(uintptr_t)hipsim::wave_collective(in, hipsim::fn_first_ptr).u;
+    std::memcpy(base + offset + (size_t)hipsim::cur->lane * size, (const char*)(uintptr_t)src + offset, size);
 }
 
 // ---- math that hipcc provides as builtins -------------------------------------------------------

@@ -46,14 +46,14 @@ def main():
     rew = th.tensor(rng.standard_normal((B, R)), dtype=th.float32)
     done = th.tensor((rng.random((B, 1)) < 0.05), dtype=th.float32)
     sw = th.tensor(orc.random_weights(R, W, "gaussian", rng=rng), dtype=th.float32)
-    ctx = ops.QNetContext(D, R, A, arch, B, W, lib=lib, fused=bool(a.fused))
+    ctx = ops.QNetContext(D, R, A, arch, B, W, lib=lib, fused=a.fused)
     P = ctx.n_params
     po, pt = flat(online).to(dev), flat(target).to(dev)
     m, v, gr = th.zeros(P, device=dev), th.zeros(P, device=dev), th.zeros(P, device=dev)
     d_obs, d_nobs, d_rew = obs.to(dev), nobs.to(dev), rew.to(dev)
     d_act, d_done, d_sw = act.reshape(-1).int().to(dev), done.reshape(-1).to(dev), sw.to(dev)
     kw = dict(gamma=0.99, lr=3e-4, max_grad_norm=1.0)
-    out = {"B": B, "W": W, "device": th.cuda.get_device_name(0), "n_params": P, "fused": ctx.fused}
+    out = {"B": B, "W": W, "device": th.cuda.get_device_name(0), "n_params": P, "engine": ctx.engine}
 
     if not a.no_check:
         res = ops.envelope_update(ctx, po, pt, gr, m, v, d_obs, d_nobs, d_act, d_rew, d_done, d_sw, adam_step=1, debug=True, **kw)
