@@ -88,9 +88,9 @@ int morl_is_device_build(void);
 /* ---- context ------------------------------------------------------------------------------ */
 int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max_batch, int max_weights);
 int morl_ctx_destroy(morl_ctx* ctx);
-/* Select the MLP engine: 0 = per-layer GEMMs, 1 = layer-fused chain with register-staged weight chunks,
- * 2 = layer-fused chain with LDS-DMA (global_load_lds) weight chunks.  The fused engines need widths <= 256 and
- * hidden widths % 4 == 0.  Returns the engine now active (0, 1 or 2), < 0 on error. */
+/* Select the MLP engine: 0 = per-layer GEMMs, 1 = layer-fused chain (row tile chosen per launch),
+ * 2 / 3 = layer-fused chain with the row tile forced to 64 / 32.  The fused engine needs widths <= 256 and hidden
+ * widths % 4 == 0.  Returns the engine now active (0..3), < 0 on error. */
 int morl_ctx_set_fused(morl_ctx* ctx, int enable);
 /* number of float parameters of `net` in the flat layout */
 int64_t morl_param_count(const morl_net_desc* net);

@@ -1,7 +1,7 @@
-// Layer-fused MLP engine: a workgroup carries a 64-row tile through a whole chain of dense layers with the
-// activations RESIDENT IN LDS -- they never round-trip through HBM between layers (gfx950, wave64).
+// Layer-fused MLP engine: a workgroup carries a TM-row tile (TM = 64 or 32) through a whole chain of dense layers
+// with the activations RESIDENT IN LDS -- they never round-trip through HBM between layers (gfx950, wave64).
 //
-//   step s:   out_s[64][N_s] = epilogue_s( act[64][K_s] @ Bmat_s[K_s][N_s] ),   act <- out_s
+//   step s:   out_s[TM][N_s] = epilogue_s( act[TM][K_s] @ Bmat_s[K_s][N_s] ),   act <- out_s
 //
 // Used three ways (same kernel, different step tables):
 //   * no-grad forward      Q(s', w) slabs:  Bmat = W_l^T (pre-transposed copy), epilogue bias+ReLU, only Q leaves
@@ -9,30 +9,34 @@
 //   * backward (dX chain)  Bmat = W_l as stored ([out][in] is already K-major for g_l @ W_l), epilogue = ReLU mask
 //                          from the saved activation; every g_l is written out for the weight-gradient GEMM
 //
-// Tiling: 256 threads = 4 waves; wave w owns output columns [64w, 64w+64) as 2x2 v_mfma_f32_32x32x2_f32 tiles
-// (64 accumulator registers; exact fp32).  Steps with N <= 32 (the Q head) instead split the contraction over the
-// four waves (8 slices of every 32-deep chunk) and reduce the partial tiles through LDS in a fixed order; both
-// shapes run the SAME inner loop (only operand offsets / trip counts differ) so the accumulators never move.
-// LDS: activations K-major sAct[k][m] (stride 65 -> the transposed epilogue stores and the MFMA operand reads are
-// both bank-conflict free) = 66.6 KB, plus a double-buffered 32 x 256 weight chunk (64 KB).  The weight stream is
-// one flat sequence of chunks over all steps: the chunk after the one being multiplied (possibly the first chunk of
-// the NEXT layer) is already in flight in registers (16-byte loads, scalar-base + per-thread-offset addressing, no
-// per-element address math) and is written to the other LDS buffer after the MFMAs; one barrier per chunk.
-// 1 workgroup per CU (133 KB LDS).  Widths up to 256; Bmat row strides must be multiples of 4 floats and Bmat must
-// be zero in columns [N, ldb) (host guarantees both, else the per-layer GEMM path is used).
+// Work split: 256 threads = 4 waves; the waves split the OUTPUT COLUMNS (wave w owns columns [64w, 64w+64)) and
+// share the activation tile.  Consequences that shape the kernel:
+//   * A operand (activations, shared by all waves): LDS, K-major sAct[k][m], row stride TM+1 -> the MFMA operand
+//     read "lane (i, h) <- A[m0+i][k+h]" and the transposed epilogue store are both bank-conflict free.
+//   * B operand (weights): every wave needs a DIFFERENT 64-column slice, nothing is shared inside the workgroup, so
+//     weights go straight from L2 into registers -- no LDS staging, no per-chunk barrier.  The MFMA column slot
+//     (tn, i) is mapped to physical column 64w + 2i + tn, so one 8-byte load per lane fetches both B operands of a
+//     k-row and the epilogue writes 8-byte pairs (full 256-B segments per row).  One 32-deep chunk of B (16 float2
+//     per lane) is consumed while the next is in flight (two named register sets, no rotation moves), including
+//     across layer boundaries.
+//   * barriers only at layer boundaries (2 per layer); 33.8 / 66.6 KB of LDS -> 2+ workgroups per CU overlap each
+//     other's epilogues and barriers.
+//   * v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain), 2 x (TM/32) tiles per wave.
+//   * steps with N <= 32 (the Q head, N = A*R) would idle three waves on the matrix path; they run on the VALU
+//     instead: lane <-> row, each (wave, lane-part) owns a few output columns, same k-ordered fmaf chain.
+// Widths up to 256; Bmat row strides must be multiples of 4 floats and Bmat must be zero in columns [N, ldb) (host
+// guarantees both, else the per-layer GEMM path is used).
 //
-// Roofline: fp32 MFMA; per 64-row tile sum_s 2*64*K_s*N_s flop, weights re-read from L2 (per-XCD resident),
-// algorithmic HBM bytes = inputs + outputs only.
+// Roofline: fp32 MFMA; per row sum_s 2*K_s*N_s flop; weights re-read from L2 (per-XCD resident); algorithmic HBM
+// bytes = inputs + outputs only.
 #pragma once
 #include "morl_device.h"
 #include "morl_hip.h"
 
 namespace morl {
 
-constexpr int CH_TM = 64;           // rows per workgroup
-constexpr int CH_LDM = 65;          // sAct row stride (floats)
 constexpr int CH_MAXW = 256;        // widest layer
-constexpr int CH_BK = 32;           // K chunk
+constexpr int CH_BK = 32;           // K chunk (one register set of B)
 constexpr int CH_THREADS = 256;
 
 struct ChainStep {
@@ -55,79 +59,61 @@ struct ChainArgs {
     int B, W, D, R, row_order;
     const float* src;       // in_mode 1
     int ldsrc, K0;
-    long long* prof;        // optional [gridDim.x][8] cycle counters (development builds of the probe only)
 };
 
-struct ChainStage {
-    float4 v[8];
+struct ChainBSet {
+    float2 v[16];           // B[k0 + 2j + h][64w + 2i .. +1], j = 0..15
 };
 
-// global -> registers: rows k0 + (tid>>6) + 4q, 16 bytes at column 4*(tid&63).  Branch-free on the full-chunk
-// path: threads whose column lies beyond the row stride re-read column 0 (their LDS columns only ever feed output
-// columns >= N, which the epilogue discards); rows beyond K are zero-filled (they meet zero activations, and
-// 0 * garbage must not produce NaN).
-__device__ __forceinline__ void chain_load(ChainStage& s, const ChainStep& st, int k0) {
-    const int tid = (int)threadIdx.x;
-    const int r0 = tid >> 6;
-    int c = (tid & 63) << 2;
-    if (c >= st.ldb) c = 0;
-    const float* base = st.Bmat + (size_t)k0 * st.ldb;           // wave-uniform
-    const int toff = r0 * st.ldb + c;                             // per-thread, step-constant
+// global/L2 -> registers for one 32-deep chunk of this wave's 64 columns.  Rows >= K are zero (they meet zero
+// activations; 0 * garbage must not make NaN); columns >= ldb are zero (they only feed discarded outputs).
+__device__ __forceinline__ void chain_load_b(ChainBSet& s, const ChainStep& st, int k0, int col, int h) {
+    const bool col_ok = col < st.ldb;
+    const unsigned loff = (unsigned)(h * st.ldb + (col_ok ? col : 0));   // per lane, 32-bit
+    const float* rowp = st.Bmat + (size_t)k0 * st.ldb;                   // wave-uniform (scalar) base
     if (k0 + CH_BK <= st.K) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s.v[q] = *reinterpret_cast<const float4*>(base + (size_t)(4 * q) * st.ldb + toff);
+        for (int j = 0; j < 16; ++j) {
+            const float* pj = rowp + (size_t)(2 * j) * st.ldb;           // wave-uniform
+            float2 v = *reinterpret_cast<const float2*>(pj + loff);
+            if (!col_ok) v = make_float2(0.f, 0.f);
+            s.v[j] = v;
+        }
     } else {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int kr = min(k0 + r0 + 4 * q, st.K - 1) - k0 - r0;   // clamp the row, then zero it
-            float4 v = *reinterpret_cast<const float4*>(base + (ptrdiff_t)kr * st.ldb + toff);
-            if (k0 + r0 + 4 * q >= st.K) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            s.v[q] = v;
+        for (int j = 0; j < 16; ++j) {
+            const int kj = k0 + 2 * j;                                   // wave-uniform
+            float2 v = make_float2(0.f, 0.f);
+            if (kj < st.K) {
+                const float* pj = rowp + (size_t)(2 * j) * st.ldb;
+                const bool second_ok = kj + 1 < st.K;                    // row kj+1 exists (lanes with h = 1)
+                v = *reinterpret_cast<const float2*>(pj + (second_ok ? loff : loff - (unsigned)(h * st.ldb)));
+                if (!col_ok || (h == 1 && !second_ok)) v = make_float2(0.f, 0.f);
+            }
+            s.v[j] = v;
         }
     }
 }
 
-__device__ __forceinline__ void chain_store(const ChainStage& s, float* __restrict__ sb) {
-    const int tid = (int)threadIdx.x;
-    float* dst = sb + (tid >> 6) * CH_MAXW + ((tid & 63) << 2);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(dst + q * 4 * CH_MAXW) = s.v[q];
-}
-
-// LDS-DMA variant of the weight stream (global_load_lds_dwordx4): each wave moves 8 whole 1-KiB rows of the chunk
-// straight from L2 into the LDS image -- no staging VGPRs, no ds_write pass.  The LDS destination of one instruction
-// is wave-uniform base + 16*lane, which is exactly one 256-float row.  Only for full chunks of full-width rows.
-__device__ __forceinline__ bool chain_dma_ok(const ChainStep& st, int k0) {
-    return st.ldb == CH_MAXW && k0 + CH_BK <= st.K;
-}
-__device__ __forceinline__ void chain_dma(const ChainStep& st, int k0, float* __restrict__ sb) {
-    const int lane = lane_id(), wave = wave_id();
-    const float* g = st.Bmat + (size_t)(k0 + wave * 8) * CH_MAXW + lane * 4;
-    float* l = sb + wave * 8 * CH_MAXW;
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + q * CH_MAXW),
-                                         (__attribute__((address_space(3))) void*)(l + q * CH_MAXW), 16, 0, 0);
-}
-
-template <bool PROF, bool DMA>
+template <int TM>
 __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
-    __shared__ __attribute__((aligned(16))) float sAct[CH_MAXW * CH_LDM];
-    __shared__ __attribute__((aligned(16))) float sB[2][CH_BK * CH_MAXW];
+    constexpr int LDM = TM + 1;
+    constexpr int MT = TM / 32;                       // 32-row MFMA tiles per wave
+    __shared__ float sAct[CH_MAXW * LDM];
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_id();
     const int h = lane >> 5, i = lane & 31;
-    const int row0 = (int)blockIdx.x * CH_TM;
-    long long t_in = 0, t_mfma = 0, t_stage = 0, t_epi = 0, t0 = 0;
-    if (PROF) t0 = clock64();
+    const int row0 = (int)blockIdx.x * TM;
+    const int colw = wave * 64 + 2 * i;               // first of this lane's two physical output columns
 
-    ChainStage stage;
-    chain_load(stage, p.step[0], 0);   // the weight stream starts before the input tile is assembled
+    ChainBSet bx, by;
+    // the weight stream starts before the input tile is assembled
+    if (p.step[0].N > 32) chain_load_b(bx, p.step[0], 0, colw, h);
 
-    // ---- input tile -> sAct[k][m] ------------------------------------------------------------
+    // ---- input tile -> sAct[k][m], zero-filled up to the next multiple of 64 rows ----------------------------
     {
         const int K0 = (p.in_mode == 0) ? (p.D + p.R) : p.K0;
-        const int K0pad = min(CH_MAXW, (K0 + 31) & ~31);   // whole 32-row chunk defined (narrow steps read all of it)
-        const int m = tid & (CH_TM - 1);
+        const int K0pad = min(CH_MAXW, (K0 + 63) & ~63);
+        const int m = tid % TM;
         const int row = row0 + m;
         int b = row, w = row;
         if (p.in_mode == 0) {
@@ -135,169 +121,156 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
             else if (p.row_order == 1) { w = row / p.B; b = row - w * p.B; }
         }
         const bool row_ok = row < p.rows;
-        for (int k = tid >> 6; k < K0pad; k += CH_THREADS / CH_TM) {
+        for (int k = tid / TM; k < K0pad; k += CH_THREADS / TM) {
             float v = 0.f;
             if (row_ok && k < K0) {
                 if (p.in_mode == 0) v = (k < p.D) ? p.obs[(size_t)b * p.D + k] : p.weights[(size_t)w * p.R + (k - p.D)];
                 else v = p.src[(size_t)row * p.ldsrc + k];
             }
-            sAct[k * CH_LDM + m] = v;
+            sAct[k * LDM + m] = v;
         }
     }
-    chain_store(stage, sB[0]);
     __syncthreads();
-    if (PROF) { const long long t = clock64(); t_in += t - t0; t0 = t; }
 
-    int buf = 0;
     for (int s = 0; s < p.n_steps; ++s) {
         const ChainStep& st = p.step[s];
         const int K = st.K, N = st.N;
-        const int Kpad = (K + 1) & ~1;
-        // Two shapes, ONE inner loop (so the 64 accumulators never move):
-        //   wide   (N > 32):  acc[tm][tn] = A[tm rows][k] . B[k][64*wave + 32*tn + i]        k over the whole chunk
-        //   narrow (N <= 32): the 4 waves x 2 "tn" slots split each 32-deep chunk into 8 slices of 4; acc[tm][tn]
-        //                     holds the partial product of slice 2*wave+tn for output columns 0..31
-        const bool narrow = (N <= 32);
-        const int kk_begin = narrow ? wave * 8 : 0;
-        const int a_off1 = narrow ? 4 * CH_LDM : 0;              // A offset of the tn = 1 operand (floats)
-        const int b_off1 = narrow ? 4 * CH_MAXW : 32;            // B offset of the tn = 1 operand (floats)
-        const int nbase = narrow ? 0 : wave * 64;
-
-        f32x16 acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-        for (int k0 = 0; k0 < Kpad; k0 += CH_BK) {
-            // next chunk of the flat stream: same step, or the first chunk of the next step
-            const bool more_here = (k0 + CH_BK) < Kpad;
-            const bool more = more_here || (s + 1 < p.n_steps);
-            const ChainStep& nst = more_here ? st : p.step[more ? s + 1 : s];
-            const int nk0 = more_here ? k0 + CH_BK : 0;
-            // sB[buf ^ 1] is free: its last readers passed the barrier that ended the previous chunk
-            const bool dma = DMA && more && chain_dma_ok(nst, nk0);
-            if (dma) chain_dma(nst, nk0, sB[buf ^ 1]);
-            else if (more) chain_load(stage, nst, nk0);
-            if (PROF) { const long long t = clock64(); t_stage += t - t0; t0 = t; }
-            const int kc = min(CH_BK, Kpad - k0);
-            // narrow: slice pair [kk_begin, kk_begin+4) and [kk_begin+4, kk_begin+8); rows >= Kpad of both operands
-            // are zero (sAct rows up to the next multiple of 32 are written by every epilogue / the input assembly)
-            const int kk_end = narrow ? min(kc, kk_begin + 4) : kc;
-            const float* pa = sAct + (k0 + h) * CH_LDM + i;
-            const float* pb = &sB[buf][h * CH_MAXW + nbase + i];
-            // Software-pipelined by hand with two named operand sets: the LDS reads of k-pair j+1 are issued before the
-            // four MFMAs of k-pair j, so the ~100-cycle ds_read latency hides under the 256 MFMA cycles (one wave per
-            // SIMD: there is no other wave to hide it).  No register rotation -> no v_mov between MFMAs.
-            const int n_kk = (kk_end - kk_begin + 1) >> 1;
-            const float* qa = pa + kk_begin * CH_LDM;
-            const float* qb = pb + kk_begin * CH_MAXW;
-#define CH_LD(S, J)                                                                                              \
-    S##a00 = qa[(J) * 2 * CH_LDM]; S##a10 = qa[(J) * 2 * CH_LDM + 32];                                           \
-    S##a01 = qa[(J) * 2 * CH_LDM + a_off1]; S##a11 = qa[(J) * 2 * CH_LDM + a_off1 + 32];                         \
-    S##b0 = qb[(J) * 2 * CH_MAXW]; S##b1 = qb[(J) * 2 * CH_MAXW + b_off1];
-#define CH_MM(S)                                   \
-    acc[0][0] = mfma32(S##a00, S##b0, acc[0][0]);  \
-    acc[0][1] = mfma32(S##a01, S##b1, acc[0][1]);  \
-    acc[1][0] = mfma32(S##a10, S##b0, acc[1][0]);  \
-    acc[1][1] = mfma32(S##a11, S##b1, acc[1][1]);
-            if (n_kk > 0) {
-                float xa00, xa10, xa01, xa11, xb0, xb1, ya00, ya10, ya01, ya11, yb0, yb1;
-                CH_LD(x, 0)
-                int j = 0;
-                while (j + 1 < n_kk) {
-                    CH_LD(y, j + 1)
-                    CH_MM(x)
-                    if (j + 2 < n_kk) { CH_LD(x, j + 2) }
-                    CH_MM(y)
-                    j += 2;
-                }
-                if (j < n_kk) { CH_MM(x) }
-            }
-#undef CH_LD
-#undef CH_MM
-            if (PROF) { const long long t = clock64(); t_mfma += t - t0; t0 = t; }
-            if (more && !dma) chain_store(stage, sB[buf ^ 1]);
-            __syncthreads();   // (hipcc drains vmcnt(0) here while an LDS-DMA is in flight)
-            buf ^= 1;
-            if (PROF) { const long long t = clock64(); t_stage += t - t0; t0 = t; }
-        }
-        // every wave is past its last read of sAct and of the consumed chunk buffer sB[buf ^ 1]
-        int n_epi = 2;                                            // 32-column tiles this wave finishes
-        if (narrow) {
-            // 8 partial 64x32 tiles -> (slice pairs summed in registers) -> LDS -> wave 0 sums in wave order
-            float* scr = sB[buf ^ 1];   // the buffer just consumed; sB[buf] may already hold the next step's chunk
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) scr[((wave * 2 + tm) * 16 + r) * 64 + lane] = acc[tm][0][r] + acc[tm][1][r];
-            __syncthreads();
-            n_epi = (wave == 0) ? 1 : 0;
-            if (wave == 0) {
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float v = scr[((0 * 2 + tm) * 16 + r) * 64 + lane];
-                        v += scr[((1 * 2 + tm) * 16 + r) * 64 + lane];
-                        v += scr[((2 * 2 + tm) * 16 + r) * 64 + lane];
-                        v += scr[((3 * 2 + tm) * 16 + r) * 64 + lane];
-                        acc[tm][0][r] = v;
-                    }
-            }
-        }
-        // ---- epilogue: passes with the wave-uniform conditions hoisted out of the element loops -----------
         const bool feed_next = (s + 1 < p.n_steps);
+        const bool next_wide = feed_next && p.step[s + 1].N > 32;
+
+        if (N > 32) {
+            // ======================= matrix-core path =======================================================
+            f32x16 acc[MT][2];
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            if (tn >= n_epi) continue;
-            const int col = nbase + tn * 32 + i;
-            const bool col_ok = col < N;
-            const float bias = (st.bias != nullptr && col_ok) ? st.bias[col] : 0.f;
+            for (int a = 0; a < MT; ++a)
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm) {
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+            // chunks are consumed in pairs (bx then by); K is treated as padded to a multiple of 64 with zero rows
+            const int n_pairs = (K + 63) >> 6;
+            chain_load_b(by, st, CH_BK, colw, h);
+            for (int pr = 0; pr < n_pairs; ++pr) {
+                const int k0 = pr * 64;
+                const float* pa = sAct + (k0 + h) * LDM + i;
+#define CH_COMPUTE(SET, KOFF)                                                              \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                       \
+        const float a0 = pa[((KOFF) + 2 * j) * LDM];                                       \
+        acc[0][0] = mfma32(a0, SET.v[j].x, acc[0][0]);                                     \
+        acc[0][1] = mfma32(a0, SET.v[j].y, acc[0][1]);                                     \
+        if (MT == 2) {                                                                     \
+            const float a1 = pa[((KOFF) + 2 * j) * LDM + 32];                              \
+            acc[MT - 1][0] = mfma32(a1, SET.v[j].x, acc[MT - 1][0]);                       \
+            acc[MT - 1][1] = mfma32(a1, SET.v[j].y, acc[MT - 1][1]);                       \
+        }                                                                                  \
+    }
+                CH_COMPUTE(bx, 0)
+                // bx is free again: fetch the chunk two ahead (this step's, or the next wide step's first chunk)
+                if (pr + 1 < n_pairs) chain_load_b(bx, st, k0 + 64, colw, h);
+                else if (next_wide) chain_load_b(bx, p.step[s + 1], 0, colw, h);
+                CH_COMPUTE(by, CH_BK)
+                if (pr + 1 < n_pairs) chain_load_b(by, st, k0 + 96, colw, h);
+#undef CH_COMPUTE
+            }
+            __syncthreads();     // every wave is past its last read of sAct
+
+            // ---- epilogue (wave-uniform conditions hoisted out of the element loops) ------------------------
+            const bool col_ok = colw < N;
+            const bool col1_ok = colw + 1 < N;
+            float bias0 = 0.f, bias1 = 0.f;
+            if (st.bias != nullptr) {
+                if (col_ok) bias0 = st.bias[colw];
+                if (col1_ok) bias1 = st.bias[colw + 1];
+            }
+#pragma unroll
+            for (int tm = 0; tm < MT; ++tm) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = acc[tm][tn][r] + bias;
-                    if (st.relu) v = fmaxf(v, 0.f);
-                    acc[tm][tn][r] = col_ok ? v : 0.f;
+                    float v0 = acc[tm][0][r] + bias0, v1 = acc[tm][1][r] + bias1;
+                    if (st.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                    acc[tm][0][r] = col_ok ? v0 : 0.f;
+                    acc[tm][1][r] = col1_ok ? v1 : 0.f;
                 }
                 if (st.mask != nullptr) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = row0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const bool ok = col_ok && row < p.rows;
-                        const float mk = ok ? st.mask[(size_t)row * st.ldmask + col] : 0.f;
-                        acc[tm][tn][r] = (mk > 0.f) ? acc[tm][tn][r] : 0.f;
+                        float2 mk = make_float2(0.f, 0.f);
+                        if (col_ok && row < p.rows) {
+                            if (col1_ok) mk = *reinterpret_cast<const float2*>(st.mask + (size_t)row * st.ldmask + colw);
+                            else mk.x = st.mask[(size_t)row * st.ldmask + colw];
+                        }
+                        acc[tm][0][r] = (mk.x > 0.f) ? acc[tm][0][r] : 0.f;
+                        acc[tm][1][r] = (mk.y > 0.f) ? acc[tm][1][r] : 0.f;
                     }
                 }
                 if (feed_next) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        sAct[col * CH_LDM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = acc[tm][tn][r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        sAct[colw * LDM + m] = acc[tm][0][r];
+                        sAct[(colw + 1) * LDM + m] = acc[tm][1][r];
+                    }
                 }
                 if (st.out != nullptr) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = row0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        if (col_ok && row < p.rows) st.out[(size_t)row * st.ldout + col] = acc[tm][tn][r];
+                        if (col_ok && row < p.rows) {
+                            float* o = st.out + (size_t)row * st.ldout + colw;
+                            if (col1_ok) *reinterpret_cast<float2*>(o) = make_float2(acc[tm][0][r], acc[tm][1][r]);
+                            else o[0] = acc[tm][0][r];
+                        }
                     }
                 }
             }
+        } else {
+            // ======================= narrow step on the VALU (Q head) ==========================================
+            // lane <-> (row m, part); (wave, part) owns NOWN consecutive output columns
+            constexpr int PARTS = 64 / TM;                        // 1 (TM = 64) or 2 (TM = 32)
+            constexpr int NOWN = 32 / (4 * PARTS);                // columns per (wave, part): 8 or 4
+            const int m = lane % TM;
+            const int part = wave * PARTS + lane / TM;            // 0 .. 4*PARTS-1
+            const int nb = part * NOWN;                           // first owned column
+            float hacc[NOWN];
+#pragma unroll
+            for (int t = 0; t < NOWN; ++t) hacc[t] = 0.f;
+            if (nb < N) {
+                for (int k = 0; k < K; ++k) {
+                    const float a = sAct[k * LDM + m];
+                    const float* brow = st.Bmat + (size_t)k * st.ldb + nb;
+#pragma unroll
+                    for (int t = 0; t < NOWN; ++t)
+                        if (nb + t < st.ldb) hacc[t] = fmaf(a, brow[t], hacc[t]);
+                }
+            }
+            __syncthreads();     // every wave is past its last read of sAct
+            const int row = row0 + m;
+#pragma unroll
+            for (int t = 0; t < NOWN; ++t) {
+                const int n = nb + t;
+                float v = hacc[t] + ((st.bias != nullptr && n < N) ? st.bias[n] : 0.f);
+                if (st.relu) v = fmaxf(v, 0.f);
+                const bool ok = n < N && row < p.rows;
+                if (st.mask != nullptr) v = (ok && st.mask[(size_t)row * st.ldmask + n] > 0.f) ? v : 0.f;
+                if (!ok) v = 0.f;
+                if (feed_next) sAct[n * LDM + m] = v;             // n < 32: the first 32 rows of the next K range
+                if (st.out != nullptr && ok) st.out[(size_t)row * st.ldout + n] = v;
+            }
+            if (feed_next) {
+                // the next step reads K' = N <= 32 padded to 64 rows: rows [32, 64) must be zero too
+                for (int e = tid; e < 32 * TM; e += CH_THREADS) sAct[(32 + e / TM) * LDM + (e % TM)] = 0.f;
+            }
+            if (next_wide) chain_load_b(bx, p.step[s + 1], 0, colw, h);
         }
         if (feed_next) __syncthreads();    // sAct of the next step complete before anyone multiplies it
-        if (PROF) { const long long t = clock64(); t_epi += t - t0; t0 = t; }
-    }
-    if (PROF && p.prof != nullptr && tid == 0) {
-        long long* o = p.prof + (size_t)blockIdx.x * 8;
-        o[0] = t_in; o[1] = t_mfma; o[2] = t_stage; o[3] = t_epi;
     }
 }
 
-__global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainArgs p) { mlp_chain_body<false, false>(p); }
-__global__ __launch_bounds__(CH_THREADS) void mlp_chain_dma_kernel(ChainArgs p) { mlp_chain_body<false, true>(p); }
+// second launch-bound argument = waves per SIMD: two workgroups per CU must fit (<= 256 VGPR+AGPR per lane)
+__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain64_kernel(ChainArgs p) { mlp_chain_body<64>(p); }
+__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain32_kernel(ChainArgs p) { mlp_chain_body<32>(p); }
 
 // W_l [N][K] (nn.Linear layout) -> Wt_l [K][ldn] with ldn = round_up(N, 4), zero padded: the K-major copy the
 // forward chain streams.  All layers in one launch.

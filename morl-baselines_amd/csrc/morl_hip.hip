@@ -132,7 +132,8 @@ struct morl_ctx {
     int ldn[MORL_MAX_LAYERS];
     bool fused_ok = false;   // architecture fits the fused engine
     bool use_fused = false;  // fused_ok and not disabled by morl_ctx_set_fused
-    bool use_dma = false;    // weight chunks via LDS-DMA (global_load_lds) instead of register staging
+    int fused_tm = 0;        // 0: pick the row tile per launch (>= 2 workgroups per CU when possible), else 64 / 32
+    int num_cus = 256;
 };
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -243,7 +244,14 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         c->offWt[l] = c->wt_count;
         c->wt_count += (int64_t)net->dims[l] * c->ldn[l];
         if (net->dims[l] > CH_MAXW || net->dims[l + 1] > CH_MAXW) c->fused_ok = false;
-        if (l >= 1 && (net->dims[l] & 3)) c->fused_ok = false;   // backward streams W_l rows with 16-byte loads
+        if (l >= 1 && (net->dims[l] & 3)) c->fused_ok = false;   // 8-byte operand / output pairs need even strides
+    }
+    if (net->dims[c->L] > 32 && (net->dims[c->L] & 3)) c->fused_ok = false;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            c->num_cus = prop.multiProcessorCount;
     }
     ALLOC(wt_online, c->wt_count);
     ALLOC(wt_target, c->wt_count);
@@ -338,9 +346,21 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
     return MORL_OK;
 }
 
+// Row tile: 64 rows per workgroup amortises the weight stream best, 32 rows doubles the workgroup count; pick 32
+// whenever 64 would leave fewer than two workgroups per CU (their epilogues / barriers then overlap).
+static int launch_chain(morl_ctx* c, const ChainArgs& a, hipStream_t s) {
+    int tm = c->fused_tm;
+    if (tm == 0) tm = ((a.rows + 63) / 64 >= 2 * c->num_cus) ? 64 : 32;
+    if (tm == 64) hipLaunchKernelGGL(mlp_chain64_kernel, dim3((a.rows + 63) / 64), dim3(CH_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(mlp_chain32_kernel, dim3((a.rows + 31) / 32), dim3(CH_THREADS), 0, s, a);
+    LAUNCH_CHECK("mlp_chain");
+    return MORL_OK;
+}
+
 // forward chain over rows assembled on the fly from (obs, weights); save => hidden activations to ctx->h[]
 static int chain_forward(morl_ctx* c, const float* params, const float* wt, const float* obs, const float* weights,
                          int B, int W, int row_order, int rows, bool save, float* q_out, int ldq_out, hipStream_t s) {
+    int rc_chain;
     ChainArgs a{};
     a.n_steps = c->L;
     a.rows = rows;
@@ -359,9 +379,7 @@ static int chain_forward(morl_ctx* c, const float* params, const float* wt, cons
         if (last) { st.out = q_out; st.ldout = ldq_out; }
         else if (save) { st.out = c->h[l + 1]; st.ldout = c->net.dims[l + 1]; }
     }
-    if (c->use_dma) hipLaunchKernelGGL(mlp_chain_dma_kernel, dim3((rows + CH_TM - 1) / CH_TM), dim3(CH_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(mlp_chain_kernel, dim3((rows + CH_TM - 1) / CH_TM), dim3(CH_THREADS), 0, s, a);
-    LAUNCH_CHECK("mlp_chain(fwd)");
+    if ((rc_chain = launch_chain(c, a, s))) return rc_chain;
     return MORL_OK;
 }
 
@@ -369,6 +387,7 @@ static int chain_forward(morl_ctx* c, const float* params, const float* wt, cons
 static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_t s) {
     const int L = c->L;
     if (L < 2) return MORL_OK;
+    int rc_chain;
     ChainArgs a{};
     a.n_steps = L - 1;
     a.rows = rows;
@@ -385,17 +404,15 @@ static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_
         st.out = c->g[l - 1];
         st.ldout = c->net.dims[l];
     }
-    if (c->use_dma) hipLaunchKernelGGL(mlp_chain_dma_kernel, dim3((rows + CH_TM - 1) / CH_TM), dim3(CH_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(mlp_chain_kernel, dim3((rows + CH_TM - 1) / CH_TM), dim3(CH_THREADS), 0, s, a);
-    LAUNCH_CHECK("mlp_chain(bwd)");
+    if ((rc_chain = launch_chain(c, a, s))) return rc_chain;
     return MORL_OK;
 }
 
 extern "C" int morl_ctx_set_fused(morl_ctx* c, int enable) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     c->use_fused = enable && c->fused_ok;
-    c->use_dma = c->use_fused && enable >= 2;
-    return c->use_fused ? (c->use_dma ? 2 : 1) : 0;
+    c->fused_tm = (enable == 2) ? 64 : (enable == 3) ? 32 : 0;
+    return c->use_fused ? (enable >= 1 && enable <= 3 ? enable : 1) : 0;
 }
 
 static int check_bw(const morl_ctx* c, int B, int W) {

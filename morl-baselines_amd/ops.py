@@ -28,8 +28,8 @@ class QNetContext:
         self.max_batch, self.max_weights = int(max_batch), int(max_weights)
         self.n_params = self.lib.param_count(self.desc)
         self.handle = self.lib.ctx_create(self.desc, self.max_batch, self.max_weights)
-        # engine: 0 per-layer GEMMs, 1 layer-fused (register-staged weights), 2 layer-fused (LDS-DMA weights);
-        # default = the fastest the architecture admits
+        # engine: 0 per-layer GEMMs, 1 layer-fused chain (row tile picked per launch), 2 / 3 row tile forced to 64 / 32;
+        # default = fused whenever the architecture admits it
         self.engine = int(self.lib.lib.morl_ctx_set_fused(self.handle, DEFAULT_ENGINE if fused is None else int(fused)))
         self.fused = self.engine > 0
 

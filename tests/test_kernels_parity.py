@@ -100,7 +100,7 @@ def check_update(res, t, o, online, m, v, c):
     assert float((t["po"].cpu() - flat(online)).abs().max()) <= 0.02 * c.lr
 
 
-@pytest.mark.parametrize("fused", [2, 1, 0], ids=["fused_dma", "fused", "perlayer"])
+@pytest.mark.parametrize("fused", [2, 3, 0], ids=["fused64", "fused32", "perlayer"])
 @pytest.mark.parametrize("c", CASES, ids=lambda c: c.name)
 def test_envelope_update_vs_oracle(be, c, fused):
     lib, dev, is_sim = be
@@ -168,7 +168,7 @@ def test_envelope_reduce_ties_bit_exact(be):
             assert th.equal(tg.cpu(), tg_o.reshape(-1, R))
 
 
-@pytest.mark.parametrize("fused", [2, 1, 0], ids=["fused_dma", "fused", "perlayer"])
+@pytest.mark.parametrize("fused", [2, 3, 0], ids=["fused64", "fused32", "perlayer"])
 @pytest.mark.parametrize("dims", [(6, 5, 3, 2, (16, 16)), (9, 4, 4, 3, (40,)), (130, 3, 5, 3, (200, 72, 136))])
 def test_qnet_forward_row_orders(be, dims, fused):
     lib, dev, _ = be
