@@ -22,8 +22,9 @@
 //   * barriers only at layer boundaries (2 per layer); 33.8 / 66.6 KB of LDS -> 2+ workgroups per CU overlap each
 //     other's epilogues and barriers.
 //   * v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain), 2 x (TM/32) tiles per wave.
-//   * steps with N <= 32 (the Q head, N = A*R) would idle three waves on the matrix path; they run on the VALU
-//     instead: lane <-> row, each (wave, lane-part) owns a few output columns, same k-ordered fmaf chain.
+//   * steps with N <= 32 (the Q head, N = A*R) would idle three waves: there the four waves split the contraction
+//     instead (wave w: k in [64w, 64w+64), weights read N-major so that a lane's 8-byte loads run along k) and the
+//     partial tiles are summed through LDS in wave order (deterministic).
 // Widths up to 256; Bmat row strides must be multiples of 4 floats and Bmat must be zero in columns [N, ldb) (host
 // guarantees both, else the per-layer GEMM path is used).
 //
@@ -41,10 +42,11 @@ constexpr int CH_THREADS = 256;
 
 struct ChainStep {
     const float* Bmat;   // [K][ldb] K-major operand (row k contiguous over n), zero in columns [N, ldb)
+    const float* Bt;     // [N][ldbt] the same matrix N-major (row n contiguous over k); needed when N <= 32
     const float* bias;   // [N] or NULL
     const float* mask;   // [rows][ldmask] or NULL: result kept where mask > 0 (ReLU backward)
     float* out;          // [rows][ldout] or NULL: global copy of this step's output
-    int K, N, ldb, ldmask, ldout;
+    int K, N, ldb, ldbt, ldmask, ldout;
     int relu;
 };
 
@@ -61,37 +63,54 @@ struct ChainArgs {
     int ldsrc, K0;
 };
 
+// One register set of B operands: 16 eight-byte loads per lane.
+//   wide step  (N > 32): v[j] = Bmat[k0 + 2j + h][64w + 2i .. +1]           -> MFMA group j, columns (tn = 0, 1)
+//   narrow step (N <= 32): v[j] = Bt[i][64w + 4j + 2h .. +1]                 -> MFMA groups 2j (.x) and 2j+1 (.y),
+//                          i.e. wave w contracts k in [64w, 64w+64) for output column i (split-K over the waves)
 struct ChainBSet {
-    float2 v[16];           // B[k0 + 2j + h][64w + 2i .. +1], j = 0..15
+    float2 v[16];
 };
 
-// global/L2 -> registers for one 32-deep chunk of this wave's 64 columns.  Rows >= K are zero (they meet zero
-// activations; 0 * garbage must not make NaN); columns >= ldb are zero (they only feed discarded outputs).
-__device__ __forceinline__ void chain_load_b(ChainBSet& s, const ChainStep& st, int k0, int col, int h) {
-    const bool col_ok = col < st.ldb;
-    const unsigned loff = (unsigned)(h * st.ldb + (col_ok ? col : 0));   // per lane, 32-bit
-    const float* rowp = st.Bmat + (size_t)k0 * st.ldb;                   // wave-uniform (scalar) base
-    if (k0 + CH_BK <= st.K) {
+// Both shapes are one strided gather  v[j] = *(float2*)(base + lane_off + j*stride)  so that a prefetch is always the
+// same 16 unconditional loads whatever it fetches (the s_waitcnt counts stay static: a load hidden in a branch would
+// force vmcnt(0) at every use).  Invalid elements (row >= K, column >= N) read a clamped valid address and are zeroed.
+struct ChainBDesc {
+    const float* base;      // wave-uniform
+    unsigned lane_off;      // floats
+    int stride;             // floats per j (wave-uniform)
+    int kfirst, kstep;      // contraction index of element .x of v[j] for this lane: kfirst + j*kstep
+    int K;
+    bool lane_ok;           // this lane's column exists
+    bool pair_in_k;         // .y is the next k (narrow) instead of the next column (wide)
+};
+
+__device__ __forceinline__ ChainBDesc chain_desc(const ChainStep& st, int k0, int wave, int i, int h) {
+    ChainBDesc d;
+    const bool narrow = st.N <= 32;
+    const int colw = wave * 64 + 2 * i;
+    // (a chunk that starts beyond K -- K padding or a dummy prefetch -- is all zeros: keep its base inside the matrix)
+    d.base = narrow ? st.Bt : st.Bmat + (size_t)(k0 < st.K ? k0 : 0) * st.ldb;
+    d.lane_ok = narrow ? (i < st.N) : (colw < st.ldb);
+    d.lane_off = d.lane_ok ? (narrow ? (unsigned)(i * st.ldbt + wave * 64 + 2 * h) : (unsigned)(h * st.ldb + colw)) : 0u;
+    d.stride = narrow ? 4 : 2 * st.ldb;
+    d.kfirst = narrow ? wave * 64 + 2 * h : k0 + h;
+    d.kstep = narrow ? 4 : 2;
+    d.K = st.K;
+    d.pair_in_k = narrow;
+    return d;
+}
+
+__device__ __forceinline__ void chain_load_b(ChainBSet& s, const ChainBDesc& d) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float* pj = rowp + (size_t)(2 * j) * st.ldb;           // wave-uniform
-            float2 v = *reinterpret_cast<const float2*>(pj + loff);
-            if (!col_ok) v = make_float2(0.f, 0.f);
-            s.v[j] = v;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int kj = k0 + 2 * j;                                   // wave-uniform
-            float2 v = make_float2(0.f, 0.f);
-            if (kj < st.K) {
-                const float* pj = rowp + (size_t)(2 * j) * st.ldb;
-                const bool second_ok = kj + 1 < st.K;                    // row kj+1 exists (lanes with h = 1)
-                v = *reinterpret_cast<const float2*>(pj + (second_ok ? loff : loff - (unsigned)(h * st.ldb)));
-                if (!col_ok || (h == 1 && !second_ok)) v = make_float2(0.f, 0.f);
-            }
-            s.v[j] = v;
-        }
+    for (int j = 0; j < 16; ++j) {
+        const int k = d.kfirst + j * d.kstep;
+        const bool ok = d.lane_ok && k < d.K;
+        // clamp: an invalid element re-reads element 0 of the matrix (always mapped)
+        const float* src = d.base + (ok ? d.lane_off + (unsigned)(j * d.stride) : 0u);
+        float2 v = *reinterpret_cast<const float2*>(src);
+        if (!ok) v = make_float2(0.f, 0.f);
+        if (d.pair_in_k && k + 1 >= d.K) v.y = 0.f;
+        s.v[j] = v;
     }
 }
 
@@ -103,11 +122,11 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_id();
     const int h = lane >> 5, i = lane & 31;
     const int row0 = (int)blockIdx.x * TM;
-    const int colw = wave * 64 + 2 * i;               // first of this lane's two physical output columns
+    const int colw = wave * 64 + 2 * i;               // first of this lane's two physical output columns (wide steps)
 
     ChainBSet bx, by;
     // the weight stream starts before the input tile is assembled
-    if (p.step[0].N > 32) chain_load_b(bx, p.step[0], 0, colw, h);
+    chain_load_b(bx, chain_desc(p.step[0], 0, wave, i, h));
 
     // ---- input tile -> sAct[k][m], zero-filled up to the next multiple of 64 rows ----------------------------
     {
@@ -136,7 +155,7 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
         const ChainStep& st = p.step[s];
         const int K = st.K, N = st.N;
         const bool feed_next = (s + 1 < p.n_steps);
-        const bool next_wide = feed_next && p.step[s + 1].N > 32;
+        const ChainStep& nxt = p.step[feed_next ? s + 1 : s];    // what the stream fetches after this step (or a dummy)
 
         if (N > 32) {
             // ======================= matrix-core path =======================================================
@@ -150,9 +169,10 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
 
             // chunks are consumed in pairs (bx then by); K is treated as padded to a multiple of 64 with zero rows
             const int n_pairs = (K + 63) >> 6;
-            chain_load_b(by, st, CH_BK, colw, h);
+            chain_load_b(by, chain_desc(st, CH_BK, wave, i, h));
             for (int pr = 0; pr < n_pairs; ++pr) {
                 const int k0 = pr * 64;
+                const bool more = pr + 1 < n_pairs;
                 const float* pa = sAct + (k0 + h) * LDM + i;
 #define CH_COMPUTE(SET, KOFF)                                                              \
     _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                       \
@@ -166,11 +186,11 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
         }                                                                                  \
     }
                 CH_COMPUTE(bx, 0)
-                // bx is free again: fetch the chunk two ahead (this step's, or the next wide step's first chunk)
-                if (pr + 1 < n_pairs) chain_load_b(bx, st, k0 + 64, colw, h);
-                else if (next_wide) chain_load_b(bx, p.step[s + 1], 0, colw, h);
+                // bx is free again: fetch the chunk two ahead -- this step's, else the next step's first set (a wide
+                // chunk 0 or the narrow head's K-slice); never skipped, so the number of loads in flight is static
+                chain_load_b(bx, chain_desc(more ? st : nxt, more ? k0 + 64 : 0, wave, i, h));
                 CH_COMPUTE(by, CH_BK)
-                if (pr + 1 < n_pairs) chain_load_b(by, st, k0 + 96, colw, h);
+                chain_load_b(by, chain_desc(st, more ? k0 + 96 : CH_BK, wave, i, h));   // (dummy re-read on the last pair)
 #undef CH_COMPUTE
             }
             __syncthreads();     // every wave is past its last read of sAct
@@ -226,43 +246,71 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
                 }
             }
         } else {
-            // ======================= narrow step on the VALU (Q head) ==========================================
-            // lane <-> (row m, part); (wave, part) owns NOWN consecutive output columns
-            constexpr int PARTS = 64 / TM;                        // 1 (TM = 64) or 2 (TM = 32)
-            constexpr int NOWN = 32 / (4 * PARTS);                // columns per (wave, part): 8 or 4
-            const int m = lane % TM;
-            const int part = wave * PARTS + lane / TM;            // 0 .. 4*PARTS-1
-            const int nb = part * NOWN;                           // first owned column
-            float hacc[NOWN];
+            // ======================= narrow step (Q head): split-K over the four waves ========================
+            // bx holds Bt[i][64w + 4j + 2h + {0,1}]: wave w contracts k in [64w, 64w+64) for output column i.
+            f32x16 hacc[MT];
 #pragma unroll
-            for (int t = 0; t < NOWN; ++t) hacc[t] = 0.f;
-            if (nb < N) {
-                for (int k = 0; k < K; ++k) {
-                    const float a = sAct[k * LDM + m];
-                    const float* brow = st.Bmat + (size_t)k * st.ldb + nb;
+            for (int a = 0; a < MT; ++a)
 #pragma unroll
-                    for (int t = 0; t < NOWN; ++t)
-                        if (nb + t < st.ldb) hacc[t] = fmaf(a, brow[t], hacc[t]);
+                for (int r = 0; r < 16; ++r) hacc[a][r] = 0.f;
+            const int ks = wave * 64 + 2 * h;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int k = ks + 4 * j + c;
+                    const float bv = c ? bx.v[j].y : bx.v[j].x;
+#pragma unroll
+                    for (int tm = 0; tm < MT; ++tm) {
+                        const float a = (k < K) ? sAct[k * LDM + tm * 32 + i] : 0.f;   // rows >= K may hold garbage
+                        hacc[tm] = mfma32(a, bv, hacc[tm]);
+                    }
                 }
             }
-            __syncthreads();     // every wave is past its last read of sAct
-            const int row = row0 + m;
+            __syncthreads();     // every wave is past its last read of sAct -> reuse it as the reduction scratch
+            float* scr = sAct;
 #pragma unroll
-            for (int t = 0; t < NOWN; ++t) {
-                const int n = nb + t;
-                float v = hacc[t] + ((st.bias != nullptr && n < N) ? st.bias[n] : 0.f);
-                if (st.relu) v = fmaxf(v, 0.f);
-                const bool ok = n < N && row < p.rows;
-                if (st.mask != nullptr) v = (ok && st.mask[(size_t)row * st.ldmask + n] > 0.f) ? v : 0.f;
-                if (!ok) v = 0.f;
-                if (feed_next) sAct[n * LDM + m] = v;             // n < 32: the first 32 rows of the next K range
-                if (st.out != nullptr && ok) st.out[(size_t)row * st.ldout + n] = v;
-            }
+            for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scr[((wave * MT + tm) * 16 + r) * 64 + lane] = hacc[tm][r];
+            // the stream moves on while the partial tiles are reduced
+            chain_load_b(bx, chain_desc(nxt, 0, wave, i, h));
+            __syncthreads();
+            // thread (rg = wave, lane) sums the four partials of registers 4rg..4rg+3 of every row tile, wave order
+            float red[MT][4];
+#pragma unroll
+            for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = wave * 4 + q;
+                    float v = scr[((0 * MT + tm) * 16 + r) * 64 + lane];
+                    v += scr[((1 * MT + tm) * 16 + r) * 64 + lane];
+                    v += scr[((2 * MT + tm) * 16 + r) * 64 + lane];
+                    v += scr[((3 * MT + tm) * 16 + r) * 64 + lane];
+                    red[tm][q] = v;
+                }
+            if (feed_next) __syncthreads();   // scratch fully consumed before sAct is rewritten
+            const int n = i;
+            const float bias = (st.bias != nullptr && n < N) ? st.bias[n] : 0.f;
+#pragma unroll
+            for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = wave * 4 + q;
+                    const int m = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int row = row0 + m;
+                    const bool ok = n < N && row < p.rows;
+                    float v = red[tm][q] + bias;
+                    if (st.relu) v = fmaxf(v, 0.f);
+                    if (st.mask != nullptr) v = (ok && st.mask[(size_t)row * st.ldmask + n] > 0.f) ? v : 0.f;
+                    if (!ok) v = 0.f;
+                    if (feed_next) sAct[n * LDM + m] = v;
+                    if (st.out != nullptr && ok) st.out[(size_t)row * st.ldout + n] = v;
+                }
             if (feed_next) {
                 // the next step reads K' = N <= 32 padded to 64 rows: rows [32, 64) must be zero too
                 for (int e = tid; e < 32 * TM; e += CH_THREADS) sAct[(32 + e / TM) * LDM + (e % TM)] = 0.f;
             }
-            if (next_wide) chain_load_b(bx, p.step[s + 1], 0, colw, h);
         }
         if (feed_next) __syncthreads();    // sAct of the next step complete before anyone multiplies it
     }

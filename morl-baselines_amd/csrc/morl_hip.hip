@@ -247,14 +247,15 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         if (l >= 1 && (net->dims[l] & 3)) c->fused_ok = false;   // 8-byte operand / output pairs need even strides
     }
     if (net->dims[c->L] > 32 && (net->dims[c->L] & 3)) c->fused_ok = false;
+    if (net->dims[1] <= 32 && (net->dims[0] & 1)) c->fused_ok = false;     // narrow first layer reads W_0 rows in pairs
     {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             c->num_cus = prop.multiProcessorCount;
     }
-    ALLOC(wt_online, c->wt_count);
-    ALLOC(wt_target, c->wt_count);
+    ALLOC(wt_online, c->wt_count + 4);   // (+4: an 8-byte operand load may touch one float past the last row)
+    ALLOC(wt_target, c->wt_count + 4);
     c->use_fused = c->fused_ok;
 #undef ALLOC
     *out = c;
@@ -372,6 +373,8 @@ static int chain_forward(morl_ctx* c, const float* params, const float* wt, cons
         const bool last = (l == c->L - 1);
         st.Bmat = wt + c->offWt[l];
         st.ldb = c->ldn[l];
+        st.Bt = params + c->offW[l];       // nn.Linear layout [out][in] = N-major
+        st.ldbt = c->net.dims[l];
         st.K = c->net.dims[l];
         st.N = c->net.dims[l + 1];
         st.bias = params + c->offB[l];
@@ -397,6 +400,8 @@ static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_
         ChainStep& st = a.step[k];
         st.Bmat = params + c->offW[l];
         st.ldb = c->net.dims[l];
+        st.Bt = c->wt_online + c->offWt[l];   // [in][ldn(out)] = N-major for the backward contraction
+        st.ldbt = c->ldn[l];
         st.K = c->net.dims[l + 1];
         st.N = c->net.dims[l];
         st.mask = c->h[l];

@@ -26,7 +26,7 @@ int main() {
         size_t off = 0;
         for (int l = 0; l < 5; ++l) {
             ChainStep& st = a.step[l];
-            st.Bmat = wt + off; st.ldb = (dims[l + 1] + 3) / 4 * 4; st.K = dims[l]; st.N = dims[l + 1]; st.bias = bias + l * 256; st.relu = l < 4;
+            st.Bmat = wt + off; st.ldb = (dims[l + 1] + 3) / 4 * 4; st.K = dims[l]; st.N = dims[l + 1]; st.bias = bias + l * 256; st.relu = l < 4; st.Bt = wt + off; st.ldbt = dims[l];
             off += (size_t)dims[l] * st.ldb;
             if (l == 4) { st.out = q; st.ldout = 20; }
             else if (save) { st.out = hbuf + (size_t)l * rows * 256; st.ldout = 256; }
