@@ -97,11 +97,12 @@ int64_t morl_param_count(const morl_net_desc* net);
 
 /* ---- replay buffer: common/buffer.py:68-96 (gather part of ReplayBuffer.sample) -------------
  * records: device, row-major [capacity][record_floats] with one transition per row laid out as
- *   obs[D] | next_obs[D] | reward[R] | done[1] | action[1] (action stored as float)
- * idx: device int64 [B].  Outputs are device arrays shaped as the reference returns them. */
+ *   obs[D] | next_obs[D] | reward[R] | done[1] | action[Ad]   (all float; record_floats = 2D+R+1+Ad)
+ * idx: device int64 [B].  Outputs are device arrays shaped as the reference returns them; actions are written as
+ * float [B][Ad] and / or int32 [B][Ad] (either pointer may be NULL, not both). */
 int morl_gather_batch(const float* records, int record_floats, int64_t capacity, const int64_t* idx, int B,
-                      int D, int R, float* obs, float* next_obs, float* rewards, float* dones,
-                      int32_t* actions, void* stream);
+                      int D, int R, int action_dim, float* obs, float* next_obs, float* rewards, float* dones,
+                      float* actions_f, int32_t* actions_i, void* stream);
 
 /* ---- QNet.forward: envelope.py:60-77 ----------------------------------------------------------
  * Evaluates Q(obs_b, w_k) for all B x W pairs.  row_order 0: row = b*W + k ("next-state slab"
@@ -117,6 +118,12 @@ int morl_qnet_forward(morl_ctx* ctx, const float* params, const float* obs, cons
  * diag_only = 1 restricts j to i (DDQN).  pref / ac may be NULL. */
 int morl_envelope_reduce(const float* qo, const float* qt, const float* weights, int B, int W, int A, int R,
                          int diag_only, float* target, int32_t* pref, int32_t* ac, void* stream);
+
+/* Same arg-max for ARBITRARY rows, i.e. exactly Envelope.envelope_target(obs, w, sampled_w) (envelope.py:404-440):
+ * row n has its own scalarisation vector row_weights[n][:] and its own slabs qo[n] / qt[n] ([n_rows][W][A][R],
+ * Q(obs_n, sampled_w_j)).  target [n_rows][R]; pref / ac [n_rows] may be NULL. */
+int morl_envelope_reduce_rows(const float* qo, const float* qt, const float* row_weights, int n_rows, int W, int A,
+                              int R, float* target, int32_t* pref, int32_t* ac, void* stream);
 
 /* ---- one Envelope gradient step: envelope.py:269-334 -------------------------------------------
  * All arrays device.  params_online / grads / exp_avg / exp_avg_sq: flat [P]; params_target: flat [P]
@@ -144,7 +151,8 @@ int morl_pareto_mask(const double* points, int N, int R, int remove_duplicates, 
  *          PrioritizedReplayBuffer.add :126-147)
  * update:  running_max = max(running_max, max(pr)); batch_set(idx, pr) keeping the first occurrence of
  *          duplicated indices and adding in ascending index order (:69-82, :187-195).
- *          pr[k] = (raw[k] + running_max_before) ** alpha when `raw` is given (envelope.py:333). */
+ *          pr[k] = powf(raw[k] + (float)running_max_before, alpha)  (envelope.py:333, numpy float32 arithmetic);
+ *          alpha < 0: pr[k] = raw[k] (the caller already formed the priorities). */
 int morl_sumtree_sample(const double* tree, int n_levels, const double* u01, int B, int64_t* idx, void* stream);
 int morl_sumtree_set(double* tree, int n_levels, const int64_t* ptr, const double* value, int n,
                      double* running_max, void* stream);

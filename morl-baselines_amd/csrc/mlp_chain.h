@@ -61,6 +61,7 @@ struct ChainArgs {
     int B, W, D, R, row_order;
     const float* src;       // in_mode 1
     int ldsrc, K0;
+    const float* zeros;     // >= 2 zero floats in device memory: where the invalid elements of an operand set point
 };
 
 // One register set of B operands: 16 eight-byte loads per lane.
@@ -73,7 +74,7 @@ struct ChainBSet {
 
 // Both shapes are one strided gather  v[j] = *(float2*)(base + lane_off + j*stride)  so that a prefetch is always the
 // same 16 unconditional loads whatever it fetches (the s_waitcnt counts stay static: a load hidden in a branch would
-// force vmcnt(0) at every use).  Invalid elements (row >= K, column >= N) read a clamped valid address and are zeroed.
+// force vmcnt(0) at every use).  Narrow steps need an even K (the pair .x/.y runs along k).
 struct ChainBDesc {
     const float* base;      // wave-uniform
     unsigned lane_off;      // floats
@@ -81,7 +82,6 @@ struct ChainBDesc {
     int kfirst, kstep;      // contraction index of element .x of v[j] for this lane: kfirst + j*kstep
     int K;
     bool lane_ok;           // this lane's column exists
-    bool pair_in_k;         // .y is the next k (narrow) instead of the next column (wide)
 };
 
 __device__ __forceinline__ ChainBDesc chain_desc(const ChainStep& st, int k0, int wave, int i, int h) {
@@ -96,21 +96,19 @@ __device__ __forceinline__ ChainBDesc chain_desc(const ChainStep& st, int k0, in
     d.kfirst = narrow ? wave * 64 + 2 * h : k0 + h;
     d.kstep = narrow ? 4 : 2;
     d.K = st.K;
-    d.pair_in_k = narrow;
     return d;
 }
 
-__device__ __forceinline__ void chain_load_b(ChainBSet& s, const ChainBDesc& d) {
+// Invalid elements (row >= K, column beyond the matrix) are redirected BY ADDRESS to a zero word instead of being
+// zeroed after the load: a select on the loaded value would be a use of it, and the compiler then waits for the data
+// right behind the load -- which would collapse the one-chunk prefetch distance to nothing.
+__device__ __forceinline__ void chain_load_b(ChainBSet& s, const ChainBDesc& d, const float* __restrict__ zeros) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int k = d.kfirst + j * d.kstep;
         const bool ok = d.lane_ok && k < d.K;
-        // clamp: an invalid element re-reads element 0 of the matrix (always mapped)
-        const float* src = d.base + (ok ? d.lane_off + (unsigned)(j * d.stride) : 0u);
-        float2 v = *reinterpret_cast<const float2*>(src);
-        if (!ok) v = make_float2(0.f, 0.f);
-        if (d.pair_in_k && k + 1 >= d.K) v.y = 0.f;
-        s.v[j] = v;
+        const float* src = ok ? d.base + (d.lane_off + (unsigned)(j * d.stride)) : zeros;
+        s.v[j] = *reinterpret_cast<const float2*>(src);
     }
 }
 
@@ -126,12 +124,13 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
 
     ChainBSet bx, by;
     // the weight stream starts before the input tile is assembled
-    chain_load_b(bx, chain_desc(p.step[0], 0, wave, i, h));
+    chain_load_b(bx, chain_desc(p.step[0], 0, wave, i, h), p.zeros);
 
-    // ---- input tile -> sAct[k][m], zero-filled up to the next multiple of 64 rows ----------------------------
+    // ---- input tile -> sAct[k][m]; every other row of the buffer is zeroed once, so that rows beyond a step's K
+    //      (met by zero weights) are always finite ------------------------------------------------------------
     {
         const int K0 = (p.in_mode == 0) ? (p.D + p.R) : p.K0;
-        const int K0pad = min(CH_MAXW, (K0 + 63) & ~63);
+        const int K0pad = CH_MAXW;
         const int m = tid % TM;
         const int row = row0 + m;
         int b = row, w = row;
@@ -169,28 +168,35 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
 
             // chunks are consumed in pairs (bx then by); K is treated as padded to a multiple of 64 with zero rows
             const int n_pairs = (K + 63) >> 6;
-            chain_load_b(by, chain_desc(st, CH_BK, wave, i, h));
+            chain_load_b(by, chain_desc(st, CH_BK, wave, i, h), p.zeros);
             for (int pr = 0; pr < n_pairs; ++pr) {
                 const int k0 = pr * 64;
                 const bool more = pr + 1 < n_pairs;
                 const float* pa = sAct + (k0 + h) * LDM + i;
+// the activation operands of k-pair j+1 are read before the MFMAs of k-pair j are issued (one wave per SIMD may
+// be all there is: nothing else hides the ds_read latency)
 #define CH_COMPUTE(SET, KOFF)                                                              \
-    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                       \
-        const float a0 = pa[((KOFF) + 2 * j) * LDM];                                       \
-        acc[0][0] = mfma32(a0, SET.v[j].x, acc[0][0]);                                     \
-        acc[0][1] = mfma32(a0, SET.v[j].y, acc[0][1]);                                     \
-        if (MT == 2) {                                                                     \
-            const float a1 = pa[((KOFF) + 2 * j) * LDM + 32];                              \
-            acc[MT - 1][0] = mfma32(a1, SET.v[j].x, acc[MT - 1][0]);                       \
-            acc[MT - 1][1] = mfma32(a1, SET.v[j].y, acc[MT - 1][1]);                       \
+    {                                                                                      \
+        float a0 = pa[(KOFF) * LDM], a1 = (MT == 2) ? pa[(KOFF) * LDM + 32] : 0.f;         \
+        _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                   \
+            const int jn = (j < 15) ? j + 1 : j;                                           \
+            const float n0 = pa[((KOFF) + 2 * jn) * LDM];                                  \
+            const float n1 = (MT == 2) ? pa[((KOFF) + 2 * jn) * LDM + 32] : 0.f;           \
+            acc[0][0] = mfma32(a0, SET.v[j].x, acc[0][0]);                                 \
+            acc[0][1] = mfma32(a0, SET.v[j].y, acc[0][1]);                                 \
+            if (MT == 2) {                                                                 \
+                acc[MT - 1][0] = mfma32(a1, SET.v[j].x, acc[MT - 1][0]);                   \
+                acc[MT - 1][1] = mfma32(a1, SET.v[j].y, acc[MT - 1][1]);                   \
+            }                                                                              \
+            a0 = n0; a1 = n1;                                                              \
         }                                                                                  \
     }
                 CH_COMPUTE(bx, 0)
                 // bx is free again: fetch the chunk two ahead -- this step's, else the next step's first set (a wide
                 // chunk 0 or the narrow head's K-slice); never skipped, so the number of loads in flight is static
-                chain_load_b(bx, chain_desc(more ? st : nxt, more ? k0 + 64 : 0, wave, i, h));
+                chain_load_b(bx, chain_desc(more ? st : nxt, more ? k0 + 64 : 0, wave, i, h), p.zeros);
                 CH_COMPUTE(by, CH_BK)
-                chain_load_b(by, chain_desc(st, more ? k0 + 96 : CH_BK, wave, i, h));   // (dummy re-read on the last pair)
+                chain_load_b(by, chain_desc(st, more ? k0 + 96 : CH_BK, wave, i, h), p.zeros);   // (dummy re-read on the last pair)
 #undef CH_COMPUTE
             }
             __syncthreads();     // every wave is past its last read of sAct
@@ -261,10 +267,8 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
                     const int k = ks + 4 * j + c;
                     const float bv = c ? bx.v[j].y : bx.v[j].x;
 #pragma unroll
-                    for (int tm = 0; tm < MT; ++tm) {
-                        const float a = (k < K) ? sAct[k * LDM + tm * 32 + i] : 0.f;   // rows >= K may hold garbage
-                        hacc[tm] = mfma32(a, bv, hacc[tm]);
-                    }
+                    for (int tm = 0; tm < MT; ++tm)   // rows >= K: finite stale values times zero weights
+                        hacc[tm] = mfma32(sAct[k * LDM + tm * 32 + i], bv, hacc[tm]);
                 }
             }
             __syncthreads();     // every wave is past its last read of sAct -> reuse it as the reduction scratch
@@ -274,7 +278,7 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) scr[((wave * MT + tm) * 16 + r) * 64 + lane] = hacc[tm][r];
             // the stream moves on while the partial tiles are reduced
-            chain_load_b(bx, chain_desc(nxt, 0, wave, i, h));
+            chain_load_b(bx, chain_desc(nxt, 0, wave, i, h), p.zeros);
             __syncthreads();
             // thread (rg = wave, lane) sums the four partials of registers 4rg..4rg+3 of every row tile, wave order
             float red[MT][4];

@@ -132,6 +132,7 @@ struct morl_ctx {
     int ldn[MORL_MAX_LAYERS];
     bool fused_ok = false;   // architecture fits the fused engine
     bool use_fused = false;  // fused_ok and not disabled by morl_ctx_set_fused
+    float* zeros = nullptr;  // 16 zero floats: target of the invalid elements of the chain's operand gathers
     int fused_tm = 0;        // 0: pick the row tile per launch (>= 2 workgroups per CU when possible), else 64 / 32
     int num_cus = 256;
 };
@@ -173,6 +174,7 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     }
     if (c->sumsq_part) (void)hipFree(c->sumsq_part);
     if (c->loss_part) (void)hipFree(c->loss_part);
+    if (c->zeros) (void)hipFree(c->zeros);
     if (c->wt_online) (void)hipFree(c->wt_online);
     if (c->wt_target) (void)hipFree(c->wt_target);
     delete c;
@@ -247,12 +249,21 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         if (l >= 1 && (net->dims[l] & 3)) c->fused_ok = false;   // 8-byte operand / output pairs need even strides
     }
     if (net->dims[c->L] > 32 && (net->dims[c->L] & 3)) c->fused_ok = false;
-    if (net->dims[1] <= 32 && (net->dims[0] & 1)) c->fused_ok = false;     // narrow first layer reads W_0 rows in pairs
+    for (int l = 0; l < c->L; ++l) {
+        if (net->dims[l + 1] <= 32 && (net->dims[l] & 1)) c->fused_ok = false;           // forward narrow step: K = dims[l]
+        if (l >= 1 && net->dims[l] <= 32 && (net->dims[l + 1] & 1)) c->fused_ok = false;  // backward narrow step: K = dims[l+1]
+    }
     {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             c->num_cus = prop.multiProcessorCount;
+    }
+    ALLOC(zeros, 16);
+    {
+        hipError_t ez = hipMemsetAsync(c->zeros, 0, 16 * sizeof(float), nullptr);
+        if (ez == hipSuccess) ez = hipStreamSynchronize(nullptr);
+        if (ez != hipSuccess) { morl_ctx_destroy(c); return fail(MORL_ERR_HIP, "zero-fill failed: %s", hipGetErrorString(ez)); }
     }
     ALLOC(wt_online, c->wt_count + 4);   // (+4: an 8-byte operand load may touch one float past the last row)
     ALLOC(wt_target, c->wt_count + 4);
@@ -367,6 +378,7 @@ static int chain_forward(morl_ctx* c, const float* params, const float* wt, cons
     a.rows = rows;
     a.in_mode = 0;
     a.obs = obs; a.weights = weights;
+    a.zeros = c->zeros;
     a.B = B; a.W = W; a.D = c->net.obs_dim; a.R = c->net.reward_dim; a.row_order = row_order;
     for (int l = 0; l < c->L; ++l) {
         ChainStep& st = a.step[l];
@@ -396,6 +408,7 @@ static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_
     a.rows = rows;
     a.in_mode = 1;
     a.src = c->dq; a.ldsrc = c->ldq; a.K0 = c->net.dims[L];
+    a.zeros = c->zeros;
     for (int l = L - 1, k = 0; l >= 1; --l, ++k) {
         ChainStep& st = a.step[k];
         st.Bmat = params + c->offW[l];
@@ -432,15 +445,17 @@ static int check_bw(const morl_ctx* c, int B, int W) {
 // public entry points
 // ------------------------------------------------------------------------------------------------
 extern "C" int morl_gather_batch(const float* records, int record_floats, int64_t capacity, const int64_t* idx, int B,
-                                 int D, int R, float* obs, float* next_obs, float* rewards, float* dones,
-                                 int32_t* actions, void* stream) {
-    if (!records || !idx || !obs || !next_obs || !rewards || !dones || !actions) return fail(MORL_ERR_ARG, "NULL array");
-    if (B < 1 || D < 1 || R < 1 || capacity < 1) return fail(MORL_ERR_ARG, "bad sizes B=%d D=%d R=%d", B, D, R);
-    if (record_floats != 2 * D + R + 2)
-        return fail(MORL_ERR_ARG, "record_floats=%d != 2*D+R+2=%d", record_floats, 2 * D + R + 2);
+                                 int D, int R, int action_dim, float* obs, float* next_obs, float* rewards, float* dones,
+                                 float* actions_f, int32_t* actions_i, void* stream) {
+    if (!records || !idx || !obs || !next_obs || !rewards || !dones || (!actions_f && !actions_i))
+        return fail(MORL_ERR_ARG, "NULL array");
+    if (B < 1 || D < 1 || R < 1 || action_dim < 1 || capacity < 1)
+        return fail(MORL_ERR_ARG, "bad sizes B=%d D=%d R=%d Ad=%d", B, D, R, action_dim);
+    if (record_floats != 2 * D + R + 1 + action_dim)
+        return fail(MORL_ERR_ARG, "record_floats=%d != 2*D+R+1+Ad=%d", record_floats, 2 * D + R + 1 + action_dim);
     const int blocks = std::min(1024, (B + 3) / 4);
     hipLaunchKernelGGL(gather_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, records, record_floats,
-                       (long long)capacity, idx, B, D, R, obs, next_obs, rewards, dones, actions);
+                       (long long)capacity, idx, B, D, R, action_dim, obs, next_obs, rewards, dones, actions_f, actions_i);
     LAUNCH_CHECK("gather_batch");
     return MORL_OK;
 }
@@ -476,6 +491,21 @@ extern "C" int morl_envelope_reduce(const float* qo, const float* qt, const floa
     p.B = B; p.W = W; p.A = A; p.R = R; p.diag_only = diag_only;
     hipLaunchKernelGGL(envelope_td_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
     LAUNCH_CHECK("envelope_td(reduce)");
+    return MORL_OK;
+}
+
+extern "C" int morl_envelope_reduce_rows(const float* qo, const float* qt, const float* row_weights, int n_rows, int W,
+                                         int A, int R, float* target, int32_t* pref, int32_t* ac, void* stream) {
+    if (!qo || !qt || !row_weights || !target) return fail(MORL_ERR_ARG, "NULL array");
+    if (n_rows < 1 || W < 1 || A < 1 || R < 1 || R > MORL_MAX_OBJ) return fail(MORL_ERR_ARG, "bad sizes");
+    if ((long long)W * A * R > ENV_MAX_SLAB || W * R > ENV_MAX_WR)
+        return fail(MORL_ERR_ARG, "W*A*R=%lld exceeds the LDS slab (%d floats)", (long long)W * A * R, ENV_MAX_SLAB);
+    EnvelopeTdArgs p{};
+    p.qo = qo; p.qt = qt; p.row_weights = row_weights;
+    p.target = target; p.pref = pref; p.ac = ac;
+    p.B = n_rows; p.W = W; p.A = A; p.R = R;
+    hipLaunchKernelGGL(envelope_td_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, p);
+    LAUNCH_CHECK("envelope_td(reduce_rows)");
     return MORL_OK;
 }
 

@@ -6,16 +6,17 @@ namespace morl {
 
 // ----------------------------------------------------------------------------------------------
 // Batch gather (ReplayBuffer.sample's five fancy-index gathers, common/buffer.py:82-91).
-// Device storage is one AoS record per transition:  obs[D] | next_obs[D] | reward[R] | done | action
-// (all fp32; record_floats = 2D+R+2) so that add() is ONE contiguous H2D copy and a sampled transition
+// Device storage is one AoS record per transition:  obs[D] | next_obs[D] | reward[R] | done | action[Ad]
+// (all fp32; record_floats = 2D+R+1+Ad) so that add() is ONE contiguous H2D copy and a sampled transition
 // is ONE contiguous read.  One wave per sampled transition, lanes stride the record (coalesced 4-B
 // loads; 272 B per record at D=32, R=3).  HBM-bound: B * record_floats * 4 bytes in, the same out.
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_batch_kernel(const float* __restrict__ records, int record_floats,
                                                            long long capacity, const int64_t* __restrict__ idx, int B,
-                                                           int D, int R, float* __restrict__ obs,
+                                                           int D, int R, int Ad, float* __restrict__ obs,
                                                            float* __restrict__ next_obs, float* __restrict__ rewards,
-                                                           float* __restrict__ dones, int32_t* __restrict__ actions) {
+                                                           float* __restrict__ dones, float* __restrict__ actions_f,
+                                                           int32_t* __restrict__ actions_i) {
     const int waves_per_block = (int)blockDim.x / kWave;
     const int lane = lane_id();
     for (int b = (int)blockIdx.x * waves_per_block + wave_id(); b < B; b += (int)gridDim.x * waves_per_block) {
@@ -29,7 +30,11 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const float* __restri
             else if (e < 2 * D) next_obs[(size_t)b * D + (e - D)] = v;
             else if (e < 2 * D + R) rewards[(size_t)b * R + (e - 2 * D)] = v;
             else if (e == 2 * D + R) dones[b] = v;
-            else actions[b] = (int32_t)v;
+            else {
+                const int a = e - (2 * D + R + 1);
+                if (actions_f) actions_f[(size_t)b * Ad + a] = v;
+                if (actions_i) actions_i[(size_t)b * Ad + a] = (int32_t)v;
+            }
         }
     }
 }
@@ -106,7 +111,8 @@ __global__ __launch_bounds__(256) void sumtree_update_kernel(double* __restrict_
     while (npad < B) npad <<= 1;
     for (int k = tid; k < npad; k += nt) {
         if (k < B) {
-            const float p = powf(__fadd_rn(raw[k], rmax), alpha);
+            // alpha < 0: raw already is the priority (plain PrioritizedReplayBuffer.update_priorities)
+            const float p = (alpha < 0.f) ? raw[k] : powf(__fadd_rn(raw[k], rmax), alpha);
             s_pr[k] = p;
             if (pr_out) pr_out[k] = (double)p;
             lmax = fmaxf(lmax, p);

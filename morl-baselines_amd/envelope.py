@@ -1,0 +1,375 @@
+"""Envelope Q-learning with the update path on MI355X HIP kernels.
+
+Drop-in for the reference ``Envelope`` (``multi_policy/envelope/envelope.py:80-572``): same constructor keyword
+arguments, ``update()``, ``envelope_target()``, ``ddqn_target()``, ``max_action()``, ``act()``, ``eval()``,
+``train()``, ``save()`` / ``load()`` (same checkpoint keys), ``get_config()``.  What differs is where the arithmetic
+runs: ``update()`` gathers the batch, evaluates the de-duplicated B*W next-state rows, takes the envelope arg-max,
+and does loss / backward / clip / Adam entirely in ``libmorl_hip.so`` (one C call per gradient step); nothing is
+synchronised with the host unless logging asks for a scalar.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Union
+
+import numpy as np
+import torch as th
+import torch.optim as optim
+
+from . import ops
+from .api import MOAgent, MOPolicy
+from .native import NativeLib, load_library
+from .qnet import QNet
+from .replay import PrioritizedReplayBuffer, ReplayBuffer
+
+
+def random_weights(dim: int, n: int = 1, dist: str = "dirichlet", seed=None, rng=None) -> np.ndarray:
+    """``common/weights.py:10-35`` (host RNG; W x R floats -- stays on the host)."""
+    if rng is None:
+        rng = np.random.default_rng(seed)
+    if dist == "gaussian":
+        w = rng.standard_normal((n, dim))
+        w = np.abs(w) / np.linalg.norm(w, ord=1, axis=1, keepdims=True)
+    elif dist == "dirichlet":
+        w = rng.dirichlet(np.ones(dim), n)
+    else:
+        raise ValueError(f"Unknown distribution {dist}")
+    return w[0] if n == 1 else w
+
+
+def linearly_decaying_value(initial_value, decay_period, step, warmup_steps, final_value):
+    """``common/utils.py:10-32``."""
+    steps_left = decay_period + warmup_steps - step
+    bonus = (initial_value - final_value) * steps_left / decay_period
+    value = final_value + bonus
+    return np.clip(value, min(initial_value, final_value), max(initial_value, final_value))
+
+
+class Envelope(MOPolicy, MOAgent):
+    """Envelope Q-Learning (Yang et al. 2019) -- HIP update path."""
+
+    def __init__(
+        self,
+        env,
+        learning_rate: float = 3e-4,
+        initial_epsilon: float = 0.01,
+        final_epsilon: float = 0.01,
+        epsilon_decay_steps: int = None,
+        tau: float = 1.0,
+        target_net_update_freq: int = 200,
+        buffer_size: int = int(1e6),
+        net_arch: List = [256, 256, 256, 256],
+        batch_size: int = 256,
+        learning_starts: int = 100,
+        gradient_updates: int = 1,
+        gamma: float = 0.99,
+        max_grad_norm: Optional[float] = 1.0,
+        envelope: bool = True,
+        num_sample_w: int = 4,
+        per: bool = True,
+        per_alpha: float = 0.6,
+        initial_homotopy_lambda: float = 0.0,
+        final_homotopy_lambda: float = 1.0,
+        homotopy_decay_steps: int = None,
+        project_name: str = "MORL-Baselines",
+        experiment_name: str = "Envelope",
+        wandb_entity: Optional[str] = None,
+        log: bool = True,
+        seed: Optional[int] = None,
+        device: Union[th.device, str] = "auto",
+        group: Optional[str] = None,
+        lib: Optional[NativeLib] = None,
+        engine: Optional[int] = None,
+    ):
+        MOAgent.__init__(self, env, device=device, seed=seed)
+        MOPolicy.__init__(self, device=device)
+        self.device = th.device(self.device)
+        self.lib = lib or load_library()
+        self.lib.check_device(th.empty(0, device=self.device))   # loud failure on a CPU device with the gfx950 build
+        self.learning_rate = learning_rate
+        self.initial_epsilon = initial_epsilon
+        self.epsilon = initial_epsilon
+        self.epsilon_decay_steps = epsilon_decay_steps
+        self.final_epsilon = final_epsilon
+        self.tau = tau
+        self.target_net_update_freq = target_net_update_freq
+        self.gamma = gamma
+        self.max_grad_norm = max_grad_norm
+        self.buffer_size = buffer_size
+        self.net_arch = net_arch
+        self.learning_starts = learning_starts
+        self.batch_size = batch_size
+        self.per = per
+        self.per_alpha = per_alpha
+        self.gradient_updates = gradient_updates
+        self.initial_homotopy_lambda = initial_homotopy_lambda
+        self.final_homotopy_lambda = final_homotopy_lambda
+        self.homotopy_decay_steps = homotopy_decay_steps
+        self.envelope = envelope
+        self.num_sample_w = num_sample_w
+        self.homotopy_lambda = self.initial_homotopy_lambda
+        self.experiment_name = experiment_name
+
+        self.q_net = QNet(self.observation_shape, self.action_dim, self.reward_dim, net_arch=net_arch,
+                          device=self.device, lib=self.lib, max_batch=batch_size, max_weights=num_sample_w,
+                          engine=engine)
+        self.target_q_net = QNet(self.observation_shape, self.action_dim, self.reward_dim, net_arch=net_arch,
+                                 device=self.device, lib=self.lib, max_batch=1, max_weights=1, engine=engine)
+        self.target_q_net.load_state_dict(self.q_net.state_dict())
+        for param in self.target_q_net.parameters():
+            param.requires_grad = False
+
+        # torch's Adam object is kept for state_dict()/load_state_dict() compatibility; its state tensors are views of
+        # the flat buffers the HIP kernel updates (torch/optim/adam.py state layout: step, exp_avg, exp_avg_sq)
+        self.q_optim = optim.Adam(self.q_net.parameters(), lr=self.learning_rate)
+        P = self.q_net.ctx.n_params
+        self._grads = th.zeros(P, dtype=th.float32, device=self.device)
+        self._exp_avg = th.zeros(P, dtype=th.float32, device=self.device)
+        self._exp_avg_sq = th.zeros(P, dtype=th.float32, device=self.device)
+        self._adam_step = 0
+        self._bind_optimizer_state()
+
+        if self.per:
+            self.replay_buffer = PrioritizedReplayBuffer(self.observation_shape, 1, rew_dim=self.reward_dim,
+                                                         max_size=buffer_size, action_dtype=np.uint8,
+                                                         device=self.device, lib=self.lib)
+        else:
+            self.replay_buffer = ReplayBuffer(self.observation_shape, 1, rew_dim=self.reward_dim, max_size=buffer_size,
+                                              action_dtype=np.uint8, device=self.device, lib=self.lib)
+        self._out = None            # device scalars / vectors of the last gradient step
+        self._losses: List[th.Tensor] = []
+        self.log = log
+        if log:
+            self.setup_wandb(project_name, experiment_name, wandb_entity, group)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _bind_optimizer_state(self) -> None:
+        """Point every parameter's .grad and Adam state at views of the flat buffers (torch-visible, kernel-owned)."""
+        params = self.q_net.ordered_parameters()
+        slices = []
+        for (wo, wshape, bo, bn) in self.q_net.ctx.layer_slices():
+            slices += [(wo, wshape[0] * wshape[1], wshape), (bo, bn, (bn,))]
+        for prm, (off, n, shape) in zip(params, slices):
+            prm.grad = self._grads[off:off + n].view(shape)
+            self.q_optim.state[prm] = {
+                "step": th.tensor(float(self._adam_step)),
+                "exp_avg": self._exp_avg[off:off + n].view(shape),
+                "exp_avg_sq": self._exp_avg_sq[off:off + n].view(shape),
+            }
+
+    def _sync_optimizer_step(self) -> None:
+        for st in self.q_optim.state.values():
+            st["step"].fill_(float(self._adam_step))
+
+    def get_config(self):
+        return {
+            "env_id": self.env.unwrapped.spec.id,
+            "learning_rate": self.learning_rate,
+            "initial_epsilon": self.initial_epsilon,
+            "epsilon_decay_steps": self.epsilon_decay_steps,
+            "batch_size": self.batch_size,
+            "tau": self.tau,
+            "clip_grand_norm": self.max_grad_norm,
+            "target_net_update_freq": self.target_net_update_freq,
+            "gamma": self.gamma,
+            "use_envelope": self.envelope,
+            "num_sample_w": self.num_sample_w,
+            "net_arch": self.net_arch,
+            "per": self.per,
+            "gradient_updates": self.gradient_updates,
+            "buffer_size": self.buffer_size,
+            "initial_homotopy_lambda": self.initial_homotopy_lambda,
+            "final_homotopy_lambda": self.final_homotopy_lambda,
+            "homotopy_decay_steps": self.homotopy_decay_steps,
+            "learning_starts": self.learning_starts,
+            "seed": self.seed,
+        }
+
+    # -- checkpointing: same keys as envelope.py:230-261 -----------------------------------------------------------
+    def save(self, save_replay_buffer: bool = True, save_dir: str = "weights/", filename: Optional[str] = None):
+        if not os.path.isdir(save_dir):
+            os.makedirs(save_dir)
+        self._sync_optimizer_step()
+        saved_params = {"q_net_state_dict": self.q_net.state_dict(),
+                        "q_net_optimizer_state_dict": self.q_optim.state_dict()}
+        if save_replay_buffer:
+            saved_params["replay_buffer"] = self.replay_buffer
+        filename = self.experiment_name if filename is None else filename
+        th.save(saved_params, save_dir + "/" + filename + ".tar")
+
+    def load(self, path: str, load_replay_buffer: bool = True):
+        params = th.load(path, weights_only=False)
+        self.q_net.load_state_dict(params["q_net_state_dict"])
+        self.target_q_net.load_state_dict(params["q_net_state_dict"])   # envelope.py:257-258
+        self.q_optim.load_state_dict(params["q_net_optimizer_state_dict"])
+        # load_state_dict re-allocates the state tensors: copy them back into the flat buffers and re-bind the views
+        prms = self.q_net.ordered_parameters()
+        step = 0
+        with th.no_grad():
+            for prm in prms:
+                st = self.q_optim.state.get(prm)
+                if st:
+                    step = int(float(st["step"]))
+            loaded = [(self.q_optim.state.get(prm) or {}) for prm in prms]
+        self._adam_step = step
+        off = 0
+        for prm, st in zip(prms, loaded):
+            n = prm.numel()
+            if "exp_avg" in st:
+                self._exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self._exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            off += n
+        self._bind_optimizer_state()
+        if load_replay_buffer and "replay_buffer" in params:
+            self.replay_buffer = params["replay_buffer"]
+
+    # -- the hot path ----------------------------------------------------------------------------------------------
+    def __sample_batch_experiences(self):
+        return self.replay_buffer.sample(self.batch_size, to_tensor=True, device=self.device)
+
+    def update(self):
+        """``envelope.py:267-367``; one C call per gradient step, no host synchronisation."""
+        self._losses = []
+        priority = None
+        self.q_net.ensure_capacity(self.batch_size, self.num_sample_w)
+        for _ in range(self.gradient_updates):
+            b_obs, b_actions, b_rewards, b_next_obs, b_dones, b_inds = self.__sample_batch_experiences()
+            sampled_w = th.as_tensor(
+                random_weights(dim=self.reward_dim, n=self.num_sample_w, dist="gaussian", rng=self.np_random)
+            ).float().reshape(self.num_sample_w, self.reward_dim).to(self.device, non_blocking=True)
+            self._adam_step += 1
+            self._out = ops.envelope_update(
+                self.q_net.ctx, self.q_net.flat, self.target_q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq,
+                b_obs, b_next_obs, b_actions.reshape(-1).to(th.int32), b_rewards, b_dones.reshape(-1), sampled_w,
+                gamma=self.gamma, lr=self.learning_rate, adam_step=self._adam_step, max_grad_norm=self.max_grad_norm,
+                homotopy_lambda=float(self.homotopy_lambda), envelope=self.envelope, outputs=None)
+            self._losses.append(self._out["loss"])
+            if self.per:
+                priority = self._out["priority"]
+                self.replay_buffer.update_priorities_from_td(b_inds, priority, self.per_alpha)
+
+        if self.tau != 1 or self.global_step % self.target_net_update_freq == 0:
+            ops.polyak(self.lib, self.q_net.flat, self.target_q_net.flat, self.tau)
+
+        if self.epsilon_decay_steps is not None:
+            self.epsilon = linearly_decaying_value(self.initial_epsilon, self.epsilon_decay_steps, self.global_step,
+                                                   self.learning_starts, self.final_epsilon)
+        if self.homotopy_decay_steps is not None:
+            self.homotopy_lambda = linearly_decaying_value(self.initial_homotopy_lambda, self.homotopy_decay_steps,
+                                                           self.global_step, self.learning_starts,
+                                                           self.final_homotopy_lambda)
+        if self.log and self.global_step % 100 == 0:
+            import wandb
+            wandb.log({
+                "losses/critic_loss": float(th.stack(self._losses).mean().item()),
+                "losses/grad_norm": float(self._out["grad_norm"].item()),
+                "metrics/epsilon": self.epsilon,
+                "metrics/homotopy_lambda": self.homotopy_lambda,
+                "global_step": self.global_step,
+            })
+            if self.per and priority is not None:
+                wandb.log({"metrics/mean_priority": float(priority.mean().item())})
+
+    def last_loss(self) -> float:
+        """Host value of the most recent critic loss (synchronises)."""
+        return float(self._losses[-1].item())
+
+    # -- targets with the reference's signatures (envelope.py:404-463) -----------------------------------------------
+    @th.no_grad()
+    def envelope_target(self, obs: th.Tensor, w: th.Tensor, sampled_w: th.Tensor) -> th.Tensor:
+        """obs (n, D), w (n, R): one scalarisation vector per row; sampled_w (W, R).  Returns (n, R)."""
+        obs = obs.to(self.device, th.float32).contiguous()
+        w = w.to(self.device, th.float32).contiguous()
+        sampled_w = sampled_w.to(self.device, th.float32).contiguous()
+        n, W = obs.size(0), sampled_w.size(0)
+        self.q_net.ensure_capacity(n, W)
+        ctx = self.q_net.ctx
+        qo = ops.qnet_forward(ctx, self.q_net.flat, obs, sampled_w, row_order=0).view(n, W, self.action_dim, self.reward_dim)
+        qt = ops.qnet_forward(ctx, self.target_q_net.flat, obs, sampled_w, row_order=0).view(n, W, self.action_dim, self.reward_dim)
+        target, _, _ = ops.envelope_reduce_rows(self.lib, qo, qt, w)
+        return target
+
+    @th.no_grad()
+    def ddqn_target(self, obs: th.Tensor, w: th.Tensor) -> th.Tensor:
+        obs = obs.to(self.device, th.float32).contiguous()
+        w = w.to(self.device, th.float32).contiguous()
+        n = obs.size(0)
+        self.q_net.ensure_capacity(n, 1)
+        qo = ops.qnet_forward_rows(self.q_net.ctx, self.q_net.flat, obs, w).view(n, 1, self.action_dim, self.reward_dim)
+        qt = ops.qnet_forward_rows(self.q_net.ctx, self.target_q_net.flat, obs, w).view(n, 1, self.action_dim, self.reward_dim)
+        target, _, _ = ops.envelope_reduce_rows(self.lib, qo, qt, w)
+        return target
+
+    # -- acting ------------------------------------------------------------------------------------------------------
+    def eval(self, obs: np.ndarray, w: np.ndarray) -> int:
+        obs = th.as_tensor(obs).float().to(self.device)
+        w = th.as_tensor(w).float().to(self.device)
+        return self.max_action(obs, w)
+
+    def act(self, obs: th.Tensor, w: th.Tensor) -> int:
+        if self.np_random.random() < self.epsilon:
+            return self.env.action_space.sample()
+        return self.max_action(obs, w)
+
+    @th.no_grad()
+    def max_action(self, obs: th.Tensor, w: th.Tensor) -> int:
+        """``envelope.py:389-402``: one row through the HIP forward, fma-chain scalarisation (the reference's
+        unbatched einsum), first arg-max."""
+        q = self.q_net(obs, w)[0]                      # (A, R)
+        w = w.to(self.device, th.float32).reshape(-1)
+        s = q[:, 0] * w[0]
+        for r in range(1, self.reward_dim):
+            s = th.addcmul(s, q[:, r], w[r])           # fused multiply-add on the device
+        return int(th.argmax(s).item())
+
+    # -- training loop (envelope.py:465-572) ---------------------------------------------------------------------------
+    def train(self, total_timesteps: int, eval_env=None, ref_point: Optional[np.ndarray] = None,
+              known_pareto_front: Optional[List[np.ndarray]] = None, weight: Optional[np.ndarray] = None,
+              total_episodes: Optional[int] = None, reset_num_timesteps: bool = True, eval_freq: int = 10000,
+              num_eval_weights_for_front: int = 100, num_eval_episodes_for_front: int = 5,
+              num_eval_weights_for_eval: int = 50, reset_learning_starts: bool = False, verbose: bool = False):
+        if eval_env is not None:
+            assert ref_point is not None, "Reference point must be provided for the hypervolume computation."
+        self.global_step = 0 if reset_num_timesteps else self.global_step
+        self.num_episodes = 0 if reset_num_timesteps else self.num_episodes
+        if reset_learning_starts:
+            self.learning_starts = self.global_step
+        num_episodes = 0
+        eval_weights = None
+        if eval_env is not None and self.log:
+            from morl_baselines.common.evaluation import log_all_multi_policy_metrics  # reference, unchanged
+            from morl_baselines.common.weights import equally_spaced_weights
+            eval_weights = equally_spaced_weights(self.reward_dim, n=num_eval_weights_for_front)
+        obs, _ = self.env.reset()
+        w = weight if weight is not None else random_weights(self.reward_dim, 1, dist="gaussian", rng=self.np_random)
+        tensor_w = th.tensor(w).float().to(self.device)
+        for _ in range(1, total_timesteps + 1):
+            if total_episodes is not None and num_episodes == total_episodes:
+                break
+            if self.global_step < self.learning_starts:
+                action = self.env.action_space.sample()
+            else:
+                action = self.act(th.as_tensor(obs).float().to(self.device), tensor_w)
+            next_obs, vec_reward, terminated, truncated, info = self.env.step(action)
+            self.global_step += 1
+            self.replay_buffer.add(obs, action, vec_reward, next_obs, terminated)
+            if self.global_step >= self.learning_starts:
+                self.update()
+            if eval_weights is not None and self.global_step % eval_freq == 0:
+                current_front = [self.policy_eval(eval_env, weights=ew, num_episodes=num_eval_episodes_for_front,
+                                                  log=self.log)[3] for ew in eval_weights]
+                log_all_multi_policy_metrics(current_front=current_front, hv_ref_point=ref_point,
+                                             reward_dim=self.reward_dim, global_step=self.global_step,
+                                             n_sample_weights=num_eval_weights_for_eval, ref_front=known_pareto_front)
+            if terminated or truncated:
+                obs, _ = self.env.reset()
+                num_episodes += 1
+                self.num_episodes += 1
+                if weight is None:
+                    w = random_weights(self.reward_dim, 1, dist="gaussian", rng=self.np_random)
+                    tensor_w = th.tensor(w).float().to(self.device)
+            else:
+                obs = next_obs
+
+
+EnvelopeHIP = Envelope

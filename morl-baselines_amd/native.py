@@ -44,12 +44,14 @@ _SIGNATURES = {
     "morl_ctx_destroy": (C.c_int, [C.c_void_p]),
     "morl_param_count": (C.c_int64, [C.POINTER(NetDesc)]),
     "morl_ctx_set_fused": (C.c_int, [C.c_void_p, C.c_int]),
-    "morl_gather_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int] +
-                          [C.c_void_p] * 5 + [C.c_void_p]),
+    "morl_gather_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] +
+                          [C.c_void_p] * 6 + [C.c_void_p]),
     "morl_qnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p]),
     "morl_envelope_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "morl_envelope_reduce_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "morl_envelope_update": (C.c_int, [C.c_void_p] * 12 + [C.c_int, C.c_int, C.POINTER(UpdateCfg),
                                                            C.POINTER(UpdateOut), C.c_void_p]),
     "morl_polyak": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
@@ -142,6 +144,13 @@ def make_net_desc(obs_dim: int, reward_dim: int, n_actions: int, net_arch: Seque
 
 
 _default: Optional[NativeLib] = None
+
+
+def use_library(lib: Optional[NativeLib]) -> None:
+    """Make ``lib`` what ``load_library()`` returns (None: back to the in-tree gfx950 build).  Test hook: objects that
+    re-create themselves without an explicit library handle (e.g. an unpickled replay buffer) call ``load_library()``."""
+    global _default
+    _default = lib
 
 
 def load_library(path: Optional[str] = None) -> NativeLib:

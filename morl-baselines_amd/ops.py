@@ -55,8 +55,13 @@ class QNetContext:
             pass
 
 
-def gather_batch(lib: NativeLib, records: th.Tensor, idx: th.Tensor, D: int, R: int):
-    """ReplayBuffer.sample gather (common/buffer.py:82-91) from the device record store."""
+def gather_batch(lib: NativeLib, records: th.Tensor, idx: th.Tensor, D: int, R: int, action_dim: int = 1,
+                 int_actions: bool = True):
+    """ReplayBuffer.sample gather (common/buffer.py:82-91) from the device record store.
+
+    Returns (obs (B,D), actions, rewards (B,R), next_obs (B,D), dones (B,1)); actions are int32 (B,) for discrete
+    action spaces (action_dim 1, int_actions) and float32 (B, action_dim) otherwise.
+    """
     _chk(records, th.float32, "records")
     _chk(idx, th.int64, "idx")
     lib.check_device(records, idx)
@@ -66,9 +71,14 @@ def gather_batch(lib: NativeLib, records: th.Tensor, idx: th.Tensor, D: int, R: 
     nobs = th.empty((B, D), dtype=th.float32, device=dev)
     rew = th.empty((B, R), dtype=th.float32, device=dev)
     done = th.empty((B, 1), dtype=th.float32, device=dev)
-    act = th.empty((B,), dtype=th.int32, device=dev)
+    if int_actions:
+        act = th.empty((B,) if action_dim == 1 else (B, action_dim), dtype=th.int32, device=dev)
+        af, ai = None, act
+    else:
+        act = th.empty((B, action_dim), dtype=th.float32, device=dev)
+        af, ai = act, None
     lib.check(lib.lib.morl_gather_batch(_ptr(records), records.shape[1], records.shape[0], _ptr(idx), B, D, R,
-                                        _ptr(obs), _ptr(nobs), _ptr(rew), _ptr(done), _ptr(act),
+                                        action_dim, _ptr(obs), _ptr(nobs), _ptr(rew), _ptr(done), _ptr(af), _ptr(ai),
                                         lib.stream_of(records)))
     return obs, act, rew, nobs, done
 
@@ -83,6 +93,33 @@ def qnet_forward(ctx: QNetContext, params: th.Tensor, obs: th.Tensor, weights: t
     lib.check(lib.lib.morl_qnet_forward(ctx.handle, _ptr(params), _ptr(obs), _ptr(weights), B, W, row_order, _ptr(q),
                                         lib.stream_of(obs)))
     return q
+
+
+def qnet_forward_rows(ctx: QNetContext, params: th.Tensor, obs: th.Tensor, w: th.Tensor) -> th.Tensor:
+    """Row-paired Q(obs_r, w_r) -> (rows, A, R): ``QNet.forward(obs, w)`` (envelope.py:60-77)."""
+    lib = ctx.lib
+    _chk(params, th.float32, "params"); _chk(obs, th.float32, "obs"); _chk(w, th.float32, "w")
+    lib.check_device(params, obs, w)
+    n = obs.shape[0]
+    if w.shape[0] != n:
+        raise ValueError("obs and w must have the same number of rows")
+    q = th.empty((n, ctx.n_actions, ctx.reward_dim), dtype=th.float32, device=obs.device)
+    lib.check(lib.lib.morl_qnet_forward(ctx.handle, _ptr(params), _ptr(obs), _ptr(w), n, 1, 2, _ptr(q),
+                                        lib.stream_of(obs)))
+    return q
+
+
+def envelope_reduce_rows(lib: NativeLib, qo: th.Tensor, qt: th.Tensor, row_w: th.Tensor):
+    """Envelope.envelope_target's arg-max for arbitrary rows: qo/qt (n, W, A, R), row_w (n, R)."""
+    _chk(qo, th.float32, "qo"); _chk(qt, th.float32, "qt"); _chk(row_w, th.float32, "row_w")
+    lib.check_device(qo, qt, row_w)
+    n, W, A, R = qo.shape
+    target = th.empty((n, R), dtype=th.float32, device=qo.device)
+    pref = th.empty((n,), dtype=th.int32, device=qo.device)
+    ac = th.empty((n,), dtype=th.int32, device=qo.device)
+    lib.check(lib.lib.morl_envelope_reduce_rows(_ptr(qo), _ptr(qt), _ptr(row_w), n, W, A, R, _ptr(target), _ptr(pref),
+                                                _ptr(ac), lib.stream_of(qo)))
+    return target, pref, ac
 
 
 def envelope_reduce(lib: NativeLib, qo: th.Tensor, qt: th.Tensor, weights: th.Tensor, diag_only: bool = False):

@@ -10,7 +10,8 @@ using namespace morl;
 int main() {
     const int B = 256, W = 64, D = 32, R = 3, rows = B * W;
     const int dims[6] = {35, 256, 256, 256, 256, 18};
-    float *obs, *wv, *wt, *bias, *q, *hbuf;
+    float *obs, *wv, *wt, *bias, *q, *hbuf, *zeros;
+    CK(hipMalloc(&zeros, 64)); CK(hipMemset(zeros, 0, 64));
     CK(hipMalloc(&obs, B * D * 4)); CK(hipMalloc(&wv, W * R * 4)); CK(hipMalloc(&wt, 4 * 256 * 256 * 4 + 256 * 20 * 4));
     CK(hipMalloc(&bias, 5 * 256 * 4)); CK(hipMalloc(&q, (size_t)rows * 20 * 4)); CK(hipMalloc(&hbuf, (size_t)4 * rows * 256 * 4));
     std::vector<float> hw(4 * 256 * 256 + 256 * 20);
@@ -22,7 +23,7 @@ int main() {
     CK(hipMemset(wv, 0, W * R * 4)); CK(hipMemset(bias, 0, 5 * 256 * 4));
     for (int save = 0; save < 2; ++save) {
         ChainArgs a{};
-        a.n_steps = 5; a.rows = rows; a.in_mode = 0; a.obs = obs; a.weights = wv; a.B = B; a.W = W; a.D = D; a.R = R; a.row_order = 0;
+        a.n_steps = 5; a.rows = rows; a.in_mode = 0; a.obs = obs; a.weights = wv; a.B = B; a.W = W; a.D = D; a.R = R; a.row_order = 0; a.zeros = zeros;
         size_t off = 0;
         for (int l = 0; l < 5; ++l) {
             ChainStep& st = a.step[l];
