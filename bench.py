@@ -1,0 +1,221 @@
+"""Envelope-Q TD-update benchmark (BASELINE.json metric) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--per 0|1] [--weights 64] [--batch 256]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one ``Envelope.update()`` gradient step (``envelope.py:267-367``) of the HIP agent on the synthetic
+workload of BASELINE.md section 3: obs dim 32, 3 objectives, 6 actions, net [256]*4, batch 256 x 64 sampled weights
+(16 384 TD rows = 49 152 scalar TD errors per step), replay buffer pre-filled with 20 000 seeded transitions, PER on
+(the reference default).  The replay data is resident in HBM before the timed region starts; the per-step host work
+(index / weight sampling on the reference's RNG streams) is inside it.
+Prints ONE JSON line (rank 0).  ``value`` = TD-row updates per second of the whole job.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch as th
+
+D, A, R = 32, 6, 3
+ARCH = [256, 256, 256, 256]
+MACS_ROW = (D + R) * 256 + 3 * 256 * 256 + 256 * A * R           # 210 176 MACs per row-forward
+FWD_FLOP_ROW = 2 * MACS_ROW                                       # 420 352
+BWD_DX_FLOP_ROW = 2 * (A * R * 256 + 3 * 256 * 256)               # dX chain (no dX for layer 0): 402 432
+PEAK_FP32_MFMA_TFLOPS = 157.3                                     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+class _Space:
+    def __init__(self, shape=None, n=None):
+        self.shape = shape
+        if n is not None:
+            self.n = n
+        self._rng = np.random.default_rng(0)
+
+    def sample(self):
+        return int(self._rng.integers(self.n))
+
+
+class SyntheticEnv:
+    """Spaces only (the benchmark never steps an environment)."""
+
+    def __init__(self):
+        self.observation_space = _Space(shape=(D,))
+        self.action_space = _Space(n=A)
+        self.reward_space = _Space(shape=(R,))
+        self.unwrapped = self
+        self.spec = type("S", (), {"id": "synthetic-minecart-like-v0"})()
+
+
+def fill_buffer(buf, n, seed=0):
+    """BASELINE.md section 3 draw order: obs, action, reward, next_obs, done per transition."""
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        obs = rng.standard_normal(D).astype(np.float32)
+        action = rng.integers(A)
+        reward = rng.standard_normal(R).astype(np.float32)
+        next_obs = rng.standard_normal(D).astype(np.float32)
+        done = rng.random() < 0.05
+        buf.add(obs, action, reward, next_obs, done)
+
+
+def cpu_baseline(batch, weights, per, budget_s=25.0):
+    """The oracle (a line-by-line port of the reference's as-written W^2*B-row update) timed on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import envelope_oracle as orc
+
+    th.manual_seed(0)
+    rng = np.random.default_rng(0)
+    online = orc.init_qnet_params(D, A, R, ARCH)
+    target = [p.clone() for p in online]
+    m = [th.zeros_like(p) for p in online]
+    v = [th.zeros_like(p) for p in online]
+    mk = lambda: (th.tensor(rng.standard_normal((batch, D)), dtype=th.float32),
+                  th.tensor(rng.integers(A, size=(batch, 1)), dtype=th.uint8),
+                  th.tensor(rng.standard_normal((batch, R)), dtype=th.float32),
+                  th.tensor(rng.standard_normal((batch, D)), dtype=th.float32),
+                  th.tensor((rng.random((batch, 1)) < 0.05), dtype=th.float32))
+    times, step = [], 0
+    t_start = time.perf_counter()
+    while True:
+        sw = th.tensor(orc.random_weights(R, weights, "gaussian", rng=rng), dtype=th.float32)
+        step += 1
+        t0 = time.perf_counter()
+        orc.envelope_update(online, target, m, v, step, mk(), sw, n_actions=A, reward_dim=R, dedup=False)
+        times.append(time.perf_counter() - t0)
+        if len(times) >= 4 or (time.perf_counter() - t_start) > budget_s:
+            break
+    timed = times[1:] if len(times) > 1 else times      # first call is the warm-up
+    sec = float(np.median(timed))
+    return {"value": batch * weights / sec, "unit": "TD-updates/s", "cores": th.get_num_threads(),
+            "kind": "port", "updates_per_s": 1.0 / sec,
+            "sample": f"{len(timed)} timed Envelope.update() steps (+1 warm-up) of the as-written reference algorithm "
+                      f"(oracle/envelope_oracle.py, B={batch}, W={weights}, W^2*B-row targets) on torch-CPU, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--per", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--weights", type=int, default=64)
+    ap.add_argument("--engine", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus}")
+    if not th.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    th.cuda.set_device(local_rank)
+    dev = th.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from morl_baselines_amd.envelope import Envelope
+
+    th.manual_seed(0)
+    np.random.seed(0)
+    B, W = a.batch, a.weights
+    agent = Envelope(SyntheticEnv(), learning_rate=3e-4, net_arch=ARCH, batch_size=B, gamma=0.99, max_grad_norm=1.0,
+                     tau=1.0, target_net_update_freq=200, envelope=True, num_sample_w=W, per=bool(a.per),
+                     per_alpha=0.6, buffer_size=100_000, gradient_updates=1, log=False, seed=0, device=dev,
+                     engine=a.engine)
+    fill_buffer(agent.replay_buffer, 20_000, seed=0)
+    agent.global_step = 1001
+    if world > 1:
+        from morl_baselines_amd.distributed import shard_envelope_agent
+        shard_envelope_agent(agent, dist)            # weight axis over the ranks: all-gather Q(w), all-reduce grads
+
+    def step():
+        agent.update()
+        agent.global_step += 1
+
+    for _ in range(a.warmup):
+        step()
+    th.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    agent.q_net.ctx.set_timing(True)
+    e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        step()
+    e1.record()
+    th.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    n_chain, chain_ms = agent.q_net.ctx.read_timing()
+    agent.q_net.ctx.set_timing(False)
+    gpu_ms = e0.elapsed_time(e1)
+    if dist is not None:
+        t = th.tensor([wall], device=dev, dtype=th.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    loss = agent.last_loss()
+
+    if rank == 0:
+        rows_step = B * W                             # TD rows per gradient step of the whole job
+        ms_per_step = wall * 1e3 / a.steps
+        # roofline of the dominant kernel (mlp_chain: 3 forward launches + 1 backward launch per step and rank)
+        rows_rank = rows_step // world
+        flop_per_launch = rows_rank * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) / 4.0
+        avg_launch_s = (chain_ms * 1e-3 / n_chain) if n_chain else float("nan")
+        achieved = flop_per_launch / avg_launch_s / 1e12 if n_chain else float("nan")
+        out = {
+            "metric": "Envelope-Q TD updates/sec (batch x weights x obj = 256 x 64 x 3)",
+            "value": rows_step * a.steps / wall,
+            "unit": "TD-updates/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"Envelope.update(): B={B} x W={W} x R={R}, obs {D}, {A} actions, net {ARCH}, "
+                                   f"PER {'on' if a.per else 'off'}, buffer 20k seeded transitions (BASELINE.md s3)",
+                       "global_batch": B, "weights": W, "objectives": R,
+                       "parallelism": "single GPU" if world == 1 else f"weight axis sharded over {world} GPUs "
+                                      "(RCCL all-gather of Q(w), all-reduce of gradients)",
+                       "engine": agent.q_net.ctx.engine},
+            "updates_per_s": a.steps / wall,
+            "scalar_td_per_s": rows_step * R * a.steps / wall,
+            "gpu_ms_per_step_events": gpu_ms / a.steps,
+            "last_loss": loss,
+            "roofline": {"bound": "mfma", "kernel": "mlp_chain (layer-fused Q-net forward / backward-dX)",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "launches_timed": n_chain, "avg_launch_us": avg_launch_s * 1e6,
+                         "algorithmic_flop_per_launch": flop_per_launch,
+                         "whole_step_algorithmic_tflops": rows_step * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW +
+                                                                       FWD_FLOP_ROW) / (ms_per_step * 1e-3) / 1e12},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(B, W, bool(a.per))
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "morl_hip.h"
 #include "morl_device.h"
@@ -133,6 +134,10 @@ struct morl_ctx {
     bool fused_ok = false;   // architecture fits the fused engine
     bool use_fused = false;  // fused_ok and not disabled by morl_ctx_set_fused
     float* zeros = nullptr;  // 16 zero floats: target of the invalid elements of the chain's operand gathers
+    // optional per-launch timing of the dominant kernel (mlp_chain): HIP event pairs on the caller's stream
+    bool timing = false;
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    size_t ev_used = 0;
     int fused_tm = 0;        // 0: pick the row tile per launch (>= 2 workgroups per CU when possible), else 64 / 32
     int num_cus = 256;
 };
@@ -174,6 +179,8 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     }
     if (c->sumsq_part) (void)hipFree(c->sumsq_part);
     if (c->loss_part) (void)hipFree(c->loss_part);
+    for (hipEvent_t e : c->ev_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_stop) (void)hipEventDestroy(e);
     if (c->zeros) (void)hipFree(c->zeros);
     if (c->wt_online) (void)hipFree(c->wt_online);
     if (c->wt_target) (void)hipFree(c->wt_target);
@@ -363,9 +370,22 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
 static int launch_chain(morl_ctx* c, const ChainArgs& a, hipStream_t s) {
     int tm = c->fused_tm;
     if (tm == 0) tm = ((a.rows + 63) / 64 >= 2 * c->num_cus) ? 64 : 32;
+    size_t slot = 0;
+    if (c->timing) {
+        if (c->ev_used == c->ev_start.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            c->ev_start.push_back(e0);
+            c->ev_stop.push_back(e1);
+        }
+        slot = c->ev_used++;
+        HIP_TRY(hipEventRecord(c->ev_start[slot], s));
+    }
     if (tm == 64) hipLaunchKernelGGL(mlp_chain64_kernel, dim3((a.rows + 63) / 64), dim3(CH_THREADS), 0, s, a);
     else hipLaunchKernelGGL(mlp_chain32_kernel, dim3((a.rows + 31) / 32), dim3(CH_THREADS), 0, s, a);
     LAUNCH_CHECK("mlp_chain");
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev_stop[slot], s));
     return MORL_OK;
 }
 
@@ -431,6 +451,29 @@ extern "C" int morl_ctx_set_fused(morl_ctx* c, int enable) {
     c->use_fused = enable && c->fused_ok;
     c->fused_tm = (enable == 2) ? 64 : (enable == 3) ? 32 : 0;
     return c->use_fused ? (enable >= 1 && enable <= 3 ? enable : 1) : 0;
+}
+
+extern "C" int morl_ctx_set_timing(morl_ctx* c, int enable) {
+    if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
+    c->timing = enable != 0;
+    c->ev_used = 0;
+    return MORL_OK;
+}
+
+// Blocks until the recorded launches finished; returns their count and summed duration, then clears the record.
+extern "C" int morl_ctx_read_timing(morl_ctx* c, int* n_launches, double* total_ms) {
+    if (!c || !n_launches || !total_ms) return fail(MORL_ERR_ARG, "NULL argument");
+    double sum = 0.0;
+    for (size_t k = 0; k < c->ev_used; ++k) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(c->ev_stop[k]));
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_start[k], c->ev_stop[k]));
+        sum += ms;
+    }
+    *n_launches = (int)c->ev_used;
+    *total_ms = sum;
+    c->ev_used = 0;
+    return MORL_OK;
 }
 
 static int check_bw(const morl_ctx* c, int B, int W) {

@@ -33,6 +33,15 @@ class QNetContext:
         self.engine = int(self.lib.lib.morl_ctx_set_fused(self.handle, DEFAULT_ENGINE if fused is None else int(fused)))
         self.fused = self.engine > 0
 
+    def set_timing(self, enable: bool) -> None:
+        self.lib.check(self.lib.lib.morl_ctx_set_timing(self.handle, int(enable)))
+
+    def read_timing(self):
+        """(number of timed chain launches, their summed duration in ms); synchronises on them."""
+        n, ms = C.c_int(0), C.c_double(0.0)
+        self.lib.check(self.lib.lib.morl_ctx_read_timing(self.handle, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def layer_slices(self):
         """[(w_offset, (out, in), b_offset, out)] of the flat parameter layout."""
         out, off = [], 0

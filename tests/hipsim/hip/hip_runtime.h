@@ -62,6 +62,12 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+typedef void* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 struct hipDeviceProp_t { int multiProcessorCount; };
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; return hipSuccess; }
