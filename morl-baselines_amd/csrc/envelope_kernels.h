@@ -65,6 +65,7 @@ struct EnvelopeTdArgs {
     double* loss_part;      // [B][2]  sum td^2, sum (wQ - wTQ)^2 over this transition's W rows, or NULL
     float* priority;        // [B] |td . w| of the i = 0 row, or NULL
     int B, W, A, R, ldq;
+    int i_groups;           // the W rows of a transition are split over this many workgroups (grid = B * i_groups)
     int diag_only;
     float gamma;
     float c_mse;            // (1 - lambda) * 2 / (W*B*R)
@@ -83,12 +84,17 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
     __shared__ float s_g[ENV_MAX_WR];     // dLoss/dQ of the taken action
     __shared__ int s_best[ENV_MAX_WR];    // flattened (j*, a*)
     __shared__ double s_red[4][2];
-    const int b = (int)blockIdx.x;
+    const int ig_n = p.i_groups > 0 ? p.i_groups : 1;
+    const int b = (int)blockIdx.x / ig_n, ig = (int)blockIdx.x % ig_n;
     const int lane = lane_id(), wave = wave_id();
     const int W = p.W, A = p.A, R = p.R;
     const int slab = W * A * R;
     const bool generic = p.row_weights != nullptr;
-    const int nI = generic ? 1 : W;          // scalarisation vectors handled by this workgroup
+    const int nI = generic ? 1 : W;          // scalarisation vectors of this transition
+    // this workgroup's share of them: i in [i_lo, i_hi) -- more, smaller workgroups hide the dependent LDS / shuffle
+    // latency chains of the arg-max (the kernel is latency- not bandwidth-bound)
+    const int per_g = (nI + ig_n - 1) / ig_n;
+    const int i_lo = min(nI, ig * per_g), i_hi = min(nI, i_lo + per_g);
     const bool train = p.q_main != nullptr;
     const int act = train ? p.actions[b] : 0;
     for (int e = (int)threadIdx.x; e < slab; e += (int)blockDim.x) {
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
 #pragma unroll
     for (int r = 0; r < MORL_MAX_OBJ; ++r) rew[r] = (train && r < R) ? p.rewards[(size_t)b * R + r] : 0.f;
 
-    for (int i = wave; i < nI; i += 4) {
+    for (int i = i_lo + wave; i < i_hi; i += 4) {
         float wi[MORL_MAX_OBJ];
 #pragma unroll
         for (int r = 0; r < MORL_MAX_OBJ; ++r) wi[r] = (r < R) ? s_w[i * R + r] : 0.f;
@@ -180,26 +186,27 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
 
     // phase 3: bulk outputs.  Output row of (i, b) is i*B + b (generic mode: b).
     const int nB = p.B;
-    for (int e = (int)threadIdx.x; e < nI * R; e += (int)blockDim.x) {
-        const int i = e / R;
+    const int nMine = i_hi - i_lo;
+    for (int e = (int)threadIdx.x; e < nMine * R; e += (int)blockDim.x) {
+        const int i = i_lo + e / R;
         const size_t row = generic ? (size_t)b : (size_t)i * nB + b;
-        if (p.target) p.target[row * R + (e % R)] = s_tgt[e];
+        if (p.target) p.target[row * R + (e % R)] = s_tgt[i * R + (e % R)];
     }
-    for (int i = (int)threadIdx.x; i < nI; i += (int)blockDim.x) {
+    for (int i = i_lo + (int)threadIdx.x; i < i_hi; i += (int)blockDim.x) {
         const size_t row = generic ? (size_t)b : (size_t)i * nB + b;
         if (p.pref) p.pref[row] = s_best[i] / A;
         if (p.ac) p.ac[row] = s_best[i] % A;
     }
     if (train && p.dq) {
-        for (int e = (int)threadIdx.x; e < nI * p.ldq; e += (int)blockDim.x) {
-            const int i = e / p.ldq, c = e % p.ldq;
+        for (int e = (int)threadIdx.x; e < nMine * p.ldq; e += (int)blockDim.x) {
+            const int i = i_lo + e / p.ldq, c = e % p.ldq;
             const int r = c - act * R;
             p.dq[((size_t)i * nB + b) * p.ldq + c] = (r >= 0 && r < R) ? s_g[i * R + r] : 0.f;
         }
     }
     if (p.loss_part && threadIdx.x == 0) {
-        p.loss_part[(size_t)b * 2 + 0] = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
-        p.loss_part[(size_t)b * 2 + 1] = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
+        p.loss_part[(size_t)blockIdx.x * 2 + 0] = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
+        p.loss_part[(size_t)blockIdx.x * 2 + 1] = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
     }
 }
 

@@ -113,13 +113,13 @@ __device__ __forceinline__ void chain_load_b(ChainBSet& s, const ChainBDesc& d, 
 }
 
 template <int TM>
-__device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
+__device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
     constexpr int LDM = TM + 1;
     constexpr int MT = TM / 32;                       // 32-row MFMA tiles per wave
     __shared__ float sAct[CH_MAXW * LDM];
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_id();
     const int h = lane >> 5, i = lane & 31;
-    const int row0 = (int)blockIdx.x * TM;
+    const int row0 = tile * TM;
     const int colw = wave * 64 + 2 * i;               // first of this lane's two physical output columns (wide steps)
 
     ChainBSet bx, by;
@@ -321,8 +321,25 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p) {
 }
 
 // second launch-bound argument = waves per SIMD: two workgroups per CU must fit (<= 256 VGPR+AGPR per lane)
-__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain64_kernel(ChainArgs p) { mlp_chain_body<64>(p); }
-__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain32_kernel(ChainArgs p) { mlp_chain_body<32>(p); }
+__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain64_kernel(ChainArgs p) { mlp_chain_body<64>(p, (int)blockIdx.x); }
+__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain32_kernel(ChainArgs p) { mlp_chain_body<32>(p, (int)blockIdx.x); }
+
+// Several independent chains in ONE launch (the three forward passes of an Envelope step: online / target network on
+// the next-state rows, online network on the TD rows).  With 64-row tiles a single pass gives only one workgroup per
+// CU; launched together the passes put 2 workgroups on every CU, whose barriers / epilogues / prologues overlap, while
+// the weight stream per pass stays what one 64-row tiling costs.
+constexpr int CH_MAX_MULTI = 3;
+struct ChainMulti {
+    ChainArgs p[CH_MAX_MULTI];
+    int tile_start[CH_MAX_MULTI + 1];   // first block of each chain
+    int n;
+};
+__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain64_multi_kernel(ChainMulti m) {
+    const int bid = (int)blockIdx.x;
+    int q = 0;
+    while (q + 1 < m.n && bid >= m.tile_start[q + 1]) ++q;
+    mlp_chain_body<64>(m.p[q], bid - m.tile_start[q]);
+}
 
 // W_l [N][K] (nn.Linear layout) -> Wt_l [K][ldn] with ldn = round_up(N, 4), zero padded: the K-major copy the
 // forward chain streams.  All layers in one launch.

@@ -245,7 +245,7 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     c->g[c->L - 1] = c->dq;
     ALLOC(slabs, (size_t)c->max_splits * c->P);
     ALLOC(sumsq_part, OPT_MAX_BLOCKS);
-    ALLOC(loss_part, (size_t)max_batch * 2);
+    ALLOC(loss_part, (size_t)max_batch * 2 * 4);
     c->fused_ok = true;
     c->wt_count = 0;
     for (int l = 0; l < c->L; ++l) {
@@ -390,9 +390,9 @@ static int launch_chain(morl_ctx* c, const ChainArgs& a, hipStream_t s) {
 }
 
 // forward chain over rows assembled on the fly from (obs, weights); save => hidden activations to ctx->h[]
-static int chain_forward(morl_ctx* c, const float* params, const float* wt, const float* obs, const float* weights,
-                         int B, int W, int row_order, int rows, bool save, float* q_out, int ldq_out, hipStream_t s) {
-    int rc_chain;
+static ChainArgs make_forward_chain(morl_ctx* c, const float* params, const float* wt, const float* obs,
+                                    const float* weights, int B, int W, int row_order, int rows, bool save,
+                                    float* q_out, int ldq_out) {
     ChainArgs a{};
     a.n_steps = c->L;
     a.rows = rows;
@@ -414,7 +414,37 @@ static int chain_forward(morl_ctx* c, const float* params, const float* wt, cons
         if (last) { st.out = q_out; st.ldout = ldq_out; }
         else if (save) { st.out = c->h[l + 1]; st.ldout = c->net.dims[l + 1]; }
     }
-    if ((rc_chain = launch_chain(c, a, s))) return rc_chain;
+    return a;
+}
+
+static int chain_forward(morl_ctx* c, const float* params, const float* wt, const float* obs, const float* weights,
+                         int B, int W, int row_order, int rows, bool save, float* q_out, int ldq_out, hipStream_t s) {
+    return launch_chain(c, make_forward_chain(c, params, wt, obs, weights, B, W, row_order, rows, save, q_out, ldq_out), s);
+}
+
+// the three forward passes of one Envelope step in a single launch of 64-row tiles
+static int chain_forward_x3(morl_ctx* c, const ChainArgs& a0, const ChainArgs& a1, const ChainArgs& a2, hipStream_t s) {
+    ChainMulti m{};
+    m.n = 3;
+    m.p[0] = a0; m.p[1] = a1; m.p[2] = a2;
+    int t = 0;
+    for (int q = 0; q < 3; ++q) { m.tile_start[q] = t; t += (m.p[q].rows + 63) / 64; }
+    m.tile_start[3] = t;
+    size_t slot = 0;
+    if (c->timing) {
+        if (c->ev_used == c->ev_start.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            c->ev_start.push_back(e0);
+            c->ev_stop.push_back(e1);
+        }
+        slot = c->ev_used++;
+        HIP_TRY(hipEventRecord(c->ev_start[slot], s));
+    }
+    hipLaunchKernelGGL(mlp_chain64_multi_kernel, dim3(t), dim3(CH_THREADS), 0, s, m);
+    LAUNCH_CHECK("mlp_chain_multi");
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev_stop[slot], s));
     return MORL_OK;
 }
 
@@ -578,9 +608,18 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         // 2./3. layer-fused passes: activations stay in LDS; rows assembled from (obs, weights) inside the kernel
         if ((rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
         if ((rc = refresh_transposed(c, params_target, c->wt_target, s))) return rc;
-        if ((rc = chain_forward(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR, s))) return rc;
-        if ((rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
-        if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm, c->ldq, s))) return rc;
+        if (c->fused_tm == 0) {
+            // one launch: 3 x rows/64 workgroups -> 2 resident per CU, their barriers / epilogues overlap
+            if ((rc = chain_forward_x3(
+                     c, make_forward_chain(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR),
+                     make_forward_chain(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR),
+                     make_forward_chain(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm, c->ldq), s)))
+                return rc;
+        } else {
+            if ((rc = chain_forward(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR, s))) return rc;
+            if ((rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
+            if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm, c->ldq, s))) return rc;
+        }
     } else {
         if ((rc = build_input(next_obs, weights, c->x0n, B, W, D, R, c->ld0, 0, s))) return rc;
         // 2. no-grad next-state slabs Qo, Qt [B][W][A][R] (B*W distinct rows instead of the reference's W^2*B)
@@ -589,7 +628,8 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         // 3. training forward, activations saved
         if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
     }
-    // 4. envelope arg-max + TD target + dLoss/dQ
+    // 4. envelope arg-max + TD target + dLoss/dQ (W rows of a transition over up to 4 workgroups: latency-bound)
+    const int td_groups = std::max(1, std::min(4, W / 4));
     {
         EnvelopeTdArgs p{};
         p.qo = c->qo; p.qt = c->qt; p.weights = weights; p.q_main = c->qm;
@@ -602,7 +642,8 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         const float lam = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
         p.c_mse = (float)((1.0 - (double)lam) * 2.0 / ((double)rows * R));
         p.c_aux = (float)((double)lam * 2.0 / (double)rows);
-        hipLaunchKernelGGL(envelope_td_kernel, dim3(B), dim3(256), 0, s, p);
+        p.i_groups = td_groups;
+        hipLaunchKernelGGL(envelope_td_kernel, dim3(B * td_groups), dim3(256), 0, s, p);
         LAUNCH_CHECK("envelope_td");
     }
     // 5. backward through the hidden layers: g[l-1] = (g[l] @ W_l) * (h[l] > 0)
@@ -659,7 +700,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     {
         const float lam = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
         hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)c->slabs, splits,
-                           (long long)c->P, grads, (long long)c->P, c->sumsq_part, (const double*)c->loss_part, B,
+                           (long long)c->P, grads, (long long)c->P, c->sumsq_part, (const double*)c->loss_part, B * td_groups,
                            1.0 / ((double)rows * R), 1.0 / (double)rows, lam, out->loss);
         LAUNCH_CHECK("grad_reduce");
     }
@@ -735,7 +776,7 @@ extern "C" int morl_sumtree_update(double* tree, int n_levels, const int64_t* id
     if (!tree || !idx || !raw || !running_max) return fail(MORL_ERR_ARG, "NULL array");
     if (n_levels < 1 || n_levels > 40) return fail(MORL_ERR_ARG, "bad n_levels");
     if (B < 1 || B > ST_MAX_B) return fail(MORL_ERR_ARG, "B=%d outside [1,%d]", B, ST_MAX_B);
-    hipLaunchKernelGGL(sumtree_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tree, n_levels, idx, raw, B,
+    hipLaunchKernelGGL(sumtree_update_kernel, dim3(1), dim3(ST_THREADS), 0, (hipStream_t)stream, tree, n_levels, idx, raw, B,
                        (float)alpha, running_max, pr_out);
     LAUNCH_CHECK("sumtree_update");
     return MORL_OK;

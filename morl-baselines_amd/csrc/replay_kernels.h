@@ -94,7 +94,8 @@ __global__ __launch_bounds__(64) void sumtree_set_kernel(double* __restrict__ tr
 //   unique indices ascending, first occurrence's priority; diff = pr - leaf; per level add diffs of the
 //   children in ascending index order (np.add.at order) -> bit-exact float64 tree.
 constexpr int ST_MAX_B = 1024;
-__global__ __launch_bounds__(256) void sumtree_update_kernel(double* __restrict__ tree, int n_levels,
+constexpr int ST_THREADS = 1024;   // 16 waves: the tree levels are updated concurrently, one wave per level
+__global__ __launch_bounds__(ST_THREADS) void sumtree_update_kernel(double* __restrict__ tree, int n_levels,
                                                              const int64_t* __restrict__ idx,
                                                              const float* __restrict__ raw, int B, float alpha,
                                                              double* __restrict__ running_max,
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void sumtree_update_kernel(double* __restrict_
     __shared__ double s_diff[ST_MAX_B];
     __shared__ long long s_node[ST_MAX_B];
     __shared__ float s_pr[ST_MAX_B];
-    __shared__ float s_max[4];
+    __shared__ float s_max[ST_THREADS / 64];
     const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
     const float rmax = (float)(*running_max);
     float lmax = -INFINITY;
@@ -125,7 +126,8 @@ __global__ __launch_bounds__(256) void sumtree_update_kernel(double* __restrict_
     if (lane_id() == 0) s_max[wave_id()] = lmax;
     __syncthreads();
     if (tid == 0) {
-        const float m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        float m = s_max[0];
+        for (int w = 1; w < nt / 64; ++w) m = fmaxf(m, s_max[w]);
         // python max(self.min_priority, priorities.max()): keeps the old value unless the new one is larger
         if ((double)m > *running_max) *running_max = (double)m;
     }
@@ -160,14 +162,16 @@ __global__ __launch_bounds__(256) void sumtree_update_kernel(double* __restrict_
         s_diff[k] = diff;
     }
     __syncthreads();
-    // per level: the head of each run of equal ancestors adds that run's diffs in order
-    for (int up = 0; up < n_levels; ++up) {
+    // per level: the head of each run of equal ancestors adds that run's diffs in order (the np.add.at order).  Levels
+    // touch disjoint memory, so each wave takes its own levels and they proceed concurrently; the critical path is the
+    // root's single run of B sequential float64 adds.
+    const int lane = lane_id(), wave = wave_id(), n_waves = nt / 64;
+    for (int up = wave; up < n_levels; up += n_waves) {
         const int l = leaf_level - up;
-        for (int k = tid; k < B; k += nt) {
+        for (int k = lane; k < B; k += 64) {
             if (s_node[k] < 0) continue;
             const long long anc = s_node[k] >> up;
-            // previous valid entry
-            int j = k - 1;
+            int j = k - 1;                                   // previous valid (non-duplicate) entry
             while (j >= 0 && s_node[j] < 0) --j;
             const bool head = (j < 0) || ((s_node[j] >> up) != anc);
             if (!head) continue;
@@ -179,7 +183,6 @@ __global__ __launch_bounds__(256) void sumtree_update_kernel(double* __restrict_
             }
             tree[level_off(l) + anc] = acc;
         }
-        // levels are disjoint memory; no barrier needed between them
     }
 }
 

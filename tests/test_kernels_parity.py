@@ -100,7 +100,7 @@ def check_update(res, t, o, online, m, v, c):
     assert float((t["po"].cpu() - flat(online)).abs().max()) <= 0.02 * c.lr
 
 
-@pytest.mark.parametrize("fused", [2, 3, 0], ids=["fused64", "fused32", "perlayer"])
+@pytest.mark.parametrize("fused", [1, 2, 3, 0], ids=["fused_auto", "fused64", "fused32", "perlayer"])
 @pytest.mark.parametrize("c", CASES, ids=lambda c: c.name)
 def test_envelope_update_vs_oracle(be, c, fused):
     lib, dev, is_sim = be
