@@ -178,7 +178,11 @@ def main():
         ms_per_step = wall * 1e3 / a.steps
         # roofline of the dominant kernel (mlp_chain: 3 forward launches + 1 backward launch per step and rank)
         rows_rank = rows_step // world
-        flop_per_launch = rows_rank * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) / 4.0
+        # per step and rank the chain kernel runs the 3 forward passes (one launch of three chains, or three launches)
+        # and the backward-dX pass: algorithmic flop of all its launches / their summed duration
+        chain_flop_step = rows_rank * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW)
+        launches_per_step = n_chain / a.steps if a.steps else 0
+        flop_per_launch = chain_flop_step / launches_per_step if launches_per_step else float("nan")
         avg_launch_s = (chain_ms * 1e-3 / n_chain) if n_chain else float("nan")
         achieved = flop_per_launch / avg_launch_s / 1e12 if n_chain else float("nan")
         out = {

@@ -61,7 +61,7 @@ struct ChainArgs {
     int B, W, D, R, row_order;
     const float* src;       // in_mode 1
     int ldsrc, K0;
-    const float* zeros;     // >= 2 zero floats in device memory: where the invalid elements of an operand set point
+    long long* prof;        // development probe only (tools/probes): [blocks][8] phase cycle counters
 };
 
 // One register set of B operands: 16 eight-byte loads per lane.
@@ -72,48 +72,56 @@ struct ChainBSet {
     float2 v[16];
 };
 
-// Both shapes are one strided gather  v[j] = *(float2*)(base + lane_off + j*stride)  so that a prefetch is always the
-// same 16 unconditional loads whatever it fetches (the s_waitcnt counts stay static: a load hidden in a branch would
-// force vmcnt(0) at every use).  Narrow steps need an even K (the pair .x/.y runs along k).
+// Both shapes are one strided gather  v[j] = *(float2*)(base + lane_off + j*stride)  issued as 16 unconditional
+// buffer_load_dwordx2 through a buffer resource that spans exactly the matrix: an element beyond the last row (K
+// padding, dummy prefetches) is out of range and the hardware returns 0 for it -- no branch, no select on the loaded
+// value (a select would be a *use* and would pull the s_waitcnt right behind the load, collapsing the one-chunk
+// prefetch distance), and the number of loads in flight is static, so the s_waitcnt vmcnt counts are exact.
+// Narrow steps need an even K (the pair .x/.y runs along k).
+constexpr int CH_OOB = 0x40000000;   // byte offset beyond any matrix (forces the out-of-range zero)
+
 struct ChainBDesc {
-    const float* base;      // wave-uniform
-    unsigned lane_off;      // floats
-    int stride;             // floats per j (wave-uniform)
-    int kfirst, kstep;      // contraction index of element .x of v[j] for this lane: kfirst + j*kstep
-    int K;
-    bool lane_ok;           // this lane's column exists
+    __amdgpu_buffer_rsrc_t rsrc;   // wave-uniform: the whole matrix [rows][ld]
+    int lane_off;                  // bytes; CH_OOB when this lane's column does not exist
+    int stride;                    // bytes per j (wave-uniform)
+    int kfirst, kstep, K;          // narrow only: contraction index of .x of v[j] is kfirst + j*kstep, valid while < K
+    bool narrow;
 };
 
 __device__ __forceinline__ ChainBDesc chain_desc(const ChainStep& st, int k0, int wave, int i, int h) {
     ChainBDesc d;
-    const bool narrow = st.N <= 32;
+    d.narrow = st.N <= 32;
     const int colw = wave * 64 + 2 * i;
-    // (a chunk that starts beyond K -- K padding or a dummy prefetch -- is all zeros: keep its base inside the matrix)
-    d.base = narrow ? st.Bt : st.Bmat + (size_t)(k0 < st.K ? k0 : 0) * st.ldb;
-    d.lane_ok = narrow ? (i < st.N) : (colw < st.ldb);
-    d.lane_off = d.lane_ok ? (narrow ? (unsigned)(i * st.ldbt + wave * 64 + 2 * h) : (unsigned)(h * st.ldb + colw)) : 0u;
-    d.stride = narrow ? 4 : 2 * st.ldb;
-    d.kfirst = narrow ? wave * 64 + 2 * h : k0 + h;
-    d.kstep = narrow ? 4 : 2;
+    const float* base = d.narrow ? st.Bt : st.Bmat;
+    const int bytes = (d.narrow ? st.N * st.ldbt : st.K * st.ldb) * 4;
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+    const bool lane_ok = d.narrow ? (i < st.N) : (colw < st.ldb);
+    const int off = d.narrow ? (i * st.ldbt + wave * 64 + 2 * h) : ((k0 + h) * st.ldb + colw);
+    d.lane_off = lane_ok ? off * 4 : CH_OOB;
+    d.stride = (d.narrow ? 4 : 2 * st.ldb) * 4;
+    d.kfirst = wave * 64 + 2 * h;
+    d.kstep = 4;
     d.K = st.K;
     return d;
 }
 
-// Invalid elements (row >= K, column beyond the matrix) are redirected BY ADDRESS to a zero word instead of being
-// zeroed after the load: a select on the loaded value would be a use of it, and the compiler then waits for the data
-// right behind the load -- which would collapse the one-chunk prefetch distance to nothing.
-__device__ __forceinline__ void chain_load_b(ChainBSet& s, const ChainBDesc& d, const float* __restrict__ zeros) {
+__device__ __forceinline__ void chain_load_b(ChainBSet& s, const ChainBDesc& d) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const int k = d.kfirst + j * d.kstep;
-        const bool ok = d.lane_ok && k < d.K;
-        const float* src = ok ? d.base + (d.lane_off + (unsigned)(j * d.stride)) : zeros;
-        s.v[j] = *reinterpret_cast<const float2*>(src);
+        int off = d.lane_off + j * d.stride;
+        // wide: rows >= K lie beyond the resource -> 0 by range check.  narrow: k >= K would run into the next row
+        if (d.narrow && d.kfirst + j * d.kstep >= d.K) off = CH_OOB;
+        s.v[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(d.rsrc, off, 0, 0));
     }
 }
 
-template <int TM>
+#define CH_TICK(slot)                                                   \
+    if (PROF) { const long long t_ = clock64(); tacc[slot] += t_ - t0; t0 = t_; }
+
+template <int TM, bool PROF = false>
 __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+    if (PROF) t0 = clock64();
     constexpr int LDM = TM + 1;
     constexpr int MT = TM / 32;                       // 32-row MFMA tiles per wave
     __shared__ float sAct[CH_MAXW * LDM];
@@ -124,13 +132,14 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
 
     ChainBSet bx, by;
     // the weight stream starts before the input tile is assembled
-    chain_load_b(bx, chain_desc(p.step[0], 0, wave, i, h), p.zeros);
+    chain_load_b(bx, chain_desc(p.step[0], 0, wave, i, h));
 
-    // ---- input tile -> sAct[k][m]; every other row of the buffer is zeroed once, so that rows beyond a step's K
-    //      (met by zero weights) are always finite ------------------------------------------------------------
+    // ---- input tile -> sAct[k][m], zero-padded to the rows the first step multiplies (a wide step: the next
+    //      multiple of 64, and its epilogue then defines all 256 rows; a narrow first step reads the whole buffer), so
+    //      that rows beyond a step's K -- met by zero weights -- are always finite --------------------------------
     {
         const int K0 = (p.in_mode == 0) ? (p.D + p.R) : p.K0;
-        const int K0pad = CH_MAXW;
+        const int K0pad = (p.step[0].N > 32) ? min(CH_MAXW, (K0 + 63) & ~63) : CH_MAXW;
         const int m = tid % TM;
         const int row = row0 + m;
         int b = row, w = row;
@@ -149,6 +158,7 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
         }
     }
     __syncthreads();
+    CH_TICK(0)                                                    // input assembly + first weight set issued
 
     for (int s = 0; s < p.n_steps; ++s) {
         const ChainStep& st = p.step[s];
@@ -168,7 +178,7 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
 
             // chunks are consumed in pairs (bx then by); K is treated as padded to a multiple of 64 with zero rows
             const int n_pairs = (K + 63) >> 6;
-            chain_load_b(by, chain_desc(st, CH_BK, wave, i, h), p.zeros);
+            chain_load_b(by, chain_desc(st, CH_BK, wave, i, h));
             for (int pr = 0; pr < n_pairs; ++pr) {
                 const int k0 = pr * 64;
                 const bool more = pr + 1 < n_pairs;
@@ -194,12 +204,14 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
                 CH_COMPUTE(bx, 0)
                 // bx is free again: fetch the chunk two ahead -- this step's, else the next step's first set (a wide
                 // chunk 0 or the narrow head's K-slice); never skipped, so the number of loads in flight is static
-                chain_load_b(bx, chain_desc(more ? st : nxt, more ? k0 + 64 : 0, wave, i, h), p.zeros);
+                chain_load_b(bx, chain_desc(more ? st : nxt, more ? k0 + 64 : 0, wave, i, h));
                 CH_COMPUTE(by, CH_BK)
-                chain_load_b(by, chain_desc(st, more ? k0 + 96 : CH_BK, wave, i, h), p.zeros);   // (dummy re-read on the last pair)
+                chain_load_b(by, chain_desc(st, more ? k0 + 96 : CH_BK, wave, i, h));   // (dummy re-read on the last pair)
 #undef CH_COMPUTE
             }
+            CH_TICK(1)                                           // MFMA pair loop (incl. operand prefetch issue)
             __syncthreads();     // every wave is past its last read of sAct
+            CH_TICK(2)                                           // barrier wait after the loop
 
             // ---- epilogue (wave-uniform conditions hoisted out of the element loops) ------------------------
             const bool col_ok = colw < N;
@@ -251,6 +263,7 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
                     }
                 }
             }
+            CH_TICK(3)                                           // wide epilogue
         } else {
             // ======================= narrow step (Q head): split-K over the four waves ========================
             // bx holds Bt[i][64w + 4j + 2h + {0,1}]: wave w contracts k in [64w, 64w+64) for output column i.
@@ -278,7 +291,7 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) scr[((wave * MT + tm) * 16 + r) * 64 + lane] = hacc[tm][r];
             // the stream moves on while the partial tiles are reduced
-            chain_load_b(bx, chain_desc(nxt, 0, wave, i, h), p.zeros);
+            chain_load_b(bx, chain_desc(nxt, 0, wave, i, h));
             __syncthreads();
             // thread (rg = wave, lane) sums the four partials of registers 4rg..4rg+3 of every row tile, wave order
             float red[MT][4];
@@ -315,9 +328,13 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
                 // the next step reads K' = N <= 32 padded to 64 rows: rows [32, 64) must be zero too
                 for (int e = tid; e < 32 * TM; e += CH_THREADS) sAct[(32 + e / TM) * LDM + (e % TM)] = 0.f;
             }
+            CH_TICK(4)                                           // narrow head (MFMAs, LDS reduction, epilogue)
         }
         if (feed_next) __syncthreads();    // sAct of the next step complete before anyone multiplies it
+        CH_TICK(5)                                               // barrier before the next step
     }
+    if (PROF && p.prof != nullptr && tid == 0)
+        for (int q = 0; q < 8; ++q) p.prof[(size_t)blockIdx.x * 8 + q] = tacc[q];
 }
 
 // second launch-bound argument = waves per SIMD: two workgroups per CU must fit (<= 256 VGPR+AGPR per lane)

@@ -398,7 +398,6 @@ static ChainArgs make_forward_chain(morl_ctx* c, const float* params, const floa
     a.rows = rows;
     a.in_mode = 0;
     a.obs = obs; a.weights = weights;
-    a.zeros = c->zeros;
     a.B = B; a.W = W; a.D = c->net.obs_dim; a.R = c->net.reward_dim; a.row_order = row_order;
     for (int l = 0; l < c->L; ++l) {
         ChainStep& st = a.step[l];
@@ -458,7 +457,6 @@ static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_
     a.rows = rows;
     a.in_mode = 1;
     a.src = c->dq; a.ldsrc = c->ldq; a.K0 = c->net.dims[L];
-    a.zeros = c->zeros;
     for (int l = L - 1, k = 0; l >= 1; --l, ++k) {
         ChainStep& st = a.step[k];
         st.Bmat = params + c->offW[l];

@@ -175,6 +175,21 @@ static inline void __builtin_amdgcn_global_load_lds(const __attribute__((address
     std::memcpy(base + offset + (size_t)hipsim::cur->lane * size, (const char*)(uintptr_t)src + offset, size);
 }
 
+// buffer resources: raw (stride 0) buffer loads with the hardware's per-dword range check (out of range -> 0)
+struct hipsim_rsrc { const char* base; long long num_records; };
+typedef hipsim_rsrc __amdgpu_buffer_rsrc_t;
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num_records, int) {
+    return hipsim_rsrc{(const char*)p, (long long)num_records};
+}
+typedef unsigned int hipsim_v2u __attribute__((vector_size(8)));
+static inline hipsim_v2u __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    hipsim_v2u v = {0u, 0u};
+    const long long off = (long long)(unsigned)voffset + soffset;
+    for (int d = 0; d < 2; ++d)
+        if (off + 4 * d + 4 <= r.num_records) { unsigned x; std::memcpy(&x, r.base + off + 4 * d, 4); v[d] = x; }
+    return v;
+}
+
 // ---- math that hipcc provides as builtins -------------------------------------------------------
 // Compile the emulated build with -ffp-contract=off so these stay separately rounded.
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }

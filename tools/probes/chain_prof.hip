@@ -5,6 +5,7 @@
 #include <vector>
 #include "mlp_chain.h"
 using namespace morl;
+__global__ __launch_bounds__(CH_THREADS, 2) void chain64_prof_kernel(ChainArgs p) { mlp_chain_body<64, true>(p, (int)blockIdx.x); }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 int main() {
@@ -23,7 +24,7 @@ int main() {
     CK(hipMemset(wv, 0, W * R * 4)); CK(hipMemset(bias, 0, 5 * 256 * 4));
     for (int save = 0; save < 2; ++save) {
         ChainArgs a{};
-        a.n_steps = 5; a.rows = rows; a.in_mode = 0; a.obs = obs; a.weights = wv; a.B = B; a.W = W; a.D = D; a.R = R; a.row_order = 0; a.zeros = zeros;
+        a.n_steps = 5; a.rows = rows; a.in_mode = 0; a.obs = obs; a.weights = wv; a.B = B; a.W = W; a.D = D; a.R = R; a.row_order = 0;
         size_t off = 0;
         for (int l = 0; l < 5; ++l) {
             ChainStep& st = a.step[l];
@@ -33,6 +34,19 @@ int main() {
             else if (save) { st.out = hbuf + (size_t)l * rows * 256; st.ldout = 256; }
         }
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        {
+            long long* prof; CK(hipMalloc(&prof, 256 * 8 * 8)); CK(hipMemset(prof, 0, 256 * 8 * 8));
+            a.prof = prof;
+            hipLaunchKernelGGL(chain64_prof_kernel, dim3(rows / 64), dim3(CH_THREADS), 0, 0, a);
+            CK(hipDeviceSynchronize());
+            std::vector<long long> hp(256 * 8);
+            CK(hipMemcpy(hp.data(), prof, 256 * 8 * 8, hipMemcpyDeviceToHost));
+            double sm[8] = {0};
+            for (int b = 0; b < 256; ++b) for (int k = 0; k < 8; ++k) sm[k] += hp[b * 8 + k] / 256.0;
+            printf("save=%d TM=64 phases (cycles, wave 0 avg): input %.0f | mfma-loop %.0f | barrier-after-loop %.0f | epilogue %.0f | head %.0f | barrier-next %.0f | total %.0f\n",
+                   save, sm[0], sm[1], sm[2], sm[3], sm[4], sm[5], sm[0] + sm[1] + sm[2] + sm[3] + sm[4] + sm[5]);
+            a.prof = nullptr;
+        }
         for (int tm = 64; tm >= 32; tm /= 2) {
             for (int rep = 0; rep < 2; ++rep) {
                 CK(hipEventRecord(e0));
