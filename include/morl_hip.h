@@ -141,6 +141,24 @@ int morl_envelope_update(morl_ctx* ctx, float* params_online, const float* param
                          const int32_t* actions, const float* rewards, const float* dones, const float* weights,
                          int B, int W, const morl_update_cfg* cfg, const morl_update_out* out, void* stream);
 
+/* ---- weight-axis sharding of the same step (no counterpart in the reference, which is single-device) ------------
+ * A rank that owns the TD rows of weights [i_offset, i_offset + W_local) of W_total:
+ *   1. morl_qnet_forward(row_order 0) on its W_local weights for the online and the target network -> local slabs;
+ *      the caller all-gathers them into qo_all / qt_all [B][W_total][A][R];
+ *   2. morl_envelope_update_shard: training forward of its rows, envelope arg-max over ALL W_total candidates, TD,
+ *      backward.  `grads` receives this rank's UNCLIPPED contribution, already normalised by the global row count
+ *      B * W_total, out->loss its share of the loss (out->priority only on the rank with i_offset == 0; target / pref /
+ *      ac / q_values are local [W_local*B] rows);
+ *   3. the caller all-reduces (sums) grads and the loss; morl_clip_adam applies clip_grad_norm_ + Adam identically
+ *      on every rank. */
+int morl_envelope_update_shard(morl_ctx* ctx, const float* params_online, float* grads, const float* obs,
+                               const int32_t* actions, const float* rewards, const float* dones,
+                               const float* weights_all, int B, int W_total, int i_offset, int W_local,
+                               const float* qo_all, const float* qt_all, const morl_update_cfg* cfg,
+                               const morl_update_out* out, void* stream);
+int morl_clip_adam(morl_ctx* ctx, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                   const morl_update_cfg* cfg, float* grad_norm_out, void* stream);
+
 /* ---- polyak_update: common/networks.py:120-139 ------------------------------------------------- */
 int morl_polyak(const float* src, float* dst, float tau, int64_t n, void* stream);
 

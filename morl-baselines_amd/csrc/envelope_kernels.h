@@ -66,6 +66,9 @@ struct EnvelopeTdArgs {
     float* priority;        // [B] |td . w| of the i = 0 row, or NULL
     int B, W, A, R, ldq;
     int i_groups;           // the W rows of a transition are split over this many workgroups (grid = B * i_groups)
+    int WI;                 // number of scalarisation vectors (TD rows per transition) in `weights`; 0 -> W.  A rank of a
+                            // weight-sharded job owns WI = W/G of them while the slabs still hold all W candidates
+    int i_offset;           // global index of weights[0] (only matters for diag_only: candidate j == global i)
     int diag_only;
     float gamma;
     float c_mse;            // (1 - lambda) * 2 / (W*B*R)
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
     const int W = p.W, A = p.A, R = p.R;
     const int slab = W * A * R;
     const bool generic = p.row_weights != nullptr;
-    const int nI = generic ? 1 : W;          // scalarisation vectors of this transition
+    const int nI = generic ? 1 : (p.WI > 0 ? p.WI : W);   // scalarisation vectors (TD rows) of this transition
     // this workgroup's share of them: i in [i_lo, i_hi) -- more, smaller workgroups hide the dependent LDS / shuffle
     // latency chains of the arg-max (the kernel is latency- not bandwidth-bound)
     const int per_g = (nI + ig_n - 1) / ig_n;
@@ -117,8 +120,8 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
         float wi[MORL_MAX_OBJ];
 #pragma unroll
         for (int r = 0; r < MORL_MAX_OBJ; ++r) wi[r] = (r < R) ? s_w[i * R + r] : 0.f;
-        const int c_begin = p.diag_only ? i * A : 0;
-        const int c_end = p.diag_only ? (i + 1) * A : W * A;
+        const int c_begin = p.diag_only ? (i + p.i_offset) * A : 0;
+        const int c_end = p.diag_only ? (i + p.i_offset + 1) * A : W * A;
         float best = -INFINITY;
         int best_c = 0x7fffffff;
         for (int c = c_begin + lane; c < c_end; c += kWave) {

@@ -580,88 +580,67 @@ extern "C" int morl_envelope_reduce_rows(const float* qo, const float* qt, const
     return MORL_OK;
 }
 
-extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const float* params_target, float* grads,
-                                    float* exp_avg, float* exp_avg_sq, const float* obs, const float* next_obs,
-                                    const int32_t* actions, const float* rewards, const float* dones,
-                                    const float* weights, int B, int W, const morl_update_cfg* cfg,
-                                    const morl_update_out* out, void* stream) {
-    int rc = check_bw(c, B, W);
-    if (rc) return rc;
-    if (!params_online || !params_target || !grads || !obs || !next_obs || !actions || !rewards || !dones || !weights ||
-        !cfg)
-        return fail(MORL_ERR_ARG, "NULL array");
-    if (cfg->apply_step && (!exp_avg || !exp_avg_sq)) return fail(MORL_ERR_ARG, "Adam state is NULL");
-    if (cfg->apply_step && cfg->adam_step < 1) return fail(MORL_ERR_ARG, "adam_step must be >= 1");
-    hipStream_t s = (hipStream_t)stream;
+// ---- one gradient step, in three stages so that a weight-sharded job can put its collectives between them ----------
+// stage B: TD rows of `WI` scalarisation vectors (weights_i) against slabs over all `W` candidates:
+//          training forward (unless the caller already ran it), envelope arg-max + TD, backward, weight gradients.
+//          Everything is normalised by the GLOBAL row count rows_total = B * W_total, so summing the gradients (and
+//          the loss) of all shards gives exactly the single-GPU values.  Gradients are left UNCLIPPED in `grads`.
+static int update_core(morl_ctx* c, const float* params_online, float* grads, const float* obs, const int32_t* actions,
+                       const float* rewards, const float* dones, const float* weights_i, int WI, const float* qo,
+                       const float* qt, int W, int i_offset, long long rows_total, int B, const morl_update_cfg* cfg,
+                       const morl_update_out* out, bool main_fwd_done, int* splits_out, int* td_groups_out,
+                       hipStream_t s) {
+    int rc;
     const morl_net_desc& n = c->net;
     const int D = n.obs_dim, R = n.reward_dim, A = n.n_actions, L = c->L;
-    const int rows = B * W, AR = A * R;
-    static const morl_update_out no_out = {};
-    if (!out) out = &no_out;
-
-    // 1. the dW GEMM reads the training pass's layer-0 input from HBM (the W-tiled batch of envelope.py:284-291 is
-    //    never materialised wider than this [rows][D+R] block)
-    if ((rc = build_input(obs, weights, c->x0m, B, W, D, R, c->ld0, 1, s))) return rc;
-    if (c->use_fused) {
-        // 2./3. layer-fused passes: activations stay in LDS; rows assembled from (obs, weights) inside the kernel
-        if ((rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
-        if ((rc = refresh_transposed(c, params_target, c->wt_target, s))) return rc;
-        if (c->fused_tm == 0) {
-            // one launch: 3 x rows/64 workgroups -> 2 resident per CU, their barriers / epilogues overlap
-            if ((rc = chain_forward_x3(
-                     c, make_forward_chain(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR),
-                     make_forward_chain(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR),
-                     make_forward_chain(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm, c->ldq), s)))
-                return rc;
+    const int rows = B * WI;
+    // the dW GEMM reads the training pass's layer-0 input from HBM (the W-tiled batch of envelope.py:284-291 is never
+    // materialised wider than this [rows][D+R] block)
+    if ((rc = build_input(obs, weights_i, c->x0m, B, WI, D, R, c->ld0, 1, s))) return rc;
+    if (!main_fwd_done) {
+        if (c->use_fused) {
+            if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights_i, B, WI, 1, rows, true, c->qm, c->ldq, s))) return rc;
         } else {
-            if ((rc = chain_forward(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR, s))) return rc;
-            if ((rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
-            if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm, c->ldq, s))) return rc;
+            if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
         }
-    } else {
-        if ((rc = build_input(next_obs, weights, c->x0n, B, W, D, R, c->ld0, 0, s))) return rc;
-        // 2. no-grad next-state slabs Qo, Qt [B][W][A][R] (B*W distinct rows instead of the reference's W^2*B)
-        if ((rc = net_forward(c, params_online, c->x0n, rows, false, c->qo, AR, s))) return rc;
-        if ((rc = net_forward(c, params_target, c->x0n, rows, false, c->qt, AR, s))) return rc;
-        // 3. training forward, activations saved
-        if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
     }
-    // 4. envelope arg-max + TD target + dLoss/dQ (W rows of a transition over up to 4 workgroups: latency-bound)
-    const int td_groups = std::max(1, std::min(4, W / 4));
+    // envelope arg-max + TD target + dLoss/dQ (the rows of a transition over up to 4 workgroups: latency-bound)
+    const int td_groups = std::max(1, std::min(4, WI / 4));
     {
         EnvelopeTdArgs p{};
-        p.qo = c->qo; p.qt = c->qt; p.weights = weights; p.q_main = c->qm;
+        p.qo = qo; p.qt = qt; p.weights = weights_i; p.q_main = c->qm;
         p.actions = actions; p.rewards = rewards; p.dones = dones;
         p.target = out->target; p.pref = out->pref; p.ac = out->ac;
-        p.dq = c->dq; p.loss_part = c->loss_part; p.priority = out->priority;
+        p.dq = c->dq; p.loss_part = c->loss_part; p.priority = (i_offset == 0) ? out->priority : nullptr;
         p.B = B; p.W = W; p.A = A; p.R = R; p.ldq = c->ldq;
+        p.WI = WI; p.i_offset = i_offset;
         p.diag_only = cfg->envelope ? 0 : 1;
         p.gamma = cfg->gamma;
         const float lam = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
-        p.c_mse = (float)((1.0 - (double)lam) * 2.0 / ((double)rows * R));
-        p.c_aux = (float)((double)lam * 2.0 / (double)rows);
+        p.c_mse = (float)((1.0 - (double)lam) * 2.0 / ((double)rows_total * R));
+        p.c_aux = (float)((double)lam * 2.0 / (double)rows_total);
         p.i_groups = td_groups;
         hipLaunchKernelGGL(envelope_td_kernel, dim3(B * td_groups), dim3(256), 0, s, p);
         LAUNCH_CHECK("envelope_td");
     }
-    // 5. backward through the hidden layers: g[l-1] = (g[l] @ W_l) * (h[l] > 0)
+    // backward through the hidden layers: g[l-1] = (g[l] @ W_l) * (h[l] > 0)
     if (c->use_fused) {
         if ((rc = chain_backward(c, params_online, rows, s))) return rc;
     } else
-    for (int l = L - 1; l >= 1; --l) {
-        GemmProblem g{};
-        g.A = c->g[l];
-        g.lda = (l == L - 1) ? c->ldq : n.dims[l + 1];
-        g.B = params_online + c->offW[l];
-        g.ldb = n.dims[l];
-        g.C = c->g[l - 1];
-        g.ldc = n.dims[l];
-        g.mask = c->h[l];
-        g.ldmask = n.dims[l];
-        g.M = rows; g.N = n.dims[l]; g.K = n.dims[l + 1];
-        if ((rc = launch_gemm<true, false, EPI_RELU_MASK>(g, s, "gemm_dx"))) return rc;
-    }
-    // 6. all dW / db in one grouped split-K launch
+        for (int l = L - 1; l >= 1; --l) {
+            GemmProblem g{};
+            g.A = c->g[l];
+            g.lda = (l == L - 1) ? c->ldq : n.dims[l + 1];
+            g.B = params_online + c->offW[l];
+            g.ldb = n.dims[l];
+            g.C = c->g[l - 1];
+            g.ldc = n.dims[l];
+            g.mask = c->h[l];
+            g.ldmask = n.dims[l];
+            g.M = rows; g.N = n.dims[l]; g.K = n.dims[l + 1];
+            if ((rc = launch_gemm<true, false, EPI_RELU_MASK>(g, s, "gemm_dx"))) return rc;
+        }
+    // all dW / db in one grouped split-K launch
     int splits = std::max(1, std::min(c->max_splits, (256 + c->dw_tiles - 1) / c->dw_tiles));
     int kps = round_up((rows + splits - 1) / splits, GEMM_BK);
     splits = (rows + kps - 1) / kps;
@@ -693,38 +672,135 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         hipLaunchKernelGGL(gemm_grouped_tn_kernel, dim3(t, splits), dim3(GEMM_THREADS), 0, s, grp);
         LAUNCH_CHECK("gemm_grouped_dw");
     }
-    // 7. reduce the split-K slabs into the caller's grad buffer (+ norm partials, loss)
+    // reduce the split-K slabs into the caller's grad buffer (+ norm partials, this shard's part of the loss)
     const int nblk = std::min(OPT_MAX_BLOCKS, stream_grid(c->P, OPT_THREADS));
     {
         const float lam = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
         hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)c->slabs, splits,
                            (long long)c->P, grads, (long long)c->P, c->sumsq_part, (const double*)c->loss_part, B * td_groups,
-                           1.0 / ((double)rows * R), 1.0 / (double)rows, lam, out->loss);
+                           1.0 / ((double)rows_total * R), 1.0 / (double)rows_total, lam, out->loss);
         LAUNCH_CHECK("grad_reduce");
     }
-    // 8. clip + Adam
-    {
-        const double b1 = cfg->beta1, b2 = cfg->beta2;
-        const int t = std::max(1, cfg->adam_step);
-        const double bc1 = 1.0 - std::pow(b1, (double)t);
-        const double bc2 = 1.0 - std::pow(b2, (double)t);
-        const double step_size = (double)cfg->lr / bc1;
-        const double bc2_sqrt = std::sqrt(bc2);
-        hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, params_online, grads, exp_avg,
-                           exp_avg_sq, (long long)c->P, (const double*)c->sumsq_part, nblk, cfg->max_grad_norm,
-                           (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(-step_size), (float)bc2_sqrt,
-                           (float)cfg->eps, cfg->apply_step, out->grad_norm);
-        LAUNCH_CHECK("clip_adam");
-    }
-    // optional debug / parity outputs
-    if (out->q_online_next) HIP_TRY(hipMemcpyAsync(out->q_online_next, c->qo, (size_t)rows * AR * 4, hipMemcpyDeviceToDevice, s));
-    if (out->q_target_next) HIP_TRY(hipMemcpyAsync(out->q_target_next, c->qt, (size_t)rows * AR * 4, hipMemcpyDeviceToDevice, s));
     if (out->q_values) {
+        const int AR = A * R;
         hipLaunchKernelGGL(copy_rows_kernel, dim3(stream_grid((long long)rows * AR, 256)), dim3(256), 0, s,
                            (const float*)c->qm, c->ldq, out->q_values, AR, (long long)rows, AR);
         LAUNCH_CHECK("copy_rows");
     }
+    if (splits_out) *splits_out = splits;
+    if (td_groups_out) *td_groups_out = td_groups;
     return MORL_OK;
+}
+
+// stage C: clip_grad_norm_ + Adam on flat buffers.  have_partials: the sum-of-squares partials of grad_reduce are valid
+// for `grads` (single GPU); otherwise (gradients were all-reduced) they are recomputed from `grads` first.
+static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                          const morl_update_cfg* cfg, float* grad_norm_out, bool have_partials, hipStream_t s) {
+    const int nblk = std::min(OPT_MAX_BLOCKS, stream_grid(c->P, OPT_THREADS));
+    if (!have_partials) {
+        hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)grads, 1, (long long)c->P,
+                           grads, (long long)c->P, c->sumsq_part, (const double*)nullptr, 0, 0.0, 0.0, 0.f, (float*)nullptr);
+        LAUNCH_CHECK("grad_sumsq");
+    }
+    const double b1 = cfg->beta1, b2 = cfg->beta2;
+    const int t = std::max(1, cfg->adam_step);
+    const double bc1 = 1.0 - std::pow(b1, (double)t);
+    const double bc2 = 1.0 - std::pow(b2, (double)t);
+    const double step_size = (double)cfg->lr / bc1;
+    const double bc2_sqrt = std::sqrt(bc2);
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq,
+                       (long long)c->P, (const double*)c->sumsq_part, nblk, cfg->max_grad_norm, (float)(1.0 - b1), (float)b2,
+                       (float)(1.0 - b2), (float)(-step_size), (float)bc2_sqrt, (float)cfg->eps, cfg->apply_step,
+                       grad_norm_out);
+    LAUNCH_CHECK("clip_adam");
+    return MORL_OK;
+}
+
+extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const float* params_target, float* grads,
+                                    float* exp_avg, float* exp_avg_sq, const float* obs, const float* next_obs,
+                                    const int32_t* actions, const float* rewards, const float* dones,
+                                    const float* weights, int B, int W, const morl_update_cfg* cfg,
+                                    const morl_update_out* out, void* stream) {
+    int rc = check_bw(c, B, W);
+    if (rc) return rc;
+    if (!params_online || !params_target || !grads || !obs || !next_obs || !actions || !rewards || !dones || !weights ||
+        !cfg)
+        return fail(MORL_ERR_ARG, "NULL array");
+    if (cfg->apply_step && (!exp_avg || !exp_avg_sq)) return fail(MORL_ERR_ARG, "Adam state is NULL");
+    if (cfg->apply_step && cfg->adam_step < 1) return fail(MORL_ERR_ARG, "adam_step must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    const morl_net_desc& n = c->net;
+    const int D = n.obs_dim, R = n.reward_dim, A = n.n_actions;
+    const int rows = B * W, AR = A * R;
+    static const morl_update_out no_out = {};
+    if (!out) out = &no_out;
+
+    // stage A: no-grad next-state slabs Qo, Qt [B][W][A][R] (B*W distinct rows instead of the reference's W^2*B)
+    bool main_done = false;
+    if (c->use_fused) {
+        // layer-fused passes: activations stay in LDS; rows assembled from (obs, weights) inside the kernel
+        if ((rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
+        if ((rc = refresh_transposed(c, params_target, c->wt_target, s))) return rc;
+        if (c->fused_tm == 0) {
+            // one launch for the three forward passes: 3 x rows/64 workgroups -> 2 resident per CU
+            if ((rc = chain_forward_x3(
+                     c, make_forward_chain(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR),
+                     make_forward_chain(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR),
+                     make_forward_chain(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm, c->ldq), s)))
+                return rc;
+            main_done = true;
+        } else {
+            if ((rc = chain_forward(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR, s))) return rc;
+            if ((rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
+        }
+    } else {
+        if ((rc = build_input(next_obs, weights, c->x0n, B, W, D, R, c->ld0, 0, s))) return rc;
+        if ((rc = net_forward(c, params_online, c->x0n, rows, false, c->qo, AR, s))) return rc;
+        if ((rc = net_forward(c, params_target, c->x0n, rows, false, c->qt, AR, s))) return rc;
+    }
+    if ((rc = update_core(c, params_online, grads, obs, actions, rewards, dones, weights, W, c->qo, c->qt, W, 0,
+                          (long long)rows, B, cfg, out, main_done, nullptr, nullptr, s)))
+        return rc;
+    if ((rc = clip_adam_step(c, params_online, grads, exp_avg, exp_avg_sq, cfg, out->grad_norm, true, s))) return rc;
+    // optional debug / parity outputs
+    if (out->q_online_next) HIP_TRY(hipMemcpyAsync(out->q_online_next, c->qo, (size_t)rows * AR * 4, hipMemcpyDeviceToDevice, s));
+    if (out->q_target_next) HIP_TRY(hipMemcpyAsync(out->q_target_next, c->qt, (size_t)rows * AR * 4, hipMemcpyDeviceToDevice, s));
+    return MORL_OK;
+}
+
+// Weight-sharded variant, stage B only: this rank owns the TD rows of weights [i_offset, i_offset + W_local) and is
+// handed the all-gathered slabs qo_all / qt_all [B][W_total][A][R].  Writes this rank's UNCLIPPED gradient
+// contribution (already normalised by the global row count) to `grads` and its share of the loss to out->loss; the
+// caller all-reduces both and then calls morl_clip_adam.
+extern "C" int morl_envelope_update_shard(morl_ctx* c, const float* params_online, float* grads, const float* obs,
+                                          const int32_t* actions, const float* rewards, const float* dones,
+                                          const float* weights_all, int B, int W_total, int i_offset, int W_local,
+                                          const float* qo_all, const float* qt_all, const morl_update_cfg* cfg,
+                                          const morl_update_out* out, void* stream) {
+    int rc = check_bw(c, B, W_local);
+    if (rc) return rc;
+    if (!params_online || !grads || !obs || !actions || !rewards || !dones || !weights_all || !qo_all || !qt_all || !cfg)
+        return fail(MORL_ERR_ARG, "NULL array");
+    if (W_total < 1 || i_offset < 0 || W_local < 1 || i_offset + W_local > W_total)
+        return fail(MORL_ERR_ARG, "bad shard [%d, %d) of %d weights", i_offset, i_offset + W_local, W_total);
+    if ((long long)W_total * c->net.n_actions * c->net.reward_dim > ENV_MAX_SLAB || W_total * c->net.reward_dim > ENV_MAX_WR)
+        return fail(MORL_ERR_ARG, "W_total*A*R exceeds the LDS slab of the envelope kernel (%d floats)", ENV_MAX_SLAB);
+    hipStream_t s = (hipStream_t)stream;
+    static const morl_update_out no_out = {};
+    if (!out) out = &no_out;
+    if (c->use_fused && (rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
+    return update_core(c, params_online, grads, obs, actions, rewards, dones,
+                       weights_all + (size_t)i_offset * c->net.reward_dim, W_local, qo_all, qt_all, W_total, i_offset,
+                       (long long)B * W_total, B, cfg, out, false, nullptr, nullptr, s);
+}
+
+// clip_grad_norm_ + Adam on flat buffers (envelope.py:324-326) -- stage C on its own, for gradients that were
+// all-reduced between the stages.
+extern "C" int morl_clip_adam(morl_ctx* c, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                              const morl_update_cfg* cfg, float* grad_norm_out, void* stream) {
+    if (!c || !params || !grads || !cfg) return fail(MORL_ERR_ARG, "NULL argument");
+    if (cfg->apply_step && (!exp_avg || !exp_avg_sq)) return fail(MORL_ERR_ARG, "Adam state is NULL");
+    return clip_adam_step(c, params, grads, exp_avg, exp_avg_sq, cfg, grad_norm_out, false, (hipStream_t)stream);
 }
 
 extern "C" int morl_polyak(const float* src, float* dst, float tau, int64_t n, void* stream) {

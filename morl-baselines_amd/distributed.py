@@ -1,0 +1,89 @@
+"""Weight-axis sharding of the Envelope step over the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The reference is single-device (no distributed code at all); this is the MI355X-native addition of
+SURVEY.md 8(e).  Every rank holds a full replica of the agent (parameters, Adam state, replay buffer) and draws the
+SAME batch and the SAME W sampled weights (identical seeds => identical host RNG streams).  Rank g owns the weights
+``[g*W/G, (g+1)*W/G)``:
+
+  1. it evaluates the next-state slabs Q_online/Q_target(s'_b, w_j) for ITS weights only            (B*W/G rows, 2 passes)
+  2. ONE all-gather makes both slabs complete on every rank             (2 * B*W*A*R*4 bytes in total; 2.4 MB @ flagship)
+  3. it runs the training forward / envelope arg-max over ALL candidates / TD / backward for its own TD rows
+  4. ONE all-reduce sums the flat gradient (+ the loss scalar appended to it)                  (0.85 MB @ flagship)
+  5. every rank applies the identical clip + Adam step -> replicas stay bit-identical
+  (PER: the priorities come from the rows of weight 0, i.e. from rank 0; they ride along in a broadcast of B floats.)
+
+Messages are far below the size where a ring would be bandwidth-bound on the point-to-point xGMI links; they are
+latency-bound, so the exchange is kept to two collectives per step and both operate on single contiguous buffers.
+The data path has real exchange steps, hence this is *strong* scaling of one 256 x 64 update.
+"""
+from __future__ import annotations
+
+import types
+from typing import Optional
+
+import torch as th
+
+from . import ops
+from .envelope import Envelope, random_weights
+
+
+def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
+    """Replace ``agent.update`` with the sharded step.  ``dist`` is ``torch.distributed`` (already initialised)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    W = agent.num_sample_w
+    if W % world:
+        raise ValueError(f"num_sample_w={W} must be divisible by the number of ranks ({world})")
+    Wl = W // world
+    i0 = rank * Wl
+    A, R = agent.action_dim, agent.reward_dim
+    dev = agent.device
+    P = agent.q_net.ctx.n_params
+    agent._shard = types.SimpleNamespace(world=world, rank=rank, Wl=Wl, i0=i0)
+    # gradient buffer with one extra slot: the loss rides in the same all-reduce
+    agent._grads_x = th.zeros(P + 1, dtype=th.float32, device=dev)
+    agent._grads = agent._grads_x[:P]
+    agent._bind_optimizer_state()
+
+    def update(self: Envelope):
+        self._losses = []
+        B = self.batch_size
+        for _ in range(self.gradient_updates):
+            b_obs, b_actions, b_rewards, b_next_obs, b_dones, b_inds = self.replay_buffer.sample(
+                B, to_tensor=True, device=self.device)
+            sampled_w = th.as_tensor(random_weights(dim=R, n=W, dist="gaussian", rng=self.np_random)).float() \
+                .reshape(W, R).to(self.device, non_blocking=True).contiguous()
+            ctx = self.q_net.ctx
+            w_loc = sampled_w[i0:i0 + Wl].contiguous()
+            # 1. local slabs [2][B][Wl][A][R]
+            loc = th.empty((2, B, Wl, A, R), dtype=th.float32, device=self.device)
+            loc[0] = ops.qnet_forward(ctx, self.q_net.flat, b_next_obs, w_loc, row_order=0).view(B, Wl, A, R)
+            loc[1] = ops.qnet_forward(ctx, self.target_q_net.flat, b_next_obs, w_loc, row_order=0).view(B, Wl, A, R)
+            # 2. one all-gather, then [G][2][B][Wl] -> [2][B][G*Wl]
+            gathered = th.empty(world * loc.numel(), dtype=th.float32, device=self.device)
+            dist.all_gather_into_tensor(gathered, loc.reshape(-1), group=group)
+            slabs = gathered.view(world, 2, B, Wl, A, R).permute(1, 2, 0, 3, 4, 5).reshape(2, B, W, A, R).contiguous()
+            # 3. this rank's TD rows
+            self._adam_step += 1
+            out = ops.envelope_update_shard(ctx, self.q_net.flat, self._grads, b_obs, b_actions.reshape(-1).to(th.int32),
+                                            b_rewards, b_dones.reshape(-1), sampled_w, i0, Wl, slabs[0], slabs[1],
+                                            gamma=self.gamma, homotopy_lambda=float(self.homotopy_lambda),
+                                            envelope=self.envelope)
+            # 4. one all-reduce: flat gradient + loss
+            self._grads_x[P:].copy_(out["loss"].reshape(1))
+            dist.all_reduce(self._grads_x, op=dist.ReduceOp.SUM, group=group)
+            loss = self._grads_x[P].clone()
+            # 5. identical optimiser step everywhere
+            ops.clip_adam(ctx, self.q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq, lr=self.learning_rate,
+                          adam_step=self._adam_step, max_grad_norm=self.max_grad_norm)
+            self._out = {"loss": loss, "priority": out["priority"]}
+            self._losses.append(loss)
+            if self.per:
+                pr = out["priority"]
+                dist.broadcast(pr, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                self.replay_buffer.update_priorities_from_td(b_inds, pr, self.per_alpha)
+        if self.tau != 1 or self.global_step % self.target_net_update_freq == 0:
+            ops.polyak(self.lib, self.q_net.flat, self.target_q_net.flat, self.tau)
+
+    agent.update = types.MethodType(update, agent)
+    agent.q_net.ensure_capacity(agent.batch_size, W)
+    return agent

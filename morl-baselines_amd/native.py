@@ -56,6 +56,10 @@ _SIGNATURES = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "morl_envelope_update": (C.c_int, [C.c_void_p] * 12 + [C.c_int, C.c_int, C.POINTER(UpdateCfg),
                                                            C.POINTER(UpdateOut), C.c_void_p]),
+    "morl_envelope_update_shard": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p,
+                                                                                 C.POINTER(UpdateCfg), C.POINTER(UpdateOut),
+                                                                                 C.c_void_p]),
+    "morl_clip_adam": (C.c_int, [C.c_void_p] * 5 + [C.POINTER(UpdateCfg), C.c_void_p, C.c_void_p]),
     "morl_polyak": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
     "morl_pareto_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "morl_sumtree_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

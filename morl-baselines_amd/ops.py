@@ -188,6 +188,55 @@ def envelope_update(ctx: QNetContext, params_online: th.Tensor, params_target: t
     return res
 
 
+def _update_cfg(gamma, lr, adam_step, max_grad_norm, homotopy_lambda, envelope, beta1, beta2, eps, apply_step):
+    return UpdateCfg(gamma=gamma, homotopy_lambda=homotopy_lambda,
+                     max_grad_norm=-1.0 if max_grad_norm is None else float(max_grad_norm), lr=lr, beta1=beta1,
+                     beta2=beta2, eps=eps, adam_step=int(adam_step), envelope=int(bool(envelope)),
+                     apply_step=int(bool(apply_step)))
+
+
+def envelope_update_shard(ctx: QNetContext, params_online: th.Tensor, grads: th.Tensor, obs: th.Tensor,
+                          actions: th.Tensor, rewards: th.Tensor, dones: th.Tensor, weights_all: th.Tensor,
+                          i_offset: int, w_local: int, qo_all: th.Tensor, qt_all: th.Tensor, *, gamma: float,
+                          homotopy_lambda: float = 0.0, envelope: bool = True,
+                          outputs: Optional[Dict[str, th.Tensor]] = None) -> Dict[str, th.Tensor]:
+    """Stage B of a weight-sharded Envelope step (see include/morl_hip.h): this rank's TD rows against the gathered
+    slabs; leaves the unclipped, globally normalised gradient contribution in ``grads``."""
+    lib = ctx.lib
+    for t, dt, n in ((params_online, th.float32, "params_online"), (grads, th.float32, "grads"),
+                     (obs, th.float32, "obs"), (actions, th.int32, "actions"), (rewards, th.float32, "rewards"),
+                     (dones, th.float32, "dones"), (weights_all, th.float32, "weights_all"),
+                     (qo_all, th.float32, "qo_all"), (qt_all, th.float32, "qt_all")):
+        _chk(t, dt, n)
+    lib.check_device(params_online, grads, obs, actions, rewards, dones, weights_all, qo_all, qt_all)
+    B, W = obs.shape[0], weights_all.shape[0]
+    dev = obs.device
+    res = outputs if outputs is not None else {}
+    if "loss" not in res:
+        res["loss"] = th.empty((), dtype=th.float32, device=dev)
+        res["priority"] = th.zeros((B,), dtype=th.float32, device=dev)
+    cfg = _update_cfg(gamma, 0.0, 1, None, homotopy_lambda, envelope, 0.9, 0.999, 1e-8, False)
+    out = UpdateOut(**{k: _ptr(res.get(k)) for k, _ in UpdateOut._fields_})
+    lib.check(lib.lib.morl_envelope_update_shard(
+        ctx.handle, _ptr(params_online), _ptr(grads), _ptr(obs), _ptr(actions), _ptr(rewards), _ptr(dones),
+        _ptr(weights_all), B, W, int(i_offset), int(w_local), _ptr(qo_all), _ptr(qt_all), C.byref(cfg), C.byref(out),
+        lib.stream_of(obs)))
+    return res
+
+
+def clip_adam(ctx: QNetContext, params: th.Tensor, grads: th.Tensor, exp_avg: th.Tensor, exp_avg_sq: th.Tensor, *,
+              lr: float, adam_step: int, max_grad_norm: Optional[float], beta1: float = 0.9, beta2: float = 0.999,
+              eps: float = 1e-8, grad_norm_out: Optional[th.Tensor] = None) -> None:
+    """clip_grad_norm_ + torch's single-tensor Adam on flat buffers (envelope.py:324-326)."""
+    lib = ctx.lib
+    for t, n in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, th.float32, n)
+    lib.check_device(params, grads, exp_avg, exp_avg_sq, grad_norm_out)
+    cfg = _update_cfg(0.0, lr, adam_step, max_grad_norm, 0.0, True, beta1, beta2, eps, True)
+    lib.check(lib.lib.morl_clip_adam(ctx.handle, _ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                     C.byref(cfg), _ptr(grad_norm_out), lib.stream_of(params)))
+
+
 def polyak(lib: NativeLib, src: th.Tensor, dst: th.Tensor, tau: float) -> None:
     """polyak_update (common/networks.py:120-139) on flat parameter buffers."""
     _chk(src, th.float32, "src"); _chk(dst, th.float32, "dst")
