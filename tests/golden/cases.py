@@ -41,6 +41,10 @@ CASES: List[Case] = [
     Case("flagship_b32w8", B=32, W=8, D=32, A=6, R=3, arch=(256, 256, 256, 256), step=2, seed=5, subsample=101),
 ]
 
+# The BASELINE.json shape itself (B=256 x W=64 x R=3).  Kept out of CASES: the emulator cannot run it and its target
+# tensor is large; tests/test_flagship_golden.py (gpu) uses the reduced fixture written by make_golden.py.
+FLAGSHIP = Case("flagship_full", B=256, W=64, D=32, A=6, R=3, arch=(256, 256, 256, 256), step=3, seed=6, subsample=257)
+
 
 def layer_dims(c: Case):
     return [c.D + c.R] + list(c.arch) + [c.A * c.R]

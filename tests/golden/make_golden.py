@@ -22,11 +22,11 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, HERE)
 
 import ref_harness as rh  # noqa: E402
-from cases import CASES, Case, make_inputs, pareto_sets  # noqa: E402
+from cases import CASES, FLAGSHIP, Case, make_inputs, pareto_sets  # noqa: E402
 
 
 def run_case(ref, c: Case) -> dict:
-    th.set_num_threads(1)
+    th.set_num_threads(1 if c.name != "flagship_full" else 8)
     inp = make_inputs(c)
     env = rh.FakeEnv(c.D, c.A, c.R)
     ag = ref.envelope.Envelope(
@@ -75,6 +75,16 @@ def run_case(ref, c: Case) -> dict:
     t_nobs = batch[3].repeat(c.W, 1)
     if c.envelope:
         rec["target"] = ag.envelope_target(t_nobs, w, sw).numpy().copy()
+        if c.name == "flagship_full":   # the arg-max indices of envelope.py:420-426, from the reference's own modules
+            with th.no_grad():
+                Wr = sw.repeat(t_nobs.size(0), 1)
+                nob = t_nobs.repeat_interleave(c.W, 0)
+                nq = ag.q_net(nob, Wr).view(t_nobs.size(0), c.W, c.A, c.R)
+                scal = th.einsum("br,bwar->bwa", w, nq)
+                max_q, ac = th.max(scal, dim=2)
+                pref = th.argmax(max_q, dim=1)
+                rec["pref"] = pref.numpy().astype(np.int16)
+                rec["ac"] = ac.gather(1, pref.reshape(-1, 1)).squeeze(1).numpy().astype(np.int16)
     else:
         rec["target"] = ag.ddqn_target(t_nobs, w).numpy().copy()
     try:
@@ -97,6 +107,9 @@ def run_case(ref, c: Case) -> dict:
         loss=np.float32(loss.item()), grad_norm=rec["grad_norm"], target=rec["target"],
         priority_final=rec["priority_final"].astype(np.float64),
     )
+    if "pref" in rec:
+        out["pref"], out["ac"] = rec["pref"], rec["ac"]
+        out["target"] = rec["target"][::16].copy()      # every 16th TD row is enough at this size
     for i, p in enumerate(params):
         out[f"param_after_{i}"] = sub(p.detach().numpy())
         out[f"grad_{i}"] = sub(p.grad.detach().numpy())  # post-clip
@@ -139,6 +152,10 @@ def main():
         out = run_case(ref, c)
         np.savez_compressed(os.path.join(HERE, f"envelope_{c.name}.npz"), **out)
         print(f"{c.name}: loss={out['loss']:.6g} grad_norm={out['grad_norm']:.6g}")
+    th.set_num_threads(8)
+    out = run_case(ref, FLAGSHIP)
+    np.savez_compressed(os.path.join(HERE, f"envelope_{FLAGSHIP.name}.npz"), **out)
+    print(f"{FLAGSHIP.name}: loss={out['loss']:.6g} grad_norm={out['grad_norm']:.6g}")
     masks = {}
     for name, pts in pareto_sets().items():
         for rd in (True, False):
