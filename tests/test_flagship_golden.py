@@ -71,11 +71,10 @@ def test_argmax_indices_match_reference_up_to_one_ulp_ties(run):
 
 def test_targets_params_and_priorities_match_reference(run):
     c, inp, res, t, sw, g = run
-    got = res["target"].cpu()[::16]
-    bad = (got != th.tensor(g["target"])).any(1)
-    assert bad.float().mean().item() <= 0.01                              # only rows whose arg-max hit a near-tie / GEMM ulp
-    rel = (got - th.tensor(g["target"])).abs().max(1).values / th.tensor(g["target"]).abs().max()
-    assert (rel[~bad] == 0).all() or float(rel[~bad].max()) <= 1e-5
+    got, want = res["target"].cpu()[::16], th.tensor(g["target"])
+    rel = (got - want).abs().max(1).values / want.abs().max()
+    # rows whose arg-max agrees differ only by GEMM rounding (1e-5); the few near-tie index flips select another slab row
+    assert (rel > 1e-5).float().mean().item() <= 0.004
     s, off = c.subsample, 0
     po, gr = t["po"].cpu(), t["g"].cpu()
     gmax = max(float(np.abs(g[f"grad_{i}"]).max()) for i in range(len(inp["online"])))
@@ -90,9 +89,8 @@ def test_targets_params_and_priorities_match_reference(run):
 
 
 def test_size_independent_properties(run):
-    """Properties that hold at any size: (1) permuting the sampled weights permutes the slabs and leaves every TD
-    row's target unchanged as a set; (2) the update is deterministic run to run (fixed-order reductions); (3) a zero
-    learning signal (target == online, gamma = 0, rewards = Q) gives zero loss / zero gradient."""
+    """Properties that hold at any size: (1) permuting the sampled weights permutes the TD rows and leaves every
+    row's envelope target unchanged; (2) the update is deterministic run to run (fixed-order reductions)."""
     c, inp, res, t, sw, g = run
     lib = load_library()
     dev = th.device("cuda:0")
