@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmorl_hip.so")
 SOURCES = ["morl_hip.hip"]
-HEADERS = ["morl_device.h", "gemm_f32.h", "envelope_kernels.h", "mlp_chain.h", "optim_kernels.h", "replay_kernels.h",
+HEADERS = ["morl_device.h", "gemm_f32.h", "envelope_kernels.h", "mlp_chain.h", "dw_wave.h", "optim_kernels.h", "replay_kernels.h",
            "pareto_kernels.h"]
 
 

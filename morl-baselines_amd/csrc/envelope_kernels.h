@@ -75,9 +75,14 @@ struct EnvelopeTdArgs {
     float c_aux;            // lambda * 2 / (W*B)
 };
 
-// LDS-resident throughout: phase 1 stages Qo[b], Qt[b], the weight vectors and the W taken-action Q entries of
-// this transition with coalesced / parallel loads; phase 2 (arg-max + TD per row) touches LDS only, so the 16
-// rows a wave owns are not serialised behind dependent global loads; phase 3 writes all outputs in bulk.
+// LDS-resident throughout: phase 1 stages Qo[b], Qt[b], the weight vectors and the taken-action Q entries of this
+// transition with coalesced / parallel loads; phase 3 writes all outputs in bulk.
+// Phase 2 mapping: lane <-> scalarisation vector i (TD row), wave q of the 4 <-> a quarter of the (j, a) candidates.
+// Every lane walks its wave's candidates in index order reading the candidate's R values as LDS *broadcasts* (all lanes
+// read the same address: one conflict-free access), so the arg-max needs no cross-lane traffic at all; the four
+// per-wave partial winners of a row are merged through LDS in candidate order (first maximum wins, like th.max /
+// th.argmax).  The kernel is latency-bound, not bandwidth-bound: what matters is that no lane waits on a dependent
+// shuffle or global load inside the candidate loop.
 __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
     __shared__ float s_qo[ENV_MAX_SLAB];
     __shared__ float s_qt[ENV_MAX_SLAB];
@@ -86,6 +91,8 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
     __shared__ float s_tgt[ENV_MAX_WR];   // selected target vectors
     __shared__ float s_g[ENV_MAX_WR];     // dLoss/dQ of the taken action
     __shared__ int s_best[ENV_MAX_WR];    // flattened (j*, a*)
+    __shared__ float s_pv[4][ENV_MAX_WR / 2];   // per-wave partial maxima ...
+    __shared__ int s_pc[4][ENV_MAX_WR / 2];     // ... and their candidate indices
     __shared__ double s_red[4][2];
     const int ig_n = p.i_groups > 0 ? p.i_groups : 1;
     const int b = (int)blockIdx.x / ig_n, ig = (int)blockIdx.x % ig_n;
@@ -94,8 +101,6 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
     const int slab = W * A * R;
     const bool generic = p.row_weights != nullptr;
     const int nI = generic ? 1 : (p.WI > 0 ? p.WI : W);   // scalarisation vectors (TD rows) of this transition
-    // this workgroup's share of them: i in [i_lo, i_hi) -- more, smaller workgroups hide the dependent LDS / shuffle
-    // latency chains of the arg-max (the kernel is latency- not bandwidth-bound)
     const int per_g = (nI + ig_n - 1) / ig_n;
     const int i_lo = min(nI, ig * per_g), i_hi = min(nI, i_lo + per_g);
     const bool train = p.q_main != nullptr;
@@ -110,81 +115,91 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
     }
     __syncthreads();
 
-    double acc_mse = 0.0, acc_aux = 0.0;
     const float not_done_gamma = train ? __fmul_rn(__fsub_rn(1.0f, p.dones[b]), p.gamma) : 0.f;  // (1 - d) * gamma
     float rew[MORL_MAX_OBJ];
 #pragma unroll
     for (int r = 0; r < MORL_MAX_OBJ; ++r) rew[r] = (train && r < R) ? p.rewards[(size_t)b * R + r] : 0.f;
+    double acc_mse = 0.0, acc_aux = 0.0;
 
-    for (int i = i_lo + wave; i < i_hi; i += 4) {
+    // rows of this workgroup in batches of 64 (one per lane)
+    for (int ib = i_lo; ib < i_hi; ib += kWave) {
+        const int i = ib + lane;
+        const bool live = i < i_hi;
         float wi[MORL_MAX_OBJ];
 #pragma unroll
-        for (int r = 0; r < MORL_MAX_OBJ; ++r) wi[r] = (r < R) ? s_w[i * R + r] : 0.f;
-        const int c_begin = p.diag_only ? (i + p.i_offset) * A : 0;
-        const int c_end = p.diag_only ? (i + p.i_offset + 1) * A : W * A;
+        for (int r = 0; r < MORL_MAX_OBJ; ++r) wi[r] = (live && r < R) ? s_w[i * R + r] : 0.f;
+        // candidate range of this wave: a quarter of (j, a) in index order (DDQN: of the A actions of slab j = i)
+        const int n_c = p.diag_only ? A : W * A;
+        const int c_off = (p.diag_only && live) ? (i + p.i_offset) * A : 0;     // per-lane base in DDQN mode
+        const int q_lo = (n_c * wave) / 4, q_hi = (n_c * (wave + 1)) / 4;
         float best = -INFINITY;
         int best_c = 0x7fffffff;
-        for (int c = c_begin + lane; c < c_end; c += kWave) {
-            const float* q = s_qo + c * R;
+        for (int c = q_lo; c < q_hi; ++c) {
+            const float* q = s_qo + (size_t)(c_off + c) * R;     // envelope: wave-uniform address -> LDS broadcast
             float s = __fmul_rn(wi[0], q[0]);
 #pragma unroll
             for (int r = 1; r < MORL_MAX_OBJ; ++r)
                 if (r < R) s = __fadd_rn(s, __fmul_rn(wi[r], q[r]));
-            if (s > best || best_c == 0x7fffffff) { best = s; best_c = c; }
+            if (s > best || best_c == 0x7fffffff) { best = s; best_c = c_off + c; }
         }
+        if (live) { s_pv[wave][i - ib] = best; s_pc[wave][i - ib] = best_c; }
+        __syncthreads();
+        if (wave == 0 && live) {
+            // merge the four quarters in candidate order: strictly greater replaces, so the first maximum wins
+            float bv = s_pv[0][lane];
+            int bc = s_pc[0][lane];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(best, off);
-            const int oc = __shfl_xor(best_c, off);
-            if (oc != 0x7fffffff && (best_c == 0x7fffffff || ov > best || (ov == best && oc < best_c))) {
-                best = ov;
-                best_c = oc;
+            for (int q = 1; q < 4; ++q) {
+                const float v = s_pv[q][lane];
+                const int cc = s_pc[q][lane];
+                if (cc != 0x7fffffff && (bc == 0x7fffffff || v > bv)) { bv = v; bc = cc; }
+            }
+            s_best[i] = bc;
+            const float* qt = s_qt + (size_t)bc * R;
+            float td[MORL_MAX_OBJ];
+            float wq = 0.f, wtq = 0.f;
+#pragma unroll
+            for (int r = 0; r < MORL_MAX_OBJ; ++r) {
+                td[r] = 0.f;
+                if (r < R) {
+                    s_tgt[i * R + r] = qt[r];
+                    if (train) {
+                        const float tq = __fadd_rn(rew[r], __fmul_rn(not_done_gamma, qt[r]));
+                        const float qv = s_qm[i * R + r];
+                        td[r] = __fsub_rn(qv, tq);
+                        wq = (r == 0) ? __fmul_rn(qv, wi[0]) : __fadd_rn(wq, __fmul_rn(qv, wi[r]));
+                        wtq = (r == 0) ? __fmul_rn(tq, wi[0]) : __fadd_rn(wtq, __fmul_rn(tq, wi[r]));
+                    }
+                }
+            }
+            if (train) {
+                const float daux = __fsub_rn(wq, wtq);
+                double m = 0.0;
+#pragma unroll
+                for (int r = 0; r < MORL_MAX_OBJ; ++r)
+                    if (r < R) {
+                        s_g[i * R + r] = p.c_mse * td[r] + p.c_aux * daux * wi[r];
+                        m += (double)td[r] * (double)td[r];
+                    }
+                acc_mse += m;
+                acc_aux += (double)daux * (double)daux;
+                if (i == 0 && p.priority) {
+                    float pr = __fmul_rn(td[0], wi[0]);
+#pragma unroll
+                    for (int r = 1; r < MORL_MAX_OBJ; ++r)
+                        if (r < R) pr = __fadd_rn(pr, __fmul_rn(td[r], wi[r]));
+                    p.priority[b] = fabsf(pr);
+                }
             }
         }
-        const float* qt = s_qt + best_c * R;
-        if (lane == 0) s_best[i] = best_c;
-        if (lane < R) s_tgt[i * R + lane] = qt[lane];
-        if (!train) continue;
-
-        // every lane evaluates the R-vector redundantly (LDS broadcasts)
-        float td[MORL_MAX_OBJ];
-        float wq = 0.f, wtq = 0.f;
-#pragma unroll
-        for (int r = 0; r < MORL_MAX_OBJ; ++r) {
-            td[r] = 0.f;
-            if (r < R) {
-                const float tq = __fadd_rn(rew[r], __fmul_rn(not_done_gamma, qt[r]));
-                const float qv = s_qm[i * R + r];
-                td[r] = __fsub_rn(qv, tq);
-                wq = (r == 0) ? __fmul_rn(qv, wi[0]) : __fadd_rn(wq, __fmul_rn(qv, wi[r]));
-                wtq = (r == 0) ? __fmul_rn(tq, wi[0]) : __fadd_rn(wtq, __fmul_rn(tq, wi[r]));
-            }
-        }
-        const float daux = __fsub_rn(wq, wtq);
-        if (lane < R) {
-            float tdr = 0.f, wr = 0.f;
-#pragma unroll
-            for (int rr = 0; rr < MORL_MAX_OBJ; ++rr)
-                if (rr == lane) { tdr = td[rr]; wr = wi[rr]; }
-            s_g[i * R + lane] = p.c_mse * tdr + p.c_aux * daux * wr;
-        }
-        if (lane == 0) {
-            double m = 0.0;
-#pragma unroll
-            for (int r = 0; r < MORL_MAX_OBJ; ++r)
-                if (r < R) m += (double)td[r] * (double)td[r];
-            acc_mse += m;
-            acc_aux += (double)daux * (double)daux;
-            if (i == 0 && p.priority) {
-                float pr = __fmul_rn(td[0], wi[0]);
-#pragma unroll
-                for (int r = 1; r < MORL_MAX_OBJ; ++r)
-                    if (r < R) pr = __fadd_rn(pr, __fmul_rn(td[r], wi[r]));
-                p.priority[b] = fabsf(pr);
-            }
-        }
+        __syncthreads();
     }
-    if (lane == 0) { s_red[wave][0] = acc_mse; s_red[wave][1] = acc_aux; }
+    // loss partials: only wave 0 accumulated; butterfly sum over its lanes (fixed order)
+    if (wave == 0) {
+        acc_mse = wave_sum(acc_mse);
+        acc_aux = wave_sum(acc_aux);
+        if (lane == 0) { s_red[0][0] = acc_mse; s_red[0][1] = acc_aux; }
+    }
     __syncthreads();
 
     // phase 3: bulk outputs.  Output row of (i, b) is i*B + b (generic mode: b).
@@ -208,8 +223,8 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
         }
     }
     if (p.loss_part && threadIdx.x == 0) {
-        p.loss_part[(size_t)blockIdx.x * 2 + 0] = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
-        p.loss_part[(size_t)blockIdx.x * 2 + 1] = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
+        p.loss_part[(size_t)blockIdx.x * 2 + 0] = s_red[0][0];
+        p.loss_part[(size_t)blockIdx.x * 2 + 1] = s_red[0][1];
     }
 }
 

@@ -16,6 +16,7 @@
 #include "gemm_f32.h"
 #include "envelope_kernels.h"
 #include "mlp_chain.h"
+#include "dw_wave.h"
 #include "optim_kernels.h"
 #include "replay_kernels.h"
 #include "pareto_kernels.h"
@@ -131,6 +132,8 @@ struct morl_ctx {
     int64_t wt_count = 0;
     int64_t offWt[MORL_MAX_LAYERS];
     int ldn[MORL_MAX_LAYERS];
+    bool dw_wave_ok = false; // wave-level dW kernel usable (all operand row strides even)
+    int dw_wave_tiles = 0;
     bool fused_ok = false;   // architecture fits the fused engine
     bool use_fused = false;  // fused_ok and not disabled by morl_ctx_set_fused
     float* zeros = nullptr;  // 16 zero floats: target of the invalid elements of the chain's operand gathers
@@ -265,6 +268,12 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             c->num_cus = prop.multiProcessorCount;
+    }
+    c->dw_wave_ok = true;
+    c->dw_wave_tiles = 0;
+    for (int l = 0; l < c->L; ++l) {
+        if (l >= 1 && (net->dims[l] & 1)) c->dw_wave_ok = false;
+        c->dw_wave_tiles += ((net->dims[l + 1] + DW_TILE - 1) / DW_TILE) * ((net->dims[l] + DW_TILE - 1) / DW_TILE);
     }
     ALLOC(zeros, 16);
     {
@@ -604,8 +613,8 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
         }
     }
-    // envelope arg-max + TD target + dLoss/dQ (the rows of a transition over up to 4 workgroups: latency-bound)
-    const int td_groups = std::max(1, std::min(4, WI / 4));
+    // envelope arg-max + TD target + dLoss/dQ: one lane per TD row of a transition, 64 rows per workgroup pass
+    const int td_groups = std::max(1, std::min(4, (WI + 63) / 64));
     {
         EnvelopeTdArgs p{};
         p.qo = qo; p.qt = qt; p.weights = weights_i; p.q_main = c->qm;
@@ -640,8 +649,38 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             g.M = rows; g.N = n.dims[l]; g.K = n.dims[l + 1];
             if ((rc = launch_gemm<true, false, EPI_RELU_MASK>(g, s, "gemm_dx"))) return rc;
         }
-    // all dW / db in one grouped split-K launch
-    int splits = std::max(1, std::min(c->max_splits, (256 + c->dw_tiles - 1) / c->dw_tiles));
+    // all dW / db of the step in one split-K launch
+    int splits;
+    if (c->dw_wave_ok && c->use_fused) {
+        // wave-level tiles (dw_wave.h): aim at one wave per SIMD over the whole chip
+        splits = std::max(1, std::min(c->max_splits, (4 * c->num_cus + c->dw_wave_tiles / 2) / c->dw_wave_tiles));
+        int kps = round_up((rows + splits - 1) / splits, DW_CHUNK);
+        splits = (rows + kps - 1) / kps;
+        DwArgs a{};
+        a.n = L;
+        a.rows = rows;
+        a.k_per_split = kps;
+        a.slab_stride = c->P;
+        int t = 0;
+        for (int l = 0; l < L; ++l) {
+            DwProblem& q = a.p[l];
+            q.G = c->g[l];
+            q.ldg = (l == L - 1) ? c->ldq : n.dims[l + 1];
+            q.H = (l == 0) ? c->x0m : c->h[l];
+            q.ldh = (l == 0) ? c->ld0 : n.dims[l];
+            q.C = c->slabs + c->offW[l];
+            q.ldc = n.dims[l];
+            q.bias = c->slabs + c->offB[l];
+            q.M = n.dims[l + 1]; q.N = n.dims[l];
+            q.tiles_n = (q.N + DW_TILE - 1) / DW_TILE;
+            a.tile_start[l] = t;
+            t += ((q.M + DW_TILE - 1) / DW_TILE) * q.tiles_n;
+        }
+        a.tile_start[L] = t;
+        hipLaunchKernelGGL(dw_wave_kernel, dim3(t, splits), dim3(64), 0, s, a);
+        LAUNCH_CHECK("dw_wave");
+    } else {
+    splits = std::max(1, std::min(c->max_splits, (256 + c->dw_tiles - 1) / c->dw_tiles));
     int kps = round_up((rows + splits - 1) / splits, GEMM_BK);
     splits = (rows + kps - 1) / kps;
     {
@@ -671,6 +710,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         grp.tile_start[L] = t;
         hipLaunchKernelGGL(gemm_grouped_tn_kernel, dim3(t, splits), dim3(GEMM_THREADS), 0, s, grp);
         LAUNCH_CHECK("gemm_grouped_dw");
+    }
     }
     // reduce the split-K slabs into the caller's grad buffer (+ norm partials, this shard's part of the loss)
     const int nblk = std::min(OPT_MAX_BLOCKS, stream_grid(c->P, OPT_THREADS));

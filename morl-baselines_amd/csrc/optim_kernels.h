@@ -24,8 +24,17 @@ __global__ __launch_bounds__(OPT_THREADS) void grad_reduce_kernel(const float* _
     double ss = 0.0;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P;
          p += (long long)gridDim.x * blockDim.x) {
+        // 8 independent loads in flight per step (the adds stay in slab order -> same bits run to run)
         float g = slabs[p];
-        for (int s = 1; s < splits; ++s) g += slabs[(size_t)s * slab_stride + p];
+        int s = 1;
+        for (; s + 8 <= splits; s += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slabs[(size_t)(s + u) * slab_stride + p];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += v[u];
+        }
+        for (; s < splits; ++s) g += slabs[(size_t)s * slab_stride + p];
         grads[p] = g;
         ss += (double)g * (double)g;
     }

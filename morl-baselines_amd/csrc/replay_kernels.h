@@ -175,12 +175,20 @@ __global__ __launch_bounds__(ST_THREADS) void sumtree_update_kernel(double* __re
             while (j >= 0 && s_node[j] < 0) --j;
             const bool head = (j < 0) || ((s_node[j] >> up) != anc);
             if (!head) continue;
+            // end of the run first (duplicates carry diff 0 and stay inside it: x + 0.0 == x), then a counted loop whose
+            // LDS reads do not depend on the running sum -> they pipeline; only the float64 adds are serial
+            int end = k + 1;
+            while (end < B && (s_node[end] < 0 || (s_node[end] >> up) == anc)) ++end;
             double acc = tree[level_off(l) + anc];
-            for (int e = k; e < B; ++e) {
-                if (s_node[e] < 0) continue;
-                if ((s_node[e] >> up) != anc) break;
-                acc = __dadd_rn(acc, s_diff[e]);
+            int e = k;
+            for (; e + 8 <= end; e += 8) {
+                double d[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) d[u] = s_diff[e + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __dadd_rn(acc, d[u]);
             }
+            for (; e < end; ++e) acc = __dadd_rn(acc, s_diff[e]);
             tree[level_off(l) + anc] = acc;
         }
     }
