@@ -134,8 +134,25 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
         const int q_lo = (n_c * wave) / 4, q_hi = (n_c * (wave + 1)) / 4;
         float best = -INFINITY;
         int best_c = 0x7fffffff;
-        for (int c = q_lo; c < q_hi; ++c) {
-            const float* q = s_qo + (size_t)(c_off + c) * R;     // envelope: wave-uniform address -> LDS broadcast
+        // 4 candidates per step: their LDS reads are independent of the running maximum and overlap
+        int c = q_lo;
+        for (; c + 4 <= q_hi; c += 4) {
+            float sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* q = s_qo + (size_t)(c_off + c + u) * R;   // envelope: wave-uniform address -> LDS broadcast
+                float s = __fmul_rn(wi[0], q[0]);
+#pragma unroll
+                for (int r = 1; r < MORL_MAX_OBJ; ++r)
+                    if (r < R) s = __fadd_rn(s, __fmul_rn(wi[r], q[r]));
+                sv[u] = s;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (sv[u] > best || best_c == 0x7fffffff) { best = sv[u]; best_c = c_off + c + u; }
+        }
+        for (; c < q_hi; ++c) {
+            const float* q = s_qo + (size_t)(c_off + c) * R;
             float s = __fmul_rn(wi[0], q[0]);
 #pragma unroll
             for (int r = 1; r < MORL_MAX_OBJ; ++r)

@@ -45,6 +45,9 @@ struct ChainStep {
     const float* Bt;     // [N][ldbt] the same matrix N-major (row n contiguous over k); needed when N <= 32
     const float* bias;   // [N] or NULL
     const float* mask;   // [rows][ldmask] or NULL: result kept where mask > 0 (ReLU backward)
+    const unsigned long long* bits_in;   // or NULL: the same mask as one 64-bit word per work-item (see bits_out)
+    unsigned long long* bits_out;        // or NULL: (output > 0) of this wide step, packed per work-item in the
+                                         // 64-row tiling: word[(row0/64)*256 + tid], bit (tm*2 + tn)*16 + r
     float* out;          // [rows][ldout] or NULL: global copy of this step's output
     int K, N, ldb, ldbt, ldmask, ldout;
     int relu;
@@ -221,6 +224,12 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
                 if (col_ok) bias0 = st.bias[colw];
                 if (col1_ok) bias1 = st.bias[colw + 1];
             }
+            // ReLU masks travel between the training forward and the backward chain as bits: 8 bytes per work-item
+            // and layer instead of 64 floats (both chains tile [rows][N] identically; a 32-row tile uses its half)
+            unsigned long long bits_w = 0ull, bits_r = 0ull;
+            const size_t bits_idx = (size_t)(row0 >> 6) * CH_THREADS + tid;
+            const int bits_shift = (TM == 32) ? ((row0 >> 5) & 1) * 32 : 0;
+            if (st.bits_in != nullptr) bits_r = st.bits_in[bits_idx] >> bits_shift;
 #pragma unroll
             for (int tm = 0; tm < MT; ++tm) {
 #pragma unroll
@@ -230,7 +239,20 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
                     acc[tm][0][r] = col_ok ? v0 : 0.f;
                     acc[tm][1][r] = col1_ok ? v1 : 0.f;
                 }
-                if (st.mask != nullptr) {
+                if (st.bits_out != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (acc[tm][0][r] > 0.f) bits_w |= 1ull << ((tm * 2 + 0) * 16 + r);
+                        if (acc[tm][1][r] > 0.f) bits_w |= 1ull << ((tm * 2 + 1) * 16 + r);
+                    }
+                }
+                if (st.bits_in != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc[tm][0][r] = ((bits_r >> ((tm * 2 + 0) * 16 + r)) & 1ull) ? acc[tm][0][r] : 0.f;
+                        acc[tm][1][r] = ((bits_r >> ((tm * 2 + 1) * 16 + r)) & 1ull) ? acc[tm][1][r] : 0.f;
+                    }
+                } else if (st.mask != nullptr) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = row0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -262,6 +284,10 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
                         }
                     }
                 }
+            }
+            if (st.bits_out != nullptr) {
+                if (TM == 64) st.bits_out[bits_idx] = bits_w;
+                // (a 32-row forward tile would have to merge two halves: the host only asks for bits with 64-row tiles)
             }
             CH_TICK(3)                                           // wide epilogue
         } else {

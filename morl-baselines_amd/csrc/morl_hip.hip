@@ -136,6 +136,8 @@ struct morl_ctx {
     int dw_wave_tiles = 0;
     bool fused_ok = false;   // architecture fits the fused engine
     bool use_fused = false;  // fused_ok and not disabled by morl_ctx_set_fused
+    unsigned long long* relu_bits[MORL_MAX_LAYERS] = {};  // [l]: (h[l] > 0) packed by the 64-row forward tiling
+    bool bits_valid = false;                               // written by the last training forward
     float* zeros = nullptr;  // 16 zero floats: target of the invalid elements of the chain's operand gathers
     // optional per-launch timing of the dominant kernel (mlp_chain): HIP event pairs on the caller's stream
     bool timing = false;
@@ -184,6 +186,8 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     if (c->loss_part) (void)hipFree(c->loss_part);
     for (hipEvent_t e : c->ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_stop) (void)hipEventDestroy(e);
+    for (int l = 0; l < MORL_MAX_LAYERS; ++l)
+        if (c->relu_bits[l]) (void)hipFree(c->relu_bits[l]);
     if (c->zeros) (void)hipFree(c->zeros);
     if (c->wt_online) (void)hipFree(c->wt_online);
     if (c->wt_target) (void)hipFree(c->wt_target);
@@ -275,6 +279,7 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         if (l >= 1 && (net->dims[l] & 1)) c->dw_wave_ok = false;
         c->dw_wave_tiles += ((net->dims[l + 1] + DW_TILE - 1) / DW_TILE) * ((net->dims[l] + DW_TILE - 1) / DW_TILE);
     }
+    for (int l = 1; l < c->L; ++l) ALLOC(relu_bits[l], ((size_t)c->max_rows + 63) / 64 * CH_THREADS);
     ALLOC(zeros, 16);
     {
         hipError_t ez = hipMemsetAsync(c->zeros, 0, 16 * sizeof(float), nullptr);
@@ -401,7 +406,7 @@ static int launch_chain(morl_ctx* c, const ChainArgs& a, hipStream_t s) {
 // forward chain over rows assembled on the fly from (obs, weights); save => hidden activations to ctx->h[]
 static ChainArgs make_forward_chain(morl_ctx* c, const float* params, const float* wt, const float* obs,
                                     const float* weights, int B, int W, int row_order, int rows, bool save,
-                                    float* q_out, int ldq_out) {
+                                    float* q_out, int ldq_out, bool emit_bits = false) {
     ChainArgs a{};
     a.n_steps = c->L;
     a.rows = rows;
@@ -420,7 +425,11 @@ static ChainArgs make_forward_chain(morl_ctx* c, const float* params, const floa
         st.bias = params + c->offB[l];
         st.relu = last ? 0 : 1;
         if (last) { st.out = q_out; st.ldout = ldq_out; }
-        else if (save) { st.out = c->h[l + 1]; st.ldout = c->net.dims[l + 1]; }
+        else if (save) {
+            st.out = c->h[l + 1];
+            st.ldout = c->net.dims[l + 1];
+            if (emit_bits && st.N > 32) st.bits_out = c->relu_bits[l + 1];
+        }
     }
     return a;
 }
@@ -476,6 +485,7 @@ static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_
         st.N = c->net.dims[l];
         st.mask = c->h[l];
         st.ldmask = c->net.dims[l];
+        if (c->bits_valid && st.N > 32) st.bits_in = c->relu_bits[l];
         st.out = c->g[l - 1];
         st.ldout = c->net.dims[l];
     }
@@ -607,6 +617,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     // materialised wider than this [rows][D+R] block)
     if ((rc = build_input(obs, weights_i, c->x0m, B, WI, D, R, c->ld0, 1, s))) return rc;
     if (!main_fwd_done) {
+        c->bits_valid = false;
         if (c->use_fused) {
             if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights_i, B, WI, 1, rows, true, c->qm, c->ldq, s))) return rc;
         } else {
@@ -786,9 +797,10 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
             if ((rc = chain_forward_x3(
                      c, make_forward_chain(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR),
                      make_forward_chain(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR),
-                     make_forward_chain(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm, c->ldq), s)))
+                     make_forward_chain(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm, c->ldq, true), s)))
                 return rc;
             main_done = true;
+            c->bits_valid = true;   // the multi launch always uses 64-row tiles
         } else {
             if ((rc = chain_forward(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR, s))) return rc;
             if ((rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;

@@ -108,18 +108,14 @@ __global__ __launch_bounds__(ST_THREADS) void sumtree_update_kernel(double* __re
     const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
     const float rmax = (float)(*running_max);
     float lmax = -INFINITY;
-    int npad = 1;
-    while (npad < B) npad <<= 1;
-    for (int k = tid; k < npad; k += nt) {
-        if (k < B) {
+    for (int k = tid; k < B; k += nt) {
+        {
             // alpha < 0: raw already is the priority (plain PrioritizedReplayBuffer.update_priorities)
             const float p = (alpha < 0.f) ? raw[k] : powf(__fadd_rn(raw[k], rmax), alpha);
             s_pr[k] = p;
             if (pr_out) pr_out[k] = (double)p;
             lmax = fmaxf(lmax, p);
             s_key[k] = (idx[k] << 11) | (long long)k;
-        } else {
-            s_key[k] = 0x7fffffffffffffffll;
         }
     }
     lmax = wave_max(lmax);
@@ -131,54 +127,43 @@ __global__ __launch_bounds__(ST_THREADS) void sumtree_update_kernel(double* __re
         // python max(self.min_priority, priorities.max()): keeps the old value unless the new one is larger
         if ((double)m > *running_max) *running_max = (double)m;
     }
-    // bitonic sort of the keys (ascending)
-    for (int size = 2; size <= npad; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int k = tid; k < npad; k += nt) {
-                const int partner = k ^ stride;
-                if (partner > k) {
-                    const bool up = ((k & size) == 0);
-                    const long long a = s_key[k], c = s_key[partner];
-                    if ((a > c) == up) { s_key[k] = c; s_key[partner] = a; }
-                }
-            }
-        }
     __syncthreads();
-    // unique (first occurrence), leaf diffs
+    // rank sort (keys are unique: they embed the position): rank = number of smaller keys, one pass over LDS broadcasts
+    long long my_key = 0;
+    int my_rank = 0;
+    if (tid < B) {
+        my_key = s_key[tid];
+        for (int j = 0; j < B; ++j) my_rank += (s_key[j] < my_key) ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < B) s_key[my_rank] = my_key;
+    __syncthreads();
+    // leaf diffs: the first occurrence of an index carries (priority - leaf), its duplicates 0.0 (x + 0.0 == x), and
+    // EVERY entry keeps its node id so that s_node is non-decreasing (run boundaries by comparison / binary search)
     const int leaf_level = n_levels - 1;
-    for (int k = tid; k < npad; k += nt) {
-        long long node = -1;
-        double diff = 0.0;
-        if (k < B) {
-            const long long id = s_key[k] >> 11;
-            const bool first = (k == 0) || ((s_key[k - 1] >> 11) != id);
-            if (first) {
-                node = id;
-                diff = __dsub_rn((double)s_pr[(int)(s_key[k] & 2047)], tree[level_off(leaf_level) + id]);
-            }
-        }
-        s_node[k] = node;
-        s_diff[k] = diff;
+    for (int k = tid; k < B; k += nt) {
+        const long long id = s_key[k] >> 11;
+        const bool first = (k == 0) || ((s_key[k - 1] >> 11) != id);
+        s_node[k] = id;
+        s_diff[k] = first ? __dsub_rn((double)s_pr[(int)(s_key[k] & 2047)], tree[level_off(leaf_level) + id]) : 0.0;
     }
     __syncthreads();
     // per level: the head of each run of equal ancestors adds that run's diffs in order (the np.add.at order).  Levels
     // touch disjoint memory, so each wave takes its own levels and they proceed concurrently; the critical path is the
-    // root's single run of B sequential float64 adds.
+    // root's single run of B sequential float64 adds, whose LDS reads do not depend on the running sum and pipeline.
     const int lane = lane_id(), wave = wave_id(), n_waves = nt / 64;
     for (int up = wave; up < n_levels; up += n_waves) {
         const int l = leaf_level - up;
         for (int k = lane; k < B; k += 64) {
-            if (s_node[k] < 0) continue;
             const long long anc = s_node[k] >> up;
-            int j = k - 1;                                   // previous valid (non-duplicate) entry
-            while (j >= 0 && s_node[j] < 0) --j;
-            const bool head = (j < 0) || ((s_node[j] >> up) != anc);
+            const bool head = (k == 0) || ((s_node[k - 1] >> up) != anc);
             if (!head) continue;
-            // end of the run first (duplicates carry diff 0 and stay inside it: x + 0.0 == x), then a counted loop whose
-            // LDS reads do not depend on the running sum -> they pipeline; only the float64 adds are serial
-            int end = k + 1;
-            while (end < B && (s_node[end] < 0 || (s_node[end] >> up) == anc)) ++end;
+            int lo = k + 1, hi = B;                            // first index whose ancestor differs (binary search)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if ((s_node[mid] >> up) == anc) lo = mid + 1; else hi = mid;
+            }
+            const int end = lo;
             double acc = tree[level_off(l) + anc];
             int e = k;
             for (; e + 8 <= end; e += 8) {
