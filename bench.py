@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--weights", type=int, default=64)
     ap.add_argument("--engine", type=int, default=None)
+    ap.add_argument("--dw-mode", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -138,6 +139,8 @@ def main():
                      tau=1.0, target_net_update_freq=200, envelope=True, num_sample_w=W, per=bool(a.per),
                      per_alpha=0.6, buffer_size=100_000, gradient_updates=1, log=False, seed=0, device=dev,
                      engine=a.engine)
+    if a.dw_mode is not None:
+        agent.q_net.ctx.set_dw_mode(a.dw_mode)
     fill_buffer(agent.replay_buffer, 20_000, seed=0)
     agent.global_step = 1001
     if world > 1:

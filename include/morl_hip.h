@@ -92,6 +92,9 @@ int morl_ctx_destroy(morl_ctx* ctx);
  * 2 / 3 = layer-fused chain with the row tile forced to 64 / 32.  The fused engine needs widths <= 256 and hidden
  * widths % 4 == 0.  Returns the engine now active (0..3), < 0 on error. */
 int morl_ctx_set_fused(morl_ctx* ctx, int enable);
+/* Weight-gradient engine: 0 = wave-level tiles streaming both operands HBM -> registers (dw_wave.h), 1 = 128x128
+ * double-buffered LDS tiles, two workgroups per CU (default), 2 = the single-buffered tiles of the per-layer engine. */
+int morl_ctx_set_dw_mode(morl_ctx* ctx, int mode);
 /* Per-launch timing of the dominant kernel (the layer-fused MLP chain): when enabled, every chain launch is bracketed
  * by a HIP event pair on the caller's stream.  morl_ctx_read_timing blocks until the recorded launches have finished,
  * returns their number and summed duration (ms) and clears the record.  Used by bench.py for the roofline figure. */

@@ -192,4 +192,86 @@ __device__ __forceinline__ void gemm_tile(const GemmProblem& g, int tile_m, int 
         g.colsum[(size_t)split * g.colsum_stride + m0 + (int)threadIdx.x] = colsum;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Double-buffered variant for the weight-gradient GEMM (both operands M/N-contiguous, i.e. straight 16-byte copies
+// into the K-major LDS image): one barrier per 32-deep chunk, the next chunk's global loads in flight under the MFMAs
+// and written to the OTHER LDS buffer afterwards, operand reads of k-pair j+1 issued before the MFMAs of k-pair j.
+// 67.6 KB of LDS -> two workgroups per CU overlap each other's barriers and epilogues.
+// ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void gemm_tile_tn_db(const GemmProblem& g, int tile_m, int tile_n, int split) {
+    __shared__ __attribute__((aligned(16))) float sA[2][GEMM_BK * GEMM_LD_N];
+    __shared__ __attribute__((aligned(16))) float sB[2][GEMM_BK * GEMM_LD_N];
+    constexpr int LD = GEMM_LD_N;
+    const int m0 = tile_m * GEMM_BM, n0 = tile_n * GEMM_BN;
+    const int kbeg = split * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+    const int lane = lane_id(), wave = wave_id();
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, i = lane & 31;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float colsum = 0.f;
+    const bool do_colsum = (g.colsum != nullptr) && (tile_n == 0);
+
+    Stage<false> ra, rb;
+    if (kbeg < kend) {
+        load_chunk<false>(ra, g.A, g.lda, m0, g.M, kbeg, kend, g.a_vec);
+        load_chunk<false>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, g.b_vec);
+        store_chunk<false>(ra, sA[0]);
+        store_chunk<false>(rb, sB[0]);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
+        const bool more = k0 + GEMM_BK < kend;
+        if (more) {
+            load_chunk<false>(ra, g.A, g.lda, m0, g.M, k0 + GEMM_BK, kend, g.a_vec);
+            load_chunk<false>(rb, g.B, g.ldb, n0, g.N, k0 + GEMM_BK, kend, g.b_vec);
+        }
+        const float* pa = sA[buf] + h * LD + wm * 64 + i;
+        const float* pb = sB[buf] + h * LD + wn * 64 + i;
+        float a0 = pa[0], a1 = pa[32], b0 = pb[0], b1 = pb[32];
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK; kk += 2) {
+            const int kn = (kk + 2 < GEMM_BK) ? kk + 2 : kk;
+            const float na0 = pa[kn * LD], na1 = pa[kn * LD + 32];
+            const float nb0 = pb[kn * LD], nb1 = pb[kn * LD + 32];
+            acc[0][0] = mfma32(a0, b0, acc[0][0]);
+            acc[0][1] = mfma32(a0, b1, acc[0][1]);
+            acc[1][0] = mfma32(a1, b0, acc[1][0]);
+            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        if (do_colsum && threadIdx.x < GEMM_BM) {
+#pragma unroll 8
+            for (int kk = 0; kk < GEMM_BK; ++kk) colsum += sA[buf][kk * LD + (int)threadIdx.x];
+        }
+        if (more) {
+            store_chunk<false>(ra, sA[buf ^ 1]);
+            store_chunk<false>(rb, sB[buf ^ 1]);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* __restrict__ C = g.C + (size_t)split * g.c_split_stride;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int col = n0 + wn * 64 + tn * 32 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < g.M && col < g.N) C[(size_t)row * g.ldc + col] = acc[tm][tn][r];
+            }
+        }
+    if (do_colsum && threadIdx.x < GEMM_BM && m0 + (int)threadIdx.x < g.M)
+        g.colsum[(size_t)split * g.colsum_stride + m0 + (int)threadIdx.x] = colsum;
+}
+
 }  // namespace morl

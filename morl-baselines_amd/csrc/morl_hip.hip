@@ -86,6 +86,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_grouped_tn_kernel(GemmGroup
     gemm_tile<false, false, EPI_STORE>(g, local / g.tiles_n, local % g.tiles_n, (int)blockIdx.y);
 }
 
+// same work, double-buffered LDS tiles, two workgroups per CU (see gemm_tile_tn_db)
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_grouped_tn_db_kernel(GemmGroup grp) {
+    const int id = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    int q = 0;
+    while (q + 1 < grp.n && id >= grp.tile_start[q + 1]) ++q;
+    const int local = id - grp.tile_start[q];
+    const GemmProblem& g = grp.p[q];
+    gemm_tile_tn_db(g, local / g.tiles_n, local % g.tiles_n, (int)blockIdx.y);
+}
+
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst,
                                                         int ldd, long long rows, int cols) {
     const long long total = rows * cols;
@@ -132,6 +142,8 @@ struct morl_ctx {
     int64_t wt_count = 0;
     int64_t offWt[MORL_MAX_LAYERS];
     int ldn[MORL_MAX_LAYERS];
+    int dw_mode = 1;         // weight-gradient engine: 0 wave-level tiles (dw_wave.h), 1 double-buffered LDS tiles,
+                             // 2 single-buffered LDS tiles (the per-layer engine's)
     bool dw_wave_ok = false; // wave-level dW kernel usable (all operand row strides even)
     int dw_wave_tiles = 0;
     bool fused_ok = false;   // architecture fits the fused engine
@@ -500,6 +512,13 @@ extern "C" int morl_ctx_set_fused(morl_ctx* c, int enable) {
     return c->use_fused ? (enable >= 1 && enable <= 3 ? enable : 1) : 0;
 }
 
+extern "C" int morl_ctx_set_dw_mode(morl_ctx* c, int mode) {
+    if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
+    if (mode < 0 || mode > 2) return fail(MORL_ERR_ARG, "dw mode must be 0, 1 or 2");
+    c->dw_mode = mode;
+    return MORL_OK;
+}
+
 extern "C" int morl_ctx_set_timing(morl_ctx* c, int enable) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     c->timing = enable != 0;
@@ -662,7 +681,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         }
     // all dW / db of the step in one split-K launch
     int splits;
-    if (c->dw_wave_ok && c->use_fused) {
+    if (c->dw_wave_ok && c->use_fused && c->dw_mode == 0) {
         // wave-level tiles (dw_wave.h): aim at one wave per SIMD over the whole chip
         splits = std::max(1, std::min(c->max_splits, (4 * c->num_cus + c->dw_wave_tiles / 2) / c->dw_wave_tiles));
         int kps = round_up((rows + splits - 1) / splits, DW_CHUNK);
@@ -691,7 +710,9 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         hipLaunchKernelGGL(dw_wave_kernel, dim3(t, splits), dim3(64), 0, s, a);
         LAUNCH_CHECK("dw_wave");
     } else {
-    splits = std::max(1, std::min(c->max_splits, (256 + c->dw_tiles - 1) / c->dw_tiles));
+    const bool db = (c->dw_mode == 1);
+    // double-buffered tiles run two workgroups per CU: twice as many, half as long row slices
+    splits = std::max(1, std::min(c->max_splits, ((db ? 2 : 1) * c->num_cus + c->dw_tiles - 1) / c->dw_tiles));
     int kps = round_up((rows + splits - 1) / splits, GEMM_BK);
     splits = (rows + kps - 1) / kps;
     {
@@ -719,7 +740,8 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             t += g.tiles_m * g.tiles_n;
         }
         grp.tile_start[L] = t;
-        hipLaunchKernelGGL(gemm_grouped_tn_kernel, dim3(t, splits), dim3(GEMM_THREADS), 0, s, grp);
+        if (db) hipLaunchKernelGGL(gemm_grouped_tn_db_kernel, dim3(t, splits), dim3(GEMM_THREADS), 0, s, grp);
+        else hipLaunchKernelGGL(gemm_grouped_tn_kernel, dim3(t, splits), dim3(GEMM_THREADS), 0, s, grp);
         LAUNCH_CHECK("gemm_grouped_dw");
     }
     }

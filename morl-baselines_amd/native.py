@@ -44,6 +44,7 @@ _SIGNATURES = {
     "morl_ctx_destroy": (C.c_int, [C.c_void_p]),
     "morl_param_count": (C.c_int64, [C.POINTER(NetDesc)]),
     "morl_ctx_set_fused": (C.c_int, [C.c_void_p, C.c_int]),
+    "morl_ctx_set_dw_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "morl_ctx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "morl_ctx_read_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "morl_gather_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] +

@@ -33,6 +33,10 @@ class QNetContext:
         self.engine = int(self.lib.lib.morl_ctx_set_fused(self.handle, DEFAULT_ENGINE if fused is None else int(fused)))
         self.fused = self.engine > 0
 
+    def set_dw_mode(self, mode: int) -> None:
+        """Weight-gradient engine: 0 wave-level tiles, 1 double-buffered LDS tiles (default), 2 single-buffered."""
+        self.lib.check(self.lib.lib.morl_ctx_set_dw_mode(self.handle, int(mode)))
+
     def set_timing(self, enable: bool) -> None:
         self.lib.check(self.lib.lib.morl_ctx_set_timing(self.handle, int(enable)))
 

@@ -42,8 +42,10 @@ def relmax(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def run_update(lib, dev, c, inp, apply_step=True, debug=True, fused=None):
+def run_update(lib, dev, c, inp, apply_step=True, debug=True, fused=None, dw_mode=None):
     ctx = ops.QNetContext(c.D, c.R, c.A, c.arch, c.B, c.W, lib=lib, fused=fused)
+    if dw_mode is not None:
+        ctx.set_dw_mode(dw_mode)
     t = dict(
         po=flat(inp["online"]).to(dev), pt=flat(inp["target"]).to(dev), m=flat(inp["exp_avg"]).to(dev),
         v=flat(inp["exp_avg_sq"]).to(dev), obs=th.tensor(inp["obs"]).to(dev), nobs=th.tensor(inp["next_obs"]).to(dev),
@@ -133,6 +135,16 @@ def test_envelope_update_vs_reference_golden(be, c):
         assert float((gr[o0:o0 + n][::s] - th.tensor(g[f"grad_{i}"])).abs().max()) <= 5e-5 * gmax
     pr = (res["priority"].cpu().numpy() + np.float32(0.125)) ** np.float32(0.6)
     np.testing.assert_allclose(pr, g["priority_final"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("dw_mode", [0, 1, 2])
+def test_weight_gradient_engines_agree_with_oracle(be, dw_mode):
+    lib, dev, _ = be
+    c = [c for c in CASES if c.name == "flagship_b32w8"][0]
+    inp = make_inputs(c)
+    res, t = run_update(lib, dev, c, inp, dw_mode=dw_mode)
+    o, online, m, v = run_oracle(c, inp)
+    check_update(res, t, o, online, m, v, c)
 
 
 def test_grads_only_leaves_state_untouched(be):
