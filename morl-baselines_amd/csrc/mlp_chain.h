@@ -287,7 +287,8 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
             }
             if (st.bits_out != nullptr) {
                 if (TM == 64) st.bits_out[bits_idx] = bits_w;
-                // (a 32-row forward tile would have to merge two halves: the host only asks for bits with 64-row tiles)
+                else   // a 32-row tile owns one 32-bit half of the word (rows 0-31 / 32-63 of the 64-row band)
+                    reinterpret_cast<unsigned int*>(st.bits_out)[2 * bits_idx + ((row0 >> 5) & 1)] = (unsigned int)bits_w;
             }
             CH_TICK(3)                                           // wide epilogue
         } else {
@@ -382,6 +383,13 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain64_multi_kernel(ChainM
     int q = 0;
     while (q + 1 < m.n && bid >= m.tile_start[q + 1]) ++q;
     mlp_chain_body<64>(m.p[q], bid - m.tile_start[q]);
+}
+// 32-row tiles, three workgroups per CU (<= 170 registers): 3 x rows/32 workgroups = two full rounds of the chip
+__global__ __launch_bounds__(CH_THREADS, 3) void mlp_chain32_multi_kernel(ChainMulti m) {
+    const int bid = (int)blockIdx.x;
+    int q = 0;
+    while (q + 1 < m.n && bid >= m.tile_start[q + 1]) ++q;
+    mlp_chain_body<32>(m.p[q], bid - m.tile_start[q]);
 }
 
 // W_l [N][K] (nn.Linear layout) -> Wt_l [K][ldn] with ldn = round_up(N, 4), zero padded: the K-major copy the

@@ -142,6 +142,7 @@ struct morl_ctx {
     int64_t wt_count = 0;
     int64_t offWt[MORL_MAX_LAYERS];
     int ldn[MORL_MAX_LAYERS];
+    int multi_tm = 64;       // row tile of the three-forward-passes launch (64: 2 workgroups / CU, 32: 3 / CU)
     int dw_mode = 1;         // weight-gradient engine: 0 wave-level tiles (dw_wave.h), 1 double-buffered LDS tiles,
                              // 2 single-buffered LDS tiles (the per-layer engine's)
     bool dw_wave_ok = false; // wave-level dW kernel usable (all operand row strides even)
@@ -456,8 +457,9 @@ static int chain_forward_x3(morl_ctx* c, const ChainArgs& a0, const ChainArgs& a
     ChainMulti m{};
     m.n = 3;
     m.p[0] = a0; m.p[1] = a1; m.p[2] = a2;
+    const int tm = c->multi_tm;
     int t = 0;
-    for (int q = 0; q < 3; ++q) { m.tile_start[q] = t; t += (m.p[q].rows + 63) / 64; }
+    for (int q = 0; q < 3; ++q) { m.tile_start[q] = t; t += (m.p[q].rows + tm - 1) / tm; }
     m.tile_start[3] = t;
     size_t slot = 0;
     if (c->timing) {
@@ -471,7 +473,8 @@ static int chain_forward_x3(morl_ctx* c, const ChainArgs& a0, const ChainArgs& a
         slot = c->ev_used++;
         HIP_TRY(hipEventRecord(c->ev_start[slot], s));
     }
-    hipLaunchKernelGGL(mlp_chain64_multi_kernel, dim3(t), dim3(CH_THREADS), 0, s, m);
+    if (tm == 64) hipLaunchKernelGGL(mlp_chain64_multi_kernel, dim3(t), dim3(CH_THREADS), 0, s, m);
+    else hipLaunchKernelGGL(mlp_chain32_multi_kernel, dim3(t), dim3(CH_THREADS), 0, s, m);
     LAUNCH_CHECK("mlp_chain_multi");
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_stop[slot], s));
     return MORL_OK;
@@ -514,8 +517,11 @@ extern "C" int morl_ctx_set_fused(morl_ctx* c, int enable) {
 
 extern "C" int morl_ctx_set_dw_mode(morl_ctx* c, int mode) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
-    if (mode < 0 || mode > 2) return fail(MORL_ERR_ARG, "dw mode must be 0, 1 or 2");
-    c->dw_mode = mode;
+    // low decimal digit: dW engine (0, 1, 2); tens digit: row tile of the three-pass forward launch (0: 64, 1: 32)
+    const int dw = mode % 10, mt = mode / 10;
+    if (dw < 0 || dw > 2 || mt < 0 || mt > 1) return fail(MORL_ERR_ARG, "bad tuning mode %d", mode);
+    c->dw_mode = dw;
+    c->multi_tm = mt ? 32 : 64;
     return MORL_OK;
 }
 
