@@ -101,6 +101,23 @@ def cpu_baseline(batch, weights, per, budget_s=25.0):
                       f"(oracle/envelope_oracle.py, B={batch}, W={weights}, W^2*B-row targets) on torch-CPU, median"}
 
 
+def measured_chain_traffic():
+    """HBM bytes per mlp_chain launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected as
+    MI355X_MICROARCH.md prescribes; profiles/*_pmc_summary.json).  PMC counters cannot be read from inside this
+    process, so the figure is the one measured offline on this same command; None if no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+        sel = [v for k, v in ks.items() if k.startswith("morl::mlp_chain")]
+        n = sum(v["launches"] for v in sel)
+        return sum(v["hbm_bytes"] * v["launches"] for v in sel) / n if n else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,7 +227,8 @@ def main():
             "last_loss": loss,
             "roofline": {"bound": "mfma", "kernel": "mlp_chain (layer-fused Q-net forward / backward-dX)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_chain_traffic(),
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
                          "launches_timed": n_chain, "avg_launch_us": avg_launch_s * 1e6,
                          "algorithmic_flop_per_launch": flop_per_launch,
                          "whole_step_algorithmic_tflops": rows_step * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW +
