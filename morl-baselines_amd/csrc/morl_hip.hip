@@ -457,7 +457,9 @@ static int chain_forward_x3(morl_ctx* c, const ChainArgs& a0, const ChainArgs& a
     ChainMulti m{};
     m.n = 3;
     m.p[0] = a0; m.p[1] = a1; m.p[2] = a2;
-    const int tm = c->multi_tm;
+    // 64-row tiles unless that leaves the chip under-filled (small shards of a weight-sharded job): then 32
+    int tm = c->multi_tm;
+    if (tm == 64 && (a0.rows + a1.rows + a2.rows + 63) / 64 < 2 * c->num_cus) tm = 32;
     int t = 0;
     for (int q = 0; q < 3; ++q) { m.tile_start[q] = t; t += (m.p[q].rows + tm - 1) / tm; }
     m.tile_start[3] = t;
