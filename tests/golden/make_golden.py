@@ -20,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
 
 import ref_harness as rh  # noqa: E402
 from cases import CASES, FLAGSHIP, Case, make_inputs, pareto_sets  # noqa: E402
@@ -146,8 +147,44 @@ def per_trace(ref) -> dict:
     return out
 
 
+TRAIN_CFG = dict(learning_rate=1e-3, net_arch=[64, 64], batch_size=32, gamma=0.95, num_sample_w=4, per=True,
+                 buffer_size=10000, learning_starts=100, initial_epsilon=1.0, final_epsilon=0.05,
+                 epsilon_decay_steps=6000, target_net_update_freq=100)
+TRAIN_STEPS, TRAIN_CHUNKS, TRAIN_SEED = 12000, 4, 0
+HV_REF = (-0.5, -20.0)
+
+
+def train_trace(ref) -> dict:
+    """Train the reference's Envelope agent on ``momdp.TreasureLine`` and record the hypervolume of its greedy front
+    after each quarter of the run -- the "HV after equal gradient steps" anchor of tests/test_train_hv.py."""
+    import momdp
+
+    th.set_num_threads(1)
+    np.random.seed(TRAIN_SEED)                      # PER sampling draws from the global numpy stream
+    ref.envelope.equally_spaced_weights = lambda *a, **k: None   # pymoo (absent); its result is unused w/o eval_env
+    env = momdp.TreasureLine(TRAIN_SEED)
+    ag = ref.envelope.Envelope(env, log=False, seed=TRAIN_SEED, device="cpu", **TRAIN_CFG)
+    out = {f"init_{i}": p.detach().numpy().copy() for i, p in enumerate(ag.q_net.parameters())}
+    weights = momdp.equally_spaced_weights_2d(11)
+    ev = momdp.TreasureLine(TRAIN_SEED)
+    hv = []
+    for chunk in range(TRAIN_CHUNKS):
+        ag.train(total_timesteps=TRAIN_STEPS // TRAIN_CHUNKS, reset_num_timesteps=(chunk == 0))
+        front = momdp.greedy_front(ag, ev, weights)
+        hv.append(momdp.hypervolume_2d(front, HV_REF))
+    out["hv"] = np.asarray(hv)
+    out["front"] = front
+    out["actions"] = np.asarray(env.action_log[:2000], dtype=np.int8)
+    return out
+
+
 def main():
     ref = rh.import_reference()
+    if "--train-only" in sys.argv:
+        tr = train_trace(ref)
+        np.savez_compressed(os.path.join(HERE, "train_trace.npz"), **tr)
+        print("train trace: HV per quarter", tr["hv"])
+        return
     for c in CASES:
         out = run_case(ref, c)
         np.savez_compressed(os.path.join(HERE, f"envelope_{c.name}.npz"), **out)
@@ -171,6 +208,9 @@ def main():
     misc["huber"] = np.float32(ref.networks.huber(x, 0.01).item())
     misc["huber_x"] = x.numpy()
     np.savez_compressed(os.path.join(HERE, "misc.npz"), **misc)
+    tr = train_trace(ref)
+    np.savez_compressed(os.path.join(HERE, "train_trace.npz"), **tr)
+    print("train trace: HV per quarter", tr["hv"])
     print("golden fixtures written to", HERE)
 
 
