@@ -147,3 +147,15 @@ def fill_buffer_synthetic(buf, n, obs_dim, n_actions, reward_dim, seed=0):
         next_obs = rng.standard_normal(obs_dim).astype(np.float32)
         done = rng.random() < 0.05
         buf.add(obs, action, reward, next_obs, done)
+
+
+def import_reference_ac():
+    """The continuous-action actor-critic agents (CAPQL, MOSAC, GPI-PD continuous) of the reference, unmodified."""
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    install_stubs()
+    from morl_baselines.multi_policy.capql import capql
+    from morl_baselines.multi_policy.gpi_pd import gpi_pd_continuous_action as gpipd_cont
+    from morl_baselines.single_policy.ser import mosac_continuous_action as mosac
+
+    return types.SimpleNamespace(capql=capql, mosac=mosac, gpipd_cont=gpipd_cont)

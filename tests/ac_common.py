@@ -1,0 +1,103 @@
+"""Shared by the actor-critic oracle / kernel parity tests: run the ORACLE on a golden case, compare with a fixture."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch as th
+
+import ac_oracle as ac
+from cases_ac import ACCase, make_inputs, specs
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(c: ACCase):
+    return np.load(os.path.join(GOLDEN_DIR, f"ac_{c.name}.npz"))
+
+
+def gpipd_rows(c: ACCase, inp):
+    """The (possibly doubled) batch and per-row weights of gpi_pd_continuous_action.py:381-393."""
+    keys = ("obs", "actions", "rewards", "next_obs", "dones")
+    batch = [th.tensor(inp[k]) for k in keys]
+    if c.n_support > 1:
+        batch = [b.repeat(2, 1) for b in batch]
+        w = th.vstack([th.tensor(inp["weight"])] * c.B + [th.tensor(inp["support"][i]) for i in inp["choice"][:c.B]])
+    else:
+        w = th.tensor(inp["weight"]).repeat(c.B, 1)
+    return batch, w
+
+
+def run_oracle(c: ACCase, inp=None):
+    """Returns (state dict of parameter lists AFTER the update, oracle output dict)."""
+    inp = inp or make_inputs(c)
+    qspec, trunk = specs(c)
+    st = dict(q=[ac.clone(n) for n in inp["q"]], tq=[ac.clone(n) for n in inp["tq"]], pol=ac.clone(inp["pol"]),
+              q_state={k: ac.clone(v) for k, v in inp["q_state"].items()},
+              p_state={k: ac.clone(v) for k, v in inp["p_state"].items()})
+    T = th.tensor
+    if c.algo == "capql":
+        batch = (T(inp["obs"]), T(inp["actions"]), T(inp["w"]), T(inp["rewards"]), T(inp["next_obs"]),
+                 T(inp["dones"]).reshape(-1))
+        out = ac.capql_update(qspec, trunk, st["q"], st["tq"], st["pol"], st["q_state"], st["p_state"], batch,
+                              T(inp["eps_next"]), T(inp["eps_pi"][0]), inp["scale"], inp["bias"], gamma=c.gamma,
+                              alpha=c.alpha, lr=c.lr, tau=c.tau, step=c.step)
+    elif c.algo == "mosac":
+        st["log_alpha"] = th.tensor([c.log_alpha0])
+        st["al_state"] = {k: ac.clone(v) for k, v in inp["al_state"].items()}
+        batch = tuple(T(inp[k]) for k in ("obs", "actions", "rewards", "next_obs", "dones"))
+        alpha = float(np.exp(np.float32(c.log_alpha0))) if c.autotune else c.alpha
+        if c.autotune:
+            alpha = th.tensor([c.log_alpha0]).exp().item()
+        out = ac.mosac_update(qspec, trunk, st["q"], st["tq"], st["pol"], st["log_alpha"], st["q_state"],
+                              st["p_state"], st["al_state"], batch, T(inp["weights"]), T(inp["eps_next"]),
+                              [T(e) for e in inp["eps_pi"]], [T(e) for e in inp["eps_alpha"]], inp["scale"],
+                              inp["bias"], gamma=c.gamma, tau=c.tau, q_lr=c.q_lr, policy_lr=c.lr, q_step=c.step,
+                              a_step=c.step, policy_freq=c.policy_freq,
+                              do_policy=(c.global_step % c.policy_freq == 0), do_target=True, autotune=c.autotune,
+                              alpha=alpha, target_entropy=-float(c.Ad))
+    else:
+        st["tpol"] = ac.clone(inp["tpol"])
+        batch, w = gpipd_rows(c, inp)
+        drop = {k: [[T(m) for m in net] for net in v] for k, v in inp["drop"].items()}
+        out = ac.gpipd_cont_update(qspec, trunk, st["q"], st["tq"], st["pol"], st["tpol"], st["q_state"],
+                                   st["p_state"], batch, w, T(inp["eps_next"]), drop, inp["scale"], inp["bias"],
+                                   gamma=c.gamma, lr=c.lr, tau=c.tau, q_step=c.step, p_step=c.step,
+                                   do_policy=(c.n_updates % 2 == 0), n_per=(c.B if c.per else None))
+    return st, out
+
+
+def _cmp(name, got, want, sub, rtol, atol):
+    got = np.asarray(got, dtype=np.float64).reshape(-1)[::sub]
+    want = np.asarray(want, dtype=np.float64).reshape(-1)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    err = np.abs(got - want)
+    tol = atol + rtol * np.abs(want)
+    assert (err <= tol).all(), f"{name}: max err {err.max():.3e} (tol {tol[np.argmax(err - tol)]:.3e})"
+
+
+def check_against_golden(c: ACCase, st, g, *, q_opt=None, p_opt=None, rtol=2e-5, lr_frac=0.02):
+    """st: parameter lists after the update; q_opt / p_opt: dicts with exp_avg / exp_avg_sq lists (chained order)."""
+    s = c.subsample
+    nq = len(st["q"][0])
+    # a first Adam step moves every entry by ~lr * g / (|g| + eps): entries whose gradient is ~eps-sized amplify
+    # 1e-9 absolute gradient differences into a fraction of lr, hence the lr-relative absolute term
+    pa = lr_frac * max(c.lr, c.q_lr if c.algo == "mosac" else 0.0)
+    for n in range(2):
+        for i in range(nq):
+            _cmp(f"q{n}_{i}", st["q"][n][i], g[f"q{n}_{i}"], s, rtol, pa)
+            _cmp(f"tq{n}_{i}", st["tq"][n][i], g[f"tq{n}_{i}"], s, rtol, pa)
+            if q_opt is not None:
+                j = n * nq + i
+                m_scale = float(np.abs(g[f"q{n}_m_{i}"]).max()) + 1e-12
+                _cmp(f"q{n}_m_{i}", q_opt["exp_avg"][j], g[f"q{n}_m_{i}"], s, 1e-4, 2e-5 * m_scale)
+                v_scale = float(np.abs(g[f"q{n}_v_{i}"]).max()) + 1e-30
+                _cmp(f"q{n}_v_{i}", q_opt["exp_avg_sq"][j], g[f"q{n}_v_{i}"], s, 2e-4, 2e-5 * v_scale)
+    for i in range(len(st["pol"])):
+        _cmp(f"pol_{i}", st["pol"][i], g[f"pol_{i}"], s, rtol, pa)
+        if p_opt is not None and f"pol_m_{i}" in g:
+            m_scale = float(np.abs(g[f"pol_m_{i}"]).max()) + 1e-12
+            _cmp(f"pol_m_{i}", p_opt["exp_avg"][i], g[f"pol_m_{i}"], s, 1e-4, 5e-5 * m_scale)
+    if "tpol" in st:
+        for i in range(len(st["tpol"])):
+            _cmp(f"tpol_{i}", st["tpol"][i], g[f"tpol_{i}"], s, rtol, pa)
