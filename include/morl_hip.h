@@ -31,7 +31,7 @@ extern "C" {
 
 #define MORL_MAX_LAYERS 8   /* linear layers per network */
 #define MORL_MAX_OBJ 8      /* reward dimension R */
-#define MORL_ABI_VERSION 1
+#define MORL_ABI_VERSION 2
 
 typedef enum morl_status {
     MORL_OK = 0,
@@ -184,6 +184,137 @@ int morl_sumtree_set(double* tree, int n_levels, const int64_t* ptr, const doubl
                      double* running_max, void* stream);
 int morl_sumtree_update(double* tree, int n_levels, const int64_t* idx, const float* raw, int B, double alpha,
                         double* running_max, double* pr_out, void* stream);
+
+/* ================================================================================================
+ * Continuous-action actor-critic updates: CAPQL, MOSAC (the MORL/D subproblem learner) and
+ * GPI-PD / GPI-LS with continuous actions (TD3 style).
+ *
+ * Replaces the arithmetic of
+ *   CAPQL.update                       multi_policy/capql/capql.py:321-349        (+ Policy :100-158, QNetwork :161-173)
+ *   MOSAC.update                       single_policy/ser/mosac_continuous_action.py:430-489 (+ actor :60-123, critic :28-57)
+ *   MORLD.__update_others              multi_policy/morld/morld.py:423-433  (population > 1: every subproblem's
+ *                                      MOSAC.update advanced by the same launches)
+ *   GPIPDContinuousAction.update       multi_policy/gpi_pd/gpi_pd_continuous_action.py:373-434 (+ Policy :34-58,
+ *                                      QNetwork :61-73 with LayerNorm / Dropout from common/networks.py:10-48)
+ *
+ * A context advances `population` independent learners of identical shape per call; every array below has
+ * the learner index as its slowest axis ([pop] ...).  population == 1 for CAPQL / GPI-PD / a single MOSAC.
+ *
+ * Flat parameter layouts (fp32; the torch nn.Parameters of the host classes are views into them):
+ *   Q-net   in = D + Ad (+ R when the critic is weight-conditioned: CAPQL, TD3), for each hidden layer l:
+ *           W_l [h_l][in_l], b_l [h_l], then LayerNorm gamma_l [h_l], beta_l [h_l] when q_layer_norm; finally
+ *           W_out [R][h_last], b_out [R].                          = nn.Sequential.parameters() order.
+ *   policy  in = D (+ R when weight-conditioned), hidden layers W_l, b_l (no LayerNorm), then the heads as ONE
+ *           linear layer: W_head [heads*Ad][h_last], b_head [heads*Ad]; heads = 2 (rows 0..Ad-1 = mean, rows
+ *           Ad..2Ad-1 = log_std) for CAPQL / MOSAC, heads = 1 (mean) for TD3.
+ *   critics of a learner are contiguous: q[pop][num_q][Pq]; one Adam state over all of them (the reference
+ *   chains the Q-nets' parameters into one optimiser).
+ * Random draws are INPUTS (device arrays the host fills from its generator): re-parameterisation noise eps,
+ * TD3 target-policy noise.  Dropout keep-masks are generated on the device from cfg.dropout_seed unless explicit
+ * masks are passed (parity tests).
+ * ================================================================================================ */
+#define MORL_AC_CAPQL 0
+#define MORL_AC_MOSAC 1
+#define MORL_AC_TD3 2
+
+typedef struct morl_ac_ctx morl_ac_ctx;
+
+typedef struct morl_ac_desc {
+    int32_t algo;                    /* MORL_AC_* */
+    int32_t obs_dim, act_dim, reward_dim;
+    int32_t n_hidden;                /* len(net_arch), 1 .. MORL_MAX_LAYERS-1 */
+    int32_t hidden[MORL_MAX_LAYERS]; /* net_arch, shared by the policy and the Q-nets (as in the reference) */
+    int32_t num_q;                   /* Q-networks per learner (reference default 2; MOSAC: exactly 2) */
+    int32_t q_layer_norm;            /* LayerNorm(eps 1e-5, affine) after every hidden Linear of the Q-nets */
+    float q_drop_rate;               /* Dropout p after every hidden Linear of the Q-nets (before LayerNorm) */
+    int32_t population;              /* learners advanced per call */
+    int32_t max_rows;                /* largest number of batch rows of one learner (2 * batch_size for GPI-PD) */
+} morl_ac_desc;
+
+typedef struct morl_ac_cfg {
+    float gamma, tau;
+    float alpha;                     /* entropy coefficient when it is not learnt (CAPQL; MOSAC autotune = 0) */
+    double q_lr, policy_lr, alpha_lr;
+    double beta1, beta2, eps;        /* torch.optim.Adam defaults 0.9 / 0.999 / 1e-8 */
+    int32_t q_step;                  /* 1-based Adam step of the critic optimiser taken by this call */
+    int32_t policy_step;             /* 1-based Adam step of the FIRST actor iteration of this call */
+    int32_t do_policy;               /* run the actor update (delayed policy updates) */
+    int32_t policy_iters;            /* MOSAC: policy_freq inner actor iterations; otherwise 1 */
+    int32_t do_target;               /* polyak the target critics (MOSAC: target_net_freq) */
+    int32_t autotune;                /* MOSAC: learn log_alpha */
+    float target_entropy;            /* MOSAC: -prod(action_shape) */
+    float policy_noise, noise_clip;  /* TD3 target policy smoothing */
+    int32_t n_per;                   /* TD3: rows whose |TD| priorities are written (0 = none) */
+    uint64_t dropout_seed;           /* changes every call */
+} morl_ac_cfg;
+
+/* caller-owned device state of the learners */
+typedef struct morl_ac_state {
+    float* q;            /* [pop][num_q][Pq] */
+    float* q_target;     /* [pop][num_q][Pq] */
+    float* q_exp_avg;    /* [pop][num_q][Pq] */
+    float* q_exp_avg_sq;
+    float* pol;          /* [pop][Pp] */
+    float* pol_exp_avg;
+    float* pol_exp_avg_sq;
+    float* pol_target;   /* [pop][Pp]  TD3 only */
+    float* log_alpha;    /* [pop]  MOSAC autotune only */
+    float* log_alpha_exp_avg;
+    float* log_alpha_exp_avg_sq;
+    const float* action_scale;  /* [Ad]  (high - low) / 2 */
+    const float* action_bias;   /* [Ad]  (high + low) / 2 */
+} morl_ac_state;
+
+typedef struct morl_ac_batch {
+    int32_t rows;               /* batch rows per learner */
+    const float* obs;           /* [pop][rows][D] */
+    const float* actions;       /* [pop][rows][Ad] */
+    const float* rewards;       /* [pop][rows][R] */
+    const float* next_obs;      /* [pop][rows][D] */
+    const float* dones;         /* [pop][rows] */
+    const float* w;             /* CAPQL / TD3: per-row weights [pop][rows][R]; MOSAC: [pop][R] */
+    const float* eps_next;      /* [pop][rows][Ad]  N(0,1): next-action sample (CAPQL / MOSAC), target noise (TD3) */
+    const float* eps_pi;        /* [policy_iters][pop][rows][Ad]  (CAPQL / MOSAC) */
+    const float* eps_alpha;     /* [policy_iters][pop][rows][Ad]  (MOSAC autotune) */
+    const uint8_t* drop_masks;  /* optional explicit keep masks, see morl_ac_mask_bytes(); NULL = device RNG */
+} morl_ac_batch;
+
+/* optional device outputs (NULL = not wanted) */
+typedef struct morl_ac_out {
+    float* critic_loss;   /* [pop]  CAPQL / TD3: (1/num_q) sum_n mse_n ; MOSAC: qf1_loss + qf2_loss */
+    float* q_losses;      /* [pop][num_q]  per-critic mse */
+    float* policy_loss;   /* [pop]  last actor iteration */
+    float* alpha_loss;    /* [pop]  MOSAC autotune, last iteration */
+    float* alpha;         /* [pop]  MOSAC: exp(log_alpha) after the call */
+    float* priority;      /* [pop][n_per]  TD3: |q_0 - target| * 0.05 . w  (before clip / pow) */
+    float* target_q;      /* [pop][rows][R]  (MOSAC: [pop][rows] scalarised) */
+    float* q_grads;       /* [pop][num_q][Pq]  critic gradients of this call */
+    float* pol_grads;     /* [pop][Pp]  actor gradients of the last iteration */
+} morl_ac_out;
+
+int64_t morl_ac_q_param_count(const morl_ac_desc* d);
+int64_t morl_ac_policy_param_count(const morl_ac_desc* d);
+/* bytes of batch.drop_masks: for phase in (target critics, critics, critics at pi): for net in [pop][num_q]:
+ * for hidden layer l: rows * h_l keep flags (row-major) */
+int64_t morl_ac_mask_bytes(const morl_ac_desc* d, int rows);
+int morl_ac_create(morl_ac_ctx** out, const morl_ac_desc* d);
+int morl_ac_destroy(morl_ac_ctx* ctx);
+
+/* One gradient update of every learner (the body of the reference's update() loop), asynchronous on `stream`. */
+int morl_ac_update(morl_ac_ctx* ctx, const morl_ac_state* st, const morl_ac_batch* batch, const morl_ac_cfg* cfg,
+                   const morl_ac_out* out, void* stream);
+
+/* Policy forward for acting / evaluation.  obs [pop][rows][D]; w as in morl_ac_batch (NULL for MOSAC);
+ * mode 0: deterministic action (CAPQL Policy.get_action, TD3 Policy.forward without noise; MOSAC: the tanh mean),
+ * mode 1: sampled action with eps [pop][rows][Ad] (MOSACActor.get_action; CAPQL Policy.sample; TD3: noise).
+ * use_target != 0 reads st->pol_target (TD3).  actions_out [pop][rows][Ad]; logp_out [pop][rows] or NULL. */
+int morl_ac_policy_forward(morl_ac_ctx* ctx, const morl_ac_state* st, const float* obs, const float* w, int rows,
+                           int mode, const float* eps, int use_target, const morl_ac_cfg* cfg, float* actions_out,
+                           float* logp_out, void* stream);
+
+/* Critic forward (eval mode: no dropout): q_out [pop][num_q][rows][R] for inputs obs / actions (/ w). */
+int morl_ac_q_forward(morl_ac_ctx* ctx, const morl_ac_state* st, const float* obs, const float* actions,
+                      const float* w, int rows, int use_target, float* q_out, void* stream);
 
 #ifdef __cplusplus
 }

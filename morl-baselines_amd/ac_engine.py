@@ -1,0 +1,209 @@
+"""Device-resident state + one-call updates of the continuous-action actor-critic learners (CAPQL, MOSAC / MORL-D
+subproblems, GPI-PD continuous) on top of ``morl_ac_*`` of the C ABI.
+
+All parameters, target networks and Adam moments of ``population`` learners live in flat fp32 device buffers
+(``q[pop][num_q][Pq]``, ``pol[pop][Pp]``); the ``nn.Parameter``s of the host-side classes are views into them, so a
+whole population advances with one ``morl_ac_update`` call and no per-parameter Python loop.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch as th
+
+from . import native
+from .native import ACBatch, ACCfg, ACDesc, ACOut, ACState, NativeLib
+
+ALGO_CAPQL, ALGO_MOSAC, ALGO_TD3 = 0, 1, 2
+
+
+class ACEngine:
+    def __init__(self, algo: int, obs_dim: int, act_dim: int, reward_dim: int, net_arch: Sequence[int], *,
+                 action_low, action_high, max_rows: int, num_q: int = 2, q_layer_norm: bool = False,
+                 q_drop_rate: float = 0.0, population: int = 1, device="cuda", lib: Optional[NativeLib] = None):
+        self.lib = lib or native.load_library()
+        self.device = th.device(device)
+        if len(net_arch) > native.MORL_MAX_LAYERS - 1:
+            raise ValueError(f"at most {native.MORL_MAX_LAYERS - 1} hidden layers are supported")
+        d = ACDesc()
+        d.algo, d.obs_dim, d.act_dim, d.reward_dim = algo, obs_dim, act_dim, reward_dim
+        d.n_hidden = len(net_arch)
+        for i, h in enumerate(net_arch):
+            d.hidden[i] = int(h)
+        d.num_q, d.q_layer_norm, d.q_drop_rate = num_q, int(bool(q_layer_norm)), float(q_drop_rate)
+        d.population, d.max_rows = population, max_rows
+        self.desc = d
+        self.algo, self.D, self.Ad, self.R = algo, obs_dim, act_dim, reward_dim
+        self.arch = [int(h) for h in net_arch]
+        self.num_q, self.pop, self.max_rows = num_q, population, max_rows
+        self.layer_norm, self.drop_rate = bool(q_layer_norm), float(q_drop_rate)
+        self.heads = 1 if algo == ALGO_TD3 else 2
+        self.w_input = algo != ALGO_MOSAC
+        self.Pq = int(self.lib.lib.morl_ac_q_param_count(C.byref(d)))
+        self.Pp = int(self.lib.lib.morl_ac_policy_param_count(C.byref(d)))
+        if self.Pq < 0 or self.Pp < 0:
+            self.lib.check(-1)
+        h = C.c_void_p()
+        self.lib.check(self.lib.lib.morl_ac_create(C.byref(h), C.byref(d)))
+        self._h = h.value
+        z = lambda *shape: th.zeros(*shape, dtype=th.float32, device=self.device)  # noqa: E731
+        self.q, self.q_target = z(population, num_q, self.Pq), z(population, num_q, self.Pq)
+        self.q_exp_avg, self.q_exp_avg_sq = z(population, num_q, self.Pq), z(population, num_q, self.Pq)
+        self.pol, self.pol_exp_avg, self.pol_exp_avg_sq = (z(population, self.Pp) for _ in range(3))
+        self.pol_target = z(population, self.Pp) if algo == ALGO_TD3 else None
+        self.log_alpha = self.log_alpha_exp_avg = self.log_alpha_exp_avg_sq = None
+        if algo == ALGO_MOSAC:
+            self.log_alpha, self.log_alpha_exp_avg, self.log_alpha_exp_avg_sq = (z(population) for _ in range(3))
+        low = np.broadcast_to(np.asarray(action_low, dtype=np.float32), (act_dim,))
+        high = np.broadcast_to(np.asarray(action_high, dtype=np.float32), (act_dim,))
+        self.action_scale = th.tensor((high - low) / 2.0, dtype=th.float32, device=self.device)
+        self.action_bias = th.tensor((high + low) / 2.0, dtype=th.float32, device=self.device)
+        self.lib.check_device(self.q)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.lib.morl_ac_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- parameter views (torch nn.Sequential.parameters() order) ---------------------------------------------------
+    def _q_shapes(self):
+        out, d = [], self.D + self.Ad + (self.R if self.w_input else 0)
+        for hdim in self.arch:
+            out += [(hdim, d), (hdim,)]
+            if self.layer_norm:
+                out += [(hdim,), (hdim,)]
+            d = hdim
+        return out + [(self.R, d), (self.R,)]
+
+    @staticmethod
+    def _views(flat: th.Tensor, shapes) -> List[th.Tensor]:
+        out, o = [], 0
+        for s in shapes:
+            n = int(np.prod(s))
+            out.append(flat[o:o + n].view(s))
+            o += n
+        assert o == flat.numel(), (o, flat.numel())
+        return out
+
+    def q_views(self, buf: th.Tensor, p: int = 0, n: int = 0) -> List[th.Tensor]:
+        """Views of critic ``n`` of learner ``p`` inside ``buf`` (self.q, self.q_target, an Adam moment buffer)."""
+        return self._views(buf[p, n], self._q_shapes())
+
+    def policy_views(self, buf: th.Tensor, p: int = 0) -> List[th.Tensor]:
+        """Trunk W/b pairs, then the heads in the reference's order: mean.W, mean.b[, log_std.W, log_std.b]."""
+        shapes, d = [], self.D + (self.R if self.w_input else 0)
+        for hdim in self.arch:
+            shapes += [(hdim, d), (hdim,)]
+            d = hdim
+        shapes += [(self.heads * self.Ad, d), (self.heads * self.Ad,)]
+        v = self._views(buf[p], shapes)
+        hw, hb = v[-2], v[-1]
+        out = v[:-2] + [hw[:self.Ad], hb[:self.Ad]]
+        if self.heads == 2:
+            out += [hw[self.Ad:], hb[self.Ad:]]
+        return out
+
+    # -- calls ----------------------------------------------------------------------------------------------------------
+    def _state(self) -> ACState:
+        st = ACState()
+        for name in native.AC_STATE_FIELDS:
+            t = getattr(self, name)
+            setattr(st, name, None if t is None else t.data_ptr())
+        return st
+
+    def _f32(self, t, name) -> th.Tensor:
+        t = th.as_tensor(t)
+        if t.dtype != th.float32 or t.device != self.q.device or not t.is_contiguous():
+            t = t.to(self.q.device, th.float32).contiguous()
+        return t
+
+    def make_cfg(self, *, gamma=0.99, tau=0.005, alpha=0.2, q_lr=3e-4, policy_lr=3e-4, alpha_lr=None, q_step=1,
+                 policy_step=1, do_policy=True, policy_iters=1, do_target=True, autotune=False, target_entropy=0.0,
+                 policy_noise=0.2, noise_clip=0.5, n_per=0, dropout_seed=0, beta1=0.9, beta2=0.999, eps=1e-8) -> ACCfg:
+        c = ACCfg()
+        c.gamma, c.tau, c.alpha = gamma, tau, alpha
+        c.q_lr, c.policy_lr, c.alpha_lr = q_lr, policy_lr, (q_lr if alpha_lr is None else alpha_lr)
+        c.beta1, c.beta2, c.eps = beta1, beta2, eps
+        c.q_step, c.policy_step, c.do_policy, c.policy_iters = q_step, policy_step, int(do_policy), policy_iters
+        c.do_target, c.autotune, c.target_entropy = int(do_target), int(autotune), target_entropy
+        c.policy_noise, c.noise_clip, c.n_per, c.dropout_seed = policy_noise, noise_clip, n_per, dropout_seed
+        return c
+
+    def update(self, cfg: ACCfg, *, obs, actions, rewards, next_obs, dones, w, eps_next, eps_pi=None, eps_alpha=None,
+               drop_masks: Optional[th.Tensor] = None, want: Sequence[str] = ("critic_loss", "policy_loss")) -> Dict:
+        """One ``morl_ac_update``.  Array shapes as in include/morl_hip.h (leading [pop] axis may be omitted when
+        population == 1).  Returns the requested device outputs (no host synchronisation)."""
+        obs = self._f32(obs, "obs")
+        rows = obs.numel() // (self.pop * self.D)
+        keep = [obs]
+        b = ACBatch()
+        b.rows = rows
+        b.obs = obs.data_ptr()
+        for name, t in (("actions", actions), ("rewards", rewards), ("next_obs", next_obs), ("dones", dones), ("w", w),
+                        ("eps_next", eps_next), ("eps_pi", eps_pi), ("eps_alpha", eps_alpha)):
+            if t is None:
+                continue
+            t = self._f32(t, name)
+            keep.append(t)
+            setattr(b, name, t.data_ptr())
+        expect = dict(actions=self.pop * rows * self.Ad, rewards=self.pop * rows * self.R, next_obs=obs.numel(),
+                      dones=self.pop * rows, w=self.pop * (rows if self.w_input else 1) * self.R,
+                      eps_next=self.pop * rows * self.Ad)
+        for (name, n), t in zip(expect.items(), keep[1:7]):
+            if t.numel() != n:
+                raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
+        if drop_masks is not None:
+            need = int(self.lib.lib.morl_ac_mask_bytes(C.byref(self.desc), rows))
+            if drop_masks.dtype != th.uint8 or drop_masks.numel() != need or not drop_masks.is_contiguous():
+                raise ValueError(f"drop_masks: expected {need} contiguous uint8 flags")
+            keep.append(drop_masks)
+            b.drop_masks = drop_masks.data_ptr()
+        self.lib.check_device(*keep)
+        o, res = ACOut(), {}
+        iters = max(1, cfg.policy_iters) if self.algo == ALGO_MOSAC else 1
+        shapes = dict(critic_loss=(self.pop,), q_losses=(self.pop, self.num_q), policy_loss=(self.pop,),
+                      alpha_loss=(self.pop,), alpha=(self.pop,), priority=(self.pop, max(cfg.n_per, 1)),
+                      target_q=(self.pop, rows) if self.algo == ALGO_MOSAC else (self.pop, rows, self.R),
+                      q_grads=(self.pop, self.num_q, self.Pq), pol_grads=(self.pop, self.Pp))
+        for name in want:
+            res[name] = th.zeros(shapes[name], dtype=th.float32, device=self.q.device)
+            setattr(o, name, res[name].data_ptr())
+        del iters
+        st = self._state()
+        self.lib.check(self.lib.lib.morl_ac_update(self._h, C.byref(st), C.byref(b), C.byref(cfg), C.byref(o),
+                                                   self.lib.stream_of(self.q)))
+        return res
+
+    def policy_forward(self, obs, w=None, *, eps=None, use_target=False, cfg: Optional[ACCfg] = None,
+                       want_logp=False):
+        obs = self._f32(obs, "obs")
+        rows = obs.numel() // (self.pop * self.D)
+        w = None if w is None else self._f32(w, "w")
+        eps = None if eps is None else self._f32(eps, "eps")
+        act = th.empty((self.pop, rows, self.Ad), dtype=th.float32, device=self.q.device)
+        logp = th.empty((self.pop, rows), dtype=th.float32, device=self.q.device) if want_logp else None
+        cfg = cfg or self.make_cfg()
+        st = self._state()
+        self.lib.check_device(obs, w, eps)
+        self.lib.check(self.lib.lib.morl_ac_policy_forward(
+            self._h, C.byref(st), obs.data_ptr(), None if w is None else w.data_ptr(), rows, 0 if eps is None else 1,
+            None if eps is None else eps.data_ptr(), int(use_target), C.byref(cfg), act.data_ptr(),
+            None if logp is None else logp.data_ptr(), self.lib.stream_of(self.q)))
+        return (act, logp) if want_logp else act
+
+    def q_forward(self, obs, actions, w=None, *, use_target=False) -> th.Tensor:
+        obs, actions = self._f32(obs, "obs"), self._f32(actions, "actions")
+        rows = obs.numel() // (self.pop * self.D)
+        w = None if w is None else self._f32(w, "w")
+        out = th.empty((self.pop, self.num_q, rows, self.R), dtype=th.float32, device=self.q.device)
+        st = self._state()
+        self.lib.check_device(obs, actions, w)
+        self.lib.check(self.lib.lib.morl_ac_q_forward(
+            self._h, C.byref(st), obs.data_ptr(), actions.data_ptr(), None if w is None else w.data_ptr(), rows,
+            int(use_target), out.data_ptr(), self.lib.stream_of(self.q)))
+        return out

@@ -16,9 +16,9 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmorl_hip.so")
-SOURCES = ["morl_hip.hip"]
-HEADERS = ["morl_device.h", "gemm_f32.h", "envelope_kernels.h", "mlp_chain.h", "dw_wave.h", "optim_kernels.h", "replay_kernels.h",
-           "pareto_kernels.h"]
+SOURCES = ["morl_hip.hip", "morl_ac.hip"]
+HEADERS = ["morl_device.h", "morl_host.h", "gemm_f32.h", "envelope_kernels.h", "mlp_chain.h", "dw_wave.h", "optim_kernels.h",
+           "replay_kernels.h", "pareto_kernels.h", "ac_kernels.h"]
 
 
 def _hipcc() -> str:
@@ -41,18 +41,35 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           # rounding contract: a*b+c is never fused behind our back (the envelope scalarisation must round every
-           # product and sum separately, as torch's einsum does); FMAs are written explicitly as fmaf()
-           "-ffp-contract=off",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+            # rounding contract: a*b+c is never fused behind our back (the envelope scalarisation must round every
+            # product and sum separately, as torch's einsum does); FMAs are written explicitly as fmaf()
+            "-ffp-contract=off",
+            "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "morl_hip.h")]
+    jobs = []
+    for src in SOURCES:                     # translation units compile concurrently, unchanged ones are kept
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        path = os.path.join(CSRC, src)
+        if (not force and os.path.exists(obj)
+                and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps + [path])):
+            jobs.append((obj, None))
+            continue
+        cmd = base + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for obj, proc in jobs:
+        if proc is not None:
+            out, _ = proc.communicate()
+            if proc.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + out)
+    cmd = base + ["-shared"] + [obj for obj, _ in jobs] + ["-o", LIB_PATH + ".tmp"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

@@ -1,0 +1,624 @@
+// Device kernels of the continuous-action actor-critic updates (CAPQL / MOSAC / GPI-PD continuous, gfx950 wave64).
+//
+// The networks are small ([256, 256] hidden, 128-256 batch rows): one learner's update is latency-bound, so every
+// kernel here is BATCHED over a leading "net" axis -- the twin critics of a learner, and every learner of a MORL/D
+// population -- and a whole population advances with the launch count of a single learner.  The dense layers reuse
+// the exact-fp32 MFMA tile engine of gemm_f32.h (blockIdx.z = net); everything else (input assembly, Dropout /
+// LayerNorm / ReLU, the squashed-Gaussian heads, TD targets, losses and their derivatives) is row-wise work:
+// one wave per activation row with shuffle reductions, or one thread per batch row for the O(Ad + R) head math.
+#pragma once
+#include "gemm_f32.h"
+#include "morl_device.h"
+#include "morl_hip.h"
+
+namespace morl {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// batched GEMMs: entry z of the batch reads A + (z / a_div) * sA (twin critics share their input rows), B + z * sB ...
+// ---------------------------------------------------------------------------------------------------------------------
+struct GemmBatched {
+    GemmProblem p;
+    long long sA, sB, sC, sBias, sMask;
+    int a_div;
+};
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_batched_kernel(GemmBatched b) {
+    GemmProblem g = b.p;
+    const int z = (int)blockIdx.z;
+    g.A += (long long)(z / b.a_div) * b.sA;
+    g.B += (long long)z * b.sB;
+    g.C += (long long)z * b.sC;
+    if (g.bias) g.bias += (long long)z * b.sBias;
+    if (g.mask) g.mask += (long long)z * b.sMask;
+    const int id = (int)blockIdx.x;
+    gemm_tile<A_KC, B_KC, EPI>(g, id / g.tiles_n, id % g.tiles_n, 0);
+}
+
+// every weight-gradient GEMM of one backward pass, for every net of the batch, in one launch:
+// dW_l[o][i] = sum_rows dZ_l[row][o] * X_l[row][i], db_l[o] = sum_rows dZ_l[row][o]   (K = batch rows, one split)
+struct GemmGroupBatched {
+    GemmProblem p[MORL_MAX_LAYERS];
+    long long sA[MORL_MAX_LAYERS], sB[MORL_MAX_LAYERS];
+    int b_div[MORL_MAX_LAYERS];
+    long long sC;                       // parameter count of one net
+    int tile_start[MORL_MAX_LAYERS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_grouped_tn_batched_kernel(GemmGroupBatched grp) {
+    const int id = (int)blockIdx.x, z = (int)blockIdx.z;
+    int q = 0;
+    while (q + 1 < grp.n && id >= grp.tile_start[q + 1]) ++q;
+    const int local = id - grp.tile_start[q];
+    GemmProblem g = grp.p[q];
+    g.A += (long long)z * grp.sA[q];
+    g.B += (long long)(z / grp.b_div[q]) * grp.sB[q];
+    g.C += (long long)z * grp.sC;
+    g.colsum += (long long)z * grp.sC;
+    gemm_tile<false, false, EPI_STORE>(g, local / g.tiles_n, local % g.tiles_n, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// input assembly: dst[g][row][:] = cat(src0, src1, src2) (zero padded to ld).  A source with rstride 0 is one vector
+// per net (MOSAC's scalarisation weights are not an input; CAPQL / TD3 weights are per row).
+// ---------------------------------------------------------------------------------------------------------------------
+struct ConcatArgs {
+    const float* src[3];
+    int width[3];
+    long long gstride[3];
+    int rstride[3];
+    int n_src;
+    float* dst;
+    int ld;
+    long long dst_gstride;
+    int rows, G;
+};
+
+__global__ __launch_bounds__(256) void ac_concat_kernel(ConcatArgs a) {
+    const long long total = (long long)a.G * a.rows * a.ld;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % a.ld);
+        const long long gr = e / a.ld;
+        const int row = (int)(gr % a.rows), g = (int)(gr / a.rows);
+        float v = 0.f;
+        int c0 = c;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (s < a.n_src) {
+                if (c0 >= 0 && c0 < a.width[s])
+                    v = a.src[s][(long long)g * a.gstride[s] + (long long)row * a.rstride[s] + c0];
+                c0 -= a.width[s];
+            }
+        }
+        a.dst[(long long)g * a.dst_gstride + (long long)row * a.ld + c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// hidden-layer post-op of common/networks.py:10-48 after the Linear: [Dropout] -> [LayerNorm(eps 1e-5, affine)] -> ReLU.
+// One wave per row (N <= 1024).  Saves what the backward needs: xhat (in place of z), rstd, the keep mask.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int POST_MAXJ = 16;   // columns per lane
+
+struct PostArgs {
+    float* z;                 // [G][..][ld]  in: Linear output; out: xhat (LayerNorm) or the dropped-out z
+    float* h;                 // [G][..][ld]  out: post-ReLU activation
+    float* rstd;              // [G][cap]
+    uint8_t* mask;            // [G][cap][N] keep flags (written when dropout is active)
+    const uint8_t* ext_mask;  // explicit keep flags [G][rows][N] (parity tests) or NULL -> counter-based RNG
+    long long ext_gstride;
+    const float* gamma;       // params + offset of this layer's LayerNorm weight; beta follows at +N
+    long long pstride;
+    long long gstride;        // floats between nets in z / h
+    int cap;                  // rows capacity (stride of rstd / mask)
+    int N, ld, rows;
+    int ln, drop;
+    float drop_p, inv_keep;
+    unsigned long long seed;
+};
+
+__device__ __forceinline__ float ac_uniform(unsigned long long seed, unsigned long long idx) {
+    unsigned long long x = seed + idx * 0x9E3779B97F4A7C15ull;      // splitmix64 finaliser
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (float)(x >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void ac_post_fwd_kernel(PostArgs a) {
+    const int row = (int)blockIdx.x * 4 + wave_id();
+    const int g = (int)blockIdx.y, lane = lane_id();
+    if (row >= a.rows) return;
+    float* __restrict__ z = a.z + (long long)g * a.gstride + (long long)row * a.ld;
+    float* __restrict__ h = a.h + (long long)g * a.gstride + (long long)row * a.ld;
+    float v[POST_MAXJ];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < POST_MAXJ; ++j) {
+        const int c = lane + 64 * j;
+        float x = 0.f;
+        if (c < a.N) {
+            x = z[c];
+            if (a.drop) {
+                bool keep;
+                if (a.ext_mask) keep = a.ext_mask[(long long)g * a.ext_gstride + (long long)row * a.N + c] != 0;
+                else keep = ac_uniform(a.seed, ((unsigned long long)g * a.cap + row) * a.N + c) >= a.drop_p;
+                a.mask[((long long)g * a.cap + row) * a.N + c] = keep ? 1 : 0;
+                x = keep ? x * a.inv_keep : 0.f;
+            }
+            sum += x;
+        }
+        v[j] = x;
+    }
+    if (!a.ln) {
+#pragma unroll
+        for (int j = 0; j < POST_MAXJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < a.N) h[c] = fmaxf(v[j], 0.f);
+        }
+        return;
+    }
+    const float mean = wave_sum(sum) / (float)a.N;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < POST_MAXJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < a.N) { const float d = v[j] - mean; sq += d * d; }
+    }
+    const float var = wave_sum(sq) / (float)a.N;
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    if (lane == 0) a.rstd[(long long)g * a.cap + row] = rstd;
+    const float* __restrict__ gam = a.gamma + (long long)g * a.pstride;
+    const float* __restrict__ bet = gam + a.N;
+#pragma unroll
+    for (int j = 0; j < POST_MAXJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < a.N) {
+            const float xh = (v[j] - mean) * rstd;
+            z[c] = xh;
+            h[c] = fmaxf(xh * gam[c] + bet[c], 0.f);
+        }
+    }
+}
+
+struct PostBwdArgs {
+    float* d;                 // [G][..][ld]  in: dLoss/dh ; out: dLoss/dz
+    const float* h;
+    const float* xhat;
+    const float* rstd;
+    const uint8_t* mask;
+    const float* gamma;
+    long long pstride, gstride;
+    int cap, N, ld, rows;
+    int ln, drop;
+    float inv_keep;
+};
+
+__global__ __launch_bounds__(256) void ac_post_bwd_kernel(PostBwdArgs a) {
+    const int row = (int)blockIdx.x * 4 + wave_id();
+    const int g = (int)blockIdx.y, lane = lane_id();
+    if (row >= a.rows) return;
+    const long long base = (long long)g * a.gstride + (long long)row * a.ld;
+    float* __restrict__ d = a.d + base;
+    const float* __restrict__ h = a.h + base;
+    float dxh[POST_MAXJ], xh[POST_MAXJ];
+    float s1 = 0.f, s2 = 0.f;
+    const float* __restrict__ gam = a.ln ? a.gamma + (long long)g * a.pstride : nullptr;
+#pragma unroll
+    for (int j = 0; j < POST_MAXJ; ++j) {
+        const int c = lane + 64 * j;
+        float t = 0.f, x = 0.f;
+        if (c < a.N) {
+            t = (h[c] > 0.f) ? d[c] : 0.f;                       // ReLU
+            if (a.ln) {
+                x = a.xhat[base + c];
+                t *= gam[c];
+                s1 += t;
+                s2 += t * x;
+            }
+        }
+        dxh[j] = t;
+        xh[j] = x;
+    }
+    float m1 = 0.f, m2 = 0.f, rstd = 1.f;
+    if (a.ln) {
+        m1 = wave_sum(s1) / (float)a.N;
+        m2 = wave_sum(s2) / (float)a.N;
+        rstd = a.rstd[(long long)g * a.cap + row];
+    }
+#pragma unroll
+    for (int j = 0; j < POST_MAXJ; ++j) {
+        const int c = lane + 64 * j;
+        if (c < a.N) {
+            float t = dxh[j];
+            if (a.ln) t = rstd * (t - m1 - xh[j] * m2);
+            if (a.drop) t = a.mask[((long long)g * a.cap + row) * a.N + c] ? t * a.inv_keep : 0.f;
+            d[c] = t;
+        }
+    }
+}
+
+// LayerNorm affine gradients: dgamma[c] = sum_rows dy * xhat, dbeta[c] = sum_rows dy, dy = dh * (h > 0).
+// Must run BEFORE ac_post_bwd_kernel overwrites dh.  One thread per column, rows in order (deterministic).
+struct LnGradArgs {
+    const float* d;
+    const float* h;
+    const float* xhat;
+    float* dgamma;            // grads + offset of gamma; dbeta follows at +N
+    long long pstride, gstride;
+    int N, ld, rows;
+};
+
+__global__ __launch_bounds__(256) void ac_ln_grad_kernel(LnGradArgs a) {
+    const int c = (int)blockIdx.x * 256 + (int)threadIdx.x, g = (int)blockIdx.y;
+    if (c >= a.N) return;
+    const long long base = (long long)g * a.gstride + c;
+    float sg = 0.f, sb = 0.f;
+    for (int r = 0; r < a.rows; ++r) {
+        const long long o = base + (long long)r * a.ld;
+        const float dy = (a.h[o] > 0.f) ? a.d[o] : 0.f;
+        sg += dy * a.xhat[o];
+        sb += dy;
+    }
+    float* __restrict__ out = a.dgamma + (long long)g * a.pstride;
+    out[c] = sg;
+    out[a.N + c] = sb;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// policy heads.  One thread per (learner, batch row); O(Ad) work each.
+//   CAPQL  capql.py:118-158      log_std = clamp(raw, -20, 2); log-prob summed per term, clamped to +-1e3
+//   MOSAC  mosac_continuous_action.py:98-123   log_std = -5 + 3.5 * (tanh(raw) + 1)
+//   TD3    gpi_pd_continuous_action.py:50-58   a = tanh(mean) [+ clamp(noise * policy_noise, +-noise_clip), clamp +-1]
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr float AC_HALF_LOG_2PI = 0.9189385332046727f;   // log(sqrt(2*pi))
+
+struct HeadArgs {
+    const float* head;        // [G][cap][ldh]: mean (cols 0..Ad-1) | raw log_std (cols Ad..2Ad-1)
+    long long head_gstride;
+    int ldh;
+    const float* eps;         // [G][rows][Ad] or NULL (deterministic action)
+    const float* scale;       // [Ad]
+    const float* bias;        // [Ad]
+    float* action;            // [G][rows][Ad]
+    float* logp;              // [G][rows] or NULL
+    float* save_y;            // [G][rows][Ad] tanh output, or NULL
+    float* save_std;          // [G][rows][Ad]
+    int rows, Ad, G, algo;
+    float policy_noise, noise_clip;
+};
+
+__global__ __launch_bounds__(256) void ac_head_fwd_kernel(HeadArgs a) {
+    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (e >= a.G * a.rows) return;
+    const int g = e / a.rows, row = e % a.rows;
+    const float* __restrict__ hd = a.head + (long long)g * a.head_gstride + (long long)row * a.ldh;
+    const long long o = ((long long)g * a.rows + row) * a.Ad;
+    if (a.algo == MORL_AC_TD3) {
+        for (int j = 0; j < a.Ad; ++j) {
+            float t = tanhf(hd[j]);
+            if (a.save_y) a.save_y[o + j] = t;
+            if (a.eps) {
+                const float n = fminf(fmaxf(a.eps[o + j] * a.policy_noise, -a.noise_clip), a.noise_clip);
+                t = fminf(fmaxf(t + n, -1.f), 1.f);
+            }
+            a.action[o + j] = t * a.scale[j] + a.bias[j];
+        }
+        return;
+    }
+    float lp_gauss = 0.f, lp_corr = 0.f, lp_elem = 0.f;
+    for (int j = 0; j < a.Ad; ++j) {
+        const float mean = hd[j];
+        if (!a.eps) {                                      // deterministic: tanh(mean) * scale + bias
+            a.action[o + j] = tanhf(mean) * a.scale[j] + a.bias[j];
+            continue;
+        }
+        const float raw = hd[a.Ad + j];
+        float ls;
+        if (a.algo == MORL_AC_CAPQL) ls = fminf(fmaxf(raw, -20.f), 2.f);
+        else ls = -5.f + 0.5f * 7.f * (tanhf(raw) + 1.f);
+        const float sd = expf(ls);
+        const float x = mean + a.eps[o + j] * sd;
+        const float y = tanhf(x);
+        a.action[o + j] = y * a.scale[j] + a.bias[j];
+        const float t = x - mean;
+        const float gauss = -(t * t) / (2.f * (sd * sd)) - logf(sd) - AC_HALF_LOG_2PI;
+        const float corr = logf(a.scale[j] * (1.f - y * y) + 1e-6f);
+        lp_gauss += gauss;
+        lp_corr += corr;
+        lp_elem += gauss - corr;
+        if (a.save_y) { a.save_y[o + j] = y; a.save_std[o + j] = sd; }
+    }
+    if (a.logp && a.eps) {
+        float lp;
+        if (a.algo == MORL_AC_CAPQL) lp = fminf(fmaxf(lp_gauss - lp_corr, -1e3f), 1e3f);
+        else lp = lp_elem;
+        a.logp[(long long)g * a.rows + row] = lp;
+    }
+}
+
+struct HeadBwdArgs {
+    const float* dx_q;        // [G*nq][cap][ld_qin]  dLoss / d(critic input); the action columns start at col0
+    long long dxq_gstride;
+    int nq, ld_qin, col0;
+    const float* head;
+    long long head_gstride;
+    int ldh;
+    const float* eps;
+    const float* save_y;
+    const float* save_std;
+    const float* logp;        // CAPQL: saturated rows pass no log-prob gradient
+    const float* scale;
+    const float* alpha_dev;   // [G]
+    float* dhead;             // [G][cap][ldh] out
+    int rows, Ad, G, algo;
+};
+
+__global__ __launch_bounds__(256) void ac_head_bwd_kernel(HeadBwdArgs a) {
+    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (e >= a.G * a.rows) return;
+    const int g = e / a.rows, row = e % a.rows;
+    const long long o = ((long long)g * a.rows + row) * a.Ad;
+    const float* __restrict__ hd = a.head + (long long)g * a.head_gstride + (long long)row * a.ldh;
+    float* __restrict__ dh = a.dhead + (long long)g * a.head_gstride + (long long)row * a.ldh;
+    float dlogp = 0.f;
+    if (a.algo != MORL_AC_TD3) {
+        dlogp = a.alpha_dev[g] / (float)a.rows;
+        if (a.algo == MORL_AC_CAPQL && fabsf(a.logp[(long long)g * a.rows + row]) >= 1e3f) dlogp = 0.f;
+    }
+    for (int j = 0; j < a.Ad; ++j) {
+        float dA = 0.f;
+        for (int n = 0; n < a.nq; ++n)
+            dA += a.dx_q[(long long)(g * a.nq + n) * a.dxq_gstride + (long long)row * a.ld_qin + a.col0 + j];
+        const float y = a.save_y[o + j];
+        const float one_m = 1.f - y * y;
+        const float sc = a.scale[j];
+        if (a.algo == MORL_AC_TD3) { dh[j] = dA * sc * one_m; continue; }
+        const float sd = a.save_std[o + j], ep = a.eps[o + j];
+        const float du = dA * sc * one_m + dlogp * (2.f * y * sc * one_m) / (sc * one_m + 1e-6f);
+        dh[j] = du;                                         // the Gaussian term's two paths to the mean cancel exactly
+        const float t = ep * sd;                            // x - mean
+        const float var = sd * sd;
+        const float dstd = du * ep + dlogp * (-t * ep / var + (t * t) / (var * sd) - 1.f / sd);
+        const float dls = dstd * sd;
+        const float raw = hd[a.Ad + j];
+        float draw;
+        if (a.algo == MORL_AC_CAPQL) draw = (raw >= -20.f && raw <= 2.f) ? dls : 0.f;
+        else { const float th_ = tanhf(raw); draw = dls * 3.5f * (1.f - th_ * th_); }
+        dh[a.Ad + j] = draw;
+    }
+    for (int j = ((a.algo == MORL_AC_TD3) ? a.Ad : 2 * a.Ad); j < a.ldh; ++j) dh[j] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// block-level deterministic sum (fixed order): every thread gets the total
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double ac_block_sum(double v, double* s_red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane_id() == 0) s_red[wave_id()] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_red[w];
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TD target + critic loss + dLoss/dQ.  One workgroup per learner, threads stride over the batch rows.
+//   CAPQL capql.py:326-334   target = r + (1-d) * gamma * (min_n Qt_n - alpha * logp')      (element-wise min)
+//   MOSAC mosac...:436-450   scalarised: t = r.w + (1-d) * gamma * (min_n (Qt_n.w) - alpha * logp'); loss = sum_n mse
+//   TD3   gpi_pd_c...:395-415  n* = argmin_n (Qt_n . w_row); target = r + (1-d) * gamma * Qt_n*; PER |q_0 - t| * 0.05 . w
+// ---------------------------------------------------------------------------------------------------------------------
+struct CriticArgs {
+    const float* tq;          // [G*nq][cap][ldo]  target critics at (s', a')
+    const float* q;           // [G*nq][cap][ldo]  critics at (s, a)
+    float* dq;                // [G*nq][cap][ldo]
+    long long gstride;
+    int ldo;
+    const float* logp_next;   // [G][rows]
+    const float* rewards;     // [G][rows][R]
+    const float* dones;       // [G][rows]
+    const float* w;           // [G][rows][R] or [G][R]
+    int w_per_row;
+    const float* alpha_dev;   // [G]
+    float* target_out;        // [G][rows][R] ([G][rows] MOSAC) or NULL
+    float* loss_out;          // [G] or NULL
+    float* q_losses;          // [G][nq] or NULL
+    float* priority;          // [G][n_per] or NULL
+    int n_per;
+    int rows, R, nq, algo;
+    float gamma;
+};
+
+__global__ __launch_bounds__(256) void ac_critic_kernel(CriticArgs a) {
+    __shared__ double s_red[4];
+    const int g = (int)blockIdx.x;
+    const float alpha = (a.algo == MORL_AC_TD3) ? 0.f : a.alpha_dev[g];
+    double part[4] = {0.0, 0.0, 0.0, 0.0};                  // per-critic squared-error sums (nq <= 4)
+    for (int row = (int)threadIdx.x; row < a.rows; row += (int)blockDim.x) {
+        const long long ro = (long long)row * a.ldo;
+        const float* __restrict__ w = a.w + (a.w_per_row ? ((long long)g * a.rows + row) * a.R : (long long)g * a.R);
+        const float* __restrict__ rew = a.rewards + ((long long)g * a.rows + row) * a.R;
+        const float nd = 1.f - a.dones[(long long)g * a.rows + row];
+        const float lp = (a.algo == MORL_AC_TD3) ? 0.f : a.logp_next[(long long)g * a.rows + row];
+        float tgt[MORL_MAX_OBJ];
+        if (a.algo == MORL_AC_CAPQL) {
+            for (int r = 0; r < a.R; ++r) {
+                float m = a.tq[(long long)(g * a.nq) * a.gstride + ro + r];
+                for (int n = 1; n < a.nq; ++n) m = fminf(m, a.tq[(long long)(g * a.nq + n) * a.gstride + ro + r]);
+                tgt[r] = rew[r] + (nd * a.gamma) * (m - alpha * lp);
+            }
+        } else if (a.algo == MORL_AC_TD3) {
+            int best = 0;
+            float bs = 0.f;
+            for (int n = 0; n < a.nq; ++n) {
+                float s = 0.f;
+                for (int r = 0; r < a.R; ++r) s += a.tq[(long long)(g * a.nq + n) * a.gstride + ro + r] * w[r];
+                if (n == 0 || s < bs) { bs = s; best = n; }
+            }
+            for (int r = 0; r < a.R; ++r)
+                tgt[r] = rew[r] + (nd * a.gamma) * a.tq[(long long)(g * a.nq + best) * a.gstride + ro + r];
+        } else {
+            float m = 0.f, sr = 0.f;
+            for (int n = 0; n < a.nq; ++n) {
+                float s = 0.f;
+                for (int r = 0; r < a.R; ++r) s += a.tq[(long long)(g * a.nq + n) * a.gstride + ro + r] * w[r];
+                m = (n == 0) ? s : fminf(m, s);
+            }
+            for (int r = 0; r < a.R; ++r) sr += rew[r] * w[r];
+            tgt[0] = sr + (nd * a.gamma) * (m - alpha * lp);
+        }
+        if (a.target_out) {
+            if (a.algo == MORL_AC_MOSAC) a.target_out[(long long)g * a.rows + row] = tgt[0];
+            else for (int r = 0; r < a.R; ++r) a.target_out[((long long)g * a.rows + row) * a.R + r] = tgt[r];
+        }
+        for (int n = 0; n < a.nq; ++n) {
+            const float* __restrict__ q = a.q + (long long)(g * a.nq + n) * a.gstride + ro;
+            float* __restrict__ dq = a.dq + (long long)(g * a.nq + n) * a.gstride + ro;
+            if (a.algo == MORL_AC_MOSAC) {
+                float s = 0.f;
+                for (int r = 0; r < a.R; ++r) s += q[r] * w[r];
+                const float e = s - tgt[0];
+                part[n] += (double)e * (double)e;
+                const float c = 2.f * e / (float)a.rows;
+                for (int r = 0; r < a.R; ++r) dq[r] = c * w[r];
+            } else {
+                const float c = 2.f / ((float)a.nq * (float)a.rows * (float)a.R);
+                for (int r = 0; r < a.R; ++r) {
+                    const float e = q[r] - tgt[r];
+                    part[n] += (double)e * (double)e;
+                    dq[r] = c * e;
+                }
+            }
+            for (int r = a.R; r < a.ldo; ++r) dq[r] = 0.f;
+        }
+        if (a.priority && row < a.n_per) {
+            const float* __restrict__ q0 = a.q + (long long)(g * a.nq) * a.gstride + ro;
+            float p = 0.f;
+            for (int r = 0; r < a.R; ++r) p += (fabsf(q0[r] - tgt[r]) * 0.05f) * w[r];
+            a.priority[(long long)g * a.n_per + row] = p;
+        }
+    }
+    double total = 0.0;
+    for (int n = 0; n < a.nq; ++n) {
+        const double s = ac_block_sum(part[n], s_red);
+        const double denom = (a.algo == MORL_AC_MOSAC) ? (double)a.rows : (double)a.rows * a.R;
+        const double l = s / denom;
+        if (threadIdx.x == 0 && a.q_losses) a.q_losses[(long long)g * a.nq + n] = (float)l;
+        total += l;
+    }
+    if (threadIdx.x == 0 && a.loss_out)
+        a.loss_out[g] = (float)((a.algo == MORL_AC_MOSAC) ? total : total / (double)a.nq);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// actor loss and its derivative w.r.t. the critic outputs at (s, pi(s)).
+//   CAPQL capql.py:341-346   mean(alpha * logp) - mean((min_n Q_n) . w)     (element-wise min over the critics)
+//   MOSAC mosac...:454-460   mean(alpha * logp) - mean(min_n (Q_n . w))
+//   TD3   gpi_pd_c...:424-426  -mean(((1/nq) sum_n Q_n) . w)
+// ---------------------------------------------------------------------------------------------------------------------
+struct ActorLossArgs {
+    const float* q;           // [G*nq][cap][ldo]
+    float* dq;
+    long long gstride;
+    int ldo;
+    const float* logp;        // [G][rows]
+    const float* w;
+    int w_per_row;
+    const float* alpha_dev;
+    float* loss_out;          // [G] or NULL
+    int rows, R, nq, algo;
+};
+
+__global__ __launch_bounds__(256) void ac_actor_loss_kernel(ActorLossArgs a) {
+    __shared__ double s_red[4];
+    const int g = (int)blockIdx.x;
+    const float alpha = (a.algo == MORL_AC_TD3) ? 0.f : a.alpha_dev[g];
+    double s_lp = 0.0, s_q = 0.0;
+    const float inv_rows = 1.f / (float)a.rows;
+    for (int row = (int)threadIdx.x; row < a.rows; row += (int)blockDim.x) {
+        const long long ro = (long long)row * a.ldo;
+        const float* __restrict__ w = a.w + (a.w_per_row ? ((long long)g * a.rows + row) * a.R : (long long)g * a.R);
+        for (int n = 0; n < a.nq; ++n) {
+            float* __restrict__ dq = a.dq + (long long)(g * a.nq + n) * a.gstride + ro;
+            for (int r = 0; r < a.ldo; ++r) dq[r] = 0.f;
+        }
+        float val = 0.f;
+        if (a.algo == MORL_AC_CAPQL) {
+            for (int r = 0; r < a.R; ++r) {
+                int best = 0;
+                float m = a.q[(long long)(g * a.nq) * a.gstride + ro + r];
+                for (int n = 1; n < a.nq; ++n) {
+                    const float v = a.q[(long long)(g * a.nq + n) * a.gstride + ro + r];
+                    if (v < m) { m = v; best = n; }
+                }
+                val += m * w[r];
+                a.dq[(long long)(g * a.nq + best) * a.gstride + ro + r] = -w[r] * inv_rows;
+            }
+        } else if (a.algo == MORL_AC_MOSAC) {
+            int best = 0;
+            for (int n = 0; n < a.nq; ++n) {
+                float s = 0.f;
+                for (int r = 0; r < a.R; ++r) s += a.q[(long long)(g * a.nq + n) * a.gstride + ro + r] * w[r];
+                if (n == 0 || s < val) { val = s; best = n; }
+            }
+            for (int r = 0; r < a.R; ++r) a.dq[(long long)(g * a.nq + best) * a.gstride + ro + r] = -w[r] * inv_rows;
+        } else {
+            const float inv_nq = 1.f / (float)a.nq;
+            for (int r = 0; r < a.R; ++r) {
+                float m = 0.f;
+                for (int n = 0; n < a.nq; ++n) m += a.q[(long long)(g * a.nq + n) * a.gstride + ro + r];
+                val += (inv_nq * m) * w[r];
+                for (int n = 0; n < a.nq; ++n)
+                    a.dq[(long long)(g * a.nq + n) * a.gstride + ro + r] = -w[r] * inv_rows * inv_nq;
+            }
+        }
+        s_q += (double)val;
+        if (a.algo != MORL_AC_TD3) s_lp += (double)(alpha * a.logp[(long long)g * a.rows + row]);
+    }
+    const double tq = ac_block_sum(s_q, s_red);
+    const double tl = ac_block_sum(s_lp, s_red);
+    if (threadIdx.x == 0 && a.loss_out) a.loss_out[g] = (float)((tl - tq) / (double)a.rows);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MOSAC entropy coefficient.  prepare: alpha[g] = autotune ? exp(log_alpha[g]) : alpha_const.
+// step (mosac...:466-474): alpha_loss = mean(-log_alpha * (logp + target_entropy)); one scalar Adam step; alpha = exp.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void ac_alpha_prepare_kernel(const float* log_alpha, float alpha_const, int autotune, float* alpha_dev,
+                                        int G) {
+    const int g = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x;
+    if (g < G) alpha_dev[g] = autotune ? expf(log_alpha[g]) : alpha_const;
+}
+
+__global__ __launch_bounds__(256) void ac_alpha_step_kernel(float* log_alpha, float* m_, float* v_, const float* logp,
+                                                            int rows, float target_entropy, float one_minus_b1,
+                                                            float b2, float one_minus_b2, float neg_step_size,
+                                                            float bc2_sqrt, float eps, float* alpha_dev,
+                                                            float* alpha_loss_out) {
+    __shared__ double s_red[4];
+    const int g = (int)blockIdx.x;
+    double s = 0.0;
+    for (int row = (int)threadIdx.x; row < rows; row += (int)blockDim.x)
+        s += (double)(logp[(long long)g * rows + row] + target_entropy);
+    const double tot = ac_block_sum(s, s_red);
+    if (threadIdx.x == 0) {
+        const float mean = (float)(tot / (double)rows);
+        const float la = log_alpha[g];
+        if (alpha_loss_out) alpha_loss_out[g] = -la * mean;
+        const float grad = -mean;
+        float m = m_[g], v = v_[g];
+        m = fmaf(one_minus_b1, __fsub_rn(grad, m), m);
+        v = __fadd_rn(__fmul_rn(v, b2), __fmul_rn(__fmul_rn(one_minus_b2, grad), grad));
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
+        const float nla = __fadd_rn(la, __fmul_rn(neg_step_size, __fdiv_rn(m, denom)));
+        log_alpha[g] = nla;
+        m_[g] = m;
+        v_[g] = v;
+        alpha_dev[g] = expf(nla);
+    }
+}
+
+}  // namespace morl

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "morl_hip.h"
+#include "morl_host.h"
 #include "morl_device.h"
 #include "gemm_f32.h"
 #include "envelope_kernels.h"
@@ -24,29 +25,15 @@
 using namespace morl;
 
 // ------------------------------------------------------------------------------------------------
-// error plumbing
+// error plumbing (morl_host.h; the per-thread message buffer lives here)
 // ------------------------------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-
-static int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                                  \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess) return fail(MORL_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-#define LAUNCH_CHECK(name)                                                                          \
-    do {                                                                                            \
-        hipError_t e_ = hipGetLastError();                                                          \
-        if (e_ != hipSuccess) return fail(MORL_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
-    } while (0)
+thread_local char morl_host::g_err[512] = "";
+using morl_host::fail;
+using morl_host::g_err;
+using morl_host::round_up;
+using morl_host::vec_ok;
+using morl_host::stream_grid;
+using morl_host::dmalloc;
 
 extern "C" const char* morl_last_error(void) { return g_err; }
 extern "C" int morl_abi_version(void) { return MORL_ABI_VERSION; }
@@ -160,7 +147,6 @@ struct morl_ctx {
     int num_cus = 256;
 };
 
-static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 extern "C" int64_t morl_param_count(const morl_net_desc* net) {
     if (!net || net->n_layers < 1 || net->n_layers > MORL_MAX_LAYERS) return -1;
@@ -208,11 +194,6 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     return MORL_OK;
 }
 
-static int dmalloc(void** p, size_t bytes) {
-    hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess) return fail(MORL_ERR_ALLOC, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-    return MORL_OK;
-}
 
 extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max_batch, int max_weights) {
     if (!out) return fail(MORL_ERR_ARG, "out is NULL");
@@ -310,12 +291,6 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-static int vec_ok(const void* p, int ld) { return (((uintptr_t)p & 15u) == 0 && (ld & 3) == 0) ? 1 : 0; }
-
-static int stream_grid(long long n, int threads, int cap = 2048) {
-    long long b = (n + threads - 1) / threads;
-    return (int)std::max(1ll, std::min<long long>(b, cap));
-}
 
 template <bool A_KC, bool B_KC, int EPI>
 static int launch_gemm(GemmProblem g, hipStream_t s, const char* name) {

@@ -14,7 +14,7 @@ constexpr int OPT_MAX_BLOCKS = 256;  // sum-of-squares partials are re-reduced b
 //   loss = (1-lambda) * sum_b part[b][0] / (W*B*R) + lambda * sum_b part[b][1] / (W*B)   (envelope.py:307-313)
 // Algorithmic bytes: 4*P*(splits + 1).
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(OPT_THREADS) void grad_reduce_kernel(const float* __restrict__ slabs, int splits,
+static __global__ __launch_bounds__(OPT_THREADS) void grad_reduce_kernel(const float* __restrict__ slabs, int splits,
                                                                   long long slab_stride, float* __restrict__ grads,
                                                                   long long P, double* __restrict__ sumsq_part,
                                                                   const double* __restrict__ loss_part, int n_loss,
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(OPT_THREADS) void grad_reduce_kernel(const float* _
 // so all blocks see the identical norm without a grid barrier.
 // Algorithmic bytes: 4*P*7 (read p,g,m,v; write p,m,v) + 4*P (clipped g written back).
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(float* __restrict__ params, float* __restrict__ grads,
+static __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(float* __restrict__ params, float* __restrict__ grads,
                                                                 float* __restrict__ exp_avg,
                                                                 float* __restrict__ exp_avg_sq, long long P,
                                                                 const double* __restrict__ sumsq_part, int n_part,
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(float* __restric
 }
 
 // polyak_update (common/networks.py:120-139): tau == 1 -> copy, else t = t*(1-tau) + tau*p
-__global__ __launch_bounds__(OPT_THREADS) void polyak_kernel(const float* __restrict__ src, float* __restrict__ dst,
+static __global__ __launch_bounds__(OPT_THREADS) void polyak_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                              long long n, float tau, float one_minus_tau) {
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n;
          p += (long long)gridDim.x * blockDim.x) {

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
 
 MORL_MAX_LAYERS = 8
 MORL_MAX_OBJ = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class NetDesc(C.Structure):
@@ -33,6 +33,43 @@ class UpdateCfg(C.Structure):
 class UpdateOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("loss", "grad_norm", "priority", "target", "pref", "ac", "q_online_next",
                                           "q_target_next", "q_values")]
+
+
+class ACDesc(C.Structure):
+    _fields_ = [("algo", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("reward_dim", C.c_int32),
+                ("n_hidden", C.c_int32), ("hidden", C.c_int32 * MORL_MAX_LAYERS), ("num_q", C.c_int32),
+                ("q_layer_norm", C.c_int32), ("q_drop_rate", C.c_float), ("population", C.c_int32),
+                ("max_rows", C.c_int32)]
+
+
+class ACCfg(C.Structure):
+    _fields_ = [("gamma", C.c_float), ("tau", C.c_float), ("alpha", C.c_float),
+                ("q_lr", C.c_double), ("policy_lr", C.c_double), ("alpha_lr", C.c_double),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("q_step", C.c_int32), ("policy_step", C.c_int32), ("do_policy", C.c_int32),
+                ("policy_iters", C.c_int32), ("do_target", C.c_int32), ("autotune", C.c_int32),
+                ("target_entropy", C.c_float), ("policy_noise", C.c_float), ("noise_clip", C.c_float),
+                ("n_per", C.c_int32), ("dropout_seed", C.c_uint64)]
+
+
+AC_STATE_FIELDS = ("q", "q_target", "q_exp_avg", "q_exp_avg_sq", "pol", "pol_exp_avg", "pol_exp_avg_sq", "pol_target",
+                   "log_alpha", "log_alpha_exp_avg", "log_alpha_exp_avg_sq", "action_scale", "action_bias")
+AC_BATCH_FIELDS = ("obs", "actions", "rewards", "next_obs", "dones", "w", "eps_next", "eps_pi", "eps_alpha",
+                   "drop_masks")
+AC_OUT_FIELDS = ("critic_loss", "q_losses", "policy_loss", "alpha_loss", "alpha", "priority", "target_q", "q_grads",
+                 "pol_grads")
+
+
+class ACState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in AC_STATE_FIELDS]
+
+
+class ACBatch(C.Structure):
+    _fields_ = [("rows", C.c_int32)] + [(n, C.c_void_p) for n in AC_BATCH_FIELDS]
+
+
+class ACOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in AC_OUT_FIELDS]
 
 
 _SIGNATURES = {
@@ -67,6 +104,17 @@ _SIGNATURES = {
     "morl_sumtree_set": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "morl_sumtree_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "morl_ac_q_param_count": (C.c_int64, [C.POINTER(ACDesc)]),
+    "morl_ac_policy_param_count": (C.c_int64, [C.POINTER(ACDesc)]),
+    "morl_ac_mask_bytes": (C.c_int64, [C.POINTER(ACDesc), C.c_int]),
+    "morl_ac_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(ACDesc)]),
+    "morl_ac_destroy": (C.c_int, [C.c_void_p]),
+    "morl_ac_update": (C.c_int, [C.c_void_p, C.POINTER(ACState), C.POINTER(ACBatch), C.POINTER(ACCfg),
+                                 C.POINTER(ACOut), C.c_void_p]),
+    "morl_ac_policy_forward": (C.c_int, [C.c_void_p, C.POINTER(ACState), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_int, C.POINTER(ACCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "morl_ac_q_forward": (C.c_int, [C.c_void_p, C.POINTER(ACState), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

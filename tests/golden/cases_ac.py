@@ -92,14 +92,22 @@ def _perturbed(ps, rng, scale=0.05):
 
 def make_inputs(c: ACCase) -> dict:
     rng = np.random.default_rng(1000 + c.seed)
-    gen = th.Generator().manual_seed(2000 + c.seed)
     qspec, trunk = specs(c)
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
-    head = lambda: [th.nn.init.orthogonal_(th.empty(c.Ad, c.arch[-1]), gain=1, generator=gen),  # noqa: E731
-                    th.tensor(f32(rng.standard_normal(c.Ad) * 0.05))]
-    q = [_perturbed(ac.init_mlp_params(qspec, gen), rng) for _ in range(2)]
-    tq = [[p + th.tensor(f32(rng.standard_normal(p.shape) * 0.01)) for p in net] for net in q]
-    pol = _perturbed(ac.init_mlp_params(trunk, gen), rng)
+
+    def dense(shape):
+        # numpy-only draws (bit-reproducible on every machine; torch's orthogonal_ goes through LAPACK, whose result
+        # depends on the host CPU / thread count, and the fixtures must be regenerable anywhere)
+        return th.tensor(f32(rng.standard_normal(shape) / np.sqrt(shape[1])))
+
+    def net(spec):
+        return _perturbed([dense(s) if len(s) == 2 else (th.ones(s) if k % 4 == 2 and spec.layer_norm else th.zeros(s))
+                           for k, s in enumerate(spec.shapes())], rng)
+
+    head = lambda: [dense((c.Ad, c.arch[-1])), th.tensor(f32(rng.standard_normal(c.Ad) * 0.05))]  # noqa: E731
+    q = [net(qspec) for _ in range(2)]
+    tq = [[p + th.tensor(f32(rng.standard_normal(p.shape) * 0.01)) for p in net_] for net_ in q]
+    pol = net(trunk)
     for _ in range(n_heads(c)):
         pol += head()
     inp = dict(q=q, tq=tq, pol=pol)

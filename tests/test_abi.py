@@ -29,7 +29,7 @@ def test_header_symbols_exported_by_the_gfx950_library():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/morl_hip.h but not exported"
     lib.morl_abi_version.restype = ctypes.c_int
-    assert lib.morl_abi_version() == 1
+    assert lib.morl_abi_version() == 2
     assert lib.morl_is_device_build() == 1
 
 
