@@ -111,6 +111,11 @@ int64_t morl_param_count(const morl_net_desc* net);
 int morl_gather_batch(const float* records, int record_floats, int64_t capacity, const int64_t* idx, int B,
                       int D, int R, int action_dim, float* obs, float* next_obs, float* rewards, float* dones,
                       float* actions_f, int32_t* actions_i, void* stream);
+/* Same gather for records with arbitrary extra fields (CAPQL ReplayMemory.sample, multi_policy/capql/capql.py:56-63,
+ * whose transitions carry the episode's weight vector): outs[f][b][0..widths[f]) = records[idx[b]][offsets[f] ..).
+ * offsets / widths / outs are HOST arrays of n_fields (<= 8) entries; outs[f] are device pointers. */
+int morl_gather_fields(const float* records, int record_floats, int64_t capacity, const int64_t* idx, int B,
+                       int n_fields, const int32_t* offsets, const int32_t* widths, float* const* outs, void* stream);
 
 /* ---- QNet.forward: envelope.py:60-77 ----------------------------------------------------------
  * Evaluates Q(obs_b, w_k) for all B x W pairs.  row_order 0: row = b*W + k ("next-state slab"
@@ -263,10 +268,17 @@ typedef struct morl_ac_state {
     float* log_alpha_exp_avg_sq;
     const float* action_scale;  /* [Ad]  (high - low) / 2 */
     const float* action_bias;   /* [Ad]  (high + low) / 2 */
+    /* optional device-resident Adam step counters (learners of a MORL/D population have taken different numbers of
+     * steps): when non-NULL the bias corrections use q_steps[p] + 1 / pol_steps[p] + 1 + iteration instead of
+     * cfg.q_step / cfg.policy_step, and the counters are advanced by the call itself. */
+    int32_t* q_steps;           /* [pop] */
+    int32_t* pol_steps;         /* [pop] */
 } morl_ac_state;
 
 typedef struct morl_ac_batch {
     int32_t rows;               /* batch rows per learner */
+    int32_t active;             /* learners advanced by this call, 1..population (0 = population); the state / batch /
+                                   output pointers then address the FIRST of `active` consecutive learners */
     const float* obs;           /* [pop][rows][D] */
     const float* actions;       /* [pop][rows][Ad] */
     const float* rewards;       /* [pop][rows][R] */
@@ -294,8 +306,8 @@ typedef struct morl_ac_out {
 
 int64_t morl_ac_q_param_count(const morl_ac_desc* d);
 int64_t morl_ac_policy_param_count(const morl_ac_desc* d);
-/* bytes of batch.drop_masks: for phase in (target critics, critics, critics at pi): for net in [pop][num_q]:
- * for hidden layer l: rows * h_l keep flags (row-major) */
+/* bytes of batch.drop_masks when every learner is active: for phase in (target critics, critics, critics at pi):
+ * for net in [active][num_q]: for hidden layer l: rows * h_l keep flags (row-major) */
 int64_t morl_ac_mask_bytes(const morl_ac_desc* d, int rows);
 int morl_ac_create(morl_ac_ctx** out, const morl_ac_desc* d);
 int morl_ac_destroy(morl_ac_ctx* ctx);

@@ -22,7 +22,11 @@ ALGO_CAPQL, ALGO_MOSAC, ALGO_TD3 = 0, 1, 2
 class ACEngine:
     def __init__(self, algo: int, obs_dim: int, act_dim: int, reward_dim: int, net_arch: Sequence[int], *,
                  action_low, action_high, max_rows: int, num_q: int = 2, q_layer_norm: bool = False,
-                 q_drop_rate: float = 0.0, population: int = 1, device="cuda", lib: Optional[NativeLib] = None):
+                 q_drop_rate: float = 0.0, population: int = 1, device="cuda", lib: Optional[NativeLib] = None,
+                 device_steps: bool = False, state: Optional[Dict[str, th.Tensor]] = None):
+        """``device_steps``: keep the Adam step counters of every learner on the device (needed when the learners of a
+        population have taken different numbers of steps).  ``state``: adopt existing state tensors instead of
+        allocating (``member()`` uses it to hand out pop-1 engines whose buffers are slices of a population's)."""
         self.lib = lib or native.load_library()
         self.device = th.device(device)
         if len(net_arch) > native.MORL_MAX_LAYERS - 1:
@@ -48,19 +52,42 @@ class ACEngine:
         h = C.c_void_p()
         self.lib.check(self.lib.lib.morl_ac_create(C.byref(h), C.byref(d)))
         self._h = h.value
-        z = lambda *shape: th.zeros(*shape, dtype=th.float32, device=self.device)  # noqa: E731
-        self.q, self.q_target = z(population, num_q, self.Pq), z(population, num_q, self.Pq)
-        self.q_exp_avg, self.q_exp_avg_sq = z(population, num_q, self.Pq), z(population, num_q, self.Pq)
-        self.pol, self.pol_exp_avg, self.pol_exp_avg_sq = (z(population, self.Pp) for _ in range(3))
-        self.pol_target = z(population, self.Pp) if algo == ALGO_TD3 else None
-        self.log_alpha = self.log_alpha_exp_avg = self.log_alpha_exp_avg_sq = None
-        if algo == ALGO_MOSAC:
-            self.log_alpha, self.log_alpha_exp_avg, self.log_alpha_exp_avg_sq = (z(population) for _ in range(3))
-        low = np.broadcast_to(np.asarray(action_low, dtype=np.float32), (act_dim,))
-        high = np.broadcast_to(np.asarray(action_high, dtype=np.float32), (act_dim,))
-        self.action_scale = th.tensor((high - low) / 2.0, dtype=th.float32, device=self.device)
-        self.action_bias = th.tensor((high + low) / 2.0, dtype=th.float32, device=self.device)
+        self._ctor = dict(algo=algo, obs_dim=obs_dim, act_dim=act_dim, reward_dim=reward_dim, net_arch=list(net_arch),
+                          action_low=action_low, action_high=action_high, max_rows=max_rows, num_q=num_q,
+                          q_layer_norm=q_layer_norm, q_drop_rate=q_drop_rate, device=device, lib=self.lib)
+        if state is not None:
+            for name in native.AC_STATE_FIELDS:
+                setattr(self, name, state.get(name))
+        else:
+            z = lambda *shape: th.zeros(*shape, dtype=th.float32, device=self.device)  # noqa: E731
+            self.q, self.q_target = z(population, num_q, self.Pq), z(population, num_q, self.Pq)
+            self.q_exp_avg, self.q_exp_avg_sq = z(population, num_q, self.Pq), z(population, num_q, self.Pq)
+            self.pol, self.pol_exp_avg, self.pol_exp_avg_sq = (z(population, self.Pp) for _ in range(3))
+            self.pol_target = z(population, self.Pp) if algo == ALGO_TD3 else None
+            self.log_alpha = self.log_alpha_exp_avg = self.log_alpha_exp_avg_sq = None
+            if algo == ALGO_MOSAC:
+                self.log_alpha, self.log_alpha_exp_avg, self.log_alpha_exp_avg_sq = (z(population) for _ in range(3))
+            low = np.broadcast_to(np.asarray(action_low, dtype=np.float32), (act_dim,))
+            high = np.broadcast_to(np.asarray(action_high, dtype=np.float32), (act_dim,))
+            self.action_scale = th.tensor((high - low) / 2.0, dtype=th.float32, device=self.device)
+            self.action_bias = th.tensor((high + low) / 2.0, dtype=th.float32, device=self.device)
+            self.q_steps = self.pol_steps = None
+            if device_steps:
+                self.q_steps = th.zeros(population, dtype=th.int32, device=self.device)
+                self.pol_steps = th.zeros(population, dtype=th.int32, device=self.device)
         self.lib.check_device(self.q)
+
+    def member(self, k: int, max_rows: Optional[int] = None) -> "ACEngine":
+        """A population-1 engine (own workspace) whose state tensors are learner ``k``'s slices of this engine's."""
+        state = {}
+        for name in native.AC_STATE_FIELDS:
+            t = getattr(self, name)
+            state[name] = t if (t is None or name in ("action_scale", "action_bias")) else t[k:k + 1]
+        kw = dict(self._ctor)
+        if max_rows is not None:
+            kw["max_rows"] = max_rows
+        algo, D, Ad, R, arch = (kw.pop(k_) for k_ in ("algo", "obs_dim", "act_dim", "reward_dim", "net_arch"))
+        return ACEngine(algo, D, Ad, R, arch, population=1, state=state, **kw)
 
     def __del__(self):
         try:
@@ -109,11 +136,16 @@ class ACEngine:
         return out
 
     # -- calls ----------------------------------------------------------------------------------------------------------
-    def _state(self) -> ACState:
+    def _state(self, first: int = 0) -> ACState:
         st = ACState()
         for name in native.AC_STATE_FIELDS:
             t = getattr(self, name)
-            setattr(st, name, None if t is None else t.data_ptr())
+            if t is None:
+                setattr(st, name, None)
+            elif name in ("action_scale", "action_bias"):
+                setattr(st, name, t.data_ptr())
+            else:
+                setattr(st, name, t[first:].data_ptr() if first else t.data_ptr())
         return st
 
     def _f32(self, t, name) -> th.Tensor:
@@ -135,14 +167,26 @@ class ACEngine:
         return c
 
     def update(self, cfg: ACCfg, *, obs, actions, rewards, next_obs, dones, w, eps_next, eps_pi=None, eps_alpha=None,
-               drop_masks: Optional[th.Tensor] = None, want: Sequence[str] = ("critic_loss", "policy_loss")) -> Dict:
+               drop_masks: Optional[th.Tensor] = None, want: Sequence[str] = ("critic_loss", "policy_loss"),
+               first: int = 0, count: Optional[int] = None) -> Dict:
         """One ``morl_ac_update``.  Array shapes as in include/morl_hip.h (leading [pop] axis may be omitted when
-        population == 1).  Returns the requested device outputs (no host synchronisation)."""
+        population == 1).  ``first`` / ``count``: advance only learners first .. first+count-1 (the arrays then hold
+        ``count`` learners).  Returns the requested device outputs (no host synchronisation)."""
         obs = self._f32(obs, "obs")
-        rows = obs.numel() // (self.pop * self.D)
+        full_pop = self.pop
+        count = full_pop - first if count is None else count
+        if first < 0 or count < 1 or first + count > full_pop:
+            raise ValueError(f"learners {first}..{first + count - 1} outside the population of {full_pop}")
+        return self._update(cfg, obs, count, first, actions, rewards, next_obs, dones, w, eps_next, eps_pi, eps_alpha,
+                            drop_masks, want)
+
+    def _update(self, cfg, obs, pop, first, actions, rewards, next_obs, dones, w, eps_next, eps_pi, eps_alpha,
+                drop_masks, want):
+        rows = obs.numel() // (pop * self.D)
         keep = [obs]
         b = ACBatch()
         b.rows = rows
+        b.active = pop
         b.obs = obs.data_ptr()
         for name, t in (("actions", actions), ("rewards", rewards), ("next_obs", next_obs), ("dones", dones), ("w", w),
                         ("eps_next", eps_next), ("eps_pi", eps_pi), ("eps_alpha", eps_alpha)):
@@ -151,14 +195,13 @@ class ACEngine:
             t = self._f32(t, name)
             keep.append(t)
             setattr(b, name, t.data_ptr())
-        expect = dict(actions=self.pop * rows * self.Ad, rewards=self.pop * rows * self.R, next_obs=obs.numel(),
-                      dones=self.pop * rows, w=self.pop * (rows if self.w_input else 1) * self.R,
-                      eps_next=self.pop * rows * self.Ad)
+        expect = dict(actions=pop * rows * self.Ad, rewards=pop * rows * self.R, next_obs=obs.numel(),
+                      dones=pop * rows, w=pop * (rows if self.w_input else 1) * self.R, eps_next=pop * rows * self.Ad)
         for (name, n), t in zip(expect.items(), keep[1:7]):
             if t.numel() != n:
                 raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
         if drop_masks is not None:
-            need = int(self.lib.lib.morl_ac_mask_bytes(C.byref(self.desc), rows))
+            need = int(self.lib.lib.morl_ac_mask_bytes(C.byref(self.desc), rows)) // self.pop * pop
             if drop_masks.dtype != th.uint8 or drop_masks.numel() != need or not drop_masks.is_contiguous():
                 raise ValueError(f"drop_masks: expected {need} contiguous uint8 flags")
             keep.append(drop_masks)
@@ -166,15 +209,15 @@ class ACEngine:
         self.lib.check_device(*keep)
         o, res = ACOut(), {}
         iters = max(1, cfg.policy_iters) if self.algo == ALGO_MOSAC else 1
-        shapes = dict(critic_loss=(self.pop,), q_losses=(self.pop, self.num_q), policy_loss=(self.pop,),
-                      alpha_loss=(self.pop,), alpha=(self.pop,), priority=(self.pop, max(cfg.n_per, 1)),
-                      target_q=(self.pop, rows) if self.algo == ALGO_MOSAC else (self.pop, rows, self.R),
-                      q_grads=(self.pop, self.num_q, self.Pq), pol_grads=(self.pop, self.Pp))
+        shapes = dict(critic_loss=(pop,), q_losses=(pop, self.num_q), policy_loss=(pop,), alpha_loss=(pop,),
+                      alpha=(pop,), priority=(pop, max(cfg.n_per, 1)),
+                      target_q=(pop, rows) if self.algo == ALGO_MOSAC else (pop, rows, self.R),
+                      q_grads=(pop, self.num_q, self.Pq), pol_grads=(pop, self.Pp))
         for name in want:
             res[name] = th.zeros(shapes[name], dtype=th.float32, device=self.q.device)
             setattr(o, name, res[name].data_ptr())
         del iters
-        st = self._state()
+        st = self._state(first)
         self.lib.check(self.lib.lib.morl_ac_update(self._h, C.byref(st), C.byref(b), C.byref(cfg), C.byref(o),
                                                    self.lib.stream_of(self.q)))
         return res

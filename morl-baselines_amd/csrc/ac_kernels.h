@@ -594,10 +594,9 @@ __global__ void ac_alpha_prepare_kernel(const float* log_alpha, float alpha_cons
 }
 
 __global__ __launch_bounds__(256) void ac_alpha_step_kernel(float* log_alpha, float* m_, float* v_, const float* logp,
-                                                            int rows, float target_entropy, float one_minus_b1,
-                                                            float b2, float one_minus_b2, float neg_step_size,
-                                                            float bc2_sqrt, float eps, float* alpha_dev,
-                                                            float* alpha_loss_out) {
+                                                            int rows, float target_entropy, const int* steps,
+                                                            int step_add, double lr, double db1, double db2, float eps,
+                                                            float* alpha_dev, float* alpha_loss_out) {
     __shared__ double s_red[4];
     const int g = (int)blockIdx.x;
     double s = 0.0;
@@ -605,6 +604,10 @@ __global__ __launch_bounds__(256) void ac_alpha_step_kernel(float* log_alpha, fl
         s += (double)(logp[(long long)g * rows + row] + target_entropy);
     const double tot = ac_block_sum(s, s_red);
     if (threadIdx.x == 0) {
+        const int t = max(1, (steps ? steps[g] : 0) + step_add);
+        const float neg_step_size = (float)(-(lr / (1.0 - pow(db1, (double)t))));
+        const float bc2_sqrt = (float)sqrt(1.0 - pow(db2, (double)t));
+        const float one_minus_b1 = (float)(1.0 - db1), b2 = (float)db2, one_minus_b2 = (float)(1.0 - db2);
         const float mean = (float)(tot / (double)rows);
         const float la = log_alpha[g];
         if (alpha_loss_out) alpha_loss_out[g] = -la * mean;
@@ -619,6 +622,40 @@ __global__ __launch_bounds__(256) void ac_alpha_step_kernel(float* log_alpha, fl
         v_[g] = v;
         alpha_dev[g] = expf(nla);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// torch _single_tensor_adam over one parameter segment per learner (blockIdx.y); the 1-based step is either the same
+// for everybody (steps == NULL) or read from the learner's device-resident counter: t = steps[g] + step_add.
+// Same arithmetic as clip_adam_kernel (optim_kernels.h) without the clipping.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ac_adam_kernel(float* __restrict__ params, const float* __restrict__ grads,
+                                                      float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                                                      long long seg, const int* __restrict__ steps, int step_add,
+                                                      double lr, double b1, double b2, float eps) {
+    const int g = (int)blockIdx.y;
+    const int t = max(1, (steps ? steps[g] : 0) + step_add);
+    const float neg_step_size = (float)(-(lr / (1.0 - pow(b1, (double)t))));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)t));
+    const float one_minus_b1 = (float)(1.0 - b1), fb2 = (float)b2, one_minus_b2 = (float)(1.0 - b2);
+    const long long base = (long long)g * seg;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < seg; p += (long long)gridDim.x * blockDim.x) {
+        const float gr = grads[base + p];
+        float m = exp_avg[base + p], v = exp_avg_sq[base + p];
+        m = fmaf(one_minus_b1, __fsub_rn(gr, m), m);
+        v = __fadd_rn(__fmul_rn(v, fb2), __fmul_rn(__fmul_rn(one_minus_b2, gr), gr));
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
+        params[base + p] = __fadd_rn(params[base + p], __fmul_rn(neg_step_size, __fdiv_rn(m, denom)));
+        exp_avg[base + p] = m;
+        exp_avg_sq[base + p] = v;
+    }
+}
+
+__global__ void ac_step_advance_kernel(int* q_steps, int* pol_steps, int G, int pol_inc) {
+    const int g = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x;
+    if (g >= G) return;
+    if (q_steps) q_steps[g] += 1;
+    if (pol_steps) pol_steps[g] += pol_inc;
 }
 
 }  // namespace morl

@@ -366,16 +366,12 @@ static int concat(morl_ac_ctx* c, float* dst, int ld, int G, int rows, const flo
     return MORL_OK;
 }
 
-static int adam(float* params, float* grads, float* m, float* v, long long n, double lr, int step, const morl_ac_cfg* cfg,
-                hipStream_t s) {
-    const double b1 = cfg->beta1, b2 = cfg->beta2;
-    const int t = std::max(1, step);
-    const double step_size = lr / (1.0 - std::pow(b1, (double)t));
-    const double bc2_sqrt = std::sqrt(1.0 - std::pow(b2, (double)t));
-    const int nblk = std::min(OPT_MAX_BLOCKS * 4, stream_grid(n, OPT_THREADS));
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, params, grads, m, v, n, (const double*)nullptr, 0,
-                       -1.0f, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(-step_size), (float)bc2_sqrt,
-                       (float)cfg->eps, 1, (float*)nullptr);
+// one Adam step on `G` learner segments of `seg` floats each; t = steps[g] + step_add, or step_add when steps == NULL
+static int adam(float* params, float* grads, float* m, float* v, long long seg, int G, double lr, const int* steps,
+                int step_add, const morl_ac_cfg* cfg, hipStream_t s) {
+    const int nblk = std::min(256, stream_grid(seg, 256));
+    hipLaunchKernelGGL(ac_adam_kernel, dim3(nblk, G), dim3(256), 0, s, params, (const float*)grads, m, v, seg, steps, step_add,
+                       lr, cfg->beta1, cfg->beta2, (float)cfg->eps);
     LAUNCH_CHECK("ac_adam");
     return MORL_OK;
 }
@@ -435,10 +431,17 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     if (cfg->do_policy && autotune && !bt->eps_alpha) return fail(MORL_ERR_ARG, "eps_alpha is NULL");
     if (cfg->n_per < 0 || cfg->n_per > rows) return fail(MORL_ERR_ARG, "n_per %d outside 0..rows", cfg->n_per);
     const Mlp &Q = c->q, &P = c->pol;
+    // learners advanced by this call (a leading sub-range of the context's capacity)
+    if (bt->active < 0 || bt->active > d.population) return fail(MORL_ERR_STATE, "active %d outside 0..population %d", bt->active, d.population);
+    const int PG = bt->active > 0 ? bt->active : d.population, QG = PG * nq;
+    c->PG = PG; c->QG = QG;
+    c->tq_a.G = c->tq_b.G = QG;
+    c->tp_a.G = c->tp_b.G = PG;
+    int64_t mask_net = 0;                                    // explicit dropout masks: bytes per net and per phase
+    for (int l = 0; l < Q.L - 1; ++l) mask_net += (int64_t)rows * Q.dims[l + 1];
+    const int64_t mask_phase = (int64_t)QG * mask_net;
     const float* w_rows = c->w_input ? bt->w : nullptr;      // weight vector as a network input
     const int wR = c->w_input ? R : 0;
-    const int64_t mask_phase = bt->drop_masks ? morl_ac_mask_bytes(&d, rows) / 3 : 0;
-    const int64_t mask_net = bt->drop_masks ? mask_phase / c->QG : 0;
     auto dropspec = [&](int phase) {
         DropSpec ds;
         ds.active = Q.drop > 0.f;
@@ -479,7 +482,8 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     if ((rc = mlp_backward(c, Q, st->q, Q.P, c->tq_b, rows, nq, Q.drop > 0.f, c->gq, false, s))) return rc;
     if (out->q_grads)
         HIP_TRY(hipMemcpyAsync(out->q_grads, c->gq, (size_t)c->QG * Q.P * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if ((rc = adam(st->q, c->gq, st->q_exp_avg, st->q_exp_avg_sq, (long long)c->QG * Q.P, cfg->q_lr, cfg->q_step, cfg, s))) return rc;
+    if ((rc = adam(st->q, c->gq, st->q_exp_avg, st->q_exp_avg_sq, (long long)nq * Q.P, PG, cfg->q_lr, st->q_steps,
+                   st->q_steps ? 1 : cfg->q_step, cfg, s))) return rc;
 
     // ---- actor phase ---------------------------------------------------------------------------------------------------
     if (cfg->do_policy) {
@@ -517,21 +521,17 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
             if ((rc = mlp_backward(c, P, st->pol, P.P, c->tp_b, rows, 1, false, c->gp, false, s))) return rc;
             if (out->pol_grads)
                 HIP_TRY(hipMemcpyAsync(out->pol_grads, c->gp, (size_t)c->PG * P.P * sizeof(float), hipMemcpyDeviceToDevice, s));
-            if ((rc = adam(st->pol, c->gp, st->pol_exp_avg, st->pol_exp_avg_sq, (long long)c->PG * P.P, cfg->policy_lr,
-                           cfg->policy_step + it, cfg, s))) return rc;
+            if ((rc = adam(st->pol, c->gp, st->pol_exp_avg, st->pol_exp_avg_sq, P.P, PG, cfg->policy_lr, st->pol_steps,
+                           (st->pol_steps ? 1 : cfg->policy_step) + it, cfg, s))) return rc;
             if (autotune) {
                 // log-prob of a fresh sample under the UPDATED actor (mosac_continuous_action.py:467-468)
                 const float* eps_al = bt->eps_alpha + (long long)it * c->PG * rows * Ad;
                 if ((rc = mlp_forward(c, P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
                 if ((rc = head_forward(c, c->tp_b, rows, eps_al, st, cfg, c->act, c->logp_pi, false, s))) return rc;
-                const double b1 = cfg->beta1, b2 = cfg->beta2;
-                const int t = std::max(1, cfg->policy_step + it);
-                const double step_size = cfg->alpha_lr / (1.0 - std::pow(b1, (double)t));
-                const double bc2_sqrt = std::sqrt(1.0 - std::pow(b2, (double)t));
                 hipLaunchKernelGGL(ac_alpha_step_kernel, dim3(c->PG), dim3(256), 0, s, st->log_alpha, st->log_alpha_exp_avg,
                                    st->log_alpha_exp_avg_sq, (const float*)c->logp_pi, rows, cfg->target_entropy,
-                                   (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(-step_size), (float)bc2_sqrt,
-                                   (float)cfg->eps, c->alpha_dev, out->alpha_loss);
+                                   (const int*)st->pol_steps, (st->pol_steps ? 1 : cfg->policy_step) + it, cfg->alpha_lr,
+                                   cfg->beta1, cfg->beta2, (float)cfg->eps, c->alpha_dev, out->alpha_loss);
                 LAUNCH_CHECK("ac_alpha_step");
             }
             if (algo == MORL_AC_TD3)
@@ -540,6 +540,11 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     }
     if (cfg->do_target)
         if ((rc = polyak(st->q, st->q_target, (long long)c->QG * Q.P, cfg->tau, s))) return rc;
+    if (st->q_steps || st->pol_steps) {
+        hipLaunchKernelGGL(ac_step_advance_kernel, dim3((PG + 63) / 64), dim3(64), 0, s, st->q_steps,
+                           cfg->do_policy ? st->pol_steps : (int32_t*)nullptr, PG, iters);
+        LAUNCH_CHECK("ac_step_advance");
+    }
     if (out->alpha)
         HIP_TRY(hipMemcpyAsync(out->alpha, c->alpha_dev, (size_t)c->PG * sizeof(float), hipMemcpyDeviceToDevice, s));
     return MORL_OK;
@@ -556,6 +561,8 @@ extern "C" int morl_ac_policy_forward(morl_ac_ctx* c, const morl_ac_state* st, c
     if (use_target && !st->pol_target) return fail(MORL_ERR_ARG, "pol_target is NULL");
     hipStream_t s = (hipStream_t)stream;
     const Mlp& P = c->pol;
+    c->PG = c->d.population; c->QG = c->PG * c->d.num_q;
+    c->tp_a.G = c->PG;
     if ((rc = concat(c, c->tp_a.x, P.ld[0], c->PG, rows, obs, c->d.obs_dim, c->w_input ? w : nullptr,
                      c->w_input ? c->d.reward_dim : 0, nullptr, 0, s))) return rc;
     if ((rc = mlp_forward(c, P, use_target ? st->pol_target : st->pol, P.P, c->tp_a, rows, 1, DropSpec(), s))) return rc;
@@ -572,6 +579,8 @@ extern "C" int morl_ac_q_forward(morl_ac_ctx* c, const morl_ac_state* st, const 
     hipStream_t s = (hipStream_t)stream;
     const Mlp& Q = c->q;
     const int R = c->d.reward_dim;
+    c->PG = c->d.population; c->QG = c->PG * c->d.num_q;
+    c->tq_a.G = c->QG;
     if ((rc = concat(c, c->tq_a.x, Q.ld[0], c->PG, rows, obs, c->d.obs_dim, actions, c->d.act_dim, c->w_input ? w : nullptr,
                      c->w_input ? R : 0, s))) return rc;
     if ((rc = mlp_forward(c, Q, use_target ? st->q_target : st->q, Q.P, c->tq_a, rows, c->d.num_q, DropSpec(), s))) return rc;

@@ -552,6 +552,25 @@ extern "C" int morl_gather_batch(const float* records, int record_floats, int64_
     return MORL_OK;
 }
 
+extern "C" int morl_gather_fields(const float* records, int record_floats, int64_t capacity, const int64_t* idx, int B,
+                                  int n_fields, const int32_t* offsets, const int32_t* widths, float* const* outs,
+                                  void* stream) {
+    if (!records || !idx || !offsets || !widths || !outs) return fail(MORL_ERR_ARG, "gather_fields: NULL argument");
+    if (B < 1 || capacity < 1 || record_floats < 1) return fail(MORL_ERR_ARG, "gather_fields: bad sizes");
+    if (n_fields < 1 || n_fields > GATHER_MAX_FIELDS) return fail(MORL_ERR_ARG, "gather_fields: 1..%d fields", GATHER_MAX_FIELDS);
+    GatherFields f{};
+    f.n = n_fields;
+    for (int k = 0; k < n_fields; ++k) {
+        if (offsets[k] < 0 || widths[k] < 1 || offsets[k] + widths[k] > record_floats || !outs[k])
+            return fail(MORL_ERR_ARG, "gather_fields: field %d [%d, +%d) outside the record / NULL output", k, offsets[k], widths[k]);
+        f.offset[k] = offsets[k]; f.width[k] = widths[k]; f.dst[k] = outs[k];
+    }
+    hipLaunchKernelGGL(gather_fields_kernel, dim3(std::min(1024, (B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, records,
+                       record_floats, (long long)capacity, idx, B, f);
+    LAUNCH_CHECK("gather_fields");
+    return MORL_OK;
+}
+
 extern "C" int morl_qnet_forward(morl_ctx* c, const float* params, const float* obs, const float* weights, int B, int W,
                                  int row_order, float* q_out, void* stream) {
     int rc = check_bw(c, B, W);

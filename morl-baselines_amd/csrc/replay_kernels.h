@@ -39,6 +39,36 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const float* __restri
     }
 }
 
+// Generic form for records with extra per-transition fields (CAPQL's ReplayMemory stores the weight vector of the
+// episode with every transition, capql.py:40-54): field f of sampled row b = record[idx[b]][offset_f .. +width_f).
+constexpr int GATHER_MAX_FIELDS = 8;
+struct GatherFields {
+    int n;
+    int offset[GATHER_MAX_FIELDS];
+    int width[GATHER_MAX_FIELDS];
+    float* dst[GATHER_MAX_FIELDS];
+};
+
+__global__ __launch_bounds__(256) void gather_fields_kernel(const float* __restrict__ records, int record_floats,
+                                                            long long capacity, const int64_t* __restrict__ idx, int B,
+                                                            GatherFields f) {
+    const int waves_per_block = (int)blockDim.x / kWave;
+    const int lane = lane_id();
+    for (int b = (int)blockIdx.x * waves_per_block + wave_id(); b < B; b += (int)gridDim.x * waves_per_block) {
+        long long t = idx[b];
+        if (t < 0) t = 0;
+        if (t >= capacity) t = capacity - 1;
+        const float* rec = records + (size_t)t * record_floats;
+        for (int e = lane; e < record_floats; e += kWave) {
+            const float v = rec[e];
+#pragma unroll
+            for (int k = 0; k < GATHER_MAX_FIELDS; ++k)
+                if (k < f.n && e >= f.offset[k] && e < f.offset[k] + f.width[k])
+                    f.dst[k][(size_t)b * f.width[k] + (e - f.offset[k])] = v;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // Sum tree (common/prioritized_buffer.py:12-82), float64 levels concatenated root first: level l has
 // 2^l nodes at offset 2^l - 1.  All arithmetic is IEEE float64 in the reference's order, so indices and

@@ -53,7 +53,8 @@ class ACCfg(C.Structure):
 
 
 AC_STATE_FIELDS = ("q", "q_target", "q_exp_avg", "q_exp_avg_sq", "pol", "pol_exp_avg", "pol_exp_avg_sq", "pol_target",
-                   "log_alpha", "log_alpha_exp_avg", "log_alpha_exp_avg_sq", "action_scale", "action_bias")
+                   "log_alpha", "log_alpha_exp_avg", "log_alpha_exp_avg_sq", "action_scale", "action_bias", "q_steps",
+                   "pol_steps")
 AC_BATCH_FIELDS = ("obs", "actions", "rewards", "next_obs", "dones", "w", "eps_next", "eps_pi", "eps_alpha",
                    "drop_masks")
 AC_OUT_FIELDS = ("critic_loss", "q_losses", "policy_loss", "alpha_loss", "alpha", "priority", "target_q", "q_grads",
@@ -65,7 +66,7 @@ class ACState(C.Structure):
 
 
 class ACBatch(C.Structure):
-    _fields_ = [("rows", C.c_int32)] + [(n, C.c_void_p) for n in AC_BATCH_FIELDS]
+    _fields_ = [("rows", C.c_int32), ("active", C.c_int32)] + [(n, C.c_void_p) for n in AC_BATCH_FIELDS]
 
 
 class ACOut(C.Structure):
@@ -86,6 +87,8 @@ _SIGNATURES = {
     "morl_ctx_read_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "morl_gather_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] +
                           [C.c_void_p] * 6 + [C.c_void_p]),
+    "morl_gather_fields": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int,
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.c_void_p]),
     "morl_qnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p]),
     "morl_envelope_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

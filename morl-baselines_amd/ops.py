@@ -96,6 +96,22 @@ def gather_batch(lib: NativeLib, records: th.Tensor, idx: th.Tensor, D: int, R: 
     return obs, act, rew, nobs, done
 
 
+def gather_fields(lib: NativeLib, records: th.Tensor, idx: th.Tensor, fields):
+    """Generic record gather: ``fields`` = [(offset, width), ...] -> one (B, width) float32 tensor per field."""
+    import ctypes as C
+    _chk(records, th.float32, "records")
+    _chk(idx, th.int64, "idx")
+    lib.check_device(records, idx)
+    B, n = idx.numel(), len(fields)
+    outs = [th.empty((B, w), dtype=th.float32, device=records.device) for _, w in fields]
+    offs = (C.c_int32 * n)(*[int(o) for o, _ in fields])
+    wids = (C.c_int32 * n)(*[int(w) for _, w in fields])
+    ptrs = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    lib.check(lib.lib.morl_gather_fields(_ptr(records), records.shape[1], records.shape[0], _ptr(idx), B, n, offs, wids,
+                                         ptrs, lib.stream_of(records)))
+    return outs
+
+
 def qnet_forward(ctx: QNetContext, params: th.Tensor, obs: th.Tensor, weights: th.Tensor, row_order: int = 0):
     """Q(obs_b, w_k) for all pairs -> (B*W, A, R); row = b*W+k (row_order 0) or k*B+b (row_order 1)."""
     lib = ctx.lib

@@ -1,0 +1,367 @@
+"""Host-side mirrors of the reference's continuous-action agents (CAPQL, MOSAC, MORL/D, GPI-LS continuous) on the HIP
+engine: replay semantics, one ``update()`` against the oracle on the very batch / noise the agent drew, checkpoint
+round trips and short training runs.  ``sim`` = kernel sources under the host wave emulator, ``hip`` = gfx950 (-m gpu)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch as th
+
+import ac_oracle as ac
+import momdp
+
+import morl_baselines_amd.native as native
+from morl_baselines_amd.capql import CAPQL, ReplayMemory, WeightSamplerAngle
+from morl_baselines_amd.gpi_pd_continuous import GPILSContinuousAction, GPIPDContinuousAction
+from morl_baselines_amd.morld import MORLD, simplex_lattice_weights
+from morl_baselines_amd.mosac import MOSAC
+
+
+class BoxEnv(momdp.PointReach):
+    """PointReach with a wider observation / action vector so the network shapes are less degenerate."""
+
+    def __init__(self, seed=0, D=5, Ad=2, low=-1.0, high=1.0):
+        super().__init__(seed)
+        self.observation_space = momdp.BoxSpace(-1.0, 1.0, (D,), seed)
+        self.action_space = momdp.BoxSpace(low, high, (Ad,), seed)
+        self._D = D
+
+    def _obs(self):
+        o = np.zeros(self._D, dtype=np.float32)
+        o[0], o[1] = self.x, self.t / self.HORIZON
+        o[2:] = np.sin(np.arange(2, self._D) * (1.0 + self.x))
+        return o
+
+
+@pytest.fixture(scope="module", params=["sim", pytest.param("hip", marks=pytest.mark.gpu)])
+def be(request):
+    if request.param == "sim":
+        import simlib
+        lib = simlib.load_sim()
+        native.use_library(lib)
+        yield lib, th.device("cpu")
+        native.use_library(None)
+        return
+    yield native.load_library(), th.device("cuda:0")
+
+
+def rng_snapshot(dev):
+    return (random.getstate(), np.random.get_state(), th.get_rng_state(),
+            th.cuda.get_rng_state(dev) if dev.type == "cuda" else None)
+
+
+def rng_restore(snap, dev):
+    random.setstate(snap[0])
+    np.random.set_state(snap[1])
+    th.set_rng_state(snap[2])
+    if snap[3] is not None:
+        th.cuda.set_rng_state(snap[3], dev)
+
+
+def fill_capql(ag, env, n, seed=0):
+    rng = np.random.default_rng(seed)
+    D, Ad, R = ag.observation_dim, ag.action_dim, ag.reward_dim
+    for _ in range(n):
+        w = np.abs(rng.standard_normal(R)); w /= w.sum()
+        ag.replay_buffer.push(rng.standard_normal(D).astype(np.float32), rng.uniform(-1, 1, Ad).astype(np.float32),
+                              w.astype(np.float32), rng.standard_normal(R).astype(np.float32),
+                              rng.standard_normal(D).astype(np.float32), rng.random() < 0.1)
+
+
+def fill_buffer(buf, n, D, Ad, R, seed=0, low=-1.0, high=1.0):
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        buf.add(rng.standard_normal(D).astype(np.float32), rng.uniform(low, high, Ad).astype(np.float32),
+                rng.standard_normal(R).astype(np.float32), rng.standard_normal(D).astype(np.float32), rng.random() < 0.1)
+
+
+def cpu(vs):
+    return [v.detach().cpu().clone() for v in vs]
+
+
+def assert_lists_close(got, want, rtol=2e-4, frac=2e-5):
+    for g, w in zip(got, want):
+        scale = float(w.abs().max()) + 1e-30
+        np.testing.assert_allclose(g.cpu().numpy(), w.numpy(), rtol=rtol, atol=frac * scale)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_replay_memory_matches_reference_sampling(be):
+    lib, dev = be
+    mem = ReplayMemory(40, device=dev, lib=lib)
+    rng = np.random.default_rng(0)
+    items = []
+    for t in range(55):                                  # wraps the ring
+        it = (rng.standard_normal(4), rng.standard_normal(2), rng.random(3), rng.standard_normal(3),
+              rng.standard_normal(4), t % 7 == 0)
+        items.append(it)
+        mem.push(*it)
+    assert len(mem) == 40 and mem.position == 55 % 40
+    random.seed(3)
+    got = mem.sample(16, to_tensor=True)
+    random.seed(3)
+    want = random.sample(mem.buffer, 16)                # capql.py:58
+    for k in range(5):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), np.stack([w[k] for w in want]).astype(np.float32))
+    np.testing.assert_array_equal(got[5].cpu().numpy(), np.stack([w[5] for w in want]).astype(np.float32))
+    random.seed(4)
+    host = mem.sample(8, to_tensor=False)
+    random.seed(4)
+    want = random.sample(mem.buffer, 8)
+    np.testing.assert_array_equal(host[0], np.stack([w[0] for w in want]))
+
+
+def test_weight_sampler_angle_properties():
+    th.manual_seed(0)
+    ws = WeightSamplerAngle(3, th.pi * 22.5 / 180).sample(200)
+    assert ws.shape == (200, 3)
+    np.testing.assert_allclose(ws.abs().sum(1).numpy(), 1.0, rtol=1e-5)
+    centre = th.ones(3) / th.norm(th.ones(3))
+    cosang = (ws / th.norm(ws, dim=1, keepdim=True)) @ centre
+    assert (th.acos(cosang.clamp(-1, 1)) <= th.pi * 22.5 / 180 + 1e-4).all()
+
+
+def test_capql_update_matches_oracle_and_checkpoints(be, tmp_path):
+    lib, dev = be
+    env = BoxEnv(low=-2.0, high=1.0)
+    th.manual_seed(0)
+    ag = CAPQL(env, net_arch=[32, 32], batch_size=16, buffer_size=256, learning_starts=10, log=False, seed=0,
+               device=dev, lib=lib, alpha=0.1)
+    fill_capql(ag, env, 80)
+    e = ag.engine
+    q0 = [cpu(e.q_views(e.q, 0, n)) for n in range(2)]
+    tq0 = [cpu(e.q_views(e.q_target, 0, n)) for n in range(2)]
+    pol0 = cpu(e.policy_views(e.pol))
+    random.seed(7)
+    th.manual_seed(7)
+    snap = rng_snapshot(dev)
+    ag.update()
+    rng_restore(snap, dev)
+    batch = ag._sample_batch_experiences()
+    eps = th.randn((2, 16, ag.action_dim), dtype=th.float32, device=dev)
+    qspec = ac.MlpSpec(env.observation_space.shape[0] + 2 + 2, (32, 32), 2)
+    trunk = ac.MlpSpec(env.observation_space.shape[0] + 2, (32, 32))
+    qs, ps = (dict(exp_avg=ac.zeros_like(sum(q0, [])), exp_avg_sq=ac.zeros_like(sum(q0, []))),
+              dict(exp_avg=ac.zeros_like(pol0), exp_avg_sq=ac.zeros_like(pol0)))
+    out = ac.capql_update(qspec, trunk, q0, tq0, pol0, qs, ps, tuple(b.cpu() for b in batch), eps[0].cpu(),
+                          eps[1].cpu(), e.action_scale.cpu(), e.action_bias.cpu(), gamma=ag.gamma, alpha=0.1,
+                          lr=ag.learning_rate, tau=ag.tau, step=1)
+    closs, ploss = ag.last_losses()
+    assert abs(closs - float(out["critic_loss"])) <= 1e-5 * abs(float(out["critic_loss"]))
+    assert abs(ploss - float(out["policy_loss"])) <= 1e-5 * max(abs(float(out["policy_loss"])), 1e-3)
+    assert_lists_close(e.policy_views(e.pol_exp_avg), ps["exp_avg"])
+    for n in range(2):
+        assert_lists_close(e.q_views(e.q_exp_avg, 0, n), qs["exp_avg"][n * 6:(n + 1) * 6])
+        assert_lists_close(e.q_views(e.q_target, 0, n), tq0[n], rtol=1e-5, frac=1e-6)
+    # deterministic action = tanh(mean) * scale + bias of the (updated) policy
+    obs, w = np.linspace(-1, 1, 5).astype(np.float32), np.array([0.3, 0.7], dtype=np.float32)
+    want = ac.capql_policy_action(trunk, cpu(e.policy_views(e.pol)), th.tensor(obs)[None], th.tensor(w)[None],
+                                  e.action_scale.cpu(), e.action_bias.cpu())[0]
+    np.testing.assert_allclose(ag.eval(obs, w), want.numpy(), rtol=1e-5, atol=1e-6)
+    # checkpoint round trip, torch.optim.Adam.state_dict() layout
+    ag.experiment_name = "capql_test"
+    ag.save(save_dir=str(tmp_path), filename="ck", save_replay_buffer=False)
+    ck = th.load(os.path.join(str(tmp_path), "ck.tar"), weights_only=False)
+    assert set(ck["policy_state_dict"]) >= {"latent_pi.0.weight", "mean.weight", "log_std_linear.bias", "action_scale"}
+    assert "net.4.weight" in ck["q_net_0_state_dict"] and float(ck["q_nets_optimizer_state_dict"]["state"][0]["step"]) == 1
+    th.manual_seed(1)
+    ag2 = CAPQL(env, net_arch=[32, 32], batch_size=16, buffer_size=256, log=False, seed=1, device=dev, lib=lib)
+    ag2.load(os.path.join(str(tmp_path), "ck.tar"), load_replay_buffer=False)
+    for name in ("q", "q_target", "pol", "q_exp_avg", "q_exp_avg_sq", "pol_exp_avg"):
+        assert th.equal(getattr(ag2.engine, name), getattr(e, name)), name
+    assert ag2._q_step == 1 and ag2._p_step == 1
+
+
+def test_mosac_update_matches_oracle_and_checkpoints(be):
+    lib, dev = be
+    env = BoxEnv(D=6, Ad=3)
+    th.manual_seed(0)
+    wts = np.array([0.25, 0.75], dtype=np.float32)
+    ag = MOSAC(env, wts, net_arch=[32, 32], batch_size=16, buffer_size=256, log=False, seed=0, device=dev, lib=lib)
+    fill_buffer(ag.buffer, 90, 6, 3, 2)
+    ag.global_step = 4                                   # % policy_freq == 0 -> actor + alpha updates
+    e = ag.engine
+    q0 = [cpu(e.q_views(e.q, 0, n)) for n in range(2)]
+    tq0 = [cpu(e.q_views(e.q_target, 0, n)) for n in range(2)]
+    pol0 = cpu(e.policy_views(e.pol))
+    np.random.seed(5)
+    th.manual_seed(5)
+    snap = rng_snapshot(dev)
+    ag.update()
+    rng_restore(snap, dev)
+    obs, act, rew, nobs, dones = ag.update_inputs()
+    eps = th.randn((5, 16, 3), dtype=th.float32, device=dev).cpu()
+    qspec, trunk = ac.MlpSpec(9, (32, 32), 2), ac.MlpSpec(6, (32, 32))
+    qs = dict(exp_avg=ac.zeros_like(q0[0] + q0[1]), exp_avg_sq=ac.zeros_like(q0[0] + q0[1]))
+    ps = dict(exp_avg=ac.zeros_like(pol0), exp_avg_sq=ac.zeros_like(pol0))
+    als = dict(exp_avg=[th.zeros(1)], exp_avg_sq=[th.zeros(1)])
+    la = th.zeros(1)
+    out = ac.mosac_update(qspec, trunk, q0, tq0, pol0, la, qs, ps, als,
+                          (obs.cpu(), act.cpu(), rew.cpu(), nobs.cpu(), dones.cpu().reshape(-1, 1)), th.tensor(wts),
+                          eps[0], [eps[1], eps[2]], [eps[3], eps[4]], e.action_scale.cpu(), e.action_bias.cpu(),
+                          gamma=ag.gamma, tau=ag.tau, q_lr=ag.q_lr, policy_lr=ag.policy_lr, q_step=1, a_step=1,
+                          policy_freq=2, do_policy=True, do_target=True, autotune=True, alpha=1.0, target_entropy=-3.0)
+    o = ag._out
+    assert abs(float(o["q_losses"][0, 0]) - float(out["qf1_loss"])) <= 1e-5 * float(out["qf1_loss"])
+    assert abs(float(o["policy_loss"][0]) - float(out["actor_losses"][-1])) <= 1e-5 * abs(float(out["actor_losses"][-1]))
+    assert abs(ag.alpha - out["alpha"]) <= 1e-5 * out["alpha"]
+    np.testing.assert_allclose(e.log_alpha.cpu().numpy(), la.numpy(), rtol=1e-5, atol=1e-8)
+    assert_lists_close(e.policy_views(e.pol_exp_avg), ps["exp_avg"])
+    assert_lists_close(e.q_views(e.q_exp_avg, 0, 0) + e.q_views(e.q_exp_avg, 0, 1), qs["exp_avg"])
+    assert ag._q_step == 1 and ag._p_step == 2
+    # save dict round trip into a fresh learner (MORL/D archives use exactly this)
+    sd = ag.get_save_dict(save_replay_buffer=False)
+    assert set(sd["actor_state_dict"]) >= {"latent_pi.0.weight", "fc_mean.weight", "fc_logstd.bias"}
+    assert "critic.4.bias" in sd["qf1_state_dict"] and "log_alpha" in sd
+    th.manual_seed(9)
+    ag2 = MOSAC(env, np.array([0.5, 0.5], dtype=np.float32), net_arch=[32, 32], batch_size=16, buffer_size=64,
+                log=False, seed=1, device=dev, lib=lib)
+    ag2.load(sd, load_replay_buffer=False)
+    for name in ("q", "q_target", "pol", "q_exp_avg", "pol_exp_avg_sq", "log_alpha"):
+        assert th.equal(getattr(ag2.engine, name), getattr(e, name)), name
+    np.testing.assert_array_equal(ag2.weights, wts)
+    # odd global step: critics only
+    ag.global_step = 5
+    pol_before = e.pol.clone()
+    ag.update()
+    assert th.equal(e.pol, pol_before) and ag._q_step == 2 and ag._p_step == 2
+
+
+def test_gpils_update_matches_oracle(be):
+    lib, dev = be
+    env = BoxEnv(D=5, Ad=2, low=-2.0, high=1.0)
+    th.manual_seed(0)
+    ag = GPILSContinuousAction(env, net_arch=[32, 32], batch_size=8, buffer_size=128, gradient_updates=1, per=True,
+                               log=False, seed=0, device=dev, lib=lib, q_drop_rate=0.0)      # LayerNorm on, no dropout
+    fill_buffer(ag.replay_buffer, 60, 5, 2, 2, low=-2.0, high=1.0)
+    support = [np.array([1.0, 0.0], np.float32), np.array([0.0, 1.0], np.float32), np.array([0.4, 0.6], np.float32)]
+    ag.set_weight_support(support)
+    e = ag.engine
+    q0 = [cpu(e.q_views(e.q, 0, n)) for n in range(2)]
+    tq0 = [cpu(e.q_views(e.q_target, 0, n)) for n in range(2)]
+    pol0, tpol0 = cpu(e.policy_views(e.pol)), cpu(e.policy_views(e.pol_target))
+    weight = th.tensor([0.7, 0.3])
+    np.random.seed(2); random.seed(2); th.manual_seed(2)
+    snap = rng_snapshot(dev)
+    ag.update(weight)
+    tree_after = ag.replay_buffer.tree_dev.clone()
+    rng_restore(snap, dev)
+    # replay the draws: PER indices come from the tree as it was BEFORE the priority update -> rebuild from a copy
+    ag2_idx_u = np.random.random_sample(8)
+    del ag2_idx_u
+    rng_restore(snap, dev)
+    qspec = ac.MlpSpec(5 + 2 + 2, (32, 32), 2, layer_norm=True)
+    trunk = ac.MlpSpec(5 + 2, (32, 32))
+    # the batch the agent used: ask a pristine twin (same buffer contents, untouched tree)
+    th.manual_seed(0)
+    twin = GPILSContinuousAction(env, net_arch=[32, 32], batch_size=8, buffer_size=128, gradient_updates=1, per=True,
+                                 log=False, seed=0, device=dev, lib=lib, q_drop_rate=0.0)
+    fill_buffer(twin.replay_buffer, 60, 5, 2, 2, low=-2.0, high=1.0)
+    rng_restore(snap, dev)
+    s_obs, s_act, s_rew, s_nobs, s_done, idx = twin._sample_batch_experiences()
+    ws = [th.tensor(s) for s in support]
+    w = th.vstack([weight.expand(8, -1)] + random.choices(ws, k=8))
+    noise = th.randn((16, 2), dtype=th.float32, device=dev).cpu()
+    batch = [x.cpu().repeat(2, 1) for x in (s_obs, s_act, s_rew, s_nobs, s_done)]
+    qs = dict(exp_avg=ac.zeros_like(q0[0] + q0[1]), exp_avg_sq=ac.zeros_like(q0[0] + q0[1]))
+    ps = dict(exp_avg=ac.zeros_like(pol0), exp_avg_sq=ac.zeros_like(pol0))
+    out = ac.gpipd_cont_update(qspec, trunk, q0, tq0, pol0, tpol0, qs, ps, batch, w, noise, {}, e.action_scale.cpu(),
+                               e.action_bias.cpu(), gamma=ag.gamma, lr=ag.learning_rate, tau=ag.tau, q_step=1, p_step=1,
+                               do_policy=True, n_per=8)
+    assert abs(float(ag._out["critic_loss"][0]) - float(out["critic_loss"])) <= 1e-5 * float(out["critic_loss"])
+    assert abs(float(ag._out["policy_loss"][0]) - float(out["policy_loss"])) <= 1e-5 * max(abs(float(out["policy_loss"])), 1e-3)
+    assert_lists_close(e.q_views(e.q_exp_avg, 0, 0) + e.q_views(e.q_exp_avg, 0, 1), qs["exp_avg"])
+    assert_lists_close(e.policy_views(e.pol_exp_avg), ps["exp_avg"], frac=5e-5)
+    assert_lists_close(e.policy_views(e.pol_target), tpol0, rtol=1e-5, frac=1e-6)
+    # priorities reached the device tree: leaves of the sampled indices = clip(|td|*0.05 . w, 0.1) ** 0.6
+    twin.replay_buffer.update_priorities(idx, th.tensor(out["priority"].astype(np.float32)))
+    np.testing.assert_allclose(tree_after.cpu().numpy(), twin.replay_buffer.tree_dev.cpu().numpy(), rtol=2e-5)
+    # GPI evaluation: best of the |M| conditioned policies under critic 0
+    ag.use_gpi = True
+    a = ag.eval(np.linspace(-1, 1, 5).astype(np.float32), np.array([0.5, 0.5], np.float32))
+    assert a.shape == (2,) and np.all(a >= -2.0 - 1e-6) and np.all(a <= 1.0 + 1e-6)
+    obs_t = th.linspace(-1, 1, 5)[None]
+    M = th.stack(ws)
+    pol = cpu(e.policy_views(e.pol))
+    acts = ac.td3_policy(trunk, pol, obs_t.expand(3, -1), M, e.action_scale.cpu(), e.action_bias.cpu())
+    qn = cpu(e.q_views(e.q, 0, 0))
+    vals = th.stack([ac.mlp_forward(qspec, qn, th.cat((obs_t.expand(3, -1), acts, M[p].expand(3, -1)), dim=-1))
+                     for p in range(3)])                                           # (p, a, R)
+    sc = th.einsum("par,r->pa", vals, th.tensor([0.5, 0.5]))
+    mq, ai = th.max(sc, dim=1)
+    np.testing.assert_allclose(a, acts[ai[th.argmax(mq)]].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_morld_population_update(be):
+    lib, dev = be
+    env = BoxEnv(D=4, Ad=2)
+    th.manual_seed(0)
+    np.random.seed(0)
+    algo = MORLD(env, pop_size=4, policy_args=dict(net_arch=[16, 16], batch_size=8, buffer_size=64), update_passes=2,
+                 shared_buffer=True, exchange_every=10, log=False, seed=3, device=dev, lib=lib,
+                 sharing_mechanism=["transfer"])
+    assert algo.weights.shape == (4, 2) and np.allclose(algo.weights.sum(1), 1.0)
+    # members are slices of the population engine and share one replay buffer
+    e = algo.engine
+    assert algo.population[2].wrapped.engine.q.data_ptr() == e.q[2].data_ptr()
+    assert all(p.wrapped.get_buffer() is algo.population[0].wrapped.get_buffer() for p in algo.population)
+    fill_buffer(algo.population[0].wrapped.get_buffer(), 40, 4, 2, 2)
+    for p in algo.population:
+        p.wrapped.global_step = 10
+    before = {k: getattr(e, k).clone() for k in ("q", "pol", "q_target", "log_alpha")}
+    cur = algo.population[1]
+    algo._update_others(cur)
+    if dev.type == "cuda":
+        th.cuda.synchronize()
+    for i in range(4):
+        changed = not th.equal(e.q[i], before["q"][i])
+        assert changed == (i != 1), i
+        assert (not th.equal(e.pol[i], before["pol"][i])) == (i != 1)
+    assert e.q_steps.cpu().tolist() == [2, 0, 2, 2] and e.pol_steps.cpu().tolist() == [4, 0, 4, 4]
+    assert [p.wrapped._q_step for p in algo.population] == [2, 0, 2, 2]
+    # a member can still advance on its own (its own workspace, its slice of the state, the device step counter)
+    cur.wrapped.update()
+    assert e.q_steps.cpu().tolist() == [2, 1, 2, 2] and not th.equal(e.q[1], before["q"][1])
+    # transfer: the trained actor is copied to the not-yet-trained neighbours
+    algo.neighborhoods[1] = [0, 2]
+    algo._share(cur)
+    assert th.equal(e.pol[2], e.pol[1]) and not th.equal(e.pol[0], e.pol[1]) and int(e.pol_steps[2]) == 0
+    # archive pruning through the device Pareto mask
+    for k, ev in enumerate([[1.0, 0.0], [0.0, 1.0], [0.4, 0.4], [0.6, 0.6]]):
+        algo.archive.add(algo.population[k], np.array(ev))
+    got = sorted(tuple(np.round(x, 3)) for x in algo.archive.evaluations)
+    assert got == [(0.0, 1.0), (0.6, 0.6), (1.0, 0.0)]
+
+
+def test_simplex_lattice_weights():
+    for dim, n in ((2, 6), (3, 6), (3, 64), (4, 10)):
+        w = simplex_lattice_weights(dim, n)
+        assert w.shape == (n, dim) and np.allclose(w.sum(1), 1.0) and (w >= 0).all()
+        assert len({tuple(r) for r in np.round(w, 9)}) == n
+
+
+def test_short_training_runs(be):
+    """train() of every agent steps the environment, fills the device replay and updates without host fallbacks."""
+    lib, dev = be
+    th.manual_seed(0); np.random.seed(0); random.seed(0)
+    env = BoxEnv(D=4, Ad=2)
+    env.reward_dim = 2
+    ag = CAPQL(env, net_arch=[16, 16], batch_size=8, buffer_size=128, learning_starts=12, log=False, seed=0,
+               device=dev, lib=lib)
+    p0 = ag.engine.pol.clone()
+    ag.train(total_timesteps=20)
+    assert ag.global_step == 20 and ag._q_step == 9 and not th.equal(p0, ag.engine.pol)
+    ms = MOSAC(BoxEnv(D=4, Ad=2), np.array([0.5, 0.5], np.float32), net_arch=[16, 16], batch_size=8, buffer_size=128,
+               learning_starts=10, log=False, seed=0, device=dev, lib=lib)
+    ms.train(total_timesteps=18)
+    assert ms.global_step == 18 and ms._q_step == 7 and np.isfinite(ms.alpha)
+    gp = GPILSContinuousAction(BoxEnv(D=4, Ad=2), net_arch=[16, 16], batch_size=8, buffer_size=128, learning_starts=10,
+                               gradient_updates=2, per=True, log=False, seed=0, device=dev, lib=lib)
+    sup = [np.array([1.0, 0.0]), np.array([0.0, 1.0])]
+    gp.train_iteration(total_timesteps=14, weight=np.array([0.5, 0.5]), weight_support=sup,
+                       change_weight_every_episode=True)
+    assert gp.global_step == 14 and gp._n_updates == 10 and gp._p_step == 5
+    assert np.isfinite(gp.replay_buffer.tree_dev.cpu().numpy()).all()
+    with pytest.raises(NotImplementedError):
+        GPIPDContinuousAction(BoxEnv(D=4, Ad=2), log=False, device=dev, lib=lib)      # dyna=True (reference default)

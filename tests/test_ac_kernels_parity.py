@@ -25,11 +25,15 @@ def be(request):
 
 
 def build_engine(c, inp, lib, dev, population=1):
+    """inp: one input dict (copied into every learner) or a list with one dict per learner."""
+    inps = inp if isinstance(inp, list) else [inp] * population
+    population = len(inps)
     eng = ACEngine(ALGO[c.algo], c.D, c.Ad, c.R, c.arch, action_low=c.low, action_high=c.high,
                    max_rows=2 * c.B, q_layer_norm=(c.algo == "gpipd" and c.layer_norm),
                    q_drop_rate=(c.drop_rate if c.algo == "gpipd" else 0.0), population=population, device=dev, lib=lib)
     with th.no_grad():
         for p in range(population):
+            inp = inps[p]
             for n in range(2):
                 for v, src in zip(eng.q_views(eng.q, p, n), inp["q"][n]):
                     v.copy_(src)
@@ -169,3 +173,53 @@ def test_update_matches_oracle_and_reference(be, c):
     if "priority" in g:
         pr = res["priority"][0].numpy().clip(min=0.1) ** 0.6
         np.testing.assert_allclose(pr, g["priority"], rtol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["mosac_small", "capql_step5", "gpipd_support_per"])
+def test_population_batch_equals_independent_learners(be, name):
+    """MORL/D row (morld.py:423-433): a population advanced by ONE call is bit-identical to its members advanced one
+    by one -- the learner axis only adds workgroups, it never mixes arithmetic between learners."""
+    import dataclasses
+    lib, dev = be
+    c = [x for x in AC_CASES if x.name == name][0]
+    inps = [make_inputs(dataclasses.replace(c, seed=c.seed + 100 * k)) for k in range(3)]
+    singles = []
+    for inp in inps:
+        e = build_engine(c, inp, lib, dev)
+        r = run_engine(c, inp, e, ["critic_loss", "policy_loss"])
+        singles.append((e, r))
+    pop = build_engine(c, inps, lib, dev)
+    stack = lambda key: np.stack([np.asarray(i[key]) for i in inps])  # noqa: E731
+    if c.algo == "mosac":
+        cfg = pop.make_cfg(gamma=c.gamma, tau=c.tau, alpha=c.alpha, q_lr=c.q_lr, policy_lr=c.lr, alpha_lr=c.q_lr,
+                           q_step=c.step, policy_step=c.step, do_policy=True, policy_iters=c.policy_freq,
+                           autotune=c.autotune, target_entropy=-float(c.Ad))
+        res = pop.update(cfg, obs=stack("obs"), actions=stack("actions"), rewards=stack("rewards"),
+                         next_obs=stack("next_obs"), dones=stack("dones"), w=stack("weights"),
+                         eps_next=stack("eps_next"),
+                         eps_pi=np.stack([np.stack([i["eps_pi"][k] for i in inps]) for k in range(c.policy_freq)]),
+                         eps_alpha=np.stack([np.stack([i["eps_alpha"][k] for i in inps]) for k in range(c.policy_freq)]))
+    elif c.algo == "capql":
+        cfg = pop.make_cfg(gamma=c.gamma, tau=c.tau, alpha=c.alpha, q_lr=c.lr, policy_lr=c.lr, q_step=c.step,
+                           policy_step=c.step)
+        res = pop.update(cfg, obs=stack("obs"), actions=stack("actions"), rewards=stack("rewards"),
+                         next_obs=stack("next_obs"), dones=stack("dones"), w=stack("w"), eps_next=stack("eps_next"),
+                         eps_pi=np.stack([i["eps_pi"][0] for i in inps]))
+    else:
+        rows = [gpipd_rows(c, i) for i in inps]
+        masks = [pack_masks(c, i, dev).cpu().numpy().reshape(3, -1) for i in inps]       # [phase][per-learner bytes]
+        cfg = pop.make_cfg(gamma=c.gamma, tau=c.tau, q_lr=c.lr, policy_lr=c.lr, q_step=c.step, policy_step=c.step,
+                           do_policy=True, n_per=c.B)
+        res = pop.update(cfg, **{k: np.stack([r[0][j].numpy() for r in rows]) for j, k in
+                                 enumerate(("obs", "actions", "rewards", "next_obs", "dones"))},
+                         w=np.stack([r[1].numpy() for r in rows]), eps_next=stack("eps_next"),
+                         drop_masks=th.tensor(np.concatenate([np.concatenate([m[ph] for m in masks]) for ph in range(3)])).to(dev))
+    for k, (e, r) in enumerate(singles):
+        assert th.equal(pop.q[k], e.q[0]) and th.equal(pop.q_target[k], e.q_target[0])
+        assert th.equal(pop.pol[k], e.pol[0]) and th.equal(pop.q_exp_avg_sq[k], e.q_exp_avg_sq[0])
+        assert th.equal(pop.pol_exp_avg[k], e.pol_exp_avg[0])
+        assert th.equal(res["critic_loss"][k], r["critic_loss"][0]) and th.equal(res["policy_loss"][k], r["policy_loss"][0])
+        if c.algo == "mosac":
+            assert th.equal(pop.log_alpha[k], e.log_alpha[0])
+        if c.algo == "gpipd":
+            assert th.equal(pop.pol_target[k], e.pol_target[0])
