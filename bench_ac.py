@@ -1,0 +1,201 @@
+"""Actor-critic update benchmark (the "next" rows of SURVEY.md section 8: C3 CAPQL, M1/M2 MOSAC / MORL-D, G7 GPI-PD
+continuous) on one MI355X.  bench.py stays the north-star (Envelope) line the driver runs; this script measures the
+widened rows with the same conventions:
+
+    python bench_ac.py --workload capql|mosac|morld|gpipd [--pop 64] [--steps K] [--warmup W] [--no-cpu-baseline]
+
+One "step" = one gradient update of every learner in the job (``update()`` body of the reference agent; for ``morld``
+one pass of ``MORLD.__update_others`` over ``pop`` sub-problem learners, morld.py:423-433), on synthetic transitions
+resident in HBM, reference-default shapes (batch 128, net [256, 256], twin critics).  ``value`` = learner-updates/s.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch as th
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+
+SHAPES = {  # obs dim, action dim, objectives of the environments BASELINE.json names
+    "capql": dict(D=17, Ad=6, R=2, env="mo-halfcheetah-v4"),
+    "mosac": dict(D=11, Ad=3, R=3, env="mo-hopper-v4"),
+    "morld": dict(D=11, Ad=3, R=3, env="mo-hopper-v4"),
+    "gpipd": dict(D=11, Ad=3, R=3, env="mo-hopper-v4"),
+}
+ARCH = [256, 256]
+B = 128
+
+
+def mlp_macs(dims):
+    return sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+
+
+def update_flop(workload, D, Ad, R, rows, policy_iters, do_policy=True):
+    """Algorithmic flop of one learner's update: 2 * MACs per row for a forward, dX backward (all layers but the first,
+    plus the first for the actor path) and dW backward; element-wise work not counted."""
+    w_in = 0 if workload in ("mosac", "morld") else R
+    heads = 1 if workload == "gpipd" else 2
+    q = [D + Ad + w_in] + ARCH + [R]
+    p = [D + w_in] + ARCH + [heads * Ad]
+    fq, fp = mlp_macs(q), mlp_macs(p)
+    dxq, dxp = fq - q[0] * q[1], fp - p[0] * p[1]
+    macs = fp + 2 * fq                 # a' and the twin target critics
+    macs += 2 * (fq + dxq + fq)        # twin critics: forward, dX, dW
+    if do_policy:
+        per_iter = fp + 2 * fq + 2 * fq + (dxp + fp)      # actor fwd, critics fwd, critics dX (incl. layer 0), actor bwd
+        if workload in ("mosac", "morld"):
+            per_iter += fp                                  # fresh log-prob for the alpha step
+        macs += policy_iters * per_iter
+    return 2.0 * macs * rows
+
+
+def cpu_baseline(workload, shp, pop, budget_s=20.0):
+    """The oracle (torch-CPU restatement of the reference update) on this box's host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ac_oracle as ac
+
+    D, Ad, R = shp["D"], shp["Ad"], shp["R"]
+    gen = th.Generator().manual_seed(0)
+    rnd = lambda *s: th.randn(*s, generator=gen)  # noqa: E731
+    w_in = workload not in ("mosac", "morld")
+    qspec = ac.MlpSpec(D + Ad + (R if w_in else 0), tuple(ARCH), R, layer_norm=(workload == "gpipd"),
+                       drop_rate=0.01 if workload == "gpipd" else 0.0)
+    trunk = ac.MlpSpec(D + (R if w_in else 0), tuple(ARCH))
+    heads = 1 if workload == "gpipd" else 2
+    q = [ac.init_mlp_params(qspec, gen) for _ in range(2)]
+    tq = [ac.clone(n) for n in q]
+    pol = ac.init_mlp_params(trunk, gen)
+    for _ in range(heads):
+        pol += [rnd(Ad, ARCH[-1]) * 0.05, th.zeros(Ad)]
+    tpol = ac.clone(pol)
+    qs = dict(exp_avg=ac.zeros_like(q[0] + q[1]), exp_avg_sq=ac.zeros_like(q[0] + q[1]))
+    ps = dict(exp_avg=ac.zeros_like(pol), exp_avg_sq=ac.zeros_like(pol))
+    als = dict(exp_avg=[th.zeros(1)], exp_avg_sq=[th.zeros(1)])
+    la = th.zeros(1)
+    scale, bias = th.ones(Ad), th.zeros(Ad)
+    wv = th.softmax(rnd(B, R), dim=1)
+    obs, act, rew, nobs, done = rnd(B, D), th.tanh(rnd(B, Ad)), rnd(B, R), rnd(B, D), (th.rand(B, 1, generator=gen) < 0.05).float()
+
+    def one(step):
+        if workload == "capql":
+            ac.capql_update(qspec, trunk, q, tq, pol, qs, ps, (obs, act, wv, rew, nobs, done.reshape(-1)), rnd(B, Ad),
+                            rnd(B, Ad), scale, bias, gamma=0.99, alpha=0.2, lr=3e-4, tau=0.005, step=step)
+        elif workload in ("mosac", "morld"):
+            ac.mosac_update(qspec, trunk, q, tq, pol, la, qs, ps, als, (obs, act, rew, nobs, done), wv[0], rnd(B, Ad),
+                            [rnd(B, Ad), rnd(B, Ad)], [rnd(B, Ad), rnd(B, Ad)], scale, bias, gamma=0.99, tau=0.005,
+                            q_lr=1e-3, policy_lr=3e-4, q_step=step, a_step=2 * step - 1, policy_freq=2, do_policy=True,
+                            do_target=True, autotune=True, alpha=float(la.exp()), target_entropy=-float(Ad))
+        else:
+            rows = 2 * B
+            rep = lambda x: x.repeat(2, 1)  # noqa: E731
+            keep = lambda: [(th.rand(rows, h, generator=gen) >= 0.01).float() for h in ARCH]  # noqa: E731
+            drop = {k: [keep(), keep()] for k in ("target", "q", "q_pi")}
+            ac.gpipd_cont_update(qspec, trunk, q, tq, pol, tpol, qs, ps, [rep(obs), rep(act), rep(rew), rep(nobs), rep(done)],
+                                 rep(wv), rnd(rows, Ad), drop, scale, bias, gamma=0.99, lr=3e-4, tau=0.005, q_step=step,
+                                 p_step=step, do_policy=True, n_per=B)
+
+    one(1)
+    times, step = [], 2
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end and len(times) < 200:
+        t0 = time.perf_counter()
+        one(step)
+        times.append(time.perf_counter() - t0)
+        step += 1
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "learner-updates/s", "cores": th.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} timed single-learner updates (+1 warm-up) of oracle/ac_oracle.py on torch-CPU, median; "
+                      f"the reference advances a population of {pop} sequentially, i.e. at this rate"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="morld", choices=sorted(SHAPES))
+    ap.add_argument("--pop", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    if not th.cuda.is_available():
+        raise SystemExit("bench_ac.py needs an MI355X (no CPU fallback exists)")
+    dev = th.device("cuda", 0)
+    th.cuda.set_device(dev)
+    from morl_baselines_amd.ac_engine import ALGO_CAPQL, ALGO_MOSAC, ALGO_TD3, ACEngine
+
+    wl, shp = a.workload, SHAPES[a.workload]
+    D, Ad, R = shp["D"], shp["Ad"], shp["R"]
+    pop = a.pop if a.pop is not None else (64 if wl == "morld" else 1)
+    algo = {"capql": ALGO_CAPQL, "mosac": ALGO_MOSAC, "morld": ALGO_MOSAC, "gpipd": ALGO_TD3}[wl]
+    rows = 2 * B if wl == "gpipd" else B
+    eng = ACEngine(algo, D, Ad, R, ARCH, action_low=-1.0, action_high=1.0, max_rows=rows, population=pop, device=dev,
+                   q_layer_norm=(wl == "gpipd"), q_drop_rate=(0.01 if wl == "gpipd" else 0.0), device_steps=True)
+    gen = th.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: th.randn(*s, generator=gen, device=dev)  # noqa: E731
+    with th.no_grad():                          # orthogonal-ish scale; the values do not matter for timing
+        eng.q.copy_(rnd(*eng.q.shape) * 0.05)
+        eng.pol.copy_(rnd(*eng.pol.shape) * 0.05)
+        if eng.layer_norm:
+            for p_ in range(pop):
+                for n in range(2):
+                    v = eng.q_views(eng.q, p_, n)
+                    for k in (2, 6):
+                        v[k].fill_(1.0)
+        eng.q_target.copy_(eng.q)
+        if eng.pol_target is not None:
+            eng.pol_target.copy_(eng.pol)
+    obs, nobs = rnd(pop, rows, D), rnd(pop, rows, D)
+    act, rew = th.tanh(rnd(pop, rows, Ad)), rnd(pop, rows, R)
+    done = (th.rand(pop, rows, generator=gen, device=dev) < 0.05).float()
+    w = th.softmax(rnd(pop, rows if eng.w_input else 1, R), dim=-1).contiguous()
+    iters = 2 if algo == ALGO_MOSAC else 1
+    state = {"seed": 0}
+
+    def step():
+        state["seed"] += 1
+        cfg = eng.make_cfg(q_lr=1e-3 if algo == ALGO_MOSAC else 3e-4, policy_iters=iters, autotune=(algo == ALGO_MOSAC),
+                           target_entropy=-float(Ad), n_per=(B if wl == "gpipd" else 0), dropout_seed=state["seed"])
+        eps = th.randn((1 + 2 * iters, pop, rows, Ad), dtype=th.float32, device=dev)      # the host agents draw these too
+        eng.update(cfg, obs=obs, actions=act, rewards=rew, next_obs=nobs, dones=done, w=w, eps_next=eps[0],
+                   eps_pi=eps[1:1 + iters], eps_alpha=eps[1 + iters:], want=("critic_loss",))
+
+    for _ in range(a.warmup):
+        step()
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    th.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = wall * 1e3 / a.steps
+    flop = update_flop(wl, D, Ad, R, rows, iters) * pop
+    tf = flop / (ms * 1e-3) / 1e12
+    out = {
+        "metric": "actor-critic learner updates/sec", "value": pop * a.steps / wall, "unit": "learner-updates/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{wl}: {pop} learner(s) x batch {B} ({rows} rows), net {ARCH}, twin critics, shapes of "
+                               f"{shp['env']} (obs {D}, act {Ad}, {R} objectives); one morl_ac_update per step",
+                   "population": pop, "rows": rows},
+        "roofline": {"bound": "mfma", "kernel": "gemm_batched (exact-fp32 MFMA layers of all nets / learners)",
+                     "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
+                     "traffic": None,
+                     "note": "algorithmic GEMM flop of the whole update / wall time of the step (launch-latency included): "
+                             "a lower bound of the kernels' own rate; per-kernel durations in profiles/"},
+        "algorithmic_flop_per_step": flop,
+    }
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, shp, pop)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -310,6 +310,10 @@ int64_t morl_ac_policy_param_count(const morl_ac_desc* d);
  * for net in [active][num_q]: for hidden layer l: rows * h_l keep flags (row-major) */
 int64_t morl_ac_mask_bytes(const morl_ac_desc* d, int rows);
 int morl_ac_create(morl_ac_ctx** out, const morl_ac_desc* d);
+/* Dense-layer engine of the actor-critic path (process-wide tuning knob; results are bit-identical either way):
+ * 0 = pick per launch (wave-level 32 x 32 MFMA tiles while the launch has < 128 LDS tiles of 128 x 128, the LDS-tiled
+ * engine above that), 1 = always LDS tiles, 2 = always wave-level tiles. */
+int morl_ac_set_gemm_mode(int mode);
 int morl_ac_destroy(morl_ac_ctx* ctx);
 
 /* One gradient update of every learner (the body of the reference's update() loop), asynchronous on `stream`. */

@@ -8,6 +8,7 @@
 // one wave per activation row with shuffle reductions, or one thread per batch row for the O(Ad + R) head math.
 #pragma once
 #include "gemm_f32.h"
+#include "gemm_wave.h"
 #include "morl_device.h"
 #include "morl_hip.h"
 
@@ -57,6 +58,36 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_grouped_tn_batched_kernel(G
     g.C += (long long)z * grp.sC;
     g.colsum += (long long)z * grp.sC;
     gemm_tile<false, false, EPI_STORE>(g, local / g.tiles_n, local % g.tiles_n, 0);
+}
+
+// wave-level variants (gemm_wave.h) for small batches of nets: 4 waves = 4 independent 32 x 32 tiles per workgroup;
+// p.tiles_m / p.tiles_n count 32-wide tiles here
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm_wave_batched_kernel(GemmBatched b) {
+    const int tile = (int)blockIdx.x * 4 + wave_id();
+    if (tile >= b.p.tiles_m * b.p.tiles_n) return;
+    GemmProblem g = b.p;
+    const int z = (int)blockIdx.z;
+    g.A += (long long)(z / b.a_div) * b.sA;
+    g.B += (long long)z * b.sB;
+    g.C += (long long)z * b.sC;
+    if (g.bias) g.bias += (long long)z * b.sBias;
+    if (g.mask) g.mask += (long long)z * b.sMask;
+    gemm_wave_tile<A_KC, B_KC, EPI>(g, tile / g.tiles_n, tile % g.tiles_n);
+}
+
+__global__ __launch_bounds__(256) void gemm_wave_grouped_tn_batched_kernel(GemmGroupBatched grp) {
+    const int id = (int)blockIdx.x * 4 + wave_id(), z = (int)blockIdx.z;
+    if (id >= grp.tile_start[grp.n]) return;
+    int q = 0;
+    while (q + 1 < grp.n && id >= grp.tile_start[q + 1]) ++q;
+    const int local = id - grp.tile_start[q];
+    GemmProblem g = grp.p[q];
+    g.A += (long long)z * grp.sA[q];
+    g.B += (long long)(z / grp.b_div[q]) * grp.sB[q];
+    g.C += (long long)z * grp.sC;
+    g.colsum += (long long)z * grp.sC;
+    gemm_wave_tile<false, false, EPI_STORE>(g, local / g.tiles_n, local % g.tiles_n);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,112 @@
+// Wave-level exact-fp32 MFMA GEMM for LATENCY-bound problems (gfx950, wave64).
+//
+// The actor-critic learners run 128-256 batch rows through [256, 256] layers: 17 MFLOP per layer.  The LDS-tiled engine
+// of gemm_f32.h gives such a problem to two workgroups, each a >= 13.6 us dependent chain of 512 MFMAs per wave plus a
+// barrier per 32-deep chunk -- the whole chip waits on 8 waves.  Here every wave owns ONE 32 x 32 tile of C and the
+// full K range: 4x the waves, no LDS, no barriers, operands streamed global/L2 -> registers (the weights of these nets
+// are L2 resident: 0.26 MB per layer), a 64-cycle v_mfma_f32_32x32x2_f32 per two k.  The k loop accumulates into one
+// register tile in ascending k, exactly like gemm_tile<> -- results are bit-identical to the tiled engine, so the host
+// can pick either by problem size.
+//
+// Operand addressing of lane (i = lane & 31, h = lane >> 5) for the MFMA of k-pair (k, k+1): A(m0+i, k+h), B(k+h, n0+i).
+//   *_KC = 1 : operand is K-contiguous in memory (activations X[m][k], weights W[n][k]): one 16-byte load covers the
+//              lane's elements of two MFMAs (k4+h and k4+2+h);
+//   *_KC = 0 : operand is M/N-contiguous (dZ^T for dW, W for dX): 4-byte loads, 128 B coalesced per half-wave.
+#pragma once
+#include "gemm_f32.h"
+
+namespace morl {
+
+constexpr int WG_CHUNK = 16;   // k values per register stage
+
+template <bool KC>
+struct WaveStage {
+    float v[WG_CHUNK / 2];     // this lane's operand elements for the 8 MFMAs of a stage
+};
+
+// load the lane's elements of k range [k0, k0 + 16): element s <-> k = k0 + 2 * s + h
+template <bool KC>
+__device__ __forceinline__ void wave_load(WaveStage<KC>& st, const float* __restrict__ P, int ld, int idx, int extent,
+                                          int k0, int kend, int h, int vec) {
+    if (KC) {
+        const bool ok = idx < extent;
+        const float* __restrict__ row = P + (size_t)(ok ? idx : 0) * ld;
+#pragma unroll
+        for (int q = 0; q < WG_CHUNK / 4; ++q) {
+            const int k4 = k0 + 4 * q;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                if (vec && k4 + 3 < kend) {
+                    t = *reinterpret_cast<const float4*>(row + k4);
+                } else {
+                    if (k4 < kend) t.x = row[k4];
+                    if (k4 + 1 < kend) t.y = row[k4 + 1];
+                    if (k4 + 2 < kend) t.z = row[k4 + 2];
+                    if (k4 + 3 < kend) t.w = row[k4 + 3];
+                }
+            }
+            st.v[2 * q] = h ? t.y : t.x;
+            st.v[2 * q + 1] = h ? t.w : t.z;
+        }
+    } else {
+        const bool ok = idx < extent;
+#pragma unroll
+        for (int s = 0; s < WG_CHUNK / 2; ++s) {
+            const int k = k0 + 2 * s + h;
+            st.v[s] = (ok && k < kend) ? P[(size_t)k * ld + idx] : 0.f;
+        }
+    }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__device__ __forceinline__ void gemm_wave_tile(const GemmProblem& g, int tile_m, int tile_n) {
+    const int lane = lane_id();
+    const int h = lane >> 5, i = lane & 31;
+    const int m0 = tile_m * 32, n0 = tile_n * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float colsum = 0.f;
+    const bool do_colsum = (g.colsum != nullptr) && (tile_n == 0);
+
+    WaveStage<A_KC> a0, a1;
+    WaveStage<B_KC> b0, b1;
+    const int K = g.K;
+    wave_load<A_KC>(a0, g.A, g.lda, m0 + i, g.M, 0, K, h, g.a_vec);
+    wave_load<B_KC>(b0, g.B, g.ldb, n0 + i, g.N, 0, K, h, g.b_vec);
+    for (int k0 = 0; k0 < K; k0 += 2 * WG_CHUNK) {
+        wave_load<A_KC>(a1, g.A, g.lda, m0 + i, g.M, k0 + WG_CHUNK, K, h, g.a_vec);
+        wave_load<B_KC>(b1, g.B, g.ldb, n0 + i, g.N, k0 + WG_CHUNK, K, h, g.b_vec);
+#pragma unroll
+        for (int s = 0; s < WG_CHUNK / 2; ++s) {
+            acc = mfma32(a0.v[s], b0.v[s], acc);
+            if (do_colsum) { const float odd = __shfl_xor(a0.v[s], 32); colsum += a0.v[s]; colsum += odd; }
+        }
+        wave_load<A_KC>(a0, g.A, g.lda, m0 + i, g.M, k0 + 2 * WG_CHUNK, K, h, g.a_vec);
+        wave_load<B_KC>(b0, g.B, g.ldb, n0 + i, g.N, k0 + 2 * WG_CHUNK, K, h, g.b_vec);
+#pragma unroll
+        for (int s = 0; s < WG_CHUNK / 2; ++s) {
+            acc = mfma32(a1.v[s], b1.v[s], acc);
+            if (do_colsum) { const float odd = __shfl_xor(a1.v[s], 32); colsum += a1.v[s]; colsum += odd; }
+        }
+    }
+
+    const int col = n0 + i;
+    float bias = 0.f;
+    if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && col < g.N) bias = g.bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < g.M && col < g.N) {
+            float v = acc[r];
+            if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) v += bias;
+            if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+            if (EPI == EPI_RELU_MASK) v = (g.mask[(size_t)row * g.ldmask + col] > 0.f) ? v : 0.f;
+            g.C[(size_t)row * g.ldc + col] = v;
+        }
+    }
+    // half-wave 0 added (even k, then its partner's odd k) in ascending k: the order of gemm_tile's column sums
+    if (do_colsum && h == 0 && m0 + i < g.M) g.colsum[m0 + i] = colsum;
+}
+
+}  // namespace morl

@@ -193,6 +193,16 @@ extern "C" int morl_ac_create(morl_ac_ctx** out, const morl_ac_desc* d) {
 // ---------------------------------------------------------------------------------------------------------------------
 // batched layer launches
 // ---------------------------------------------------------------------------------------------------------------------
+// Engine choice per launch: the LDS-tiled 128 x 128 engine needs >= ~half a chip of tiles to be worth its barriers;
+// below that the work is latency-bound and the wave-level 32 x 32 tiles (gemm_wave.h) spread it over 16x more waves.
+// Both accumulate in the same order -> identical bits, so the choice never shows in the results.
+static int g_ac_gemm_mode = 0;      // 0 auto, 1 always LDS tiles, 2 always wave tiles (morl_ac_set_gemm_mode)
+static bool use_wave_tiles(long long tiles128) {
+    if (g_ac_gemm_mode == 1) return false;
+    if (g_ac_gemm_mode == 2) return true;
+    return tiles128 < 128;
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 static int launch_bgemm(GemmBatched b, int G, hipStream_t s, const char* name) {
     GemmProblem& g = b.p;
@@ -201,8 +211,20 @@ static int launch_bgemm(GemmBatched b, int G, hipStream_t s, const char* name) {
     g.a_vec = vec_ok(g.A, g.lda) && (b.sA % 4 == 0);
     g.b_vec = vec_ok(g.B, g.ldb) && (b.sB % 4 == 0);
     g.k_per_split = round_up(g.K, GEMM_BK);
-    hipLaunchKernelGGL((gemm_batched_kernel<A_KC, B_KC, EPI>), dim3(g.tiles_m * g.tiles_n, 1, G), dim3(GEMM_THREADS), 0, s, b);
+    if (use_wave_tiles((long long)g.tiles_m * g.tiles_n * G)) {
+        g.tiles_m = (g.M + 31) / 32;
+        g.tiles_n = (g.N + 31) / 32;
+        hipLaunchKernelGGL((gemm_wave_batched_kernel<A_KC, B_KC, EPI>), dim3((g.tiles_m * g.tiles_n + 3) / 4, 1, G), dim3(256), 0, s, b);
+    } else {
+        hipLaunchKernelGGL((gemm_batched_kernel<A_KC, B_KC, EPI>), dim3(g.tiles_m * g.tiles_n, 1, G), dim3(GEMM_THREADS), 0, s, b);
+    }
     LAUNCH_CHECK(name);
+    return MORL_OK;
+}
+
+extern "C" int morl_ac_set_gemm_mode(int mode) {
+    if (mode < 0 || mode > 2) return fail(MORL_ERR_ARG, "gemm mode %d not in 0..2", mode);
+    g_ac_gemm_mode = mode;
     return MORL_OK;
 }
 
@@ -341,7 +363,20 @@ static int mlp_backward(morl_ac_ctx* c, const Mlp& m, const float* params, int64
             tiles += g.tiles_m * g.tiles_n;
         }
         grp.tile_start[m.L] = tiles;
-        hipLaunchKernelGGL(gemm_grouped_tn_batched_kernel, dim3(tiles, 1, t.G), dim3(GEMM_THREADS), 0, s, grp);
+        if (use_wave_tiles((long long)tiles * t.G)) {
+            tiles = 0;
+            for (int l = 0; l < m.L; ++l) {
+                GemmProblem& g = grp.p[l];
+                g.tiles_m = (g.M + 31) / 32;
+                g.tiles_n = (g.N + 31) / 32;
+                grp.tile_start[l] = tiles;
+                tiles += g.tiles_m * g.tiles_n;
+            }
+            grp.tile_start[m.L] = tiles;
+            hipLaunchKernelGGL(gemm_wave_grouped_tn_batched_kernel, dim3((tiles + 3) / 4, 1, t.G), dim3(256), 0, s, grp);
+        } else {
+            hipLaunchKernelGGL(gemm_grouped_tn_batched_kernel, dim3(tiles, 1, t.G), dim3(GEMM_THREADS), 0, s, grp);
+        }
         LAUNCH_CHECK("ac_gemm_dw");
     }
     return MORL_OK;

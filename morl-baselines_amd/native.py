@@ -112,6 +112,7 @@ _SIGNATURES = {
     "morl_ac_mask_bytes": (C.c_int64, [C.POINTER(ACDesc), C.c_int]),
     "morl_ac_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(ACDesc)]),
     "morl_ac_destroy": (C.c_int, [C.c_void_p]),
+    "morl_ac_set_gemm_mode": (C.c_int, [C.c_int]),
     "morl_ac_update": (C.c_int, [C.c_void_p, C.POINTER(ACState), C.POINTER(ACBatch), C.POINTER(ACCfg),
                                  C.POINTER(ACOut), C.c_void_p]),
     "morl_ac_policy_forward": (C.c_int, [C.c_void_p, C.POINTER(ACState), C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -223,3 +223,27 @@ def test_population_batch_equals_independent_learners(be, name):
             assert th.equal(pop.log_alpha[k], e.log_alpha[0])
         if c.algo == "gpipd":
             assert th.equal(pop.pol_target[k], e.pol_target[0])
+
+
+@pytest.mark.parametrize("name", ["capql_small", "mosac_noauto_odd", "gpipd_support_per", "capql_cheetah"])
+def test_wave_and_lds_tile_engines_are_bit_identical(be, name):
+    """The latency-bound launches use wave-level 32x32 MFMA tiles (gemm_wave.h), the throughput-bound ones the
+    LDS-tiled 128x128 engine (gemm_f32.h); both accumulate in ascending k in one register tile, so every bit agrees."""
+    lib, dev = be
+    c = [x for x in AC_CASES if x.name == name][0]
+    if dev.type == "cpu" and max(c.arch) >= 256:
+        pytest.skip("reference-sized networks run on the GPU only")
+    inp = make_inputs(c)
+    states = []
+    try:
+        for mode in (1, 2):
+            lib.check(lib.lib.morl_ac_set_gemm_mode(mode))
+            eng = build_engine(c, inp, lib, dev)
+            res = run_engine(c, inp, eng, ["critic_loss", "q_grads"])
+            states.append((eng, res))
+    finally:
+        lib.lib.morl_ac_set_gemm_mode(0)
+    (e1, r1), (e2, r2) = states
+    for k in ("q", "q_target", "pol", "q_exp_avg", "q_exp_avg_sq", "pol_exp_avg", "pol_exp_avg_sq"):
+        assert th.equal(getattr(e1, k), getattr(e2, k)), k
+    assert th.equal(r1["q_grads"], r2["q_grads"]) and th.equal(r1["critic_loss"], r2["critic_loss"])
