@@ -332,6 +332,78 @@ int morl_ac_policy_forward(morl_ac_ctx* ctx, const morl_ac_state* st, const floa
 int morl_ac_q_forward(morl_ac_ctx* ctx, const morl_ac_state* st, const float* obs, const float* actions,
                       const float* w, int rows, int use_target, float* q_out, void* stream);
 
+/* ================================================================================================
+ * GPI-PD / GPI-LS with discrete actions: multi_policy/gpi_pd/gpi_pd.py
+ *   QNet (:41-76)            sf = relu(Linear(D, h0)(obs)); wf = relu(Linear(R, h0)(w)); net(sf * wf) with
+ *                            net = [Linear, Dropout(p), LayerNorm, ReLU] * (len(arch) - 1) -> Linear(A * R)
+ *   GPIPD.update (:416-520)  min-over-ensemble TD target, GPI envelope target over a weight set (gpi_pd),
+ *                            non-standard Huber (common/networks.py:90-100), per-net clip, Adam, PER errors
+ *   gpi_action / max_action (:564-582, :608-617), _envelope_target (:662-690), _reset_priorities (:619-660)
+ * Flat parameter layout of ONE net (= QNet.parameters() order): weights_features.0.weight [h0][R], .bias [h0],
+ * state_features.0.weight [h0][D], .bias [h0], then net.* as in morl_ac (W, b[, gamma, beta] per hidden layer, W_out
+ * [A*R][h_last], b_out).  The num_nets ensemble members are contiguous: q[num_nets][P]; one Adam state over all.
+ * ================================================================================================ */
+typedef struct morl_gpi_ctx morl_gpi_ctx;
+
+typedef struct morl_gpi_desc {
+    int32_t obs_dim, reward_dim, n_actions;
+    int32_t n_hidden;                  /* len(net_arch) >= 2 */
+    int32_t hidden[MORL_MAX_LAYERS];   /* net_arch; hidden[0] is the width of the two feature embeddings */
+    int32_t num_nets;                  /* ensemble size (reference default 2), 1..4 */
+    int32_t layer_norm;
+    float drop_rate;
+    int32_t max_rows;                  /* most rows of one call (2 * batch_size for update) */
+    int32_t max_support;               /* most weight vectors of one envelope target / GPI action */
+} morl_gpi_desc;
+
+typedef struct morl_gpi_cfg {
+    float gamma;
+    float min_priority;                /* the Huber threshold (gpi_pd.py:476) */
+    float max_grad_norm;               /* < 0: no clipping; else clip_grad_norm_ of every net separately */
+    double lr, beta1, beta2, eps;
+    int32_t adam_step;                 /* 1-based */
+    int32_t gpi_pd;                    /* also form the envelope target and the gtd errors */
+    int32_t n_per;                     /* rows whose PER errors are written */
+    int32_t apply_step;                /* 0: gradients only */
+    uint64_t dropout_seed;
+} morl_gpi_cfg;
+
+typedef struct morl_gpi_out {          /* optional device outputs */
+    float* critic_loss;                /* scalar */
+    float* td_error;                   /* [n_per]  |w . max_n |psi_n - target||  (before clip / pow) */
+    float* gtd_error;                  /* [n_per]  same with the envelope target */
+    float* target_q;                   /* [rows][R] */
+    float* target_q_envelope;          /* [rows][R] */
+    float* grads;                      /* [num_nets][P]  (after clipping) */
+    float* grad_norm;                  /* [num_nets]  pre-clip norms (only when clipping) */
+} morl_gpi_out;
+
+int64_t morl_gpi_param_count(const morl_gpi_desc* d);
+/* keep-mask bytes of one dropout phase over `rows` input rows: for net: for hidden layer l >= 1: rows * h_l flags;
+ * morl_gpi_update consumes phases (target nets on rows, target nets on rows * K when gpi_pd, nets on rows) in order */
+int64_t morl_gpi_mask_bytes(const morl_gpi_desc* d, int rows);
+int morl_gpi_create(morl_gpi_ctx** out, const morl_gpi_desc* d);
+int morl_gpi_destroy(morl_gpi_ctx* ctx);
+/* One gradient update (the loop body of GPIPD.update).  w: per-row weights [rows][R]; sampled_w [K][R] (gpi_pd). */
+int morl_gpi_update(morl_gpi_ctx* ctx, float* q, const float* q_target, float* exp_avg, float* exp_avg_sq,
+                    const float* obs, const int32_t* actions, const float* rewards, const float* next_obs,
+                    const float* dones, const float* w, int rows, const float* sampled_w, int K,
+                    const uint8_t* drop_masks, const morl_gpi_cfg* cfg, const morl_gpi_out* out, void* stream);
+/* Q(obs_row, w_row) of `n_nets` consecutive nets starting at `params`, eval mode (no dropout):
+ * q_out [n_nets][rows][A*R].  w_per_row = 0: one weight vector for every row. */
+int morl_gpi_q_forward(morl_gpi_ctx* ctx, const float* params, int n_nets, const float* obs, const float* w,
+                       int w_per_row, int rows, float* q_out, void* stream);
+/* GPI action: arg max_i max_a w . Q_0(obs, a, support_i); M = 0 selects max_action (min over the ensemble at w).
+ * action_out / policy_out: device int32 (policy_out may be NULL). */
+int morl_gpi_action(morl_gpi_ctx* ctx, const float* q, const float* obs, const float* support, int M, const float* w,
+                    int32_t* action_out, int32_t* policy_out, void* stream);
+/* _reset_priorities errors of `rows` transitions: |w . (r + (1-d) gamma max_next - Q_0(s, w)[a])| with max_next the
+ * envelope target over `support` (gpi_pd != 0; rows * M <= max_rows * max_support) or the double-Q target. */
+int morl_gpi_priorities(morl_gpi_ctx* ctx, const float* q, const float* q_target, const float* obs,
+                        const int32_t* actions, const float* rewards, const float* next_obs, const float* dones,
+                        int rows, const float* w, const float* support, int M, int gpi_pd, float gamma,
+                        float* gtd_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,7 @@ struct Mlp {
 // activations of one batched forward pass (G nets x cap rows), kept for the backward
 struct Tape {
     int G = 0, xG = 0;
+    int cap = 0;                                 // rows capacity (row-block stride of every buffer)
     float* x = nullptr;                          // [xG][cap][ld0]
     float* h[MORL_MAX_LAYERS] = {};              // post-ReLU activations of the hidden layers
     float* zx[MORL_MAX_LAYERS] = {};             // Linear output -> xhat (LayerNorm / Dropout nets only)
@@ -79,18 +80,19 @@ struct morl_ac_ctx {
     std::vector<void*> allocs;
 };
 
-static int alloc_f(morl_ac_ctx* c, float** p, size_t n) {
+static int alloc_f(std::vector<void*>& allocs, float** p, size_t n) {
     int rc = dmalloc((void**)p, std::max<size_t>(n, 4) * sizeof(float));
     if (rc) return rc;
-    c->allocs.push_back(*p);
+    allocs.push_back(*p);
     return hipMemsetAsync(*p, 0, std::max<size_t>(n, 4) * sizeof(float), nullptr) == hipSuccess
                ? MORL_OK : fail(MORL_ERR_HIP, "hipMemsetAsync failed");
 }
+static int alloc_f(morl_ac_ctx* c, float** p, size_t n) { return alloc_f(c->allocs, p, n); }
 
-static int alloc_tape(morl_ac_ctx* c, const Mlp& m, Tape& t, int G, int xG, bool post) {
+static int alloc_tape(std::vector<void*>& c, const Mlp& m, Tape& t, int G, int xG, int cap_rows, bool post) {
     int rc;
-    const size_t cap = (size_t)c->cap;
-    t.G = G; t.xG = xG;
+    const size_t cap = (size_t)cap_rows;
+    t.G = G; t.xG = xG; t.cap = cap_rows;
     if ((rc = alloc_f(c, &t.x, (size_t)xG * cap * m.ld[0]))) return rc;
     if ((rc = alloc_f(c, &t.dx, (size_t)G * cap * m.ld[0]))) return rc;
     for (int l = 0; l < m.L; ++l) {
@@ -176,8 +178,10 @@ extern "C" int morl_ac_create(morl_ac_ctx** out, const morl_ac_desc* d) {
     c->PG = d->population; c->QG = d->population * d->num_q; c->cap = d->max_rows;
     const bool post = q.ln || q.drop > 0.f;
     const size_t cap = (size_t)c->cap, Ad = (size_t)d->act_dim;
-    if ((rc = alloc_tape(c, c->q, c->tq_a, c->QG, c->PG, post)) || (rc = alloc_tape(c, c->q, c->tq_b, c->QG, c->PG, post)) ||
-        (rc = alloc_tape(c, c->pol, c->tp_a, c->PG, c->PG, false)) || (rc = alloc_tape(c, c->pol, c->tp_b, c->PG, c->PG, false)) ||
+    if ((rc = alloc_tape(c->allocs, c->q, c->tq_a, c->QG, c->PG, c->cap, post)) ||
+        (rc = alloc_tape(c->allocs, c->q, c->tq_b, c->QG, c->PG, c->cap, post)) ||
+        (rc = alloc_tape(c->allocs, c->pol, c->tp_a, c->PG, c->PG, c->cap, false)) ||
+        (rc = alloc_tape(c->allocs, c->pol, c->tp_b, c->PG, c->PG, c->cap, false)) ||
         (rc = alloc_f(c, &c->act, c->PG * cap * Ad)) || (rc = alloc_f(c, &c->logp_next, c->PG * cap)) ||
         (rc = alloc_f(c, &c->logp_pi, c->PG * cap)) || (rc = alloc_f(c, &c->save_y, c->PG * cap * Ad)) ||
         (rc = alloc_f(c, &c->save_std, c->PG * cap * Ad)) || (rc = alloc_f(c, &c->gq, (size_t)c->QG * q.P)) ||
@@ -236,9 +240,9 @@ struct DropSpec {
 };
 
 // forward of G nets (params + g * pstride) on t.x (shared by groups of x_div nets); result in t.out
-static int mlp_forward(morl_ac_ctx* c, const Mlp& m, const float* params, int64_t pstride, Tape& t, int rows, int x_div,
+static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape& t, int rows, int x_div,
                        const DropSpec& ds, hipStream_t s) {
-    const long long cap = c->cap;
+    const long long cap = t.cap;
     int64_t ext_off = 0;
     for (int l = 0; l < m.L; ++l) {
         const bool last = (l == m.L - 1);
@@ -270,7 +274,7 @@ static int mlp_forward(morl_ac_ctx* c, const Mlp& m, const float* params, int64_
             a.gamma = m.ln ? params + m.offG[l] : nullptr;
             a.pstride = pstride;
             a.gstride = cap * m.ld[l + 1];
-            a.cap = c->cap; a.N = m.dims[l + 1]; a.ld = m.ld[l + 1]; a.rows = rows;
+            a.cap = t.cap; a.N = m.dims[l + 1]; a.ld = m.ld[l + 1]; a.rows = rows;
             a.ln = m.ln ? 1 : 0; a.drop = drop ? 1 : 0;
             a.drop_p = m.drop; a.inv_keep = 1.0f / (1.0f - m.drop);
             a.seed = ds.seed * 0x100000001B3ull + (unsigned long long)(l + 1) * 0x9E3779B97F4A7C15ull;
@@ -284,9 +288,10 @@ static int mlp_forward(morl_ac_ctx* c, const Mlp& m, const float* params, int64_
 
 // backward of the same pass: t.g[L-1] holds dLoss/d(out).  grads ([G][P], fully overwritten) may be NULL (no parameter
 // gradients wanted); need_dx -> t.dx = dLoss/d(input rows).  `dropped` = the forward ran with train-mode dropout.
-static int mlp_backward(morl_ac_ctx* c, const Mlp& m, const float* params, int64_t pstride, Tape& t, int rows, int x_div,
-                        bool dropped, float* grads, bool need_dx, hipStream_t s) {
-    const long long cap = c->cap;
+static int mlp_backward(const Mlp& m, const float* params, int64_t pstride, Tape& t, int rows, int x_div,
+                        bool dropped, float* grads, bool need_dx, hipStream_t s, int64_t grad_stride = -1) {
+    const long long cap = t.cap;
+    if (grad_stride < 0) grad_stride = m.P;      // floats between the gradient blocks of consecutive nets
     for (int l = m.L - 1; l >= 0; --l) {
         if (l == 0 && !need_dx) break;
         const bool drop = l > 0 && dropped && m.drop > 0.f;
@@ -320,7 +325,7 @@ static int mlp_backward(morl_ac_ctx* c, const Mlp& m, const float* params, int64
                 LnGradArgs a{};
                 a.d = t.g[hl]; a.h = t.h[hl]; a.xhat = t.zx[hl];
                 a.dgamma = grads + m.offG[hl];
-                a.pstride = m.P; a.gstride = cap * m.ld[l];
+                a.pstride = grad_stride; a.gstride = cap * m.ld[l];
                 a.N = m.dims[l]; a.ld = m.ld[l]; a.rows = rows;
                 hipLaunchKernelGGL(ac_ln_grad_kernel, dim3((a.N + 255) / 256, t.G), dim3(256), 0, s, a);
                 LAUNCH_CHECK("ac_ln_grad");
@@ -329,7 +334,7 @@ static int mlp_backward(morl_ac_ctx* c, const Mlp& m, const float* params, int64
             a.d = t.g[hl]; a.h = t.h[hl]; a.xhat = t.zx[hl]; a.rstd = t.rstd[hl]; a.mask = t.mask[hl];
             a.gamma = m.ln ? params + m.offG[hl] : nullptr;
             a.pstride = pstride; a.gstride = cap * m.ld[l];
-            a.cap = c->cap; a.N = m.dims[l]; a.ld = m.ld[l]; a.rows = rows;
+            a.cap = t.cap; a.N = m.dims[l]; a.ld = m.ld[l]; a.rows = rows;
             a.ln = m.ln ? 1 : 0; a.drop = drop ? 1 : 0;
             a.inv_keep = 1.0f / (1.0f - m.drop);
             hipLaunchKernelGGL(ac_post_bwd_kernel, dim3((rows + 3) / 4, t.G), dim3(256), 0, s, a);
@@ -339,7 +344,7 @@ static int mlp_backward(morl_ac_ctx* c, const Mlp& m, const float* params, int64
     if (grads) {
         GemmGroupBatched grp{};
         grp.n = m.L;
-        grp.sC = m.P;
+        grp.sC = grad_stride;
         int tiles = 0;
         for (int l = 0; l < m.L; ++l) {
             GemmProblem& g = grp.p[l];
@@ -494,12 +499,12 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
 
     // ---- critic phase: a' ~ pi(s'), target critics at (s', a'), critics at (s, a), TD loss, backward, Adam --------------
     if ((rc = concat(c, c->tp_a.x, P.ld[0], c->PG, rows, bt->next_obs, D, w_rows, wR, nullptr, 0, s))) return rc;
-    if ((rc = mlp_forward(c, P, algo == MORL_AC_TD3 ? st->pol_target : st->pol, P.P, c->tp_a, rows, 1, nodrop, s))) return rc;
+    if ((rc = mlp_forward(P, algo == MORL_AC_TD3 ? st->pol_target : st->pol, P.P, c->tp_a, rows, 1, nodrop, s))) return rc;
     if ((rc = head_forward(c, c->tp_a, rows, bt->eps_next, st, cfg, c->act, c->logp_next, false, s))) return rc;
     if ((rc = concat(c, c->tq_a.x, Q.ld[0], c->PG, rows, bt->next_obs, D, c->act, Ad, w_rows, wR, s))) return rc;
-    if ((rc = mlp_forward(c, Q, st->q_target, Q.P, c->tq_a, rows, nq, dropspec(0), s))) return rc;
+    if ((rc = mlp_forward(Q, st->q_target, Q.P, c->tq_a, rows, nq, dropspec(0), s))) return rc;
     if ((rc = concat(c, c->tq_b.x, Q.ld[0], c->PG, rows, bt->obs, D, bt->actions, Ad, w_rows, wR, s))) return rc;
-    if ((rc = mlp_forward(c, Q, st->q, Q.P, c->tq_b, rows, nq, dropspec(1), s))) return rc;
+    if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, nq, dropspec(1), s))) return rc;
     {
         CriticArgs a{};
         a.tq = c->tq_a.out; a.q = c->tq_b.out; a.dq = c->tq_b.g[Q.L - 1];
@@ -514,7 +519,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
         hipLaunchKernelGGL(ac_critic_kernel, dim3(c->PG), dim3(256), 0, s, a);
         LAUNCH_CHECK("ac_critic");
     }
-    if ((rc = mlp_backward(c, Q, st->q, Q.P, c->tq_b, rows, nq, Q.drop > 0.f, c->gq, false, s))) return rc;
+    if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_b, rows, nq, Q.drop > 0.f, c->gq, false, s))) return rc;
     if (out->q_grads)
         HIP_TRY(hipMemcpyAsync(out->q_grads, c->gq, (size_t)c->QG * Q.P * sizeof(float), hipMemcpyDeviceToDevice, s));
     if ((rc = adam(st->q, c->gq, st->q_exp_avg, st->q_exp_avg_sq, (long long)nq * Q.P, PG, cfg->q_lr, st->q_steps,
@@ -525,10 +530,10 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
         for (int it = 0; it < iters; ++it) {
             const float* eps_pi = (algo == MORL_AC_TD3) ? nullptr : bt->eps_pi + (long long)it * c->PG * rows * Ad;
             if ((rc = concat(c, c->tp_b.x, P.ld[0], c->PG, rows, bt->obs, D, w_rows, wR, nullptr, 0, s))) return rc;
-            if ((rc = mlp_forward(c, P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
+            if ((rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
             if ((rc = head_forward(c, c->tp_b, rows, eps_pi, st, cfg, c->act, c->logp_pi, true, s))) return rc;
             if ((rc = concat(c, c->tq_a.x, Q.ld[0], c->PG, rows, bt->obs, D, c->act, Ad, w_rows, wR, s))) return rc;
-            if ((rc = mlp_forward(c, Q, st->q, Q.P, c->tq_a, rows, nq, dropspec(2), s))) return rc;
+            if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_a, rows, nq, dropspec(2), s))) return rc;
             {
                 ActorLossArgs a{};
                 a.q = c->tq_a.out; a.dq = c->tq_a.g[Q.L - 1];
@@ -540,7 +545,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                 hipLaunchKernelGGL(ac_actor_loss_kernel, dim3(c->PG), dim3(256), 0, s, a);
                 LAUNCH_CHECK("ac_actor_loss");
             }
-            if ((rc = mlp_backward(c, Q, st->q, Q.P, c->tq_a, rows, nq, Q.drop > 0.f, nullptr, true, s))) return rc;
+            if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_a, rows, nq, Q.drop > 0.f, nullptr, true, s))) return rc;
             {
                 HeadBwdArgs a{};
                 a.dx_q = c->tq_a.dx; a.dxq_gstride = (long long)c->cap * Q.ld[0];
@@ -553,7 +558,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                 hipLaunchKernelGGL(ac_head_bwd_kernel, dim3((c->PG * rows + 255) / 256), dim3(256), 0, s, a);
                 LAUNCH_CHECK("ac_head_bwd");
             }
-            if ((rc = mlp_backward(c, P, st->pol, P.P, c->tp_b, rows, 1, false, c->gp, false, s))) return rc;
+            if ((rc = mlp_backward(P, st->pol, P.P, c->tp_b, rows, 1, false, c->gp, false, s))) return rc;
             if (out->pol_grads)
                 HIP_TRY(hipMemcpyAsync(out->pol_grads, c->gp, (size_t)c->PG * P.P * sizeof(float), hipMemcpyDeviceToDevice, s));
             if ((rc = adam(st->pol, c->gp, st->pol_exp_avg, st->pol_exp_avg_sq, P.P, PG, cfg->policy_lr, st->pol_steps,
@@ -561,7 +566,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
             if (autotune) {
                 // log-prob of a fresh sample under the UPDATED actor (mosac_continuous_action.py:467-468)
                 const float* eps_al = bt->eps_alpha + (long long)it * c->PG * rows * Ad;
-                if ((rc = mlp_forward(c, P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
+                if ((rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
                 if ((rc = head_forward(c, c->tp_b, rows, eps_al, st, cfg, c->act, c->logp_pi, false, s))) return rc;
                 hipLaunchKernelGGL(ac_alpha_step_kernel, dim3(c->PG), dim3(256), 0, s, st->log_alpha, st->log_alpha_exp_avg,
                                    st->log_alpha_exp_avg_sq, (const float*)c->logp_pi, rows, cfg->target_entropy,
@@ -600,7 +605,7 @@ extern "C" int morl_ac_policy_forward(morl_ac_ctx* c, const morl_ac_state* st, c
     c->tp_a.G = c->PG;
     if ((rc = concat(c, c->tp_a.x, P.ld[0], c->PG, rows, obs, c->d.obs_dim, c->w_input ? w : nullptr,
                      c->w_input ? c->d.reward_dim : 0, nullptr, 0, s))) return rc;
-    if ((rc = mlp_forward(c, P, use_target ? st->pol_target : st->pol, P.P, c->tp_a, rows, 1, DropSpec(), s))) return rc;
+    if ((rc = mlp_forward(P, use_target ? st->pol_target : st->pol, P.P, c->tp_a, rows, 1, DropSpec(), s))) return rc;
     return head_forward(c, c->tp_a, rows, mode == 1 ? eps : nullptr, st, cfg, actions_out, logp_out, false, s);
 }
 
@@ -618,7 +623,7 @@ extern "C" int morl_ac_q_forward(morl_ac_ctx* c, const morl_ac_state* st, const 
     c->tq_a.G = c->QG;
     if ((rc = concat(c, c->tq_a.x, Q.ld[0], c->PG, rows, obs, c->d.obs_dim, actions, c->d.act_dim, c->w_input ? w : nullptr,
                      c->w_input ? R : 0, s))) return rc;
-    if ((rc = mlp_forward(c, Q, use_target ? st->q_target : st->q, Q.P, c->tq_a, rows, c->d.num_q, DropSpec(), s))) return rc;
+    if ((rc = mlp_forward(Q, use_target ? st->q_target : st->q, Q.P, c->tq_a, rows, c->d.num_q, DropSpec(), s))) return rc;
     // compact [QG][cap][ld] -> [QG][rows][R]
     ConcatArgs a{};
     a.src[0] = c->tq_a.out; a.width[0] = R; a.gstride[0] = (long long)c->cap * Q.ld[Q.L]; a.rstride[0] = Q.ld[Q.L];
@@ -626,5 +631,378 @@ extern "C" int morl_ac_q_forward(morl_ac_ctx* c, const morl_ac_state* st, const 
     a.dst = q_out; a.ld = R; a.dst_gstride = (long long)rows * R; a.rows = rows; a.G = c->QG;
     hipLaunchKernelGGL(ac_concat_kernel, dim3(stream_grid((long long)c->QG * rows * R, 256)), dim3(256), 0, s, a);
     LAUNCH_CHECK("ac_q_compact");
+    return MORL_OK;
+}
+
+// =====================================================================================================================
+// GPI-PD / GPI-LS with discrete actions (include/morl_hip.h, "GPI-PD / GPI-LS with discrete actions")
+// =====================================================================================================================
+#include "gpi_kernels.h"
+
+namespace {
+
+struct GpiTape {
+    Tape t;                    // trunk `net` activations (t.x = sf * wf)
+    float* sf = nullptr;       // [nn][cap][ldH]
+    float* wf = nullptr;
+    float* dwf = nullptr;
+};
+
+__global__ __launch_bounds__(256) void gpi_expand_kernel(const float* __restrict__ obs, int D,
+                                                         const float* __restrict__ support, int R, int K, int rows,
+                                                         float* __restrict__ obs_rep, float* __restrict__ w_rep) {
+    const long long total = (long long)rows * K * (D + R);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % (D + R));
+        const long long rk = e / (D + R);
+        const int k = (int)(rk % K);
+        const long long row = rk / K;
+        if (c < D) obs_rep[rk * D + c] = obs[row * D + c];
+        else w_rep[rk * R + (c - D)] = support[(long long)k * R + (c - D)];
+    }
+}
+
+}  // namespace
+
+struct morl_gpi_ctx {
+    morl_gpi_desc d{};
+    Mlp net;
+    int H0 = 0, ldH = 0, nn = 0, cap = 0, cap_env = 0;
+    int64_t offWw = 0, offBw = 0, offWs = 0, offBs = 0, offNet = 0, P = 0;
+    GpiTape tt, te, tq;        // target nets on rows, target nets on rows * K, online nets on rows (kept for backward)
+    float* grads = nullptr;    // [nn][P]
+    float* target = nullptr;   // [cap][R]
+    float* target_env = nullptr;
+    float* obs_rep = nullptr;  // [cap_env][D]
+    float* w_rep = nullptr;    // [cap_env][R]
+    float* qmin = nullptr;     // [ldq]
+    std::vector<void*> allocs;
+};
+
+static int gpi_fill(const morl_gpi_desc* d, morl_gpi_ctx& c) {
+    if (!d) return fail(MORL_ERR_ARG, "desc is NULL");
+    if (d->n_hidden < 2 || d->n_hidden > MORL_MAX_LAYERS) return fail(MORL_ERR_ARG, "n_hidden %d not in 2..%d", d->n_hidden, MORL_MAX_LAYERS);
+    if (d->obs_dim < 1 || d->n_actions < 1 || d->reward_dim < 1 || d->reward_dim > MORL_MAX_OBJ)
+        return fail(MORL_ERR_ARG, "bad dims D=%d A=%d R=%d", d->obs_dim, d->n_actions, d->reward_dim);
+    if (d->num_nets < 1 || d->num_nets > 4) return fail(MORL_ERR_ARG, "num_nets %d not in 1..4", d->num_nets);
+    if (d->drop_rate < 0.f || d->drop_rate >= 1.f) return fail(MORL_ERR_ARG, "drop rate %g", (double)d->drop_rate);
+    for (int l = 0; l < d->n_hidden; ++l)
+        if (d->hidden[l] < 1 || d->hidden[l] > 64 * POST_MAXJ) return fail(MORL_ERR_ARG, "hidden[%d] = %d", l, d->hidden[l]);
+    c.d = *d;
+    c.nn = d->num_nets;
+    c.H0 = d->hidden[0];
+    c.ldH = round_up(c.H0, 4);
+    c.net = Mlp();
+    c.net.L = d->n_hidden;                       // (n_hidden - 1) hidden layers + output
+    for (int l = 0; l < d->n_hidden; ++l) c.net.dims[l] = d->hidden[l];
+    c.net.dims[d->n_hidden] = d->n_actions * d->reward_dim;
+    c.net.ln = d->layer_norm != 0;
+    c.net.drop = d->drop_rate;
+    c.net.finish();
+    int64_t o = 0;
+    c.offWw = o; o += (int64_t)c.H0 * d->reward_dim;
+    c.offBw = o; o += c.H0;
+    c.offWs = o; o += (int64_t)c.H0 * d->obs_dim;
+    c.offBs = o; o += c.H0;
+    c.offNet = o;
+    c.P = o + c.net.P;
+    return MORL_OK;
+}
+
+extern "C" int64_t morl_gpi_param_count(const morl_gpi_desc* d) {
+    morl_gpi_ctx c;
+    return gpi_fill(d, c) ? -1 : c.P;
+}
+
+extern "C" int64_t morl_gpi_mask_bytes(const morl_gpi_desc* d, int rows) {
+    morl_gpi_ctx c;
+    if (gpi_fill(d, c)) return -1;
+    int64_t per_net = 0;
+    for (int l = 0; l < c.net.L - 1; ++l) per_net += (int64_t)rows * c.net.dims[l + 1];
+    return (int64_t)c.nn * per_net;
+}
+
+extern "C" int morl_gpi_destroy(morl_gpi_ctx* c) {
+    if (!c) return MORL_OK;
+    for (void* p : c->allocs) (void)hipFree(p);
+    delete c;
+    return MORL_OK;
+}
+
+static int gpi_alloc_tape(morl_gpi_ctx* c, GpiTape& g, int cap, bool post) {
+    int rc;
+    if ((rc = alloc_tape(c->allocs, c->net, g.t, c->nn, c->nn, cap, post))) return rc;
+    const size_t n = (size_t)c->nn * cap * c->ldH;
+    if ((rc = alloc_f(c->allocs, &g.sf, n)) || (rc = alloc_f(c->allocs, &g.wf, n)) || (rc = alloc_f(c->allocs, &g.dwf, n))) return rc;
+    return MORL_OK;
+}
+
+extern "C" int morl_gpi_create(morl_gpi_ctx** out, const morl_gpi_desc* d) {
+    if (!out) return fail(MORL_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    morl_gpi_ctx* c = new (std::nothrow) morl_gpi_ctx();
+    if (!c) return fail(MORL_ERR_ALLOC, "out of host memory");
+    int rc = gpi_fill(d, *c);
+    if (rc) { delete c; return rc; }
+    if (d->max_rows < 1 || d->max_support < 1) { delete c; return fail(MORL_ERR_ARG, "max_rows %d / max_support %d", d->max_rows, d->max_support); }
+    c->cap = d->max_rows;
+    c->cap_env = d->max_rows * d->max_support;
+    const bool post = c->net.ln || c->net.drop > 0.f;
+    const int ldq = c->net.ld[c->net.L];
+    if ((rc = gpi_alloc_tape(c, c->tt, c->cap, post)) || (rc = gpi_alloc_tape(c, c->te, c->cap_env, post)) ||
+        (rc = gpi_alloc_tape(c, c->tq, c->cap, post)) || (rc = alloc_f(c->allocs, &c->grads, (size_t)c->nn * c->P)) ||
+        (rc = alloc_f(c->allocs, &c->target, (size_t)c->cap * d->reward_dim)) ||
+        (rc = alloc_f(c->allocs, &c->target_env, (size_t)c->cap * d->reward_dim)) ||
+        (rc = alloc_f(c->allocs, &c->obs_rep, (size_t)c->cap_env * d->obs_dim)) ||
+        (rc = alloc_f(c->allocs, &c->w_rep, (size_t)c->cap_env * d->reward_dim)) || (rc = alloc_f(c->allocs, &c->qmin, ldq))) {
+        morl_gpi_destroy(c);
+        return rc;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { morl_gpi_destroy(c); return fail(MORL_ERR_HIP, "workspace init failed"); }
+    *out = c;
+    return MORL_OK;
+}
+
+// QNet.forward of n_nets nets (params + g * P) on `rows` inputs shared by the nets
+static int gpi_forward(morl_gpi_ctx* c, const float* params, int n_nets, GpiTape& g, const float* obs, const float* w,
+                       int w_rstride, int rows, const DropSpec& ds, hipStream_t s) {
+    const morl_gpi_desc& d = c->d;
+    g.t.G = n_nets;
+    {   // sf = relu(obs @ Ws^T + bs): every net reads the same obs rows
+        GemmBatched b{};
+        GemmProblem& p = b.p;
+        p.A = obs; p.lda = d.obs_dim; b.sA = 0; b.a_div = 1;
+        p.B = params + c->offWs; p.ldb = d.obs_dim; b.sB = c->P;
+        p.bias = params + c->offBs; b.sBias = c->P;
+        p.C = g.sf; p.ldc = c->ldH; b.sC = (long long)g.t.cap * c->ldH;
+        p.M = rows; p.N = c->H0; p.K = d.obs_dim;
+        int rc = launch_bgemm<true, true, EPI_BIAS_RELU>(b, n_nets, s, "gpi_gemm_sf");
+        if (rc) return rc;
+    }
+    {
+        EmbedArgs a{};
+        a.sf = g.sf; a.wf = g.wf; a.x = g.t.x;
+        a.w = w; a.w_rstride = w_rstride;
+        a.params = params; a.pstride = c->P; a.offWw = c->offWw; a.offBw = c->offBw;
+        a.gstride = (long long)g.t.cap * c->ldH;
+        a.H = c->H0; a.ld = c->ldH; a.R = d.reward_dim; a.rows = rows; a.G = n_nets;
+        hipLaunchKernelGGL(gpi_embed_fwd_kernel, dim3(stream_grid((long long)n_nets * rows * c->H0, 256)), dim3(256), 0, s, a);
+        LAUNCH_CHECK("gpi_embed_fwd");
+    }
+    return mlp_forward(c->net, params + c->offNet, c->P, g.t, rows, 1, ds, s);
+}
+
+static int gpi_backward(morl_gpi_ctx* c, const float* params, GpiTape& g, const float* obs, const float* w, int w_rstride,
+                        int rows, bool dropped, float* grads, hipStream_t s) {
+    const morl_gpi_desc& d = c->d;
+    int rc = mlp_backward(c->net, params + c->offNet, c->P, g.t, rows, 1, dropped, grads + c->offNet, true, s, c->P);
+    if (rc) return rc;
+    {
+        EmbedBwdArgs a{};
+        a.dx = g.t.dx; a.dwf = g.dwf; a.sf = g.sf; a.wf = g.wf;
+        a.gstride = (long long)g.t.cap * c->ldH;
+        a.H = c->H0; a.ld = c->ldH; a.rows = rows; a.G = c->nn;
+        hipLaunchKernelGGL(gpi_embed_bwd_kernel, dim3(stream_grid((long long)c->nn * rows * c->H0, 256)), dim3(256), 0, s, a);
+        LAUNCH_CHECK("gpi_embed_bwd");
+    }
+    {   // dWs = d(z_s)^T @ obs, dbs = column sums
+        GemmGroupBatched grp{};
+        grp.n = 1;
+        grp.sC = c->P;
+        GemmProblem& p = grp.p[0];
+        p.A = g.t.dx; p.lda = c->ldH; grp.sA[0] = (long long)g.t.cap * c->ldH;
+        p.B = obs; p.ldb = d.obs_dim; grp.sB[0] = 0; grp.b_div[0] = 1;
+        p.C = grads + c->offWs; p.ldc = d.obs_dim;
+        p.colsum = grads + c->offBs;
+        p.M = c->H0; p.N = d.obs_dim; p.K = rows;
+        p.k_per_split = round_up(rows, GEMM_BK);
+        p.a_vec = vec_ok(p.A, p.lda) && (grp.sA[0] % 4 == 0);
+        p.b_vec = vec_ok(p.B, p.ldb);
+        p.tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM;
+        p.tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
+        int tiles = p.tiles_m * p.tiles_n;
+        grp.tile_start[0] = 0;
+        if (use_wave_tiles((long long)tiles * c->nn)) {
+            p.tiles_m = (p.M + 31) / 32;
+            p.tiles_n = (p.N + 31) / 32;
+            tiles = p.tiles_m * p.tiles_n;
+            grp.tile_start[1] = tiles;
+            hipLaunchKernelGGL(gemm_wave_grouped_tn_batched_kernel, dim3((tiles + 3) / 4, 1, c->nn), dim3(256), 0, s, grp);
+        } else {
+            grp.tile_start[1] = tiles;
+            hipLaunchKernelGGL(gemm_grouped_tn_batched_kernel, dim3(tiles, 1, c->nn), dim3(GEMM_THREADS), 0, s, grp);
+        }
+        LAUNCH_CHECK("gpi_gemm_dws");
+    }
+    {
+        EmbedGradArgs a{};
+        a.dwf = g.dwf; a.w = w; a.w_rstride = w_rstride;
+        a.grads = grads; a.pstride = c->P; a.offWw = c->offWw; a.offBw = c->offBw;
+        a.gstride = (long long)g.t.cap * c->ldH;
+        a.H = c->H0; a.ld = c->ldH; a.R = d.reward_dim; a.rows = rows; a.G = c->nn;
+        hipLaunchKernelGGL(gpi_embed_grad_kernel, dim3((c->nn * c->H0 + 255) / 256), dim3(256), 0, s, a);
+        LAUNCH_CHECK("gpi_embed_grad");
+    }
+    return MORL_OK;
+}
+
+static int gpi_envelope_inputs(morl_gpi_ctx* c, const float* obs, const float* support, int K, int rows, hipStream_t s) {
+    const int D = c->d.obs_dim, R = c->d.reward_dim;
+    hipLaunchKernelGGL(gpi_expand_kernel, dim3(stream_grid((long long)rows * K * (D + R), 256)), dim3(256), 0, s, obs, D, support,
+                       R, K, rows, c->obs_rep, c->w_rep);
+    LAUNCH_CHECK("gpi_expand");
+    return MORL_OK;
+}
+
+extern "C" int morl_gpi_update(morl_gpi_ctx* c, float* q, const float* q_target, float* exp_avg, float* exp_avg_sq,
+                               const float* obs, const int32_t* actions, const float* rewards, const float* next_obs,
+                               const float* dones, const float* w, int rows, const float* sampled_w, int K,
+                               const uint8_t* drop_masks, const morl_gpi_cfg* cfg, const morl_gpi_out* out_in, void* stream) {
+    if (!c || !cfg) return fail(MORL_ERR_ARG, "ctx / cfg is NULL");
+    if (!q || !q_target || !exp_avg || !exp_avg_sq || !obs || !actions || !rewards || !next_obs || !dones || !w)
+        return fail(MORL_ERR_ARG, "NULL argument");
+    if (rows < 1 || rows > c->cap) return fail(MORL_ERR_STATE, "rows %d outside 1..max_rows %d", rows, c->cap);
+    const bool env = cfg->gpi_pd != 0;
+    if (env && (!sampled_w || K < 1 || K > c->d.max_support)) return fail(MORL_ERR_STATE, "K %d outside 1..max_support %d", K, c->d.max_support);
+    if (cfg->n_per < 0 || cfg->n_per > rows) return fail(MORL_ERR_ARG, "n_per %d outside 0..rows", cfg->n_per);
+    static const morl_gpi_out no_out{};
+    const morl_gpi_out* out = out_in ? out_in : &no_out;
+    hipStream_t s = (hipStream_t)stream;
+    const morl_gpi_desc& d = c->d;
+    const int R = d.reward_dim, A = d.n_actions, L = c->net.L;
+    const int ldq = c->net.ld[L];
+    const int64_t mb_rows = morl_gpi_mask_bytes(&d, rows), mb_env = env ? morl_gpi_mask_bytes(&d, rows * K) : 0;
+    auto dropspec = [&](int phase) {
+        DropSpec ds;
+        ds.active = c->net.drop > 0.f;
+        const int64_t off = phase == 0 ? 0 : (phase == 1 ? mb_rows : mb_rows + mb_env);
+        const int64_t bytes = phase == 1 ? mb_env : mb_rows;
+        ds.ext = drop_masks ? drop_masks + off : nullptr;
+        ds.ext_net_bytes = bytes / c->nn;
+        ds.seed = cfg->dropout_seed * 4 + (unsigned long long)phase;
+        return ds;
+    };
+    int rc;
+    if ((rc = gpi_forward(c, q_target, c->nn, c->tt, next_obs, w, R, rows, dropspec(0), s))) return rc;
+    if (env) {
+        if ((rc = gpi_envelope_inputs(c, next_obs, sampled_w, K, rows, s))) return rc;
+        if ((rc = gpi_forward(c, q_target, c->nn, c->te, c->obs_rep, c->w_rep, R, rows * K, dropspec(1), s))) return rc;
+    }
+    {
+        GpiTargetArgs a{};
+        a.qt = c->tt.t.out; a.gstride = (long long)c->tt.t.cap * ldq;
+        a.qt_env = env ? c->te.t.out : nullptr; a.gstride_env = (long long)c->te.t.cap * ldq;
+        a.ldq = ldq;
+        a.w = w; a.w_rstride = R;
+        a.rewards = rewards; a.dones = dones;
+        a.target = c->target; a.target_env = env ? c->target_env : nullptr;
+        a.rows = rows; a.A = A; a.R = R; a.nn = c->nn; a.K = K; a.gamma = cfg->gamma;
+        hipLaunchKernelGGL(gpi_target_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, a);
+        LAUNCH_CHECK("gpi_target");
+    }
+    if ((rc = gpi_forward(c, q, c->nn, c->tq, obs, w, R, rows, dropspec(2), s))) return rc;
+    {
+        GpiLossArgs a{};
+        a.q = c->tq.t.out; a.dq = c->tq.t.g[L - 1]; a.gstride = (long long)c->tq.t.cap * ldq; a.ldq = ldq;
+        a.actions = actions; a.target = c->target; a.target_env = env ? c->target_env : nullptr; a.w = w;
+        a.loss_out = out->critic_loss; a.td_prio = out->td_error; a.gtd_prio = out->gtd_error;
+        a.rows = rows; a.A = A; a.R = R; a.nn = c->nn; a.n_per = cfg->n_per; a.delta = cfg->min_priority;
+        hipLaunchKernelGGL(gpi_loss_kernel, dim3(1), dim3(256), 0, s, a);
+        LAUNCH_CHECK("gpi_loss");
+    }
+    if ((rc = gpi_backward(c, q, c->tq, obs, w, R, rows, c->net.drop > 0.f, c->grads, s))) return rc;
+    if (cfg->max_grad_norm >= 0.f) {
+        hipLaunchKernelGGL(gpi_clip_kernel, dim3(c->nn), dim3(1024), 0, s, c->grads, (long long)c->P, cfg->max_grad_norm, out->grad_norm);
+        LAUNCH_CHECK("gpi_clip");
+    }
+    const size_t rb = (size_t)rows * R * sizeof(float);
+    if (out->target_q) HIP_TRY(hipMemcpyAsync(out->target_q, c->target, rb, hipMemcpyDeviceToDevice, s));
+    if (out->target_q_envelope && env) HIP_TRY(hipMemcpyAsync(out->target_q_envelope, c->target_env, rb, hipMemcpyDeviceToDevice, s));
+    if (out->grads) HIP_TRY(hipMemcpyAsync(out->grads, c->grads, (size_t)c->nn * c->P * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (cfg->apply_step) {
+        morl_ac_cfg ac{};
+        ac.beta1 = cfg->beta1; ac.beta2 = cfg->beta2; ac.eps = cfg->eps;
+        if ((rc = adam(q, c->grads, exp_avg, exp_avg_sq, (long long)c->nn * c->P, 1, cfg->lr, nullptr, cfg->adam_step, &ac, s))) return rc;
+    }
+    return MORL_OK;
+}
+
+extern "C" int morl_gpi_q_forward(morl_gpi_ctx* c, const float* params, int n_nets, const float* obs, const float* w,
+                                  int w_per_row, int rows, float* q_out, void* stream) {
+    if (!c || !params || !obs || !w || !q_out) return fail(MORL_ERR_ARG, "NULL argument");
+    if (n_nets < 1 || n_nets > c->nn) return fail(MORL_ERR_ARG, "n_nets %d outside 1..%d", n_nets, c->nn);
+    if (rows < 1 || rows > c->cap_env) return fail(MORL_ERR_STATE, "rows %d outside 1..%d", rows, c->cap_env);
+    hipStream_t s = (hipStream_t)stream;
+    const int R = c->d.reward_dim, AR = c->d.n_actions * R, ldq = c->net.ld[c->net.L];
+    int rc = gpi_forward(c, params, n_nets, c->te, obs, w, w_per_row ? R : 0, rows, DropSpec(), s);
+    if (rc) return rc;
+    ConcatArgs a{};
+    a.src[0] = c->te.t.out; a.width[0] = AR; a.gstride[0] = (long long)c->te.t.cap * ldq; a.rstride[0] = ldq;
+    a.n_src = 1;
+    a.dst = q_out; a.ld = AR; a.dst_gstride = (long long)rows * AR; a.rows = rows; a.G = n_nets;
+    hipLaunchKernelGGL(ac_concat_kernel, dim3(stream_grid((long long)n_nets * rows * AR, 256)), dim3(256), 0, s, a);
+    LAUNCH_CHECK("gpi_q_compact");
+    return MORL_OK;
+}
+
+extern "C" int morl_gpi_action(morl_gpi_ctx* c, const float* q, const float* obs, const float* support, int M, const float* w,
+                               int32_t* action_out, int32_t* policy_out, void* stream) {
+    if (!c || !q || !obs || !w || !action_out) return fail(MORL_ERR_ARG, "NULL argument");
+    if (M < 0 || M > c->cap_env || (M > 0 && !support)) return fail(MORL_ERR_STATE, "support size %d outside 0..%d", M, c->cap_env);
+    hipStream_t s = (hipStream_t)stream;
+    const int R = c->d.reward_dim, A = c->d.n_actions, D = c->d.obs_dim, ldq = c->net.ld[c->net.L];
+    int rc;
+    if (M > 0) {
+        // rows = the M support weights, same observation: expand with "K = M, one row"
+        if ((rc = gpi_envelope_inputs(c, obs, support, M, 1, s))) return rc;
+        if ((rc = gpi_forward(c, q, 1, c->te, c->obs_rep, c->w_rep, R, M, DropSpec(), s))) return rc;
+        hipLaunchKernelGGL(gpi_action_kernel, dim3(1), dim3(64), 0, s, (const float*)c->te.t.out, ldq, M, A, R, w, action_out, policy_out);
+    } else {
+        (void)D;
+        if ((rc = gpi_forward(c, q, c->nn, c->te, obs, w, 0, 1, DropSpec(), s))) return rc;
+        hipLaunchKernelGGL(gpi_min_nets_kernel, dim3((A * R + 255) / 256), dim3(256), 0, s, (const float*)c->te.t.out,
+                           (long long)c->te.t.cap * ldq, c->nn, A * R, c->qmin);
+        LAUNCH_CHECK("gpi_min_nets");
+        hipLaunchKernelGGL(gpi_action_kernel, dim3(1), dim3(64), 0, s, (const float*)c->qmin, ldq, 1, A, R, w, action_out, policy_out);
+    }
+    LAUNCH_CHECK("gpi_action");
+    return MORL_OK;
+}
+
+extern "C" int morl_gpi_priorities(morl_gpi_ctx* c, const float* q, const float* q_target, const float* obs,
+                                   const int32_t* actions, const float* rewards, const float* next_obs, const float* dones,
+                                   int rows, const float* w, const float* support, int M, int gpi_pd, float gamma,
+                                   float* gtd_out, void* stream) {
+    if (!c || !q || !q_target || !obs || !actions || !rewards || !next_obs || !dones || !w || !gtd_out)
+        return fail(MORL_ERR_ARG, "NULL argument");
+    if (rows < 1 || rows > c->cap) return fail(MORL_ERR_STATE, "rows %d outside 1..max_rows %d", rows, c->cap);
+    if (gpi_pd && (!support || M < 1 || (long long)rows * M > c->cap_env))
+        return fail(MORL_ERR_STATE, "rows * M = %lld exceeds max_rows * max_support = %d", (long long)rows * M, c->cap_env);
+    hipStream_t s = (hipStream_t)stream;
+    const int R = c->d.reward_dim, A = c->d.n_actions, ldq = c->net.ld[c->net.L];
+    int rc;
+    GpiTargetArgs a{};
+    a.ldq = ldq; a.w = w; a.w_rstride = 0; a.rewards = rewards; a.dones = dones;
+    a.rows = rows; a.A = A; a.R = R; a.gamma = gamma;
+    if (gpi_pd) {
+        if ((rc = gpi_envelope_inputs(c, next_obs, support, M, rows, s))) return rc;
+        if ((rc = gpi_forward(c, q_target, c->nn, c->te, c->obs_rep, c->w_rep, R, rows * M, DropSpec(), s))) return rc;
+        a.qt_env = c->te.t.out; a.gstride_env = (long long)c->te.t.cap * ldq;
+        a.target_env = c->target_env; a.nn = c->nn; a.K = M;
+        hipLaunchKernelGGL(gpi_target_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, a);
+    } else {
+        // gpi_pd.py:641-649: greedy action of ONLINE net 0 under w, value from TARGET net 0 -- as the envelope kernel with the
+        // "ensemble" = {online 0} would pick the wrong values, run the two single nets and let a 1-net target pick from qt
+        if ((rc = gpi_forward(c, q, 1, c->tt, next_obs, w, 0, rows, DropSpec(), s))) return rc;          // online: arg-max source
+        if ((rc = gpi_forward(c, q_target, 1, c->te, next_obs, w, 0, rows, DropSpec(), s))) return rc;   // target: values
+        hipLaunchKernelGGL(gpi_ddqn_target_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, (const float*)c->tt.t.out,
+                           (const float*)c->te.t.out, ldq, w, rewards, dones, rows, A, R, gamma, c->target_env);
+    }
+    LAUNCH_CHECK("gpi_prio_target");
+    if ((rc = gpi_forward(c, q, 1, c->tq, obs, w, 0, rows, DropSpec(), s))) return rc;
+    hipLaunchKernelGGL(gpi_gtd_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, (const float*)c->tq.t.out, ldq, actions,
+                       (const float*)c->target_env, w, 0, rows, R, gtd_out);
+    LAUNCH_CHECK("gpi_gtd");
     return MORL_OK;
 }

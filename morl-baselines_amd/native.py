@@ -73,6 +73,26 @@ class ACOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in AC_OUT_FIELDS]
 
 
+class GPIDesc(C.Structure):
+    _fields_ = [("obs_dim", C.c_int32), ("reward_dim", C.c_int32), ("n_actions", C.c_int32), ("n_hidden", C.c_int32),
+                ("hidden", C.c_int32 * MORL_MAX_LAYERS), ("num_nets", C.c_int32), ("layer_norm", C.c_int32),
+                ("drop_rate", C.c_float), ("max_rows", C.c_int32), ("max_support", C.c_int32)]
+
+
+class GPICfg(C.Structure):
+    _fields_ = [("gamma", C.c_float), ("min_priority", C.c_float), ("max_grad_norm", C.c_float),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("adam_step", C.c_int32), ("gpi_pd", C.c_int32), ("n_per", C.c_int32), ("apply_step", C.c_int32),
+                ("dropout_seed", C.c_uint64)]
+
+
+GPI_OUT_FIELDS = ("critic_loss", "td_error", "gtd_error", "target_q", "target_q_envelope", "grads", "grad_norm")
+
+
+class GPIOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in GPI_OUT_FIELDS]
+
+
 _SIGNATURES = {
     # name: (restype, argtypes)
     "morl_last_error": (C.c_char_p, []),
@@ -107,6 +127,18 @@ _SIGNATURES = {
     "morl_sumtree_set": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "morl_sumtree_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "morl_gpi_param_count": (C.c_int64, [C.POINTER(GPIDesc)]),
+    "morl_gpi_mask_bytes": (C.c_int64, [C.POINTER(GPIDesc), C.c_int]),
+    "morl_gpi_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(GPIDesc)]),
+    "morl_gpi_destroy": (C.c_int, [C.c_void_p]),
+    "morl_gpi_update": (C.c_int, [C.c_void_p] * 11 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(GPICfg),
+                                                       C.POINTER(GPIOut), C.c_void_p]),
+    "morl_gpi_q_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p]),
+    "morl_gpi_action": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "morl_gpi_priorities": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                                          C.c_void_p, C.c_void_p]),
     "morl_ac_q_param_count": (C.c_int64, [C.POINTER(ACDesc)]),
     "morl_ac_policy_param_count": (C.c_int64, [C.POINTER(ACDesc)]),
     "morl_ac_mask_bytes": (C.c_int64, [C.POINTER(ACDesc), C.c_int]),

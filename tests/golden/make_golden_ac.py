@@ -56,8 +56,8 @@ class Pins:
             if not training or p == 0.0:
                 return x
             a = self.drop.pop(0)
-            assert tuple(x.shape) == tuple(a.shape), (x.shape, a.shape)
-            return x * th.tensor(a) * (1.0 / (1.0 - p))
+            assert x.numel() == a.size and x.shape[-1] == a.shape[-1], (x.shape, a.shape)
+            return x * th.tensor(a).reshape(x.shape) * (1.0 / (1.0 - p))
 
         tdn._standard_normal, th.randn_like, F.dropout = std_normal, randn_like, dropout
         if self.choices is not None:
