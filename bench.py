@@ -129,6 +129,12 @@ def main():
     ap.add_argument("--engine", type=int, default=None)
     ap.add_argument("--dw-mode", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every GPU keeps the metric's 256 x 64 x 3 workload (the weight axis grows to "
+                         "64*N and every TD row's envelope max runs over all 64*N candidates after the all-gather); "
+                         "strong = the 64 weights are split over the GPUs")
+    ap.add_argument("--force-shard", action="store_true",
+                    help="run the weight-sharded step (RCCL collectives) even with one rank (path check on a 1-GPU box)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -142,16 +148,19 @@ def main():
     th.cuda.set_device(local_rank)
     dev = th.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_shard:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from morl_baselines_amd.envelope import Envelope
 
     th.manual_seed(0)
     np.random.seed(0)
-    B, W = a.batch, a.weights
+    B = a.batch
+    weak = a.scaling == "weak" and world > 1
+    W = a.weights * (world if weak else 1)        # total sampled weights of the job
     agent = Envelope(SyntheticEnv(), learning_rate=3e-4, net_arch=ARCH, batch_size=B, gamma=0.99, max_grad_norm=1.0,
                      tau=1.0, target_net_update_freq=200, envelope=True, num_sample_w=W, per=bool(a.per),
                      per_alpha=0.6, buffer_size=100_000, gradient_updates=1, log=False, seed=0, device=dev,
@@ -160,7 +169,7 @@ def main():
         agent.q_net.ctx.set_dw_mode(a.dw_mode)
     fill_buffer(agent.replay_buffer, 20_000, seed=0)
     agent.global_step = 1001
-    if world > 1:
+    if dist is not None:
         from morl_baselines_amd.distributed import shard_envelope_agent
         shard_envelope_agent(agent, dist)            # weight axis over the ranks: all-gather Q(w), all-reduce grads
 
@@ -211,15 +220,17 @@ def main():
             "unit": "TD-updates/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if (weak or world == 1) else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"Envelope.update(): B={B} x W={W} x R={R}, obs {D}, {A} actions, net {ARCH}, "
                                    f"PER {'on' if a.per else 'off'}, buffer 20k seeded transitions (BASELINE.md s3)",
                        "global_batch": B, "weights": W, "objectives": R,
-                       "parallelism": "single GPU" if world == 1 else f"weight axis sharded over {world} GPUs "
-                                      "(RCCL all-gather of Q(w), all-reduce of gradients)",
+                       "weights_per_gpu": W // world,
+                       "parallelism": "single GPU" if world == 1 else f"weight axis sharded over {world} GPUs, "
+                                      f"{W // world} weights each ({a.scaling} scaling; RCCL all-gather of Q(w), "
+                                      "all-reduce of gradients)",
                        "engine": agent.q_net.ctx.engine},
             "updates_per_s": a.steps / wall,
             "scalar_td_per_s": rows_step * R * a.steps / wall,

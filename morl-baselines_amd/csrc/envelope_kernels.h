@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void build_input_kernel(const float* __restric
 // diag_only restricts j to i (DDQN target, envelope.py:442-463).
 // HBM-bound and tiny: reads 2*B*W*A*R*4 bytes once.
 // ----------------------------------------------------------------------------------------------
-constexpr int ENV_MAX_SLAB = 6144;   // floats of LDS for one Qo[b] / Qt[b] slab (W*A*R)
-constexpr int ENV_MAX_WR = 1024;     // floats of LDS for the weight vectors (W*R)
+constexpr int ENV_MAX_SLAB = 9216;   // floats of LDS for one Qo[b] / Qt[b] slab (W*A*R)
+constexpr int ENV_MAX_WR = 1536;     // floats of LDS for the weight vectors (W*R)
 
 struct EnvelopeTdArgs {
     const float* qo;        // [B][W][A][R]
