@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-mode", type=int, default=0, help="0 auto, 1 LDS tiles, 2 wave tiles (morl_ac_set_gemm_mode)")
     a = ap.parse_args()
     if not th.cuda.is_available():
         raise SystemExit("bench_ac.py needs an MI355X (no CPU fallback exists)")
@@ -137,6 +138,7 @@ def main():
     rows = 2 * B if wl == "gpipd" else B
     eng = ACEngine(algo, D, Ad, R, ARCH, action_low=-1.0, action_high=1.0, max_rows=rows, population=pop, device=dev,
                    q_layer_norm=(wl == "gpipd"), q_drop_rate=(0.01 if wl == "gpipd" else 0.0), device_steps=True)
+    eng.lib.check(eng.lib.lib.morl_ac_set_gemm_mode(a.gemm_mode))
     gen = th.Generator(device=dev).manual_seed(0)
     rnd = lambda *s: th.randn(*s, generator=gen, device=dev)  # noqa: E731
     with th.no_grad():                          # orthogonal-ish scale; the values do not matter for timing
