@@ -219,7 +219,10 @@ class CAPQL(MOAgent, MOPolicy):
         for _ in range(self.gradient_updates):
             s_obs, s_actions, w, s_rewards, s_next_obs, s_dones = self._sample_batch_experiences()
             B = s_obs.shape[0]
-            eps = th.randn((2, B, self.action_dim), dtype=th.float32, device=e.q.device)   # next-action / pi draws
+            # two draws shaped like the reference's two rsample() calls (capql.py:326, :341): on the CPU test backend
+            # this consumes torch's generator exactly as the reference does
+            eps = (th.randn((B, self.action_dim), dtype=th.float32, device=e.q.device),
+                   th.randn((B, self.action_dim), dtype=th.float32, device=e.q.device))
             self._q_step += 1
             self._p_step += 1
             cfg = e.make_cfg(gamma=self.gamma, tau=self.tau, alpha=self.alpha, q_lr=self.learning_rate,

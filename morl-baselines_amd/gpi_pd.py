@@ -93,7 +93,7 @@ class GPIPD(MOPolicy, MOAgent):
         self.stacked_weight_support = None
         self.police_indices = []
         self._adam_step = 0
-        self._drop_seed = int(self.np_random.integers(1 << 62))
+        self._drop_seed = (0 if seed is None else int(seed)) * 1000003 + 12345   # never touches self.np_random
         self._out = None
         self.experiment_name = experiment_name
         self.log = log

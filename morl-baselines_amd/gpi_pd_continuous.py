@@ -95,7 +95,7 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
         self.stacked_weight_support = []
         self._n_updates = 0
         self._q_step = self._p_step = 0
-        self._drop_seed = int(self.np_random.integers(1 << 62))
+        self._drop_seed = (0 if seed is None else int(seed)) * 1000003 + 12345   # never touches self.np_random
         self._out = None
         self.experiment_name = experiment_name
         self.log = log

@@ -223,7 +223,16 @@ class MOSAC(MOPolicy):
         obs, act, rew, nobs, dones = self.update_inputs()
         B, Ad = obs.shape[0], e.Ad
         cfg = self.make_cfg()
-        eps = th.randn((1 + 2 * self.policy_freq, B, Ad), dtype=th.float32, device=e.q.device)
+        # draws in the reference's order (next action; per actor iteration: pi, then the alpha re-sample), one call each,
+        # so that the CPU test backend consumes torch's generator exactly as mosac_continuous_action.py:436-468 does
+        pf = self.policy_freq
+        eps = th.empty((1 + 2 * pf, B, Ad), dtype=th.float32, device=e.q.device)
+        eps[0].normal_()
+        if cfg.do_policy:
+            for k in range(pf):
+                eps[1 + k].normal_()
+                if self.autotune:
+                    eps[1 + pf + k].normal_()
         self._out = e.update(cfg, obs=obs, actions=act, rewards=rew, next_obs=nobs, dones=dones, w=self.weights_tensor,
                              eps_next=eps[0], eps_pi=eps[1:1 + self.policy_freq], eps_alpha=eps[1 + self.policy_freq:],
                              want=("critic_loss", "q_losses", "policy_loss", "alpha_loss"))

@@ -1,0 +1,110 @@
+"""End-to-end training traces of the UNMODIFIED reference agents (CAPQL, MOSAC, GPI-LS continuous, GPI-LS) on the
+self-contained MOMDPs of tests/momdp.py, CPU, a few dozen environment steps with learning.  The HIP agents are run on
+the same environments with the same seeds on the CPU test backend (tests/test_train_traces.py): they must take the same
+actions and end with the same parameters -- i.e. the host loops consume every RNG stream (torch, numpy, random, the
+environment's) exactly as the reference does and the update arithmetic agrees step after step.
+
+    PYTHONDONTWRITEBYTECODE=1 python -B tests/golden/make_golden_train_ac.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch as th
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import ref_harness as rh  # noqa: E402
+import train_cases as tc  # noqa: E402
+
+
+def params_of(mods):
+    return [p.detach().numpy().copy() for m in mods for p in m.parameters()]
+
+
+def dump(out, prefix, arrs):
+    for i, a in enumerate(arrs):
+        out[f"{prefix}_{i}"] = a
+
+
+def main():
+    ref = rh.import_reference_ac()
+    from morl_baselines.multi_policy.gpi_pd import gpi_pd as gpi_mod
+    import momdp
+
+    th.set_num_threads(1)
+    noop = lambda *a, **k: None  # noqa: E731
+    out = {}
+
+    # ---- CAPQL -------------------------------------------------------------------------------------------------------
+    ref.capql.equally_spaced_weights = noop
+    tc.reseed(tc.SEED)
+    env = momdp.PointReach(tc.SEED)
+    ag = ref.capql.CAPQL(env, log=False, seed=tc.SEED, device="cpu", **tc.CAPQL)
+    nets = ag.q_nets + ag.target_q_nets + [ag.policy]
+    dump(out, "capql_init", params_of(nets))
+    tc.reseed()
+    ag.train(total_timesteps=tc.CAPQL_STEPS, eval_env=None, ref_point=np.zeros(2))
+    dump(out, "capql_final", params_of(nets))
+    out["capql_actions"] = np.asarray(env.action_log)
+
+    # ---- MOSAC -------------------------------------------------------------------------------------------------------
+    tc.reseed(tc.SEED)
+    env = momdp.PointReach(tc.SEED)
+    ag = ref.mosac.MOSAC(env, weights=tc.MOSAC_WEIGHTS.copy(), log=False, seed=tc.SEED, device="cpu", **tc.MOSAC)
+    nets = [ag.actor, ag.qf1, ag.qf2, ag.qf1_target, ag.qf2_target]
+    dump(out, "mosac_init", params_of(nets))
+    tc.reseed()
+    ag.train(total_timesteps=tc.MOSAC_STEPS)
+    dump(out, "mosac_final", params_of(nets))
+    out["mosac_actions"] = np.asarray(env.action_log)
+    out["mosac_log_alpha"] = ag.log_alpha.detach().numpy().copy()
+
+    # ---- GPI-LS continuous (critics without dropout: the device generator cannot replay torch's bernoulli draws) ------
+    mod = ref.gpipd_cont
+    tc.reseed(tc.SEED)
+    env = momdp.PointReach(tc.SEED)
+    ag = mod.GPILSContinuousAction(env, log=False, seed=tc.SEED, device="cpu", **tc.GPILS_CONT)
+    for lst in (ag.q_nets, ag.target_q_nets):
+        for n in range(2):
+            lst[n] = mod.QNetwork(2, 1, 2, net_arch=tc.GPILS_CONT["net_arch"], layer_norm=True, drop_rate=0.0)
+    for q, t in zip(ag.q_nets, ag.target_q_nets):
+        t.load_state_dict(q.state_dict())
+        for p in t.parameters():
+            p.requires_grad = False
+    ag.q_optim = th.optim.Adam([p for net in ag.q_nets for p in net.parameters()], lr=ag.learning_rate)
+    nets = ag.q_nets + ag.target_q_nets + [ag.policy, ag.target_policy]
+    dump(out, "gpic_init", params_of(nets))
+    tc.reseed()
+    ag.train_iteration(total_timesteps=tc.GPILS_CONT_STEPS, weight=tc.WEIGHT.copy(), weight_support=[s.copy() for s in tc.SUPPORT],
+                       change_weight_every_episode=True)
+    dump(out, "gpic_final", params_of(nets))
+    out["gpic_actions"] = np.asarray(env.action_log)
+    out["gpic_tree_root"] = np.float64(ag.replay_buffer.tree.nodes[0][0])
+
+    # ---- GPI-LS (discrete) ----------------------------------------------------------------------------------------------
+    tc.reseed(tc.SEED)
+    env = momdp.TreasureLine(tc.SEED)
+    ag = gpi_mod.GPILS(env, log=False, seed=tc.SEED, device="cpu", **tc.GPILS)
+    nets = ag.q_nets + ag.target_q_nets
+    dump(out, "gpi_init", params_of(nets))
+    tc.reseed()
+    ag.train_iteration(total_timesteps=tc.GPILS_STEPS, weight=tc.WEIGHT.copy(), weight_support=[s.copy() for s in tc.SUPPORT],
+                       change_w_every_episode=True)
+    dump(out, "gpi_final", params_of(nets))
+    out["gpi_actions"] = np.asarray(env.action_log, dtype=np.int8)
+    out["gpi_tree_root"] = np.float64(ag.replay_buffer.tree.nodes[0][0])
+
+    np.savez_compressed(os.path.join(HERE, "train_traces_ac.npz"), **out)
+    for k in ("capql_actions", "mosac_actions", "gpic_actions", "gpi_actions"):
+        print(k, out[k].shape, np.asarray(out[k]).reshape(len(out[k]), -1)[-3:].tolist())
+
+
+if __name__ == "__main__":
+    main()

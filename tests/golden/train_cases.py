@@ -1,0 +1,28 @@
+"""Configuration of the short end-to-end training traces (reference vs HIP agents on the CPU test backend)."""
+import numpy as np
+
+SEED = 7
+CAPQL = dict(net_arch=[16, 16], batch_size=12, learning_starts=20, buffer_size=500, alpha=0.2)
+CAPQL_STEPS = 60
+MOSAC = dict(net_arch=[16, 16], batch_size=12, learning_starts=20, buffer_size=500)
+MOSAC_WEIGHTS = np.array([0.3, 0.7], dtype=np.float32)
+MOSAC_STEPS = 50
+GPILS_CONT = dict(net_arch=[16, 16], batch_size=8, learning_starts=16, buffer_size=500, gradient_updates=2, per=True)
+GPILS_CONT_STEPS = 40
+GPILS = dict(net_arch=[16, 16, 16], batch_size=8, learning_starts=16, buffer_size=500, gradient_updates=2, per=True,
+             drop_rate=0.0, layer_norm=True, initial_epsilon=0.3, final_epsilon=0.3, target_net_update_freq=7)
+GPILS_STEPS = 50
+SUPPORT = [np.array([1.0, 0.0], dtype=np.float32), np.array([0.0, 1.0], dtype=np.float32),
+           np.array([0.5, 0.5], dtype=np.float32)]
+WEIGHT = np.array([0.4, 0.6], dtype=np.float32)
+
+
+def reseed(seed=SEED + 1):
+    """Align every host RNG stream the training loops consume (called after construction + parameter loading)."""
+    import random
+
+    import torch as th
+
+    random.seed(seed)
+    np.random.seed(seed)
+    th.manual_seed(seed)

@@ -115,6 +115,7 @@ class PointReach:
         self.spec = types.SimpleNamespace(id=env_id)
         self.x = 0.0
         self.t = 0
+        self.action_log = []
 
     def _obs(self):
         return np.array([self.x, self.t / self.HORIZON], dtype=np.float32)
@@ -124,6 +125,7 @@ class PointReach:
         return self._obs(), {}
 
     def step(self, action):
+        self.action_log.append(np.asarray(action, dtype=np.float32).reshape(-1).copy())
         a = float(np.clip(np.asarray(action, dtype=np.float64).reshape(-1)[0], -1.0, 1.0))
         self.x = float(np.clip(self.x + 0.25 * a, -1.0, 1.0))
         self.t += 1

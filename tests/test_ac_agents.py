@@ -139,7 +139,7 @@ def test_capql_update_matches_oracle_and_checkpoints(be, tmp_path):
     ag.update()
     rng_restore(snap, dev)
     batch = ag._sample_batch_experiences()
-    eps = th.randn((2, 16, ag.action_dim), dtype=th.float32, device=dev)
+    eps = [th.randn((16, ag.action_dim), dtype=th.float32, device=dev) for _ in range(2)]
     qspec = ac.MlpSpec(env.observation_space.shape[0] + 2 + 2, (32, 32), 2)
     trunk = ac.MlpSpec(env.observation_space.shape[0] + 2, (32, 32))
     qs, ps = (dict(exp_avg=ac.zeros_like(sum(q0, [])), exp_avg_sq=ac.zeros_like(sum(q0, []))),
@@ -191,7 +191,12 @@ def test_mosac_update_matches_oracle_and_checkpoints(be):
     ag.update()
     rng_restore(snap, dev)
     obs, act, rew, nobs, dones = ag.update_inputs()
-    eps = th.randn((5, 16, 3), dtype=th.float32, device=dev).cpu()
+    eps = th.empty((5, 16, 3), dtype=th.float32, device=dev)       # the agent's draw order: next, (pi_k, alpha_k) per iteration
+    eps[0].normal_()
+    for k in range(2):
+        eps[1 + k].normal_()
+        eps[3 + k].normal_()
+    eps = eps.cpu()
     qspec, trunk = ac.MlpSpec(9, (32, 32), 2), ac.MlpSpec(6, (32, 32))
     qs = dict(exp_avg=ac.zeros_like(q0[0] + q0[1]), exp_avg_sq=ac.zeros_like(q0[0] + q0[1]))
     ps = dict(exp_avg=ac.zeros_like(pol0), exp_avg_sq=ac.zeros_like(pol0))

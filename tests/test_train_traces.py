@@ -1,0 +1,105 @@
+"""End-to-end training-loop parity on the CPU test backend: the HIP agents (kernel sources under the wave emulator) run
+the SAME short training as the unmodified reference did for tests/golden/train_traces_ac.npz -- same environment, same
+seeds, same initial parameters -- and must take the same actions and end with the same parameters.  This pins the host
+loops (RNG consumption order of torch / numpy / random / the environment, buffer semantics, schedules, delayed and
+target updates) on top of the per-update parity of the kernel tests."""
+import os
+
+import numpy as np
+import pytest
+import torch as th
+
+import momdp
+import train_cases as tc
+
+import morl_baselines_amd.native as native
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_traces_ac.npz")
+
+
+@pytest.fixture(scope="module")
+def sim():
+    import simlib
+    lib = simlib.load_sim()
+    native.use_library(lib)
+    yield lib
+    native.use_library(None)
+
+
+def load_init(g, prefix, modules):
+    params = [p for m in modules for p in m.parameters()]
+    with th.no_grad():
+        for i, p in enumerate(params):
+            p.copy_(th.tensor(g[f"{prefix}_{i}"]))
+    return params
+
+
+def check_final(g, prefix, params, atol):
+    worst = 0.0
+    for i, p in enumerate(params):
+        want = g[f"{prefix}_{i}"]
+        err = float(np.abs(p.detach().cpu().numpy() - want).max())
+        worst = max(worst, err)
+        assert err <= atol, f"{prefix}_{i}: max |diff| {err:.3e}"
+    return worst
+
+
+def test_capql_trace(sim):
+    from morl_baselines_amd.capql import CAPQL
+    g = np.load(GOLD)
+    tc.reseed(tc.SEED)
+    env = momdp.PointReach(tc.SEED)
+    ag = CAPQL(env, log=False, seed=tc.SEED, device="cpu", lib=sim, **tc.CAPQL)
+    params = load_init(g, "capql_init", ag.q_nets + ag.target_q_nets + [ag.policy])
+    tc.reseed()
+    ag.train(total_timesteps=tc.CAPQL_STEPS)
+    np.testing.assert_allclose(np.asarray(env.action_log), g["capql_actions"], rtol=0, atol=2e-5)
+    worst = check_final(g, "capql_final", params, atol=3e-5)
+    print(f"\nCAPQL: {tc.CAPQL_STEPS} steps / {ag._q_step} updates, max parameter deviation {worst:.2e}")
+
+
+def test_mosac_trace(sim):
+    from morl_baselines_amd.mosac import MOSAC
+    g = np.load(GOLD)
+    tc.reseed(tc.SEED)
+    env = momdp.PointReach(tc.SEED)
+    ag = MOSAC(env, tc.MOSAC_WEIGHTS.copy(), log=False, seed=tc.SEED, device="cpu", lib=sim, **tc.MOSAC)
+    params = load_init(g, "mosac_init", [ag.actor, ag.qf1, ag.qf2, ag.qf1_target, ag.qf2_target])
+    tc.reseed()
+    ag.train(total_timesteps=tc.MOSAC_STEPS)
+    np.testing.assert_allclose(np.asarray(env.action_log), g["mosac_actions"], rtol=0, atol=5e-5)
+    worst = check_final(g, "mosac_final", params, atol=1e-4)
+    np.testing.assert_allclose(ag.log_alpha.numpy(), g["mosac_log_alpha"], rtol=0, atol=2e-5)
+    print(f"\nMOSAC: {tc.MOSAC_STEPS} steps / {ag._q_step} updates, max parameter deviation {worst:.2e}")
+
+
+def test_gpils_continuous_trace(sim):
+    from morl_baselines_amd.gpi_pd_continuous import GPILSContinuousAction
+    g = np.load(GOLD)
+    tc.reseed(tc.SEED)
+    env = momdp.PointReach(tc.SEED)
+    ag = GPILSContinuousAction(env, log=False, seed=tc.SEED, device="cpu", lib=sim, q_drop_rate=0.0, **tc.GPILS_CONT)
+    params = load_init(g, "gpic_init", ag.q_nets + ag.target_q_nets + [ag.policy, ag.target_policy])
+    tc.reseed()
+    ag.train_iteration(total_timesteps=tc.GPILS_CONT_STEPS, weight=tc.WEIGHT.copy(),
+                       weight_support=[s.copy() for s in tc.SUPPORT], change_weight_every_episode=True)
+    np.testing.assert_allclose(np.asarray(env.action_log), g["gpic_actions"], rtol=0, atol=5e-5)
+    worst = check_final(g, "gpic_final", params, atol=1e-4)
+    assert float(ag.replay_buffer.tree.nodes[0][0]) == pytest.approx(float(g["gpic_tree_root"]), rel=1e-4)
+    print(f"\nGPI-LS continuous: {tc.GPILS_CONT_STEPS} steps / {ag._n_updates} updates, max parameter deviation {worst:.2e}")
+
+
+def test_gpils_discrete_trace(sim):
+    from morl_baselines_amd.gpi_pd import GPILS
+    g = np.load(GOLD)
+    tc.reseed(tc.SEED)
+    env = momdp.TreasureLine(tc.SEED)
+    ag = GPILS(env, log=False, seed=tc.SEED, device="cpu", lib=sim, **tc.GPILS)
+    params = load_init(g, "gpi_init", ag.q_nets + ag.target_q_nets)
+    tc.reseed()
+    ag.train_iteration(total_timesteps=tc.GPILS_STEPS, weight=tc.WEIGHT.copy(), weight_support=[s.copy() for s in tc.SUPPORT],
+                       change_w_every_episode=True)
+    assert np.array_equal(np.asarray(env.action_log, dtype=np.int8), g["gpi_actions"])
+    worst = check_final(g, "gpi_final", params, atol=1e-4)
+    assert float(ag.replay_buffer.tree.nodes[0][0]) == pytest.approx(float(g["gpi_tree_root"]), rel=1e-4)
+    print(f"\nGPI-LS: {tc.GPILS_STEPS} steps / {ag._adam_step} updates, max parameter deviation {worst:.2e}")
