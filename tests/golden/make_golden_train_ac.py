@@ -101,8 +101,23 @@ def main():
     out["gpi_actions"] = np.asarray(env.action_log, dtype=np.int8)
     out["gpi_tree_root"] = np.float64(ag.replay_buffer.tree.nodes[0][0])
 
+    # ---- Envelope (epsilon / homotopy schedules, PER, periodic target copy) --------------------------------------------------
+    refe = rh.import_reference()
+    refe.envelope.equally_spaced_weights = noop
+    tc.reseed(tc.SEED)
+    env = momdp.TreasureLine(tc.SEED)
+    ag = refe.envelope.Envelope(env, log=False, seed=tc.SEED, device="cpu", **tc.ENVELOPE)
+    nets = [ag.q_net, ag.target_q_net]
+    dump(out, "env_init", params_of(nets))
+    tc.reseed()
+    ag.train(total_timesteps=tc.ENVELOPE_STEPS)
+    dump(out, "env_final", params_of(nets))
+    out["env_actions"] = np.asarray(env.action_log, dtype=np.int8)
+    out["env_tree_root"] = np.float64(ag.replay_buffer.tree.nodes[0][0])
+    out["env_eps_lambda"] = np.array([ag.epsilon, ag.homotopy_lambda])
+
     np.savez_compressed(os.path.join(HERE, "train_traces_ac.npz"), **out)
-    for k in ("capql_actions", "mosac_actions", "gpic_actions", "gpi_actions"):
+    for k in ("capql_actions", "mosac_actions", "gpic_actions", "gpi_actions", "env_actions"):
         print(k, out[k].shape, np.asarray(out[k]).reshape(len(out[k]), -1)[-3:].tolist())
 
 
