@@ -2,7 +2,7 @@
 continuous) on one MI355X.  bench.py stays the north-star (Envelope) line the driver runs; this script measures the
 widened rows with the same conventions:
 
-    python bench_ac.py --workload capql|mosac|morld|gpipd [--pop 64] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python bench_ac.py --workload capql|mosac|morld|gpipd|gpi [--pop 64] [--steps K] [--warmup W] [--no-cpu-baseline]
 
 One "step" = one gradient update of every learner in the job (``update()`` body of the reference agent; for ``morld``
 one pass of ``MORLD.__update_others`` over ``pop`` sub-problem learners, morld.py:423-433), on synthetic transitions
@@ -29,6 +29,7 @@ SHAPES = {  # obs dim, action dim, objectives of the environments BASELINE.json 
     "mosac": dict(D=11, Ad=3, R=3, env="mo-hopper-v4"),
     "morld": dict(D=11, Ad=3, R=3, env="mo-hopper-v4"),
     "gpipd": dict(D=11, Ad=3, R=3, env="mo-hopper-v4"),
+    "gpi": dict(D=7, Ad=6, R=3, env="mo-minecart-v0 (GPI-PD, discrete: 6 actions)"),
 }
 ARCH = [256, 256]
 B = 128
@@ -116,6 +117,88 @@ def cpu_baseline(workload, shp, pop, budget_s=20.0):
                       f"the reference advances a population of {pop} sequentially, i.e. at this rate"}
 
 
+def bench_gpi(a):
+    """GPI-PD with discrete actions: one ``morl_gpi_update`` (batch 128 doubled to 256 rows, ensemble of 2 conditioned
+    Q-nets [256]*4 with LayerNorm + Dropout, envelope target over K = 5 weights) per step."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from morl_baselines_amd.gpi_engine import GPIEngine
+
+    dev = th.device("cuda", 0)
+    shp = SHAPES["gpi"]
+    D, A, R, K, rows, arch = shp["D"], shp["Ad"], shp["R"], 5, 2 * B, [256, 256, 256, 256]
+    eng = GPIEngine(D, A, R, arch, max_rows=rows, max_support=K, device=dev)
+    gen = th.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: th.randn(*s, generator=gen, device=dev)  # noqa: E731
+    with th.no_grad():
+        eng.q.copy_(rnd(*eng.q.shape) * 0.05)
+        for n in range(2):
+            v = eng.views(eng.q, n)
+            for k in (6, 10, 14):
+                v[k].fill_(1.0)
+        eng.q_target.copy_(eng.q)
+    obs, nobs, rew = rnd(rows, D), rnd(rows, D), rnd(rows, R)
+    act = th.randint(0, A, (rows,), generator=gen, device=dev)
+    done = (th.rand(rows, generator=gen, device=dev) < 0.05).float()
+    w = th.softmax(rnd(rows, R), dim=-1).contiguous()
+    sw = th.softmax(rnd(K, R), dim=-1).contiguous()
+    st = {"n": 0}
+
+    def step():
+        st["n"] += 1
+        eng.update(obs=obs, actions=act, rewards=rew, next_obs=nobs, dones=done, w=w, sampled_w=sw, adam_step=st["n"],
+                   gpi_pd=True, n_per=B, dropout_seed=st["n"], want=("critic_loss", "gtd_error"))
+
+    for _ in range(a.warmup):
+        step()
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    th.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    macs = D * 256 + 3 * 256 * 256 + 256 * A * R             # per row and net (the R-input weight embedding not counted)
+    flop = 2.0 * macs * 2 * (rows + rows * K + 3 * rows)      # target, envelope target, online forward + dX + dW
+    ms = wall * 1e3 / a.steps
+    tf = flop / (ms * 1e-3) / 1e12
+    out = {"metric": "GPI-PD gradient updates/sec", "value": a.steps / wall, "unit": "updates/s", "n_gpus": 1,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"GPIPD.update() body: batch {B} doubled to {rows} rows, 2 conditioned Q-nets {arch} "
+                                  f"(LayerNorm, Dropout 0.01), envelope target over {K} weights, PER errors; shapes of "
+                                  f"{shp['env']}"},
+           "roofline": {"bound": "mfma", "kernel": "gemm_batched / gemm_wave_batched", "achieved": tf,
+                        "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "note": "algorithmic GEMM flop of the update / wall time (launch-latency-bound workload)"},
+           "algorithmic_flop_per_step": flop}
+    if not a.no_cpu_baseline:
+        import gpi_oracle as go
+        from ac_oracle import clone
+
+        spec = go.GpiSpec(D, R, A, tuple(arch), True, 0.01)
+        q = [[p.cpu().clone() for p in eng.views(eng.q, n)] for n in range(2)]
+        tq = [clone(n) for n in q]
+        flat = [p for n in q for p in n]
+        state = dict(exp_avg=[th.zeros_like(p) for p in flat], exp_avg_sq=[th.zeros_like(p) for p in flat])
+        batch = [obs.cpu(), act.cpu().float().reshape(-1, 1), rew.cpu(), nobs.cpu(), done.cpu().reshape(-1, 1)]
+        g2 = th.Generator().manual_seed(0)
+        keep = lambda n_: [[(th.rand(n_, h, generator=g2) >= 0.01).float() for h in arch[1:]] for _ in range(2)]  # noqa: E731
+        times = []
+        t_end = time.perf_counter() + 15.0
+        k = 0
+        while time.perf_counter() < t_end and len(times) < 100:
+            k += 1
+            drop = dict(target=keep(rows), env=keep(rows * K), q=keep(rows))
+            t1 = time.perf_counter()
+            go.gpi_update(spec, q, tq, state, batch, w.cpu(), sw.cpu(), drop, gamma=0.99, lr=3e-4, step=k, min_priority=0.01,
+                          gpi_pd=True, n_per=B)
+            times.append(time.perf_counter() - t1)
+        med = float(np.median(times[1:] or times))
+        out["cpu_baseline"] = {"value": 1.0 / med, "unit": "updates/s", "cores": th.get_num_threads(), "kind": "port",
+                               "sample": f"{len(times)} timed updates of oracle/gpi_oracle.py on torch-CPU, median"}
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="morld", choices=sorted(SHAPES))
@@ -129,6 +212,8 @@ def main():
         raise SystemExit("bench_ac.py needs an MI355X (no CPU fallback exists)")
     dev = th.device("cuda", 0)
     th.cuda.set_device(dev)
+    if a.workload == "gpi":
+        return bench_gpi(a)
     from morl_baselines_amd.ac_engine import ALGO_CAPQL, ALGO_MOSAC, ALGO_TD3, ACEngine
 
     wl, shp = a.workload, SHAPES[a.workload]

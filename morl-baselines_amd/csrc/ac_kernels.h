@@ -272,7 +272,10 @@ __global__ __launch_bounds__(256) void ac_post_bwd_kernel(PostBwdArgs a) {
 }
 
 // LayerNorm affine gradients: dgamma[c] = sum_rows dy * xhat, dbeta[c] = sum_rows dy, dy = dh * (h > 0).
-// Must run BEFORE ac_post_bwd_kernel overwrites dh.  One thread per column, rows in order (deterministic).
+// Must run BEFORE ac_post_bwd_kernel overwrites dh.  One workgroup of 16 waves per (64 columns, net): lane = column
+// (coalesced 256-byte row segments), wave w sums rows w, w + 16, ...; the 16 partials are combined in wave order
+// (deterministic).  The naive "one thread walks all rows of its column" form was the slowest kernel of a GPI-PD update
+// (122 us for 256 rows: one dependent load chain per column on 512 threads).
 struct LnGradArgs {
     const float* d;
     const float* h;
@@ -282,20 +285,33 @@ struct LnGradArgs {
     int N, ld, rows;
 };
 
-__global__ __launch_bounds__(256) void ac_ln_grad_kernel(LnGradArgs a) {
-    const int c = (int)blockIdx.x * 256 + (int)threadIdx.x, g = (int)blockIdx.y;
-    if (c >= a.N) return;
-    const long long base = (long long)g * a.gstride + c;
+constexpr int COLRED_WAVES = 16;
+
+__global__ __launch_bounds__(64 * COLRED_WAVES) void ac_ln_grad_kernel(LnGradArgs a) {
+    __shared__ float s_g[COLRED_WAVES][64], s_b[COLRED_WAVES][64];
+    const int lane = lane_id(), wave = wave_id();
+    const int c = (int)blockIdx.x * 64 + lane, g = (int)blockIdx.y;
     float sg = 0.f, sb = 0.f;
-    for (int r = 0; r < a.rows; ++r) {
-        const long long o = base + (long long)r * a.ld;
-        const float dy = (a.h[o] > 0.f) ? a.d[o] : 0.f;
-        sg += dy * a.xhat[o];
-        sb += dy;
+    if (c < a.N) {
+        const long long base = (long long)g * a.gstride + c;
+        for (int r = wave; r < a.rows; r += COLRED_WAVES) {
+            const long long o = base + (long long)r * a.ld;
+            const float dy = (a.h[o] > 0.f) ? a.d[o] : 0.f;
+            sg += dy * a.xhat[o];
+            sb += dy;
+        }
     }
-    float* __restrict__ out = a.dgamma + (long long)g * a.pstride;
-    out[c] = sg;
-    out[a.N + c] = sb;
+    s_g[wave][lane] = sg;
+    s_b[wave][lane] = sb;
+    __syncthreads();
+    if (wave == 0 && c < a.N) {
+        float tg = 0.f, tb = 0.f;
+#pragma unroll
+        for (int w = 0; w < COLRED_WAVES; ++w) { tg += s_g[w][lane]; tb += s_b[w][lane]; }
+        float* __restrict__ out = a.dgamma + (long long)g * a.pstride;
+        out[c] = tg;
+        out[a.N + c] = tb;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -67,8 +67,9 @@ __global__ __launch_bounds__(256) void gpi_embed_bwd_kernel(EmbedBwdArgs a) {
     }
 }
 
-// gradients of the weight embedding (K = rows, N = R <= 8): dWw[j][r] = sum_rows dwf[row][j] * w[row][r], dbw[j] = sum
-// One thread per (net, j); rows in ascending order (deterministic).
+// gradients of the weight embedding (K = rows, N = R <= 8): dWw[j][r] = sum_rows dwf[row][j] * w[row][r], dbw[j] = sum.
+// One workgroup of 16 waves per (64 features, net): lane = feature j, wave w sums rows w, w + 16, ...; partials combined
+// in wave order (deterministic).
 struct EmbedGradArgs {
     const float* dwf;
     const float* w;
@@ -78,22 +79,35 @@ struct EmbedGradArgs {
     int H, ld, R, rows, G;
 };
 
-__global__ __launch_bounds__(256) void gpi_embed_grad_kernel(EmbedGradArgs a) {
-    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (e >= a.G * a.H) return;
-    const int g = e / a.H, j = e % a.H;
-    float acc[MORL_MAX_OBJ];
-    float b = 0.f;
-    for (int r = 0; r < a.R; ++r) acc[r] = 0.f;
-    for (int row = 0; row < a.rows; ++row) {
-        const float d = a.dwf[(long long)g * a.gstride + (long long)row * a.ld + j];
-        const float* __restrict__ wr = a.w + (long long)row * a.w_rstride;
-        for (int r = 0; r < a.R; ++r) acc[r] = fmaf(d, wr[r], acc[r]);
-        b += d;
+__global__ __launch_bounds__(1024) void gpi_embed_grad_kernel(EmbedGradArgs a) {
+    __shared__ float s_p[16][MORL_MAX_OBJ + 1][64];
+    const int lane = lane_id(), wave = wave_id();
+    const int j = (int)blockIdx.x * 64 + lane, g = (int)blockIdx.y;
+    float acc[MORL_MAX_OBJ + 1];
+#pragma unroll
+    for (int r = 0; r <= MORL_MAX_OBJ; ++r) acc[r] = 0.f;
+    if (j < a.H) {
+        for (int row = wave; row < a.rows; row += 16) {
+            const float d = a.dwf[(long long)g * a.gstride + (long long)row * a.ld + j];
+            const float* __restrict__ wr = a.w + (long long)row * a.w_rstride;
+            for (int r = 0; r < a.R; ++r) acc[r] = fmaf(d, wr[r], acc[r]);
+            acc[MORL_MAX_OBJ] += d;
+        }
     }
-    float* __restrict__ out = a.grads + (long long)g * a.pstride;
-    for (int r = 0; r < a.R; ++r) out[a.offWw + (long long)j * a.R + r] = acc[r];
-    out[a.offBw + j] = b;
+#pragma unroll
+    for (int r = 0; r <= MORL_MAX_OBJ; ++r) s_p[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (wave == 0 && j < a.H) {
+        float* __restrict__ out = a.grads + (long long)g * a.pstride;
+        for (int r = 0; r < a.R; ++r) {
+            float t = 0.f;
+            for (int w_ = 0; w_ < 16; ++w_) t += s_p[w_][r][lane];
+            out[a.offWw + (long long)j * a.R + r] = t;
+        }
+        float t = 0.f;
+        for (int w_ = 0; w_ < 16; ++w_) t += s_p[w_][MORL_MAX_OBJ][lane];
+        out[a.offBw + j] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -123,51 +137,56 @@ __device__ __forceinline__ float gpi_dot(const float* __restrict__ q, const floa
     return s;
 }
 
+// One WAVE per batch row: lane = candidate (k, a) in k-major order (strided when there are more than 64); each lane takes
+// the min over the ensemble of its candidate, then a butterfly arg-max keeps the largest value with the LOWEST candidate
+// index -- which is "max over a (first), then arg-max over k (first)" of the reference.
+__device__ __forceinline__ void gpi_best_candidate(const float* __restrict__ qbase, long long gstride, int ldq, int row0,
+                                                  int K, int A, int R, int nn, const float* __restrict__ w, float& best,
+                                                  int& best_i, const float*& best_q) {
+    const int lane = lane_id();
+    int best_n = 0;
+    best = -INFINITY; best_i = 0x7fffffff;
+    for (int cand = lane; cand < K * A; cand += kWave) {
+        const int k = cand / A, ac = cand % A;
+        float ms = 0.f;
+        int mn = 0;
+        for (int n = 0; n < nn; ++n) {
+            const float s = gpi_dot(qbase + (long long)n * gstride + ((long long)row0 + k) * ldq + ac * R, w, R);
+            if (n == 0 || s < ms) { ms = s; mn = n; }
+        }
+        if (ms > best) { best = ms; best_i = cand; best_n = mn; }       // ascending cand per lane: first maximum kept
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int oi = __shfl_xor(best_i, off), on = __shfl_xor(best_n, off);
+        if (ov > best || (ov == best && oi < best_i)) { best = ov; best_i = oi; best_n = on; }
+    }
+    best_q = qbase + (long long)best_n * gstride + ((long long)row0 + best_i / A) * ldq + (best_i % A) * R;
+}
+
 __global__ __launch_bounds__(256) void gpi_target_kernel(GpiTargetArgs a) {
-    const int row = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int row = (int)blockIdx.x * 4 + wave_id();
     if (row >= a.rows) return;
+    const int lane = lane_id();
     const float* __restrict__ w = a.w + (long long)row * a.w_rstride;
     const float nd = a.dones ? 1.f - a.dones[row] : 1.f;
+    float best;
+    int bi;
+    const float* bq;
     if (a.target) {
-        float best = 0.f;
-        const float* bq = nullptr;
-        for (int ac = 0; ac < a.A; ++ac) {
-            float ms = 0.f;
-            const float* mq = nullptr;
-            for (int n = 0; n < a.nn; ++n) {
-                const float* q = a.qt + (long long)n * a.gstride + (long long)row * a.ldq + ac * a.R;
-                const float s = gpi_dot(q, w, a.R);
-                if (n == 0 || s < ms) { ms = s; mq = q; }
-            }
-            if (ac == 0 || ms > best) { best = ms; bq = mq; }     // w . Q_min(s', a) is the min member's scalarised value
-        }
-        for (int r = 0; r < a.R; ++r) {
-            const float v = bq[r];
-            a.target[(long long)row * a.R + r] = a.rewards ? a.rewards[(long long)row * a.R + r] + (nd * a.gamma) * v : v;
+        gpi_best_candidate(a.qt, a.gstride, a.ldq, row, 1, a.A, a.R, a.nn, w, best, bi, bq);
+        if (lane < a.R) {
+            const float v = bq[lane];
+            a.target[(long long)row * a.R + lane] = a.rewards ? a.rewards[(long long)row * a.R + lane] + (nd * a.gamma) * v : v;
         }
     }
     if (a.target_env && a.qt_env) {
-        float best_k = 0.f;
-        const float* bq = nullptr;
-        for (int k = 0; k < a.K; ++k) {
-            float best_a = 0.f;
-            const float* aq = nullptr;
-            for (int ac = 0; ac < a.A; ++ac) {
-                float ms = 0.f;
-                const float* mq = nullptr;
-                for (int n = 0; n < a.nn; ++n) {
-                    const float* q = a.qt_env + (long long)n * a.gstride_env + ((long long)row * a.K + k) * a.ldq + ac * a.R;
-                    const float s = gpi_dot(q, w, a.R);
-                    if (n == 0 || s < ms) { ms = s; mq = q; }
-                }
-                if (ac == 0 || ms > best_a) { best_a = ms; aq = mq; }
-            }
-            if (k == 0 || best_a > best_k) { best_k = best_a; bq = aq; }
-        }
-        for (int r = 0; r < a.R; ++r) {
-            const float v = bq[r];
-            a.target_env[(long long)row * a.R + r] =
-                a.rewards ? a.rewards[(long long)row * a.R + r] + (nd * a.gamma) * v : v;
+        gpi_best_candidate(a.qt_env, a.gstride_env, a.ldq, row * a.K, a.K, a.A, a.R, a.nn, w, best, bi, bq);
+        if (lane < a.R) {
+            const float v = bq[lane];
+            a.target_env[(long long)row * a.R + lane] =
+                a.rewards ? a.rewards[(long long)row * a.R + lane] + (nd * a.gamma) * v : v;
         }
     }
 }

@@ -327,7 +327,7 @@ static int mlp_backward(const Mlp& m, const float* params, int64_t pstride, Tape
                 a.dgamma = grads + m.offG[hl];
                 a.pstride = grad_stride; a.gstride = cap * m.ld[l];
                 a.N = m.dims[l]; a.ld = m.ld[l]; a.rows = rows;
-                hipLaunchKernelGGL(ac_ln_grad_kernel, dim3((a.N + 255) / 256, t.G), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(ac_ln_grad_kernel, dim3((a.N + 63) / 64, t.G), dim3(64 * COLRED_WAVES), 0, s, a);
                 LAUNCH_CHECK("ac_ln_grad");
             }
             PostBwdArgs a{};
@@ -841,7 +841,7 @@ static int gpi_backward(morl_gpi_ctx* c, const float* params, GpiTape& g, const 
         a.grads = grads; a.pstride = c->P; a.offWw = c->offWw; a.offBw = c->offBw;
         a.gstride = (long long)g.t.cap * c->ldH;
         a.H = c->H0; a.ld = c->ldH; a.R = d.reward_dim; a.rows = rows; a.G = c->nn;
-        hipLaunchKernelGGL(gpi_embed_grad_kernel, dim3((c->nn * c->H0 + 255) / 256), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gpi_embed_grad_kernel, dim3((c->H0 + 63) / 64, c->nn), dim3(1024), 0, s, a);
         LAUNCH_CHECK("gpi_embed_grad");
     }
     return MORL_OK;
@@ -898,7 +898,7 @@ extern "C" int morl_gpi_update(morl_gpi_ctx* c, float* q, const float* q_target,
         a.rewards = rewards; a.dones = dones;
         a.target = c->target; a.target_env = env ? c->target_env : nullptr;
         a.rows = rows; a.A = A; a.R = R; a.nn = c->nn; a.K = K; a.gamma = cfg->gamma;
-        hipLaunchKernelGGL(gpi_target_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gpi_target_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a);
         LAUNCH_CHECK("gpi_target");
     }
     if ((rc = gpi_forward(c, q, c->nn, c->tq, obs, w, R, rows, dropspec(2), s))) return rc;
@@ -990,7 +990,7 @@ extern "C" int morl_gpi_priorities(morl_gpi_ctx* c, const float* q, const float*
         if ((rc = gpi_forward(c, q_target, c->nn, c->te, c->obs_rep, c->w_rep, R, rows * M, DropSpec(), s))) return rc;
         a.qt_env = c->te.t.out; a.gstride_env = (long long)c->te.t.cap * ldq;
         a.target_env = c->target_env; a.nn = c->nn; a.K = M;
-        hipLaunchKernelGGL(gpi_target_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gpi_target_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a);
     } else {
         // gpi_pd.py:641-649: greedy action of ONLINE net 0 under w, value from TARGET net 0 -- as the envelope kernel with the
         // "ensemble" = {online 0} would pick the wrong values, run the two single nets and let a 1-net target pick from qt
