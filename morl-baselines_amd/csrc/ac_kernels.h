@@ -106,7 +106,7 @@ struct ConcatArgs {
     int rows, G;
 };
 
-__global__ __launch_bounds__(256) void ac_concat_kernel(ConcatArgs a) {
+__device__ __forceinline__ void ac_concat_body(const ConcatArgs& a) {
     const long long total = (long long)a.G * a.rows * a.ld;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (long long)gridDim.x * blockDim.x) {
@@ -118,13 +118,25 @@ __global__ __launch_bounds__(256) void ac_concat_kernel(ConcatArgs a) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             if (s < a.n_src) {
-                if (c0 >= 0 && c0 < a.width[s])
+                if (c0 >= 0 && c0 < a.width[s] && a.src[s] != nullptr)      // a NULL source leaves its columns zero
                     v = a.src[s][(long long)g * a.gstride[s] + (long long)row * a.rstride[s] + c0];
                 c0 -= a.width[s];
             }
         }
         a.dst[(long long)g * a.dst_gstride + (long long)row * a.ld + c] = v;
     }
+}
+
+__global__ __launch_bounds__(256) void ac_concat_kernel(ConcatArgs a) { ac_concat_body(a); }
+
+// all network inputs of one update in a single launch (blockIdx.y = destination matrix)
+struct ConcatMulti {
+    ConcatArgs c[4];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void ac_concat_multi_kernel(ConcatMulti m) {
+    if ((int)blockIdx.y < m.n) ac_concat_body(m.c[blockIdx.y]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -314,6 +326,12 @@ __global__ __launch_bounds__(64 * COLRED_WAVES) void ac_ln_grad_kernel(LnGradArg
     }
 }
 
+// entropy coefficient of learner g: exp(log_alpha[g]) when it is learnt (mosac...:474 alpha_tensor = log_alpha.exp()),
+// the constant otherwise
+__device__ __forceinline__ float ac_alpha(const float* __restrict__ log_alpha, float alpha_const, int g) {
+    return log_alpha ? expf(log_alpha[g]) : alpha_const;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // policy heads.  One thread per (learner, batch row); O(Ad) work each.
 //   CAPQL  capql.py:118-158      log_std = clamp(raw, -20, 2); log-prob summed per term, clamped to +-1e3
@@ -333,6 +351,9 @@ struct HeadArgs {
     float* logp;              // [G][rows] or NULL
     float* save_y;            // [G][rows][Ad] tanh output, or NULL
     float* save_std;          // [G][rows][Ad]
+    float* xdst;              // optional: also write the action into columns [xcol0, xcol0 + Ad) of a critic-input matrix
+    long long x_gstride;      // [G][cap][xld]
+    int xld, xcol0;
     int rows, Ad, G, algo;
     float policy_noise, noise_clip;
 };
@@ -343,6 +364,7 @@ __global__ __launch_bounds__(256) void ac_head_fwd_kernel(HeadArgs a) {
     const int g = e / a.rows, row = e % a.rows;
     const float* __restrict__ hd = a.head + (long long)g * a.head_gstride + (long long)row * a.ldh;
     const long long o = ((long long)g * a.rows + row) * a.Ad;
+    float* __restrict__ xd = a.xdst ? a.xdst + (long long)g * a.x_gstride + (long long)row * a.xld + a.xcol0 : nullptr;
     if (a.algo == MORL_AC_TD3) {
         for (int j = 0; j < a.Ad; ++j) {
             float t = tanhf(hd[j]);
@@ -351,7 +373,9 @@ __global__ __launch_bounds__(256) void ac_head_fwd_kernel(HeadArgs a) {
                 const float n = fminf(fmaxf(a.eps[o + j] * a.policy_noise, -a.noise_clip), a.noise_clip);
                 t = fminf(fmaxf(t + n, -1.f), 1.f);
             }
-            a.action[o + j] = t * a.scale[j] + a.bias[j];
+            const float act = t * a.scale[j] + a.bias[j];
+            a.action[o + j] = act;
+            if (xd) xd[j] = act;
         }
         return;
     }
@@ -359,7 +383,9 @@ __global__ __launch_bounds__(256) void ac_head_fwd_kernel(HeadArgs a) {
     for (int j = 0; j < a.Ad; ++j) {
         const float mean = hd[j];
         if (!a.eps) {                                      // deterministic: tanh(mean) * scale + bias
-            a.action[o + j] = tanhf(mean) * a.scale[j] + a.bias[j];
+            const float act = tanhf(mean) * a.scale[j] + a.bias[j];
+            a.action[o + j] = act;
+            if (xd) xd[j] = act;
             continue;
         }
         const float raw = hd[a.Ad + j];
@@ -369,7 +395,9 @@ __global__ __launch_bounds__(256) void ac_head_fwd_kernel(HeadArgs a) {
         const float sd = expf(ls);
         const float x = mean + a.eps[o + j] * sd;
         const float y = tanhf(x);
-        a.action[o + j] = y * a.scale[j] + a.bias[j];
+        const float act = y * a.scale[j] + a.bias[j];
+        a.action[o + j] = act;
+        if (xd) xd[j] = act;
         const float t = x - mean;
         const float gauss = -(t * t) / (2.f * (sd * sd)) - logf(sd) - AC_HALF_LOG_2PI;
         const float corr = logf(a.scale[j] * (1.f - y * y) + 1e-6f);
@@ -398,7 +426,8 @@ struct HeadBwdArgs {
     const float* save_std;
     const float* logp;        // CAPQL: saturated rows pass no log-prob gradient
     const float* scale;
-    const float* alpha_dev;   // [G]
+    const float* log_alpha;   // [G] or NULL (constant coefficient)
+    float alpha_const;
     float* dhead;             // [G][cap][ldh] out
     int rows, Ad, G, algo;
 };
@@ -412,7 +441,7 @@ __global__ __launch_bounds__(256) void ac_head_bwd_kernel(HeadBwdArgs a) {
     float* __restrict__ dh = a.dhead + (long long)g * a.head_gstride + (long long)row * a.ldh;
     float dlogp = 0.f;
     if (a.algo != MORL_AC_TD3) {
-        dlogp = a.alpha_dev[g] / (float)a.rows;
+        dlogp = ac_alpha(a.log_alpha, a.alpha_const, g) / (float)a.rows;
         if (a.algo == MORL_AC_CAPQL && fabsf(a.logp[(long long)g * a.rows + row]) >= 1e3f) dlogp = 0.f;
     }
     for (int j = 0; j < a.Ad; ++j) {
@@ -469,7 +498,8 @@ struct CriticArgs {
     const float* dones;       // [G][rows]
     const float* w;           // [G][rows][R] or [G][R]
     int w_per_row;
-    const float* alpha_dev;   // [G]
+    const float* log_alpha;   // [G] or NULL (constant coefficient)
+    float alpha_const;
     float* target_out;        // [G][rows][R] ([G][rows] MOSAC) or NULL
     float* loss_out;          // [G] or NULL
     float* q_losses;          // [G][nq] or NULL
@@ -482,7 +512,7 @@ struct CriticArgs {
 __global__ __launch_bounds__(256) void ac_critic_kernel(CriticArgs a) {
     __shared__ double s_red[4];
     const int g = (int)blockIdx.x;
-    const float alpha = (a.algo == MORL_AC_TD3) ? 0.f : a.alpha_dev[g];
+    const float alpha = (a.algo == MORL_AC_TD3) ? 0.f : ac_alpha(a.log_alpha, a.alpha_const, g);
     double part[4] = {0.0, 0.0, 0.0, 0.0};                  // per-critic squared-error sums (nq <= 4)
     for (int row = (int)threadIdx.x; row < a.rows; row += (int)blockDim.x) {
         const long long ro = (long long)row * a.ldo;
@@ -574,7 +604,8 @@ struct ActorLossArgs {
     const float* logp;        // [G][rows]
     const float* w;
     int w_per_row;
-    const float* alpha_dev;
+    const float* log_alpha;   // [G] or NULL (constant coefficient)
+    float alpha_const;
     float* loss_out;          // [G] or NULL
     int rows, R, nq, algo;
 };
@@ -582,7 +613,7 @@ struct ActorLossArgs {
 __global__ __launch_bounds__(256) void ac_actor_loss_kernel(ActorLossArgs a) {
     __shared__ double s_red[4];
     const int g = (int)blockIdx.x;
-    const float alpha = (a.algo == MORL_AC_TD3) ? 0.f : a.alpha_dev[g];
+    const float alpha = (a.algo == MORL_AC_TD3) ? 0.f : ac_alpha(a.log_alpha, a.alpha_const, g);
     double s_lp = 0.0, s_q = 0.0;
     const float inv_rows = 1.f / (float)a.rows;
     for (int row = (int)threadIdx.x; row < a.rows; row += (int)blockDim.x) {
@@ -631,7 +662,7 @@ __global__ __launch_bounds__(256) void ac_actor_loss_kernel(ActorLossArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// MOSAC entropy coefficient.  prepare: alpha[g] = autotune ? exp(log_alpha[g]) : alpha_const.
+// MOSAC entropy coefficient.  export (optional output only): alpha[g] = autotune ? exp(log_alpha[g]) : alpha_const.
 // step (mosac...:466-474): alpha_loss = mean(-log_alpha * (logp + target_entropy)); one scalar Adam step; alpha = exp.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void ac_alpha_prepare_kernel(const float* log_alpha, float alpha_const, int autotune, float* alpha_dev,
@@ -643,7 +674,7 @@ __global__ void ac_alpha_prepare_kernel(const float* log_alpha, float alpha_cons
 __global__ __launch_bounds__(256) void ac_alpha_step_kernel(float* log_alpha, float* m_, float* v_, const float* logp,
                                                             int rows, float target_entropy, const int* steps,
                                                             int step_add, double lr, double db1, double db2, float eps,
-                                                            float* alpha_dev, float* alpha_loss_out) {
+                                                            float* alpha_loss_out) {
     __shared__ double s_red[4];
     const int g = (int)blockIdx.x;
     double s = 0.0;
@@ -667,7 +698,6 @@ __global__ __launch_bounds__(256) void ac_alpha_step_kernel(float* log_alpha, fl
         log_alpha[g] = nla;
         m_[g] = m;
         v_[g] = v;
-        alpha_dev[g] = expf(nla);
     }
 }
 
@@ -696,6 +726,22 @@ __global__ __launch_bounds__(256) void ac_adam_kernel(float* __restrict__ params
         exp_avg[base + p] = m;
         exp_avg_sq[base + p] = v;
     }
+}
+
+// last kernel of an update: Polyak of the target critics (common/networks.py:120-139; tau == 1 -> copy) fused with the
+// advance of the device-resident Adam step counters (nothing reads them after the optimiser kernels)
+__global__ __launch_bounds__(256) void ac_polyak_advance_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                long long n, float tau, float one_minus_tau,
+                                                                int* q_steps, int* pol_steps, int G, int pol_inc) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        if (tau == 1.0f) dst[p] = src[p];
+        else dst[p] = __fadd_rn(__fmul_rn(dst[p], one_minus_tau), __fmul_rn(tau, src[p]));
+    }
+    if (blockIdx.x == 0)
+        for (int g = (int)threadIdx.x; g < G; g += (int)blockDim.x) {
+            if (q_steps) q_steps[g] += 1;
+            if (pol_steps) pol_steps[g] += pol_inc;
+        }
 }
 
 __global__ void ac_step_advance_kernel(int* q_steps, int* pol_steps, int G, int pol_inc) {

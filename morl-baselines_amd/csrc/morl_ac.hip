@@ -423,7 +423,8 @@ static int polyak(const float* src, float* dst, long long n, float tau, hipStrea
 }
 
 static int head_forward(morl_ac_ctx* c, Tape& tp, int rows, const float* eps, const morl_ac_state* st,
-                        const morl_ac_cfg* cfg, float* action, float* logp, bool save, hipStream_t s) {
+                        const morl_ac_cfg* cfg, float* action, float* logp, bool save, hipStream_t s,
+                        Tape* qin = nullptr) {
     HeadArgs a{};
     a.head = tp.out;
     a.head_gstride = (long long)c->cap * c->pol.ld[c->pol.L];
@@ -433,6 +434,9 @@ static int head_forward(morl_ac_ctx* c, Tape& tp, int rows, const float* eps, co
     a.action = action; a.logp = logp;
     a.save_y = save ? c->save_y : nullptr;
     a.save_std = save ? c->save_std : nullptr;
+    if (qin) {                // also drop the action straight into the critics' input rows
+        a.xdst = qin->x; a.x_gstride = (long long)qin->cap * c->q.ld[0]; a.xld = c->q.ld[0]; a.xcol0 = c->d.obs_dim;
+    }
     a.rows = rows; a.Ad = c->d.act_dim; a.G = c->PG; a.algo = c->d.algo;
     a.policy_noise = cfg ? cfg->policy_noise : 0.f;
     a.noise_clip = cfg ? cfg->noise_clip : 0.f;
@@ -493,17 +497,38 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     const DropSpec nodrop;
     const long long q_ldo = Q.ld[Q.L], q_gs = (long long)c->cap * q_ldo;
 
-    hipLaunchKernelGGL(ac_alpha_prepare_kernel, dim3((c->PG + 63) / 64), dim3(64), 0, s, (const float*)st->log_alpha,
-                       cfg->alpha, autotune ? 1 : 0, c->alpha_dev, c->PG);
-    LAUNCH_CHECK("ac_alpha_prepare");
+    const float* la = autotune ? st->log_alpha : nullptr;    // entropy coefficient source of every kernel below
+
+    // ---- every network input of the update in one launch: policy at s' / s, critics at (s', .) / (s, a) -----------------------
+    {
+        auto fill = [&](ConcatArgs& a, float* dst, int ld, const float* s0, int w0, const float* s1, int w1, const float* s2, int w2) {
+            const float* src[3] = {s0, s1, s2};
+            const int wd[3] = {w0, w1, w2};
+            int n = 0;
+            for (int k = 0; k < 3; ++k)
+                if (wd[k] > 0) {
+                    a.src[n] = src[k]; a.width[n] = wd[k];
+                    a.gstride[n] = (long long)rows * wd[k]; a.rstride[n] = wd[k];
+                    ++n;
+                }
+            a.n_src = n;
+            a.dst = dst; a.ld = ld; a.dst_gstride = (long long)c->cap * ld; a.rows = rows; a.G = PG;
+        };
+        ConcatMulti m{};
+        m.n = 4;
+        fill(m.c[0], c->tp_a.x, P.ld[0], bt->next_obs, D, w_rows, wR, nullptr, 0);
+        fill(m.c[1], c->tq_a.x, Q.ld[0], bt->next_obs, D, nullptr, Ad, w_rows, wR);      // a' is written by the head kernel
+        fill(m.c[2], c->tq_b.x, Q.ld[0], bt->obs, D, bt->actions, Ad, w_rows, wR);
+        fill(m.c[3], c->tp_b.x, P.ld[0], bt->obs, D, w_rows, wR, nullptr, 0);
+        const long long biggest = (long long)PG * rows * Q.ld[0];
+        hipLaunchKernelGGL(ac_concat_multi_kernel, dim3(stream_grid(biggest, 256, 512), 4), dim3(256), 0, s, m);
+        LAUNCH_CHECK("ac_inputs");
+    }
 
     // ---- critic phase: a' ~ pi(s'), target critics at (s', a'), critics at (s, a), TD loss, backward, Adam --------------
-    if ((rc = concat(c, c->tp_a.x, P.ld[0], c->PG, rows, bt->next_obs, D, w_rows, wR, nullptr, 0, s))) return rc;
     if ((rc = mlp_forward(P, algo == MORL_AC_TD3 ? st->pol_target : st->pol, P.P, c->tp_a, rows, 1, nodrop, s))) return rc;
-    if ((rc = head_forward(c, c->tp_a, rows, bt->eps_next, st, cfg, c->act, c->logp_next, false, s))) return rc;
-    if ((rc = concat(c, c->tq_a.x, Q.ld[0], c->PG, rows, bt->next_obs, D, c->act, Ad, w_rows, wR, s))) return rc;
+    if ((rc = head_forward(c, c->tp_a, rows, bt->eps_next, st, cfg, c->act, c->logp_next, false, s, &c->tq_a))) return rc;
     if ((rc = mlp_forward(Q, st->q_target, Q.P, c->tq_a, rows, nq, dropspec(0), s))) return rc;
-    if ((rc = concat(c, c->tq_b.x, Q.ld[0], c->PG, rows, bt->obs, D, bt->actions, Ad, w_rows, wR, s))) return rc;
     if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, nq, dropspec(1), s))) return rc;
     {
         CriticArgs a{};
@@ -511,7 +536,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
         a.gstride = q_gs; a.ldo = (int)q_ldo;
         a.logp_next = c->logp_next; a.rewards = bt->rewards; a.dones = bt->dones;
         a.w = bt->w; a.w_per_row = c->w_input ? 1 : 0;
-        a.alpha_dev = c->alpha_dev;
+        a.log_alpha = la; a.alpha_const = cfg->alpha;
         a.target_out = out->target_q; a.loss_out = out->critic_loss; a.q_losses = out->q_losses;
         a.priority = (algo == MORL_AC_TD3 && cfg->n_per > 0) ? out->priority : nullptr;
         a.n_per = cfg->n_per;
@@ -529,30 +554,29 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     if (cfg->do_policy) {
         for (int it = 0; it < iters; ++it) {
             const float* eps_pi = (algo == MORL_AC_TD3) ? nullptr : bt->eps_pi + (long long)it * c->PG * rows * Ad;
-            if ((rc = concat(c, c->tp_b.x, P.ld[0], c->PG, rows, bt->obs, D, w_rows, wR, nullptr, 0, s))) return rc;
+            // the critics' input rows (obs | . | w) are already in tq_b; the head kernel overwrites the action columns with pi(s)
             if ((rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
-            if ((rc = head_forward(c, c->tp_b, rows, eps_pi, st, cfg, c->act, c->logp_pi, true, s))) return rc;
-            if ((rc = concat(c, c->tq_a.x, Q.ld[0], c->PG, rows, bt->obs, D, c->act, Ad, w_rows, wR, s))) return rc;
-            if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_a, rows, nq, dropspec(2), s))) return rc;
+            if ((rc = head_forward(c, c->tp_b, rows, eps_pi, st, cfg, c->act, c->logp_pi, true, s, &c->tq_b))) return rc;
+            if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, nq, dropspec(2), s))) return rc;
             {
                 ActorLossArgs a{};
-                a.q = c->tq_a.out; a.dq = c->tq_a.g[Q.L - 1];
+                a.q = c->tq_b.out; a.dq = c->tq_b.g[Q.L - 1];
                 a.gstride = q_gs; a.ldo = (int)q_ldo;
                 a.logp = c->logp_pi; a.w = bt->w; a.w_per_row = c->w_input ? 1 : 0;
-                a.alpha_dev = c->alpha_dev;
+                a.log_alpha = la; a.alpha_const = cfg->alpha;
                 a.loss_out = out->policy_loss;
                 a.rows = rows; a.R = R; a.nq = nq; a.algo = algo;
                 hipLaunchKernelGGL(ac_actor_loss_kernel, dim3(c->PG), dim3(256), 0, s, a);
                 LAUNCH_CHECK("ac_actor_loss");
             }
-            if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_a, rows, nq, Q.drop > 0.f, nullptr, true, s))) return rc;
+            if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_b, rows, nq, Q.drop > 0.f, nullptr, true, s))) return rc;
             {
                 HeadBwdArgs a{};
-                a.dx_q = c->tq_a.dx; a.dxq_gstride = (long long)c->cap * Q.ld[0];
+                a.dx_q = c->tq_b.dx; a.dxq_gstride = (long long)c->cap * Q.ld[0];
                 a.nq = nq; a.ld_qin = Q.ld[0]; a.col0 = D;
                 a.head = c->tp_b.out; a.head_gstride = (long long)c->cap * P.ld[P.L]; a.ldh = P.ld[P.L];
                 a.eps = eps_pi; a.save_y = c->save_y; a.save_std = c->save_std; a.logp = c->logp_pi;
-                a.scale = st->action_scale; a.alpha_dev = c->alpha_dev;
+                a.scale = st->action_scale; a.log_alpha = la; a.alpha_const = cfg->alpha;
                 a.dhead = c->tp_b.g[P.L - 1];
                 a.rows = rows; a.Ad = Ad; a.G = c->PG; a.algo = algo;
                 hipLaunchKernelGGL(ac_head_bwd_kernel, dim3((c->PG * rows + 255) / 256), dim3(256), 0, s, a);
@@ -571,22 +595,31 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                 hipLaunchKernelGGL(ac_alpha_step_kernel, dim3(c->PG), dim3(256), 0, s, st->log_alpha, st->log_alpha_exp_avg,
                                    st->log_alpha_exp_avg_sq, (const float*)c->logp_pi, rows, cfg->target_entropy,
                                    (const int*)st->pol_steps, (st->pol_steps ? 1 : cfg->policy_step) + it, cfg->alpha_lr,
-                                   cfg->beta1, cfg->beta2, (float)cfg->eps, c->alpha_dev, out->alpha_loss);
+                                   cfg->beta1, cfg->beta2, (float)cfg->eps, out->alpha_loss);
                 LAUNCH_CHECK("ac_alpha_step");
             }
             if (algo == MORL_AC_TD3)
                 if ((rc = polyak(st->pol, st->pol_target, (long long)c->PG * P.P, cfg->tau, s))) return rc;
         }
     }
-    if (cfg->do_target)
-        if ((rc = polyak(st->q, st->q_target, (long long)c->QG * Q.P, cfg->tau, s))) return rc;
-    if (st->q_steps || st->pol_steps) {
-        hipLaunchKernelGGL(ac_step_advance_kernel, dim3((PG + 63) / 64), dim3(64), 0, s, st->q_steps,
-                           cfg->do_policy ? st->pol_steps : (int32_t*)nullptr, PG, iters);
-        LAUNCH_CHECK("ac_step_advance");
+    {
+        int32_t* qs = st->q_steps;
+        int32_t* ps = cfg->do_policy ? st->pol_steps : nullptr;
+        if (cfg->do_target) {
+            const long long n = (long long)c->QG * Q.P;
+            hipLaunchKernelGGL(ac_polyak_advance_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const float*)st->q,
+                               st->q_target, n, cfg->tau, 1.0f - cfg->tau, qs, ps, PG, iters);
+            LAUNCH_CHECK("ac_polyak_advance");
+        } else if (qs || ps) {
+            hipLaunchKernelGGL(ac_step_advance_kernel, dim3((PG + 63) / 64), dim3(64), 0, s, qs, ps, PG, iters);
+            LAUNCH_CHECK("ac_step_advance");
+        }
     }
-    if (out->alpha)
-        HIP_TRY(hipMemcpyAsync(out->alpha, c->alpha_dev, (size_t)c->PG * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out->alpha) {
+        hipLaunchKernelGGL(ac_alpha_prepare_kernel, dim3((PG + 63) / 64), dim3(64), 0, s, (const float*)st->log_alpha, cfg->alpha,
+                           autotune ? 1 : 0, out->alpha, PG);
+        LAUNCH_CHECK("ac_alpha_export");
+    }
     return MORL_OK;
 }
 
