@@ -76,6 +76,32 @@ __global__ __launch_bounds__(256) void gemm_wave_batched_kernel(GemmBatched b) {
     gemm_wave_tile<A_KC, B_KC, EPI>(g, tile / g.tiles_n, tile % g.tiles_n);
 }
 
+// split-K variants: one 32 x 32 tile per workgroup, the four waves share the contraction (gemm_wave4_tile)
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm_wave4_batched_kernel(GemmBatched b) {
+    GemmProblem g = b.p;
+    const int z = (int)blockIdx.z, tile = (int)blockIdx.x;
+    g.A += (long long)(z / b.a_div) * b.sA;
+    g.B += (long long)z * b.sB;
+    g.C += (long long)z * b.sC;
+    if (g.bias) g.bias += (long long)z * b.sBias;
+    if (g.mask) g.mask += (long long)z * b.sMask;
+    gemm_wave4_tile<A_KC, B_KC, EPI>(g, tile / g.tiles_n, tile % g.tiles_n);
+}
+
+__global__ __launch_bounds__(256) void gemm_wave4_grouped_tn_batched_kernel(GemmGroupBatched grp) {
+    const int id = (int)blockIdx.x, z = (int)blockIdx.z;
+    int q = 0;
+    while (q + 1 < grp.n && id >= grp.tile_start[q + 1]) ++q;
+    const int local = id - grp.tile_start[q];
+    GemmProblem g = grp.p[q];
+    g.A += (long long)z * grp.sA[q];
+    g.B += (long long)(z / grp.b_div[q]) * grp.sB[q];
+    g.C += (long long)z * grp.sC;
+    g.colsum += (long long)z * grp.sC;
+    gemm_wave4_tile<false, false, EPI_STORE>(g, local / g.tiles_n, local % g.tiles_n);
+}
+
 __global__ __launch_bounds__(256) void gemm_wave_grouped_tn_batched_kernel(GemmGroupBatched grp) {
     const int id = (int)blockIdx.x * 4 + wave_id(), z = (int)blockIdx.z;
     if (id >= grp.tile_start[grp.n]) return;

@@ -5,8 +5,8 @@
 // barrier per 32-deep chunk -- the whole chip waits on 8 waves.  Here every wave owns ONE 32 x 32 tile of C and the
 // full K range: 4x the waves, no LDS, no barriers, operands streamed global/L2 -> registers (the weights of these nets
 // are L2 resident: 0.26 MB per layer), a 64-cycle v_mfma_f32_32x32x2_f32 per two k.  The k loop accumulates into one
-// register tile in ascending k, exactly like gemm_tile<> -- results are bit-identical to the tiled engine, so the host
-// can pick either by problem size.
+// register tile in ascending k, exactly like gemm_tile<> -- results are bit-identical to the tiled engine.  Used for
+// K <= 32 (first layers); deeper contractions use the split-K form at the end of this file.
 //
 // Operand addressing of lane (i = lane & 31, h = lane >> 5) for the MFMA of k-pair (k, k+1): A(m0+i, k+h), B(k+h, n0+i).
 //   *_KC = 1 : operand is K-contiguous in memory (activations X[m][k], weights W[n][k]): one 16-byte load covers the
@@ -107,6 +107,99 @@ __device__ __forceinline__ void gemm_wave_tile(const GemmProblem& g, int tile_m,
     }
     // half-wave 0 added (even k, then its partner's odd k) in ascending k: the order of gemm_tile's column sums
     if (do_colsum && h == 0 && m0 + i < g.M) g.colsum[m0 + i] = colsum;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Split-K form for K > 32: the FOUR waves of a workgroup share one 32 x 32 tile, wave w owning the contiguous k range
+// [w * kper, (w + 1) * kper).  A wave's whole range (64 k at K = 256) is fetched with all its loads in flight at once --
+// the single-wave form above exposes one memory round trip per 16 k (measured 42 us for a 128 x 256 x 256 layer: 16
+// dependent trips on a chip whose other 1000 SIMDs idle); here it is ONE trip, 32 MFMAs and an LDS reduction of the four
+// partial tiles in wave order (deterministic; the summation order differs from the single-chain engines by design).
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int WG4_CHUNK = 64;   // k values a wave keeps in registers at a time
+
+template <bool KC>
+__device__ __forceinline__ void wave_load64(float (&v)[WG4_CHUNK / 2], const float* __restrict__ P, int ld, int idx,
+                                            int extent, int k0, int kend, int h, int vec) {
+    const bool ok = idx < extent;
+    if (KC) {
+        const float* __restrict__ row = P + (size_t)(ok ? idx : 0) * ld;
+#pragma unroll
+        for (int q = 0; q < WG4_CHUNK / 4; ++q) {
+            const int k4 = k0 + 4 * q;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                if (vec && k4 + 3 < kend) {
+                    t = *reinterpret_cast<const float4*>(row + k4);
+                } else {
+                    if (k4 < kend) t.x = row[k4];
+                    if (k4 + 1 < kend) t.y = row[k4 + 1];
+                    if (k4 + 2 < kend) t.z = row[k4 + 2];
+                    if (k4 + 3 < kend) t.w = row[k4 + 3];
+                }
+            }
+            v[2 * q] = h ? t.y : t.x;
+            v[2 * q + 1] = h ? t.w : t.z;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < WG4_CHUNK / 2; ++s) {
+            const int k = k0 + 2 * s + h;
+            v[s] = (ok && k < kend) ? P[(size_t)k * ld + idx] : 0.f;
+        }
+    }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__device__ __forceinline__ void gemm_wave4_tile(const GemmProblem& g, int tile_m, int tile_n) {
+    __shared__ float s_red[3][16][64];
+    __shared__ float s_col[3][32];
+    const int lane = lane_id(), wave = wave_id();
+    const int h = lane >> 5, i = lane & 31;
+    const int m0 = tile_m * 32, n0 = tile_n * 32;
+    const int kper = ((g.K + 3) / 4 + 3) / 4 * 4;            // per-wave k range, multiple of 4 (16-byte loads stay aligned)
+    const int kbeg = wave * kper, kend = min(g.K, kbeg + kper);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float colsum = 0.f;
+    const bool do_colsum = (g.colsum != nullptr) && (tile_n == 0);
+    for (int k0 = kbeg; k0 < kend; k0 += WG4_CHUNK) {
+        float a[WG4_CHUNK / 2], b[WG4_CHUNK / 2];
+        wave_load64<A_KC>(a, g.A, g.lda, m0 + i, g.M, k0, kend, h, g.a_vec);
+        wave_load64<B_KC>(b, g.B, g.ldb, n0 + i, g.N, k0, kend, h, g.b_vec);
+#pragma unroll
+        for (int s = 0; s < WG4_CHUNK / 2; ++s) {
+            acc = mfma32(a[s], b[s], acc);
+            if (do_colsum) { const float odd = __shfl_xor(a[s], 32); colsum += a[s]; colsum += odd; }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_red[wave - 1][r][lane] = acc[r];
+        if (do_colsum && h == 0) s_col[wave - 1][i] = colsum;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += s_red[w][r][lane];
+    const int col = n0 + i;
+    float bias = 0.f;
+    if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && col < g.N) bias = g.bias[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < g.M && col < g.N) {
+            float v = acc[r];
+            if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) v += bias;
+            if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+            if (EPI == EPI_RELU_MASK) v = (g.mask[(size_t)row * g.ldmask + col] > 0.f) ? v : 0.f;
+            g.C[(size_t)row * g.ldc + col] = v;
+        }
+    }
+    if (do_colsum && h == 0 && m0 + i < g.M) g.colsum[m0 + i] = ((colsum + s_col[0][i]) + s_col[1][i]) + s_col[2][i];
 }
 
 }  // namespace morl

@@ -198,8 +198,8 @@ extern "C" int morl_ac_create(morl_ac_ctx** out, const morl_ac_desc* d) {
 // batched layer launches
 // ---------------------------------------------------------------------------------------------------------------------
 // Engine choice per launch: the LDS-tiled 128 x 128 engine needs >= ~half a chip of tiles to be worth its barriers;
-// below that the work is latency-bound and the wave-level 32 x 32 tiles (gemm_wave.h) spread it over 16x more waves.
-// Both accumulate in the same order -> identical bits, so the choice never shows in the results.
+// below that the work is latency-bound and the wave-level 32 x 32 tiles (gemm_wave.h) spread it over many more waves
+// (split-K over the four waves of a workgroup once K > 32: same sums in a different, still deterministic order).
 static int g_ac_gemm_mode = 0;      // 0 auto, 1 always LDS tiles, 2 always wave tiles (morl_ac_set_gemm_mode)
 static bool use_wave_tiles(long long tiles128) {
     if (g_ac_gemm_mode == 1) return false;
@@ -218,7 +218,10 @@ static int launch_bgemm(GemmBatched b, int G, hipStream_t s, const char* name) {
     if (use_wave_tiles((long long)g.tiles_m * g.tiles_n * G)) {
         g.tiles_m = (g.M + 31) / 32;
         g.tiles_n = (g.N + 31) / 32;
-        hipLaunchKernelGGL((gemm_wave_batched_kernel<A_KC, B_KC, EPI>), dim3((g.tiles_m * g.tiles_n + 3) / 4, 1, G), dim3(256), 0, s, b);
+        if (g.K > 32)      // deep contraction: the four waves of a workgroup split K (one memory round trip per wave)
+            hipLaunchKernelGGL((gemm_wave4_batched_kernel<A_KC, B_KC, EPI>), dim3(g.tiles_m * g.tiles_n, 1, G), dim3(256), 0, s, b);
+        else
+            hipLaunchKernelGGL((gemm_wave_batched_kernel<A_KC, B_KC, EPI>), dim3((g.tiles_m * g.tiles_n + 3) / 4, 1, G), dim3(256), 0, s, b);
     } else {
         hipLaunchKernelGGL((gemm_batched_kernel<A_KC, B_KC, EPI>), dim3(g.tiles_m * g.tiles_n, 1, G), dim3(GEMM_THREADS), 0, s, b);
     }
@@ -378,7 +381,10 @@ static int mlp_backward(const Mlp& m, const float* params, int64_t pstride, Tape
                 tiles += g.tiles_m * g.tiles_n;
             }
             grp.tile_start[m.L] = tiles;
-            hipLaunchKernelGGL(gemm_wave_grouped_tn_batched_kernel, dim3((tiles + 3) / 4, 1, t.G), dim3(256), 0, s, grp);
+            if (rows > 32)
+                hipLaunchKernelGGL(gemm_wave4_grouped_tn_batched_kernel, dim3(tiles, 1, t.G), dim3(256), 0, s, grp);
+            else
+                hipLaunchKernelGGL(gemm_wave_grouped_tn_batched_kernel, dim3((tiles + 3) / 4, 1, t.G), dim3(256), 0, s, grp);
         } else {
             hipLaunchKernelGGL(gemm_grouped_tn_batched_kernel, dim3(tiles, 1, t.G), dim3(GEMM_THREADS), 0, s, grp);
         }
@@ -861,7 +867,10 @@ static int gpi_backward(morl_gpi_ctx* c, const float* params, GpiTape& g, const 
             p.tiles_n = (p.N + 31) / 32;
             tiles = p.tiles_m * p.tiles_n;
             grp.tile_start[1] = tiles;
-            hipLaunchKernelGGL(gemm_wave_grouped_tn_batched_kernel, dim3((tiles + 3) / 4, 1, c->nn), dim3(256), 0, s, grp);
+            if (rows > 32)
+                hipLaunchKernelGGL(gemm_wave4_grouped_tn_batched_kernel, dim3(tiles, 1, c->nn), dim3(256), 0, s, grp);
+            else
+                hipLaunchKernelGGL(gemm_wave_grouped_tn_batched_kernel, dim3((tiles + 3) / 4, 1, c->nn), dim3(256), 0, s, grp);
         } else {
             grp.tile_start[1] = tiles;
             hipLaunchKernelGGL(gemm_grouped_tn_batched_kernel, dim3(tiles, 1, c->nn), dim3(GEMM_THREADS), 0, s, grp);

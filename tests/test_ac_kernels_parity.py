@@ -226,24 +226,26 @@ def test_population_batch_equals_independent_learners(be, name):
 
 
 @pytest.mark.parametrize("name", ["capql_small", "mosac_noauto_odd", "gpipd_support_per", "capql_cheetah"])
-def test_wave_and_lds_tile_engines_are_bit_identical(be, name):
-    """The latency-bound launches use wave-level 32x32 MFMA tiles (gemm_wave.h), the throughput-bound ones the
-    LDS-tiled 128x128 engine (gemm_f32.h); both accumulate in ascending k in one register tile, so every bit agrees."""
+def test_wave_and_lds_tile_engines_agree(be, name):
+    """The latency-bound launches use wave-level 32x32 MFMA tiles (gemm_wave.h; split-K over the four waves of a workgroup
+    for K > 32), the throughput-bound ones the LDS-tiled 128x128 engine (gemm_f32.h).  Same exact-fp32 products, different
+    (each deterministic) summation orders: gradients agree to fp32 round-off, and each engine reproduces itself bit for bit."""
     lib, dev = be
     c = [x for x in AC_CASES if x.name == name][0]
     if dev.type == "cpu" and max(c.arch) >= 256:
         pytest.skip("reference-sized networks run on the GPU only")
     inp = make_inputs(c)
-    states = []
+    runs = {}
     try:
-        for mode in (1, 2):
+        for mode in (1, 2, 2):
             lib.check(lib.lib.morl_ac_set_gemm_mode(mode))
             eng = build_engine(c, inp, lib, dev)
             res = run_engine(c, inp, eng, ["critic_loss", "q_grads"])
-            states.append((eng, res))
+            runs.setdefault(mode, []).append((eng, res))
     finally:
         lib.lib.morl_ac_set_gemm_mode(0)
-    (e1, r1), (e2, r2) = states
-    for k in ("q", "q_target", "pol", "q_exp_avg", "q_exp_avg_sq", "pol_exp_avg", "pol_exp_avg_sq"):
-        assert th.equal(getattr(e1, k), getattr(e2, k)), k
-    assert th.equal(r1["q_grads"], r2["q_grads"]) and th.equal(r1["critic_loss"], r2["critic_loss"])
+    (e1, r1), (e2, r2), (e3, r3) = runs[1][0], runs[2][0], runs[2][1]
+    assert th.equal(r2["q_grads"], r3["q_grads"]) and th.equal(e2.q, e3.q) and th.equal(e2.pol, e3.pol)   # run-to-run
+    g1, g2 = r1["q_grads"].cpu().double(), r2["q_grads"].cpu().double()
+    assert float((g1 - g2).abs().max()) <= 2e-6 * float(g1.abs().max())
+    assert abs(float(r1["critic_loss"][0]) - float(r2["critic_loss"][0])) <= 2e-6 * abs(float(r1["critic_loss"][0]))
