@@ -77,13 +77,16 @@ struct EnvelopeTdArgs {
 
 // LDS-resident throughout: phase 1 stages Qo[b], Qt[b], the weight vectors and the taken-action Q entries of this
 // transition with coalesced / parallel loads; phase 3 writes all outputs in bulk.
-// Phase 2 mapping: lane <-> scalarisation vector i (TD row), wave q of the 4 <-> a quarter of the (j, a) candidates.
+// Phase 2 mapping: lane <-> scalarisation vector i (TD row), wave q of the block's NW (4..16) <-> a 1/NW slice of the
+// (j, a) candidates (NW grows with the candidate count: a weight-sharded job reduces over all gathered W * A).
 // Every lane walks its wave's candidates in index order reading the candidate's R values as LDS *broadcasts* (all lanes
-// read the same address: one conflict-free access), so the arg-max needs no cross-lane traffic at all; the four
+// read the same address: one conflict-free access), so the arg-max needs no cross-lane traffic at all; the NW
 // per-wave partial winners of a row are merged through LDS in candidate order (first maximum wins, like th.max /
 // th.argmax).  The kernel is latency-bound, not bandwidth-bound: what matters is that no lane waits on a dependent
 // shuffle or global load inside the candidate loop.
-__global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
+constexpr int ENV_MAX_WAVES = 16;
+
+__global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(EnvelopeTdArgs p) {
     __shared__ float s_qo[ENV_MAX_SLAB];
     __shared__ float s_qt[ENV_MAX_SLAB];
     __shared__ float s_w[ENV_MAX_WR];
@@ -91,9 +94,10 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
     __shared__ float s_tgt[ENV_MAX_WR];   // selected target vectors
     __shared__ float s_g[ENV_MAX_WR];     // dLoss/dQ of the taken action
     __shared__ int s_best[ENV_MAX_WR];    // flattened (j*, a*)
-    __shared__ float s_pv[4][ENV_MAX_WR / 2];   // per-wave partial maxima ...
-    __shared__ int s_pc[4][ENV_MAX_WR / 2];     // ... and their candidate indices
+    __shared__ float s_pv[ENV_MAX_WAVES][kWave];   // per-wave partial maxima of the 64 rows in flight ...
+    __shared__ int s_pc[ENV_MAX_WAVES][kWave];     // ... and their candidate indices
     __shared__ double s_red[4][2];
+    const int nw = (int)(blockDim.x >> 6);
     const int ig_n = p.i_groups > 0 ? p.i_groups : 1;
     const int b = (int)blockIdx.x / ig_n, ig = (int)blockIdx.x % ig_n;
     const int lane = lane_id(), wave = wave_id();
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
         // candidate range of this wave: a quarter of (j, a) in index order (DDQN: of the A actions of slab j = i)
         const int n_c = p.diag_only ? A : W * A;
         const int c_off = (p.diag_only && live) ? (i + p.i_offset) * A : 0;     // per-lane base in DDQN mode
-        const int q_lo = (n_c * wave) / 4, q_hi = (n_c * (wave + 1)) / 4;
+        const int q_lo = (int)(((long long)n_c * wave) / nw), q_hi = (int)(((long long)n_c * (wave + 1)) / nw);
         float best = -INFINITY;
         int best_c = 0x7fffffff;
         // 4 candidates per step: their LDS reads are independent of the running maximum and overlap
@@ -162,11 +166,10 @@ __global__ __launch_bounds__(256) void envelope_td_kernel(EnvelopeTdArgs p) {
         if (live) { s_pv[wave][i - ib] = best; s_pc[wave][i - ib] = best_c; }
         __syncthreads();
         if (wave == 0 && live) {
-            // merge the four quarters in candidate order: strictly greater replaces, so the first maximum wins
+            // merge the slices in candidate order: strictly greater replaces, so the first maximum wins
             float bv = s_pv[0][lane];
             int bc = s_pc[0][lane];
-#pragma unroll
-            for (int q = 1; q < 4; ++q) {
+            for (int q = 1; q < nw; ++q) {
                 const float v = s_pv[q][lane];
                 const int cc = s_pc[q][lane];
                 if (cc != 0x7fffffff && (bc == 0x7fffffff || v > bv)) { bv = v; bc = cc; }

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -661,7 +662,12 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         p.c_mse = (float)((1.0 - (double)lam) * 2.0 / ((double)rows_total * R));
         p.c_aux = (float)((double)lam * 2.0 / (double)rows_total);
         p.i_groups = td_groups;
-        hipLaunchKernelGGL(envelope_td_kernel, dim3(B * td_groups), dim3(256), 0, s, p);
+        // waves per workgroup ~ candidates per TD row: 4 at the single-GPU 64 x 6, up to 16 when a sharded job reduces over
+        // all gathered weights (MORL_TD_WAVES overrides, for tuning)
+        const long long n_cand = cfg->envelope ? (long long)W * A : A;
+        int td_waves = n_cand >= 256 ? 16 : (n_cand >= 64 ? 8 : 4);
+        if (const char* e = getenv("MORL_TD_WAVES")) td_waves = std::max(1, std::min(ENV_MAX_WAVES, atoi(e)));
+        hipLaunchKernelGGL(envelope_td_kernel, dim3(B * td_groups), dim3(64 * td_waves), 0, s, p);
         LAUNCH_CHECK("envelope_td");
     }
     // backward through the hidden layers: g[l-1] = (g[l] @ W_l) * (h[l] > 0)
