@@ -65,23 +65,29 @@ struct GemmGroup {
 
 // All weight-gradient GEMMs of one backward pass in a single launch (split-K over the batch rows):
 // dW_l[o][i] = sum_m g_l[m][o] * h_l[m][i], db_l[o] = sum_m g_l[m][o].
+// Grid: 1-D over (split, tile) pairs, XCD-remapped so that ALL tiles of a K-split -- which share the split's slices of
+// dZ_l and h_l -- run on one XCD and hit its L2 (the dispatcher round-robins consecutive workgroups over the 8 XCDs).
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_grouped_tn_kernel(GemmGroup grp) {
-    const int id = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int n_tiles = grp.tile_start[grp.n];
+    const int logical = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int split = logical / n_tiles, id = logical % n_tiles;
     int q = 0;
     while (q + 1 < grp.n && id >= grp.tile_start[q + 1]) ++q;
     const int local = id - grp.tile_start[q];
     const GemmProblem& g = grp.p[q];
-    gemm_tile<false, false, EPI_STORE>(g, local / g.tiles_n, local % g.tiles_n, (int)blockIdx.y);
+    gemm_tile<false, false, EPI_STORE>(g, local / g.tiles_n, local % g.tiles_n, split);
 }
 
 // same work, double-buffered LDS tiles, two workgroups per CU (see gemm_tile_tn_db)
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_grouped_tn_db_kernel(GemmGroup grp) {
-    const int id = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int n_tiles = grp.tile_start[grp.n];
+    const int logical = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int split = logical / n_tiles, id = logical % n_tiles;
     int q = 0;
     while (q + 1 < grp.n && id >= grp.tile_start[q + 1]) ++q;
     const int local = id - grp.tile_start[q];
     const GemmProblem& g = grp.p[q];
-    gemm_tile_tn_db(g, local / g.tiles_n, local % g.tiles_n, (int)blockIdx.y);
+    gemm_tile_tn_db(g, local / g.tiles_n, local % g.tiles_n, split);
 }
 
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst,
@@ -748,8 +754,8 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             t += g.tiles_m * g.tiles_n;
         }
         grp.tile_start[L] = t;
-        if (db) hipLaunchKernelGGL(gemm_grouped_tn_db_kernel, dim3(t, splits), dim3(GEMM_THREADS), 0, s, grp);
-        else hipLaunchKernelGGL(gemm_grouped_tn_kernel, dim3(t, splits), dim3(GEMM_THREADS), 0, s, grp);
+        if (db) hipLaunchKernelGGL(gemm_grouped_tn_db_kernel, dim3(t * splits), dim3(GEMM_THREADS), 0, s, grp);
+        else hipLaunchKernelGGL(gemm_grouped_tn_kernel, dim3(t * splits), dim3(GEMM_THREADS), 0, s, grp);
         LAUNCH_CHECK("gemm_grouped_dw");
     }
     }
