@@ -212,6 +212,9 @@ int morl_sumtree_update(double* tree, int n_levels, const int64_t* idx, const fl
  *   policy  in = D (+ R when weight-conditioned), hidden layers W_l, b_l (no LayerNorm), then the heads as ONE
  *           linear layer: W_head [heads*Ad][h_last], b_head [heads*Ad]; heads = 2 (rows 0..Ad-1 = mean, rows
  *           Ad..2Ad-1 = log_std) for CAPQL / MOSAC, heads = 1 (mean) for TD3.
+ *   SACD    critics: in = D, out = A * R (Q of every action); actor: in = D, out = A logits.  batch.actions holds the
+ *           taken action index as a float ([pop][rows], ReplayBuffer's float32 action column); batch.w is [pop][R];
+ *           no noise inputs (the expectation over actions is exact); the actor is updated once per call.
  *   critics of a learner are contiguous: q[pop][num_q][Pq]; one Adam state over all of them (the reference
  *   chains the Q-nets' parameters into one optimiser).
  * Random draws are INPUTS (device arrays the host fills from its generator): re-parameterisation noise eps,
@@ -221,12 +224,13 @@ int morl_sumtree_update(double* tree, int n_levels, const int64_t* idx, const fl
 #define MORL_AC_CAPQL 0
 #define MORL_AC_MOSAC 1
 #define MORL_AC_TD3 2
+#define MORL_AC_SACD 3   /* MOSAC with discrete actions: single_policy/ser/mosac_discrete_action.py:440-503 */
 
 typedef struct morl_ac_ctx morl_ac_ctx;
 
 typedef struct morl_ac_desc {
     int32_t algo;                    /* MORL_AC_* */
-    int32_t obs_dim, act_dim, reward_dim;
+    int32_t obs_dim, act_dim, reward_dim;   /* SACD: act_dim = number of discrete actions */
     int32_t n_hidden;                /* len(net_arch), 1 .. MORL_MAX_LAYERS-1 */
     int32_t hidden[MORL_MAX_LAYERS]; /* net_arch, shared by the policy and the Q-nets (as in the reference) */
     int32_t num_q;                   /* Q-networks per learner (reference default 2; MOSAC: exactly 2) */
@@ -323,12 +327,14 @@ int morl_ac_update(morl_ac_ctx* ctx, const morl_ac_state* st, const morl_ac_batc
 /* Policy forward for acting / evaluation.  obs [pop][rows][D]; w as in morl_ac_batch (NULL for MOSAC);
  * mode 0: deterministic action (CAPQL Policy.get_action, TD3 Policy.forward without noise; MOSAC: the tanh mean),
  * mode 1: sampled action with eps [pop][rows][Ad] (MOSACActor.get_action; CAPQL Policy.sample; TD3: noise).
- * use_target != 0 reads st->pol_target (TD3).  actions_out [pop][rows][Ad]; logp_out [pop][rows] or NULL. */
+ * use_target != 0 reads st->pol_target (TD3).  actions_out [pop][rows][Ad]; logp_out [pop][rows] or NULL.
+ * SACD: actions_out receives the actor LOGITS [pop][rows][A] (Categorical sampling stays with the caller). */
 int morl_ac_policy_forward(morl_ac_ctx* ctx, const morl_ac_state* st, const float* obs, const float* w, int rows,
                            int mode, const float* eps, int use_target, const morl_ac_cfg* cfg, float* actions_out,
                            float* logp_out, void* stream);
 
-/* Critic forward (eval mode: no dropout): q_out [pop][num_q][rows][R] for inputs obs / actions (/ w). */
+/* Critic forward (eval mode: no dropout): q_out [pop][num_q][rows][R] for inputs obs / actions (/ w);
+ * SACD: q_out [pop][num_q][rows][A*R], actions ignored. */
 int morl_ac_q_forward(morl_ac_ctx* ctx, const morl_ac_state* st, const float* obs, const float* actions,
                       const float* w, int rows, int use_target, float* q_out, void* stream);
 

@@ -16,7 +16,7 @@ import torch as th
 from . import native
 from .native import ACBatch, ACCfg, ACDesc, ACOut, ACState, NativeLib
 
-ALGO_CAPQL, ALGO_MOSAC, ALGO_TD3 = 0, 1, 2
+ALGO_CAPQL, ALGO_MOSAC, ALGO_TD3, ALGO_SACD = 0, 1, 2, 3
 
 
 class ACEngine:
@@ -43,8 +43,9 @@ class ACEngine:
         self.arch = [int(h) for h in net_arch]
         self.num_q, self.pop, self.max_rows = num_q, population, max_rows
         self.layer_norm, self.drop_rate = bool(q_layer_norm), float(q_drop_rate)
-        self.heads = 1 if algo == ALGO_TD3 else 2
-        self.w_input = algo != ALGO_MOSAC
+        self.heads = 1 if algo in (ALGO_TD3, ALGO_SACD) else 2
+        self.w_input = algo not in (ALGO_MOSAC, ALGO_SACD)
+        self.discrete = algo == ALGO_SACD            # act_dim = number of actions; critics output A * R values
         self.Pq = int(self.lib.lib.morl_ac_q_param_count(C.byref(d)))
         self.Pp = int(self.lib.lib.morl_ac_policy_param_count(C.byref(d)))
         if self.Pq < 0 or self.Pp < 0:
@@ -65,7 +66,7 @@ class ACEngine:
             self.pol, self.pol_exp_avg, self.pol_exp_avg_sq = (z(population, self.Pp) for _ in range(3))
             self.pol_target = z(population, self.Pp) if algo == ALGO_TD3 else None
             self.log_alpha = self.log_alpha_exp_avg = self.log_alpha_exp_avg_sq = None
-            if algo == ALGO_MOSAC:
+            if algo in (ALGO_MOSAC, ALGO_SACD):
                 self.log_alpha, self.log_alpha_exp_avg, self.log_alpha_exp_avg_sq = (z(population) for _ in range(3))
             low = np.broadcast_to(np.asarray(action_low, dtype=np.float32), (act_dim,))
             high = np.broadcast_to(np.asarray(action_high, dtype=np.float32), (act_dim,))
@@ -99,13 +100,14 @@ class ACEngine:
 
     # -- parameter views (torch nn.Sequential.parameters() order) ---------------------------------------------------
     def _q_shapes(self):
-        out, d = [], self.D + self.Ad + (self.R if self.w_input else 0)
+        out, d = [], (self.D if self.discrete else self.D + self.Ad + (self.R if self.w_input else 0))
         for hdim in self.arch:
             out += [(hdim, d), (hdim,)]
             if self.layer_norm:
                 out += [(hdim,), (hdim,)]
             d = hdim
-        return out + [(self.R, d), (self.R,)]
+        n_out = self.Ad * self.R if self.discrete else self.R
+        return out + [(n_out, d), (n_out,)]
 
     @staticmethod
     def _views(flat: th.Tensor, shapes) -> List[th.Tensor]:
@@ -166,7 +168,7 @@ class ACEngine:
         c.policy_noise, c.noise_clip, c.n_per, c.dropout_seed = policy_noise, noise_clip, n_per, dropout_seed
         return c
 
-    def update(self, cfg: ACCfg, *, obs, actions, rewards, next_obs, dones, w, eps_next, eps_pi=None, eps_alpha=None,
+    def update(self, cfg: ACCfg, *, obs, actions, rewards, next_obs, dones, w, eps_next=None, eps_pi=None, eps_alpha=None,
                drop_masks: Optional[th.Tensor] = None, want: Sequence[str] = ("critic_loss", "policy_loss"),
                first: int = 0, count: Optional[int] = None) -> Dict:
         """One ``morl_ac_update``.  Array shapes as in include/morl_hip.h (leading [pop] axis may be omitted when
@@ -195,9 +197,11 @@ class ACEngine:
             t = self._f32(t, name)
             keep.append(t)
             setattr(b, name, t.data_ptr())
-        expect = dict(actions=pop * rows * self.Ad, rewards=pop * rows * self.R, next_obs=obs.numel(),
-                      dones=pop * rows, w=pop * (rows if self.w_input else 1) * self.R, eps_next=pop * rows * self.Ad)
-        for (name, n), t in zip(expect.items(), keep[1:7]):
+        expect = dict(actions=pop * rows * (1 if self.discrete else self.Ad), rewards=pop * rows * self.R,
+                      next_obs=obs.numel(), dones=pop * rows, w=pop * (rows if self.w_input else 1) * self.R)
+        if not self.discrete:
+            expect["eps_next"] = pop * rows * self.Ad
+        for (name, n), t in zip(expect.items(), keep[1:1 + len(expect)]):
             if t.numel() != n:
                 raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
         if drop_masks is not None:
@@ -211,7 +215,7 @@ class ACEngine:
         iters = max(1, cfg.policy_iters) if self.algo == ALGO_MOSAC else 1
         shapes = dict(critic_loss=(pop,), q_losses=(pop, self.num_q), policy_loss=(pop,), alpha_loss=(pop,),
                       alpha=(pop,), priority=(pop, max(cfg.n_per, 1)),
-                      target_q=(pop, rows) if self.algo == ALGO_MOSAC else (pop, rows, self.R),
+                      target_q=(pop, rows) if self.algo in (ALGO_MOSAC, ALGO_SACD) else (pop, rows, self.R),
                       q_grads=(pop, self.num_q, self.Pq), pol_grads=(pop, self.Pp))
         for name in want:
             res[name] = th.zeros(shapes[name], dtype=th.float32, device=self.q.device)
@@ -239,14 +243,17 @@ class ACEngine:
             None if logp is None else logp.data_ptr(), self.lib.stream_of(self.q)))
         return (act, logp) if want_logp else act
 
-    def q_forward(self, obs, actions, w=None, *, use_target=False) -> th.Tensor:
-        obs, actions = self._f32(obs, "obs"), self._f32(actions, "actions")
+    def q_forward(self, obs, actions=None, w=None, *, use_target=False) -> th.Tensor:
+        obs = self._f32(obs, "obs")
+        actions = None if actions is None else self._f32(actions, "actions")
         rows = obs.numel() // (self.pop * self.D)
         w = None if w is None else self._f32(w, "w")
-        out = th.empty((self.pop, self.num_q, rows, self.R), dtype=th.float32, device=self.q.device)
+        n_out = self.Ad * self.R if self.discrete else self.R
+        out = th.empty((self.pop, self.num_q, rows, n_out), dtype=th.float32, device=self.q.device)
         st = self._state()
         self.lib.check_device(obs, actions, w)
         self.lib.check(self.lib.lib.morl_ac_q_forward(
-            self._h, C.byref(st), obs.data_ptr(), actions.data_ptr(), None if w is None else w.data_ptr(), rows,
+            self._h, C.byref(st), obs.data_ptr(), None if actions is None else actions.data_ptr(),
+            None if w is None else w.data_ptr(), rows,
             int(use_target), out.data_ptr(), self.lib.stream_of(self.q)))
         return out

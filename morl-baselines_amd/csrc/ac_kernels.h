@@ -728,6 +728,176 @@ __global__ __launch_bounds__(256) void ac_alpha_step_kernel(float* log_alpha, fl
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// MOSAC with discrete actions (mosac_discrete_action.py:440-503).  One workgroup per learner, threads stride over rows.
+//   critic: p', logp' = softmax / log_softmax of the actor logits at s'; v = sum_a p'_a * (min_n(Qt_n[a] . w) - alpha logp'_a);
+//           target = r . w + (1 - d) * gamma * v;  loss = sum_n mse(Q_n[a_taken] . w, target)
+//   actor : c_a = alpha logp_a - min_n(Q_n[a] . w);  loss = mean_{rows x A}(p_a c_a);
+//           dLoss/dlogit_k = p_k (c_k - sum_a p_a c_a) / (rows * A)        (the alpha * d(logp) terms cancel)
+//   alpha : loss = mean_{rows x A}(p_a * (-exp(log_alpha) * (logp_a + target_entropy))), same probabilities -> done in the
+//           actor kernel right after the block sum (scalar Adam step on log_alpha)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SACD_MAX_A = 64;
+
+__device__ __forceinline__ void sacd_softmax(const float* __restrict__ logits, int A, float* p, float* lp) {
+    float mx = logits[0];
+    for (int a = 1; a < A; ++a) mx = fmaxf(mx, logits[a]);
+    float se = 0.f;
+    for (int a = 0; a < A; ++a) se += expf(logits[a] - mx);
+    const float lse = logf(se);
+    for (int a = 0; a < A; ++a) {
+        lp[a] = (logits[a] - mx) - lse;
+        p[a] = expf(lp[a]);
+    }
+}
+
+struct SacdCriticArgs {
+    const float* logits_next; // [G][cap][ldp]
+    long long p_gstride;
+    int ldp;
+    const float* tq;          // [G*2][cap][ldo]  target critics at s' (A*R per row)
+    const float* q;           // [G*2][cap][ldo]  critics at s
+    float* dq;
+    long long gstride;
+    int ldo;
+    const float* actions;     // [G][rows] action index as float
+    const float* rewards;     // [G][rows][R]
+    const float* dones;       // [G][rows]
+    const float* w;           // [G][R]
+    const float* log_alpha;
+    float alpha_const;
+    float* target_out;        // [G][rows] or NULL
+    float* loss_out;          // [G]
+    float* q_losses;          // [G][2]
+    int rows, A, R;
+    float gamma;
+};
+
+__global__ __launch_bounds__(256) void sacd_critic_kernel(SacdCriticArgs a) {
+    __shared__ double s_red[4];
+    const int g = (int)blockIdx.x;
+    const float alpha = ac_alpha(a.log_alpha, a.alpha_const, g);
+    const float* __restrict__ w = a.w + (long long)g * a.R;
+    double part[2] = {0.0, 0.0};
+    for (int row = (int)threadIdx.x; row < a.rows; row += (int)blockDim.x) {
+        float p[SACD_MAX_A], lp[SACD_MAX_A];
+        sacd_softmax(a.logits_next + (long long)g * a.p_gstride + (long long)row * a.ldp, a.A, p, lp);
+        const long long ro = (long long)row * a.ldo;
+        float v = 0.f;
+        for (int ac = 0; ac < a.A; ++ac) {
+            float m = 0.f;
+            for (int n = 0; n < 2; ++n) {
+                float s = 0.f;
+                for (int r = 0; r < a.R; ++r) s += a.tq[(long long)(g * 2 + n) * a.gstride + ro + ac * a.R + r] * w[r];
+                m = (n == 0) ? s : fminf(m, s);
+            }
+            v += p[ac] * (m - alpha * lp[ac]);
+        }
+        float sr = 0.f;
+        for (int r = 0; r < a.R; ++r) sr += a.rewards[((long long)g * a.rows + row) * a.R + r] * w[r];
+        const float tgt = sr + ((1.f - a.dones[(long long)g * a.rows + row]) * a.gamma) * v;
+        if (a.target_out) a.target_out[(long long)g * a.rows + row] = tgt;
+        const int act = (int)a.actions[(long long)g * a.rows + row];
+        for (int n = 0; n < 2; ++n) {
+            const float* __restrict__ q = a.q + (long long)(g * 2 + n) * a.gstride + ro;
+            float* __restrict__ dq = a.dq + (long long)(g * 2 + n) * a.gstride + ro;
+            for (int e = 0; e < a.ldo; ++e) dq[e] = 0.f;
+            float s = 0.f;
+            for (int r = 0; r < a.R; ++r) s += q[act * a.R + r] * w[r];
+            const float e = s - tgt;
+            part[n] += (double)e * (double)e;
+            const float c = 2.f * e / (float)a.rows;
+            for (int r = 0; r < a.R; ++r) dq[act * a.R + r] = c * w[r];
+        }
+    }
+    double total = 0.0;
+    for (int n = 0; n < 2; ++n) {
+        const double l = ac_block_sum(part[n], s_red) / (double)a.rows;
+        if (threadIdx.x == 0 && a.q_losses) a.q_losses[(long long)g * 2 + n] = (float)l;
+        total += l;
+    }
+    if (threadIdx.x == 0 && a.loss_out) a.loss_out[g] = (float)total;
+}
+
+struct SacdActorArgs {
+    const float* logits;      // [G][cap][ldp]
+    float* dlogits;           // [G][cap][ldp]
+    long long p_gstride;
+    int ldp;
+    const float* q;           // [G*2][cap][ldo]  (updated) critics at s
+    long long gstride;
+    int ldo;
+    const float* w;           // [G][R]
+    float* log_alpha;         // [G] or NULL (constant coefficient)
+    float* la_m;
+    float* la_v;
+    float alpha_const;
+    int autotune;
+    float target_entropy;
+    const int* steps;         // device Adam step counters of the actor or NULL
+    int step_add;
+    double alpha_lr, b1, b2;
+    float eps;
+    float* loss_out;          // [G] or NULL
+    float* alpha_loss_out;    // [G] or NULL
+    int rows, A, R;
+};
+
+__global__ __launch_bounds__(256) void sacd_actor_kernel(SacdActorArgs a) {
+    __shared__ double s_red[4];
+    const int g = (int)blockIdx.x;
+    const float alpha = ac_alpha(a.autotune ? a.log_alpha : nullptr, a.alpha_const, g);
+    const float* __restrict__ w = a.w + (long long)g * a.R;
+    const float inv = 1.f / ((float)a.rows * (float)a.A);
+    double s_loss = 0.0, s_ent = 0.0;
+    for (int row = (int)threadIdx.x; row < a.rows; row += (int)blockDim.x) {
+        float p[SACD_MAX_A], lp[SACD_MAX_A], c[SACD_MAX_A];
+        sacd_softmax(a.logits + (long long)g * a.p_gstride + (long long)row * a.ldp, a.A, p, lp);
+        const long long ro = (long long)row * a.ldo;
+        float cbar = 0.f, ent = 0.f;
+        for (int ac = 0; ac < a.A; ++ac) {
+            float m = 0.f;
+            for (int n = 0; n < 2; ++n) {
+                float s = 0.f;
+                for (int r = 0; r < a.R; ++r) s += a.q[(long long)(g * 2 + n) * a.gstride + ro + ac * a.R + r] * w[r];
+                m = (n == 0) ? s : fminf(m, s);
+            }
+            c[ac] = alpha * lp[ac] - m;
+            cbar += p[ac] * c[ac];
+            ent += p[ac] * (lp[ac] + a.target_entropy);
+        }
+        float* __restrict__ dl = a.dlogits + (long long)g * a.p_gstride + (long long)row * a.ldp;
+        for (int ac = 0; ac < a.A; ++ac) dl[ac] = p[ac] * (c[ac] - cbar) * inv;
+        for (int e = a.A; e < a.ldp; ++e) dl[e] = 0.f;
+        s_loss += (double)cbar;
+        s_ent += (double)ent;
+    }
+    const double tl = ac_block_sum(s_loss, s_red);
+    const double te = ac_block_sum(s_ent, s_red);
+    if (threadIdx.x == 0) {
+        if (a.loss_out) a.loss_out[g] = (float)(tl * (double)inv);
+        if (a.autotune) {
+            const float la = a.log_alpha[g];
+            const float ea = expf(la);
+            const float x = (float)(te * (double)inv);           // mean_{rows x A} p * (logp + target_entropy)
+            if (a.alpha_loss_out) a.alpha_loss_out[g] = -ea * x;
+            const float grad = -ea * x;                           // d/d(log_alpha) of -exp(log_alpha) * x
+            const int t = max(1, (a.steps ? a.steps[g] : 0) + a.step_add);
+            const float neg_step_size = (float)(-(a.alpha_lr / (1.0 - pow(a.b1, (double)t))));
+            const float bc2_sqrt = (float)sqrt(1.0 - pow(a.b2, (double)t));
+            const float one_minus_b1 = (float)(1.0 - a.b1), b2 = (float)a.b2, one_minus_b2 = (float)(1.0 - a.b2);
+            float m = a.la_m[g], v = a.la_v[g];
+            m = fmaf(one_minus_b1, __fsub_rn(grad, m), m);
+            v = __fadd_rn(__fmul_rn(v, b2), __fmul_rn(__fmul_rn(one_minus_b2, grad), grad));
+            const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), a.eps);
+            // NOTE: the update must not be visible to this kernel's own alpha read above: every thread took `alpha` at entry
+            a.log_alpha[g] = __fadd_rn(la, __fmul_rn(neg_step_size, __fdiv_rn(m, denom)));
+            a.la_m[g] = m;
+            a.la_v[g] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // torch _single_tensor_adam over one parameter segment per learner (blockIdx.y); the 1-based step is either the same
 // for everybody (steps == NULL) or read from the learner's device-resident counter: t = steps[g] + step_add.
 // Same arithmetic as clip_adam_kernel (optim_kernels.h) without the clipping.

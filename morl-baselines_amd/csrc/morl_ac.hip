@@ -115,25 +115,28 @@ static int alloc_tape(std::vector<void*>& c, const Mlp& m, Tape& t, int G, int x
 
 static int fill_nets(const morl_ac_desc* d, Mlp& q, Mlp& pol, int& heads, bool& w_input) {
     if (!d) return fail(MORL_ERR_ARG, "desc is NULL");
-    if (d->algo < MORL_AC_CAPQL || d->algo > MORL_AC_TD3) return fail(MORL_ERR_ARG, "unknown algo %d", d->algo);
+    if (d->algo < MORL_AC_CAPQL || d->algo > MORL_AC_SACD) return fail(MORL_ERR_ARG, "unknown algo %d", d->algo);
+    if (d->algo == MORL_AC_SACD && (d->num_q != 2 || d->act_dim > SACD_MAX_A || d->q_layer_norm || d->q_drop_rate > 0.f))
+        return fail(MORL_ERR_ARG, "discrete MOSAC: two plain critics, at most %d actions", SACD_MAX_A);
     if (d->n_hidden < 1 || d->n_hidden > MORL_MAX_LAYERS - 1) return fail(MORL_ERR_ARG, "n_hidden %d out of range", d->n_hidden);
     if (d->obs_dim < 1 || d->act_dim < 1 || d->reward_dim < 1 || d->reward_dim > MORL_MAX_OBJ)
         return fail(MORL_ERR_ARG, "bad dims D=%d Ad=%d R=%d", d->obs_dim, d->act_dim, d->reward_dim);
     if (d->num_q < 1 || d->num_q > 4) return fail(MORL_ERR_ARG, "num_q %d not in 1..4", d->num_q);
     if (d->algo == MORL_AC_MOSAC && d->num_q != 2) return fail(MORL_ERR_ARG, "MOSAC uses exactly two critics");
     if (d->q_drop_rate < 0.f || d->q_drop_rate >= 1.f) return fail(MORL_ERR_ARG, "drop rate %g", (double)d->q_drop_rate);
-    w_input = d->algo != MORL_AC_MOSAC;
-    heads = d->algo == MORL_AC_TD3 ? 1 : 2;
+    const bool sacd = d->algo == MORL_AC_SACD;
+    w_input = d->algo != MORL_AC_MOSAC && !sacd;
+    heads = (d->algo == MORL_AC_TD3 || sacd) ? 1 : 2;
     q = Mlp();
     pol = Mlp();
     q.L = pol.L = d->n_hidden + 1;
-    q.dims[0] = d->obs_dim + d->act_dim + (w_input ? d->reward_dim : 0);
+    q.dims[0] = sacd ? d->obs_dim : d->obs_dim + d->act_dim + (w_input ? d->reward_dim : 0);
     pol.dims[0] = d->obs_dim + (w_input ? d->reward_dim : 0);
     for (int l = 0; l < d->n_hidden; ++l) {
         if (d->hidden[l] < 1 || d->hidden[l] > 64 * POST_MAXJ) return fail(MORL_ERR_ARG, "hidden[%d] = %d", l, d->hidden[l]);
         q.dims[l + 1] = pol.dims[l + 1] = d->hidden[l];
     }
-    q.dims[q.L] = d->reward_dim;
+    q.dims[q.L] = sacd ? d->act_dim * d->reward_dim : d->reward_dim;
     pol.dims[pol.L] = heads * d->act_dim;
     q.ln = d->q_layer_norm != 0;
     q.drop = d->q_drop_rate;
@@ -458,6 +461,93 @@ static int check_state(const morl_ac_ctx* c, const morl_ac_state* st, int rows) 
     return MORL_OK;
 }
 
+// MOSAC with discrete actions (mosac_discrete_action.py:440-503): no action input to the critics, exact expectation over
+// the actions instead of sampling, one actor step (and one alpha step) per call.
+static int sacd_update(morl_ac_ctx* c, const morl_ac_state* st, const morl_ac_batch* bt, const morl_ac_cfg* cfg,
+                       const morl_ac_out* out, int PG, hipStream_t s) {
+    const morl_ac_desc& d = c->d;
+    const int rows = bt->rows, D = d.obs_dim, A = d.act_dim, R = d.reward_dim;
+    const Mlp &Q = c->q, &P = c->pol;
+    const bool autotune = cfg->autotune != 0;
+    const DropSpec nodrop;
+    int rc;
+    {
+        auto fill = [&](ConcatArgs& a, float* dst, int ld, const float* src) {
+            a.src[0] = src; a.width[0] = D; a.gstride[0] = (long long)rows * D; a.rstride[0] = D; a.n_src = 1;
+            a.dst = dst; a.ld = ld; a.dst_gstride = (long long)c->cap * ld; a.rows = rows; a.G = PG;
+        };
+        ConcatMulti m{};
+        m.n = 4;
+        fill(m.c[0], c->tp_a.x, P.ld[0], bt->next_obs);
+        fill(m.c[1], c->tq_a.x, Q.ld[0], bt->next_obs);
+        fill(m.c[2], c->tq_b.x, Q.ld[0], bt->obs);
+        fill(m.c[3], c->tp_b.x, P.ld[0], bt->obs);
+        hipLaunchKernelGGL(ac_concat_multi_kernel, dim3(stream_grid((long long)PG * rows * Q.ld[0], 256, 512), 4), dim3(256), 0, s, m);
+        LAUNCH_CHECK("sacd_inputs");
+    }
+    if ((rc = mlp_forward(P, st->pol, P.P, c->tp_a, rows, 1, nodrop, s))) return rc;
+    if ((rc = mlp_forward(Q, st->q_target, Q.P, c->tq_a, rows, 2, nodrop, s))) return rc;
+    if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, 2, nodrop, s))) return rc;
+    const long long q_gs = (long long)c->cap * Q.ld[Q.L], p_gs = (long long)c->cap * P.ld[P.L];
+    {
+        SacdCriticArgs a{};
+        a.logits_next = c->tp_a.out; a.p_gstride = p_gs; a.ldp = P.ld[P.L];
+        a.tq = c->tq_a.out; a.q = c->tq_b.out; a.dq = c->tq_b.g[Q.L - 1]; a.gstride = q_gs; a.ldo = Q.ld[Q.L];
+        a.actions = bt->actions; a.rewards = bt->rewards; a.dones = bt->dones; a.w = bt->w;
+        a.log_alpha = autotune ? st->log_alpha : nullptr; a.alpha_const = cfg->alpha;
+        a.target_out = out->target_q; a.loss_out = out->critic_loss; a.q_losses = out->q_losses;
+        a.rows = rows; a.A = A; a.R = R; a.gamma = cfg->gamma;
+        hipLaunchKernelGGL(sacd_critic_kernel, dim3(PG), dim3(256), 0, s, a);
+        LAUNCH_CHECK("sacd_critic");
+    }
+    if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_b, rows, 2, false, c->gq, false, s))) return rc;
+    if (out->q_grads)
+        HIP_TRY(hipMemcpyAsync(out->q_grads, c->gq, (size_t)c->QG * Q.P * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if ((rc = adam(st->q, c->gq, st->q_exp_avg, st->q_exp_avg_sq, 2ll * Q.P, PG, cfg->q_lr, st->q_steps,
+                   st->q_steps ? 1 : cfg->q_step, cfg, s))) return rc;
+    // actor (+ alpha) through the UPDATED critics
+    if ((rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
+    if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, 2, nodrop, s))) return rc;
+    {
+        SacdActorArgs a{};
+        a.logits = c->tp_b.out; a.dlogits = c->tp_b.g[P.L - 1]; a.p_gstride = p_gs; a.ldp = P.ld[P.L];
+        a.q = c->tq_b.out; a.gstride = q_gs; a.ldo = Q.ld[Q.L];
+        a.w = bt->w;
+        a.log_alpha = st->log_alpha; a.la_m = st->log_alpha_exp_avg; a.la_v = st->log_alpha_exp_avg_sq;
+        a.alpha_const = cfg->alpha; a.autotune = autotune ? 1 : 0; a.target_entropy = cfg->target_entropy;
+        a.steps = st->pol_steps; a.step_add = st->pol_steps ? 1 : cfg->policy_step;
+        a.alpha_lr = cfg->alpha_lr; a.b1 = cfg->beta1; a.b2 = cfg->beta2; a.eps = (float)cfg->eps;
+        a.loss_out = out->policy_loss; a.alpha_loss_out = out->alpha_loss;
+        a.rows = rows; a.A = A; a.R = R;
+        hipLaunchKernelGGL(sacd_actor_kernel, dim3(PG), dim3(256), 0, s, a);
+        LAUNCH_CHECK("sacd_actor");
+    }
+    if ((rc = mlp_backward(P, st->pol, P.P, c->tp_b, rows, 1, false, c->gp, false, s))) return rc;
+    if (out->pol_grads)
+        HIP_TRY(hipMemcpyAsync(out->pol_grads, c->gp, (size_t)PG * P.P * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if ((rc = adam(st->pol, c->gp, st->pol_exp_avg, st->pol_exp_avg_sq, P.P, PG, cfg->policy_lr, st->pol_steps,
+                   st->pol_steps ? 1 : cfg->policy_step, cfg, s))) return rc;
+    {
+        int32_t* qs = st->q_steps;
+        int32_t* ps = st->pol_steps;
+        if (cfg->do_target) {
+            const long long n = (long long)c->QG * Q.P;
+            hipLaunchKernelGGL(ac_polyak_advance_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const float*)st->q,
+                               st->q_target, n, cfg->tau, 1.0f - cfg->tau, qs, ps, PG, 1);
+            LAUNCH_CHECK("ac_polyak_advance");
+        } else if (qs || ps) {
+            hipLaunchKernelGGL(ac_step_advance_kernel, dim3((PG + 63) / 64), dim3(64), 0, s, qs, ps, PG, 1);
+            LAUNCH_CHECK("ac_step_advance");
+        }
+    }
+    if (out->alpha) {
+        hipLaunchKernelGGL(ac_alpha_prepare_kernel, dim3((PG + 63) / 64), dim3(64), 0, s, (const float*)st->log_alpha, cfg->alpha,
+                           autotune ? 1 : 0, out->alpha, PG);
+        LAUNCH_CHECK("ac_alpha_export");
+    }
+    return MORL_OK;
+}
+
 extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const morl_ac_batch* bt, const morl_ac_cfg* cfg,
                               const morl_ac_out* out_in, void* stream) {
     if (!bt || !cfg) return fail(MORL_ERR_ARG, "batch / cfg is NULL");
@@ -471,14 +561,15 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     if (!st->q_target || !st->q_exp_avg || !st->q_exp_avg_sq || !st->pol_exp_avg || !st->pol_exp_avg_sq)
         return fail(MORL_ERR_ARG, "state has NULL optimiser / target pointers");
     if (algo == MORL_AC_TD3 && !st->pol_target) return fail(MORL_ERR_ARG, "TD3 needs pol_target");
-    if (!bt->obs || !bt->actions || !bt->rewards || !bt->next_obs || !bt->dones || !bt->w || !bt->eps_next)
+    if (!bt->obs || !bt->actions || !bt->rewards || !bt->next_obs || !bt->dones || !bt->w ||
+        (!bt->eps_next && algo != MORL_AC_SACD))
         return fail(MORL_ERR_ARG, "batch has NULL arrays");
-    const bool autotune = algo == MORL_AC_MOSAC && cfg->autotune;
+    const bool autotune = (algo == MORL_AC_MOSAC || algo == MORL_AC_SACD) && cfg->autotune;
     if (autotune && (!st->log_alpha || !st->log_alpha_exp_avg || !st->log_alpha_exp_avg_sq))
         return fail(MORL_ERR_ARG, "autotune needs log_alpha and its Adam state");
     const int iters = (algo == MORL_AC_MOSAC) ? std::max(1, cfg->policy_iters) : 1;
-    if (cfg->do_policy && algo != MORL_AC_TD3 && !bt->eps_pi) return fail(MORL_ERR_ARG, "eps_pi is NULL");
-    if (cfg->do_policy && autotune && !bt->eps_alpha) return fail(MORL_ERR_ARG, "eps_alpha is NULL");
+    if (cfg->do_policy && algo != MORL_AC_TD3 && algo != MORL_AC_SACD && !bt->eps_pi) return fail(MORL_ERR_ARG, "eps_pi is NULL");
+    if (cfg->do_policy && autotune && algo == MORL_AC_MOSAC && !bt->eps_alpha) return fail(MORL_ERR_ARG, "eps_alpha is NULL");
     if (cfg->n_per < 0 || cfg->n_per > rows) return fail(MORL_ERR_ARG, "n_per %d outside 0..rows", cfg->n_per);
     const Mlp &Q = c->q, &P = c->pol;
     // learners advanced by this call (a leading sub-range of the context's capacity)
@@ -504,6 +595,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     const long long q_ldo = Q.ld[Q.L], q_gs = (long long)c->cap * q_ldo;
 
     const float* la = autotune ? st->log_alpha : nullptr;    // entropy coefficient source of every kernel below
+    if (algo == MORL_AC_SACD) return sacd_update(c, st, bt, cfg, out, PG, s);
 
     // ---- every network input of the update in one launch: policy at s' / s, critics at (s', .) / (s, a) -----------------------
     {
@@ -645,6 +737,16 @@ extern "C" int morl_ac_policy_forward(morl_ac_ctx* c, const morl_ac_state* st, c
     if ((rc = concat(c, c->tp_a.x, P.ld[0], c->PG, rows, obs, c->d.obs_dim, c->w_input ? w : nullptr,
                      c->w_input ? c->d.reward_dim : 0, nullptr, 0, s))) return rc;
     if ((rc = mlp_forward(P, use_target ? st->pol_target : st->pol, P.P, c->tp_a, rows, 1, DropSpec(), s))) return rc;
+    if (c->d.algo == MORL_AC_SACD) {   // discrete actor: hand back the logits [pop][rows][A]; sampling is the caller's
+        const int A = c->d.act_dim;
+        ConcatArgs a{};
+        a.src[0] = c->tp_a.out; a.width[0] = A; a.gstride[0] = (long long)c->cap * P.ld[P.L]; a.rstride[0] = P.ld[P.L];
+        a.n_src = 1;
+        a.dst = actions_out; a.ld = A; a.dst_gstride = (long long)rows * A; a.rows = rows; a.G = c->PG;
+        hipLaunchKernelGGL(ac_concat_kernel, dim3(stream_grid((long long)c->PG * rows * A, 256)), dim3(256), 0, s, a);
+        LAUNCH_CHECK("sacd_logits");
+        return MORL_OK;
+    }
     return head_forward(c, c->tp_a, rows, mode == 1 ? eps : nullptr, st, cfg, actions_out, logp_out, false, s);
 }
 
@@ -652,16 +754,17 @@ extern "C" int morl_ac_q_forward(morl_ac_ctx* c, const morl_ac_state* st, const 
                                  const float* w, int rows, int use_target, float* q_out, void* stream) {
     int rc = check_state(c, st, rows);
     if (rc) return rc;
-    if (!obs || !actions || !q_out) return fail(MORL_ERR_ARG, "obs / actions / q_out is NULL");
+    const bool sacd = c && c->d.algo == MORL_AC_SACD;
+    if (!obs || (!actions && !sacd) || !q_out) return fail(MORL_ERR_ARG, "obs / actions / q_out is NULL");
     if (c->w_input && !w) return fail(MORL_ERR_ARG, "this critic is weight-conditioned: w is NULL");
     if (use_target && !st->q_target) return fail(MORL_ERR_ARG, "q_target is NULL");
     hipStream_t s = (hipStream_t)stream;
     const Mlp& Q = c->q;
-    const int R = c->d.reward_dim;
+    const int R = Q.dims[Q.L];                   // values per row: R, or A * R for the discrete critics
     c->PG = c->d.population; c->QG = c->PG * c->d.num_q;
     c->tq_a.G = c->QG;
-    if ((rc = concat(c, c->tq_a.x, Q.ld[0], c->PG, rows, obs, c->d.obs_dim, actions, c->d.act_dim, c->w_input ? w : nullptr,
-                     c->w_input ? R : 0, s))) return rc;
+    if ((rc = concat(c, c->tq_a.x, Q.ld[0], c->PG, rows, obs, c->d.obs_dim, sacd ? nullptr : actions, sacd ? 0 : c->d.act_dim,
+                     c->w_input ? w : nullptr, c->w_input ? c->d.reward_dim : 0, s))) return rc;
     if ((rc = mlp_forward(Q, use_target ? st->q_target : st->q, Q.P, c->tq_a, rows, c->d.num_q, DropSpec(), s))) return rc;
     // compact [QG][cap][ld] -> [QG][rows][R]
     ConcatArgs a{};

@@ -28,9 +28,10 @@ from typing import Callable, List, Optional, Tuple, Union
 import numpy as np
 import torch as th
 
-from .ac_engine import ALGO_MOSAC, ACEngine
+from .ac_engine import ALGO_MOSAC, ALGO_SACD, ACEngine
 from .api import MOAgent
 from .mosac import MOSAC
+from .mosac_discrete import MOSACDiscrete
 from .native import NativeLib, load_library
 from .pareto import ParetoArchive
 
@@ -91,8 +92,8 @@ class MORLD(MOAgent):
         self.np_random = rng if rng is not None else np.random.default_rng(self.seed)
         if scalarization_method != "ws":
             raise NotImplementedError("only the weighted-sum scalarisation ('ws') runs on the HIP engine")
-        if policy_name != "MOSAC":
-            raise NotImplementedError("MOSAC is the sub-problem learner of the HIP engine")
+        if policy_name not in ("MOSAC", "MOSACDiscrete"):
+            raise NotImplementedError("MOSAC / MOSACDiscrete are the sub-problem learners of the HIP engine")
         self.scalarization_method, self.scalarization = scalarization_method, np.dot
         self.evaluation_mode, self.pop_size = evaluation_mode, pop_size
         self.weight_init_method, self.weight_adaptation_method = weight_init_method, weight_adaptation_method
@@ -120,16 +121,24 @@ class MORLD(MOAgent):
         a = self.policy_args
         arch = a.get("net_arch", [256, 256])
         self.batch_size = a.get("batch_size", 128)
-        D, Ad = int(np.prod(env.observation_space.shape)), int(np.prod(env.action_space.shape))
-        self.engine = ACEngine(ALGO_MOSAC, D, Ad, self.reward_dim, arch, action_low=np.asarray(env.action_space.low),
-                               action_high=np.asarray(env.action_space.high), max_rows=self.batch_size,
-                               population=pop_size, device=self.device, lib=self.lib, device_steps=True)
+        D = int(np.prod(env.observation_space.shape))
+        self.discrete = policy_name == "MOSACDiscrete"
+        if self.discrete:
+            self.engine = ACEngine(ALGO_SACD, D, int(env.action_space.n), self.reward_dim, arch, action_low=0.0,
+                                   action_high=1.0, max_rows=self.batch_size, population=pop_size, device=self.device,
+                                   lib=self.lib, device_steps=True)
+        else:
+            Ad = int(np.prod(env.action_space.shape))
+            self.engine = ACEngine(ALGO_MOSAC, D, Ad, self.reward_dim, arch, action_low=np.asarray(env.action_space.low),
+                                   action_high=np.asarray(env.action_space.high), max_rows=self.batch_size,
+                                   population=pop_size, device=self.device, lib=self.lib, device_steps=True)
+        learner = MOSACDiscrete if self.discrete else MOSAC
         self.current_policy = 0
         self.population = [
             Policy(id=i, weights=w,
-                   wrapped=MOSAC(id=i, env=self.env, weights=w, scalarization=th.matmul, gamma=gamma, log=self.log,
-                                 seed=self.seed, parent_rng=self.np_random, device=self.device, lib=self.lib,
-                                 engine=self.engine.member(i), **self.policy_args))
+                   wrapped=learner(id=i, env=self.env, weights=w, scalarization=th.matmul, gamma=gamma, log=self.log,
+                                   seed=self.seed, parent_rng=self.np_random, device=self.device, lib=self.lib,
+                                   engine=self.engine.member(i), **self.policy_args))
             for i, w in enumerate(self.weights)]
         self.archive = ParetoArchive()
         self._update_neighborhoods()
@@ -254,13 +263,17 @@ class MORLD(MOAgent):
                 n, B = len(run), ref.batch_size
                 stack = lambda k_: th.stack([batches[i][k_] for i in run])  # noqa: E731
                 cfg = ref.make_cfg()
-                eps = th.randn((1 + 2 * ref.policy_freq, n, B, e.Ad), dtype=th.float32, device=e.q.device)
                 w = th.stack([self.population[i].wrapped.weights_tensor for i in run])
-                e.update(cfg, obs=stack(0), actions=stack(1), rewards=stack(2), next_obs=stack(3), dones=stack(4), w=w,
-                         eps_next=eps[0], eps_pi=eps[1:1 + ref.policy_freq], eps_alpha=eps[1 + ref.policy_freq:],
-                         want=(), first=run[0], count=n)
+                if self.discrete:
+                    e.update(cfg, obs=stack(0), actions=stack(1), rewards=stack(2), next_obs=stack(3), dones=stack(4), w=w,
+                             want=(), first=run[0], count=n)
+                else:
+                    eps = th.randn((1 + 2 * ref.policy_freq, n, B, e.Ad), dtype=th.float32, device=e.q.device)
+                    e.update(cfg, obs=stack(0), actions=stack(1), rewards=stack(2), next_obs=stack(3), dones=stack(4), w=w,
+                             eps_next=eps[0], eps_pi=eps[1:1 + ref.policy_freq], eps_alpha=eps[1 + ref.policy_freq:],
+                             want=(), first=run[0], count=n)
                 for i in run:
-                    self.population[i].wrapped.note_update(bool(cfg.do_policy))
+                    self.population[i].wrapped.note_update(True if self.discrete else bool(cfg.do_policy))
 
     # -- checkpoints ---------------------------------------------------------------------------------------------------------
     def save(self, save_dir="weights/", filename=None, save_replay_buffer=True):

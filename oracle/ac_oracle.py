@@ -303,3 +303,60 @@ def gpipd_cont_update(qspec: MlpSpec, trunk: MlpSpec, q_nets: List[Params], tq_n
             polyak_update(pol, tpol, tau)
         out.update(policy_loss=policy_loss.detach(), p_grads=p_grads)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MOSAC with discrete actions (single_policy/ser/mosac_discrete_action.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def sacd_actor(pspec: MlpSpec, ap: Params, obs):
+    """``MOSACDiscreteActor.get_action`` (:98-106) without the sample: (log_prob, action_probs)."""
+    logits = mlp_forward(pspec, ap, obs)
+    return F.log_softmax(logits, dim=1), th.softmax(logits, dim=1)
+
+
+def mosac_discrete_update(qspec: MlpSpec, pspec: MlpSpec, qf: List[Params], qf_t: List[Params], actor: Params, log_alpha,
+                          q_state: Dict, a_state: Dict, al_state: Dict, batch, weights, *, n_actions, reward_dim, gamma,
+                          tau, q_lr, policy_lr, step, do_target, autotune, alpha, target_entropy, adam_eps=1e-4) -> Dict:
+    """``MOSACDiscrete.update`` (mosac_discrete_action.py:440-503).  qspec: mlp(D -> A*R), pspec: mlp(D -> A).  batch =
+    obs, actions (B,1), rewards, next_obs, dones (B,1).  Mutates networks / optimiser states / log_alpha in place."""
+    obs, act, rewards, next_obs, dones = batch
+    A, R = n_actions, reward_dim
+    qv = lambda p, x: mlp_forward(qspec, p, x).view(-1, A, R)  # noqa: E731
+    alpha_t = th.tensor(float(alpha))
+    with th.no_grad():
+        nlp, nprobs = sacd_actor(pspec, actor, next_obs)
+        q1n = th.matmul(qv(qf_t[0], next_obs), weights)
+        q2n = th.matmul(qv(qf_t[1], next_obs), weights)
+        mn = (nprobs * (th.min(q1n, q2n) - alpha_t * nlp)).sum(dim=1)
+        next_q = th.matmul(rewards, weights).flatten() + (1 - dones.flatten()) * gamma * mn
+    qs = [clone(q, True) for q in qf]
+    q1a = th.matmul(qv(qs[0], obs), weights).gather(1, act.long()).view(-1)
+    q2a = th.matmul(qv(qs[1], obs), weights).gather(1, act.long()).view(-1)
+    qf1_loss, qf2_loss = F.mse_loss(q1a, next_q), F.mse_loss(q2a, next_q)
+    q_grads = list(th.autograd.grad(qf1_loss + qf2_loss, qs[0] + qs[1]))
+    with th.no_grad():
+        adam_step(qf[0] + qf[1], q_grads, q_state["exp_avg"], q_state["exp_avg_sq"], step, q_lr, eps=adam_eps)
+    ap = clone(actor, True)
+    log_pi, probs = sacd_actor(pspec, ap, obs)
+    with th.no_grad():
+        min_q = th.min(th.matmul(qv(qf[0], obs), weights), th.matmul(qv(qf[1], obs), weights))
+    actor_loss = (probs * ((float(alpha) * log_pi) - min_q)).mean()
+    a_grads = list(th.autograd.grad(actor_loss, ap))
+    with th.no_grad():
+        adam_step(actor, a_grads, a_state["exp_avg"], a_state["exp_avg_sq"], step, policy_lr, eps=adam_eps)
+    out = dict(qf1_loss=qf1_loss.detach(), qf2_loss=qf2_loss.detach(), q_grads=q_grads, next_q=next_q,
+               actor_loss=actor_loss.detach(), a_grads=a_grads)
+    if autotune:
+        la = log_alpha.detach().clone().requires_grad_(True)
+        alpha_loss = (probs.detach() * (-la.exp() * (log_pi + target_entropy).detach())).mean()
+        g = th.autograd.grad(alpha_loss, la)[0]
+        with th.no_grad():
+            adam_step([log_alpha], [g], al_state["exp_avg"], al_state["exp_avg_sq"], step, q_lr, eps=adam_eps)
+        out["alpha_loss"] = alpha_loss.detach()
+        alpha_t = log_alpha.detach().exp().reshape(())
+    if do_target:
+        with th.no_grad():
+            polyak_update(qf[0], qf_t[0], tau)
+            polyak_update(qf[1], qf_t[1], tau)
+    out["alpha"] = float(alpha_t)
+    return out

@@ -157,5 +157,6 @@ def import_reference_ac():
     from morl_baselines.multi_policy.capql import capql
     from morl_baselines.multi_policy.gpi_pd import gpi_pd_continuous_action as gpipd_cont
     from morl_baselines.single_policy.ser import mosac_continuous_action as mosac
+    from morl_baselines.single_policy.ser import mosac_discrete_action as sacd
 
-    return types.SimpleNamespace(capql=capql, mosac=mosac, gpipd_cont=gpipd_cont)
+    return types.SimpleNamespace(capql=capql, mosac=mosac, gpipd_cont=gpipd_cont, sacd=sacd)

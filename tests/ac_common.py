@@ -56,6 +56,17 @@ def run_oracle(c: ACCase, inp=None):
                               a_step=c.step, policy_freq=c.policy_freq,
                               do_policy=(c.global_step % c.policy_freq == 0), do_target=True, autotune=c.autotune,
                               alpha=alpha, target_entropy=-float(c.Ad))
+    elif c.algo == "sacd":
+        st["log_alpha"] = th.tensor([c.log_alpha0])
+        st["al_state"] = {k: ac.clone(v) for k, v in inp["al_state"].items()}
+        batch = tuple(T(inp[k]) for k in ("obs", "actions", "rewards", "next_obs", "dones"))
+        alpha = th.tensor([c.log_alpha0]).exp().item() if c.autotune else c.alpha
+        te = float(-0.89 * th.log(1 / th.tensor(c.Ad))) if c.autotune else 0.0
+        pspec = ac.MlpSpec(c.D, c.arch, c.Ad)
+        out = ac.mosac_discrete_update(qspec, pspec, st["q"], st["tq"], st["pol"], st["log_alpha"], st["q_state"],
+                                       st["p_state"], st["al_state"], batch, T(inp["weights"]), n_actions=c.Ad,
+                                       reward_dim=c.R, gamma=c.gamma, tau=c.tau, q_lr=c.q_lr, policy_lr=c.lr,
+                                       step=c.step, do_target=True, autotune=c.autotune, alpha=alpha, target_entropy=te)
     else:
         st["tpol"] = ac.clone(inp["tpol"])
         batch, w = gpipd_rows(c, inp)
@@ -95,7 +106,7 @@ def check_against_golden(c: ACCase, st, g, *, q_opt=None, p_opt=None, rtol=2e-5,
     nq = len(st["q"][0])
     # a first Adam step moves every entry by ~lr * g / (|g| + eps): entries whose gradient is ~eps-sized amplify
     # 1e-9 absolute gradient differences into a fraction of lr, hence the lr-relative absolute term
-    q_lr = c.q_lr if c.algo == "mosac" else c.lr
+    q_lr = c.q_lr if c.algo in ("mosac", "sacd") else c.lr
     pa_q, pa_p = lr_frac * q_lr, lr_frac * c.lr
 
     def tol(key, lr, base):

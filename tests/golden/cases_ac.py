@@ -56,6 +56,11 @@ AC_CASES = [
            low=-0.5, high=2.0, seed=12),
     ACCase("mosac_hopper", "mosac", D=11, Ad=3, R=3, arch=(256, 256), B=128, step=3, seed=13, subsample=7,
            log_alpha0=-0.7),
+    ACCase("sacd_small", "sacd", D=9, Ad=4, R=2, arch=(32, 32), B=24, seed=31, tau=1.0, q_lr=3e-4),
+    ACCase("sacd_step3_noauto", "sacd", D=6, Ad=3, R=3, arch=(24, 32), B=16, step=3, autotune=False, seed=32, tau=0.3,
+           q_lr=1e-3, log_alpha0=0.0),
+    ACCase("sacd_minecart", "sacd", D=7, Ad=6, R=3, arch=(256, 256), B=128, step=2, seed=33, tau=1.0, q_lr=3e-4,
+           subsample=7, log_alpha0=-0.4),
     ACCase("gpipd_small", "gpipd", D=11, Ad=3, R=2, arch=(64, 64), B=32, seed=21),
     ACCase("gpipd_support_per", "gpipd", D=7, Ad=2, R=3, arch=(48, 32), B=16, step=3, n_support=3, per=True, seed=22,
            low=-2.0, high=1.0),
@@ -72,12 +77,14 @@ def specs(c: ACCase):
         return (ac.MlpSpec(c.D + c.Ad + c.R, c.arch, c.R), ac.MlpSpec(c.D + c.R, c.arch))
     if c.algo == "mosac":
         return (ac.MlpSpec(c.D + c.Ad, c.arch, c.R), ac.MlpSpec(c.D, c.arch))
+    if c.algo == "sacd":                      # Ad = number of discrete actions; the "trunk" + one head of A logits
+        return (ac.MlpSpec(c.D, c.arch, c.Ad * c.R), ac.MlpSpec(c.D, c.arch))
     return (ac.MlpSpec(c.D + c.Ad + c.R, c.arch, c.R, layer_norm=c.layer_norm, drop_rate=c.drop_rate),
             ac.MlpSpec(c.D + c.R, c.arch))
 
 
 def n_heads(c: ACCase) -> int:
-    return 1 if c.algo == "gpipd" else 2
+    return 1 if c.algo in ("gpipd", "sacd") else 2
 
 
 def _perturbed(ps, rng, scale=0.05):
@@ -124,7 +131,8 @@ def make_inputs(c: ACCase) -> dict:
     inp["p_state"] = opt_state(pol)
     nrows = c.B * (2 if (c.algo == "gpipd" and c.n_support > 1) else 1)
     inp["obs"] = f32(rng.standard_normal((c.B, c.D)))
-    inp["actions"] = f32(rng.uniform(c.low, c.high, (c.B, c.Ad)))
+    inp["actions"] = (f32(rng.integers(0, c.Ad, (c.B, 1))) if c.algo == "sacd" else
+                      f32(rng.uniform(c.low, c.high, (c.B, c.Ad))))
     inp["rewards"] = f32(rng.standard_normal((c.B, c.R)))
     inp["next_obs"] = f32(rng.standard_normal((c.B, c.D)))
     inp["dones"] = f32(rng.random((c.B, 1)) < 0.1)
@@ -133,7 +141,7 @@ def make_inputs(c: ACCase) -> dict:
     inp["eps_next"] = f32(rng.standard_normal((nrows, c.Ad)))
     inp["eps_pi"] = [f32(rng.standard_normal((c.B, c.Ad))) for _ in range(max(1, c.policy_freq))]
     inp["eps_alpha"] = [f32(rng.standard_normal((c.B, c.Ad))) for _ in range(max(1, c.policy_freq))]
-    if c.algo == "mosac":
+    if c.algo in ("mosac", "sacd"):
         wv = np.abs(rng.standard_normal(c.R))
         inp["weights"] = f32(wv / wv.sum())
         inp["al_state"] = (dict(exp_avg=[th.zeros(1)], exp_avg_sq=[th.zeros(1)]) if c.step <= 1 else

@@ -182,6 +182,42 @@ def run_mosac(ref, c: ACCase) -> dict:
     return out
 
 
+def run_sacd(ref, c: ACCase) -> dict:
+    inp = make_inputs(c)
+    env = rh.FakeEnv(c.D, c.Ad, c.R, env_id="fake-minecart-v0")
+    ag = ref.sacd.MOSACDiscrete(env, weights=inp["weights"].copy(), gamma=c.gamma, tau=c.tau, batch_size=c.B,
+                                net_arch=list(c.arch), policy_lr=c.lr, q_lr=c.q_lr, alpha=c.alpha, autotune=c.autotune,
+                                target_net_freq=4, update_frequency=4, log=False, seed=0, device="cpu", buffer_size=64)
+    _load(ag.qf1, inp["q"][0]); _load(ag.qf2, inp["q"][1])
+    _load(ag.qf1_target, inp["tq"][0]); _load(ag.qf2_target, inp["tq"][1])
+    _load(ag.actor, inp["pol"])
+    _seed_opt(ag.q_optimizer, list(ag.qf1.parameters()) + list(ag.qf2.parameters()), inp["q_state"], c.step)
+    _seed_opt(ag.actor_optimizer, list(ag.actor.parameters()), inp["p_state"], c.step)
+    if c.autotune:
+        with th.no_grad():
+            ag.log_alpha.fill_(c.log_alpha0)
+        ag.alpha = ag.log_alpha.exp().item()
+        ag.alpha_tensor = th.scalar_tensor(ag.alpha)
+        _seed_opt(ag.a_optimizer, [ag.log_alpha], inp["al_state"], c.step)
+    batch = tuple(_t(inp[k]) for k in ("obs", "actions", "rewards", "next_obs", "dones")) + (None,)
+    ag.buffer.sample = lambda *a, **k: batch
+    ag.global_step, ag.log = 100, True          # % target_net_freq == 0 -> polyak; % 100 == 0 -> losses are logged
+    with Pins() as pins:
+        ag.update()
+    out = dict(alpha=np.float64(ag.alpha), target_entropy=np.float64(float(ag.target_entropy)) if c.autotune else np.float64(0))
+    for k, v in pins.logged.items():
+        if k.startswith("losses/"):
+            out[k.split("/")[1]] = np.float64(v)
+    _dump(out, "q0", list(ag.qf1.parameters()), ag.q_optimizer, c.subsample)
+    _dump(out, "q1", list(ag.qf2.parameters()), ag.q_optimizer, c.subsample)
+    _dump(out, "tq0", list(ag.qf1_target.parameters()), None, c.subsample)
+    _dump(out, "tq1", list(ag.qf2_target.parameters()), None, c.subsample)
+    _dump(out, "pol", list(ag.actor.parameters()), ag.actor_optimizer, c.subsample)
+    if c.autotune:
+        out["log_alpha"] = ag.log_alpha.detach().numpy().copy()
+    return out
+
+
 def run_gpipd(ref, c: ACCase) -> dict:
     inp = make_inputs(c)
     qspec, _ = specs(c)
@@ -240,7 +276,7 @@ def run_gpipd(ref, c: ACCase) -> dict:
 def main():
     ref = rh.import_reference_ac()
     th.set_num_threads(1)
-    runners = dict(capql=run_capql, mosac=run_mosac, gpipd=run_gpipd)
+    runners = dict(capql=run_capql, mosac=run_mosac, gpipd=run_gpipd, sacd=run_sacd)
     only = [a for a in sys.argv[1:] if not a.startswith("-")]
     for c in AC_CASES:
         if only and c.name not in only and c.algo not in only:

@@ -101,6 +101,18 @@ def main():
     out["gpi_actions"] = np.asarray(env.action_log, dtype=np.int8)
     out["gpi_tree_root"] = np.float64(ag.replay_buffer.tree.nodes[0][0])
 
+    # ---- MOSAC with discrete actions -------------------------------------------------------------------------------------------
+    tc.reseed(tc.SEED)
+    env = momdp.TreasureLine(tc.SEED)
+    ag = ref.sacd.MOSACDiscrete(env, weights=tc.SACD_WEIGHTS.copy(), log=False, seed=tc.SEED, device="cpu", **tc.SACD)
+    nets = [ag.actor, ag.qf1, ag.qf2, ag.qf1_target, ag.qf2_target]
+    dump(out, "sacd_init", params_of(nets))
+    tc.reseed()
+    ag.train(total_timesteps=tc.SACD_STEPS)
+    dump(out, "sacd_final", params_of(nets))
+    out["sacd_actions"] = np.asarray(env.action_log, dtype=np.int8)
+    out["sacd_log_alpha"] = ag.log_alpha.detach().numpy().copy()
+
     # ---- Envelope (epsilon / homotopy schedules, PER, periodic target copy) --------------------------------------------------
     refe = rh.import_reference()
     refe.envelope.equally_spaced_weights = noop
@@ -117,7 +129,7 @@ def main():
     out["env_eps_lambda"] = np.array([ag.epsilon, ag.homotopy_lambda])
 
     np.savez_compressed(os.path.join(HERE, "train_traces_ac.npz"), **out)
-    for k in ("capql_actions", "mosac_actions", "gpic_actions", "gpi_actions", "env_actions"):
+    for k in ("capql_actions", "mosac_actions", "gpic_actions", "gpi_actions", "sacd_actions", "env_actions"):
         print(k, out[k].shape, np.asarray(out[k]).reshape(len(out[k]), -1)[-3:].tolist())
 
 

@@ -16,6 +16,10 @@ ENVELOPE = dict(net_arch=[16, 16], batch_size=8, num_sample_w=4, learning_starts
                 initial_epsilon=0.5, final_epsilon=0.1, epsilon_decay_steps=40, target_net_update_freq=9, gamma=0.95,
                 initial_homotopy_lambda=0.2, final_homotopy_lambda=0.8, homotopy_decay_steps=40)
 ENVELOPE_STEPS = 60
+SACD = dict(net_arch=[16, 16], batch_size=8, learning_starts=14, buffer_size=500, update_frequency=2, target_net_freq=6,
+            tau=0.5)
+SACD_WEIGHTS = np.array([0.6, 0.4], dtype=np.float32)
+SACD_STEPS = 60
 SUPPORT = [np.array([1.0, 0.0], dtype=np.float32), np.array([0.0, 1.0], dtype=np.float32),
            np.array([0.5, 0.5], dtype=np.float32)]
 WEIGHT = np.array([0.4, 0.6], dtype=np.float32)

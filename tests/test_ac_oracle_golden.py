@@ -24,6 +24,12 @@ def test_oracle_reproduces_reference_update(c):
         assert rel(out["alpha"], g["alpha"])
         if "log_alpha" in g:
             np.testing.assert_allclose(st["log_alpha"].numpy(), g["log_alpha"], rtol=1e-5, atol=1e-7)
+    elif c.algo == "sacd":
+        assert rel(out["qf1_loss"], g["qf1_loss"]) and rel(out["qf2_loss"], g["qf2_loss"])
+        assert rel(out["actor_loss"], g["actor_loss"]) and rel(out["alpha"], g["alpha"])
+        if c.autotune:
+            assert rel(out["alpha_loss"], g["alpha_loss"])
+            np.testing.assert_allclose(st["log_alpha"].numpy(), g["log_alpha"], rtol=1e-5, atol=1e-7)
     else:
         if "critic_loss" in g:
             assert rel(out["critic_loss"], g["critic_loss"]) and rel(out["policy_loss"], g["policy_loss"])

@@ -119,3 +119,18 @@ def test_envelope_trace(sim):
     assert float(ag.replay_buffer.tree.nodes[0][0]) == pytest.approx(float(g["env_tree_root"]), rel=1e-4)
     np.testing.assert_allclose([ag.epsilon, ag.homotopy_lambda], g["env_eps_lambda"], rtol=1e-12)
     print(f"\nEnvelope: {tc.ENVELOPE_STEPS} steps / {ag._adam_step} updates, max parameter deviation {worst:.2e}")
+
+
+def test_mosac_discrete_trace(sim):
+    from morl_baselines_amd.mosac_discrete import MOSACDiscrete
+    g = np.load(GOLD)
+    tc.reseed(tc.SEED)
+    env = momdp.TreasureLine(tc.SEED)
+    ag = MOSACDiscrete(env, tc.SACD_WEIGHTS.copy(), log=False, seed=tc.SEED, device="cpu", lib=sim, **tc.SACD)
+    params = load_init(g, "sacd_init", [ag.actor, ag.qf1, ag.qf2, ag.qf1_target, ag.qf2_target])
+    tc.reseed()
+    ag.train(total_timesteps=tc.SACD_STEPS)
+    assert np.array_equal(np.asarray(env.action_log, dtype=np.int8), g["sacd_actions"])
+    worst = check_final(g, "sacd_final", params, atol=1e-4)
+    np.testing.assert_allclose(ag.log_alpha.numpy(), g["sacd_log_alpha"], rtol=0, atol=2e-5)
+    print(f"\nMOSAC discrete: {tc.SACD_STEPS} steps / {ag._q_step} updates, max parameter deviation {worst:.2e}")
