@@ -3,6 +3,9 @@ continuous) on one MI355X.  bench.py stays the north-star (Envelope) line the dr
 widened rows with the same conventions:
 
     python bench_ac.py --workload capql|mosac|morld|gpipd|gpi [--pop 64] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench_ac.py --workload morld --gpus N --pop 64      # the population's learners are independent units: pop / N per
+                                                                # GPU, no data-path collective ("replicas only", weak scaling)
 
 One "step" = one gradient update of every learner in the job (``update()`` body of the reference agent; for ``morld``
 one pass of ``MORLD.__update_others`` over ``pop`` sub-problem learners, morld.py:423-433), on synthetic transitions
@@ -232,11 +235,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-mode", type=int, default=0, help="0 auto, 1 LDS tiles, 2 wave tiles (morl_ac_set_gemm_mode)")
+    ap.add_argument("--gpus", type=int, default=1)
     a = ap.parse_args()
     if not th.cuda.is_available():
         raise SystemExit("bench_ac.py needs an MI355X (no CPU fallback exists)")
-    dev = th.device("cuda", 0)
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus}")
+    dev = th.device("cuda", local_rank)
     th.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.workload != "morld":
+            raise SystemExit("only the MORL/D population shards over GPUs (independent learners, no collective)")
     if a.workload == "gpi":
         return bench_gpi(a)
     from morl_baselines_amd.ac_engine import ALGO_CAPQL, ALGO_MOSAC, ALGO_TD3, ACEngine
@@ -244,6 +258,11 @@ def main():
     wl, shp = a.workload, SHAPES[a.workload]
     D, Ad, R = shp["D"], shp["Ad"], shp["R"]
     pop = a.pop if a.pop is not None else (64 if wl == "morld" else 1)
+    pop_total = pop
+    if world > 1:
+        if pop % world:
+            raise SystemExit(f"--pop {pop} must be divisible by the number of GPUs")
+        pop = pop // world                       # this rank's learners
     algo = {"capql": ALGO_CAPQL, "mosac": ALGO_MOSAC, "morld": ALGO_MOSAC, "gpipd": ALGO_TD3}[wl]
     rows = 2 * B if wl == "gpipd" else B
     eng = ACEngine(algo, D, Ad, R, ARCH, action_low=-1.0, action_high=1.0, max_rows=rows, population=pop, device=dev,
@@ -281,21 +300,35 @@ def main():
     for _ in range(a.warmup):
         step()
     th.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     th.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     wall = time.perf_counter() - t0
+    if dist is not None:
+        t = th.tensor([wall], device=dev, dtype=th.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        pop = pop_total
+        if rank != 0:
+            dist.destroy_process_group()
+            return
     ms = wall * 1e3 / a.steps
     flop = update_flop(wl, D, Ad, R, rows, iters) * pop
     tf = flop / (ms * 1e-3) / 1e12
     out = {
         "metric": "actor-critic learner updates/sec", "value": pop * a.steps / wall, "unit": "learner-updates/s",
-        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{wl}: {pop} learner(s) x batch {B} ({rows} rows), net {ARCH}, twin critics, shapes of "
                                f"{shp['env']} (obs {D}, act {Ad}, {R} objectives); one morl_ac_update per step",
-                   "population": pop, "rows": rows},
+                   "population": pop, "rows": rows,
+                   "parallelism": "single GPU" if world == 1 else f"population split over {world} GPUs ({pop // world} "
+                                  "learners each), independent replicas, no data-path collective"},
         "roofline": {"bound": "mfma", "kernel": "gemm_batched (exact-fp32 MFMA layers of all nets / learners)",
                      "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
                      "traffic": None,
@@ -303,10 +336,12 @@ def main():
                              "a lower bound of the kernels' own rate; per-kernel durations in profiles/"},
         "algorithmic_flop_per_step": flop,
     }
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(wl, shp, pop)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
