@@ -410,6 +410,51 @@ int morl_gpi_priorities(morl_gpi_ctx* ctx, const float* q, const float* q_target
                         int rows, const float* w, const float* support, int M, int gpi_pd, float gamma,
                         float* gtd_out, void* stream);
 
+/* ================================================================================================
+ * Probabilistic dynamics ensemble of the Dyna part of GPI-PD: common/model_based/probabilistic_ensemble.py
+ *   forward (:88-129)            h = (x - mu) / sigma; [EnsembleLayer, ReLU] * len(arch); EnsembleLayer -> (mean, logvar)
+ *                                logvar = max_logvar - softplus(max_logvar - logvar); = min_logvar + softplus(. - min_logvar)
+ *   _compute_loss (:156-169)     mean of F.gaussian_nll_loss(mean, y, exp(logvar)) + 0.01 * (sum max_logvar - sum min_logvar)
+ *   fit's optimiser step (:206-212, :248-252)  Adam(lr) with per-layer L2 weight decay, max / min_logvar without
+ *   _compute_mse_losses (:171-176)
+ * Parameters of ONE member in the flat buffer (E members contiguous, [E][Pm]): for every layer W [out][in]
+ * (= the reference's W[e] transposed: EnsembleLayer stores [in][out]) then b [out].  max_logvar / min_logvar [out_dim]
+ * are shared by the members and live in their own small arrays (with their own Adam moments).
+ * ================================================================================================ */
+typedef struct morl_ens_ctx morl_ens_ctx;
+
+typedef struct morl_ens_desc {
+    int32_t input_dim, output_dim;      /* model output is 2 * output_dim (mean | logvar) */
+    int32_t n_hidden;
+    int32_t hidden[MORL_MAX_LAYERS];
+    int32_t ensemble_size;
+    int32_t max_rows;                   /* rows per member of one call */
+} morl_ens_desc;
+
+typedef struct morl_ens_cfg {
+    double lr, beta1, beta2, eps;
+    int32_t adam_step;                  /* 1-based */
+    float weight_decay[MORL_MAX_LAYERS];/* L2 coefficient of layer l (W and b), probabilistic_ensemble.py:206 */
+} morl_ens_cfg;
+
+int64_t morl_ens_param_count(const morl_ens_desc* d);
+int morl_ens_create(morl_ens_ctx** out, const morl_ens_desc* d);
+int morl_ens_destroy(morl_ens_ctx* ctx);
+/* One optimiser step of fit().  x [E][rows][in], y [E][rows][out] (the members' bootstrap batches); mu / sigma [in]
+ * (NULL: no input normalisation); logvar_bounds [2][out] = max_logvar | min_logvar with moments lv_m / lv_v [2][out];
+ * loss_out: device scalar (the value _compute_loss returns) or NULL. */
+int morl_ens_train_step(morl_ens_ctx* ctx, float* params, float* exp_avg, float* exp_avg_sq, float* logvar_bounds,
+                        float* lv_m, float* lv_v, const float* mu, const float* sigma, const float* x, const float* y,
+                        int rows, const morl_ens_cfg* cfg, float* loss_out, void* stream);
+/* Forward of every member.  x: [rows][in] shared by the members (x_per_member = 0) or [E][rows][in].
+ * mean_out / logvar_out [E][rows][out] (logvar already bounded; logvar_out may be NULL). */
+int morl_ens_forward(morl_ens_ctx* ctx, const float* params, const float* logvar_bounds, const float* mu,
+                     const float* sigma, const float* x, int x_per_member, int rows, float* mean_out, float* logvar_out,
+                     void* stream);
+/* Per-member holdout MSE (_compute_mse_losses): x [rows][in] shared, y [rows][out]; mse_out [E]. */
+int morl_ens_mse(morl_ens_ctx* ctx, const float* params, const float* logvar_bounds, const float* mu, const float* sigma,
+                 const float* x, const float* y, int rows, float* mse_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1151,3 +1151,162 @@ extern "C" int morl_gpi_priorities(morl_gpi_ctx* c, const float* q, const float*
     LAUNCH_CHECK("gpi_gtd");
     return MORL_OK;
 }
+
+// =====================================================================================================================
+// Probabilistic dynamics ensemble (include/morl_hip.h, "Probabilistic dynamics ensemble of the Dyna part of GPI-PD")
+// =====================================================================================================================
+#include "ens_kernels.h"
+
+struct morl_ens_ctx {
+    morl_ens_desc d{};
+    Mlp net;                   // dims [in, hidden..., 2 * out]; members are the batch axis of every launch
+    int E = 0, cap = 0;
+    Tape t;
+    float* grads = nullptr;    // [E][Pm]
+    double* part = nullptr;    // [n_blocks][1 + 2 * out]
+    int max_blocks = 0;
+    std::vector<void*> allocs;
+};
+
+static int ens_fill(const morl_ens_desc* d, morl_ens_ctx& c) {
+    if (!d) return fail(MORL_ERR_ARG, "desc is NULL");
+    if (d->n_hidden < 1 || d->n_hidden > MORL_MAX_LAYERS - 1) return fail(MORL_ERR_ARG, "n_hidden %d out of range", d->n_hidden);
+    if (d->input_dim < 1 || d->output_dim < 1 || d->output_dim > ENS_MAX_OUT) return fail(MORL_ERR_ARG, "bad dims in=%d out=%d", d->input_dim, d->output_dim);
+    if (d->ensemble_size < 1 || d->ensemble_size > 64) return fail(MORL_ERR_ARG, "ensemble_size %d", d->ensemble_size);
+    c.d = *d;
+    c.E = d->ensemble_size;
+    c.net = Mlp();
+    c.net.L = d->n_hidden + 1;
+    c.net.dims[0] = d->input_dim;
+    for (int l = 0; l < d->n_hidden; ++l) {
+        if (d->hidden[l] < 1) return fail(MORL_ERR_ARG, "hidden[%d] = %d", l, d->hidden[l]);
+        c.net.dims[l + 1] = d->hidden[l];
+    }
+    c.net.dims[c.net.L] = 2 * d->output_dim;
+    c.net.finish();
+    return MORL_OK;
+}
+
+extern "C" int64_t morl_ens_param_count(const morl_ens_desc* d) {
+    morl_ens_ctx c;
+    return ens_fill(d, c) ? -1 : c.net.P;
+}
+
+extern "C" int morl_ens_destroy(morl_ens_ctx* c) {
+    if (!c) return MORL_OK;
+    for (void* p : c->allocs) (void)hipFree(p);
+    delete c;
+    return MORL_OK;
+}
+
+extern "C" int morl_ens_create(morl_ens_ctx** out, const morl_ens_desc* d) {
+    if (!out) return fail(MORL_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    morl_ens_ctx* c = new (std::nothrow) morl_ens_ctx();
+    if (!c) return fail(MORL_ERR_ALLOC, "out of host memory");
+    int rc = ens_fill(d, *c);
+    if (rc) { delete c; return rc; }
+    if (d->max_rows < 1) { delete c; return fail(MORL_ERR_ARG, "max_rows %d", d->max_rows); }
+    c->cap = d->max_rows;
+    c->max_blocks = (int)(((long long)c->E * c->cap + 3) / 4);
+    float* part = nullptr;
+    if ((rc = alloc_tape(c->allocs, c->net, c->t, c->E, c->E, c->cap, false)) ||
+        (rc = alloc_f(c->allocs, &c->grads, (size_t)c->E * c->net.P)) ||
+        (rc = alloc_f(c->allocs, &part, (size_t)c->max_blocks * (1 + 2 * d->output_dim) * 2))) {
+        morl_ens_destroy(c);
+        return rc;
+    }
+    c->part = reinterpret_cast<double*>(part);
+    if (hipDeviceSynchronize() != hipSuccess) { morl_ens_destroy(c); return fail(MORL_ERR_HIP, "workspace init failed"); }
+    *out = c;
+    return MORL_OK;
+}
+
+static int ens_forward_core(morl_ens_ctx* c, const float* params, const float* mu, const float* sigma, const float* x,
+                            int x_per_member, int rows, hipStream_t s) {
+    if (rows < 1 || rows > c->cap) return fail(MORL_ERR_STATE, "rows %d outside 1..max_rows %d", rows, c->cap);
+    if ((mu == nullptr) != (sigma == nullptr)) return fail(MORL_ERR_ARG, "mu and sigma go together");
+    c->t.G = c->E;
+    EnsNormArgs a{};
+    a.x = x; a.x_gstride = x_per_member ? (long long)rows * c->d.input_dim : 0;
+    a.mu = mu; a.sigma = sigma;
+    a.dst = c->t.x; a.dst_gstride = (long long)c->cap * c->net.ld[0];
+    a.in_dim = c->d.input_dim; a.ld = c->net.ld[0]; a.rows = rows; a.E = c->E;
+    hipLaunchKernelGGL(ens_norm_kernel, dim3(stream_grid((long long)c->E * rows * c->net.ld[0], 256)), dim3(256), 0, s, a);
+    LAUNCH_CHECK("ens_norm");
+    return mlp_forward(c->net, params, c->net.P, c->t, rows, 1, DropSpec(), s);
+}
+
+extern "C" int morl_ens_train_step(morl_ens_ctx* c, float* params, float* exp_avg, float* exp_avg_sq, float* logvar_bounds,
+                                   float* lv_m, float* lv_v, const float* mu, const float* sigma, const float* x,
+                                   const float* y, int rows, const morl_ens_cfg* cfg, float* loss_out, void* stream) {
+    if (!c || !params || !exp_avg || !exp_avg_sq || !logvar_bounds || !lv_m || !lv_v || !x || !y || !cfg)
+        return fail(MORL_ERR_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ens_forward_core(c, params, mu, sigma, x, 1, rows, s);
+    if (rc) return rc;
+    const Mlp& m = c->net;
+    const int O = c->d.output_dim;
+    const int n_blocks = (int)(((long long)c->E * rows + 3) / 4);
+    const float inv_count = 1.0f / ((float)c->E * (float)rows * (float)O);
+    {
+        EnsNllArgs a{};
+        a.head = c->t.out; a.dhead = c->t.g[m.L - 1]; a.gstride = (long long)c->cap * m.ld[m.L]; a.ld = m.ld[m.L];
+        a.y = y; a.bounds = logvar_bounds; a.part = c->part;
+        a.rows = rows; a.O = O; a.E = c->E; a.inv_count = inv_count;
+        hipLaunchKernelGGL(ens_nll_kernel, dim3(n_blocks), dim3(256), 0, s, a);
+        LAUNCH_CHECK("ens_nll");
+    }
+    if ((rc = mlp_backward(m, params, m.P, c->t, rows, 1, false, c->grads, false, s))) return rc;
+    const double b1 = cfg->beta1, b2 = cfg->beta2;
+    const int t = std::max(1, cfg->adam_step);
+    const float neg_step = (float)(-(cfg->lr / (1.0 - std::pow(b1, (double)t))));
+    const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow(b2, (double)t));
+    {
+        EnsAdamArgs a{};
+        a.params = params; a.grads = c->grads; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq;
+        a.Pm = m.P; a.n_layers = m.L; a.total = (long long)c->E * m.P;
+        for (int l = 0; l < m.L; ++l) {
+            a.layer_end[l] = m.offB[l] + m.dims[l + 1];
+            a.wd[l] = cfg->weight_decay[l];
+        }
+        a.neg_step_size = neg_step; a.bc2_sqrt = bc2_sqrt;
+        a.one_minus_b1 = (float)(1.0 - b1); a.b2 = (float)b2; a.one_minus_b2 = (float)(1.0 - b2); a.eps = (float)cfg->eps;
+        hipLaunchKernelGGL(ens_adam_kernel, dim3(stream_grid(a.total, 256)), dim3(256), 0, s, a);
+        LAUNCH_CHECK("ens_adam");
+    }
+    hipLaunchKernelGGL(ens_bounds_step_kernel, dim3(1), dim3(256), 0, s, (const double*)c->part, n_blocks, O, inv_count,
+                       logvar_bounds, lv_m, lv_v, neg_step, bc2_sqrt, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2),
+                       (float)cfg->eps, loss_out);
+    LAUNCH_CHECK("ens_bounds_step");
+    return MORL_OK;
+}
+
+extern "C" int morl_ens_forward(morl_ens_ctx* c, const float* params, const float* logvar_bounds, const float* mu,
+                                const float* sigma, const float* x, int x_per_member, int rows, float* mean_out,
+                                float* logvar_out, void* stream) {
+    if (!c || !params || !x || !mean_out || (logvar_out && !logvar_bounds)) return fail(MORL_ERR_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ens_forward_core(c, params, mu, sigma, x, x_per_member, rows, s);
+    if (rc) return rc;
+    EnsOutArgs a{};
+    a.head = c->t.out; a.gstride = (long long)c->cap * c->net.ld[c->net.L]; a.ld = c->net.ld[c->net.L];
+    a.bounds = logvar_bounds; a.mean = mean_out; a.logvar = logvar_out;
+    a.rows = rows; a.O = c->d.output_dim; a.E = c->E;
+    hipLaunchKernelGGL(ens_out_kernel, dim3(stream_grid((long long)c->E * rows * a.O, 256)), dim3(256), 0, s, a);
+    LAUNCH_CHECK("ens_out");
+    return MORL_OK;
+}
+
+extern "C" int morl_ens_mse(morl_ens_ctx* c, const float* params, const float* logvar_bounds, const float* mu,
+                            const float* sigma, const float* x, const float* y, int rows, float* mse_out, void* stream) {
+    (void)logvar_bounds;
+    if (!c || !params || !x || !y || !mse_out) return fail(MORL_ERR_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ens_forward_core(c, params, mu, sigma, x, 0, rows, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ens_mse_kernel, dim3(c->E), dim3(256), 0, s, (const float*)c->t.out,
+                       (long long)c->cap * c->net.ld[c->net.L], c->net.ld[c->net.L], y, rows, c->d.output_dim, mse_out);
+    LAUNCH_CHECK("ens_mse");
+    return MORL_OK;
+}

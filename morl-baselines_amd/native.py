@@ -93,6 +93,16 @@ class GPIOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in GPI_OUT_FIELDS]
 
 
+class EnsDesc(C.Structure):
+    _fields_ = [("input_dim", C.c_int32), ("output_dim", C.c_int32), ("n_hidden", C.c_int32),
+                ("hidden", C.c_int32 * MORL_MAX_LAYERS), ("ensemble_size", C.c_int32), ("max_rows", C.c_int32)]
+
+
+class EnsCfg(C.Structure):
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("adam_step", C.c_int32), ("weight_decay", C.c_float * MORL_MAX_LAYERS)]
+
+
 _SIGNATURES = {
     # name: (restype, argtypes)
     "morl_last_error": (C.c_char_p, []),
@@ -127,6 +137,12 @@ _SIGNATURES = {
     "morl_sumtree_set": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "morl_sumtree_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "morl_ens_param_count": (C.c_int64, [C.POINTER(EnsDesc)]),
+    "morl_ens_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(EnsDesc)]),
+    "morl_ens_destroy": (C.c_int, [C.c_void_p]),
+    "morl_ens_train_step": (C.c_int, [C.c_void_p] * 11 + [C.c_int, C.POINTER(EnsCfg), C.c_void_p, C.c_void_p]),
+    "morl_ens_forward": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "morl_ens_mse": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p]),
     "morl_gpi_param_count": (C.c_int64, [C.POINTER(GPIDesc)]),
     "morl_gpi_mask_bytes": (C.c_int64, [C.POINTER(GPIDesc), C.c_int]),
     "morl_gpi_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(GPIDesc)]),
