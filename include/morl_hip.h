@@ -403,6 +403,10 @@ int morl_gpi_q_forward(morl_gpi_ctx* ctx, const float* params, int n_nets, const
  * action_out / policy_out: device int32 (policy_out may be NULL). */
 int morl_gpi_action(morl_gpi_ctx* ctx, const float* q, const float* obs, const float* support, int M, const float* w,
                     int32_t* action_out, int32_t* policy_out, void* stream);
+/* GPI actions of n observations at once (the Dyna rollouts, gpi_pd.py:377-387): actions_out[i] = action of
+ * arg max_k max_a w . Q_0(obs_i, a, support_k); n * M <= max_rows * max_support.  Eval mode (no dropout). */
+int morl_gpi_actions(morl_gpi_ctx* ctx, const float* q, const float* obs, int n, const float* support, int M,
+                     const float* w, int32_t* actions_out, void* stream);
 /* _reset_priorities errors of `rows` transitions: |w . (r + (1-d) gamma max_next - Q_0(s, w)[a])| with max_next the
  * envelope target over `support` (gpi_pd != 0; rows * M <= max_rows * max_support) or the double-Q target. */
 int morl_gpi_priorities(morl_gpi_ctx* ctx, const float* q, const float* q_target, const float* obs,

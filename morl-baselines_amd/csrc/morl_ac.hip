@@ -1115,6 +1115,22 @@ extern "C" int morl_gpi_action(morl_gpi_ctx* c, const float* q, const float* obs
     return MORL_OK;
 }
 
+extern "C" int morl_gpi_actions(morl_gpi_ctx* c, const float* q, const float* obs, int n, const float* support, int M,
+                                const float* w, int32_t* actions_out, void* stream) {
+    if (!c || !q || !obs || !support || !w || !actions_out) return fail(MORL_ERR_ARG, "NULL argument");
+    if (n < 1 || M < 1 || (long long)n * M > c->cap_env)
+        return fail(MORL_ERR_STATE, "n * M = %lld exceeds max_rows * max_support = %d", (long long)n * M, c->cap_env);
+    hipStream_t s = (hipStream_t)stream;
+    const int R = c->d.reward_dim, A = c->d.n_actions, ldq = c->net.ld[c->net.L];
+    int rc;
+    if ((rc = gpi_envelope_inputs(c, obs, support, M, n, s))) return rc;
+    if ((rc = gpi_forward(c, q, 1, c->te, c->obs_rep, c->w_rep, R, n * M, DropSpec(), s))) return rc;
+    hipLaunchKernelGGL(gpi_actions_kernel, dim3((n + 3) / 4), dim3(256), 0, s, (const float*)c->te.t.out, ldq, n, M, A, R, w,
+                       actions_out);
+    LAUNCH_CHECK("gpi_actions");
+    return MORL_OK;
+}
+
 extern "C" int morl_gpi_priorities(morl_gpi_ctx* c, const float* q, const float* q_target, const float* obs,
                                    const int32_t* actions, const float* rewards, const float* next_obs, const float* dones,
                                    int rows, const float* w, const float* support, int M, int gpi_pd, float gamma,

@@ -255,3 +255,80 @@ class ProbabilisticEnsemble(nn.Module):
                 num_epochs_no_improvement += 1
             epoch += 1
         return np.mean(holdout_losses)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# model-as-environment (common/model_based/utils.py:105-186).  The termination rules are environment knowledge on the
+# host side: the reference's own functions are used when ``morl_baselines`` is importable, restatements otherwise.
+# ---------------------------------------------------------------------------------------------------------------------
+def termination_fn_false(obs, act, next_obs, rew):
+    return np.zeros((len(obs), 1), dtype=bool)
+
+
+def termination_fn_mountaincar(obs, act, next_obs, rew):
+    return ((next_obs[:, 0] >= 0.45) * (next_obs[:, 1] >= 0.0))[:, np.newaxis]
+
+
+def termination_fn_minecart(obs, act, next_obs, rew):
+    old_pos, pos = obs[:, 0:2], next_obs[:, 0:2]
+    in_base = np.sqrt(np.einsum("ij,ij->i", pos, pos)) < 0.15
+    was_out_base = np.sqrt(np.einsum("ij,ij->i", old_pos, old_pos)) >= 0.15
+    return (was_out_base * in_base)[:, np.newaxis]
+
+
+def termination_fn_hopper(obs, act, next_obs, rew):
+    height, angle = next_obs[:, 0], next_obs[:, 1]
+    not_done = (np.isfinite(next_obs).all(axis=-1) * np.abs(next_obs[:, 1:] < 100).all(axis=-1) * (height > 0.7)
+                * (np.abs(angle) < 0.2))
+    return (~not_done)[:, np.newaxis]
+
+
+def termination_fn_lunarlander(obs, act, next_obs, rew):
+    exited = abs(next_obs[:, 0]) >= 1.0
+    landed = (rew[:, 0] != 0) & (next_obs[:, 6] >= 0.95) & (next_obs[:, 7] >= 0.95)
+    return (exited | landed)[:, np.newaxis]
+
+
+def termination_fn_humanoid(obs, act, next_obs, rew):
+    return (~((1.0 < next_obs[:, 0]) & (next_obs[:, 0] < 2.0)))[:, np.newaxis]
+
+
+def _termination_for(env_id: str):
+    try:  # the reference's table, unchanged, when it is installed
+        from morl_baselines.common.model_based import utils as ref_utils
+        return ref_utils.ModelEnv(None, env_id, 1).termination_func
+    except ImportError:
+        pass
+    table = (("hopper", termination_fn_hopper), ("halfcheetah", termination_fn_false),
+             ("humanoid", termination_fn_humanoid), ("lunar-lander", termination_fn_lunarlander),
+             ("mo-reacher", termination_fn_false), ("mountaincar", termination_fn_mountaincar),
+             ("minecart", termination_fn_minecart), ("mo-highway", termination_fn_false))
+    for key, fn in table:
+        if key in env_id:
+            return fn
+    raise NotImplementedError(f"no termination rule for '{env_id}': pass termination_func=")
+
+
+class ModelEnv:
+    """``ModelEnv`` (model_based/utils.py:105-186): one model step for a batch of (obs, one-hot / continuous action)."""
+
+    def __init__(self, model, env_id=None, rew_dim=1, termination_func=None):
+        self.model, self.rew_dim = model, rew_dim
+        self.termination_func = termination_func or _termination_for(env_id or "")
+
+    def step(self, obs: th.Tensor, act: th.Tensor, deterministic: bool = False):
+        single = obs.dim() == 1
+        if single:
+            obs, act = obs.unsqueeze(0), act.unsqueeze(0)
+        inputs = th.cat((obs, act), dim=-1).float().to(self.model.device)
+        with th.no_grad():
+            samples, vars_, uncertainties = self.model.sample(inputs, deterministic=deterministic)
+        obs = obs.detach().cpu().numpy()
+        samples[:, self.rew_dim:] += obs
+        rewards, next_obs = samples[:, :self.rew_dim], samples[:, self.rew_dim:]
+        terminals = self.termination_func(obs, act, next_obs, rewards)
+        var_rewards, var_obs = vars_[:, :self.rew_dim], vars_[:, self.rew_dim:]
+        if single:
+            next_obs, rewards, terminals = next_obs[0], rewards[0], terminals[0]
+            uncertainties, var_obs, var_rewards = uncertainties[0], var_obs[0], var_rewards[0]
+        return next_obs, rewards, terminals, {"uncertainty": uncertainties, "var_obs": var_obs, "var_rewards": var_rewards}

@@ -136,6 +136,21 @@ class GPIEngine:
                                                     res[1:].data_ptr(), self.lib.stream_of(self.q)))
         return res
 
+    def actions_batch(self, obs, w, support) -> th.Tensor:
+        """GPI actions (int32, (n,)) of n observations under weight ``w`` and the support set; chunked to the workspace."""
+        obs, w = self._f32(obs).reshape(-1, self.D), self._f32(w).reshape(-1)
+        support = self._f32(support).reshape(-1, self.R)
+        n, M = obs.shape[0], support.shape[0]
+        out = th.empty(n, dtype=th.int32, device=self.q.device)
+        chunk = max(1, (self.max_rows * self.max_support) // M)
+        self.lib.check_device(obs, w, support)
+        for b in range(0, n, chunk):
+            m = min(chunk, n - b)
+            self.lib.check(self.lib.lib.morl_gpi_actions(self._h, self.q.data_ptr(), obs[b:b + m].data_ptr(), m,
+                                                         support.data_ptr(), M, w.data_ptr(), out[b:b + m].data_ptr(),
+                                                         self.lib.stream_of(self.q)))
+        return out
+
     def priority_errors(self, obs, actions, rewards, next_obs, dones, w, support=None, *, gamma=0.99, gpi_pd=True):
         obs, rewards, next_obs = self._f32(obs), self._f32(rewards), self._f32(next_obs)
         dones, w = self._f32(dones).reshape(-1), self._f32(w).reshape(-1)

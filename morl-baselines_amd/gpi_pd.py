@@ -7,9 +7,11 @@ device: the prioritised replay (sum tree + gather), the ensemble of conditioned 
 backward, per-net clipping, Adam, PER errors), the GPI action as one ``morl_gpi_action`` call, and ``_reset_priorities``
 as chunked ``morl_gpi_priorities`` calls over the device-resident records.
 
-The Dyna part (probabilistic dynamics ensemble, imagined rollouts) is outside this framework's hot path:
-``dyna=True`` raises; ``GPILS`` is the model-free flavour the reference ships.  Dropout is not applied when acting or
-re-prioritising (the reference leaves the nets in train mode there).
+``dyna=True`` (GPI-PD proper): the probabilistic dynamics ensemble is trained on the device (``dynamics.py``,
+``morl_ens_*``), the imagined rollouts pick their GPI actions for the whole observation batch in one
+``morl_gpi_actions`` call and enter the model buffer with one batched ``add`` instead of the reference's per-row Python
+loop (gpi_pd.py:394-397).  Dropout is not applied when acting, rolling out or re-prioritising (the reference leaves the
+nets in train mode there).
 """
 from __future__ import annotations
 
@@ -58,10 +60,7 @@ class GPIPD(MOPolicy, MOAgent):
                  dynamics_num_elites: int = 2, real_ratio: float = 0.5, project_name: str = "MORL-Baselines",
                  experiment_name: str = "GPI-PD", wandb_entity: Optional[str] = None, log: bool = True,
                  seed: Optional[int] = None, device: Union[th.device, str] = "auto", lib: Optional[NativeLib] = None,
-                 max_support: int = 64):
-        if dyna:
-            raise NotImplementedError("the Dyna / dynamics-ensemble part of GPI-PD is not part of the HIP hot path; "
-                                      "use GPILS (dyna=False)")
+                 max_support: int = 64, dynamics_max_rows: int = 10000):
         MOAgent.__init__(self, env, device=device, seed=seed)
         MOPolicy.__init__(self, device=device)
         self.learning_rate, self.initial_epsilon, self.epsilon = learning_rate, initial_epsilon, initial_epsilon
@@ -87,7 +86,26 @@ class GPIPD(MOPolicy, MOAgent):
         self.replay_buffer = buf_cls(self.observation_shape, 1, rew_dim=self.reward_dim, max_size=buffer_size,
                                      action_dtype=np.uint8, device=self.device, lib=self.lib)
         self.min_priority, self.alpha = min_priority, alpha_per
-        self.dyna, self.dynamics, self.dynamics_buffer = False, None, None
+        # model-based part (gpi_pd.py:232-266)
+        self.dyna, self.dynamics_net_arch, self.dynamics, self.dynamics_buffer = dyna, dynamics_net_arch, None, None
+        if self.dyna:
+            from .dynamics import ProbabilisticEnsemble
+            self.dynamics = ProbabilisticEnsemble(input_dim=self.observation_dim + self.action_dim,
+                                                  output_dim=self.observation_dim + self.reward_dim,
+                                                  arch=self.dynamics_net_arch, normalize_inputs=dynamics_normalize_inputs,
+                                                  ensemble_size=dynamics_ensemble_size, num_elites=dynamics_num_elites,
+                                                  device=self.device, lib=self.lib,
+                                                  max_rows=dynamics_max_rows)   # >= fit batch (256) / holdout / rollout rows
+            self.dynamics_buffer = ReplayBuffer(self.observation_shape, 1, rew_dim=self.reward_dim,
+                                                max_size=dynamics_buffer_size, action_dtype=np.uint8, device=self.device,
+                                                lib=self.lib)
+        self.dynamics_train_freq, self.dynamics_buffer_size = dynamics_train_freq, dynamics_buffer_size
+        self.dynamics_normalize_inputs, self.dynamics_num_elites = dynamics_normalize_inputs, dynamics_num_elites
+        self.dynamics_ensemble_size, self.dynamics_rollout_len = dynamics_ensemble_size, dynamics_rollout_len
+        self.dynamics_rollout_freq, self.dynamics_rollout_batch_size = dynamics_rollout_freq, dynamics_rollout_batch_size
+        self.dynamics_uncertainty_threshold, self.real_ratio = dynamics_uncertainty_threshold, real_ratio
+        self.dynamics_fit_kwargs = {}                 # forwarded to ProbabilisticEnsemble.fit (reference: defaults)
+        self.model_termination_func = None            # optional override of the environment's termination rule
         self.dynamics_rollout_starts = dynamics_rollout_starts
         self.weight_support: List[th.Tensor] = []
         self.stacked_weight_support = None
@@ -141,7 +159,42 @@ class GPIPD(MOPolicy, MOAgent):
             self.replay_buffer = params["replay_buffer"]
 
     def _sample_batch_experiences(self):
-        return self.replay_buffer.sample(self.batch_size, to_tensor=True, device=self.device)
+        """``gpi_pd.py:343-365``: real transitions, or a real / imagined mix once the model buffer is in use."""
+        if not self.dyna or self.global_step < self.dynamics_rollout_starts or len(self.dynamics_buffer) == 0:
+            return self.replay_buffer.sample(self.batch_size, to_tensor=True, device=self.device)
+        num_real = int(self.batch_size * self.real_ratio)
+        real = self.replay_buffer.sample(num_real, to_tensor=True, device=self.device)
+        model = self.dynamics_buffer.sample(self.batch_size - num_real, to_tensor=True, device=self.device)
+        mixed = tuple(th.cat([r.reshape(r.shape[0], -1), m.reshape(m.shape[0], -1)], dim=0) for r, m in zip(real[:5], model[:5]))
+        return mixed + ((real[5],) if self.per else ())
+
+    @th.no_grad()
+    def _rollout_dynamics(self, w: th.Tensor):
+        """``gpi_pd.py:367-414``: imagined transitions from GPI actions under the current weight."""
+        from .dynamics import ModelEnv
+        num_times = int(np.ceil(self.dynamics_rollout_batch_size / 10000))
+        batch_size = min(self.dynamics_rollout_batch_size, 10000)
+        added = 0
+        w = th.as_tensor(w).to(self.engine.q.device, th.float32).reshape(-1)
+        for _ in range(num_times):
+            obs = self.replay_buffer.sample_obs(batch_size, to_tensor=False)
+            model_env = ModelEnv(self.dynamics, self.env.unwrapped.spec.id, rew_dim=len(w),
+                                 termination_func=self.model_termination_func)
+            for h in range(self.dynamics_rollout_len):
+                obs_t = th.as_tensor(np.ascontiguousarray(obs, dtype=np.float32)).to(self.engine.q.device)
+                actions = self.engine.actions_batch(obs_t, w, self.stacked_weight_support).long()
+                one_hot = th.nn.functional.one_hot(actions, num_classes=self.action_dim)
+                next_obs_pred, r_pred, dones, info = model_env.step(obs_t, one_hot, deterministic=False)
+                unc = info["uncertainty"]
+                keep = unc < self.dynamics_uncertainty_threshold
+                obs_h, act_h = obs_t.cpu().numpy(), actions.cpu().numpy()
+                self.dynamics_buffer.add_batch(obs_h[keep], act_h[keep], r_pred[keep], next_obs_pred[keep], dones[keep])
+                added += int(keep.sum())
+                nonterm = ~dones.squeeze(-1)
+                if nonterm.sum() == 0:
+                    break
+                obs = next_obs_pred[nonterm]
+        self._last_rollout = {"imagined": added, "uncertainty_mean": float(unc.mean())}
 
     # -- the hot path (gpi_pd.py:416-562) --------------------------------------------------------------------------------------
     def update(self, weight: th.Tensor):
@@ -154,8 +207,10 @@ class GPIPD(MOPolicy, MOAgent):
             s_obs, s_actions, s_rewards, s_next_obs, s_dones = batch[:5]
             idxes = batch[5] if self.per else None
             B = s_obs.size(0)
+            n_per = idxes.numel() if idxes is not None else B      # the imagined rows of a Dyna batch carry no priority
             if len(self.weight_support) > 1:
-                s_obs, s_rewards, s_next_obs, s_dones = (x.repeat(2, 1) for x in (s_obs, s_rewards, s_next_obs, s_dones))
+                s_obs, s_rewards, s_next_obs, s_dones = (x.reshape(B, -1).repeat(2, 1) for x in
+                                                         (s_obs, s_rewards, s_next_obs, s_dones))
                 s_actions = s_actions.reshape(-1).repeat(2)
                 w = th.vstack([weight.expand(B, -1)] + random.choices(self.weight_support, k=B))
             else:
@@ -171,7 +226,7 @@ class GPIPD(MOPolicy, MOAgent):
             out = e.update(obs=s_obs, actions=s_actions, rewards=s_rewards, next_obs=s_next_obs, dones=s_dones, w=w,
                            sampled_w=sampled_w, gamma=self.gamma, lr=self.learning_rate, adam_step=self._adam_step,
                            min_priority=self.min_priority, max_grad_norm=self.max_grad_norm, gpi_pd=self.gpi_pd,
-                           n_per=(B if (self.per or self.gpi_pd) else 0), dropout_seed=self._drop_seed, want=want)
+                           n_per=(n_per if (self.per or self.gpi_pd) else 0), dropout_seed=self._drop_seed, want=want)
             self._out = out
             critic_losses.append(out["critic_loss"])
             if self.per or self.gpi_pd:
@@ -288,6 +343,17 @@ class GPIPD(MOPolicy, MOAgent):
             next_obs, vec_reward, terminated, truncated, info = self.env.step(action)
             self.replay_buffer.add(obs, action, vec_reward, next_obs, terminated)
             if self.global_step >= self.learning_starts:
+                if self.dyna:
+                    if self.global_step % self.dynamics_train_freq(self.global_step) == 0:
+                        m_obs, m_actions, m_rewards, m_next_obs, m_dones = self.replay_buffer.get_all_data()
+                        one_hot = np.zeros((len(m_obs), self.action_dim))
+                        one_hot[np.arange(len(m_obs)), m_actions.astype(int).reshape(len(m_obs))] = 1
+                        X = np.hstack((m_obs, one_hot))
+                        Y = np.hstack((m_rewards, m_next_obs - m_obs))
+                        self._last_holdout = self.dynamics.fit(X, Y, **self.dynamics_fit_kwargs)
+                    if self.global_step >= self.dynamics_rollout_starts and \
+                            self.global_step % self.dynamics_rollout_freq == 0:
+                        self._rollout_dynamics(tensor_w)
                 self.update(tensor_w)
             if eval_env is not None and self.log and self.global_step % eval_freq == 0:
                 self.policy_eval(eval_env, weights=weight, log=self.log)

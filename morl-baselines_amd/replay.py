@@ -122,6 +122,37 @@ class ReplayBuffer:
         self.ptr = (self.ptr + 1) % self.max_size
         self.size = min(self.size + 1, self.max_size)
 
+    def add_batch(self, obs, actions, rewards, next_obs, dones):
+        """``add`` for n transitions at once, in order (what the reference's Dyna loop does one call at a time,
+        gpi_pd.py:394-397): host arrays and device records are written with slice copies, one H2D per contiguous range."""
+        obs = np.asarray(obs, dtype=np.float32).reshape(-1, self._D)
+        n = obs.shape[0]
+        if n == 0:
+            return
+        if n > self.max_size:
+            raise ValueError("batch larger than the buffer")
+        self.flush()
+        next_obs = np.asarray(next_obs, dtype=np.float32).reshape(n, self._D)
+        rewards = np.asarray(rewards, dtype=np.float32).reshape(n, self._R)
+        actions_h = np.asarray(actions).reshape(n, self._Ad)
+        dones_h = np.asarray(dones, dtype=np.float32).reshape(n, 1)
+        rec = np.empty((n, self._rec), dtype=np.float32)
+        D, R = self._D, self._R
+        rec[:, :D], rec[:, D:2 * D], rec[:, 2 * D:2 * D + R] = obs, next_obs, rewards
+        rec[:, 2 * D + R] = dones_h[:, 0]
+        rec[:, 2 * D + R + 1:] = actions_h.astype(np.float32)
+        start = self.ptr
+        first = min(n, self.max_size - start)
+        rec_t = th.from_numpy(rec)
+        for lo, hi, at in ((0, first, start), (first, n, 0)):
+            if hi > lo:
+                sl = slice(at, at + hi - lo)
+                self.obs[sl], self.next_obs[sl], self.rewards[sl] = obs[lo:hi], next_obs[lo:hi], rewards[lo:hi]
+                self.actions[sl], self.dones[sl] = actions_h[lo:hi].astype(self.actions.dtype), dones_h[lo:hi]
+                self.records[sl].copy_(rec_t[lo:hi])
+        self.ptr = (self.ptr + n) % self.max_size
+        self.size = min(self.size + n, self.max_size)
+
     def _gather(self, inds: np.ndarray):
         self.flush()
         idx = th.as_tensor(inds, dtype=th.int64).to(self.device, non_blocking=True)

@@ -101,6 +101,31 @@ def main():
     out["gpi_actions"] = np.asarray(env.action_log, dtype=np.int8)
     out["gpi_tree_root"] = np.float64(ag.replay_buffer.tree.nodes[0][0])
 
+    # ---- GPI-PD with the Dyna model (dynamics ensemble fit, imagined rollouts, mixed batches) -----------------------------------
+    tc.reseed(tc.SEED)
+    env = momdp.TreasureLine(tc.SEED, env_id=tc.GPIPD_DYNA_ENV_ID)
+    ag = gpi_mod.GPIPD(env, log=False, seed=tc.SEED, device="cpu",
+                       dynamics_train_freq=lambda t: tc.GPIPD_DYNA_TRAIN_FREQ, **tc.GPIPD_DYNA)
+    nets = ag.q_nets + ag.target_q_nets
+    ref_fit = ag.dynamics.fit
+    ag.dynamics.fit = lambda X, Y: ref_fit(X, Y, **tc.GPIPD_DYNA_FIT)      # instance attribute: same fit(), fewer epochs
+    dump(out, "dyna_init", params_of(nets))
+    for l, layer in enumerate(ag.dynamics.layers):
+        out[f"dyna_model_init_W{l}"], out[f"dyna_model_init_b{l}"] = layer.W.detach().numpy().copy(), layer.b.detach().numpy().copy()
+    tc.reseed()
+    ag.train_iteration(total_timesteps=tc.GPIPD_DYNA_STEPS, weight=tc.WEIGHT.copy(), weight_support=[s.copy() for s in tc.SUPPORT],
+                       change_w_every_episode=True)
+    dump(out, "dyna_final", params_of(nets))
+    for l, layer in enumerate(ag.dynamics.layers):
+        out[f"dyna_model_W{l}"], out[f"dyna_model_b{l}"] = layer.W.detach().numpy().copy(), layer.b.detach().numpy().copy()
+    out["dyna_actions"] = np.asarray(env.action_log, dtype=np.int8)
+    out["dyna_model_buffer"] = np.array([len(ag.dynamics_buffer), ag.dynamics_buffer.ptr])
+    nb = len(ag.dynamics_buffer)
+    out["dyna_model_obs"] = ag.dynamics_buffer.obs[:nb].copy()
+    out["dyna_model_rewards"] = ag.dynamics_buffer.rewards[:nb].copy()
+    out["dyna_tree_root"] = np.float64(ag.replay_buffer.tree.nodes[0][0])
+    print("dyna: model buffer", nb, "elites", ag.dynamics.elites)
+
     # ---- MOSAC with discrete actions -------------------------------------------------------------------------------------------
     tc.reseed(tc.SEED)
     env = momdp.TreasureLine(tc.SEED)
@@ -129,7 +154,7 @@ def main():
     out["env_eps_lambda"] = np.array([ag.epsilon, ag.homotopy_lambda])
 
     np.savez_compressed(os.path.join(HERE, "train_traces_ac.npz"), **out)
-    for k in ("capql_actions", "mosac_actions", "gpic_actions", "gpi_actions", "sacd_actions", "env_actions"):
+    for k in ("capql_actions", "mosac_actions", "gpic_actions", "gpi_actions", "dyna_actions", "sacd_actions", "env_actions"):
         print(k, out[k].shape, np.asarray(out[k]).reshape(len(out[k]), -1)[-3:].tolist())
 
 

@@ -20,6 +20,16 @@ SACD = dict(net_arch=[16, 16], batch_size=8, learning_starts=14, buffer_size=500
             tau=0.5)
 SACD_WEIGHTS = np.array([0.6, 0.4], dtype=np.float32)
 SACD_STEPS = 60
+GPIPD_DYNA = dict(net_arch=[16, 16, 16], batch_size=8, learning_starts=16, buffer_size=500, gradient_updates=2, per=True,
+                  gpi_pd=True, dyna=True, drop_rate=0.0, layer_norm=True, initial_epsilon=0.3, final_epsilon=0.3,
+                  target_net_update_freq=7, dynamics_net_arch=[16, 16], dynamics_ensemble_size=3, dynamics_num_elites=2,
+                  dynamics_rollout_len=2, dynamics_rollout_starts=24, dynamics_rollout_freq=6, dynamics_rollout_batch_size=20,
+                  dynamics_buffer_size=300, dynamics_uncertainty_threshold=8.655, real_ratio=0.5,
+                  dynamics_normalize_inputs=True)
+GPIPD_DYNA_TRAIN_FREQ = 12
+GPIPD_DYNA_FIT = dict(max_epochs=6)    # few epochs: early stopping is a discrete decision that amplifies fp32 round-off
+GPIPD_DYNA_STEPS = 44
+GPIPD_DYNA_ENV_ID = "mo-mountaincar-like-treasure-v0"     # any id the reference's ModelEnv has a termination rule for
 SUPPORT = [np.array([1.0, 0.0], dtype=np.float32), np.array([0.0, 1.0], dtype=np.float32),
            np.array([0.5, 0.5], dtype=np.float32)]
 WEIGHT = np.array([0.4, 0.6], dtype=np.float32)

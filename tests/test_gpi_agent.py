@@ -123,5 +123,21 @@ def test_gpils_training_iteration(be):
     assert np.isfinite(ag.replay_buffer.tree_dev.cpu().numpy()).all()
     ag.train_iteration(total_timesteps=6, weight=np.array([0.2, 0.8]), weight_support=sup, reset_num_timesteps=False)
     assert ag.global_step == 30                                        # second iteration re-prioritised the buffer first
-    with pytest.raises(NotImplementedError):
-        GPIPD(env, log=False, device=dev, lib=lib)                     # dyna=True is the reference default
+
+
+def test_gpipd_dyna_iteration_runs(be):
+    """GPI-PD with the Dyna model on either backend: the ensemble is fitted, rollouts fill the model buffer with batched
+    adds, updates draw mixed real / imagined batches (step-for-step parity with the reference: test_train_traces.py)."""
+    lib, dev = be
+    import train_cases as tc
+    th.manual_seed(0); np.random.seed(0); random.seed(0)
+    env = momdp.TreasureLine(0, env_id=tc.GPIPD_DYNA_ENV_ID)
+    ag = GPIPD(env, log=False, seed=0, device=dev, lib=lib, dynamics_train_freq=lambda t: 12, dynamics_max_rows=256,
+               **{**tc.GPIPD_DYNA, "dynamics_uncertainty_threshold": 1e9})
+    ag.dynamics_fit_kwargs = dict(max_epochs=3)
+    ag.train_iteration(total_timesteps=34, weight=tc.WEIGHT.copy(), weight_support=[s.copy() for s in tc.SUPPORT])
+    assert ag.global_step == 34 and len(ag.dynamics_buffer) > 0 and ag._last_rollout["imagined"] > 0
+    assert np.isfinite(ag._last_holdout) and len(ag.dynamics.elites) == 2
+    b = ag._sample_batch_experiences()
+    assert b[0].shape[0] == 8 and b[5].numel() == 4                    # real_ratio 0.5: half real (with indices), half imagined
+    assert np.isfinite(ag.engine.q.cpu().numpy()).all()

@@ -134,3 +134,35 @@ def test_mosac_discrete_trace(sim):
     worst = check_final(g, "sacd_final", params, atol=1e-4)
     np.testing.assert_allclose(ag.log_alpha.numpy(), g["sacd_log_alpha"], rtol=0, atol=2e-5)
     print(f"\nMOSAC discrete: {tc.SACD_STEPS} steps / {ag._q_step} updates, max parameter deviation {worst:.2e}")
+
+
+def test_gpipd_dyna_trace(sim):
+    """GPI-PD proper: dynamics-ensemble fits (early stopping, elites), imagined rollouts with batched GPI actions and
+    model noise, real / imagined batch mixing, PER + GPI priorities -- the whole loop against the reference's seeded run."""
+    from morl_baselines_amd.gpi_pd import GPIPD
+    g = np.load(GOLD)
+    tc.reseed(tc.SEED)
+    env = momdp.TreasureLine(tc.SEED, env_id=tc.GPIPD_DYNA_ENV_ID)
+    ag = GPIPD(env, log=False, seed=tc.SEED, device="cpu", lib=sim, dynamics_train_freq=lambda t: tc.GPIPD_DYNA_TRAIN_FREQ,
+               dynamics_max_rows=256, **tc.GPIPD_DYNA)
+    params = load_init(g, "dyna_init", ag.q_nets + ag.target_q_nets)
+    ag.dynamics_fit_kwargs = dict(tc.GPIPD_DYNA_FIT)
+    nl = len(tc.GPIPD_DYNA["dynamics_net_arch"]) + 1
+    sd = ag.dynamics.state_dict()
+    ag.dynamics.load_state_dict({**sd, **{f"layers.{l}.W": th.tensor(g[f"dyna_model_init_W{l}"]) for l in range(nl)},
+                                 **{f"layers.{l}.b": th.tensor(g[f"dyna_model_init_b{l}"]) for l in range(nl)}})
+    tc.reseed()
+    ag.train_iteration(total_timesteps=tc.GPIPD_DYNA_STEPS, weight=tc.WEIGHT.copy(), weight_support=[s.copy() for s in tc.SUPPORT],
+                       change_w_every_episode=True)
+    assert np.array_equal(np.asarray(env.action_log, dtype=np.int8), g["dyna_actions"])
+    assert [len(ag.dynamics_buffer), ag.dynamics_buffer.ptr] == g["dyna_model_buffer"].tolist()
+    nb = len(ag.dynamics_buffer)
+    np.testing.assert_allclose(ag.dynamics_buffer.obs[:nb], g["dyna_model_obs"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(ag.dynamics_buffer.rewards[:nb], g["dyna_model_rewards"], rtol=0, atol=2e-4)
+    sd = ag.dynamics.state_dict()
+    for l in range(nl):
+        np.testing.assert_allclose(sd[f"layers.{l}.W"].numpy(), g[f"dyna_model_W{l}"], rtol=0, atol=1e-4)
+    worst = check_final(g, "dyna_final", params, atol=2e-4)
+    assert float(ag.replay_buffer.tree.nodes[0][0]) == pytest.approx(float(g["dyna_tree_root"]), rel=1e-3)
+    print(f"\nGPI-PD + Dyna: {tc.GPIPD_DYNA_STEPS} steps / {ag._adam_step} updates, {nb} imagined transitions, "
+          f"max parameter deviation {worst:.2e}")
