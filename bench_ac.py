@@ -2,7 +2,7 @@
 continuous) on one MI355X.  bench.py stays the north-star (Envelope) line the driver runs; this script measures the
 widened rows with the same conventions:
 
-    python bench_ac.py --workload capql|mosac|morld|gpipd|gpi [--pop 64] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python bench_ac.py --workload capql|mosac|morld|gpipd|gpi|ens [--pop 64] [--steps K] [--warmup W] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench_ac.py --workload morld --gpus N --pop 64      # the population's learners are independent units: pop / N per
                                                                 # GPU, no data-path collective ("replicas only", weak scaling)
@@ -33,6 +33,7 @@ SHAPES = {  # obs dim, action dim, objectives of the environments BASELINE.json 
     "morld": dict(D=11, Ad=3, R=3, env="mo-hopper-v4"),
     "gpipd": dict(D=11, Ad=3, R=3, env="mo-hopper-v4"),
     "gpi": dict(D=7, Ad=6, R=3, env="mo-minecart-v0 (GPI-PD, discrete: 6 actions)"),
+    "ens": dict(D=7, Ad=6, R=3, env="mo-minecart-v0 (GPI-PD Dyna model: one-hot action in, next-obs delta + reward out)"),
 }
 ARCH = [256, 256]
 B = 128
@@ -227,6 +228,84 @@ def bench_gpi(a):
     print(json.dumps(out))
 
 
+def bench_ens(a):
+    """Dyna model of GPI-PD: one optimiser step of ``ProbabilisticEnsemble.fit`` (probabilistic_ensemble.py:248-252) --
+    5 members x batch 256, net [256, 256, 256] (gpi_pd.py defaults), Gaussian NLL with bounded log-variance, Adam with
+    per-layer weight decay -- per step."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from morl_baselines_amd.dynamics import DECAYS, ProbabilisticEnsemble
+
+    dev = th.device("cuda", 0)
+    shp = SHAPES["ens"]
+    E, rows, arch = 5, 256, [256, 256, 256]
+    din, dout = shp["D"] + shp["Ad"], shp["D"] + shp["R"]
+    th.manual_seed(0)
+    ens = ProbabilisticEnsemble(din, dout, ensemble_size=E, arch=arch, device=dev, max_rows=rows)
+    ens.decays = list(DECAYS)
+    gen = th.Generator(device=dev).manual_seed(0)
+    x = th.randn(E, rows, din, generator=gen, device=dev)
+    y = th.randn(E, rows, dout, generator=gen, device=dev) * 0.1
+    ens.inputs_mu = th.zeros((1, din), device=dev)
+    ens.inputs_sigma = th.ones((1, din), device=dev)
+    p0 = ens.flat.clone()
+    for _ in range(a.warmup):
+        ens.train_step(x, y)
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ens.train_step(x, y)
+    th.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dims = [din] + arch + [2 * dout]
+    macs = sum(i * o for i, o in zip(dims[:-1], dims[1:]))
+    flop = 2.0 * macs * E * rows * 3 - 2.0 * dims[0] * dims[1] * E * rows     # forward + dX + dW (no dX for the input layer)
+    ms = wall * 1e3 / a.steps
+    tf = flop / (ms * 1e-3) / 1e12
+    out = {"metric": "dynamics-ensemble optimiser steps/sec", "value": a.steps / wall, "unit": "steps/s", "n_gpus": 1,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"ProbabilisticEnsemble.fit() inner step: {E} members x batch {rows}, net {arch}, "
+                                  f"in {din} / out 2x{dout}; shapes of {shp['env']}"},
+           "roofline": {"bound": "mfma", "kernel": "gemm_batched / gemm_wave_batched", "achieved": tf,
+                        "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "note": "algorithmic GEMM flop of the step / wall time (launch-latency-bound workload)"},
+           "algorithmic_flop_per_step": flop}
+    if not a.no_cpu_baseline:
+        import ens_oracle as eo
+
+        views = ens._layer_views(p0)
+        state = dict(W=[w.transpose(1, 2).contiguous().cpu() for w, _ in views],
+                     b=[b.reshape(E, 1, -1).contiguous().cpu() for _, b in views],
+                     max_lv=th.ones(1, dout) / 2.0, min_lv=-th.ones(1, dout) * 10.0, mu=th.zeros(1, din),
+                     sigma=th.ones(1, din))
+        order = [p for pair in zip(state["W"], state["b"]) for p in pair] + [state["max_lv"], state["min_lv"]]
+        state["m"], state["v"] = [th.zeros_like(p) for p in order], [th.zeros_like(p) for p in order]
+        xc, yc = x.cpu(), y.cpu()
+        k, best = 0, (None, float("inf"))
+        for nt in (1, 4, 16, th.get_num_threads()):
+            th.set_num_threads(nt)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                k += 1
+                eo.train_step(state, xc, yc, k)
+            dt = (time.perf_counter() - t1) / 3
+            if dt < best[1]:
+                best = (nt, dt)
+        th.set_num_threads(best[0])
+        times, t_end = [], time.perf_counter() + 15.0
+        while time.perf_counter() < t_end and len(times) < 200:
+            k += 1
+            t1 = time.perf_counter()
+            eo.train_step(state, xc, yc, k)
+            times.append(time.perf_counter() - t1)
+        med = float(np.median(times[1:] or times))
+        out["cpu_baseline"] = {"value": 1.0 / med, "unit": "steps/s", "cores": best[0], "kind": "port",
+                               "sample": f"{len(times)} timed steps of oracle/ens_oracle.py::train_step on torch-CPU at the "
+                                         f"best of 1/4/16/all threads ({best[0]}), median"}
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="morld", choices=sorted(SHAPES))
@@ -253,6 +332,8 @@ def main():
             raise SystemExit("only the MORL/D population shards over GPUs (independent learners, no collective)")
     if a.workload == "gpi":
         return bench_gpi(a)
+    if a.workload == "ens":
+        return bench_ens(a)
     from morl_baselines_amd.ac_engine import ALGO_CAPQL, ALGO_MOSAC, ALGO_TD3, ACEngine
 
     wl, shp = a.workload, SHAPES[a.workload]

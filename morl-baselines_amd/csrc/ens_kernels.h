@@ -129,9 +129,12 @@ __global__ __launch_bounds__(256) void ens_bounds_step_kernel(const double* __re
     if (lane_id() == 0) s_red[wave_id()] = l;
     __syncthreads();
     if (threadIdx.x == 0 && loss_out) *loss_out = (float)(((s_red[0] + s_red[1]) + s_red[2]) + s_red[3]);
-    for (int e = (int)threadIdx.x; e < 2 * O; e += (int)blockDim.x) {
+    // one wave per bound: lanes stride over the partial blocks (fixed order, so the sum is reproducible), butterfly after
+    for (int e = wave_id(); e < 2 * O; e += (int)blockDim.x / 64) {
         double g = 0.0;
-        for (int b = 0; b < n_blocks; ++b) g += part[(long long)b * stride + 1 + e];
+        for (int b = lane_id(); b < n_blocks; b += 64) g += part[(long long)b * stride + 1 + e];
+        g = wave_sum(g);
+        if (lane_id() != 0) continue;
         const float grad = (float)g + (e < O ? 0.01f : -0.01f);
         float m = m_[e], v = v_[e];
         m = fmaf(one_minus_b1, __fsub_rn(grad, m), m);

@@ -150,10 +150,61 @@ __device__ __forceinline__ void wave_load64(float (&v)[WG4_CHUNK / 2], const flo
     }
 }
 
+// K-contiguous operands (activations X[m][k], weights W[n][k]) through LDS: the direct form above has every lane walk its
+// own row -- 32 rows at a >= 1 KB pitch per load instruction, 32 cache lines each, which measured +5 us per such operand
+// on a 128 x 256 x 256 layer.  Here a wave fetches its 32 x 64 panel with fully coalesced 16-byte loads (four rows of
+// 256 B per instruction), parks it in a wave-private LDS panel (pitch 68 floats: the 16 lanes of a ds_read_b128 phase hit
+// disjoint banks) and reads its MFMA operands back row-wise.  Wave-private => a wave barrier, no workgroup barrier.
+constexpr int WG4_PITCH = WG4_CHUNK + 4;
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// issue the coalesced global loads of panel rows [idx0, idx0 + 32) x k [k0, k0 + 64): instruction q covers rows 4q .. 4q+3
+__device__ __forceinline__ void panel_fetch(float4 (&t)[8], const float* __restrict__ P, int ld, int idx0, int extent,
+                                            int k0, int kend, int lane) {
+    const int kk = k0 + (lane & 15) * 4;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int row = idx0 + 4 * q + (lane >> 4);
+        t[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < extent) {
+            const float* __restrict__ src = P + (size_t)row * ld + kk;
+            if (kk + 3 < kend) {
+                t[q] = *reinterpret_cast<const float4*>(src);
+            } else {
+                if (kk < kend) t[q].x = src[0];
+                if (kk + 1 < kend) t[q].y = src[1];
+                if (kk + 2 < kend) t[q].z = src[2];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void panel_transpose(float (&v)[WG4_CHUNK / 2], const float4 (&t)[8], float* __restrict__ panel,
+                                                int lane) {
+    wave_lds_sync();                                           // earlier reads of the panel are done
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        *reinterpret_cast<float4*>(panel + (4 * q + (lane >> 4)) * WG4_PITCH + (lane & 15) * 4) = t[q];
+    wave_lds_sync();
+    const int h = lane >> 5, i = lane & 31;
+#pragma unroll
+    for (int q = 0; q < WG4_CHUNK / 4; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(panel + i * WG4_PITCH + 4 * q);
+        v[2 * q] = h ? x.y : x.x;
+        v[2 * q + 1] = h ? x.w : x.z;
+    }
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 __device__ __forceinline__ void gemm_wave4_tile(const GemmProblem& g, int tile_m, int tile_n) {
     __shared__ float s_red[3][16][64];
     __shared__ float s_col[3][32];
+    __shared__ __attribute__((aligned(16))) float s_panel[(A_KC || B_KC) ? 4 : 1][(A_KC || B_KC) ? 32 * WG4_PITCH : 4];
     const int lane = lane_id(), wave = wave_id();
     const int h = lane >> 5, i = lane & 31;
     const int m0 = tile_m * 32, n0 = tile_n * 32;
@@ -164,10 +215,17 @@ __device__ __forceinline__ void gemm_wave4_tile(const GemmProblem& g, int tile_m
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float colsum = 0.f;
     const bool do_colsum = (g.colsum != nullptr) && (tile_n == 0);
+    const bool a_lds = A_KC && g.a_vec, b_lds = B_KC && g.b_vec;          // wave-uniform
     for (int k0 = kbeg; k0 < kend; k0 += WG4_CHUNK) {
         float a[WG4_CHUNK / 2], b[WG4_CHUNK / 2];
-        wave_load64<A_KC>(a, g.A, g.lda, m0 + i, g.M, k0, kend, h, g.a_vec);
-        wave_load64<B_KC>(b, g.B, g.ldb, n0 + i, g.N, k0, kend, h, g.b_vec);
+        float4 ta[8], tb[8];
+        // all global loads of the stage are issued before the first LDS round trip
+        if (a_lds) panel_fetch(ta, g.A, g.lda, m0, g.M, k0, kend, lane);
+        if (b_lds) panel_fetch(tb, g.B, g.ldb, n0, g.N, k0, kend, lane);
+        if (!a_lds) wave_load64<A_KC>(a, g.A, g.lda, m0 + i, g.M, k0, kend, h, g.a_vec);
+        if (!b_lds) wave_load64<B_KC>(b, g.B, g.ldb, n0 + i, g.N, k0, kend, h, g.b_vec);
+        if (a_lds) panel_transpose(a, ta, s_panel[(A_KC || B_KC) ? wave : 0], lane);
+        if (b_lds) panel_transpose(b, tb, s_panel[(A_KC || B_KC) ? wave : 0], lane);
 #pragma unroll
         for (int s = 0; s < WG4_CHUNK / 2; ++s) {
             acc = mfma32(a[s], b[s], acc);

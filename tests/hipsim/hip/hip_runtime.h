@@ -145,6 +145,9 @@ static inline double __shfl_xor(double v, int m, int = 64) { hipsim::CollIn in{}
 static inline float __shfl(float v, int s, int = 64) { hipsim::CollIn in{}; in.f[0] = v; in.i = s; return hipsim::wave_collective(in, hipsim::fn_shfl_idx_f).f[0]; }
 static inline int __shfl(int v, int s, int = 64) { hipsim::CollIn in{}; in.u = (unsigned)v; in.i = s; return (int)hipsim::wave_collective(in, hipsim::fn_shfl_idx_i).u; }
 static inline double __shfl(double v, int s, int = 64) { hipsim::CollIn in{}; in.d = v; in.i = s; return hipsim::wave_collective(in, hipsim::fn_shfl_idx_d).d; }
+// wave-private LDS hand-offs: the fibres of a wave meet at a collective, fences are meaningless on the host
+static inline void __builtin_amdgcn_wave_barrier() { hipsim::CollIn in{}; in.u = 0; in.i = 0; (void)hipsim::wave_collective(in, hipsim::fn_shfl_idx_i); }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 static inline unsigned long long __ballot(int p) { hipsim::CollIn in{}; in.i = p != 0; return hipsim::wave_collective(in, hipsim::fn_ballot).u; }
 static inline int __all(int p) { return __ballot(!p) == 0ull; }
 static inline int __any(int p) { return __ballot(p) != 0ull; }
