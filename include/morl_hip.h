@@ -407,6 +407,12 @@ int morl_gpi_action(morl_gpi_ctx* ctx, const float* q, const float* obs, const f
  * arg max_k max_a w . Q_0(obs_i, a, support_k); n * M <= max_rows * max_support.  Eval mode (no dropout). */
 int morl_gpi_actions(morl_gpi_ctx* ctx, const float* q, const float* obs, int n, const float* support, int M,
                      const float* w, int32_t* actions_out, void* stream);
+/* The same for n (observation, weight) PAIRS -- evaluation episodes of many weight vectors stepped in lock-step
+ * (common/evaluation.py:118-144 calls agent.eval once per weight and step): row i acts under w_rows[i].
+ * M > 0: GPIPD.gpi_action (gpi_pd.py:564-582) per row over the support; M = 0: GPIPD.max_action (:608-617) per row
+ * (element-wise min over the ensemble).  n * max(M, 1) <= max_rows * max_support. */
+int morl_gpi_actions_rows(morl_gpi_ctx* ctx, const float* q, const float* obs, const float* w_rows, int n,
+                          const float* support, int M, int32_t* actions_out, void* stream);
 /* _reset_priorities errors of `rows` transitions: |w . (r + (1-d) gamma max_next - Q_0(s, w)[a])| with max_next the
  * envelope target over `support` (gpi_pd != 0; rows * M <= max_rows * max_support) or the double-Q target. */
 int morl_gpi_priorities(morl_gpi_ctx* ctx, const float* q, const float* q_target, const float* obs,

@@ -20,6 +20,7 @@ import numpy as np
 import torch as th
 
 from . import ops
+from .evaluation import front_returns
 from .ac_engine import ALGO_CAPQL, ACEngine
 from .acnets import PolicyShell, QNetworkShell, adam_state_dict, as_f32, bind, load_adam_state_dict
 from .api import MOAgent, MOPolicy
@@ -248,6 +249,16 @@ class CAPQL(MOAgent, MOPolicy):
         action = self.engine.policy_forward(obs, w)[0, 0]
         return action if torch_action else action.detach().cpu().numpy()
 
+    @th.no_grad()
+    def eval_batch(self, obs: np.ndarray, w: np.ndarray) -> np.ndarray:
+        """``eval`` for n (observation, weight) pairs per pass (lock-step evaluation episodes, ``evaluation.py``)."""
+        e = self.engine
+        obs = as_f32(np.asarray(obs, dtype=np.float32), e.q.device).reshape(-1, e.D)
+        w = as_f32(np.asarray(w, dtype=np.float32), e.q.device).reshape(-1, e.R)
+        out = [e.policy_forward(obs[b:b + e.max_rows].contiguous(), w[b:b + e.max_rows].contiguous())[0]
+               for b in range(0, obs.shape[0], e.max_rows)]
+        return th.cat(out, dim=0).cpu().numpy()
+
     def train(self, total_timesteps: int, eval_env=None, ref_point: Optional[np.ndarray] = None,
               known_pareto_front: Optional[List[np.ndarray]] = None, num_eval_weights_for_front: int = 100,
               num_eval_episodes_for_front: int = 5, num_eval_weights_for_eval: int = 50, eval_freq: int = 10000,
@@ -287,8 +298,7 @@ class CAPQL(MOAgent, MOPolicy):
             else:
                 obs = next_obs
             if self.log and self.global_step % eval_freq == 0:
-                returns_test_tasks = [policy_evaluation_mo(self, eval_env, ew, rep=num_eval_episodes_for_front)[3]
-                                      for ew in eval_weights]
+                returns_test_tasks = front_returns(self, eval_env, eval_weights, rep=num_eval_episodes_for_front)
                 log_all_multi_policy_metrics(current_front=returns_test_tasks, hv_ref_point=ref_point,
                                              reward_dim=self.reward_dim, global_step=self.global_step,
                                              n_sample_weights=num_eval_weights_for_eval, ref_front=known_pareto_front)

@@ -7,7 +7,7 @@ namespace morl {
 
 // ----------------------------------------------------------------------------------------------
 // X0[row][0:D] = obs[b][:], X0[row][D:D+R] = weights[k][:], zero padding up to ldx.
-// row_order 0: row = b*W + k (next-state slab order); 1: row = k*B + b (reference TD-row order,
+// row_order 2: row r = (obs[r], weights[r]);  0: row = b*W + k (next-state slab order); 1: row = k*B + b (reference TD-row order,
 // envelope.py:284-291).  Replaces th.cat((obs, w)) of QNet.forward (envelope.py:75) together with the
 // repeat / repeat_interleave tiling (envelope.py:284-291, 416-418) -- the tiled batch is never built.
 // HBM-bound: writes rows*ldx*4 bytes, reads are L2 hits.
@@ -20,7 +20,9 @@ __global__ __launch_bounds__(256) void build_input_kernel(const float* __restric
          e += (long long)gridDim.x * blockDim.x) {
         const int row = (int)(e / ldx), c = (int)(e % ldx);
         int b, k;
-        if (row_order == 0) { b = row / W; k = row % W; } else { k = row / B; b = row % B; }
+        if (row_order == 0) { b = row / W; k = row % W; }
+        else if (row_order == 1) { k = row / B; b = row % B; }
+        else { b = row; k = row; }                                  // 2: paired rows, weights [B][R] (W = 1)
         float v = 0.f;
         if (c < D) v = obs[(size_t)b * D + c];
         else if (c < D + R) v = weights[(size_t)k * R + (c - D)];

@@ -323,21 +323,23 @@ __global__ __launch_bounds__(64) void gpi_action_kernel(const float* __restrict_
 }
 
 // GPI actions of a BATCH of observations (the Dyna rollouts, gpi_pd.py:377-387): q rows (obs_i, w_k) at i * M + k from
-// net 0; one wave per observation: arg-max over (k, a) of w . q, lowest index on ties -> a.
+// net 0; one wave per observation: arg-max over (k, a) of w . q, lowest index on ties -> a.  w_rstride = R gives every
+// observation its own weight vector (evaluation episodes of many weights in lock-step), 0 shares one.
 __global__ __launch_bounds__(256) void gpi_actions_kernel(const float* __restrict__ q, int ldq, int n, int M, int A, int R,
-                                                          const float* __restrict__ w, int32_t* __restrict__ actions) {
+                                                          const float* __restrict__ w, int w_rstride,
+                                                          int32_t* __restrict__ actions) {
     const int i = (int)blockIdx.x * 4 + wave_id();
     if (i >= n) return;
     float best;
     int bi;
     const float* bq;
-    gpi_best_candidate(q, 0, ldq, i * M, M, A, R, 1, w, best, bi, bq);
+    gpi_best_candidate(q, 0, ldq, i * M, M, A, R, 1, w + (long long)i * w_rstride, best, bi, bq);
     if (lane_id() == 0) actions[i] = bi % A;
 }
 
 // element-wise min over the ensemble (max_action's th.min(th.stack(...), dim=0)[0], gpi_pd.py:612)
-__global__ __launch_bounds__(256) void gpi_min_nets_kernel(const float* __restrict__ q, long long gstride, int nn, int n,
-                                                           float* __restrict__ out) {
+// (out may alias net 0's rows of q: every element is read before it is written, by the same thread)
+__global__ __launch_bounds__(256) void gpi_min_nets_kernel(const float* q, long long gstride, int nn, int n, float* out) {
     const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
     if (e >= n) return;
     float m = q[e];

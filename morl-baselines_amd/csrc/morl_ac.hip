@@ -1126,8 +1126,39 @@ extern "C" int morl_gpi_actions(morl_gpi_ctx* c, const float* q, const float* ob
     if ((rc = gpi_envelope_inputs(c, obs, support, M, n, s))) return rc;
     if ((rc = gpi_forward(c, q, 1, c->te, c->obs_rep, c->w_rep, R, n * M, DropSpec(), s))) return rc;
     hipLaunchKernelGGL(gpi_actions_kernel, dim3((n + 3) / 4), dim3(256), 0, s, (const float*)c->te.t.out, ldq, n, M, A, R, w,
-                       actions_out);
+                       0, actions_out);
     LAUNCH_CHECK("gpi_actions");
+    return MORL_OK;
+}
+
+// evaluation in lock-step over many (observation, weight) pairs: row i acts under its own w_rows[i]
+extern "C" int morl_gpi_actions_rows(morl_gpi_ctx* c, const float* q, const float* obs, const float* w_rows, int n,
+                                     const float* support, int M, int32_t* actions_out, void* stream) {
+    if (!c || !q || !obs || !w_rows || !actions_out) return fail(MORL_ERR_ARG, "NULL argument");
+    if (M < 0 || (M > 0 && !support)) return fail(MORL_ERR_ARG, "support size %d without a support set", M);
+    if (n < 1 || (long long)n * std::max(M, 1) > c->cap_env)
+        return fail(MORL_ERR_STATE, "n * max(M, 1) = %lld exceeds max_rows * max_support = %d", (long long)n * std::max(M, 1),
+                    c->cap_env);
+    hipStream_t s = (hipStream_t)stream;
+    const int R = c->d.reward_dim, A = c->d.n_actions, ldq = c->net.ld[c->net.L];
+    int rc;
+    if (M > 0) {
+        // gpi_action (gpi_pd.py:564-582) per row: net 0 on (obs_i, support_k), scalarised with the row's weight
+        if ((rc = gpi_envelope_inputs(c, obs, support, M, n, s))) return rc;
+        if ((rc = gpi_forward(c, q, 1, c->te, c->obs_rep, c->w_rep, R, n * M, DropSpec(), s))) return rc;
+    } else {
+        // max_action (gpi_pd.py:608-617) per row: element-wise min over the ensemble at (obs_i, w_i), in place in net 0's rows
+        if ((rc = gpi_forward(c, q, c->nn, c->te, obs, w_rows, R, n, DropSpec(), s))) return rc;
+        if (c->nn > 1) {
+            const int e = n * ldq;
+            hipLaunchKernelGGL(gpi_min_nets_kernel, dim3((e + 255) / 256), dim3(256), 0, s, (const float*)c->te.t.out,
+                               (long long)c->te.t.cap * ldq, c->nn, e, c->te.t.out);
+            LAUNCH_CHECK("gpi_min_nets_rows");
+        }
+    }
+    hipLaunchKernelGGL(gpi_actions_kernel, dim3((n + 3) / 4), dim3(256), 0, s, (const float*)c->te.t.out, ldq, n, std::max(M, 1),
+                       A, R, w_rows, R, actions_out);
+    LAUNCH_CHECK("gpi_actions_rows");
     return MORL_OK;
 }
 

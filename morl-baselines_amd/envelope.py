@@ -17,6 +17,7 @@ import torch as th
 import torch.optim as optim
 
 from . import ops
+from .evaluation import front_returns
 from .api import MOAgent, MOPolicy
 from .native import NativeLib, load_library
 from .qnet import QNet
@@ -306,6 +307,18 @@ class Envelope(MOPolicy, MOAgent):
         w = th.as_tensor(w).float().to(self.device)
         return self.max_action(obs, w)
 
+    @th.no_grad()
+    def eval_batch(self, obs: np.ndarray, w: np.ndarray) -> np.ndarray:
+        """``eval`` for n (observation, weight) pairs in one pass (lock-step evaluation episodes, ``evaluation.py``):
+        rows through the HIP forward, then the envelope kernel's arg-max with one candidate weight per row."""
+        obs = th.as_tensor(np.asarray(obs)).float().to(self.device).reshape(-1, self.observation_dim).contiguous()
+        w = th.as_tensor(np.asarray(w)).float().to(self.device).reshape(-1, self.reward_dim).contiguous()
+        n = obs.size(0)
+        self.q_net.ensure_capacity(n, 1)
+        q = ops.qnet_forward_rows(self.q_net.ctx, self.q_net.flat, obs, w).view(n, 1, self.action_dim, self.reward_dim)
+        _, _, ac = ops.envelope_reduce_rows(self.lib, q, q, w)
+        return ac.cpu().numpy().astype(np.int64)
+
     def act(self, obs: th.Tensor, w: th.Tensor) -> int:
         if self.np_random.random() < self.epsilon:
             return self.env.action_space.sample()
@@ -356,8 +369,11 @@ class Envelope(MOPolicy, MOAgent):
             if self.global_step >= self.learning_starts:
                 self.update()
             if eval_weights is not None and self.global_step % eval_freq == 0:
-                current_front = [self.policy_eval(eval_env, weights=ew, num_episodes=num_eval_episodes_for_front,
-                                                  log=self.log)[3] for ew in eval_weights]
+                if isinstance(eval_env, (list, tuple)):      # one environment per weight: lock-step roll-outs (evaluation.py)
+                    current_front = front_returns(self, eval_env, eval_weights, rep=num_eval_episodes_for_front)
+                else:
+                    current_front = [self.policy_eval(eval_env, weights=ew, num_episodes=num_eval_episodes_for_front,
+                                                      log=self.log)[3] for ew in eval_weights]
                 log_all_multi_policy_metrics(current_front=current_front, hv_ref_point=ref_point,
                                              reward_dim=self.reward_dim, global_step=self.global_step,
                                              n_sample_weights=num_eval_weights_for_eval, ref_front=known_pareto_front)

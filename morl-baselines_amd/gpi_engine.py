@@ -151,6 +151,27 @@ class GPIEngine:
                                                          self.lib.stream_of(self.q)))
         return out
 
+    def actions_rows(self, obs, w_rows, support: Optional[th.Tensor] = None) -> th.Tensor:
+        """Actions (int32, (n,)) of n (observation, weight) pairs: GPI over ``support`` when given, ``max_action`` otherwise
+        (``morl_gpi_actions_rows``); chunked to the workspace."""
+        obs, w_rows = self._f32(obs).reshape(-1, self.D), self._f32(w_rows).reshape(-1, self.R)
+        M = 0
+        if support is not None and len(support) > 0:
+            support = self._f32(support).reshape(-1, self.R)
+            M = support.shape[0]
+        n = obs.shape[0]
+        if w_rows.shape[0] != n:
+            raise ValueError(f"{n} observations but {w_rows.shape[0]} weight rows")
+        out = th.empty(n, dtype=th.int32, device=self.q.device)
+        chunk = max(1, (self.max_rows * self.max_support) // max(M, 1))
+        self.lib.check_device(obs, w_rows, support if M else None)
+        for b in range(0, n, chunk):
+            m = min(chunk, n - b)
+            self.lib.check(self.lib.lib.morl_gpi_actions_rows(
+                self._h, self.q.data_ptr(), obs[b:b + m].data_ptr(), w_rows[b:b + m].data_ptr(), m,
+                support.data_ptr() if M else None, M, out[b:b + m].data_ptr(), self.lib.stream_of(self.q)))
+        return out
+
     def priority_errors(self, obs, actions, rewards, next_obs, dones, w, support=None, *, gamma=0.99, gpi_pd=True):
         obs, rewards, next_obs = self._f32(obs), self._f32(rewards), self._f32(next_obs)
         dones, w = self._f32(dones).reshape(-1), self._f32(w).reshape(-1)

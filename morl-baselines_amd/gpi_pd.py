@@ -23,6 +23,7 @@ import numpy as np
 import torch as th
 from torch import nn
 
+from .evaluation import front_returns
 from .acnets import adam_state_dict, bind, build_mlp, layer_init, load_adam_state_dict
 from .api import MOAgent, MOPolicy
 from .envelope import linearly_decaying_value
@@ -280,6 +281,13 @@ class GPIPD(MOPolicy, MOAgent):
             return self.gpi_action(obs, w, include_w=False)
         return self.max_action(obs, w)
 
+    @th.no_grad()
+    def eval_batch(self, obs: np.ndarray, w: np.ndarray) -> np.ndarray:
+        """``eval`` for n (observation, weight) pairs in one pass (lock-step evaluation episodes, ``evaluation.py``)."""
+        sup = self.stacked_weight_support if self.use_gpi else None
+        return self.engine.actions_rows(th.as_tensor(np.asarray(obs)).float(), th.as_tensor(np.asarray(w)).float(),
+                                        sup).cpu().numpy().astype(np.int64)
+
     def _act(self, obs: th.Tensor, w: th.Tensor) -> int:
         if self.np_random.random() < self.epsilon:
             return self.env.action_space.sample()
@@ -412,8 +420,7 @@ class GPIPD(MOPolicy, MOAgent):
                     linear_support.add_solution(
                         policy_evaluation_mo(self, eval_env, wcw, rep=num_eval_episodes_for_front)[3], wcw)
             if self.log and self.global_step % eval_mo_freq == 0:
-                front = [policy_evaluation_mo(self, eval_env, ew, rep=num_eval_episodes_for_front)[3]
-                         for ew in eval_weights]
+                front = front_returns(self, eval_env, eval_weights, rep=num_eval_episodes_for_front)
                 log_all_multi_policy_metrics(current_front=front, hv_ref_point=ref_point, reward_dim=self.reward_dim,
                                              global_step=self.global_step, n_sample_weights=num_eval_weights_for_eval,
                                              ref_front=known_pareto_front)

@@ -20,6 +20,7 @@ from typing import List, Optional, Union
 import numpy as np
 import torch as th
 
+from .evaluation import front_returns
 from .ac_engine import ALGO_TD3, ACEngine
 from .acnets import PolicyShell, QNetworkShell, adam_state_dict, as_f32, bind, load_adam_state_dict
 from .api import MOAgent, MOPolicy
@@ -319,8 +320,7 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
                     linear_support.add_solution(
                         policy_evaluation_mo(self, eval_env, wcw, rep=num_eval_episodes_for_front)[3], wcw)
             if self.log and self.global_step % eval_mo_freq == 0:
-                front = [policy_evaluation_mo(self, eval_env, ew, rep=num_eval_episodes_for_front)[3]
-                         for ew in eval_weights]
+                front = front_returns(self, eval_env, eval_weights, rep=num_eval_episodes_for_front)
                 log_all_multi_policy_metrics(current_front=front, hv_ref_point=ref_point, reward_dim=self.reward_dim,
                                              global_step=self.global_step, n_sample_weights=num_eval_weights_for_eval,
                                              ref_front=known_pareto_front)

@@ -155,6 +155,8 @@ _SIGNATURES = {
                                   C.c_void_p, C.c_void_p]),
     "morl_gpi_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    "morl_gpi_actions_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p]),
     "morl_gpi_priorities": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                                           C.c_void_p, C.c_void_p]),
     "morl_ac_q_param_count": (C.c_int64, [C.POINTER(ACDesc)]),

@@ -196,6 +196,10 @@ def test_qnet_forward_row_orders(be, dims, fused):
     pf = flat(params).to(dev)
     q0 = ops.qnet_forward(ctx, pf, obs.to(dev), sw.to(dev), row_order=0).cpu()
     q1 = ops.qnet_forward(ctx, pf, obs.to(dev), sw.to(dev), row_order=1).cpu()
+    # row_order 2: paired rows (obs[r], w[r]) -- QNet.forward on a batch, the evaluation / acting path
+    pw = th.tensor(orc.random_weights(R, B, "gaussian", rng=rng), dtype=th.float32).reshape(B, R)
+    q2 = ops.qnet_forward_rows(ctx, pf, obs.to(dev), pw.to(dev)).cpu()
+    assert relmax(q2, orc.qnet_forward(params, obs, pw, A, R)) <= RTOL
     ctx.close()
     ref0 = orc.qnet_forward(params, obs.repeat_interleave(W, 0), sw.repeat(B, 1), A, R)
     ref1 = orc.qnet_forward(params, obs.repeat(W, 1), sw.repeat_interleave(B, 0), A, R)
