@@ -64,6 +64,8 @@ struct ChainArgs {
     int B, W, D, R, row_order;
     const float* src;       // in_mode 1
     int ldsrc, K0;
+    float* x0_out;          // in_mode 0, or NULL: the assembled rows also go to HBM as [rows][ldx0] (zero padded) -- the
+    int ldx0;               // weight-gradient GEMM of layer 0 reads them; saves the separate input-assembly launch
     long long* prof;        // development probe only (tools/probes): [blocks][8] phase cycle counters
 };
 
@@ -158,6 +160,7 @@ __device__ __forceinline__ void mlp_chain_body(const ChainArgs& p, int tile) {
                 else v = p.src[(size_t)row * p.ldsrc + k];
             }
             sAct[k * LDM + m] = v;
+            if (p.x0_out != nullptr && row_ok && k < p.ldx0) p.x0_out[(size_t)row * p.ldx0 + k] = v;
         }
     }
     __syncthreads();
@@ -402,8 +405,11 @@ struct TransposeArgs {
     int n;
 };
 
+// blockIdx.y = 0: params -> wt; 1: params2 -> wt2 (online and target net of one update step in a single launch)
 __global__ __launch_bounds__(256) void transpose_params_kernel(const float* __restrict__ params,
-                                                               float* __restrict__ wt, TransposeArgs t) {
+                                                               float* __restrict__ wt, const float* __restrict__ params2,
+                                                               float* __restrict__ wt2, TransposeArgs t) {
+    if (blockIdx.y == 1) { params = params2; wt = wt2; }
     const long long total = t.elem_start[t.n];
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (long long)gridDim.x * blockDim.x) {

@@ -355,7 +355,8 @@ static int build_input(const float* obs, const float* weights, float* x0, int B,
 }
 
 // ---- layer-fused path --------------------------------------------------------------------------
-static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipStream_t s) {
+static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipStream_t s, const float* params2 = nullptr,
+                              float* wt2 = nullptr) {
     TransposeArgs t{};
     t.n = c->L;
     long long e = 0;
@@ -369,7 +370,8 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
         e += (long long)t.K[l] * t.ldn[l];
     }
     t.elem_start[c->L] = e;
-    hipLaunchKernelGGL(transpose_params_kernel, dim3(stream_grid(e, 256)), dim3(256), 0, s, params, wt, t);
+    hipLaunchKernelGGL(transpose_params_kernel, dim3(stream_grid(e, 256), params2 ? 2 : 1), dim3(256), 0, s, params, wt,
+                       params2, wt2, t);
     LAUNCH_CHECK("transpose_params");
     return MORL_OK;
 }
@@ -643,7 +645,8 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     const int rows = B * WI;
     // the dW GEMM reads the training pass's layer-0 input from HBM (the W-tiled batch of envelope.py:284-291 is never
     // materialised wider than this [rows][D+R] block)
-    if ((rc = build_input(obs, weights_i, c->x0m, B, WI, D, R, c->ld0, 1, s))) return rc;
+    // (the fused three-pass launch has already written it from its own input assembly)
+    if (!main_fwd_done && (rc = build_input(obs, weights_i, c->x0m, B, WI, D, R, c->ld0, 1, s))) return rc;
     if (!main_fwd_done) {
         c->bits_valid = false;
         if (c->use_fused) {
@@ -826,14 +829,17 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     bool main_done = false;
     if (c->use_fused) {
         // layer-fused passes: activations stay in LDS; rows assembled from (obs, weights) inside the kernel
-        if ((rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
-        if ((rc = refresh_transposed(c, params_target, c->wt_target, s))) return rc;
+        if ((rc = refresh_transposed(c, params_online, c->wt_online, s, params_target, c->wt_target))) return rc;
         if (c->fused_tm == 0) {
             // one launch for the three forward passes: 3 x rows/64 workgroups -> 2 resident per CU
+            ChainArgs main_chain = make_forward_chain(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm,
+                                                      c->ldq, true);
+            main_chain.x0_out = c->x0m;      // layer-0 input of the dW GEMM, written by the pass that assembles it anyway
+            main_chain.ldx0 = c->ld0;
             if ((rc = chain_forward_x3(
                      c, make_forward_chain(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR),
                      make_forward_chain(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR),
-                     make_forward_chain(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm, c->ldq, true), s)))
+                     main_chain, s)))
                 return rc;
             main_done = true;
             c->bits_valid = true;   // the multi launch always uses 64-row tiles

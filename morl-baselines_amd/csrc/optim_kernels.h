@@ -6,7 +6,7 @@
 namespace morl {
 
 constexpr int OPT_THREADS = 256;
-constexpr int OPT_MAX_BLOCKS = 256;  // sum-of-squares partials are re-reduced by every clip_adam block
+constexpr int OPT_MAX_BLOCKS = 1024;  // sum-of-squares partials are re-reduced by every clip_adam wave (16 loads per lane)
 
 // ----------------------------------------------------------------------------------------------
 // grads[p] = sum_{s < splits} slabs[s][p]  (fixed order -> run-to-run deterministic), plus one
