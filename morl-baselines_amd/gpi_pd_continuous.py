@@ -7,9 +7,11 @@ priorities, Polyak, and every ``delay_policy_update``-th iteration the determini
 plus the target-policy Polyak.  The GPI evaluation (``eval`` with ``use_gpi``: |M| policy actions x |M| weights through
 the first critic, ``max_a`` then ``argmax_i``) runs the |M|^2 critic rows through ``morl_ac_q_forward``.
 
-The model-based part of GPI-PD (the probabilistic dynamics ensemble and Dyna rollouts, ``dyna=True``) is outside the
-hot path of this framework: constructing with ``dyna=True`` raises; ``GPILSContinuousAction`` (model-free) is the
-supported flavour.
+``dyna=True`` (GPI-PD proper): the probabilistic dynamics ensemble is trained on the device (``dynamics.py``,
+``morl_ens_*``), roll-outs from replayed states act with the noisy TD3 policy (one ``morl_ac_policy_forward`` per plan
+step), the uncertainty-filtered imagined transitions go into the model buffer with one batched add, and updates draw
+real / imagined mixes (``gpi_pd_continuous_action.py:313-371, 548-561``).  ``GPILSContinuousAction`` is the model-free
+flavour.
 """
 from __future__ import annotations
 
@@ -58,17 +60,15 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
                  project_name: str = "MORL-Baselines", experiment_name: str = "GPI-PD Continuous Action",
                  wandb_entity: Optional[str] = None, log: bool = True, seed: Optional[int] = None,
                  device: Union[th.device, str] = "auto", lib: Optional[NativeLib] = None,
-                 q_layer_norm: bool = True, q_drop_rate: float = 0.01):
-        if dyna:
-            raise NotImplementedError("the Dyna / dynamics-ensemble part of GPI-PD is not part of the HIP hot path; "
-                                      "use GPILSContinuousAction (dyna=False)")
+                 q_layer_norm: bool = True, q_drop_rate: float = 0.01, dynamics_max_rows: int = 10000,
+                 model_termination_func=None):
         MOAgent.__init__(self, env, device=device, seed=seed)
         MOPolicy.__init__(self, device=device)
         self.learning_rate, self.tau, self.gamma, self.use_gpi = learning_rate, tau, gamma, use_gpi
         self.policy_noise, self.noise_clip, self.buffer_size = policy_noise, noise_clip, buffer_size
         self.num_q_nets, self.delay_policy_update, self.net_arch = num_q_nets, delay_policy_update, net_arch
         self.learning_starts, self.batch_size, self.gradient_updates = learning_starts, batch_size, gradient_updates
-        self.per, self.min_priority, self.alpha, self.dyna = per, min_priority, alpha, False
+        self.per, self.min_priority, self.alpha, self.dyna = per, min_priority, alpha, dyna
         self.lib = lib or load_library()
         buf_cls = PrioritizedReplayBuffer if per else ReplayBuffer
         self.replay_buffer = buf_cls(self.observation_shape, self.action_dim, rew_dim=self.reward_dim,
@@ -92,6 +92,23 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
         bind(self.target_policy, e.policy_views(e.pol_target), copy_in=False)
         e.q_target.copy_(e.q)
         e.pol_target.copy_(e.pol)
+        # the Dyna model (gpi_pd_continuous_action.py:216-235): input (obs, action), output (reward, next_obs - obs)
+        self.dynamics_net_arch, self.dynamics, self.dynamics_buffer = dynamics_net_arch, None, None
+        if self.dyna:
+            from .dynamics import ProbabilisticEnsemble
+            self.dynamics = ProbabilisticEnsemble(input_dim=self.observation_dim + self.action_dim,
+                                                  output_dim=self.observation_dim + self.reward_dim,
+                                                  arch=self.dynamics_net_arch, device=self.device, lib=self.lib,
+                                                  max_rows=dynamics_max_rows)   # >= fit batch / hold-out / roll-out rows
+            self.dynamics_buffer = ReplayBuffer(self.observation_shape, self.action_dim, rew_dim=self.reward_dim,
+                                                max_size=dynamics_buffer_size, device=self.device, lib=self.lib)
+        self.dynamics_train_freq, self.dynamics_rollout_len = dynamics_train_freq, dynamics_rollout_len
+        self.dynamics_rollout_starts, self.dynamics_rollout_freq = dynamics_rollout_starts, dynamics_rollout_freq
+        self.dynamics_rollout_batch_size, self.dynamics_min_uncertainty = dynamics_rollout_batch_size, dynamics_min_uncertainty
+        self.dynamics_real_ratio, self.dynamics_max_rows = dynamics_real_ratio, dynamics_max_rows
+        self.dynamics_fit_kwargs = {}                 # forwarded to ProbabilisticEnsemble.fit (reference: defaults)
+        self.model_termination_func = model_termination_func   # None: looked up from the environment id like ModelEnv does
+        self._last_rollout, self._last_holdout = None, None
         self.weight_support: List[th.Tensor] = []
         self.stacked_weight_support = []
         self._n_updates = 0
@@ -131,6 +148,8 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
                                                                self._q_views(e.q_exp_avg_sq), self._q_step,
                                                                self.learning_rate)
         saved["M"] = self.weight_support
+        if self.dyna:
+            saved["dynamics_state_dict"] = self.dynamics.state_dict()
         saved["target_policy_state_dict"] = self.target_policy.state_dict()   # (extension: not in the reference file)
         if save_replay_buffer:
             saved["replay_buffer"] = self.replay_buffer
@@ -153,11 +172,62 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
             tq.load_state_dict(params["target_q_net_" + str(i) + "_state_dict"])
         self._q_step = load_adam_state_dict(params["q_nets_optimizer_state_dict"], self._q_views(e.q_exp_avg),
                                             self._q_views(e.q_exp_avg_sq))
+        if self.dyna and "dynamics_state_dict" in params:
+            self.dynamics.load_state_dict(params["dynamics_state_dict"])
         if load_replay_buffer and "replay_buffer" in params:
             self.replay_buffer = params["replay_buffer"]
 
     def _sample_batch_experiences(self):
-        return self.replay_buffer.sample(self.batch_size, to_tensor=True, device=self.device)
+        """``gpi_pd_continuous_action.py:313-335``: real transitions, or a real / imagined mix once the model buffer is used."""
+        if not self.dyna or self.global_step < self.dynamics_rollout_starts or len(self.dynamics_buffer) == 0:
+            return self.replay_buffer.sample(self.batch_size, to_tensor=True, device=self.device)
+        num_real = int(self.batch_size * self.dynamics_real_ratio)
+        real = self.replay_buffer.sample(num_real, to_tensor=True, device=self.device)
+        model = self.dynamics_buffer.sample(self.batch_size - num_real, to_tensor=True, device=self.device)
+        mixed = tuple(th.cat([r.reshape(r.shape[0], -1), m.reshape(m.shape[0], -1)], dim=0)
+                      for r, m in zip(real[:5], model[:5]))
+        return mixed + ((real[5],) if self.per else ())
+
+    @th.no_grad()
+    def _rollout_dynamics(self, weight: th.Tensor):
+        """``gpi_pd_continuous_action.py:336-371``: imagined transitions from the noisy policy under the current weight."""
+        from .dynamics import ModelEnv
+        e = self.engine
+        dev = e.q.device
+        num_times = int(np.ceil(self.dynamics_rollout_batch_size / 10000))
+        batch_size = min(self.dynamics_rollout_batch_size, 10000)
+        weight = as_f32(weight, dev).reshape(1, -1)
+        cfg = e.make_cfg(policy_noise=self.policy_noise, noise_clip=self.noise_clip)
+        added, unc = 0, np.zeros(1)
+        for _ in range(num_times):
+            obs = self.replay_buffer.sample_obs(batch_size, to_tensor=False)
+            model_env = ModelEnv(self.dynamics, self.env.unwrapped.spec.id, rew_dim=self.reward_dim,
+                                 termination_func=self.model_termination_func)
+            for _plan_step in range(self.dynamics_rollout_len):
+                obs_t = as_f32(np.ascontiguousarray(obs, dtype=np.float32), dev)
+                n = obs_t.shape[0]
+                w = weight.repeat(n, 1)
+                # Policy.forward with noise (:50-58): one th.randn_like draw per call, the whole batch at once
+                noise = th.randn((n, self.action_dim), dtype=th.float32, device=dev)
+                actions = th.cat([e.policy_forward(obs_t[b:b + e.max_rows].contiguous(), w[b:b + e.max_rows].contiguous(),
+                                                   eps=noise[b:b + e.max_rows].contiguous(), cfg=cfg)[0]
+                                  for b in range(0, n, e.max_rows)], dim=0)
+                next_obs_pred, r_pred, dones, info = model_env.step(obs_t, actions)
+                unc = info["uncertainty"]
+                keep = unc < self.dynamics_min_uncertainty
+                obs_h, act_h = obs_t.cpu().numpy(), actions.cpu().numpy()
+                self.dynamics_buffer.add_batch(obs_h[keep], act_h[keep], r_pred[keep], next_obs_pred[keep], dones[keep])
+                added += int(keep.sum())
+                nonterm = ~dones.squeeze(-1)
+                if nonterm.sum() == 0:
+                    break
+                obs = next_obs_pred[nonterm]
+        self._last_rollout = {"imagined": added, "uncertainty_mean": float(unc.mean()), "uncertainty_max": float(unc.max()),
+                              "uncertainty_min": float(unc.min())}
+        if self.log:
+            import wandb
+            wandb.log({"dynamics/uncertainty_mean": unc.mean(), "dynamics/uncertainty_max": unc.max(),
+                       "dynamics/uncertainty_min": unc.min(), "global_step": self.global_step})
 
     # -- the hot path (gpi_pd_continuous_action.py:373-452) ---------------------------------------------------------------
     def update(self, weight: th.Tensor):
@@ -170,6 +240,7 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
             s_obs, s_actions, s_rewards, s_next_obs, s_dones = batch[:5]
             idxes = batch[5] if self.per else None
             B = s_obs.size(0)
+            n_per = idxes.numel() if idxes is not None else B      # the imagined rows of a Dyna batch carry no priority
             if len(self.weight_support) > 1:
                 s_obs, s_actions, s_rewards, s_next_obs, s_dones = (x.repeat(2, 1) for x in
                                                                     (s_obs, s_actions, s_rewards, s_next_obs, s_dones))
@@ -184,7 +255,7 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
             self._drop_seed += 1
             cfg = e.make_cfg(gamma=self.gamma, tau=self.tau, q_lr=self.learning_rate, policy_lr=self.learning_rate,
                              q_step=self._q_step, policy_step=self._p_step, do_policy=do_policy,
-                             policy_noise=self.policy_noise, noise_clip=self.noise_clip, n_per=(B if self.per else 0),
+                             policy_noise=self.policy_noise, noise_clip=self.noise_clip, n_per=(n_per if self.per else 0),
                              dropout_seed=self._drop_seed)
             noise = th.randn((rows, self.action_dim), dtype=th.float32, device=dev)
             want = ("critic_loss",) + (("policy_loss",) if do_policy else ()) + (("priority",) if self.per else ())
@@ -246,7 +317,7 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
     def train_iteration(self, total_timesteps: int, weight: np.ndarray, weight_support: List[np.ndarray],
                         change_weight_every_episode: bool = False, eval_env=None, eval_freq: int = 1000,
                         reset_num_timesteps: bool = False):
-        """``gpi_pd_continuous_action.py:493-584`` (model-free branch)."""
+        """``gpi_pd_continuous_action.py:493-584``."""
         weight_support = unique_tol(weight_support)
         self.set_weight_support(weight_support)
         dev = self.engine.q.device
@@ -263,6 +334,18 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
             next_obs, vector_reward, terminated, truncated, info = self.env.step(action)
             self.replay_buffer.add(obs, action, vector_reward, next_obs, terminated)
             if self.global_step >= self.learning_starts:
+                if self.dyna:
+                    if self.global_step % self.dynamics_train_freq == 0:
+                        m_obs, m_actions, m_rewards, m_next_obs, _ = self.replay_buffer.get_all_data()
+                        X = np.hstack((m_obs, m_actions))
+                        Y = np.hstack((m_rewards, m_next_obs - m_obs))
+                        self._last_holdout = self.dynamics.fit(X, Y, **self.dynamics_fit_kwargs)
+                        if self.log:
+                            import wandb
+                            wandb.log({"dynamics/mean_holdout_loss": self._last_holdout, "global_step": self.global_step})
+                    if self.global_step >= self.dynamics_rollout_starts and \
+                            self.global_step % self.dynamics_rollout_freq == 0:
+                        self._rollout_dynamics(tensor_w)
                 self.update(tensor_w)
             if eval_env is not None and self.log and self.global_step % eval_freq == 0:
                 self.policy_eval(eval_env, weights=weight, log=self.log)

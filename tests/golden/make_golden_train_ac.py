@@ -126,6 +126,47 @@ def main():
     out["dyna_tree_root"] = np.float64(ag.replay_buffer.tree.nodes[0][0])
     print("dyna: model buffer", nb, "elites", ag.dynamics.elites)
 
+    # ---- GPI-PD continuous with the Dyna model (critics without dropout, as above) ---------------------------------------------
+    mod = ref.gpipd_cont
+    tc.reseed(tc.SEED)
+    env = momdp.PointReach(tc.SEED, env_id=tc.GPIPD_CONT_DYNA_ENV_ID)
+    ag = mod.GPIPDContinuousAction(env, log=False, seed=tc.SEED, device="cpu", **tc.GPIPD_CONT_DYNA)
+    for lst in (ag.q_nets, ag.target_q_nets):
+        for n in range(2):
+            lst[n] = mod.QNetwork(2, 1, 2, net_arch=tc.GPIPD_CONT_DYNA["net_arch"], layer_norm=True, drop_rate=0.0)
+    for q, t in zip(ag.q_nets, ag.target_q_nets):
+        t.load_state_dict(q.state_dict())
+        for p in t.parameters():
+            p.requires_grad = False
+    ag.q_optim = th.optim.Adam([p for net in ag.q_nets for p in net.parameters()], lr=ag.learning_rate)
+    ref_fit_c = ag.dynamics.fit
+    ag.dynamics.fit = lambda X, Y: ref_fit_c(X, Y, **tc.GPIPD_DYNA_FIT)
+    uncs, ref_step = [], mod.ModelEnv.step
+
+    def recording_step(self, obs, act, deterministic=False):     # observe only: which uncertainties does the filter see?
+        res = ref_step(self, obs, act, deterministic)
+        uncs.append(np.asarray(res[3]["uncertainty"]).copy())
+        return res
+    mod.ModelEnv.step = recording_step
+    nets = ag.q_nets + ag.target_q_nets + [ag.policy, ag.target_policy]
+    dump(out, "dynac_init", params_of(nets))
+    for l, layer in enumerate(ag.dynamics.layers):
+        out[f"dynac_model_init_W{l}"], out[f"dynac_model_init_b{l}"] = layer.W.detach().numpy().copy(), layer.b.detach().numpy().copy()
+    tc.reseed()
+    ag.train_iteration(total_timesteps=tc.GPIPD_CONT_DYNA_STEPS, weight=tc.WEIGHT.copy(),
+                       weight_support=[s.copy() for s in tc.SUPPORT], change_weight_every_episode=True)
+    dump(out, "dynac_final", params_of(nets))
+    out["dynac_actions"] = np.asarray(env.action_log)
+    nb = len(ag.dynamics_buffer)
+    out["dynac_model_buffer"] = np.array([nb, ag.dynamics_buffer.ptr])
+    out["dynac_model_obs"] = ag.dynamics_buffer.obs[:nb].copy()
+    out["dynac_model_actions"] = ag.dynamics_buffer.actions[:nb].copy()
+    out["dynac_model_rewards"] = ag.dynamics_buffer.rewards[:nb].copy()
+    out["dynac_tree_root"] = np.float64(ag.replay_buffer.tree.nodes[0][0])
+    mod.ModelEnv.step = ref_step
+    print("dyna continuous: model buffer", nb, "elites", ag.dynamics.elites, "uncertainty quantiles",
+          np.quantile(np.concatenate(uncs), [0.0, 0.25, 0.5, 0.75, 1.0]))
+
     # ---- MOSAC with discrete actions -------------------------------------------------------------------------------------------
     tc.reseed(tc.SEED)
     env = momdp.TreasureLine(tc.SEED)

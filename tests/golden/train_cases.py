@@ -30,6 +30,12 @@ GPIPD_DYNA_TRAIN_FREQ = 12
 GPIPD_DYNA_FIT = dict(max_epochs=6)    # few epochs: early stopping is a discrete decision that amplifies fp32 round-off
 GPIPD_DYNA_STEPS = 44
 GPIPD_DYNA_ENV_ID = "mo-mountaincar-like-treasure-v0"     # any id the reference's ModelEnv has a termination rule for
+GPIPD_CONT_DYNA = dict(net_arch=[16, 16], batch_size=8, learning_starts=16, buffer_size=500, gradient_updates=2, per=True,
+                       dyna=True, dynamics_net_arch=[16, 16], dynamics_train_freq=12, dynamics_rollout_len=2,
+                       dynamics_rollout_starts=24, dynamics_rollout_freq=6, dynamics_rollout_batch_size=20,
+                       dynamics_buffer_size=300, dynamics_min_uncertainty=3.143, dynamics_real_ratio=0.5)
+GPIPD_CONT_DYNA_STEPS = 44
+GPIPD_CONT_DYNA_ENV_ID = "mo-mountaincar-like-point-v0"   # terminates imagined roll-outs at x >= 0.45
 SUPPORT = [np.array([1.0, 0.0], dtype=np.float32), np.array([0.0, 1.0], dtype=np.float32),
            np.array([0.5, 0.5], dtype=np.float32)]
 WEIGHT = np.array([0.4, 0.6], dtype=np.float32)

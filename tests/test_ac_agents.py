@@ -368,8 +368,20 @@ def test_short_training_runs(be):
                        change_weight_every_episode=True)
     assert gp.global_step == 14 and gp._n_updates == 10 and gp._p_step == 5
     assert np.isfinite(gp.replay_buffer.tree_dev.cpu().numpy()).all()
-    with pytest.raises(NotImplementedError):
-        GPIPDContinuousAction(BoxEnv(D=4, Ad=2), log=False, device=dev, lib=lib)      # dyna=True (reference default)
+    # GPI-PD proper: ensemble fit, noisy-policy roll-outs into the model buffer, mixed batches (parity: test_train_traces.py)
+    env = BoxEnv(D=4, Ad=2)
+    env.spec.id = "mo-halfcheetah-like-box-v0"                                        # an id with a termination rule (never done)
+    pd = GPIPDContinuousAction(env, net_arch=[16, 16], batch_size=8, buffer_size=128, learning_starts=10, gradient_updates=2,
+                               per=True, log=False, seed=0, device=dev, lib=lib, dynamics_net_arch=[16, 16],
+                               dynamics_train_freq=12, dynamics_rollout_len=2, dynamics_rollout_starts=12,
+                               dynamics_rollout_freq=6, dynamics_rollout_batch_size=12, dynamics_buffer_size=64,
+                               dynamics_min_uncertainty=1e9, dynamics_real_ratio=0.5, dynamics_max_rows=256)
+    pd.dynamics_fit_kwargs = dict(max_epochs=3)
+    pd.train_iteration(total_timesteps=26, weight=np.array([0.5, 0.5]), weight_support=sup)
+    assert pd.global_step == 26 and len(pd.dynamics_buffer) > 0 and pd._last_rollout["imagined"] == 2 * 12
+    b = pd._sample_batch_experiences()
+    assert b[0].shape[0] == 8 and b[1].shape == (8, 2) and b[5].numel() == 4       # half real (with PER indices), half imagined
+    assert np.isfinite(pd.engine.q.cpu().numpy()).all() and np.isfinite(pd._last_holdout)
 
 
 def test_mosac_discrete_update_and_morld_population(be):

@@ -166,3 +166,33 @@ def test_gpipd_dyna_trace(sim):
     assert float(ag.replay_buffer.tree.nodes[0][0]) == pytest.approx(float(g["dyna_tree_root"]), rel=1e-3)
     print(f"\nGPI-PD + Dyna: {tc.GPIPD_DYNA_STEPS} steps / {ag._adam_step} updates, {nb} imagined transitions, "
           f"max parameter deviation {worst:.2e}")
+
+
+def test_gpipd_continuous_dyna_trace(sim):
+    """GPI-PD with continuous actions and the Dyna model: ensemble fits, roll-outs with the noisy TD3 policy, the
+    uncertainty filter, mixed real / imagined batches with PER on the real half -- against the reference's seeded run."""
+    from morl_baselines_amd.gpi_pd_continuous import GPIPDContinuousAction
+    g = np.load(GOLD)
+    tc.reseed(tc.SEED)
+    env = momdp.PointReach(tc.SEED, env_id=tc.GPIPD_CONT_DYNA_ENV_ID)
+    ag = GPIPDContinuousAction(env, log=False, seed=tc.SEED, device="cpu", lib=sim, q_drop_rate=0.0, dynamics_max_rows=256,
+                               **tc.GPIPD_CONT_DYNA)
+    params = load_init(g, "dynac_init", ag.q_nets + ag.target_q_nets + [ag.policy, ag.target_policy])
+    ag.dynamics_fit_kwargs = dict(tc.GPIPD_DYNA_FIT)
+    nl = len(tc.GPIPD_CONT_DYNA["dynamics_net_arch"]) + 1
+    sd = ag.dynamics.state_dict()
+    ag.dynamics.load_state_dict({**sd, **{f"layers.{l}.W": th.tensor(g[f"dynac_model_init_W{l}"]) for l in range(nl)},
+                                 **{f"layers.{l}.b": th.tensor(g[f"dynac_model_init_b{l}"]) for l in range(nl)}})
+    tc.reseed()
+    ag.train_iteration(total_timesteps=tc.GPIPD_CONT_DYNA_STEPS, weight=tc.WEIGHT.copy(),
+                       weight_support=[s.copy() for s in tc.SUPPORT], change_weight_every_episode=True)
+    np.testing.assert_allclose(np.asarray(env.action_log), g["dynac_actions"], rtol=0, atol=5e-5)
+    assert [len(ag.dynamics_buffer), ag.dynamics_buffer.ptr] == g["dynac_model_buffer"].tolist()
+    nb = len(ag.dynamics_buffer)
+    np.testing.assert_allclose(ag.dynamics_buffer.obs[:nb], g["dynac_model_obs"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(ag.dynamics_buffer.actions[:nb], g["dynac_model_actions"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(ag.dynamics_buffer.rewards[:nb], g["dynac_model_rewards"], rtol=0, atol=2e-4)
+    worst = check_final(g, "dynac_final", params, atol=2e-4)
+    assert float(ag.replay_buffer.tree.nodes[0][0]) == pytest.approx(float(g["dynac_tree_root"]), rel=1e-3)
+    print(f"\nGPI-PD continuous + Dyna: {tc.GPIPD_CONT_DYNA_STEPS} steps / {ag._n_updates} updates, {nb} imagined transitions, "
+          f"max parameter deviation {worst:.2e}")
