@@ -174,6 +174,18 @@ int morl_polyak(const float* src, float* dst, float tau, int64_t n, void* stream
  * points: device float64 [N][R]; mask_out: device uint8 [N] (1 = keep).  Bit-exact boolean result. */
 int morl_pareto_mask(const double* points, int N, int R, int remove_duplicates, uint8_t* mask_out, void* stream);
 
+/* ---- front metrics: common/performance_indicators.py -------------------------------------------------------------
+ * hypervolume(ref_point, points) (:15-25; the reference negates both and calls pymoo's minimisation HV -- the quantity
+ * is the volume dominated by the points and dominating ref_point) and expected_utility(front, weights_set) (:71-91,
+ * utility = dot).  All arrays are device float64: points / front [N][R], ref_point [R], weights [M][R]; results are
+ * one device double each.  workspace: morl_metrics_workspace_doubles(N, R) doubles (the larger of the two calls' needs;
+ * M <= 4096 weight vectors).  Exact up to the rounding of a fixed-order fp64 sum; N <= 512 points. */
+int64_t morl_metrics_workspace_doubles(int N, int R);
+int morl_hypervolume(const double* points, int N, int R, const double* ref_point, double* workspace, double* hv_out,
+                     void* stream);
+int morl_expected_utility(const double* front, int N, int R, const double* weights, int M, double* workspace,
+                          double* eum_out, void* stream);
+
 /* ---- PER sum-tree: common/prioritized_buffer.py:12-82 (device-resident) -------------------------
  * tree: device float64, levels concatenated root first; level l has 2^l nodes and starts at offset
  * 2^l - 1; n_levels = ceil(log2(capacity)) + 1.

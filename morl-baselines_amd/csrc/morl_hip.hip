@@ -22,6 +22,7 @@
 #include "optim_kernels.h"
 #include "replay_kernels.h"
 #include "pareto_kernels.h"
+#include "metrics_kernels.h"
 
 using namespace morl;
 
@@ -915,6 +916,58 @@ extern "C" int morl_pareto_mask(const double* points, int N, int R, int remove_d
     hipLaunchKernelGGL(pareto_mask_kernel, dim3((N + PARETO_THREADS - 1) / PARETO_THREADS), dim3(PARETO_THREADS), 0,
                        (hipStream_t)stream, points, N, R, remove_duplicates, mask_out);
     LAUNCH_CHECK("pareto_mask");
+    return MORL_OK;
+}
+
+// ---- front metrics (performance_indicators.py:15-25, 71-91) ---------------------------------------------------------------
+extern "C" int64_t morl_metrics_workspace_doubles(int N, int R) {
+    if (N < 0 || R < 1) return -1;
+    return (int64_t)std::max(R - 1, 0) * N + HV_MAX_BLOCKS;
+}
+
+extern "C" int morl_hypervolume(const double* points, int N, int R, const double* ref_point, double* workspace,
+                                double* hv_out, void* stream) {
+    if (!ref_point || !hv_out || (N > 0 && (!points || !workspace))) return fail(MORL_ERR_ARG, "NULL array");
+    if (N < 0 || N > HV_MAX_N || R < 1 || R > MORL_MAX_OBJ)
+        return fail(MORL_ERR_ARG, "bad sizes N=%d R=%d (N <= %d, R <= %d)", N, R, HV_MAX_N, MORL_MAX_OBJ);
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        HIP_TRY(hipMemsetAsync(hv_out, 0, sizeof(double), s));
+        return MORL_OK;
+    }
+    double boxes = 1.0;
+    for (int d = 0; d < R - 1; ++d) boxes *= (double)N;
+    if (boxes * (double)N > 4e11)
+        return fail(MORL_ERR_ARG, "hypervolume of %d points in %d objectives needs %.3g point tests (limit 4e11)", N, R,
+                    boxes * (double)N);
+    const long long n_boxes = (long long)boxes;
+    double* coords = workspace;
+    double* part = workspace + (size_t)(R - 1) * N;
+    if (R > 1) {
+        hipLaunchKernelGGL(hv_sort_kernel, dim3(R - 1), dim3(HV_THREADS), 0, s, points, N, R, ref_point, coords);
+        LAUNCH_CHECK("hv_sort");
+    }
+    const int blocks = (int)std::max(1ll, std::min<long long>(HV_MAX_BLOCKS, (n_boxes + HV_THREADS - 1) / HV_THREADS));
+    hipLaunchKernelGGL(hv_boxes_kernel, dim3(blocks), dim3(HV_THREADS), 0, s, points, N, R, ref_point, (const double*)coords,
+                       n_boxes, part);
+    LAUNCH_CHECK("hv_boxes");
+    hipLaunchKernelGGL(metric_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)part, blocks, 1.0, hv_out);
+    LAUNCH_CHECK("hv_finish");
+    return MORL_OK;
+}
+
+extern "C" int morl_expected_utility(const double* front, int N, int R, const double* weights, int M, double* workspace,
+                                     double* eum_out, void* stream) {
+    if (!front || !weights || !workspace || !eum_out) return fail(MORL_ERR_ARG, "NULL array");
+    if (N < 1 || M < 1 || R < 1 || R > MORL_MAX_OBJ || (M + 3) / 4 > HV_MAX_BLOCKS)
+        return fail(MORL_ERR_ARG, "bad sizes N=%d M=%d R=%d (M <= %d, R <= %d)", N, M, R, 4 * HV_MAX_BLOCKS, MORL_MAX_OBJ);
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (M + HV_THREADS / 64 - 1) / (HV_THREADS / 64);
+    hipLaunchKernelGGL(eum_kernel, dim3(blocks), dim3(HV_THREADS), 0, s, front, N, R, weights, M, workspace);
+    LAUNCH_CHECK("eum");
+    hipLaunchKernelGGL(metric_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, blocks, 1.0 / (double)M,
+                       eum_out);
+    LAUNCH_CHECK("eum_finish");
     return MORL_OK;
 }
 

@@ -102,3 +102,24 @@ def front_returns(agent, eval_env, eval_weights: Sequence[np.ndarray], rep: int 
         res = policy_evaluation_mo_batched(agent, list(eval_env[:len(eval_weights)]), list(eval_weights), rep=rep)
         return [r[3] for r in res]
     return [policy_evaluation_mo(agent, eval_env, ew, rep=rep)[3] for ew in eval_weights]
+
+
+def multi_policy_metrics(current_front: Sequence[np.ndarray], hv_ref_point: np.ndarray, weights_set: Sequence[np.ndarray],
+                         ref_front: Optional[Sequence[np.ndarray]] = None, mul_weights: Optional[np.ndarray] = None,
+                         lib=None, device=None) -> dict:
+    """The numbers ``log_all_multi_policy_metrics`` (``evaluation.py:147-198``) logs, as a dict and without pymoo / wandb:
+    Pareto filter (``morl_pareto_mask``), hypervolume and expected utility on the device (``morl_hypervolume``,
+    ``morl_expected_utility``), cardinality; with a known front also IGD and the maximum utility loss.  The weight sets are
+    the caller's (the reference draws them with pymoo's Riesz s-energy directions)."""
+    from . import performance_indicators as pi
+    from .pareto import filter_pareto_dominated
+
+    front = list(filter_pareto_dominated(current_front, lib=lib, device=device))
+    out = {"eval/hypervolume": pi.hypervolume(hv_ref_point, front, lib=lib, device=device),
+           "eval/eum": pi.expected_utility(front, list(weights_set), lib=lib, device=device),
+           "eval/cardinality": pi.cardinality(front), "front": front}
+    if ref_front is not None:
+        out["eval/igd"] = pi.igd(known_front=list(ref_front), current_estimate=front)
+        out["eval/mul"] = pi.maximum_utility_loss(front=front, reference_set=list(ref_front),
+                                                  weights_set=weights_set if mul_weights is None else mul_weights)
+    return out

@@ -133,6 +133,10 @@ _SIGNATURES = {
     "morl_clip_adam": (C.c_int, [C.c_void_p] * 5 + [C.POINTER(UpdateCfg), C.c_void_p, C.c_void_p]),
     "morl_polyak": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
     "morl_pareto_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "morl_metrics_workspace_doubles": (C.c_int64, [C.c_int, C.c_int]),
+    "morl_hypervolume": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "morl_expected_utility": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "morl_sumtree_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "morl_sumtree_set": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "morl_sumtree_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
