@@ -315,6 +315,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-mode", type=int, default=0, help="0 auto, 1 LDS tiles, 2 wave tiles (morl_ac_set_gemm_mode)")
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--force-dp", action="store_true",
+                    help="capql on ONE rank through the data-parallel path (gradient hook + RCCL all-reduce with itself)")
     a = ap.parse_args()
     if not th.cuda.is_available():
         raise SystemExit("bench_ac.py needs an MI355X (no CPU fallback exists)")
@@ -324,12 +326,14 @@ def main():
     dev = th.device("cuda", local_rank)
     th.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        if a.workload != "morld":
-            raise SystemExit("only the MORL/D population shards over GPUs (independent learners, no collective)")
+        if world > 1 and a.workload not in ("morld", "capql"):
+            raise SystemExit("--gpus N: the MORL/D population shards as independent learners (no collective); CAPQL runs "
+                             "data-parallel (gradient all-reduce inside the update)")
     if a.workload == "gpi":
         return bench_gpi(a)
     if a.workload == "ens":
@@ -340,7 +344,8 @@ def main():
     D, Ad, R = shp["D"], shp["Ad"], shp["R"]
     pop = a.pop if a.pop is not None else (64 if wl == "morld" else 1)
     pop_total = pop
-    if world > 1:
+    dp = (world > 1 or a.force_dp) and wl == "capql"         # data-parallel: every rank B rows of the job's world * B batch, grads averaged
+    if world > 1 and not dp:
         if pop % world:
             raise SystemExit(f"--pop {pop} must be divisible by the number of GPUs")
         pop = pop // world                       # this rank's learners
@@ -369,6 +374,12 @@ def main():
     w = th.softmax(rnd(pop, rows if eng.w_input else 1, R), dim=-1).contiguous()
     iters = 2 if algo == ALGO_MOSAC else 1
     state = {"seed": 0}
+    sync = None
+    if dp:
+        from morl_baselines_amd.distributed import average_gradients
+        sync = average_gradients(dist)
+        for buf in (eng.q, eng.pol, eng.q_target):
+            dist.broadcast(buf, src=0)
 
     def step():
         state["seed"] += 1
@@ -376,7 +387,7 @@ def main():
                            target_entropy=-float(Ad), n_per=(B if wl == "gpipd" else 0), dropout_seed=state["seed"])
         eps = th.randn((1 + 2 * iters, pop, rows, Ad), dtype=th.float32, device=dev)      # the host agents draw these too
         eng.update(cfg, obs=obs, actions=act, rewards=rew, next_obs=nobs, dones=done, w=w, eps_next=eps[0],
-                   eps_pi=eps[1:1 + iters], eps_alpha=eps[1 + iters:], want=("critic_loss",))
+                   eps_pi=eps[1:1 + iters], eps_alpha=eps[1 + iters:], want=("critic_loss",), grad_sync=sync)
 
     for _ in range(a.warmup):
         step()
@@ -395,6 +406,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
         pop = pop_total
+        if dp:
+            rows = rows * world              # the job's batch
         if rank != 0:
             dist.destroy_process_group()
             return
@@ -403,13 +416,17 @@ def main():
     tf = flop / (ms * 1e-3) / 1e12
     out = {
         "metric": "actor-critic learner updates/sec", "value": pop * a.steps / wall, "unit": "learner-updates/s",
+        "rows_per_s": pop * rows * a.steps / wall,
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
-        "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak" if (world == 1 or dp) else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{wl}: {pop} learner(s) x batch {B} ({rows} rows), net {ARCH}, twin critics, shapes of "
                                f"{shp['env']} (obs {D}, act {Ad}, {R} objectives); one morl_ac_update per step",
                    "population": pop, "rows": rows,
-                   "parallelism": "single GPU" if world == 1 else f"population split over {world} GPUs ({pop // world} "
-                                  "learners each), independent replicas, no data-path collective"},
+                   "parallelism": "single GPU" if world == 1 else
+                                  (f"data-parallel over {world} GPUs: {rows // world} rows each, critic and actor gradients "
+                                   "all-reduced (RCCL) inside the update, identical Adam steps" if dp else
+                                   f"population split over {world} GPUs ({pop // world} learners each), independent "
+                                   "replicas, no data-path collective")},
         "roofline": {"bound": "mfma", "kernel": "gemm_batched (exact-fp32 MFMA layers of all nets / learners)",
                      "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
                      "traffic": None,

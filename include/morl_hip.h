@@ -31,7 +31,7 @@ extern "C" {
 
 #define MORL_MAX_LAYERS 8   /* linear layers per network */
 #define MORL_MAX_OBJ 8      /* reward dimension R */
-#define MORL_ABI_VERSION 2
+#define MORL_ABI_VERSION 3
 
 typedef enum morl_status {
     MORL_OK = 0,
@@ -252,6 +252,9 @@ typedef struct morl_ac_desc {
     int32_t max_rows;                /* largest number of batch rows of one learner (2 * batch_size for GPI-PD) */
 } morl_ac_desc;
 
+/* see morl_ac_cfg.grad_hook */
+typedef int (*morl_grad_hook)(void* user, int which, float* grads, int64_t count, void* stream);
+
 typedef struct morl_ac_cfg {
     float gamma, tau;
     float alpha;                     /* entropy coefficient when it is not learnt (CAPQL; MOSAC autotune = 0) */
@@ -267,6 +270,13 @@ typedef struct morl_ac_cfg {
     float policy_noise, noise_clip;  /* TD3 target policy smoothing */
     int32_t n_per;                   /* TD3: rows whose |TD| priorities are written (0 = none) */
     uint64_t dropout_seed;           /* changes every call */
+    /* Data-parallel learners (several processes, each with its own rows of the batch): when grad_hook is set, the critic
+     * gradients (which = 0, out->q_grads, required) and the actor gradients (which = 1, out->pol_grads, required when
+     * do_policy) are handed to the hook BEFORE their Adam step; the hook reduces them in place over the job (e.g. an RCCL
+     * all-reduce AVG enqueued so that `stream` waits for it) and returns 0.  Every process then takes the identical step.
+     * Not available with a learnt entropy coefficient (autotune) or the discrete-action SAC. */
+    morl_grad_hook grad_hook;
+    void* grad_hook_user;
 } morl_ac_cfg;
 
 /* caller-owned device state of the learners */

@@ -14,7 +14,7 @@ import numpy as np
 import torch as th
 
 from . import native
-from .native import ACBatch, ACCfg, ACDesc, ACOut, ACState, NativeLib
+from .native import GRAD_HOOK, ACBatch, ACCfg, ACDesc, ACOut, ACState, NativeLib
 
 ALGO_CAPQL, ALGO_MOSAC, ALGO_TD3, ALGO_SACD = 0, 1, 2, 3
 
@@ -170,20 +170,22 @@ class ACEngine:
 
     def update(self, cfg: ACCfg, *, obs, actions, rewards, next_obs, dones, w, eps_next=None, eps_pi=None, eps_alpha=None,
                drop_masks: Optional[th.Tensor] = None, want: Sequence[str] = ("critic_loss", "policy_loss"),
-               first: int = 0, count: Optional[int] = None) -> Dict:
+               first: int = 0, count: Optional[int] = None, grad_sync=None) -> Dict:
         """One ``morl_ac_update``.  Array shapes as in include/morl_hip.h (leading [pop] axis may be omitted when
         population == 1).  ``first`` / ``count``: advance only learners first .. first+count-1 (the arrays then hold
-        ``count`` learners).  Returns the requested device outputs (no host synchronisation)."""
+        ``count`` learners).  Returns the requested device outputs (no host synchronisation).
+        ``grad_sync(which, grads)``: data-parallel job -- reduce the critic (0) / actor (1) gradient tensor in place over
+        the processes before its Adam step (``morl_ac_cfg.grad_hook``; see ``distributed.average_gradients``)."""
         obs = self._f32(obs, "obs")
         full_pop = self.pop
         count = full_pop - first if count is None else count
         if first < 0 or count < 1 or first + count > full_pop:
             raise ValueError(f"learners {first}..{first + count - 1} outside the population of {full_pop}")
         return self._update(cfg, obs, count, first, actions, rewards, next_obs, dones, w, eps_next, eps_pi, eps_alpha,
-                            drop_masks, want)
+                            drop_masks, want, grad_sync)
 
     def _update(self, cfg, obs, pop, first, actions, rewards, next_obs, dones, w, eps_next, eps_pi, eps_alpha,
-                drop_masks, want):
+                drop_masks, want, grad_sync=None):
         rows = obs.numel() // (pop * self.D)
         keep = [obs]
         b = ACBatch()
@@ -217,13 +219,34 @@ class ACEngine:
                       alpha=(pop,), priority=(pop, max(cfg.n_per, 1)),
                       target_q=(pop, rows) if self.algo in (ALGO_MOSAC, ALGO_SACD) else (pop, rows, self.R),
                       q_grads=(pop, self.num_q, self.Pq), pol_grads=(pop, self.Pp))
+        hook_error: List[BaseException] = []
+        if grad_sync is not None:
+            want = tuple(want) + tuple(n for n in ("q_grads",) + (("pol_grads",) if cfg.do_policy else ()) if n not in want)
         for name in want:
             res[name] = th.zeros(shapes[name], dtype=th.float32, device=self.q.device)
             setattr(o, name, res[name].data_ptr())
         del iters
+        hook = None
+        if grad_sync is not None:
+            def _hook(_user, which, _ptr, _count, _stream):
+                try:
+                    grad_sync(int(which), res["q_grads" if which == 0 else "pol_grads"])
+                    return 0
+                except BaseException as e:  # noqa: BLE001  (must not propagate through the C frame)
+                    hook_error.append(e)
+                    return 1
+            hook = GRAD_HOOK(_hook)
+            cfg.grad_hook = C.cast(hook, C.c_void_p).value
+            cfg.grad_hook_user = None
         st = self._state(first)
-        self.lib.check(self.lib.lib.morl_ac_update(self._h, C.byref(st), C.byref(b), C.byref(cfg), C.byref(o),
-                                                   self.lib.stream_of(self.q)))
+        try:
+            rc = self.lib.lib.morl_ac_update(self._h, C.byref(st), C.byref(b), C.byref(cfg), C.byref(o),
+                                             self.lib.stream_of(self.q))
+        finally:
+            cfg.grad_hook = None
+        if hook_error:
+            raise hook_error[0]
+        self.lib.check(rc)
         return res
 
     def policy_forward(self, obs, w=None, *, eps=None, use_target=False, cfg: Optional[ACCfg] = None,

@@ -571,6 +571,12 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     if (cfg->do_policy && algo != MORL_AC_TD3 && algo != MORL_AC_SACD && !bt->eps_pi) return fail(MORL_ERR_ARG, "eps_pi is NULL");
     if (cfg->do_policy && autotune && algo == MORL_AC_MOSAC && !bt->eps_alpha) return fail(MORL_ERR_ARG, "eps_alpha is NULL");
     if (cfg->n_per < 0 || cfg->n_per > rows) return fail(MORL_ERR_ARG, "n_per %d outside 0..rows", cfg->n_per);
+    if (cfg->grad_hook) {
+        if (autotune || algo == MORL_AC_SACD)
+            return fail(MORL_ERR_ARG, "grad_hook: a learnt entropy coefficient / discrete SAC is not data-parallel here");
+        if (!out->q_grads || (cfg->do_policy && !out->pol_grads))
+            return fail(MORL_ERR_ARG, "grad_hook needs out->q_grads (and out->pol_grads with do_policy)");
+    }
     const Mlp &Q = c->q, &P = c->pol;
     // learners advanced by this call (a leading sub-range of the context's capacity)
     if (bt->active < 0 || bt->active > d.population) return fail(MORL_ERR_STATE, "active %d outside 0..population %d", bt->active, d.population);
@@ -645,6 +651,12 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_b, rows, nq, Q.drop > 0.f, c->gq, false, s))) return rc;
     if (out->q_grads)
         HIP_TRY(hipMemcpyAsync(out->q_grads, c->gq, (size_t)c->QG * Q.P * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (cfg->grad_hook) {
+        // data-parallel job: the caller's buffer is reduced over the processes, then becomes the gradient of the step
+        if (cfg->grad_hook(cfg->grad_hook_user, 0, out->q_grads, (int64_t)c->QG * Q.P, stream))
+            return fail(MORL_ERR_STATE, "grad_hook failed on the critic gradients");
+        HIP_TRY(hipMemcpyAsync(c->gq, out->q_grads, (size_t)c->QG * Q.P * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
     if ((rc = adam(st->q, c->gq, st->q_exp_avg, st->q_exp_avg_sq, (long long)nq * Q.P, PG, cfg->q_lr, st->q_steps,
                    st->q_steps ? 1 : cfg->q_step, cfg, s))) return rc;
 
@@ -683,6 +695,11 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
             if ((rc = mlp_backward(P, st->pol, P.P, c->tp_b, rows, 1, false, c->gp, false, s))) return rc;
             if (out->pol_grads)
                 HIP_TRY(hipMemcpyAsync(out->pol_grads, c->gp, (size_t)c->PG * P.P * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if (cfg->grad_hook) {
+                if (cfg->grad_hook(cfg->grad_hook_user, 1, out->pol_grads, (int64_t)c->PG * P.P, stream))
+                    return fail(MORL_ERR_STATE, "grad_hook failed on the actor gradients");
+                HIP_TRY(hipMemcpyAsync(c->gp, out->pol_grads, (size_t)c->PG * P.P * sizeof(float), hipMemcpyDeviceToDevice, s));
+            }
             if ((rc = adam(st->pol, c->gp, st->pol_exp_avg, st->pol_exp_avg_sq, P.P, PG, cfg->policy_lr, st->pol_steps,
                            (st->pol_steps ? 1 : cfg->policy_step) + it, cfg, s))) return rc;
             if (autotune) {

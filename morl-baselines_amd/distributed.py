@@ -15,6 +15,12 @@ SAME batch and the SAME W sampled weights (identical seeds => identical host RNG
 Messages are far below the size where a ring would be bandwidth-bound on the point-to-point xGMI links; they are
 latency-bound, so the exchange is kept to two collectives per step and both operate on single contiguous buffers.
 The data path has real exchange steps, hence this is *strong* scaling of one 256 x 64 update.
+
+Actor-critic learners (CAPQL, BASELINE config 4) are data-parallel instead: ``shard_capql_agent`` gives every rank its own
+rows of the (transition, weight-vector) batch; the critic and the actor gradients are averaged over the ranks inside
+``morl_ac_update`` (``morl_ac_cfg.grad_hook`` -> one all-reduce each, 0.3 MB / 0.3 MB at [256, 256]) right before their
+Adam steps, so every replica takes the identical step.  A 128-row update is dispatch-latency-bound, so this is *weak*
+scaling: per-rank rows stay at ``batch_size`` and the job's batch is ``world * batch_size``.
 """
 from __future__ import annotations
 
@@ -25,6 +31,50 @@ import torch as th
 
 from . import ops
 from .envelope import Envelope, random_weights
+
+
+def average_gradients(dist, group=None):
+    """``grad_sync`` callable for ``ACEngine.update``: in-place mean over the ranks.  On RCCL the collective runs on its
+    own stream; ``wait()`` makes the update's stream wait for it without blocking the host."""
+    world = dist.get_world_size(group)
+    avg = dist.get_backend(group) == "nccl"            # RCCL averages in the collective; gloo only sums
+
+    def sync(_which: int, grads: th.Tensor):
+        work = dist.all_reduce(grads, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True)
+        work.wait()
+        if not avg:
+            grads.mul_(1.0 / world)
+    return sync
+
+
+def shard_capql_agent(agent, dist, group=None):
+    """Data-parallel CAPQL: every rank keeps a full replica (identical initial parameters are the caller's job: same seed
+    or a broadcast) and ITS OWN replay shard / RNG streams; ``update`` averages the critic and actor gradients over the
+    ranks before each Adam step.  The job's batch is ``world * agent.batch_size`` rows."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sync = average_gradients(dist, group)
+    agent._shard = types.SimpleNamespace(world=world, rank=rank)
+    for buf in (agent.engine.q, agent.engine.pol):         # replicas start from rank 0's parameters
+        dist.broadcast(buf, src=0, group=group)
+    agent.engine.q_target.copy_(agent.engine.q)
+
+    def update(self):
+        e = self.engine
+        for _ in range(self.gradient_updates):
+            s_obs, s_actions, w, s_rewards, s_next_obs, s_dones = self._sample_batch_experiences()
+            B = s_obs.shape[0]
+            eps = (th.randn((B, self.action_dim), dtype=th.float32, device=e.q.device),
+                   th.randn((B, self.action_dim), dtype=th.float32, device=e.q.device))
+            self._q_step += 1
+            self._p_step += 1
+            cfg = e.make_cfg(gamma=self.gamma, tau=self.tau, alpha=self.alpha, q_lr=self.learning_rate,
+                             policy_lr=self.learning_rate, q_step=self._q_step, policy_step=self._p_step)
+            self._out = e.update(cfg, obs=s_obs, actions=s_actions, rewards=s_rewards, next_obs=s_next_obs,
+                                 dones=s_dones, w=w, eps_next=eps[0], eps_pi=eps[1], grad_sync=sync)
+            self._n_updates += 1
+
+    agent.update = types.MethodType(update, agent)
+    return agent
 
 
 def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:

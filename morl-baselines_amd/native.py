@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
 
 MORL_MAX_LAYERS = 8
 MORL_MAX_OBJ = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class NetDesc(C.Structure):
@@ -49,7 +49,12 @@ class ACCfg(C.Structure):
                 ("q_step", C.c_int32), ("policy_step", C.c_int32), ("do_policy", C.c_int32),
                 ("policy_iters", C.c_int32), ("do_target", C.c_int32), ("autotune", C.c_int32),
                 ("target_entropy", C.c_float), ("policy_noise", C.c_float), ("noise_clip", C.c_float),
-                ("n_per", C.c_int32), ("dropout_seed", C.c_uint64)]
+                ("n_per", C.c_int32), ("dropout_seed", C.c_uint64),
+                ("grad_hook", C.c_void_p), ("grad_hook_user", C.c_void_p)]
+
+
+# int hook(void* user, int which, float* grads, int64_t count, void* stream) -- morl_ac_cfg.grad_hook
+GRAD_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
 
 
 AC_STATE_FIELDS = ("q", "q_target", "q_exp_avg", "q_exp_avg_sq", "pol", "pol_exp_avg", "pol_exp_avg_sq", "pol_target",

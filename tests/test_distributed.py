@@ -81,3 +81,83 @@ def test_sharded_update_equals_single_process(per):
     if per:
         assert np.array_equal(t0, t1)
         np.testing.assert_allclose(t0[0], want_tree[0], rtol=1e-5)
+
+
+# ---- data-parallel CAPQL (BASELINE config 4): gradients averaged inside morl_ac_update -----------------------------------------
+def _capql_case():
+    from cases_ac import ACCase
+    return ACCase("capql_dp", "capql", D=7, Ad=2, R=3, arch=(32, 32), B=24, step=3, seed=11)
+
+
+def _dp_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "oracle")]
+    import torch.distributed as dist
+    import simlib
+    import morl_baselines_amd.native as native
+    from morl_baselines_amd.distributed import average_gradients
+    from cases_ac import make_inputs
+    from test_ac_kernels_parity import build_engine, engine_state, run_engine
+    th.set_num_threads(1)
+    lib = simlib.load_sim()
+    native.use_library(lib)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = _capql_case()
+    inp = make_inputs(c)
+    half = c.B // world
+    rows = slice(rank * half, (rank + 1) * half)
+    loc = dict(inp)
+    for k in ("obs", "actions", "rewards", "next_obs", "dones", "w", "eps_next"):
+        loc[k] = inp[k][rows]
+    loc["eps_pi"] = [inp["eps_pi"][0][rows]]
+    eng = build_engine(c, inp, lib, th.device("cpu"))            # identical replicas, each with its own rows
+    sync = average_gradients(dist)
+    cfg = eng.make_cfg(gamma=c.gamma, tau=c.tau, alpha=c.alpha, q_lr=c.lr, policy_lr=c.lr, q_step=c.step, policy_step=c.step)
+    res = eng.update(cfg, obs=loc["obs"], actions=loc["actions"], rewards=loc["rewards"], next_obs=loc["next_obs"],
+                     dones=loc["dones"], w=loc["w"], eps_next=loc["eps_next"], eps_pi=loc["eps_pi"][0],
+                     want=("critic_loss", "policy_loss"), grad_sync=sync)
+    st = engine_state(c, eng)
+    ret[rank] = (eng.q.clone().numpy(), eng.pol.clone().numpy(), eng.q_target.clone().numpy(),
+                 float(res["critic_loss"][0]), float(res["policy_loss"][0]), res["q_grads"].clone().numpy(),
+                 [[p.numpy() for p in n] for n in st["q"]], [p.numpy() for p in st["pol"]])
+    # a failing hook surfaces as a Python exception on every rank, not as a hang or a silent local step
+    def broken(which, g):
+        raise RuntimeError("sync failed")
+    try:
+        eng.update(cfg, obs=loc["obs"], actions=loc["actions"], rewards=loc["rewards"], next_obs=loc["next_obs"],
+                   dones=loc["dones"], w=loc["w"], eps_next=loc["eps_next"], eps_pi=loc["eps_pi"][0], grad_sync=broken)
+        ret[f"err{rank}"] = "no error"
+    except RuntimeError as e:
+        ret[f"err{rank}"] = str(e)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_capql_equals_big_batch_oracle():
+    sys.path[:0] = [os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "oracle")]
+    from ac_common import run_oracle
+    c = _capql_case()
+    st_o, out = run_oracle(c)                                        # one process, all B rows
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    q0, p0, t0, cl0, pl0, g0, qs0, ps0 = ret[0]
+    q1, p1, t1, cl1, pl1, g1, _, _ = ret[1]
+    assert np.array_equal(q0, q1) and np.array_equal(p0, p1) and np.array_equal(t0, t1) and np.array_equal(g0, g1)
+    # the job's loss is the mean of the ranks' losses; parameters after the step == the oracle's big-batch step
+    assert 0.5 * (cl0 + cl1) == pytest.approx(float(out["critic_loss"]), rel=2e-5)
+    assert 0.5 * (pl0 + pl1) == pytest.approx(float(out["policy_loss"]), rel=2e-5, abs=1e-6)
+    lr = c.lr
+    for n in range(2):
+        for got, want in zip(qs0[n], st_o["q"][n]):
+            assert np.abs(got - want.numpy()).max() <= 0.03 * lr
+    for got, want in zip(ps0, st_o["pol"]):
+        assert np.abs(got - want.numpy()).max() <= 0.03 * lr
+    assert ret["err0"] == ret["err1"] == "sync failed"
