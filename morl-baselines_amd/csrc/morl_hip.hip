@@ -913,8 +913,22 @@ extern "C" int morl_pareto_mask(const double* points, int N, int R, int remove_d
     if (N == 0) return MORL_OK;
     if (!points || !mask_out) return fail(MORL_ERR_ARG, "NULL array");
     if (N < 0 || R < 1 || R > MORL_MAX_OBJ) return fail(MORL_ERR_ARG, "bad sizes N=%d R=%d (R <= %d)", N, R, MORL_MAX_OBJ);
-    hipLaunchKernelGGL(pareto_mask_kernel, dim3((N + PARETO_THREADS - 1) / PARETO_THREADS), dim3(PARETO_THREADS), 0,
-                       (hipStream_t)stream, points, N, R, remove_duplicates, mask_out);
+    hipStream_t s = (hipStream_t)stream;
+    // j ranges: aim at ~16 waves per SIMD over the chip (1024 SIMDs), ranges of whole unroll groups, at least 64 points
+    const int bx = (N + PARETO_THREADS - 1) / PARETO_THREADS;
+    const int want = std::max(1, (16 * 1024) / (bx * (PARETO_THREADS / 64)));
+    int chunk = (N + want - 1) / want;
+    chunk = std::max(64, (chunk + 63) / 64 * 64);
+    const int by = (N + chunk - 1) / chunk;
+    const dim3 grid(bx, by), block(PARETO_THREADS);
+    HIP_TRY(hipMemsetAsync(mask_out, 1, (size_t)N, s));            // keep unless some j range clears it
+    switch (R) {      // one instantiation per objective count: the comparison chain is fully unrolled
+#define MORL_PARETO_CASE(r) case r: hipLaunchKernelGGL(pareto_mask_kernel<r>, grid, block, 0, s, points, N, remove_duplicates, chunk, mask_out); break;
+        MORL_PARETO_CASE(1) MORL_PARETO_CASE(2) MORL_PARETO_CASE(3) MORL_PARETO_CASE(4)
+        MORL_PARETO_CASE(5) MORL_PARETO_CASE(6) MORL_PARETO_CASE(7) MORL_PARETO_CASE(8)
+#undef MORL_PARETO_CASE
+        default: return fail(MORL_ERR_ARG, "R=%d", R);
+    }
     LAUNCH_CHECK("pareto_mask");
     return MORL_OK;
 }
