@@ -249,6 +249,15 @@ class PrioritizedReplayBuffer(ReplayBuffer):
         self._pending_prio.append(-1.0 if priority is None else float(priority))
         super().add(obs, action, reward, next_obs, done)
 
+    def add_batch(self, obs, actions, rewards, next_obs, dones):
+        """n ``add`` calls at once: the new leaves get the running-max priority, in order (``prioritized_buffer.py:141-146``)."""
+        start = self.ptr
+        n = np.asarray(obs, dtype=np.float32).reshape(-1, self._D).shape[0]
+        super().add_batch(obs, actions, rewards, next_obs, dones)       # (flushes pending single adds first)
+        if n:
+            ptr_t = th.as_tensor((start + np.arange(n)) % self.max_size, dtype=th.int64).to(self.device, non_blocking=True)
+            ops.sumtree_set(self.lib, self.tree_dev, self.n_levels, ptr_t, None, self.running_max)
+
     def _on_flush(self, start: int, n: int) -> None:
         ptrs = (start + np.arange(n)) % self.max_size
         ptr_t = th.as_tensor(ptrs, dtype=th.int64).to(self.device, non_blocking=True)

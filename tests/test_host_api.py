@@ -251,3 +251,35 @@ def test_pareto_archive_matches_reference_semantics(be):
     assert arch2.individuals == [{"id": 0}, {"id": 1}]
     single = par.filter_pareto_dominated(np.array([[1.0, 2.0]]), lib=lib, device=dev)
     assert single.shape == (1, 2)
+
+
+@pytest.mark.parametrize("prioritized", [False, True])
+def test_add_batch_equals_sequential_adds(be, prioritized):
+    """``add_batch`` (the Dyna roll-outs' bulk insert) leaves the buffer -- host arrays, device records, ring pointer and,
+    for PER, the sum tree -- exactly as the same transitions added one by one do, including a wrap-around."""
+    lib, dev = be
+    D, A, R, cap = 4, 3, 2, 40
+    cls = rp.PrioritizedReplayBuffer if prioritized else rp.ReplayBuffer
+    mk = lambda: cls((D,), 1, rew_dim=R, max_size=cap, action_dtype=np.uint8, device=dev, lib=lib)  # noqa: E731
+    one, bulk = mk(), mk()
+    rng = np.random.default_rng(4)
+    for n in (7, 25, 0, 19, 1):                                   # 52 > cap: the ring wraps inside the 19-block
+        o = rng.standard_normal((n, D)).astype(np.float32)
+        a = rng.integers(0, A, n)
+        r = rng.standard_normal((n, R)).astype(np.float32)
+        no = rng.standard_normal((n, D)).astype(np.float32)
+        d = rng.random(n) < 0.3
+        for k in range(n):
+            one.add(o[k], a[k], r[k], no[k], d[k])
+        bulk.add_batch(o, a, r, no, d)
+        if prioritized and n:                                     # move the running max between blocks
+            idx = th.tensor([one.ptr - 1], dtype=th.int64)
+            for b in (one, bulk):
+                b.update_priorities(idx, np.array([2.5 + n], dtype=np.float32))
+    one.flush(); bulk.flush()
+    assert (one.ptr, one.size) == (bulk.ptr, bulk.size) == (52 % cap, cap)
+    for f in ("obs", "actions", "rewards", "next_obs", "dones"):
+        np.testing.assert_array_equal(getattr(one, f), getattr(bulk, f))
+    assert th.equal(one.records.cpu(), bulk.records.cpu())
+    if prioritized:
+        assert th.equal(one.tree_dev.cpu(), bulk.tree_dev.cpu()) and float(one.running_max) == float(bulk.running_max)
