@@ -217,6 +217,8 @@ class ReplayBuffer:
 class PrioritizedReplayBuffer(ReplayBuffer):
     """Prioritized replay (``common/prioritized_buffer.py:85-226``) with the sum tree resident on the device."""
 
+    TREE_BLOCK = 1024      # entries per morl_sumtree_update launch (ST_MAX_B of csrc/replay_kernels.h)
+
     def __init__(self, obs_shape, action_dim, rew_dim=1, max_size=100000, obs_dtype=np.float32,
                  action_dtype=np.float32, min_priority=1e-5, device="cuda", lib: Optional[NativeLib] = None):
         self._init_min_priority = float(min_priority)
@@ -298,7 +300,21 @@ class PrioritizedReplayBuffer(ReplayBuffer):
         idx = th.as_tensor(idxes, dtype=th.int64).to(self.device).contiguous()
         pr = th.as_tensor(np.asarray(priorities, dtype=np.float32) if not th.is_tensor(priorities) else priorities)
         pr = pr.to(self.device, th.float32).contiguous().reshape(-1)
-        ops.sumtree_update(self.lib, self.tree_dev, self.n_levels, idx, pr, -1.0, self.running_max)
+        if idx.numel() <= self.TREE_BLOCK:
+            ops.sumtree_update(self.lib, self.tree_dev, self.n_levels, idx, pr, -1.0, self.running_max)
+            return
+        # more entries than one tree-update launch holds (e.g. GPIPD._reset_priorities over the whole buffer): batch_set
+        # keeps, per distinct index, the priority of its FIRST occurrence and adds the leaf differences level by level in
+        # ascending index order (prioritized_buffer.py:69-82) -- ascending blocks of the de-duplicated indices perform
+        # exactly the same additions in the same order, so the tree stays bit-identical to the one-call result
+        order = th.argsort(idx, stable=True)
+        s_idx, s_pr = idx[order], pr[order]
+        first = th.ones_like(s_idx, dtype=th.bool)
+        first[1:] = s_idx[1:] != s_idx[:-1]
+        u_idx, u_pr = s_idx[first].contiguous(), s_pr[first].contiguous()
+        for b in range(0, u_idx.numel(), self.TREE_BLOCK):
+            ops.sumtree_update(self.lib, self.tree_dev, self.n_levels, u_idx[b:b + self.TREE_BLOCK].contiguous(),
+                               u_pr[b:b + self.TREE_BLOCK].contiguous(), -1.0, self.running_max)
 
     def update_priorities_from_td(self, idx: th.Tensor, raw_abs_td: th.Tensor, alpha: float) -> None:
         """Device-only path of ``envelope.py:329-334``: priority = (|td . w| + min_priority) ** alpha, then update."""

@@ -283,3 +283,28 @@ def test_add_batch_equals_sequential_adds(be, prioritized):
     assert th.equal(one.records.cpu(), bulk.records.cpu())
     if prioritized:
         assert th.equal(one.tree_dev.cpu(), bulk.tree_dev.cpu()) and float(one.running_max) == float(bulk.running_max)
+
+
+def test_priority_update_larger_than_one_launch(be, monkeypatch):
+    """``update_priorities`` with more entries than one tree-update launch holds (GPIPD._reset_priorities hands over the
+    whole buffer): blocks of the de-duplicated, ascending indices leave the tree bit-identical to the oracle's single
+    ``batch_set`` -- duplicates keep their first priority, the running maximum follows."""
+    lib, dev = be
+    D, A, R, cap = 3, 2, 2, 300
+    buf = rp.PrioritizedReplayBuffer((D,), 1, rew_dim=R, max_size=cap, action_dtype=np.uint8, device=dev, lib=lib)
+    monkeypatch.setattr(rp.PrioritizedReplayBuffer, "TREE_BLOCK", 64)          # 300 entries -> 5 launches
+    rng = np.random.default_rng(2)
+    n = 280
+    buf.add_batch(rng.standard_normal((n, D)), rng.integers(0, A, n), rng.standard_normal((n, R)),
+                  rng.standard_normal((n, D)), rng.random(n) < 0.1)
+    tree = orc.SumTree(cap)
+    for p in range(n):
+        tree.set(p, 1e-5)
+    idx = np.concatenate([rng.permutation(n), rng.integers(0, n, 40)])       # every index once, then 40 repeats
+    pr = rng.random(idx.size).astype(np.float32) + 0.01
+    buf.update_priorities(idx, pr)
+    tree.batch_set(idx, pr)
+    got = buf.tree
+    for lvl in range(len(tree.nodes)):
+        np.testing.assert_array_equal(got.nodes[lvl][:len(tree.nodes[lvl])], tree.nodes[lvl])
+    assert buf.min_priority == float(max(1e-5, pr.max()))
