@@ -51,10 +51,21 @@ def main():
     th.cuda.synchronize()
     print(f"dynamics.fit 20000 samples x 5 epochs: {(time.perf_counter() - t) * 1e3:.1f} ms")
     ag.global_step = 10 ** 6
+    ag._rollout_dynamics(w)
+    th.cuda.synchronize()
     t = time.perf_counter()
     ag._rollout_dynamics(w)
     th.cuda.synchronize()
     print(f"rollout 25000 states x |M|={n_sup}: {(time.perf_counter() - t) * 1e3:.1f} ms, {ag._last_rollout}")
+    if os.environ.get("PROFILE"):
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        ag._rollout_dynamics(w)
+        th.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
 
 
 if __name__ == "__main__":
