@@ -1,0 +1,65 @@
+"""Collect the per-kernel PMC figures behind bench.py's `roofline.traffic` (run ON the GPU box):
+
+    cd /tmp && export TMPDIR=/tmp && python $REPO/tools/pmc_summary.py $REPO/gpurun_out/pmc_summary.json
+
+Three separate `rocprofv3 --pmc` passes of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline` (FETCH_SIZE, WRITE_SIZE
+and an SQ set do not fit one pass; counter passes are never combined with the trace domains), averaged per launch and kernel.
+FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950 (it reports
+TCC_EA0_RDREQ x 64 B for 128-B requests); WRITE_SIZE is uncalibrated and reported as counted (KB -> bytes).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PASSES = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
+          "sq": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"]}
+
+
+def run_pass(name, counters, outdir):
+    d = os.path.join(outdir, name)
+    cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(set)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            launches[k].add(r["Dispatch_Id"])
+    return {k: {c: v / len(launches[k]) for c, v in cs.items()} | {"launches": len(launches[k])} for k, cs in acc.items()}
+
+
+def main():
+    out_path = sys.argv[1]
+    work = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pmc_passes")
+    res = {n: run_pass(n, c, work) for n, c in PASSES.items()}
+    kernels = {}
+    for k in sorted(res["fetch"]):
+        if not k.startswith("morl::"):
+            continue
+        f, w, s = res["fetch"][k], res["write"].get(k, {}), res["sq"].get(k, {})
+        fetch = 2.0 * 1024.0 * f.get("FETCH_SIZE", 0.0)            # KB counted at 64 B per 128-B request -> bytes, doubled
+        write = 1024.0 * w.get("WRITE_SIZE", 0.0)
+        sq = {c: s.get(c, 0.0) for c in PASSES["sq"]}
+        kernels[k] = {"launches": f["launches"], "fetch_bytes_corrected": fetch, "write_bytes": write,
+                      "hbm_bytes": fetch + write,
+                      # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs:
+                      # busy fraction = busy / (active / 8 * 1024)
+                      "mfma_busy_frac": (sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] * 128.0)) if sq["GRBM_GUI_ACTIVE"] else 0.0,
+                      "lds_bank_conflict_over_wave_cycles": (sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_WAVE_CYCLES"]) if sq["SQ_WAVE_CYCLES"] else 0.0,
+                      "sq": sq}
+    json.dump({"note": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "command": "python bench.py --steps 10 --warmup 3 "
+               "--no-cpu-baseline", "kernels": kernels}, open(out_path, "w"), indent=1)
+    for k, v in kernels.items():
+        print(f"{k:45s} launches {v['launches']:4d}  HBM {v['hbm_bytes'] / 1e6:9.2f} MB  mfma_busy {v['mfma_busy_frac']:.3f}")
+
+
+if __name__ == "__main__":
+    main()
