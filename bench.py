@@ -133,7 +133,17 @@ def measured_chain_traffic():
         return None
 
 
+def _claim_stdout():
+    """stdout must carry exactly ONE line, rank 0's JSON: C libraries (RCCL prints a version banner to stdout, flushed
+    at exit, i.e. after the JSON) and the other ranks are moved to stderr; the result is written to the saved descriptor."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
+    result_out = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -263,7 +273,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B, W, bool(a.per))
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        print(json.dumps(out), file=result_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -26,6 +26,7 @@ import numpy as np
 import torch as th
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
+RESULT_OUT = sys.stdout
 
 SHAPES = {  # obs dim, action dim, objectives of the environments BASELINE.json names
     "capql": dict(D=17, Ad=6, R=2, env="mo-halfcheetah-v4"),
@@ -225,7 +226,7 @@ def bench_gpi(a):
                                "sample": f"{len(times)} timed updates of oracle/gpi_oracle.py on torch-CPU at the best of "
                                          f"1/4/16/all threads ({best[0]}), median"}
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-    print(json.dumps(out))
+    print(json.dumps(out), file=RESULT_OUT, flush=True)
 
 
 def bench_ens(a):
@@ -303,10 +304,21 @@ def bench_ens(a):
                                "sample": f"{len(times)} timed steps of oracle/ens_oracle.py::train_step on torch-CPU at the "
                                          f"best of 1/4/16/all threads ({best[0]}), median"}
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-    print(json.dumps(out))
+    print(json.dumps(out), file=RESULT_OUT, flush=True)
+
+
+def _claim_stdout():
+    """stdout must carry exactly ONE line, rank 0's JSON: C libraries (RCCL prints a version banner to stdout, flushed
+    at exit, i.e. after the JSON) and the other ranks are moved to stderr; the result is written to the saved descriptor."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
 
 
 def main():
+    global RESULT_OUT
+    RESULT_OUT = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="morld", choices=sorted(SHAPES))
     ap.add_argument("--pop", type=int, default=None)
@@ -437,7 +449,7 @@ def main():
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(wl, shp, pop)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-    print(json.dumps(out))
+    print(json.dumps(out), file=RESULT_OUT, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

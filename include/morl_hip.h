@@ -65,6 +65,12 @@ typedef struct morl_update_cfg {
     int32_t adam_step;       /* 1-based index of the step being taken */
     int32_t envelope;        /* 1: envelope target (envelope.py:404-440), 0: DDQN target (:442-463) */
     int32_t apply_step;      /* 0: stop after gradients (parity tests) */
+    /* morl_envelope_update_shard only: */
+    int32_t main_forward_done; /* 1: morl_envelope_main_forward has already run for this batch (it can overlap the all-gather) */
+    int32_t slab_parts;      /* 0 / 1: qo_all, qt_all are [B][W_total][A][R].  G > 1: they point at part 0 of an all-gathered
+                              * buffer [G][2][B][W_total/G][A][R] (what all_gather_into_tensor builds from every rank's
+                              * morl_envelope_slabs output): qt_all = qo_all + B*(W_total/G)*A*R, parts 2*B*(W_total/G)*A*R
+                              * floats apart -- read in place, no re-layout pass */
 } morl_update_cfg;
 
 /* Optional device outputs of morl_envelope_update (any may be NULL). */
@@ -151,14 +157,23 @@ int morl_envelope_update(morl_ctx* ctx, float* params_online, const float* param
 
 /* ---- weight-axis sharding of the same step (no counterpart in the reference, which is single-device) ------------
  * A rank that owns the TD rows of weights [i_offset, i_offset + W_local) of W_total:
- *   1. morl_qnet_forward(row_order 0) on its W_local weights for the online and the target network -> local slabs;
- *      the caller all-gathers them into qo_all / qt_all [B][W_total][A][R];
+ *   1. morl_envelope_slabs: Q_online / Q_target(s'_b, w_j) for its W_local weights in one launch pair -> local slabs
+ *      [2][B][W_local][A][R]; the caller all-gathers them (cfg->slab_parts describes the gathered layout) and, while that
+ *      collective is in flight, runs morl_envelope_main_forward (the training forward does not need the slabs);
  *   2. morl_envelope_update_shard: training forward of its rows, envelope arg-max over ALL W_total candidates, TD,
  *      backward.  `grads` receives this rank's UNCLIPPED contribution, already normalised by the global row count
  *      B * W_total, out->loss its share of the loss (out->priority only on the rank with i_offset == 0; target / pref /
  *      ac / q_values are local [W_local*B] rows);
  *   3. the caller all-reduces (sums) grads and the loss; morl_clip_adam applies clip_grad_norm_ + Adam identically
  *      on every rank. */
+/* next-state slabs of this rank: slabs_out [2][B][W_local][A][R] (online, then target network), rows (b, j) of
+ * (next_obs_b, weights_local_j) -- envelope.py:416-420 on the de-duplicated rows. */
+int morl_envelope_slabs(morl_ctx* ctx, const float* params_online, const float* params_target, const float* next_obs,
+                        const float* weights_local, int B, int W_local, float* slabs_out, void* stream);
+/* training forward Q_online(s_b, w_i) of this rank's TD rows (envelope.py:300), activations kept in the context for
+ * morl_envelope_update_shard(cfg->main_forward_done = 1).  weights_local = this rank's W_local vectors.  */
+int morl_envelope_main_forward(morl_ctx* ctx, const float* params_online, const float* obs, const float* weights_local,
+                               int B, int W_local, void* stream);
 int morl_envelope_update_shard(morl_ctx* ctx, const float* params_online, float* grads, const float* obs,
                                const int32_t* actions, const float* rewards, const float* dones,
                                const float* weights_all, int B, int W_total, int i_offset, int W_local,

@@ -75,6 +75,8 @@ struct EnvelopeTdArgs {
     float gamma;
     float c_mse;            // (1 - lambda) * 2 / (W*B*R)
     float c_aux;            // lambda * 2 / (W*B)
+    int part_floats;        // 0: qo / qt are [B][W][A][R].  > 0: all-gathered layout, the slab of transition b is made of
+    long long part_stride;  //    W*A*R / part_floats pieces of part_floats floats, piece g at  g * part_stride + b * part_floats
 };
 
 // LDS-resident throughout: phase 1 stages Qo[b], Qt[b], the weight vectors and the taken-action Q entries of this
@@ -111,9 +113,12 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
     const int i_lo = min(nI, ig * per_g), i_hi = min(nI, i_lo + per_g);
     const bool train = p.q_main != nullptr;
     const int act = train ? p.actions[b] : 0;
+    const int pf = p.part_floats > 0 ? p.part_floats : slab;
     for (int e = (int)threadIdx.x; e < slab; e += (int)blockDim.x) {
-        s_qo[e] = p.qo[(size_t)b * slab + e];
-        s_qt[e] = p.qt[(size_t)b * slab + e];
+        const int g = e / pf;
+        const size_t off = (size_t)g * (size_t)p.part_stride + (size_t)b * pf + (size_t)(e - g * pf);
+        s_qo[e] = p.qo[off];
+        s_qt[e] = p.qt[off];
     }
     for (int e = (int)threadIdx.x; e < nI * R; e += (int)blockDim.x) {
         s_w[e] = generic ? p.row_weights[(size_t)b * R + e] : p.weights[e];

@@ -150,6 +150,7 @@ struct morl_ctx {
     // optional per-launch timing of the dominant kernel (mlp_chain): HIP event pairs on the caller's stream
     bool timing = false;
     std::vector<hipEvent_t> ev_start, ev_stop;
+    int main_rows = -1;                  // rows of a hoisted training forward (morl_envelope_main_forward), -1 = none
     size_t ev_used = 0;
     int fused_tm = 0;        // 0: pick the row tile per launch (>= 2 workgroups per CU when possible), else 64 / 32
     int num_cus = 256;
@@ -438,16 +439,23 @@ static int chain_forward(morl_ctx* c, const float* params, const float* wt, cons
 }
 
 // the three forward passes of one Envelope step in a single launch of 64-row tiles
+static int chain_forward_multi(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s);
 static int chain_forward_x3(morl_ctx* c, const ChainArgs& a0, const ChainArgs& a1, const ChainArgs& a2, hipStream_t s) {
+    const ChainArgs a[3] = {a0, a1, a2};
+    return chain_forward_multi(c, a, 3, s);
+}
+// up to CH_MAX_MULTI forward passes in one launch
+static int chain_forward_multi(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s) {
     ChainMulti m{};
-    m.n = 3;
-    m.p[0] = a0; m.p[1] = a1; m.p[2] = a2;
+    m.n = n;
+    long long rows_all = 0;
+    for (int q = 0; q < n; ++q) { m.p[q] = chains[q]; rows_all += chains[q].rows; }
     // 64-row tiles unless that leaves the chip under-filled (small shards of a weight-sharded job): then 32
     int tm = c->multi_tm;
-    if (tm == 64 && (a0.rows + a1.rows + a2.rows + 63) / 64 < 2 * c->num_cus) tm = 32;
+    if (tm == 64 && (rows_all + 63) / 64 < 2 * c->num_cus) tm = 32;
     int t = 0;
-    for (int q = 0; q < 3; ++q) { m.tile_start[q] = t; t += (m.p[q].rows + tm - 1) / tm; }
-    m.tile_start[3] = t;
+    for (int q = 0; q < n; ++q) { m.tile_start[q] = t; t += (m.p[q].rows + tm - 1) / tm; }
+    for (int q = n; q <= CH_MAX_MULTI; ++q) m.tile_start[q] = t;
     size_t slot = 0;
     if (c->timing) {
         if (c->ev_used == c->ev_start.size()) {
@@ -672,6 +680,10 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         p.c_mse = (float)((1.0 - (double)lam) * 2.0 / ((double)rows_total * R));
         p.c_aux = (float)((double)lam * 2.0 / (double)rows_total);
         p.i_groups = td_groups;
+        if (cfg->slab_parts > 1) {      // all-gathered slabs read in place: [G][2][B][W/G][A][R]
+            p.part_floats = (W / cfg->slab_parts) * A * R;
+            p.part_stride = 2ll * B * p.part_floats;
+        }
         // waves per workgroup ~ candidates per TD row: 4 at the single-GPU 64 x 6, up to 16 when a sharded job reduces over
         // all gathered weights (MORL_TD_WAVES overrides, for tuning)
         const long long n_cand = cfg->envelope ? (long long)W * A : A;
@@ -883,10 +895,60 @@ extern "C" int morl_envelope_update_shard(morl_ctx* c, const float* params_onlin
     hipStream_t s = (hipStream_t)stream;
     static const morl_update_out no_out = {};
     if (!out) out = &no_out;
-    if (c->use_fused && (rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
+    if (cfg->slab_parts > 1 && W_total % cfg->slab_parts)
+        return fail(MORL_ERR_ARG, "slab_parts %d does not divide W_total %d", cfg->slab_parts, W_total);
+    const bool fwd_done = cfg->main_forward_done != 0;
+    if (fwd_done && (c->main_rows != B * W_local))
+        return fail(MORL_ERR_STATE, "main_forward_done: morl_envelope_main_forward was not run for %d rows", B * W_local);
+    if (!fwd_done && c->use_fused && (rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
+    c->main_rows = -1;
     return update_core(c, params_online, grads, obs, actions, rewards, dones,
                        weights_all + (size_t)i_offset * c->net.reward_dim, W_local, qo_all, qt_all, W_total, i_offset,
-                       (long long)B * W_total, B, cfg, out, false, nullptr, nullptr, s);
+                       (long long)B * W_total, B, cfg, out, fwd_done, nullptr, nullptr, s);
+}
+
+extern "C" int morl_envelope_slabs(morl_ctx* c, const float* params_online, const float* params_target, const float* next_obs,
+                                   const float* weights_local, int B, int W_local, float* slabs_out, void* stream) {
+    int rc = check_bw(c, B, W_local);
+    if (rc) return rc;
+    if (!params_online || !params_target || !next_obs || !weights_local || !slabs_out) return fail(MORL_ERR_ARG, "NULL array");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = B * W_local, AR = c->net.n_actions * c->net.reward_dim;
+    float* qo = slabs_out;
+    float* qt = slabs_out + (size_t)rows * AR;
+    if (c->use_fused) {
+        // one transpose launch for both networks, one launch for both passes (2 x rows/64 workgroups share the chip)
+        if ((rc = refresh_transposed(c, params_online, c->wt_online, s, params_target, c->wt_target))) return rc;
+        const ChainArgs two[2] = {
+            make_forward_chain(c, params_online, c->wt_online, next_obs, weights_local, B, W_local, 0, rows, false, qo, AR),
+            make_forward_chain(c, params_target, c->wt_target, next_obs, weights_local, B, W_local, 0, rows, false, qt, AR)};
+        return chain_forward_multi(c, two, 2, s);
+    }
+    if ((rc = build_input(next_obs, weights_local, c->x0n, B, W_local, c->net.obs_dim, c->net.reward_dim, c->ld0, 0, s))) return rc;
+    if ((rc = net_forward(c, params_online, c->x0n, rows, false, qo, AR, s))) return rc;
+    return net_forward(c, params_target, c->x0n, rows, false, qt, AR, s);
+}
+
+extern "C" int morl_envelope_main_forward(morl_ctx* c, const float* params_online, const float* obs,
+                                          const float* weights_local, int B, int W_local, void* stream) {
+    int rc = check_bw(c, B, W_local);
+    if (rc) return rc;
+    if (!params_online || !obs || !weights_local) return fail(MORL_ERR_ARG, "NULL array");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = B * W_local;
+    // the same passes update_core runs when the forward is not hoisted: the layer-0 input for the dW GEMM, then the chain
+    // (or the per-layer GEMMs) with the activations saved in the context
+    if ((rc = build_input(obs, weights_local, c->x0m, B, W_local, c->net.obs_dim, c->net.reward_dim, c->ld0, 1, s))) return rc;
+    c->bits_valid = false;
+    if (c->use_fused) {
+        if ((rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
+        if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights_local, B, W_local, 1, rows, true, c->qm, c->ldq, s)))
+            return rc;
+    } else if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) {
+        return rc;
+    }
+    c->main_rows = rows;
+    return MORL_OK;
 }
 
 // clip_grad_norm_ + Adam on flat buffers (envelope.py:324-326) -- stage C on its own, for gradients that were

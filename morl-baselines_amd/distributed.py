@@ -5,12 +5,16 @@ SURVEY.md 8(e).  Every rank holds a full replica of the agent (parameters, Adam 
 SAME batch and the SAME W sampled weights (identical seeds => identical host RNG streams).  Rank g owns the weights
 ``[g*W/G, (g+1)*W/G)``:
 
-  1. it evaluates the next-state slabs Q_online/Q_target(s'_b, w_j) for ITS weights only            (B*W/G rows, 2 passes)
-  2. ONE all-gather makes both slabs complete on every rank             (2 * B*W*A*R*4 bytes in total; 2.4 MB @ flagship)
-  3. it runs the training forward / envelope arg-max over ALL candidates / TD / backward for its own TD rows
-  4. ONE all-reduce sums the flat gradient (+ the loss scalar appended to it)                  (0.85 MB @ flagship)
+  1. it evaluates the next-state slabs Q_online/Q_target(s'_b, w_j) for ITS weights only   (B*W/G rows, both networks
+     in one launch pair: ``morl_envelope_slabs``)
+  2. ONE all-gather makes both slabs complete on every rank (2 * B*W*A*R*4 bytes in total; 2.4 MB at 256 x 64, 19 MB at
+     the weak-scaled 256 x 512 of 8 GPUs); it is issued asynchronously and the training forward of the rank's own rows
+     (``morl_envelope_main_forward``, independent of the slabs) runs while it is in flight; the gathered buffer
+     [G][2][B][W/G][A][R] is read in place by the TD kernel (no re-layout pass)
+  3. envelope arg-max over ALL candidates / TD / backward for its own TD rows (``morl_envelope_update_shard``)
+  4. ONE all-reduce sums one flat buffer: gradient | loss | the B PER priorities (non-zero only on the rank that owns
+     weight 0, so the sum is exact)                                                              (0.85 MB at [256]*4)
   5. every rank applies the identical clip + Adam step -> replicas stay bit-identical
-  (PER: the priorities come from the rows of weight 0, i.e. from rank 0; they ride along in a broadcast of B floats.)
 
 Messages are far below the size where a ring would be bandwidth-bound on the point-to-point xGMI links; they are
 latency-bound, so the exchange is kept to two collectives per step and both operate on single contiguous buffers.
@@ -89,14 +93,17 @@ def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
     dev = agent.device
     P = agent.q_net.ctx.n_params
     agent._shard = types.SimpleNamespace(world=world, rank=rank, Wl=Wl, i0=i0)
-    # gradient buffer with one extra slot: the loss rides in the same all-reduce
-    agent._grads_x = th.zeros(P + 1, dtype=th.float32, device=dev)
+    B0 = agent.batch_size
+    # one flat buffer rides in the single all-reduce: [P gradient | 1 loss | B priorities (rank 0's rows of weight 0)]
+    agent._grads_x = th.zeros(P + 1 + B0, dtype=th.float32, device=dev)
     agent._grads = agent._grads_x[:P]
     agent._bind_optimizer_state()
 
     def update(self: Envelope):
         self._losses = []
         B = self.batch_size
+        if B != B0:
+            raise ValueError("batch_size changed after shard_envelope_agent")
         for _ in range(self.gradient_updates):
             b_obs, b_actions, b_rewards, b_next_obs, b_dones, b_inds = self.replay_buffer.sample(
                 B, to_tensor=True, device=self.device)
@@ -104,32 +111,33 @@ def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
                 .reshape(W, R).to(self.device, non_blocking=True).contiguous()
             ctx = self.q_net.ctx
             w_loc = sampled_w[i0:i0 + Wl].contiguous()
-            # 1. local slabs [2][B][Wl][A][R]
-            loc = th.empty((2, B, Wl, A, R), dtype=th.float32, device=self.device)
-            loc[0] = ops.qnet_forward(ctx, self.q_net.flat, b_next_obs, w_loc, row_order=0).view(B, Wl, A, R)
-            loc[1] = ops.qnet_forward(ctx, self.target_q_net.flat, b_next_obs, w_loc, row_order=0).view(B, Wl, A, R)
-            # 2. one all-gather, then [G][2][B][Wl] -> [2][B][G*Wl]
-            gathered = th.empty(world * loc.numel(), dtype=th.float32, device=self.device)
-            dist.all_gather_into_tensor(gathered, loc.reshape(-1), group=group)
-            slabs = gathered.view(world, 2, B, Wl, A, R).permute(1, 2, 0, 3, 4, 5).reshape(2, B, W, A, R).contiguous()
-            # 3. this rank's TD rows
+            # 1. local slabs [2][B][Wl][A][R]: both networks in one launch pair
+            loc = ops.envelope_slabs(ctx, self.q_net.flat, self.target_q_net.flat, b_next_obs, w_loc)
+            # 2. one all-gather -> [G][2][B][Wl][A][R], read in place by the TD kernel; while it is in flight ...
+            gathered = th.empty((world,) + tuple(loc.shape), dtype=th.float32, device=self.device)
+            work = dist.all_gather_into_tensor(gathered.view(-1), loc.view(-1), group=group, async_op=True)
+            # ... the training forward of this rank's rows runs (it does not need the slabs)
+            ops.envelope_main_forward(ctx, self.q_net.flat, b_obs, w_loc)
+            work.wait()
+            # 3. this rank's TD rows: arg-max over ALL gathered candidates, TD, backward
             self._adam_step += 1
-            out = ops.envelope_update_shard(ctx, self.q_net.flat, self._grads, b_obs, b_actions.reshape(-1).to(th.int32),
-                                            b_rewards, b_dones.reshape(-1), sampled_w, i0, Wl, slabs[0], slabs[1],
-                                            gamma=self.gamma, homotopy_lambda=float(self.homotopy_lambda),
-                                            envelope=self.envelope)
-            # 4. one all-reduce: flat gradient + loss
-            self._grads_x[P:].copy_(out["loss"].reshape(1))
-            dist.all_reduce(self._grads_x, op=dist.ReduceOp.SUM, group=group)
-            loss = self._grads_x[P].clone()
+            gx = self._grads_x
+            gx[P + 1:].zero_()                         # priorities: written by the rank that owns weight 0 only
+            outs = {"loss": gx[P], "priority": gx[P + 1:]}
+            ops.envelope_update_shard(ctx, self.q_net.flat, self._grads, b_obs, b_actions.reshape(-1).to(th.int32),
+                                      b_rewards, b_dones.reshape(-1), sampled_w, i0, Wl, gathered[0, 0], gathered[0, 1],
+                                      gamma=self.gamma, homotopy_lambda=float(self.homotopy_lambda),
+                                      envelope=self.envelope, outputs=outs, main_forward_done=True, slab_parts=world)
+            # 4. one all-reduce: flat gradient + loss + priorities
+            dist.all_reduce(gx, op=dist.ReduceOp.SUM, group=group)
+            loss = gx[P].clone()
             # 5. identical optimiser step everywhere
             ops.clip_adam(ctx, self.q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq, lr=self.learning_rate,
                           adam_step=self._adam_step, max_grad_norm=self.max_grad_norm)
-            self._out = {"loss": loss, "priority": out["priority"]}
+            pr = gx[P + 1:].clone()
+            self._out = {"loss": loss, "priority": pr}
             self._losses.append(loss)
             if self.per:
-                pr = out["priority"]
-                dist.broadcast(pr, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
                 self.replay_buffer.update_priorities_from_td(b_inds, pr, self.per_alpha)
         if self.tau != 1 or self.global_step % self.target_net_update_freq == 0:
             ops.polyak(self.lib, self.q_net.flat, self.target_q_net.flat, self.tau)

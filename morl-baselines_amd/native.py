@@ -27,7 +27,8 @@ class NetDesc(C.Structure):
 class UpdateCfg(C.Structure):
     _fields_ = [("gamma", C.c_float), ("homotopy_lambda", C.c_float), ("max_grad_norm", C.c_float),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
-                ("adam_step", C.c_int32), ("envelope", C.c_int32), ("apply_step", C.c_int32)]
+                ("adam_step", C.c_int32), ("envelope", C.c_int32), ("apply_step", C.c_int32),
+                ("main_forward_done", C.c_int32), ("slab_parts", C.c_int32)]
 
 
 class UpdateOut(C.Structure):
@@ -132,6 +133,9 @@ _SIGNATURES = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "morl_envelope_update": (C.c_int, [C.c_void_p] * 12 + [C.c_int, C.c_int, C.POINTER(UpdateCfg),
                                                            C.POINTER(UpdateOut), C.c_void_p]),
+    "morl_envelope_slabs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p]),
+    "morl_envelope_main_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "morl_envelope_update_shard": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p,
                                                                                  C.POINTER(UpdateCfg), C.POINTER(UpdateOut),
                                                                                  C.c_void_p]),

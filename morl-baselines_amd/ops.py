@@ -215,13 +215,42 @@ def _update_cfg(gamma, lr, adam_step, max_grad_norm, homotopy_lambda, envelope, 
                      apply_step=int(bool(apply_step)))
 
 
+def envelope_slabs(ctx: QNetContext, params_online: th.Tensor, params_target: th.Tensor, next_obs: th.Tensor,
+                   weights_local: th.Tensor, out: Optional[th.Tensor] = None) -> th.Tensor:
+    """This rank's next-state slabs [2][B][W_local][A][R] (online, target) in one call (``morl_envelope_slabs``)."""
+    lib = ctx.lib
+    for t, n in ((params_online, "params_online"), (params_target, "params_target"), (next_obs, "next_obs"),
+                 (weights_local, "weights_local")):
+        _chk(t, th.float32, n)
+    B, Wl = next_obs.shape[0], weights_local.shape[0]
+    if out is None:
+        out = th.empty((2, B, Wl, ctx.n_actions, ctx.reward_dim), dtype=th.float32, device=next_obs.device)
+    lib.check_device(params_online, params_target, next_obs, weights_local, out)
+    lib.check(lib.lib.morl_envelope_slabs(ctx.handle, _ptr(params_online), _ptr(params_target), _ptr(next_obs),
+                                          _ptr(weights_local), B, Wl, _ptr(out), lib.stream_of(next_obs)))
+    return out
+
+
+def envelope_main_forward(ctx: QNetContext, params_online: th.Tensor, obs: th.Tensor, weights_local: th.Tensor) -> None:
+    """Hoisted training forward of this rank's TD rows (``morl_envelope_main_forward``): independent of the gathered
+    slabs, so it can run while the all-gather is in flight."""
+    lib = ctx.lib
+    for t, n in ((params_online, "params_online"), (obs, "obs"), (weights_local, "weights_local")):
+        _chk(t, th.float32, n)
+    lib.check_device(params_online, obs, weights_local)
+    lib.check(lib.lib.morl_envelope_main_forward(ctx.handle, _ptr(params_online), _ptr(obs), _ptr(weights_local),
+                                                 obs.shape[0], weights_local.shape[0], lib.stream_of(obs)))
+
+
 def envelope_update_shard(ctx: QNetContext, params_online: th.Tensor, grads: th.Tensor, obs: th.Tensor,
                           actions: th.Tensor, rewards: th.Tensor, dones: th.Tensor, weights_all: th.Tensor,
                           i_offset: int, w_local: int, qo_all: th.Tensor, qt_all: th.Tensor, *, gamma: float,
                           homotopy_lambda: float = 0.0, envelope: bool = True,
-                          outputs: Optional[Dict[str, th.Tensor]] = None) -> Dict[str, th.Tensor]:
+                          outputs: Optional[Dict[str, th.Tensor]] = None, main_forward_done: bool = False,
+                          slab_parts: int = 0) -> Dict[str, th.Tensor]:
     """Stage B of a weight-sharded Envelope step (see include/morl_hip.h): this rank's TD rows against the gathered
-    slabs; leaves the unclipped, globally normalised gradient contribution in ``grads``."""
+    slabs; leaves the unclipped, globally normalised gradient contribution in ``grads``.  ``slab_parts`` = G > 1:
+    ``qo_all`` / ``qt_all`` are views of part 0 inside the all-gathered buffer [G][2][B][W/G][A][R] (read in place)."""
     lib = ctx.lib
     for t, dt, n in ((params_online, th.float32, "params_online"), (grads, th.float32, "grads"),
                      (obs, th.float32, "obs"), (actions, th.int32, "actions"), (rewards, th.float32, "rewards"),
@@ -236,6 +265,7 @@ def envelope_update_shard(ctx: QNetContext, params_online: th.Tensor, grads: th.
         res["loss"] = th.empty((), dtype=th.float32, device=dev)
         res["priority"] = th.zeros((B,), dtype=th.float32, device=dev)
     cfg = _update_cfg(gamma, 0.0, 1, None, homotopy_lambda, envelope, 0.9, 0.999, 1e-8, False)
+    cfg.main_forward_done, cfg.slab_parts = int(bool(main_forward_done)), int(slab_parts)
     out = UpdateOut(**{k: _ptr(res.get(k)) for k, _ in UpdateOut._fields_})
     lib.check(lib.lib.morl_envelope_update_shard(
         ctx.handle, _ptr(params_online), _ptr(grads), _ptr(obs), _ptr(actions), _ptr(rewards), _ptr(dones),
