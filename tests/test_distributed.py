@@ -161,3 +161,67 @@ def test_data_parallel_capql_equals_big_batch_oracle():
     for got, want in zip(ps0, st_o["pol"]):
         assert np.abs(got - want.numpy()).max() <= 0.03 * lr
     assert ret["err0"] == ret["err1"] == "sync failed"
+
+
+# ---- the same sharded step over RCCL on a real GPU (one rank talking to itself: the collectives, streams and the in-place
+#      gathered-slab layout are the production ones; N > 1 needs more GPUs than the test box has) --------------------------
+def _rccl_worker(port, per, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    import morl_baselines_amd.envelope as envmod
+    import morl_baselines_amd.native as native
+    from morl_baselines_amd.distributed import shard_envelope_agent
+    from test_host_api import ToyEnv, _fill
+    dev = th.device("cuda:0")
+    th.cuda.set_device(dev)
+    lib = native.load_library()
+
+    def make():
+        env = ToyEnv()
+        th.manual_seed(0)
+        np.random.seed(0)
+        ag = envmod.Envelope(env, net_arch=[64, 64], batch_size=16, num_sample_w=8, buffer_size=256, per=per,
+                             learning_starts=0, log=False, seed=0, device=dev, lib=lib)
+        _fill(ag.replay_buffer, 100, env.D, env.A, env.R)
+        ag.global_step = 7
+        return ag
+
+    ref = make()
+    for _ in range(3):
+        ref.update()
+        ref.global_step += 1
+    want, want_loss = ref.q_net.flat.clone().cpu().numpy(), ref.last_loss()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    ag = make()
+    shard_envelope_agent(ag, dist)
+    for _ in range(3):
+        ag.update()
+        ag.global_step += 1
+    th.cuda.synchronize()
+    ret["params"] = ag.q_net.flat.clone().cpu().numpy()
+    ret["loss"] = float(ag.last_loss())
+    ret["want"], ret["want_loss"] = want, want_loss
+    if per:
+        ret["tree"] = ag.replay_buffer.tree_dev.cpu().numpy()
+        ret["want_tree"] = ref.replay_buffer.tree_dev.cpu().numpy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per", [False, True])
+def test_sharded_update_over_rccl_single_rank(per):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_rccl_worker, args=(32500 + (os.getpid() % 2000) + int(per), per, ret))
+    p.start()
+    p.join(300)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("RCCL single-rank worker did not finish")
+    assert p.exitcode == 0
+    assert abs(ret["loss"] - ret["want_loss"]) <= 1e-5 * abs(ret["want_loss"])
+    assert np.abs(ret["params"] - ret["want"]).max() <= 0.02 * 3e-4 * 3
+    if per:
+        np.testing.assert_allclose(ret["tree"][0], ret["want_tree"][0], rtol=1e-5)
