@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import List, Sequence
 
+import os
+
 import numpy as np
 import torch as th
 from torch import nn
@@ -110,6 +112,22 @@ def load_adam_state_dict(sd: dict, m_views, v_views) -> int:
             v.copy_(st["exp_avg_sq"].to(v.device))
             step = int(float(st["step"]))
     return step
+
+
+# Where the exploration / target / model noise is drawn.  Default: on the device that consumes it (its own generator).
+# HOST_NOISE = True (or MORL_HOST_NOISE=1) draws every sample from torch's CPU generator -- the stream the reference consumes
+# when it runs on CPU -- and copies it over: a seeded GPU run then replays the reference's seeded CPU run draw for draw
+# (tests/test_train_traces.py on the MI355X).  A few KB per update; the training loops are host-bound anyway.
+HOST_NOISE = os.environ.get("MORL_HOST_NOISE", "0") == "1"
+
+
+def noise_device(device) -> th.device:
+    return th.device("cpu") if HOST_NOISE else th.device(device)
+
+
+def randn(shape, device) -> th.Tensor:
+    """Standard-normal draws of ``shape`` for ``device`` (see HOST_NOISE)."""
+    return th.randn(tuple(shape), dtype=th.float32, device=noise_device(device)).to(device)
 
 
 def as_f32(x, device) -> th.Tensor:

@@ -22,7 +22,7 @@ import torch as th
 from . import ops
 from .evaluation import front_returns
 from .ac_engine import ALGO_CAPQL, ACEngine
-from .acnets import PolicyShell, QNetworkShell, adam_state_dict, as_f32, bind, load_adam_state_dict
+from .acnets import PolicyShell, QNetworkShell, adam_state_dict, as_f32, bind, load_adam_state_dict, randn
 from .api import MOAgent, MOPolicy
 from .native import NativeLib, load_library
 
@@ -222,8 +222,7 @@ class CAPQL(MOAgent, MOPolicy):
             B = s_obs.shape[0]
             # two draws shaped like the reference's two rsample() calls (capql.py:326, :341): on the CPU test backend
             # this consumes torch's generator exactly as the reference does
-            eps = (th.randn((B, self.action_dim), dtype=th.float32, device=e.q.device),
-                   th.randn((B, self.action_dim), dtype=th.float32, device=e.q.device))
+            eps = (randn((B, self.action_dim), e.q.device), randn((B, self.action_dim), e.q.device))
             self._q_step += 1
             self._p_step += 1
             cfg = e.make_cfg(gamma=self.gamma, tau=self.tau, alpha=self.alpha, q_lr=self.learning_rate,

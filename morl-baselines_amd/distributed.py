@@ -34,6 +34,7 @@ from typing import Optional
 import torch as th
 
 from . import ops
+from .acnets import randn
 from .envelope import Envelope, random_weights
 
 
@@ -67,8 +68,7 @@ def shard_capql_agent(agent, dist, group=None):
         for _ in range(self.gradient_updates):
             s_obs, s_actions, w, s_rewards, s_next_obs, s_dones = self._sample_batch_experiences()
             B = s_obs.shape[0]
-            eps = (th.randn((B, self.action_dim), dtype=th.float32, device=e.q.device),
-                   th.randn((B, self.action_dim), dtype=th.float32, device=e.q.device))
+            eps = (randn((B, self.action_dim), e.q.device), randn((B, self.action_dim), e.q.device))
             self._q_step += 1
             self._p_step += 1
             cfg = e.make_cfg(gamma=self.gamma, tau=self.tau, alpha=self.alpha, q_lr=self.learning_rate,

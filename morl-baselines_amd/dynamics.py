@@ -19,6 +19,7 @@ import torch as th
 from torch import nn
 
 from . import native
+from .acnets import randn
 from .native import EnsCfg, EnsDesc, NativeLib
 
 DECAYS = (0.000025, 0.00005, 0.000075, 0.000075, 0.0001)      # probabilistic_ensemble.py:205
@@ -156,7 +157,7 @@ class ProbabilisticEnsemble(nn.Module):
         if deterministic:
             return (mean, logvar) if return_dist else mean
         std = th.exp(0.5 * logvar)
-        samples = mean + std * th.randn(std.shape, device=std.device)
+        samples = mean + std * randn(std.shape, std.device)
         return (samples, mean, logvar) if return_dist else samples
 
     def sample(self, input, deterministic=False):

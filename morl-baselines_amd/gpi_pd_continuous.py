@@ -24,7 +24,7 @@ import torch as th
 
 from .evaluation import front_returns
 from .ac_engine import ALGO_TD3, ACEngine
-from .acnets import PolicyShell, QNetworkShell, adam_state_dict, as_f32, bind, load_adam_state_dict
+from .acnets import PolicyShell, QNetworkShell, adam_state_dict, as_f32, bind, load_adam_state_dict, randn
 from .api import MOAgent, MOPolicy
 from .native import NativeLib, load_library
 from .replay import PrioritizedReplayBuffer, ReplayBuffer
@@ -208,7 +208,7 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
                 n = obs_t.shape[0]
                 w = weight.repeat(n, 1)
                 # Policy.forward with noise (:50-58): one th.randn_like draw per call, the whole batch at once
-                noise = th.randn((n, self.action_dim), dtype=th.float32, device=dev)
+                noise = randn((n, self.action_dim), dev)
                 actions = th.cat([e.policy_forward(obs_t[b:b + e.max_rows].contiguous(), w[b:b + e.max_rows].contiguous(),
                                                    eps=noise[b:b + e.max_rows].contiguous(), cfg=cfg)[0]
                                   for b in range(0, n, e.max_rows)], dim=0)
@@ -257,7 +257,7 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
                              q_step=self._q_step, policy_step=self._p_step, do_policy=do_policy,
                              policy_noise=self.policy_noise, noise_clip=self.noise_clip, n_per=(n_per if self.per else 0),
                              dropout_seed=self._drop_seed)
-            noise = th.randn((rows, self.action_dim), dtype=th.float32, device=dev)
+            noise = randn((rows, self.action_dim), dev)
             want = ("critic_loss",) + (("policy_loss",) if do_policy else ()) + (("priority",) if self.per else ())
             out = e.update(cfg, obs=s_obs, actions=s_actions, rewards=s_rewards, next_obs=s_next_obs,
                            dones=s_dones.reshape(-1), w=w, eps_next=noise, want=want)
@@ -310,7 +310,7 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
     def _explore_action(self, obs, tensor_w) -> np.ndarray:
         e = self.engine
         o = as_f32(np.asarray(obs, dtype=np.float32), e.q.device).reshape(1, -1)
-        noise = th.randn((1, self.action_dim), dtype=th.float32, device=e.q.device)
+        noise = randn((1, self.action_dim), e.q.device)
         cfg = e.make_cfg(policy_noise=self.policy_noise, noise_clip=self.noise_clip)
         return e.policy_forward(o, tensor_w.reshape(1, -1), eps=noise, cfg=cfg)[0, 0].cpu().numpy()
 

@@ -28,6 +28,7 @@ from typing import Callable, List, Optional, Tuple, Union
 import numpy as np
 import torch as th
 
+from .acnets import randn
 from .ac_engine import ALGO_MOSAC, ALGO_SACD, ACEngine
 from .api import MOAgent
 from .mosac import MOSAC
@@ -268,7 +269,7 @@ class MORLD(MOAgent):
                     e.update(cfg, obs=stack(0), actions=stack(1), rewards=stack(2), next_obs=stack(3), dones=stack(4), w=w,
                              want=(), first=run[0], count=n)
                 else:
-                    eps = th.randn((1 + 2 * ref.policy_freq, n, B, e.Ad), dtype=th.float32, device=e.q.device)
+                    eps = randn((1 + 2 * ref.policy_freq, n, B, e.Ad), e.q.device)
                     e.update(cfg, obs=stack(0), actions=stack(1), rewards=stack(2), next_obs=stack(3), dones=stack(4), w=w,
                              eps_next=eps[0], eps_pi=eps[1:1 + ref.policy_freq], eps_alpha=eps[1 + ref.policy_freq:],
                              want=(), first=run[0], count=n)

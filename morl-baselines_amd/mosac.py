@@ -20,7 +20,7 @@ import numpy as np
 import torch as th
 
 from .ac_engine import ALGO_MOSAC, ACEngine
-from .acnets import PolicyShell, SoftQShell, adam_state_dict, as_f32, bind, load_adam_state_dict
+from .acnets import PolicyShell, SoftQShell, adam_state_dict, as_f32, bind, load_adam_state_dict, noise_device, randn
 from .api import MOPolicy
 from .native import NativeLib, load_library
 from .replay import ReplayBuffer
@@ -195,7 +195,7 @@ class MOSAC(MOPolicy):
     def _sampled_action(self, obs) -> np.ndarray:
         e = self.engine
         obs = as_f32(np.asarray(obs, dtype=np.float32), e.q.device).reshape(1, -1)
-        eps = th.randn((1, e.Ad), dtype=th.float32, device=e.q.device)
+        eps = randn((1, e.Ad), e.q.device)
         return e.policy_forward(obs, eps=eps)[0, 0].detach().cpu().numpy()
 
     def eval(self, obs: np.ndarray, w: Optional[np.ndarray] = None) -> Union[int, np.ndarray]:
@@ -226,13 +226,14 @@ class MOSAC(MOPolicy):
         # draws in the reference's order (next action; per actor iteration: pi, then the alpha re-sample), one call each,
         # so that the CPU test backend consumes torch's generator exactly as mosac_continuous_action.py:436-468 does
         pf = self.policy_freq
-        eps = th.empty((1 + 2 * pf, B, Ad), dtype=th.float32, device=e.q.device)
+        eps = th.empty((1 + 2 * pf, B, Ad), dtype=th.float32, device=noise_device(e.q.device))
         eps[0].normal_()
         if cfg.do_policy:
             for k in range(pf):
                 eps[1 + k].normal_()
                 if self.autotune:
                     eps[1 + pf + k].normal_()
+        eps = eps.to(e.q.device)
         self._out = e.update(cfg, obs=obs, actions=act, rewards=rew, next_obs=nobs, dones=dones, w=self.weights_tensor,
                              eps_next=eps[0], eps_pi=eps[1:1 + self.policy_freq], eps_alpha=eps[1 + self.policy_freq:],
                              want=("critic_loss", "q_losses", "policy_loss", "alpha_loss"))

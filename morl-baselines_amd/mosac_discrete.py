@@ -19,7 +19,7 @@ from torch import nn
 from torch.distributions import Categorical
 
 from .ac_engine import ALGO_SACD, ACEngine
-from .acnets import adam_state_dict, as_f32, bind, build_mlp, layer_init, load_adam_state_dict
+from .acnets import adam_state_dict, as_f32, bind, build_mlp, layer_init, load_adam_state_dict, noise_device
 from .api import MOPolicy
 from .native import NativeLib, load_library
 from .replay import ReplayBuffer
@@ -196,7 +196,7 @@ class MOSACDiscrete(MOPolicy):
         e = self.engine
         o = as_f32(np.asarray(obs, dtype=np.float32), e.q.device).reshape(1, -1)
         logits = e.policy_forward(o)[0]                       # (1, A)
-        action = Categorical(logits=logits).sample()          # torch generator of the logits' device, as in the reference
+        action = Categorical(logits=logits.to(noise_device(logits.device))).sample()   # (see acnets.HOST_NOISE)
         return action[0].detach().cpu().numpy()
 
     def eval(self, obs: np.ndarray, w: Optional[np.ndarray] = None) -> Union[int, np.ndarray]:
@@ -221,7 +221,7 @@ class MOSACDiscrete(MOPolicy):
         # The reference's update() calls actor.get_action() twice and throws the sampled actions away
         # (mosac_discrete_action.py:450, :476): those two Categorical.sample() calls still advance torch's generator.  Burn
         # the same draws (one per row, independent of the probabilities) so that seeded runs keep acting identically.
-        burn = th.ones((obs.shape[0], self.action_dim), dtype=th.float32, device=self.engine.q.device)
+        burn = th.ones((obs.shape[0], self.action_dim), dtype=th.float32, device=noise_device(self.engine.q.device))
         th.multinomial(burn, 1, True)
         th.multinomial(burn, 1, True)
         self._out = self.engine.update(cfg, obs=obs, actions=act, rewards=rew, next_obs=nobs, dones=dones,

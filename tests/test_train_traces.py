@@ -17,13 +17,29 @@ import morl_baselines_amd.native as native
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_traces_ac.npz")
 
 
-@pytest.fixture(scope="module")
-def sim():
-    import simlib
-    lib = simlib.load_sim()
-    native.use_library(lib)
-    yield lib
-    native.use_library(None)
+class _Backend:
+    """What the trace tests need: the library, the device string the agents get, and the RNG placement."""
+
+    def __init__(self, lib, device):
+        self.lib, self.device = lib, device
+
+
+@pytest.fixture(scope="module", params=["sim", pytest.param("hip", marks=pytest.mark.gpu)])
+def sim(request):
+    """CPU: the kernel sources under the wave emulator.  MI355X: the real library, with every noise draw taken from torch's
+    CPU generator (acnets.HOST_NOISE) -- the stream the reference consumed when the golden traces were recorded -- so the
+    GPU run replays the reference's seeded run draw for draw."""
+    import morl_baselines_amd.acnets as acnets
+    if request.param == "sim":
+        import simlib
+        lib = simlib.load_sim()
+        native.use_library(lib)
+        yield _Backend(lib, "cpu")
+        native.use_library(None)
+        return
+    acnets.HOST_NOISE = True
+    yield _Backend(native.load_library(), "cuda:0")
+    acnets.HOST_NOISE = False
 
 
 def load_init(g, prefix, modules):
@@ -49,7 +65,7 @@ def test_capql_trace(sim):
     g = np.load(GOLD)
     tc.reseed(tc.SEED)
     env = momdp.PointReach(tc.SEED)
-    ag = CAPQL(env, log=False, seed=tc.SEED, device="cpu", lib=sim, **tc.CAPQL)
+    ag = CAPQL(env, log=False, seed=tc.SEED, device=sim.device, lib=sim.lib, **tc.CAPQL)
     params = load_init(g, "capql_init", ag.q_nets + ag.target_q_nets + [ag.policy])
     tc.reseed()
     ag.train(total_timesteps=tc.CAPQL_STEPS)
@@ -63,13 +79,13 @@ def test_mosac_trace(sim):
     g = np.load(GOLD)
     tc.reseed(tc.SEED)
     env = momdp.PointReach(tc.SEED)
-    ag = MOSAC(env, tc.MOSAC_WEIGHTS.copy(), log=False, seed=tc.SEED, device="cpu", lib=sim, **tc.MOSAC)
+    ag = MOSAC(env, tc.MOSAC_WEIGHTS.copy(), log=False, seed=tc.SEED, device=sim.device, lib=sim.lib, **tc.MOSAC)
     params = load_init(g, "mosac_init", [ag.actor, ag.qf1, ag.qf2, ag.qf1_target, ag.qf2_target])
     tc.reseed()
     ag.train(total_timesteps=tc.MOSAC_STEPS)
     np.testing.assert_allclose(np.asarray(env.action_log), g["mosac_actions"], rtol=0, atol=5e-5)
     worst = check_final(g, "mosac_final", params, atol=1e-4)
-    np.testing.assert_allclose(ag.log_alpha.numpy(), g["mosac_log_alpha"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ag.log_alpha.cpu().numpy(), g["mosac_log_alpha"], rtol=0, atol=2e-5)
     print(f"\nMOSAC: {tc.MOSAC_STEPS} steps / {ag._q_step} updates, max parameter deviation {worst:.2e}")
 
 
@@ -78,7 +94,7 @@ def test_gpils_continuous_trace(sim):
     g = np.load(GOLD)
     tc.reseed(tc.SEED)
     env = momdp.PointReach(tc.SEED)
-    ag = GPILSContinuousAction(env, log=False, seed=tc.SEED, device="cpu", lib=sim, q_drop_rate=0.0, **tc.GPILS_CONT)
+    ag = GPILSContinuousAction(env, log=False, seed=tc.SEED, device=sim.device, lib=sim.lib, q_drop_rate=0.0, **tc.GPILS_CONT)
     params = load_init(g, "gpic_init", ag.q_nets + ag.target_q_nets + [ag.policy, ag.target_policy])
     tc.reseed()
     ag.train_iteration(total_timesteps=tc.GPILS_CONT_STEPS, weight=tc.WEIGHT.copy(),
@@ -94,7 +110,7 @@ def test_gpils_discrete_trace(sim):
     g = np.load(GOLD)
     tc.reseed(tc.SEED)
     env = momdp.TreasureLine(tc.SEED)
-    ag = GPILS(env, log=False, seed=tc.SEED, device="cpu", lib=sim, **tc.GPILS)
+    ag = GPILS(env, log=False, seed=tc.SEED, device=sim.device, lib=sim.lib, **tc.GPILS)
     params = load_init(g, "gpi_init", ag.q_nets + ag.target_q_nets)
     tc.reseed()
     ag.train_iteration(total_timesteps=tc.GPILS_STEPS, weight=tc.WEIGHT.copy(), weight_support=[s.copy() for s in tc.SUPPORT],
@@ -110,7 +126,7 @@ def test_envelope_trace(sim):
     g = np.load(GOLD)
     tc.reseed(tc.SEED)
     env = momdp.TreasureLine(tc.SEED)
-    ag = Envelope(env, log=False, seed=tc.SEED, device="cpu", lib=sim, **tc.ENVELOPE)
+    ag = Envelope(env, log=False, seed=tc.SEED, device=sim.device, lib=sim.lib, **tc.ENVELOPE)
     params = load_init(g, "env_init", [ag.q_net, ag.target_q_net])
     tc.reseed()
     ag.train(total_timesteps=tc.ENVELOPE_STEPS)
@@ -126,13 +142,13 @@ def test_mosac_discrete_trace(sim):
     g = np.load(GOLD)
     tc.reseed(tc.SEED)
     env = momdp.TreasureLine(tc.SEED)
-    ag = MOSACDiscrete(env, tc.SACD_WEIGHTS.copy(), log=False, seed=tc.SEED, device="cpu", lib=sim, **tc.SACD)
+    ag = MOSACDiscrete(env, tc.SACD_WEIGHTS.copy(), log=False, seed=tc.SEED, device=sim.device, lib=sim.lib, **tc.SACD)
     params = load_init(g, "sacd_init", [ag.actor, ag.qf1, ag.qf2, ag.qf1_target, ag.qf2_target])
     tc.reseed()
     ag.train(total_timesteps=tc.SACD_STEPS)
     assert np.array_equal(np.asarray(env.action_log, dtype=np.int8), g["sacd_actions"])
     worst = check_final(g, "sacd_final", params, atol=1e-4)
-    np.testing.assert_allclose(ag.log_alpha.numpy(), g["sacd_log_alpha"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(ag.log_alpha.cpu().numpy(), g["sacd_log_alpha"], rtol=0, atol=2e-5)
     print(f"\nMOSAC discrete: {tc.SACD_STEPS} steps / {ag._q_step} updates, max parameter deviation {worst:.2e}")
 
 
@@ -143,7 +159,7 @@ def test_gpipd_dyna_trace(sim):
     g = np.load(GOLD)
     tc.reseed(tc.SEED)
     env = momdp.TreasureLine(tc.SEED, env_id=tc.GPIPD_DYNA_ENV_ID)
-    ag = GPIPD(env, log=False, seed=tc.SEED, device="cpu", lib=sim, dynamics_train_freq=lambda t: tc.GPIPD_DYNA_TRAIN_FREQ,
+    ag = GPIPD(env, log=False, seed=tc.SEED, device=sim.device, lib=sim.lib, dynamics_train_freq=lambda t: tc.GPIPD_DYNA_TRAIN_FREQ,
                dynamics_max_rows=256, **tc.GPIPD_DYNA)
     params = load_init(g, "dyna_init", ag.q_nets + ag.target_q_nets)
     ag.dynamics_fit_kwargs = dict(tc.GPIPD_DYNA_FIT)
@@ -161,7 +177,7 @@ def test_gpipd_dyna_trace(sim):
     np.testing.assert_allclose(ag.dynamics_buffer.rewards[:nb], g["dyna_model_rewards"], rtol=0, atol=2e-4)
     sd = ag.dynamics.state_dict()
     for l in range(nl):
-        np.testing.assert_allclose(sd[f"layers.{l}.W"].numpy(), g[f"dyna_model_W{l}"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(sd[f"layers.{l}.W"].cpu().numpy(), g[f"dyna_model_W{l}"], rtol=0, atol=1e-4)
     worst = check_final(g, "dyna_final", params, atol=2e-4)
     assert float(ag.replay_buffer.tree.nodes[0][0]) == pytest.approx(float(g["dyna_tree_root"]), rel=1e-3)
     print(f"\nGPI-PD + Dyna: {tc.GPIPD_DYNA_STEPS} steps / {ag._adam_step} updates, {nb} imagined transitions, "
@@ -175,7 +191,7 @@ def test_gpipd_continuous_dyna_trace(sim):
     g = np.load(GOLD)
     tc.reseed(tc.SEED)
     env = momdp.PointReach(tc.SEED, env_id=tc.GPIPD_CONT_DYNA_ENV_ID)
-    ag = GPIPDContinuousAction(env, log=False, seed=tc.SEED, device="cpu", lib=sim, q_drop_rate=0.0, dynamics_max_rows=256,
+    ag = GPIPDContinuousAction(env, log=False, seed=tc.SEED, device=sim.device, lib=sim.lib, q_drop_rate=0.0, dynamics_max_rows=256,
                                **tc.GPIPD_CONT_DYNA)
     params = load_init(g, "dynac_init", ag.q_nets + ag.target_q_nets + [ag.policy, ag.target_policy])
     ag.dynamics_fit_kwargs = dict(tc.GPIPD_DYNA_FIT)
