@@ -28,7 +28,7 @@ from typing import Callable, List, Optional, Tuple, Union
 import numpy as np
 import torch as th
 
-from .acnets import randn
+from .acnets import noise_device, randn
 from .ac_engine import ALGO_MOSAC, ALGO_SACD, ACEngine
 from .api import MOAgent
 from .mosac import MOSAC
@@ -191,8 +191,9 @@ class MORLD(MOAgent):
     def _eval_policy(self, policy: Policy, eval_env, num_eval_episodes_for_front: int) -> np.ndarray:
         acc = np.zeros(self.reward_dim)
         for _ in range(num_eval_episodes_for_front):
+            # (each call is itself the mean of policy_eval's default 5 episodes, as in the reference: morld.py:280-290)
             _, _, _, disc = policy.wrapped.policy_eval(eval_env, weights=policy.weights, scalarization=self.scalarization,
-                                                       num_episodes=1, log=self.log)
+                                                       log=self.log)
             acc += disc
         return acc / num_eval_episodes_for_front
 
@@ -269,7 +270,22 @@ class MORLD(MOAgent):
                     e.update(cfg, obs=stack(0), actions=stack(1), rewards=stack(2), next_obs=stack(3), dones=stack(4), w=w,
                              want=(), first=run[0], count=n)
                 else:
-                    eps = randn((1 + 2 * ref.policy_freq, n, B, e.Ad), e.q.device)
+                    pf = ref.policy_freq
+                    if noise_device(e.q.device).type == "cpu":
+                        # host generator: one call per tensor in the order of the reference's sequential updates (learner by
+                        # learner: next-action noise, then per actor iteration pi and, with autotune, the alpha re-sample --
+                        # mosac_continuous_action.py:436-468), so a seeded run consumes the stream exactly like the reference
+                        eps = th.empty((1 + 2 * pf, n, B, e.Ad), dtype=th.float32)
+                        for j in range(n):
+                            eps[0, j].normal_()
+                            if cfg.do_policy:
+                                for k in range(pf):
+                                    eps[1 + k, j].normal_()
+                                    if ref.autotune:
+                                        eps[1 + pf + k, j].normal_()
+                        eps = eps.to(e.q.device)
+                    else:
+                        eps = randn((1 + 2 * pf, n, B, e.Ad), e.q.device)
                     e.update(cfg, obs=stack(0), actions=stack(1), rewards=stack(2), next_obs=stack(3), dones=stack(4), w=w,
                              eps_next=eps[0], eps_pi=eps[1:1 + ref.policy_freq], eps_alpha=eps[1 + ref.policy_freq:],
                              want=(), first=run[0], count=n)

@@ -167,6 +167,28 @@ def main():
     print("dyna continuous: model buffer", nb, "elites", ag.dynamics.elites, "uncertainty quantiles",
           np.quantile(np.concatenate(uncs), [0.0, 0.25, 0.5, 0.75, 1.0]))
 
+    # ---- MORL/D: population of MOSAC learners, shared buffer, transfer, PSA weight adaptation ---------------------------------
+    from morl_baselines.multi_policy.morld import morld as morld_mod
+    morld_mod.equally_spaced_weights = lambda dim, n, seed=None: [w.copy() for w in tc.MORLD_WEIGHTS]   # pymoo is absent
+    tc.reseed(tc.SEED)
+    env, eval_env = momdp.PointReach(tc.SEED), momdp.PointReach(tc.SEED + 1)
+    ag = morld_mod.MORLD(env, log=False, seed=tc.SEED, device="cpu", **tc.MORLD)
+    for k, pol in enumerate(ag.population):
+        w = pol.wrapped
+        dump(out, f"morld_init_{k}", params_of([w.actor, w.qf1, w.qf2, w.qf1_target, w.qf2_target]))
+    tc.reseed()
+    ag.train(total_timesteps=tc.MORLD_STEPS, eval_env=eval_env, ref_point=np.zeros(2), num_eval_episodes_for_front=1,
+             checkpoints=False)
+    for k, pol in enumerate(ag.population):
+        w = pol.wrapped
+        dump(out, f"morld_final_{k}", params_of([w.actor, w.qf1, w.qf2, w.qf1_target, w.qf2_target]))
+        out[f"morld_log_alpha_{k}"] = w.log_alpha.detach().numpy().copy()
+    out["morld_actions"] = np.asarray(env.action_log)
+    out["morld_eval_actions"] = np.asarray(eval_env.action_log)
+    out["morld_weights"] = np.stack([np.asarray(p_.weights, dtype=np.float64) for p_ in ag.population])
+    out["morld_archive"] = np.stack(ag.archive.evaluations)
+    print("morld: archive", len(ag.archive.evaluations), "weights", out["morld_weights"].round(3).tolist())
+
     # ---- MOSAC with discrete actions -------------------------------------------------------------------------------------------
     tc.reseed(tc.SEED)
     env = momdp.TreasureLine(tc.SEED)

@@ -36,6 +36,12 @@ GPIPD_CONT_DYNA = dict(net_arch=[16, 16], batch_size=8, learning_starts=16, buff
                        dynamics_buffer_size=300, dynamics_min_uncertainty=3.143, dynamics_real_ratio=0.5)
 GPIPD_CONT_DYNA_STEPS = 44
 GPIPD_CONT_DYNA_ENV_ID = "mo-mountaincar-like-point-v0"   # terminates imagined roll-outs at x >= 0.45
+MORLD = dict(pop_size=3, exchange_every=14, update_passes=2, neighborhood_size=1, sharing_mechanism=[],   # ("transfer" crashes
+             # in the reference with MOSAC learners: morld.py:365 reads a learning_rate attribute MOSAC does not have)
+             shared_buffer=True, weight_adaptation_method="PSA", gamma=0.97,
+             policy_args=dict(net_arch=[16, 16], batch_size=8, learning_starts=6, buffer_size=500))
+MORLD_STEPS = 56
+MORLD_WEIGHTS = np.array([[0.0, 1.0], [0.5, 0.5], [1.0, 0.0]])     # what equally_spaced_weights is patched to return (pymoo absent)
 SUPPORT = [np.array([1.0, 0.0], dtype=np.float32), np.array([0.0, 1.0], dtype=np.float32),
            np.array([0.5, 0.5], dtype=np.float32)]
 WEIGHT = np.array([0.4, 0.6], dtype=np.float32)

@@ -75,6 +75,9 @@ class TreasureLine:
         self.r = self.c = self.t = 0
         return self._obs(), {}
 
+    def close(self):
+        pass
+
     def step(self, action):
         action = int(action)
         self.action_log.append(action)
@@ -123,6 +126,9 @@ class PointReach:
     def reset(self, seed=None, options=None):
         self.x, self.t = 0.0, 0
         return self._obs(), {}
+
+    def close(self):
+        pass
 
     def step(self, action):
         self.action_log.append(np.asarray(action, dtype=np.float32).reshape(-1).copy())
