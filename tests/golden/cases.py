@@ -44,6 +44,10 @@ CASES: List[Case] = [
 # The BASELINE.json shape itself (B=256 x W=64 x R=3).  Kept out of CASES: the emulator cannot run it and its target
 # tensor is large; tests/test_flagship_golden.py (gpu) uses the reduced fixture written by make_golden.py.
 FLAGSHIP = Case("flagship_full", B=256, W=64, D=32, A=6, R=3, arch=(256, 256, 256, 256), step=3, seed=6, subsample=257)
+# BASELINE.json configs[1]: Envelope on mo-minecart-v0 (7 observations, 6 actions, 3 objectives), batch 256 x 32 weights
+MINECART = Case("minecart_b256w32", B=256, W=32, D=7, A=6, R=3, arch=(256, 256, 256, 256), step=2, seed=8, gamma=0.98,
+                max_grad_norm=0.1, subsample=257)
+FULL_SIZE = [FLAGSHIP, MINECART]
 
 
 def layer_dims(c: Case):

@@ -23,7 +23,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
 import ref_harness as rh  # noqa: E402
-from cases import CASES, FLAGSHIP, Case, make_inputs, pareto_sets  # noqa: E402
+from cases import CASES, FULL_SIZE, Case, make_inputs, pareto_sets  # noqa: E402
 
 
 def run_case(ref, c: Case) -> dict:
@@ -76,7 +76,7 @@ def run_case(ref, c: Case) -> dict:
     t_nobs = batch[3].repeat(c.W, 1)
     if c.envelope:
         rec["target"] = ag.envelope_target(t_nobs, w, sw).numpy().copy()
-        if c.name == "flagship_full":   # the arg-max indices of envelope.py:420-426, from the reference's own modules
+        if c.subsample >= 200:          # full-size cases: the arg-max indices of envelope.py:420-426, from the reference's own modules
             with th.no_grad():
                 Wr = sw.repeat(t_nobs.size(0), 1)
                 nob = t_nobs.repeat_interleave(c.W, 0)
@@ -185,14 +185,20 @@ def main():
         np.savez_compressed(os.path.join(HERE, "train_trace.npz"), **tr)
         print("train trace: HV per quarter", tr["hv"])
         return
-    for c in CASES:
+    only_new = "--only-new" in sys.argv       # add fixtures of new full-size cases without rewriting the committed ones
+    for c in ([] if only_new else CASES):
         out = run_case(ref, c)
         np.savez_compressed(os.path.join(HERE, f"envelope_{c.name}.npz"), **out)
         print(f"{c.name}: loss={out['loss']:.6g} grad_norm={out['grad_norm']:.6g}")
     th.set_num_threads(8)
-    out = run_case(ref, FLAGSHIP)
-    np.savez_compressed(os.path.join(HERE, f"envelope_{FLAGSHIP.name}.npz"), **out)
-    print(f"{FLAGSHIP.name}: loss={out['loss']:.6g} grad_norm={out['grad_norm']:.6g}")
+    for big in FULL_SIZE:
+        if only_new and os.path.exists(os.path.join(HERE, f"envelope_{big.name}.npz")):
+            continue
+        out = run_case(ref, big)
+        np.savez_compressed(os.path.join(HERE, f"envelope_{big.name}.npz"), **out)
+        print(f"{big.name}: loss={out['loss']:.6g} grad_norm={out['grad_norm']:.6g}")
+    if only_new:
+        return
     masks = {}
     for name, pts in pareto_sets().items():
         for rd in (True, False):

@@ -1,4 +1,5 @@
-"""BASELINE.json's own shape (B=256 x W=64 x R=3, net [256]*4) on the GPU, against what the unmodified reference
+"""BASELINE.json's own shapes (the metric's B=256 x W=64 x R=3 with 32 observations, and configs[1]: mo-minecart, B=256 x
+W=32; net [256]*4) on the GPU, against what the unmodified reference
 produced for the same seeded inputs (tests/golden/envelope_flagship_full.npz, written by tests/golden/make_golden.py)
 and through size-independent properties.  GPU only: the emulator cannot run 16 384 rows."""
 import os
@@ -8,7 +9,7 @@ import pytest
 import torch as th
 
 import envelope_oracle as orc
-from cases import FLAGSHIP, make_inputs
+from cases import FULL_SIZE, make_inputs
 
 import morl_baselines_amd.ops as ops
 from morl_baselines_amd.native import load_library
@@ -21,9 +22,9 @@ def flat(ps):
     return th.cat([th.as_tensor(p).reshape(-1) for p in ps])
 
 
-@pytest.fixture(scope="module")
-def run():
-    c = FLAGSHIP
+@pytest.fixture(scope="module", params=FULL_SIZE, ids=lambda c: c.name)
+def run(request):
+    c = request.param
     lib = load_library()
     dev = th.device("cuda:0")
     inp = make_inputs(c)
@@ -39,7 +40,7 @@ def run():
                               sw.to(dev), gamma=c.gamma, lr=c.lr, adam_step=c.step, max_grad_norm=c.max_grad_norm,
                               debug=True)
     th.cuda.synchronize()
-    return c, inp, res, t, sw, np.load(os.path.join(GOLD, "envelope_flagship_full.npz"))
+    return c, inp, res, t, sw, np.load(os.path.join(GOLD, f"envelope_{c.name}.npz"))
 
 
 def test_loss_and_grad_norm_match_reference(run):
