@@ -285,10 +285,15 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
         if self.use_gpi and len(self.weight_support) > 0:
             M = self.stacked_weight_support
             m = M.size(0)
-            actions_original = e.policy_forward(obs.expand(m, -1).contiguous(), M)[0]            # (m, Ad): pi(s, w_i)
-            # critic 0 at every (policy action a_i, conditioning weight w_p) pair: row p * m + i
-            q = e.q_forward(obs.expand(m * m, -1).contiguous(), actions_original.repeat(m, 1),
-                            M.repeat_interleave(m, dim=0))[0, 0].view(m, m, self.reward_dim)
+            cap = e.max_rows
+            actions_original = th.cat([e.policy_forward(obs.expand(min(cap, m - b), -1).contiguous(), M[b:b + cap].contiguous())[0]
+                                       for b in range(0, m, cap)], dim=0)                           # (m, Ad): pi(s, w_i)
+            # critic 0 at every (policy action a_i, conditioning weight w_p) pair: row p * m + i -- |M|^2 rows (4096 at the
+            # 64-weight GPI set of BASELINE config 3), streamed through the engine's workspace in chunks of max_rows
+            acts_rows, w_rows = actions_original.repeat(m, 1), M.repeat_interleave(m, dim=0)
+            q = th.cat([e.q_forward(obs.expand(min(cap, m * m - b), -1).contiguous(), acts_rows[b:b + cap].contiguous(),
+                                    w_rows[b:b + cap].contiguous())[0, 0] for b in range(0, m * m, cap)], dim=0)
+            q = q.view(m, m, self.reward_dim)
             scalar_values = th.einsum("par,r->pa", q, w)
             max_q, a = th.max(scalar_values, dim=1)
             action = actions_original[a[th.argmax(max_q)]]
@@ -302,9 +307,6 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
         self.weight_support = [th.tensor(w).float().to(dev) for w in weights_no_repeat]
         if len(self.weight_support) > 0:
             self.stacked_weight_support = th.stack(self.weight_support)
-            need = len(self.weight_support) ** 2
-            if self.use_gpi and need > self.engine.max_rows:
-                raise ValueError(f"GPI evaluation needs {need} critic rows; construct with batch_size >= {need // 2}")
 
     @th.no_grad()
     def _explore_action(self, obs, tensor_w) -> np.ndarray:

@@ -445,3 +445,42 @@ def test_mosac_discrete_update_and_morld_population(be):
     algo._update_others(algo.population[0])
     assert th.equal(algo.engine.q[0], before[0]) and not th.equal(algo.engine.q[1], before[1])
     assert algo.engine.q_steps.cpu().tolist() == [0, 2, 2] and algo.engine.pol_steps.cpu().tolist() == [0, 2, 2]
+
+
+def test_gpi_eval_with_64_weight_support(be):
+    """BASELINE config 3: the GPI set of 64 weight vectors -- |M|^2 = 4096 critic rows per evaluated action, streamed
+    through a batch-128 engine's workspace in chunks; must pick the action the oracle's dense evaluation picks."""
+    lib, dev = be
+    if dev.type == "cpu":
+        pytest.skip("reference-sized networks run on the GPU only (the emulator is slow)")
+    D, Ad, R, m = 11, 3, 3, 64                              # mo-hopper-v4 shapes
+    env = BoxEnv(D=D, Ad=Ad)
+    env.reward_space = momdp.BoxSpace(0.0, 1.0, (R,), 0)
+    env.reward_dim = R
+    th.manual_seed(3)
+    ag = GPILSContinuousAction(env, net_arch=[256, 256], batch_size=128, buffer_size=256, log=False, seed=0, device=dev,
+                               lib=lib, q_drop_rate=0.0)
+    e = ag.engine
+    rng = np.random.default_rng(0)
+    sup = [w.astype(np.float32) for w in rng.dirichlet(np.ones(R), m)]
+    ag.set_weight_support(sup)
+    ag.use_gpi = True
+    qspec = ac.MlpSpec(D + Ad + R, (256, 256), R, layer_norm=True, drop_rate=0.0)
+    trunk = ac.MlpSpec(D + R, (256, 256))
+    pol, qn = cpu(e.policy_views(e.pol)), cpu(e.q_views(e.q, 0, 0))
+    M = th.stack([th.tensor(s) for s in sup])
+    for trial in range(3):
+        obs = rng.standard_normal(D).astype(np.float32)
+        w = rng.dirichlet(np.ones(R)).astype(np.float32)
+        a = ag.eval(obs, w)
+        obs_t = th.tensor(obs)[None]
+        acts = ac.td3_policy(trunk, pol, obs_t.expand(m, -1), M, e.action_scale.cpu(), e.action_bias.cpu())
+        vals = th.stack([ac.mlp_forward(qspec, qn, th.cat((obs_t.expand(m, -1), acts, M[p].expand(m, -1)), dim=-1))
+                         for p in range(m)])
+        sc = th.einsum("par,r->pa", vals, th.tensor(w))
+        mq, ai = th.max(sc, dim=1)
+        best = float(mq.max())
+        np.testing.assert_allclose(a, acts[ai[th.argmax(mq)]].numpy(), rtol=1e-4, atol=1e-5)
+        # the device's own best value is the oracle's (guards against a near-tie flipping the index silently)
+        got_rows = (np.abs(acts.numpy() - a[None]).max(1) < 1e-4).nonzero()[0]
+        assert got_rows.size >= 1 and abs(float(sc[:, got_rows[0]].max()) - best) <= 1e-5 * max(1.0, abs(best))
