@@ -855,7 +855,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
                      main_chain, s)))
                 return rc;
             main_done = true;
-            c->bits_valid = true;   // the multi launch always uses 64-row tiles
+            c->bits_valid = true;   // (64- and 32-row tiles write the same word layout)
         } else {
             if ((rc = chain_forward(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR, s))) return rc;
             if ((rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
@@ -936,16 +936,20 @@ extern "C" int morl_envelope_main_forward(morl_ctx* c, const float* params_onlin
     if (!params_online || !obs || !weights_local) return fail(MORL_ERR_ARG, "NULL array");
     hipStream_t s = (hipStream_t)stream;
     const int rows = B * W_local;
-    // the same passes update_core runs when the forward is not hoisted: the layer-0 input for the dW GEMM, then the chain
-    // (or the per-layer GEMMs) with the activations saved in the context
-    if ((rc = build_input(obs, weights_local, c->x0m, B, W_local, c->net.obs_dim, c->net.reward_dim, c->ld0, 1, s))) return rc;
-    c->bits_valid = false;
     if (c->use_fused) {
+        // exactly the third pass of the unsharded step's fused launch: activations and ReLU sign bits saved in the context,
+        // the layer-0 input of the dW GEMM written from the kernel's own input assembly
         if ((rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
-        if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights_local, B, W_local, 1, rows, true, c->qm, c->ldq, s)))
-            return rc;
-    } else if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) {
-        return rc;
+        ChainArgs one = make_forward_chain(c, params_online, c->wt_online, obs, weights_local, B, W_local, 1, rows, true, c->qm,
+                                           c->ldq, true);
+        one.x0_out = c->x0m;
+        one.ldx0 = c->ld0;
+        if ((rc = chain_forward_multi(c, &one, 1, s))) return rc;
+        c->bits_valid = true;
+    } else {
+        if ((rc = build_input(obs, weights_local, c->x0m, B, W_local, c->net.obs_dim, c->net.reward_dim, c->ld0, 1, s))) return rc;
+        c->bits_valid = false;
+        if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
     }
     c->main_rows = rows;
     return MORL_OK;

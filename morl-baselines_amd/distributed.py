@@ -134,7 +134,7 @@ def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
             # 5. identical optimiser step everywhere
             ops.clip_adam(ctx, self.q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq, lr=self.learning_rate,
                           adam_step=self._adam_step, max_grad_norm=self.max_grad_norm)
-            pr = gx[P + 1:].clone()
+            pr = gx[P + 1:]                           # (a view: consumed below, valid until the next step's all-reduce)
             self._out = {"loss": loss, "priority": pr}
             self._losses.append(loss)
             if self.per:
