@@ -21,17 +21,32 @@ struct GemmBatched {
     GemmProblem p;
     long long sA, sB, sC, sBias, sMask;
     int a_div;
+    // optional second segment: entries z >= split (split > 0) are the same layer shape on other buffers -- two passes
+    // that do not depend on each other (target critics at (s', a') and online critics at (s, a)) share one launch
+    int split;
+    const float* A2;
+    const float* B2;
+    const float* bias2;
+    float* C2;
 };
 
-template <bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_batched_kernel(GemmBatched b) {
+__device__ __forceinline__ GemmProblem gemm_batched_select(const GemmBatched& b, int z) {
     GemmProblem g = b.p;
-    const int z = (int)blockIdx.z;
+    if (b.split > 0 && z >= b.split) {
+        z -= b.split;
+        g.A = b.A2; g.B = b.B2; g.bias = b.bias2; g.C = b.C2;
+    }
     g.A += (long long)(z / b.a_div) * b.sA;
     g.B += (long long)z * b.sB;
     g.C += (long long)z * b.sC;
     if (g.bias) g.bias += (long long)z * b.sBias;
     if (g.mask) g.mask += (long long)z * b.sMask;
+    return g;
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_batched_kernel(GemmBatched b) {
+    const GemmProblem g = gemm_batched_select(b, (int)blockIdx.z);
     const int id = (int)blockIdx.x;
     gemm_tile<A_KC, B_KC, EPI>(g, id / g.tiles_n, id % g.tiles_n, 0);
 }
@@ -66,26 +81,15 @@ template <bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(256) void gemm_wave_batched_kernel(GemmBatched b) {
     const int tile = (int)blockIdx.x * 4 + wave_id();
     if (tile >= b.p.tiles_m * b.p.tiles_n) return;
-    GemmProblem g = b.p;
-    const int z = (int)blockIdx.z;
-    g.A += (long long)(z / b.a_div) * b.sA;
-    g.B += (long long)z * b.sB;
-    g.C += (long long)z * b.sC;
-    if (g.bias) g.bias += (long long)z * b.sBias;
-    if (g.mask) g.mask += (long long)z * b.sMask;
+    const GemmProblem g = gemm_batched_select(b, (int)blockIdx.z);
     gemm_wave_tile<A_KC, B_KC, EPI>(g, tile / g.tiles_n, tile % g.tiles_n);
 }
 
 // split-K variants: one 32 x 32 tile per workgroup, the four waves share the contraction (gemm_wave4_tile)
 template <bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(256) void gemm_wave4_batched_kernel(GemmBatched b) {
-    GemmProblem g = b.p;
-    const int z = (int)blockIdx.z, tile = (int)blockIdx.x;
-    g.A += (long long)(z / b.a_div) * b.sA;
-    g.B += (long long)z * b.sB;
-    g.C += (long long)z * b.sC;
-    if (g.bias) g.bias += (long long)z * b.sBias;
-    if (g.mask) g.mask += (long long)z * b.sMask;
+    const GemmProblem g = gemm_batched_select(b, (int)blockIdx.z);
+    const int tile = (int)blockIdx.x;
     gemm_wave4_tile<A_KC, B_KC, EPI>(g, tile / g.tiles_n, tile % g.tiles_n);
 }
 

@@ -246,9 +246,13 @@ struct DropSpec {
 };
 
 // forward of G nets (params + g * pstride) on t.x (shared by groups of x_div nets); result in t.out
+// params2 / t2 / ds2: a second, independent pass of the same network shape (other parameters, other rows) whose layer GEMMs
+// ride in the same launches (GemmBatched::split); its Dropout / LayerNorm post-ops, if any, are launched per tape
 static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape& t, int rows, int x_div,
-                       const DropSpec& ds, hipStream_t s) {
+                       const DropSpec& ds, hipStream_t s, const float* params2 = nullptr, Tape* t2 = nullptr,
+                       const DropSpec* ds2 = nullptr) {
     const long long cap = t.cap;
+    if (t2 && (t2->cap != t.cap || t2->G != t.G)) return fail(MORL_ERR_STATE, "paired passes need equally shaped tapes");
     int64_t ext_off = 0;
     for (int l = 0; l < m.L; ++l) {
         const bool last = (l == m.L - 1);
@@ -269,22 +273,39 @@ static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape&
         g.ldc = m.ld[l + 1];
         b.sC = cap * m.ld[l + 1];
         g.M = rows; g.N = m.dims[l + 1]; g.K = m.dims[l];
-        int rc = (last || post) ? launch_bgemm<true, true, EPI_BIAS>(b, t.G, s, "ac_gemm_fwd")
-                                : launch_bgemm<true, true, EPI_BIAS_RELU>(b, t.G, s, "ac_gemm_fwd_relu");
+        const bool drop2 = t2 && !last && ds2 && ds2->active && m.drop > 0.f;
+        const bool post2 = t2 && !last && (m.ln || drop2);
+        int G = t.G;
+        if (t2) {
+            // the epilogue (bias vs bias + ReLU) is chosen per launch: both passes must agree on whether a post-op follows
+            if (post != post2) return fail(MORL_ERR_STATE, "paired passes disagree on the post-op of layer %d", l);
+            b.split = t.G;
+            b.A2 = (l == 0) ? t2->x : t2->h[l - 1];
+            b.B2 = params2 + m.offW[l];
+            b.bias2 = params2 + m.offB[l];
+            b.C2 = last ? t2->out : (post ? t2->zx[l] : t2->h[l]);
+            G = 2 * t.G;
+        }
+        int rc = (last || post) ? launch_bgemm<true, true, EPI_BIAS>(b, G, s, "ac_gemm_fwd")
+                                : launch_bgemm<true, true, EPI_BIAS_RELU>(b, G, s, "ac_gemm_fwd_relu");
         if (rc) return rc;
-        if (post) {
+        for (int pass = 0; pass < (t2 ? 2 : 1) && post; ++pass) {
+            Tape& tt = pass ? *t2 : t;
+            const DropSpec& dd = pass ? *ds2 : ds;
+            const float* pp = pass ? params2 : params;
+            const bool dr = pass ? drop2 : drop;
             PostArgs a{};
-            a.z = t.zx[l]; a.h = t.h[l]; a.rstd = t.rstd[l]; a.mask = t.mask[l];
-            a.ext_mask = (drop && ds.ext) ? ds.ext + ext_off : nullptr;
-            a.ext_gstride = ds.ext_net_bytes;
-            a.gamma = m.ln ? params + m.offG[l] : nullptr;
+            a.z = tt.zx[l]; a.h = tt.h[l]; a.rstd = tt.rstd[l]; a.mask = tt.mask[l];
+            a.ext_mask = (dr && dd.ext) ? dd.ext + ext_off : nullptr;
+            a.ext_gstride = dd.ext_net_bytes;
+            a.gamma = m.ln ? pp + m.offG[l] : nullptr;
             a.pstride = pstride;
             a.gstride = cap * m.ld[l + 1];
-            a.cap = t.cap; a.N = m.dims[l + 1]; a.ld = m.ld[l + 1]; a.rows = rows;
-            a.ln = m.ln ? 1 : 0; a.drop = drop ? 1 : 0;
+            a.cap = tt.cap; a.N = m.dims[l + 1]; a.ld = m.ld[l + 1]; a.rows = rows;
+            a.ln = m.ln ? 1 : 0; a.drop = dr ? 1 : 0;
             a.drop_p = m.drop; a.inv_keep = 1.0f / (1.0f - m.drop);
-            a.seed = ds.seed * 0x100000001B3ull + (unsigned long long)(l + 1) * 0x9E3779B97F4A7C15ull;
-            hipLaunchKernelGGL(ac_post_fwd_kernel, dim3((rows + 3) / 4, t.G), dim3(256), 0, s, a);
+            a.seed = dd.seed * 0x100000001B3ull + (unsigned long long)(l + 1) * 0x9E3779B97F4A7C15ull;
+            hipLaunchKernelGGL(ac_post_fwd_kernel, dim3((rows + 3) / 4, tt.G), dim3(256), 0, s, a);
             LAUNCH_CHECK("ac_post_fwd");
         }
         if (!last) ext_off += (int64_t)rows * m.dims[l + 1];
@@ -632,8 +653,11 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     // ---- critic phase: a' ~ pi(s'), target critics at (s', a'), critics at (s, a), TD loss, backward, Adam --------------
     if ((rc = mlp_forward(P, algo == MORL_AC_TD3 ? st->pol_target : st->pol, P.P, c->tp_a, rows, 1, nodrop, s))) return rc;
     if ((rc = head_forward(c, c->tp_a, rows, bt->eps_next, st, cfg, c->act, c->logp_next, false, s, &c->tq_a))) return rc;
-    if ((rc = mlp_forward(Q, st->q_target, Q.P, c->tq_a, rows, nq, dropspec(0), s))) return rc;
-    if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, nq, dropspec(1), s))) return rc;
+    {
+        // target critics at (s', a') and online critics at (s, a): independent passes, one launch per layer
+        const DropSpec d0 = dropspec(0), d1 = dropspec(1);
+        if ((rc = mlp_forward(Q, st->q_target, Q.P, c->tq_a, rows, nq, d0, s, st->q, &c->tq_b, &d1))) return rc;
+    }
     {
         CriticArgs a{};
         a.tq = c->tq_a.out; a.q = c->tq_b.out; a.dq = c->tq_b.g[Q.L - 1];
@@ -664,8 +688,12 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     if (cfg->do_policy) {
         for (int it = 0; it < iters; ++it) {
             const float* eps_pi = (algo == MORL_AC_TD3) ? nullptr : bt->eps_pi + (long long)it * c->PG * rows * Ad;
-            // the critics' input rows (obs | . | w) are already in tq_b; the head kernel overwrites the action columns with pi(s)
-            if ((rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
+            // the critics' input rows (obs | . | w) are already in tq_b; the head kernel overwrites the action columns with pi(s).
+            // From the second iteration on with a learnt alpha, the actor's trunk and head pre-activations at s are already
+            // in tp_b: the alpha re-sample below ran the UPDATED actor on the same rows and nothing has changed it since --
+            // only the noise differs, which enters in head_forward
+            const bool trunk_current = it > 0 && autotune && algo == MORL_AC_MOSAC;
+            if (!trunk_current && (rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
             if ((rc = head_forward(c, c->tp_b, rows, eps_pi, st, cfg, c->act, c->logp_pi, true, s, &c->tq_b))) return rc;
             if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, nq, dropspec(2), s))) return rc;
             {
