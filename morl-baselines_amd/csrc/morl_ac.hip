@@ -952,10 +952,14 @@ extern "C" int morl_gpi_create(morl_gpi_ctx** out, const morl_gpi_desc* d) {
 }
 
 // QNet.forward of n_nets nets (params + g * P) on `rows` inputs shared by the nets
+// params2 / g2 / obs2 / ds2: a second, independent pass (same number of nets, rows and weight rows -- the target ensemble at
+// s' next to the online ensemble at s) whose GEMMs share the launches of the first (GemmBatched::split)
 static int gpi_forward(morl_gpi_ctx* c, const float* params, int n_nets, GpiTape& g, const float* obs, const float* w,
-                       int w_rstride, int rows, const DropSpec& ds, hipStream_t s) {
+                       int w_rstride, int rows, const DropSpec& ds, hipStream_t s, const float* params2 = nullptr,
+                       GpiTape* g2 = nullptr, const float* obs2 = nullptr, const DropSpec* ds2 = nullptr) {
     const morl_gpi_desc& d = c->d;
     g.t.G = n_nets;
+    if (g2) g2->t.G = n_nets;
     {   // sf = relu(obs @ Ws^T + bs): every net reads the same obs rows
         GemmBatched b{};
         GemmProblem& p = b.p;
@@ -964,19 +968,27 @@ static int gpi_forward(morl_gpi_ctx* c, const float* params, int n_nets, GpiTape
         p.bias = params + c->offBs; b.sBias = c->P;
         p.C = g.sf; p.ldc = c->ldH; b.sC = (long long)g.t.cap * c->ldH;
         p.M = rows; p.N = c->H0; p.K = d.obs_dim;
-        int rc = launch_bgemm<true, true, EPI_BIAS_RELU>(b, n_nets, s, "gpi_gemm_sf");
+        if (g2) {
+            if (g2->t.cap != g.t.cap) return fail(MORL_ERR_STATE, "paired passes need equally shaped tapes");
+            b.split = n_nets;
+            b.A2 = obs2; b.B2 = params2 + c->offWs; b.bias2 = params2 + c->offBs; b.C2 = g2->sf;
+        }
+        int rc = launch_bgemm<true, true, EPI_BIAS_RELU>(b, g2 ? 2 * n_nets : n_nets, s, "gpi_gemm_sf");
         if (rc) return rc;
     }
-    {
+    for (int pass = 0; pass < (g2 ? 2 : 1); ++pass) {
+        GpiTape& gg = pass ? *g2 : g;
+        const float* pp = pass ? params2 : params;
         EmbedArgs a{};
-        a.sf = g.sf; a.wf = g.wf; a.x = g.t.x;
+        a.sf = gg.sf; a.wf = gg.wf; a.x = gg.t.x;
         a.w = w; a.w_rstride = w_rstride;
-        a.params = params; a.pstride = c->P; a.offWw = c->offWw; a.offBw = c->offBw;
-        a.gstride = (long long)g.t.cap * c->ldH;
+        a.params = pp; a.pstride = c->P; a.offWw = c->offWw; a.offBw = c->offBw;
+        a.gstride = (long long)gg.t.cap * c->ldH;
         a.H = c->H0; a.ld = c->ldH; a.R = d.reward_dim; a.rows = rows; a.G = n_nets;
         hipLaunchKernelGGL(gpi_embed_fwd_kernel, dim3(stream_grid((long long)n_nets * rows * c->H0, 256)), dim3(256), 0, s, a);
         LAUNCH_CHECK("gpi_embed_fwd");
     }
+    if (g2) return mlp_forward(c->net, params + c->offNet, c->P, g.t, rows, 1, ds, s, params2 + c->offNet, &g2->t, ds2);
     return mlp_forward(c->net, params + c->offNet, c->P, g.t, rows, 1, ds, s);
 }
 
@@ -1074,7 +1086,11 @@ extern "C" int morl_gpi_update(morl_gpi_ctx* c, float* q, const float* q_target,
         return ds;
     };
     int rc;
-    if ((rc = gpi_forward(c, q_target, c->nn, c->tt, next_obs, w, R, rows, dropspec(0), s))) return rc;
+    {
+        // the target ensemble at s' and the online ensemble at s do not depend on each other: one launch per layer for both
+        const DropSpec d0 = dropspec(0), d2 = dropspec(2);
+        if ((rc = gpi_forward(c, q_target, c->nn, c->tt, next_obs, w, R, rows, d0, s, q, &c->tq, obs, &d2))) return rc;
+    }
     if (env) {
         if ((rc = gpi_envelope_inputs(c, next_obs, sampled_w, K, rows, s))) return rc;
         if ((rc = gpi_forward(c, q_target, c->nn, c->te, c->obs_rep, c->w_rep, R, rows * K, dropspec(1), s))) return rc;
@@ -1091,7 +1107,6 @@ extern "C" int morl_gpi_update(morl_gpi_ctx* c, float* q, const float* q_target,
         hipLaunchKernelGGL(gpi_target_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, a);
         LAUNCH_CHECK("gpi_target");
     }
-    if ((rc = gpi_forward(c, q, c->nn, c->tq, obs, w, R, rows, dropspec(2), s))) return rc;
     {
         GpiLossArgs a{};
         a.q = c->tq.t.out; a.dq = c->tq.t.g[L - 1]; a.gstride = (long long)c->tq.t.cap * ldq; a.ldq = ldq;
