@@ -507,8 +507,8 @@ static int sacd_update(morl_ac_ctx* c, const morl_ac_state* st, const morl_ac_ba
         LAUNCH_CHECK("sacd_inputs");
     }
     if ((rc = mlp_forward(P, st->pol, P.P, c->tp_a, rows, 1, nodrop, s))) return rc;
-    if ((rc = mlp_forward(Q, st->q_target, Q.P, c->tq_a, rows, 2, nodrop, s))) return rc;
-    if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, 2, nodrop, s))) return rc;
+    // target critics at s' and online critics at s: independent passes, one launch per layer
+    if ((rc = mlp_forward(Q, st->q_target, Q.P, c->tq_a, rows, 2, nodrop, s, st->q, &c->tq_b, &nodrop))) return rc;
     const long long q_gs = (long long)c->cap * Q.ld[Q.L], p_gs = (long long)c->cap * P.ld[P.L];
     {
         SacdCriticArgs a{};
