@@ -651,7 +651,11 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     }
 
     // ---- critic phase: a' ~ pi(s'), target critics at (s', a'), critics at (s, a), TD loss, backward, Adam --------------
-    if ((rc = mlp_forward(P, algo == MORL_AC_TD3 ? st->pol_target : st->pol, P.P, c->tp_a, rows, 1, nodrop, s))) return rc;
+    // the actor phase's first forward, pi(s), uses the not-yet-updated actor too: it shares the launches of pi(s')
+    const bool pi_s_early = cfg->do_policy != 0;
+    if ((rc = mlp_forward(P, algo == MORL_AC_TD3 ? st->pol_target : st->pol, P.P, c->tp_a, rows, 1, nodrop, s,
+                          pi_s_early ? st->pol : nullptr, pi_s_early ? &c->tp_b : nullptr, &nodrop)))
+        return rc;
     if ((rc = head_forward(c, c->tp_a, rows, bt->eps_next, st, cfg, c->act, c->logp_next, false, s, &c->tq_a))) return rc;
     {
         // target critics at (s', a') and online critics at (s, a): independent passes, one launch per layer
@@ -689,10 +693,10 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
         for (int it = 0; it < iters; ++it) {
             const float* eps_pi = (algo == MORL_AC_TD3) ? nullptr : bt->eps_pi + (long long)it * c->PG * rows * Ad;
             // the critics' input rows (obs | . | w) are already in tq_b; the head kernel overwrites the action columns with pi(s).
-            // From the second iteration on with a learnt alpha, the actor's trunk and head pre-activations at s are already
-            // in tp_b: the alpha re-sample below ran the UPDATED actor on the same rows and nothing has changed it since --
+            // The first iteration's pre-activations were computed next to pi(s') above.  From the second iteration on with a
+            // learnt alpha, the actor's trunk and head pre-activations at s are already in tp_b: the alpha re-sample below ran the UPDATED actor on the same rows and nothing has changed it since --
             // only the noise differs, which enters in head_forward
-            const bool trunk_current = it > 0 && autotune && algo == MORL_AC_MOSAC;
+            const bool trunk_current = (it == 0 && pi_s_early) || (it > 0 && autotune && algo == MORL_AC_MOSAC);
             if (!trunk_current && (rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
             if ((rc = head_forward(c, c->tp_b, rows, eps_pi, st, cfg, c->act, c->logp_pi, true, s, &c->tq_b))) return rc;
             if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, nq, dropspec(2), s))) return rc;
