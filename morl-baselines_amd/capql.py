@@ -271,7 +271,7 @@ class CAPQL(MOAgent, MOPolicy):
                 "num_eval_episodes_for_front": num_eval_episodes_for_front,
                 "num_eval_weights_for_eval": num_eval_weights_for_eval, "eval_freq": eval_freq,
                 "reset_num_timesteps": reset_num_timesteps})
-            from morl_baselines.common.evaluation import log_all_multi_policy_metrics, policy_evaluation_mo
+            from morl_baselines.common.evaluation import log_all_multi_policy_metrics
             from morl_baselines.common.weights import equally_spaced_weights
             eval_weights = equally_spaced_weights(self.reward_dim, n=num_eval_weights_for_front)
         angle = th.pi * (22.5 / 180)

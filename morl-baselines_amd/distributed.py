@@ -29,7 +29,6 @@ scaling: per-rank rows stay at ``batch_size`` and the job's batch is ``world * b
 from __future__ import annotations
 
 import types
-from typing import Optional
 
 import torch as th
 

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional, Sequence
+from typing import Optional
 
 import numpy as np
 import torch as th

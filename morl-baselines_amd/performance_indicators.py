@@ -7,7 +7,6 @@ be scored on machines without pymoo (the GPU box).  Same signatures, same conven
 worst corner)."""
 from __future__ import annotations
 
-import ctypes as C
 from typing import Callable, List, Optional
 
 import numpy as np
