@@ -906,10 +906,57 @@ __global__ __launch_bounds__(256) void sacd_actor_kernel(SacdActorArgs a) {
 // for everybody (steps == NULL) or read from the learner's device-resident counter: t = steps[g] + step_add.
 // Same arithmetic as clip_adam_kernel (optim_kernels.h) without the clipping.
 // ---------------------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------------------
+// K-major shadow copies of the weight matrices.  nn.Linear stores W_l as [out][in] = contraction-contiguous per output
+// column; a forward GEMM that reads it that way has to transpose 32 x 64 panels through LDS (gemm_wave.h), which measured
+// 13 us against 7.4 us for the otherwise identical dX launch whose weight operand is read along the output index.  The
+// update therefore keeps Wt_l [in][out] next to every parameter set: one launch at the start of an update fills them (the
+// caller may have changed the parameters between calls) and the Adam kernel refreshes the entries it steps.  Values and
+// the MFMA k order are unchanged -> results are bit-identical to the contraction-contiguous read.
+// ---------------------------------------------------------------------------------------------------------------------
+struct MlpLayout {
+    long long offW[MORL_MAX_LAYERS];
+    int K[MORL_MAX_LAYERS], N[MORL_MAX_LAYERS];
+    int L;
+    long long P;             // parameters of one net
+};
+
+// element p of a net's flat buffer -> its index in the K-major copy (non-matrix entries keep their place)
+__device__ __forceinline__ long long mlp_transposed_index(const MlpLayout& t, long long p) {
+    for (int l = 0; l < t.L; ++l) {
+        const long long rel = p - t.offW[l];
+        if (rel >= 0 && rel < (long long)t.K[l] * t.N[l]) {
+            const int n = (int)(rel / t.K[l]), k = (int)(rel - (long long)n * t.K[l]);
+            return t.offW[l] + (long long)k * t.N[l] + n;
+        }
+    }
+    return p;
+}
+
+struct TransposeMulti {
+    const float* src[4];
+    float* dst[4];
+    MlpLayout lay[4];
+    int nets[4];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void ac_transpose_multi_kernel(TransposeMulti a) {
+    const int q = (int)blockIdx.z;
+    if (q >= a.n) return;
+    const MlpLayout& t = a.lay[q];
+    const long long total = t.P * a.nets[q];
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long net = e / t.P, p = e - net * t.P;
+        a.dst[q][net * t.P + mlp_transposed_index(t, p)] = a.src[q][e];
+    }
+}
+
 __global__ __launch_bounds__(256) void ac_adam_kernel(float* __restrict__ params, const float* __restrict__ grads,
                                                       float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                                       long long seg, const int* __restrict__ steps, int step_add,
-                                                      double lr, double b1, double b2, float eps) {
+                                                      double lr, double b1, double b2, float eps,
+                                                      float* __restrict__ wt = nullptr, MlpLayout lay = MlpLayout{}) {
     const int g = (int)blockIdx.y;
     const int t = max(1, (steps ? steps[g] : 0) + step_add);
     const float neg_step_size = (float)(-(lr / (1.0 - pow(b1, (double)t))));
@@ -922,9 +969,14 @@ __global__ __launch_bounds__(256) void ac_adam_kernel(float* __restrict__ params
         m = fmaf(one_minus_b1, __fsub_rn(gr, m), m);
         v = __fadd_rn(__fmul_rn(v, fb2), __fmul_rn(__fmul_rn(one_minus_b2, gr), gr));
         const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
-        params[base + p] = __fadd_rn(params[base + p], __fmul_rn(neg_step_size, __fdiv_rn(m, denom)));
+        const float np_ = __fadd_rn(params[base + p], __fmul_rn(neg_step_size, __fdiv_rn(m, denom)));
+        params[base + p] = np_;
         exp_avg[base + p] = m;
         exp_avg_sq[base + p] = v;
+        if (wt != nullptr) {      // keep the K-major shadow copy current (seg may span several nets of lay.P parameters)
+            const long long net = p / lay.P, pp = p - net * lay.P;
+            wt[base + net * lay.P + mlp_transposed_index(lay, pp)] = np_;
+        }
     }
 }
 

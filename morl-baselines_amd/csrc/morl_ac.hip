@@ -77,6 +77,11 @@ struct morl_ac_ctx {
     float* gq = nullptr;                         // [QG][Pq]
     float* gp = nullptr;                         // [PG][Pp]
     float* alpha_dev = nullptr;                  // [PG]
+    // K-major shadow copies of the weight matrices used by the forward GEMMs of an update (ac_kernels.h: MlpLayout)
+    float* wt_q = nullptr;                       // [QG][Pq]
+    float* wt_qt = nullptr;                      // [QG][Pq]  target critics
+    float* wt_pol = nullptr;                     // [PG][Pp]
+    float* wt_polt = nullptr;                    // [PG][Pp]  target actor (TD3)
     std::vector<void*> allocs;
 };
 
@@ -188,7 +193,9 @@ extern "C" int morl_ac_create(morl_ac_ctx** out, const morl_ac_desc* d) {
         (rc = alloc_f(c, &c->act, c->PG * cap * Ad)) || (rc = alloc_f(c, &c->logp_next, c->PG * cap)) ||
         (rc = alloc_f(c, &c->logp_pi, c->PG * cap)) || (rc = alloc_f(c, &c->save_y, c->PG * cap * Ad)) ||
         (rc = alloc_f(c, &c->save_std, c->PG * cap * Ad)) || (rc = alloc_f(c, &c->gq, (size_t)c->QG * q.P)) ||
-        (rc = alloc_f(c, &c->gp, (size_t)c->PG * p.P)) || (rc = alloc_f(c, &c->alpha_dev, c->PG))) {
+        (rc = alloc_f(c, &c->gp, (size_t)c->PG * p.P)) || (rc = alloc_f(c, &c->alpha_dev, c->PG)) ||
+        (rc = alloc_f(c, &c->wt_q, (size_t)c->QG * q.P)) || (rc = alloc_f(c, &c->wt_qt, (size_t)c->QG * q.P)) ||
+        (rc = alloc_f(c, &c->wt_pol, (size_t)c->PG * p.P)) || (rc = alloc_f(c, &c->wt_polt, (size_t)c->PG * p.P))) {
         morl_ac_destroy(c);
         return rc;
     }
@@ -250,8 +257,11 @@ struct DropSpec {
 // ride in the same launches (GemmBatched::split); its Dropout / LayerNorm post-ops, if any, are launched per tape
 static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape& t, int rows, int x_div,
                        const DropSpec& ds, hipStream_t s, const float* params2 = nullptr, Tape* t2 = nullptr,
-                       const DropSpec* ds2 = nullptr) {
+                       const DropSpec* ds2 = nullptr, const float* wt = nullptr, const float* wt2 = nullptr) {
+    // wt / wt2: K-major shadow copies of params / params2 (same flat layout): the weight operand is then read along the
+    // output index like the dX GEMMs do, without the LDS panel transposes of the contraction-contiguous form
     const long long cap = t.cap;
+    if ((wt != nullptr) != (t2 ? wt2 != nullptr : wt != nullptr)) return fail(MORL_ERR_STATE, "paired passes: both or no shadow copy");
     if (t2 && (t2->cap != t.cap || t2->G != t.G)) return fail(MORL_ERR_STATE, "paired passes need equally shaped tapes");
     int64_t ext_off = 0;
     for (int l = 0; l < m.L; ++l) {
@@ -264,8 +274,8 @@ static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape&
         g.lda = m.ld[l];
         b.sA = cap * m.ld[l];
         b.a_div = (l == 0) ? x_div : 1;
-        g.B = params + m.offW[l];
-        g.ldb = m.dims[l];
+        g.B = (wt ? wt : params) + m.offW[l];
+        g.ldb = wt ? m.dims[l + 1] : m.dims[l];
         b.sB = pstride;
         g.bias = params + m.offB[l];
         b.sBias = pstride;
@@ -281,13 +291,16 @@ static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape&
             if (post != post2) return fail(MORL_ERR_STATE, "paired passes disagree on the post-op of layer %d", l);
             b.split = t.G;
             b.A2 = (l == 0) ? t2->x : t2->h[l - 1];
-            b.B2 = params2 + m.offW[l];
+            b.B2 = (wt2 ? wt2 : params2) + m.offW[l];
             b.bias2 = params2 + m.offB[l];
             b.C2 = last ? t2->out : (post ? t2->zx[l] : t2->h[l]);
             G = 2 * t.G;
         }
-        int rc = (last || post) ? launch_bgemm<true, true, EPI_BIAS>(b, G, s, "ac_gemm_fwd")
-                                : launch_bgemm<true, true, EPI_BIAS_RELU>(b, G, s, "ac_gemm_fwd_relu");
+        int rc;
+        if (wt) rc = (last || post) ? launch_bgemm<true, false, EPI_BIAS>(b, G, s, "ac_gemm_fwd_t")
+                                    : launch_bgemm<true, false, EPI_BIAS_RELU>(b, G, s, "ac_gemm_fwd_relu_t");
+        else rc = (last || post) ? launch_bgemm<true, true, EPI_BIAS>(b, G, s, "ac_gemm_fwd")
+                                 : launch_bgemm<true, true, EPI_BIAS_RELU>(b, G, s, "ac_gemm_fwd_relu");
         if (rc) return rc;
         for (int pass = 0; pass < (t2 ? 2 : 1) && post; ++pass) {
             Tape& tt = pass ? *t2 : t;
@@ -437,11 +450,20 @@ static int concat(morl_ac_ctx* c, float* dst, int ld, int G, int rows, const flo
 }
 
 // one Adam step on `G` learner segments of `seg` floats each; t = steps[g] + step_add, or step_add when steps == NULL
+static MlpLayout layout_of(const Mlp& m) {
+    MlpLayout t{};
+    t.L = m.L;
+    t.P = m.P;
+    for (int l = 0; l < m.L; ++l) { t.offW[l] = m.offW[l]; t.K[l] = m.dims[l]; t.N[l] = m.dims[l + 1]; }
+    return t;
+}
+
+// wt / net: also refresh the K-major shadow copy of the stepped parameters (seg = a whole number of `net`-shaped nets)
 static int adam(float* params, float* grads, float* m, float* v, long long seg, int G, double lr, const int* steps,
-                int step_add, const morl_ac_cfg* cfg, hipStream_t s) {
+                int step_add, const morl_ac_cfg* cfg, hipStream_t s, float* wt = nullptr, const Mlp* net = nullptr) {
     const int nblk = std::min(256, stream_grid(seg, 256));
     hipLaunchKernelGGL(ac_adam_kernel, dim3(nblk, G), dim3(256), 0, s, params, (const float*)grads, m, v, seg, steps, step_add,
-                       lr, cfg->beta1, cfg->beta2, (float)cfg->eps);
+                       lr, cfg->beta1, cfg->beta2, (float)cfg->eps, wt, wt ? layout_of(*net) : MlpLayout{});
     LAUNCH_CHECK("ac_adam");
     return MORL_OK;
 }
@@ -650,17 +672,45 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
         LAUNCH_CHECK("ac_inputs");
     }
 
+    // ---- K-major shadow copies of every parameter set this update reads in a forward pass (one launch) -----------------------
+    static const bool shadow_env = [] { const char* e = getenv("MORL_AC_SHADOW"); return e ? atoi(e) != 0 : true; }();
+    // only where the wave-tile engine runs the layers (single learners, small populations): the LDS-tiled engine of a large
+    // population stages 128 x 32 chunks either way and measured slower with the K-major weights (1.70 vs 1.27 ms at 64 learners)
+    int widest = 0;
+    for (int l = 1; l < Q.L; ++l) widest = std::max(widest, Q.dims[l]);
+    const bool use_wt = shadow_env && use_wave_tiles((long long)((rows + 127) / 128) * ((widest + 127) / 128) * QG * 2);
+#define WT(p) (use_wt ? (p) : nullptr)
+    if (use_wt) {
+        TransposeMulti tm{};
+        const bool td3 = algo == MORL_AC_TD3;
+        const float* srcs[4] = {st->q, st->q_target, st->pol, td3 ? st->pol_target : nullptr};
+        float* dsts[4] = {c->wt_q, c->wt_qt, c->wt_pol, c->wt_polt};
+        long long longest = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (!srcs[k]) continue;
+            const bool is_q = k < 2;
+            tm.src[tm.n] = srcs[k]; tm.dst[tm.n] = dsts[k];
+            tm.lay[tm.n] = layout_of(is_q ? Q : P);
+            tm.nets[tm.n] = is_q ? QG : PG;
+            longest = std::max(longest, tm.lay[tm.n].P * tm.nets[tm.n]);
+            ++tm.n;
+        }
+        hipLaunchKernelGGL(ac_transpose_multi_kernel, dim3(stream_grid(longest, 256, 1024), 1, tm.n), dim3(256), 0, s, tm);
+        LAUNCH_CHECK("ac_transpose");
+    }
+
     // ---- critic phase: a' ~ pi(s'), target critics at (s', a'), critics at (s, a), TD loss, backward, Adam --------------
     // the actor phase's first forward, pi(s), uses the not-yet-updated actor too: it shares the launches of pi(s')
     const bool pi_s_early = cfg->do_policy != 0;
     if ((rc = mlp_forward(P, algo == MORL_AC_TD3 ? st->pol_target : st->pol, P.P, c->tp_a, rows, 1, nodrop, s,
-                          pi_s_early ? st->pol : nullptr, pi_s_early ? &c->tp_b : nullptr, &nodrop)))
+                          pi_s_early ? st->pol : nullptr, pi_s_early ? &c->tp_b : nullptr, &nodrop,
+                          algo == MORL_AC_TD3 ? WT(c->wt_polt) : WT(c->wt_pol), pi_s_early ? WT(c->wt_pol) : nullptr)))
         return rc;
     if ((rc = head_forward(c, c->tp_a, rows, bt->eps_next, st, cfg, c->act, c->logp_next, false, s, &c->tq_a))) return rc;
     {
         // target critics at (s', a') and online critics at (s, a): independent passes, one launch per layer
         const DropSpec d0 = dropspec(0), d1 = dropspec(1);
-        if ((rc = mlp_forward(Q, st->q_target, Q.P, c->tq_a, rows, nq, d0, s, st->q, &c->tq_b, &d1))) return rc;
+        if ((rc = mlp_forward(Q, st->q_target, Q.P, c->tq_a, rows, nq, d0, s, st->q, &c->tq_b, &d1, WT(c->wt_qt), WT(c->wt_q)))) return rc;
     }
     {
         CriticArgs a{};
@@ -686,7 +736,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
         HIP_TRY(hipMemcpyAsync(c->gq, out->q_grads, (size_t)c->QG * Q.P * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     if ((rc = adam(st->q, c->gq, st->q_exp_avg, st->q_exp_avg_sq, (long long)nq * Q.P, PG, cfg->q_lr, st->q_steps,
-                   st->q_steps ? 1 : cfg->q_step, cfg, s))) return rc;
+                   st->q_steps ? 1 : cfg->q_step, cfg, s, WT(c->wt_q), &Q))) return rc;
 
     // ---- actor phase ---------------------------------------------------------------------------------------------------
     if (cfg->do_policy) {
@@ -697,9 +747,10 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
             // learnt alpha, the actor's trunk and head pre-activations at s are already in tp_b: the alpha re-sample below ran the UPDATED actor on the same rows and nothing has changed it since --
             // only the noise differs, which enters in head_forward
             const bool trunk_current = (it == 0 && pi_s_early) || (it > 0 && autotune && algo == MORL_AC_MOSAC);
-            if (!trunk_current && (rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
+            if (!trunk_current && (rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s, nullptr, nullptr, nullptr, WT(c->wt_pol))))
+                return rc;
             if ((rc = head_forward(c, c->tp_b, rows, eps_pi, st, cfg, c->act, c->logp_pi, true, s, &c->tq_b))) return rc;
-            if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, nq, dropspec(2), s))) return rc;
+            if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, nq, dropspec(2), s, nullptr, nullptr, nullptr, WT(c->wt_q)))) return rc;
             {
                 ActorLossArgs a{};
                 a.q = c->tq_b.out; a.dq = c->tq_b.g[Q.L - 1];
@@ -733,11 +784,11 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                 HIP_TRY(hipMemcpyAsync(c->gp, out->pol_grads, (size_t)c->PG * P.P * sizeof(float), hipMemcpyDeviceToDevice, s));
             }
             if ((rc = adam(st->pol, c->gp, st->pol_exp_avg, st->pol_exp_avg_sq, P.P, PG, cfg->policy_lr, st->pol_steps,
-                           (st->pol_steps ? 1 : cfg->policy_step) + it, cfg, s))) return rc;
+                           (st->pol_steps ? 1 : cfg->policy_step) + it, cfg, s, WT(c->wt_pol), &P))) return rc;
             if (autotune) {
                 // log-prob of a fresh sample under the UPDATED actor (mosac_continuous_action.py:467-468)
                 const float* eps_al = bt->eps_alpha + (long long)it * c->PG * rows * Ad;
-                if ((rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
+                if ((rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s, nullptr, nullptr, nullptr, WT(c->wt_pol)))) return rc;
                 if ((rc = head_forward(c, c->tp_b, rows, eps_al, st, cfg, c->act, c->logp_pi, false, s))) return rc;
                 hipLaunchKernelGGL(ac_alpha_step_kernel, dim3(c->PG), dim3(256), 0, s, st->log_alpha, st->log_alpha_exp_avg,
                                    st->log_alpha_exp_avg_sq, (const float*)c->logp_pi, rows, cfg->target_entropy,
@@ -770,6 +821,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     return MORL_OK;
 }
 
+#undef WT
 extern "C" int morl_ac_policy_forward(morl_ac_ctx* c, const morl_ac_state* st, const float* obs, const float* w, int rows,
                                       int mode, const float* eps, int use_target, const morl_ac_cfg* cfg,
                                       float* actions_out, float* logp_out, void* stream) {

@@ -29,6 +29,11 @@ __global__ __launch_bounds__(256) void probe_kernel(GemmBatched b) {
         float a[32], bb[32];
         if (V == 1) {
             for (int s = 0; s < 32; ++s) { a[s] = 0.001f * (lane + s); bb[s] = 0.002f * (lane - s); }
+        } else if (V == 7) {
+            float4 ta[8];
+            panel_fetch(ta, g.A, g.lda, m0, g.M, k0, kend, lane);
+            wave_load64<false>(bb, g.B, g.ldb, n0 + i, g.N, k0, kend, h, 1);     // B read as [k][n]: coalesced along n
+            panel_transpose(a, ta, s_panel[wave], lane);
         } else if (V == 5) {
             wave_load64<true>(a, g.A, g.lda, m0 + i, g.M, k0, kend, h, 1);
             wave_load64<true>(bb, g.B, g.ldb, n0 + i, g.N, k0, kend, h, 1);
@@ -75,8 +80,8 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const dim3 grid(b.p.tiles_m * b.p.tiles_n, 1, G);
     const char* names[] = {"product kernel", "no global loads", "no MFMA (fma instead)", "empty kernel", "no split-K reduce",
-                           "direct row-walk loads", "loads + LDS transpose only"};
-    for (int v = 0; v <= 6; ++v) {
+                           "direct row-walk loads", "loads + LDS transpose only", "A panel + B n-contiguous"};
+    for (int v = 0; v <= 7; ++v) {
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0, 0));
             for (int it = 0; it < iters; ++it) {
@@ -89,6 +94,7 @@ int main(int argc, char** argv) {
                     case 4: hipLaunchKernelGGL(probe_kernel<4>, grid, dim3(256), 0, 0, b); break;
                     case 5: hipLaunchKernelGGL(probe_kernel<5>, grid, dim3(256), 0, 0, b); break;
                     case 6: hipLaunchKernelGGL(probe_kernel<6>, grid, dim3(256), 0, 0, b); break;
+                    case 7: hipLaunchKernelGGL(probe_kernel<7>, grid, dim3(256), 0, 0, b); break;
                 }
             }
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
