@@ -460,10 +460,11 @@ static MlpLayout layout_of(const Mlp& m) {
 
 // wt / net: also refresh the K-major shadow copy of the stepped parameters (seg = a whole number of `net`-shaped nets)
 static int adam(float* params, float* grads, float* m, float* v, long long seg, int G, double lr, const int* steps,
-                int step_add, const morl_ac_cfg* cfg, hipStream_t s, float* wt = nullptr, const Mlp* net = nullptr) {
+                int step_add, const morl_ac_cfg* cfg, hipStream_t s, float* wt = nullptr, const Mlp* net = nullptr,
+                const MlpLayout* lay = nullptr) {
     const int nblk = std::min(256, stream_grid(seg, 256));
     hipLaunchKernelGGL(ac_adam_kernel, dim3(nblk, G), dim3(256), 0, s, params, (const float*)grads, m, v, seg, steps, step_add,
-                       lr, cfg->beta1, cfg->beta2, (float)cfg->eps, wt, wt ? layout_of(*net) : MlpLayout{});
+                       lr, cfg->beta1, cfg->beta2, (float)cfg->eps, wt, wt ? (lay ? *lay : layout_of(*net)) : MlpLayout{});
     LAUNCH_CHECK("ac_adam");
     return MORL_OK;
 }
@@ -920,6 +921,8 @@ struct morl_gpi_ctx {
     float* obs_rep = nullptr;  // [cap_env][D]
     float* w_rep = nullptr;    // [cap_env][R]
     float* qmin = nullptr;     // [ldq]
+    float* wt_q = nullptr;     // [nn][P] K-major shadow copies of the trunk matrices (ac_kernels.h: MlpLayout), online ...
+    float* wt_qt = nullptr;    // ... and target ensemble
     std::vector<void*> allocs;
 };
 
@@ -995,6 +998,7 @@ extern "C" int morl_gpi_create(morl_gpi_ctx** out, const morl_gpi_desc* d) {
     const int ldq = c->net.ld[c->net.L];
     if ((rc = gpi_alloc_tape(c, c->tt, c->cap, post)) || (rc = gpi_alloc_tape(c, c->te, c->cap_env, post)) ||
         (rc = gpi_alloc_tape(c, c->tq, c->cap, post)) || (rc = alloc_f(c->allocs, &c->grads, (size_t)c->nn * c->P)) ||
+        (rc = alloc_f(c->allocs, &c->wt_q, (size_t)c->nn * c->P)) || (rc = alloc_f(c->allocs, &c->wt_qt, (size_t)c->nn * c->P)) ||
         (rc = alloc_f(c->allocs, &c->target, (size_t)c->cap * d->reward_dim)) ||
         (rc = alloc_f(c->allocs, &c->target_env, (size_t)c->cap * d->reward_dim)) ||
         (rc = alloc_f(c->allocs, &c->obs_rep, (size_t)c->cap_env * d->obs_dim)) ||
@@ -1012,7 +1016,9 @@ extern "C" int morl_gpi_create(morl_gpi_ctx** out, const morl_gpi_desc* d) {
 // s' next to the online ensemble at s) whose GEMMs share the launches of the first (GemmBatched::split)
 static int gpi_forward(morl_gpi_ctx* c, const float* params, int n_nets, GpiTape& g, const float* obs, const float* w,
                        int w_rstride, int rows, const DropSpec& ds, hipStream_t s, const float* params2 = nullptr,
-                       GpiTape* g2 = nullptr, const float* obs2 = nullptr, const DropSpec* ds2 = nullptr) {
+                       GpiTape* g2 = nullptr, const float* obs2 = nullptr, const DropSpec* ds2 = nullptr,
+                       const float* wt = nullptr, const float* wt2 = nullptr) {
+    // wt / wt2: K-major shadow copies of params / params2 for the trunk layers (morl_gpi_update fills them)
     const morl_gpi_desc& d = c->d;
     g.t.G = n_nets;
     if (g2) g2->t.G = n_nets;
@@ -1044,8 +1050,10 @@ static int gpi_forward(morl_gpi_ctx* c, const float* params, int n_nets, GpiTape
         hipLaunchKernelGGL(gpi_embed_fwd_kernel, dim3(stream_grid((long long)n_nets * rows * c->H0, 256)), dim3(256), 0, s, a);
         LAUNCH_CHECK("gpi_embed_fwd");
     }
-    if (g2) return mlp_forward(c->net, params + c->offNet, c->P, g.t, rows, 1, ds, s, params2 + c->offNet, &g2->t, ds2);
-    return mlp_forward(c->net, params + c->offNet, c->P, g.t, rows, 1, ds, s);
+    if (g2) return mlp_forward(c->net, params + c->offNet, c->P, g.t, rows, 1, ds, s, params2 + c->offNet, &g2->t, ds2,
+                               wt ? wt + c->offNet : nullptr, wt2 ? wt2 + c->offNet : nullptr);
+    return mlp_forward(c->net, params + c->offNet, c->P, g.t, rows, 1, ds, s, nullptr, nullptr, nullptr,
+                       wt ? wt + c->offNet : nullptr);
 }
 
 static int gpi_backward(morl_gpi_ctx* c, const float* params, GpiTape& g, const float* obs, const float* w, int w_rstride,
@@ -1142,14 +1150,29 @@ extern "C" int morl_gpi_update(morl_gpi_ctx* c, float* q, const float* q_target,
         return ds;
     };
     int rc;
+    {   // K-major shadow copies of the trunk matrices of both ensembles for this update's forward passes (one launch)
+        TransposeMulti tm{};
+        MlpLayout lay = layout_of(c->net);
+        for (int l = 0; l < lay.L; ++l) lay.offW[l] += c->offNet;
+        lay.P = c->P;
+        tm.n = 2;
+        tm.src[0] = q; tm.dst[0] = c->wt_q; tm.src[1] = q_target; tm.dst[1] = c->wt_qt;
+        tm.lay[0] = tm.lay[1] = lay;
+        tm.nets[0] = tm.nets[1] = c->nn;
+        hipLaunchKernelGGL(ac_transpose_multi_kernel, dim3(stream_grid((long long)c->nn * c->P, 256, 1024), 1, 2), dim3(256), 0, s, tm);
+        LAUNCH_CHECK("gpi_transpose");
+    }
     {
         // the target ensemble at s' and the online ensemble at s do not depend on each other: one launch per layer for both
         const DropSpec d0 = dropspec(0), d2 = dropspec(2);
-        if ((rc = gpi_forward(c, q_target, c->nn, c->tt, next_obs, w, R, rows, d0, s, q, &c->tq, obs, &d2))) return rc;
+        if ((rc = gpi_forward(c, q_target, c->nn, c->tt, next_obs, w, R, rows, d0, s, q, &c->tq, obs, &d2, c->wt_qt, c->wt_q)))
+            return rc;
     }
     if (env) {
         if ((rc = gpi_envelope_inputs(c, next_obs, sampled_w, K, rows, s))) return rc;
-        if ((rc = gpi_forward(c, q_target, c->nn, c->te, c->obs_rep, c->w_rep, R, rows * K, dropspec(1), s))) return rc;
+        if ((rc = gpi_forward(c, q_target, c->nn, c->te, c->obs_rep, c->w_rep, R, rows * K, dropspec(1), s, nullptr, nullptr,
+                              nullptr, nullptr, c->wt_qt)))
+            return rc;
     }
     {
         GpiTargetArgs a{};
