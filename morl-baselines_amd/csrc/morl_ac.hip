@@ -529,9 +529,28 @@ static int sacd_update(morl_ac_ctx* c, const morl_ac_state* st, const morl_ac_ba
         hipLaunchKernelGGL(ac_concat_multi_kernel, dim3(stream_grid((long long)PG * rows * Q.ld[0], 256, 512), 4), dim3(256), 0, s, m);
         LAUNCH_CHECK("sacd_inputs");
     }
-    if ((rc = mlp_forward(P, st->pol, P.P, c->tp_a, rows, 1, nodrop, s))) return rc;
+    // K-major shadow copies for the forward GEMMs (single learners / small populations; see morl_ac_update)
+    int widest = 0;
+    for (int l = 1; l < Q.L; ++l) widest = std::max(widest, Q.dims[l]);
+    static const bool shadow_env = [] { const char* e = getenv("MORL_AC_SHADOW"); return e ? atoi(e) != 0 : true; }();
+    const bool use_wt = shadow_env && use_wave_tiles((long long)((rows + 127) / 128) * ((widest + 127) / 128) * c->QG * 2);
+    const float* wq = use_wt ? c->wt_q : nullptr;
+    const float* wqt = use_wt ? c->wt_qt : nullptr;
+    const float* wp = use_wt ? c->wt_pol : nullptr;
+    if (use_wt) {
+        TransposeMulti tm{};
+        tm.n = 3;
+        tm.src[0] = st->q; tm.dst[0] = c->wt_q; tm.lay[0] = layout_of(Q); tm.nets[0] = c->QG;
+        tm.src[1] = st->q_target; tm.dst[1] = c->wt_qt; tm.lay[1] = layout_of(Q); tm.nets[1] = c->QG;
+        tm.src[2] = st->pol; tm.dst[2] = c->wt_pol; tm.lay[2] = layout_of(P); tm.nets[2] = PG;
+        const long long longest = std::max((long long)c->QG * Q.P, (long long)PG * P.P);
+        hipLaunchKernelGGL(ac_transpose_multi_kernel, dim3(stream_grid(longest, 256, 1024), 1, 3), dim3(256), 0, s, tm);
+        LAUNCH_CHECK("sacd_transpose");
+    }
+    // pi(s') and pi(s): the actor is stepped only at the end of the update, so both passes share their launches
+    if ((rc = mlp_forward(P, st->pol, P.P, c->tp_a, rows, 1, nodrop, s, st->pol, &c->tp_b, &nodrop, wp, wp))) return rc;
     // target critics at s' and online critics at s: independent passes, one launch per layer
-    if ((rc = mlp_forward(Q, st->q_target, Q.P, c->tq_a, rows, 2, nodrop, s, st->q, &c->tq_b, &nodrop))) return rc;
+    if ((rc = mlp_forward(Q, st->q_target, Q.P, c->tq_a, rows, 2, nodrop, s, st->q, &c->tq_b, &nodrop, wqt, wq))) return rc;
     const long long q_gs = (long long)c->cap * Q.ld[Q.L], p_gs = (long long)c->cap * P.ld[P.L];
     {
         SacdCriticArgs a{};
@@ -548,10 +567,9 @@ static int sacd_update(morl_ac_ctx* c, const morl_ac_state* st, const morl_ac_ba
     if (out->q_grads)
         HIP_TRY(hipMemcpyAsync(out->q_grads, c->gq, (size_t)c->QG * Q.P * sizeof(float), hipMemcpyDeviceToDevice, s));
     if ((rc = adam(st->q, c->gq, st->q_exp_avg, st->q_exp_avg_sq, 2ll * Q.P, PG, cfg->q_lr, st->q_steps,
-                   st->q_steps ? 1 : cfg->q_step, cfg, s))) return rc;
-    // actor (+ alpha) through the UPDATED critics
-    if ((rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s))) return rc;
-    if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, 2, nodrop, s))) return rc;
+                   st->q_steps ? 1 : cfg->q_step, cfg, s, use_wt ? c->wt_q : nullptr, &Q))) return rc;
+    // actor (+ alpha) through the UPDATED critics (the actor's logits at s are already in tp_b)
+    if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, 2, nodrop, s, nullptr, nullptr, nullptr, wq))) return rc;
     {
         SacdActorArgs a{};
         a.logits = c->tp_b.out; a.dlogits = c->tp_b.g[P.L - 1]; a.p_gstride = p_gs; a.ldp = P.ld[P.L];
