@@ -214,7 +214,8 @@ static int g_ac_gemm_mode = 0;      // 0 auto, 1 always LDS tiles, 2 always wave
 static bool use_wave_tiles(long long tiles128) {
     if (g_ac_gemm_mode == 1) return false;
     if (g_ac_gemm_mode == 2) return true;
-    return tiles128 < 128;
+    static const long long below = [] { const char* e = getenv("MORL_AC_WAVE_TILES_BELOW"); return e ? atoll(e) : 128ll; }();   // (tuning)
+    return tiles128 < below;
 }
 
 template <bool A_KC, bool B_KC, int EPI>

@@ -13,6 +13,6 @@ for r in 2 3 4; do python bench_front.py --workload hv --r $r > gpurun_out/final
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_env -- python $R/bench.py --steps 80 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_pareto -- python $R/bench_front.py --workload pareto --n 16384 --no-cpu-baseline > /dev/null 2>&1
-for w in mosac gpi ens; do rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_$w -- python $R/bench_ac.py --workload $w --steps 60 --no-cpu-baseline > /dev/null 2>&1; done
+for w in mosac gpi ens morld; do rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof_$w -- python $R/bench_ac.py --workload $w --steps 60 --no-cpu-baseline > /dev/null 2>&1; done
 cd $R
 tail -2 gpurun_out/final/gpu_tests.log; tail -2 gpurun_out/final/smoke.log; cut -c1-400 gpurun_out/final/bench_per_on.json
