@@ -200,7 +200,7 @@ __device__ __forceinline__ float ac_uniform(unsigned long long seed, unsigned lo
     return (float)(x >> 40) * (1.0f / 16777216.0f);
 }
 
-__global__ __launch_bounds__(256) void ac_post_fwd_kernel(PostArgs a) {
+__device__ __forceinline__ void ac_post_fwd_body(const PostArgs& a) {
     const int row = (int)blockIdx.x * 4 + wave_id();
     const int g = (int)blockIdx.y, lane = lane_id();
     if (row >= a.rows) return;
@@ -255,6 +255,10 @@ __global__ __launch_bounds__(256) void ac_post_fwd_kernel(PostArgs a) {
         }
     }
 }
+
+__global__ __launch_bounds__(256) void ac_post_fwd_kernel(PostArgs a) { ac_post_fwd_body(a); }
+// two independent passes of the same layer (paired forward passes, GemmBatched::split): blockIdx.z picks the tape
+__global__ __launch_bounds__(256) void ac_post_fwd_pair_kernel(PostArgs a, PostArgs b) { ac_post_fwd_body(blockIdx.z ? b : a); }
 
 struct PostBwdArgs {
     float* d;                 // [G][..][ld]  in: dLoss/dh ; out: dLoss/dz

@@ -25,7 +25,7 @@ struct EmbedArgs {
     int H, ld, R, rows, G;
 };
 
-__global__ __launch_bounds__(256) void gpi_embed_fwd_kernel(EmbedArgs a) {
+__device__ __forceinline__ void gpi_embed_fwd_body(const EmbedArgs& a) {
     const long long total = (long long)a.G * a.rows * a.H;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (long long)gridDim.x * blockDim.x) {
@@ -42,6 +42,10 @@ __global__ __launch_bounds__(256) void gpi_embed_fwd_kernel(EmbedArgs a) {
         a.x[o] = a.sf[o] * wf;
     }
 }
+
+__global__ __launch_bounds__(256) void gpi_embed_fwd_kernel(EmbedArgs a) { gpi_embed_fwd_body(a); }
+// the two passes of a paired forward (target ensemble at s', online ensemble at s): blockIdx.y picks the pass
+__global__ __launch_bounds__(256) void gpi_embed_fwd_pair_kernel(EmbedArgs a, EmbedArgs b) { gpi_embed_fwd_body(blockIdx.y ? b : a); }
 
 // backward of the product: dsf = dx * wf * (sf > 0) (in place of dx), dwf = dx * sf * (wf > 0)
 struct EmbedBwdArgs {

@@ -303,6 +303,7 @@ static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape&
         else rc = (last || post) ? launch_bgemm<true, true, EPI_BIAS>(b, G, s, "ac_gemm_fwd")
                                  : launch_bgemm<true, true, EPI_BIAS_RELU>(b, G, s, "ac_gemm_fwd_relu");
         if (rc) return rc;
+        PostArgs both[2];
         for (int pass = 0; pass < (t2 ? 2 : 1) && post; ++pass) {
             Tape& tt = pass ? *t2 : t;
             const DropSpec& dd = pass ? *ds2 : ds;
@@ -319,7 +320,13 @@ static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape&
             a.ln = m.ln ? 1 : 0; a.drop = dr ? 1 : 0;
             a.drop_p = m.drop; a.inv_keep = 1.0f / (1.0f - m.drop);
             a.seed = dd.seed * 0x100000001B3ull + (unsigned long long)(l + 1) * 0x9E3779B97F4A7C15ull;
-            hipLaunchKernelGGL(ac_post_fwd_kernel, dim3((rows + 3) / 4, tt.G), dim3(256), 0, s, a);
+            both[pass] = a;
+        }
+        if (post && t2) {
+            hipLaunchKernelGGL(ac_post_fwd_pair_kernel, dim3((rows + 3) / 4, t.G, 2), dim3(256), 0, s, both[0], both[1]);
+            LAUNCH_CHECK("ac_post_fwd_pair");
+        } else if (post) {
+            hipLaunchKernelGGL(ac_post_fwd_kernel, dim3((rows + 3) / 4, t.G), dim3(256), 0, s, both[0]);
             LAUNCH_CHECK("ac_post_fwd");
         }
         if (!last) ext_off += (int64_t)rows * m.dims[l + 1];
@@ -1057,6 +1064,7 @@ static int gpi_forward(morl_gpi_ctx* c, const float* params, int n_nets, GpiTape
         int rc = launch_bgemm<true, true, EPI_BIAS_RELU>(b, g2 ? 2 * n_nets : n_nets, s, "gpi_gemm_sf");
         if (rc) return rc;
     }
+    EmbedArgs emb[2];
     for (int pass = 0; pass < (g2 ? 2 : 1); ++pass) {
         GpiTape& gg = pass ? *g2 : g;
         const float* pp = pass ? params2 : params;
@@ -1066,9 +1074,12 @@ static int gpi_forward(morl_gpi_ctx* c, const float* params, int n_nets, GpiTape
         a.params = pp; a.pstride = c->P; a.offWw = c->offWw; a.offBw = c->offBw;
         a.gstride = (long long)gg.t.cap * c->ldH;
         a.H = c->H0; a.ld = c->ldH; a.R = d.reward_dim; a.rows = rows; a.G = n_nets;
-        hipLaunchKernelGGL(gpi_embed_fwd_kernel, dim3(stream_grid((long long)n_nets * rows * c->H0, 256)), dim3(256), 0, s, a);
-        LAUNCH_CHECK("gpi_embed_fwd");
+        emb[pass] = a;
     }
+    if (g2) hipLaunchKernelGGL(gpi_embed_fwd_pair_kernel, dim3(stream_grid((long long)n_nets * rows * c->H0, 256), 2), dim3(256), 0, s,
+                               emb[0], emb[1]);
+    else hipLaunchKernelGGL(gpi_embed_fwd_kernel, dim3(stream_grid((long long)n_nets * rows * c->H0, 256)), dim3(256), 0, s, emb[0]);
+    LAUNCH_CHECK("gpi_embed_fwd");
     if (g2) return mlp_forward(c->net, params + c->offNet, c->P, g.t, rows, 1, ds, s, params2 + c->offNet, &g2->t, ds2,
                                wt ? wt + c->offNet : nullptr, wt2 ? wt2 + c->offNet : nullptr);
     return mlp_forward(c->net, params + c->offNet, c->P, g.t, rows, 1, ds, s, nullptr, nullptr, nullptr,
