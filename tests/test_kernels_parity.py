@@ -180,6 +180,28 @@ def test_envelope_reduce_ties_bit_exact(be):
             assert th.equal(tg.cpu(), tg_o.reshape(-1, R))
 
 
+def test_envelope_reduce_maximum_slab_and_loud_refusal(be):
+    """The LDS slab of the envelope kernel holds W * A * R <= 9216 floats (512 weights x 6 actions x 3 objectives: the
+    weak-scaled candidate set of an 8-GPU job).  At the limit the arg-max is still bit-exact; one weight more is refused
+    with an error, never truncated."""
+    lib, dev, is_sim = be
+    rng = np.random.default_rng(12)
+    B, A, R = (2, 6, 3) if is_sim else (16, 6, 3)
+    W = 512
+    qo = th.tensor(rng.standard_normal((B, W, A, R)), dtype=th.float32)
+    qt = th.tensor(rng.standard_normal((B, W, A, R)), dtype=th.float32)
+    sw = th.tensor(rng.dirichlet(np.ones(R), W), dtype=th.float32)
+    if not is_sim:                                        # (16 waves x 3072 candidates per row: GPU only, the emulator is slow)
+        tg, pref, ac = ops.envelope_reduce(lib, qo.to(dev), qt.to(dev), sw.to(dev))
+        tg_o, pref_o, ac_o = orc.envelope_reduce(qo, qt, sw)
+        assert th.equal(pref.cpu().long(), pref_o.reshape(-1)) and th.equal(ac.cpu().long(), ac_o.reshape(-1))
+        assert th.equal(tg.cpu(), tg_o.reshape(-1, R))
+    W1 = W + 1
+    qo1 = th.zeros((B, W1, A, R)); sw1 = th.full((W1, R), 1.0 / R)
+    with pytest.raises(RuntimeError, match="LDS slab|exceeds|W"):
+        ops.envelope_reduce(lib, qo1.to(dev), qo1.to(dev), sw1.to(dev))
+
+
 @pytest.mark.parametrize("fused", [2, 3, 0], ids=["fused64", "fused32", "perlayer"])
 @pytest.mark.parametrize("dims", [(6, 5, 3, 2, (16, 16)), (9, 4, 4, 3, (40,)), (130, 3, 5, 3, (200, 72, 136))])
 def test_qnet_forward_row_orders(be, dims, fused):
