@@ -101,10 +101,12 @@ int morl_ctx_set_fused(morl_ctx* ctx, int enable);
 /* Weight-gradient engine: 0 = wave-level tiles streaming both operands HBM -> registers (dw_wave.h), 1 = 128x128
  * double-buffered LDS tiles, two workgroups per CU (default), 2 = the single-buffered tiles of the per-layer engine. */
 int morl_ctx_set_dw_mode(morl_ctx* ctx, int mode);
-/* Per-launch timing of the dominant kernel (the layer-fused MLP chain): when enabled, every chain launch is bracketed
- * by a HIP event pair on the caller's stream.  morl_ctx_read_timing blocks until the recorded launches have finished,
- * returns their number and summed duration (ms) and clears the record.  Used by bench.py for the roofline figure. */
-int morl_ctx_set_timing(morl_ctx* ctx, int enable);
+/* Per-launch timing of the dominant kernel (the layer-fused MLP chain): every = n > 0 brackets the chain launches of every
+ * n-th Envelope step (counted from this call; the first one is timed) with HIP event pairs on the caller's stream, 0 turns it
+ * off.  An event record costs a few microseconds of stream time, so sampling keeps the measurement from perturbing the step
+ * it measures.  morl_ctx_read_timing blocks until the recorded launches have finished, returns their number and summed
+ * duration (ms) and clears the record.  Used by bench.py for the roofline figure. */
+int morl_ctx_set_timing(morl_ctx* ctx, int every);
 int morl_ctx_read_timing(morl_ctx* ctx, int* n_launches, double* total_ms);
 /* number of float parameters of `net` in the flat layout */
 int64_t morl_param_count(const morl_net_desc* net);

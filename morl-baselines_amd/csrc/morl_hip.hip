@@ -148,7 +148,9 @@ struct morl_ctx {
     bool bits_valid = false;                               // written by the last training forward
     float* zeros = nullptr;  // 16 zero floats: target of the invalid elements of the chain's operand gathers
     // optional per-launch timing of the dominant kernel (mlp_chain): HIP event pairs on the caller's stream
-    bool timing = false;
+    bool timing = false;                 // chain launches of the current step are bracketed by events
+    int timing_every = 0;                // 0 = off, n = every n-th Envelope step is timed (event records cost ~4 us of stream
+    long long timing_step = 0;           //     time each, so timing every step would perturb what it measures)
     std::vector<hipEvent_t> ev_start, ev_stop;
     int main_rows = -1;                  // rows of a hoisted training forward (morl_envelope_main_forward), -1 = none
     size_t ev_used = 0;
@@ -520,11 +522,20 @@ extern "C" int morl_ctx_set_dw_mode(morl_ctx* c, int mode) {
     return MORL_OK;
 }
 
-extern "C" int morl_ctx_set_timing(morl_ctx* c, int enable) {
+extern "C" int morl_ctx_set_timing(morl_ctx* c, int every) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
-    c->timing = enable != 0;
+    if (every < 0) return fail(MORL_ERR_ARG, "every < 0");
+    c->timing_every = every;
+    c->timing_step = 0;
+    c->timing = false;
     c->ev_used = 0;
     return MORL_OK;
+}
+
+// called at the first library entry of an Envelope step (morl_envelope_update, or morl_envelope_slabs of a sharded step)
+static void timing_begin_step(morl_ctx* c) {
+    c->timing = c->timing_every > 0 && (c->timing_step % c->timing_every) == 0;
+    ++c->timing_step;
 }
 
 // Blocks until the recorded launches finished; returns their count and summed duration, then clears the record.
@@ -837,6 +848,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     const int rows = B * W, AR = A * R;
     static const morl_update_out no_out = {};
     if (!out) out = &no_out;
+    timing_begin_step(c);
 
     // stage A: no-grad next-state slabs Qo, Qt [B][W][A][R] (B*W distinct rows instead of the reference's W^2*B)
     bool main_done = false;
@@ -914,6 +926,7 @@ extern "C" int morl_envelope_slabs(morl_ctx* c, const float* params_online, cons
     if (!params_online || !params_target || !next_obs || !weights_local || !slabs_out) return fail(MORL_ERR_ARG, "NULL array");
     hipStream_t s = (hipStream_t)stream;
     const int rows = B * W_local, AR = c->net.n_actions * c->net.reward_dim;
+    timing_begin_step(c);
     float* qo = slabs_out;
     float* qt = slabs_out + (size_t)rows * AR;
     if (c->use_fused) {

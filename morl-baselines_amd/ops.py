@@ -37,8 +37,9 @@ class QNetContext:
         """Weight-gradient engine: 0 wave-level tiles, 1 double-buffered LDS tiles (default), 2 single-buffered."""
         self.lib.check(self.lib.lib.morl_ctx_set_dw_mode(self.handle, int(mode)))
 
-    def set_timing(self, enable: bool) -> None:
-        self.lib.check(self.lib.lib.morl_ctx_set_timing(self.handle, int(enable)))
+    def set_timing(self, every: int) -> None:
+        """Time the chain launches of every ``every``-th Envelope step with HIP events (0 / False: off, True: every step)."""
+        self.lib.check(self.lib.lib.morl_ctx_set_timing(self.handle, int(every)))
 
     def read_timing(self):
         """(number of timed chain launches, their summed duration in ms); synchronises on them."""
