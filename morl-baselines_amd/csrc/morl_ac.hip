@@ -1180,7 +1180,15 @@ extern "C" int morl_gpi_update(morl_gpi_ctx* c, float* q, const float* q_target,
         return ds;
     };
     int rc;
-    {   // K-major shadow copies of the trunk matrices of both ensembles for this update's forward passes (one launch)
+    // K-major shadow copies of the trunk matrices of both ensembles for this update's forward passes (one launch) -- in the
+    // wave-tile regime only (see morl_ac_update): a very large batch runs the LDS-tiled engine on the original layout
+    int widest = 0;
+    for (int l = 1; l < c->net.L; ++l) widest = std::max(widest, c->net.dims[l]);
+    const long long big_rows = env ? (long long)rows * K : rows;
+    const bool use_wt = use_wave_tiles(((big_rows + 127) / 128) * ((widest + 127) / 128) * c->nn);
+    const float* wq = use_wt ? c->wt_q : nullptr;
+    const float* wqt = use_wt ? c->wt_qt : nullptr;
+    if (use_wt) {
         TransposeMulti tm{};
         MlpLayout lay = layout_of(c->net);
         for (int l = 0; l < lay.L; ++l) lay.offW[l] += c->offNet;
@@ -1195,13 +1203,13 @@ extern "C" int morl_gpi_update(morl_gpi_ctx* c, float* q, const float* q_target,
     {
         // the target ensemble at s' and the online ensemble at s do not depend on each other: one launch per layer for both
         const DropSpec d0 = dropspec(0), d2 = dropspec(2);
-        if ((rc = gpi_forward(c, q_target, c->nn, c->tt, next_obs, w, R, rows, d0, s, q, &c->tq, obs, &d2, c->wt_qt, c->wt_q)))
+        if ((rc = gpi_forward(c, q_target, c->nn, c->tt, next_obs, w, R, rows, d0, s, q, &c->tq, obs, &d2, wqt, wq)))
             return rc;
     }
     if (env) {
         if ((rc = gpi_envelope_inputs(c, next_obs, sampled_w, K, rows, s))) return rc;
         if ((rc = gpi_forward(c, q_target, c->nn, c->te, c->obs_rep, c->w_rep, R, rows * K, dropspec(1), s, nullptr, nullptr,
-                              nullptr, nullptr, c->wt_qt)))
+                              nullptr, nullptr, wqt)))
             return rc;
     }
     {
