@@ -225,3 +225,49 @@ def test_sharded_update_over_rccl_single_rank(per):
     assert np.abs(ret["params"] - ret["want"]).max() <= 0.02 * 3e-4 * 3
     if per:
         np.testing.assert_allclose(ret["tree"][0], ret["want_tree"][0], rtol=1e-5)
+
+
+def _dp_rccl_worker(port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "oracle")]
+    import torch.distributed as dist
+    import morl_baselines_amd.native as native
+    from morl_baselines_amd.distributed import average_gradients
+    from cases_ac import make_inputs
+    from test_ac_kernels_parity import build_engine
+    dev = th.device("cuda:0")
+    th.cuda.set_device(dev)
+    lib = native.load_library()
+    c = _capql_case()
+    inp = make_inputs(c)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    res = {}
+    for name, sync in (("plain", None), ("dp", average_gradients(dist))):
+        eng = build_engine(c, inp, lib, dev)
+        cfg = eng.make_cfg(gamma=c.gamma, tau=c.tau, alpha=c.alpha, q_lr=c.lr, policy_lr=c.lr, q_step=c.step, policy_step=c.step)
+        out = eng.update(cfg, obs=inp["obs"], actions=inp["actions"], rewards=inp["rewards"], next_obs=inp["next_obs"],
+                         dones=inp["dones"], w=inp["w"], eps_next=inp["eps_next"], eps_pi=inp["eps_pi"][0],
+                         want=("critic_loss", "policy_loss"), grad_sync=sync)
+        th.cuda.synchronize()
+        res[name] = (eng.q.cpu().numpy(), eng.pol.cpu().numpy(), eng.q_target.cpu().numpy(), float(out["critic_loss"][0]))
+    ret.update(res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_data_parallel_capql_over_rccl_single_rank():
+    """The gradient hook with a real RCCL all-reduce (one rank: the average is the identity): the data-parallel update must
+    equal the plain update bit for bit -- the hook, the staging copies and the stream hand-over change nothing else."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_dp_rccl_worker, args=(34500 + (os.getpid() % 2000), ret))
+    p.start()
+    p.join(300)
+    if p.is_alive():
+        p.kill()
+        pytest.fail("RCCL single-rank worker did not finish")
+    assert p.exitcode == 0
+    for a, b in zip(ret["plain"][:3], ret["dp"][:3]):
+        assert np.array_equal(a, b)
+    assert ret["plain"][3] == ret["dp"][3]
