@@ -173,7 +173,9 @@ int morl_envelope_update(morl_ctx* ctx, float* params_online, const float* param
 int morl_envelope_slabs(morl_ctx* ctx, const float* params_online, const float* params_target, const float* next_obs,
                         const float* weights_local, int B, int W_local, float* slabs_out, void* stream);
 /* training forward Q_online(s_b, w_i) of this rank's TD rows (envelope.py:300), activations kept in the context for
- * morl_envelope_update_shard(cfg->main_forward_done = 1).  weights_local = this rank's W_local vectors.  */
+ * morl_envelope_update_shard(cfg->main_forward_done = 1).  weights_local = this rank's W_local vectors.  (Reuses the
+ * transposed weights of this step's morl_envelope_slabs when params_online is the same buffer and no morl_clip_adam /
+ * morl_envelope_update ran in between; a caller that rewrites the parameters itself between the two calls must not rely on that.) */
 int morl_envelope_main_forward(morl_ctx* ctx, const float* params_online, const float* obs, const float* weights_local,
                                int B, int W_local, void* stream);
 int morl_envelope_update_shard(morl_ctx* ctx, const float* params_online, float* grads, const float* obs,

@@ -153,6 +153,8 @@ struct morl_ctx {
     long long timing_step = 0;           //     time each, so timing every step would perturb what it measures)
     std::vector<hipEvent_t> ev_start, ev_stop;
     int main_rows = -1;                  // rows of a hoisted training forward (morl_envelope_main_forward), -1 = none
+    const float* wt_online_src = nullptr;   // parameters wt_online was transposed from by this step's morl_envelope_slabs
+                                         // (cleared by every optimiser step of the library)
     size_t ev_used = 0;
     int fused_tm = 0;        // 0: pick the row tile per launch (>= 2 workgroups per CU when possible), else 64 / 32
     int num_cus = 256;
@@ -810,6 +812,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
 // for `grads` (single GPU); otherwise (gradients were all-reduced) they are recomputed from `grads` first.
 static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                           const morl_update_cfg* cfg, float* grad_norm_out, bool have_partials, hipStream_t s) {
+    c->wt_online_src = nullptr;          // the parameters change: any transposed copy is stale from here on
     const int nblk = std::min(OPT_MAX_BLOCKS, stream_grid(c->P, OPT_THREADS));
     if (!have_partials) {
         hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)grads, 1, (long long)c->P,
@@ -932,6 +935,7 @@ extern "C" int morl_envelope_slabs(morl_ctx* c, const float* params_online, cons
     if (c->use_fused) {
         // one transpose launch for both networks, one launch for both passes (2 x rows/64 workgroups share the chip)
         if ((rc = refresh_transposed(c, params_online, c->wt_online, s, params_target, c->wt_target))) return rc;
+        c->wt_online_src = params_online;
         const ChainArgs two[2] = {
             make_forward_chain(c, params_online, c->wt_online, next_obs, weights_local, B, W_local, 0, rows, false, qo, AR),
             make_forward_chain(c, params_target, c->wt_target, next_obs, weights_local, B, W_local, 0, rows, false, qt, AR)};
@@ -952,7 +956,9 @@ extern "C" int morl_envelope_main_forward(morl_ctx* c, const float* params_onlin
     if (c->use_fused) {
         // exactly the third pass of the unsharded step's fused launch: activations and ReLU sign bits saved in the context,
         // the layer-0 input of the dW GEMM written from the kernel's own input assembly
-        if ((rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
+        // the K-major copy made by this step's morl_envelope_slabs is still current unless an optimiser step intervened
+        if (c->wt_online_src != params_online && (rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
+        c->wt_online_src = nullptr;      // one-shot: only the call that directly follows the slabs call of a step reuses it
         ChainArgs one = make_forward_chain(c, params_online, c->wt_online, obs, weights_local, B, W_local, 1, rows, true, c->qm,
                                            c->ldq, true);
         one.x0_out = c->x0m;
