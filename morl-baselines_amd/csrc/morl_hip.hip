@@ -756,6 +756,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     const bool db = (c->dw_mode == 1);
     // double-buffered tiles run two workgroups per CU: twice as many, half as long row slices
     splits = std::max(1, std::min(c->max_splits, ((db ? 2 : 1) * c->num_cus + c->dw_tiles - 1) / c->dw_tiles));
+    if (const char* e = getenv("MORL_DW_SPLITS")) splits = std::max(1, std::min(c->max_splits, atoi(e)));   // (tuning)
     int kps = round_up((rows + splits - 1) / splits, GEMM_BK);
     splits = (rows + kps - 1) / kps;
     {
