@@ -4,6 +4,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
+``python bench.py --gpus N`` from a bare shell (no WORLD_SIZE in the environment) re-executes itself under
+``torch.distributed.run`` with N ranks on 127.0.0.1, one per GPU, and passes rank 0's JSON line through.
+N > 1: the headline is STRONG scaling of the metric's fixed 256 x 64 x 3 update (the 64 sampled weights are split over the
+ranks, ``config.weights`` stays 64); the weak-scaled job (64 weights per GPU, W = 64*N) is measured right after it and
+reported as the clearly labelled sub-record ``weak_scaling`` of the same line (``--scaling weak`` makes it the headline).
+
 One "step" = one ``Envelope.update()`` gradient step (``envelope.py:267-367``) of the HIP agent on the synthetic
 workload of BASELINE.md section 3: obs dim 32, 3 objectives, 6 actions, net [256]*4, batch 256 x 64 sampled weights
 (16 384 TD rows = 49 152 scalar TD errors per step), replay buffer pre-filled with 20 000 seeded transitions, PER on
@@ -109,11 +115,31 @@ def cpu_baseline(batch, weights, per, budget_s=25.0):
         timed.append(one())
     th.set_num_threads(all_threads)
     sec = float(np.median(timed))
-    return {"value": batch * weights / sec, "unit": "TD-updates/s", "cores": best,
+    return {"value": batch * weights / sec, "unit": "TD-updates/s", "cores": best, "threads_used": best,
+            "host_logical_cpus": os.cpu_count(), "host_physical_cores": _physical_cores(),
+            "threads_probed": {str(k): v for k, v in probe.items()},
             "kind": "port", "updates_per_s": 1.0 / sec,
             "sample": f"{len(timed)} timed Envelope.update() steps (after a warm-up, at the best of {cands} threads) of the "
                       f"as-written reference algorithm (oracle/envelope_oracle.py, B={batch}, W={weights}, W^2*B-row targets) "
                       "on torch-CPU, median"}
+
+
+def _physical_cores():
+    """Physical core count of this host (unique (package, core) pairs of /proc/cpuinfo); None if it cannot be read."""
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        return len(pairs) or None
+    except OSError:
+        return None
 
 
 def measured_chain_traffic():
@@ -142,6 +168,119 @@ def _claim_stdout():
     return real
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _self_spawn(n: int, argv, result_out) -> int:
+    """``python bench.py --gpus N`` from a bare shell: re-execute under torch.distributed.run (one rank per GPU, rendezvous on
+    127.0.0.1) and pass rank 0's JSON line through to the real stdout."""
+    import subprocess
+    have = th.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible on this node")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print("[bench] self-spawn:", " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:                                   # the ranks keep stdout clean: only rank 0's JSON arrives here
+        if ln.lstrip().startswith("{"):
+            line = ln.strip()
+        else:
+            print(ln, end="", file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, file=result_out, flush=True)
+    return rc if rc else (0 if line is not None else 1)
+
+
+def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup):
+    """Build the agent for a job of W sampled weights in total, run warm-up + `steps` timed Envelope.update() steps bracketed
+    by barrier + synchronize on both sides; returns the measurements (wall = max over ranks)."""
+    from morl_baselines_amd.envelope import Envelope
+
+    th.manual_seed(0)
+    np.random.seed(0)
+    B = a.batch
+    agent = Envelope(SyntheticEnv(), learning_rate=3e-4, net_arch=ARCH, batch_size=B, gamma=0.99, max_grad_norm=1.0,
+                     tau=1.0, target_net_update_freq=200, envelope=True, num_sample_w=W, per=bool(a.per),
+                     per_alpha=0.6, buffer_size=100_000, gradient_updates=1, log=False, seed=0, device=dev,
+                     engine=a.engine)
+    if a.dw_mode is not None:
+        agent.q_net.ctx.set_dw_mode(a.dw_mode)
+    fill_buffer(agent.replay_buffer, 20_000, seed=0)
+    agent.global_step = 1001
+    if sharded:
+        from morl_baselines_amd.distributed import shard_envelope_agent
+        shard_envelope_agent(agent, dist)            # weight axis over the ranks: all-gather Q(w), all-reduce grads
+
+    def step():
+        agent.update()
+        agent.global_step += 1
+
+    for _ in range(warmup):
+        step()
+    th.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        th.cuda.synchronize()
+    # chain launches are event-timed on the library's stream: every step for short runs (the driver's --steps 20), every
+    # 4th step for long ones (an event pair costs ~4 us of stream time; the step it brackets is ~2 % slower for it)
+    timing_every = 1 if steps <= 50 else 4
+    agent.q_net.ctx.set_timing(timing_every)
+    e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    t_enq = time.perf_counter() - t0                 # host time to enqueue the timed steps (no synchronisation inside)
+    th.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        th.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    n_chain, chain_ms = agent.q_net.ctx.read_timing()
+    agent.q_net.ctx.set_timing(False)
+    gpu_ms = e0.elapsed_time(e1)
+    if dist is not None:
+        t = th.tensor([wall], device=dev, dtype=th.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    res = {"wall": wall, "host_enqueue_ms_per_step": t_enq * 1e3 / steps, "gpu_ms_per_step_events": gpu_ms / steps,
+           "n_chain": n_chain, "chain_ms": chain_ms, "timed_steps": len(range(0, steps, timing_every)),
+           "loss": agent.last_loss(), "engine": agent.q_net.ctx.engine, "W": W, "B": B}
+    del agent
+    return res
+
+
+def _roofline(res, rows_rank):
+    """Dominant kernel = mlp_chain (per step and rank: the forward passes -- one launch of three chains, or the slabs launch +
+    the hoisted training forward of a sharded step -- and the backward-dX launch): algorithmic flop of the timed launches
+    over their summed HIP-event duration."""
+    n_chain, chain_ms, timed_steps = res["n_chain"], res["chain_ms"], res["timed_steps"]
+    chain_flop_step = rows_rank * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW)
+    launches_per_step = n_chain / timed_steps if timed_steps else 0
+    flop_per_launch = chain_flop_step / launches_per_step if launches_per_step else float("nan")
+    avg_launch_s = (chain_ms * 1e-3 / n_chain) if n_chain else float("nan")
+    achieved = flop_per_launch / avg_launch_s / 1e12 if n_chain else float("nan")
+    traffic = measured_chain_traffic()
+    return {"bound": "mfma", "kernel": "mlp_chain (layer-fused Q-net forward / backward-dX)",
+            "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
+            "traffic_source": "committed profile (profiles/*_pmc_summary.json: PMC counters cannot be read in-process); "
+                              "constant of the repo, not of this run" if traffic is not None else None,
+            "launches_timed": n_chain, "timed_steps": timed_steps, "avg_launch_us": avg_launch_s * 1e6,
+            "algorithmic_flop_per_launch": flop_per_launch}
+
+
 def main():
     result_out = _claim_stdout()
     ap = argparse.ArgumentParser()
@@ -154,20 +293,23 @@ def main():
     ap.add_argument("--engine", type=int, default=None)
     ap.add_argument("--dw-mode", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = every GPU keeps the metric's 256 x 64 x 3 workload (the weight axis grows to "
-                         "64*N and every TD row's envelope max runs over all 64*N candidates after the all-gather); "
-                         "strong = the 64 weights are split over the GPUs")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1 headline: strong = the metric's fixed 256 x 64 x 3 update, its 64 weights split over the "
+                         "GPUs (default); weak = every GPU keeps 64 weights (the job's weight axis grows to 64*N and every "
+                         "TD row's envelope max runs over all 64*N candidates after the all-gather).  The other one is "
+                         "measured too and attached as a labelled sub-record unless --no-sub-record")
+    ap.add_argument("--no-sub-record", action="store_true")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the weight-sharded step (RCCL collectives) even with one rank (path check on a 1-GPU box)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(_self_spawn(a.gpus, sys.argv[1:], result_out))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not th.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
     th.cuda.set_device(local_rank)
@@ -178,105 +320,77 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        print(f"[bench] rank {rank}/{world} on {dev}: RCCL nranks={dist.get_world_size()}", file=sys.stderr, flush=True)
+    sharded = dist is not None
 
-    from morl_baselines_amd.envelope import Envelope
-
-    th.manual_seed(0)
-    np.random.seed(0)
+    if a.weights % world:
+        raise SystemExit(f"--weights {a.weights} must be divisible by the number of ranks ({world})")
     B = a.batch
-    weak = a.scaling == "weak" and world > 1
-    W = a.weights * (world if weak else 1)        # total sampled weights of the job
-    agent = Envelope(SyntheticEnv(), learning_rate=3e-4, net_arch=ARCH, batch_size=B, gamma=0.99, max_grad_norm=1.0,
-                     tau=1.0, target_net_update_freq=200, envelope=True, num_sample_w=W, per=bool(a.per),
-                     per_alpha=0.6, buffer_size=100_000, gradient_updates=1, log=False, seed=0, device=dev,
-                     engine=a.engine)
-    if a.dw_mode is not None:
-        agent.q_net.ctx.set_dw_mode(a.dw_mode)
-    fill_buffer(agent.replay_buffer, 20_000, seed=0)
-    agent.global_step = 1001
-    if dist is not None:
-        from morl_baselines_amd.distributed import shard_envelope_agent
-        shard_envelope_agent(agent, dist)            # weight axis over the ranks: all-gather Q(w), all-reduce grads
-
-    def step():
-        agent.update()
-        agent.global_step += 1
-
-    for _ in range(a.warmup):
-        step()
-    th.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    TIMING_EVERY = 8      # the chain launches of every 8th step are event-timed: an event record costs ~4 us of stream time
-    agent.q_net.ctx.set_timing(TIMING_EVERY)
-    e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(a.steps):
-        step()
-    e1.record()
-    th.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    wall = time.perf_counter() - t0
-    n_chain, chain_ms = agent.q_net.ctx.read_timing()
-    agent.q_net.ctx.set_timing(False)
-    gpu_ms = e0.elapsed_time(e1)
-    if dist is not None:
-        t = th.tensor([wall], device=dev, dtype=th.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    loss = agent.last_loss()
+    W_head = a.weights * (world if (a.scaling == "weak" and world > 1) else 1)
+    head = run_job(a, dist, world, rank, dev, W_head, sharded, a.steps, a.warmup)
+    sub = None
+    if world > 1 and not a.no_sub_record:
+        # the other scaling mode, same steps / warm-up, reported as a sub-record of the same line
+        W_sub = a.weights if a.scaling == "weak" else a.weights * world
+        try:
+            sub = run_job(a, dist, world, rank, dev, W_sub, sharded, a.steps, a.warmup)
+        except Exception as exc:                      # the headline must survive a failing sub-record
+            sub = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
-        rows_step = B * W                             # TD rows per gradient step of the whole job
-        ms_per_step = wall * 1e3 / a.steps
-        # roofline of the dominant kernel (mlp_chain: 3 forward launches + 1 backward launch per step and rank)
-        rows_rank = rows_step // world
-        # per step and rank the chain kernel runs the 3 forward passes (one launch of three chains, or three launches)
-        # and the backward-dX pass: algorithmic flop of all its launches / their summed duration
-        chain_flop_step = rows_rank * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW)
-        timed_steps = len(range(0, a.steps, TIMING_EVERY))
-        launches_per_step = n_chain / timed_steps if timed_steps else 0
-        flop_per_launch = chain_flop_step / launches_per_step if launches_per_step else float("nan")
-        avg_launch_s = (chain_ms * 1e-3 / n_chain) if n_chain else float("nan")
-        achieved = flop_per_launch / avg_launch_s / 1e12 if n_chain else float("nan")
+        def record(res, W, scaling):
+            rows_step = B * W                             # TD rows per gradient step of the whole job
+            ms = res["wall"] * 1e3 / a.steps
+            return {"value": rows_step * a.steps / res["wall"], "unit": "TD-updates/s", "ms_per_step": ms,
+                    "scaling": scaling, "weights": W, "weights_per_gpu": W // world,
+                    "updates_per_s": a.steps / res["wall"],
+                    "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
+                    "gpu_ms_per_step_events": res["gpu_ms_per_step_events"], "last_loss": res["loss"],
+                    "roofline": _roofline(res, rows_step // world),
+                    "whole_step_algorithmic_tflops": rows_step * (4 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) / (ms * 1e-3) / 1e12}
+
+        scaling = "weak" if world == 1 else a.scaling     # (one GPU: per-GPU work is the metric's workload either way)
+        h = record(head, W_head, scaling)
         out = {
             "metric": "Envelope-Q TD updates/sec (batch x weights x obj = 256 x 64 x 3)",
-            "value": rows_step * a.steps / wall,
+            "value": h["value"],
             "unit": "TD-updates/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": h["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak" if (weak or world == 1) else "strong",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"Envelope.update(): B={B} x W={W} x R={R}, obs {D}, {A} actions, net {ARCH}, "
+            "config": {"workload": f"Envelope.update(): B={B} x W={W_head} x R={R}, obs {D}, {A} actions, net {ARCH}, "
                                    f"PER {'on' if a.per else 'off'}, buffer 20k seeded transitions (BASELINE.md s3)",
-                       "global_batch": B, "weights": W, "objectives": R,
-                       "weights_per_gpu": W // world,
+                       "global_batch": B, "weights": W_head, "objectives": R,
+                       "weights_per_gpu": W_head // world,
                        "parallelism": "single GPU" if world == 1 else f"weight axis sharded over {world} GPUs, "
-                                      f"{W // world} weights each ({a.scaling} scaling; RCCL all-gather of Q(w), "
+                                      f"{W_head // world} weights each ({scaling} scaling; RCCL all-gather of Q(w), "
                                       "all-reduce of gradients)",
-                       "engine": agent.q_net.ctx.engine},
-            "updates_per_s": a.steps / wall,
-            "scalar_td_per_s": rows_step * R * a.steps / wall,
-            "gpu_ms_per_step_events": gpu_ms / a.steps,
-            "last_loss": loss,
-            "roofline": {"bound": "mfma", "kernel": "mlp_chain (layer-fused Q-net forward / backward-dX)",
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_chain_traffic(),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
-                         "launches_timed": n_chain, "timed_steps": timed_steps, "avg_launch_us": avg_launch_s * 1e6,
-                         "algorithmic_flop_per_launch": flop_per_launch,
-                         "whole_step_algorithmic_tflops": rows_step * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW +
-                                                                       FWD_FLOP_ROW) / (ms_per_step * 1e-3) / 1e12},
+                       "engine": head["engine"]},
+            "updates_per_s": h["updates_per_s"],
+            "scalar_td_per_s": h["value"] * R,
+            "gpu_ms_per_step_events": h["gpu_ms_per_step_events"],
+            "host_enqueue_ms_per_step": h["host_enqueue_ms_per_step"],
+            "last_loss": h["last_loss"],
+            "roofline": dict(h["roofline"], whole_step_algorithmic_tflops=h["whole_step_algorithmic_tflops"]),
         }
+        if sub is not None:
+            key = "weak_scaling" if scaling == "strong" else "strong_scaling"
+            if "error" in sub:
+                out[key] = sub
+            else:
+                other = "weak" if scaling == "strong" else "strong"
+                out[key] = dict(record(sub, sub["W"], other),
+                                note=f"sub-record, NOT the headline: {other} scaling, W = {sub['W']} sampled weights in total "
+                                     f"({sub['W'] // world} per GPU), same steps / warm-up, measured right after the headline")
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(B, W, bool(a.per))
+            out["cpu_baseline"] = cpu_baseline(B, W_head, bool(a.per))
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), file=result_out, flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -138,8 +138,8 @@ def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
             self._losses.append(loss)
             if self.per:
                 self.replay_buffer.update_priorities_from_td(b_inds, pr, self.per_alpha)
-        if self.tau != 1 or self.global_step % self.target_net_update_freq == 0:
-            ops.polyak(self.lib, self.q_net.flat, self.target_q_net.flat, self.tau)
+        # target sync + epsilon / homotopy schedules + logging: the same tail as the single-GPU step
+        self._finish_update(pr if self.per else None)
 
     agent.update = types.MethodType(update, agent)
     agent.q_net.ensure_capacity(agent.batch_size, W)

@@ -249,6 +249,11 @@ class Envelope(MOPolicy, MOAgent):
                 priority = self._out["priority"]
                 self.replay_buffer.update_priorities_from_td(b_inds, priority, self.per_alpha)
 
+        self._finish_update(priority)
+
+    def _finish_update(self, priority=None):
+        """Tail of ``Envelope.update`` (``envelope.py:336-367``): target sync, epsilon / homotopy schedules, logging.
+        Shared by the single-GPU step and the weight-sharded step of ``distributed.py``."""
         if self.tau != 1 or self.global_step % self.target_net_update_freq == 0:
             ops.polyak(self.lib, self.q_net.flat, self.target_q_net.flat, self.tau)
 
@@ -261,13 +266,15 @@ class Envelope(MOPolicy, MOAgent):
                                                            self.final_homotopy_lambda)
         if self.log and self.global_step % 100 == 0:
             import wandb
-            wandb.log({
+            log = {
                 "losses/critic_loss": float(th.stack(self._losses).mean().item()),
-                "losses/grad_norm": float(self._out["grad_norm"].item()),
                 "metrics/epsilon": self.epsilon,
                 "metrics/homotopy_lambda": self.homotopy_lambda,
                 "global_step": self.global_step,
-            })
+            }
+            if self._out is not None and "grad_norm" in self._out:
+                log["losses/grad_norm"] = float(self._out["grad_norm"].item())
+            wandb.log(log)
             if self.per and priority is not None:
                 wandb.log({"metrics/mean_priority": float(priority.mean().item())})
 

@@ -142,6 +142,8 @@ class GPIPD(MOPolicy, MOAgent):
                                                                  self._all_views(e.exp_avg_sq), self._adam_step,
                                                                  self.learning_rate)
         saved["M"] = self.weight_support
+        if self.dyna:                                   # gpi_pd.py:323-324
+            saved["dynamics_state_dict"] = self.dynamics.state_dict()
         if save_replay_buffer:
             saved["replay_buffer"] = self.replay_buffer
         filename = self.experiment_name if filename is None else filename
@@ -156,6 +158,8 @@ class GPIPD(MOPolicy, MOAgent):
         self._adam_step = load_adam_state_dict(params["psi_nets_optimizer_state_dict"], self._all_views(e.exp_avg),
                                                self._all_views(e.exp_avg_sq))
         self.set_weight_support([w.cpu().numpy() for w in params["M"]])
+        if self.dyna and "dynamics_state_dict" in params:   # gpi_pd.py:338-339
+            self.dynamics.load_state_dict(params["dynamics_state_dict"])
         if load_replay_buffer and "replay_buffer" in params:
             self.replay_buffer = params["replay_buffer"]
 

@@ -77,14 +77,15 @@ class ReplayBuffer:
         row[2 * D + R + 1:] = np.asarray(action, dtype=np.float32).reshape(-1)
 
     def _stage_row(self, obs, action, reward, next_obs, done) -> None:
+        # a flush copies at most two contiguous ring ranges, so the pending rows may wrap the ring at most once: flush as
+        # soon as they would cover the whole buffer (max_size < _PENDING with learning_starts > buffer_size)
+        if self._pending_n == min(self._PENDING, self.max_size):
+            self.flush()
         if self._pending_n == 0:
             self._pending_start = self.ptr
             evt = self._stage_evt[self._cur]
             if evt is not None:
                 evt.synchronize()     # the previous H2D out of this staging buffer must have finished
-        if self._pending_n == self._PENDING:
-            self.flush()
-            self._pending_start = self.ptr
         self._write_record(self._stage_np[self._cur][self._pending_n], obs, action, reward, next_obs, done)
         self._pending_n += 1
 
@@ -166,7 +167,7 @@ class ReplayBuffer:
         """``buffer.py:68-96``: host index selection on the global numpy RNG, device gather when ``to_tensor``."""
         inds = np.random.choice(self.size, batch_size, replace=replace)
         if use_cer:
-            inds[0] = self.ptr - 1
+            inds[0] = (self.ptr - 1) % self.max_size     # numpy wraps -1 to the newest slot; the device gather must too
         if to_tensor:
             return self._gather(inds)
         return (self.obs[inds], self.actions[inds], self.rewards[inds], self.next_obs[inds], self.dones[inds], inds)

@@ -12,21 +12,25 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _make_agent(lib, per):
+N_STEPS = {False: 2, True: 5}      # plain / with the epsilon + homotopy schedules running
+
+
+def _make_agent(lib, per, schedules=False):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     import morl_baselines_amd.envelope as envmod
     from test_host_api import ToyEnv, _fill
     env = ToyEnv()
     th.manual_seed(0)
     np.random.seed(0)
+    extra = dict(homotopy_decay_steps=6, initial_epsilon=0.5, final_epsilon=0.05, epsilon_decay_steps=8) if schedules else {}
     ag = envmod.Envelope(env, net_arch=[32, 32], batch_size=8, num_sample_w=4, buffer_size=256, per=per,
-                         learning_starts=0, log=False, seed=0, device=th.device("cpu"), lib=lib)
+                         learning_starts=0, log=False, seed=0, device=th.device("cpu"), lib=lib, **extra)
     _fill(ag.replay_buffer, 100, env.D, env.A, env.R)
     ag.global_step = 7
     return ag
 
 
-def _worker(rank, world, port, per, ret):
+def _worker(rank, world, port, per, ret, schedules=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -38,46 +42,54 @@ def _worker(rank, world, port, per, ret):
     lib = simlib.load_sim()
     native.use_library(lib)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ag = _make_agent(lib, per)
+    ag = _make_agent(lib, per, schedules)
     shard_envelope_agent(ag, dist)
-    for _ in range(2):
+    for _ in range(N_STEPS[schedules]):
         ag.update()
         ag.global_step += 1
     ret[rank] = (ag.q_net.flat.clone().numpy(), float(ag.last_loss()),
-                 ag.replay_buffer.tree_dev.clone().numpy() if per else None)
+                 ag.replay_buffer.tree_dev.clone().numpy() if per else None,
+                 float(ag.homotopy_lambda), float(ag.epsilon))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("per", [False, True])
-def test_sharded_update_equals_single_process(per):
+@pytest.mark.parametrize("per,schedules", [(False, False), (True, False), (True, True)])
+def test_sharded_update_equals_single_process(per, schedules):
+    """``schedules``: several steps with ``homotopy_decay_steps`` / ``epsilon_decay_steps`` set -- the sharded step must run
+    the same tail as ``Envelope.update`` (envelope.py:336-355), or the auxiliary loss never turns on under sharding."""
     import simlib
     import morl_baselines_amd.native as native
     lib = simlib.load_sim()
     native.use_library(lib)
+    n_steps = N_STEPS[schedules]
     try:
-        ref = _make_agent(lib, per)
-        for _ in range(2):
+        ref = _make_agent(lib, per, schedules)
+        for _ in range(n_steps):
             ref.update()
             ref.global_step += 1
         want, want_loss = ref.q_net.flat.clone().numpy(), ref.last_loss()
         want_tree = ref.replay_buffer.tree_dev.clone().numpy() if per else None
+        want_lam, want_eps = float(ref.homotopy_lambda), float(ref.epsilon)
     finally:
         native.use_library(None)
+    if schedules:
+        assert 0.0 < want_lam <= 1.0 and want_eps < 0.5            # the schedules actually moved
     world = 2
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, per, ret)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + 7 * int(schedules)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per, ret, schedules)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
-    p0, l0, t0 = ret[0]
-    p1, l1, t1 = ret[1]
+    p0, l0, t0, lam0, eps0 = ret[0]
+    p1, l1, t1, lam1, eps1 = ret[1]
     assert np.array_equal(p0, p1) and l0 == l1                      # replicas bit-identical
+    assert lam0 == lam1 == want_lam and eps0 == eps1 == want_eps     # same schedules as the unsharded agent
     assert abs(l0 - want_loss) <= 1e-5 * abs(want_loss)              # sharded == unsharded (fp32 order tolerance)
-    assert np.abs(p0 - want).max() <= 0.02 * 3e-4 * 2
+    assert np.abs(p0 - want).max() <= 0.02 * 3e-4 * n_steps
     if per:
         assert np.array_equal(t0, t1)
         np.testing.assert_allclose(t0[0], want_tree[0], rtol=1e-5)
@@ -165,7 +177,7 @@ def test_data_parallel_capql_equals_big_batch_oracle():
 
 # ---- the same sharded step over RCCL on a real GPU (one rank talking to itself: the collectives, streams and the in-place
 #      gathered-slab layout are the production ones; N > 1 needs more GPUs than the test box has) --------------------------
-def _rccl_worker(port, per, ret):
+def _rccl_worker(port, per, ret, rank=0, world=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -174,7 +186,7 @@ def _rccl_worker(port, per, ret):
     import morl_baselines_amd.native as native
     from morl_baselines_amd.distributed import shard_envelope_agent
     from test_host_api import ToyEnv, _fill
-    dev = th.device("cuda:0")
+    dev = th.device("cuda", rank)
     th.cuda.set_device(dev)
     lib = native.load_library()
 
@@ -193,18 +205,22 @@ def _rccl_worker(port, per, ret):
         ref.update()
         ref.global_step += 1
     want, want_loss = ref.q_net.flat.clone().cpu().numpy(), ref.last_loss()
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    print(f"[rccl test] rank {rank}: nranks={dist.get_world_size()} backend={dist.get_backend()} device={dev}",
+          file=sys.stderr, flush=True)
     ag = make()
     shard_envelope_agent(ag, dist)
     for _ in range(3):
         ag.update()
         ag.global_step += 1
     th.cuda.synchronize()
-    ret["params"] = ag.q_net.flat.clone().cpu().numpy()
-    ret["loss"] = float(ag.last_loss())
+    sfx = "" if world == 1 else str(rank)
+    ret["params" + sfx] = ag.q_net.flat.clone().cpu().numpy()
+    ret["loss" + sfx] = float(ag.last_loss())
     ret["want"], ret["want_loss"] = want, want_loss
+    ret["nranks" + sfx] = dist.get_world_size()
     if per:
-        ret["tree"] = ag.replay_buffer.tree_dev.cpu().numpy()
+        ret["tree" + sfx] = ag.replay_buffer.tree_dev.cpu().numpy()
         ret["want_tree"] = ref.replay_buffer.tree_dev.cpu().numpy()
     dist.destroy_process_group()
 
@@ -225,6 +241,37 @@ def test_sharded_update_over_rccl_single_rank(per):
     assert np.abs(ret["params"] - ret["want"]).max() <= 0.02 * 3e-4 * 3
     if per:
         np.testing.assert_allclose(ret["tree"][0], ret["want_tree"][0], rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(th.cuda.device_count() < 2, reason="needs >= 2 GPUs (the multi-rank RCCL path)")
+@pytest.mark.parametrize("per", [False, True])
+def test_sharded_update_over_rccl_multi_rank(per):
+    """The gloo world-size-2 assertions on real RCCL: min(4, device_count) ranks (a power of two dividing the 8 sampled
+    weights), one per GPU; replicas bit-identical to each other and equal to the single-GPU step up to fp32 summation order."""
+    world = 4 if th.cuda.device_count() >= 4 else 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 36500 + (os.getpid() % 2000) + int(per)
+    procs = [ctx.Process(target=_rccl_worker, args=(port, per, ret, r, world)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        if p.is_alive():
+            for q in procs:
+                q.kill()
+            pytest.fail("RCCL multi-rank worker did not finish")
+        assert p.exitcode == 0
+    assert all(ret[f"nranks{r}"] == world for r in range(world))
+    for r in range(1, world):
+        assert np.array_equal(ret["params0"], ret[f"params{r}"]) and ret["loss0"] == ret[f"loss{r}"]
+        if per:
+            assert np.array_equal(ret["tree0"], ret[f"tree{r}"])
+    assert abs(ret["loss0"] - ret["want_loss"]) <= 1e-5 * abs(ret["want_loss"])
+    assert np.abs(ret["params0"] - ret["want"]).max() <= 0.02 * 3e-4 * 3
+    if per:
+        np.testing.assert_allclose(ret["tree0"][0], ret["want_tree"][0], rtol=1e-5)
 
 
 def _dp_rccl_worker(port, ret):
