@@ -51,6 +51,7 @@ struct ChainStep {
     float* out;          // [rows][ldout] or NULL: global copy of this step's output
     int K, N, ldb, ldbt, ldmask, ldout;
     int relu;
+    int kpad;            // mlp_chain2: rows of Bmat physically present (>= K, zero beyond K); 0 = exactly K
 };
 
 struct ChainArgs {
@@ -67,6 +68,7 @@ struct ChainArgs {
     float* x0_out;          // in_mode 0, or NULL: the assembled rows also go to HBM as [rows][ldx0] (zero padded) -- the
     int ldx0;               // weight-gradient GEMM of layer 0 reads them; saves the separate input-assembly launch
     long long* prof;        // development probe only (tools/probes): [blocks][8] phase cycle counters
+    int fast;               // mlp_chain2: every wide step has ldb == 256 and kpad a multiple of 64 (constant-stride weight stream)
 };
 
 // One register set of B operands: 16 eight-byte loads per lane.

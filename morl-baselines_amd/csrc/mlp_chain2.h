@@ -1,0 +1,541 @@
+// Layer-fused MLP engine, second generation (gfx950, wave64): same contract as mlp_chain.h (a workgroup carries a TM-row tile
+// through a whole chain of dense layers, activations resident in LDS), re-laid-out around what round 1's profiles showed:
+//
+//   * activations are M-MAJOR in LDS, sAct[m][k] with row stride 260 floats: the MFMA A operand of lane (i, h) for FOUR
+//     consecutive k-pairs is ONE ds_read_b128 (k = 8c + 4h + 0..3; the contraction order inside a chunk is permuted
+//     accordingly -- any order is a valid exact-fp32 chain, and it is the same for every tile size, so a row's result does
+//     not depend on the tile that carried it).  16 MFMAs per LDS read per row tile instead of 4, and the read of group g+1
+//     is issued a whole group (>= 512 cycles) ahead of its first use.  Row stride 260 = 4 (mod 64) banks: the 16-lane
+//     groups of a b128 access cover all 64 banks once.
+//   * the epilogue stores column PAIRS (ds_write_b64, 32 per lane and layer instead of 128 scalar stores) -- rows of a
+//     half-wave are contiguous 256-byte segments.
+//   * activations / gradients that must also reach HBM (saved h_l of the training forward, g_l of the backward chain) are
+//     NOT stored from the accumulators in the epilogue: they sit in LDS as the next step's input anyway, so they are copied
+//     LDS -> HBM in 16-byte pieces (one wave = one full 1-KB row per instruction) INSIDE the next step's MFMA loop, where
+//     the memory pipes are idle.
+//   * weights stream L2 -> registers exactly as before (the waves split the output columns, nothing is shared): one
+//     buffer_load_dwordx2 per k-row and lane, two named register sets; the per-load address is one v_add of a scalar.
+//   * persistent schedule: the grid is 2 workgroups per CU; every workgroup takes 64-row tiles in full rounds and the
+//     remainder as 32-row half tiles, so that all slots finish together (3 x 16 384 rows = 768 tiles on 512 slots used to
+//     run as one full and one half-empty round), and the second half of the grid takes its jobs in the opposite order, which
+//     staggers the two workgroups of a CU: one is in its MFMA loop while the other is in an epilogue.
+#pragma once
+#include "mlp_chain.h"
+
+namespace morl {
+
+constexpr int C2_LDK = CH_MAXW + 4;      // floats per activation row in LDS
+constexpr int C2_TM = 64;                // rows of the LDS tile (32-row jobs use the first half)
+
+struct C2BSet {
+    float2 v[16];
+};
+struct C2ASet {
+    float4 a[2];
+};
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int c2_u32x4 __attribute__((ext_vector_type(4)));
+
+// wide step: lane (i, h) of wave w loads B[k][64w + 2i .. +1]; v[j] <-> k = k0 + 8*(j >> 2) + 4h + (j & 3)
+struct C2WideDesc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int lane_off;     // bytes: (4h * ldb + colw) * 4, or CH_OOB when the lane's columns do not exist
+    int stride;       // bytes per k-row (wave-uniform)
+};
+
+__device__ __forceinline__ C2WideDesc c2_wide_desc(const ChainStep& st, int wave, int i, int h) {
+    C2WideDesc d;
+    const int colw = wave * 64 + 2 * i;
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st.Bmat, 0, (st.kpad > st.K ? st.kpad : st.K) * st.ldb * 4, 0x00020000);
+    d.lane_off = (colw < st.ldb) ? (4 * h * st.ldb + colw) * 4 : CH_OOB;
+    d.stride = st.ldb * 4;
+    return d;
+}
+
+// rows >= K lie beyond the resource: the hardware returns 0 (K padding, dummy prefetches) -- no branch, no select
+__device__ __forceinline__ void c2_load_wide(C2BSet& s, const C2WideDesc& d, int k0) {
+    const int base = d.lane_off + k0 * d.stride;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int off = base + (8 * (j >> 2) + (j & 3)) * d.stride;
+        s.v[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(d.rsrc, off, 0, 0));
+    }
+}
+
+// constant-stride form (ChainArgs::fast: ldb == 256, rows physically padded to a multiple of 64): the per-lane offset is
+// loop-invariant, the row of group c goes through the SGPR offset and the row inside the group through the instruction's
+// immediate -- no VALU work at all in the stream
+__device__ __forceinline__ void c2_load_fast(C2BSet& s, const C2WideDesc& d, int k0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        s.v[j] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(d.rsrc, d.lane_off + (j & 3) * 1024,
+                                                                                  (k0 + 8 * (j >> 2)) * 1024, 0));
+}
+
+// narrow step (N <= 32): the four waves split the contraction, wave w: k in [64w, 64w + 64); lane (i = n, h) loads
+// Bt[n][64w + 8c + 4h .. +3] for c = 0..7 as eight float4 = the 16 float2 of the set (v[2c], v[2c+1])
+__device__ __forceinline__ void c2_load_narrow(C2BSet& s, const ChainStep& st, int wave, int i, int h) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st.Bt, 0, st.N * st.ldbt * 4, 0x00020000);
+    const int kbase = wave * 64 + 4 * h;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int k = kbase + 8 * c;
+        // K is a multiple of 4 (host guarantee), so a quad is wholly inside or wholly outside the row
+        const int off = (i < st.N && k < st.K) ? (i * st.ldbt + k) * 4 : CH_OOB;
+        s.v[2 * c] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+        s.v[2 * c + 1] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 8, 0, 0));
+    }
+}
+
+// LDS -> HBM copy of the tile in sAct (the step's input = the previous step's output) in TM / 4 pieces: piece `it` moves
+// rows 4*it .. 4*it + 3, one wave = one full row (64 x 16 bytes) per instruction.  Branch-free: the destination is a buffer
+// resource spanning exactly out[rows][ldout], so rows beyond the matrix (ragged last tile) are dropped by the range check,
+// and lanes whose columns do not exist carry an out-of-range offset.  Per piece: one ds_read_b128 with an immediate
+// offset, one v_add, one buffer_store_dwordx4.
+struct C2CopyDst {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff0;        // bytes: ((row0 + tid / 64) * ldout + 4 * (tid % 64)) * 4, or CH_OOB
+    int step;         // bytes between pieces: 4 rows
+    int lds0;         // floats: (tid / 64) * C2_LDK + 4 * (tid % 64)
+};
+
+__device__ __forceinline__ C2CopyDst c2_copy_dst(float* out, int ldout, int n, int rows, int row0, int tid) {
+    C2CopyDst d;
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, rows * ldout * 4, 0x00020000);
+    const int m = tid >> 6, c4 = (tid & 63) << 2;
+    d.voff0 = (c4 < n) ? ((row0 + m) * ldout + c4) * 4 : CH_OOB;
+    d.step = 4 * ldout * 4;
+    d.lds0 = m * C2_LDK + c4;
+    return d;
+}
+
+__device__ __forceinline__ void c2_copy_piece(const float* sAct, const C2CopyDst& d, int it) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(sAct + d.lds0 + it * 4 * C2_LDK);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(c2_u32x4, v), d.rsrc, d.voff0 + it * d.step, 0, 0);
+}
+
+// ---- the MFMA loop of a wide step ---------------------------------------------------------------------------------------
+// SCHED = 1 pins the instruction interleave with sched_group_barrier: the look-ahead operand reads FIRST in every group
+// (hipcc otherwise sinks each ds_read next to its first use and waits for it on the spot), the weight loads and their address
+// adds spread over the MFMAs of the other register set, one copy piece per group.
+#define C2_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+
+template <int TM, bool COPY, int SCHED, bool FAST>
+__device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& bx, C2BSet& by, const float* sAct, const float* pa,
+                                             const C2WideDesc& dcur, const C2WideDesc& dnext, bool nxt_wide, int n_pairs,
+                                             const C2CopyDst& cd) {
+    constexpr int MT = TM / 32;
+    constexpr int N_PIECES = TM / 4;
+    constexpr int PP = TM / 16;             // copy pieces per 64-deep pair: all of them within the 4 pairs of a 256-wide step
+    C2ASet ax, ay;
+#pragma unroll
+    for (int tm = 0; tm < MT; ++tm) ax.a[tm] = *reinterpret_cast<const float4*>(pa + tm * 32 * C2_LDK);
+    int piece = 0;
+    for (int pr = 0; pr < n_pairs; ++pr) {
+        const int k0 = pr * 64;
+        const bool more = pr + 1 < n_pairs;
+        // bx's refill: this step's chunk two ahead, else the next wide step's chunk 0, else a dummy re-read (a narrow step
+        // loads its own operands); by's refill: this step's chunk three ahead, else a dummy.  Never skipped and branch-free,
+        // so the loop body is one scheduling region and the number of loads in flight is static.
+        const bool from_next = !more && nxt_wide;
+        C2WideDesc dx;
+        dx.rsrc = from_next ? dnext.rsrc : dcur.rsrc;
+        dx.lane_off = from_next ? dnext.lane_off : dcur.lane_off;
+        dx.stride = from_next ? dnext.stride : dcur.stride;
+        const int kx = more ? k0 + 64 : 0;
+        const int ky = more ? k0 + 96 : CH_BK;
+// one group = 8 contraction indices = 4 MFMA k-pairs x (2 * MT) tiles; the A quad of the NEXT group is read first
+#define C2_GROUP(SET, C, ACUR, ANEXT, KNEXT)                                                               \
+    {                                                                                                      \
+        _Pragma("unroll") for (int tm = 0; tm < MT; ++tm)                                                  \
+            ANEXT.a[tm] = *reinterpret_cast<const float4*>(pa + tm * 32 * C2_LDK + (KNEXT));              \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                    \
+            const float2 bv = SET.v[4 * (C) + t];                                                          \
+            _Pragma("unroll") for (int tm = 0; tm < MT; ++tm) {                                            \
+                const float av = (t == 0) ? ACUR.a[tm].x : (t == 1) ? ACUR.a[tm].y : (t == 2) ? ACUR.a[tm].z : ACUR.a[tm].w; \
+                acc[tm][0] = mfma32(av, bv.x, acc[tm][0]);                                                 \
+                acc[tm][1] = mfma32(av, bv.y, acc[tm][1]);                                                 \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+        C2_GROUP(bx, 0, ax, ay, k0 + 8)
+        C2_GROUP(bx, 1, ay, ax, k0 + 16)
+        C2_GROUP(bx, 2, ax, ay, k0 + 24)
+        C2_GROUP(bx, 3, ay, ax, k0 + 32)
+        if (FAST) c2_load_fast(bx, dx, kx);
+        else c2_load_wide(bx, dx, kx);
+        C2_GROUP(by, 0, ax, ay, k0 + 40)
+        C2_GROUP(by, 1, ay, ax, k0 + 48)
+        C2_GROUP(by, 2, ax, ay, k0 + 56)
+        // (the last group's look-ahead read stays inside the buffer: column k0 + 64 + 7 <= 263, 8 spare floats at its end)
+        C2_GROUP(by, 3, ay, ax, k0 + 64)
+        if (FAST) c2_load_fast(by, dcur, ky);
+        else c2_load_wide(by, dcur, ky);
+#undef C2_GROUP
+        if (COPY) {
+#pragma unroll
+            for (int u = 0; u < PP; ++u) c2_copy_piece(sAct, cd, piece + u);
+            piece += PP;
+        }
+        if (SCHED) {
+            // program order above: 8 x [MT ds_read, 8*MT MFMA], bx loads after group 3, by loads after group 7, 4 copy pieces.
+            // wanted: groups 0-3 (bx) carry the copy pieces, groups 4-7 (by) carry bx's 16 loads, by's loads trail (they
+            // have the whole next bx half to land)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                C2_SGB(0x100, MT);                              // look-ahead A reads
+                if (COPY && g < PP) C2_SGB(0x100, 1);           // a copy piece's LDS read ...
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    C2_SGB(0x008, 2 * MT);
+                    if (g >= 4) { if (!FAST) C2_SGB(0x002, 1); C2_SGB(0x020, 1); }   // (address add +) one weight load
+                }
+                if (COPY && g < PP) { C2_SGB(0x002, 1); C2_SGB(0x040, 1); }   // ... its address add and its store
+            }
+        }
+    }
+    if (COPY)
+        for (; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cd, piece);
+}
+
+template <int TM, int SCHED, bool FAST>
+__device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, float* sAct) {
+    constexpr int MT = TM / 32;                       // 32-row MFMA tiles per wave
+    constexpr int N_PIECES = TM / 4;                  // 16-byte copy pieces per thread and tile (256 floats per row)
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_id();
+    const int h = lane >> 5, i = lane & 31;
+    const int colw = wave * 64 + 2 * i;               // first of this lane's two physical output columns (wide steps)
+
+    C2BSet bx, by;
+    const bool first_wide = p.step[0].N > 32;
+    C2WideDesc dcur = c2_wide_desc(p.step[0], wave, i, h);
+    // the weight stream starts before the input tile is assembled
+    if (first_wide) { if (FAST) c2_load_fast(bx, dcur, 0); else c2_load_wide(bx, dcur, 0); }
+    else c2_load_narrow(bx, p.step[0], wave, i, h);
+
+    // ---- input tile -> sAct[m][k], zero-padded to the columns the first step multiplies -------------------------------
+    {
+        const int K0 = (p.in_mode == 0) ? (p.D + p.R) : p.K0;
+        const int K0pad = first_wide ? min(CH_MAXW, (K0 + 63) & ~63) : CH_MAXW;
+        const int m = tid & (TM - 1);
+        constexpr int TPR = CH_THREADS / TM;           // threads per row
+        const int q = tid / TM;
+        const int row = row0 + m;
+        int b = row, w = row;
+        if (p.in_mode == 0) {
+            if (p.row_order == 0) { b = row / p.W; w = row - b * p.W; }
+            else if (p.row_order == 1) { w = row / p.B; b = row - w * p.B; }
+        }
+        const bool row_ok = row < p.rows;
+        const float* src_a = (p.in_mode == 0) ? p.obs + (size_t)b * p.D : p.src + (size_t)row * p.ldsrc;
+        const float* src_w = p.weights + (size_t)w * p.R;
+        for (int kb = q * 16; kb < K0pad; kb += TPR * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = kb + u;
+                float x = 0.f;
+                if (row_ok && k < K0) {
+                    if (p.in_mode == 0) x = (k < p.D) ? src_a[k] : src_w[k - p.D];
+                    else x = src_a[k];
+                }
+                v[u] = x;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u += 4)
+                *reinterpret_cast<float4*>(sAct + m * C2_LDK + kb + u) = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
+            if (p.x0_out != nullptr && row_ok) {
+#pragma unroll
+                for (int u = 0; u < 16; u += 4)
+                    if (kb + u < p.ldx0)      // ldx0 is a multiple of 4
+                        *reinterpret_cast<float4*>(p.x0_out + (size_t)row * p.ldx0 + kb + u) =
+                            make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
+            }
+        }
+    }
+    __syncthreads();
+
+    bool do_copy = false;                // the tile now in sAct must also be written to HBM (deferred store) ...
+    C2CopyDst cdst = c2_copy_dst(sAct, 0, 0, 0, 0, tid);   // ... to here
+
+    for (int s = 0; s < p.n_steps; ++s) {
+        const ChainStep& st = p.step[s];
+        const int K = st.K, N = st.N;
+        const bool feed_next = (s + 1 < p.n_steps);
+        const ChainStep& nxt = p.step[feed_next ? s + 1 : s];    // what the stream fetches after this step (or a dummy)
+        const bool nxt_wide = nxt.N > 32;
+
+        if (N > 32) {
+            // ======================= matrix-core path =======================================================
+            f32x16 acc[MT][2];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+            const int n_pairs = (K + 63) >> 6;         // K is treated as padded to a multiple of 64 with zero rows
+            if (FAST) c2_load_fast(by, dcur, CH_BK); else c2_load_wide(by, dcur, CH_BK);
+            const float* pa = sAct + i * C2_LDK + 4 * h;
+            const C2WideDesc dnext = c2_wide_desc(nxt, wave, i, h);
+            if (do_copy) c2_wide_loop<TM, true, SCHED, FAST>(acc, bx, by, sAct, pa, dcur, dnext, nxt_wide, n_pairs, cdst);
+            else c2_wide_loop<TM, false, SCHED, FAST>(acc, bx, by, sAct, pa, dcur, dnext, nxt_wide, n_pairs, cdst);
+            dcur = dnext;
+            __syncthreads();     // every wave is past its last read of sAct (MFMA operands and copy pieces)
+
+            // ---- epilogue ---------------------------------------------------------------------------------
+            const bool col_ok = colw < N;
+            const bool col1_ok = colw + 1 < N;
+            float bias0 = 0.f, bias1 = 0.f;
+            if (st.bias != nullptr) {
+                if (col_ok) bias0 = st.bias[colw];
+                if (col1_ok) bias1 = st.bias[colw + 1];
+            }
+            unsigned long long bits_w = 0ull, bits_r = 0ull;
+            const size_t bits_idx = (size_t)(row0 >> 6) * CH_THREADS + tid;
+            const int bits_shift = (TM == 32) ? ((row0 >> 5) & 1) * 32 : 0;
+            if (st.bits_in != nullptr) bits_r = st.bits_in[bits_idx] >> bits_shift;
+#pragma unroll
+            for (int tm = 0; tm < MT; ++tm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v0 = acc[tm][0][r] + bias0, v1 = acc[tm][1][r] + bias1;
+                    if (st.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                    acc[tm][0][r] = col_ok ? v0 : 0.f;
+                    acc[tm][1][r] = col1_ok ? v1 : 0.f;
+                }
+                if (st.bits_out != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (acc[tm][0][r] > 0.f) bits_w |= 1ull << ((tm * 2 + 0) * 16 + r);
+                        if (acc[tm][1][r] > 0.f) bits_w |= 1ull << ((tm * 2 + 1) * 16 + r);
+                    }
+                }
+                if (st.bits_in != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc[tm][0][r] = ((bits_r >> ((tm * 2 + 0) * 16 + r)) & 1ull) ? acc[tm][0][r] : 0.f;
+                        acc[tm][1][r] = ((bits_r >> ((tm * 2 + 1) * 16 + r)) & 1ull) ? acc[tm][1][r] : 0.f;
+                    }
+                }
+                // the tile goes to LDS whenever somebody reads it from there: the next step, or the deferred HBM copy
+                if (feed_next || st.out != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        *reinterpret_cast<float2*>(sAct + m * C2_LDK + colw) = make_float2(acc[tm][0][r], acc[tm][1][r]);
+                    }
+                }
+            }
+            if (st.bits_out != nullptr) {
+                if (TM == 64) st.bits_out[bits_idx] = bits_w;
+                else   // a 32-row tile owns one 32-bit half of the word (rows 0-31 / 32-63 of the 64-row band)
+                    reinterpret_cast<unsigned int*>(st.bits_out)[2 * bits_idx + ((row0 >> 5) & 1)] = (unsigned int)bits_w;
+            }
+            do_copy = st.out != nullptr;
+            if (do_copy) cdst = c2_copy_dst(st.out, st.ldout, N, p.rows, row0, tid);
+        } else {
+            // ======================= narrow step (Q head): split-K over the four waves ========================
+            // bx holds Bt[i][64w + 8c + 4h + 0..3] (c = 0..7): wave w contracts k in [64w, 64w + 64) for output column i
+            f32x16 hacc[MT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hacc[a][r] = 0.f;
+            const float* pa = sAct + i * C2_LDK + wave * 64 + 4 * h;
+            // the saved input of this step goes to HBM first (its LDS image becomes the reduction scratch below)
+            if (s > 0) c2_load_narrow(bx, st, wave, i, h);   // (step 0's operands were fetched by the prologue)
+            if (do_copy)
+                for (int piece = 0; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cdst, piece);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float4 a4[MT];
+#pragma unroll
+                for (int tm = 0; tm < MT; ++tm) a4[tm] = *reinterpret_cast<const float4*>(pa + tm * 32 * C2_LDK + 8 * c);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float bv = (t == 0) ? bx.v[2 * c].x : (t == 1) ? bx.v[2 * c].y : (t == 2) ? bx.v[2 * c + 1].x : bx.v[2 * c + 1].y;
+#pragma unroll
+                    for (int tm = 0; tm < MT; ++tm) {   // columns >= K of sAct: finite stale values times zero weights
+                        const float av = (t == 0) ? a4[tm].x : (t == 1) ? a4[tm].y : (t == 2) ? a4[tm].z : a4[tm].w;
+                        hacc[tm] = mfma32(av, bv, hacc[tm]);
+                    }
+                }
+            }
+            __syncthreads();     // every wave is past its last read of sAct -> reuse it as the reduction scratch
+            float* scr = sAct;
+#pragma unroll
+            for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scr[((wave * MT + tm) * 16 + r) * 64 + lane] = hacc[tm][r];
+            // the stream moves on while the partial tiles are reduced
+            const C2WideDesc dnext = c2_wide_desc(nxt, wave, i, h);
+            if (nxt_wide) { if (FAST) c2_load_fast(bx, dnext, 0); else c2_load_wide(bx, dnext, 0); }
+            dcur = dnext;
+            __syncthreads();
+            // thread (rg = wave, lane) sums the four partials of registers 4rg..4rg+3 of every row tile, wave order
+            float red[MT][4];
+#pragma unroll
+            for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = wave * 4 + q;
+                    float v = scr[((0 * MT + tm) * 16 + r) * 64 + lane];
+                    v += scr[((1 * MT + tm) * 16 + r) * 64 + lane];
+                    v += scr[((2 * MT + tm) * 16 + r) * 64 + lane];
+                    v += scr[((3 * MT + tm) * 16 + r) * 64 + lane];
+                    red[tm][q] = v;
+                }
+            if (feed_next) __syncthreads();   // scratch fully consumed before sAct is rewritten
+            const int n = i;
+            const float bias = (st.bias != nullptr && n < N) ? st.bias[n] : 0.f;
+#pragma unroll
+            for (int tm = 0; tm < MT; ++tm)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = wave * 4 + q;
+                    const int m = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int row = row0 + m;
+                    const bool ok = n < N && row < p.rows;
+                    float v = red[tm][q] + bias;
+                    if (st.relu) v = fmaxf(v, 0.f);
+                    if (st.mask != nullptr) v = (ok && st.mask[(size_t)row * st.ldmask + n] > 0.f) ? v : 0.f;
+                    if (!ok) v = 0.f;
+                    if (feed_next) sAct[m * C2_LDK + n] = v;
+                    if (st.out != nullptr && ok) st.out[(size_t)row * st.ldout + n] = v;
+                }
+            if (feed_next) {
+                // the next step reads K' = N <= 32 padded to 64 columns: columns [32, 64) must be zero too
+                for (int e = tid; e < 32 * TM; e += CH_THREADS) sAct[(e >> 5) * C2_LDK + 32 + (e & 31)] = 0.f;
+            }
+            do_copy = false;
+        }
+        __syncthreads();    // sAct of the next step (or of the trailing copy) complete before anyone reads it
+    }
+    // a wide last step whose output goes to HBM (the backward chain's g_0): nothing is left to hide the copy behind
+    if (do_copy)
+        for (int piece = 0; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cdst, piece);
+}
+
+// ---- persistent launch over up to CH_MAX_MULTI chains ------------------------------------------------------------------
+// Units are 64-row tiles, numbered chain after chain.  Workgroup b (of S = gridDim.x) takes unit r*S + b in each of
+// `full_rounds` rounds; the `tail_units` remaining units are done as 32-row halves when 2 * tail_units <= S (workgroup b
+// takes half b & 1 of unit tail_base + b / 2), else as whole units by the first tail_units workgroups.  The second half of
+// the grid runs its tail job first.
+struct Chain2Multi {
+    ChainArgs p[CH_MAX_MULTI];
+    int unit_start[CH_MAX_MULTI + 1];   // first 64-row unit of each chain
+    int n;
+    int full_rounds;
+    int tail_base, tail_units;
+    int tail_halves;                    // 1: 32-row half tiles
+};
+
+__device__ __forceinline__ int c2_find_chain(const Chain2Multi& m, int unit) {
+    int q = 0;
+    while (q + 1 < m.n && unit >= m.unit_start[q + 1]) ++q;
+    return q;
+}
+
+template <int SCHED>
+__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain2_kernel(Chain2Multi m) {
+    // (+8: the last group's look-ahead operand read of the last row runs 4 floats past the tile; the values are unused)
+    __shared__ __attribute__((aligned(16))) float sAct[C2_TM * C2_LDK + 8];
+    const int b = (int)blockIdx.x, S = (int)gridDim.x;
+    const bool tail_first = b >= (S >> 1);
+    // jobs of this workgroup: `full_rounds` whole units and at most one tail job (every condition below is workgroup-uniform)
+    for (int j = 0; j <= m.full_rounds; ++j) {
+        const bool is_tail = tail_first ? (j == 0) : (j == m.full_rounds);
+        int unit, half = -1;
+        if (is_tail) {
+            if (m.tail_halves) {
+                if (b >= 2 * m.tail_units) continue;
+                unit = m.tail_base + (b >> 1);
+                half = b & 1;
+            } else {
+                if (b >= m.tail_units) continue;
+                unit = m.tail_base + b;
+            }
+        } else {
+            unit = (tail_first ? j - 1 : j) * S + b;
+        }
+        const int q = c2_find_chain(m, unit);
+        const int row0 = (unit - m.unit_start[q]) * 64 + (half > 0 ? 32 : 0);
+        if (m.p[q].fast) {
+            if (half >= 0) {
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, true>(m.p[q], row0, sAct);
+            } else {
+                mlp_chain2_body<64, SCHED, true>(m.p[q], row0, sAct);
+            }
+        } else {
+            if (half >= 0) {
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, false>(m.p[q], row0, sAct);
+            } else {
+                mlp_chain2_body<64, SCHED, false>(m.p[q], row0, sAct);
+            }
+        }
+        __syncthreads();     // the tile buffer is free for the next job
+    }
+}
+
+// ---- K-major shadow copies of the weights ----------------------------------------------------------------------------------
+// job mode 0: W_l [N][K] (nn.Linear layout) -> Wt_l [Kpad][ldn], Kpad = round_up(K, 64), zero outside [K][N]: the operand the
+//             forward chain streams (and, read N-major, the narrow-step operand of the backward chain)
+// job mode 1: W_l [K = out][ld = in] -> the same rows followed by zero rows up to Kpad: the backward chain's operand when
+//             `out` is not a multiple of 64 (the Q head), so that its weight stream never relies on the range check
+// 64 x 64 tiles through LDS: global reads and writes are both coalesced (the round-1 kernel read with stride K: 13 MB
+// fetched to move 1.7 MB).  blockIdx.y = 0: params -> wt; 1: params2 -> wt2.
+struct ShadowJob {
+    long long src_off, dst_off;
+    int rows_src, cols_src;     // source matrix [rows_src][cols_src] (row-major, dense)
+    int dst_rows, dst_ld;       // destination [dst_rows][dst_ld]
+    int mode;
+    int tiles_c;                // tiles along the destination's column axis
+    int tile_start;
+};
+struct ShadowArgs {
+    ShadowJob job[2 * MORL_MAX_LAYERS];
+    int n, tiles;
+};
+
+__global__ __launch_bounds__(256) void shadow_weights_kernel(const float* __restrict__ params, float* __restrict__ wt,
+                                                             const float* __restrict__ params2, float* __restrict__ wt2,
+                                                             ShadowArgs a) {
+    __shared__ float tile[64 * 65];
+    if (blockIdx.y == 1) { params = params2; wt = wt2; }
+    const int tid = (int)threadIdx.x, fast = tid & 63, slow = tid >> 6;
+    for (int t = (int)blockIdx.x; t < a.tiles; t += (int)gridDim.x) {
+        int q = 0;
+        while (q + 1 < a.n && t >= a.job[q + 1].tile_start) ++q;
+        const ShadowJob& j = a.job[q];
+        const int lt = t - j.tile_start;
+        const int r0 = (lt / j.tiles_c) * 64, c0 = (lt % j.tiles_c) * 64;   // destination tile origin
+        const float* src = params + j.src_off;
+        float* dst = wt + j.dst_off;
+        if (j.mode == 0) {
+            // destination (k, n) <- source (n, k): read source rows n0 + nn along k, write destination rows k0 + kk along n
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int nn = slow + 4 * it, n = c0 + nn, k = r0 + fast;
+                tile[nn * 65 + fast] = (n < j.rows_src && k < j.cols_src) ? src[(size_t)n * j.cols_src + k] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int kk = slow + 4 * it, k = r0 + kk, n = c0 + fast;
+                if (k < j.dst_rows && n < j.dst_ld) dst[(size_t)k * j.dst_ld + n] = tile[fast * 65 + kk];
+            }
+            __syncthreads();
+        } else {
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int r = r0 + slow + 4 * it, c = c0 + fast;
+                if (r < j.dst_rows && c < j.dst_ld)
+                    dst[(size_t)r * j.dst_ld + c] = (r < j.rows_src && c < j.cols_src) ? src[(size_t)r * j.cols_src + c] : 0.f;
+            }
+        }
+    }
+}
+
+}  // namespace morl

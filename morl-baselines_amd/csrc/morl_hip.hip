@@ -18,6 +18,7 @@
 #include "gemm_f32.h"
 #include "envelope_kernels.h"
 #include "mlp_chain.h"
+#include "mlp_chain2.h"
 #include "dw_wave.h"
 #include "optim_kernels.h"
 #include "replay_kernels.h"
@@ -135,7 +136,8 @@ struct morl_ctx {
     float* wt_online = nullptr;
     float* wt_target = nullptr;
     int64_t wt_count = 0;
-    int64_t offWt[MORL_MAX_LAYERS];
+    int64_t offWt[MORL_MAX_LAYERS];          // Wt_l [round_up(in, 64)][ldn] (zero rows / columns beyond [in][out])
+    int64_t offWb[MORL_MAX_LAYERS];          // row-padded copy of W_l for the backward chain (out % 64 != 0), or -1
     int ldn[MORL_MAX_LAYERS];
     int multi_tm = 64;       // row tile of the three-forward-passes launch (64: 2 workgroups / CU, 32: 3 / CU)
     int dw_mode = 1;         // weight-gradient engine: 0 wave-level tiles (dw_wave.h), 1 double-buffered LDS tiles,
@@ -156,6 +158,9 @@ struct morl_ctx {
     const float* wt_online_src = nullptr;   // parameters wt_online was transposed from by this step's morl_envelope_slabs
                                          // (cleared by every optimiser step of the library)
     size_t ev_used = 0;
+    int chain_gen = 2;       // 2: M-major persistent chain (mlp_chain2.h); 1: round-1 kernels (mlp_chain.h), kept for A/B runs
+    int chain_sched = 1;     // mlp_chain2: instruction interleave pinned with sched_group_barrier (0: hipcc's own schedule)
+    bool gen2_ok = false;    // architecture fits mlp_chain2 (narrow steps contract over a multiple of 4)
     int fused_tm = 0;        // 0: pick the row tile per launch (>= 2 workgroups per CU when possible), else 64 / 32
     int num_cus = 256;
 };
@@ -265,15 +270,30 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     for (int l = 0; l < c->L; ++l) {
         c->ldn[l] = round_up(net->dims[l + 1], 4);
         c->offWt[l] = c->wt_count;
-        c->wt_count += (int64_t)net->dims[l] * c->ldn[l];
+        c->wt_count += (int64_t)round_up(net->dims[l], 64) * c->ldn[l];
         if (net->dims[l] > CH_MAXW || net->dims[l + 1] > CH_MAXW) c->fused_ok = false;
         if (l >= 1 && (net->dims[l] & 3)) c->fused_ok = false;   // 8-byte operand / output pairs need even strides
+    }
+    for (int l = 0; l < c->L; ++l) {
+        c->offWb[l] = -1;
+        if (l >= 1 && (net->dims[l + 1] & 63)) {
+            c->offWb[l] = c->wt_count;
+            c->wt_count += (int64_t)round_up(net->dims[l + 1], 64) * net->dims[l];
+        }
     }
     if (net->dims[c->L] > 32 && (net->dims[c->L] & 3)) c->fused_ok = false;
     for (int l = 0; l < c->L; ++l) {
         if (net->dims[l + 1] <= 32 && (net->dims[l] & 1)) c->fused_ok = false;           // forward narrow step: K = dims[l]
         if (l >= 1 && net->dims[l] <= 32 && (net->dims[l + 1] & 1)) c->fused_ok = false;  // backward narrow step: K = dims[l+1]
     }
+    c->gen2_ok = c->fused_ok;
+    for (int l = 0; l < c->L; ++l) {
+        if (net->dims[l + 1] <= 32 && (net->dims[l] & 3)) c->gen2_ok = false;            // forward narrow step: K = dims[l]
+        if (l >= 1 && net->dims[l] <= 32 && (net->dims[l + 1] & 3)) c->gen2_ok = false;   // backward narrow step: K = dims[l+1]
+    }
+    if (c->ld0 & 3) c->gen2_ok = false;
+    if (const char* e = getenv("MORL_CHAIN_GEN")) c->chain_gen = (atoi(e) == 1) ? 1 : 2;
+    if (const char* e = getenv("MORL_CHAIN_SCHED")) c->chain_sched = atoi(e) ? 1 : 0;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -363,28 +383,81 @@ static int build_input(const float* obs, const float* weights, float* x0, int B,
 // ---- layer-fused path --------------------------------------------------------------------------
 static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipStream_t s, const float* params2 = nullptr,
                               float* wt2 = nullptr) {
-    TransposeArgs t{};
-    t.n = c->L;
-    long long e = 0;
+    ShadowArgs t{};
+    int tiles = 0, n = 0;
     for (int l = 0; l < c->L; ++l) {
-        t.src_off[l] = c->offW[l];
-        t.dst_off[l] = c->offWt[l];
-        t.K[l] = c->net.dims[l];
-        t.N[l] = c->net.dims[l + 1];
-        t.ldn[l] = c->ldn[l];
-        t.elem_start[l] = e;
-        e += (long long)t.K[l] * t.ldn[l];
+        ShadowJob& j = t.job[n++];
+        j.src_off = c->offW[l];
+        j.dst_off = c->offWt[l];
+        j.rows_src = c->net.dims[l + 1];
+        j.cols_src = c->net.dims[l];
+        j.dst_rows = round_up(c->net.dims[l], 64);
+        j.dst_ld = c->ldn[l];
+        j.mode = 0;
+        j.tiles_c = (j.dst_ld + 63) / 64;
+        j.tile_start = tiles;
+        tiles += (j.dst_rows / 64) * j.tiles_c;
     }
-    t.elem_start[c->L] = e;
-    hipLaunchKernelGGL(transpose_params_kernel, dim3(stream_grid(e, 256), params2 ? 2 : 1), dim3(256), 0, s, params, wt,
-                       params2, wt2, t);
-    LAUNCH_CHECK("transpose_params");
+    for (int l = 1; l < c->L; ++l) {
+        if (c->offWb[l] < 0) continue;
+        ShadowJob& j = t.job[n++];
+        j.src_off = c->offW[l];
+        j.dst_off = c->offWb[l];
+        j.rows_src = c->net.dims[l + 1];
+        j.cols_src = c->net.dims[l];
+        j.dst_rows = round_up(c->net.dims[l + 1], 64);
+        j.dst_ld = c->net.dims[l];
+        j.mode = 1;
+        j.tiles_c = (j.dst_ld + 63) / 64;
+        j.tile_start = tiles;
+        tiles += (j.dst_rows / 64) * j.tiles_c;
+    }
+    t.n = n;
+    t.tiles = tiles;
+    hipLaunchKernelGGL(shadow_weights_kernel, dim3(tiles, params2 ? 2 : 1), dim3(256), 0, s, params, wt, params2, wt2, t);
+    LAUNCH_CHECK("shadow_weights");
+    return MORL_OK;
+}
+
+// ---- second-generation chain (mlp_chain2.h): one persistent launch of 2 workgroups per CU over all units --------------
+static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s) {
+    Chain2Multi m{};
+    m.n = n;
+    int units = 0;
+    for (int q = 0; q < n; ++q) { m.p[q] = chains[q]; m.unit_start[q] = units; units += (chains[q].rows + 63) / 64; }
+    for (int q = n; q <= CH_MAX_MULTI; ++q) m.unit_start[q] = units;
+    int S = 2 * c->num_cus;
+    if (const char* e = getenv("MORL_CHAIN_SLOTS")) S = std::max(1, atoi(e));   // (tuning)
+    // small jobs: no more slots than half units, so that every slot has work
+    S = std::max(1, std::min(S, 2 * units));
+    m.full_rounds = units / S;
+    m.tail_base = m.full_rounds * S;
+    m.tail_units = units - m.tail_base;
+    m.tail_halves = (2 * m.tail_units <= S) ? 1 : 0;
+    if (c->fused_tm == 64) m.tail_halves = 0;
+    size_t slot = 0;
+    if (c->timing) {
+        if (c->ev_used == c->ev_start.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            c->ev_start.push_back(e0);
+            c->ev_stop.push_back(e1);
+        }
+        slot = c->ev_used++;
+        HIP_TRY(hipEventRecord(c->ev_start[slot], s));
+    }
+    if (c->chain_sched) hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
+    else hipLaunchKernelGGL(mlp_chain2_kernel<0>, dim3(S), dim3(CH_THREADS), 0, s, m);
+    LAUNCH_CHECK("mlp_chain2");
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev_stop[slot], s));
     return MORL_OK;
 }
 
 // Row tile: 64 rows per workgroup amortises the weight stream best, 32 rows doubles the workgroup count; pick 32
 // whenever 64 would leave fewer than two workgroups per CU (their epilogues / barriers then overlap).
 static int launch_chain(morl_ctx* c, const ChainArgs& a, hipStream_t s) {
+    if (c->chain_gen == 2 && c->gen2_ok) return chain2_launch(c, &a, 1, s);
     int tm = c->fused_tm;
     if (tm == 0) tm = ((a.rows + 63) / 64 >= 2 * c->num_cus) ? 64 : 32;
     size_t slot = 0;
@@ -414,6 +487,8 @@ static ChainArgs make_forward_chain(morl_ctx* c, const float* params, const floa
     a.n_steps = c->L;
     a.rows = rows;
     a.in_mode = 0;
+    a.fast = 1;
+    if (c->chain_gen == 2 && c->gen2_ok) emit_bits = true;   // mlp_chain2's backward takes its ReLU masks as bits only
     a.obs = obs; a.weights = weights;
     a.B = B; a.W = W; a.D = c->net.obs_dim; a.R = c->net.reward_dim; a.row_order = row_order;
     for (int l = 0; l < c->L; ++l) {
@@ -424,7 +499,9 @@ static ChainArgs make_forward_chain(morl_ctx* c, const float* params, const floa
         st.Bt = params + c->offW[l];       // nn.Linear layout [out][in] = N-major
         st.ldbt = c->net.dims[l];
         st.K = c->net.dims[l];
+        st.kpad = round_up(st.K, 64);
         st.N = c->net.dims[l + 1];
+        if (st.N > 32 && st.ldb != 256) a.fast = 0;
         st.bias = params + c->offB[l];
         st.relu = last ? 0 : 1;
         if (last) { st.out = q_out; st.ldout = ldq_out; }
@@ -450,6 +527,7 @@ static int chain_forward_x3(morl_ctx* c, const ChainArgs& a0, const ChainArgs& a
 }
 // up to CH_MAX_MULTI forward passes in one launch
 static int chain_forward_multi(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s) {
+    if (c->chain_gen == 2 && c->gen2_ok) return chain2_launch(c, chains, n, s);
     ChainMulti m{};
     m.n = n;
     long long rows_all = 0;
@@ -488,11 +566,14 @@ static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_
     a.n_steps = L - 1;
     a.rows = rows;
     a.in_mode = 1;
+    a.fast = 1;
     a.src = c->dq; a.ldsrc = c->ldq; a.K0 = c->net.dims[L];
     for (int l = L - 1, k = 0; l >= 1; --l, ++k) {
         ChainStep& st = a.step[k];
         st.Bmat = params + c->offW[l];
         st.ldb = c->net.dims[l];
+        if (c->offWb[l] >= 0) { st.Bmat = c->wt_online + c->offWb[l]; st.kpad = round_up(c->net.dims[l + 1], 64); }
+        if (c->net.dims[l] > 32 && st.ldb != 256) a.fast = 0;
         st.Bt = c->wt_online + c->offWt[l];   // [in][ldn(out)] = N-major for the backward contraction
         st.ldbt = c->ldn[l];
         st.K = c->net.dims[l + 1];
@@ -673,6 +754,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         c->bits_valid = false;
         if (c->use_fused) {
             if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights_i, B, WI, 1, rows, true, c->qm, c->ldq, s))) return rc;
+            c->bits_valid = (c->chain_gen == 2 && c->gen2_ok);   // (the second-generation forward always emits the sign bits)
         } else {
             if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
         }

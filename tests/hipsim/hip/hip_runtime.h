@@ -194,6 +194,17 @@ static inline hipsim_v2u __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rs
     return v;
 }
 
+
+typedef unsigned int hipsim_v4u __attribute__((ext_vector_type(4)));
+static inline void __builtin_amdgcn_raw_buffer_store_b128(hipsim_v4u v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    const long long off = (long long)(unsigned)voffset + soffset;
+    for (int d = 0; d < 4; ++d)
+        if (off + 4 * d + 4 <= r.num_records) { unsigned x = v[d]; std::memcpy((char*)r.base + off + 4 * d, &x, 4); }
+}
+// scheduling hints have no meaning on the host
+#define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+
 // ---- math that hipcc provides as builtins -------------------------------------------------------
 // Compile the emulated build with -ffp-contract=off so these stay separately rounded.
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
