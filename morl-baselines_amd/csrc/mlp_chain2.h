@@ -33,8 +33,6 @@ struct C2BSet {
 struct C2ASet {
     float4 a[2];
 };
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int c2_u32x4 __attribute__((ext_vector_type(4)));
 
 // wide step: lane (i, h) of wave w loads B[k][64w + 2i .. +1]; v[j] <-> k = k0 + 8*(j >> 2) + 4h + (j & 3)
 struct C2WideDesc {
@@ -198,8 +196,14 @@ __device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& 
         for (; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cd, piece);
 }
 
-template <int TM, int SCHED, bool FAST>
-__device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, float* sAct) {
+// PROF (development probes only, tools/probes/chain2_probe.hip): wave 0 stamps s_memtime at the phase boundaries of the job
+#define C2_TICK() if (PROF) { if (n_tick < 24) ticks[n_tick] = clock64(); ++n_tick; }
+
+template <int TM, int SCHED, bool FAST, bool PROF = false>
+__device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, float* sAct, long long* prof_out = nullptr) {
+    long long ticks[24];
+    int n_tick = 0;
+    C2_TICK()
     constexpr int MT = TM / 32;                       // 32-row MFMA tiles per wave
     constexpr int N_PIECES = TM / 4;                  // 16-byte copy pieces per thread and tile (256 floats per row)
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_id();
@@ -254,6 +258,7 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
         }
     }
     __syncthreads();
+    C2_TICK()
 
     bool do_copy = false;                // the tile now in sAct must also be written to HBM (deferred store) ...
     C2CopyDst cdst = c2_copy_dst(sAct, 0, 0, 0, 0, tid);   // ... to here
@@ -282,7 +287,9 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
             if (do_copy) c2_wide_loop<TM, true, SCHED, FAST>(acc, bx, by, sAct, pa, dcur, dnext, nxt_wide, n_pairs, cdst);
             else c2_wide_loop<TM, false, SCHED, FAST>(acc, bx, by, sAct, pa, dcur, dnext, nxt_wide, n_pairs, cdst);
             dcur = dnext;
+            C2_TICK()
             __syncthreads();     // every wave is past its last read of sAct (MFMA operands and copy pieces)
+            C2_TICK()
 
             // ---- epilogue ---------------------------------------------------------------------------------
             const bool col_ok = colw < N;
@@ -411,12 +418,17 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
             }
             do_copy = false;
         }
+        C2_TICK()
         __syncthreads();    // sAct of the next step (or of the trailing copy) complete before anyone reads it
     }
     // a wide last step whose output goes to HBM (the backward chain's g_0): nothing is left to hide the copy behind
     if (do_copy)
         for (int piece = 0; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cdst, piece);
+    C2_TICK()
+    if (PROF && prof_out != nullptr && tid == 0)
+        for (int q = 0; q < 24; ++q) prof_out[q] = (q < n_tick) ? ticks[q] : 0;
 }
+#undef C2_TICK
 
 // ---- persistent launch over up to CH_MAX_MULTI chains ------------------------------------------------------------------
 // Units are 64-row tiles, numbered chain after chain.  Workgroup b (of S = gridDim.x) takes unit r*S + b in each of
@@ -430,7 +442,12 @@ struct Chain2Multi {
     int full_rounds;
     int tail_base, tail_units;
     int tail_halves;                    // 1: 32-row half tiles
+    int stagger;                        // which workgroups run their tail job first: 0 none, 1 the second half of the grid,
+                                        // 2 odd XCD-local index, 3 every second arrival on its CU (ticket from cu_tickets)
+    unsigned int* cu_tickets;           // [C2_CU_SLOTS] monotonically increasing arrival counters (stagger 3)
+    long long* prof;                    // probes only: [gridDim.x][2][24] phase stamps
 };
+constexpr int C2_CU_SLOTS = 8192;
 
 __device__ __forceinline__ int c2_find_chain(const Chain2Multi& m, int unit) {
     int q = 0;
@@ -438,12 +455,27 @@ __device__ __forceinline__ int c2_find_chain(const Chain2Multi& m, int unit) {
     return q;
 }
 
-template <int SCHED>
-__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain2_kernel(Chain2Multi m) {
-    // (+8: the last group's look-ahead operand read of the last row runs 4 floats past the tile; the values are unused)
-    __shared__ __attribute__((aligned(16))) float sAct[C2_TM * C2_LDK + 8];
+// identity of the CU this workgroup runs on (XCC, shader engine / array, CU): only used to pair up co-resident workgroups
+__device__ __forceinline__ unsigned c2_cu_key() {
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_REG_HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));     // HW_REG_XCC_ID[3:0]
+    return ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
+}
+
+template <int SCHED, bool PROF>
+__device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, float* sAct) {
     const int b = (int)blockIdx.x, S = (int)gridDim.x;
-    const bool tail_first = b >= (S >> 1);
+    bool tail_first = false;
+    if (m.stagger == 1) tail_first = b >= (S >> 1);
+    else if (m.stagger == 2) tail_first = ((b >> 3) & 1) != 0;
+    else if (m.stagger == 3) {
+        // the two workgroups of a CU take opposite job orders whatever the dispatcher's placement: every second arrival on a
+        // CU (a ticket from a counter that only ever increments -- no reset between launches) runs its tail job first
+        __shared__ unsigned s_ticket;
+        if (threadIdx.x == 0) s_ticket = atomicAdd(m.cu_tickets + (c2_cu_key() & (C2_CU_SLOTS - 1)), 1u);
+        __syncthreads();
+        tail_first = (s_ticket & 1u) != 0;
+    }
     // jobs of this workgroup: `full_rounds` whole units and at most one tail job (every condition below is workgroup-uniform)
     for (int j = 0; j <= m.full_rounds; ++j) {
         const bool is_tail = tail_first ? (j == 0) : (j == m.full_rounds);
@@ -462,21 +494,29 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain2_kernel(Chain2Multi m
         }
         const int q = c2_find_chain(m, unit);
         const int row0 = (unit - m.unit_start[q]) * 64 + (half > 0 ? 32 : 0);
+        long long* pout = (PROF && m.prof != nullptr) ? m.prof + ((size_t)b * 2 + (j > 0 ? 1 : 0)) * 24 : nullptr;
         if (m.p[q].fast) {
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, true>(m.p[q], row0, sAct);
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, true, PROF>(m.p[q], row0, sAct, pout);
             } else {
-                mlp_chain2_body<64, SCHED, true>(m.p[q], row0, sAct);
+                mlp_chain2_body<64, SCHED, true, PROF>(m.p[q], row0, sAct, pout);
             }
         } else {
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, false>(m.p[q], row0, sAct);
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, false, PROF>(m.p[q], row0, sAct, pout);
             } else {
-                mlp_chain2_body<64, SCHED, false>(m.p[q], row0, sAct);
+                mlp_chain2_body<64, SCHED, false, PROF>(m.p[q], row0, sAct, pout);
             }
         }
         __syncthreads();     // the tile buffer is free for the next job
     }
+}
+
+template <int SCHED>
+__global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain2_kernel(Chain2Multi m) {
+    // (+8: the last group's look-ahead operand read of the last row runs 4 floats past the tile; the values are unused)
+    __shared__ __attribute__((aligned(16))) float sAct[C2_TM * C2_LDK + 8];
+    mlp_chain2_persistent<SCHED, false>(m, sAct);
 }
 
 // ---- K-major shadow copies of the weights ----------------------------------------------------------------------------------

@@ -6,6 +6,8 @@
 namespace morl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int c2_u32x4 __attribute__((ext_vector_type(4)));   // payload type of the 16-byte raw buffer builtins
 
 constexpr int kWave = 64;
 

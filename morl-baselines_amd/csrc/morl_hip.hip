@@ -20,6 +20,7 @@
 #include "mlp_chain.h"
 #include "mlp_chain2.h"
 #include "dw_wave.h"
+#include "dw_tiles.h"
 #include "optim_kernels.h"
 #include "replay_kernels.h"
 #include "pareto_kernels.h"
@@ -140,7 +141,8 @@ struct morl_ctx {
     int64_t offWb[MORL_MAX_LAYERS];          // row-padded copy of W_l for the backward chain (out % 64 != 0), or -1
     int ldn[MORL_MAX_LAYERS];
     int multi_tm = 64;       // row tile of the three-forward-passes launch (64: 2 workgroups / CU, 32: 3 / CU)
-    int dw_mode = 1;         // weight-gradient engine: 0 wave-level tiles (dw_wave.h), 1 double-buffered LDS tiles,
+    int dw_mode = 3;         // weight-gradient engine: 3 balanced wave-layout tiles (dw_tiles.h); older engines kept for A/B
+                             // runs: 0 wave-level tiles (dw_wave.h), 1 double-buffered LDS tiles,
                              // 2 single-buffered LDS tiles (the per-layer engine's)
     bool dw_wave_ok = false; // wave-level dW kernel usable (all operand row strides even)
     int dw_wave_tiles = 0;
@@ -159,6 +161,8 @@ struct morl_ctx {
                                          // (cleared by every optimiser step of the library)
     size_t ev_used = 0;
     int chain_gen = 2;       // 2: M-major persistent chain (mlp_chain2.h); 1: round-1 kernels (mlp_chain.h), kept for A/B runs
+    int chain_stagger = 3;   // mlp_chain2: job-order staggering of co-resident workgroups (Chain2Multi::stagger)
+    unsigned int* cu_tickets = nullptr;
     int chain_sched = 1;     // mlp_chain2: instruction interleave pinned with sched_group_barrier (0: hipcc's own schedule)
     bool gen2_ok = false;    // architecture fits mlp_chain2 (narrow steps contract over a multiple of 4)
     int fused_tm = 0;        // 0: pick the row tile per launch (>= 2 workgroups per CU when possible), else 64 / 32
@@ -206,6 +210,7 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     for (int l = 0; l < MORL_MAX_LAYERS; ++l)
         if (c->relu_bits[l]) (void)hipFree(c->relu_bits[l]);
     if (c->zeros) (void)hipFree(c->zeros);
+    if (c->cu_tickets) (void)hipFree(c->cu_tickets);
     if (c->wt_online) (void)hipFree(c->wt_online);
     if (c->wt_target) (void)hipFree(c->wt_target);
     delete c;
@@ -294,6 +299,7 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     if (c->ld0 & 3) c->gen2_ok = false;
     if (const char* e = getenv("MORL_CHAIN_GEN")) c->chain_gen = (atoi(e) == 1) ? 1 : 2;
     if (const char* e = getenv("MORL_CHAIN_SCHED")) c->chain_sched = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("MORL_CHAIN_STAGGER")) c->chain_stagger = std::max(0, std::min(3, atoi(e)));
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -308,6 +314,8 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     }
     for (int l = 1; l < c->L; ++l) ALLOC(relu_bits[l], ((size_t)c->max_rows + 63) / 64 * CH_THREADS);
     ALLOC(zeros, 16);
+    ALLOC(cu_tickets, C2_CU_SLOTS);
+    if (hipMemsetAsync(c->cu_tickets, 0, C2_CU_SLOTS * sizeof(unsigned int), nullptr) != hipSuccess) { morl_ctx_destroy(c); return fail(MORL_ERR_HIP, "zero-fill failed"); }
     {
         hipError_t ez = hipMemsetAsync(c->zeros, 0, 16 * sizeof(float), nullptr);
         if (ez == hipSuccess) ez = hipStreamSynchronize(nullptr);
@@ -435,6 +443,8 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
     m.tail_units = units - m.tail_base;
     m.tail_halves = (2 * m.tail_units <= S) ? 1 : 0;
     if (c->fused_tm == 64) m.tail_halves = 0;
+    m.stagger = c->chain_stagger;
+    m.cu_tickets = c->cu_tickets;
     size_t slot = 0;
     if (c->timing) {
         if (c->ev_used == c->ev_start.size()) {
@@ -599,7 +609,7 @@ extern "C" int morl_ctx_set_dw_mode(morl_ctx* c, int mode) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     // low decimal digit: dW engine (0, 1, 2); tens digit: row tile of the three-pass forward launch (0: 64, 1: 32)
     const int dw = mode % 10, mt = mode / 10;
-    if (dw < 0 || dw > 2 || mt < 0 || mt > 1) return fail(MORL_ERR_ARG, "bad tuning mode %d", mode);
+    if (dw < 0 || dw > 3 || mt < 0 || mt > 1) return fail(MORL_ERR_ARG, "bad tuning mode %d", mode);
     c->dw_mode = dw;
     c->multi_tm = mt ? 32 : 64;
     return MORL_OK;
@@ -806,7 +816,66 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         }
     // all dW / db of the step in one split-K launch
     int splits;
-    if (c->dw_wave_ok && c->use_fused && c->dw_mode == 0) {
+    Dw2Ranges ranges{};
+    bool dw2_ok = (c->ld0 & 3) == 0 && (c->ldq & 3) == 0;      // dw_tiles.h streams 16-byte pieces of 16-byte aligned rows
+    for (int l = 1; l < L; ++l) dw2_ok = dw2_ok && (n.dims[l] & 3) == 0;
+    if (c->dw_mode == 3 && dw2_ok) {
+        // dw_tiles.h: per-problem wave layout; a layout with fewer MFMAs per contraction step gets longer row slices so that
+        // every workgroup carries the same matrix-core work, and the whole launch is one round of ~2 workgroups per CU
+        Dw2Args a{};
+        a.n = L;
+        a.rows = rows;
+        a.slab_stride = c->P;
+        static const int lay_bm[3] = {128, 128, 32}, lay_bn[3] = {128, 64, 128}, lay_cost[3] = {4, 2, 1};
+        double unit_tiles = 0.0;            // tiles in units of the 2x2 layout's cost
+        for (int l = 0; l < L; ++l) {
+            Dw2Problem& q = a.p[l];
+            q.G = c->g[l];
+            q.ldg = (l == L - 1) ? c->ldq : n.dims[l + 1];
+            q.H = (l == 0) ? c->x0m : c->h[l];
+            q.ldh = (l == 0) ? c->ld0 : n.dims[l];
+            q.C = c->slabs + c->offW[l];
+            q.ldc = n.dims[l];
+            q.colsum = c->slabs + c->offB[l];
+            q.M = n.dims[l + 1]; q.N = n.dims[l];
+            q.layout = (q.M <= 32) ? 2 : (q.N <= 64) ? 1 : 0;
+            q.tiles_m = (q.M + lay_bm[q.layout] - 1) / lay_bm[q.layout];
+            q.tiles_n = (q.N + lay_bn[q.layout] - 1) / lay_bn[q.layout];
+            q.gcols = q.ldg;                 // (pad columns of dq / x0 are written as zeros by their producers)
+            q.hcols = q.ldh;
+            q.c_vec2 = ((((uintptr_t)q.C) & 7u) == 0 && (q.ldc & 1) == 0 && (c->P & 1) == 0) ? 1 : 0;
+            unit_tiles += (double)q.tiles_m * q.tiles_n * lay_cost[q.layout] / 4.0;
+        }
+        int target = 2 * c->num_cus;
+        if (const char* e = getenv("MORL_DW_JOBS")) target = std::max(1, atoi(e));     // (tuning)
+        // base slice of the 2x2 layout: unit_tiles * rows / base ~ target jobs, a multiple of the 32-row chunk
+        int base = round_up(std::max(1, (int)std::ceil(unit_tiles * rows / (double)target)), DW2_BK);
+        for (;;) {      // the split count of every problem must fit the slab buffer
+            bool ok = true;
+            for (int l = 0; l < L; ++l) {
+                const int kps = base * 4 / lay_cost[a.p[l].layout];
+                if ((rows + kps - 1) / kps > c->max_splits) ok = false;
+            }
+            if (ok) break;
+            base += DW2_BK;
+        }
+        int jobs = 0, r = 0;
+        splits = 0;
+        for (int l = 0; l < L; ++l) {
+            Dw2Problem& q = a.p[l];
+            q.k_per_split = base * 4 / lay_cost[q.layout];
+            q.splits = (rows + q.k_per_split - 1) / q.k_per_split;
+            q.job_start = jobs;
+            jobs += q.splits * q.tiles_m * q.tiles_n;
+            splits = std::max(splits, q.splits);
+            ranges.end[r] = c->offB[l];                                   ranges.splits[r++] = q.splits;   // W_l
+            ranges.end[r] = c->offB[l] + n.dims[l + 1];                   ranges.splits[r++] = q.splits;   // b_l
+        }
+        ranges.n = r;
+        a.jobs = jobs;
+        hipLaunchKernelGGL(dw_tiles_kernel, dim3(jobs), dim3(DW2_THREADS), 0, s, a);
+        LAUNCH_CHECK("dw_tiles");
+    } else if (c->dw_wave_ok && c->use_fused && c->dw_mode == 0) {
         // wave-level tiles (dw_wave.h): aim at one wave per SIMD over the whole chip
         splits = std::max(1, std::min(c->max_splits, (4 * c->num_cus + c->dw_wave_tiles / 2) / c->dw_wave_tiles));
         int kps = round_up((rows + splits - 1) / splits, DW_CHUNK);
@@ -835,7 +904,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         hipLaunchKernelGGL(dw_wave_kernel, dim3(t, splits), dim3(64), 0, s, a);
         LAUNCH_CHECK("dw_wave");
     } else {
-    const bool db = (c->dw_mode == 1);
+    const bool db = (c->dw_mode == 1 || c->dw_mode == 3);
     // double-buffered tiles run two workgroups per CU: twice as many, half as long row slices
     splits = std::max(1, std::min(c->max_splits, ((db ? 2 : 1) * c->num_cus + c->dw_tiles - 1) / c->dw_tiles));
     if (const char* e = getenv("MORL_DW_SPLITS")) splits = std::max(1, std::min(c->max_splits, atoi(e)));   // (tuning)
@@ -875,9 +944,14 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     const int nblk = std::min(OPT_MAX_BLOCKS, stream_grid(c->P, OPT_THREADS));
     {
         const float lam = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
-        hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)c->slabs, splits,
-                           (long long)c->P, grads, (long long)c->P, c->sumsq_part, (const double*)c->loss_part, B * td_groups,
-                           1.0 / ((double)rows_total * R), 1.0 / (double)rows_total, lam, out->loss);
+        if (ranges.n > 0)
+            hipLaunchKernelGGL(grad_reduce_ranges_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)c->slabs, ranges,
+                               (long long)c->P, grads, (long long)c->P, c->sumsq_part, (const double*)c->loss_part,
+                               B * td_groups, 1.0 / ((double)rows_total * R), 1.0 / (double)rows_total, lam, out->loss);
+        else
+            hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)c->slabs, splits,
+                               (long long)c->P, grads, (long long)c->P, c->sumsq_part, (const double*)c->loss_part,
+                               B * td_groups, 1.0 / ((double)rows_total * R), 1.0 / (double)rows_total, lam, out->loss);
         LAUNCH_CHECK("grad_reduce");
     }
     if (out->q_values) {

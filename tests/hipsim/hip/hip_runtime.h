@@ -196,11 +196,20 @@ static inline hipsim_v2u __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rs
 
 
 typedef unsigned int hipsim_v4u __attribute__((ext_vector_type(4)));
+static inline hipsim_v4u __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    hipsim_v4u v = {0u, 0u, 0u, 0u};
+    const long long off = (long long)(unsigned)voffset + soffset;
+    for (int d = 0; d < 4; ++d)
+        if (off + 4 * d + 4 <= r.num_records) { unsigned x; std::memcpy(&x, r.base + off + 4 * d, 4); v[d] = x; }
+    return v;
+}
 static inline void __builtin_amdgcn_raw_buffer_store_b128(hipsim_v4u v, __amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
     const long long off = (long long)(unsigned)voffset + soffset;
     for (int d = 0; d < 4; ++d)
         if (off + 4 * d + 4 <= r.num_records) { unsigned x = v[d]; std::memcpy((char*)r.base + off + 4 * d, &x, 4); }
 }
+static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }   // hardware identity registers: one CU on the host
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 // scheduling hints have no meaning on the host
 #define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
