@@ -31,7 +31,7 @@ extern "C" {
 
 #define MORL_MAX_LAYERS 8   /* linear layers per network */
 #define MORL_MAX_OBJ 8      /* reward dimension R */
-#define MORL_ABI_VERSION 3
+#define MORL_ABI_VERSION 4
 
 typedef enum morl_status {
     MORL_OK = 0,
@@ -119,6 +119,20 @@ int64_t morl_param_count(const morl_net_desc* net);
 int morl_gather_batch(const float* records, int record_floats, int64_t capacity, const int64_t* idx, int B,
                       int D, int R, int action_dim, float* obs, float* next_obs, float* rewards, float* dones,
                       float* actions_f, int32_t* actions_i, void* stream);
+
+/* ---- one training batch in one launch: PrioritizedReplayBuffer.sample (common/prioritized_buffer.py:149-185: SumTree.sample
+ * :30-54 + the gathers) or ReplayBuffer.sample (common/buffer.py:68-96) ------------------------------------------------------
+ * tree != NULL: idx[b] = sum-tree descent with u01[b] (float64, reference order); tree == NULL: idx[b] = idx_in[b].
+ * idx_out (device int64 [B], may be NULL) receives the indices; the record gather is that of morl_gather_batch.
+ * u01 / idx_in / aux_src may point to PINNED HOST memory mapped into the device address space (see morl_host_device_pointer):
+ * they are read inside the kernel instead of by separate copy launches.  aux_src != NULL: aux_floats floats are also moved
+ * aux_src -> aux_dst (device) -- the step's sampled weight vectors ride along (envelope.py:281-283). */
+int morl_sample_gather(const double* tree, int n_levels, const double* u01, const int64_t* idx_in, const float* records,
+                       int record_floats, int64_t capacity, int B, int D, int R, int action_dim, float* obs,
+                       float* next_obs, float* rewards, float* dones, float* actions_f, int32_t* actions_i,
+                       int64_t* idx_out, const float* aux_src, float* aux_dst, int aux_floats, void* stream);
+/* device-side address of a pinned (page-locked, mapped) host allocation; MORL_ERR_HIP if the memory is not mapped */
+int morl_host_device_pointer(void* host_ptr, void** device_ptr);
 /* Same gather for records with arbitrary extra fields (CAPQL ReplayMemory.sample, multi_policy/capql/capql.py:56-63,
  * whose transitions carry the episode's weight vector): outs[f][b][0..widths[f]) = records[idx[b]][offsets[f] ..).
  * offsets / widths / outs are HOST arrays of n_fields (<= 8) entries; outs[f] are device pointers. */
@@ -145,6 +159,12 @@ int morl_envelope_reduce(const float* qo, const float* qt, const float* weights,
  * Q(obs_n, sampled_w_j)).  target [n_rows][R]; pref / ac [n_rows] may be NULL. */
 int morl_envelope_reduce_rows(const float* qo, const float* qt, const float* row_weights, int n_rows, int W, int A,
                               int R, float* target, int32_t* pref, int32_t* ac, void* stream);
+
+/* ---- Envelope.max_action (envelope.py:389-402) for n (observation, weight) rows in ONE call: Q(obs_r, w_r) through the
+ * network, scalarisation w_r . Q[a] as the fma chain torch's unbatched einsum evaluates to, first arg-max over the actions.
+ * obs [n][D], w [n][R], actions_out int32 [n] (all device).  n <= max_batch * max_weights of the context. */
+int morl_envelope_greedy_actions(morl_ctx* ctx, const float* params, const float* obs, const float* w, int n,
+                                 int32_t* actions_out, void* stream);
 
 /* ---- one Envelope gradient step: envelope.py:269-334 -------------------------------------------
  * All arrays device.  params_online / grads / exp_avg / exp_avg_sq: flat [P]; params_target: flat [P]

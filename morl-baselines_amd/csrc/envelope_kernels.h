@@ -41,9 +41,11 @@ __global__ __launch_bounds__(256) void build_input_kernel(const float* __restric
 //   tq = r_b + ((1 - done_b) * gamma) * target                             (envelope.py:298)
 //   td = Q[i,b,action_b,:] - tq ; dQ = dLoss/dQ for MSE (+ homotopy term)  (envelope.py:300-313)
 //
-// The Qo[b] slab (W*A*R floats) and the weight vectors are staged in LDS once and shared by the W
-// rows of this transition; each wave owns rows i = wave, wave+4, ...; the 64 lanes split the W*A
-// candidates and reduce (value, index) with wave shuffles, lowest index winning ties.
+// The Qo[b] slab (W*A*R floats) and the weight vectors are staged in LDS once and shared by the W rows of this
+// transition.  Lane <-> TD row i; the waves of the workgroup split the (j, a) candidates and read each candidate's R values
+// as LDS broadcasts, so the arg-max loop has no cross-lane traffic at all; the per-wave partial winners of a row are merged
+// through LDS in candidate order, lowest index winning ties (a shuffle / ballot reduction over the candidates was measured
+// slower here: with 64 rows per transition the lanes are better spent on rows).
 // diag_only restricts j to i (DDQN target, envelope.py:442-463).
 // HBM-bound and tiny: reads 2*B*W*A*R*4 bytes once.
 // ----------------------------------------------------------------------------------------------
@@ -75,6 +77,9 @@ struct EnvelopeTdArgs {
     float gamma;
     float c_mse;            // (1 - lambda) * 2 / (W*B*R)
     float c_aux;            // lambda * 2 / (W*B)
+    int fma_scal;           // 1: scalarise with an fma chain  fma(w_r, q_r, ...fma(w_1, q_1, w_0 * q_0))  -- what torch's unbatched
+                            // einsum("r,bar->ba") of Envelope.max_action (envelope.py:389-402) evaluates to -- instead of
+                            // separately rounded products and sums (the batched einsum of the TD target)
     int part_floats;        // 0: qo / qt are [B][W][A][R].  > 0: all-gathered layout, the slab of transition b is made of
     long long part_stride;  //    W*A*R / part_floats pieces of part_floats floats, piece g at  g * part_stride + b * part_floats
 };
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
                 float s = __fmul_rn(wi[0], q[0]);
 #pragma unroll
                 for (int r = 1; r < MORL_MAX_OBJ; ++r)
-                    if (r < R) s = __fadd_rn(s, __fmul_rn(wi[r], q[r]));
+                    if (r < R) s = p.fma_scal ? fmaf(q[r], wi[r], s) : __fadd_rn(s, __fmul_rn(wi[r], q[r]));
                 sv[u] = s;
             }
 #pragma unroll
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
             float s = __fmul_rn(wi[0], q[0]);
 #pragma unroll
             for (int r = 1; r < MORL_MAX_OBJ; ++r)
-                if (r < R) s = __fadd_rn(s, __fmul_rn(wi[r], q[r]));
+                if (r < R) s = p.fma_scal ? fmaf(q[r], wi[r], s) : __fadd_rn(s, __fmul_rn(wi[r], q[r]));
             if (s > best || best_c == 0x7fffffff) { best = s; best_c = c_off + c; }
         }
         if (live) { s_pv[wave][i - ib] = best; s_pc[wave][i - ib] = best_c; }

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain2_kernel(Chain2Multi m
 //             forward chain streams (and, read N-major, the narrow-step operand of the backward chain)
 // job mode 1: W_l [K = out][ld = in] -> the same rows followed by zero rows up to Kpad: the backward chain's operand when
 //             `out` is not a multiple of 64 (the Q head), so that its weight stream never relies on the range check
-// 64 x 64 tiles through LDS: global reads and writes are both coalesced (the round-1 kernel read with stride K: 13 MB
+// 32 x 32 tiles through LDS: global reads and writes are both coalesced (the round-1 kernel read with stride K: 13 MB
 // fetched to move 1.7 MB).  blockIdx.y = 0: params -> wt; 1: params2 -> wt2.
 struct ShadowJob {
     long long src_off, dst_off;
@@ -539,38 +539,43 @@ struct ShadowArgs {
     int n, tiles;
 };
 
+constexpr int SH_T = 32;     // tile edge: 32 x 32 tiles -> ~480 workgroups for both flagship networks, one load + one store round each
+
 __global__ __launch_bounds__(256) void shadow_weights_kernel(const float* __restrict__ params, float* __restrict__ wt,
                                                              const float* __restrict__ params2, float* __restrict__ wt2,
                                                              ShadowArgs a) {
-    __shared__ float tile[64 * 65];
+    __shared__ float tile[SH_T * (SH_T + 1)];
     if (blockIdx.y == 1) { params = params2; wt = wt2; }
-    const int tid = (int)threadIdx.x, fast = tid & 63, slow = tid >> 6;
+    const int tid = (int)threadIdx.x, fast = tid & (SH_T - 1), slow = tid / SH_T;     // slow in [0, 8)
     for (int t = (int)blockIdx.x; t < a.tiles; t += (int)gridDim.x) {
         int q = 0;
         while (q + 1 < a.n && t >= a.job[q + 1].tile_start) ++q;
         const ShadowJob& j = a.job[q];
         const int lt = t - j.tile_start;
-        const int r0 = (lt / j.tiles_c) * 64, c0 = (lt % j.tiles_c) * 64;   // destination tile origin
+        const int r0 = (lt / j.tiles_c) * SH_T, c0 = (lt % j.tiles_c) * SH_T;   // destination tile origin
         const float* src = params + j.src_off;
         float* dst = wt + j.dst_off;
         if (j.mode == 0) {
             // destination (k, n) <- source (n, k): read source rows n0 + nn along k, write destination rows k0 + kk along n
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int nn = slow + 4 * it, n = c0 + nn, k = r0 + fast;
-                tile[nn * 65 + fast] = (n < j.rows_src && k < j.cols_src) ? src[(size_t)n * j.cols_src + k] : 0.f;
+            float v[SH_T / 8];
+#pragma unroll
+            for (int it = 0; it < SH_T / 8; ++it) {
+                const int n = c0 + slow + 8 * it, k = r0 + fast;
+                v[it] = (n < j.rows_src && k < j.cols_src) ? src[(size_t)n * j.cols_src + k] : 0.f;
             }
+#pragma unroll
+            for (int it = 0; it < SH_T / 8; ++it) tile[(slow + 8 * it) * (SH_T + 1) + fast] = v[it];
             __syncthreads();
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int kk = slow + 4 * it, k = r0 + kk, n = c0 + fast;
-                if (k < j.dst_rows && n < j.dst_ld) dst[(size_t)k * j.dst_ld + n] = tile[fast * 65 + kk];
+#pragma unroll
+            for (int it = 0; it < SH_T / 8; ++it) {
+                const int kk = slow + 8 * it, k = r0 + kk, n = c0 + fast;
+                if (k < j.dst_rows && n < j.dst_ld) dst[(size_t)k * j.dst_ld + n] = tile[fast * (SH_T + 1) + kk];
             }
             __syncthreads();
         } else {
-#pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int r = r0 + slow + 4 * it, c = c0 + fast;
+#pragma unroll
+            for (int it = 0; it < SH_T / 8; ++it) {
+                const int r = r0 + slow + 8 * it, c = c0 + fast;
                 if (r < j.dst_rows && c < j.dst_ld)
                     dst[(size_t)r * j.dst_ld + c] = (r < j.rows_src && c < j.cols_src) ? src[(size_t)r * j.cols_src + c] : 0.f;
             }

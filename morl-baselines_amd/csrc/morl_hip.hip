@@ -402,9 +402,9 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
         j.dst_rows = round_up(c->net.dims[l], 64);
         j.dst_ld = c->ldn[l];
         j.mode = 0;
-        j.tiles_c = (j.dst_ld + 63) / 64;
+        j.tiles_c = (j.dst_ld + SH_T - 1) / SH_T;
         j.tile_start = tiles;
-        tiles += (j.dst_rows / 64) * j.tiles_c;
+        tiles += (j.dst_rows / SH_T) * j.tiles_c;
     }
     for (int l = 1; l < c->L; ++l) {
         if (c->offWb[l] < 0) continue;
@@ -416,9 +416,9 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
         j.dst_rows = round_up(c->net.dims[l + 1], 64);
         j.dst_ld = c->net.dims[l];
         j.mode = 1;
-        j.tiles_c = (j.dst_ld + 63) / 64;
+        j.tiles_c = (j.dst_ld + SH_T - 1) / SH_T;
         j.tile_start = tiles;
-        tiles += (j.dst_rows / 64) * j.tiles_c;
+        tiles += (j.dst_rows / SH_T) * j.tiles_c;
     }
     t.n = n;
     t.tiles = tiles;
@@ -674,6 +674,33 @@ extern "C" int morl_gather_batch(const float* records, int record_floats, int64_
     return MORL_OK;
 }
 
+extern "C" int morl_sample_gather(const double* tree, int n_levels, const double* u01, const int64_t* idx_in,
+                                  const float* records, int record_floats, int64_t capacity, int B, int D, int R,
+                                  int action_dim, float* obs, float* next_obs, float* rewards, float* dones, float* actions_f,
+                                  int32_t* actions_i, int64_t* idx_out, const float* aux_src, float* aux_dst, int aux_floats,
+                                  void* stream) {
+    if (!records || !obs || !next_obs || !rewards || !dones || (!actions_f && !actions_i)) return fail(MORL_ERR_ARG, "NULL array");
+    if (tree ? !u01 : !idx_in) return fail(MORL_ERR_ARG, "sample_gather: uniforms (with a tree) or indices (without) are required");
+    if (tree && (n_levels < 1 || n_levels > 40)) return fail(MORL_ERR_ARG, "bad n_levels");
+    if (B < 1 || D < 1 || R < 1 || action_dim < 1 || capacity < 1)
+        return fail(MORL_ERR_ARG, "bad sizes B=%d D=%d R=%d Ad=%d", B, D, R, action_dim);
+    if (record_floats != 2 * D + R + 1 + action_dim)
+        return fail(MORL_ERR_ARG, "record_floats=%d != 2*D+R+1+Ad=%d", record_floats, 2 * D + R + 1 + action_dim);
+    if (aux_src && (!aux_dst || aux_floats < 1)) return fail(MORL_ERR_ARG, "sample_gather: aux copy without destination / size");
+    const int blocks = std::min(1024, (B + 3) / 4);
+    hipLaunchKernelGGL(sample_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tree, n_levels, u01, idx_in, records,
+                       record_floats, (long long)capacity, B, D, R, action_dim, obs, next_obs, rewards, dones, actions_f, actions_i,
+                       idx_out, aux_src, aux_dst, aux_floats);
+    LAUNCH_CHECK("sample_gather");
+    return MORL_OK;
+}
+
+extern "C" int morl_host_device_pointer(void* host_ptr, void** device_ptr) {
+    if (!host_ptr || !device_ptr) return fail(MORL_ERR_ARG, "NULL argument");
+    HIP_TRY(hipHostGetDevicePointer(device_ptr, host_ptr, 0));
+    return MORL_OK;
+}
+
 extern "C" int morl_gather_fields(const float* records, int record_floats, int64_t capacity, const int64_t* idx, int B,
                                   int n_fields, const int32_t* offsets, const int32_t* widths, float* const* outs,
                                   void* stream) {
@@ -739,6 +766,32 @@ extern "C" int morl_envelope_reduce_rows(const float* qo, const float* qt, const
     p.B = n_rows; p.W = W; p.A = A; p.R = R;
     hipLaunchKernelGGL(envelope_td_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, p);
     LAUNCH_CHECK("envelope_td(reduce_rows)");
+    return MORL_OK;
+}
+
+extern "C" int morl_envelope_greedy_actions(morl_ctx* c, const float* params, const float* obs, const float* w, int n,
+                                            int32_t* actions_out, void* stream) {
+    if (!c || !params || !obs || !w || !actions_out) return fail(MORL_ERR_ARG, "NULL argument");
+    if (n < 1 || (int64_t)n > c->max_rows) return fail(MORL_ERR_STATE, "n=%d outside [1, %lld]", n, (long long)c->max_rows);
+    hipStream_t s = (hipStream_t)stream;
+    const int A = c->net.n_actions, R = c->net.reward_dim;
+    int rc;
+    // rows through the network (paired rows: row r = (obs_r, w_r)) into the context's Q buffer
+    if (c->use_fused) {
+        if ((rc = refresh_transposed(c, params, c->wt_online, s))) return rc;
+        c->wt_online_src = nullptr;
+        if ((rc = chain_forward(c, params, c->wt_online, obs, w, n, 1, 2, n, false, c->qo, A * R, s))) return rc;
+    } else {
+        if ((rc = build_input(obs, w, c->x0n, n, 1, c->net.obs_dim, R, c->ld0, 2, s))) return rc;
+        if ((rc = net_forward(c, params, c->x0n, n, false, c->qo, A * R, s))) return rc;
+    }
+    EnvelopeTdArgs p{};
+    p.qo = c->qo; p.qt = c->qo; p.row_weights = w;
+    p.target = nullptr; p.pref = nullptr; p.ac = actions_out;
+    p.B = n; p.W = 1; p.A = A; p.R = R;
+    p.fma_scal = 1;
+    hipLaunchKernelGGL(envelope_td_kernel, dim3(n), dim3(256), 0, s, p);
+    LAUNCH_CHECK("envelope_td(greedy_actions)");
     return MORL_OK;
 }
 

@@ -4,6 +4,9 @@
 
 namespace morl {
 
+// sum-tree levels are concatenated root first: level l has 2^l nodes at offset 2^l - 1
+__device__ __forceinline__ long long level_off(int l) { return (1ll << l) - 1; }
+
 // ----------------------------------------------------------------------------------------------
 // Batch gather (ReplayBuffer.sample's five fancy-index gathers, common/buffer.py:82-91).
 // Device storage is one AoS record per transition:  obs[D] | next_obs[D] | reward[R] | done | action[Ad]
@@ -21,6 +24,68 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const float* __restri
     const int lane = lane_id();
     for (int b = (int)blockIdx.x * waves_per_block + wave_id(); b < B; b += (int)gridDim.x * waves_per_block) {
         long long t = idx[b];
+        if (t < 0) t = 0;
+        if (t >= capacity) t = capacity - 1;
+        const float* rec = records + (size_t)t * record_floats;
+        for (int e = lane; e < record_floats; e += kWave) {
+            const float v = rec[e];
+            if (e < D) obs[(size_t)b * D + e] = v;
+            else if (e < 2 * D) next_obs[(size_t)b * D + (e - D)] = v;
+            else if (e < 2 * D + R) rewards[(size_t)b * R + (e - 2 * D)] = v;
+            else if (e == 2 * D + R) dones[b] = v;
+            else {
+                const int a = e - (2 * D + R + 1);
+                if (actions_f) actions_f[(size_t)b * Ad + a] = v;
+                if (actions_i) actions_i[(size_t)b * Ad + a] = (int32_t)v;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Index selection + gather of one training batch in ONE launch (round 1 ran a sum-tree descent kernel, a gather kernel and
+// two host->device copies for the B uniforms and the W x R sampled weights back to back: four dependent ~5 us launches).
+// One wave per sampled transition: lane 0 walks the sum tree with its uniform (tree != NULL; SumTree.sample,
+// prioritized_buffer.py:30-54, float64 in the reference's order) or takes the host-drawn index (ReplayBuffer.sample,
+// buffer.py:80), broadcasts it, and the lanes stride the record.  `u01` / `idx_in` / `aux_src` may be PINNED HOST memory
+// (mapped into the device's address space): a few KB read over PCIe inside the kernel instead of separate copy launches.
+// Workgroup 0 also moves `aux_floats` floats from aux_src to aux_dst (the step's sampled weight vectors).
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_gather_kernel(const double* __restrict__ tree, int n_levels,
+                                                            const double* __restrict__ u01,
+                                                            const int64_t* __restrict__ idx_in,
+                                                            const float* __restrict__ records, int record_floats,
+                                                            long long capacity, int B, int D, int R, int Ad,
+                                                            float* __restrict__ obs, float* __restrict__ next_obs,
+                                                            float* __restrict__ rewards, float* __restrict__ dones,
+                                                            float* __restrict__ actions_f, int32_t* __restrict__ actions_i,
+                                                            int64_t* __restrict__ idx_out, const float* __restrict__ aux_src,
+                                                            float* __restrict__ aux_dst, int aux_floats) {
+    const int waves_per_block = (int)blockDim.x / kWave;
+    const int lane = lane_id();
+    if (blockIdx.x == 0 && aux_src != nullptr)
+        for (int e = (int)threadIdx.x; e < aux_floats; e += (int)blockDim.x) aux_dst[e] = aux_src[e];
+    for (int b = (int)blockIdx.x * waves_per_block + wave_id(); b < B; b += (int)gridDim.x * waves_per_block) {
+        long long t = 0;
+        if (lane == 0) {
+            if (tree != nullptr) {
+                double q = __dadd_rn(0.0, __dmul_rn(__dsub_rn(tree[0], 0.0), u01[b]));
+                long long node = 0;
+                for (int l = 1; l < n_levels; ++l) {
+                    node *= 2;
+                    const double left = tree[level_off(l) + node];
+                    const bool gt = q > left;
+                    node += gt ? 1 : 0;
+                    q = __dsub_rn(q, __dmul_rn(left, gt ? 1.0 : 0.0));
+                }
+                t = node;
+            } else {
+                t = idx_in[b];
+            }
+            if (idx_out) idx_out[b] = t;
+        }
+        const int lo = __shfl((int)(t & 0xffffffffll), 0), hi = __shfl((int)(t >> 32), 0);
+        t = ((long long)hi << 32) | (unsigned int)lo;
         if (t < 0) t = 0;
         if (t >= capacity) t = capacity - 1;
         const float* rec = records + (size_t)t * record_floats;
@@ -74,7 +139,6 @@ __global__ __launch_bounds__(256) void gather_fields_kernel(const float* __restr
 // 2^l nodes at offset 2^l - 1.  All arithmetic is IEEE float64 in the reference's order, so indices and
 // node values are bit-exact.
 // ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ long long level_off(int l) { return (1ll << l) - 1; }
 
 // SumTree.sample (:30-54): query = 0 + (root - 0) * u ; per level: go right iff query > left_sum.
 __global__ __launch_bounds__(256) void sumtree_sample_kernel(const double* __restrict__ tree, int n_levels,

@@ -104,10 +104,10 @@ def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
         if B != B0:
             raise ValueError("batch_size changed after shard_envelope_agent")
         for _ in range(self.gradient_updates):
+            aux, sampled_w = self._draw_weights()
             b_obs, b_actions, b_rewards, b_next_obs, b_dones, b_inds = self.replay_buffer.sample(
-                B, to_tensor=True, device=self.device)
-            sampled_w = th.as_tensor(random_weights(dim=R, n=W, dist="gaussian", rng=self.np_random)).float() \
-                .reshape(W, R).to(self.device, non_blocking=True).contiguous()
+                B, to_tensor=True, device=self.device, aux=aux)
+            self._w_ring.mark_used()
             ctx = self.q_net.ctx
             w_loc = sampled_w[i0:i0 + Wl].contiguous()
             # 1. local slabs [2][B][Wl][A][R]: both networks in one launch pair

@@ -225,8 +225,21 @@ class Envelope(MOPolicy, MOAgent):
             self.replay_buffer = params["replay_buffer"]
 
     # -- the hot path ----------------------------------------------------------------------------------------------
-    def __sample_batch_experiences(self):
-        return self.replay_buffer.sample(self.batch_size, to_tensor=True, device=self.device)
+    def __sample_batch_experiences(self, aux=None):
+        return self.replay_buffer.sample(self.batch_size, to_tensor=True, device=self.device, aux=aux)
+
+    def _draw_weights(self):
+        """The step's ``num_sample_w`` weight vectors (``envelope.py:281-283``: host RNG, fp32): staged in pinned memory and
+        moved to a persistent device buffer by the batch-gather launch (no copy launch of their own).  Returns the ``aux``
+        argument of ``replay_buffer.sample`` and the device tensor (valid once that launch has been enqueued)."""
+        W, R = self.num_sample_w, self.reward_dim
+        ring = getattr(self, "_w_ring", None)
+        if ring is None or ring.buf.shape[1] != W * R:
+            ring = self._w_ring = ops.HostRing(self.lib, self.device, W * R, th.float32)
+            self._w_dev = th.zeros((W, R), dtype=th.float32, device=self.device)
+        slot, ptr = ring.next()
+        slot[:] = random_weights(dim=R, n=W, dist="gaussian", rng=self.np_random).reshape(-1)   # float64 -> fp32 (.float())
+        return (ptr, self._w_dev), self._w_dev
 
     def update(self):
         """``envelope.py:267-367``; one C call per gradient step, no host synchronisation."""
@@ -234,10 +247,9 @@ class Envelope(MOPolicy, MOAgent):
         priority = None
         self.q_net.ensure_capacity(self.batch_size, self.num_sample_w)
         for _ in range(self.gradient_updates):
-            b_obs, b_actions, b_rewards, b_next_obs, b_dones, b_inds = self.__sample_batch_experiences()
-            sampled_w = th.as_tensor(
-                random_weights(dim=self.reward_dim, n=self.num_sample_w, dist="gaussian", rng=self.np_random)
-            ).float().reshape(self.num_sample_w, self.reward_dim).to(self.device, non_blocking=True)
+            aux, sampled_w = self._draw_weights()
+            b_obs, b_actions, b_rewards, b_next_obs, b_dones, b_inds = self.__sample_batch_experiences(aux)
+            self._w_ring.mark_used()
             self._adam_step += 1
             self._out = ops.envelope_update(
                 self.q_net.ctx, self.q_net.flat, self.target_q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq,
@@ -333,14 +345,13 @@ class Envelope(MOPolicy, MOAgent):
 
     @th.no_grad()
     def max_action(self, obs: th.Tensor, w: th.Tensor) -> int:
-        """``envelope.py:389-402``: one row through the HIP forward, fma-chain scalarisation (the reference's
-        unbatched einsum), first arg-max."""
-        q = self.q_net(obs, w)[0]                      # (A, R)
-        w = w.to(self.device, th.float32).reshape(-1)
-        s = q[:, 0] * w[0]
-        for r in range(1, self.reward_dim):
-            s = th.addcmul(s, q[:, r], w[r])           # fused multiply-add on the device
-        return int(th.argmax(s).item())
+        """``envelope.py:389-402`` in one C call (``morl_envelope_greedy_actions``): the row through the HIP forward, fma-chain
+        scalarisation (what the reference's unbatched einsum evaluates to) and first arg-max on the device; one 4-byte
+        read-back for the environment."""
+        obs = th.as_tensor(obs).to(self.device, th.float32).reshape(1, -1).contiguous()
+        w = th.as_tensor(w).to(self.device, th.float32).reshape(1, -1).contiguous()
+        self.q_net.ensure_capacity(1, 1)
+        return int(ops.envelope_greedy_actions(self.q_net.ctx, self.q_net.flat, obs, w).item())
 
     # -- training loop (envelope.py:465-572) ---------------------------------------------------------------------------
     def train(self, total_timesteps: int, eval_env=None, ref_point: Optional[np.ndarray] = None,

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
 
 MORL_MAX_LAYERS = 8
 MORL_MAX_OBJ = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class NetDesc(C.Structure):
@@ -123,6 +123,9 @@ _SIGNATURES = {
     "morl_ctx_read_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "morl_gather_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] +
                           [C.c_void_p] * 6 + [C.c_void_p]),
+    "morl_sample_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                     C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p]),
+    "morl_host_device_pointer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "morl_gather_fields": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.c_void_p]),
     "morl_qnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -131,6 +134,7 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "morl_envelope_reduce_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "morl_envelope_greedy_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "morl_envelope_update": (C.c_int, [C.c_void_p] * 12 + [C.c_int, C.c_int, C.POINTER(UpdateCfg),
                                                            C.POINTER(UpdateOut), C.c_void_p]),
     "morl_envelope_slabs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

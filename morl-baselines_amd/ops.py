@@ -97,6 +97,78 @@ def gather_batch(lib: NativeLib, records: th.Tensor, idx: th.Tensor, D: int, R: 
     return obs, act, rew, nobs, done
 
 
+class HostRing:
+    """A ring of small PINNED host buffers that kernels read in place (mapped into the device address space): the per-step
+    host-drawn numbers (B uniforms or indices, W x R sampled weights) reach the device without a copy launch of their own.
+    A slot is handed out again only after the kernel that read it has finished.  Event records cost a few microseconds of
+    stream time each, so ONE event guards a whole group of slots: it is recorded after the group's last slot was used and
+    waited for (normally long since complete) before the group's first slot is reused a lap later."""
+
+    def __init__(self, lib: NativeLib, device: th.device, count: int, dtype, slots: int = 64, group: int = 16):
+        assert slots % group == 0 and slots // group >= 2
+        self.lib, self.device = lib, th.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        self.buf = th.zeros((slots, count), dtype=dtype, pin_memory=self.on_gpu)
+        self.np = self.buf.numpy()
+        self.group = group
+        self.events = [None] * (slots // group)
+        self.cur = -1
+        self.dev_ptrs = []
+        for k in range(slots):
+            host = self.buf[k].data_ptr()
+            if self.on_gpu:
+                out = C.c_void_p()
+                lib.check(lib.lib.morl_host_device_pointer(C.c_void_p(host), C.byref(out)))
+                self.dev_ptrs.append(out.value)
+            else:
+                self.dev_ptrs.append(host)
+
+    def next(self):
+        """(numpy view to fill, device-side address of the slot)."""
+        self.cur = (self.cur + 1) % len(self.dev_ptrs)
+        if self.cur % self.group == 0:
+            evt = self.events[self.cur // self.group]
+            if evt is not None:
+                evt.synchronize()
+        return self.np[self.cur], self.dev_ptrs[self.cur]
+
+    def mark_used(self) -> None:
+        """Call right after enqueueing the kernel that reads the slot handed out last."""
+        if self.on_gpu and self.cur % self.group == self.group - 1:
+            g = self.cur // self.group
+            evt = self.events[g] or th.cuda.Event()
+            evt.record(th.cuda.current_stream(self.device))
+            self.events[g] = evt
+
+
+def sample_gather(lib: NativeLib, records: th.Tensor, B: int, D: int, R: int, action_dim: int = 1, int_actions: bool = True, *,
+                  tree: Optional[th.Tensor] = None, n_levels: int = 0, u01_ptr: Optional[int] = None,
+                  idx_ptr: Optional[int] = None, aux_src_ptr: Optional[int] = None, aux_dst: Optional[th.Tensor] = None):
+    """One training batch in one launch (``morl_sample_gather``): sum-tree descent with the uniforms at ``u01_ptr`` (PER) or
+    the indices at ``idx_ptr`` (uniform replay), then the record gather; ``aux_src_ptr`` -> ``aux_dst`` rides along.  The raw
+    addresses are device-visible (device memory or mapped pinned host memory of a ``HostRing``).
+    Returns (obs, actions, rewards, next_obs, dones, idx)."""
+    _chk(records, th.float32, "records")
+    lib.check_device(records, tree, aux_dst)
+    dev = records.device
+    obs = th.empty((B, D), dtype=th.float32, device=dev)
+    nobs = th.empty((B, D), dtype=th.float32, device=dev)
+    rew = th.empty((B, R), dtype=th.float32, device=dev)
+    done = th.empty((B, 1), dtype=th.float32, device=dev)
+    idx = th.empty((B,), dtype=th.int64, device=dev)
+    if int_actions:
+        act = th.empty((B,) if action_dim == 1 else (B, action_dim), dtype=th.int32, device=dev)
+        af, ai = None, act
+    else:
+        act = th.empty((B, action_dim), dtype=th.float32, device=dev)
+        af, ai = act, None
+    lib.check(lib.lib.morl_sample_gather(_ptr(tree), int(n_levels), u01_ptr, idx_ptr, _ptr(records), records.shape[1],
+                                         records.shape[0], B, D, R, action_dim, _ptr(obs), _ptr(nobs), _ptr(rew), _ptr(done),
+                                         _ptr(af), _ptr(ai), _ptr(idx), aux_src_ptr, _ptr(aux_dst),
+                                         0 if aux_dst is None else aux_dst.numel(), lib.stream_of(records)))
+    return obs, act, rew, nobs, done, idx
+
+
 def gather_fields(lib: NativeLib, records: th.Tensor, idx: th.Tensor, fields):
     """Generic record gather: ``fields`` = [(offset, width), ...] -> one (B, width) float32 tensor per field."""
     import ctypes as C
@@ -150,6 +222,20 @@ def envelope_reduce_rows(lib: NativeLib, qo: th.Tensor, qt: th.Tensor, row_w: th
     lib.check(lib.lib.morl_envelope_reduce_rows(_ptr(qo), _ptr(qt), _ptr(row_w), n, W, A, R, _ptr(target), _ptr(pref),
                                                 _ptr(ac), lib.stream_of(qo)))
     return target, pref, ac
+
+
+def envelope_greedy_actions(ctx: QNetContext, params: th.Tensor, obs: th.Tensor, w: th.Tensor) -> th.Tensor:
+    """``Envelope.max_action`` (envelope.py:389-402) for n paired (obs, w) rows in one C call -> int32 actions (n,)."""
+    lib = ctx.lib
+    _chk(params, th.float32, "params"); _chk(obs, th.float32, "obs"); _chk(w, th.float32, "w")
+    lib.check_device(params, obs, w)
+    n = obs.shape[0]
+    if w.shape[0] != n:
+        raise ValueError("obs and w must have the same number of rows")
+    ac = th.empty((n,), dtype=th.int32, device=obs.device)
+    lib.check(lib.lib.morl_envelope_greedy_actions(ctx.handle, _ptr(params), _ptr(obs), _ptr(w), n, _ptr(ac),
+                                                   lib.stream_of(obs)))
+    return ac
 
 
 def envelope_reduce(lib: NativeLib, qo: th.Tensor, qt: th.Tensor, weights: th.Tensor, diag_only: bool = False):

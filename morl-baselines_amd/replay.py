@@ -154,22 +154,37 @@ class ReplayBuffer:
         self.ptr = (self.ptr + n) % self.max_size
         self.size = min(self.size + n, self.max_size)
 
-    def _gather(self, inds: np.ndarray):
+    def _ring(self, name: str, count: int, dtype) -> "ops.HostRing":
+        """Pinned staging ring for the host-drawn numbers of a batch (re-created when the batch size changes)."""
+        ring = self.__dict__.get(name)
+        if ring is None or ring.buf.shape[1] != count:
+            ring = ops.HostRing(self.lib, self.device, count, dtype)
+            self.__dict__[name] = ring
+        return ring
+
+    def _gather(self, inds: np.ndarray, aux=None):
+        """The host-drawn indices are read in place from pinned memory by the gather launch itself."""
         self.flush()
-        idx = th.as_tensor(inds, dtype=th.int64).to(self.device, non_blocking=True)
-        obs, act, rew, nobs, done = ops.gather_batch(self.lib, self.records, idx, self._D, self._R, self._Ad,
-                                                     int_actions=self._int_actions)
+        B = int(len(inds))
+        ring = self._ring("_idx_ring", B, th.int64)
+        slot, ptr = ring.next()
+        slot[:] = inds
+        obs, act, rew, nobs, done, idx = ops.sample_gather(
+            self.lib, self.records, B, self._D, self._R, self._Ad, self._int_actions, idx_ptr=ptr,
+            aux_src_ptr=None if aux is None else aux[0], aux_dst=None if aux is None else aux[1])
+        ring.mark_used()
         if self._int_actions and self._Ad == 1:
             act = act.view(-1, 1)
         return obs, act, rew, nobs, done, idx
 
-    def sample(self, batch_size, replace=True, use_cer=False, to_tensor=False, device=None):
-        """``buffer.py:68-96``: host index selection on the global numpy RNG, device gather when ``to_tensor``."""
+    def sample(self, batch_size, replace=True, use_cer=False, to_tensor=False, device=None, aux=None):
+        """``buffer.py:68-96``: host index selection on the global numpy RNG, device gather when ``to_tensor``.
+        ``aux`` = (device-visible source address, device tensor): copied along by the gather launch (``ops.sample_gather``)."""
         inds = np.random.choice(self.size, batch_size, replace=replace)
         if use_cer:
             inds[0] = (self.ptr - 1) % self.max_size     # numpy wraps -1 to the newest slot; the device gather must too
         if to_tensor:
-            return self._gather(inds)
+            return self._gather(inds, aux)
         return (self.obs[inds], self.actions[inds], self.rewards[inds], self.next_obs[inds], self.dones[inds], inds)
 
     def sample_obs(self, batch_size, replace=True, to_tensor=False, device=None):
@@ -192,7 +207,8 @@ class ReplayBuffer:
     def __getstate__(self):
         self.flush()
         st = {k: v for k, v in self.__dict__.items()
-              if k not in ("records", "lib", "_stage", "_stage_np", "_stage_evt", "tree_dev", "running_max")}
+              if k not in ("records", "lib", "_stage", "_stage_np", "_stage_evt", "tree_dev", "running_max", "_idx_ring",
+                           "_u_ring")}
         st["device"] = str(self.device)
         return st
 
@@ -278,14 +294,24 @@ class PrioritizedReplayBuffer(ReplayBuffer):
         u = th.as_tensor(np.random.random_sample(batch_size)).to(self.device, non_blocking=True)
         return ops.sumtree_sample(self.lib, self.tree_dev, self.n_levels, u)
 
-    def sample(self, batch_size, to_tensor=False, device=None):
-        idx = self.sample_indices(batch_size)
+    def sample(self, batch_size, to_tensor=False, device=None, aux=None):
+        """``prioritized_buffer.py:149-185``.  ``to_tensor``: uniforms from the global numpy RNG (the stream
+        ``np.random.uniform`` consumes) staged in pinned memory, descent + gather (+ the ``aux`` copy, see
+        ``ReplayBuffer.sample``) in one launch."""
         if to_tensor:
-            obs, act, rew, nobs, done = ops.gather_batch(self.lib, self.records, idx, self._D, self._R, self._Ad,
-                                                         int_actions=self._int_actions)
+            self.flush()
+            ring = self._ring("_u_ring", int(batch_size), th.float64)
+            slot, ptr = ring.next()
+            slot[:] = np.random.random_sample(batch_size)
+            obs, act, rew, nobs, done, idx = ops.sample_gather(
+                self.lib, self.records, int(batch_size), self._D, self._R, self._Ad, self._int_actions,
+                tree=self.tree_dev, n_levels=self.n_levels, u01_ptr=ptr,
+                aux_src_ptr=None if aux is None else aux[0], aux_dst=None if aux is None else aux[1])
+            ring.mark_used()
             if self._int_actions and self._Ad == 1:
                 act = act.view(-1, 1)
             return obs, act, rew, nobs, done, idx
+        idx = self.sample_indices(batch_size)
         i = idx.cpu().numpy()
         return (self.obs[i], self.actions[i], self.rewards[i], self.next_obs[i], self.dones[i], i)
 
