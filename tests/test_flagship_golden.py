@@ -61,6 +61,18 @@ def test_argmax_indices_match_reference_up_to_one_ulp_ties(run):
     assert th.equal(res["target"].cpu(), tg.reshape(-1, c.R))
     pref_ref, ac_ref = th.tensor(g["pref"].astype(np.int64)), th.tensor(g["ac"].astype(np.int64))
     mism = ((res["pref"].cpu().long() != pref_ref) | (res["ac"].cpu().long() != ac_ref)).nonzero().flatten()
+    # the observed count is part of the record: printed, stored next to the run's other outputs, and
+    # bounded by what the device's GEMM summation order has been seen to produce (the oracle reproduces the reference's
+    # indices EXACTLY from the reference's own Q -- tests/test_oracle_golden.py::test_full_size_indices_exact_given_reference_q
+    # -- so every flip below comes from the ~1e-7 difference between the device's and torch-CPU's Q, none from the einsum)
+    print(f"[near-tie flips] {c.name}: {mism.numel()} of {c.B * c.W} TD rows differ from the reference's arg-max")
+    try:
+        os.makedirs(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out"), exist_ok=True)
+        with open(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out", f"near_tie_flips_{c.name}.json"), "w") as fh:
+            import json
+            json.dump({"case": c.name, "td_rows": c.B * c.W, "flips": int(mism.numel())}, fh)
+    except OSError:
+        pass
     assert mism.numel() <= 0.002 * c.B * c.W
     for r in mism.tolist():                                               # every mismatch is a near-tie
         i, b = r // c.B, r % c.B

@@ -85,6 +85,22 @@ def test_device_hypervolume_matches_oracle(be, R, N):
         assert pi.hypervolume(ref, list(extra), lib=lib, device=dev) == pytest.approx(want, rel=1e-12)
 
 
+# Deep Sea Treasure (Vamplew et al. 2011): the ten treasures and the steps needed to reach them.  The hypervolume of this Pareto
+# front w.r.t. the reference point (0, -25) is the figure the MORL literature quotes for the environment -- 1155 (e.g. Van
+# Moffaert & Nowe, JMLR 2014, Pareto Q-learning) -- an anchor that is independent of this repository and of pymoo.
+DST_FRONT = [(1, -1), (2, -3), (3, -5), (5, -7), (8, -8), (16, -9), (24, -13), (50, -14), (74, -17), (124, -19)]
+
+
+def test_hypervolume_of_the_deep_sea_treasure_front_is_the_published_1155(be):
+    lib, dev = be
+    pts = [np.array(p, dtype=np.float64) for p in DST_FRONT]
+    ref = np.array([0.0, -25.0])
+    assert mo.hypervolume(ref, pts) == 1155.0
+    assert pi.hypervolume(ref, pts, lib=lib, device=dev) == 1155.0
+    # dominated policies of a learning agent's archive do not change it
+    assert pi.hypervolume(ref, pts + [np.array([7.0, -9.0]), np.array([1.0, -2.0])], lib=lib, device=dev) == 1155.0
+
+
 def test_device_hypervolume_edges(be):
     lib, dev = be
     assert pi.hypervolume(np.zeros(2), [np.array([-1.0, 5.0])], lib=lib, device=dev) == 0.0          # nothing above ref
