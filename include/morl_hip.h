@@ -31,7 +31,7 @@ extern "C" {
 
 #define MORL_MAX_LAYERS 8   /* linear layers per network */
 #define MORL_MAX_OBJ 8      /* reward dimension R */
-#define MORL_ABI_VERSION 4
+#define MORL_ABI_VERSION 5
 
 typedef enum morl_status {
     MORL_OK = 0,
@@ -71,6 +71,15 @@ typedef struct morl_update_cfg {
                               * buffer [G][2][B][W_total/G][A][R] (what all_gather_into_tensor builds from every rank's
                               * morl_envelope_slabs output): qt_all = qo_all + B*(W_total/G)*A*R, parts 2*B*(W_total/G)*A*R
                               * floats apart -- read in place, no re-layout pass */
+    /* prioritized replay (envelope.py:329-334 -> prioritized_buffer.py:187-195), optional: per_tree != NULL makes
+     * morl_envelope_update apply  priority = (|td . w| + running_max)^per_alpha  to the device sum tree itself (the same
+     * arithmetic as morl_sumtree_update), as an extra workgroup of the weight-gradient launch instead of a launch of its
+     * own.  per_idx: device int64 [B] sampled leaf indices; per_running_max: device double [1]. */
+    double* per_tree;
+    const int64_t* per_idx;
+    double* per_running_max;
+    int32_t per_levels;
+    float per_alpha;
 } morl_update_cfg;
 
 /* Optional device outputs of morl_envelope_update (any may be NULL). */

@@ -20,6 +20,7 @@
 #pragma once
 #include "morl_device.h"
 #include "morl_hip.h"
+#include "replay_kernels.h"
 
 namespace morl {
 
@@ -47,6 +48,11 @@ struct Dw2Args {
     Dw2Problem p[MORL_MAX_LAYERS];
     int n, rows, jobs;
     long long slab_stride;     // floats between split slabs
+    SumTreeUpdate per;         // per.tree != NULL: one extra workgroup (block `jobs`) applies the step's PER priority update
+                               // (prioritized_buffer.py:187-195) -- it only depends on the TD kernel's priorities, nothing here
+                               // depends on it, and the launch has a free slot: 16 us of serial tail disappear
+    int stagger;               // s_sleep units (64 cycles) the second half of the grid waits before starting: the two workgroups of a
+                               // CU (blocks b and b + grid/2) run identical chunk loops and would otherwise hit their barriers together
 };
 
 // global -> registers: a 32 x WIDTH chunk of a row-major operand (rows = contraction index), 16 bytes per load
@@ -206,8 +212,14 @@ __global__ __launch_bounds__(DW2_THREADS, 2) void dw_tiles_kernel(Dw2Args a) {
     __shared__ __attribute__((aligned(16))) float sA[2][DW2_BK * DW2_LD];
     __shared__ __attribute__((aligned(16))) float sB[2][DW2_BK * DW2_LD];
     // consecutive jobs = the tiles of one row slice, which share that slice of g_l / h_l: keep them on one XCD's L2
-    const int job = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    if (job >= a.jobs) return;
+    static_assert(sizeof(sA) >= ST_LDS_BYTES, "the tree update borrows the A-operand buffers as scratch");
+    if ((int)blockIdx.x >= a.jobs) {
+        if ((int)blockIdx.x == a.jobs && a.per.tree != nullptr) sumtree_update_body(a.per, &sA[0][0]);
+        return;
+    }
+    const int job = xcd_remap((int)blockIdx.x, a.jobs);
+    if (a.stagger > 0 && (int)blockIdx.x >= (a.jobs >> 1))
+        for (int k = 0; k < a.stagger; k += 64) __builtin_amdgcn_s_sleep(64);
     int q = 0;
     while (q + 1 < a.n && job >= a.p[q + 1].job_start) ++q;
     const Dw2Problem& g = a.p[q];

@@ -1,5 +1,6 @@
-// Layer-fused MLP engine, second generation (gfx950, wave64): same contract as mlp_chain.h (a workgroup carries a TM-row tile
-// through a whole chain of dense layers, activations resident in LDS), re-laid-out around what round 1's profiles showed:
+// Layer-fused MLP engine (gfx950, wave64), kernels; contract and argument structures in mlp_chain.h (a workgroup carries a
+// TM-row tile through a whole chain of dense layers, activations resident in LDS).  Second generation, laid out around what
+// round 1's profiles showed:
 //
 //   * activations are M-MAJOR in LDS, sAct[m][k] with row stride 260 floats: the MFMA A operand of lane (i, h) for FOUR
 //     consecutive k-pairs is ONE ds_read_b128 (k = 8c + 4h + 0..3; the contraction order inside a chunk is permuted
@@ -41,10 +42,10 @@ struct C2WideDesc {
     int stride;       // bytes per k-row (wave-uniform)
 };
 
-__device__ __forceinline__ C2WideDesc c2_wide_desc(const ChainStep& st, int wave, int i, int h) {
+__device__ __forceinline__ C2WideDesc c2_wide_desc(const ChainStep& st, int wave, int i, int h, int g = 0) {
     C2WideDesc d;
     const int colw = wave * 64 + 2 * i;
-    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st.Bmat, 0, (st.kpad > st.K ? st.kpad : st.K) * st.ldb * 4, 0x00020000);
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bmat + g * st.sW), 0, (st.kpad > st.K ? st.kpad : st.K) * st.ldb * 4, 0x00020000);
     d.lane_off = (colw < st.ldb) ? (4 * h * st.ldb + colw) * 4 : CH_OOB;
     d.stride = st.ldb * 4;
     return d;
@@ -72,8 +73,8 @@ __device__ __forceinline__ void c2_load_fast(C2BSet& s, const C2WideDesc& d, int
 
 // narrow step (N <= 32): the four waves split the contraction, wave w: k in [64w, 64w + 64); lane (i = n, h) loads
 // Bt[n][64w + 8c + 4h .. +3] for c = 0..7 as eight float4 = the 16 float2 of the set (v[2c], v[2c+1])
-__device__ __forceinline__ void c2_load_narrow(C2BSet& s, const ChainStep& st, int wave, int i, int h) {
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st.Bt, 0, st.N * st.ldbt * 4, 0x00020000);
+__device__ __forceinline__ void c2_load_narrow(C2BSet& s, const ChainStep& st, int wave, int i, int h, int g = 0) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bt + g * st.sW), 0, st.N * st.ldbt * 4, 0x00020000);
     const int kbase = wave * 64 + 4 * h;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -200,7 +201,8 @@ __device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& 
 #define C2_TICK() if (PROF) { if (n_tick < 24) ticks[n_tick] = clock64(); ++n_tick; }
 
 template <int TM, int SCHED, bool FAST, bool PROF = false>
-__device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, float* sAct, long long* prof_out = nullptr) {
+__device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, float* sAct, long long* prof_out = nullptr,
+                                                int g = 0) {
     long long ticks[24];
     int n_tick = 0;
     C2_TICK()
@@ -212,10 +214,10 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
 
     C2BSet bx, by;
     const bool first_wide = p.step[0].N > 32;
-    C2WideDesc dcur = c2_wide_desc(p.step[0], wave, i, h);
+    C2WideDesc dcur = c2_wide_desc(p.step[0], wave, i, h, g);
     // the weight stream starts before the input tile is assembled
     if (first_wide) { if (FAST) c2_load_fast(bx, dcur, 0); else c2_load_wide(bx, dcur, 0); }
-    else c2_load_narrow(bx, p.step[0], wave, i, h);
+    else c2_load_narrow(bx, p.step[0], wave, i, h, g);
 
     // ---- input tile -> sAct[m][k], zero-padded to the columns the first step multiplies -------------------------------
     {
@@ -231,7 +233,8 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
             else if (p.row_order == 1) { w = row / p.B; b = row - w * p.B; }
         }
         const bool row_ok = row < p.rows;
-        const float* src_a = (p.in_mode == 0) ? p.obs + (size_t)b * p.D : p.src + (size_t)row * p.ldsrc;
+        const float* src_a = (p.in_mode == 0) ? p.obs + (size_t)b * p.D
+                                              : p.src + (p.nb > 1 ? (g / p.src_div) * p.sSrc : 0) + (size_t)row * p.ldsrc;
         const float* src_w = p.weights + (size_t)w * p.R;
         for (int kb = q * 16; kb < K0pad; kb += TPR * 16) {
             float v[16];
@@ -283,7 +286,7 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
             const int n_pairs = (K + 63) >> 6;         // K is treated as padded to a multiple of 64 with zero rows
             if (FAST) c2_load_fast(by, dcur, CH_BK); else c2_load_wide(by, dcur, CH_BK);
             const float* pa = sAct + i * C2_LDK + 4 * h;
-            const C2WideDesc dnext = c2_wide_desc(nxt, wave, i, h);
+            const C2WideDesc dnext = c2_wide_desc(nxt, wave, i, h, g);
             if (do_copy) c2_wide_loop<TM, true, SCHED, FAST>(acc, bx, by, sAct, pa, dcur, dnext, nxt_wide, n_pairs, cdst);
             else c2_wide_loop<TM, false, SCHED, FAST>(acc, bx, by, sAct, pa, dcur, dnext, nxt_wide, n_pairs, cdst);
             dcur = dnext;
@@ -296,11 +299,11 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
             const bool col1_ok = colw + 1 < N;
             float bias0 = 0.f, bias1 = 0.f;
             if (st.bias != nullptr) {
-                if (col_ok) bias0 = st.bias[colw];
-                if (col1_ok) bias1 = st.bias[colw + 1];
+                if (col_ok) bias0 = st.bias[g * st.sW + colw];
+                if (col1_ok) bias1 = st.bias[g * st.sW + colw + 1];
             }
             unsigned long long bits_w = 0ull, bits_r = 0ull;
-            const size_t bits_idx = (size_t)(row0 >> 6) * CH_THREADS + tid;
+            const size_t bits_idx = (size_t)g * st.sBits + (size_t)(row0 >> 6) * CH_THREADS + tid;
             const int bits_shift = (TM == 32) ? ((row0 >> 5) & 1) * 32 : 0;
             if (st.bits_in != nullptr) bits_r = st.bits_in[bits_idx] >> bits_shift;
 #pragma unroll
@@ -341,7 +344,7 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
                     reinterpret_cast<unsigned int*>(st.bits_out)[2 * bits_idx + ((row0 >> 5) & 1)] = (unsigned int)bits_w;
             }
             do_copy = st.out != nullptr;
-            if (do_copy) cdst = c2_copy_dst(st.out, st.ldout, N, p.rows, row0, tid);
+            if (do_copy) cdst = c2_copy_dst(st.out + g * st.sOut, st.ldout, N, p.rows, row0, tid);
         } else {
             // ======================= narrow step (Q head): split-K over the four waves ========================
             // bx holds Bt[i][64w + 8c + 4h + 0..3] (c = 0..7): wave w contracts k in [64w, 64w + 64) for output column i
@@ -352,7 +355,7 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
                 for (int r = 0; r < 16; ++r) hacc[a][r] = 0.f;
             const float* pa = sAct + i * C2_LDK + wave * 64 + 4 * h;
             // the saved input of this step goes to HBM first (its LDS image becomes the reduction scratch below)
-            if (s > 0) c2_load_narrow(bx, st, wave, i, h);   // (step 0's operands were fetched by the prologue)
+            if (s > 0) c2_load_narrow(bx, st, wave, i, h, g);   // (step 0's operands were fetched by the prologue)
             if (do_copy)
                 for (int piece = 0; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cdst, piece);
 #pragma unroll
@@ -377,7 +380,7 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
 #pragma unroll
                 for (int r = 0; r < 16; ++r) scr[((wave * MT + tm) * 16 + r) * 64 + lane] = hacc[tm][r];
             // the stream moves on while the partial tiles are reduced
-            const C2WideDesc dnext = c2_wide_desc(nxt, wave, i, h);
+            const C2WideDesc dnext = c2_wide_desc(nxt, wave, i, h, g);
             if (nxt_wide) { if (FAST) c2_load_fast(bx, dnext, 0); else c2_load_wide(bx, dnext, 0); }
             dcur = dnext;
             __syncthreads();
@@ -396,7 +399,7 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
                 }
             if (feed_next) __syncthreads();   // scratch fully consumed before sAct is rewritten
             const int n = i;
-            const float bias = (st.bias != nullptr && n < N) ? st.bias[n] : 0.f;
+            const float bias = (st.bias != nullptr && n < N) ? st.bias[g * st.sW + n] : 0.f;
 #pragma unroll
             for (int tm = 0; tm < MT; ++tm)
 #pragma unroll
@@ -410,7 +413,7 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
                     if (st.mask != nullptr) v = (ok && st.mask[(size_t)row * st.ldmask + n] > 0.f) ? v : 0.f;
                     if (!ok) v = 0.f;
                     if (feed_next) sAct[m * C2_LDK + n] = v;
-                    if (st.out != nullptr && ok) st.out[(size_t)row * st.ldout + n] = v;
+                    if (st.out != nullptr && ok) st.out[g * st.sOut + (size_t)row * st.ldout + n] = v;
                 }
             if (feed_next) {
                 // the next step reads K' = N <= 32 padded to 64 columns: columns [32, 64) must be zero too
@@ -493,19 +496,21 @@ __device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, floa
             unit = (tail_first ? j - 1 : j) * S + b;
         }
         const int q = c2_find_chain(m, unit);
-        const int row0 = (unit - m.unit_start[q]) * 64 + (half > 0 ? 32 : 0);
+        int lu = unit - m.unit_start[q], g = 0;                  // batched chain: unit -> (network, row tile)
+        if (m.p[q].nb > 1) { const int upn = (m.p[q].rows + 63) >> 6; g = lu / upn; lu -= g * upn; }
+        const int row0 = lu * 64 + (half > 0 ? 32 : 0);
         long long* pout = (PROF && m.prof != nullptr) ? m.prof + ((size_t)b * 2 + (j > 0 ? 1 : 0)) * 24 : nullptr;
         if (m.p[q].fast) {
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, true, PROF>(m.p[q], row0, sAct, pout);
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, true, PROF>(m.p[q], row0, sAct, pout, g);
             } else {
-                mlp_chain2_body<64, SCHED, true, PROF>(m.p[q], row0, sAct, pout);
+                mlp_chain2_body<64, SCHED, true, PROF>(m.p[q], row0, sAct, pout, g);
             }
         } else {
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, false, PROF>(m.p[q], row0, sAct, pout);
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, false, PROF>(m.p[q], row0, sAct, pout, g);
             } else {
-                mlp_chain2_body<64, SCHED, false, PROF>(m.p[q], row0, sAct, pout);
+                mlp_chain2_body<64, SCHED, false, PROF>(m.p[q], row0, sAct, pout, g);
             }
         }
         __syncthreads();     // the tile buffer is free for the next job
@@ -541,7 +546,7 @@ struct ShadowArgs {
 
 constexpr int SH_T = 32;     // tile edge: 32 x 32 tiles -> ~480 workgroups for both flagship networks, one load + one store round each
 
-__global__ __launch_bounds__(256) void shadow_weights_kernel(const float* __restrict__ params, float* __restrict__ wt,
+static __global__ __launch_bounds__(256) void shadow_weights_kernel(const float* __restrict__ params, float* __restrict__ wt,
                                                              const float* __restrict__ params2, float* __restrict__ wt2,
                                                              ShadowArgs a) {
     __shared__ float tile[SH_T * (SH_T + 1)];

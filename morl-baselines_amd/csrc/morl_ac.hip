@@ -13,6 +13,7 @@
 #include "morl_host.h"
 #include "morl_device.h"
 #include "gemm_f32.h"
+#include "mlp_chain2.h"
 #include "optim_kernels.h"
 #include "ac_kernels.h"
 
@@ -59,6 +60,9 @@ struct Tape {
     float* out = nullptr;                        // [G][cap][ld[L]]
     float* g[MORL_MAX_LAYERS] = {};              // dLoss/dz of every linear layer
     float* dx = nullptr;                         // [G][cap][ld0]
+    // layer-fused passes (mlp_chain2.h): (h[l] > 0) packed by the chain's tiling, [G][ceil(cap / 64)][256] words per layer
+    unsigned long long* bits[MORL_MAX_LAYERS] = {};
+    bool bits_valid = false;                     // written by the last forward of this tape
 };
 
 }  // namespace
@@ -106,6 +110,11 @@ static int alloc_tape(std::vector<void*>& c, const Mlp& m, Tape& t, int G, int x
         if (l == m.L - 1) { if ((rc = alloc_f(c, &t.out, n))) return rc; }
         else {
             if ((rc = alloc_f(c, &t.h[l], n))) return rc;
+            {
+                float* bw = nullptr;     // 64-bit words, allocated as pairs of floats
+                if ((rc = alloc_f(c, &bw, (size_t)G * ((cap + 63) / 64) * CH_THREADS * 2))) return rc;
+                t.bits[l] = reinterpret_cast<unsigned long long*>(bw);
+            }
             if (post) {
                 if ((rc = alloc_f(c, &t.zx[l], n))) return rc;
                 if ((rc = alloc_f(c, &t.rstd[l], (size_t)G * cap))) return rc;
@@ -246,6 +255,85 @@ extern "C" int morl_ac_set_gemm_mode(int mode) {
     return MORL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// layer-fused passes: a plain ReLU MLP (no LayerNorm, no active Dropout, widths <= 256) runs ALL its layers in one launch of
+// the persistent chain kernel (mlp_chain2.h) -- the G networks of a tape are one batched chain, a paired pass a second one
+// in the same launch.  Round 1 ran one GEMM launch per layer: a single-learner update was 35-52 dependent ~8 us launches.
+// ---------------------------------------------------------------------------------------------------------------------
+// Measured on MI355X (round 2): NOT a win for one learner's 128-row batch -- a pass is then 4-8 workgroups whose 32-row tiles
+// carry a whole 256 x 256 layer each (7 us of MFMA on one CU), 23 us per pass against 3 x 8 us for the per-layer wave-tile
+// GEMMs that spread every layer over 32 workgroups (CAPQL 0.217 vs 0.210 ms, MOSAC 0.368 vs 0.355 ms per update).  Kept
+// behind MORL_AC_CHAIN=1 (parity-tested) until a 16-row tile variant exists; the per-layer engines stay the default.
+static const bool g_ac_chain = [] { const char* e = getenv("MORL_AC_CHAIN"); return e ? atoi(e) != 0 : false; }();
+
+static bool chain_shape_ok(const Mlp& m) {
+    if (!g_ac_chain || m.ln || m.L < 2 || m.L > MORL_MAX_LAYERS) return false;
+    if (m.dims[0] > CH_MAXW) return false;
+    for (int l = 1; l < m.L; ++l)
+        if (m.dims[l] > CH_MAXW || m.dims[l] <= 32 || (m.dims[l] & 3)) return false;     // hidden layers: wide steps, 16-byte rows
+    if (m.dims[m.L] > CH_MAXW || (m.dims[m.L] > 32 && (m.dims[m.L] & 3))) return false;
+    return true;
+}
+
+static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
+    static const int num_cus = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            return prop.multiProcessorCount;
+        return 256;
+    }();
+    Chain2Multi m{};
+    m.n = n;
+    int units = 0;
+    for (int q = 0; q < n; ++q) {
+        m.p[q] = chains[q];
+        m.unit_start[q] = units;
+        units += std::max(1, chains[q].nb) * ((chains[q].rows + 63) / 64);
+    }
+    for (int q = n; q <= CH_MAX_MULTI; ++q) m.unit_start[q] = units;
+    const int S = std::max(1, std::min(2 * num_cus, 2 * units));
+    m.full_rounds = units / S;
+    m.tail_base = m.full_rounds * S;
+    m.tail_units = units - m.tail_base;
+    m.tail_halves = (2 * m.tail_units <= S) ? 1 : 0;
+    m.stagger = 1;
+    hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
+    LAUNCH_CHECK("ac_chain");
+    return MORL_OK;
+}
+
+// forward chain of the G networks of `t`: input rows t.x (shared by x_div networks), every hidden activation saved to t.h[]
+// (the weight-gradient GEMM reads them) together with its sign bits, output to t.out
+static ChainArgs ac_forward_chain(const Mlp& m, const float* params, const float* wt, int64_t pstride, Tape& t, int rows, int x_div) {
+    ChainArgs a{};
+    a.n_steps = m.L;
+    a.rows = rows;
+    a.in_mode = 1;
+    a.src = t.x; a.ldsrc = m.ld[0]; a.K0 = m.dims[0];
+    a.nb = t.G; a.sSrc = (long long)t.cap * m.ld[0]; a.src_div = x_div;
+    a.fast = 0;
+    const long long units = (t.cap + 63) / 64;
+    for (int l = 0; l < m.L; ++l) {
+        ChainStep& st = a.step[l];
+        const bool last = (l == m.L - 1);
+        st.Bmat = wt + m.offW[l];              // K-major shadow copy [in][out]
+        st.ldb = m.dims[l + 1];
+        st.Bt = params + m.offW[l];            // nn.Linear layout [out][in] = N-major
+        st.ldbt = m.dims[l];
+        st.K = m.dims[l];
+        st.N = m.dims[l + 1];
+        st.bias = params + m.offB[l];
+        st.relu = last ? 0 : 1;
+        st.sW = pstride;
+        st.out = last ? t.out : t.h[l];
+        st.ldout = m.ld[l + 1];
+        st.sOut = (long long)t.cap * m.ld[l + 1];
+        if (!last) { st.bits_out = t.bits[l]; st.sBits = units * CH_THREADS; }
+    }
+    return a;
+}
+
 struct DropSpec {
     bool active = false;              // train-mode dropout
     const uint8_t* ext = nullptr;     // explicit masks of this phase: [G][per_net bytes]
@@ -264,6 +352,18 @@ static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape&
     const long long cap = t.cap;
     if ((wt != nullptr) != (t2 ? wt2 != nullptr : wt != nullptr)) return fail(MORL_ERR_STATE, "paired passes: both or no shadow copy");
     if (t2 && (t2->cap != t.cap || t2->G != t.G)) return fail(MORL_ERR_STATE, "paired passes need equally shaped tapes");
+    t.bits_valid = false;
+    if (t2) t2->bits_valid = false;
+    const bool plain = !(ds.active && m.drop > 0.f) && !(t2 && ds2 && ds2->active && m.drop > 0.f);
+    if (wt != nullptr && plain && chain_shape_ok(m)) {
+        ChainArgs ch[2] = {ac_forward_chain(m, params, wt, pstride, t, rows, x_div), ChainArgs{}};
+        if (t2) ch[1] = ac_forward_chain(m, params2, wt2, pstride, *t2, rows, x_div);
+        int rc = ac_chain_launch(ch, t2 ? 2 : 1, s);
+        if (rc) return rc;
+        t.bits_valid = true;
+        if (t2) t2->bits_valid = true;
+        return MORL_OK;
+    }
     int64_t ext_off = 0;
     for (int l = 0; l < m.L; ++l) {
         const bool last = (l == m.L - 1);
@@ -337,11 +437,48 @@ static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape&
 // backward of the same pass: t.g[L-1] holds dLoss/d(out).  grads ([G][P], fully overwritten) may be NULL (no parameter
 // gradients wanted); need_dx -> t.dx = dLoss/d(input rows).  `dropped` = the forward ran with train-mode dropout.
 static int mlp_backward(const Mlp& m, const float* params, int64_t pstride, Tape& t, int rows, int x_div,
-                        bool dropped, float* grads, bool need_dx, hipStream_t s, int64_t grad_stride = -1) {
+                        bool dropped, float* grads, bool need_dx, hipStream_t s, int64_t grad_stride = -1,
+                        const float* wt = nullptr) {
     const long long cap = t.cap;
     if (grad_stride < 0) grad_stride = m.P;      // floats between the gradient blocks of consecutive nets
+    // dX chain in one launch when the forward was the layer-fused one (its ReLU sign bits are in the tape): g[L-1] -> ... ->
+    // g[0] (-> dx), every g[l] written for the weight-gradient GEMM below.  A narrow input layer (<= 32 columns) needs the
+    // K-major shadow copy as its N-major operand; without one that last dX step stays a GEMM launch.
+    int chain_down_to = -1;                      // layers [chain_down_to, L-1] had their dX computed by the chain
+    if (t.bits_valid && chain_shape_ok(m) && !(dropped && m.drop > 0.f)) {
+        const int last_l = need_dx ? ((m.dims[0] > 32 || wt != nullptr) ? 0 : 1) : 1;
+        if (m.L - 1 >= last_l) {
+            ChainArgs a{};
+            a.rows = rows;
+            a.in_mode = 1;
+            a.src = t.g[m.L - 1]; a.ldsrc = m.ld[m.L]; a.K0 = m.dims[m.L];
+            a.nb = t.G; a.sSrc = cap * m.ld[m.L]; a.src_div = 1;
+            a.fast = 0;
+            const long long units = (t.cap + 63) / 64;
+            int k = 0;
+            for (int l = m.L - 1; l >= last_l; --l, ++k) {
+                ChainStep& st = a.step[k];
+                st.Bmat = params + m.offW[l];          // [out][in]: K-major for g_l @ W_l
+                st.ldb = m.dims[l];
+                st.Bt = wt ? wt + m.offW[l] : nullptr; // [in][out]: N-major (narrow steps only)
+                st.ldbt = m.dims[l + 1];
+                st.K = m.dims[l + 1];
+                st.N = m.dims[l];
+                st.sW = pstride;
+                if (l > 0) { st.bits_in = t.bits[l - 1]; st.sBits = units * CH_THREADS; }
+                st.out = (l == 0) ? t.dx : t.g[l - 1];
+                st.ldout = m.ld[l];
+                st.sOut = cap * m.ld[l];
+            }
+            a.n_steps = k;
+            int rc = ac_chain_launch(&a, 1, s);
+            if (rc) return rc;
+            chain_down_to = last_l;
+        }
+    }
     for (int l = m.L - 1; l >= 0; --l) {
         if (l == 0 && !need_dx) break;
+        if (chain_down_to >= 0 && l >= chain_down_to) continue;
         const bool drop = l > 0 && dropped && m.drop > 0.f;
         const bool post = l > 0 && (m.ln || drop);
         GemmBatched b{};
@@ -753,7 +890,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
         hipLaunchKernelGGL(ac_critic_kernel, dim3(c->PG), dim3(256), 0, s, a);
         LAUNCH_CHECK("ac_critic");
     }
-    if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_b, rows, nq, Q.drop > 0.f, c->gq, false, s))) return rc;
+    if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_b, rows, nq, Q.drop > 0.f, c->gq, false, s, -1, WT(c->wt_q)))) return rc;
     if (out->q_grads)
         HIP_TRY(hipMemcpyAsync(out->q_grads, c->gq, (size_t)c->QG * Q.P * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (cfg->grad_hook) {
@@ -789,7 +926,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                 hipLaunchKernelGGL(ac_actor_loss_kernel, dim3(c->PG), dim3(256), 0, s, a);
                 LAUNCH_CHECK("ac_actor_loss");
             }
-            if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_b, rows, nq, Q.drop > 0.f, nullptr, true, s))) return rc;
+            if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_b, rows, nq, Q.drop > 0.f, nullptr, true, s, -1, WT(c->wt_q)))) return rc;
             {
                 HeadBwdArgs a{};
                 a.dx_q = c->tq_b.dx; a.dxq_gstride = (long long)c->cap * Q.ld[0];
@@ -802,7 +939,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                 hipLaunchKernelGGL(ac_head_bwd_kernel, dim3((c->PG * rows + 255) / 256), dim3(256), 0, s, a);
                 LAUNCH_CHECK("ac_head_bwd");
             }
-            if ((rc = mlp_backward(P, st->pol, P.P, c->tp_b, rows, 1, false, c->gp, false, s))) return rc;
+            if ((rc = mlp_backward(P, st->pol, P.P, c->tp_b, rows, 1, false, c->gp, false, s, -1, WT(c->wt_pol)))) return rc;
             if (out->pol_grads)
                 HIP_TRY(hipMemcpyAsync(out->pol_grads, c->gp, (size_t)c->PG * P.P * sizeof(float), hipMemcpyDeviceToDevice, s));
             if (cfg->grad_hook) {

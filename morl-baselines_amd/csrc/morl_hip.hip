@@ -140,7 +140,6 @@ struct morl_ctx {
     int64_t offWt[MORL_MAX_LAYERS];          // Wt_l [round_up(in, 64)][ldn] (zero rows / columns beyond [in][out])
     int64_t offWb[MORL_MAX_LAYERS];          // row-padded copy of W_l for the backward chain (out % 64 != 0), or -1
     int ldn[MORL_MAX_LAYERS];
-    int multi_tm = 64;       // row tile of the three-forward-passes launch (64: 2 workgroups / CU, 32: 3 / CU)
     int dw_mode = 3;         // weight-gradient engine: 3 balanced wave-layout tiles (dw_tiles.h); older engines kept for A/B
                              // runs: 0 wave-level tiles (dw_wave.h), 1 double-buffered LDS tiles,
                              // 2 single-buffered LDS tiles (the per-layer engine's)
@@ -160,11 +159,9 @@ struct morl_ctx {
     const float* wt_online_src = nullptr;   // parameters wt_online was transposed from by this step's morl_envelope_slabs
                                          // (cleared by every optimiser step of the library)
     size_t ev_used = 0;
-    int chain_gen = 2;       // 2: M-major persistent chain (mlp_chain2.h); 1: round-1 kernels (mlp_chain.h), kept for A/B runs
     int chain_stagger = 3;   // mlp_chain2: job-order staggering of co-resident workgroups (Chain2Multi::stagger)
     unsigned int* cu_tickets = nullptr;
     int chain_sched = 1;     // mlp_chain2: instruction interleave pinned with sched_group_barrier (0: hipcc's own schedule)
-    bool gen2_ok = false;    // architecture fits mlp_chain2 (narrow steps contract over a multiple of 4)
     int fused_tm = 0;        // 0: pick the row tile per launch (>= 2 workgroups per CU when possible), else 64 / 32
     int num_cus = 256;
 };
@@ -291,13 +288,10 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         if (net->dims[l + 1] <= 32 && (net->dims[l] & 1)) c->fused_ok = false;           // forward narrow step: K = dims[l]
         if (l >= 1 && net->dims[l] <= 32 && (net->dims[l + 1] & 1)) c->fused_ok = false;  // backward narrow step: K = dims[l+1]
     }
-    c->gen2_ok = c->fused_ok;
-    for (int l = 0; l < c->L; ++l) {
-        if (net->dims[l + 1] <= 32 && (net->dims[l] & 3)) c->gen2_ok = false;            // forward narrow step: K = dims[l]
-        if (l >= 1 && net->dims[l] <= 32 && (net->dims[l + 1] & 3)) c->gen2_ok = false;   // backward narrow step: K = dims[l+1]
+    for (int l = 0; l < c->L; ++l) {     // narrow steps contract over a multiple of 4
+        if (net->dims[l + 1] <= 32 && (net->dims[l] & 3)) c->fused_ok = false;            // forward narrow step: K = dims[l]
+        if (l >= 1 && net->dims[l] <= 32 && (net->dims[l + 1] & 3)) c->fused_ok = false;   // backward narrow step: K = dims[l+1]
     }
-    if (c->ld0 & 3) c->gen2_ok = false;
-    if (const char* e = getenv("MORL_CHAIN_GEN")) c->chain_gen = (atoi(e) == 1) ? 1 : 2;
     if (const char* e = getenv("MORL_CHAIN_SCHED")) c->chain_sched = atoi(e) ? 1 : 0;
     if (const char* e = getenv("MORL_CHAIN_STAGGER")) c->chain_stagger = std::max(0, std::min(3, atoi(e)));
     {
@@ -432,7 +426,11 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
     Chain2Multi m{};
     m.n = n;
     int units = 0;
-    for (int q = 0; q < n; ++q) { m.p[q] = chains[q]; m.unit_start[q] = units; units += (chains[q].rows + 63) / 64; }
+    for (int q = 0; q < n; ++q) {
+        m.p[q] = chains[q];
+        m.unit_start[q] = units;
+        units += std::max(1, chains[q].nb) * ((chains[q].rows + 63) / 64);
+    }
     for (int q = n; q <= CH_MAX_MULTI; ++q) m.unit_start[q] = units;
     int S = 2 * c->num_cus;
     if (const char* e = getenv("MORL_CHAIN_SLOTS")) S = std::max(1, atoi(e));   // (tuning)
@@ -464,30 +462,7 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
     return MORL_OK;
 }
 
-// Row tile: 64 rows per workgroup amortises the weight stream best, 32 rows doubles the workgroup count; pick 32
-// whenever 64 would leave fewer than two workgroups per CU (their epilogues / barriers then overlap).
-static int launch_chain(morl_ctx* c, const ChainArgs& a, hipStream_t s) {
-    if (c->chain_gen == 2 && c->gen2_ok) return chain2_launch(c, &a, 1, s);
-    int tm = c->fused_tm;
-    if (tm == 0) tm = ((a.rows + 63) / 64 >= 2 * c->num_cus) ? 64 : 32;
-    size_t slot = 0;
-    if (c->timing) {
-        if (c->ev_used == c->ev_start.size()) {
-            hipEvent_t e0, e1;
-            HIP_TRY(hipEventCreate(&e0));
-            HIP_TRY(hipEventCreate(&e1));
-            c->ev_start.push_back(e0);
-            c->ev_stop.push_back(e1);
-        }
-        slot = c->ev_used++;
-        HIP_TRY(hipEventRecord(c->ev_start[slot], s));
-    }
-    if (tm == 64) hipLaunchKernelGGL(mlp_chain64_kernel, dim3((a.rows + 63) / 64), dim3(CH_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(mlp_chain32_kernel, dim3((a.rows + 31) / 32), dim3(CH_THREADS), 0, s, a);
-    LAUNCH_CHECK("mlp_chain");
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev_stop[slot], s));
-    return MORL_OK;
-}
+static int launch_chain(morl_ctx* c, const ChainArgs& a, hipStream_t s) { return chain2_launch(c, &a, 1, s); }
 
 // forward chain over rows assembled on the fly from (obs, weights); save => hidden activations to ctx->h[]
 static ChainArgs make_forward_chain(morl_ctx* c, const float* params, const float* wt, const float* obs,
@@ -498,7 +473,7 @@ static ChainArgs make_forward_chain(morl_ctx* c, const float* params, const floa
     a.rows = rows;
     a.in_mode = 0;
     a.fast = 1;
-    if (c->chain_gen == 2 && c->gen2_ok) emit_bits = true;   // mlp_chain2's backward takes its ReLU masks as bits only
+    emit_bits = true;   // the backward chain takes its ReLU masks as bits only
     a.obs = obs; a.weights = weights;
     a.B = B; a.W = W; a.D = c->net.obs_dim; a.R = c->net.reward_dim; a.row_order = row_order;
     for (int l = 0; l < c->L; ++l) {
@@ -536,36 +511,7 @@ static int chain_forward_x3(morl_ctx* c, const ChainArgs& a0, const ChainArgs& a
     return chain_forward_multi(c, a, 3, s);
 }
 // up to CH_MAX_MULTI forward passes in one launch
-static int chain_forward_multi(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s) {
-    if (c->chain_gen == 2 && c->gen2_ok) return chain2_launch(c, chains, n, s);
-    ChainMulti m{};
-    m.n = n;
-    long long rows_all = 0;
-    for (int q = 0; q < n; ++q) { m.p[q] = chains[q]; rows_all += chains[q].rows; }
-    // 64-row tiles unless that leaves the chip under-filled (small shards of a weight-sharded job): then 32
-    int tm = c->multi_tm;
-    if (tm == 64 && (rows_all + 63) / 64 < 2 * c->num_cus) tm = 32;
-    int t = 0;
-    for (int q = 0; q < n; ++q) { m.tile_start[q] = t; t += (m.p[q].rows + tm - 1) / tm; }
-    for (int q = n; q <= CH_MAX_MULTI; ++q) m.tile_start[q] = t;
-    size_t slot = 0;
-    if (c->timing) {
-        if (c->ev_used == c->ev_start.size()) {
-            hipEvent_t e0, e1;
-            HIP_TRY(hipEventCreate(&e0));
-            HIP_TRY(hipEventCreate(&e1));
-            c->ev_start.push_back(e0);
-            c->ev_stop.push_back(e1);
-        }
-        slot = c->ev_used++;
-        HIP_TRY(hipEventRecord(c->ev_start[slot], s));
-    }
-    if (tm == 64) hipLaunchKernelGGL(mlp_chain64_multi_kernel, dim3(t), dim3(CH_THREADS), 0, s, m);
-    else hipLaunchKernelGGL(mlp_chain32_multi_kernel, dim3(t), dim3(CH_THREADS), 0, s, m);
-    LAUNCH_CHECK("mlp_chain_multi");
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev_stop[slot], s));
-    return MORL_OK;
-}
+static int chain_forward_multi(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s) { return chain2_launch(c, chains, n, s); }
 
 // backward chain: g[L-1] = dq  ->  g[l-1] = (g[l] @ W_l) * (h[l] > 0), every g[l-1] written to ctx->g[]
 static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_t s) {
@@ -611,7 +557,7 @@ extern "C" int morl_ctx_set_dw_mode(morl_ctx* c, int mode) {
     const int dw = mode % 10, mt = mode / 10;
     if (dw < 0 || dw > 3 || mt < 0 || mt > 1) return fail(MORL_ERR_ARG, "bad tuning mode %d", mode);
     c->dw_mode = dw;
-    c->multi_tm = mt ? 32 : 64;
+    (void)mt;
     return MORL_OK;
 }
 
@@ -817,7 +763,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         c->bits_valid = false;
         if (c->use_fused) {
             if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights_i, B, WI, 1, rows, true, c->qm, c->ldq, s))) return rc;
-            c->bits_valid = (c->chain_gen == 2 && c->gen2_ok);   // (the second-generation forward always emits the sign bits)
+            c->bits_valid = true;   // (the layer-fused forward always emits the sign bits)
         } else {
             if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
         }
@@ -869,6 +815,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         }
     // all dW / db of the step in one split-K launch
     int splits;
+    bool per_done = false;
     Dw2Ranges ranges{};
     bool dw2_ok = (c->ld0 & 3) == 0 && (c->ldq & 3) == 0;      // dw_tiles.h streams 16-byte pieces of 16-byte aligned rows
     for (int l = 1; l < L; ++l) dw2_ok = dw2_ok && (n.dims[l] & 3) == 0;
@@ -926,7 +873,17 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         }
         ranges.n = r;
         a.jobs = jobs;
-        hipLaunchKernelGGL(dw_tiles_kernel, dim3(jobs), dim3(DW2_THREADS), 0, s, a);
+        int extra = 0;
+        if (cfg->per_tree && i_offset == 0 && out->priority && B <= ST_MAX_B) {     // the step's PER update rides along
+            a.per.tree = cfg->per_tree; a.per.idx = cfg->per_idx; a.per.raw = out->priority;
+            a.per.running_max = cfg->per_running_max; a.per.pr_out = nullptr;
+            a.per.n_levels = cfg->per_levels; a.per.B = B; a.per.alpha = cfg->per_alpha;
+            extra = 1;
+            per_done = true;
+        }
+        a.stagger = 0;
+        if (const char* e = getenv("MORL_DW_STAGGER")) a.stagger = std::max(0, atoi(e));     // (tuning)
+        hipLaunchKernelGGL(dw_tiles_kernel, dim3(jobs + extra), dim3(DW2_THREADS), 0, s, a);
         LAUNCH_CHECK("dw_tiles");
     } else if (c->dw_wave_ok && c->use_fused && c->dw_mode == 0) {
         // wave-level tiles (dw_wave.h): aim at one wave per SIMD over the whole chip
@@ -1007,6 +964,14 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
                                B * td_groups, 1.0 / ((double)rows_total * R), 1.0 / (double)rows_total, lam, out->loss);
         LAUNCH_CHECK("grad_reduce");
     }
+    if (cfg->per_tree && i_offset == 0 && out->priority && !per_done) {
+        if (B > ST_MAX_B) return fail(MORL_ERR_ARG, "PER update inside the step: B=%d > %d", B, ST_MAX_B);
+        SumTreeUpdate u{};
+        u.tree = cfg->per_tree; u.idx = cfg->per_idx; u.raw = out->priority; u.running_max = cfg->per_running_max;
+        u.n_levels = cfg->per_levels; u.B = B; u.alpha = cfg->per_alpha;
+        hipLaunchKernelGGL(sumtree_update_kernel, dim3(1), dim3(ST_THREADS), 0, s, u);
+        LAUNCH_CHECK("sumtree_update(step)");
+    }
     if (out->q_values) {
         const int AR = A * R;
         hipLaunchKernelGGL(copy_rows_kernel, dim3(stream_grid((long long)rows * AR, 256)), dim3(256), 0, s,
@@ -1055,6 +1020,8 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         return fail(MORL_ERR_ARG, "NULL array");
     if (cfg->apply_step && (!exp_avg || !exp_avg_sq)) return fail(MORL_ERR_ARG, "Adam state is NULL");
     if (cfg->apply_step && cfg->adam_step < 1) return fail(MORL_ERR_ARG, "adam_step must be >= 1");
+    if (cfg->per_tree && (!cfg->per_idx || !cfg->per_running_max || cfg->per_levels < 1 || cfg->per_levels > 40 || !out || !out->priority))
+        return fail(MORL_ERR_ARG, "per_tree needs per_idx, per_running_max, per_levels and out->priority");
     hipStream_t s = (hipStream_t)stream;
     const morl_net_desc& n = c->net;
     const int D = n.obs_dim, R = n.reward_dim, A = n.n_actions;
@@ -1306,8 +1273,10 @@ extern "C" int morl_sumtree_update(double* tree, int n_levels, const int64_t* id
     if (!tree || !idx || !raw || !running_max) return fail(MORL_ERR_ARG, "NULL array");
     if (n_levels < 1 || n_levels > 40) return fail(MORL_ERR_ARG, "bad n_levels");
     if (B < 1 || B > ST_MAX_B) return fail(MORL_ERR_ARG, "B=%d outside [1,%d]", B, ST_MAX_B);
-    hipLaunchKernelGGL(sumtree_update_kernel, dim3(1), dim3(ST_THREADS), 0, (hipStream_t)stream, tree, n_levels, idx, raw, B,
-                       (float)alpha, running_max, pr_out);
+    SumTreeUpdate u{};
+    u.tree = tree; u.idx = idx; u.raw = raw; u.running_max = running_max; u.pr_out = pr_out;
+    u.n_levels = n_levels; u.B = B; u.alpha = (float)alpha;
+    hipLaunchKernelGGL(sumtree_update_kernel, dim3(1), dim3(ST_THREADS), 0, (hipStream_t)stream, u);
     LAUNCH_CHECK("sumtree_update");
     return MORL_OK;
 }

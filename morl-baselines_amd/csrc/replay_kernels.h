@@ -189,28 +189,39 @@ __global__ __launch_bounds__(64) void sumtree_set_kernel(double* __restrict__ tr
 //   children in ascending index order (np.add.at order) -> bit-exact float64 tree.
 constexpr int ST_MAX_B = 1024;
 constexpr int ST_THREADS = 1024;   // 16 waves: the tree levels are updated concurrently, one wave per level
-__global__ __launch_bounds__(ST_THREADS) void sumtree_update_kernel(double* __restrict__ tree, int n_levels,
-                                                             const int64_t* __restrict__ idx,
-                                                             const float* __restrict__ raw, int B, float alpha,
-                                                             double* __restrict__ running_max,
-                                                             double* __restrict__ pr_out) {
-    __shared__ long long s_key[ST_MAX_B];   // (index << 11) | position  -> sort gives ascending index, first position first
-    __shared__ double s_diff[ST_MAX_B];
-    __shared__ long long s_node[ST_MAX_B];
-    __shared__ float s_pr[ST_MAX_B];
-    __shared__ float s_max[ST_THREADS / 64];
+constexpr int ST_LDS_BYTES = ST_MAX_B * (8 + 8 + 8 + 4) + 64 * 4;   // scratch of sumtree_update_body
+
+struct SumTreeUpdate {
+    double* tree;
+    const int64_t* idx;
+    const float* raw;
+    double* running_max;
+    double* pr_out;          // or NULL
+    int n_levels, B;
+    float alpha;
+};
+
+// The update as a workgroup-level routine (any block size that is a multiple of 64; `lds` = ST_LDS_BYTES of scratch, 8-byte
+// aligned), so that it can run as its own launch or ride as an extra workgroup of another kernel of the step
+// (dw_tiles_kernel: the tree update only depends on the TD priorities and nothing of the backward pass depends on it).
+__device__ __forceinline__ void sumtree_update_body(const SumTreeUpdate& a, void* lds) {
+    long long* s_key = reinterpret_cast<long long*>(lds);   // (index << 11) | position -> ascending index, first position first
+    double* s_diff = reinterpret_cast<double*>(s_key + ST_MAX_B);
+    long long* s_node = reinterpret_cast<long long*>(s_diff + ST_MAX_B);
+    float* s_pr = reinterpret_cast<float*>(s_node + ST_MAX_B);
+    float* s_max = s_pr + ST_MAX_B;
+    double* __restrict__ tree = a.tree;
+    const int n_levels = a.n_levels, B = a.B;
     const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
-    const float rmax = (float)(*running_max);
+    const float rmax = (float)(*a.running_max);
     float lmax = -INFINITY;
     for (int k = tid; k < B; k += nt) {
-        {
-            // alpha < 0: raw already is the priority (plain PrioritizedReplayBuffer.update_priorities)
-            const float p = (alpha < 0.f) ? raw[k] : powf(__fadd_rn(raw[k], rmax), alpha);
-            s_pr[k] = p;
-            if (pr_out) pr_out[k] = (double)p;
-            lmax = fmaxf(lmax, p);
-            s_key[k] = (idx[k] << 11) | (long long)k;
-        }
+        // alpha < 0: raw already is the priority (plain PrioritizedReplayBuffer.update_priorities)
+        const float p = (a.alpha < 0.f) ? a.raw[k] : powf(__fadd_rn(a.raw[k], rmax), a.alpha);
+        s_pr[k] = p;
+        if (a.pr_out) a.pr_out[k] = (double)p;
+        lmax = fmaxf(lmax, p);
+        s_key[k] = (a.idx[k] << 11) | (long long)k;
     }
     lmax = wave_max(lmax);
     if (lane_id() == 0) s_max[wave_id()] = lmax;
@@ -219,18 +230,23 @@ __global__ __launch_bounds__(ST_THREADS) void sumtree_update_kernel(double* __re
         float m = s_max[0];
         for (int w = 1; w < nt / 64; ++w) m = fmaxf(m, s_max[w]);
         // python max(self.min_priority, priorities.max()): keeps the old value unless the new one is larger
-        if ((double)m > *running_max) *running_max = (double)m;
+        if ((double)m > *a.running_max) *a.running_max = (double)m;
     }
     __syncthreads();
-    // rank sort (keys are unique: they embed the position): rank = number of smaller keys, one pass over LDS broadcasts
-    long long my_key = 0;
-    int my_rank = 0;
-    if (tid < B) {
-        my_key = s_key[tid];
-        for (int j = 0; j < B; ++j) my_rank += (s_key[j] < my_key) ? 1 : 0;
+    // rank sort (keys are unique: they embed the position): rank = number of smaller keys, one pass over LDS broadcasts.
+    // Ranks first (all reads), then the scatter (all writes).
+    long long my_key[ST_MAX_B / 64 > 4 ? 4 : ST_MAX_B / 64];     // up to 4 keys per thread (B <= 4 * blockDim)
+    int my_rank[4];
+    int n_mine = 0;
+    for (int k = tid; k < B && n_mine < 4; k += nt, ++n_mine) {
+        const long long key = s_key[k];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) rank += (s_key[j] < key) ? 1 : 0;
+        my_key[n_mine] = key;
+        my_rank[n_mine] = rank;
     }
     __syncthreads();
-    if (tid < B) s_key[my_rank] = my_key;
+    for (int q = 0; q < n_mine; ++q) s_key[my_rank[q]] = my_key[q];
     __syncthreads();
     // leaf diffs: the first occurrence of an index carries (priority - leaf), its duplicates 0.0 (x + 0.0 == x), and
     // EVERY entry keeps its node id so that s_node is non-decreasing (run boundaries by comparison / binary search)
@@ -271,6 +287,11 @@ __global__ __launch_bounds__(ST_THREADS) void sumtree_update_kernel(double* __re
             tree[level_off(l) + anc] = acc;
         }
     }
+}
+
+__global__ __launch_bounds__(ST_THREADS) void sumtree_update_kernel(SumTreeUpdate a) {
+    __shared__ __attribute__((aligned(8))) unsigned char lds[ST_LDS_BYTES];
+    sumtree_update_body(a, lds);
 }
 
 }  // namespace morl

@@ -255,11 +255,11 @@ class Envelope(MOPolicy, MOAgent):
                 self.q_net.ctx, self.q_net.flat, self.target_q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq,
                 b_obs, b_next_obs, b_actions.reshape(-1).to(th.int32), b_rewards, b_dones.reshape(-1), sampled_w,
                 gamma=self.gamma, lr=self.learning_rate, adam_step=self._adam_step, max_grad_norm=self.max_grad_norm,
-                homotopy_lambda=float(self.homotopy_lambda), envelope=self.envelope, outputs=None)
+                homotopy_lambda=float(self.homotopy_lambda), envelope=self.envelope, outputs=None,
+                per=self.replay_buffer.per_update_args(b_inds, self.per_alpha) if self.per else None)
             self._losses.append(self._out["loss"])
             if self.per:
-                priority = self._out["priority"]
-                self.replay_buffer.update_priorities_from_td(b_inds, priority, self.per_alpha)
+                priority = self._out["priority"]      # (the sum tree was updated inside the step: envelope.py:329-334)
 
         self._finish_update(priority)
 

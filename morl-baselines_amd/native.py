@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
 
 MORL_MAX_LAYERS = 8
 MORL_MAX_OBJ = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class NetDesc(C.Structure):
@@ -28,7 +28,9 @@ class UpdateCfg(C.Structure):
     _fields_ = [("gamma", C.c_float), ("homotopy_lambda", C.c_float), ("max_grad_norm", C.c_float),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("adam_step", C.c_int32), ("envelope", C.c_int32), ("apply_step", C.c_int32),
-                ("main_forward_done", C.c_int32), ("slab_parts", C.c_int32)]
+                ("main_forward_done", C.c_int32), ("slab_parts", C.c_int32),
+                ("per_tree", C.c_void_p), ("per_idx", C.c_void_p), ("per_running_max", C.c_void_p),
+                ("per_levels", C.c_int32), ("per_alpha", C.c_float)]
 
 
 class UpdateOut(C.Structure):

@@ -258,8 +258,10 @@ def envelope_update(ctx: QNetContext, params_online: th.Tensor, params_target: t
                     weights: th.Tensor, *, gamma: float, lr: float, adam_step: int, max_grad_norm: Optional[float],
                     homotopy_lambda: float = 0.0, envelope: bool = True, beta1: float = 0.9, beta2: float = 0.999,
                     eps: float = 1e-8, apply_step: bool = True, outputs: Optional[Dict[str, th.Tensor]] = None,
-                    debug: bool = False) -> Dict[str, th.Tensor]:
-    """One Envelope gradient step (envelope.py:269-334) entirely on the device."""
+                    debug: bool = False, per=None) -> Dict[str, th.Tensor]:
+    """One Envelope gradient step (envelope.py:269-334) entirely on the device.  ``per`` = (tree, n_levels, idx, alpha,
+    running_max): the step also applies its PER priority update to the device sum tree (envelope.py:329-334), as an extra
+    workgroup of the weight-gradient launch."""
     lib = ctx.lib
     for t, dt, n in ((params_online, th.float32, "params_online"), (params_target, th.float32, "params_target"),
                      (grads, th.float32, "grads"), (obs, th.float32, "obs"), (next_obs, th.float32, "next_obs"),
@@ -287,6 +289,14 @@ def envelope_update(ctx: QNetContext, params_online: th.Tensor, params_target: t
                     max_grad_norm=-1.0 if max_grad_norm is None else float(max_grad_norm), lr=lr, beta1=beta1,
                     beta2=beta2, eps=eps, adam_step=int(adam_step), envelope=int(bool(envelope)),
                     apply_step=int(bool(apply_step)))
+    if per is not None:
+        tree, n_levels, idx, alpha, running_max = per
+        _chk(tree, th.float64, "per tree"); _chk(idx, th.int64, "per idx"); _chk(running_max, th.float64, "per running_max")
+        lib.check_device(tree, idx, running_max)
+        if idx.numel() != B:
+            raise ValueError("per: one sampled index per transition of the batch")
+        cfg.per_tree, cfg.per_idx, cfg.per_running_max = _ptr(tree), _ptr(idx), _ptr(running_max)
+        cfg.per_levels, cfg.per_alpha = int(n_levels), float(alpha)
     out = UpdateOut(**{k: _ptr(res.get(k)) for k, _ in UpdateOut._fields_})
     lib.check(lib.lib.morl_envelope_update(
         ctx.handle, _ptr(params_online), _ptr(params_target), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(obs),

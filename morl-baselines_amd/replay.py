@@ -343,6 +343,11 @@ class PrioritizedReplayBuffer(ReplayBuffer):
             ops.sumtree_update(self.lib, self.tree_dev, self.n_levels, u_idx[b:b + self.TREE_BLOCK].contiguous(),
                                u_pr[b:b + self.TREE_BLOCK].contiguous(), -1.0, self.running_max)
 
+    def per_update_args(self, idx: th.Tensor, alpha: float):
+        """What ``ops.envelope_update(per=...)`` needs to apply ``update_priorities_from_td`` inside the gradient step."""
+        self.flush()
+        return (self.tree_dev, self.n_levels, idx, float(alpha), self.running_max)
+
     def update_priorities_from_td(self, idx: th.Tensor, raw_abs_td: th.Tensor, alpha: float) -> None:
         """Device-only path of ``envelope.py:329-334``: priority = (|td . w| + min_priority) ** alpha, then update."""
         self.flush()
