@@ -31,7 +31,7 @@ extern "C" {
 
 #define MORL_MAX_LAYERS 8   /* linear layers per network */
 #define MORL_MAX_OBJ 8      /* reward dimension R */
-#define MORL_ABI_VERSION 5
+#define MORL_ABI_VERSION 6
 
 typedef enum morl_status {
     MORL_OK = 0,
@@ -214,6 +214,26 @@ int morl_envelope_update_shard(morl_ctx* ctx, const float* params_online, float*
                                const morl_update_out* out, void* stream);
 int morl_clip_adam(morl_ctx* ctx, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                    const morl_update_cfg* cfg, float* grad_norm_out, void* stream);
+
+/* ---- the collectives of the sharded step (the reference has no counterpart: common/morl_algorithm.py:42
+ * places everything on one device).  One process per GPU, RCCL over xGMI, bound at run time (an instance the process already
+ * loaded -- PyTorch's -- is reused).  Nothing synchronises the host.
+ *   morl_comm_unique_id   rank 0 draws the 128-byte id and hands it to the other ranks (any side channel)
+ *   morl_comm_init        every rank, collectively; blocks until all `world` ranks joined (current HIP device = the rank's GPU)
+ *   morl_allgather_q_begin  all-gather of the ranks' morl_envelope_slabs outputs into recv [world][count_per_rank], issued on
+ *                         the communicator's own stream behind everything already enqueued on `stream`; what the caller
+ *                         enqueues on `stream` afterwards (morl_envelope_main_forward) runs beside the exchange
+ *   morl_comm_wait        `stream` waits for that all-gather (before morl_envelope_update_shard)
+ *   morl_allreduce_grads  in-place sum over the ranks of the flat [gradient | loss | priorities] buffer, on `stream` */
+#define MORL_COMM_ID_BYTES 128
+typedef struct morl_comm morl_comm;
+int morl_comm_unique_id(void* id_out);
+int morl_comm_init(morl_comm** out, const void* unique_id, int rank, int world);
+int morl_comm_destroy(morl_comm* comm);
+int morl_comm_size(const morl_comm* comm, int* rank, int* world);
+int morl_allgather_q_begin(morl_comm* comm, const float* send, float* recv, int64_t count_per_rank, void* stream);
+int morl_comm_wait(morl_comm* comm, void* stream);
+int morl_allreduce_grads(morl_comm* comm, float* buf, int64_t count, void* stream);
 
 /* ---- polyak_update: common/networks.py:120-139 ------------------------------------------------- */
 int morl_polyak(const float* src, float* dst, float tau, int64_t n, void* stream);

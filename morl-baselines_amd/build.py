@@ -16,7 +16,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmorl_hip.so")
-SOURCES = ["morl_hip.hip", "morl_ac.hip"]
+SOURCES = ["morl_hip.hip", "morl_ac.hip", "morl_comm.hip"]
 HEADERS = ["morl_device.h", "morl_host.h", "gemm_f32.h", "envelope_kernels.h", "mlp_chain.h", "mlp_chain2.h", "dw_wave.h", "dw_tiles.h", "optim_kernels.h",
            "replay_kernels.h", "pareto_kernels.h", "metrics_kernels.h", "ac_kernels.h", "gemm_wave.h", "gpi_kernels.h", "ens_kernels.h"]
 
@@ -66,7 +66,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             out, _ = proc.communicate()
             if proc.returncode != 0:
                 raise RuntimeError("hipcc failed:\n" + out)
-    cmd = base + ["-shared"] + [obj for obj, _ in jobs] + ["-o", LIB_PATH + ".tmp"]
+    cmd = base + ["-shared"] + [obj for obj, _ in jobs] + ["-ldl", "-o", LIB_PATH + ".tmp"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + r.stdout + r.stderr)

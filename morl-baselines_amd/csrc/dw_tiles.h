@@ -51,6 +51,7 @@ struct Dw2Args {
     SumTreeUpdate per;         // per.tree != NULL: one extra workgroup (block `jobs`) applies the step's PER priority update
                                // (prioritized_buffer.py:187-195) -- it only depends on the TD kernel's priorities, nothing here
                                // depends on it, and the launch has a free slot: 16 us of serial tail disappear
+    long long* prof;           // development probe only (tools/probes/dw_probe.hip): [jobs][4] cycle sums of the chunk phases
     int stagger;               // s_sleep units (64 cycles) the second half of the grid waits before starting: the two workgroups of a
                                // CU (blocks b and b + grid/2) run identical chunk loops and would otherwise hit their barriers together
 };
@@ -102,9 +103,12 @@ template <> struct Dw2Shape<0> { static constexpr int BM = 128, BN = 128, TMW = 
 template <> struct Dw2Shape<1> { static constexpr int BM = 128, BN = 64, TMW = 1, TNW = 2; };
 template <> struct Dw2Shape<2> { static constexpr int BM = 32, BN = 128, TMW = 1, TNW = 1; };
 
-template <int LAYOUT>
+template <int LAYOUT, bool PROF = false>
 __device__ __forceinline__ void dw2_tile(const Dw2Problem& g, int tile_m, int tile_n, int split, int rows, long long slab_stride,
-                                         float* sAbase, float* sBbase) {
+                                         float* sAbase, float* sBbase, long long* prof = nullptr) {
+    long long pt[4] = {0, 0, 0, 0}, tprev = 0;
+    if (PROF) tprev = clock64();
+#define DW2_TICK(q) if (PROF) { const long long t_ = clock64(); pt[q] += t_ - tprev; tprev = t_; }
     using S = Dw2Shape<LAYOUT>;
     constexpr int BM = S::BM, BN = S::BN, TMW = S::TMW, TNW = S::TNW;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -142,6 +146,7 @@ __device__ __forceinline__ void dw2_tile(const Dw2Problem& g, int tile_m, int ti
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += DW2_BK) {
         const bool more = k0 + DW2_BK < kend;
+        DW2_TICK(3)
         // next chunk's operands: in flight under this chunk's MFMAs (beyond the slice: zeros, never stored)
         dw2_load<BM>(ra, rg, g.ldg, m0, g.gcols, k0 + DW2_BK);
         dw2_load<BN>(rb, rh, g.ldh, n0, g.hcols, k0 + DW2_BK);
@@ -174,17 +179,27 @@ __device__ __forceinline__ void dw2_tile(const Dw2Problem& g, int tile_m, int ti
         }
 #undef DW2_READ
         __builtin_amdgcn_sched_barrier(0);      // the LDS stores below wait for the loads: keep them below the MFMAs
-        if (do_colsum && (int)threadIdx.x < BM) {
-#pragma unroll 8
-            for (int kk = 0; kk < DW2_BK; ++kk) colsum += sAc[kk * DW2_LD + (int)threadIdx.x];
+        DW2_TICK(0)
+        if (do_colsum) {
+            // db: all 256 threads share the row sums of the chunk (thread -> row tid % BM, k-slice tid / BM), so that no wave
+            // lags behind the others at the barrier below
+            constexpr int PARTS = DW2_THREADS / BM, KPP = DW2_BK / PARTS;
+            const int crow = (int)threadIdx.x % BM, part = (int)threadIdx.x / BM;
+#pragma unroll
+            for (int kk = 0; kk < KPP; ++kk) colsum += sAc[(part * KPP + kk) * DW2_LD + crow];
         }
         if (more) {
             dw2_store<BM>(ra, sAbase + (buf ^ 1) * SBUF);
             dw2_store<BN>(rb, sBbase + (buf ^ 1) * SBUF);
         }
+        DW2_TICK(1)
         __syncthreads();
+        DW2_TICK(2)
         buf ^= 1;
     }
+    if (PROF && prof != nullptr && threadIdx.x == 0)
+        for (int q = 0; q < 4; ++q) prof[q] = pt[q];
+#undef DW2_TICK
     // epilogue: D register r of lane (ci, h) of tile (a, b) is physical row wrow + TMW * ((r & 3) + 8 * (r >> 2) + 4h) + a,
     // physical column wcol + TNW * ci + b
     float* __restrict__ C = g.C + (size_t)split * slab_stride;
@@ -204,11 +219,23 @@ __device__ __forceinline__ void dw2_tile(const Dw2Problem& g, int tile_m, int ti
                 }
             } else if (col < g.N) dst[0] = acc[a][0][r];
         }
-    if (do_colsum && (int)threadIdx.x < BM && m0 + (int)threadIdx.x < g.M)
-        g.colsum[(size_t)split * slab_stride + m0 + (int)threadIdx.x] = colsum;
+    if (do_colsum) {
+        // combine the k-slices in slice order (the operand buffers are free: the loop ended with a barrier)
+        constexpr int PARTS = DW2_THREADS / BM;
+        float* scr = sAbase;
+        scr[threadIdx.x] = colsum;
+        __syncthreads();
+        if ((int)threadIdx.x < BM && m0 + (int)threadIdx.x < g.M) {
+            float t = scr[threadIdx.x];
+#pragma unroll
+            for (int q = 1; q < PARTS; ++q) t += scr[q * BM + (int)threadIdx.x];
+            g.colsum[(size_t)split * slab_stride + m0 + (int)threadIdx.x] = t;
+        }
+    }
 }
 
-__global__ __launch_bounds__(DW2_THREADS, 2) void dw_tiles_kernel(Dw2Args a) {
+template <bool PROF>
+__device__ __forceinline__ void dw_tiles_body(const Dw2Args& a) {
     __shared__ __attribute__((aligned(16))) float sA[2][DW2_BK * DW2_LD];
     __shared__ __attribute__((aligned(16))) float sB[2][DW2_BK * DW2_LD];
     // consecutive jobs = the tiles of one row slice, which share that slice of g_l / h_l: keep them on one XCD's L2
@@ -227,10 +254,12 @@ __global__ __launch_bounds__(DW2_THREADS, 2) void dw_tiles_kernel(Dw2Args a) {
     const int tiles = g.tiles_m * g.tiles_n;
     const int split = local / tiles, tile = local % tiles;
     const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
-    if (g.layout == 0) dw2_tile<0>(g, tm, tn, split, a.rows, a.slab_stride, &sA[0][0], &sB[0][0]);
-    else if (g.layout == 1) dw2_tile<1>(g, tm, tn, split, a.rows, a.slab_stride, &sA[0][0], &sB[0][0]);
-    else dw2_tile<2>(g, tm, tn, split, a.rows, a.slab_stride, &sA[0][0], &sB[0][0]);
+    if (g.layout == 0) dw2_tile<0, PROF>(g, tm, tn, split, a.rows, a.slab_stride, &sA[0][0], &sB[0][0], PROF && a.prof ? a.prof + 4 * job : nullptr);
+    else if (g.layout == 1) dw2_tile<1, PROF>(g, tm, tn, split, a.rows, a.slab_stride, &sA[0][0], &sB[0][0], PROF && a.prof ? a.prof + 4 * job : nullptr);
+    else dw2_tile<2, PROF>(g, tm, tn, split, a.rows, a.slab_stride, &sA[0][0], &sB[0][0], PROF && a.prof ? a.prof + 4 * job : nullptr);
 }
+
+__global__ __launch_bounds__(DW2_THREADS, 2) void dw_tiles_kernel(Dw2Args a) { dw_tiles_body<false>(a); }
 
 // ----------------------------------------------------------------------------------------------------------------------------
 // grads[p] = sum_{s < splits(p)} slabs[s][p] for slabs whose split count differs per parameter range (the layouts above), plus

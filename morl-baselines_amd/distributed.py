@@ -28,6 +28,8 @@ scaling: per-rank rows stay at ``batch_size`` and the job's batch is ``world * b
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 import types
 
 import torch as th
@@ -35,6 +37,41 @@ import torch as th
 from . import ops
 from .acnets import randn
 from .envelope import Envelope, random_weights
+
+
+class NativeComm:
+    """The sharded step's collectives behind the C ABI (``morl_comm_*`` / ``morl_allgather_q_begin`` / ``morl_allreduce_grads``
+    of include/morl_hip.h: RCCL over xGMI inside libmorl_hip.so).  ``torch.distributed`` is only the side channel that hands
+    rank 0's unique id to the other ranks."""
+
+    def __init__(self, lib, dist, device, group=None):
+        self.lib, self.device = lib, th.device(device)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        ident = th.zeros(128, dtype=th.uint8)
+        if self.rank == 0:
+            lib.check(lib.lib.morl_comm_unique_id(C.c_void_p(ident.data_ptr())))
+        ident = ident.to(self.device)
+        dist.broadcast(ident, src=0, group=group)
+        ident = ident.cpu()
+        handle = C.c_void_p()
+        with th.cuda.device(self.device):
+            lib.check(lib.lib.morl_comm_init(C.byref(handle), C.c_void_p(ident.data_ptr()), self.rank, self.world))
+        self.handle = handle.value
+
+    def allgather_begin(self, send: th.Tensor, recv: th.Tensor) -> None:
+        self.lib.check(self.lib.lib.morl_allgather_q_begin(self.handle, send.data_ptr(), recv.data_ptr(), send.numel(),
+                                                           self.lib.stream_of(send)))
+
+    def wait(self, on: th.Tensor) -> None:
+        self.lib.check(self.lib.lib.morl_comm_wait(self.handle, self.lib.stream_of(on)))
+
+    def allreduce(self, buf: th.Tensor) -> None:
+        self.lib.check(self.lib.lib.morl_allreduce_grads(self.handle, buf.data_ptr(), buf.numel(), self.lib.stream_of(buf)))
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.lib.morl_comm_destroy(self.handle)
+            self.handle = None
 
 
 def average_gradients(dist, group=None):
@@ -97,6 +134,14 @@ def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
     agent._grads_x = th.zeros(P + 1 + B0, dtype=th.float32, device=dev)
     agent._grads = agent._grads_x[:P]
     agent._bind_optimizer_state()
+    # collectives: inside libmorl_hip.so (RCCL behind the C ABI) on the GPU; torch.distributed itself for the gloo CPU tests
+    # (and with MORL_COMM=torch)
+    comm = None
+    if dist.get_backend(group) == "nccl" and agent.lib.is_device_build and os.environ.get("MORL_COMM", "native") != "torch":
+        comm = NativeComm(agent.lib, dist, dev, group)
+    agent._shard.comm = comm
+    slab_loc = th.empty((2, B0, Wl, A, R), dtype=th.float32, device=dev)
+    slab_all = th.empty((world, 2, B0, Wl, A, R), dtype=th.float32, device=dev)
 
     def update(self: Envelope):
         self._losses = []
@@ -111,13 +156,19 @@ def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
             ctx = self.q_net.ctx
             w_loc = sampled_w[i0:i0 + Wl].contiguous()
             # 1. local slabs [2][B][Wl][A][R]: both networks in one launch pair
-            loc = ops.envelope_slabs(ctx, self.q_net.flat, self.target_q_net.flat, b_next_obs, w_loc)
+            loc = ops.envelope_slabs(ctx, self.q_net.flat, self.target_q_net.flat, b_next_obs, w_loc, out=slab_loc)
             # 2. one all-gather -> [G][2][B][Wl][A][R], read in place by the TD kernel; while it is in flight ...
-            gathered = th.empty((world,) + tuple(loc.shape), dtype=th.float32, device=self.device)
-            work = dist.all_gather_into_tensor(gathered.view(-1), loc.view(-1), group=group, async_op=True)
+            gathered = slab_all
+            if comm is not None:
+                comm.allgather_begin(loc, gathered)
+            else:
+                work = dist.all_gather_into_tensor(gathered.view(-1), loc.view(-1), group=group, async_op=True)
             # ... the training forward of this rank's rows runs (it does not need the slabs)
             ops.envelope_main_forward(ctx, self.q_net.flat, b_obs, w_loc)
-            work.wait()
+            if comm is not None:
+                comm.wait(gathered)
+            else:
+                work.wait()
             # 3. this rank's TD rows: arg-max over ALL gathered candidates, TD, backward
             self._adam_step += 1
             gx = self._grads_x
@@ -128,7 +179,10 @@ def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
                                       gamma=self.gamma, homotopy_lambda=float(self.homotopy_lambda),
                                       envelope=self.envelope, outputs=outs, main_forward_done=True, slab_parts=world)
             # 4. one all-reduce: flat gradient + loss + priorities
-            dist.all_reduce(gx, op=dist.ReduceOp.SUM, group=group)
+            if comm is not None:
+                comm.allreduce(gx)
+            else:
+                dist.all_reduce(gx, op=dist.ReduceOp.SUM, group=group)
             loss = gx[P].clone()
             # 5. identical optimiser step everywhere
             ops.clip_adam(ctx, self.q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq, lr=self.learning_rate,

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
 
 MORL_MAX_LAYERS = 8
 MORL_MAX_OBJ = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class NetDesc(C.Structure):
@@ -145,6 +145,13 @@ _SIGNATURES = {
     "morl_envelope_update_shard": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p,
                                                                                  C.POINTER(UpdateCfg), C.POINTER(UpdateOut),
                                                                                  C.c_void_p]),
+    "morl_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "morl_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
+    "morl_comm_destroy": (C.c_int, [C.c_void_p]),
+    "morl_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "morl_allgather_q_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "morl_comm_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "morl_allreduce_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "morl_clip_adam": (C.c_int, [C.c_void_p] * 5 + [C.POINTER(UpdateCfg), C.c_void_p, C.c_void_p]),
     "morl_polyak": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
     "morl_pareto_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -65,6 +65,11 @@ static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { 
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 typedef void* hipEvent_t;
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(void** e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, void*, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }

@@ -29,8 +29,8 @@ def build_sim(force=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [_clang(), "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off",
            "-I", SIM_DIR, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           os.path.join(CSRC, "morl_hip.hip"), os.path.join(CSRC, "morl_ac.hip"), os.path.join(SIM_DIR, "hipsim.cpp"),
-           "-o", OUT]
+           os.path.join(CSRC, "morl_hip.hip"), os.path.join(CSRC, "morl_ac.hip"), os.path.join(CSRC, "morl_comm.hip"),
+           os.path.join(SIM_DIR, "hipsim.cpp"), "-ldl", "-o", OUT]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("emulated build failed:\n" + r.stdout + r.stderr)
