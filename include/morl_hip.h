@@ -247,7 +247,8 @@ int morl_pareto_mask(const double* points, int N, int R, int remove_duplicates, 
  * is the volume dominated by the points and dominating ref_point) and expected_utility(front, weights_set) (:71-91,
  * utility = dot).  All arrays are device float64: points / front [N][R], ref_point [R], weights [M][R]; results are
  * one device double each.  workspace: morl_metrics_workspace_doubles(N, R) doubles (the larger of the two calls' needs;
- * M <= 4096 weight vectors).  Exact up to the rounding of a fixed-order fp64 sum; N <= 512 points. */
+ * M <= 4096 weight vectors).  Exact up to the rounding of a fixed-order fp64 sum; fronts of up to 512 points are staged in
+ * LDS, larger ones are read in place; N^R point tests above 4e11 are refused. */
 int64_t morl_metrics_workspace_doubles(int N, int R);
 int morl_hypervolume(const double* points, int N, int R, const double* ref_point, double* workspace, double* hv_out,
                      void* stream);

@@ -15,7 +15,8 @@
 
 namespace morl {
 
-constexpr int HV_MAX_N = 512;     // points and cut coordinates of a front stay in LDS (60 KB at 8 objectives)
+constexpr int HV_MAX_N = 512;     // up to here the points and cut coordinates of a front are staged in LDS (60 KB at 8
+                                  // objectives); larger fronts are read in place (L2-resident)
 constexpr int HV_THREADS = 256;
 constexpr int HV_MAX_BLOCKS = 1024;
 
@@ -25,12 +26,19 @@ __global__ __launch_bounds__(HV_THREADS) void hv_sort_kernel(const double* __res
                                                              const double* __restrict__ ref, double* __restrict__ coords) {
     __shared__ double s_v[HV_MAX_N];
     const int d = (int)blockIdx.x;
-    for (int t = (int)threadIdx.x; t < N; t += (int)blockDim.x) s_v[t] = fmax(pts[(size_t)t * R + d], ref[d]);
-    __syncthreads();
+    const bool staged = N <= HV_MAX_N;
+    const double rd = ref[d];
+    if (staged) {
+        for (int t = (int)threadIdx.x; t < N; t += (int)blockDim.x) s_v[t] = fmax(pts[(size_t)t * R + d], rd);
+        __syncthreads();
+    }
     for (int t = (int)threadIdx.x; t < N; t += (int)blockDim.x) {
-        const double v = s_v[t];
+        const double v = staged ? s_v[t] : fmax(pts[(size_t)t * R + d], rd);
         int rank = 0;
-        for (int j = 0; j < N; ++j) rank += (s_v[j] < v || (s_v[j] == v && j < t)) ? 1 : 0;
+        for (int j = 0; j < N; ++j) {
+            const double u = staged ? s_v[j] : fmax(pts[(size_t)j * R + d], rd);
+            rank += (u < v || (u == v && j < t)) ? 1 : 0;
+        }
         coords[(size_t)d * N + rank] = v;
     }
 }
@@ -42,9 +50,14 @@ __global__ __launch_bounds__(HV_THREADS) void hv_boxes_kernel(const double* __re
     __shared__ double s_pts[HV_MAX_N * MORL_MAX_OBJ];         // points [N][R]
     __shared__ double s_co[HV_MAX_N * (MORL_MAX_OBJ - 1)];    // cut coordinates [R-1][N]
     __shared__ double s_red[HV_THREADS / 64];
-    for (int e = (int)threadIdx.x; e < N * R; e += (int)blockDim.x) s_pts[e] = pts[e];
-    for (int e = (int)threadIdx.x; e < N * (R - 1); e += (int)blockDim.x) s_co[e] = coords[e];
-    __syncthreads();
+    const bool staged = N <= HV_MAX_N;
+    if (staged) {
+        for (int e = (int)threadIdx.x; e < N * R; e += (int)blockDim.x) s_pts[e] = pts[e];
+        for (int e = (int)threadIdx.x; e < N * (R - 1); e += (int)blockDim.x) s_co[e] = coords[e];
+        __syncthreads();
+    }
+    const double* __restrict__ P = staged ? s_pts : pts;      // larger fronts: read in place (every workgroup walks the
+    const double* __restrict__ CO = staged ? s_co : coords;   // same arrays: L2 / L1 resident)
     const double ref_last = ref[R - 1];
     double acc = 0.0;
     for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < n_boxes; b += (long long)gridDim.x * blockDim.x) {
@@ -54,8 +67,8 @@ __global__ __launch_bounds__(HV_THREADS) void hv_boxes_kernel(const double* __re
         for (int d = 0; d < R - 1; ++d) {
             const int i = (int)(rem % N);
             rem /= N;
-            const double hi = s_co[d * N + i];
-            const double lo = (i > 0) ? s_co[d * N + i - 1] : ref[d];
+            const double hi = CO[(size_t)d * N + i];
+            const double lo = (i > 0) ? CO[(size_t)d * N + i - 1] : ref[d];
             upper[d] = hi;
             vol *= (hi - lo);
         }
@@ -63,8 +76,8 @@ __global__ __launch_bounds__(HV_THREADS) void hv_boxes_kernel(const double* __re
         double top = ref_last;
         for (int j = 0; j < N; ++j) {
             bool covers = true;
-            for (int d = 0; d < R - 1; ++d) covers = covers && (s_pts[j * R + d] >= upper[d]);
-            if (covers) top = fmax(top, s_pts[j * R + R - 1]);
+            for (int d = 0; d < R - 1; ++d) covers = covers && (P[(size_t)j * R + d] >= upper[d]);
+            if (covers) top = fmax(top, P[(size_t)j * R + R - 1]);
         }
         acc += vol * (top - ref_last);
     }

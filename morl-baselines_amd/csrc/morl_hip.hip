@@ -1204,8 +1204,7 @@ extern "C" int64_t morl_metrics_workspace_doubles(int N, int R) {
 extern "C" int morl_hypervolume(const double* points, int N, int R, const double* ref_point, double* workspace,
                                 double* hv_out, void* stream) {
     if (!ref_point || !hv_out || (N > 0 && (!points || !workspace))) return fail(MORL_ERR_ARG, "NULL array");
-    if (N < 0 || N > HV_MAX_N || R < 1 || R > MORL_MAX_OBJ)
-        return fail(MORL_ERR_ARG, "bad sizes N=%d R=%d (N <= %d, R <= %d)", N, R, HV_MAX_N, MORL_MAX_OBJ);
+    if (N < 0 || R < 1 || R > MORL_MAX_OBJ) return fail(MORL_ERR_ARG, "bad sizes N=%d R=%d (R <= %d)", N, R, MORL_MAX_OBJ);
     hipStream_t s = (hipStream_t)stream;
     if (N == 0) {
         HIP_TRY(hipMemsetAsync(hv_out, 0, sizeof(double), s));

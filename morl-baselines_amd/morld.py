@@ -92,7 +92,12 @@ class MORLD(MOAgent):
         self.gamma, self.seed = gamma, seed
         self.np_random = rng if rng is not None else np.random.default_rng(self.seed)
         if scalarization_method != "ws":
-            raise NotImplementedError("only the weighted-sum scalarisation ('ws') runs on the HIP engine")
+            # 'tch' has no behaviour to match: the reference hands common/scalarization.py:20-41's NUMPY thunk to MOSAC as
+            # `scalarization` (morld.py:141-146, :198), where it is applied to batched torch tensors
+            # (mosac_continuous_action.py:438-459) -- the thunk enumerates the batch rows into its reward_dim-long
+            # best_so_far list and raises on the first update; every reference example and sweep uses 'ws'
+            raise NotImplementedError("only the weighted-sum scalarisation ('ws') runs on the HIP engine (the reference's "
+                                      "'tch' path does not run with MOSAC either: see the comment above this line)")
         if policy_name not in ("MOSAC", "MOSACDiscrete"):
             raise NotImplementedError("MOSAC / MOSACDiscrete are the sub-problem learners of the HIP engine")
         self.scalarization_method, self.scalarization = scalarization_method, np.dot

@@ -15,6 +15,9 @@ import torch as th
 from .native import NativeLib, load_library
 
 
+PRUNE_ABOVE = 256     # fronts with more points are Pareto-pruned on the device before the hypervolume kernel
+
+
 def _dev(lib: NativeLib, device=None) -> th.device:
     if device is not None:
         return th.device(device)
@@ -50,6 +53,13 @@ def hypervolume(ref_point: np.ndarray, points: List[np.ndarray], lib: Optional[N
     dev = _dev(lib, device)
     ref = _f64(ref_point, dev).reshape(-1)
     pts = _f64(np.array(points), dev).reshape(-1, ref.numel())
+    if pts.shape[0] > PRUNE_ABOVE:
+        # a large archive (the reference's pymoo HV takes any N): dominated and duplicate points add nothing to the dominated
+        # volume, so the device Pareto prune shrinks the front first; what is left may still exceed the LDS-staged size
+        # (it is then read in place) but not the kernel's test budget, which is refused loudly
+        from . import ops
+        keep = ops.pareto_mask(lib, pts, remove_duplicates=True).bool()
+        pts = pts[keep].contiguous()
     return float(hypervolume_device(ref, pts, lib).item())
 
 

@@ -101,16 +101,32 @@ def test_hypervolume_of_the_deep_sea_treasure_front_is_the_published_1155(be):
     assert pi.hypervolume(ref, pts + [np.array([7.0, -9.0]), np.array([1.0, -2.0])], lib=lib, device=dev) == 1155.0
 
 
+def test_hypervolume_of_a_large_archive(be):
+    """More points than the LDS-staged kernel holds (the reference's pymoo HV takes any N): 1 500 points of which most are
+    dominated -- pruned on the device first -- and a 700-point non-dominated 2-D front that stays above the staged size."""
+    lib, dev = be
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(0.0, 1.0, (1500, 3))
+    ref = np.full(3, -0.1)
+    want = mo.hypervolume(ref, list(pts[momdp.non_dominated(pts)])) if hasattr(momdp, "non_dominated") else mo.hypervolume(ref, list(pts))
+    assert pi.hypervolume(ref, list(pts), lib=lib, device=dev) == pytest.approx(want, rel=1e-12)
+    x = np.sort(rng.uniform(0.0, 1.0, 700))
+    front = np.stack([x, 1.0 - x ** 2], axis=1)                      # strictly decreasing: all non-dominated
+    want2 = momdp.hypervolume_2d(front, [-0.5, -0.5])
+    assert pi.hypervolume(np.array([-0.5, -0.5]), list(front), lib=lib, device=dev) == pytest.approx(want2, rel=1e-12)
+
+
 def test_device_hypervolume_edges(be):
     lib, dev = be
     assert pi.hypervolume(np.zeros(2), [np.array([-1.0, 5.0])], lib=lib, device=dev) == 0.0          # nothing above ref
     assert pi.hypervolume(np.zeros(3), [np.array([1.0, 2.0, 3.0])], lib=lib, device=dev) == 6.0
     assert float(pi.hypervolume_device(th.zeros(2, dtype=th.float64, device=dev), th.zeros((0, 2), dtype=th.float64, device=dev),
                                        lib).item()) == 0.0
-    with pytest.raises(Exception):
-        pi.hypervolume(np.zeros(2), list(np.ones((513, 2))), lib=lib, device=dev)                     # over the LDS-resident limit
-    with pytest.raises(Exception):
-        pi.hypervolume(np.zeros(8), list(np.ones((200, 8))), lib=lib, device=dev)                     # 200^7 boxes: refused, loudly
+    # 513 copies of one point: beyond the LDS-staged size, pruned to a single point on the device first
+    assert pi.hypervolume(np.zeros(2), list(np.ones((513, 2))), lib=lib, device=dev) == 1.0
+    with pytest.raises(Exception):                                                                    # 200^7 boxes: refused, loudly
+        pi.hypervolume_device(th.zeros(8, dtype=th.float64, device=dev),
+                              th.rand((200, 8), dtype=th.float64, device=dev) + 0.5, lib)
 
 
 def test_device_expected_utility_matches_reference_golden(be):
