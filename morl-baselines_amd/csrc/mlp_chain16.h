@@ -1,0 +1,335 @@
+// Layer-fused MLP engine, SMALL-ROW variant (gfx950, wave64): 16-row tiles on v_mfma_f32_16x16x4_f32.
+//
+// Same contract and argument structures as mlp_chain2.h (ChainArgs / ChainStep of mlp_chain.h, activations M-major in LDS,
+// weights streamed L2 -> registers, deferred LDS -> HBM saves), for launches whose row count cannot fill the chip with
+// 32 / 64-row tiles: the 128-row batches of the actor-critic learners (one 32-row tile carries a whole 256 x 256 layer on ONE
+// CU: 7 us of MFMA per layer, 4-8 busy CUs per pass) and the 2 048-row shards of an 8-GPU strong-scaled Envelope step.
+// A 16-row tile halves the per-workgroup MFMA time again and doubles the workgroups; a tile's LDS footprint is 16.6 KB and its
+// waves need ~110 registers, so four tiles share a CU.
+//
+//   MFMA 16x16x4: lane l supplies A[row = l & 15][k = l >> 4] and B[k = l >> 4][col = l & 15]; D register r of lane l is
+//   row (l >> 4) * 4 + r, column l & 15.  Exact fp32, k-ordered fma chain like the 32x32x2 form.
+//   * A operand: lane (row, kq) reads sAct[row][16c + 4kq .. +3] as ONE ds_read_b128 per 16-deep group c; MFMA step t of the
+//     group multiplies the contraction indices {16c + 4kq + t : kq = 0..3}.
+//   * B operand: the MFMA column slot j of a wave's four column tiles is mapped to the physical columns 64w + 4j + ct, so one
+//     buffer_load_dwordx4 per lane and step feeds all four tiles, and the epilogue writes 16-byte column quads.
+//   * narrow steps (N <= 32): the four waves split the contraction (wave w: k in [64w, 64w + 64)), operand read N-major, two
+//     column tiles of 16, partial tiles summed through LDS in wave order.
+// The ReLU sign bits of a tile are one 16-bit word per work-item (bit ct * 4 + r) in the same buffers mlp_chain2 uses (same
+// bytes per row); a forward / backward pair must use the same tile size -- the host decides from the row count alone.
+#pragma once
+#include "mlp_chain2.h"
+
+namespace morl {
+
+constexpr int C16_TM = 16;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+struct C16BSet {
+    float4 v[8];       // one 32-deep chunk: v[4g + t] = B[k0 + 16g + 4kq + t][64w + 4j .. +3]  (narrow: see c16_load_narrow)
+};
+
+struct C16Desc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int lane_off;      // bytes: (4kq * ldb + 64w + 4j) * 4, or CH_OOB
+    int stride;        // bytes per k-row
+};
+
+__device__ __forceinline__ C16Desc c16_desc(const ChainStep& st, int wave, int j, int kq, int g) {
+    C16Desc d;
+    const int col = wave * 64 + 4 * j;
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bmat + g * st.sW), 0, (st.kpad > st.K ? st.kpad : st.K) * st.ldb * 4, 0x00020000);
+    d.lane_off = (col < st.ldb) ? (4 * kq * st.ldb + col) * 4 : CH_OOB;
+    d.stride = st.ldb * 4;
+    return d;
+}
+
+// rows >= K lie beyond the resource -> 0 (K padding, dummy prefetches)
+__device__ __forceinline__ void c16_load_wide(C16BSet& s, const C16Desc& d, int k0) {
+    const int base = d.lane_off + k0 * d.stride;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int off = base + (16 * (q >> 2) + (q & 3)) * d.stride;
+        s.v[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d.rsrc, off, 0, 0));
+    }
+}
+
+// narrow step: wave w contracts k in [64w, 64w + 64) = 4 groups of 16; lane (j = column within the tile, kq) loads
+// Bt[n][64w + 16c + 4kq .. +3] for the two column tiles n = j and n = 16 + j: v[2c + ct]
+__device__ __forceinline__ void c16_load_narrow(C16BSet& s, const ChainStep& st, int wave, int j, int kq, int g) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bt + g * st.sW), 0, st.N * st.ldbt * 4, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = wave * 64 + 16 * c + 4 * kq;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int n = 16 * ct + j;
+            const int off = (n < st.N && k < st.K) ? (n * st.ldbt + k) * 4 : CH_OOB;     // K is a multiple of 4
+            s.v[2 * c + ct] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+        }
+    }
+}
+
+__device__ __forceinline__ float c16_elem(const float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
+
+// one 16-row tile (rows [row0, row0 + 16) of network g) through the whole chain
+__device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, float* sAct, int g) {
+    constexpr int N_PIECES = 4;                       // 16 rows x 64 quads / 256 threads
+    const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_id();
+    const int kq = lane >> 4, j = lane & 15;
+    const int col0 = wave * 64 + 4 * j;               // first of this lane's four physical output columns (wide steps)
+
+    C16BSet bx, by;
+    const bool first_wide = p.step[0].N > 32;
+    C16Desc dcur = c16_desc(p.step[0], wave, j, kq, g);
+    if (first_wide) c16_load_wide(bx, dcur, 0);
+    else c16_load_narrow(bx, p.step[0], wave, j, kq, g);
+
+    // ---- input tile -> sAct[m][k], zero-padded to the columns the first step multiplies --------------------------------
+    {
+        const int K0 = (p.in_mode == 0) ? (p.D + p.R) : p.K0;
+        const int K0pad = first_wide ? min(CH_MAXW, (K0 + 63) & ~63) : CH_MAXW;
+        const int m = tid & 15, q = tid >> 4;          // 16 threads per row, 16 columns each
+        const int row = row0 + m;
+        int b = row, w = row;
+        if (p.in_mode == 0) {
+            if (p.row_order == 0) { b = row / p.W; w = row - b * p.W; }
+            else if (p.row_order == 1) { w = row / p.B; b = row - w * p.B; }
+        }
+        const bool row_ok = row < p.rows;
+        const float* src_a = (p.in_mode == 0) ? p.obs + (size_t)b * p.D
+                                              : p.src + (p.nb > 1 ? (g / p.src_div) * p.sSrc : 0) + (size_t)row * p.ldsrc;
+        const float* src_w = p.weights + (size_t)w * p.R;
+        const int kb = q * 16;
+        if (kb < K0pad) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = kb + u;
+                float x = 0.f;
+                if (row_ok && k < K0) {
+                    if (p.in_mode == 0) x = (k < p.D) ? src_a[k] : src_w[k - p.D];
+                    else x = src_a[k];
+                }
+                v[u] = x;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u += 4)
+                *reinterpret_cast<float4*>(sAct + m * C2_LDK + kb + u) = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
+            if (p.x0_out != nullptr && row_ok) {
+#pragma unroll
+                for (int u = 0; u < 16; u += 4)
+                    if (kb + u < p.ldx0)
+                        *reinterpret_cast<float4*>(p.x0_out + (size_t)row * p.ldx0 + kb + u) =
+                            make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
+            }
+        }
+    }
+    __syncthreads();
+
+    bool do_copy = false;
+    C2CopyDst cdst = c2_copy_dst(sAct, 0, 0, 0, 0, tid);
+
+    for (int s = 0; s < p.n_steps; ++s) {
+        const ChainStep& st = p.step[s];
+        const int K = st.K, N = st.N;
+        const bool feed_next = (s + 1 < p.n_steps);
+        const ChainStep& nxt = p.step[feed_next ? s + 1 : s];
+        const bool nxt_wide = nxt.N > 32;
+
+        if (N > 32) {
+            // ======================= matrix-core path =======================================================
+            f32x4 acc[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ct][r] = 0.f;
+            const int n_pairs = (K + 63) >> 6;          // K is treated as padded to a multiple of 64 with zero rows
+            c16_load_wide(by, dcur, CH_BK);
+            const float* pa = sAct + j * C2_LDK + 4 * kq;
+            const C16Desc dnext = c16_desc(nxt, wave, j, kq, g);
+            float4 an, ac = *reinterpret_cast<const float4*>(pa);
+            int piece = 0;
+            for (int pr = 0; pr < n_pairs; ++pr) {
+                const int k0 = pr * 64;
+                const bool more = pr + 1 < n_pairs;
+                const bool from_next = !more && nxt_wide;
+                C16Desc dx;
+                dx.rsrc = from_next ? dnext.rsrc : dcur.rsrc;
+                dx.lane_off = from_next ? dnext.lane_off : dcur.lane_off;
+                dx.stride = from_next ? dnext.stride : dcur.stride;
+// one group = 16 contraction indices = 4 MFMA steps x 4 column tiles; the A quad of the NEXT group is read first
+#define C16_GROUP(SET, G, KNEXT)                                                      \
+    {                                                                                 \
+        an = *reinterpret_cast<const float4*>(pa + (KNEXT));                          \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                               \
+            const float av = c16_elem(ac, t);                                         \
+            const float4 bv = SET.v[4 * (G) + t];                                     \
+            acc[0] = mfma16(av, bv.x, acc[0]);                                        \
+            acc[1] = mfma16(av, bv.y, acc[1]);                                        \
+            acc[2] = mfma16(av, bv.z, acc[2]);                                        \
+            acc[3] = mfma16(av, bv.w, acc[3]);                                        \
+        }                                                                             \
+        ac = an;                                                                      \
+        C2_SGB(0x100, 1);                                                             \
+        C2_SGB(0x008, 16);                                                            \
+    }
+                C16_GROUP(bx, 0, k0 + 16)
+                C16_GROUP(bx, 1, k0 + 32)
+                c16_load_wide(bx, dx, more ? k0 + 64 : 0);
+                C16_GROUP(by, 0, k0 + 48)
+                // (the last group's look-ahead read stays inside the buffer: column k0 + 64 + 15 <= 271 -> see the kernel's array)
+                C16_GROUP(by, 1, k0 + 64)
+                c16_load_wide(by, dcur, more ? k0 + 96 : CH_BK);
+#undef C16_GROUP
+                if (do_copy && piece < N_PIECES) { c2_copy_piece(sAct, cdst, piece); ++piece; }
+            }
+            if (do_copy)
+                for (; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cdst, piece);
+            dcur = dnext;
+            __syncthreads();     // every wave is past its last read of sAct
+
+            // ---- epilogue ---------------------------------------------------------------------------------
+            float bias[4] = {0.f, 0.f, 0.f, 0.f};
+            if (st.bias != nullptr) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    if (col0 + ct < N) bias[ct] = st.bias[g * st.sW + col0 + ct];
+            }
+            unsigned int bits_w = 0u, bits_r = 0u;
+            // 16-bit words: same bytes per row as the 64-bit words of the 32 / 64-row tilings
+            const size_t bits_idx = ((size_t)g * st.sBits) * 4 + (size_t)(row0 >> 4) * CH_THREADS + tid;
+            if (st.bits_in != nullptr) bits_r = reinterpret_cast<const unsigned short*>(st.bits_in)[bits_idx];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v[4];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    float x = acc[ct][r] + bias[ct];
+                    if (st.relu) x = fmaxf(x, 0.f);
+                    x = (col0 + ct < N) ? x : 0.f;
+                    if (st.bits_out != nullptr && x > 0.f) bits_w |= 1u << (ct * 4 + r);
+                    if (st.bits_in != nullptr) x = ((bits_r >> (ct * 4 + r)) & 1u) ? x : 0.f;
+                    v[ct] = x;
+                }
+                if (feed_next || st.out != nullptr)
+                    *reinterpret_cast<float4*>(sAct + (kq * 4 + r) * C2_LDK + col0) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (st.bits_out != nullptr) reinterpret_cast<unsigned short*>(st.bits_out)[bits_idx] = (unsigned short)bits_w;
+            do_copy = st.out != nullptr;
+            if (do_copy) cdst = c2_copy_dst(st.out + g * st.sOut, st.ldout, N, p.rows, row0, tid);
+        } else {
+            // ======================= narrow step: split-K over the four waves ==================================
+            f32x4 hacc[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hacc[ct][r] = 0.f;
+            if (s > 0) c16_load_narrow(bx, st, wave, j, kq, g);
+            if (do_copy)
+                for (int piece = 0; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cdst, piece);
+            const float* pa = sAct + j * C2_LDK + wave * 64 + 4 * kq;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 a4 = *reinterpret_cast<const float4*>(pa + 16 * c);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float av = c16_elem(a4, t);        // columns >= K of sAct: finite stale values times zero weights
+                    hacc[0] = mfma16(av, c16_elem(bx.v[2 * c], t), hacc[0]);
+                    hacc[1] = mfma16(av, c16_elem(bx.v[2 * c + 1], t), hacc[1]);
+                }
+            }
+            __syncthreads();     // every wave is past its last read of sAct -> reuse it as the reduction scratch
+            float* scr = sAct;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scr[((wave * 2 + ct) * 4 + r) * 64 + lane] = hacc[ct][r];
+            const C16Desc dnext = c16_desc(nxt, wave, j, kq, g);
+            if (nxt_wide) c16_load_wide(bx, dnext, 0);
+            dcur = dnext;
+            __syncthreads();
+            // thread (wave, lane): column tile ct = wave >> 1, registers 2 * (wave & 1) + {0, 1} -- sums the four partials in wave order
+            const int ct = wave >> 1;
+            float red[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = 2 * (wave & 1) + q;
+                float v = scr[((0 * 2 + ct) * 4 + r) * 64 + lane];
+                v += scr[((1 * 2 + ct) * 4 + r) * 64 + lane];
+                v += scr[((2 * 2 + ct) * 4 + r) * 64 + lane];
+                v += scr[((3 * 2 + ct) * 4 + r) * 64 + lane];
+                red[q] = v;
+            }
+            if (feed_next) __syncthreads();
+            const int n = 16 * ct + j;
+            const float bias = (st.bias != nullptr && n < N) ? st.bias[g * st.sW + n] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = 2 * (wave & 1) + q;
+                const int m = kq * 4 + r;
+                const int row = row0 + m;
+                const bool ok = n < N && row < p.rows;
+                float v = red[q] + bias;
+                if (st.relu) v = fmaxf(v, 0.f);
+                if (st.mask != nullptr) v = (ok && st.mask[(size_t)row * st.ldmask + n] > 0.f) ? v : 0.f;
+                if (!ok) v = 0.f;
+                if (feed_next) sAct[m * C2_LDK + n] = v;
+                if (st.out != nullptr && ok) st.out[g * st.sOut + (size_t)row * st.ldout + n] = v;
+            }
+            if (feed_next)      // the next step reads K' = N <= 32 padded to 64 columns: columns [32, 64) must be zero too
+                for (int e = tid; e < 32 * C16_TM; e += CH_THREADS) sAct[(e >> 5) * C2_LDK + 32 + (e & 31)] = 0.f;
+            do_copy = false;
+        }
+        __syncthreads();
+    }
+    if (do_copy)
+        for (int piece = 0; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cdst, piece);
+}
+
+// One workgroup per 16-row tile; tiles are numbered chain after chain, network after network.
+struct Chain16Multi {
+    ChainArgs p[CH_MAX_MULTI];
+    int tile_start[CH_MAX_MULTI + 1];
+    int n;
+};
+
+static __global__ __launch_bounds__(CH_THREADS, 4) void mlp_chain16_kernel(Chain16Multi m) {
+    // (+16: the last group's look-ahead operand read of the last row runs up to 12 floats past the tile; the values are unused)
+    __shared__ __attribute__((aligned(16))) float sAct[C16_TM * C2_LDK + 16];
+    const int b = (int)blockIdx.x;
+    int q = 0;
+    while (q + 1 < m.n && b >= m.tile_start[q + 1]) ++q;
+    int lt = b - m.tile_start[q], g = 0;
+    const int tpn = (m.p[q].rows + C16_TM - 1) / C16_TM;          // tiles per network
+    if (m.p[q].nb > 1) { g = lt / tpn; lt -= g * tpn; }
+    mlp_chain16_body(m.p[q], lt * C16_TM, sAct, g);
+}
+
+// Host side: which launches take the 16-row tiles, and the tile table.  The choice must be the same for a forward pass and
+// the backward pass that consumes its sign bits, so it depends only on the rows (x networks) of a chain -- equal for both.
+constexpr int C16_MAX_ROWS = 4096;     // chains of up to this many rows: 16-row tiles (<= 256 tiles per chain)
+
+inline bool chain16_wanted(const ChainArgs* chains, int n) {
+    long long most = 0;
+    for (int q = 0; q < n; ++q) {
+        const long long r = (long long)chains[q].rows * (chains[q].nb > 1 ? chains[q].nb : 1);
+        most = r > most ? r : most;
+    }
+    return most <= C16_MAX_ROWS;
+}
+
+inline int chain16_fill(Chain16Multi& m, const ChainArgs* chains, int n) {
+    m.n = n;
+    int tiles = 0;
+    for (int q = 0; q < n; ++q) {
+        m.p[q] = chains[q];
+        m.tile_start[q] = tiles;
+        tiles += (chains[q].nb > 1 ? chains[q].nb : 1) * ((chains[q].rows + C16_TM - 1) / C16_TM);
+    }
+    for (int q = n; q <= CH_MAX_MULTI; ++q) m.tile_start[q] = tiles;
+    return tiles;
+}
+
+}  // namespace morl

@@ -14,6 +14,7 @@
 #include "morl_device.h"
 #include "gemm_f32.h"
 #include "mlp_chain2.h"
+#include "mlp_chain16.h"
 #include "optim_kernels.h"
 #include "ac_kernels.h"
 
@@ -260,11 +261,12 @@ extern "C" int morl_ac_set_gemm_mode(int mode) {
 // the persistent chain kernel (mlp_chain2.h) -- the G networks of a tape are one batched chain, a paired pass a second one
 // in the same launch.  Round 1 ran one GEMM launch per layer: a single-learner update was 35-52 dependent ~8 us launches.
 // ---------------------------------------------------------------------------------------------------------------------
-// Measured on MI355X (round 2): NOT a win for one learner's 128-row batch -- a pass is then 4-8 workgroups whose 32-row tiles
-// carry a whole 256 x 256 layer each (7 us of MFMA on one CU), 23 us per pass against 3 x 8 us for the per-layer wave-tile
-// GEMMs that spread every layer over 32 workgroups (CAPQL 0.217 vs 0.210 ms, MOSAC 0.368 vs 0.355 ms per update).  Kept
-// behind MORL_AC_CHAIN=1 (parity-tested) until a 16-row tile variant exists; the per-layer engines stay the default.
-static const bool g_ac_chain = [] { const char* e = getenv("MORL_AC_CHAIN"); return e ? atoi(e) != 0 : false; }();
+// Measured on MI355X (round 2, one learner, 128-row batch; ms per update, per-layer engines -> fused passes): with the
+// 16-row tiles of mlp_chain16.h CAPQL 0.197 -> 0.164, MOSAC 0.342 -> 0.276, GPI-PD continuous 0.261 -> 0.250.  (With 32-row
+// tiles the fused pass LOSES: a pass is then 4-8 workgroups whose tiles carry a whole 256 x 256 layer each, 23 us per pass
+// against 3 x 8 us for the wave-tile GEMMs that spread a layer over 32 workgroups -- CAPQL 0.214, MOSAC 0.367.)
+// MORL_AC_CHAIN=0 restores the per-layer engines.
+static const bool g_ac_chain = [] { const char* e = getenv("MORL_AC_CHAIN"); return e ? atoi(e) != 0 : true; }();
 
 static bool chain_shape_ok(const Mlp& m) {
     if (!g_ac_chain || m.ln || m.L < 2 || m.L > MORL_MAX_LAYERS) return false;
@@ -283,6 +285,14 @@ static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
             return prop.multiProcessorCount;
         return 256;
     }();
+    static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
+    if (small_rows && chain16_wanted(chains, n)) {
+        Chain16Multi m16{};
+        const int tiles = chain16_fill(m16, chains, n);
+        hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
+        LAUNCH_CHECK("ac_chain16");
+        return MORL_OK;
+    }
     Chain2Multi m{};
     m.n = n;
     int units = 0;

@@ -19,6 +19,7 @@
 #include "envelope_kernels.h"
 #include "mlp_chain.h"
 #include "mlp_chain2.h"
+#include "mlp_chain16.h"
 #include "dw_wave.h"
 #include "dw_tiles.h"
 #include "optim_kernels.h"
@@ -455,7 +456,13 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
         slot = c->ev_used++;
         HIP_TRY(hipEventRecord(c->ev_start[slot], s));
     }
-    if (c->chain_sched) hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
+    static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
+    if (small_rows && chain16_wanted(chains, n)) {
+        // few rows (small batches, shards of a strong-scaled job): 16-row tiles, one workgroup each (mlp_chain16.h)
+        Chain16Multi m16{};
+        const int tiles = chain16_fill(m16, chains, n);
+        hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
+    } else if (c->chain_sched) hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
     else hipLaunchKernelGGL(mlp_chain2_kernel<0>, dim3(S), dim3(CH_THREADS), 0, s, m);
     LAUNCH_CHECK("mlp_chain2");
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_stop[slot], s));

@@ -172,6 +172,29 @@ static inline hipsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float 
     return d;
 }
 
+namespace hipsim {
+static void fn_mfma_16x16x4(const CollIn* in, CollOut* out, int n) {
+    if (n != 64) { std::fprintf(stderr, "hipsim: MFMA needs a full wave (got %d lanes)\n", n); std::abort(); }
+    for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < 4; ++r) {
+            const int row = (l >> 4) * 4 + r, col = l & 15;
+            float acc = in[l].f[2 + r];
+            for (int k = 0; k < 4; ++k) acc = std::fmaf(in[row + 16 * k].f[0], in[col + 16 * k].f[1], acc);
+            out[l].f[r] = acc;
+        }
+}
+}  // namespace hipsim
+typedef float hipsim_f32x4 __attribute__((ext_vector_type(4)));
+static inline hipsim_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipsim_f32x4 c, int, int, int) {
+    hipsim::CollIn in{};
+    in.f[0] = a; in.f[1] = b;
+    for (int r = 0; r < 4; ++r) in.f[2 + r] = c[r];
+    hipsim::CollOut o = hipsim::wave_collective(in, hipsim::fn_mfma_16x16x4);
+    hipsim_f32x4 d;
+    for (int r = 0; r < 4; ++r) d[r] = o.f[r];
+    return d;
+}
+
 // LDS-DMA: lane l copies `size` bytes from its own global address to (first lane's LDS pointer) + l*size
 namespace hipsim {
 static void fn_first_ptr(const CollIn* in, CollOut* out, int n) { for (int l = 0; l < n; ++l) out[l].u = in[0].u; }

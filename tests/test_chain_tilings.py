@@ -1,0 +1,18 @@
+"""Both tilings of the layer-fused chain on the emulator.  The library picks 16-row tiles (mlp_chain16.h) whenever a chain has
+at most 4 096 rows -- which is every case the emulator can afford -- so the 64 / 32-row persistent kernel (mlp_chain2.h) would
+only be exercised on the GPU.  This test re-runs the chain-centred parity tests in a fresh interpreter with MORL_CHAIN16=0 (the
+switch is read once per process), i.e. the same oracle / reference-golden assertions on the large-tile kernel."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_large_tile_chain_passes_the_same_parity_tests():
+    env = dict(os.environ, MORL_CHAIN16="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_parity.py"), "-x", "-q", "-m", "not gpu",
+                        "-k", "envelope_update_vs_reference_golden or qnet_forward_row_orders or grads_only", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
