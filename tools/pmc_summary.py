@@ -28,18 +28,41 @@ def run_pass(name, counters, outdir):
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.defaultdict(set)
+    dur = collections.defaultdict(dict)           # kernel -> dispatch -> ns (when the counter pass carries timestamps)
     for f in files:
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             launches[k].add(r["Dispatch_Id"])
-    return {k: {c: v / len(launches[k]) for c, v in cs.items()} | {"launches": len(launches[k])} for k, cs in acc.items()}
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                dur[k][r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    out = {}
+    for k, cs in acc.items():
+        out[k] = {c: v / len(launches[k]) for c, v in cs.items()} | {"launches": len(launches[k])}
+        if dur[k]:
+            out[k]["avg_ns_in_pass"] = sum(dur[k].values()) / len(dur[k])
+    return out
+
+
+def run_trace(outdir):
+    """Average launch duration per kernel (ns) from a plain kernel-trace pass of the same command: joined with
+    GRBM_GUI_ACTIVE it gives the clock the chip sustained INSIDE each kernel (DVFS: MI355X_MICROARCH.md, 'DVFS give-back')."""
+    d = os.path.join(outdir, "trace")
+    cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            out[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"])
+    return out
 
 
 def main():
     out_path = sys.argv[1]
     work = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pmc_passes")
     res = {n: run_pass(n, c, work) for n, c in PASSES.items()}
+    avg_ns = run_trace(work)
     kernels = {}
     for k in sorted(res["fetch"]):
         if not k.startswith("morl::"):
@@ -54,6 +77,11 @@ def main():
                       # busy fraction = busy / (active / 8 * 1024)
                       "mfma_busy_frac": (sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] * 128.0)) if sq["GRBM_GUI_ACTIVE"] else 0.0,
                       "lds_bank_conflict_over_wave_cycles": (sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_WAVE_CYCLES"]) if sq["SQ_WAVE_CYCLES"] else 0.0,
+                      "avg_launch_ns_unprofiled": avg_ns.get(k),
+                      # GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles per XCD / launch duration = sustained clock
+                      "effective_clock_ghz": (sq["GRBM_GUI_ACTIVE"] / 8.0 / avg_ns[k]) if avg_ns.get(k) else None,
+                      "avg_launch_ns_in_counter_pass": s.get("avg_ns_in_pass"),
+                      "effective_clock_ghz_in_counter_pass": (sq["GRBM_GUI_ACTIVE"] / 8.0 / s["avg_ns_in_pass"]) if s.get("avg_ns_in_pass") else None,
                       "sq": sq}
     json.dump({"note": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "command": "python bench.py --steps 10 --warmup 3 "
                "--no-cpu-baseline", "kernels": kernels}, open(out_path, "w"), indent=1)
