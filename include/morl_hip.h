@@ -31,7 +31,7 @@ extern "C" {
 
 #define MORL_MAX_LAYERS 8   /* linear layers per network */
 #define MORL_MAX_OBJ 8      /* reward dimension R */
-#define MORL_ABI_VERSION 6
+#define MORL_ABI_VERSION 7
 
 typedef enum morl_status {
     MORL_OK = 0,
@@ -140,6 +140,15 @@ int morl_sample_gather(const double* tree, int n_levels, const double* u01, cons
                        int record_floats, int64_t capacity, int B, int D, int R, int action_dim, float* obs,
                        float* next_obs, float* rewards, float* dones, float* actions_f, int32_t* actions_i,
                        int64_t* idx_out, const float* aux_src, float* aux_dst, int aux_floats, void* stream);
+/* The whole prologue of an Envelope step in one launch: morl_sample_gather's work beside the K-major shadow copies of both
+ * networks' weights that the layer-fused kernels stream (made for exactly these two parameter buffers; the step's
+ * morl_envelope_update / morl_envelope_slabs on the same context then skips its own shadow-weight launch -- one-shot, dropped by
+ * every optimiser step of the library).  Arguments after params_target as morl_sample_gather. */
+int morl_envelope_prepare(morl_ctx* ctx, const float* params_online, const float* params_target, const double* tree,
+                          int n_levels, const double* u01, const int64_t* idx_in, const float* records, int record_floats,
+                          int64_t capacity, int B, int D, int R, int action_dim, float* obs, float* next_obs, float* rewards,
+                          float* dones, float* actions_f, int32_t* actions_i, int64_t* idx_out, const float* aux_src,
+                          float* aux_dst, int aux_floats, void* stream);
 /* device-side address of a pinned (page-locked, mapped) host allocation; MORL_ERR_HIP if the memory is not mapped */
 int morl_host_device_pointer(void* host_ptr, void** device_ptr);
 /* Same gather for records with arbitrary extra fields (CAPQL ReplayMemory.sample, multi_policy/capql/capql.py:56-63,

@@ -531,6 +531,8 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain2_kernel(Chain2Multi m
 //             `out` is not a multiple of 64 (the Q head), so that its weight stream never relies on the range check
 // 32 x 32 tiles through LDS: global reads and writes are both coalesced (the round-1 kernel read with stride K: 13 MB
 // fetched to move 1.7 MB).  blockIdx.y = 0: params -> wt; 1: params2 -> wt2.
+constexpr int SH_T = 32;     // tile edge: 32 x 32 tiles -> ~480 workgroups for both flagship networks, one load + one store round each
+
 struct ShadowJob {
     long long src_off, dst_off;
     int rows_src, cols_src;     // source matrix [rows_src][cols_src] (row-major, dense)
@@ -544,15 +546,11 @@ struct ShadowArgs {
     int n, tiles;
 };
 
-constexpr int SH_T = 32;     // tile edge: 32 x 32 tiles -> ~480 workgroups for both flagship networks, one load + one store round each
-
-static __global__ __launch_bounds__(256) void shadow_weights_kernel(const float* __restrict__ params, float* __restrict__ wt,
-                                                             const float* __restrict__ params2, float* __restrict__ wt2,
-                                                             ShadowArgs a) {
-    __shared__ float tile[SH_T * (SH_T + 1)];
-    if (blockIdx.y == 1) { params = params2; wt = wt2; }
+// tiles [first_tile, ...) of network `net` (0: params -> wt, 1: params2 -> wt2), strided by `tile_stride`
+__device__ __forceinline__ void shadow_tiles_body(const float* __restrict__ params, float* __restrict__ wt, const ShadowArgs& a,
+                                                  int first_tile, int tile_stride, float* tile) {
     const int tid = (int)threadIdx.x, fast = tid & (SH_T - 1), slow = tid / SH_T;     // slow in [0, 8)
-    for (int t = (int)blockIdx.x; t < a.tiles; t += (int)gridDim.x) {
+    for (int t = first_tile; t < a.tiles; t += tile_stride) {
         int q = 0;
         while (q + 1 < a.n && t >= a.job[q + 1].tile_start) ++q;
         const ShadowJob& j = a.job[q];
@@ -586,6 +584,14 @@ static __global__ __launch_bounds__(256) void shadow_weights_kernel(const float*
             }
         }
     }
+}
+
+static __global__ __launch_bounds__(256) void shadow_weights_kernel(const float* __restrict__ params, float* __restrict__ wt,
+                                                                    const float* __restrict__ params2, float* __restrict__ wt2,
+                                                                    ShadowArgs a) {
+    __shared__ float tile[SH_T * (SH_T + 1)];
+    if (blockIdx.y == 1) shadow_tiles_body(params2, wt2, a, (int)blockIdx.x, (int)gridDim.x, tile);
+    else shadow_tiles_body(params, wt, a, (int)blockIdx.x, (int)gridDim.x, tile);
 }
 
 }  // namespace morl

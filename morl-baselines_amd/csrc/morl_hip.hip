@@ -105,6 +105,20 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
     }
 }
 
+// The step's prologue in ONE launch: batch selection + gather + weight upload (workgroups [0, sg_blocks)) beside the K-major
+// shadow weights of both networks (the remaining workgroups) -- two independent pieces of work that round 1 and the first
+// half of round 2 ran as two launches (and, before that, as five).
+__global__ __launch_bounds__(256) void step_prologue_kernel(SampleGatherArgs sg, int sg_blocks, const float* __restrict__ params,
+                                                            float* __restrict__ wt, const float* __restrict__ params2,
+                                                            float* __restrict__ wt2, ShadowArgs sh) {
+    __shared__ float tile[SH_T * (SH_T + 1)];
+    const int b = (int)blockIdx.x;
+    if (b < sg_blocks) { sample_gather_body(sg, b, sg_blocks); return; }
+    const int t = b - sg_blocks;
+    if (t < sh.tiles) shadow_tiles_body(params, wt, sh, t, sh.tiles, tile);
+    else shadow_tiles_body(params2, wt2, sh, t - sh.tiles, sh.tiles, tile);
+}
+
 }  // namespace morl
 
 // ------------------------------------------------------------------------------------------------
@@ -157,6 +171,10 @@ struct morl_ctx {
     long long timing_step = 0;           //     time each, so timing every step would perturb what it measures)
     std::vector<hipEvent_t> ev_start, ev_stop;
     int main_rows = -1;                  // rows of a hoisted training forward (morl_envelope_main_forward), -1 = none
+    // shadow copies made by morl_envelope_prepare for exactly these parameter buffers; consumed (one-shot) by the step's first
+    // library entry, dropped by every optimiser step of the library
+    const float* fresh_online = nullptr;
+    const float* fresh_target = nullptr;
     const float* wt_online_src = nullptr;   // parameters wt_online was transposed from by this step's morl_envelope_slabs
                                          // (cleared by every optimiser step of the library)
     size_t ev_used = 0;
@@ -384,8 +402,7 @@ static int build_input(const float* obs, const float* weights, float* x0, int B,
 }
 
 // ---- layer-fused path --------------------------------------------------------------------------
-static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipStream_t s, const float* params2 = nullptr,
-                              float* wt2 = nullptr) {
+static ShadowArgs shadow_args(morl_ctx* c) {
     ShadowArgs t{};
     int tiles = 0, n = 0;
     for (int l = 0; l < c->L; ++l) {
@@ -417,7 +434,18 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
     }
     t.n = n;
     t.tiles = tiles;
-    hipLaunchKernelGGL(shadow_weights_kernel, dim3(tiles, params2 ? 2 : 1), dim3(256), 0, s, params, wt, params2, wt2, t);
+    return t;
+}
+
+static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipStream_t s, const float* params2 = nullptr,
+                              float* wt2 = nullptr) {
+    // already made by this step's morl_envelope_prepare for exactly these buffers?  (one-shot)
+    const bool have = (wt == c->wt_online && c->fresh_online == params) &&
+                      (params2 == nullptr || (wt2 == c->wt_target && c->fresh_target == params2));
+    c->fresh_online = c->fresh_target = nullptr;
+    if (have) return MORL_OK;
+    const ShadowArgs t = shadow_args(c);
+    hipLaunchKernelGGL(shadow_weights_kernel, dim3(t.tiles, params2 ? 2 : 1), dim3(256), 0, s, params, wt, params2, wt2, t);
     LAUNCH_CHECK("shadow_weights");
     return MORL_OK;
 }
@@ -627,11 +655,10 @@ extern "C" int morl_gather_batch(const float* records, int record_floats, int64_
     return MORL_OK;
 }
 
-extern "C" int morl_sample_gather(const double* tree, int n_levels, const double* u01, const int64_t* idx_in,
-                                  const float* records, int record_floats, int64_t capacity, int B, int D, int R,
-                                  int action_dim, float* obs, float* next_obs, float* rewards, float* dones, float* actions_f,
-                                  int32_t* actions_i, int64_t* idx_out, const float* aux_src, float* aux_dst, int aux_floats,
-                                  void* stream) {
+static int fill_sample_gather(SampleGatherArgs& a, const double* tree, int n_levels, const double* u01, const int64_t* idx_in,
+                              const float* records, int record_floats, int64_t capacity, int B, int D, int R, int action_dim,
+                              float* obs, float* next_obs, float* rewards, float* dones, float* actions_f, int32_t* actions_i,
+                              int64_t* idx_out, const float* aux_src, float* aux_dst, int aux_floats) {
     if (!records || !obs || !next_obs || !rewards || !dones || (!actions_f && !actions_i)) return fail(MORL_ERR_ARG, "NULL array");
     if (tree ? !u01 : !idx_in) return fail(MORL_ERR_ARG, "sample_gather: uniforms (with a tree) or indices (without) are required");
     if (tree && (n_levels < 1 || n_levels > 40)) return fail(MORL_ERR_ARG, "bad n_levels");
@@ -640,11 +667,51 @@ extern "C" int morl_sample_gather(const double* tree, int n_levels, const double
     if (record_floats != 2 * D + R + 1 + action_dim)
         return fail(MORL_ERR_ARG, "record_floats=%d != 2*D+R+1+Ad=%d", record_floats, 2 * D + R + 1 + action_dim);
     if (aux_src && (!aux_dst || aux_floats < 1)) return fail(MORL_ERR_ARG, "sample_gather: aux copy without destination / size");
+    a.tree = tree; a.u01 = u01; a.idx_in = idx_in; a.records = records;
+    a.obs = obs; a.next_obs = next_obs; a.rewards = rewards; a.dones = dones; a.actions_f = actions_f; a.actions_i = actions_i;
+    a.idx_out = idx_out; a.aux_src = aux_src; a.aux_dst = aux_dst;
+    a.capacity = (long long)capacity; a.n_levels = n_levels; a.record_floats = record_floats;
+    a.B = B; a.D = D; a.R = R; a.Ad = action_dim; a.aux_floats = aux_floats;
+    return MORL_OK;
+}
+
+extern "C" int morl_sample_gather(const double* tree, int n_levels, const double* u01, const int64_t* idx_in,
+                                  const float* records, int record_floats, int64_t capacity, int B, int D, int R,
+                                  int action_dim, float* obs, float* next_obs, float* rewards, float* dones, float* actions_f,
+                                  int32_t* actions_i, int64_t* idx_out, const float* aux_src, float* aux_dst, int aux_floats,
+                                  void* stream) {
+    SampleGatherArgs a{};
+    int rc = fill_sample_gather(a, tree, n_levels, u01, idx_in, records, record_floats, capacity, B, D, R, action_dim, obs, next_obs,
+                                rewards, dones, actions_f, actions_i, idx_out, aux_src, aux_dst, aux_floats);
+    if (rc) return rc;
     const int blocks = std::min(1024, (B + 3) / 4);
-    hipLaunchKernelGGL(sample_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tree, n_levels, u01, idx_in, records,
-                       record_floats, (long long)capacity, B, D, R, action_dim, obs, next_obs, rewards, dones, actions_f, actions_i,
-                       idx_out, aux_src, aux_dst, aux_floats);
+    hipLaunchKernelGGL(sample_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     LAUNCH_CHECK("sample_gather");
+    return MORL_OK;
+}
+
+extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, const float* params_target, const double* tree,
+                                     int n_levels, const double* u01, const int64_t* idx_in, const float* records,
+                                     int record_floats, int64_t capacity, int B, int D, int R, int action_dim, float* obs,
+                                     float* next_obs, float* rewards, float* dones, float* actions_f, int32_t* actions_i,
+                                     int64_t* idx_out, const float* aux_src, float* aux_dst, int aux_floats, void* stream) {
+    if (!c || !params_online || !params_target) return fail(MORL_ERR_ARG, "NULL argument");
+    SampleGatherArgs a{};
+    int rc = fill_sample_gather(a, tree, n_levels, u01, idx_in, records, record_floats, capacity, B, D, R, action_dim, obs, next_obs,
+                                rewards, dones, actions_f, actions_i, idx_out, aux_src, aux_dst, aux_floats);
+    if (rc) return rc;
+    const int blocks = std::min(1024, (B + 3) / 4);
+    if (!c->use_fused) {                                    // per-layer engine: no shadow copies to make
+        hipLaunchKernelGGL(sample_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        LAUNCH_CHECK("sample_gather");
+        return MORL_OK;
+    }
+    const ShadowArgs sh = shadow_args(c);
+    hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks + 2 * sh.tiles), dim3(256), 0, (hipStream_t)stream, a, blocks, params_online,
+                       c->wt_online, params_target, c->wt_target, sh);
+    LAUNCH_CHECK("step_prologue");
+    c->fresh_online = params_online;
+    c->fresh_target = params_target;
     return MORL_OK;
 }
 
@@ -995,6 +1062,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
 static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                           const morl_update_cfg* cfg, float* grad_norm_out, bool have_partials, hipStream_t s) {
     c->wt_online_src = nullptr;          // the parameters change: any transposed copy is stale from here on
+    c->fresh_online = c->fresh_target = nullptr;
     const int nblk = std::min(OPT_MAX_BLOCKS, stream_grid(c->P, OPT_THREADS));
     if (!have_partials) {
         hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)grads, 1, (long long)c->P,

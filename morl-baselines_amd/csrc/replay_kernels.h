@@ -51,58 +51,68 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const float* __restri
 // (mapped into the device's address space): a few KB read over PCIe inside the kernel instead of separate copy launches.
 // Workgroup 0 also moves `aux_floats` floats from aux_src to aux_dst (the step's sampled weight vectors).
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sample_gather_kernel(const double* __restrict__ tree, int n_levels,
-                                                            const double* __restrict__ u01,
-                                                            const int64_t* __restrict__ idx_in,
-                                                            const float* __restrict__ records, int record_floats,
-                                                            long long capacity, int B, int D, int R, int Ad,
-                                                            float* __restrict__ obs, float* __restrict__ next_obs,
-                                                            float* __restrict__ rewards, float* __restrict__ dones,
-                                                            float* __restrict__ actions_f, int32_t* __restrict__ actions_i,
-                                                            int64_t* __restrict__ idx_out, const float* __restrict__ aux_src,
-                                                            float* __restrict__ aux_dst, int aux_floats) {
+struct SampleGatherArgs {
+    const double* tree;        // NULL: indices come from idx_in
+    const double* u01;
+    const int64_t* idx_in;
+    const float* records;
+    float *obs, *next_obs, *rewards, *dones, *actions_f;
+    int32_t* actions_i;
+    int64_t* idx_out;
+    const float* aux_src;
+    float* aux_dst;
+    long long capacity;
+    int n_levels, record_floats, B, D, R, Ad, aux_floats;
+};
+
+// workgroup `block` of `n_blocks` (so that the routine can run as its own launch or as the leading workgroups of the step's
+// prologue launch, beside the shadow-weight tiles)
+__device__ __forceinline__ void sample_gather_body(const SampleGatherArgs& a, int block, int n_blocks) {
     const int waves_per_block = (int)blockDim.x / kWave;
     const int lane = lane_id();
-    if (blockIdx.x == 0 && aux_src != nullptr)
-        for (int e = (int)threadIdx.x; e < aux_floats; e += (int)blockDim.x) aux_dst[e] = aux_src[e];
-    for (int b = (int)blockIdx.x * waves_per_block + wave_id(); b < B; b += (int)gridDim.x * waves_per_block) {
+    const int D = a.D, R = a.R, Ad = a.Ad;
+    if (block == 0 && a.aux_src != nullptr)
+        for (int e = (int)threadIdx.x; e < a.aux_floats; e += (int)blockDim.x) a.aux_dst[e] = a.aux_src[e];
+    for (int b = block * waves_per_block + wave_id(); b < a.B; b += n_blocks * waves_per_block) {
         long long t = 0;
         if (lane == 0) {
-            if (tree != nullptr) {
-                double q = __dadd_rn(0.0, __dmul_rn(__dsub_rn(tree[0], 0.0), u01[b]));
+            if (a.tree != nullptr) {
+                double q = __dadd_rn(0.0, __dmul_rn(__dsub_rn(a.tree[0], 0.0), a.u01[b]));
                 long long node = 0;
-                for (int l = 1; l < n_levels; ++l) {
+                for (int l = 1; l < a.n_levels; ++l) {
                     node *= 2;
-                    const double left = tree[level_off(l) + node];
+                    const double left = a.tree[level_off(l) + node];
                     const bool gt = q > left;
                     node += gt ? 1 : 0;
                     q = __dsub_rn(q, __dmul_rn(left, gt ? 1.0 : 0.0));
                 }
                 t = node;
             } else {
-                t = idx_in[b];
+                t = a.idx_in[b];
             }
-            if (idx_out) idx_out[b] = t;
+            if (a.idx_out) a.idx_out[b] = t;
         }
         const int lo = __shfl((int)(t & 0xffffffffll), 0), hi = __shfl((int)(t >> 32), 0);
         t = ((long long)hi << 32) | (unsigned int)lo;
         if (t < 0) t = 0;
-        if (t >= capacity) t = capacity - 1;
-        const float* rec = records + (size_t)t * record_floats;
-        for (int e = lane; e < record_floats; e += kWave) {
+        if (t >= a.capacity) t = a.capacity - 1;
+        const float* rec = a.records + (size_t)t * a.record_floats;
+        for (int e = lane; e < a.record_floats; e += kWave) {
             const float v = rec[e];
-            if (e < D) obs[(size_t)b * D + e] = v;
-            else if (e < 2 * D) next_obs[(size_t)b * D + (e - D)] = v;
-            else if (e < 2 * D + R) rewards[(size_t)b * R + (e - 2 * D)] = v;
-            else if (e == 2 * D + R) dones[b] = v;
+            if (e < D) a.obs[(size_t)b * D + e] = v;
+            else if (e < 2 * D) a.next_obs[(size_t)b * D + (e - D)] = v;
+            else if (e < 2 * D + R) a.rewards[(size_t)b * R + (e - 2 * D)] = v;
+            else if (e == 2 * D + R) a.dones[b] = v;
             else {
-                const int a = e - (2 * D + R + 1);
-                if (actions_f) actions_f[(size_t)b * Ad + a] = v;
-                if (actions_i) actions_i[(size_t)b * Ad + a] = (int32_t)v;
+                const int k = e - (2 * D + R + 1);
+                if (a.actions_f) a.actions_f[(size_t)b * Ad + k] = v;
+                if (a.actions_i) a.actions_i[(size_t)b * Ad + k] = (int32_t)v;
             }
         }
     }
 }
+
+__global__ __launch_bounds__(256) void sample_gather_kernel(SampleGatherArgs a) { sample_gather_body(a, (int)blockIdx.x, (int)gridDim.x); }
 
 // Generic form for records with extra per-transition fields (CAPQL's ReplayMemory stores the weight vector of the
 // episode with every transition, capql.py:40-54): field f of sampled row b = record[idx[b]][offset_f .. +width_f).

@@ -151,7 +151,8 @@ def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
         for _ in range(self.gradient_updates):
             aux, sampled_w = self._draw_weights()
             b_obs, b_actions, b_rewards, b_next_obs, b_dones, b_inds = self.replay_buffer.sample(
-                B, to_tensor=True, device=self.device, aux=aux)
+                B, to_tensor=True, device=self.device, aux=aux,
+                prepare=(self.q_net.ctx, self.q_net.flat, self.target_q_net.flat))
             self._w_ring.mark_used()
             ctx = self.q_net.ctx
             w_loc = sampled_w[i0:i0 + Wl].contiguous()

@@ -226,7 +226,9 @@ class Envelope(MOPolicy, MOAgent):
 
     # -- the hot path ----------------------------------------------------------------------------------------------
     def __sample_batch_experiences(self, aux=None):
-        return self.replay_buffer.sample(self.batch_size, to_tensor=True, device=self.device, aux=aux)
+        # (the same launch makes the K-major shadow weights of both networks for the step that follows)
+        return self.replay_buffer.sample(self.batch_size, to_tensor=True, device=self.device, aux=aux,
+                                         prepare=(self.q_net.ctx, self.q_net.flat, self.target_q_net.flat))
 
     def _draw_weights(self):
         """The step's ``num_sample_w`` weight vectors (``envelope.py:281-283``: host RNG, fp32): staged in pinned memory and

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
 
 MORL_MAX_LAYERS = 8
 MORL_MAX_OBJ = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class NetDesc(C.Structure):
@@ -127,6 +127,9 @@ _SIGNATURES = {
                           [C.c_void_p] * 6 + [C.c_void_p]),
     "morl_sample_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,
                                      C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_void_p]),
+    "morl_envelope_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9 +
+                              [C.c_int, C.c_void_p]),
     "morl_host_device_pointer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "morl_gather_fields": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.c_void_p]),

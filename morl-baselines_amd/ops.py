@@ -143,10 +143,13 @@ class HostRing:
 
 def sample_gather(lib: NativeLib, records: th.Tensor, B: int, D: int, R: int, action_dim: int = 1, int_actions: bool = True, *,
                   tree: Optional[th.Tensor] = None, n_levels: int = 0, u01_ptr: Optional[int] = None,
-                  idx_ptr: Optional[int] = None, aux_src_ptr: Optional[int] = None, aux_dst: Optional[th.Tensor] = None):
+                  idx_ptr: Optional[int] = None, aux_src_ptr: Optional[int] = None, aux_dst: Optional[th.Tensor] = None,
+                  prepare=None):
     """One training batch in one launch (``morl_sample_gather``): sum-tree descent with the uniforms at ``u01_ptr`` (PER) or
     the indices at ``idx_ptr`` (uniform replay), then the record gather; ``aux_src_ptr`` -> ``aux_dst`` rides along.  The raw
     addresses are device-visible (device memory or mapped pinned host memory of a ``HostRing``).
+    ``prepare`` = (QNetContext, params_online, params_target): the launch also makes the K-major shadow weights the Envelope step
+    on that context streams (``morl_envelope_prepare``), so the step itself starts with its forward passes.
     Returns (obs, actions, rewards, next_obs, dones, idx)."""
     _chk(records, th.float32, "records")
     lib.check_device(records, tree, aux_dst)
@@ -162,10 +165,16 @@ def sample_gather(lib: NativeLib, records: th.Tensor, B: int, D: int, R: int, ac
     else:
         act = th.empty((B, action_dim), dtype=th.float32, device=dev)
         af, ai = act, None
-    lib.check(lib.lib.morl_sample_gather(_ptr(tree), int(n_levels), u01_ptr, idx_ptr, _ptr(records), records.shape[1],
-                                         records.shape[0], B, D, R, action_dim, _ptr(obs), _ptr(nobs), _ptr(rew), _ptr(done),
-                                         _ptr(af), _ptr(ai), _ptr(idx), aux_src_ptr, _ptr(aux_dst),
-                                         0 if aux_dst is None else aux_dst.numel(), lib.stream_of(records)))
+    tail = (_ptr(tree), int(n_levels), u01_ptr, idx_ptr, _ptr(records), records.shape[1], records.shape[0], B, D, R, action_dim,
+            _ptr(obs), _ptr(nobs), _ptr(rew), _ptr(done), _ptr(af), _ptr(ai), _ptr(idx), aux_src_ptr, _ptr(aux_dst),
+            0 if aux_dst is None else aux_dst.numel(), lib.stream_of(records))
+    if prepare is not None:
+        ctx, p_online, p_target = prepare
+        _chk(p_online, th.float32, "params_online"); _chk(p_target, th.float32, "params_target")
+        lib.check_device(p_online, p_target)
+        lib.check(lib.lib.morl_envelope_prepare(ctx.handle, _ptr(p_online), _ptr(p_target), *tail))
+    else:
+        lib.check(lib.lib.morl_sample_gather(*tail))
     return obs, act, rew, nobs, done, idx
 
 

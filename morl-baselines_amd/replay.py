@@ -162,7 +162,7 @@ class ReplayBuffer:
             self.__dict__[name] = ring
         return ring
 
-    def _gather(self, inds: np.ndarray, aux=None):
+    def _gather(self, inds: np.ndarray, aux=None, prepare=None):
         """The host-drawn indices are read in place from pinned memory by the gather launch itself."""
         self.flush()
         B = int(len(inds))
@@ -171,20 +171,20 @@ class ReplayBuffer:
         slot[:] = inds
         obs, act, rew, nobs, done, idx = ops.sample_gather(
             self.lib, self.records, B, self._D, self._R, self._Ad, self._int_actions, idx_ptr=ptr,
-            aux_src_ptr=None if aux is None else aux[0], aux_dst=None if aux is None else aux[1])
+            aux_src_ptr=None if aux is None else aux[0], aux_dst=None if aux is None else aux[1], prepare=prepare)
         ring.mark_used()
         if self._int_actions and self._Ad == 1:
             act = act.view(-1, 1)
         return obs, act, rew, nobs, done, idx
 
-    def sample(self, batch_size, replace=True, use_cer=False, to_tensor=False, device=None, aux=None):
+    def sample(self, batch_size, replace=True, use_cer=False, to_tensor=False, device=None, aux=None, prepare=None):
         """``buffer.py:68-96``: host index selection on the global numpy RNG, device gather when ``to_tensor``.
         ``aux`` = (device-visible source address, device tensor): copied along by the gather launch (``ops.sample_gather``)."""
         inds = np.random.choice(self.size, batch_size, replace=replace)
         if use_cer:
             inds[0] = (self.ptr - 1) % self.max_size     # numpy wraps -1 to the newest slot; the device gather must too
         if to_tensor:
-            return self._gather(inds, aux)
+            return self._gather(inds, aux, prepare)
         return (self.obs[inds], self.actions[inds], self.rewards[inds], self.next_obs[inds], self.dones[inds], inds)
 
     def sample_obs(self, batch_size, replace=True, to_tensor=False, device=None):
@@ -294,7 +294,7 @@ class PrioritizedReplayBuffer(ReplayBuffer):
         u = th.as_tensor(np.random.random_sample(batch_size)).to(self.device, non_blocking=True)
         return ops.sumtree_sample(self.lib, self.tree_dev, self.n_levels, u)
 
-    def sample(self, batch_size, to_tensor=False, device=None, aux=None):
+    def sample(self, batch_size, to_tensor=False, device=None, aux=None, prepare=None):
         """``prioritized_buffer.py:149-185``.  ``to_tensor``: uniforms from the global numpy RNG (the stream
         ``np.random.uniform`` consumes) staged in pinned memory, descent + gather (+ the ``aux`` copy, see
         ``ReplayBuffer.sample``) in one launch."""
@@ -306,7 +306,7 @@ class PrioritizedReplayBuffer(ReplayBuffer):
             obs, act, rew, nobs, done, idx = ops.sample_gather(
                 self.lib, self.records, int(batch_size), self._D, self._R, self._Ad, self._int_actions,
                 tree=self.tree_dev, n_levels=self.n_levels, u01_ptr=ptr,
-                aux_src_ptr=None if aux is None else aux[0], aux_dst=None if aux is None else aux[1])
+                aux_src_ptr=None if aux is None else aux[0], aux_dst=None if aux is None else aux[1], prepare=prepare)
             ring.mark_used()
             if self._int_actions and self._Ad == 1:
                 act = act.view(-1, 1)

@@ -1,6 +1,6 @@
 set -x
 R=$PWD
-O=gpurun_out/t7
+O=gpurun_out/t12
 mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; tail -3 $O/bench.err
