@@ -72,6 +72,8 @@ class NativeComm:
         if getattr(self, "handle", None):
             self.lib.lib.morl_comm_destroy(self.handle)
             self.handle = None
+    # (no __del__: tearing a communicator down implicitly at interpreter exit, at different moments on different ranks, is how
+    # multi-process jobs hang; the process exit releases it)
 
 
 def average_gradients(dist, group=None):
