@@ -97,6 +97,17 @@ __device__ __forceinline__ void dw2_store(const Dw2Stage<WIDTH>& s, float* __res
     }
 }
 
+// piece q of the same store (the pieces of a stage are spread over the MFMA loop of the chunk before)
+template <int WIDTH>
+__device__ __forceinline__ void dw2_store_piece(const Dw2Stage<WIDTH>& s, float* __restrict__ sm, int q) {
+    constexpr int QPR = WIDTH / 4;
+    constexpr int N = (DW2_BK * QPR + DW2_THREADS - 1) / DW2_THREADS;
+    if (q < N) {
+        const int f = (int)threadIdx.x + q * DW2_THREADS;
+        if (f < DW2_BK * QPR) *reinterpret_cast<float4*>(sm + (f / QPR) * DW2_LD + (f % QPR) * 4) = s.v[q];
+    }
+}
+
 // LAYOUT -> tile shape and the waves' sub-tiles (TMW x TNW tiles of 32 x 32 per wave)
 template <int LAYOUT> struct Dw2Shape;
 template <> struct Dw2Shape<0> { static constexpr int BM = 128, BN = 128, TMW = 2, TNW = 2; };
@@ -130,31 +141,63 @@ __device__ __forceinline__ void dw2_tile(const Dw2Problem& g, int tile_m, int ti
     float colsum = 0.f;
     const bool do_colsum = (g.colsum != nullptr) && (tile_n == 0);
 
-    Dw2Stage<BM> ra;
-    Dw2Stage<BN> rb;
+    // three-stage pipeline: chunk c is multiplied out of LDS while chunk c+1 waits in registers to be stored and chunk c+2 is
+    // in flight from memory -- the loads of a chunk have a whole chunk of MFMAs plus a barrier to land (with one chunk of
+    // look-ahead every workgroup waited ~2 000 cycles per chunk for them: 16 MB in flight chip-wide, ~3 us of loaded latency)
+    Dw2Stage<BM> ra0, ra1;
+    Dw2Stage<BN> rb0, rb1;
     constexpr int SBUF = DW2_BK * DW2_LD;      // floats per LDS buffer
     // rows [0, kend) of the operands: everything beyond this split's slice reads as zero
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)g.G, 0, kend * g.ldg * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc((void*)g.H, 0, kend * g.ldh * 4, 0x00020000);
     if (kbeg < kend) {
-        dw2_load<BM>(ra, rg, g.ldg, m0, g.gcols, kbeg);
-        dw2_load<BN>(rb, rh, g.ldh, n0, g.hcols, kbeg);
-        dw2_store<BM>(ra, sAbase);
-        dw2_store<BN>(rb, sBbase);
+        dw2_load<BM>(ra0, rg, g.ldg, m0, g.gcols, kbeg);
+        dw2_load<BN>(rb0, rh, g.ldh, n0, g.hcols, kbeg);
+        dw2_load<BM>(ra1, rg, g.ldg, m0, g.gcols, kbeg + DW2_BK);
+        dw2_load<BN>(rb1, rh, g.ldh, n0, g.hcols, kbeg + DW2_BK);
+        dw2_store<BM>(ra0, sAbase);
+        dw2_store<BN>(rb0, sBbase);
     }
     __syncthreads();
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += DW2_BK) {
-        const bool more = k0 + DW2_BK < kend;
-        DW2_TICK(3)
-        // next chunk's operands: in flight under this chunk's MFMAs (beyond the slice: zeros, never stored)
-        dw2_load<BM>(ra, rg, g.ldg, m0, g.gcols, k0 + DW2_BK);
-        dw2_load<BN>(rb, rh, g.ldh, n0, g.hcols, k0 + DW2_BK);
-        // operand (i, h) of contraction pair kk: A rows wrow + TMW*i .. +TMW-1, B columns wcol + TNW*i .. +TNW-1 at k = kk + h
-        const float* sAc = sAbase + buf * SBUF;
-        const float* pa = sAc + h * DW2_LD + wrow + TMW * i;
-        const float* pb = sBbase + buf * SBUF + h * DW2_LD + wcol + TNW * i;
-        float av[2][2], bv[2][2];          // [parity of the pair][tile]
+    float av[2][2], bv[2][2];          // [parity of the pair][tile]
+// one 32-row chunk: BUF = LDS buffer holding it, LOADS = register stage that takes chunk + 2, STORES = stage holding chunk + 1
+#define DW2_CHUNK(BUF, LA, LB, SA, SB, K0)                                                                           \
+    {                                                                                                                \
+        DW2_TICK(3)                                                                                                  \
+        dw2_load<BM>(LA, rg, g.ldg, m0, g.gcols, (K0) + 2 * DW2_BK);                                                 \
+        dw2_load<BN>(LB, rh, g.ldh, n0, g.hcols, (K0) + 2 * DW2_BK);                                                 \
+        const float* sAc = sAbase + (BUF) * SBUF;                                                                    \
+        const float* pa = sAc + h * DW2_LD + wrow + TMW * i;                                                         \
+        const float* pb = sBbase + (BUF) * SBUF + h * DW2_LD + wcol + TNW * i;                                       \
+        const bool st_ = (K0) + DW2_BK < kend;      /* chunk + 1 exists: its stage goes to the other buffer, piece by piece, */ \
+        float* sAo = sAbase + ((BUF) ^ 1) * SBUF;   /* under this chunk's MFMAs (nobody reads that buffer now)              */ \
+        float* sBo = sBbase + ((BUF) ^ 1) * SBUF;                                                                    \
+        DW2_READ(0, 0)                                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                           \
+        _Pragma("unroll") for (int kk = 0; kk < DW2_BK; kk += 2) {                                                   \
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;                                                            \
+            const int kn = (kk + 2 < DW2_BK) ? kk + 2 : kk;                                                          \
+            DW2_READ(nxt, kn)                                                                                        \
+            _Pragma("unroll") for (int a = 0; a < TMW; ++a)                                                          \
+                _Pragma("unroll") for (int b = 0; b < TNW; ++b) acc[a][b] = mfma32(av[cur][a], bv[cur][b], acc[a][b]); \
+            if (st_ && (kk & 2) == 0) {             /* one 16-byte piece of each operand every other contraction step */ \
+                dw2_store_piece<BM>(SA, sAo, kk >> 2);                                                               \
+                dw2_store_piece<BN>(SB, sBo, kk >> 2);                                                               \
+            }                                                                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, TMW * TNW, 0);                                               \
+        }                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        DW2_TICK(0)                                                                                                  \
+        if (do_colsum) {                                                                                             \
+            constexpr int PARTS = DW2_THREADS / BM, KPP = DW2_BK / PARTS;                                            \
+            const int crow = (int)threadIdx.x % BM, part = (int)threadIdx.x / BM;                                    \
+            _Pragma("unroll") for (int kk = 0; kk < KPP; ++kk) colsum += sAc[(part * KPP + kk) * DW2_LD + crow];     \
+        }                                                                                                            \
+        DW2_TICK(1)                                                                                                  \
+        __syncthreads();                                                                                             \
+        DW2_TICK(2)                                                                                                  \
+    }
 #define DW2_READ(SLOT, KK)                                                                              \
     {                                                                                                   \
         if (TMW == 2) { const float2 t = *reinterpret_cast<const float2*>(pa + (KK) * DW2_LD); av[SLOT][0] = t.x; av[SLOT][1] = t.y; } \
@@ -162,41 +205,14 @@ __device__ __forceinline__ void dw2_tile(const Dw2Problem& g, int tile_m, int ti
         if (TNW == 2) { const float2 t = *reinterpret_cast<const float2*>(pb + (KK) * DW2_LD); bv[SLOT][0] = t.x; bv[SLOT][1] = t.y; } \
         else bv[SLOT][0] = pb[(KK) * DW2_LD];                                                           \
     }
-        DW2_READ(0, 0)
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // (the prologue reads are a group of their own)
-#pragma unroll
-        for (int kk = 0; kk < DW2_BK; kk += 2) {
-            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-            const int kn = (kk + 2 < DW2_BK) ? kk + 2 : kk;
-            DW2_READ(nxt, kn)
-#pragma unroll
-            for (int a = 0; a < TMW; ++a)
-#pragma unroll
-                for (int b = 0; b < TNW; ++b) acc[a][b] = mfma32(av[cur][a], bv[cur][b], acc[a][b]);
-            // pin the interleave: this step's look-ahead reads first, then its MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TMW * TNW, 0);
-        }
-#undef DW2_READ
-        __builtin_amdgcn_sched_barrier(0);      // the LDS stores below wait for the loads: keep them below the MFMAs
-        DW2_TICK(0)
-        if (do_colsum) {
-            // db: all 256 threads share the row sums of the chunk (thread -> row tid % BM, k-slice tid / BM), so that no wave
-            // lags behind the others at the barrier below
-            constexpr int PARTS = DW2_THREADS / BM, KPP = DW2_BK / PARTS;
-            const int crow = (int)threadIdx.x % BM, part = (int)threadIdx.x / BM;
-#pragma unroll
-            for (int kk = 0; kk < KPP; ++kk) colsum += sAc[(part * KPP + kk) * DW2_LD + crow];
-        }
-        if (more) {
-            dw2_store<BM>(ra, sAbase + (buf ^ 1) * SBUF);
-            dw2_store<BN>(rb, sBbase + (buf ^ 1) * SBUF);
-        }
-        DW2_TICK(1)
-        __syncthreads();
-        DW2_TICK(2)
-        buf ^= 1;
+    // (bias sums: all 256 threads share the row sums of a chunk -- thread -> row tid % BM, k-slice tid / BM -- so that no wave
+    // lags behind the others at the chunk's barrier)
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * DW2_BK) {
+        DW2_CHUNK(0, ra0, rb0, ra1, rb1, k0)                         // chunk in buffer 0; chunk + 1 (stage 1) -> buffer 1
+        if (k0 + DW2_BK < kend) DW2_CHUNK(1, ra1, rb1, ra0, rb0, k0 + DW2_BK)
     }
+#undef DW2_READ
+#undef DW2_CHUNK
     if (PROF && prof != nullptr && threadIdx.x == 0)
         for (int q = 0; q < 4; ++q) prof[q] = pt[q];
 #undef DW2_TICK

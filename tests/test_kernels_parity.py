@@ -325,3 +325,108 @@ def test_sumtree_trace_bit_exact(be):
             got = tree_d.cpu().numpy()
             for l in range(n_levels):
                 assert np.array_equal(got[2 ** l - 1: 2 ** (l + 1) - 1], tree_o.nodes[l]), (cap, rnd, l)
+
+
+# ---- round 2: fused launches must equal the launches they replaced, bit for bit ------------------------------------------------
+def _records(dev, n=300, D=5, R=2, Ad=1, seed=0):
+    rng = np.random.default_rng(seed)
+    rec = rng.standard_normal((n, 2 * D + R + 1 + Ad)).astype(np.float32)
+    rec[:, -1] = rng.integers(0, 4, n)
+    return th.tensor(rec).to(dev), D, R, Ad
+
+
+def _tree(dev, n_leaves=300, seed=1):
+    """A device sum tree whose nodes are exact float64 sums of small integers (any summation order gives the same bits)."""
+    rng = np.random.default_rng(seed)
+    n_levels = int(np.ceil(np.log2(n_leaves))) + 1
+    leaves = np.zeros(2 ** (n_levels - 1))
+    leaves[:n_leaves] = rng.integers(1, 50, n_leaves)
+    levels = [leaves]
+    while len(levels[0]) > 1:
+        levels.insert(0, levels[0].reshape(-1, 2).sum(1))
+    return th.tensor(np.concatenate(levels)).to(dev), n_levels
+
+
+def test_sample_gather_equals_descent_plus_gather(be):
+    """morl_sample_gather == morl_sumtree_sample followed by morl_gather_batch (and the aux copy is a copy); indices path too."""
+    lib, dev, _ = be
+    records, D, R, Ad = _records(dev)
+    tree, n_levels = _tree(dev)
+    B = 37
+    u = th.tensor(np.random.default_rng(2).random(B)).to(dev)
+    aux_src = th.arange(24, dtype=th.float32, device=dev) * 0.5
+    aux_dst = th.zeros(24, dtype=th.float32, device=dev)
+    got = ops.sample_gather(lib, records, B, D, R, Ad, True, tree=tree, n_levels=n_levels, u01_ptr=u.data_ptr(),
+                            aux_src_ptr=aux_src.data_ptr(), aux_dst=aux_dst)
+    idx = ops.sumtree_sample(lib, tree, n_levels, u)
+    want = ops.gather_batch(lib, records, idx, D, R, Ad, int_actions=True)
+    assert th.equal(got[5], idx) and th.equal(aux_dst, aux_src)
+    for a, b in zip(got[:5], want):
+        assert th.equal(a.reshape(-1), b.reshape(-1))
+    inds = th.tensor(np.random.default_rng(3).integers(0, 300, B), dtype=th.int64).to(dev)
+    got2 = ops.sample_gather(lib, records, B, D, R, Ad, True, idx_ptr=inds.data_ptr())
+    want2 = ops.gather_batch(lib, records, inds, D, R, Ad, int_actions=True)
+    assert th.equal(got2[5], inds)
+    for a, b in zip(got2[:5], want2):
+        assert th.equal(a.reshape(-1), b.reshape(-1))
+
+
+def test_prologue_and_in_step_per_update_change_nothing(be):
+    """An update whose shadow weights were made by morl_envelope_prepare and whose PER update rides in the weight-gradient
+    launch == the same update with the library's own shadow launch followed by a separate morl_sumtree_update: parameters,
+    moments, loss and the float64 tree are bit-identical."""
+    lib, dev, _ = be
+    c = [c for c in CASES if c.name == "flagship_b32w8"][0]
+    inp = make_inputs(c)
+    records, D, R, Ad = _records(dev, n=300, D=c.D, R=c.R)
+    idx = th.tensor(np.random.default_rng(5).integers(0, 300, c.B), dtype=th.int64).to(dev)
+    idx[3] = idx[1]                                        # a duplicate index: batch_set keeps the first occurrence
+
+    def run(fused_path):
+        ctx = ops.QNetContext(c.D, c.R, c.A, c.arch, c.B, c.W, lib=lib)
+        t = dict(po=flat(inp["online"]).to(dev), pt=flat(inp["target"]).to(dev), m=flat(inp["exp_avg"]).to(dev),
+                 v=flat(inp["exp_avg_sq"]).to(dev))
+        t["g"] = th.zeros_like(t["po"])
+        tree, n_levels = _tree(dev)
+        rmax = th.tensor([0.125], dtype=th.float64, device=dev)
+        per = None
+        if fused_path:
+            ops.sample_gather(lib, records, c.B, D, R, Ad, True, idx_ptr=idx.data_ptr(), prepare=(ctx, t["po"], t["pt"]))
+            per = (tree, n_levels, idx, 0.6, rmax)
+        res = ops.envelope_update(ctx, t["po"], t["pt"], t["g"], t["m"], t["v"], th.tensor(inp["obs"]).to(dev),
+                                  th.tensor(inp["next_obs"]).to(dev),
+                                  th.tensor(inp["actions"].astype(np.int32).reshape(-1)).to(dev), th.tensor(inp["rewards"]).to(dev),
+                                  th.tensor(inp["dones"]).reshape(-1).to(dev), th.tensor(inp["sampled_w"]).float().to(dev),
+                                  gamma=c.gamma, lr=c.lr, adam_step=c.step, max_grad_norm=c.max_grad_norm, per=per)
+        if not fused_path:
+            ops.sumtree_update(lib, tree, n_levels, idx, res["priority"], 0.6, rmax)
+        if dev.type == "cuda":
+            th.cuda.synchronize()
+        out = (t["po"].clone(), t["m"].clone(), t["v"].clone(), res["loss"].clone(), tree.clone(), rmax.clone())
+        ctx.close()
+        return out
+    for a, b in zip(run(True), run(False)):
+        assert th.equal(a, b)
+
+
+def test_greedy_actions_follow_the_fma_chain(be):
+    """morl_envelope_greedy_actions == first arg-max of fma(w2, q2, fma(w1, q1, w0 * q0)) over the device's own Q rows
+    (Envelope.max_action, envelope.py:389-402)."""
+    lib, dev, _ = be
+    c = [c for c in CASES if c.name == "flagship_b32w8"][0]
+    inp = make_inputs(c)
+    n = 48
+    ctx = ops.QNetContext(c.D, c.R, c.A, c.arch, n, 1, lib=lib)
+    po = flat(inp["online"]).to(dev)
+    rng = np.random.default_rng(9)
+    obs = th.tensor(rng.standard_normal((n, c.D)).astype(np.float32)).to(dev)
+    w = th.tensor(rng.dirichlet(np.ones(c.R), n).astype(np.float32)).to(dev)
+    ac = ops.envelope_greedy_actions(ctx, po, obs, w).cpu().numpy()
+    q = ops.qnet_forward_rows(ctx, po, obs, w).cpu().numpy().astype(np.float64)          # (n, A, R)
+    wd = w.cpu().numpy().astype(np.float64)
+    f32 = lambda x: x.astype(np.float32).astype(np.float64)
+    s = f32(wd[:, None, 0] * q[..., 0])
+    for r in range(1, c.R):
+        s = f32(q[..., r] * wd[:, None, r] + s)                                           # one rounding: an fma
+    assert np.array_equal(ac, s.argmax(1))
+    ctx.close()
