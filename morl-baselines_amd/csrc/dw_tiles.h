@@ -51,7 +51,7 @@ struct Dw2Args {
     SumTreeUpdate per;         // per.tree != NULL: one extra workgroup (block `jobs`) applies the step's PER priority update
                                // (prioritized_buffer.py:187-195) -- it only depends on the TD kernel's priorities, nothing here
                                // depends on it, and the launch has a free slot: 16 us of serial tail disappear
-    long long* prof;           // development probe only (tools/probes/dw_probe.hip): [jobs][4] cycle sums of the chunk phases
+    long long* prof;           // development probe only (tools/probes/dw_probe.hip): [jobs][6] cycle sums of the phases
     int stagger;               // s_sleep units (64 cycles) the second half of the grid waits before starting: the two workgroups of a
                                // CU (blocks b and b + grid/2) run identical chunk loops and would otherwise hit their barriers together
 };
@@ -117,7 +117,7 @@ template <> struct Dw2Shape<2> { static constexpr int BM = 32, BN = 128, TMW = 1
 template <int LAYOUT, bool PROF = false>
 __device__ __forceinline__ void dw2_tile(const Dw2Problem& g, int tile_m, int tile_n, int split, int rows, long long slab_stride,
                                          float* sAbase, float* sBbase, long long* prof = nullptr) {
-    long long pt[4] = {0, 0, 0, 0}, tprev = 0;
+    long long pt[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     if (PROF) tprev = clock64();
 #define DW2_TICK(q) if (PROF) { const long long t_ = clock64(); pt[q] += t_ - tprev; tprev = t_; }
     using S = Dw2Shape<LAYOUT>;
@@ -159,6 +159,7 @@ __device__ __forceinline__ void dw2_tile(const Dw2Problem& g, int tile_m, int ti
         dw2_store<BN>(rb0, sBbase);
     }
     __syncthreads();
+    DW2_TICK(4)                        // prologue: the first two chunks' loads, the first chunk staged
     float av[2][2], bv[2][2];          // [parity of the pair][tile]
 // one 32-row chunk: BUF = LDS buffer holding it, LOADS = register stage that takes chunk + 2, STORES = stage holding chunk + 1
 #define DW2_CHUNK(BUF, LA, LB, SA, SB, K0)                                                                           \
@@ -213,9 +214,7 @@ __device__ __forceinline__ void dw2_tile(const Dw2Problem& g, int tile_m, int ti
     }
 #undef DW2_READ
 #undef DW2_CHUNK
-    if (PROF && prof != nullptr && threadIdx.x == 0)
-        for (int q = 0; q < 4; ++q) prof[q] = pt[q];
-#undef DW2_TICK
+
     // epilogue: D register r of lane (ci, h) of tile (a, b) is physical row wrow + TMW * ((r & 3) + 8 * (r >> 2) + 4h) + a,
     // physical column wcol + TNW * ci + b
     float* __restrict__ C = g.C + (size_t)split * slab_stride;
@@ -248,6 +247,10 @@ __device__ __forceinline__ void dw2_tile(const Dw2Problem& g, int tile_m, int ti
             g.colsum[(size_t)split * slab_stride + m0 + (int)threadIdx.x] = t;
         }
     }
+    DW2_TICK(5)                        // epilogue: slab tile and bias sums to HBM
+    if (PROF && prof != nullptr && threadIdx.x == 0)
+        for (int q = 0; q < 6; ++q) prof[q] = pt[q];
+#undef DW2_TICK
 }
 
 template <bool PROF>
@@ -270,9 +273,9 @@ __device__ __forceinline__ void dw_tiles_body(const Dw2Args& a) {
     const int tiles = g.tiles_m * g.tiles_n;
     const int split = local / tiles, tile = local % tiles;
     const int tm = tile / g.tiles_n, tn = tile % g.tiles_n;
-    if (g.layout == 0) dw2_tile<0, PROF>(g, tm, tn, split, a.rows, a.slab_stride, &sA[0][0], &sB[0][0], PROF && a.prof ? a.prof + 4 * job : nullptr);
-    else if (g.layout == 1) dw2_tile<1, PROF>(g, tm, tn, split, a.rows, a.slab_stride, &sA[0][0], &sB[0][0], PROF && a.prof ? a.prof + 4 * job : nullptr);
-    else dw2_tile<2, PROF>(g, tm, tn, split, a.rows, a.slab_stride, &sA[0][0], &sB[0][0], PROF && a.prof ? a.prof + 4 * job : nullptr);
+    if (g.layout == 0) dw2_tile<0, PROF>(g, tm, tn, split, a.rows, a.slab_stride, &sA[0][0], &sB[0][0], PROF && a.prof ? a.prof + 6 * job : nullptr);
+    else if (g.layout == 1) dw2_tile<1, PROF>(g, tm, tn, split, a.rows, a.slab_stride, &sA[0][0], &sB[0][0], PROF && a.prof ? a.prof + 6 * job : nullptr);
+    else dw2_tile<2, PROF>(g, tm, tn, split, a.rows, a.slab_stride, &sA[0][0], &sB[0][0], PROF && a.prof ? a.prof + 6 * job : nullptr);
 }
 
 __global__ __launch_bounds__(DW2_THREADS, 2) void dw_tiles_kernel(Dw2Args a) { dw_tiles_body<false>(a); }

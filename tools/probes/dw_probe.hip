@@ -61,7 +61,7 @@ int main() {
         }
         printf("target %4d: jobs %4d base slice %4d  %7.1f us  %6.1f TFLOP/s (algorithmic 6.89 GF)\n", target, jobs, base, best * 1e3, 6.887e9 / (best * 1e-3) / 1e12);
         if (target == 512) {
-            long long* prof; CK(hipMalloc(&prof, (size_t)jobs * 4 * 8)); CK(hipMemset(prof, 0, (size_t)jobs * 4 * 8));
+            long long* prof; CK(hipMalloc(&prof, (size_t)jobs * 6 * 8)); CK(hipMemset(prof, 0, (size_t)jobs * 6 * 8));
             a.prof = prof;
             hipLaunchKernelGGL(dw_prof_kernel, dim3(jobs), dim3(DW2_THREADS), 0, 0, a);
             CK(hipDeviceSynchronize());
@@ -69,15 +69,16 @@ int main() {
             hipLaunchKernelGGL(dw_prof_kernel, dim3(jobs), dim3(DW2_THREADS), 0, 0, a);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             { float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("  instrumented launch: %.1f us\n", ms * 1e3); }
-            std::vector<long long> hp((size_t)jobs * 4); CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<long long> hp((size_t)jobs * 6); CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
             for (int l = 0; l < L; ++l) {
                 const Dw2Problem& q = a.p[l];
                 const int nj = q.splits * q.tiles_m * q.tiles_n;
-                double s[4] = {0, 0, 0, 0};
-                for (int j = 0; j < nj; ++j) for (int k = 0; k < 4; ++k) s[k] += (double)hp[(size_t)(q.job_start + j) * 4 + k] / nj;
+                double s[6] = {0, 0, 0, 0, 0, 0};
+                for (int j = 0; j < nj; ++j) for (int k = 0; k < 6; ++k) s[k] += (double)hp[(size_t)(q.job_start + j) * 6 + k] / nj;
                 const int chunks = (q.k_per_split + 31) / 32;
-                printf("  problem %d layout %d: %d jobs, %d chunks; per chunk cycles: load-issue %.0f | mfma loop %.0f | wait+lds stores %.0f | barrier %.0f   (mfma ideal %d)\n",
-                       l, q.layout, nj, chunks, s[3] / chunks, s[0] / chunks, s[1] / chunks, s[2] / chunks, 16 * lay_cost[q.layout] * 64);
+                printf("  problem %d layout %d: %d jobs, %d chunks; per chunk cycles: load-issue %.0f | mfma loop %.0f | wait+lds stores %.0f | barrier %.0f   (mfma ideal %d); whole job: prologue %.0f | loop %.0f | epilogue %.0f\n",
+                       l, q.layout, nj, chunks, s[3] / chunks, s[0] / chunks, s[1] / chunks, s[2] / chunks, 16 * lay_cost[q.layout] * 64,
+                       s[4], s[0] + s[1] + s[2] + s[3], s[5]);
             }
         }
     }
