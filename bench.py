@@ -232,22 +232,30 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup):
     agent.global_step = 1001
     if sharded:
         from morl_baselines_amd.distributed import shard_envelope_agent
-        shard_envelope_agent(agent, dist)            # weight axis over the ranks: all-gather Q(w), all-reduce grads
+        emu = (a.emulate_world, 0) if (a.emulate_world > 1 and world == 1) else None
+        shard_envelope_agent(agent, dist, emulate=emu)   # weight axis over the ranks: all-gather Q(w), all-reduce grads
 
     def step():
         agent.update()
         agent.global_step += 1
 
     _clock_ramp(dev)
-    for _ in range(warmup):
+    for _ in range(max(warmup - 1, 0)):
+        step()
+    agent.q_net.ctx.set_timing(1)                    # the last warm-up step counts the chain launches of a step
+    if warmup > 0:
         step()
     th.cuda.synchronize()
+    launches_per_step, _ = agent.q_net.ctx.read_timing()
     if dist is not None:
         dist.barrier()
         th.cuda.synchronize()
-    # chain launches are event-timed on the library's stream: every step for short runs (the driver's --steps 20), every
-    # 4th step for long ones (an event pair costs ~4 us of stream time; the step it brackets is ~2 % slower for it)
-    timing_every = 1 if steps <= 50 else 4
+    # chain launches are event-timed on the library's stream.  An event record costs ~3.5 us of stream time (four records
+    # around the two chain launches of a step: +14 us = 4 %), so short runs (the driver's --steps 20) bracket ONE launch per
+    # step, the launches of a step taking turns, and long runs bracket all launches of every 4th step.
+    timing_every = int(os.environ.get("MORL_BENCH_TIMING", -1 if steps <= 50 else 4))
+    if not launches_per_step:
+        timing_every = 1 if timing_every == -1 else timing_every
     agent.q_net.ctx.set_timing(timing_every)
     e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -269,7 +277,8 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     res = {"wall": wall, "host_enqueue_ms_per_step": t_enq * 1e3 / steps, "gpu_ms_per_step_events": gpu_ms / steps,
-           "n_chain": n_chain, "chain_ms": chain_ms, "timed_steps": len(range(0, steps, timing_every)),
+           "n_chain": n_chain, "chain_ms": chain_ms, "timed_steps": (len(range(0, steps, timing_every)) if timing_every > 0 else steps if timing_every == -1 else 0),
+           "launches_per_step": launches_per_step, "timing_mode": timing_every,
            "loss": agent.last_loss(), "engine": agent.q_net.ctx.engine, "W": W, "B": B}
     del agent
     return res
@@ -281,7 +290,7 @@ def _roofline(res, rows_rank):
     over their summed HIP-event duration."""
     n_chain, chain_ms, timed_steps = res["n_chain"], res["chain_ms"], res["timed_steps"]
     chain_flop_step = rows_rank * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW)
-    launches_per_step = n_chain / timed_steps if timed_steps else 0
+    launches_per_step = res.get("launches_per_step") or (n_chain / timed_steps if timed_steps else 0)
     flop_per_launch = chain_flop_step / launches_per_step if launches_per_step else float("nan")
     avg_launch_s = (chain_ms * 1e-3 / n_chain) if n_chain else float("nan")
     achieved = flop_per_launch / avg_launch_s / 1e12 if n_chain else float("nan")
@@ -292,7 +301,10 @@ def _roofline(res, rows_rank):
             "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
             "traffic_source": "committed profile (profiles/*_pmc_summary.json: PMC counters cannot be read in-process); "
                               "constant of the repo, not of this run" if traffic is not None else None,
-            "launches_timed": n_chain, "timed_steps": timed_steps, "avg_launch_us": avg_launch_s * 1e6,
+            "launches_timed": n_chain, "timed_steps": timed_steps, "launches_per_step": launches_per_step,
+            "timing": ("one launch per step, taking turns" if res.get("timing_mode") == -1 else
+                       "all launches of every %d-th step" % res.get("timing_mode", 0)),
+            "avg_launch_us": avg_launch_s * 1e6,
             "algorithmic_flop_per_launch": flop_per_launch}
 
 
@@ -314,6 +326,10 @@ def main():
                          "TD row's envelope max runs over all 64*N candidates after the all-gather).  The other one is "
                          "measured too and attached as a labelled sub-record unless --no-sub-record")
     ap.add_argument("--no-sub-record", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="with --force-shard on one GPU: run the step of rank 0 of a job of this many ranks (its kernels, "
+                         "launches, host work and message sizes; the other ranks' slabs are zeros) -- a measurement aid, "
+                         "the line it prints is labelled as such")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the weight-sharded step (RCCL collectives) even with one rank (path check on a 1-GPU box)")
     a = ap.parse_args()
@@ -361,7 +377,7 @@ def main():
                     "updates_per_s": a.steps / res["wall"],
                     "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
                     "gpu_ms_per_step_events": res["gpu_ms_per_step_events"], "last_loss": res["loss"],
-                    "roofline": _roofline(res, rows_step // world),
+                    "roofline": _roofline(res, rows_step // max(world, a.emulate_world if a.force_shard else 1)),
                     "whole_step_algorithmic_tflops": rows_step * (4 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) / (ms * 1e-3) / 1e12}
 
         scaling = "weak" if world == 1 else a.scaling     # (one GPU: per-GPU work is the metric's workload either way)
@@ -392,6 +408,9 @@ def main():
             "last_loss": h["last_loss"],
             "roofline": dict(h["roofline"], whole_step_algorithmic_tflops=h["whole_step_algorithmic_tflops"]),
         }
+        if a.force_shard and a.emulate_world > 1 and world == 1:
+            out["emulated"] = (f"NOT a job throughput: the step of rank 0 of a {a.emulate_world}-rank job "
+                               f"({W_head // a.emulate_world} weights) run alone on one GPU; value / ms_per_step describe that rank")
         if sub is not None:
             key = "weak_scaling" if scaling == "strong" else "strong_scaling"
             if "error" in sub:

@@ -31,7 +31,7 @@ extern "C" {
 
 #define MORL_MAX_LAYERS 8   /* linear layers per network */
 #define MORL_MAX_OBJ 8      /* reward dimension R */
-#define MORL_ABI_VERSION 7
+#define MORL_ABI_VERSION 8
 
 typedef enum morl_status {
     MORL_OK = 0,
@@ -108,11 +108,13 @@ int morl_ctx_destroy(morl_ctx* ctx);
  * widths % 4 == 0.  Returns the engine now active (0..3), < 0 on error. */
 int morl_ctx_set_fused(morl_ctx* ctx, int enable);
 /* Weight-gradient engine: 0 = wave-level tiles streaming both operands HBM -> registers (dw_wave.h), 1 = 128x128
- * double-buffered LDS tiles, two workgroups per CU (default), 2 = the single-buffered tiles of the per-layer engine. */
+ * double-buffered LDS tiles, two workgroups per CU, 2 = the single-buffered tiles of the per-layer engine, 3 = per-problem wave
+ * layouts with a three-stage operand pipeline (dw_tiles.h; default). */
 int morl_ctx_set_dw_mode(morl_ctx* ctx, int mode);
 /* Per-launch timing of the dominant kernel (the layer-fused MLP chain): every = n > 0 brackets the chain launches of every
  * n-th Envelope step (counted from this call; the first one is timed) with HIP event pairs on the caller's stream, 0 turns it
- * off.  An event record costs a few microseconds of stream time, so sampling keeps the measurement from perturbing the step
+ * off, -1 brackets ONE chain launch of every step (the launches of a step take turns, so that every kind of launch is sampled
+ * equally often at a quarter of the event records).  An event record costs a few microseconds of stream time, so sampling keeps the measurement from perturbing the step
  * it measures.  morl_ctx_read_timing blocks until the recorded launches have finished, returns their number and summed
  * duration (ms) and clears the record.  Used by bench.py for the roofline figure. */
 int morl_ctx_set_timing(morl_ctx* ctx, int every);
@@ -202,8 +204,9 @@ int morl_envelope_update(morl_ctx* ctx, float* params_online, const float* param
  *      collective is in flight, runs morl_envelope_main_forward (the training forward does not need the slabs);
  *   2. morl_envelope_update_shard: training forward of its rows, envelope arg-max over ALL W_total candidates, TD,
  *      backward.  `grads` receives this rank's UNCLIPPED contribution, already normalised by the global row count
- *      B * W_total, out->loss its share of the loss (out->priority only on the rank with i_offset == 0; target / pref /
- *      ac / q_values are local [W_local*B] rows);
+ *      B * W_total, out->loss its share of the loss (out->priority: |td . w| of weight 0's rows on the rank with
+ *      i_offset == 0, zeros on the others, so that the sum over the ranks is the priority; target / pref / ac / q_values are
+ *      local [W_local*B] rows);
  *   3. the caller all-reduces (sums) grads and the loss; morl_clip_adam applies clip_grad_norm_ + Adam identically
  *      on every rank. */
 /* next-state slabs of this rank: slabs_out [2][B][W_local][A][R] (online, then target network), rows (b, j) of
@@ -228,7 +231,8 @@ int morl_clip_adam(morl_ctx* ctx, float* params, float* grads, float* exp_avg, f
  * places everything on one device).  One process per GPU, RCCL over xGMI, bound at run time (an instance the process already
  * loaded -- PyTorch's -- is reused).  Nothing synchronises the host.
  *   morl_comm_unique_id   rank 0 draws the 128-byte id and hands it to the other ranks (any side channel)
- *   morl_comm_init        every rank, collectively; blocks until all `world` ranks joined (current HIP device = the rank's GPU)
+ *   morl_comm_init        every rank, collectively; blocks until all `world` ranks joined (current HIP device = the rank's GPU).
+ *                         world == 1 with an all-zero id makes a loopback communicator that never loads RCCL
  *   morl_allgather_q_begin  all-gather of the ranks' morl_envelope_slabs outputs into recv [world][count_per_rank], issued on
  *                         the communicator's own stream behind everything already enqueued on `stream`; what the caller
  *                         enqueues on `stream` afterwards (morl_envelope_main_forward) runs beside the exchange
@@ -243,6 +247,21 @@ int morl_comm_size(const morl_comm* comm, int* rank, int* world);
 int morl_allgather_q_begin(morl_comm* comm, const float* send, float* recv, int64_t count_per_rank, void* stream);
 int morl_comm_wait(morl_comm* comm, void* stream);
 int morl_allreduce_grads(morl_comm* comm, float* buf, int64_t count, void* stream);
+/* The whole sharded step of one rank in ONE call (what distributed.py's update() runs per gradient step): slabs of its
+ * W_local weights -> all-gather on the communicator's stream, beside the training forward of its rows -> TD / backward /
+ * weight gradients of its rows -> all-reduce of grads_x = [P gradient | 1 loss | B priorities] -> clip_grad_norm_ + Adam
+ * (cfg->apply_step, lr, betas, eps, adam_step, max_grad_norm) -> the PER priority update from the summed priorities when
+ * cfg->per_tree is set.  A strong-scaled rank's kernels take ~20 us each, so the host work between them is what bounds the
+ * step: one library entry instead of seven keeps the interpreter out of it.  slab_local [2][B][W_local][A][R] is this rank's
+ * send buffer, slab_all [W_total / W_local][2][B][W_local][A][R] the gathered slabs (read in place); n_params = P.  After the
+ * call grads_x[P] is the job's loss and grads_x[P + 1 ...] the B priorities (defined on every rank).  The communicator has
+ * W_total / W_local ranks; a communicator of ONE rank with W_local < W_total runs the step of that one rank of the larger
+ * job alone (a measurement aid for single-GPU boxes: the other parts of slab_all are read as the caller left them). */
+int morl_envelope_step_sharded(morl_ctx* ctx, morl_comm* comm, float* params_online, const float* params_target,
+                               float* grads_x, int64_t n_params, float* exp_avg, float* exp_avg_sq, const float* obs,
+                               const float* next_obs, const int32_t* actions, const float* rewards, const float* dones,
+                               const float* weights_all, int B, int W_total, int i_offset, int W_local, float* slab_local,
+                               float* slab_all, const morl_update_cfg* cfg, void* stream);
 
 /* ---- polyak_update: common/networks.py:120-139 ------------------------------------------------- */
 int morl_polyak(const float* src, float* dst, float tau, int64_t n, void* stream);

@@ -68,6 +68,7 @@ struct EnvelopeTdArgs {
     float* dq;              // [W*B][ldq] gradient wrt Q (zero outside the taken action) or NULL
     double* loss_part;      // [B][2]  sum td^2, sum (wQ - wTQ)^2 over this transition's W rows, or NULL
     float* priority;        // [B] |td . w| of the i = 0 row, or NULL
+    float* priority_clear;  // [B] zeroed instead (a shard that does not own weight 0: the ranks' priorities are summed), or NULL
     int B, W, A, R, ldq;
     int i_groups;           // the W rows of a transition are split over this many workgroups (grid = B * i_groups)
     int WI;                 // number of scalarisation vectors (TD rows per transition) in `weights`; 0 -> W.  A rank of a
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
             p.dq[((size_t)i * nB + b) * p.ldq + c] = (r >= 0 && r < R) ? s_g[i * R + r] : 0.f;
         }
     }
+    if (p.priority_clear && ig == 0 && threadIdx.x == 0) p.priority_clear[b] = 0.f;
     if (p.loss_part && threadIdx.x == 0) {
         p.loss_part[(size_t)blockIdx.x * 2 + 0] = s_red[0][0];
         p.loss_part[(size_t)blockIdx.x * 2 + 1] = s_red[0][1];

@@ -169,6 +169,7 @@ struct morl_ctx {
     bool timing = false;                 // chain launches of the current step are bracketed by events
     int timing_every = 0;                // 0 = off, n = every n-th Envelope step is timed (event records cost ~4 us of stream
     long long timing_step = 0;           //     time each, so timing every step would perturb what it measures)
+    int timing_idx = 0, timing_prev_launches = 0, timing_rotate = -1;   // every == -1: one launch per step, taking turns
     std::vector<hipEvent_t> ev_start, ev_stop;
     int main_rows = -1;                  // rows of a hoisted training forward (morl_envelope_main_forward), -1 = none
     // shadow copies made by morl_envelope_prepare for exactly these parameter buffers; consumed (one-shot) by the step's first
@@ -473,11 +474,21 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
     m.stagger = c->chain_stagger;
     m.cu_tickets = c->cu_tickets;
     size_t slot = 0;
-    if (c->timing) {
+    // rotating mode: one launch per step is bracketed, the k-th launch of the step on step k (mod launches per step)
+    const int idx_in_step = c->timing_idx++;
+    const bool timed = c->timing && (c->timing_rotate < 0 || idx_in_step == c->timing_rotate);
+    if (timed) {
         if (c->ev_used == c->ev_start.size()) {
+            // no system-scope fence at the record: the fence is not part of the kernel, delays the launch behind it (a
+            // bracketed chain launch measured 128.9 us with it, 126.4 us without; rocprofv3's kernel trace says 124.7 us)
+            // and costs the step 2 us per record
+            static const unsigned ev_flags = [] {
+                const char* e = getenv("MORL_EV_FLAGS");   // (tuning)
+                return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)hipEventDisableSystemFence;
+            }();
             hipEvent_t e0, e1;
-            HIP_TRY(hipEventCreate(&e0));
-            HIP_TRY(hipEventCreate(&e1));
+            HIP_TRY(hipEventCreateWithFlags(&e0, ev_flags));
+            HIP_TRY(hipEventCreateWithFlags(&e1, ev_flags));
             c->ev_start.push_back(e0);
             c->ev_stop.push_back(e1);
         }
@@ -493,7 +504,7 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
     } else if (c->chain_sched) hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
     else hipLaunchKernelGGL(mlp_chain2_kernel<0>, dim3(S), dim3(CH_THREADS), 0, s, m);
     LAUNCH_CHECK("mlp_chain2");
-    if (c->timing) HIP_TRY(hipEventRecord(c->ev_stop[slot], s));
+    if (timed) HIP_TRY(hipEventRecord(c->ev_stop[slot], s));
     return MORL_OK;
 }
 
@@ -598,8 +609,10 @@ extern "C" int morl_ctx_set_dw_mode(morl_ctx* c, int mode) {
 
 extern "C" int morl_ctx_set_timing(morl_ctx* c, int every) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
-    if (every < 0) return fail(MORL_ERR_ARG, "every < 0");
+    if (every < -1) return fail(MORL_ERR_ARG, "every < -1");
     c->timing_every = every;
+    c->timing_idx = c->timing_prev_launches = 0;
+    c->timing_rotate = -1;
     c->timing_step = 0;
     c->timing = false;
     c->ev_used = 0;
@@ -608,7 +621,16 @@ extern "C" int morl_ctx_set_timing(morl_ctx* c, int every) {
 
 // called at the first library entry of an Envelope step (morl_envelope_update, or morl_envelope_slabs of a sharded step)
 static void timing_begin_step(morl_ctx* c) {
-    c->timing = c->timing_every > 0 && (c->timing_step % c->timing_every) == 0;
+    if (c->timing_every == -1) {
+        // every step, one launch: the launches of a step take turns (two event records instead of two per launch)
+        c->timing = true;
+        if (c->timing_idx > 0) c->timing_prev_launches = c->timing_idx;
+        c->timing_rotate = c->timing_prev_launches > 0 ? (int)(c->timing_step % c->timing_prev_launches) : 0;
+    } else {
+        c->timing = c->timing_every > 0 && (c->timing_step % c->timing_every) == 0;
+        c->timing_rotate = -1;
+    }
+    c->timing_idx = 0;
     ++c->timing_step;
 }
 
@@ -850,6 +872,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         p.actions = actions; p.rewards = rewards; p.dones = dones;
         p.target = out->target; p.pref = out->pref; p.ac = out->ac;
         p.dq = c->dq; p.loss_part = c->loss_part; p.priority = (i_offset == 0) ? out->priority : nullptr;
+        p.priority_clear = (i_offset != 0) ? out->priority : nullptr;
         p.B = B; p.W = W; p.A = A; p.R = R; p.ldq = c->ldq;
         p.WI = WI; p.i_offset = i_offset;
         p.diag_only = cfg->envelope ? 0 : 1;
@@ -1223,6 +1246,55 @@ extern "C" int morl_envelope_main_forward(morl_ctx* c, const float* params_onlin
         if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
     }
     c->main_rows = rows;
+    return MORL_OK;
+}
+
+// The sharded step of one rank in one call (include/morl_hip.h): the entry points above and the collectives of morl_comm.hip
+// in the order distributed.py used to issue them from the interpreter.
+extern "C" int morl_envelope_step_sharded(morl_ctx* c, morl_comm* comm, float* params_online, const float* params_target,
+                                          float* grads_x, int64_t n_params, float* exp_avg, float* exp_avg_sq,
+                                          const float* obs, const float* next_obs, const int32_t* actions,
+                                          const float* rewards, const float* dones, const float* weights_all, int B,
+                                          int W_total, int i_offset, int W_local, float* slab_local, float* slab_all,
+                                          const morl_update_cfg* cfg, void* stream) {
+    if (!c || !comm || !cfg || !grads_x || !slab_local || !slab_all || !weights_all)
+        return fail(MORL_ERR_ARG, "NULL argument");
+    if (n_params != c->P) return fail(MORL_ERR_ARG, "n_params %lld, the network has %lld", (long long)n_params, (long long)c->P);
+    if (W_total < 1 || W_local < 1 || i_offset < 0 || i_offset + W_local > W_total || W_total % W_local || i_offset % W_local)
+        return fail(MORL_ERR_ARG, "bad shard [%d, %d) of %d weights", i_offset, i_offset + W_local, W_total);
+    if (cfg->per_tree && (!cfg->per_idx || !cfg->per_running_max || cfg->per_levels < 1 || cfg->per_levels > 40))
+        return fail(MORL_ERR_ARG, "per_tree needs per_idx, per_running_max and per_levels");
+    int rank = 0, world = 1, rc;
+    if ((rc = morl_comm_size(comm, &rank, &world))) return rc;
+    const int parts = W_total / W_local;
+    if (world != parts && world != 1)
+        return fail(MORL_ERR_ARG, "%d ranks in the communicator, %d shards of the weight axis", world, parts);
+    if (world == parts && rank != i_offset / W_local)
+        return fail(MORL_ERR_ARG, "rank %d does not own the weights from %d on", rank, i_offset);
+    const int R = c->net.reward_dim, AR = c->net.n_actions * R;
+    const int64_t half = (int64_t)B * W_local * AR;            // one network's slab of one rank
+    const float* w_loc = weights_all + (size_t)i_offset * R;
+    float* recv = (world == parts) ? slab_all : slab_all + (size_t)(i_offset / W_local) * 2 * half;
+    if ((rc = morl_envelope_slabs(c, params_online, params_target, next_obs, w_loc, B, W_local, slab_local, stream))) return rc;
+    if ((rc = morl_allgather_q_begin(comm, slab_local, recv, 2 * half, stream))) return rc;
+    if ((rc = morl_envelope_main_forward(c, params_online, obs, w_loc, B, W_local, stream))) return rc;   // beside the exchange
+    if ((rc = morl_comm_wait(comm, stream))) return rc;
+    morl_update_cfg shard = *cfg;
+    shard.apply_step = 0;
+    shard.main_forward_done = 1;
+    shard.slab_parts = parts;
+    shard.per_tree = nullptr;                                  // priorities are complete only after the all-reduce
+    morl_update_out out = {};
+    out.loss = grads_x + n_params;
+    out.priority = grads_x + n_params + 1;
+    if ((rc = morl_envelope_update_shard(c, params_online, grads_x, obs, actions, rewards, dones, weights_all, B, W_total,
+                                         i_offset, W_local, slab_all, slab_all + half, &shard, &out, stream)))
+        return rc;
+    if ((rc = morl_allreduce_grads(comm, grads_x, n_params + 1 + B, stream))) return rc;
+    if ((rc = morl_clip_adam(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, stream))) return rc;
+    if (cfg->per_tree)
+        return morl_sumtree_update(cfg->per_tree, cfg->per_levels, cfg->per_idx, grads_x + n_params + 1, B, cfg->per_alpha,
+                                   cfg->per_running_max, nullptr, stream);
     return MORL_OK;
 }
 

@@ -44,16 +44,22 @@ class NativeComm:
     of include/morl_hip.h: RCCL over xGMI inside libmorl_hip.so).  ``torch.distributed`` is only the side channel that hands
     rank 0's unique id to the other ranks."""
 
-    def __init__(self, lib, dist, device, group=None):
+    def __init__(self, lib, dist, device, group=None, loopback=False):
         self.lib, self.device = lib, th.device(device)
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         ident = th.zeros(128, dtype=th.uint8)
+        handle = C.c_void_p()
+        if loopback:
+            # one rank, no RCCL: the all-zero id (morl_comm_init) -- single-rank runs and the emulated build of the CPU tests
+            self.rank, self.world = 0, 1
+            lib.check(lib.lib.morl_comm_init(C.byref(handle), C.c_void_p(ident.data_ptr()), 0, 1))
+            self.handle = handle.value
+            return
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         if self.rank == 0:
             lib.check(lib.lib.morl_comm_unique_id(C.c_void_p(ident.data_ptr())))
         ident = ident.to(self.device)
         dist.broadcast(ident, src=0, group=group)
         ident = ident.cpu()
-        handle = C.c_void_p()
         with th.cuda.device(self.device):
             lib.check(lib.lib.morl_comm_init(C.byref(handle), C.c_void_p(ident.data_ptr()), self.rank, self.world))
         self.handle = handle.value
@@ -119,9 +125,19 @@ def shard_capql_agent(agent, dist, group=None):
     return agent
 
 
-def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
-    """Replace ``agent.update`` with the sharded step.  ``dist`` is ``torch.distributed`` (already initialised)."""
+def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=None) -> Envelope:
+    """Replace ``agent.update`` with the sharded step.  ``dist`` is ``torch.distributed`` (already initialised).
+
+    ``emulate=(world, rank)`` is a measurement aid for boxes with one GPU (bench.py --emulate-world): the step of ONE rank of a
+    ``world``-rank job with the collectives running among the ranks that really exist -- the other ranks' slabs stay zero and
+    nothing is added to the gradient, so the numbers it trains on are meaningless; the kernels, launches, host work and
+    message sizes are those of the real job's rank."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    real_world = world
+    if emulate is not None:
+        if real_world != 1:
+            raise ValueError("emulate= needs a single real rank")
+        world, rank = int(emulate[0]), int(emulate[1])
     W = agent.num_sample_w
     if W % world:
         raise ValueError(f"num_sample_w={W} must be divisible by the number of ranks ({world})")
@@ -138,12 +154,13 @@ def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
     agent._bind_optimizer_state()
     # collectives: inside libmorl_hip.so (RCCL behind the C ABI) on the GPU; torch.distributed itself for the gloo CPU tests
     # (and with MORL_COMM=torch)
-    comm = None
-    if dist.get_backend(group) == "nccl" and agent.lib.is_device_build and os.environ.get("MORL_COMM", "native") != "torch":
+    # (``comm``: a ready NativeComm, e.g. the loopback one of a single-rank run)
+    if comm is None and dist.get_backend(group) == "nccl" and agent.lib.is_device_build and os.environ.get("MORL_COMM", "native") != "torch":
         comm = NativeComm(agent.lib, dist, dev, group)
     agent._shard.comm = comm
     slab_loc = th.empty((2, B0, Wl, A, R), dtype=th.float32, device=dev)
-    slab_all = th.empty((world, 2, B0, Wl, A, R), dtype=th.float32, device=dev)
+    slab_all = th.zeros((world, 2, B0, Wl, A, R), dtype=th.float32, device=dev)
+    slab_recv = slab_all if emulate is None else slab_all[rank]
 
     def update(self: Envelope):
         self._losses = []
@@ -157,44 +174,47 @@ def shard_envelope_agent(agent: Envelope, dist, group=None) -> Envelope:
                 prepare=(self.q_net.ctx, self.q_net.flat, self.target_q_net.flat))
             self._w_ring.mark_used()
             ctx = self.q_net.ctx
-            w_loc = sampled_w[i0:i0 + Wl].contiguous()
-            # 1. local slabs [2][B][Wl][A][R]: both networks in one launch pair
-            loc = ops.envelope_slabs(ctx, self.q_net.flat, self.target_q_net.flat, b_next_obs, w_loc, out=slab_loc)
-            # 2. one all-gather -> [G][2][B][Wl][A][R], read in place by the TD kernel; while it is in flight ...
-            gathered = slab_all
-            if comm is not None:
-                comm.allgather_begin(loc, gathered)
-            else:
-                work = dist.all_gather_into_tensor(gathered.view(-1), loc.view(-1), group=group, async_op=True)
-            # ... the training forward of this rank's rows runs (it does not need the slabs)
-            ops.envelope_main_forward(ctx, self.q_net.flat, b_obs, w_loc)
-            if comm is not None:
-                comm.wait(gathered)
-            else:
-                work.wait()
-            # 3. this rank's TD rows: arg-max over ALL gathered candidates, TD, backward
             self._adam_step += 1
             gx = self._grads_x
-            gx[P + 1:].zero_()                         # priorities: written by the rank that owns weight 0 only
-            outs = {"loss": gx[P], "priority": gx[P + 1:]}
-            ops.envelope_update_shard(ctx, self.q_net.flat, self._grads, b_obs, b_actions.reshape(-1).to(th.int32),
-                                      b_rewards, b_dones.reshape(-1), sampled_w, i0, Wl, gathered[0, 0], gathered[0, 1],
-                                      gamma=self.gamma, homotopy_lambda=float(self.homotopy_lambda),
-                                      envelope=self.envelope, outputs=outs, main_forward_done=True, slab_parts=world)
-            # 4. one all-reduce: flat gradient + loss + priorities
+            actions = b_actions.reshape(-1).to(th.int32)
             if comm is not None:
-                comm.allreduce(gx)
+                # the whole step of this rank in one library call (RCCL inside libmorl_hip.so): slabs -> all-gather beside
+                # the training forward -> TD / backward -> all-reduce of [gradient | loss | priorities] -> clip + Adam -> PER
+                ops.envelope_step_sharded(
+                    ctx, comm.handle, self.q_net.flat, self.target_q_net.flat, gx, self._exp_avg, self._exp_avg_sq, b_obs,
+                    b_next_obs, actions, b_rewards, b_dones.reshape(-1), sampled_w, i0, Wl, slab_loc, slab_all,
+                    gamma=self.gamma, lr=self.learning_rate, adam_step=self._adam_step, max_grad_norm=self.max_grad_norm,
+                    homotopy_lambda=float(self.homotopy_lambda), envelope=self.envelope,
+                    per=self.replay_buffer.per_update_args(b_inds, self.per_alpha) if self.per else None)
             else:
+                # the same stages one by one, the collectives through torch.distributed (gloo in the CPU tests)
+                w_loc = sampled_w[i0:i0 + Wl].contiguous()
+                # 1. local slabs [2][B][Wl][A][R]: both networks in one launch pair
+                loc = ops.envelope_slabs(ctx, self.q_net.flat, self.target_q_net.flat, b_next_obs, w_loc, out=slab_loc)
+                # 2. one all-gather -> [G][2][B][Wl][A][R], read in place by the TD kernel; while it is in flight ...
+                work = dist.all_gather_into_tensor(slab_recv.view(-1), loc.view(-1), group=group, async_op=True)
+                # ... the training forward of this rank's rows runs (it does not need the slabs)
+                ops.envelope_main_forward(ctx, self.q_net.flat, b_obs, w_loc)
+                work.wait()
+                # 3. this rank's TD rows: arg-max over ALL gathered candidates, TD, backward (priorities: written by the
+                #    rank that owns weight 0, zeroed by the others)
+                outs = {"loss": gx[P], "priority": gx[P + 1:]}
+                ops.envelope_update_shard(ctx, self.q_net.flat, self._grads, b_obs, actions, b_rewards, b_dones.reshape(-1),
+                                          sampled_w, i0, Wl, slab_all[0, 0], slab_all[0, 1], gamma=self.gamma,
+                                          homotopy_lambda=float(self.homotopy_lambda), envelope=self.envelope, outputs=outs,
+                                          main_forward_done=True, slab_parts=world)
+                # 4. one all-reduce: flat gradient + loss + priorities
                 dist.all_reduce(gx, op=dist.ReduceOp.SUM, group=group)
-            loss = gx[P].clone()
-            # 5. identical optimiser step everywhere
-            ops.clip_adam(ctx, self.q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq, lr=self.learning_rate,
-                          adam_step=self._adam_step, max_grad_norm=self.max_grad_norm)
-            pr = gx[P + 1:]                           # (a view: consumed below, valid until the next step's all-reduce)
+                # 5. identical optimiser step everywhere
+                ops.clip_adam(ctx, self.q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq, lr=self.learning_rate,
+                              adam_step=self._adam_step, max_grad_norm=self.max_grad_norm)
+                if self.per:
+                    self.replay_buffer.update_priorities_from_td(b_inds, gx[P + 1:], self.per_alpha)
+            # (views of the all-reduced buffer: valid until the next gradient step overwrites it)
+            loss = gx[P] if self.gradient_updates == 1 else gx[P].clone()
+            pr = gx[P + 1:]
             self._out = {"loss": loss, "priority": pr}
             self._losses.append(loss)
-            if self.per:
-                self.replay_buffer.update_priorities_from_td(b_inds, pr, self.per_alpha)
         # target sync + epsilon / homotopy schedules + logging: the same tail as the single-GPU step
         self._finish_update(pr if self.per else None)
 

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
 
 MORL_MAX_LAYERS = 8
 MORL_MAX_OBJ = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class NetDesc(C.Structure):
@@ -148,6 +148,8 @@ _SIGNATURES = {
     "morl_envelope_update_shard": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p,
                                                                                  C.POINTER(UpdateCfg), C.POINTER(UpdateOut),
                                                                                  C.c_void_p]),
+    "morl_envelope_step_sharded": (C.c_int, [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 8 + [C.c_int] * 4 +
+                                   [C.c_void_p, C.c_void_p, C.POINTER(UpdateCfg), C.c_void_p]),
     "morl_comm_unique_id": (C.c_int, [C.c_void_p]),
     "morl_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
     "morl_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -205,6 +207,12 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 
+_raw_stream = getattr(th._C, "_cuda_getCurrentRawStream", None)
+if _raw_stream is None:                                   # (a torch without the private fast path)
+    def _raw_stream(index: int) -> int:
+        return th.cuda.current_stream(index).cuda_stream
+
+
 def _ptr(t: Optional[th.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -251,8 +259,11 @@ class NativeLib:
 
     @staticmethod
     def stream_of(t: th.Tensor) -> int:
-        if t.device.type == "cuda":
-            return th.cuda.current_stream(t.device).cuda_stream
+        """Raw handle of torch's current stream on the tensor's device (what every entry point enqueues on)."""
+        dev = t.device
+        if dev.type == "cuda":
+            # (the raw-handle query: th.cuda.current_stream() builds a Stream object, ~4 us per call and ten calls per step)
+            return _raw_stream(dev.index if dev.index is not None else th.cuda.current_device())
         return 0
 
     # -- thin wrappers (argument order == header) -----------------------------------------------------

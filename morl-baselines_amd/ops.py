@@ -380,6 +380,46 @@ def envelope_update_shard(ctx: QNetContext, params_online: th.Tensor, grads: th.
     return res
 
 
+def envelope_step_sharded(ctx: QNetContext, comm_handle: int, params_online: th.Tensor, params_target: th.Tensor,
+                          grads_x: th.Tensor, exp_avg: th.Tensor, exp_avg_sq: th.Tensor, obs: th.Tensor, next_obs: th.Tensor,
+                          actions: th.Tensor, rewards: th.Tensor, dones: th.Tensor, weights_all: th.Tensor, i_offset: int,
+                          w_local: int, slab_local: th.Tensor, slab_all: th.Tensor, *, gamma: float, lr: float,
+                          adam_step: int, max_grad_norm: Optional[float], homotopy_lambda: float = 0.0,
+                          envelope: bool = True, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                          per=None) -> None:
+    """One rank's whole sharded Envelope step in one C call (``morl_envelope_step_sharded``): slabs, all-gather beside the
+    training forward, TD / backward, all-reduce of ``grads_x`` = [P gradient | loss | B priorities], clip + Adam and -- with
+    ``per`` = (tree, n_levels, idx, alpha, running_max) -- the PER update from the summed priorities."""
+    lib = ctx.lib
+    for t, dt, n in ((params_online, th.float32, "params_online"), (params_target, th.float32, "params_target"),
+                     (grads_x, th.float32, "grads_x"), (exp_avg, th.float32, "exp_avg"), (exp_avg_sq, th.float32, "exp_avg_sq"),
+                     (obs, th.float32, "obs"), (next_obs, th.float32, "next_obs"), (actions, th.int32, "actions"),
+                     (rewards, th.float32, "rewards"), (dones, th.float32, "dones"), (weights_all, th.float32, "weights_all"),
+                     (slab_local, th.float32, "slab_local"), (slab_all, th.float32, "slab_all")):
+        _chk(t, dt, n)
+    lib.check_device(params_online, params_target, grads_x, exp_avg, exp_avg_sq, obs, next_obs, actions, rewards, dones,
+                     weights_all, slab_local, slab_all)
+    B, W = obs.shape[0], weights_all.shape[0]
+    P = ctx.n_params
+    if grads_x.numel() != P + 1 + B:
+        raise ValueError("grads_x must hold P + 1 + B floats")
+    if slab_local.numel() * (W // w_local) != slab_all.numel():
+        raise ValueError("slab_all must hold W / w_local parts of slab_local's size")
+    cfg = _update_cfg(gamma, lr, adam_step, max_grad_norm, homotopy_lambda, envelope, beta1, beta2, eps, True)
+    if per is not None:
+        tree, n_levels, idx, alpha, running_max = per
+        _chk(tree, th.float64, "per tree"); _chk(idx, th.int64, "per idx"); _chk(running_max, th.float64, "per running_max")
+        lib.check_device(tree, idx, running_max)
+        if idx.numel() != B:
+            raise ValueError("per: one sampled index per transition of the batch")
+        cfg.per_tree, cfg.per_idx, cfg.per_running_max = _ptr(tree), _ptr(idx), _ptr(running_max)
+        cfg.per_levels, cfg.per_alpha = int(n_levels), float(alpha)
+    lib.check(lib.lib.morl_envelope_step_sharded(
+        ctx.handle, comm_handle, _ptr(params_online), _ptr(params_target), _ptr(grads_x), P, _ptr(exp_avg), _ptr(exp_avg_sq),
+        _ptr(obs), _ptr(next_obs), _ptr(actions), _ptr(rewards), _ptr(dones), _ptr(weights_all), B, W, int(i_offset),
+        int(w_local), _ptr(slab_local), _ptr(slab_all), C.byref(cfg), lib.stream_of(obs)))
+
+
 def clip_adam(ctx: QNetContext, params: th.Tensor, grads: th.Tensor, exp_avg: th.Tensor, exp_avg_sq: th.Tensor, *,
               lr: float, adam_step: int, max_grad_norm: Optional[float], beta1: float = 0.9, beta2: float = 0.999,
               eps: float = 1e-8, grad_norm_out: Optional[th.Tensor] = None) -> None:

@@ -65,7 +65,7 @@ static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { 
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 typedef void* hipEvent_t;
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipEventDisableSystemFence = 0x20000000 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(void** e, unsigned) { *e = nullptr; return hipSuccess; }

@@ -95,6 +95,71 @@ def test_sharded_update_equals_single_process(per, schedules):
         np.testing.assert_allclose(t0[0], want_tree[0], rtol=1e-5)
 
 
+class _OneRank:
+    """torch.distributed of a single rank, without a process group (what the staged path of the sharded step needs)."""
+
+    class _Done:
+        def wait(self):
+            return None
+
+    def get_world_size(self, group=None):
+        return 1
+
+    def get_rank(self, group=None):
+        return 0
+
+    def get_backend(self, group=None):
+        return "gloo"
+
+    def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+        out.copy_(inp)
+        return self._Done()
+
+    def all_reduce(self, t, op=None, group=None):
+        return None
+
+    class ReduceOp:
+        SUM = "sum"
+
+
+@pytest.mark.parametrize("per", [False, True])
+def test_one_call_sharded_step_equals_the_staged_one(per):
+    """``morl_envelope_step_sharded`` (one library call per step, collectives of a loopback communicator) takes exactly the
+    steps of the staged path (seven calls, collectives through torch.distributed) and, with one rank owning every weight, those
+    of the unsharded step up to fp32 summation order.  Second case: one rank of a two-rank job run alone (bench.py
+    --emulate-world) -- the staged and the one-call path must still agree bit for bit."""
+    import simlib
+    import morl_baselines_amd.native as native
+    from morl_baselines_amd.distributed import NativeComm, shard_envelope_agent
+    lib = simlib.load_sim()
+    native.use_library(lib)
+    try:
+        for emulate in (None, (2, 1)):
+            runs = []
+            for one_call in (False, True, None):
+                ag = _make_agent(lib, per, schedules=True)
+                if one_call is not None:
+                    comm = NativeComm(lib, None, "cpu", loopback=True) if one_call else None
+                    shard_envelope_agent(ag, _OneRank(), emulate=emulate, comm=comm)
+                    assert (ag._shard.comm is not None) == one_call
+                for _ in range(3):
+                    ag.update()
+                    ag.global_step += 1
+                runs.append((ag.q_net.flat.clone().numpy(), ag.last_loss(),
+                             ag.replay_buffer.tree_dev.clone().numpy() if per else None, float(ag.homotopy_lambda)))
+            staged, fused, plain = runs
+            assert np.array_equal(staged[0], fused[0]) and staged[1] == fused[1] and staged[3] == fused[3] == plain[3]
+            if per:
+                assert np.array_equal(staged[2], fused[2])
+            if emulate is None:
+                assert abs(fused[1] - plain[1]) <= 1e-5 * abs(plain[1])
+                assert np.abs(fused[0] - plain[0]).max() <= 0.02 * 3e-4 * 3
+                if per:
+                    np.testing.assert_allclose(fused[2][0], plain[2][0], rtol=1e-5)
+    finally:
+        native.use_library(None)
+
+
 # ---- data-parallel CAPQL (BASELINE config 4): gradients averaged inside morl_ac_update -----------------------------------------
 def _capql_case():
     from cases_ac import ACCase

@@ -166,6 +166,32 @@ def test_envelope_update_matches_oracle(be, per):
         assert float((p_dev.detach().cpu() - p_ref).abs().max()) <= 0.02 * 3e-4
 
 
+def test_chain_launch_timing_modes(be):
+    """morl_ctx_set_timing: every step (n = 1), every n-th step, one launch per step taking turns (-1), off (0)."""
+    lib, dev = be
+    env = ToyEnv()
+    ag = envmod.Envelope(env, net_arch=[64, 64], batch_size=16, num_sample_w=4, buffer_size=512, per=False, learning_starts=20,
+                         log=False, seed=0, device=dev, lib=lib)
+    _fill(ag.replay_buffer, 200, env.D, env.A, env.R)
+    ag.global_step = 21
+    ctx = ag.q_net.ctx
+    assert ctx.engine > 0                                   # the layer-fused chain is what is timed
+    ctx.set_timing(1)
+    ag.update()
+    per_step, ms = ctx.read_timing()
+    assert per_step >= 2 and ms >= 0.0                      # the forward launch(es) and the backward-dX launch
+    for every, steps, want in ((1, 3, 3 * per_step), (2, 4, 2 * per_step), (-1, 5, 5), (0, 2, 0)):
+        ctx.set_timing(every)
+        for _ in range(steps):
+            ag.update()
+        n, ms = ctx.read_timing()
+        assert n == want and ms >= 0.0
+    assert ctx.read_timing() == (0, 0.0)                    # reading clears the record
+    ctx.set_timing(0)
+    with pytest.raises(Exception):
+        ctx.set_timing(-2)
+
+
 def test_envelope_train_save_load(be, tmp_path):
     lib, dev = be
     ag, env = _make_agent(lib, dev, per=True)
