@@ -448,6 +448,9 @@ struct Chain2Multi {
     int stagger;                        // which workgroups run their tail job first: 0 none, 1 the second half of the grid,
                                         // 2 odd XCD-local index, 3 every second arrival on its CU (ticket from cu_tickets)
     unsigned int* cu_tickets;           // [C2_CU_SLOTS] monotonically increasing arrival counters (stagger 3)
+    int xcd_contig;                     // 1 (grid % 8 == 0): consecutive LOGICAL workgroups run on one XCD.  Batched chains
+                                        // (nb networks of a population): the two or four tiles of one network then share an
+                                        // L2 and its weights are fetched from HBM once instead of once per tile
     long long* prof;                    // probes only: [gridDim.x][2][24] phase stamps
 };
 constexpr int C2_CU_SLOTS = 8192;
@@ -467,7 +470,9 @@ __device__ __forceinline__ unsigned c2_cu_key() {
 
 template <int SCHED, bool PROF>
 __device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, float* sAct) {
-    const int b = (int)blockIdx.x, S = (int)gridDim.x;
+    const int S = (int)gridDim.x;
+    // (workgroup x runs on XCD x % 8)
+    const int b = (m.xcd_contig && (S & 7) == 0) ? ((int)blockIdx.x & 7) * (S >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     bool tail_first = false;
     if (m.stagger == 1) tail_first = b >= (S >> 1);
     else if (m.stagger == 2) tail_first = ((b >> 3) & 1) != 0;

@@ -308,6 +308,8 @@ static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
     m.tail_units = units - m.tail_base;
     m.tail_halves = (2 * m.tail_units <= S) ? 1 : 0;
     m.stagger = 1;
+    static const bool xcd_env = [] { const char* e = getenv("MORL_AC_XCD_CONTIG"); return e ? atoi(e) != 0 : true; }();   // (tuning)
+    for (int q = 0; q < n; ++q) m.xcd_contig |= (xcd_env && chains[q].nb > 1) ? 1 : 0;
     hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
     LAUNCH_CHECK("ac_chain");
     return MORL_OK;
@@ -613,14 +615,43 @@ static MlpLayout layout_of(const Mlp& m) {
     return t;
 }
 
+static int host_tiles(const MlpLayout& t) {
+    int n = 0;
+    for (int l = 0; l < t.L; ++l) n += ((t.N[l] + TR_T - 1) / TR_T) * ((t.K[l] + TR_T - 1) / TR_T);
+    return n;
+}
+
+// K-major shadow copies of up to four parameter sets in one launch (ac_kernels.h: ac_transpose_multi_kernel)
+static int launch_transposes(const TransposeMulti& tm, hipStream_t s) {
+    int tiles = 0, nets = 0;
+    for (int k = 0; k < tm.n; ++k) { tiles = std::max(tiles, host_tiles(tm.lay[k])); nets = std::max(nets, tm.nets[k]); }
+    if (tm.n < 1 || nets < 1) return MORL_OK;
+    if (nets > 65535) return fail(MORL_ERR_ARG, "%d nets in one transpose launch", nets);
+    hipLaunchKernelGGL(ac_transpose_multi_kernel, dim3(tiles + 1, nets, tm.n), dim3(256), 0, s, tm);
+    LAUNCH_CHECK("ac_transpose");
+    return MORL_OK;
+}
+
 // wt / net: also refresh the K-major shadow copy of the stepped parameters (seg = a whole number of `net`-shaped nets)
 static int adam(float* params, float* grads, float* m, float* v, long long seg, int G, double lr, const int* steps,
                 int step_add, const morl_ac_cfg* cfg, hipStream_t s, float* wt = nullptr, const Mlp* net = nullptr,
                 const MlpLayout* lay = nullptr) {
     const int nblk = std::min(256, stream_grid(seg, 256));
+    // a few nets: the Adam kernel scatters the stepped values into the shadow copy itself (one launch fewer); a population:
+    // the scattered 4-byte stores cost more than the step (93 against 37 us at 64 learners), so the copy is re-made by the
+    // tiled transpose kernel behind it
+    const MlpLayout layout = wt ? (lay ? *lay : layout_of(*net)) : MlpLayout{};
+    static const long long scatter_max = [] { const char* e = getenv("MORL_AC_SCATTER_MAX"); return e ? atoll(e) : (1ll << 20); }();   // (tests)
+    const bool scatter = wt && seg * G <= scatter_max;
     hipLaunchKernelGGL(ac_adam_kernel, dim3(nblk, G), dim3(256), 0, s, params, (const float*)grads, m, v, seg, steps, step_add,
-                       lr, cfg->beta1, cfg->beta2, (float)cfg->eps, wt, wt ? (lay ? *lay : layout_of(*net)) : MlpLayout{});
+                       lr, cfg->beta1, cfg->beta2, (float)cfg->eps, scatter ? wt : nullptr, layout);
     LAUNCH_CHECK("ac_adam");
+    if (wt && !scatter) {
+        TransposeMulti tm{};
+        tm.n = 1;
+        tm.src[0] = params; tm.dst[0] = wt; tm.lay[0] = layout; tm.nets[0] = (int)(seg / layout.P) * G;
+        return launch_transposes(tm, s);
+    }
     return MORL_OK;
 }
 
@@ -688,7 +719,8 @@ static int sacd_update(morl_ac_ctx* c, const morl_ac_state* st, const morl_ac_ba
     int widest = 0;
     for (int l = 1; l < Q.L; ++l) widest = std::max(widest, Q.dims[l]);
     static const bool shadow_env = [] { const char* e = getenv("MORL_AC_SHADOW"); return e ? atoi(e) != 0 : true; }();
-    const bool use_wt = shadow_env && use_wave_tiles((long long)((rows + 127) / 128) * ((widest + 127) / 128) * c->QG * 2);
+    const bool use_wt = shadow_env && (use_wave_tiles((long long)((rows + 127) / 128) * ((widest + 127) / 128) * c->QG * 2) ||
+                                       (chain_shape_ok(Q) && chain_shape_ok(P)));
     const float* wq = use_wt ? c->wt_q : nullptr;
     const float* wqt = use_wt ? c->wt_qt : nullptr;
     const float* wp = use_wt ? c->wt_pol : nullptr;
@@ -698,9 +730,7 @@ static int sacd_update(morl_ac_ctx* c, const morl_ac_state* st, const morl_ac_ba
         tm.src[0] = st->q; tm.dst[0] = c->wt_q; tm.lay[0] = layout_of(Q); tm.nets[0] = c->QG;
         tm.src[1] = st->q_target; tm.dst[1] = c->wt_qt; tm.lay[1] = layout_of(Q); tm.nets[1] = c->QG;
         tm.src[2] = st->pol; tm.dst[2] = c->wt_pol; tm.lay[2] = layout_of(P); tm.nets[2] = PG;
-        const long long longest = std::max((long long)c->QG * Q.P, (long long)PG * P.P);
-        hipLaunchKernelGGL(ac_transpose_multi_kernel, dim3(stream_grid(longest, 256, 1024), 1, 3), dim3(256), 0, s, tm);
-        LAUNCH_CHECK("sacd_transpose");
+        if ((rc = launch_transposes(tm, s))) return rc;
     }
     // pi(s') and pi(s): the actor is stepped only at the end of the update, so both passes share their launches
     if ((rc = mlp_forward(P, st->pol, P.P, c->tp_a, rows, 1, nodrop, s, st->pol, &c->tp_b, &nodrop, wp, wp))) return rc;
@@ -852,25 +882,24 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     // population stages 128 x 32 chunks either way and measured slower with the K-major weights (1.70 vs 1.27 ms at 64 learners)
     int widest = 0;
     for (int l = 1; l < Q.L; ++l) widest = std::max(widest, Q.dims[l]);
-    const bool use_wt = shadow_env && use_wave_tiles((long long)((rows + 127) / 128) * ((widest + 127) / 128) * QG * 2);
+    // ... and for every population whose networks the layer-fused chain kernels take (they read K-major weights)
+    const bool use_wt = shadow_env && (use_wave_tiles((long long)((rows + 127) / 128) * ((widest + 127) / 128) * QG * 2) ||
+                                       (chain_shape_ok(Q) && chain_shape_ok(P)));
 #define WT(p) (use_wt ? (p) : nullptr)
     if (use_wt) {
         TransposeMulti tm{};
         const bool td3 = algo == MORL_AC_TD3;
         const float* srcs[4] = {st->q, st->q_target, st->pol, td3 ? st->pol_target : nullptr};
         float* dsts[4] = {c->wt_q, c->wt_qt, c->wt_pol, c->wt_polt};
-        long long longest = 0;
         for (int k = 0; k < 4; ++k) {
             if (!srcs[k]) continue;
             const bool is_q = k < 2;
             tm.src[tm.n] = srcs[k]; tm.dst[tm.n] = dsts[k];
             tm.lay[tm.n] = layout_of(is_q ? Q : P);
             tm.nets[tm.n] = is_q ? QG : PG;
-            longest = std::max(longest, tm.lay[tm.n].P * tm.nets[tm.n]);
             ++tm.n;
         }
-        hipLaunchKernelGGL(ac_transpose_multi_kernel, dim3(stream_grid(longest, 256, 1024), 1, tm.n), dim3(256), 0, s, tm);
-        LAUNCH_CHECK("ac_transpose");
+        if ((rc = launch_transposes(tm, s))) return rc;
     }
 
     // ---- critic phase: a' ~ pi(s'), target critics at (s', a'), critics at (s, a), TD loss, backward, Adam --------------
@@ -1344,8 +1373,7 @@ extern "C" int morl_gpi_update(morl_gpi_ctx* c, float* q, const float* q_target,
         tm.src[0] = q; tm.dst[0] = c->wt_q; tm.src[1] = q_target; tm.dst[1] = c->wt_qt;
         tm.lay[0] = tm.lay[1] = lay;
         tm.nets[0] = tm.nets[1] = c->nn;
-        hipLaunchKernelGGL(ac_transpose_multi_kernel, dim3(stream_grid((long long)c->nn * c->P, 256, 1024), 1, 2), dim3(256), 0, s, tm);
-        LAUNCH_CHECK("gpi_transpose");
+        if ((rc = launch_transposes(tm, s))) return rc;
     }
     {
         // the target ensemble at s' and the online ensemble at s do not depend on each other: one launch per layer for both

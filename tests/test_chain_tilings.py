@@ -16,3 +16,16 @@ def test_large_tile_chain_passes_the_same_parity_tests():
                        capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_population_sized_shadow_refresh_passes_the_same_parity_tests():
+    """Populations re-make the K-major shadow weights with the tiled transpose kernel behind the Adam step instead of scattering
+    them from inside it (morl_ac.hip: adam); the switch is by size, so the emulator-sized cases never take that branch unless
+    forced to (MORL_AC_SCATTER_MAX=0).  With the large-tile chain as well, this is the path a 64-learner MORL/D update takes."""
+    for extra in ({}, {"MORL_CHAIN16": "0"}):
+        env = dict(os.environ, MORL_AC_SCATTER_MAX="0", **extra)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_ac_kernels_parity.py"), "-x", "-q", "-m",
+                            "not gpu", "-k", "population_batch_equals_independent_learners or update_matches_oracle_and_reference", "-p",
+                            "no:cacheprovider"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        assert " passed" in r.stdout
