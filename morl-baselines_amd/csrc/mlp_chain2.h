@@ -178,7 +178,7 @@ __device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& 
         }
         if (SCHED) {
             // program order above: 8 x [MT ds_read, 8*MT MFMA], bx loads after group 3, by loads after group 7, 4 copy pieces.
-            // wanted: groups 0-3 (bx) carry the copy pieces, groups 4-7 (by) carry bx's 16 loads, by's loads trail (they
+            // wanted: groups 0-3 (bx) carry the copy pieces, groups 4-5 (by) carry bx's 16 loads, by's loads trail (they
             // have the whole next bx half to land)
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
@@ -187,7 +187,10 @@ __device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     C2_SGB(0x008, 2 * MT);
-                    if (g >= 4) { if (!FAST) C2_SGB(0x002, 1); C2_SGB(0x020, 1); }   // (address add +) one weight load
+                    // bx's 16 refill loads, two per MFMA quad of groups 4 and 5 (one per quad over groups 4-7 measured
+                    // 184 us for the three forward passes, this 181 us; issuing the copy stores after them instead of
+                    // before -- vmcnt retires loads and stores in order -- measured worse, 187 us)
+                    if (g == 4 || g == 5) { if (!FAST) C2_SGB(0x002, 2); C2_SGB(0x020, 2); }
                 }
                 if (COPY && g < PP) { C2_SGB(0x002, 1); C2_SGB(0x040, 1); }   // ... its address add and its store
             }
