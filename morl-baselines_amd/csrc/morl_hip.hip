@@ -1082,8 +1082,29 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
 
 // stage C: clip_grad_norm_ + Adam on flat buffers.  have_partials: the sum-of-squares partials of grad_reduce are valid
 // for `grads` (single GPU); otherwise (gradients were all-reduced) they are recomputed from `grads` first.
+// clip + Adam with the step's PER tree update as one extra workgroup of the same launch (the sharded step: the priorities
+// are complete only after the all-reduce, so the update cannot ride in the weight-gradient launch as it does on one GPU;
+// its 17 us of serial tree levels run beside Adam's 7 instead of behind them)
+// (ST_THREADS = 1024 work-items per workgroup: the tree update walks its levels one wave per level)
+static __global__ __launch_bounds__(ST_THREADS) void clip_adam_per_kernel(float* __restrict__ params, float* __restrict__ grads,
+                                                                    float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                                                                    long long P, const double* __restrict__ sumsq_part,
+                                                                    int n_part, float max_norm, float one_minus_b1, float b2,
+                                                                    float one_minus_b2, float neg_step_size, float bc2_sqrt,
+                                                                    float eps, int apply_step, float* __restrict__ grad_norm_out,
+                                                                    SumTreeUpdate per) {
+    __shared__ __attribute__((aligned(8))) unsigned char lds[ST_LDS_BYTES];
+    if (blockIdx.x + 1 == gridDim.x) {
+        sumtree_update_body(per, lds);
+        return;
+    }
+    clip_adam_body(params, grads, exp_avg, exp_avg_sq, P, sumsq_part, n_part, max_norm, one_minus_b1, b2, one_minus_b2,
+                   neg_step_size, bc2_sqrt, eps, apply_step, grad_norm_out, (int)gridDim.x - 1);
+}
+
 static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
-                          const morl_update_cfg* cfg, float* grad_norm_out, bool have_partials, hipStream_t s) {
+                          const morl_update_cfg* cfg, float* grad_norm_out, bool have_partials, hipStream_t s,
+                          const SumTreeUpdate* per = nullptr) {
     c->wt_online_src = nullptr;          // the parameters change: any transposed copy is stale from here on
     c->fresh_online = c->fresh_target = nullptr;
     const int nblk = std::min(OPT_MAX_BLOCKS, stream_grid(c->P, OPT_THREADS));
@@ -1098,10 +1119,16 @@ static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_a
     const double bc2 = 1.0 - std::pow(b2, (double)t);
     const double step_size = (double)cfg->lr / bc1;
     const double bc2_sqrt = std::sqrt(bc2);
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq,
-                       (long long)c->P, (const double*)c->sumsq_part, nblk, cfg->max_grad_norm, (float)(1.0 - b1), (float)b2,
-                       (float)(1.0 - b2), (float)(-step_size), (float)bc2_sqrt, (float)cfg->eps, cfg->apply_step,
-                       grad_norm_out);
+    if (per != nullptr)
+        hipLaunchKernelGGL(clip_adam_per_kernel, dim3(stream_grid(c->P, ST_THREADS) + 1), dim3(ST_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq,
+                           (long long)c->P, (const double*)c->sumsq_part, nblk, cfg->max_grad_norm, (float)(1.0 - b1), (float)b2,
+                           (float)(1.0 - b2), (float)(-step_size), (float)bc2_sqrt, (float)cfg->eps, cfg->apply_step,
+                           grad_norm_out, *per);
+    else
+        hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq,
+                           (long long)c->P, (const double*)c->sumsq_part, nblk, cfg->max_grad_norm, (float)(1.0 - b1), (float)b2,
+                           (float)(1.0 - b2), (float)(-step_size), (float)bc2_sqrt, (float)cfg->eps, cfg->apply_step,
+                           grad_norm_out);
     LAUNCH_CHECK("clip_adam");
     return MORL_OK;
 }
@@ -1291,6 +1318,13 @@ extern "C" int morl_envelope_step_sharded(morl_ctx* c, morl_comm* comm, float* p
                                          i_offset, W_local, slab_all, slab_all + half, &shard, &out, stream)))
         return rc;
     if ((rc = morl_allreduce_grads(comm, grads_x, n_params + 1 + B, stream))) return rc;
+    if (cfg->apply_step && (!exp_avg || !exp_avg_sq)) return fail(MORL_ERR_ARG, "Adam state is NULL");
+    if (cfg->per_tree && B <= ST_MAX_B) {
+        SumTreeUpdate u{};
+        u.tree = cfg->per_tree; u.idx = cfg->per_idx; u.raw = grads_x + n_params + 1; u.running_max = cfg->per_running_max;
+        u.n_levels = cfg->per_levels; u.B = B; u.alpha = cfg->per_alpha;
+        return clip_adam_step(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, false, (hipStream_t)stream, &u);
+    }
     if ((rc = morl_clip_adam(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, stream))) return rc;
     if (cfg->per_tree)
         return morl_sumtree_update(cfg->per_tree, cfg->per_levels, cfg->per_idx, grads_x + n_params + 1, B, cfg->per_alpha,

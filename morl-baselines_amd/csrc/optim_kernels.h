@@ -71,14 +71,13 @@ static __global__ __launch_bounds__(OPT_THREADS) void grad_reduce_kernel(const f
 // so all blocks see the identical norm without a grid barrier.
 // Algorithmic bytes: 4*P*7 (read p,g,m,v; write p,m,v) + 4*P (clipped g written back).
 // ----------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(float* __restrict__ params, float* __restrict__ grads,
-                                                                float* __restrict__ exp_avg,
-                                                                float* __restrict__ exp_avg_sq, long long P,
-                                                                const double* __restrict__ sumsq_part, int n_part,
-                                                                float max_norm, float one_minus_b1, float b2,
-                                                                float one_minus_b2, float neg_step_size,
-                                                                float bc2_sqrt, float eps, int apply_step,
-                                                                float* __restrict__ grad_norm_out) {
+// (`nblk` workgroups share the parameters: the kernel that carries the PER tree update as one extra workgroup -- morl_hip.hip:
+// clip_adam_per_kernel -- has one more than take part here)
+__device__ __forceinline__ void clip_adam_body(float* __restrict__ params, float* __restrict__ grads, float* __restrict__ exp_avg,
+                                               float* __restrict__ exp_avg_sq, long long P, const double* __restrict__ sumsq_part,
+                                               int n_part, float max_norm, float one_minus_b1, float b2, float one_minus_b2,
+                                               float neg_step_size, float bc2_sqrt, float eps, int apply_step,
+                                               float* __restrict__ grad_norm_out, int nblk) {
     double t = 0.0;
     for (int e = lane_id(); e < n_part; e += kWave) t += sumsq_part[e];
     t = wave_sum(t);
@@ -87,7 +86,7 @@ static __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(float* __
     if (max_norm >= 0.f) coef = fminf(__fdiv_rn(max_norm, __fadd_rn(total, 1e-6f)), 1.0f);
     if (blockIdx.x == 0 && threadIdx.x == 0 && grad_norm_out) *grad_norm_out = total;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P;
-         p += (long long)gridDim.x * blockDim.x) {
+         p += (long long)nblk * blockDim.x) {
         float g = grads[p];
         if (max_norm >= 0.f) { g = __fmul_rn(g, coef); grads[p] = g; }
         if (!apply_step) continue;
@@ -100,6 +99,18 @@ static __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(float* __
         exp_avg[p] = m;
         exp_avg_sq[p] = v;
     }
+}
+
+static __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(float* __restrict__ params, float* __restrict__ grads,
+                                                                float* __restrict__ exp_avg,
+                                                                float* __restrict__ exp_avg_sq, long long P,
+                                                                const double* __restrict__ sumsq_part, int n_part,
+                                                                float max_norm, float one_minus_b1, float b2,
+                                                                float one_minus_b2, float neg_step_size,
+                                                                float bc2_sqrt, float eps, int apply_step,
+                                                                float* __restrict__ grad_norm_out) {
+    clip_adam_body(params, grads, exp_avg, exp_avg_sq, P, sumsq_part, n_part, max_norm, one_minus_b1, b2, one_minus_b2,
+                   neg_step_size, bc2_sqrt, eps, apply_step, grad_norm_out, (int)gridDim.x);
 }
 
 // polyak_update (common/networks.py:120-139): tau == 1 -> copy, else t = t*(1-tau) + tau*p
