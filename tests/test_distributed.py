@@ -160,6 +160,50 @@ def test_one_call_sharded_step_equals_the_staged_one(per):
         native.use_library(None)
 
 
+def test_one_call_sharded_step_rejects_bad_arguments():
+    """Error behaviour of ``morl_envelope_step_sharded``: a status code + message, never a launch on bad geometry."""
+    import ctypes as C
+    import simlib
+    import morl_baselines_amd.native as native
+    from morl_baselines_amd import ops
+    from morl_baselines_amd.distributed import NativeComm
+    lib = simlib.load_sim()
+    native.use_library(lib)
+    try:
+        ag = _make_agent(lib, per=False)
+        comm = NativeComm(lib, None, "cpu", loopback=True)
+        ctx, P = ag.q_net.ctx, ag.q_net.ctx.n_params
+        B, W, A, R = ag.batch_size, ag.num_sample_w, ag.action_dim, ag.reward_dim
+        D = ag.observation_dim
+        gx = th.zeros(P + 1 + B)
+        obs, nobs = th.zeros(B, D), th.zeros(B, D)
+        act, rew, done = th.zeros(B, dtype=th.int32), th.zeros(B, R), th.zeros(B)
+        w = th.full((W, R), 1.0 / R)
+
+        def call(i0, wl, slab_parts=None, handle=comm.handle, grads=gx):
+            parts = W // wl if slab_parts is None else slab_parts
+            loc, allb = th.zeros(2, B, wl, A, R), th.zeros(parts, 2, B, wl, A, R)
+            ops.envelope_step_sharded(ctx, handle, ag.q_net.flat, ag.target_q_net.flat, grads, ag._exp_avg, ag._exp_avg_sq, obs, nobs,
+                                      act, rew, done, w, i0, wl, loc, allb, gamma=0.99, lr=1e-3, adam_step=1, max_grad_norm=1.0)
+
+        ag.q_net.ensure_capacity(B, W)
+        call(0, W)                                              # the whole weight axis on one rank: fine
+        call(W // 2, W // 2)                                    # one rank of two, run alone (loopback communicator): fine
+        with pytest.raises(RuntimeError, match="bad shard"):
+            call(1, W // 2)                                     # a shard must start at a multiple of its width
+        with pytest.raises(RuntimeError, match="NULL"):
+            call(0, W, handle=None)
+        with pytest.raises(ValueError):
+            call(0, W, grads=th.zeros(P))                        # gradient | loss | priorities buffer too short
+        with pytest.raises(ValueError):
+            call(0, W // 2, slab_parts=1)                        # gathered buffer does not hold every rank's slabs
+        assert lib.lib.morl_envelope_step_sharded(ctx.handle, comm.handle, None, None, None, P, None, None, None, None, None, None,
+                                                  None, None, B, W, 0, W, None, None, None, None) != 0
+        assert b"NULL" in lib.lib.morl_last_error()
+    finally:
+        native.use_library(None)
+
+
 # ---- data-parallel CAPQL (BASELINE config 4): gradients averaged inside morl_ac_update -----------------------------------------
 def _capql_case():
     from cases_ac import ACCase
