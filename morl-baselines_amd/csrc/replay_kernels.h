@@ -75,25 +75,36 @@ __device__ __forceinline__ void sample_gather_body(const SampleGatherArgs& a, in
         for (int e = (int)threadIdx.x; e < a.aux_floats; e += (int)blockDim.x) a.aux_dst[e] = a.aux_src[e];
     for (int b = block * waves_per_block + wave_id(); b < a.B; b += n_blocks * waves_per_block) {
         long long t = 0;
-        if (lane == 0) {
-            if (a.tree != nullptr) {
-                double q = __dadd_rn(0.0, __dmul_rn(__dsub_rn(a.tree[0], 0.0), a.u01[b]));
-                long long node = 0;
-                for (int l = 1; l < a.n_levels; ++l) {
-                    node *= 2;
-                    const double left = a.tree[level_off(l) + node];
+        if (a.tree != nullptr) {
+            // SumTree.sample's descent (prioritized_buffer.py:30-54), five levels per memory round trip: the wave fetches the
+            // 62 nodes of the subtree below the current node in ONE load (lane (2^j - 2) + i holds node i of relative level j)
+            // and walks it with shuffles -- 4 round trips for a 100 000-leaf tree instead of 17 dependent loads by one lane.
+            // Same comparisons and the same fp64 subtractions in the same order: indices stay bit-exact.
+            double q = __dadd_rn(0.0, __dmul_rn(__dsub_rn(a.tree[0], 0.0), a.u01[b]));     // (wave-uniform)
+            long long node = 0;
+            const int ln = lane + 2;
+            int j = 1;
+            while ((2 << j) <= ln) ++j;
+            const int i = ln - (1 << j);
+            for (int l = 0; l < a.n_levels - 1;) {
+                const int depth = min(5, a.n_levels - 1 - l);
+                double v = 0.0;
+                if (j <= depth) v = a.tree[level_off(l + j) + (node << j) + i];
+                int loc = 0;
+                for (int jj = 1; jj <= depth; ++jj) {
+                    const double left = __shfl(v, (1 << jj) - 2 + 2 * loc);
                     const bool gt = q > left;
-                    node += gt ? 1 : 0;
+                    loc = 2 * loc + (gt ? 1 : 0);
                     q = __dsub_rn(q, __dmul_rn(left, gt ? 1.0 : 0.0));
                 }
-                t = node;
-            } else {
-                t = a.idx_in[b];
+                node = (node << depth) + loc;
+                l += depth;
             }
-            if (a.idx_out) a.idx_out[b] = t;
+            t = node;
+        } else {
+            t = a.idx_in[b];
         }
-        const int lo = __shfl((int)(t & 0xffffffffll), 0), hi = __shfl((int)(t >> 32), 0);
-        t = ((long long)hi << 32) | (unsigned int)lo;
+        if (lane == 0 && a.idx_out) a.idx_out[b] = t;
         if (t < 0) t = 0;
         if (t >= a.capacity) t = a.capacity - 1;
         const float* rec = a.records + (size_t)t * a.record_floats;
