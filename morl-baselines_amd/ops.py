@@ -34,11 +34,13 @@ class QNetContext:
         self.fused = self.engine > 0
 
     def set_dw_mode(self, mode: int) -> None:
-        """Weight-gradient engine: 0 wave-level tiles, 1 double-buffered LDS tiles (default), 2 single-buffered."""
+        """Weight-gradient engine: 0 wave-level tiles, 1 double-buffered LDS tiles, 2 single-buffered, 3 balanced per-problem
+        wave layouts with a three-stage operand pipeline (``dw_tiles.h``; default)."""
         self.lib.check(self.lib.lib.morl_ctx_set_dw_mode(self.handle, int(mode)))
 
     def set_timing(self, every: int) -> None:
-        """Time the chain launches of every ``every``-th Envelope step with HIP events (0 / False: off, True: every step)."""
+        """Time the chain launches of every ``every``-th Envelope step with HIP events (0 / False: off, True: every step,
+        -1: one launch of every step, the launches of a step taking turns)."""
         self.lib.check(self.lib.lib.morl_ctx_set_timing(self.handle, int(every)))
 
     def read_timing(self):
