@@ -53,8 +53,8 @@ def _worker(rank, world, port, per, ret, schedules=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("per,schedules", [(False, False), (True, False), (True, True)])
-def test_sharded_update_equals_single_process(per, schedules):
+@pytest.mark.parametrize("per,schedules,world", [(False, False, 2), (True, False, 2), (True, True, 2), (True, False, 4)])
+def test_sharded_update_equals_single_process(per, schedules, world):
     """``schedules``: several steps with ``homotopy_decay_steps`` / ``epsilon_decay_steps`` set -- the sharded step must run
     the same tail as ``Envelope.update`` (envelope.py:336-355), or the auxiliary loss never turns on under sharding."""
     import simlib
@@ -74,10 +74,9 @@ def test_sharded_update_equals_single_process(per, schedules):
         native.use_library(None)
     if schedules:
         assert 0.0 < want_lam <= 1.0 and want_eps < 0.5            # the schedules actually moved
-    world = 2
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 29500 + (os.getpid() % 2000) + 7 * int(schedules)
+    port = 29500 + (os.getpid() % 2000) + 7 * int(schedules) + 13 * (world - 2)
     procs = [ctx.Process(target=_worker, args=(r, world, port, per, ret, schedules)) for r in range(world)]
     for p in procs:
         p.start()
@@ -85,9 +84,12 @@ def test_sharded_update_equals_single_process(per, schedules):
         p.join(600)
         assert p.exitcode == 0
     p0, l0, t0, lam0, eps0 = ret[0]
-    p1, l1, t1, lam1, eps1 = ret[1]
-    assert np.array_equal(p0, p1) and l0 == l1                      # replicas bit-identical
-    assert lam0 == lam1 == want_lam and eps0 == eps1 == want_eps     # same schedules as the unsharded agent
+    for r in range(1, world):                                       # (world 4: one weight per rank, four slab parts)
+        p1, l1, t1, lam1, eps1 = ret[r]
+        assert np.array_equal(p0, p1) and l0 == l1                  # replicas bit-identical
+        assert lam0 == lam1 == want_lam and eps0 == eps1 == want_eps     # same schedules as the unsharded agent
+        if per:
+            assert np.array_equal(t0, t1)
     assert abs(l0 - want_loss) <= 1e-5 * abs(want_loss)              # sharded == unsharded (fp32 order tolerance)
     assert np.abs(p0 - want).max() <= 0.02 * 3e-4 * n_steps
     if per:
