@@ -340,11 +340,24 @@ __global__ __launch_bounds__(64 * COLRED_WAVES) void ac_ln_grad_kernel(LnGradArg
     float sg = 0.f, sb = 0.f;
     if (c < a.N) {
         const long long base = (long long)g * a.gstride + c;
-        for (int r = wave; r < a.rows; r += COLRED_WAVES) {
-            const long long o = base + (long long)r * a.ld;
-            const float dy = (a.h[o] > 0.f) ? a.d[o] : 0.f;
-            sg += dy * a.xhat[o];
-            sb += dy;
+        // eight rows of this wave per trip: their 24 loads are issued together (the plain loop waited for one row's three
+        // loads at a time: 16 dependent round trips for 256 rows, 11.5 us), then summed in the same row order as before
+        constexpr int U = 8;
+        for (int r0 = wave; r0 < a.rows; r0 += COLRED_WAVES * U) {
+            float hv[U], dv[U], xv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + COLRED_WAVES * u;
+                const long long o = base + (long long)(r < a.rows ? r : r0) * a.ld;
+                hv[u] = a.h[o]; dv[u] = a.d[o]; xv[u] = a.xhat[o];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r0 + COLRED_WAVES * u >= a.rows) break;
+                const float dy = (hv[u] > 0.f) ? dv[u] : 0.f;
+                sg += dy * xv[u];
+                sb += dy;
+            }
         }
     }
     s_g[wave][lane] = sg;

@@ -91,11 +91,23 @@ __global__ __launch_bounds__(1024) void gpi_embed_grad_kernel(EmbedGradArgs a) {
 #pragma unroll
     for (int r = 0; r <= MORL_MAX_OBJ; ++r) acc[r] = 0.f;
     if (j < a.H) {
-        for (int row = wave; row < a.rows; row += 16) {
-            const float d = a.dwf[(long long)g * a.gstride + (long long)row * a.ld + j];
-            const float* __restrict__ wr = a.w + (long long)row * a.w_rstride;
-            for (int r = 0; r < a.R; ++r) acc[r] = fmaf(d, wr[r], acc[r]);
-            acc[MORL_MAX_OBJ] += d;
+        // eight rows per trip, their loads issued together, accumulated in the same row order (see ac_ln_grad_kernel)
+        constexpr int U = 8;
+        for (int row0 = wave; row0 < a.rows; row0 += 16 * U) {
+            float dv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = row0 + 16 * u;
+                dv[u] = a.dwf[(long long)g * a.gstride + (long long)(row < a.rows ? row : row0) * a.ld + j];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = row0 + 16 * u;
+                if (row >= a.rows) break;
+                const float* __restrict__ wr = a.w + (long long)row * a.w_rstride;
+                for (int r = 0; r < a.R; ++r) acc[r] = fmaf(dv[u], wr[r], acc[r]);
+                acc[MORL_MAX_OBJ] += dv[u];
+            }
         }
     }
 #pragma unroll
