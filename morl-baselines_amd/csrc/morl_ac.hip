@@ -626,6 +626,14 @@ static int launch_transposes(const TransposeMulti& tm, hipStream_t s) {
     int tiles = 0, nets = 0;
     for (int k = 0; k < tm.n; ++k) { tiles = std::max(tiles, host_tiles(tm.lay[k])); nets = std::max(nets, tm.nets[k]); }
     if (tm.n < 1 || nets < 1) return MORL_OK;
+    long long longest = 0;
+    for (int k = 0; k < tm.n; ++k) longest = std::max(longest, tm.lay[k].P * tm.nets[k]);
+    static const long long scatter_max = [] { const char* e = getenv("MORL_AC_SCATTER_MAX"); return e ? atoll(e) : (1ll << 20); }();   // (tests)
+    if (longest <= scatter_max) {
+        hipLaunchKernelGGL(ac_transpose_scatter_kernel, dim3(stream_grid(longest, 256, 1024), 1, tm.n), dim3(256), 0, s, tm);
+        LAUNCH_CHECK("ac_transpose");
+        return MORL_OK;
+    }
     if (nets > 65535) return fail(MORL_ERR_ARG, "%d nets in one transpose launch", nets);
     hipLaunchKernelGGL(ac_transpose_multi_kernel, dim3(tiles + 1, nets, tm.n), dim3(256), 0, s, tm);
     LAUNCH_CHECK("ac_transpose");
