@@ -1,0 +1,45 @@
+"""Seeded shape sweep of one Envelope gradient step: random batch / weight counts (ragged against every tile size: 16, 32, 64
+rows), observation / action / objective counts and hidden widths (multiples of 4 up to 256, one to four layers), through every
+MLP engine, against the oracle with the per-update parity contract of test_kernels_parity.py.  The fixtures pin the reference's
+shapes; this pins the edges between them -- partial row tiles, K padding of odd input widths, narrow / wide last layers, split
+counts of the weight-gradient jobs.  The emulator takes the three smallest cases, the GPU all of them."""
+import numpy as np
+import pytest
+
+from cases import Case, make_inputs
+from test_kernels_parity import be, check_update, run_oracle, run_update  # noqa: F401  (be: the backend fixture)
+
+
+def _random_cases(n, seed=2024):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        L = int(rng.integers(1, 5))
+        arch = tuple(int(4 * rng.integers(9, 65)) for _ in range(L))            # 36 .. 256, multiples of 4
+        if k % 5 == 0:
+            arch = tuple(256 for _ in range(L))                                  # the fast (constant-stride) weight stream
+        B = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 31, 33, 48, 63, 64, 65, 96, 130]))
+        W = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 24, 33]))
+        if B * W > 2600:
+            W = max(1, 2600 // B)
+        out.append(Case(f"fuzz{k}_B{B}W{W}_{'x'.join(map(str, arch))}", B=B, W=max(W, 1 if k % 7 else 2), D=int(rng.integers(1, 41)),
+                        A=int(rng.integers(1, 8)), R=int(rng.integers(2, 5)), arch=arch, envelope=bool(k % 6 != 5),
+                        homotopy_lambda=float(rng.choice([0.0, 0.0, 0.4])), max_grad_norm=[1.0, 0.1, None][k % 3],
+                        step=int(rng.integers(1, 9)), seed=100 + k))
+    return out
+
+
+FUZZ = _random_cases(30)
+SMALL = sorted(FUZZ, key=lambda c: c.B * c.W * sum(c.arch))[:3]
+
+
+@pytest.mark.parametrize("fused", [1, 0], ids=["fused", "perlayer"])
+@pytest.mark.parametrize("c", FUZZ, ids=lambda c: c.name)
+def test_random_shapes_match_the_oracle(be, c, fused):
+    lib, dev, is_sim = be
+    if is_sim and c not in SMALL:
+        pytest.skip("the emulator runs the three smallest shapes; the rest need the GPU")
+    inp = make_inputs(c)
+    res, t = run_update(lib, dev, c, inp, fused=fused)
+    o, online, m, v = run_oracle(c, inp)
+    check_update(res, t, o, online, m, v, c)
