@@ -115,11 +115,9 @@ def close(a, b, rtol, atol_frac=1e-5):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_frac * scale)
 
 
-@pytest.mark.parametrize("c", AC_CASES, ids=lambda c: c.name)
-def test_update_matches_oracle_and_reference(be, c):
-    lib, dev = be
-    if dev.type == "cpu" and max(c.arch) >= 256:
-        pytest.skip("reference-sized networks run on the GPU only (the emulator is slow)")
+def run_and_check_against_oracle(lib, dev, c):
+    """One update of case ``c`` through the C ABI, every exposed intermediate compared with the oracle on the same inputs;
+    returns (engine, device results, whether the policy was stepped) for further checks."""
     inp = make_inputs(c)
     eng = build_engine(c, inp, lib, dev)
     want = ["critic_loss", "q_losses", "target_q", "q_grads"]
@@ -161,6 +159,16 @@ def test_update_matches_oracle_and_reference(be, c):
             close(g_.cpu(), w_, 2e-4, 5e-5)
     if "priority" in res:
         close(res["priority"][0], out["priority_raw"], 1e-5)
+    return eng, res, do_policy
+
+
+@pytest.mark.parametrize("c", AC_CASES, ids=lambda c: c.name)
+def test_update_matches_oracle_and_reference(be, c):
+    lib, dev = be
+    if dev.type == "cpu" and max(c.arch) >= 256:
+        pytest.skip("reference-sized networks run on the GPU only (the emulator is slow)")
+    eng, res, do_policy = run_and_check_against_oracle(lib, dev, c)
+    rel = lambda a, b: abs(float(a) - float(b)) <= 1e-5 * max(abs(float(b)), 1e-3)  # noqa: E731
     # ---- against the fixture the unmodified reference produced --------------------------------------------------------
     g = load_golden(c)
     st = engine_state(c, eng)

@@ -43,3 +43,43 @@ def test_random_shapes_match_the_oracle(be, c, fused):
     res, t = run_update(lib, dev, c, inp, fused=fused)
     o, online, m, v = run_oracle(c, inp)
     check_update(res, t, o, online, m, v, c)
+
+
+# ---- the actor-critic updates (CAPQL, MOSAC, MOSAC-discrete, GPI-PD continuous): the same sweep over their shapes ------------
+from cases_ac import ACCase  # noqa: E402
+from test_ac_kernels_parity import run_and_check_against_oracle  # noqa: E402
+from test_ac_kernels_parity import be as ac_be  # noqa: E402,F401
+
+
+def _random_ac_cases(n, seed=77):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        algo = ["capql", "mosac", "gpipd", "sacd"][k % 4]
+        arch = tuple(int(4 * rng.integers(9, 65)) for _ in range(2))
+        if k % 3 == 0:
+            arch = (256, 256)
+        B = int(rng.choice([1, 3, 15, 16, 17, 31, 33, 64, 100, 128, 200]))
+        kw = dict(D=int(rng.integers(2, 24)), Ad=int(rng.integers(1, 7)), R=int(rng.integers(2, 5)), arch=arch, B=B,
+                  step=int(rng.integers(1, 6)), seed=500 + k)
+        if algo == "mosac":
+            kw.update(autotune=bool(k % 8 < 4), global_step=100 + (k // 4) % 2)
+        if algo == "sacd":
+            kw.update(Ad=max(2, kw["Ad"]), tau=float(rng.choice([1.0, 0.3])), autotune=bool(k % 8 < 4))
+        if algo == "gpipd":
+            kw.update(n_support=int(rng.choice([1, 3])), per=bool(k % 8 < 4), n_updates=(k // 4) % 2,
+                      layer_norm=bool(k % 16 < 12), drop_rate=0.01 if k % 16 < 12 else 0.0)
+        out.append(ACCase(f"acfuzz{k}_{algo}_B{B}_{arch[0]}x{arch[1]}", algo, **kw))
+    return out
+
+
+AC_FUZZ = _random_ac_cases(24)
+AC_SMALL = sorted(AC_FUZZ, key=lambda c: c.B * sum(c.arch))[:3]
+
+
+@pytest.mark.parametrize("c", AC_FUZZ, ids=lambda c: c.name)
+def test_random_actor_critic_shapes_match_the_oracle(ac_be, c):
+    lib, dev = ac_be
+    if dev.type == "cpu" and c not in AC_SMALL:
+        pytest.skip("the emulator runs the three smallest shapes; the rest need the GPU")
+    run_and_check_against_oracle(lib, dev, c)
