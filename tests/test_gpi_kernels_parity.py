@@ -55,11 +55,9 @@ def close(a, b, rtol, frac):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=frac * (np.abs(b).max() + 1e-30))
 
 
-@pytest.mark.parametrize("c", GPI_CASES, ids=lambda c: c.name)
-def test_update_actions_priorities(be, c):
-    lib, dev = be
-    if dev.type == "cpu" and max(c.arch) >= 256:
-        pytest.skip("reference-sized networks run on the GPU only (the emulator is slow)")
+def run_and_check_against_oracle(lib, dev, c):
+    """One ``GPIPD.update`` body of case ``c`` through the C ABI against the oracle on the same inputs; returns
+    (engine, inputs, device results)."""
     inp = make_inputs(c)
     eng = build(c, inp, lib, dev)
     batch, w, sampled_w = rows_and_weights(c, inp)
@@ -88,6 +86,15 @@ def test_update_actions_priorities(be, c):
             o += k
     if c.max_grad_norm >= 0:
         close(res["grad_norm"], th.stack(out["norms"]), 1e-5, 1e-6)
+    return eng, inp, res
+
+
+@pytest.mark.parametrize("c", GPI_CASES, ids=lambda c: c.name)
+def test_update_actions_priorities(be, c):
+    lib, dev = be
+    if dev.type == "cpu" and max(c.arch) >= 256:
+        pytest.skip("reference-sized networks run on the GPU only (the emulator is slow)")
+    eng, inp, res = run_and_check_against_oracle(lib, dev, c)
     # ---- the fixture of the unmodified reference -------------------------------------------------------------------------
     g = load_golden(c)
     assert abs(float(res["critic_loss"]) - float(g["critic_loss"])) <= 1e-5 * float(g["critic_loss"])

@@ -83,3 +83,37 @@ def test_random_actor_critic_shapes_match_the_oracle(ac_be, c):
     if dev.type == "cpu" and c not in AC_SMALL:
         pytest.skip("the emulator runs the three smallest shapes; the rest need the GPU")
     run_and_check_against_oracle(lib, dev, c)
+
+
+# ---- GPIPD.update (conditioned Q-networks with Dropout / LayerNorm, envelope targets over a support set) ---------------------
+from cases_gpi import GpiCase  # noqa: E402
+from test_gpi_kernels_parity import run_and_check_against_oracle as gpi_check  # noqa: E402
+from test_gpi_kernels_parity import be as gpi_be  # noqa: E402,F401
+
+
+def _random_gpi_cases(n, seed=909):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        L = int(rng.integers(2, 5))
+        arch = tuple(int(4 * rng.integers(6, 65)) for _ in range(L))
+        if k % 4 == 0:
+            arch = tuple(256 for _ in range(L))
+        B = int(rng.choice([1, 2, 7, 16, 17, 33, 64, 100, 128]))
+        out.append(GpiCase(f"gpifuzz{k}_B{B}_{'x'.join(map(str, arch))}", D=int(rng.integers(1, 20)), A=int(rng.integers(2, 8)),
+                           R=int(rng.integers(2, 5)), arch=arch, B=B, n_support=int(rng.choice([1, 2, 5])),
+                           gpi_pd=bool(k % 5 != 4), step=int(rng.integers(1, 6)), layer_norm=bool(k % 6 != 5),
+                           drop_rate=0.01 if k % 6 != 5 else 0.0, max_grad_norm=[-1.0, 0.5][k % 2], seed=700 + k))
+    return out
+
+
+GPI_FUZZ = _random_gpi_cases(16)
+GPI_SMALL = sorted(GPI_FUZZ, key=lambda c: c.B * c.n_support * sum(c.arch))[:2]
+
+
+@pytest.mark.parametrize("c", GPI_FUZZ, ids=lambda c: c.name)
+def test_random_gpi_shapes_match_the_oracle(gpi_be, c):
+    lib, dev = gpi_be
+    if dev.type == "cpu" and c not in GPI_SMALL:
+        pytest.skip("the emulator runs the two smallest shapes; the rest need the GPU")
+    gpi_check(lib, dev, c)
