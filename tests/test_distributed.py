@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_STEPS = {False: 2, True: 5}      # plain / with the epsilon + homotopy schedules running
 
 
-def _make_agent(lib, per, schedules=False):
+def _make_agent(lib, per, schedules=False, dev=th.device("cpu"), arch=(32, 32), B=8, W=4):
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     import morl_baselines_amd.envelope as envmod
     from test_host_api import ToyEnv, _fill
@@ -23,8 +23,8 @@ def _make_agent(lib, per, schedules=False):
     th.manual_seed(0)
     np.random.seed(0)
     extra = dict(homotopy_decay_steps=6, initial_epsilon=0.5, final_epsilon=0.05, epsilon_decay_steps=8) if schedules else {}
-    ag = envmod.Envelope(env, net_arch=[32, 32], batch_size=8, num_sample_w=4, buffer_size=256, per=per,
-                         learning_starts=0, log=False, seed=0, device=th.device("cpu"), lib=lib, **extra)
+    ag = envmod.Envelope(env, net_arch=list(arch), batch_size=B, num_sample_w=W, buffer_size=256, per=per,
+                         learning_starts=0, log=False, seed=0, device=dev, lib=lib, **extra)
     _fill(ag.replay_buffer, 100, env.D, env.A, env.R)
     ag.global_step = 7
     return ag
@@ -122,6 +122,39 @@ class _OneRank:
 
     class ReduceOp:
         SUM = "sum"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("per", [False, True])
+def test_one_call_sharded_step_equals_the_staged_one_on_the_gpu(per):
+    """The same equality on the MI355X at a shape that takes the production kernels (16-row chain tiles, the weight-gradient
+    tiles, the PER update inside the clip + Adam launch): loopback communicator, one rank of 1 / 2 / 4."""
+    import morl_baselines_amd.native as native
+    from morl_baselines_amd.distributed import NativeComm, shard_envelope_agent
+    lib = native.load_library()
+    dev = th.device("cuda:0")
+    for emulate in (None, (2, 1), (4, 3)):
+        runs = []
+        for one_call in (False, True, None):
+            ag = _make_agent(lib, per, schedules=True, dev=dev, arch=(256, 256, 256), B=64, W=16)
+            if one_call is not None:
+                comm = NativeComm(lib, None, dev, loopback=True) if one_call else None
+                shard_envelope_agent(ag, _OneRank(), emulate=emulate, comm=comm)
+            for _ in range(4):
+                ag.update()
+                ag.global_step += 1
+            th.cuda.synchronize()
+            runs.append((ag.q_net.flat.clone().cpu().numpy(), ag.last_loss(),
+                         ag.replay_buffer.tree_dev.clone().cpu().numpy() if per else None))
+        staged, fused, plain = runs
+        assert np.array_equal(staged[0], fused[0]) and staged[1] == fused[1]
+        if per:
+            assert np.array_equal(staged[2], fused[2])
+        if emulate is None:
+            assert abs(fused[1] - plain[1]) <= 1e-5 * abs(plain[1])
+            assert np.abs(fused[0] - plain[0]).max() <= 0.02 * 3e-4 * 4
+            if per:
+                np.testing.assert_allclose(fused[2][0], plain[2][0], rtol=1e-5)
 
 
 @pytest.mark.parametrize("per", [False, True])
