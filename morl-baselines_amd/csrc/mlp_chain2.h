@@ -40,6 +40,7 @@ struct C2WideDesc {
     __amdgpu_buffer_rsrc_t rsrc;
     int lane_off;     // bytes: (4h * ldb + colw) * 4, or CH_OOB when the lane's columns do not exist
     int stride;       // bytes per k-row (wave-uniform)
+    int lane_off1;    // N-major stream (LD = 2) only: the lane's second column, see c2_wide_desc_n
 };
 
 __device__ __forceinline__ C2WideDesc c2_wide_desc(const ChainStep& st, int wave, int i, int h, int g = 0) {
@@ -49,6 +50,36 @@ __device__ __forceinline__ C2WideDesc c2_wide_desc(const ChainStep& st, int wave
     d.lane_off = (colw < st.ldb) ? (4 * h * st.ldb + colw) * 4 : CH_OOB;
     d.stride = st.ldb * 4;
     return d;
+}
+
+// N-major stream (LD = 2): the operand is read from the nn.Linear matrix itself, Bt [N][ldbt] (row n contiguous over k), so a
+// forward pass needs no K-major shadow copy of its weights.  Lane (i, h) still multiplies k = k0 + 8c + 4h + t in MFMA step t of
+// group c -- four consecutive k of one row = ONE 16-byte load per column and group (8 loads per set instead of 16): same
+// values, same MFMA k order, bit-identical results.  A quad that runs past its row's K reads the next row's first weights
+// (finite) against activation columns that are exactly zero there, past the matrix the range check returns 0.
+__device__ __forceinline__ C2WideDesc c2_wide_desc_n(const ChainStep& st, int wave, int i, int h, int g = 0) {
+    C2WideDesc d;
+    const int colw = wave * 64 + 2 * i;
+    // (K not a multiple of 4: the last row's last quad straddles the end of the matrix; the range covers the whole quad -- the
+    // bias vector follows every matrix in the flat parameter layout -- so that no valid weight is cut by a partial range check)
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bt + g * st.sW), 0, (st.N * st.ldbt + ((st.K & 3) ? 4 : 0)) * 4, 0x00020000);
+    d.lane_off = (colw < st.N) ? (colw * st.ldbt + 4 * h) * 4 : CH_OOB;
+    d.lane_off1 = (colw + 1 < st.N) ? ((colw + 1) * st.ldbt + 4 * h) * 4 : CH_OOB;
+    d.stride = 0;
+    return d;
+}
+
+__device__ __forceinline__ void c2_load_nmajor(C2BSet& s, const C2WideDesc& d, int k0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int kb = (k0 + 8 * c) * 4;
+        const float4 q0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d.rsrc, d.lane_off + kb, 0, 0));
+        const float4 q1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d.rsrc, d.lane_off1 + kb, 0, 0));
+        s.v[4 * c + 0] = make_float2(q0.x, q1.x);
+        s.v[4 * c + 1] = make_float2(q0.y, q1.y);
+        s.v[4 * c + 2] = make_float2(q0.z, q1.z);
+        s.v[4 * c + 3] = make_float2(q0.w, q1.w);
+    }
 }
 
 // rows >= K lie beyond the resource: the hardware returns 0 (K padding, dummy prefetches) -- no branch, no select
@@ -86,6 +117,25 @@ __device__ __forceinline__ void c2_load_narrow(C2BSet& s, const ChainStep& st, i
     }
 }
 
+// the same operand from the K-major matrix Bmat [K][ldb] when no N-major copy exists (st.Bt == NULL: the first-layer dX step of
+// a backward chain reads the nn.Linear matrix [out = K][in = N] as it is): four dword loads instead of one 16-byte load
+__device__ __forceinline__ void c2_load_narrow_k(C2BSet& s, const ChainStep& st, int wave, int i, int h, int g = 0) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bmat + g * st.sW), 0, st.K * st.ldb * 4, 0x00020000);
+    const int kbase = wave * 64 + 4 * h;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int k = kbase + 8 * c;
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int off = (i < st.N && k + t < st.K) ? ((k + t) * st.ldb + i) * 4 : CH_OOB;
+            v[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+        }
+        s.v[2 * c] = make_float2(v[0], v[1]);
+        s.v[2 * c + 1] = make_float2(v[2], v[3]);
+    }
+}
+
 // LDS -> HBM copy of the tile in sAct (the step's input = the previous step's output) in TM / 4 pieces: piece `it` moves
 // rows 4*it .. 4*it + 3, one wave = one full row (64 x 16 bytes) per instruction.  Branch-free: the destination is a buffer
 // resource spanning exactly out[rows][ldout], so rows beyond the matrix (ragged last tile) are dropped by the range check,
@@ -119,7 +169,19 @@ __device__ __forceinline__ void c2_copy_piece(const float* sAct, const C2CopyDst
 // adds spread over the MFMAs of the other register set, one copy piece per group.
 #define C2_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 
-template <int TM, bool COPY, int SCHED, bool FAST>
+// LD: the weight stream -- 0 K-major, any stride; 1 K-major, constant stride (ChainArgs::fast == 1); 2 N-major (fast == 2)
+template <int LD>
+__device__ __forceinline__ void c2_load(C2BSet& s, const C2WideDesc& d, int k0) {
+    if (LD == 1) c2_load_fast(s, d, k0);
+    else if (LD == 2) c2_load_nmajor(s, d, k0);
+    else c2_load_wide(s, d, k0);
+}
+template <int LD>
+__device__ __forceinline__ C2WideDesc c2_desc(const ChainStep& st, int wave, int i, int h, int g) {
+    return LD == 2 ? c2_wide_desc_n(st, wave, i, h, g) : c2_wide_desc(st, wave, i, h, g);
+}
+
+template <int TM, bool COPY, int SCHED, int LD>
 __device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& bx, C2BSet& by, const float* sAct, const float* pa,
                                              const C2WideDesc& dcur, const C2WideDesc& dnext, bool nxt_wide, int n_pairs,
                                              const C2CopyDst& cd) {
@@ -141,6 +203,7 @@ __device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& 
         dx.rsrc = from_next ? dnext.rsrc : dcur.rsrc;
         dx.lane_off = from_next ? dnext.lane_off : dcur.lane_off;
         dx.stride = from_next ? dnext.stride : dcur.stride;
+        dx.lane_off1 = from_next ? dnext.lane_off1 : dcur.lane_off1;
         const int kx = more ? k0 + 64 : 0;
         const int ky = more ? k0 + 96 : CH_BK;
 // one group = 8 contraction indices = 4 MFMA k-pairs x (2 * MT) tiles; the A quad of the NEXT group is read first
@@ -161,15 +224,13 @@ __device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& 
         C2_GROUP(bx, 1, ay, ax, k0 + 16)
         C2_GROUP(bx, 2, ax, ay, k0 + 24)
         C2_GROUP(bx, 3, ay, ax, k0 + 32)
-        if (FAST) c2_load_fast(bx, dx, kx);
-        else c2_load_wide(bx, dx, kx);
+        c2_load<LD>(bx, dx, kx);
         C2_GROUP(by, 0, ax, ay, k0 + 40)
         C2_GROUP(by, 1, ay, ax, k0 + 48)
         C2_GROUP(by, 2, ax, ay, k0 + 56)
         // (the last group's look-ahead read stays inside the buffer: column k0 + 64 + 7 <= 263, 8 spare floats at its end)
         C2_GROUP(by, 3, ay, ax, k0 + 64)
-        if (FAST) c2_load_fast(by, dcur, ky);
-        else c2_load_wide(by, dcur, ky);
+        c2_load<LD>(by, dcur, ky);
 #undef C2_GROUP
         if (COPY) {
 #pragma unroll
@@ -190,7 +251,7 @@ __device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& 
                     // bx's 16 refill loads, two per MFMA quad of groups 4 and 5 (one per quad over groups 4-7 measured
                     // 184 us for the three forward passes, this 181 us; issuing the copy stores after them instead of
                     // before -- vmcnt retires loads and stores in order -- measured worse, 187 us)
-                    if (g == 4 || g == 5) { if (!FAST) C2_SGB(0x002, 2); C2_SGB(0x020, 2); }
+                    if (g == 4 || g == 5) { if (LD == 0) C2_SGB(0x002, 2); C2_SGB(0x020, LD == 2 ? 1 : 2); }
                 }
                 if (COPY && g < PP) { C2_SGB(0x002, 1); C2_SGB(0x040, 1); }   // ... its address add and its store
             }
@@ -203,7 +264,7 @@ __device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& 
 // PROF (development probes only, tools/probes/chain2_probe.hip): wave 0 stamps s_memtime at the phase boundaries of the job
 #define C2_TICK() if (PROF) { if (n_tick < 24) ticks[n_tick] = clock64(); ++n_tick; }
 
-template <int TM, int SCHED, bool FAST, bool PROF = false>
+template <int TM, int SCHED, int LD, bool PROF = false>
 __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, float* sAct, long long* prof_out = nullptr,
                                                 int g = 0) {
     long long ticks[24];
@@ -217,10 +278,11 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
 
     C2BSet bx, by;
     const bool first_wide = p.step[0].N > 32;
-    C2WideDesc dcur = c2_wide_desc(p.step[0], wave, i, h, g);
+    C2WideDesc dcur = c2_desc<LD>(p.step[0], wave, i, h, g);
     // the weight stream starts before the input tile is assembled
-    if (first_wide) { if (FAST) c2_load_fast(bx, dcur, 0); else c2_load_wide(bx, dcur, 0); }
-    else c2_load_narrow(bx, p.step[0], wave, i, h, g);
+    if (first_wide) c2_load<LD>(bx, dcur, 0);
+    else if (p.step[0].Bt != nullptr) c2_load_narrow(bx, p.step[0], wave, i, h, g);
+    else c2_load_narrow_k(bx, p.step[0], wave, i, h, g);
 
     // ---- input tile -> sAct[m][k], zero-padded to the columns the first step multiplies -------------------------------
     {
@@ -287,11 +349,11 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
                     for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
             const int n_pairs = (K + 63) >> 6;         // K is treated as padded to a multiple of 64 with zero rows
-            if (FAST) c2_load_fast(by, dcur, CH_BK); else c2_load_wide(by, dcur, CH_BK);
+            c2_load<LD>(by, dcur, CH_BK);
             const float* pa = sAct + i * C2_LDK + 4 * h;
-            const C2WideDesc dnext = c2_wide_desc(nxt, wave, i, h, g);
-            if (do_copy) c2_wide_loop<TM, true, SCHED, FAST>(acc, bx, by, sAct, pa, dcur, dnext, nxt_wide, n_pairs, cdst);
-            else c2_wide_loop<TM, false, SCHED, FAST>(acc, bx, by, sAct, pa, dcur, dnext, nxt_wide, n_pairs, cdst);
+            const C2WideDesc dnext = c2_desc<LD>(nxt, wave, i, h, g);
+            if (do_copy) c2_wide_loop<TM, true, SCHED, LD>(acc, bx, by, sAct, pa, dcur, dnext, nxt_wide, n_pairs, cdst);
+            else c2_wide_loop<TM, false, SCHED, LD>(acc, bx, by, sAct, pa, dcur, dnext, nxt_wide, n_pairs, cdst);
             dcur = dnext;
             C2_TICK()
             __syncthreads();     // every wave is past its last read of sAct (MFMA operands and copy pieces)
@@ -358,7 +420,10 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
                 for (int r = 0; r < 16; ++r) hacc[a][r] = 0.f;
             const float* pa = sAct + i * C2_LDK + wave * 64 + 4 * h;
             // the saved input of this step goes to HBM first (its LDS image becomes the reduction scratch below)
-            if (s > 0) c2_load_narrow(bx, st, wave, i, h, g);   // (step 0's operands were fetched by the prologue)
+            if (s > 0) {   // (step 0's operands were fetched by the prologue)
+                if (st.Bt != nullptr) c2_load_narrow(bx, st, wave, i, h, g);
+                else c2_load_narrow_k(bx, st, wave, i, h, g);
+            }
             if (do_copy)
                 for (int piece = 0; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cdst, piece);
 #pragma unroll
@@ -383,8 +448,8 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
 #pragma unroll
                 for (int r = 0; r < 16; ++r) scr[((wave * MT + tm) * 16 + r) * 64 + lane] = hacc[tm][r];
             // the stream moves on while the partial tiles are reduced
-            const C2WideDesc dnext = c2_wide_desc(nxt, wave, i, h, g);
-            if (nxt_wide) { if (FAST) c2_load_fast(bx, dnext, 0); else c2_load_wide(bx, dnext, 0); }
+            const C2WideDesc dnext = c2_desc<LD>(nxt, wave, i, h, g);
+            if (nxt_wide) c2_load<LD>(bx, dnext, 0);
             dcur = dnext;
             __syncthreads();
             // thread (rg = wave, lane) sums the four partials of registers 4rg..4rg+3 of every row tile, wave order
@@ -471,7 +536,7 @@ __device__ __forceinline__ unsigned c2_cu_key() {
     return ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
 }
 
-template <int SCHED, bool PROF>
+template <int SCHED, bool PROF, bool NMAJOR = false>
 __device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, float* sAct) {
     const int S = (int)gridDim.x;
     // (workgroup x runs on XCD x % 8)
@@ -508,17 +573,23 @@ __device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, floa
         if (m.p[q].nb > 1) { const int upn = (m.p[q].rows + 63) >> 6; g = lu / upn; lu -= g * upn; }
         const int row0 = lu * 64 + (half > 0 ? 32 : 0);
         long long* pout = (PROF && m.prof != nullptr) ? m.prof + ((size_t)b * 2 + (j > 0 ? 1 : 0)) * 24 : nullptr;
-        if (m.p[q].fast) {
+        if (NMAJOR) {        // (every chain of the launch streams its wide steps N-major: ChainArgs::fast == 2)
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, true, PROF>(m.p[q], row0, sAct, pout, g);
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 2, PROF>(m.p[q], row0, sAct, pout, g);
             } else {
-                mlp_chain2_body<64, SCHED, true, PROF>(m.p[q], row0, sAct, pout, g);
+                mlp_chain2_body<64, SCHED, 2, PROF>(m.p[q], row0, sAct, pout, g);
+            }
+        } else if (m.p[q].fast) {
+            if (half >= 0) {
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 1, PROF>(m.p[q], row0, sAct, pout, g);
+            } else {
+                mlp_chain2_body<64, SCHED, 1, PROF>(m.p[q], row0, sAct, pout, g);
             }
         } else {
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, false, PROF>(m.p[q], row0, sAct, pout, g);
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 0, PROF>(m.p[q], row0, sAct, pout, g);
             } else {
-                mlp_chain2_body<64, SCHED, false, PROF>(m.p[q], row0, sAct, pout, g);
+                mlp_chain2_body<64, SCHED, 0, PROF>(m.p[q], row0, sAct, pout, g);
             }
         }
         __syncthreads();     // the tile buffer is free for the next job
@@ -530,6 +601,12 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain2_kernel(Chain2Multi m
     // (+8: the last group's look-ahead operand read of the last row runs 4 floats past the tile; the values are unused)
     __shared__ __attribute__((aligned(16))) float sAct[C2_TM * C2_LDK + 8];
     mlp_chain2_persistent<SCHED, false>(m, sAct);
+}
+
+// the same schedule with the N-major weight stream (forward passes that read the nn.Linear matrices as they are: morl_ac.hip)
+static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain2_n_kernel(Chain2Multi m) {
+    __shared__ __attribute__((aligned(16))) float sAct[C2_TM * C2_LDK + 8];
+    mlp_chain2_persistent<1, false, true>(m, sAct);
 }
 
 // ---- K-major shadow copies of the weights ----------------------------------------------------------------------------------

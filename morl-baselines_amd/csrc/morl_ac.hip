@@ -310,9 +310,20 @@ static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
     m.stagger = 1;
     static const bool xcd_env = [] { const char* e = getenv("MORL_AC_XCD_CONTIG"); return e ? atoi(e) != 0 : true; }();   // (tuning)
     for (int q = 0; q < n; ++q) m.xcd_contig |= (xcd_env && chains[q].nb > 1) ? 1 : 0;
-    hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
+    if (chains[0].fast == 2) hipLaunchKernelGGL(mlp_chain2_n_kernel, dim3(S), dim3(CH_THREADS), 0, s, m);
+    else hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
     LAUNCH_CHECK("ac_chain");
     return MORL_OK;
+}
+
+// Populations (every pass of the update in the 32 / 64-row regime of the chain): the forward chain streams the nn.Linear
+// matrices as they are (N-major weight stream, mlp_chain2.h) and the first-layer dX step of the backward chain reads them
+// K-major -- no K-major shadow copies, no transposes at the start of an update and behind every Adam step (98 of the 840 us of a
+// 64-learner MORL/D update).  Single learners keep the shadow copies: their 16-row chain has no N-major stream.
+static const bool g_ac_nmajor = [] { const char* e = getenv("MORL_AC_NMAJOR"); return e ? atoi(e) != 0 : true; }();   // (A/B runs)
+static bool chain_nmajor(const Mlp& m, int rows, int G) {
+    static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
+    return g_ac_nmajor && chain_shape_ok(m) && (!small_rows || (long long)rows * G > C16_MAX_ROWS);
 }
 
 // forward chain of the G networks of `t`: input rows t.x (shared by x_div networks), every hidden activation saved to t.h[]
@@ -324,12 +335,12 @@ static ChainArgs ac_forward_chain(const Mlp& m, const float* params, const float
     a.in_mode = 1;
     a.src = t.x; a.ldsrc = m.ld[0]; a.K0 = m.dims[0];
     a.nb = t.G; a.sSrc = (long long)t.cap * m.ld[0]; a.src_div = x_div;
-    a.fast = 0;
+    a.fast = wt ? 0 : 2;                       // no shadow copy: N-major weight stream (populations, see chain_nmajor)
     const long long units = (t.cap + 63) / 64;
     for (int l = 0; l < m.L; ++l) {
         ChainStep& st = a.step[l];
         const bool last = (l == m.L - 1);
-        st.Bmat = wt + m.offW[l];              // K-major shadow copy [in][out]
+        st.Bmat = wt ? wt + m.offW[l] : nullptr;   // K-major shadow copy [in][out]
         st.ldb = m.dims[l + 1];
         st.Bt = params + m.offW[l];            // nn.Linear layout [out][in] = N-major
         st.ldbt = m.dims[l];
@@ -367,7 +378,7 @@ static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape&
     t.bits_valid = false;
     if (t2) t2->bits_valid = false;
     const bool plain = !(ds.active && m.drop > 0.f) && !(t2 && ds2 && ds2->active && m.drop > 0.f);
-    if (wt != nullptr && plain && chain_shape_ok(m)) {
+    if ((wt != nullptr || chain_nmajor(m, rows, t.G)) && plain && chain_shape_ok(m)) {
         ChainArgs ch[2] = {ac_forward_chain(m, params, wt, pstride, t, rows, x_div), ChainArgs{}};
         if (t2) ch[1] = ac_forward_chain(m, params2, wt2, pstride, *t2, rows, x_div);
         int rc = ac_chain_launch(ch, t2 ? 2 : 1, s);
@@ -458,7 +469,8 @@ static int mlp_backward(const Mlp& m, const float* params, int64_t pstride, Tape
     // K-major shadow copy as its N-major operand; without one that last dX step stays a GEMM launch.
     int chain_down_to = -1;                      // layers [chain_down_to, L-1] had their dX computed by the chain
     if (t.bits_valid && chain_shape_ok(m) && !(dropped && m.drop > 0.f)) {
-        const int last_l = need_dx ? ((m.dims[0] > 32 || wt != nullptr) ? 0 : 1) : 1;
+        // (the 32 / 64-row chain reads a narrow step's operand K-major when there is no shadow copy)
+        const int last_l = need_dx ? ((m.dims[0] > 32 || wt != nullptr || chain_nmajor(m, rows, t.G)) ? 0 : 1) : 1;
         if (m.L - 1 >= last_l) {
             ChainArgs a{};
             a.rows = rows;
@@ -727,8 +739,11 @@ static int sacd_update(morl_ac_ctx* c, const morl_ac_state* st, const morl_ac_ba
     int widest = 0;
     for (int l = 1; l < Q.L; ++l) widest = std::max(widest, Q.dims[l]);
     static const bool shadow_env = [] { const char* e = getenv("MORL_AC_SHADOW"); return e ? atoi(e) != 0 : true; }();
-    const bool use_wt = shadow_env && (use_wave_tiles((long long)((rows + 127) / 128) * ((widest + 127) / 128) * c->QG * 2) ||
-                                       (chain_shape_ok(Q) && chain_shape_ok(P)));
+    // (a population whose every pass runs on the 32 / 64-row chain needs none: N-major weight stream, see chain_nmajor)
+    const bool nmajor = chain_nmajor(Q, rows, c->QG) && chain_nmajor(P, rows, PG);
+    const bool use_wt = shadow_env && !nmajor &&
+                        (use_wave_tiles((long long)((rows + 127) / 128) * ((widest + 127) / 128) * c->QG * 2) ||
+                         (chain_shape_ok(Q) && chain_shape_ok(P)));
     const float* wq = use_wt ? c->wt_q : nullptr;
     const float* wqt = use_wt ? c->wt_qt : nullptr;
     const float* wp = use_wt ? c->wt_pol : nullptr;
@@ -890,9 +905,12 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     // population stages 128 x 32 chunks either way and measured slower with the K-major weights (1.70 vs 1.27 ms at 64 learners)
     int widest = 0;
     for (int l = 1; l < Q.L; ++l) widest = std::max(widest, Q.dims[l]);
-    // ... and for every population whose networks the layer-fused chain kernels take (they read K-major weights)
-    const bool use_wt = shadow_env && (use_wave_tiles((long long)((rows + 127) / 128) * ((widest + 127) / 128) * QG * 2) ||
-                                       (chain_shape_ok(Q) && chain_shape_ok(P)));
+    // ... and for the small populations whose networks the 16-row chain takes (it reads K-major weights); a population whose
+    // every pass runs on the 32 / 64-row chain needs none (N-major weight stream, see chain_nmajor)
+    const bool nmajor = chain_nmajor(Q, rows, QG) && chain_nmajor(P, rows, c->PG);
+    const bool use_wt = shadow_env && !nmajor &&
+                        (use_wave_tiles((long long)((rows + 127) / 128) * ((widest + 127) / 128) * QG * 2) ||
+                         (chain_shape_ok(Q) && chain_shape_ok(P)));
 #define WT(p) (use_wt ? (p) : nullptr)
     if (use_wt) {
         TransposeMulti tm{};

@@ -224,6 +224,13 @@ static inline hipsim_v2u __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rs
 }
 
 
+static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    unsigned x = 0u;
+    const long long off = (long long)(unsigned)voffset + soffset;
+    if (off + 4 <= r.num_records) std::memcpy(&x, r.base + off, 4);
+    return x;
+}
+
 typedef unsigned int hipsim_v4u __attribute__((ext_vector_type(4)));
 static inline hipsim_v4u __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
     hipsim_v4u v = {0u, 0u, 0u, 0u};
