@@ -319,7 +319,9 @@ static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
 // Populations (every pass of the update in the 32 / 64-row regime of the chain): the forward chain streams the nn.Linear
 // matrices as they are (N-major weight stream, mlp_chain2.h) and the first-layer dX step of the backward chain reads them
 // K-major -- no K-major shadow copies, no transposes at the start of an update and behind every Adam step (98 of the 840 us of a
-// 64-learner MORL/D update).  Single learners keep the shadow copies: their 16-row chain has no N-major stream.
+// 64-learner MORL/D update), and the stream itself is faster than the generic K-major one (half the load instructions).  Single
+// learners keep the shadow copies: the same stream on the 16-row chain issues as many loads as the K-major one, uncoalesced, and
+// measured slower than the transposes it saves (CAPQL 0.168 vs 0.165 ms, MOSAC 0.290 vs 0.275 ms).
 static const bool g_ac_nmajor = [] { const char* e = getenv("MORL_AC_NMAJOR"); return e ? atoi(e) != 0 : true; }();   // (A/B runs)
 static bool chain_nmajor(const Mlp& m, int rows, int G) {
     static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();

@@ -22,8 +22,8 @@ def test_population_sized_shadow_refresh_passes_the_same_parity_tests():
     """Populations re-make the K-major shadow weights with the tiled transpose kernel behind the Adam step instead of scattering
     them from inside it (morl_ac.hip: adam); the switch is by size, so the emulator-sized cases never take that branch unless
     forced to (MORL_AC_SCATTER_MAX=0).  With the large-tile chain as well, this is the path a 64-learner MORL/D update takes."""
-    # third leg: the large-tile chain reading K-major shadow copies (MORL_AC_NMAJOR=0); by default it streams the nn.Linear
-    # matrices N-major and reads the first-layer dX operand K-major, with no shadow copies at all
+    # legs: the 16-row chain (K-major shadow copies), the large-tile chain with its default N-major weight stream (no shadow
+    # copies at all) and with the K-major shadow copies (MORL_AC_NMAJOR=0)
     for extra in ({}, {"MORL_CHAIN16": "0"}, {"MORL_CHAIN16": "0", "MORL_AC_NMAJOR": "0"}):
         env = dict(os.environ, MORL_AC_SCATTER_MAX="0", **extra)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_ac_kernels_parity.py"), "-x", "-q", "-m",

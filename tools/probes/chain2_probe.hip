@@ -73,7 +73,7 @@ static ChainArgs bwd_chain() {
     return a;
 }
 
-struct Cfg { int S, stagger, sched, lb1; };
+struct Cfg { int S, stagger, sched, lb1; int nmajor = 0; };
 
 static Chain2Multi make_multi(const std::vector<ChainArgs>& ch, const Cfg& c) {
     Chain2Multi m{};
@@ -92,7 +92,9 @@ static Chain2Multi make_multi(const std::vector<ChainArgs>& ch, const Cfg& c) {
 }
 
 static void launch(const Chain2Multi& m, const Cfg& c, int S) {
-    if (c.lb1) {
+    if (c.nmajor) {
+        hipLaunchKernelGGL(mlp_chain2_n_kernel, dim3(S), dim3(CH_THREADS), 0, 0, m);
+    } else if (c.lb1) {
         if (c.sched) hipLaunchKernelGGL(chain2_lb1_kernel<1>, dim3(S), dim3(CH_THREADS), 0, 0, m);
         else hipLaunchKernelGGL(chain2_lb1_kernel<0>, dim3(S), dim3(CH_THREADS), 0, 0, m);
     } else {
@@ -186,6 +188,13 @@ int main() {
     for (int sched = 0; sched < 2; ++sched)
         for (int stg = 0; stg < 4; ++stg) time_cfg("forward x3 (production shape)", fwd3, Cfg{512, stg, sched, 0}, 3 * F_FWD);
     for (int sched = 0; sched < 2; ++sched) {
+        if (sched) {
+            // the same passes reading the nn.Linear matrices themselves (N-major weight stream, no shadow copy)
+            auto nm = [](std::vector<ChainArgs> v) { for (auto& a : v) a.fast = 2; return v; };
+            for (int stg : {0, 3}) time_cfg("forward x3, N-major stream", nm(fwd3), Cfg{512, stg, 1, 0, 1}, 3 * F_FWD);
+            time_cfg("forward x1 no-save halves, N-major", nm(fwd1), Cfg{512, 0, 1, 0, 1}, F_FWD);
+            time_cfg("forward x1 save halves, N-major", nm(fwd1s), Cfg{512, 0, 1, 0, 1}, F_FWD);
+        }
         time_cfg("forward x2 no-save, 1 round, 2 WG/CU", fwd2, Cfg{512, 0, sched, 0}, 2 * F_FWD);
         time_cfg("forward x2 no-save, 2 rounds, 1 WG/CU", fwd2, Cfg{256, 0, sched, 0}, 2 * F_FWD);
         time_cfg("forward x2 no-save, 2 rounds, 1 WG/CU lb1", fwd2, Cfg{256, 0, sched, 1}, 2 * F_FWD);
