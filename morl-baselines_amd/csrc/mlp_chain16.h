@@ -55,6 +55,42 @@ __device__ __forceinline__ void c16_load_wide(C16BSet& s, const C16Desc& d, int 
     }
 }
 
+// ChainArgs::fast == 1 (the contexts whose wide steps all have 256 columns): the operand is in the K4 layout of mlp_chain2.h's
+// c2_load_fast -- element (k, n) at ((k >> 2) * 256 + n) * 4 + (k & 3).  The four k of a lane's group are 16 contiguous bytes
+// per column: four loads per group as before, one per COLUMN instead of one per k, the register set filled transposed.
+__device__ __forceinline__ C16Desc c16_desc_k4(const ChainStep& st, int wave, int j, int kq, int g) {
+    C16Desc d;
+    const int col = wave * 64 + 4 * j;
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bmat + g * st.sW), 0, (st.kpad > st.K ? st.kpad : st.K) * 256 * 4, 0x00020000);
+    d.lane_off = (kq * 256 + col) * 16;
+    d.stride = 256 * 16;              // bytes per k4-row
+    return d;
+}
+
+__device__ __forceinline__ void c16_load_k4(C16BSet& s, const C16Desc& d, int k0) {
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+        float4 q[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            q[ct] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d.rsrc, d.lane_off + ct * 16,
+                                                                                      ((k0 >> 2) + 4 * gq) * d.stride, 0));
+        s.v[4 * gq + 0] = make_float4(q[0].x, q[1].x, q[2].x, q[3].x);
+        s.v[4 * gq + 1] = make_float4(q[0].y, q[1].y, q[2].y, q[3].y);
+        s.v[4 * gq + 2] = make_float4(q[0].z, q[1].z, q[2].z, q[3].z);
+        s.v[4 * gq + 3] = make_float4(q[0].w, q[1].w, q[2].w, q[3].w);
+    }
+}
+
+template <bool K4>
+__device__ __forceinline__ C16Desc c16_desc_t(const ChainStep& st, int wave, int j, int kq, int g) {
+    return K4 ? c16_desc_k4(st, wave, j, kq, g) : c16_desc(st, wave, j, kq, g);
+}
+template <bool K4>
+__device__ __forceinline__ void c16_load_t(C16BSet& s, const C16Desc& d, int k0) {
+    if (K4) c16_load_k4(s, d, k0); else c16_load_wide(s, d, k0);
+}
+
 // narrow step: wave w contracts k in [64w, 64w + 64) = 4 groups of 16; lane (j = column within the tile, kq) loads
 // Bt[n][64w + 16c + 4kq .. +3] for the two column tiles n = j and n = 16 + j: v[2c + ct]
 __device__ __forceinline__ void c16_load_narrow(C16BSet& s, const ChainStep& st, int wave, int j, int kq, int g) {
@@ -73,7 +109,8 @@ __device__ __forceinline__ void c16_load_narrow(C16BSet& s, const ChainStep& st,
 
 __device__ __forceinline__ float c16_elem(const float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
 
-// one 16-row tile (rows [row0, row0 + 16) of network g) through the whole chain
+// one 16-row tile (rows [row0, row0 + 16) of network g) through the whole chain; K4: the weight layout of ChainArgs::fast == 1
+template <bool K4>
 __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, float* sAct, int g) {
     constexpr int N_PIECES = 4;                       // 16 rows x 64 quads / 256 threads
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_id();
@@ -82,8 +119,8 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
 
     C16BSet bx, by;
     const bool first_wide = p.step[0].N > 32;
-    C16Desc dcur = c16_desc(p.step[0], wave, j, kq, g);
-    if (first_wide) c16_load_wide(bx, dcur, 0);
+    C16Desc dcur = c16_desc_t<K4>(p.step[0], wave, j, kq, g);
+    if (first_wide) c16_load_t<K4>(bx, dcur, 0);
     else c16_load_narrow(bx, p.step[0], wave, j, kq, g);
 
     // ---- input tile -> sAct[m][k], zero-padded to the columns the first step multiplies --------------------------------
@@ -146,9 +183,9 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[ct][r] = 0.f;
             const int n_pairs = (K + 63) >> 6;          // K is treated as padded to a multiple of 64 with zero rows
-            c16_load_wide(by, dcur, CH_BK);
+            c16_load_t<K4>(by, dcur, CH_BK);
             const float* pa = sAct + j * C2_LDK + 4 * kq;
-            const C16Desc dnext = c16_desc(nxt, wave, j, kq, g);
+            const C16Desc dnext = c16_desc_t<K4>(nxt, wave, j, kq, g);
             float4 an, ac = *reinterpret_cast<const float4*>(pa);
             int piece = 0;
             for (int pr = 0; pr < n_pairs; ++pr) {
@@ -177,11 +214,11 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
     }
                 C16_GROUP(bx, 0, k0 + 16)
                 C16_GROUP(bx, 1, k0 + 32)
-                c16_load_wide(bx, dx, more ? k0 + 64 : 0);
+                c16_load_t<K4>(bx, dx, more ? k0 + 64 : 0);
                 C16_GROUP(by, 0, k0 + 48)
                 // (the last group's look-ahead read stays inside the buffer: column k0 + 64 + 15 <= 271 -> see the kernel's array)
                 C16_GROUP(by, 1, k0 + 64)
-                c16_load_wide(by, dcur, more ? k0 + 96 : CH_BK);
+                c16_load_t<K4>(by, dcur, more ? k0 + 96 : CH_BK);
 #undef C16_GROUP
                 if (do_copy && piece < N_PIECES) { c2_copy_piece(sAct, cdst, piece); ++piece; }
             }
@@ -246,8 +283,8 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) scr[((wave * 2 + ct) * 4 + r) * 64 + lane] = hacc[ct][r];
-            const C16Desc dnext = c16_desc(nxt, wave, j, kq, g);
-            if (nxt_wide) c16_load_wide(bx, dnext, 0);
+            const C16Desc dnext = c16_desc_t<K4>(nxt, wave, j, kq, g);
+            if (nxt_wide) c16_load_t<K4>(bx, dnext, 0);
             dcur = dnext;
             __syncthreads();
             // thread (wave, lane): column tile ct = wave >> 1, registers 2 * (wave & 1) + {0, 1} -- sums the four partials in wave order
@@ -304,7 +341,8 @@ static __global__ __launch_bounds__(CH_THREADS, 4) void mlp_chain16_kernel(Chain
     int lt = b - m.tile_start[q], g = 0;
     const int tpn = (m.p[q].rows + C16_TM - 1) / C16_TM;          // tiles per network
     if (m.p[q].nb > 1) { g = lt / tpn; lt -= g * tpn; }
-    mlp_chain16_body(m.p[q], lt * C16_TM, sAct, g);
+    if (m.p[q].fast == 1) mlp_chain16_body<true>(m.p[q], lt * C16_TM, sAct, g);
+    else mlp_chain16_body<false>(m.p[q], lt * C16_TM, sAct, g);
 }
 
 // Host side: which launches take the 16-row tiles, and the tile table.  The choice must be the same for a forward pass and

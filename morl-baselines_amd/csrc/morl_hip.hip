@@ -153,7 +153,10 @@ struct morl_ctx {
     float* wt_target = nullptr;
     int64_t wt_count = 0;
     int64_t offWt[MORL_MAX_LAYERS];          // Wt_l [round_up(in, 64)][ldn] (zero rows / columns beyond [in][out])
-    int64_t offWb[MORL_MAX_LAYERS];          // row-padded copy of W_l for the backward chain (out % 64 != 0), or -1
+    int64_t offWb[MORL_MAX_LAYERS];          // row-padded copy of W_l for the backward chain (out % 64 != 0; every layer in the
+                                             // K4 layout when k4), or -1
+    bool k4 = false;                         // every wide chain step has 256 columns: constant-stride weight stream over the K4
+                                             // layout (mlp_chain2.h: c2_load_fast); ChainArgs::fast of this context's chains
     int ldn[MORL_MAX_LAYERS];
     int dw_mode = 3;         // weight-gradient engine: 3 balanced wave-layout tiles (dw_tiles.h); older engines kept for A/B
                              // runs: 0 wave-level tiles (dw_wave.h), 1 double-buffered LDS tiles,
@@ -296,9 +299,16 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         if (net->dims[l] > CH_MAXW || net->dims[l + 1] > CH_MAXW) c->fused_ok = false;
         if (l >= 1 && (net->dims[l] & 3)) c->fused_ok = false;   // 8-byte operand / output pairs need even strides
     }
+    // K4 weight stream: every wide step of the forward chain (N = dims[l+1] > 32) and of the backward chain (N = dims[l] > 32,
+    // l >= 1) has exactly 256 columns, and the backward chain has no narrow step (it would read the forward copy N-major)
+    c->k4 = true;
+    for (int l = 0; l < c->L; ++l) {
+        if (net->dims[l + 1] > 32 && c->ldn[l] != 256) c->k4 = false;
+        if (l >= 1 && net->dims[l] != 256) c->k4 = false;
+    }
     for (int l = 0; l < c->L; ++l) {
         c->offWb[l] = -1;
-        if (l >= 1 && (net->dims[l + 1] & 63)) {
+        if (l >= 1 && ((net->dims[l + 1] & 63) || c->k4)) {
             c->offWb[l] = c->wt_count;
             c->wt_count += (int64_t)round_up(net->dims[l + 1], 64) * net->dims[l];
         }
@@ -415,6 +425,7 @@ static ShadowArgs shadow_args(morl_ctx* c) {
         j.dst_rows = round_up(c->net.dims[l], 64);
         j.dst_ld = c->ldn[l];
         j.mode = 0;
+        j.k4 = (c->k4 && c->net.dims[l + 1] > 32) ? 1 : 0;
         j.tiles_c = (j.dst_ld + SH_T - 1) / SH_T;
         j.tile_start = tiles;
         tiles += (j.dst_rows / SH_T) * j.tiles_c;
@@ -429,6 +440,7 @@ static ShadowArgs shadow_args(morl_ctx* c) {
         j.dst_rows = round_up(c->net.dims[l + 1], 64);
         j.dst_ld = c->net.dims[l];
         j.mode = 1;
+        j.k4 = c->k4 ? 1 : 0;
         j.tiles_c = (j.dst_ld + SH_T - 1) / SH_T;
         j.tile_start = tiles;
         tiles += (j.dst_rows / SH_T) * j.tiles_c;
@@ -518,7 +530,7 @@ static ChainArgs make_forward_chain(morl_ctx* c, const float* params, const floa
     a.n_steps = c->L;
     a.rows = rows;
     a.in_mode = 0;
-    a.fast = 1;
+    a.fast = c->k4 ? 1 : 0;
     emit_bits = true;   // the backward chain takes its ReLU masks as bits only
     a.obs = obs; a.weights = weights;
     a.B = B; a.W = W; a.D = c->net.obs_dim; a.R = c->net.reward_dim; a.row_order = row_order;
@@ -532,7 +544,6 @@ static ChainArgs make_forward_chain(morl_ctx* c, const float* params, const floa
         st.K = c->net.dims[l];
         st.kpad = round_up(st.K, 64);
         st.N = c->net.dims[l + 1];
-        if (st.N > 32 && st.ldb != 256) a.fast = 0;
         st.bias = params + c->offB[l];
         st.relu = last ? 0 : 1;
         if (last) { st.out = q_out; st.ldout = ldq_out; }
@@ -568,15 +579,14 @@ static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_
     a.n_steps = L - 1;
     a.rows = rows;
     a.in_mode = 1;
-    a.fast = 1;
+    a.fast = c->k4 ? 1 : 0;
     a.src = c->dq; a.ldsrc = c->ldq; a.K0 = c->net.dims[L];
     for (int l = L - 1, k = 0; l >= 1; --l, ++k) {
         ChainStep& st = a.step[k];
         st.Bmat = params + c->offW[l];
         st.ldb = c->net.dims[l];
         if (c->offWb[l] >= 0) { st.Bmat = c->wt_online + c->offWb[l]; st.kpad = round_up(c->net.dims[l + 1], 64); }
-        if (c->net.dims[l] > 32 && st.ldb != 256) a.fast = 0;
-        st.Bt = c->wt_online + c->offWt[l];   // [in][ldn(out)] = N-major for the backward contraction
+        st.Bt = c->wt_online + c->offWt[l];   // [in][ldn(out)] = N-major for the backward contraction (narrow steps; never K4)
         st.ldbt = c->ldn[l];
         st.K = c->net.dims[l + 1];
         st.N = c->net.dims[l];
