@@ -665,20 +665,37 @@ __device__ __forceinline__ void shadow_tiles_body(const float* __restrict__ para
 #pragma unroll
             for (int it = 0; it < SH_T / 8; ++it) tile[(slow + 8 * it) * (SH_T + 1) + fast] = v[it];
             __syncthreads();
+            if (j.k4) {
+                // K4 layout: thread (k-quad = slow, n = fast) writes the four k of its quad as one 16-byte piece; a half-wave
+                // covers 512 contiguous bytes (dst_rows is a multiple of 64, the destination 16-byte aligned)
+                const int n = c0 + fast, k = r0 + 4 * slow;
+                if (n < j.dst_ld) {
+                    const float* tq = tile + fast * (SH_T + 1) + 4 * slow;
+                    *reinterpret_cast<float4*>(dst + (((size_t)(k >> 2) * j.dst_ld + n) << 2)) = make_float4(tq[0], tq[1], tq[2], tq[3]);
+                }
+            } else {
 #pragma unroll
-            for (int it = 0; it < SH_T / 8; ++it) {
-                const int kk = slow + 8 * it, k = r0 + kk, n = c0 + fast;
-                if (k < j.dst_rows && n < j.dst_ld)
-                    dst[j.k4 ? (((size_t)(k >> 2) * j.dst_ld + n) << 2) + (k & 3) : (size_t)k * j.dst_ld + n] = tile[fast * (SH_T + 1) + kk];
+                for (int it = 0; it < SH_T / 8; ++it) {
+                    const int kk = slow + 8 * it, k = r0 + kk, n = c0 + fast;
+                    if (k < j.dst_rows && n < j.dst_ld) dst[(size_t)k * j.dst_ld + n] = tile[fast * (SH_T + 1) + kk];
+                }
             }
             __syncthreads();
+        } else if (j.k4) {
+            // rows r0 + 4 * slow .. + 3 of column c0 + fast: four coalesced row reads, one 16-byte piece of the K4 copy
+            const int r = r0 + 4 * slow, c = c0 + fast;
+            if (c < j.dst_ld) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = (r + u < j.rows_src && c < j.cols_src) ? src[(size_t)(r + u) * j.cols_src + c] : 0.f;
+                *reinterpret_cast<float4*>(dst + (((size_t)(r >> 2) * j.dst_ld + c) << 2)) = make_float4(v[0], v[1], v[2], v[3]);
+            }
         } else {
 #pragma unroll
             for (int it = 0; it < SH_T / 8; ++it) {
                 const int r = r0 + slow + 8 * it, c = c0 + fast;
                 if (r < j.dst_rows && c < j.dst_ld)
-                    dst[j.k4 ? (((size_t)(r >> 2) * j.dst_ld + c) << 2) + (r & 3) : (size_t)r * j.dst_ld + c] =
-                        (r < j.rows_src && c < j.cols_src) ? src[(size_t)r * j.cols_src + c] : 0.f;
+                    dst[(size_t)r * j.dst_ld + c] = (r < j.rows_src && c < j.cols_src) ? src[(size_t)r * j.cols_src + c] : 0.f;
             }
         }
     }
