@@ -22,6 +22,7 @@ for r in 2 3 4; do python bench_front.py --workload hv --r $r > $O/bench_front_h
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_env -- python $R/bench.py --steps 80 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
 for w in capql mosac gpi ens morld; do rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$w -- python $R/bench_ac.py --workload $w --steps 60 --no-cpu-baseline > /dev/null 2>&1; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_emu8 -- python $R/bench.py --force-shard --emulate-world 8 --steps 80 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_pareto -- python $R/bench_front.py --workload pareto --n 16384 --no-cpu-baseline > /dev/null 2>&1
 python $R/tools/pmc_summary.py $R/$O/pmc_summary.json > $R/$O/pmc_summary.txt 2>&1
 cd $R
