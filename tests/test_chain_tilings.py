@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -31,3 +33,15 @@ def test_population_sized_shadow_refresh_passes_the_same_parity_tests():
                             "no:cacheprovider"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
         assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_large_tile_chain_passes_the_shape_sweep_on_the_gpu():
+    """The seeded shape sweep (tests/test_shape_fuzz.py: ragged batches, odd widths, every update family) takes the 16-row tiles by
+    size; here it runs on the MI355X with MORL_CHAIN16=0, i.e. through the 64 / 32-row persistent kernel with all three weight
+    streams (generic K-major, K4 constant-stride, N-major)."""
+    env = dict(os.environ, MORL_CHAIN16="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_shape_fuzz.py"), "-x", "-q", "-m", "gpu", "-p",
+                        "no:cacheprovider"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

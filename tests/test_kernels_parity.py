@@ -76,7 +76,7 @@ def run_oracle(c, inp):
     return o, online, m, v
 
 
-def check_update(res, t, o, online, m, v, c):
+def check_update(res, t, o, online, m, v, c, param_tol_frac=0.02, grad_tol=5e-5):
     """The per-update parity contract (single update, identical parameters and batch)."""
     assert abs(res["loss"].item() - o["loss"].item()) <= RTOL * abs(o["loss"].item())
     assert relmax(res["q_values"], o["q_values"]) <= RTOL
@@ -94,12 +94,12 @@ def check_update(res, t, o, online, m, v, c):
     assert relmax(res["target"], o["target"]) <= 1e-4 if c.envelope else relmax(res["target"], o["target"]) <= RTOL
     gn = o["grad_norm"].item()
     assert abs(res["grad_norm"].item() - gn) <= RTOL * gn
-    assert relmax(t["g"], flat(o["grads"])) <= 5e-5
+    assert relmax(t["g"], flat(o["grads"])) <= grad_tol
     assert relmax(res["priority"], o["priority_raw"]) <= 1e-4
-    assert relmax(t["m"], flat(m)) <= 5e-5
-    assert relmax(t["v"], flat(v)) <= 5e-5
+    assert relmax(t["m"], flat(m)) <= grad_tol
+    assert relmax(t["v"], flat(v)) <= grad_tol
     # one Adam step moves a parameter by <= lr; the device must agree to a small fraction of that
-    assert float((t["po"].cpu() - flat(online)).abs().max()) <= 0.02 * c.lr
+    assert float((t["po"].cpu() - flat(online)).abs().max()) <= param_tol_frac * c.lr
 
 
 @pytest.mark.parametrize("fused", [1, 2, 3, 0], ids=["fused_auto", "fused64", "fused32", "perlayer"])
