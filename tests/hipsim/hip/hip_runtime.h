@@ -250,6 +250,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p 
 #define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_setprio(n) ((void)0)
 
 // ---- math that hipcc provides as builtins -------------------------------------------------------
 // Compile the emulated build with -ffp-contract=off so these stay separately rounded.
