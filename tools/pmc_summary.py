@@ -16,14 +16,15 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the profiled command: bench.py by default, or `pmc_summary.py out.json <script under the repo root> <its arguments...>`
+COMMAND = [os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]
 PASSES = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
           "sq": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"]}
 
 
 def run_pass(name, counters, outdir):
     d = os.path.join(outdir, name)
-    cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable,
-           os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]
+    cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, *COMMAND]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -48,8 +49,7 @@ def run_trace(outdir):
     """Average launch duration per kernel (ns) from a plain kernel-trace pass of the same command: joined with
     GRBM_GUI_ACTIVE it gives the clock the chip sustained INSIDE each kernel (DVFS: MI355X_MICROARCH.md, 'DVFS give-back')."""
     d = os.path.join(outdir, "trace")
-    cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", sys.executable,
-           os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]
+    cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", sys.executable, *COMMAND]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     out = {}
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
@@ -59,7 +59,10 @@ def run_trace(outdir):
 
 
 def main():
+    global COMMAND
     out_path = sys.argv[1]
+    if len(sys.argv) > 2:
+        COMMAND = [os.path.join(ROOT, sys.argv[2]), *sys.argv[3:]]
     work = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pmc_passes")
     res = {n: run_pass(n, c, work) for n, c in PASSES.items()}
     avg_ns = run_trace(work)
@@ -83,8 +86,7 @@ def main():
                       "avg_launch_ns_in_counter_pass": s.get("avg_ns_in_pass"),
                       "effective_clock_ghz_in_counter_pass": (sq["GRBM_GUI_ACTIVE"] / 8.0 / s["avg_ns_in_pass"]) if s.get("avg_ns_in_pass") else None,
                       "sq": sq}
-    json.dump({"note": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "command": "python bench.py --steps 10 --warmup 3 "
-               "--no-cpu-baseline", "kernels": kernels}, open(out_path, "w"), indent=1)
+    json.dump({"note": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "command": "python " + " ".join([os.path.relpath(COMMAND[0], ROOT)] + COMMAND[1:]), "kernels": kernels}, open(out_path, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k:45s} launches {v['launches']:4d}  HBM {v['hbm_bytes'] / 1e6:9.2f} MB  mfma_busy {v['mfma_busy_frac']:.3f}")
 
