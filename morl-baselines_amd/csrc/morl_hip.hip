@@ -1192,10 +1192,22 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         if ((rc = net_forward(c, params_online, c->x0n, rows, false, c->qo, AR, s))) return rc;
         if ((rc = net_forward(c, params_target, c->x0n, rows, false, c->qt, AR, s))) return rc;
     }
+    // The PER tree update (17 us of serial levels) rides as an extra workgroup of a longer launch: the weight gradients when they
+    // take longer than it does, the clip + Adam launch for small steps (<= 4 096 rows: the weight-gradient launch would wait for
+    // it -- 37 instead of 20 us at 256 x 8)
+    const bool per_with_adam = cfg->per_tree && out->priority && B <= ST_MAX_B && rows <= 4096 && c->dw_mode == 3;
+    morl_update_cfg core_cfg = *cfg;
+    if (per_with_adam) core_cfg.per_tree = nullptr;
     if ((rc = update_core(c, params_online, grads, obs, actions, rewards, dones, weights, W, c->qo, c->qt, W, 0,
-                          (long long)rows, B, cfg, out, main_done, nullptr, nullptr, s)))
+                          (long long)rows, B, &core_cfg, out, main_done, nullptr, nullptr, s)))
         return rc;
-    if ((rc = clip_adam_step(c, params_online, grads, exp_avg, exp_avg_sq, cfg, out->grad_norm, true, s))) return rc;
+    SumTreeUpdate per{};
+    if (per_with_adam) {
+        per.tree = cfg->per_tree; per.idx = cfg->per_idx; per.raw = out->priority; per.running_max = cfg->per_running_max;
+        per.n_levels = cfg->per_levels; per.B = B; per.alpha = cfg->per_alpha;
+    }
+    if ((rc = clip_adam_step(c, params_online, grads, exp_avg, exp_avg_sq, cfg, out->grad_norm, true, s, per_with_adam ? &per : nullptr)))
+        return rc;
     // optional debug / parity outputs
     if (out->q_online_next) HIP_TRY(hipMemcpyAsync(out->q_online_next, c->qo, (size_t)rows * AR * 4, hipMemcpyDeviceToDevice, s));
     if (out->q_target_next) HIP_TRY(hipMemcpyAsync(out->q_target_next, c->qt, (size_t)rows * AR * 4, hipMemcpyDeviceToDevice, s));
