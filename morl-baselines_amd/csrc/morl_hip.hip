@@ -1195,7 +1195,8 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     // The PER tree update (17 us of serial levels) rides as an extra workgroup of a longer launch: the weight gradients when they
     // take longer than it does, the clip + Adam launch for small steps (<= 4 096 rows: the weight-gradient launch would wait for
     // it -- 37 instead of 20 us at 256 x 8)
-    const bool per_with_adam = cfg->per_tree && out->priority && B <= ST_MAX_B && rows <= 4096 && c->dw_mode == 3;
+    static const int per_adam_rows = [] { const char* e = getenv("MORL_PER_ADAM_ROWS"); return e ? atoi(e) : 4096; }();   // (tuning)
+    const bool per_with_adam = cfg->per_tree && out->priority && B <= ST_MAX_B && rows <= per_adam_rows && c->dw_mode == 3;
     morl_update_cfg core_cfg = *cfg;
     if (per_with_adam) core_cfg.per_tree = nullptr;
     if ((rc = update_core(c, params_online, grads, obs, actions, rewards, dones, weights, W, c->qo, c->qt, W, 0,
