@@ -18,6 +18,8 @@
 // The ReLU sign bits of a tile are one 16-bit word per work-item (bit ct * 4 + r) in the same buffers mlp_chain2 uses (same
 // bytes per row); a forward / backward pair must use the same tile size -- the host decides from the row count alone.
 #pragma once
+#include <cstdlib>
+
 #include "mlp_chain2.h"
 
 namespace morl {
@@ -347,15 +349,19 @@ static __global__ __launch_bounds__(CH_THREADS, 4) void mlp_chain16_kernel(Chain
 
 // Host side: which launches take the 16-row tiles, and the tile table.  The choice must be the same for a forward pass and
 // the backward pass that consumes its sign bits, so it depends only on the rows (x networks) of a chain -- equal for both.
-constexpr int C16_MAX_ROWS = 4096;     // chains of up to this many rows: 16-row tiles (<= 256 tiles per chain)
+// chains of up to this many rows take the 16-row tiles.  The Envelope step (five-layer nets): 256 x 24 = 6 144 rows 0.215 ms on
+// 16-row tiles against 0.242 ms on 64 / 32-row ones, 8 192 rows 0.240 vs 0.245, 12 288 rows equal.  The actor-critic learners keep
+// 4 096 (AC_C16_MAX_ROWS in morl_ac.hip): beyond it their populations run the N-major weight stream of the large-tile chain.
+constexpr int C16_MAX_ROWS = 8192;
 
-inline bool chain16_wanted(const ChainArgs* chains, int n) {
+inline bool chain16_wanted(const ChainArgs* chains, int n, long long max_rows = C16_MAX_ROWS) {
     long long most = 0;
     for (int q = 0; q < n; ++q) {
         const long long r = (long long)chains[q].rows * (chains[q].nb > 1 ? chains[q].nb : 1);
         most = r > most ? r : most;
     }
-    return most <= C16_MAX_ROWS;
+    static const long long env_limit = [] { const char* e = getenv("MORL_CHAIN16_MAX_ROWS"); return e ? atoll(e) : -1ll; }();   // (tuning)
+    return most <= (env_limit >= 0 ? env_limit : max_rows);
 }
 
 inline int chain16_fill(Chain16Multi& m, const ChainArgs* chains, int n) {

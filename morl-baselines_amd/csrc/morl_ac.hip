@@ -277,6 +277,7 @@ static bool chain_shape_ok(const Mlp& m) {
     return true;
 }
 
+constexpr long long AC_C16_MAX_ROWS = 4096;     // row count up to which a chain of these three-layer nets takes the 16-row tiles
 static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
     static const int num_cus = [] {
         int dev = 0;
@@ -286,7 +287,7 @@ static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
         return 256;
     }();
     static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
-    if (small_rows && chain16_wanted(chains, n)) {
+    if (small_rows && chain16_wanted(chains, n, AC_C16_MAX_ROWS)) {
         Chain16Multi m16{};
         const int tiles = chain16_fill(m16, chains, n);
         hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
@@ -325,7 +326,7 @@ static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
 static const bool g_ac_nmajor = [] { const char* e = getenv("MORL_AC_NMAJOR"); return e ? atoi(e) != 0 : true; }();   // (A/B runs)
 static bool chain_nmajor(const Mlp& m, int rows, int G) {
     static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
-    return g_ac_nmajor && chain_shape_ok(m) && (!small_rows || (long long)rows * G > C16_MAX_ROWS);
+    return g_ac_nmajor && chain_shape_ok(m) && (!small_rows || (long long)rows * G > AC_C16_MAX_ROWS);
 }
 
 // forward chain of the G networks of `t`: input rows t.x (shared by x_div networks), every hidden activation saved to t.h[]
