@@ -214,7 +214,7 @@ def _clock_ramp(dev, seconds=0.5):
     del x
 
 
-def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup):
+def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch"):
     """Build the agent for a job of W sampled weights in total, run warm-up + `steps` timed Envelope.update() steps bracketed
     by barrier + synchronize on both sides; returns the measurements (wall = max over ranks)."""
     from morl_baselines_amd.envelope import Envelope
@@ -233,7 +233,9 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup):
     if sharded:
         from morl_baselines_amd.distributed import shard_envelope_agent
         emu = (a.emulate_world, 0) if (a.emulate_world > 1 and world == 1) else None
-        shard_envelope_agent(agent, dist, emulate=emu)   # weight axis over the ranks: all-gather Q(w), all-reduce grads
+        # batch axis: every rank runs the unsharded pipeline on B/N transitions, one all-reduce (the strong-scaled job);
+        # weight axis: W/N weights per rank, all-gather of Q(w) + all-reduce (the weak-scaled job, whose weight axis grows)
+        shard_envelope_agent(agent, dist, emulate=emu, axis=axis)
 
     def step():
         agent.update()
@@ -330,6 +332,10 @@ def main():
                     help="with --force-shard on one GPU: run the step of rank 0 of a job of this many ranks (its kernels, "
                          "launches, host work and message sizes; the other ranks' slabs are zeros) -- a measurement aid, "
                          "the line it prints is labelled as such")
+    ap.add_argument("--shard-axis", choices=["auto", "batch", "weights"], default="auto",
+                    help="how N > 1 ranks split one update: batch (B/N transitions per rank, one all-reduce), weights (W/N "
+                         "weights per rank: all-gather of Q(w) + all-reduce, the north_star's description); auto = batch for "
+                         "the strong-scaled job, weights for the weak-scaled one (its weight axis is what grows)")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the weight-sharded step (RCCL collectives) even with one rank (path check on a 1-GPU box)")
     a = ap.parse_args()
@@ -358,13 +364,19 @@ def main():
         raise SystemExit(f"--weights {a.weights} must be divisible by the number of ranks ({world})")
     B = a.batch
     W_head = a.weights * (world if (a.scaling == "weak" and world > 1) else 1)
-    head = run_job(a, dist, world, rank, dev, W_head, sharded, a.steps, a.warmup)
+    def axis_of(scaling_mode):
+        return a.shard_axis if a.shard_axis != "auto" else ("weights" if scaling_mode == "weak" else "batch")
+    head_axis = axis_of(a.scaling)
+    if sharded and head_axis == "batch" and B % max(world, a.emulate_world if a.force_shard else 1):
+        raise SystemExit(f"--batch {B} must be divisible by the number of ranks")
+    head = run_job(a, dist, world, rank, dev, W_head, sharded, a.steps, a.warmup, head_axis)
     sub = None
     if world > 1 and not a.no_sub_record:
         # the other scaling mode, same steps / warm-up, reported as a sub-record of the same line
         W_sub = a.weights if a.scaling == "weak" else a.weights * world
         try:
-            sub = run_job(a, dist, world, rank, dev, W_sub, sharded, a.steps, a.warmup)
+            sub = run_job(a, dist, world, rank, dev, W_sub, sharded, a.steps, a.warmup,
+                          axis_of("weak" if a.scaling == "strong" else "strong"))
         except Exception as exc:                      # the headline must survive a failing sub-record
             sub = {"error": f"{type(exc).__name__}: {exc}"}
 
@@ -396,9 +408,12 @@ def main():
                                    f"PER {'on' if a.per else 'off'}, buffer 20k seeded transitions (BASELINE.md s3)",
                        "global_batch": B, "weights": W_head, "objectives": R,
                        "weights_per_gpu": W_head // world,
-                       "parallelism": "single GPU" if world == 1 else f"weight axis sharded over {world} GPUs, "
-                                      f"{W_head // world} weights each ({scaling} scaling; RCCL all-gather of Q(w), "
-                                      "all-reduce of gradients)",
+                       "parallelism": "single GPU" if world == 1 else (
+                           f"batch axis sharded over {world} GPUs, {B // world} transitions x {W_head} weights each "
+                           f"({scaling} scaling; one RCCL all-reduce of gradient | loss | priorities)" if head_axis == "batch" else
+                           f"weight axis sharded over {world} GPUs, {W_head // world} weights each ({scaling} scaling; RCCL "
+                           "all-gather of Q(w), all-reduce of gradients)"),
+                       "shard_axis": head_axis if (world > 1 or a.force_shard) else None,
                        "engine": head["engine"],
                        "setup": "0.5 s device clock ramp (dummy GEMMs) before the warm-up steps"},
             "updates_per_s": h["updates_per_s"],
@@ -409,8 +424,10 @@ def main():
             "roofline": dict(h["roofline"], whole_step_algorithmic_tflops=h["whole_step_algorithmic_tflops"]),
         }
         if a.force_shard and a.emulate_world > 1 and world == 1:
-            out["emulated"] = (f"NOT a job throughput: the step of rank 0 of a {a.emulate_world}-rank job "
-                               f"({W_head // a.emulate_world} weights) run alone on one GPU; value / ms_per_step describe that rank")
+            share = (f"{B // a.emulate_world} transitions x {W_head} weights" if head_axis == "batch"
+                     else f"{B} transitions x {W_head // a.emulate_world} weights")
+            out["emulated"] = (f"NOT a job throughput: the step of rank 0 of a {a.emulate_world}-rank job ({share}) run alone on "
+                               "one GPU; value / ms_per_step describe that rank")
         if sub is not None:
             key = "weak_scaling" if scaling == "strong" else "strong_scaling"
             if "error" in sub:
@@ -419,7 +436,7 @@ def main():
                 other = "weak" if scaling == "strong" else "strong"
                 out[key] = dict(record(sub, sub["W"], other),
                                 note=f"sub-record, NOT the headline: {other} scaling, W = {sub['W']} sampled weights in total "
-                                     f"({sub['W'] // world} per GPU), same steps / warm-up, measured right after the headline")
+                                     f"({sub['W'] // world} per GPU; {axis_of(other)} axis sharded), same steps / warm-up, measured right after the headline")
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B, W_head, bool(a.per))
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -31,7 +31,7 @@ extern "C" {
 
 #define MORL_MAX_LAYERS 8   /* linear layers per network */
 #define MORL_MAX_OBJ 8      /* reward dimension R */
-#define MORL_ABI_VERSION 8
+#define MORL_ABI_VERSION 9
 
 typedef enum morl_status {
     MORL_OK = 0,
@@ -80,6 +80,9 @@ typedef struct morl_update_cfg {
     double* per_running_max;
     int32_t per_levels;
     float per_alpha;
+    /* batch-axis sharding (a rank updates on its B transitions of a larger batch): the TD rows of the whole job, by which
+     * the loss and its gradient are normalised.  0 => B * W (this call is the whole batch). */
+    int64_t rows_total;
 } morl_update_cfg;
 
 /* Optional device outputs of morl_envelope_update (any may be NULL). */
@@ -262,6 +265,20 @@ int morl_envelope_step_sharded(morl_ctx* ctx, morl_comm* comm, float* params_onl
                                const float* next_obs, const int32_t* actions, const float* rewards, const float* dones,
                                const float* weights_all, int B, int W_total, int i_offset, int W_local, float* slab_local,
                                float* slab_all, const morl_update_cfg* cfg, void* stream);
+
+/* The other way to shard the same step: over the BATCH axis.  Every rank draws the same B_total transitions and W weight
+ * vectors, rank r keeps transitions [b_offset, b_offset + B) and runs the WHOLE unsharded pipeline on them (all W weights: the
+ * envelope arg-max of a TD row only looks at slabs of its own transition, so nothing has to be gathered), normalised by the
+ * job's B_total * W rows; ONE collective -- the all-reduce of grads_x = [P gradient | 1 loss | B_total priorities] (a rank
+ * writes the priorities of its own transitions, zeros elsewhere) -- then clip + Adam and the PER update from the B_total summed
+ * priorities.  The arrays are the rank's slices ([B] rows); cfg->per_idx the B_total sampled leaves.  Compared with the
+ * weight-axis form above: no all-gather, the three forward passes stay one launch, the same rows per rank.  A communicator of
+ * one rank with B < B_total runs one rank of the larger job alone (measurement aid, as above). */
+int morl_envelope_step_batch_sharded(morl_ctx* ctx, morl_comm* comm, float* params_online, const float* params_target,
+                                     float* grads_x, int64_t n_params, float* exp_avg, float* exp_avg_sq, const float* obs,
+                                     const float* next_obs, const int32_t* actions, const float* rewards, const float* dones,
+                                     const float* weights, int B, int B_total, int b_offset, int W,
+                                     const morl_update_cfg* cfg, void* stream);
 
 /* ---- polyak_update: common/networks.py:120-139 ------------------------------------------------- */
 int morl_polyak(const float* src, float* dst, float tau, int64_t n, void* stream);

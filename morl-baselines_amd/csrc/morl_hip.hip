@@ -1199,15 +1199,20 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     const bool per_with_adam = cfg->per_tree && out->priority && B <= ST_MAX_B && rows <= per_adam_rows && c->dw_mode == 3;
     morl_update_cfg core_cfg = *cfg;
     if (per_with_adam) core_cfg.per_tree = nullptr;
+    if (cfg->rows_total != 0 && cfg->rows_total < rows) return fail(MORL_ERR_ARG, "rows_total %lld < B * W", (long long)cfg->rows_total);
+    const long long rows_total = cfg->rows_total > 0 ? (long long)cfg->rows_total : (long long)rows;
     if ((rc = update_core(c, params_online, grads, obs, actions, rewards, dones, weights, W, c->qo, c->qt, W, 0,
-                          (long long)rows, B, &core_cfg, out, main_done, nullptr, nullptr, s)))
+                          rows_total, B, &core_cfg, out, main_done, nullptr, nullptr, s)))
         return rc;
     SumTreeUpdate per{};
     if (per_with_adam) {
         per.tree = cfg->per_tree; per.idx = cfg->per_idx; per.raw = out->priority; per.running_max = cfg->per_running_max;
         per.n_levels = cfg->per_levels; per.B = B; per.alpha = cfg->per_alpha;
     }
-    if ((rc = clip_adam_step(c, params_online, grads, exp_avg, exp_avg_sq, cfg, out->grad_norm, true, s, per_with_adam ? &per : nullptr)))
+    // (gradients only, unclipped, nobody asks for the norm: nothing left to do -- the batch-sharded step's local part)
+    const bool nothing_left = !cfg->apply_step && cfg->max_grad_norm < 0.f && !out->grad_norm && !per_with_adam;
+    if (!nothing_left &&
+        (rc = clip_adam_step(c, params_online, grads, exp_avg, exp_avg_sq, cfg, out->grad_norm, true, s, per_with_adam ? &per : nullptr)))
         return rc;
     // optional debug / parity outputs
     if (out->q_online_next) HIP_TRY(hipMemcpyAsync(out->q_online_next, c->qo, (size_t)rows * AR * 4, hipMemcpyDeviceToDevice, s));
@@ -1351,6 +1356,56 @@ extern "C" int morl_envelope_step_sharded(morl_ctx* c, morl_comm* comm, float* p
     if ((rc = morl_clip_adam(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, stream))) return rc;
     if (cfg->per_tree)
         return morl_sumtree_update(cfg->per_tree, cfg->per_levels, cfg->per_idx, grads_x + n_params + 1, B, cfg->per_alpha,
+                                   cfg->per_running_max, nullptr, stream);
+    return MORL_OK;
+}
+
+// Batch-axis sharding of the step in one call (include/morl_hip.h): the unsharded pipeline on this rank's transitions, one
+// all-reduce, the optimiser step.
+extern "C" int morl_envelope_step_batch_sharded(morl_ctx* c, morl_comm* comm, float* params_online, const float* params_target,
+                                                float* grads_x, int64_t n_params, float* exp_avg, float* exp_avg_sq,
+                                                const float* obs, const float* next_obs, const int32_t* actions,
+                                                const float* rewards, const float* dones, const float* weights, int B,
+                                                int B_total, int b_offset, int W, const morl_update_cfg* cfg, void* stream) {
+    if (!c || !comm || !cfg || !grads_x) return fail(MORL_ERR_ARG, "NULL argument");
+    if (n_params != c->P) return fail(MORL_ERR_ARG, "n_params %lld, the network has %lld", (long long)n_params, (long long)c->P);
+    if (B < 1 || B_total < B || b_offset < 0 || b_offset + B > B_total || B_total % B || b_offset % B)
+        return fail(MORL_ERR_ARG, "bad shard [%d, %d) of a batch of %d", b_offset, b_offset + B, B_total);
+    if (cfg->per_tree && (!cfg->per_idx || !cfg->per_running_max || cfg->per_levels < 1 || cfg->per_levels > 40))
+        return fail(MORL_ERR_ARG, "per_tree needs per_idx, per_running_max and per_levels");
+    if (cfg->apply_step && (!exp_avg || !exp_avg_sq)) return fail(MORL_ERR_ARG, "Adam state is NULL");
+    int rank = 0, world = 1, rc;
+    if ((rc = morl_comm_size(comm, &rank, &world))) return rc;
+    const int parts = B_total / B;
+    if (world != parts && world != 1)
+        return fail(MORL_ERR_ARG, "%d ranks in the communicator, %d shards of the batch", world, parts);
+    if (world == parts && rank != b_offset / B) return fail(MORL_ERR_ARG, "rank %d does not own the transitions from %d on", rank, b_offset);
+    hipStream_t s = (hipStream_t)stream;
+    float* prio = grads_x + n_params + 1;
+    if (parts > 1) HIP_TRY(hipMemsetAsync(prio, 0, (size_t)B_total * sizeof(float), s));   // the other ranks' transitions: zeros
+    morl_update_cfg local = *cfg;
+    local.apply_step = 0;
+    local.per_tree = nullptr;                                  // priorities are complete only after the all-reduce
+    local.rows_total = (int64_t)B_total * W;
+    const float max_norm = local.max_grad_norm;
+    local.max_grad_norm = -1.f;                                // the clip belongs to the SUMMED gradient
+    morl_update_out out = {};
+    out.loss = grads_x + n_params;
+    out.priority = prio + b_offset;
+    if ((rc = morl_envelope_update(c, params_online, params_target, grads_x, exp_avg, exp_avg_sq, obs, next_obs, actions, rewards,
+                                   dones, weights, B, W, &local, &out, stream)))
+        return rc;
+    if ((rc = morl_allreduce_grads(comm, grads_x, n_params + 1 + B_total, stream))) return rc;
+    (void)max_norm;
+    if (cfg->per_tree && B_total <= ST_MAX_B) {
+        SumTreeUpdate u{};
+        u.tree = cfg->per_tree; u.idx = cfg->per_idx; u.raw = prio; u.running_max = cfg->per_running_max;
+        u.n_levels = cfg->per_levels; u.B = B_total; u.alpha = cfg->per_alpha;
+        return clip_adam_step(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, false, s, &u);
+    }
+    if ((rc = morl_clip_adam(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, stream))) return rc;
+    if (cfg->per_tree)
+        return morl_sumtree_update(cfg->per_tree, cfg->per_levels, cfg->per_idx, prio, B_total, cfg->per_alpha,
                                    cfg->per_running_max, nullptr, stream);
     return MORL_OK;
 }

@@ -16,6 +16,14 @@ SAME batch and the SAME W sampled weights (identical seeds => identical host RNG
      weight 0, so the sum is exact)                                                              (0.85 MB at [256]*4)
   5. every rank applies the identical clip + Adam step -> replicas stay bit-identical
 
+``shard_envelope_agent(..., axis="batch")`` shards the same step over the BATCH axis instead: rank g keeps the transitions
+``[g*B/G, (g+1)*B/G)`` of the common batch and all W weights.  The envelope arg-max of a TD row only looks at the slabs of its
+own transition, so nothing has to be gathered: the rank runs the unsharded pipeline (three forward passes in one launch) on its
+B/G transitions, normalised by the job's B*W rows, and the ONE collective left is the all-reduce of gradient | loss | priorities.
+Same rows per rank as the weight-axis form, one collective and two launches fewer -- this is what ``bench.py`` runs for the
+strong-scaled headline; the weight-axis form (the one BASELINE.json's north_star describes) stays for the weak-scaled job, whose
+weight axis is the one that grows.
+
 Messages are far below the size where a ring would be bandwidth-bound on the point-to-point xGMI links; they are
 latency-bound, so the exchange is kept to two collectives per step and both operate on single contiguous buffers.
 The data path has real exchange steps, hence this is *strong* scaling of one 256 x 64 update.
@@ -125,7 +133,7 @@ def shard_capql_agent(agent, dist, group=None):
     return agent
 
 
-def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=None) -> Envelope:
+def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=None, axis: str = "weights") -> Envelope:
     """Replace ``agent.update`` with the sharded step.  ``dist`` is ``torch.distributed`` (already initialised).
 
     ``emulate=(world, rank)`` is a measurement aid for boxes with one GPU (bench.py --emulate-world): the step of ONE rank of a
@@ -138,6 +146,10 @@ def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=N
         if real_world != 1:
             raise ValueError("emulate= needs a single real rank")
         world, rank = int(emulate[0]), int(emulate[1])
+    if axis == "batch":
+        return _shard_envelope_batch(agent, dist, group, emulate, comm, world, rank)
+    if axis != "weights":
+        raise ValueError("axis must be 'weights' or 'batch'")
     W = agent.num_sample_w
     if W % world:
         raise ValueError(f"num_sample_w={W} must be divisible by the number of ranks ({world})")
@@ -220,4 +232,70 @@ def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=N
 
     agent.update = types.MethodType(update, agent)
     agent.q_net.ensure_capacity(agent.batch_size, W)
+    return agent
+
+
+def _shard_envelope_batch(agent: Envelope, dist, group, emulate, comm, world: int, rank: int) -> Envelope:
+    """Batch-axis sharding (see the module docstring): ``agent.update`` becomes the step of rank ``rank`` of ``world``."""
+    B0 = agent.batch_size
+    if B0 % world:
+        raise ValueError(f"batch_size={B0} must be divisible by the number of ranks ({world})")
+    Bl = B0 // world
+    b0 = rank * Bl
+    dev = agent.device
+    P = agent.q_net.ctx.n_params
+    agent._shard = types.SimpleNamespace(world=world, rank=rank, Bl=Bl, b0=b0, axis="batch")
+    agent._grads_x = th.zeros(P + 1 + B0, dtype=th.float32, device=dev)
+    agent._grads = agent._grads_x[:P]
+    agent._bind_optimizer_state()
+    if comm is None and dist.get_backend(group) == "nccl" and agent.lib.is_device_build and os.environ.get("MORL_COMM", "native") != "torch":
+        comm = NativeComm(agent.lib, dist, dev, group)
+    agent._shard.comm = comm
+
+    def update(self: Envelope):
+        self._losses = []
+        if self.batch_size != B0:
+            raise ValueError("batch_size changed after shard_envelope_agent")
+        W = self.num_sample_w
+        for _ in range(self.gradient_updates):
+            aux, sampled_w = self._draw_weights()
+            b_obs, b_actions, b_rewards, b_next_obs, b_dones, b_inds = self.replay_buffer.sample(
+                B0, to_tensor=True, device=self.device, aux=aux,
+                prepare=(self.q_net.ctx, self.q_net.flat, self.target_q_net.flat))
+            self._w_ring.mark_used()
+            ctx = self.q_net.ctx
+            self._adam_step += 1
+            gx = self._grads_x
+            sl = slice(b0, b0 + Bl)                      # this rank's transitions (row slices of contiguous tensors: views)
+            actions = b_actions.reshape(-1).to(th.int32)[sl]
+            obs, nobs, rew, done = b_obs[sl], b_next_obs[sl], b_rewards[sl], b_dones.reshape(-1)[sl]
+            per = self.replay_buffer.per_update_args(b_inds, self.per_alpha) if self.per else None
+            if comm is not None:
+                ops.envelope_step_batch_sharded(
+                    ctx, comm.handle, self.q_net.flat, self.target_q_net.flat, gx, self._exp_avg, self._exp_avg_sq, obs, nobs,
+                    actions, rew, done, sampled_w, B0, b0, gamma=self.gamma, lr=self.learning_rate, adam_step=self._adam_step,
+                    max_grad_norm=self.max_grad_norm, homotopy_lambda=float(self.homotopy_lambda), envelope=self.envelope,
+                    per=per)
+            else:
+                # the same stages through torch.distributed (gloo in the CPU tests): local gradients of the job's loss ...
+                gx[P + 1:].zero_()
+                outs = {"loss": gx[P], "priority": gx[P + 1 + b0:P + 1 + b0 + Bl], "grad_norm": None}
+                ops.envelope_update(ctx, self.q_net.flat, self.target_q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq,
+                                    obs, nobs, actions, rew, done, sampled_w, gamma=self.gamma, lr=self.learning_rate,
+                                    adam_step=self._adam_step, max_grad_norm=None, homotopy_lambda=float(self.homotopy_lambda),
+                                    envelope=self.envelope, apply_step=False, outputs=outs, rows_total=B0 * W)
+                # ... one all-reduce, the identical optimiser step everywhere
+                dist.all_reduce(gx, op=dist.ReduceOp.SUM, group=group)
+                ops.clip_adam(ctx, self.q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq, lr=self.learning_rate,
+                              adam_step=self._adam_step, max_grad_norm=self.max_grad_norm)
+                if self.per:
+                    self.replay_buffer.update_priorities_from_td(b_inds, gx[P + 1:], self.per_alpha)
+            loss = gx[P] if self.gradient_updates == 1 else gx[P].clone()
+            pr = gx[P + 1:]
+            self._out = {"loss": loss, "priority": pr}
+            self._losses.append(loss)
+        self._finish_update(pr if self.per else None)
+
+    agent.update = types.MethodType(update, agent)
+    agent.q_net.ensure_capacity(Bl, agent.num_sample_w)
     return agent

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
 
 MORL_MAX_LAYERS = 8
 MORL_MAX_OBJ = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class NetDesc(C.Structure):
@@ -30,7 +30,7 @@ class UpdateCfg(C.Structure):
                 ("adam_step", C.c_int32), ("envelope", C.c_int32), ("apply_step", C.c_int32),
                 ("main_forward_done", C.c_int32), ("slab_parts", C.c_int32),
                 ("per_tree", C.c_void_p), ("per_idx", C.c_void_p), ("per_running_max", C.c_void_p),
-                ("per_levels", C.c_int32), ("per_alpha", C.c_float)]
+                ("per_levels", C.c_int32), ("per_alpha", C.c_float), ("rows_total", C.c_int64)]
 
 
 class UpdateOut(C.Structure):
@@ -150,6 +150,8 @@ _SIGNATURES = {
                                                                                  C.c_void_p]),
     "morl_envelope_step_sharded": (C.c_int, [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 8 + [C.c_int] * 4 +
                                    [C.c_void_p, C.c_void_p, C.POINTER(UpdateCfg), C.c_void_p]),
+    "morl_envelope_step_batch_sharded": (C.c_int, [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 8 + [C.c_int] * 4 +
+                                         [C.POINTER(UpdateCfg), C.c_void_p]),
     "morl_comm_unique_id": (C.c_int, [C.c_void_p]),
     "morl_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
     "morl_comm_destroy": (C.c_int, [C.c_void_p]),

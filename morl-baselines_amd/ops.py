@@ -269,7 +269,7 @@ def envelope_update(ctx: QNetContext, params_online: th.Tensor, params_target: t
                     weights: th.Tensor, *, gamma: float, lr: float, adam_step: int, max_grad_norm: Optional[float],
                     homotopy_lambda: float = 0.0, envelope: bool = True, beta1: float = 0.9, beta2: float = 0.999,
                     eps: float = 1e-8, apply_step: bool = True, outputs: Optional[Dict[str, th.Tensor]] = None,
-                    debug: bool = False, per=None) -> Dict[str, th.Tensor]:
+                    debug: bool = False, per=None, rows_total: int = 0) -> Dict[str, th.Tensor]:
     """One Envelope gradient step (envelope.py:269-334) entirely on the device.  ``per`` = (tree, n_levels, idx, alpha,
     running_max): the step also applies its PER priority update to the device sum tree (envelope.py:329-334), as an extra
     workgroup of the weight-gradient launch."""
@@ -300,6 +300,7 @@ def envelope_update(ctx: QNetContext, params_online: th.Tensor, params_target: t
                     max_grad_norm=-1.0 if max_grad_norm is None else float(max_grad_norm), lr=lr, beta1=beta1,
                     beta2=beta2, eps=eps, adam_step=int(adam_step), envelope=int(bool(envelope)),
                     apply_step=int(bool(apply_step)))
+    cfg.rows_total = int(rows_total)          # > 0: this call is one rank's share of a batch-sharded step (see distributed.py)
     if per is not None:
         tree, n_levels, idx, alpha, running_max = per
         _chk(tree, th.float64, "per tree"); _chk(idx, th.int64, "per idx"); _chk(running_max, th.float64, "per running_max")
@@ -420,6 +421,40 @@ def envelope_step_sharded(ctx: QNetContext, comm_handle: int, params_online: th.
         ctx.handle, comm_handle, _ptr(params_online), _ptr(params_target), _ptr(grads_x), P, _ptr(exp_avg), _ptr(exp_avg_sq),
         _ptr(obs), _ptr(next_obs), _ptr(actions), _ptr(rewards), _ptr(dones), _ptr(weights_all), B, W, int(i_offset),
         int(w_local), _ptr(slab_local), _ptr(slab_all), C.byref(cfg), lib.stream_of(obs)))
+
+
+def envelope_step_batch_sharded(ctx: QNetContext, comm_handle: int, params_online: th.Tensor, params_target: th.Tensor,
+                                grads_x: th.Tensor, exp_avg: th.Tensor, exp_avg_sq: th.Tensor, obs: th.Tensor,
+                                next_obs: th.Tensor, actions: th.Tensor, rewards: th.Tensor, dones: th.Tensor,
+                                weights: th.Tensor, b_total: int, b_offset: int, *, gamma: float, lr: float, adam_step: int,
+                                max_grad_norm: Optional[float], homotopy_lambda: float = 0.0, envelope: bool = True,
+                                beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, per=None) -> None:
+    """One rank's whole BATCH-sharded Envelope step in one C call (``morl_envelope_step_batch_sharded``): the unsharded pipeline
+    on its slice of the batch, the all-reduce of ``grads_x`` = [P gradient | loss | b_total priorities], clip + Adam and -- with
+    ``per`` = (tree, n_levels, idx of ALL b_total transitions, alpha, running_max) -- the PER update."""
+    lib = ctx.lib
+    for t, dt, n in ((params_online, th.float32, "params_online"), (params_target, th.float32, "params_target"),
+                     (grads_x, th.float32, "grads_x"), (exp_avg, th.float32, "exp_avg"), (exp_avg_sq, th.float32, "exp_avg_sq"),
+                     (obs, th.float32, "obs"), (next_obs, th.float32, "next_obs"), (actions, th.int32, "actions"),
+                     (rewards, th.float32, "rewards"), (dones, th.float32, "dones"), (weights, th.float32, "weights")):
+        _chk(t, dt, n)
+    lib.check_device(params_online, params_target, grads_x, exp_avg, exp_avg_sq, obs, next_obs, actions, rewards, dones, weights)
+    B, W, P = obs.shape[0], weights.shape[0], ctx.n_params
+    if grads_x.numel() != P + 1 + b_total:
+        raise ValueError("grads_x must hold P + 1 + b_total floats")
+    cfg = _update_cfg(gamma, lr, adam_step, max_grad_norm, homotopy_lambda, envelope, beta1, beta2, eps, True)
+    if per is not None:
+        tree, n_levels, idx, alpha, running_max = per
+        _chk(tree, th.float64, "per tree"); _chk(idx, th.int64, "per idx"); _chk(running_max, th.float64, "per running_max")
+        lib.check_device(tree, idx, running_max)
+        if idx.numel() != b_total:
+            raise ValueError("per: one sampled index per transition of the WHOLE batch")
+        cfg.per_tree, cfg.per_idx, cfg.per_running_max = _ptr(tree), _ptr(idx), _ptr(running_max)
+        cfg.per_levels, cfg.per_alpha = int(n_levels), float(alpha)
+    lib.check(lib.lib.morl_envelope_step_batch_sharded(
+        ctx.handle, comm_handle, _ptr(params_online), _ptr(params_target), _ptr(grads_x), P, _ptr(exp_avg), _ptr(exp_avg_sq),
+        _ptr(obs), _ptr(next_obs), _ptr(actions), _ptr(rewards), _ptr(dones), _ptr(weights), B, int(b_total), int(b_offset), W,
+        C.byref(cfg), lib.stream_of(obs)))
 
 
 def clip_adam(ctx: QNetContext, params: th.Tensor, grads: th.Tensor, exp_avg: th.Tensor, exp_avg_sq: th.Tensor, *,

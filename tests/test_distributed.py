@@ -30,7 +30,7 @@ def _make_agent(lib, per, schedules=False, dev=th.device("cpu"), arch=(32, 32), 
     return ag
 
 
-def _worker(rank, world, port, per, ret, schedules=False):
+def _worker(rank, world, port, per, ret, schedules=False, axis="weights"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -43,7 +43,7 @@ def _worker(rank, world, port, per, ret, schedules=False):
     native.use_library(lib)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ag = _make_agent(lib, per, schedules)
-    shard_envelope_agent(ag, dist)
+    shard_envelope_agent(ag, dist, axis=axis)
     for _ in range(N_STEPS[schedules]):
         ag.update()
         ag.global_step += 1
@@ -53,8 +53,9 @@ def _worker(rank, world, port, per, ret, schedules=False):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("axis", ["weights", "batch"])
 @pytest.mark.parametrize("per,schedules,world", [(False, False, 2), (True, False, 2), (True, True, 2), (True, False, 4)])
-def test_sharded_update_equals_single_process(per, schedules, world):
+def test_sharded_update_equals_single_process(per, schedules, world, axis):
     """``schedules``: several steps with ``homotopy_decay_steps`` / ``epsilon_decay_steps`` set -- the sharded step must run
     the same tail as ``Envelope.update`` (envelope.py:336-355), or the auxiliary loss never turns on under sharding."""
     import simlib
@@ -76,8 +77,8 @@ def test_sharded_update_equals_single_process(per, schedules, world):
         assert 0.0 < want_lam <= 1.0 and want_eps < 0.5            # the schedules actually moved
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 29500 + (os.getpid() % 2000) + 7 * int(schedules) + 13 * (world - 2)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, per, ret, schedules)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + 7 * int(schedules) + 13 * (world - 2) + 31 * int(axis == "batch") + 3 * int(per)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per, ret, schedules, axis)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -133,13 +134,13 @@ def test_one_call_sharded_step_equals_the_staged_one_on_the_gpu(per):
     from morl_baselines_amd.distributed import NativeComm, shard_envelope_agent
     lib = native.load_library()
     dev = th.device("cuda:0")
-    for emulate in (None, (2, 1), (4, 3)):
+    for emulate, axis in ((None, "weights"), ((2, 1), "weights"), ((4, 3), "weights"), (None, "batch"), ((2, 1), "batch"), ((8, 5), "batch")):
         runs = []
         for one_call in (False, True, None):
             ag = _make_agent(lib, per, schedules=True, dev=dev, arch=(256, 256, 256), B=64, W=16)
             if one_call is not None:
                 comm = NativeComm(lib, None, dev, loopback=True) if one_call else None
-                shard_envelope_agent(ag, _OneRank(), emulate=emulate, comm=comm)
+                shard_envelope_agent(ag, _OneRank(), emulate=emulate, comm=comm, axis=axis)
             for _ in range(4):
                 ag.update()
                 ag.global_step += 1
@@ -169,13 +170,13 @@ def test_one_call_sharded_step_equals_the_staged_one(per):
     lib = simlib.load_sim()
     native.use_library(lib)
     try:
-        for emulate in (None, (2, 1)):
+        for emulate, axis in ((None, "weights"), ((2, 1), "weights"), (None, "batch"), ((2, 1), "batch"), ((4, 2), "batch")):
             runs = []
             for one_call in (False, True, None):
                 ag = _make_agent(lib, per, schedules=True)
                 if one_call is not None:
                     comm = NativeComm(lib, None, "cpu", loopback=True) if one_call else None
-                    shard_envelope_agent(ag, _OneRank(), emulate=emulate, comm=comm)
+                    shard_envelope_agent(ag, _OneRank(), emulate=emulate, comm=comm, axis=axis)
                     assert (ag._shard.comm is not None) == one_call
                 for _ in range(3):
                     ag.update()
@@ -232,6 +233,22 @@ def test_one_call_sharded_step_rejects_bad_arguments():
             call(0, W, grads=th.zeros(P))                        # gradient | loss | priorities buffer too short
         with pytest.raises(ValueError):
             call(0, W // 2, slab_parts=1)                        # gathered buffer does not hold every rank's slabs
+        # the batch-axis entry: same conventions
+        gxb = th.zeros(P + 1 + B)
+
+        def call_b(b0, bl, handle=comm.handle, grads=gxb):
+            ops.envelope_step_batch_sharded(ctx, handle, ag.q_net.flat, ag.target_q_net.flat, grads, ag._exp_avg, ag._exp_avg_sq,
+                                            obs[:bl], nobs[:bl], act[:bl], rew[:bl], done[:bl], w, B, b0, gamma=0.99, lr=1e-3,
+                                            adam_step=1, max_grad_norm=1.0)
+
+        call_b(0, B)
+        call_b(B // 2, B // 2)                                  # one rank of two, run alone
+        with pytest.raises(RuntimeError, match="bad shard"):
+            call_b(1, B // 2)
+        with pytest.raises(RuntimeError, match="NULL"):
+            call_b(0, B, handle=None)
+        with pytest.raises(ValueError):
+            call_b(0, B, grads=th.zeros(P))
         assert lib.lib.morl_envelope_step_sharded(ctx.handle, comm.handle, None, None, None, P, None, None, None, None, None, None,
                                                   None, None, B, W, 0, W, None, None, None, None) != 0
         assert b"NULL" in lib.lib.morl_last_error()
@@ -321,7 +338,7 @@ def test_data_parallel_capql_equals_big_batch_oracle():
 
 # ---- the same sharded step over RCCL on a real GPU (one rank talking to itself: the collectives, streams and the in-place
 #      gathered-slab layout are the production ones; N > 1 needs more GPUs than the test box has) --------------------------
-def _rccl_worker(port, per, ret, rank=0, world=1):
+def _rccl_worker(port, per, ret, rank=0, world=1, axis="weights"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -353,7 +370,7 @@ def _rccl_worker(port, per, ret, rank=0, world=1):
     print(f"[rccl test] rank {rank}: nranks={dist.get_world_size()} backend={dist.get_backend()} device={dev}",
           file=sys.stderr, flush=True)
     ag = make()
-    shard_envelope_agent(ag, dist)
+    shard_envelope_agent(ag, dist, axis=axis)
     for _ in range(3):
         ag.update()
         ag.global_step += 1
@@ -370,11 +387,12 @@ def _rccl_worker(port, per, ret, rank=0, world=1):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("axis", ["weights", "batch"])
 @pytest.mark.parametrize("per", [False, True])
-def test_sharded_update_over_rccl_single_rank(per):
+def test_sharded_update_over_rccl_single_rank(per, axis):
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    p = ctx.Process(target=_rccl_worker, args=(32500 + (os.getpid() % 2000) + int(per), per, ret))
+    p = ctx.Process(target=_rccl_worker, args=(32500 + (os.getpid() % 2000) + int(per) + 2 * int(axis == "batch"), per, ret, 0, 1, axis))
     p.start()
     p.join(300)
     if p.is_alive():
@@ -389,15 +407,16 @@ def test_sharded_update_over_rccl_single_rank(per):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(th.cuda.device_count() < 2, reason="needs >= 2 GPUs (the multi-rank RCCL path)")
+@pytest.mark.parametrize("axis", ["weights", "batch"])
 @pytest.mark.parametrize("per", [False, True])
-def test_sharded_update_over_rccl_multi_rank(per):
+def test_sharded_update_over_rccl_multi_rank(per, axis):
     """The gloo world-size-2 assertions on real RCCL: min(4, device_count) ranks (a power of two dividing the 8 sampled
     weights), one per GPU; replicas bit-identical to each other and equal to the single-GPU step up to fp32 summation order."""
     world = 4 if th.cuda.device_count() >= 4 else 2
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 36500 + (os.getpid() % 2000) + int(per)
-    procs = [ctx.Process(target=_rccl_worker, args=(port, per, ret, r, world)) for r in range(world)]
+    port = 36500 + (os.getpid() % 2000) + int(per) + 2 * int(axis == "batch")
+    procs = [ctx.Process(target=_rccl_worker, args=(port, per, ret, r, world, axis)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
