@@ -11,6 +11,8 @@ python bench.py --per 0 --no-cpu-baseline > $O/bench_per_off.json 2>/dev/null ||
 python bench.py --gpus 1 --force-shard --no-cpu-baseline > $O/bench_force_shard_1rank.json 2>/dev/null || true
 python bench.py --weights 8 --no-cpu-baseline > $O/bench_shard_sized_w8.json 2>/dev/null || true
 for n in 2 4 8; do python bench.py --gpus 1 --force-shard --emulate-world $n --no-cpu-baseline > $O/bench_emulated_rank_of_$n.json 2>/dev/null || true; done
+for n in 2 4 8; do python bench.py --gpus 1 --force-shard --emulate-world $n --shard-axis weights --no-cpu-baseline > $O/bench_emulated_rank_of_${n}_weight_axis.json 2>/dev/null || true; done
+python bench.py --gpus 1 --force-shard --shard-axis weights --no-cpu-baseline > $O/bench_force_shard_1rank_weight_axis.json 2>/dev/null || true
 python tools/host_profile.py --weights 64 --emulate-world 8 > $O/host_profile_emulated_rank_of_8.txt 2>&1 || true
 for w in capql mosac gpipd gpi ens; do python bench_ac.py --workload $w > $O/bench_ac_$w.json 2>/dev/null; done
 python bench_ac.py --workload morld --pop 64 > $O/bench_ac_morld64.json 2>/dev/null
