@@ -31,7 +31,7 @@ extern "C" {
 
 #define MORL_MAX_LAYERS 8   /* linear layers per network */
 #define MORL_MAX_OBJ 8      /* reward dimension R */
-#define MORL_ABI_VERSION 9
+#define MORL_ABI_VERSION 10
 
 typedef enum morl_status {
     MORL_OK = 0,
@@ -154,6 +154,11 @@ int morl_envelope_prepare(morl_ctx* ctx, const float* params_online, const float
                           int64_t capacity, int B, int D, int R, int action_dim, float* obs, float* next_obs, float* rewards,
                           float* dones, float* actions_f, int32_t* actions_i, int64_t* idx_out, const float* aux_src,
                           float* aux_dst, int aux_floats, void* stream);
+/* The shadow copies made by morl_envelope_prepare are consumed ONLY by the gradient step that directly follows it
+ * (morl_envelope_update / morl_envelope_slabs / the one-call sharded steps); every other entry point re-makes its copies.  A
+ * caller that writes the parameter buffers in place between prepare and that step (morl_polyak, load_state_dict, copy_) calls
+ * this to drop the prepared copies explicitly. */
+int morl_ctx_invalidate_shadows(morl_ctx* ctx);
 /* device-side address of a pinned (page-locked, mapped) host allocation; MORL_ERR_HIP if the memory is not mapped */
 int morl_host_device_pointer(void* host_ptr, void** device_ptr);
 /* Same gather for records with arbitrary extra fields (CAPQL ReplayMemory.sample, multi_policy/capql/capql.py:56-63,
@@ -240,11 +245,20 @@ int morl_clip_adam(morl_ctx* ctx, float* params, float* grads, float* exp_avg, f
  *                         the communicator's own stream behind everything already enqueued on `stream`; what the caller
  *                         enqueues on `stream` afterwards (morl_envelope_main_forward) runs beside the exchange
  *   morl_comm_wait        `stream` waits for that all-gather (before morl_envelope_update_shard)
- *   morl_allreduce_grads  in-place sum over the ranks of the flat [gradient | loss | priorities] buffer, on `stream` */
+ *   morl_allreduce_grads  in-place sum over the ranks of the flat [gradient | loss | priorities] buffer, on `stream`
+ *   morl_comm_init_custom a communicator over the CALLER's transport instead of RCCL: two call-backs that enqueue the all-gather
+ *                         (recv [world][count_per_rank] complete) and the in-place sum in stream order on the stream they are
+ *                         handed and return 0.  RCCL is one transport, the one-rank loopback another; torch.distributed is
+ *                         bound this way for the gloo CPU tests (world 2 / 4 through the same one-call rank step) and for
+ *                         MORL_COMM=torch on the GPU.  `user` is passed back untouched. */
 #define MORL_COMM_ID_BYTES 128
 typedef struct morl_comm morl_comm;
+typedef int (*morl_allgather_fn)(void* user, const float* send, float* recv, int64_t count_per_rank, void* stream);
+typedef int (*morl_allreduce_fn)(void* user, float* buf, int64_t count, void* stream);
 int morl_comm_unique_id(void* id_out);
 int morl_comm_init(morl_comm** out, const void* unique_id, int rank, int world);
+int morl_comm_init_custom(morl_comm** out, int rank, int world, morl_allgather_fn allgather, morl_allreduce_fn allreduce,
+                          void* user);
 int morl_comm_destroy(morl_comm* comm);
 int morl_comm_size(const morl_comm* comm, int* rank, int* world);
 int morl_allgather_q_begin(morl_comm* comm, const float* send, float* recv, int64_t count_per_rank, void* stream);

@@ -278,6 +278,14 @@ static bool chain_shape_ok(const Mlp& m) {
 }
 
 constexpr long long AC_C16_MAX_ROWS = 4096;     // row count up to which a chain of these three-layer nets takes the 16-row tiles
+// ONE decision for "does a chain of this many rows (x networks) run on the 16-row tiles": ac_chain_launch (which kernel) and
+// chain_nmajor (does the pass have K-major shadow weights at all) both ask here, so the MORL_CHAIN16_MAX_ROWS tuning variable
+// cannot make them disagree (an N-major chain has no shadow copy for the 16-row kernel to stream)
+static bool ac_rows_take_chain16(long long rows_x_nets) {
+    static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
+    static const long long limit = [] { const char* e = getenv("MORL_CHAIN16_MAX_ROWS"); return e ? atoll(e) : AC_C16_MAX_ROWS; }();   // (tuning)
+    return small_rows && rows_x_nets <= limit;
+}
 static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
     static const int num_cus = [] {
         int dev = 0;
@@ -286,8 +294,17 @@ static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
             return prop.multiProcessorCount;
         return 256;
     }();
-    static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
-    if (small_rows && chain16_wanted(chains, n, AC_C16_MAX_ROWS)) {
+    long long most = 0;
+    for (int q = 0; q < n; ++q) {
+        most = std::max(most, (long long)chains[q].rows * std::max(1, chains[q].nb));
+        if ((chains[q].fast == 2) != (chains[0].fast == 2))
+            return fail(MORL_ERR_STATE, "ac_chain_launch: chains of one launch disagree on the weight stream (fast %d vs %d)",
+                        chains[0].fast, chains[q].fast);
+    }
+    if (chains[0].fast != 2 && ac_rows_take_chain16(most)) {
+        for (int q = 0; q < n; ++q)
+            for (int l = 0; l < chains[q].n_steps; ++l)
+                if (chains[q].step[l].N > 32 && !chains[q].step[l].Bmat) return fail(MORL_ERR_STATE, "ac_chain_launch: 16-row chain without a K-major operand");
         Chain16Multi m16{};
         const int tiles = chain16_fill(m16, chains, n);
         hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
@@ -325,8 +342,7 @@ static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
 // measured slower than the transposes it saves (CAPQL 0.168 vs 0.165 ms, MOSAC 0.290 vs 0.275 ms).
 static const bool g_ac_nmajor = [] { const char* e = getenv("MORL_AC_NMAJOR"); return e ? atoi(e) != 0 : true; }();   // (A/B runs)
 static bool chain_nmajor(const Mlp& m, int rows, int G) {
-    static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
-    return g_ac_nmajor && chain_shape_ok(m) && (!small_rows || (long long)rows * G > AC_C16_MAX_ROWS);
+    return g_ac_nmajor && chain_shape_ok(m) && !ac_rows_take_chain16((long long)rows * G);
 }
 
 // forward chain of the G networks of `t`: input rows t.x (shared by x_div networks), every hidden activation saved to t.h[]

@@ -450,10 +450,15 @@ static ShadowArgs shadow_args(morl_ctx* c) {
     return t;
 }
 
+// `step_entry`: the caller is the gradient step that directly follows morl_envelope_prepare in Envelope.update (the unsharded
+// step, the slabs call of a sharded one) -- the ONLY consumers of the shadow copies that launch made.  The copies are keyed on
+// the parameter pointer, which does not change when the parameters do (morl_polyak, load_state_dict, copy_ write in place), so
+// every other entry point (morl_qnet_forward, greedy actions, a skipped step's successor) refreshes unconditionally and drops
+// the flags; morl_ctx_invalidate_shadows drops them explicitly.
 static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipStream_t s, const float* params2 = nullptr,
-                              float* wt2 = nullptr) {
+                              float* wt2 = nullptr, bool step_entry = false) {
     // already made by this step's morl_envelope_prepare for exactly these buffers?  (one-shot)
-    const bool have = (wt == c->wt_online && c->fresh_online == params) &&
+    const bool have = step_entry && (wt == c->wt_online && c->fresh_online == params) &&
                       (params2 == nullptr || (wt2 == c->wt_target && c->fresh_target == params2));
     c->fresh_online = c->fresh_target = nullptr;
     if (have) return MORL_OK;
@@ -744,6 +749,13 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
     LAUNCH_CHECK("step_prologue");
     c->fresh_online = params_online;
     c->fresh_target = params_target;
+    return MORL_OK;
+}
+
+extern "C" int morl_ctx_invalidate_shadows(morl_ctx* c) {
+    if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
+    c->fresh_online = c->fresh_target = nullptr;
+    c->wt_online_src = nullptr;
     return MORL_OK;
 }
 
@@ -1157,6 +1169,10 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     if (cfg->apply_step && cfg->adam_step < 1) return fail(MORL_ERR_ARG, "adam_step must be >= 1");
     if (cfg->per_tree && (!cfg->per_idx || !cfg->per_running_max || cfg->per_levels < 1 || cfg->per_levels > 40 || !out || !out->priority))
         return fail(MORL_ERR_ARG, "per_tree needs per_idx, per_running_max, per_levels and out->priority");
+    // (checked HERE, before the first launch: a failure after the forward / backward launches would leave the caller with an
+    // exception and a half-taken step)
+    if (cfg->per_tree && B > ST_MAX_B)
+        return fail(MORL_ERR_ARG, "PER update inside the step: B=%d > %d (update the tree in chunks with morl_sumtree_update)", B, ST_MAX_B);
     hipStream_t s = (hipStream_t)stream;
     const morl_net_desc& n = c->net;
     const int D = n.obs_dim, R = n.reward_dim, A = n.n_actions;
@@ -1169,7 +1185,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     bool main_done = false;
     if (c->use_fused) {
         // layer-fused passes: activations stay in LDS; rows assembled from (obs, weights) inside the kernel
-        if ((rc = refresh_transposed(c, params_online, c->wt_online, s, params_target, c->wt_target))) return rc;
+        if ((rc = refresh_transposed(c, params_online, c->wt_online, s, params_target, c->wt_target, true))) return rc;
         if (c->fused_tm == 0) {
             // one launch for the three forward passes: 3 x rows/64 workgroups -> 2 resident per CU
             ChainArgs main_chain = make_forward_chain(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm,
@@ -1264,7 +1280,7 @@ extern "C" int morl_envelope_slabs(morl_ctx* c, const float* params_online, cons
     float* qt = slabs_out + (size_t)rows * AR;
     if (c->use_fused) {
         // one transpose launch for both networks, one launch for both passes (2 x rows/64 workgroups share the chip)
-        if ((rc = refresh_transposed(c, params_online, c->wt_online, s, params_target, c->wt_target))) return rc;
+        if ((rc = refresh_transposed(c, params_online, c->wt_online, s, params_target, c->wt_target, true))) return rc;
         c->wt_online_src = params_online;
         const ChainArgs two[2] = {
             make_forward_chain(c, params_online, c->wt_online, next_obs, weights_local, B, W_local, 0, rows, false, qo, AR),
@@ -1319,6 +1335,11 @@ extern "C" int morl_envelope_step_sharded(morl_ctx* c, morl_comm* comm, float* p
         return fail(MORL_ERR_ARG, "bad shard [%d, %d) of %d weights", i_offset, i_offset + W_local, W_total);
     if (cfg->per_tree && (!cfg->per_idx || !cfg->per_running_max || cfg->per_levels < 1 || cfg->per_levels > 40))
         return fail(MORL_ERR_ARG, "per_tree needs per_idx, per_running_max and per_levels");
+    // everything that can be refused is refused before the first launch / collective: a status after the all-reduce would leave
+    // the ranks with the optimiser state advanced and the priorities not (or the other way round)
+    if (cfg->apply_step && (!exp_avg || !exp_avg_sq)) return fail(MORL_ERR_ARG, "Adam state is NULL");
+    if (cfg->apply_step && cfg->adam_step < 1) return fail(MORL_ERR_ARG, "adam_step must be >= 1");
+    if (cfg->per_tree && B > ST_MAX_B) return fail(MORL_ERR_ARG, "PER update inside the step: B=%d > %d", B, ST_MAX_B);
     int rank = 0, world = 1, rc;
     if ((rc = morl_comm_size(comm, &rank, &world))) return rc;
     const int parts = W_total / W_local;
@@ -1346,18 +1367,13 @@ extern "C" int morl_envelope_step_sharded(morl_ctx* c, morl_comm* comm, float* p
                                          i_offset, W_local, slab_all, slab_all + half, &shard, &out, stream)))
         return rc;
     if ((rc = morl_allreduce_grads(comm, grads_x, n_params + 1 + B, stream))) return rc;
-    if (cfg->apply_step && (!exp_avg || !exp_avg_sq)) return fail(MORL_ERR_ARG, "Adam state is NULL");
-    if (cfg->per_tree && B <= ST_MAX_B) {
+    if (cfg->per_tree) {
         SumTreeUpdate u{};
         u.tree = cfg->per_tree; u.idx = cfg->per_idx; u.raw = grads_x + n_params + 1; u.running_max = cfg->per_running_max;
         u.n_levels = cfg->per_levels; u.B = B; u.alpha = cfg->per_alpha;
         return clip_adam_step(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, false, (hipStream_t)stream, &u);
     }
-    if ((rc = morl_clip_adam(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, stream))) return rc;
-    if (cfg->per_tree)
-        return morl_sumtree_update(cfg->per_tree, cfg->per_levels, cfg->per_idx, grads_x + n_params + 1, B, cfg->per_alpha,
-                                   cfg->per_running_max, nullptr, stream);
-    return MORL_OK;
+    return morl_clip_adam(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, stream);
 }
 
 // Batch-axis sharding of the step in one call (include/morl_hip.h): the unsharded pipeline on this rank's transitions, one
@@ -1374,6 +1390,8 @@ extern "C" int morl_envelope_step_batch_sharded(morl_ctx* c, morl_comm* comm, fl
     if (cfg->per_tree && (!cfg->per_idx || !cfg->per_running_max || cfg->per_levels < 1 || cfg->per_levels > 40))
         return fail(MORL_ERR_ARG, "per_tree needs per_idx, per_running_max and per_levels");
     if (cfg->apply_step && (!exp_avg || !exp_avg_sq)) return fail(MORL_ERR_ARG, "Adam state is NULL");
+    if (cfg->apply_step && cfg->adam_step < 1) return fail(MORL_ERR_ARG, "adam_step must be >= 1");
+    if (cfg->per_tree && B_total > ST_MAX_B) return fail(MORL_ERR_ARG, "PER update inside the step: B_total=%d > %d", B_total, ST_MAX_B);
     int rank = 0, world = 1, rc;
     if ((rc = morl_comm_size(comm, &rank, &world))) return rc;
     const int parts = B_total / B;
@@ -1397,17 +1415,13 @@ extern "C" int morl_envelope_step_batch_sharded(morl_ctx* c, morl_comm* comm, fl
         return rc;
     if ((rc = morl_allreduce_grads(comm, grads_x, n_params + 1 + B_total, stream))) return rc;
     (void)max_norm;
-    if (cfg->per_tree && B_total <= ST_MAX_B) {
+    if (cfg->per_tree) {
         SumTreeUpdate u{};
         u.tree = cfg->per_tree; u.idx = cfg->per_idx; u.raw = prio; u.running_max = cfg->per_running_max;
         u.n_levels = cfg->per_levels; u.B = B_total; u.alpha = cfg->per_alpha;
         return clip_adam_step(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, false, s, &u);
     }
-    if ((rc = morl_clip_adam(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, stream))) return rc;
-    if (cfg->per_tree)
-        return morl_sumtree_update(cfg->per_tree, cfg->per_levels, cfg->per_idx, prio, B_total, cfg->per_alpha,
-                                   cfg->per_running_max, nullptr, stream);
-    return MORL_OK;
+    return morl_clip_adam(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, stream);
 }
 
 // clip_grad_norm_ + Adam on flat buffers (envelope.py:324-326) -- stage C on its own, for gradients that were

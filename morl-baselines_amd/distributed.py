@@ -40,6 +40,7 @@ import ctypes as C
 import os
 import types
 
+import numpy as np
 import torch as th
 
 from . import ops
@@ -47,22 +48,43 @@ from .acnets import randn
 from .envelope import Envelope, random_weights
 
 
+def _raw_view(ptr: int, count: int, device: th.device) -> th.Tensor:
+    """A float32 tensor over ``count`` floats at a raw address the library handed to a transport call-back."""
+    if device.type == "cpu":
+        return th.from_numpy(np.ctypeslib.as_array((C.c_float * count).from_address(ptr)))
+
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    return th.as_tensor(_Raw(), device=device)
+
+
 class NativeComm:
     """The sharded step's collectives behind the C ABI (``morl_comm_*`` / ``morl_allgather_q_begin`` / ``morl_allreduce_grads``
-    of include/morl_hip.h: RCCL over xGMI inside libmorl_hip.so).  ``torch.distributed`` is only the side channel that hands
-    rank 0's unique id to the other ranks."""
+    of include/morl_hip.h).  A communicator is (rank, world) + a TRANSPORT:
 
-    def __init__(self, lib, dist, device, group=None, loopback=False):
+    * ``"rccl"``     RCCL over xGMI inside libmorl_hip.so (``morl_comm_init``); ``torch.distributed`` is only the side channel
+                     that hands rank 0's unique id to the other ranks
+    * ``"torch"``    the caller's transport (``morl_comm_init_custom``): two call-backs that run the all-gather / all-reduce
+                     through ``torch.distributed`` on the stream the library hands them -- gloo in the CPU tests (the one-call
+                     rank step at world 2 / 4 without a GPU), torch's own RCCL communicator with ``MORL_COMM=torch``
+    * ``"loopback"`` one rank, no RCCL (single-rank runs, the emulated build)"""
+
+    def __init__(self, lib, dist, device, group=None, loopback=False, transport="rccl"):
         self.lib, self.device = lib, th.device(device)
         ident = th.zeros(128, dtype=th.uint8)
         handle = C.c_void_p()
         if loopback:
             # one rank, no RCCL: the all-zero id (morl_comm_init) -- single-rank runs and the emulated build of the CPU tests
-            self.rank, self.world = 0, 1
+            self.rank, self.world, self.transport = 0, 1, "loopback"
             lib.check(lib.lib.morl_comm_init(C.byref(handle), C.c_void_p(ident.data_ptr()), 0, 1))
             self.handle = handle.value
             return
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.rank, self.world, self.transport = dist.get_rank(group), dist.get_world_size(group), transport
+        if transport == "torch":
+            self._bind_torch(dist, group, handle)
+            return
+        if transport != "rccl":
+            raise ValueError("transport must be 'rccl' or 'torch'")
         if self.rank == 0:
             lib.check(lib.lib.morl_comm_unique_id(C.c_void_p(ident.data_ptr())))
         ident = ident.to(self.device)
@@ -70,6 +92,54 @@ class NativeComm:
         ident = ident.cpu()
         with th.cuda.device(self.device):
             lib.check(lib.lib.morl_comm_init(C.byref(handle), C.c_void_p(ident.data_ptr()), self.rank, self.world))
+        self.handle = handle.value
+
+    def _bind_torch(self, dist, group, handle) -> None:
+        from .native import ALLGATHER_FN, ALLREDUCE_FN
+        dev, world, views = self.device, self.world, {}
+        self.calls = {"allgather": 0, "allreduce": 0}      # (tests: the one-call path really went through the call-backs)
+        self.last_error = None
+
+        def view(ptr, count):
+            t = views.get((ptr, count))
+            if t is None:                                   # the step's buffers are persistent: a handful of entries
+                t = views[(ptr, count)] = _raw_view(ptr, count, dev)
+            return t
+
+        def on(stream):
+            if dev.type != "cuda":
+                import contextlib
+                return contextlib.nullcontext()             # the emulated build runs launches synchronously
+            return th.cuda.stream(th.cuda.ExternalStream(int(stream or 0), device=dev))
+
+        def allgather(_user, send, recv, count, stream):
+            try:
+                with on(stream):
+                    dist.all_gather_into_tensor(view(recv, count * world), view(send, count), group=group)
+                self.calls["allgather"] += 1
+                return 0
+            except Exception as exc:                        # never let an exception cross the C frames
+                self.last_error = exc
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def allreduce(_user, buf, count, stream):
+            try:
+                with on(stream):
+                    dist.all_reduce(view(buf, count), op=dist.ReduceOp.SUM, group=group)
+                self.calls["allreduce"] += 1
+                return 0
+            except Exception as exc:
+                self.last_error = exc
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cbs = (ALLGATHER_FN(allgather), ALLREDUCE_FN(allreduce))        # keep the thunks alive with the communicator
+        with (th.cuda.device(dev) if dev.type == "cuda" else __import__("contextlib").nullcontext()):
+            self.lib.check(self.lib.lib.morl_comm_init_custom(C.byref(handle), self.rank, self.world,
+                                                              C.cast(self._cbs[0], C.c_void_p), C.cast(self._cbs[1], C.c_void_p), None))
         self.handle = handle.value
 
     def allgather_begin(self, send: th.Tensor, recv: th.Tensor) -> None:
@@ -88,6 +158,40 @@ class NativeComm:
             self.handle = None
     # (no __del__: tearing a communicator down implicitly at interpreter exit, at different moments on different ranks, is how
     # multi-process jobs hang; the process exit releases it)
+
+
+def make_comm(lib, dist, device, group=None, transport=None):
+    """The communicator of a sharded agent.  ``transport``: "rccl" | "torch" | "staged" (None: the ``MORL_COMM`` environment
+    variable -- "native" / "rccl", "torch", "staged" --, default RCCL on an RCCL process group of the gfx950 build and the
+    torch call-backs everywhere else).  If RCCL cannot be brought up inside the library on EVERY rank (librccl missing, a
+    second communicator refused) all ranks fall back to the torch transport together and say so on stderr -- the job runs
+    instead of dying.  Returns (NativeComm or None for the staged path, name of the transport in use)."""
+    import sys
+    want = transport or {"native": "rccl"}.get(os.environ.get("MORL_COMM", ""), os.environ.get("MORL_COMM") or None)
+    if want == "staged":
+        return None, "staged (torch.distributed between library calls)"
+    can_rccl = dist.get_backend(group) == "nccl" and lib.is_device_build
+    if want is None:
+        want = "rccl" if can_rccl else "torch"
+    if want == "rccl":
+        if not can_rccl:
+            raise ValueError("transport 'rccl' needs an RCCL ('nccl') process group and the gfx950 build")
+        comm, err = None, None
+        try:
+            comm = NativeComm(lib, dist, device, group, transport="rccl")
+        except RuntimeError as exc:
+            err = exc
+        ok = th.tensor([0 if comm is None else 1], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            return comm, "rccl (inside libmorl_hip.so)"
+        if comm is not None:
+            comm.close()
+        print(f"[morl_comm] rank {dist.get_rank(group)}: RCCL inside the library unavailable ({err}); every rank falls back to "
+              "the torch.distributed transport", file=sys.stderr, flush=True)
+        want = "torch (fallback: morl_comm_init failed)"
+    comm = NativeComm(lib, dist, device, group, transport="torch")
+    return comm, want + " (torch.distributed call-backs, " + dist.get_backend(group) + ")" if want == "torch" else want
 
 
 def average_gradients(dist, group=None):
@@ -133,7 +237,8 @@ def shard_capql_agent(agent, dist, group=None):
     return agent
 
 
-def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=None, axis: str = "weights") -> Envelope:
+def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=None, axis: str = "weights",
+                         transport=None) -> Envelope:
     """Replace ``agent.update`` with the sharded step.  ``dist`` is ``torch.distributed`` (already initialised).
 
     ``emulate=(world, rank)`` is a measurement aid for boxes with one GPU (bench.py --emulate-world): the step of ONE rank of a
@@ -147,7 +252,7 @@ def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=N
             raise ValueError("emulate= needs a single real rank")
         world, rank = int(emulate[0]), int(emulate[1])
     if axis == "batch":
-        return _shard_envelope_batch(agent, dist, group, emulate, comm, world, rank)
+        return _shard_envelope_batch(agent, dist, group, emulate, comm, world, rank, transport)
     if axis != "weights":
         raise ValueError("axis must be 'weights' or 'batch'")
     W = agent.num_sample_w
@@ -167,8 +272,10 @@ def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=N
     # collectives: inside libmorl_hip.so (RCCL behind the C ABI) on the GPU; torch.distributed itself for the gloo CPU tests
     # (and with MORL_COMM=torch)
     # (``comm``: a ready NativeComm, e.g. the loopback one of a single-rank run)
-    if comm is None and dist.get_backend(group) == "nccl" and agent.lib.is_device_build and os.environ.get("MORL_COMM", "native") != "torch":
-        comm = NativeComm(agent.lib, dist, dev, group)
+    if comm is None and hasattr(dist, "broadcast"):          # (a real torch.distributed, not a test stub)
+        comm, agent._shard.transport = make_comm(agent.lib, dist, dev, group, transport)
+    else:
+        agent._shard.transport = "staged" if comm is None else comm.transport
     agent._shard.comm = comm
     slab_loc = th.empty((2, B0, Wl, A, R), dtype=th.float32, device=dev)
     slab_all = th.zeros((world, 2, B0, Wl, A, R), dtype=th.float32, device=dev)
@@ -235,7 +342,7 @@ def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=N
     return agent
 
 
-def _shard_envelope_batch(agent: Envelope, dist, group, emulate, comm, world: int, rank: int) -> Envelope:
+def _shard_envelope_batch(agent: Envelope, dist, group, emulate, comm, world: int, rank: int, transport=None) -> Envelope:
     """Batch-axis sharding (see the module docstring): ``agent.update`` becomes the step of rank ``rank`` of ``world``."""
     B0 = agent.batch_size
     if B0 % world:
@@ -248,8 +355,10 @@ def _shard_envelope_batch(agent: Envelope, dist, group, emulate, comm, world: in
     agent._grads_x = th.zeros(P + 1 + B0, dtype=th.float32, device=dev)
     agent._grads = agent._grads_x[:P]
     agent._bind_optimizer_state()
-    if comm is None and dist.get_backend(group) == "nccl" and agent.lib.is_device_build and os.environ.get("MORL_COMM", "native") != "torch":
-        comm = NativeComm(agent.lib, dist, dev, group)
+    if comm is None and hasattr(dist, "broadcast"):          # (a real torch.distributed, not a test stub)
+        comm, agent._shard.transport = make_comm(agent.lib, dist, dev, group, transport)
+    else:
+        agent._shard.transport = "staged" if comm is None else comm.transport
     agent._shard.comm = comm
 
     def update(self: Envelope):

@@ -202,6 +202,7 @@ class Envelope(MOPolicy, MOAgent):
         params = th.load(path, weights_only=False)
         self.q_net.load_state_dict(params["q_net_state_dict"])
         self.target_q_net.load_state_dict(params["q_net_state_dict"])   # envelope.py:257-258
+        self.q_net.ctx.invalidate_shadows()                             # (in-place writes behind the library's back)
         self.q_optim.load_state_dict(params["q_net_optimizer_state_dict"])
         # load_state_dict re-allocates the state tensors: copy them back into the flat buffers and re-bind the views
         prms = self.q_net.ordered_parameters()
@@ -235,11 +236,10 @@ class Envelope(MOPolicy, MOAgent):
         moved to a persistent device buffer by the batch-gather launch (no copy launch of their own).  Returns the ``aux``
         argument of ``replay_buffer.sample`` and the device tensor (valid once that launch has been enqueued)."""
         W, R = self.num_sample_w, self.reward_dim
-        ring = getattr(self, "_w_ring", None)
-        if ring is None or ring.buf.shape[1] != W * R:
-            ring = self._w_ring = ops.HostRing(self.lib, self.device, W * R, th.float32)
+        ring = self._w_ring = ops.HostRing.fit(getattr(self, "_w_ring", None), self.lib, self.device, W * R, th.float32)
+        if getattr(self, "_w_dev", None) is None or self._w_dev.shape != (W, R):
             self._w_dev = th.zeros((W, R), dtype=th.float32, device=self.device)
-        slot, ptr = ring.next()
+        slot, ptr = ring.next(W * R)
         slot[:] = random_weights(dim=R, n=W, dist="gaussian", rng=self.np_random).reshape(-1)   # float64 -> fp32 (.float())
         return (ptr, self._w_dev), self._w_dev
 

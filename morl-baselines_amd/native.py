@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
 
 MORL_MAX_LAYERS = 8
 MORL_MAX_OBJ = 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class NetDesc(C.Structure):
@@ -58,6 +58,9 @@ class ACCfg(C.Structure):
 
 # int hook(void* user, int which, float* grads, int64_t count, void* stream) -- morl_ac_cfg.grad_hook
 GRAD_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
+# morl_allgather_fn / morl_allreduce_fn of morl_comm_init_custom
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 
 AC_STATE_FIELDS = ("q", "q_target", "q_exp_avg", "q_exp_avg_sq", "pol", "pol_exp_avg", "pol_exp_avg_sq", "pol_target",
@@ -130,6 +133,7 @@ _SIGNATURES = {
     "morl_envelope_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9 +
                               [C.c_int, C.c_void_p]),
+    "morl_ctx_invalidate_shadows": (C.c_int, [C.c_void_p]),
     "morl_host_device_pointer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "morl_gather_fields": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int,
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.c_void_p]),
@@ -154,6 +158,7 @@ _SIGNATURES = {
                                          [C.POINTER(UpdateCfg), C.c_void_p]),
     "morl_comm_unique_id": (C.c_int, [C.c_void_p]),
     "morl_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
+    "morl_comm_init_custom": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "morl_comm_destroy": (C.c_int, [C.c_void_p]),
     "morl_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "morl_allgather_q_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

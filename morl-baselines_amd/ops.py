@@ -43,6 +43,11 @@ class QNetContext:
         -1: one launch of every step, the launches of a step taking turns)."""
         self.lib.check(self.lib.lib.morl_ctx_set_timing(self.handle, int(every)))
 
+    def invalidate_shadows(self) -> None:
+        """Drop the K-major shadow copies a ``sample(prepare=...)`` launch made (``morl_ctx_invalidate_shadows``): for callers
+        that write the parameter buffers in place between that launch and the step it prepared."""
+        self.lib.check(self.lib.lib.morl_ctx_invalidate_shadows(self.handle))
+
     def read_timing(self):
         """(number of timed chain launches, their summed duration in ms); synchronises on them."""
         n, ms = C.c_int(0), C.c_double(0.0)
@@ -104,12 +109,19 @@ class HostRing:
     host-drawn numbers (B uniforms or indices, W x R sampled weights) reach the device without a copy launch of their own.
     A slot is handed out again only after the kernel that read it has finished.  Event records cost a few microseconds of
     stream time each, so ONE event guards a whole group of slots: it is recorded after the group's last slot was used and
-    waited for (normally long since complete) before the group's first slot is reused a lap later."""
+    waited for (normally long since complete) before the group's first slot is reused a lap later.
+
+    Lifetime: the pinned block belongs to torch's caching HOST allocator, which knows of no stream use -- a ring that is
+    dropped while a kernel still reads one of its slots could be handed out again and overwritten under that kernel.  A
+    ring is therefore sized for the LARGEST count it has been asked for (``HostRing.fit``: a smaller request is a prefix of
+    the slot, no re-creation when GPI-PD alternates between batch sizes) and, when it does have to be replaced, ``retire()``
+    first waits for an event recorded behind its last use."""
 
     def __init__(self, lib: NativeLib, device: th.device, count: int, dtype, slots: int = 64, group: int = 16):
         assert slots % group == 0 and slots // group >= 2
         self.lib, self.device = lib, th.device(device)
         self.on_gpu = self.device.type == "cuda"
+        self.capacity, self.dtype = int(count), dtype
         self.buf = th.zeros((slots, count), dtype=dtype, pin_memory=self.on_gpu)
         self.np = self.buf.numpy()
         self.group = group
@@ -125,14 +137,25 @@ class HostRing:
             else:
                 self.dev_ptrs.append(host)
 
-    def next(self):
-        """(numpy view to fill, device-side address of the slot)."""
+    @staticmethod
+    def fit(ring: "Optional[HostRing]", lib: NativeLib, device, count: int, dtype) -> "HostRing":
+        """``ring`` if it can hold ``count`` elements per slot, else a larger replacement (the old one retired safely)."""
+        if ring is not None and ring.capacity >= count and ring.dtype == dtype:
+            return ring
+        if ring is not None:
+            ring.retire()
+            count = max(count, ring.capacity)
+        return HostRing(lib, device, count, dtype)
+
+    def next(self, count: Optional[int] = None):
+        """(numpy view to fill -- the first ``count`` elements of the slot --, device-side address of the slot)."""
         self.cur = (self.cur + 1) % len(self.dev_ptrs)
         if self.cur % self.group == 0:
             evt = self.events[self.cur // self.group]
             if evt is not None:
                 evt.synchronize()
-        return self.np[self.cur], self.dev_ptrs[self.cur]
+        view = self.np[self.cur]
+        return (view if count is None or count == self.capacity else view[:count]), self.dev_ptrs[self.cur]
 
     def mark_used(self) -> None:
         """Call right after enqueueing the kernel that reads the slot handed out last."""
@@ -141,6 +164,14 @@ class HostRing:
             evt = self.events[g] or th.cuda.Event()
             evt.record(th.cuda.current_stream(self.device))
             self.events[g] = evt
+
+    def retire(self) -> None:
+        """Block until every kernel enqueued so far on the device's current stream (the readers of this ring's slots) has
+        finished; only then may the pinned block go back to the host allocator.  Rare path (a ring outgrown)."""
+        if self.on_gpu and self.cur >= 0:
+            evt = th.cuda.Event()
+            evt.record(th.cuda.current_stream(self.device))
+            evt.synchronize()
 
 
 def sample_gather(lib: NativeLib, records: th.Tensor, B: int, D: int, R: int, action_dim: int = 1, int_actions: bool = True, *,

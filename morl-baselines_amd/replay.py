@@ -155,11 +155,10 @@ class ReplayBuffer:
         self.size = min(self.size + n, self.max_size)
 
     def _ring(self, name: str, count: int, dtype) -> "ops.HostRing":
-        """Pinned staging ring for the host-drawn numbers of a batch (re-created when the batch size changes)."""
-        ring = self.__dict__.get(name)
-        if ring is None or ring.buf.shape[1] != count:
-            ring = ops.HostRing(self.lib, self.device, count, dtype)
-            self.__dict__[name] = ring
+        """Pinned staging ring for the host-drawn numbers of a batch: sized for the largest batch seen, a smaller batch uses
+        a prefix of the slot (GPI-PD alternates between batch sizes; see ``ops.HostRing`` on why rings are not dropped)."""
+        ring = ops.HostRing.fit(self.__dict__.get(name), self.lib, self.device, count, dtype)
+        self.__dict__[name] = ring
         return ring
 
     def _gather(self, inds: np.ndarray, aux=None, prepare=None):
@@ -167,7 +166,7 @@ class ReplayBuffer:
         self.flush()
         B = int(len(inds))
         ring = self._ring("_idx_ring", B, th.int64)
-        slot, ptr = ring.next()
+        slot, ptr = ring.next(B)
         slot[:] = inds
         obs, act, rew, nobs, done, idx = ops.sample_gather(
             self.lib, self.records, B, self._D, self._R, self._Ad, self._int_actions, idx_ptr=ptr,
@@ -301,7 +300,7 @@ class PrioritizedReplayBuffer(ReplayBuffer):
         if to_tensor:
             self.flush()
             ring = self._ring("_u_ring", int(batch_size), th.float64)
-            slot, ptr = ring.next()
+            slot, ptr = ring.next(int(batch_size))
             slot[:] = np.random.random_sample(batch_size)
             obs, act, rew, nobs, done, idx = ops.sample_gather(
                 self.lib, self.records, int(batch_size), self._D, self._R, self._Ad, self._int_actions,

@@ -31,6 +31,10 @@ def _make_agent(lib, per, schedules=False, dev=th.device("cpu"), arch=(32, 32), 
 
 
 def _worker(rank, world, port, per, ret, schedules=False, axis="weights"):
+    """One rank of a gloo job.  The sharded agent is run TWICE from identical seeds: through the staged path (seven library
+    calls, the collectives issued by ``torch.distributed`` between them) and through the production path -- ONE library call
+    per step (``morl_envelope_step_sharded`` / ``_batch_sharded``) whose collectives are the communicator's transport, here
+    ``morl_comm_init_custom`` call-backs over gloo."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -42,14 +46,23 @@ def _worker(rank, world, port, per, ret, schedules=False, axis="weights"):
     lib = simlib.load_sim()
     native.use_library(lib)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ag = _make_agent(lib, per, schedules)
-    shard_envelope_agent(ag, dist, axis=axis)
-    for _ in range(N_STEPS[schedules]):
-        ag.update()
-        ag.global_step += 1
-    ret[rank] = (ag.q_net.flat.clone().numpy(), float(ag.last_loss()),
-                 ag.replay_buffer.tree_dev.clone().numpy() if per else None,
-                 float(ag.homotopy_lambda), float(ag.epsilon))
+    for transport in ("staged", None):                    # None = what a job gets by default: the one-call step
+        ag = _make_agent(lib, per, schedules)
+        shard_envelope_agent(ag, dist, axis=axis, transport=transport)
+        comm = ag._shard.comm
+        assert (comm is None) == (transport == "staged"), ag._shard.transport
+        for _ in range(N_STEPS[schedules]):
+            ag.update()
+            ag.global_step += 1
+        calls = None
+        if comm is not None:
+            assert comm.transport == "torch" and comm.world == world and comm.rank == rank
+            calls = dict(comm.calls)
+            comm.close()
+        ret[(rank, transport or "one-call")] = (
+            ag.q_net.flat.clone().numpy(), float(ag.last_loss()),
+            ag.replay_buffer.tree_dev.clone().numpy() if per else None,
+            float(ag.homotopy_lambda), float(ag.epsilon), calls)
     dist.destroy_process_group()
 
 
@@ -57,7 +70,9 @@ def _worker(rank, world, port, per, ret, schedules=False, axis="weights"):
 @pytest.mark.parametrize("per,schedules,world", [(False, False, 2), (True, False, 2), (True, True, 2), (True, False, 4)])
 def test_sharded_update_equals_single_process(per, schedules, world, axis):
     """``schedules``: several steps with ``homotopy_decay_steps`` / ``epsilon_decay_steps`` set -- the sharded step must run
-    the same tail as ``Envelope.update`` (envelope.py:336-355), or the auxiliary loss never turns on under sharding."""
+    the same tail as ``Envelope.update`` (envelope.py:336-355), or the auxiliary loss never turns on under sharding.
+    Both code paths of the rank step are run at world > 1: the one-call step (the production path; its collectives go through
+    the pluggable transport of ``morl_comm``) must equal the staged one BIT FOR BIT and the unsharded step to 1e-5."""
     import simlib
     import morl_baselines_amd.native as native
     lib = simlib.load_sim()
@@ -84,18 +99,26 @@ def test_sharded_update_equals_single_process(per, schedules, world, axis):
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
-    p0, l0, t0, lam0, eps0 = ret[0]
-    for r in range(1, world):                                       # (world 4: one weight per rank, four slab parts)
-        p1, l1, t1, lam1, eps1 = ret[r]
-        assert np.array_equal(p0, p1) and l0 == l1                  # replicas bit-identical
-        assert lam0 == lam1 == want_lam and eps0 == eps1 == want_eps     # same schedules as the unsharded agent
+    for path in ("staged", "one-call"):
+        p0, l0, t0, lam0, eps0, calls0 = ret[(0, path)]
+        for r in range(1, world):                                       # (world 4: one weight per rank, four slab parts)
+            p1, l1, t1, lam1, eps1, _ = ret[(r, path)]
+            assert np.array_equal(p0, p1) and l0 == l1                  # replicas bit-identical
+            assert lam0 == lam1 == want_lam and eps0 == eps1 == want_eps     # same schedules as the unsharded agent
+            if per:
+                assert np.array_equal(t0, t1)
+        assert abs(l0 - want_loss) <= 1e-5 * abs(want_loss)              # sharded == unsharded (fp32 order tolerance)
+        assert np.abs(p0 - want).max() <= 0.02 * 3e-4 * n_steps
         if per:
-            assert np.array_equal(t0, t1)
-    assert abs(l0 - want_loss) <= 1e-5 * abs(want_loss)              # sharded == unsharded (fp32 order tolerance)
-    assert np.abs(p0 - want).max() <= 0.02 * 3e-4 * n_steps
-    if per:
-        assert np.array_equal(t0, t1)
-        np.testing.assert_allclose(t0[0], want_tree[0], rtol=1e-5)
+            np.testing.assert_allclose(t0[0], want_tree[0], rtol=1e-5)
+    # the production path took the same steps as the staged one, bit for bit, and its collectives were the transport's
+    for r in range(world):
+        ps, ls, ts, _, _, _ = ret[(r, "staged")]
+        po, lo, to, _, _, calls = ret[(r, "one-call")]
+        assert np.array_equal(ps, po) and ls == lo
+        if per:
+            assert np.array_equal(ts, to)
+        assert calls == {"allgather": n_steps if axis == "weights" else 0, "allreduce": n_steps}
 
 
 class _OneRank:
@@ -192,6 +215,35 @@ def test_one_call_sharded_step_equals_the_staged_one(per):
                 assert np.abs(fused[0] - plain[0]).max() <= 0.02 * 3e-4 * 3
                 if per:
                     np.testing.assert_allclose(fused[2][0], plain[2][0], rtol=1e-5)
+    finally:
+        native.use_library(None)
+
+
+def test_custom_transport_failure_is_a_status_not_a_crash():
+    """A transport call-back that raises (or returns non-zero) fails the step with a status + message; the exception never
+    crosses the C frames.  Also: the custom communicator reports the rank / world it was given."""
+    import ctypes as C
+    import simlib
+    import morl_baselines_amd.native as native
+    from morl_baselines_amd.distributed import NativeComm, shard_envelope_agent
+    lib = simlib.load_sim()
+    native.use_library(lib)
+    try:
+        class Broken(_OneRank):
+            def all_reduce(self, t, op=None, group=None):
+                raise RuntimeError("link down")
+        ag = _make_agent(lib, per=False)
+        comm = NativeComm(lib, Broken(), "cpu", transport="torch")
+        r, w = C.c_int(-1), C.c_int(-1)
+        lib.check(lib.lib.morl_comm_size(comm.handle, C.byref(r), C.byref(w)))
+        assert (r.value, w.value) == (0, 1)
+        shard_envelope_agent(ag, Broken(), comm=comm, axis="batch")
+        before = ag.q_net.flat.clone()
+        with pytest.raises(RuntimeError, match="all-reduce call-back failed"):
+            ag.update()
+        assert isinstance(comm.last_error, RuntimeError) and "link down" in str(comm.last_error)
+        assert th.equal(before, ag.q_net.flat)                 # the optimiser step behind the failed collective was not taken
+        assert lib.lib.morl_comm_init_custom(None, 0, 1, None, None, None) != 0
     finally:
         native.use_library(None)
 
