@@ -122,6 +122,15 @@ int morl_ctx_set_dw_mode(morl_ctx* ctx, int mode);
  * duration (ms) and clears the record.  Used by bench.py for the roofline figure. */
 int morl_ctx_set_timing(morl_ctx* ctx, int every);
 int morl_ctx_read_timing(morl_ctx* ctx, int* n_launches, double* total_ms);
+/* The same record split by launch kind: n_launches / total_ms are arrays of MORL_TIMED_KINDS entries -- the forward chain launch
+ * (the step's three passes, or the slabs / training-forward launches of a sharded step), the backward-dX chain launch and the
+ * weight-gradient launch (dw_tiles; bracketed too, so in the rotating mode the three take turns).  morl_ctx_read_timing returns
+ * the two chain kinds summed.  Either call clears the record. */
+#define MORL_TIMED_FORWARD 0
+#define MORL_TIMED_BACKWARD 1
+#define MORL_TIMED_DW 2
+#define MORL_TIMED_KINDS 3
+int morl_ctx_read_timing_kinds(morl_ctx* ctx, int* n_launches, double* total_ms);
 /* number of float parameters of `net` in the flat layout */
 int64_t morl_param_count(const morl_net_desc* net);
 

@@ -174,6 +174,7 @@ struct morl_ctx {
     long long timing_step = 0;           //     time each, so timing every step would perturb what it measures)
     int timing_idx = 0, timing_prev_launches = 0, timing_rotate = -1;   // every == -1: one launch per step, taking turns
     std::vector<hipEvent_t> ev_start, ev_stop;
+    std::vector<int> ev_kind;            // MORL_TIMED_* of each recorded launch
     int main_rows = -1;                  // rows of a hoisted training forward (morl_envelope_main_forward), -1 = none
     // shadow copies made by morl_envelope_prepare for exactly these parameter buffers; consumed (one-shot) by the step's first
     // library entry, dropped by every optimiser step of the library
@@ -468,6 +469,38 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
     return MORL_OK;
 }
 
+// ---- optional event brackets around the GEMM launches of a step (bench.py's roofline figures) --------------------------------
+// rotating mode (every == -1): ONE launch per step is bracketed, the k-th timed launch site of the step on step k (mod sites).
+static int timing_open(morl_ctx* c, int kind, hipStream_t s, int* slot) {
+    *slot = -1;
+    const int idx_in_step = c->timing_idx++;
+    const bool timed = c->timing && (c->timing_rotate < 0 || idx_in_step == c->timing_rotate);
+    if (!timed) return MORL_OK;
+    if (c->ev_used == c->ev_start.size()) {
+        // no system-scope fence at the record: the fence is not part of the kernel, delays the launch behind it (a
+        // bracketed chain launch measured 128.9 us with it, 126.4 us without; rocprofv3's kernel trace says 124.7 us)
+        // and costs the step 2 us per record
+        static const unsigned ev_flags = [] {
+            const char* e = getenv("MORL_EV_FLAGS");   // (tuning)
+            return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)hipEventDisableSystemFence;
+        }();
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreateWithFlags(&e0, ev_flags));
+        HIP_TRY(hipEventCreateWithFlags(&e1, ev_flags));
+        c->ev_start.push_back(e0);
+        c->ev_stop.push_back(e1);
+        c->ev_kind.push_back(kind);
+    }
+    *slot = (int)c->ev_used++;
+    c->ev_kind[*slot] = kind;
+    HIP_TRY(hipEventRecord(c->ev_start[*slot], s));
+    return MORL_OK;
+}
+static int timing_close(morl_ctx* c, int slot, hipStream_t s) {
+    if (slot >= 0) HIP_TRY(hipEventRecord(c->ev_stop[slot], s));
+    return MORL_OK;
+}
+
 // ---- second-generation chain (mlp_chain2.h): one persistent launch of 2 workgroups per CU over all units --------------
 static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s) {
     Chain2Multi m{};
@@ -490,28 +523,10 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
     if (c->fused_tm == 64) m.tail_halves = 0;
     m.stagger = c->chain_stagger;
     m.cu_tickets = c->cu_tickets;
-    size_t slot = 0;
-    // rotating mode: one launch per step is bracketed, the k-th launch of the step on step k (mod launches per step)
-    const int idx_in_step = c->timing_idx++;
-    const bool timed = c->timing && (c->timing_rotate < 0 || idx_in_step == c->timing_rotate);
-    if (timed) {
-        if (c->ev_used == c->ev_start.size()) {
-            // no system-scope fence at the record: the fence is not part of the kernel, delays the launch behind it (a
-            // bracketed chain launch measured 128.9 us with it, 126.4 us without; rocprofv3's kernel trace says 124.7 us)
-            // and costs the step 2 us per record
-            static const unsigned ev_flags = [] {
-                const char* e = getenv("MORL_EV_FLAGS");   // (tuning)
-                return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)hipEventDisableSystemFence;
-            }();
-            hipEvent_t e0, e1;
-            HIP_TRY(hipEventCreateWithFlags(&e0, ev_flags));
-            HIP_TRY(hipEventCreateWithFlags(&e1, ev_flags));
-            c->ev_start.push_back(e0);
-            c->ev_stop.push_back(e1);
-        }
-        slot = c->ev_used++;
-        HIP_TRY(hipEventRecord(c->ev_start[slot], s));
-    }
+    // (backward chain: the one whose input is the TD kernel's dLoss/dQ)
+    const int kind = (chains[0].in_mode == 1 && chains[0].src == c->dq) ? MORL_TIMED_BACKWARD : MORL_TIMED_FORWARD;
+    int slot = -1, rc_t;
+    if ((rc_t = timing_open(c, kind, s, &slot))) return rc_t;
     static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
     if (small_rows && chain16_wanted(chains, n)) {
         // few rows (small batches, shards of a strong-scaled job): 16-row tiles, one workgroup each (mlp_chain16.h)
@@ -521,8 +536,7 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
     } else if (c->chain_sched) hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
     else hipLaunchKernelGGL(mlp_chain2_kernel<0>, dim3(S), dim3(CH_THREADS), 0, s, m);
     LAUNCH_CHECK("mlp_chain2");
-    if (timed) HIP_TRY(hipEventRecord(c->ev_stop[slot], s));
-    return MORL_OK;
+    return timing_close(c, slot, s);
 }
 
 static int launch_chain(morl_ctx* c, const ChainArgs& a, hipStream_t s) { return chain2_launch(c, &a, 1, s); }
@@ -649,19 +663,31 @@ static void timing_begin_step(morl_ctx* c) {
     ++c->timing_step;
 }
 
-// Blocks until the recorded launches finished; returns their count and summed duration, then clears the record.
-extern "C" int morl_ctx_read_timing(morl_ctx* c, int* n_launches, double* total_ms) {
+// Blocks until the recorded launches finished; per kind (MORL_TIMED_*) their count and summed duration, then clears the record.
+extern "C" int morl_ctx_read_timing_kinds(morl_ctx* c, int* n_launches, double* total_ms) {
     if (!c || !n_launches || !total_ms) return fail(MORL_ERR_ARG, "NULL argument");
-    double sum = 0.0;
+    for (int k = 0; k < MORL_TIMED_KINDS; ++k) { n_launches[k] = 0; total_ms[k] = 0.0; }
     for (size_t k = 0; k < c->ev_used; ++k) {
         float ms = 0.f;
         HIP_TRY(hipEventSynchronize(c->ev_stop[k]));
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_start[k], c->ev_stop[k]));
-        sum += ms;
+        const int kind = c->ev_kind[k];
+        ++n_launches[kind];
+        total_ms[kind] += ms;
     }
-    *n_launches = (int)c->ev_used;
-    *total_ms = sum;
     c->ev_used = 0;
+    return MORL_OK;
+}
+
+// the chain launches only (forward + backward-dX), as before the weight-gradient launch was bracketed too
+extern "C" int morl_ctx_read_timing(morl_ctx* c, int* n_launches, double* total_ms) {
+    if (!c || !n_launches || !total_ms) return fail(MORL_ERR_ARG, "NULL argument");
+    int n[MORL_TIMED_KINDS];
+    double ms[MORL_TIMED_KINDS];
+    const int rc = morl_ctx_read_timing_kinds(c, n, ms);
+    if (rc) return rc;
+    *n_launches = n[MORL_TIMED_FORWARD] + n[MORL_TIMED_BACKWARD];
+    *total_ms = ms[MORL_TIMED_FORWARD] + ms[MORL_TIMED_BACKWARD];
     return MORL_OK;
 }
 
@@ -1002,8 +1028,11 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         }
         a.stagger = 0;
         if (const char* e = getenv("MORL_DW_STAGGER")) a.stagger = std::max(0, atoi(e));     // (tuning)
+        int tslot = -1;
+        if ((rc = timing_open(c, MORL_TIMED_DW, s, &tslot))) return rc;
         hipLaunchKernelGGL(dw_tiles_kernel, dim3(jobs + extra), dim3(DW2_THREADS), 0, s, a);
         LAUNCH_CHECK("dw_tiles");
+        if ((rc = timing_close(c, tslot, s))) return rc;
     } else if (c->dw_wave_ok && c->use_fused && c->dw_mode == 0) {
         // wave-level tiles (dw_wave.h): aim at one wave per SIMD over the whole chip
         splits = std::max(1, std::min(c->max_splits, (4 * c->num_cus + c->dw_wave_tiles / 2) / c->dw_wave_tiles));

@@ -126,6 +126,7 @@ _SIGNATURES = {
     "morl_ctx_set_dw_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "morl_ctx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "morl_ctx_read_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "morl_ctx_read_timing_kinds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "morl_gather_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] +
                           [C.c_void_p] * 6 + [C.c_void_p]),
     "morl_sample_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int,

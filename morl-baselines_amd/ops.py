@@ -54,6 +54,12 @@ class QNetContext:
         self.lib.check(self.lib.lib.morl_ctx_read_timing(self.handle, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def read_timing_kinds(self):
+        """{"forward" | "backward" | "dw": (launches, summed ms)} of the bracketed launches; synchronises, clears the record."""
+        n, ms = (C.c_int * 3)(), (C.c_double * 3)()
+        self.lib.check(self.lib.lib.morl_ctx_read_timing_kinds(self.handle, n, ms))
+        return {k: (n[i], ms[i]) for i, k in enumerate(("forward", "backward", "dw"))}
+
     def layer_slices(self):
         """[(w_offset, (out, in), b_offset, out)] of the flat parameter layout."""
         out, off = [], 0

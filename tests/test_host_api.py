@@ -178,14 +178,22 @@ def test_chain_launch_timing_modes(be):
     assert ctx.engine > 0                                   # the layer-fused chain is what is timed
     ctx.set_timing(1)
     ag.update()
-    per_step, ms = ctx.read_timing()
-    assert per_step >= 2 and ms >= 0.0                      # the forward launch(es) and the backward-dX launch
-    for every, steps, want in ((1, 3, 3 * per_step), (2, 4, 2 * per_step), (-1, 5, 5), (0, 2, 0)):
+    kinds = ctx.read_timing_kinds()
+    assert kinds["forward"][0] >= 1 and kinds["backward"][0] == 1 and kinds["dw"][0] == 1     # the three GEMM launches
+    per_step = sum(n for n, _ in kinds.values())
+    chain_per_step = kinds["forward"][0] + kinds["backward"][0]
+    ctx.set_timing(1)
+    ag.update()
+    n_chain, ms_chain = ctx.read_timing()                    # the two chain kinds only
+    assert n_chain == chain_per_step and ms_chain >= 0.0
+    for every, steps, want in ((1, 3, 3 * per_step), (2, 4, 2 * per_step), (-1, 2 * per_step, 2 * per_step), (0, 2, 0)):
         ctx.set_timing(every)
         for _ in range(steps):
             ag.update()
-        n, ms = ctx.read_timing()
-        assert n == want and ms >= 0.0
+        got = ctx.read_timing_kinds()
+        assert sum(n for n, _ in got.values()) == want and all(ms >= 0.0 for _, ms in got.values())
+        if every == -1:                                      # taking turns: every launch site sampled equally often
+            assert got["backward"][0] == 2 and got["dw"][0] == 2 and got["forward"][0] == 2 * kinds["forward"][0]
     assert ctx.read_timing() == (0, 0.0)                    # reading clears the record
     ctx.set_timing(0)
     with pytest.raises(Exception):
