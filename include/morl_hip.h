@@ -131,6 +131,11 @@ int morl_ctx_read_timing(morl_ctx* ctx, int* n_launches, double* total_ms);
 #define MORL_TIMED_DW 2
 #define MORL_TIMED_KINDS 3
 int morl_ctx_read_timing_kinds(morl_ctx* ctx, int* n_launches, double* total_ms);
+/* Parity-test aid: out [rows][dims[layer]] <- the post-ReLU activations of hidden layer `layer` (1 .. n_layers - 1) that the last
+ * training forward on this context saved for the weight-gradient GEMM; out > 0 is the ReLU mask its backward pass applied.
+ * tests/flip_aware.py feeds these masks to the oracle, so that a unit whose pre-activation is within rounding of zero (and lands
+ * on the other side of the ReLU than in torch's GEMM) is accounted for exactly instead of by a blanket tolerance. */
+int morl_ctx_debug_hidden(morl_ctx* ctx, int layer, int rows, float* out, void* stream);
 /* number of float parameters of `net` in the flat layout */
 int64_t morl_param_count(const morl_net_desc* net);
 

@@ -785,6 +785,17 @@ extern "C" int morl_ctx_invalidate_shadows(morl_ctx* c) {
     return MORL_OK;
 }
 
+// parity-test aid: the post-ReLU activations h_l [rows][dims[l]] the LAST training forward on this context saved (what the
+// weight-gradient GEMM reads; h_l > 0 is the ReLU mask the backward pass applied)
+extern "C" int morl_ctx_debug_hidden(morl_ctx* c, int layer, int rows, float* out, void* stream) {
+    if (!c || !out) return fail(MORL_ERR_ARG, "NULL argument");
+    if (layer < 1 || layer >= c->L) return fail(MORL_ERR_ARG, "layer %d outside [1, %d)", layer, c->L);
+    if (rows < 1 || rows > c->max_rows) return fail(MORL_ERR_ARG, "rows %d outside [1, %d]", rows, c->max_rows);
+    HIP_TRY(hipMemcpyAsync(out, c->h[layer], (size_t)rows * c->net.dims[layer] * sizeof(float), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    return MORL_OK;
+}
+
 extern "C" int morl_host_device_pointer(void* host_ptr, void** device_ptr) {
     if (!host_ptr || !device_ptr) return fail(MORL_ERR_ARG, "NULL argument");
     HIP_TRY(hipHostGetDevicePointer(device_ptr, host_ptr, 0));

@@ -54,6 +54,13 @@ class QNetContext:
         self.lib.check(self.lib.lib.morl_ctx_read_timing(self.handle, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def debug_hidden(self, layer: int, rows: int, like: th.Tensor) -> th.Tensor:
+        """Parity-test aid (``morl_ctx_debug_hidden``): post-ReLU activations (rows, width) of hidden layer ``layer`` saved by
+        the last training forward; ``like`` fixes the device / stream."""
+        out = th.empty((rows, self.desc.dims[layer]), dtype=th.float32, device=like.device)
+        self.lib.check(self.lib.lib.morl_ctx_debug_hidden(self.handle, int(layer), int(rows), _ptr(out), self.lib.stream_of(like)))
+        return out
+
     def read_timing_kinds(self):
         """{"forward" | "backward" | "dw": (launches, summed ms)} of the bracketed launches; synchronises, clears the record."""
         n, ms = (C.c_int * 3)(), (C.c_double * 3)()

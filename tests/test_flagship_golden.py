@@ -39,6 +39,8 @@ def run(request):
                               th.tensor(inp["rewards"]).to(dev), th.tensor(inp["dones"]).reshape(-1).to(dev),
                               sw.to(dev), gamma=c.gamma, lr=c.lr, adam_step=c.step, max_grad_norm=c.max_grad_norm,
                               debug=True)
+    # the ReLU decisions of the training forward (tests/flip_aware.py), fetched while the context is alive
+    res["hidden"] = [ctx.debug_hidden(l, c.B * c.W, t["po"]).cpu() for l in range(1, len(c.arch) + 1)]
     th.cuda.synchronize()
     return c, inp, res, t, sw, np.load(os.path.join(GOLD, f"envelope_{c.name}.npz"))
 
@@ -73,7 +75,9 @@ def test_argmax_indices_match_reference_up_to_one_ulp_ties(run):
             json.dump({"case": c.name, "td_rows": c.B * c.W, "flips": int(mism.numel())}, fh)
     except OSError:
         pass
-    assert mism.numel() <= 0.002 * c.B * c.W
+    # observed on MI355X in round 2: 1 of 16 384 (256 x 64) and 0 of 8 192 (256 x 32) -- profiles/r02_near_tie_flips_*.json; a
+    # handful is what ~1e-7 of GEMM rounding can produce among 16 384 x 384 candidates, hundreds would be an error
+    assert mism.numel() <= 8
     for r in mism.tolist():                                               # every mismatch is a near-tie
         i, b = r // c.B, r % c.B
         s = (sw[i].double() * qo[b].double()).sum(-1)                     # (W, A) scalarised values
@@ -88,14 +92,34 @@ def test_targets_params_and_priorities_match_reference(run):
     rel = (got - want).abs().max(1).values / want.abs().max()
     # rows whose arg-max agrees differ only by GEMM rounding (1e-5); the few near-tie index flips select another slab row
     assert (rel > 1e-5).float().mean().item() <= 0.004
+    # (1) the device against the oracle re-run under the device's OWN discrete decisions (ReLU masks, selected targets): the
+    #     tight contract -- gradients 5e-5 of the largest entry, parameters within the bound Adam derives from that; every mask
+    #     difference is asserted to sit within 1e-6 of a zero pre-activation (tests/flip_aware.py)
+    import flip_aware as fa
+    obs = fa.check_step(c, inp, res, t, res["hidden"], f"golden_{c.name}")
+    print(f"[flip-aware] {c.name}: {obs}")
+    # (2) against the unmodified reference's fixture.  The oracle under ITS OWN decisions reproduces the fixture bit for bit
+    #     (tests/test_oracle_golden.py), so what the device's flips (near-zero ReLU units, near-tie arg-max rows) move is exactly
+    #     the difference between the two oracle runs; the device may be that far from the fixture plus the tight tolerance
+    o_full = orc.envelope_update([th.tensor(a) for a in inp["online"]], [th.tensor(a) for a in inp["target"]],
+                                 [th.tensor(a) for a in inp["exp_avg"]], [th.tensor(a) for a in inp["exp_avg_sq"]], c.step,
+                                 tuple(th.tensor(inp[k]) for k in ("obs", "actions", "rewards", "next_obs", "dones")),
+                                 th.tensor(inp["sampled_w"]).float(), n_actions=c.A, reward_dim=c.R, gamma=c.gamma, lr=c.lr,
+                                 max_grad_norm=c.max_grad_norm, dedup=True, apply_step=False)
+    own = fa.oracle_step_under(c, inp, None, o_full["target"])
+    under = fa.oracle_step_under(c, inp, [h > 0 for h in res["hidden"]], res["target"].cpu().view(c.B * c.W, c.R))
+    moved_g = (own["grads"] - under["grads"]).abs()
+    moved_p = (own["params"] - under["params"]).abs()
     s, off = c.subsample, 0
     po, gr = t["po"].cpu(), t["g"].cpu()
     gmax = max(float(np.abs(g[f"grad_{i}"]).max()) for i in range(len(inp["online"])))
+    bound_p = fa.adam_bound(own["grads"], own["m0"], own["v0"], fa.GRAD_TOL * gmax, c.step, c.lr) + 2.4e-7 * own["params"].abs().double()
     for i, p in enumerate(inp["online"]):
         n = p.size
-        assert float((gr[off:off + n][::s] - th.tensor(g[f"grad_{i}"])).abs().max()) <= 5e-5 * gmax
-        # Adam moves a parameter by <= lr per step; agree to a small fraction of that
-        assert float((po[off:off + n][::s] - th.tensor(g[f"param_after_{i}"])).abs().max()) <= 0.05 * c.lr
+        sl = slice(off, off + n)
+        assert float((own["grads"][sl][::s] - th.tensor(g[f"grad_{i}"])).abs().max()) <= 1e-6 * gmax    # (the fixture IS this run)
+        assert bool(((gr[sl][::s] - th.tensor(g[f"grad_{i}"])).abs() <= fa.GRAD_TOL * gmax + moved_g[sl][::s]).all())
+        assert bool(((po[sl][::s] - th.tensor(g[f"param_after_{i}"])).abs().double() <= (bound_p[sl] + moved_p[sl].double())[::s] + 1e-12).all())
         off += n
     pr = (res["priority"].cpu().numpy() + np.float32(0.125)) ** np.float32(0.6)
     np.testing.assert_allclose(pr, g["priority_final"], rtol=2e-4)

@@ -42,7 +42,7 @@ def relmax(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-def run_update(lib, dev, c, inp, apply_step=True, debug=True, fused=None, dw_mode=None):
+def run_update(lib, dev, c, inp, apply_step=True, debug=True, fused=None, dw_mode=None, hidden=False):
     ctx = ops.QNetContext(c.D, c.R, c.A, c.arch, c.B, c.W, lib=lib, fused=fused)
     if dw_mode is not None:
         ctx.set_dw_mode(dw_mode)
@@ -56,6 +56,8 @@ def run_update(lib, dev, c, inp, apply_step=True, debug=True, fused=None, dw_mod
                               t["done"], t["sw"], gamma=c.gamma, lr=c.lr, adam_step=c.step,
                               max_grad_norm=c.max_grad_norm, homotopy_lambda=c.homotopy_lambda, envelope=c.envelope,
                               apply_step=apply_step, debug=debug)
+    if hidden:      # the ReLU decisions the device took (tests/flip_aware.py): post-ReLU activations of every hidden layer
+        res["hidden"] = [ctx.debug_hidden(l, c.B * c.W, t["po"]).cpu() for l in range(1, len(c.arch) + 1)]
     if dev.type == "cuda":
         th.cuda.synchronize()
     ctx.close()
@@ -76,8 +78,11 @@ def run_oracle(c, inp):
     return o, online, m, v
 
 
-def check_update(res, t, o, online, m, v, c, param_tol_frac=0.02, grad_tol=5e-5):
-    """The per-update parity contract (single update, identical parameters and batch)."""
+def check_update(res, t, o, online, m, v, c, param_tol_frac=0.02, grad_tol=5e-5, flip_aware=None):
+    """The per-update parity contract (single update, identical parameters and batch).  ``flip_aware`` = (inputs, tag): the
+    gradient / moment / parameter comparison is made against the oracle re-run under the device's own ReLU masks and targets
+    (tests/flip_aware.py: tight tolerance + a derived Adam bound, every mask difference checked to be a rounding flip) instead
+    of against the oracle's own decisions with ``grad_tol`` / ``param_tol_frac``."""
     assert abs(res["loss"].item() - o["loss"].item()) <= RTOL * abs(o["loss"].item())
     assert relmax(res["q_values"], o["q_values"]) <= RTOL
     if c.envelope:
@@ -94,8 +99,12 @@ def check_update(res, t, o, online, m, v, c, param_tol_frac=0.02, grad_tol=5e-5)
     assert relmax(res["target"], o["target"]) <= 1e-4 if c.envelope else relmax(res["target"], o["target"]) <= RTOL
     gn = o["grad_norm"].item()
     assert abs(res["grad_norm"].item() - gn) <= RTOL * gn
-    assert relmax(t["g"], flat(o["grads"])) <= grad_tol
     assert relmax(res["priority"], o["priority_raw"]) <= 1e-4
+    if flip_aware is not None:
+        import flip_aware as fa
+        inp, tag = flip_aware
+        return fa.check_step(c, inp, res, t, res["hidden"], tag)
+    assert relmax(t["g"], flat(o["grads"])) <= grad_tol
     assert relmax(t["m"], flat(m)) <= grad_tol
     assert relmax(t["v"], flat(v)) <= grad_tol
     # one Adam step moves a parameter by <= lr; the device must agree to a small fraction of that

@@ -101,6 +101,28 @@ def test_hypervolume_of_the_deep_sea_treasure_front_is_the_published_1155(be):
     assert pi.hypervolume(ref, pts + [np.array([7.0, -9.0]), np.array([1.0, -2.0])], lib=lib, device=dev) == 1155.0
 
 
+def test_hypervolume_pinned_to_pymoo(be):
+    """The pin against the reference's own hypervolume (pymoo's HV through ``performance_indicators.hypervolume``): values
+    committed by tests/golden/make_golden_hv.py wherever pymoo was importable, or computed live when it is importable here.
+    Skips -- loudly -- while neither exists (this image has no pymoo): the hypervolume then stays "unpinned against pymoo"."""
+    import make_golden_hv as mh
+    lib, dev = be
+    if os.path.exists(mh.OUT):
+        want = {k: float(v) for k, v in np.load(mh.OUT).items()}
+    elif mh.pymoo_available():
+        want = {k: float(v) for k, v in mh.compute().items()}
+    else:
+        pytest.skip("pymoo is not importable and tests/golden/hv.npz has not been written yet: hypervolume parity with pymoo "
+                    "stays UNPINNED (run tests/golden/make_golden_hv.py wherever pymoo exists)")
+    for k, (R, N, seed) in enumerate(mh.CASES):
+        ref, pts = mh.case_inputs(R, N, seed)
+        assert mo.hypervolume(ref, list(pts)) == pytest.approx(want[f"hv_{k}"], rel=1e-12)
+        assert pi.hypervolume(ref, list(pts), lib=lib, device=dev) == pytest.approx(want[f"hv_{k}"], rel=1e-12)
+    ref, pts = mh.dst_front()
+    assert want["hv_dst"] == pytest.approx(1155.0, rel=1e-14)
+    assert pi.hypervolume(ref, list(pts), lib=lib, device=dev) == pytest.approx(want["hv_dst"], rel=1e-12)
+
+
 def test_hypervolume_of_a_large_archive(be):
     """More points than the LDS-staged kernel holds (the reference's pymoo HV takes any N): 1 500 points of which most are
     dominated -- pruned on the device first -- and a 700-point non-dominated 2-D front that stays above the staged size."""
