@@ -487,6 +487,14 @@ int morl_ac_destroy(morl_ac_ctx* ctx);
 /* One gradient update of every learner (the body of the reference's update() loop), asynchronous on `stream`. */
 int morl_ac_update(morl_ac_ctx* ctx, const morl_ac_state* st, const morl_ac_batch* batch, const morl_ac_cfg* cfg,
                    const morl_ac_out* out, void* stream);
+/* The reference's `for _ in range(self.gradient_updates)` loop (capql.py:322, mosac_continuous_action.py:431,
+ * gpi_pd_continuous_action.py:375 -- GPI-PD runs 20 updates per environment step; the reference's own jitted precedent is
+ * multi_policy/gpi_ls_jax/gpi_ls_jax.py:342-477, a fori_loop over the gradient updates) in ONE call: update k consumes
+ * batches[k] / cfgs[k] (its Adam step index, dropout seed, do_policy / do_target flags) and writes outs[k] (outs may be NULL).
+ * The host draws the n batches (indices, noise) beforehand on the reference's RNG streams; the n x ~20 launches are enqueued by
+ * one library entry.  Stops at the first failing update (the message names it); updates before it have been enqueued. */
+int morl_ac_update_n(morl_ac_ctx* ctx, const morl_ac_state* st, int n, const morl_ac_batch* batches, const morl_ac_cfg* cfgs,
+                     const morl_ac_out* outs, void* stream);
 
 /* Policy forward for acting / evaluation.  obs [pop][rows][D]; w as in morl_ac_batch (NULL for MOSAC);
  * mode 0: deterministic action (CAPQL Policy.get_action, TD3 Policy.forward without noise; MOSAC: the tanh mean),
@@ -554,11 +562,27 @@ int64_t morl_gpi_param_count(const morl_gpi_desc* d);
 int64_t morl_gpi_mask_bytes(const morl_gpi_desc* d, int rows);
 int morl_gpi_create(morl_gpi_ctx** out, const morl_gpi_desc* d);
 int morl_gpi_destroy(morl_gpi_ctx* ctx);
+/* the per-update arguments of morl_gpi_update as a struct (morl_gpi_update_n) */
+typedef struct morl_gpi_batch {
+    const float* obs;                  /* [rows][D] */
+    const int32_t* actions;            /* [rows] */
+    const float* rewards;              /* [rows][R] */
+    const float* next_obs;             /* [rows][D] */
+    const float* dones;                /* [rows] */
+    const float* w;                    /* [rows][R] */
+    const float* sampled_w;            /* [K][R] (gpi_pd) */
+    const uint8_t* drop_masks;         /* optional explicit keep masks */
+    int32_t rows, K;
+} morl_gpi_batch;
 /* One gradient update (the loop body of GPIPD.update).  w: per-row weights [rows][R]; sampled_w [K][R] (gpi_pd). */
 int morl_gpi_update(morl_gpi_ctx* ctx, float* q, const float* q_target, float* exp_avg, float* exp_avg_sq,
                     const float* obs, const int32_t* actions, const float* rewards, const float* next_obs,
                     const float* dones, const float* w, int rows, const float* sampled_w, int K,
                     const uint8_t* drop_masks, const morl_gpi_cfg* cfg, const morl_gpi_out* out, void* stream);
+/* GPIPD.update's `for g in range(self.gradient_updates)` loop (gpi_pd.py:418-419, 20 by default) in one call: update k =
+ * morl_gpi_update on batches[k] / cfgs[k] -> outs[k] (outs may be NULL).  See morl_ac_update_n. */
+int morl_gpi_update_n(morl_gpi_ctx* ctx, float* q, const float* q_target, float* exp_avg, float* exp_avg_sq, int n,
+                      const morl_gpi_batch* batches, const morl_gpi_cfg* cfgs, const morl_gpi_out* outs, void* stream);
 /* Q(obs_row, w_row) of `n_nets` consecutive nets starting at `params`, eval mode (no dropout):
  * q_out [n_nets][rows][A*R].  w_per_row = 0: one weight vector for every row. */
 int morl_gpi_q_forward(morl_gpi_ctx* ctx, const float* params, int n_nets, const float* obs, const float* w,

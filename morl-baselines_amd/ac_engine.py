@@ -184,8 +184,8 @@ class ACEngine:
         return self._update(cfg, obs, count, first, actions, rewards, next_obs, dones, w, eps_next, eps_pi, eps_alpha,
                             drop_masks, want, grad_sync)
 
-    def _update(self, cfg, obs, pop, first, actions, rewards, next_obs, dones, w, eps_next, eps_pi, eps_alpha,
-                drop_masks, want, grad_sync=None):
+    def _pack(self, cfg, obs, pop, actions, rewards, next_obs, dones, w, eps_next, eps_pi, eps_alpha, drop_masks, want):
+        """The C structs of one ``morl_ac_update``: (ACBatch, ACOut, {name: output tensor}, tensors to keep alive)."""
         rows = obs.numel() // (pop * self.D)
         keep = [obs]
         b = ACBatch()
@@ -214,18 +214,22 @@ class ACEngine:
             b.drop_masks = drop_masks.data_ptr()
         self.lib.check_device(*keep)
         o, res = ACOut(), {}
-        iters = max(1, cfg.policy_iters) if self.algo == ALGO_MOSAC else 1
         shapes = dict(critic_loss=(pop,), q_losses=(pop, self.num_q), policy_loss=(pop,), alpha_loss=(pop,),
                       alpha=(pop,), priority=(pop, max(cfg.n_per, 1)),
                       target_q=(pop, rows) if self.algo in (ALGO_MOSAC, ALGO_SACD) else (pop, rows, self.R),
                       q_grads=(pop, self.num_q, self.Pq), pol_grads=(pop, self.Pp))
-        hook_error: List[BaseException] = []
-        if grad_sync is not None:
-            want = tuple(want) + tuple(n for n in ("q_grads",) + (("pol_grads",) if cfg.do_policy else ()) if n not in want)
         for name in want:
             res[name] = th.zeros(shapes[name], dtype=th.float32, device=self.q.device)
             setattr(o, name, res[name].data_ptr())
-        del iters
+        return b, o, res, keep
+
+    def _update(self, cfg, obs, pop, first, actions, rewards, next_obs, dones, w, eps_next, eps_pi, eps_alpha,
+                drop_masks, want, grad_sync=None):
+        hook_error: List[BaseException] = []
+        if grad_sync is not None:
+            want = tuple(want) + tuple(n for n in ("q_grads",) + (("pol_grads",) if cfg.do_policy else ()) if n not in want)
+        b, o, res, _keep = self._pack(cfg, obs, pop, actions, rewards, next_obs, dones, w, eps_next, eps_pi, eps_alpha,
+                                      drop_masks, want)
         hook = None
         if grad_sync is not None:
             def _hook(_user, which, _ptr, _count, _stream):
@@ -248,6 +252,28 @@ class ACEngine:
             raise hook_error[0]
         self.lib.check(rc)
         return res
+
+    def update_n(self, items: Sequence[dict], want: Sequence[str] = ("critic_loss", "policy_loss")) -> List[Dict]:
+        """``morl_ac_update_n``: the reference's ``for _ in range(self.gradient_updates)`` loop in ONE library entry.  ``items``:
+        for each of the n updates a dict with ``cfg`` (its own ``ACCfg``: Adam step indices, dropout seed, do_policy ...) and the
+        batch keywords of ``update`` (already drawn: the host consumes its RNG streams in the reference's order beforehand).
+        Every learner of the population takes part; no ``grad_sync``.  Returns the n output dicts."""
+        n = len(items)
+        bs, cs, os_ = (ACBatch * n)(), (ACCfg * n)(), (ACOut * n)()
+        results, keep = [], []
+        for k, it in enumerate(items):
+            it = dict(it)
+            cfg = it.pop("cfg")
+            obs = self._f32(it.pop("obs"), "obs")
+            b, o, res, kp = self._pack(cfg, obs, self.pop, it.get("actions"), it.get("rewards"), it.get("next_obs"), it.get("dones"),
+                                       it.get("w"), it.get("eps_next"), it.get("eps_pi"), it.get("eps_alpha"), it.get("drop_masks"),
+                                       it.get("want", want))
+            bs[k], cs[k], os_[k] = b, cfg, o
+            results.append(res)
+            keep.append(kp)
+        st = self._state(0)
+        self.lib.check(self.lib.lib.morl_ac_update_n(self._h, C.byref(st), n, bs, cs, os_, self.lib.stream_of(self.q)))
+        return results
 
     def policy_forward(self, obs, w=None, *, eps=None, use_target=False, cfg: Optional[ACCfg] = None,
                        want_logp=False):

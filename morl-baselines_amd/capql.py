@@ -216,7 +216,11 @@ class CAPQL(MOAgent, MOPolicy):
 
     # -- the hot path (capql.py:321-362) ----------------------------------------------------------------------------------
     def update(self):
+        """``capql.py:321-362``.  The batches and the noise of all ``gradient_updates`` iterations are drawn first (each RNG
+        stream -- Python's ``random`` for the batch, torch's generator for the two ``rsample()`` draws -- is consumed in the
+        reference's order), then the whole loop is ONE library entry (``morl_ac_update_n``)."""
         e = self.engine
+        items = []
         for _ in range(self.gradient_updates):
             s_obs, s_actions, w, s_rewards, s_next_obs, s_dones = self._sample_batch_experiences()
             B = s_obs.shape[0]
@@ -227,9 +231,14 @@ class CAPQL(MOAgent, MOPolicy):
             self._p_step += 1
             cfg = e.make_cfg(gamma=self.gamma, tau=self.tau, alpha=self.alpha, q_lr=self.learning_rate,
                              policy_lr=self.learning_rate, q_step=self._q_step, policy_step=self._p_step)
-            self._out = e.update(cfg, obs=s_obs, actions=s_actions, rewards=s_rewards, next_obs=s_next_obs,
-                                 dones=s_dones, w=w, eps_next=eps[0], eps_pi=eps[1])
+            items.append(dict(cfg=cfg, obs=s_obs, actions=s_actions, rewards=s_rewards, next_obs=s_next_obs, dones=s_dones, w=w,
+                              eps_next=eps[0], eps_pi=eps[1]))
             self._n_updates += 1
+        if len(items) == 1:
+            it = items[0]
+            self._out = e.update(it.pop("cfg"), **it)
+        else:
+            self._out = e.update_n(items)[-1]
         if self.log and self.global_step % 100 == 0:
             import wandb
             wandb.log({"losses/critic_loss": float(self._out["critic_loss"][0].item()),

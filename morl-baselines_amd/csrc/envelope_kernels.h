@@ -81,6 +81,8 @@ struct EnvelopeTdArgs {
     int fma_scal;           // 1: scalarise with an fma chain  fma(w_r, q_r, ...fma(w_1, q_1, w_0 * q_0))  -- what torch's unbatched
                             // einsum("r,bar->ba") of Envelope.max_action (envelope.py:389-402) evaluates to -- instead of
                             // separately rounded products and sums (the batched einsum of the TD target)
+    int argmax_mode;        // 0: lanes <-> TD rows, candidates as LDS broadcasts (default).  1: lanes <-> candidates, wave-level
+                            // butterfly arg-max carrying (value, index) -- the shuffle form north_star names; A/B in DESIGN.md 4
     int part_floats;        // 0: qo / qt are [B][W][A][R].  > 0: all-gathered layout, the slab of transition b is made of
     long long part_stride;  //    W*A*R / part_floats pieces of part_floats floats, piece g at  g * part_stride + b * part_floats
 };
@@ -145,8 +147,40 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
         float wi[MORL_MAX_OBJ];
 #pragma unroll
         for (int r = 0; r < MORL_MAX_OBJ; ++r) wi[r] = (live && r < R) ? s_w[i * R + r] : 0.f;
-        // candidate range of this wave: a quarter of (j, a) in index order (DDQN: of the A actions of slab j = i)
         const int n_c = p.diag_only ? A : W * A;
+        if (p.argmax_mode == 1) {
+            // ---- shuffle form: wave q owns the rows ib + q, ib + q + nw, ...; its lanes stride the (j, a) candidates of ONE
+            // row (LDS reads at a stride of R words: conflict-free for the odd R = 3, two-way for even R), keep their own first
+            // maximum, and a six-stage butterfly over (value, index) leaves the row's first maximum in every lane
+            if (wave > 0) s_pc[wave][lane] = 0x7fffffff;                    // the merge below only sees slice 0
+            const int i_end = min(ib + kWave, i_hi);
+            for (int ii = ib + wave; ii < i_end; ii += nw) {
+                float wr[MORL_MAX_OBJ];
+#pragma unroll
+                for (int r = 0; r < MORL_MAX_OBJ; ++r) wr[r] = (r < R) ? s_w[ii * R + r] : 0.f;      // wave-uniform: broadcast
+                const int co = p.diag_only ? (ii + p.i_offset) * A : 0;
+                float bv = -INFINITY;
+                int bc = 0x7fffffff;
+                for (int cc = lane; cc < n_c; cc += kWave) {
+                    const float* q = s_qo + (size_t)(co + cc) * R;
+                    float sc = __fmul_rn(wr[0], q[0]);
+#pragma unroll
+                    for (int r = 1; r < MORL_MAX_OBJ; ++r)
+                        if (r < R) sc = p.fma_scal ? fmaf(q[r], wr[r], sc) : __fadd_rn(sc, __fmul_rn(wr[r], q[r]));
+                    if (sc > bv || bc == 0x7fffffff) { bv = sc; bc = co + cc; }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float ov = __shfl_xor(bv, off);
+                    const int oc = __shfl_xor(bc, off);
+                    // strictly greater wins; equal values: the lower candidate index (th.max / th.argmax: first maximum)
+                    if (oc != 0x7fffffff && (bc == 0x7fffffff || ov > bv || (ov == bv && oc < bc))) { bv = ov; bc = oc; }
+                }
+                if (lane == 0) { s_pv[0][ii - ib] = bv; s_pc[0][ii - ib] = bc; }
+            }
+            __syncthreads();
+        } else {
+        // candidate range of this wave: a quarter of (j, a) in index order (DDQN: of the A actions of slab j = i)
         const int c_off = (p.diag_only && live) ? (i + p.i_offset) * A : 0;     // per-lane base in DDQN mode
         const int q_lo = (int)(((long long)n_c * wave) / nw), q_hi = (int)(((long long)n_c * (wave + 1)) / nw);
         float best = -INFINITY;
@@ -178,6 +212,7 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
         }
         if (live) { s_pv[wave][i - ib] = best; s_pc[wave][i - ib] = best_c; }
         __syncthreads();
+        }
         if (wave == 0 && live) {
             // merge the slices in candidate order: strictly greater replaces, so the first maximum wins
             float bv = s_pv[0][lane];

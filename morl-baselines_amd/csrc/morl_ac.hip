@@ -1754,3 +1754,37 @@ extern "C" int morl_ens_mse(morl_ens_ctx* c, const float* params, const float* l
     LAUNCH_CHECK("ens_mse");
     return MORL_OK;
 }
+
+
+// ---- the gradient_updates loop of the reference inside one library entry (include/morl_hip.h) ------------------------------
+extern "C" int morl_ac_update_n(morl_ac_ctx* c, const morl_ac_state* st, int n, const morl_ac_batch* batches,
+                                const morl_ac_cfg* cfgs, const morl_ac_out* outs, void* stream) {
+    if (!c || !st || !batches || !cfgs) return fail(MORL_ERR_ARG, "NULL argument");
+    if (n < 1) return fail(MORL_ERR_ARG, "n = %d updates", n);
+    for (int k = 0; k < n; ++k) {
+        const int rc = morl_ac_update(c, st, batches + k, cfgs + k, outs ? outs + k : nullptr, stream);
+        if (rc) {
+            char msg[400];
+            snprintf(msg, sizeof(msg), "%s", morl_last_error());
+            return fail(rc, "update %d of %d: %s", k, n, msg);
+        }
+    }
+    return MORL_OK;
+}
+
+extern "C" int morl_gpi_update_n(morl_gpi_ctx* c, float* q, const float* q_target, float* exp_avg, float* exp_avg_sq, int n,
+                                 const morl_gpi_batch* batches, const morl_gpi_cfg* cfgs, const morl_gpi_out* outs, void* stream) {
+    if (!c || !batches || !cfgs) return fail(MORL_ERR_ARG, "NULL argument");
+    if (n < 1) return fail(MORL_ERR_ARG, "n = %d updates", n);
+    for (int k = 0; k < n; ++k) {
+        const morl_gpi_batch& b = batches[k];
+        const int rc = morl_gpi_update(c, q, q_target, exp_avg, exp_avg_sq, b.obs, b.actions, b.rewards, b.next_obs, b.dones, b.w,
+                                       b.rows, b.sampled_w, b.K, b.drop_masks, cfgs + k, outs ? outs + k : nullptr, stream);
+        if (rc) {
+            char msg[400];
+            snprintf(msg, sizeof(msg), "%s", morl_last_error());
+            return fail(rc, "update %d of %d: %s", k, n, msg);
+        }
+    }
+    return MORL_OK;
+}

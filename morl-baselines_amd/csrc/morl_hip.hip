@@ -469,6 +469,14 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
     return MORL_OK;
 }
 
+// arg-max form of envelope_td_kernel: 0 = lanes <-> TD rows, candidates as LDS broadcasts (default); 1 = lanes <-> candidates, wave
+// butterfly over (value, index).  MORL_TD_SHFL=1 selects the shuffle form (A/B measurements); both give
+// bit-identical indices (tests/test_kernels_parity.py runs the tie tests under both).
+static int td_argmax_mode() {
+    static const int mode = [] { const char* e = getenv("MORL_TD_SHFL"); return e ? (atoi(e) != 0 ? 1 : 0) : 0; }();
+    return mode;
+}
+
 // ---- optional event brackets around the GEMM launches of a step (bench.py's roofline figures) --------------------------------
 // rotating mode (every == -1): ONE launch per step is bracketed, the k-th timed launch site of the step on step k (mod sites).
 static int timing_open(morl_ctx* c, int kind, hipStream_t s, int* slot) {
@@ -847,6 +855,7 @@ extern "C" int morl_envelope_reduce(const float* qo, const float* qt, const floa
     if ((long long)W * A * R > ENV_MAX_SLAB || W * R > ENV_MAX_WR)
         return fail(MORL_ERR_ARG, "W*A*R=%lld exceeds the LDS slab (%d floats)", (long long)W * A * R, ENV_MAX_SLAB);
     EnvelopeTdArgs p{};
+    p.argmax_mode = td_argmax_mode();
     p.qo = qo; p.qt = qt; p.weights = weights;
     p.target = target; p.pref = pref; p.ac = ac;
     p.B = B; p.W = W; p.A = A; p.R = R; p.diag_only = diag_only;
@@ -862,6 +871,7 @@ extern "C" int morl_envelope_reduce_rows(const float* qo, const float* qt, const
     if ((long long)W * A * R > ENV_MAX_SLAB || W * R > ENV_MAX_WR)
         return fail(MORL_ERR_ARG, "W*A*R=%lld exceeds the LDS slab (%d floats)", (long long)W * A * R, ENV_MAX_SLAB);
     EnvelopeTdArgs p{};
+    p.argmax_mode = td_argmax_mode();
     p.qo = qo; p.qt = qt; p.row_weights = row_weights;
     p.target = target; p.pref = pref; p.ac = ac;
     p.B = n_rows; p.W = W; p.A = A; p.R = R;
@@ -887,6 +897,7 @@ extern "C" int morl_envelope_greedy_actions(morl_ctx* c, const float* params, co
         if ((rc = net_forward(c, params, c->x0n, n, false, c->qo, A * R, s))) return rc;
     }
     EnvelopeTdArgs p{};
+    p.argmax_mode = td_argmax_mode();
     p.qo = c->qo; p.qt = c->qo; p.row_weights = w;
     p.target = nullptr; p.pref = nullptr; p.ac = actions_out;
     p.B = n; p.W = 1; p.A = A; p.R = R;
@@ -927,6 +938,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     const int td_groups = std::max(1, std::min(4, (WI + 63) / 64));
     {
         EnvelopeTdArgs p{};
+    p.argmax_mode = td_argmax_mode();
         p.qo = qo; p.qt = qt; p.weights = weights_i; p.q_main = c->qm;
         p.actions = actions; p.rewards = rewards; p.dones = dones;
         p.target = out->target; p.pref = out->pref; p.ac = out->ac;

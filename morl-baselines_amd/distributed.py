@@ -112,10 +112,19 @@ class NativeComm:
                 return contextlib.nullcontext()             # the emulated build runs launches synchronously
             return th.cuda.stream(th.cuda.ExternalStream(int(stream or 0), device=dev))
 
+        # gloo moves device tensors for all_reduce but not for all_gather: stage that one through the host (a test transport --
+        # several ranks sharing ONE GPU run the production rank step at world > 1 on hardware; RCCL refuses duplicate devices)
+        host_staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
+
         def allgather(_user, send, recv, count, stream):
             try:
                 with on(stream):
-                    dist.all_gather_into_tensor(view(recv, count * world), view(send, count), group=group)
+                    if host_staged:
+                        out = th.empty(count * world, dtype=th.float32)
+                        dist.all_gather_into_tensor(out, view(send, count).cpu(), group=group)
+                        view(recv, count * world).copy_(out)
+                    else:
+                        dist.all_gather_into_tensor(view(recv, count * world), view(send, count), group=group)
                 self.calls["allgather"] += 1
                 return 0
             except Exception as exc:                        # never let an exception cross the C frames

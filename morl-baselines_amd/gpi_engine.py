@@ -8,7 +8,7 @@ import numpy as np
 import torch as th
 
 from . import native
-from .native import GPICfg, GPIDesc, GPIOut, NativeLib
+from .native import GPIBatch, GPICfg, GPIDesc, GPIOut, NativeLib
 
 
 class GPIEngine:
@@ -76,9 +76,10 @@ class GPIEngine:
     def mask_bytes(self, rows: int) -> int:
         return int(self.lib.lib.morl_gpi_mask_bytes(C.byref(self.desc), rows))
 
-    def update(self, *, obs, actions, rewards, next_obs, dones, w, sampled_w=None, gamma=0.99, lr=3e-4, adam_step=1,
-               min_priority=0.01, max_grad_norm=None, gpi_pd=True, n_per=0, dropout_seed=0, apply_step=True,
-               drop_masks: Optional[th.Tensor] = None, want: Sequence[str] = ("critic_loss",)) -> Dict[str, th.Tensor]:
+    def _pack(self, *, obs, actions, rewards, next_obs, dones, w, sampled_w=None, gamma=0.99, lr=3e-4, adam_step=1,
+              min_priority=0.01, max_grad_norm=None, gpi_pd=True, n_per=0, dropout_seed=0, apply_step=True,
+              drop_masks: Optional[th.Tensor] = None, want: Sequence[str] = ("critic_loss",)):
+        """The C structs of one ``morl_gpi_update``: (GPIBatch, GPICfg, GPIOut, {name: output tensor}, tensors to keep alive)."""
         obs, rewards, next_obs, w = self._f32(obs), self._f32(rewards), self._f32(next_obs), self._f32(w)
         dones = self._f32(dones).reshape(-1)
         rows = obs.shape[0]
@@ -102,13 +103,34 @@ class GPIEngine:
         if drop_masks is not None and (drop_masks.dtype != th.uint8 or not drop_masks.is_contiguous()):
             raise ValueError("drop_masks must be contiguous uint8")
         self.lib.check_device(obs, actions, rewards, next_obs, dones, w, sampled_w, drop_masks)
+        b = GPIBatch()
+        b.obs, b.actions, b.rewards, b.next_obs, b.dones, b.w = (t.data_ptr() for t in (obs, actions, rewards, next_obs, dones, w))
+        b.sampled_w = None if sampled_w is None else sampled_w.data_ptr()
+        b.drop_masks = None if drop_masks is None else drop_masks.data_ptr()
+        b.rows, b.K = rows, K
+        return b, cfg, out, res, (obs, actions, rewards, next_obs, dones, w, sampled_w, drop_masks)
+
+    def update(self, **kw) -> Dict[str, th.Tensor]:
+        """One ``morl_gpi_update`` (the loop body of ``GPIPD.update``, gpi_pd.py:418-520); keyword arguments: see ``_pack``."""
+        b, cfg, out, res, _keep = self._pack(**kw)
         self.lib.check(self.lib.lib.morl_gpi_update(
             self._h, self.q.data_ptr(), self.q_target.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-            obs.data_ptr(), actions.data_ptr(), rewards.data_ptr(), next_obs.data_ptr(), dones.data_ptr(), w.data_ptr(),
-            rows, None if sampled_w is None else sampled_w.data_ptr(), K,
-            None if drop_masks is None else drop_masks.data_ptr(), C.byref(cfg), C.byref(out),
-            self.lib.stream_of(self.q)))
+            b.obs, b.actions, b.rewards, b.next_obs, b.dones, b.w, b.rows, b.sampled_w, b.K, b.drop_masks, C.byref(cfg),
+            C.byref(out), self.lib.stream_of(self.q)))
         return res
+
+    def update_n(self, items: Sequence[dict]):
+        """``morl_gpi_update_n``: the reference's ``for g in range(self.gradient_updates)`` loop in ONE library entry.  ``items``:
+        the keyword arguments of ``update`` for each of the n updates (batches already drawn); returns their output dicts."""
+        n = len(items)
+        packed = [self._pack(**kw) for kw in items]
+        bs, cs, os_ = (GPIBatch * n)(), (GPICfg * n)(), (GPIOut * n)()
+        for k, (b, cfg, out, _res, _keep) in enumerate(packed):
+            bs[k], cs[k], os_[k] = b, cfg, out
+        self.lib.check(self.lib.lib.morl_gpi_update_n(
+            self._h, self.q.data_ptr(), self.q_target.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), n, bs, cs,
+            os_, self.lib.stream_of(self.q)))
+        return [p[3] for p in packed]
 
     def q_forward(self, obs, w, *, nets: int = 1, target: bool = False) -> th.Tensor:
         """Q(obs_row, w) of the first ``nets`` ensemble members, eval mode: (nets, rows, A, R).  ``w``: (R,) or (rows, R)."""

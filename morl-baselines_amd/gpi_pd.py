@@ -206,7 +206,7 @@ class GPIPD(MOPolicy, MOAgent):
         e = self.engine
         dev = e.q.device
         weight = th.as_tensor(weight).to(dev, th.float32).reshape(-1)
-        critic_losses, priority, gpriority = [], None, None
+        critic_losses, priority, gpriority, deferred = [], None, None, []
         for g in range(self.gradient_updates if self.global_step >= self.dynamics_rollout_starts else 1):
             batch = self._sample_batch_experiences()
             s_obs, s_actions, s_rewards, s_next_obs, s_dones = batch[:5]
@@ -228,19 +228,29 @@ class GPIPD(MOPolicy, MOAgent):
             self._drop_seed += 1
             want = ("critic_loss",) + (("td_error",) if self.per else ()) + (("gtd_error",) if self.gpi_pd else ()) + \
                 (("grad_norm",) if self.max_grad_norm is not None else ())
-            out = e.update(obs=s_obs, actions=s_actions, rewards=s_rewards, next_obs=s_next_obs, dones=s_dones, w=w,
-                           sampled_w=sampled_w, gamma=self.gamma, lr=self.learning_rate, adam_step=self._adam_step,
-                           min_priority=self.min_priority, max_grad_norm=self.max_grad_norm, gpi_pd=self.gpi_pd,
-                           n_per=(n_per if (self.per or self.gpi_pd) else 0), dropout_seed=self._drop_seed, want=want)
+            kw = dict(obs=s_obs, actions=s_actions, rewards=s_rewards, next_obs=s_next_obs, dones=s_dones, w=w,
+                      sampled_w=sampled_w, gamma=self.gamma, lr=self.learning_rate, adam_step=self._adam_step,
+                      min_priority=self.min_priority, max_grad_norm=self.max_grad_norm, gpi_pd=self.gpi_pd,
+                      n_per=(n_per if (self.per or self.gpi_pd) else 0), dropout_seed=self._drop_seed, want=want)
+            if idxes is None:
+                # no prioritised replay: iteration g + 1 does not sample through what iteration g wrote, so the whole loop is
+                # drawn first and submitted as ONE library entry below (morl_gpi_update_n)
+                deferred.append(kw)
+                continue
+            out = e.update(**kw)
             self._out = out
             critic_losses.append(out["critic_loss"])
-            if self.per or self.gpi_pd:
-                if self.gpi_pd:
-                    gpriority = out["gtd_error"].clamp(min=self.min_priority).pow(self.alpha)
-                if self.per:
-                    priority = out["td_error"].clamp(min=self.min_priority).pow(self.alpha)
-                if idxes is not None:
-                    self.replay_buffer.update_priorities(idxes, gpriority if self.gpi_pd else priority)
+            if self.gpi_pd:
+                gpriority = out["gtd_error"].clamp(min=self.min_priority).pow(self.alpha)
+            if self.per:
+                priority = out["td_error"].clamp(min=self.min_priority).pow(self.alpha)
+            self.replay_buffer.update_priorities(idxes, gpriority if self.gpi_pd else priority)
+        if deferred:
+            outs = [e.update(**deferred[0])] if len(deferred) == 1 else e.update_n(deferred)
+            self._out = outs[-1]
+            critic_losses += [o["critic_loss"] for o in outs]
+            if self.gpi_pd:
+                gpriority = outs[-1]["gtd_error"].clamp(min=self.min_priority).pow(self.alpha)
         if self.tau != 1 or self.global_step % self.target_net_update_freq == 0:
             from . import ops
             ops.polyak(self.lib, e.q.view(-1), e.q_target.view(-1), self.tau)

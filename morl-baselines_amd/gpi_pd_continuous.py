@@ -234,7 +234,7 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
         e = self.engine
         dev = e.q.device
         weight = as_f32(weight, dev).reshape(-1)
-        priority = None
+        priority, deferred = None, []
         for _ in range(self.gradient_updates):
             batch = self._sample_batch_experiences()
             s_obs, s_actions, s_rewards, s_next_obs, s_dones = batch[:5]
@@ -259,13 +259,26 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
                              dropout_seed=self._drop_seed)
             noise = randn((rows, self.action_dim), dev)
             want = ("critic_loss",) + (("policy_loss",) if do_policy else ()) + (("priority",) if self.per else ())
-            out = e.update(cfg, obs=s_obs, actions=s_actions, rewards=s_rewards, next_obs=s_next_obs,
-                           dones=s_dones.reshape(-1), w=w, eps_next=noise, want=want)
-            self._out = {**(self._out or {}), **out}
-            if self.per:
-                priority = out["priority"][0].clamp(min=self.min_priority).pow(self.alpha)
-                self.replay_buffer.update_priorities(idxes, priority)
+            kw = dict(obs=s_obs, actions=s_actions, rewards=s_rewards, next_obs=s_next_obs, dones=s_dones.reshape(-1), w=w,
+                      eps_next=noise, want=want)
             self._n_updates += 1
+            if not self.per:
+                # no prioritised replay: nothing of iteration g feeds the sampling of iteration g + 1 -- the loop is drawn first
+                # and submitted as ONE library entry below (morl_ac_update_n)
+                deferred.append(dict(kw, cfg=cfg))
+                continue
+            out = e.update(cfg, **kw)
+            self._out = {**(self._out or {}), **out}
+            priority = out["priority"][0].clamp(min=self.min_priority).pow(self.alpha)
+            self.replay_buffer.update_priorities(idxes, priority)
+        if deferred:
+            if len(deferred) == 1:
+                kw = deferred[0]
+                outs = [e.update(kw.pop("cfg"), **kw)]
+            else:
+                outs = e.update_n(deferred)
+            for out in outs:
+                self._out = {**(self._out or {}), **out}
         if self.log and self.global_step % 100 == 0:
             import wandb
             if self.per:

@@ -97,6 +97,11 @@ class GPICfg(C.Structure):
                 ("dropout_seed", C.c_uint64)]
 
 
+class GPIBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "actions", "rewards", "next_obs", "dones", "w", "sampled_w", "drop_masks")] + \
+               [("rows", C.c_int32), ("K", C.c_int32)]
+
+
 GPI_OUT_FIELDS = ("critic_loss", "td_error", "gtd_error", "target_q", "target_q_envelope", "grads", "grad_norm")
 
 
@@ -207,6 +212,10 @@ _SIGNATURES = {
     "morl_ac_set_gemm_mode": (C.c_int, [C.c_int]),
     "morl_ac_update": (C.c_int, [C.c_void_p, C.POINTER(ACState), C.POINTER(ACBatch), C.POINTER(ACCfg),
                                  C.POINTER(ACOut), C.c_void_p]),
+    "morl_ac_update_n": (C.c_int, [C.c_void_p, C.POINTER(ACState), C.c_int, C.POINTER(ACBatch), C.POINTER(ACCfg),
+                                   C.POINTER(ACOut), C.c_void_p]),
+    "morl_gpi_update_n": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.POINTER(GPIBatch), C.POINTER(GPICfg), C.POINTER(GPIOut),
+                                                        C.c_void_p]),
     "morl_ac_policy_forward": (C.c_int, [C.c_void_p, C.POINTER(ACState), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                          C.c_void_p, C.c_int, C.POINTER(ACCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
     "morl_ac_q_forward": (C.c_int, [C.c_void_p, C.POINTER(ACState), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

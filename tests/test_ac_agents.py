@@ -122,6 +122,27 @@ def test_weight_sampler_angle_properties():
     assert (th.acos(cosang.clamp(-1, 1)) <= th.pi * 22.5 / 180 + 1e-4).all()
 
 
+def test_gradient_updates_loop_in_one_call_equals_sequential_updates(be):
+    """``CAPQL.update`` with ``gradient_updates = 3`` runs its loop as ONE library entry (``morl_ac_update_n``: batches and
+    noise drawn beforehand in the reference's RNG order); it must take exactly the steps of three single-update calls."""
+    lib, dev = be
+    runs = []
+    for gu, calls in ((3, 1), (1, 3)):
+        env = BoxEnv(low=-2.0, high=1.0)
+        th.manual_seed(0)
+        ag = CAPQL(env, net_arch=[32, 32], batch_size=16, buffer_size=256, learning_starts=10, log=False, seed=0,
+                   device=dev, lib=lib, alpha=0.1, gradient_updates=gu)
+        fill_capql(ag, env, 80)
+        random.seed(11)
+        th.manual_seed(11)
+        for _ in range(calls):
+            ag.update()
+        e = ag.engine
+        runs.append((e.q.clone().cpu(), e.pol.clone().cpu(), e.q_target.clone().cpu(), ag.last_losses(), ag._q_step))
+    a, b = runs
+    assert th.equal(a[0], b[0]) and th.equal(a[1], b[1]) and th.equal(a[2], b[2]) and a[3] == b[3] and a[4] == b[4] == 3
+
+
 def test_capql_update_matches_oracle_and_checkpoints(be, tmp_path):
     lib, dev = be
     env = BoxEnv(low=-2.0, high=1.0)

@@ -45,3 +45,26 @@ def test_large_tile_chain_passes_the_shape_sweep_on_the_gpu():
                         "no:cacheprovider"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_shuffle_argmax_form_passes_the_same_parity_tests():
+    """``envelope_td_kernel`` has two arg-max forms -- lanes <-> TD rows with the candidates read as LDS broadcasts (default) and
+    lanes <-> candidates with a wave butterfly over (value, index) (``MORL_TD_SHFL=1``, the form north_star names).  Indices are
+    bit-exact under both: the tie tests, the update-vs-oracle tests and the reduce entry points re-run under the shuffle form."""
+    env = dict(os.environ, MORL_TD_SHFL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_parity.py"), "-x", "-q", "-m", "not gpu",
+                        "-k", "ties_bit_exact or envelope_update_vs_reference_golden or envelope_reduce or max_slab", "-p",
+                        "no:cacheprovider"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_shuffle_argmax_form_on_the_gpu():
+    env = dict(os.environ, MORL_TD_SHFL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_parity.py"),
+                        os.path.join(ROOT, "tests", "test_flagship_golden.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "ties_bit_exact or envelope_update_vs_reference_golden or envelope_reduce or max_slab or argmax_indices", "-p",
+                        "no:cacheprovider"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -533,3 +533,76 @@ def test_data_parallel_capql_over_rccl_single_rank():
     for a, b in zip(ret["plain"][:3], ret["dp"][:3]):
         assert np.array_equal(a, b)
     assert ret["plain"][3] == ret["dp"][3]
+
+
+# ---- world > 1 ON THE MI355X through the production rank step: several ranks share the one GPU of the test box ----------------
+# RCCL refuses two ranks on one device ("duplicate GPU"), so the ranks' collectives go through the pluggable transport of
+# morl_comm (torch.distributed over gloo, device tensors): everything else -- morl_envelope_step_sharded / _batch_sharded, the
+# gfx950 kernels, the side-stream all-gather beside the training forward, the gathered-slab layout read in place, the PER update
+# behind the all-reduce -- is what a multi-GPU job runs.  Replicas must stay bit-identical and equal the unsharded step.
+def _shared_gpu_worker(rank, world, port, per, axis, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    import morl_baselines_amd.native as native
+    from morl_baselines_amd.distributed import shard_envelope_agent
+    dev = th.device("cuda", 0)
+    th.cuda.set_device(dev)
+    lib = native.load_library()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ag = _make_agent(lib, per, schedules=True, dev=dev, arch=(256, 256, 256), B=64, W=16)
+    shard_envelope_agent(ag, dist, axis=axis)
+    comm = ag._shard.comm
+    assert comm is not None and comm.transport == "torch" and comm.world == world
+    n = 4
+    for _ in range(n):
+        ag.update()
+        ag.global_step += 1
+    th.cuda.synchronize()
+    ret[rank] = (ag.q_net.flat.clone().cpu().numpy(), float(ag.last_loss()),
+                 ag.replay_buffer.tree_dev.clone().cpu().numpy() if per else None, dict(comm.calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("axis", ["weights", "batch"])
+@pytest.mark.parametrize("per,world", [(True, 2), (False, 4), (True, 4)])
+def test_one_call_rank_step_at_world_gt_1_on_one_shared_gpu(per, world, axis):
+    import morl_baselines_amd.native as native
+    lib = native.load_library()
+    dev = th.device("cuda:0")
+    n = 4
+    ref = _make_agent(lib, per, schedules=True, dev=dev, arch=(256, 256, 256), B=64, W=16)
+    for _ in range(n):
+        ref.update()
+        ref.global_step += 1
+    th.cuda.synchronize()
+    want, want_loss = ref.q_net.flat.clone().cpu().numpy(), ref.last_loss()
+    want_tree = ref.replay_buffer.tree_dev.clone().cpu().numpy() if per else None
+    del ref
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 38500 + (os.getpid() % 2000) + 5 * world + 3 * int(per) + 17 * int(axis == "batch")
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, per, axis, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(420)
+        if p.is_alive():
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank of the shared-GPU job did not finish")
+        assert p.exitcode == 0
+    p0, l0, t0, calls = ret[0]
+    assert calls == {"allgather": n if axis == "weights" else 0, "allreduce": n}
+    for r in range(1, world):
+        p1, l1, t1, _ = ret[r]
+        assert np.array_equal(p0, p1) and l0 == l1                        # replicas bit-identical
+        if per:
+            assert np.array_equal(t0, t1)
+    assert abs(l0 - want_loss) <= 1e-5 * abs(want_loss)                   # == the unsharded step up to fp32 summation order
+    assert np.abs(p0 - want).max() <= 0.02 * 3e-4 * n
+    if per:
+        np.testing.assert_allclose(t0[0], want_tree[0], rtol=1e-5)

@@ -141,3 +141,27 @@ def test_gpipd_dyna_iteration_runs(be):
     b = ag._sample_batch_experiences()
     assert b[0].shape[0] == 8 and b[5].numel() == 4                    # real_ratio 0.5: half real (with indices), half imagined
     assert np.isfinite(ag.engine.q.cpu().numpy()).all()
+
+
+def test_gradient_updates_loop_in_one_call_equals_sequential_updates(be):
+    """Without prioritised replay the ``for g in range(self.gradient_updates)`` loop of ``GPIPD.update`` is drawn first and
+    submitted as ONE library entry (``morl_gpi_update_n``); it must take exactly the steps of the sequential loop."""
+    lib, dev = be
+    D, A, R = 9, 4, 2
+    support = [np.array([1.0, 0.0], np.float32), np.array([0.0, 1.0], np.float32), np.array([0.3, 0.7], np.float32)]
+    runs = []
+    for gu, calls in ((3, 1), (1, 3)):
+        env = momdp.TreasureLine(0)
+        th.manual_seed(0)
+        ag = GPILS(env, net_arch=[32, 32, 32], batch_size=8, buffer_size=128, learning_starts=10, gradient_updates=gu,
+                   per=False, drop_rate=0.01, log=False, seed=0, device=dev, lib=lib)
+        fill(ag.replay_buffer, 50, D, A, R)
+        ag.set_weight_support(support)
+        ag.global_step = ag.dynamics_rollout_starts + 7          # past the single-update phase; not a target-sync step
+        np.random.seed(5); random.seed(5)
+        for _ in range(calls):
+            ag.update(th.tensor([0.5, 0.5]))
+        e = ag.engine
+        runs.append((e.q.clone().cpu(), e.exp_avg.clone().cpu(), ag.last_loss(), ag._adam_step))
+    a, b = runs
+    assert th.equal(a[0], b[0]) and th.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] == 3
