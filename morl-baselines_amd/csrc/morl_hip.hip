@@ -1405,8 +1405,10 @@ extern "C" int morl_envelope_step_sharded(morl_ctx* c, morl_comm* comm, float* p
     float* recv = (world == parts) ? slab_all : slab_all + (size_t)(i_offset / W_local) * 2 * half;
     if ((rc = morl_envelope_slabs(c, params_online, params_target, next_obs, w_loc, B, W_local, slab_local, stream))) return rc;
     if ((rc = morl_allgather_q_begin(comm, slab_local, recv, 2 * half, stream))) return rc;
+    static const bool no_overlap = [] { const char* e = getenv("MORL_COMM_NO_OVERLAP"); return e && atoi(e) != 0; }();   // (diagnostics)
+    if (no_overlap && (rc = morl_comm_wait(comm, stream))) return rc;
     if ((rc = morl_envelope_main_forward(c, params_online, obs, w_loc, B, W_local, stream))) return rc;   // beside the exchange
-    if ((rc = morl_comm_wait(comm, stream))) return rc;
+    if (!no_overlap && (rc = morl_comm_wait(comm, stream))) return rc;
     morl_update_cfg shard = *cfg;
     shard.apply_step = 0;
     shard.main_forward_done = 1;

@@ -112,8 +112,12 @@ class NativeComm:
                 return contextlib.nullcontext()             # the emulated build runs launches synchronously
             return th.cuda.stream(th.cuda.ExternalStream(int(stream or 0), device=dev))
 
-        # gloo moves device tensors for all_reduce but not for all_gather: stage that one through the host (a test transport --
-        # several ranks sharing ONE GPU run the production rank step at world > 1 on hardware; RCCL refuses duplicate devices)
+        # gloo with device tensors: both collectives are staged through the host here (D2H on the stream the library hands
+        # over, the collective on the host copy, H2D on the same stream).  A test transport -- several ranks sharing ONE GPU run
+        # the production rank step at world > 1 on hardware; RCCL refuses duplicate devices.  gloo's own device path for
+        # all_reduce (copies on its internal pool streams) was measured to race with the step's kernels when four processes share
+        # the device (tools/diag_shared_gpu.py: wrong losses at world 4, right ones with the host staging or with device-wide
+        # syncs around the call; profiles/r03_shared_gpu_transport_diag.txt), and it has no device all_gather at all
         host_staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
 
         def allgather(_user, send, recv, count, stream):
@@ -136,7 +140,12 @@ class NativeComm:
         def allreduce(_user, buf, count, stream):
             try:
                 with on(stream):
-                    dist.all_reduce(view(buf, count), op=dist.ReduceOp.SUM, group=group)
+                    if host_staged:
+                        h = view(buf, count).cpu()
+                        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                        view(buf, count).copy_(h)
+                    else:
+                        dist.all_reduce(view(buf, count), op=dist.ReduceOp.SUM, group=group)
                 self.calls["allreduce"] += 1
                 return 0
             except Exception as exc:

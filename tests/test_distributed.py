@@ -567,8 +567,7 @@ def _shared_gpu_worker(rank, world, port, per, axis, ret):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("axis", ["weights", "batch"])
-@pytest.mark.parametrize("per,world", [(True, 2), (False, 4), (True, 4)])
+@pytest.mark.parametrize("per,world,axis", [(True, 2, "weights"), (True, 4, "weights"), (False, 4, "batch")])
 def test_one_call_rank_step_at_world_gt_1_on_one_shared_gpu(per, world, axis):
     import morl_baselines_amd.native as native
     lib = native.load_library()
