@@ -81,6 +81,9 @@ struct EnvelopeTdArgs {
     int fma_scal;           // 1: scalarise with an fma chain  fma(w_r, q_r, ...fma(w_1, q_1, w_0 * q_0))  -- what torch's unbatched
                             // einsum("r,bar->ba") of Envelope.max_action (envelope.py:389-402) evaluates to -- instead of
                             // separately rounded products and sums (the batched einsum of the TD target)
+    int bmajor;             // internal row order of q_main / dq: 0 = row i * B + b (reference order, envelope.py:284-291),
+                            // 1 = row b * WI + i (what the layer-fused engines use: the rows of a transition are contiguous, so a
+                            // backward tile needs one or two slabs, chain_td.h).  target / pref / ac stay in reference order
     int argmax_mode;        // 0: lanes <-> TD rows, candidates as LDS broadcasts (default).  1: lanes <-> candidates, wave-level
                             // butterfly arg-max carrying (value, index) -- the shuffle form north_star names; A/B in DESIGN.md 4
     int part_floats;        // 0: qo / qt are [B][W][A][R].  > 0: all-gathered layout, the slab of transition b is made of
@@ -97,6 +100,35 @@ struct EnvelopeTdArgs {
 // th.argmax).  The kernel is latency-bound, not bandwidth-bound: what matters is that no lane waits on a dependent
 // shuffle or global load inside the candidate loop.
 constexpr int ENV_MAX_WAVES = 16;
+
+// candidates [q_lo, q_hi) of one TD row in index order (q0: the row's first candidate): scal = w . Q, products and sums rounded
+// separately in objective order (FMA: the fma chain of Envelope.max_action's unbatched einsum); first maximum wins
+template <int RT, bool FMA>
+__device__ __forceinline__ void env_scan(const float* q0, const float (&wi)[MORL_MAX_OBJ], int q_lo, int q_hi, int c_off,
+                                         float& best, int& best_c) {
+    int c = q_lo;
+    for (; c + 4 <= q_hi; c += 4) {                    // 4 candidates per step: their LDS reads overlap
+        float sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* q = q0 + (size_t)(c + u) * RT;   // envelope: wave-uniform address -> LDS broadcast
+            float s = __fmul_rn(wi[0], q[0]);
+#pragma unroll
+            for (int r = 1; r < RT; ++r) s = FMA ? fmaf(q[r], wi[r], s) : __fadd_rn(s, __fmul_rn(wi[r], q[r]));
+            sv[u] = s;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (sv[u] > best || best_c == 0x7fffffff) { best = sv[u]; best_c = c_off + c + u; }
+    }
+    for (; c < q_hi; ++c) {
+        const float* q = q0 + (size_t)c * RT;
+        float s = __fmul_rn(wi[0], q[0]);
+#pragma unroll
+        for (int r = 1; r < RT; ++r) s = FMA ? fmaf(q[r], wi[r], s) : __fadd_rn(s, __fmul_rn(wi[r], q[r]));
+        if (s > best || best_c == 0x7fffffff) { best = s; best_c = c_off + c; }
+    }
+}
 
 __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(EnvelopeTdArgs p) {
     __shared__ float s_qo[ENV_MAX_SLAB];
@@ -130,7 +162,10 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
     }
     for (int e = (int)threadIdx.x; e < nI * R; e += (int)blockDim.x) {
         s_w[e] = generic ? p.row_weights[(size_t)b * R + e] : p.weights[e];
-        if (train) s_qm[e] = p.q_main[((size_t)(e / R) * p.B + b) * p.ldq + act * R + (e % R)];
+        if (train) {
+            const size_t qrow = p.bmajor ? (size_t)b * nI + (e / R) : (size_t)(e / R) * p.B + b;
+            s_qm[e] = p.q_main[qrow * p.ldq + act * R + (e % R)];
+        }
     }
     __syncthreads();
 
@@ -185,30 +220,16 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
         const int q_lo = (int)(((long long)n_c * wave) / nw), q_hi = (int)(((long long)n_c * (wave + 1)) / nw);
         float best = -INFINITY;
         int best_c = 0x7fffffff;
-        // 4 candidates per step: their LDS reads are independent of the running maximum and overlap
-        int c = q_lo;
-        for (; c + 4 <= q_hi; c += 4) {
-            float sv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float* q = s_qo + (size_t)(c_off + c + u) * R;   // envelope: wave-uniform address -> LDS broadcast
-                float s = __fmul_rn(wi[0], q[0]);
-#pragma unroll
-                for (int r = 1; r < MORL_MAX_OBJ; ++r)
-                    if (r < R) s = p.fma_scal ? fmaf(q[r], wi[r], s) : __fadd_rn(s, __fmul_rn(wi[r], q[r]));
-                sv[u] = s;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (sv[u] > best || best_c == 0x7fffffff) { best = sv[u]; best_c = c_off + c + u; }
-        }
-        for (; c < q_hi; ++c) {
-            const float* q = s_qo + (size_t)(c_off + c) * R;
-            float s = __fmul_rn(wi[0], q[0]);
-#pragma unroll
-            for (int r = 1; r < MORL_MAX_OBJ; ++r)
-                if (r < R) s = p.fma_scal ? fmaf(q[r], wi[r], s) : __fadd_rn(s, __fmul_rn(wi[r], q[r]));
-            if (s > best || best_c == 0x7fffffff) { best = s; best_c = c_off + c; }
+        // one straight-line instantiation per objective count and scalarisation form (a run-time R made the inner loop an
+        // eight-way predicated one: most of this kernel's time)
+        const float* qb = s_qo + (size_t)c_off * R;
+        switch (p.fma_scal ? R + MORL_MAX_OBJ : R) {
+#define MORL_TD_CASE(r) case r: env_scan<r, false>(qb, wi, q_lo, q_hi, c_off, best, best_c); break; \
+                        case r + MORL_MAX_OBJ: env_scan<r, true>(qb, wi, q_lo, q_hi, c_off, best, best_c); break;
+            MORL_TD_CASE(1) MORL_TD_CASE(2) MORL_TD_CASE(3) MORL_TD_CASE(4)
+            MORL_TD_CASE(5) MORL_TD_CASE(6) MORL_TD_CASE(7) MORL_TD_CASE(8)
+#undef MORL_TD_CASE
+            default: break;
         }
         if (live) { s_pv[wave][i - ib] = best; s_pc[wave][i - ib] = best_c; }
         __syncthreads();
@@ -287,7 +308,8 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
         for (int e = (int)threadIdx.x; e < nMine * p.ldq; e += (int)blockDim.x) {
             const int i = i_lo + e / p.ldq, c = e % p.ldq;
             const int r = c - act * R;
-            p.dq[((size_t)i * nB + b) * p.ldq + c] = (r >= 0 && r < R) ? s_g[i * R + r] : 0.f;
+            const size_t drow = p.bmajor ? (size_t)b * nI + i : (size_t)i * nB + b;
+            p.dq[drow * p.ldq + c] = (r >= 0 && r < R) ? s_g[i * R + r] : 0.f;
         }
     }
     if (p.priority_clear && ig == 0 && threadIdx.x == 0) p.priority_clear[b] = 0.f;

@@ -44,7 +44,8 @@ struct ChainArgs {
     int n_steps;
     int rows;
     // input assembly
-    int in_mode;            // 0: cat(obs[b], weights[k]) with row -> (b, k) by row_order ; 1: dense matrix src[rows][ldsrc]
+    int in_mode;            // 0: cat(obs[b], weights[k]) with row -> (b, k) by row_order ; 1: dense matrix src[rows][ldsrc] ;
+                            // 2 (mlp_chain2 only): the rows are dLoss/dQ of a gradient step, computed by the tile itself (chain_td.h)
     const float* obs;       // [B][D]
     const float* weights;   // [W][R]  (row_order 2: [rows][R], paired with obs rows)
     int B, W, D, R, row_order;

@@ -22,6 +22,7 @@
 //     staggers the two workgroups of a CU: one is in its MFMA loop while the other is in an epilogue.
 #pragma once
 #include "mlp_chain.h"
+#include "chain_td.h"
 
 namespace morl {
 
@@ -276,7 +277,7 @@ __device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& 
 
 template <int TM, int SCHED, int LD, bool PROF = false>
 __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, float* sAct, long long* prof_out = nullptr,
-                                                int g = 0) {
+                                                int g = 0, const ChainTd* td = nullptr, ChainTdScratch* td_scratch = nullptr) {
     long long ticks[24];
     int n_tick = 0;
     C2_TICK()
@@ -295,7 +296,12 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
     else c2_load_narrow_k(bx, p.step[0], wave, i, h, g);
 
     // ---- input tile -> sAct[m][k], zero-padded to the columns the first step multiplies -------------------------------
-    {
+    if (p.in_mode == 2) {
+        // backward chain of a gradient step: the tile's dLoss/dQ rows are computed here (envelope arg-max, TD target, loss
+        // gradient: chain_td.h) instead of being read from a separate launch's output
+        const int K0pad = first_wide ? min(CH_MAXW, (p.K0 + 63) & ~63) : CH_MAXW;
+        chain_td_stage<TM>(*td, row0, p.rows, sAct, C2_LDK, K0pad, td_scratch);
+    } else {
         const int K0 = (p.in_mode == 0) ? (p.D + p.R) : p.K0;
         const int K0pad = first_wide ? min(CH_MAXW, (K0 + 63) & ~63) : CH_MAXW;
         const int m = tid & (TM - 1);
@@ -530,6 +536,7 @@ struct Chain2Multi {
                                         // (nb networks of a population): the two or four tiles of one network then share an
                                         // L2 and its weights are fetched from HBM once instead of once per tile
     long long* prof;                    // probes only: [gridDim.x][2][24] phase stamps
+    ChainTd td;                         // the chain with in_mode == 2 (a step's backward chain with the TD stage fused in)
 };
 constexpr int C2_CU_SLOTS = 8192;
 
@@ -547,7 +554,7 @@ __device__ __forceinline__ unsigned c2_cu_key() {
 }
 
 template <int SCHED, bool PROF, bool NMAJOR = false>
-__device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, float* sAct) {
+__device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, float* sAct, ChainTdScratch* td_scratch = nullptr) {
     const int S = (int)gridDim.x;
     // (workgroup x runs on XCD x % 8)
     const int b = (m.xcd_contig && (S & 7) == 0) ? ((int)blockIdx.x & 7) * (S >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
@@ -585,21 +592,21 @@ __device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, floa
         long long* pout = (PROF && m.prof != nullptr) ? m.prof + ((size_t)b * 2 + (j > 0 ? 1 : 0)) * 24 : nullptr;
         if (NMAJOR) {        // (every chain of the launch streams its wide steps N-major: ChainArgs::fast == 2)
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 2, PROF>(m.p[q], row0, sAct, pout, g);
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 2, PROF>(m.p[q], row0, sAct, pout, g, &m.td, td_scratch);
             } else {
-                mlp_chain2_body<64, SCHED, 2, PROF>(m.p[q], row0, sAct, pout, g);
+                mlp_chain2_body<64, SCHED, 2, PROF>(m.p[q], row0, sAct, pout, g, &m.td, td_scratch);
             }
         } else if (m.p[q].fast) {
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 1, PROF>(m.p[q], row0, sAct, pout, g);
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 1, PROF>(m.p[q], row0, sAct, pout, g, &m.td, td_scratch);
             } else {
-                mlp_chain2_body<64, SCHED, 1, PROF>(m.p[q], row0, sAct, pout, g);
+                mlp_chain2_body<64, SCHED, 1, PROF>(m.p[q], row0, sAct, pout, g, &m.td, td_scratch);
             }
         } else {
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 0, PROF>(m.p[q], row0, sAct, pout, g);
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 0, PROF>(m.p[q], row0, sAct, pout, g, &m.td, td_scratch);
             } else {
-                mlp_chain2_body<64, SCHED, 0, PROF>(m.p[q], row0, sAct, pout, g);
+                mlp_chain2_body<64, SCHED, 0, PROF>(m.p[q], row0, sAct, pout, g, &m.td, td_scratch);
             }
         }
         __syncthreads();     // the tile buffer is free for the next job
@@ -610,7 +617,8 @@ template <int SCHED>
 __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain2_kernel(Chain2Multi m) {
     // (+8: the last group's look-ahead operand read of the last row runs 4 floats past the tile; the values are unused)
     __shared__ __attribute__((aligned(16))) float sAct[C2_TM * C2_LDK + 8];
-    mlp_chain2_persistent<SCHED, false>(m, sAct);
+    __shared__ ChainTdScratch td_scratch;          // 5.6 KB: with the tile buffer two workgroups still share a CU's 160 KB
+    mlp_chain2_persistent<SCHED, false>(m, sAct, &td_scratch);
 }
 
 // the same schedule with the N-major weight stream (forward passes that read the nn.Linear matrices as they are: morl_ac.hip)

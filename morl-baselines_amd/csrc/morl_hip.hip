@@ -105,6 +105,20 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict_
     }
 }
 
+// dst[i * B + b][0 .. cols) = src[b * W + i][0 .. cols): rows kept transition-major by the layer-fused engines, handed out in the
+// reference's TD-row order (envelope.py:284-291) -- parity / debug outputs only
+__global__ __launch_bounds__(256) void copy_rows_bmajor_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst,
+                                                               int ldd, int B, int W, int cols) {
+    const long long total = (long long)B * W * cols;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / cols;                 // destination row i * B + b
+        const int c = (int)(e % cols);
+        const int i = (int)(r / B), b = (int)(r % B);
+        dst[r * ldd + c] = src[((long long)b * W + i) * lds + c];
+    }
+}
+
 // The step's prologue in ONE launch: batch selection + gather + weight upload (workgroups [0, sg_blocks)) beside the K-major
 // shadow weights of both networks (the remaining workgroups) -- two independent pieces of work that round 1 and the first
 // half of round 2 ran as two launches (and, before that, as five).
@@ -175,6 +189,7 @@ struct morl_ctx {
     int timing_idx = 0, timing_prev_launches = 0, timing_rotate = -1;   // every == -1: one launch per step, taking turns
     std::vector<hipEvent_t> ev_start, ev_stop;
     std::vector<int> ev_kind;            // MORL_TIMED_* of each recorded launch
+    int last_B = 0, last_WI = 0;         // shape of the last training forward (morl_ctx_debug_hidden)
     int main_rows = -1;                  // rows of a hoisted training forward (morl_envelope_main_forward), -1 = none
     // shadow copies made by morl_envelope_prepare for exactly these parameter buffers; consumed (one-shot) by the step's first
     // library entry, dropped by every optimiser step of the library
@@ -183,6 +198,8 @@ struct morl_ctx {
     const float* wt_online_src = nullptr;   // parameters wt_online was transposed from by this step's morl_envelope_slabs
                                          // (cleared by every optimiser step of the library)
     size_t ev_used = 0;
+    bool td_fused = false;   // MORL_TD_FUSED=1: large steps run the TD stage inside the backward chain's launch (chain_td.h) --
+                             // measured break-even against envelope_td_kernel in front of it, so off by default
     int chain_stagger = 3;   // mlp_chain2: job-order staggering of co-resident workgroups (Chain2Multi::stagger)
     unsigned int* cu_tickets = nullptr;
     int chain_sched = 1;     // mlp_chain2: instruction interleave pinned with sched_group_barrier (0: hipcc's own schedule)
@@ -290,7 +307,7 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     c->g[c->L - 1] = c->dq;
     ALLOC(slabs, (size_t)c->max_splits * c->P);
     ALLOC(sumsq_part, OPT_MAX_BLOCKS);
-    ALLOC(loss_part, (size_t)max_batch * 2 * 4);
+    ALLOC(loss_part, std::max((size_t)max_batch * 2 * 4, ((size_t)rows / 16 + 8) * 2));   // per (transition, group) or per 16 rows
     c->fused_ok = true;
     c->wt_count = 0;
     for (int l = 0; l < c->L; ++l) {
@@ -324,6 +341,7 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         if (l >= 1 && net->dims[l] <= 32 && (net->dims[l + 1] & 3)) c->fused_ok = false;   // backward narrow step: K = dims[l+1]
     }
     if (const char* e = getenv("MORL_CHAIN_SCHED")) c->chain_sched = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("MORL_TD_FUSED")) c->td_fused = atoi(e) != 0;      // (A/B runs)
     if (const char* e = getenv("MORL_CHAIN_STAGGER")) c->chain_stagger = std::max(0, std::min(3, atoi(e)));
     {
         int dev = 0;
@@ -510,8 +528,9 @@ static int timing_close(morl_ctx* c, int slot, hipStream_t s) {
 }
 
 // ---- second-generation chain (mlp_chain2.h): one persistent launch of 2 workgroups per CU over all units --------------
-static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s) {
+static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s, const ChainTd* td = nullptr) {
     Chain2Multi m{};
+    if (td) m.td = *td;
     m.n = n;
     int units = 0;
     for (int q = 0; q < n; ++q) {
@@ -532,7 +551,8 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
     m.stagger = c->chain_stagger;
     m.cu_tickets = c->cu_tickets;
     // (backward chain: the one whose input is the TD kernel's dLoss/dQ)
-    const int kind = (chains[0].in_mode == 1 && chains[0].src == c->dq) ? MORL_TIMED_BACKWARD : MORL_TIMED_FORWARD;
+    const int kind = (chains[0].in_mode == 2 || (chains[0].in_mode == 1 && chains[0].src == c->dq)) ? MORL_TIMED_BACKWARD
+                                                                                                       : MORL_TIMED_FORWARD;
     int slot = -1, rc_t;
     if ((rc_t = timing_open(c, kind, s, &slot))) return rc_t;
     static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
@@ -547,7 +567,7 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
     return timing_close(c, slot, s);
 }
 
-static int launch_chain(morl_ctx* c, const ChainArgs& a, hipStream_t s) { return chain2_launch(c, &a, 1, s); }
+static int launch_chain(morl_ctx* c, const ChainArgs& a, hipStream_t s, const ChainTd* td = nullptr) { return chain2_launch(c, &a, 1, s, td); }
 
 // forward chain over rows assembled on the fly from (obs, weights); save => hidden activations to ctx->h[]
 static ChainArgs make_forward_chain(morl_ctx* c, const float* params, const float* wt, const float* obs,
@@ -598,14 +618,15 @@ static int chain_forward_x3(morl_ctx* c, const ChainArgs& a0, const ChainArgs& a
 static int chain_forward_multi(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s) { return chain2_launch(c, chains, n, s); }
 
 // backward chain: g[L-1] = dq  ->  g[l-1] = (g[l] @ W_l) * (h[l] > 0), every g[l-1] written to ctx->g[]
-static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_t s) {
+// `td`: the TD stage runs inside this launch (in_mode 2, chain_td.h) instead of envelope_td_kernel in front of it
+static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_t s, const ChainTd* td = nullptr) {
     const int L = c->L;
     if (L < 2) return MORL_OK;
     int rc_chain;
     ChainArgs a{};
     a.n_steps = L - 1;
     a.rows = rows;
-    a.in_mode = 1;
+    a.in_mode = td ? 2 : 1;
     a.fast = c->k4 ? 1 : 0;
     a.src = c->dq; a.ldsrc = c->ldq; a.K0 = c->net.dims[L];
     for (int l = L - 1, k = 0; l >= 1; --l, ++k) {
@@ -623,8 +644,16 @@ static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_
         st.out = c->g[l - 1];
         st.ldout = c->net.dims[l];
     }
-    if ((rc_chain = launch_chain(c, a, s))) return rc_chain;
+    if ((rc_chain = launch_chain(c, a, s, td))) return rc_chain;
     return MORL_OK;
+}
+
+// does a chain launch over `rows` rows take the 16-row tiles (mlp_chain16.h)?  -- the decision chain2_launch makes
+static bool chain_rows_take_16(long long rows) {
+    static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
+    ChainArgs probe{};
+    probe.rows = (int)std::min<long long>(rows, 0x7fffffff);
+    return small_rows && chain16_wanted(&probe, 1);
 }
 
 extern "C" int morl_ctx_set_fused(morl_ctx* c, int enable) {
@@ -799,6 +828,16 @@ extern "C" int morl_ctx_debug_hidden(morl_ctx* c, int layer, int rows, float* ou
     if (!c || !out) return fail(MORL_ERR_ARG, "NULL argument");
     if (layer < 1 || layer >= c->L) return fail(MORL_ERR_ARG, "layer %d outside [1, %d)", layer, c->L);
     if (rows < 1 || rows > c->max_rows) return fail(MORL_ERR_ARG, "rows %d outside [1, %d]", rows, c->max_rows);
+    if (c->use_fused) {
+        // the layer-fused engines keep the rows transition-major (row b * W + i): hand them out in the reference's order
+        if (c->last_B < 1 || c->last_WI < 1 || (long long)c->last_B * c->last_WI != rows)
+            return fail(MORL_ERR_STATE, "rows %d != the %d x %d rows of the last training forward", rows, c->last_B, c->last_WI);
+        const int cols = c->net.dims[layer];
+        hipLaunchKernelGGL(copy_rows_bmajor_kernel, dim3(stream_grid((long long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)c->h[layer], cols, out, cols, c->last_B, c->last_WI, cols);
+        LAUNCH_CHECK("copy_rows_bmajor");
+        return MORL_OK;
+    }
     HIP_TRY(hipMemcpyAsync(out, c->h[layer], (size_t)rows * c->net.dims[layer] * sizeof(float), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
     return MORL_OK;
@@ -924,18 +963,50 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     // the dW GEMM reads the training pass's layer-0 input from HBM (the W-tiled batch of envelope.py:284-291 is never
     // materialised wider than this [rows][D+R] block)
     // (the fused three-pass launch has already written it from its own input assembly)
-    if (!main_fwd_done && (rc = build_input(obs, weights_i, c->x0m, B, WI, D, R, c->ld0, 1, s))) return rc;
+    // internal TD-row order: the layer-fused engines keep the rows of a transition together (row b * WI + i), the per-layer
+    // engine the reference's i * B + b; everything between the training forward and the weight gradients only needs the SAME
+    // order everywhere (a sum over rows), the parity outputs are handed out in reference order
+    const int bmajor = c->use_fused ? 1 : 0;
+    const int main_ro = bmajor ? 0 : 1;
+    c->last_B = B; c->last_WI = WI;
+    if (!main_fwd_done && (rc = build_input(obs, weights_i, c->x0m, B, WI, D, R, c->ld0, main_ro, s))) return rc;
     if (!main_fwd_done) {
         c->bits_valid = false;
         if (c->use_fused) {
-            if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights_i, B, WI, 1, rows, true, c->qm, c->ldq, s))) return rc;
+            if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights_i, B, WI, main_ro, rows, true, c->qm, c->ldq, s))) return rc;
             c->bits_valid = true;   // (the layer-fused forward always emits the sign bits)
         } else {
             if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
         }
     }
-    // envelope arg-max + TD target + dLoss/dQ: one lane per TD row of a transition, 64 rows per workgroup pass
-    const int td_groups = std::max(1, std::min(4, (WI + 63) / 64));
+    // envelope arg-max + TD target + dLoss/dQ.  Large steps on the layer-fused engine run it INSIDE the backward chain's launch
+    // (chain_td.h: every tile computes the dLoss/dQ rows it is about to propagate); otherwise envelope_td_kernel runs in front
+    // of the backward pass: one lane per TD row of a transition, 64 rows per workgroup pass
+    const float lam_td = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
+    const bool td_in_chain = c->use_fused && c->td_fused && L >= 2 && !chain_rows_take_16(rows) &&
+                             ctd_slab_ok((long long)W * A * R, WI, C2_TM * C2_LDK);
+    int td_groups = std::max(1, std::min(4, (WI + 63) / 64));
+    int n_loss = B * td_groups;
+    ChainTd ctd{};
+    if (td_in_chain) {
+        ctd.qo = qo; ctd.qt = qt; ctd.weights = weights_i; ctd.q_main = c->qm;
+        ctd.actions = actions; ctd.rewards = rewards; ctd.dones = dones;
+        ctd.dq = c->dq; ctd.loss_part = c->loss_part;
+        ctd.priority = (i_offset == 0) ? out->priority : nullptr;
+        ctd.priority_clear = (i_offset != 0) ? out->priority : nullptr;
+        ctd.target = out->target; ctd.pref = out->pref; ctd.ac = out->ac;
+        ctd.B = B; ctd.W = W; ctd.A = A; ctd.R = R; ctd.ldq = c->ldq;
+        ctd.WI = WI; ctd.i_offset = i_offset;
+        ctd.diag_only = cfg->envelope ? 0 : 1;
+        ctd.gamma = cfg->gamma;
+        ctd.c_mse = (float)((1.0 - (double)lam_td) * 2.0 / ((double)rows_total * R));
+        ctd.c_aux = (float)((double)lam_td * 2.0 / (double)rows_total);
+        if (cfg->slab_parts > 1) {
+            ctd.part_floats = (W / cfg->slab_parts) * A * R;
+            ctd.part_stride = 2ll * B * ctd.part_floats;
+        }
+        n_loss = (rows + 15) / 16;
+    } else
     {
         EnvelopeTdArgs p{};
     p.argmax_mode = td_argmax_mode();
@@ -946,6 +1017,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         p.priority_clear = (i_offset != 0) ? out->priority : nullptr;
         p.B = B; p.W = W; p.A = A; p.R = R; p.ldq = c->ldq;
         p.WI = WI; p.i_offset = i_offset;
+        p.bmajor = bmajor;
         p.diag_only = cfg->envelope ? 0 : 1;
         p.gamma = cfg->gamma;
         const float lam = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
@@ -966,7 +1038,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     }
     // backward through the hidden layers: g[l-1] = (g[l] @ W_l) * (h[l] > 0)
     if (c->use_fused) {
-        if ((rc = chain_backward(c, params_online, rows, s))) return rc;
+        if ((rc = chain_backward(c, params_online, rows, s, td_in_chain ? &ctd : nullptr))) return rc;
     } else
         for (int l = L - 1; l >= 1; --l) {
             GemmProblem g{};
@@ -1128,11 +1200,11 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         if (ranges.n > 0)
             hipLaunchKernelGGL(grad_reduce_ranges_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)c->slabs, ranges,
                                (long long)c->P, grads, (long long)c->P, c->sumsq_part, (const double*)c->loss_part,
-                               B * td_groups, 1.0 / ((double)rows_total * R), 1.0 / (double)rows_total, lam, out->loss);
+                               n_loss, 1.0 / ((double)rows_total * R), 1.0 / (double)rows_total, lam, out->loss);
         else
             hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)c->slabs, splits,
                                (long long)c->P, grads, (long long)c->P, c->sumsq_part, (const double*)c->loss_part,
-                               B * td_groups, 1.0 / ((double)rows_total * R), 1.0 / (double)rows_total, lam, out->loss);
+                               n_loss, 1.0 / ((double)rows_total * R), 1.0 / (double)rows_total, lam, out->loss);
         LAUNCH_CHECK("grad_reduce");
     }
     if (cfg->per_tree && i_offset == 0 && out->priority && !per_done) {
@@ -1145,8 +1217,12 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     }
     if (out->q_values) {
         const int AR = A * R;
-        hipLaunchKernelGGL(copy_rows_kernel, dim3(stream_grid((long long)rows * AR, 256)), dim3(256), 0, s,
-                           (const float*)c->qm, c->ldq, out->q_values, AR, (long long)rows, AR);
+        if (bmajor)
+            hipLaunchKernelGGL(copy_rows_bmajor_kernel, dim3(stream_grid((long long)rows * AR, 256)), dim3(256), 0, s,
+                               (const float*)c->qm, c->ldq, out->q_values, AR, B, WI, AR);
+        else
+            hipLaunchKernelGGL(copy_rows_kernel, dim3(stream_grid((long long)rows * AR, 256)), dim3(256), 0, s,
+                               (const float*)c->qm, c->ldq, out->q_values, AR, (long long)rows, AR);
         LAUNCH_CHECK("copy_rows");
     }
     if (splits_out) *splits_out = splits;
@@ -1240,7 +1316,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         if ((rc = refresh_transposed(c, params_online, c->wt_online, s, params_target, c->wt_target, true))) return rc;
         if (c->fused_tm == 0) {
             // one launch for the three forward passes: 3 x rows/64 workgroups -> 2 resident per CU
-            ChainArgs main_chain = make_forward_chain(c, params_online, c->wt_online, obs, weights, B, W, 1, rows, true, c->qm,
+            ChainArgs main_chain = make_forward_chain(c, params_online, c->wt_online, obs, weights, B, W, 0, rows, true, c->qm,
                                                       c->ldq, true);
             main_chain.x0_out = c->x0m;      // layer-0 input of the dW GEMM, written by the pass that assembles it anyway
             main_chain.ldx0 = c->ld0;
@@ -1357,7 +1433,7 @@ extern "C" int morl_envelope_main_forward(morl_ctx* c, const float* params_onlin
         // the K-major copy made by this step's morl_envelope_slabs is still current unless an optimiser step intervened
         if (c->wt_online_src != params_online && (rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
         c->wt_online_src = nullptr;      // one-shot: only the call that directly follows the slabs call of a step reuses it
-        ChainArgs one = make_forward_chain(c, params_online, c->wt_online, obs, weights_local, B, W_local, 1, rows, true, c->qm,
+        ChainArgs one = make_forward_chain(c, params_online, c->wt_online, obs, weights_local, B, W_local, 0, rows, true, c->qm,
                                            c->ldq, true);
         one.x0_out = c->x0m;
         one.ldx0 = c->ld0;
