@@ -273,6 +273,17 @@ int morl_comm_unique_id(void* id_out);
 int morl_comm_init(morl_comm** out, const void* unique_id, int rank, int world);
 int morl_comm_init_custom(morl_comm** out, int rank, int world, morl_allgather_fn allgather, morl_allreduce_fn allreduce,
                           void* user);
+/* Single-hop transport over peer-mapped memory (hipIpc): the step's messages are latency-bound, so instead of a
+ * ring every rank writes its contribution straight into the memory of the rank that needs it, all links at once -- all-gather =
+ * push + collect, all-reduce = push (reduce-scatter) + reduce in rank order + pull (csrc/morl_comm.hip).  Two-phase set-up, at most
+ * 8 ranks: _create allocates this rank's shared region (sized for all-reduces of max_allreduce_floats and all-gathers of
+ * max_allgather_floats per rank) and returns its 64-byte handle; the caller all-gathers the world's handles through any side
+ * channel; _connect maps the peers.  Waits are bounded (3 s): morl_comm_check reports a peer that never arrived. */
+#define MORL_COMM_IPC_HANDLE_BYTES 64
+int morl_comm_ipc_create(morl_comm** out, int rank, int world, int64_t max_allreduce_floats, int64_t max_allgather_floats,
+                         void* handle_out);
+int morl_comm_ipc_connect(morl_comm* comm, const void* all_handles);
+int morl_comm_check(morl_comm* comm);
 int morl_comm_destroy(morl_comm* comm);
 int morl_comm_size(const morl_comm* comm, int* rank, int* world);
 int morl_allgather_q_begin(morl_comm* comm, const float* send, float* recv, int64_t count_per_rank, void* stream);

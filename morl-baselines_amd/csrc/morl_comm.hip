@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
 
@@ -180,8 +181,10 @@ extern "C" int morl_comm_init_custom(morl_comm** out, int rank, int world, morl_
     return finish_comm(c, out);
 }
 
+static void ipc_release(morl_comm* c);
 extern "C" int morl_comm_destroy(morl_comm* c) {
     if (!c) return MORL_OK;
+    ipc_release(c);
     if (c->nccl) (void)rccl().CommDestroy(c->nccl);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ready) (void)hipEventDestroy(c->ready);
@@ -224,4 +227,287 @@ extern "C" int morl_allreduce_grads(morl_comm* c, float* buf, int64_t count, voi
     const int rc = c->allreduce(c->user, buf, count, stream);
     if (rc) return c->custom ? fail(MORL_ERR_STATE, "the transport's all-reduce call-back failed (%d)", rc) : rc;
     return MORL_OK;
+}
+
+// ================================================================================================================================
+// Single-hop transport over peer-mapped memory: the messages of the sharded step are 0.15 - 2.4 MB, far below
+// the size at which a ring is bandwidth-bound on the seven point-to-point xGMI links of a GPU -- they are latency-bound, and a
+// ring / tree pays its latency once per hop.  Here every rank owns ONE region of device memory that all its peers map (hipIpc);
+// a collective is two or three small kernels that write (or read) the peers' regions directly, every link busy at once:
+//
+//   all-gather   push   : my slabs -> slot [me] of EVERY peer's gather area, then one flag per peer          (1 hop)
+//                collect: wait for the world's flags, gather area -> the caller's buffer (local copy)
+//   all-reduce   push   : chunk j of my buffer -> slot [me] of peer j's inbox, then one flag per peer         (reduce-scatter, 1 hop)
+//                reduce : wait; my chunk = sum over the inbox slots IN RANK ORDER (one rank computes a chunk, so every replica
+//                         receives the same bits) -> my outbox and my buffer; one flag per peer
+//                pull   : wait; peer j's outbox -> chunk j of my buffer (remote reads)                         (all-gather, 1 hop)
+//
+// Flags carry the epoch (call count) of the collective, one 64-byte line per (phase, source); a kernel's last workgroup to finish
+// its writes (device-scope ticket behind a system-scope fence) stores them with release semantics, waiters poll with acquire loads
+// -- and give up after IPC_TIMEOUT (wall clock): a lost peer costs a wrong step and an error code (morl_comm_check), never a hung
+// GPU.  The region is fine-grained (uncached) device memory so that a peer's writes are visible to a running kernel.
+// The reference has no counterpart (common/morl_algorithm.py:42: one device).
+// ================================================================================================================================
+namespace {
+
+constexpr int IPC_MAX_WORLD = 8;
+constexpr int IPC_THREADS = 256;
+constexpr long long IPC_TIMEOUT_TICKS = 300000000ll;       // wall_clock64() ticks at 100 MHz: 3 s
+enum { IPC_PH_AG = 0, IPC_PH_RS = 1, IPC_PH_AR = 2 };
+
+struct IpcHeader {                                  // at the start of every rank's region
+    unsigned int flag[3][IPC_MAX_WORLD][16];        // [phase][source rank]: the last epoch that source signalled (64-byte lines)
+    unsigned int error;                             // 1 + phase of a wait that ran out
+    unsigned int pad[15];
+};
+struct IpcPeers { float* base[IPC_MAX_WORLD]; };    // every rank's region as mapped HERE (base[me] = my own)
+struct IpcGeom {
+    long long inbox_off, outbox_off, gather_off;    // float offsets from the region base
+    long long chunk_cap, ag_cap;                    // floats per inbox slot / per gather slot
+    int rank, world;
+};
+
+__device__ __forceinline__ IpcHeader* ipc_hdr(float* base) { return reinterpret_cast<IpcHeader*>(base); }
+
+// every workgroup calls this after its last write: the last one to arrive tells every peer that this rank's part of `phase` is
+// complete for `epoch` (and re-arms the ticket)
+__device__ __forceinline__ void ipc_finish_and_signal(const IpcPeers& P, const IpcGeom& g, int phase, unsigned epoch,
+                                                      unsigned* ticket, unsigned n_blocks) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = atomicAdd(ticket, 1u);
+        if (prev + 1u == n_blocks) {
+            *ticket = 0u;
+            __threadfence_system();
+            for (int j = 0; j < g.world; ++j)
+                __hip_atomic_store(&ipc_hdr(P.base[j])->flag[phase][g.rank][0], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// the workgroup waits until every rank has signalled `epoch` for `phase` in MY header (bounded)
+__device__ __forceinline__ void ipc_wait(IpcHeader* mine, int world, int phase, unsigned epoch) {
+    if ((int)threadIdx.x < world) {
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(&mine->flag[phase][threadIdx.x][0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+            __builtin_amdgcn_s_sleep(63);
+            if (wall_clock64() - t0 > IPC_TIMEOUT_TICKS) { mine->error = 1u + (unsigned)phase; break; }
+        }
+    }
+    __syncthreads();
+}
+
+// push: blockIdx.y = destination rank j; floats [src_start(j), +len(j)) of `src` -> P.base[j] + dst_off + rank * slot_cap.
+// all-gather: every destination gets the same `count` floats; reduce-scatter: destination j gets chunk j.
+__global__ __launch_bounds__(IPC_THREADS) void ipc_push_kernel(IpcPeers P, IpcGeom g, const float* __restrict__ src, long long count,
+                                                               long long chunk, int scatter, long long dst_off, long long slot_cap,
+                                                               int phase, unsigned epoch, unsigned* ticket) {
+    const int j = (int)blockIdx.y;
+    const long long start = scatter ? (j * chunk < count ? j * chunk : count) : 0;
+    const long long len = scatter ? (count - start < chunk ? count - start : chunk) : count;
+    float* dst = P.base[j] + dst_off + (long long)g.rank * slot_cap;
+    const float* s = src + start;
+    for (long long e = (long long)blockIdx.x * IPC_THREADS + threadIdx.x; e < len; e += (long long)gridDim.x * IPC_THREADS) dst[e] = s[e];
+    ipc_finish_and_signal(P, g, phase, epoch, ticket, gridDim.x * gridDim.y);
+}
+
+__global__ __launch_bounds__(IPC_THREADS) void ipc_collect_kernel(IpcPeers P, IpcGeom g, float* __restrict__ recv, long long count,
+                                                                  unsigned epoch) {
+    float* mine = P.base[g.rank];
+    ipc_wait(ipc_hdr(mine), g.world, IPC_PH_AG, epoch);
+    const float* gather = mine + g.gather_off;
+    for (int r = 0; r < g.world; ++r)
+        for (long long e = (long long)blockIdx.x * IPC_THREADS + threadIdx.x; e < count; e += (long long)gridDim.x * IPC_THREADS)
+            recv[(long long)r * count + e] = gather[(long long)r * g.ag_cap + e];
+}
+
+__global__ __launch_bounds__(IPC_THREADS) void ipc_reduce_kernel(IpcPeers P, IpcGeom g, float* __restrict__ buf, long long count,
+                                                                 long long chunk, unsigned epoch, unsigned* ticket) {
+    float* mine = P.base[g.rank];
+    ipc_wait(ipc_hdr(mine), g.world, IPC_PH_RS, epoch);
+    const long long start = g.rank * chunk < count ? g.rank * chunk : count;
+    const long long len = count - start < chunk ? count - start : chunk;
+    const float* inbox = mine + g.inbox_off;
+    float* outbox = mine + g.outbox_off;
+    for (long long e = (long long)blockIdx.x * IPC_THREADS + threadIdx.x; e < len; e += (long long)gridDim.x * IPC_THREADS) {
+        float s = inbox[e];                                   // rank order: the same bits whoever asks
+        for (int r = 1; r < g.world; ++r) s += inbox[(long long)r * g.chunk_cap + e];
+        outbox[e] = s;
+        buf[start + e] = s;
+    }
+    ipc_finish_and_signal(P, g, IPC_PH_AR, epoch, ticket, gridDim.x);
+}
+
+__global__ __launch_bounds__(IPC_THREADS) void ipc_pull_kernel(IpcPeers P, IpcGeom g, float* __restrict__ buf, long long count,
+                                                               long long chunk, unsigned epoch) {
+    ipc_wait(ipc_hdr(P.base[g.rank]), g.world, IPC_PH_AR, epoch);
+    const int j = (int)blockIdx.y;
+    if (j == g.rank) return;
+    const long long start = j * chunk < count ? j * chunk : count;
+    const long long len = count - start < chunk ? count - start : chunk;
+    const float* src = P.base[j] + g.outbox_off;
+    for (long long e = (long long)blockIdx.x * IPC_THREADS + threadIdx.x; e < len; e += (long long)gridDim.x * IPC_THREADS)
+        buf[start + e] = src[e];
+}
+
+struct IpcState {
+    IpcPeers peers{};
+    IpcGeom geom{};
+    void* region = nullptr;
+    size_t region_bytes = 0;
+    bool opened[IPC_MAX_WORLD] = {};
+    unsigned* tickets = nullptr;          // [2] device counters of the last-workgroup pattern
+    unsigned epoch_ag = 0, epoch_ar = 0;
+    long long max_ar = 0, max_ag = 0;
+    bool connected = false;
+};
+
+long long round4(long long v) { return (v + 3) / 4 * 4; }
+
+}  // namespace
+
+// (kept outside morl_comm's definition above: a side table keyed by the communicator, so the struct shared with the other
+// transports stays what it was)
+#include <map>
+#include <mutex>
+namespace {
+std::mutex g_ipc_mu;
+std::map<const morl_comm*, IpcState*> g_ipc;
+IpcState* ipc_of(const morl_comm* c) {
+    std::lock_guard<std::mutex> lk(g_ipc_mu);
+    auto it = g_ipc.find(c);
+    return it == g_ipc.end() ? nullptr : it->second;
+}
+
+int ipc_allgather(void* user, const float* send, float* recv, int64_t count, void* stream) {
+    morl_comm* c = (morl_comm*)user;
+    IpcState* st = ipc_of(c);
+    if (!st || !st->connected) return fail(MORL_ERR_STATE, "ipc communicator is not connected");
+    if (count > st->max_ag) return fail(MORL_ERR_STATE, "all-gather of %lld floats per rank, the region holds %lld", (long long)count, st->max_ag);
+    const unsigned epoch = ++st->epoch_ag;
+    const int gx = (int)std::max<long long>(1, std::min<long long>(32, (count + IPC_THREADS * 4 - 1) / (IPC_THREADS * 4)));
+    hipLaunchKernelGGL(ipc_push_kernel, dim3(gx, st->geom.world), dim3(IPC_THREADS), 0, (hipStream_t)stream, st->peers, st->geom, send,
+                       (long long)count, 0ll, 0, st->geom.gather_off, st->geom.ag_cap, (int)IPC_PH_AG, epoch, st->tickets + 0);
+    LAUNCH_CHECK("ipc_push(all-gather)");
+    const int gc = (int)std::max<long long>(1, std::min<long long>(64, (count + IPC_THREADS * 2 - 1) / (IPC_THREADS * 2)));
+    hipLaunchKernelGGL(ipc_collect_kernel, dim3(gc), dim3(IPC_THREADS), 0, (hipStream_t)stream, st->peers, st->geom, recv, (long long)count,
+                       epoch);
+    LAUNCH_CHECK("ipc_collect");
+    return MORL_OK;
+}
+
+int ipc_allreduce(void* user, float* buf, int64_t count, void* stream) {
+    morl_comm* c = (morl_comm*)user;
+    IpcState* st = ipc_of(c);
+    if (!st || !st->connected) return fail(MORL_ERR_STATE, "ipc communicator is not connected");
+    if (count > st->max_ar) return fail(MORL_ERR_STATE, "all-reduce of %lld floats, the region holds %lld", (long long)count, st->max_ar);
+    const int world = st->geom.world;
+    const long long chunk = round4(((long long)count + world - 1) / world);
+    const unsigned epoch = ++st->epoch_ar;
+    const int gx = (int)std::max<long long>(1, std::min<long long>(32, (chunk + IPC_THREADS * 4 - 1) / (IPC_THREADS * 4)));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ipc_push_kernel, dim3(gx, world), dim3(IPC_THREADS), 0, s, st->peers, st->geom, (const float*)buf, (long long)count,
+                       chunk, 1, st->geom.inbox_off, st->geom.chunk_cap, (int)IPC_PH_RS, epoch, st->tickets + 0);
+    LAUNCH_CHECK("ipc_push(reduce-scatter)");
+    hipLaunchKernelGGL(ipc_reduce_kernel, dim3(gx), dim3(IPC_THREADS), 0, s, st->peers, st->geom, buf, (long long)count, chunk, epoch,
+                       st->tickets + 1);
+    LAUNCH_CHECK("ipc_reduce");
+    hipLaunchKernelGGL(ipc_pull_kernel, dim3(gx, world), dim3(IPC_THREADS), 0, s, st->peers, st->geom, buf, (long long)count, chunk, epoch);
+    LAUNCH_CHECK("ipc_pull");
+    return MORL_OK;
+}
+}  // namespace
+
+extern "C" int morl_comm_ipc_create(morl_comm** out, int rank, int world, int64_t max_allreduce_floats, int64_t max_allgather_floats,
+                                    void* handle_out) {
+    if (!out || !handle_out) return fail(MORL_ERR_ARG, "NULL argument");
+    *out = nullptr;
+    if (world < 1 || world > IPC_MAX_WORLD || rank < 0 || rank >= world)
+        return fail(MORL_ERR_ARG, "rank %d / world %d (at most %d ranks)", rank, world, IPC_MAX_WORLD);
+    if (max_allreduce_floats < 1 || max_allgather_floats < 0) return fail(MORL_ERR_ARG, "bad buffer sizes");
+    morl_comm* c = new (std::nothrow) morl_comm();
+    IpcState* st = new (std::nothrow) IpcState();
+    if (!c || !st) { delete c; delete st; return fail(MORL_ERR_ALLOC, "out of host memory"); }
+    c->rank = rank; c->world = world;
+    st->max_ar = max_allreduce_floats; st->max_ag = max_allgather_floats;
+    IpcGeom& g = st->geom;
+    g.rank = rank; g.world = world;
+    g.chunk_cap = round4((max_allreduce_floats + world - 1) / world);
+    g.ag_cap = round4(std::max<int64_t>(max_allgather_floats, 4));
+    g.inbox_off = (long long)(sizeof(IpcHeader) / sizeof(float));
+    g.outbox_off = g.inbox_off + (long long)world * g.chunk_cap;
+    g.gather_off = g.outbox_off + g.chunk_cap;
+    st->region_bytes = (size_t)(g.gather_off + (long long)world * g.ag_cap) * sizeof(float);
+    // fine-grained (uncached) device memory: a peer's writes must become visible to a kernel that is already running
+    if (hipExtMallocWithFlags(&st->region, st->region_bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        st->region = nullptr;
+        if (hipMalloc(&st->region, st->region_bytes) != hipSuccess) { delete c; delete st; return fail(MORL_ERR_ALLOC, "hipMalloc(%zu) failed", st->region_bytes); }
+    }
+    if (hipMemset(st->region, 0, st->region_bytes) != hipSuccess || hipMalloc((void**)&st->tickets, 2 * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(st->tickets, 0, 2 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(st->region); delete c; delete st;
+        return fail(MORL_ERR_HIP, "setting up the shared region failed");
+    }
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, st->region) != hipSuccess) {
+        (void)hipFree(st->region); (void)hipFree(st->tickets); delete c; delete st;
+        return fail(MORL_ERR_HIP, "hipIpcGetMemHandle failed (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+    }
+    static_assert(sizeof(hipIpcMemHandle_t) <= MORL_COMM_IPC_HANDLE_BYTES, "handle size");
+    std::memset(handle_out, 0, MORL_COMM_IPC_HANDLE_BYTES);
+    std::memcpy(handle_out, &h, sizeof(h));
+    st->peers.base[rank] = (float*)st->region;
+    c->allgather = ipc_allgather; c->allreduce = ipc_allreduce; c->user = c;
+    { std::lock_guard<std::mutex> lk(g_ipc_mu); g_ipc[c] = st; }
+    const int rc = finish_comm(c, out);
+    if (rc) { std::lock_guard<std::mutex> lk(g_ipc_mu); g_ipc.erase(c); }
+    return rc;
+}
+
+extern "C" int morl_comm_ipc_connect(morl_comm* c, const void* all_handles) {
+    IpcState* st = c ? ipc_of(c) : nullptr;
+    if (!st || !all_handles) return fail(MORL_ERR_ARG, "not an ipc communicator / NULL handles");
+    for (int j = 0; j < st->geom.world; ++j) {
+        if (j == st->geom.rank || st->opened[j]) continue;
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, (const char*)all_handles + (size_t)j * MORL_COMM_IPC_HANDLE_BYTES, sizeof(h));
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(MORL_ERR_HIP, "hipIpcOpenMemHandle(rank %d) failed: %s", j, hipGetErrorString(e));
+        st->peers.base[j] = (float*)p;
+        st->opened[j] = true;
+    }
+    st->connected = true;
+    return MORL_OK;
+}
+
+// 0 if no bounded wait of this rank's collectives has run out so far; synchronises the device
+extern "C" int morl_comm_check(morl_comm* c) {
+    IpcState* st = c ? ipc_of(c) : nullptr;
+    if (!c) return fail(MORL_ERR_ARG, "comm is NULL");
+    if (!st) return MORL_OK;                       // the other transports report their failures at the call
+    IpcHeader h;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&h, st->region, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.error) return fail(MORL_ERR_STATE, "a peer did not arrive within the time limit (phase %u of the single-hop collectives)", h.error - 1);
+    return MORL_OK;
+}
+
+static void ipc_release(morl_comm* c) {
+    IpcState* st = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_ipc_mu);
+        auto it = g_ipc.find(c);
+        if (it == g_ipc.end()) return;
+        st = it->second;
+        g_ipc.erase(it);
+    }
+    (void)hipDeviceSynchronize();
+    for (int j = 0; j < st->geom.world; ++j)
+        if (st->opened[j]) (void)hipIpcCloseMemHandle(st->peers.base[j]);
+    if (st->region) (void)hipFree(st->region);
+    if (st->tickets) (void)hipFree(st->tickets);
+    delete st;
 }

@@ -69,7 +69,7 @@ class NativeComm:
                      rank step at world 2 / 4 without a GPU), torch's own RCCL communicator with ``MORL_COMM=torch``
     * ``"loopback"`` one rank, no RCCL (single-rank runs, the emulated build)"""
 
-    def __init__(self, lib, dist, device, group=None, loopback=False, transport="rccl"):
+    def __init__(self, lib, dist, device, group=None, loopback=False, transport="rccl", max_allreduce=0, max_allgather=0):
         self.lib, self.device = lib, th.device(device)
         ident = th.zeros(128, dtype=th.uint8)
         handle = C.c_void_p()
@@ -83,8 +83,11 @@ class NativeComm:
         if transport == "torch":
             self._bind_torch(dist, group, handle)
             return
+        if transport == "ipc":
+            self._bind_ipc(dist, group, handle, max_allreduce, max_allgather)
+            return
         if transport != "rccl":
-            raise ValueError("transport must be 'rccl' or 'torch'")
+            raise ValueError("transport must be 'rccl', 'ipc' or 'torch'")
         if self.rank == 0:
             lib.check(lib.lib.morl_comm_unique_id(C.c_void_p(ident.data_ptr())))
         ident = ident.to(self.device)
@@ -93,6 +96,27 @@ class NativeComm:
         with th.cuda.device(self.device):
             lib.check(lib.lib.morl_comm_init(C.byref(handle), C.c_void_p(ident.data_ptr()), self.rank, self.world))
         self.handle = handle.value
+
+    def _bind_ipc(self, dist, group, handle, max_allreduce: int, max_allgather: int) -> None:
+        """The single-hop transport (``morl_comm_ipc_*``): this rank's shared region, the world's 64-byte handles exchanged
+        through ``torch.distributed`` (the side channel), the peers mapped."""
+        if max_allreduce < 1:
+            raise ValueError("the ipc transport needs the size of the largest all-reduce (floats)")
+        mine = th.zeros(64, dtype=th.uint8)
+        with (th.cuda.device(self.device) if self.device.type == "cuda" else __import__("contextlib").nullcontext()):
+            self.lib.check(self.lib.lib.morl_comm_ipc_create(C.byref(handle), self.rank, self.world, int(max_allreduce),
+                                                             int(max_allgather), C.c_void_p(mine.data_ptr())))
+            self.handle = handle.value
+            on_dev = dist.get_backend(group) == "nccl"
+            every = th.zeros(64 * self.world, dtype=th.uint8, device=self.device if on_dev else "cpu")
+            dist.all_gather_into_tensor(every, mine.to(every.device), group=group)
+            every = every.cpu().contiguous()
+            self.lib.check(self.lib.lib.morl_comm_ipc_connect(self.handle, C.c_void_p(every.data_ptr())))
+        dist.barrier(group=group)            # nobody pushes before everybody has mapped everybody
+
+    def check(self) -> None:
+        """Raises if a bounded wait of the single-hop collectives ran out (a peer never arrived); synchronises the device."""
+        self.lib.check(self.lib.lib.morl_comm_check(self.handle))
 
     def _bind_torch(self, dist, group, handle) -> None:
         from .native import ALLGATHER_FN, ALLREDUCE_FN
@@ -178,9 +202,9 @@ class NativeComm:
     # multi-process jobs hang; the process exit releases it)
 
 
-def make_comm(lib, dist, device, group=None, transport=None):
-    """The communicator of a sharded agent.  ``transport``: "rccl" | "torch" | "staged" (None: the ``MORL_COMM`` environment
-    variable -- "native" / "rccl", "torch", "staged" --, default RCCL on an RCCL process group of the gfx950 build and the
+def make_comm(lib, dist, device, group=None, transport=None, max_allreduce=0, max_allgather=0):
+    """The communicator of a sharded agent.  ``transport``: "rccl" | "ipc" | "torch" | "staged" (None: the ``MORL_COMM`` environment
+    variable -- "native" / "rccl", "ipc", "torch", "staged" --, default RCCL on an RCCL process group of the gfx950 build and the
     torch call-backs everywhere else).  If RCCL cannot be brought up inside the library on EVERY rank (librccl missing, a
     second communicator refused) all ranks fall back to the torch transport together and say so on stderr -- the job runs
     instead of dying.  Returns (NativeComm or None for the staged path, name of the transport in use)."""
@@ -191,6 +215,9 @@ def make_comm(lib, dist, device, group=None, transport=None):
     can_rccl = dist.get_backend(group) == "nccl" and lib.is_device_build
     if want is None:
         want = "rccl" if can_rccl else "torch"
+    if want == "ipc":
+        comm = NativeComm(lib, dist, device, group, transport="ipc", max_allreduce=max_allreduce, max_allgather=max_allgather)
+        return comm, "ipc (single-hop direct writes over peer-mapped memory, inside libmorl_hip.so)"
     if want == "rccl":
         if not can_rccl:
             raise ValueError("transport 'rccl' needs an RCCL ('nccl') process group and the gfx950 build")
@@ -291,7 +318,8 @@ def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=N
     # (and with MORL_COMM=torch)
     # (``comm``: a ready NativeComm, e.g. the loopback one of a single-rank run)
     if comm is None and hasattr(dist, "broadcast"):          # (a real torch.distributed, not a test stub)
-        comm, agent._shard.transport = make_comm(agent.lib, dist, dev, group, transport)
+        comm, agent._shard.transport = make_comm(agent.lib, dist, dev, group, transport, max_allreduce=P + 1 + B0,
+                                                 max_allgather=2 * B0 * Wl * A * R)
     else:
         agent._shard.transport = "staged" if comm is None else comm.transport
     agent._shard.comm = comm
@@ -374,7 +402,7 @@ def _shard_envelope_batch(agent: Envelope, dist, group, emulate, comm, world: in
     agent._grads = agent._grads_x[:P]
     agent._bind_optimizer_state()
     if comm is None and hasattr(dist, "broadcast"):          # (a real torch.distributed, not a test stub)
-        comm, agent._shard.transport = make_comm(agent.lib, dist, dev, group, transport)
+        comm, agent._shard.transport = make_comm(agent.lib, dist, dev, group, transport, max_allreduce=P + 1 + B0)
     else:
         agent._shard.transport = "staged" if comm is None else comm.transport
     agent._shard.comm = comm

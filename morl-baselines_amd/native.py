@@ -166,6 +166,9 @@ _SIGNATURES = {
     "morl_comm_unique_id": (C.c_int, [C.c_void_p]),
     "morl_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
     "morl_comm_init_custom": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "morl_comm_ipc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "morl_comm_ipc_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "morl_comm_check": (C.c_int, [C.c_void_p]),
     "morl_comm_destroy": (C.c_int, [C.c_void_p]),
     "morl_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "morl_allgather_q_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -57,7 +57,8 @@ enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemc
 static inline const char* hipGetErrorString(hipError_t) { return "hipsim error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+namespace hipsim { bool shm_free(void* p); }
+static inline hipError_t hipFree(void* p) { if (!hipsim::shm_free(p)) std::free(p); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
@@ -76,6 +77,85 @@ static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuc
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
+
+// ---- "peer-mapped device memory" of the emulated build: POSIX shared memory, so that the single-hop collectives of
+// morl_comm.hip (hipIpc between the ranks of a job) run between the PROCESSES of a gloo CPU test exactly as they do between GPUs
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
+enum { hipDeviceMallocFinegrained = 1, hipDeviceMallocUncached = 3, hipIpcMemLazyEnablePeerAccess = 1 };
+struct hipIpcMemHandle_t { char reserved[64]; };
+namespace hipsim {
+struct ShmRec { void* ptr; size_t bytes; char name[48]; bool owner; };
+inline ShmRec* shm_table() { static ShmRec t[64]; return t; }
+inline ShmRec* shm_find(const void* p) { for (int k = 0; k < 64; ++k) if (shm_table()[k].ptr == p && p) return &shm_table()[k]; return nullptr; }
+inline ShmRec* shm_slot() { for (int k = 0; k < 64; ++k) if (!shm_table()[k].ptr) return &shm_table()[k]; return nullptr; }
+}
+static inline hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) {
+    static int counter = 0;
+    hipsim::ShmRec* r = hipsim::shm_slot();
+    if (!r) return hipErrorOutOfMemory;
+    std::snprintf(r->name, sizeof(r->name), "/hipsim_%d_%d", (int)getpid(), counter++);
+    const int fd = shm_open(r->name, O_CREAT | O_RDWR | O_EXCL, 0600);
+    if (fd < 0) return hipErrorOutOfMemory;
+    if (ftruncate(fd, (off_t)n) != 0) { close(fd); shm_unlink(r->name); return hipErrorOutOfMemory; }
+    void* m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { shm_unlink(r->name); return hipErrorOutOfMemory; }
+    r->ptr = m; r->bytes = n; r->owner = true;
+    *p = m;
+    return hipSuccess;
+}
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {
+    hipsim::ShmRec* r = hipsim::shm_find(p);
+    if (!r) return hipErrorInvalidValue;
+    std::memset(h, 0, sizeof(*h));
+    std::snprintf(h->reserved, sizeof(h->reserved), "%zu %s", r->bytes, r->name);
+    return hipSuccess;
+}
+static inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) {
+    size_t n = 0; char name[48] = {0};
+    if (std::sscanf(h.reserved, "%zu %47s", &n, name) != 2) return hipErrorInvalidValue;
+    const int fd = shm_open(name, O_RDWR, 0600);
+    if (fd < 0) return hipErrorInvalidValue;
+    void* m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return hipErrorInvalidValue;
+    hipsim::ShmRec* r = hipsim::shm_slot();
+    if (r) { r->ptr = m; r->bytes = n; r->owner = false; std::snprintf(r->name, sizeof(r->name), "%s", name); }
+    *p = m;
+    return hipSuccess;
+}
+static inline hipError_t hipIpcCloseMemHandle(void* p) {
+    hipsim::ShmRec* r = hipsim::shm_find(p);
+    if (!r) return hipErrorInvalidValue;
+    munmap(r->ptr, r->bytes);
+    r->ptr = nullptr;
+    return hipSuccess;
+}
+namespace hipsim {
+inline bool shm_free(void* p) {
+    ShmRec* r = shm_find(p);
+    if (!r) return false;
+    munmap(r->ptr, r->bytes);
+    if (r->owner) shm_unlink(r->name);
+    r->ptr = nullptr;
+    return true;
+}
+}
+static inline long long wall_clock64() {          // 100 MHz, like the device's constant-rate counter
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 100000000ll + ts.tv_nsec / 10;
+}
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), (order))
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), (order))
+static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
 struct hipDeviceProp_t { int multiProcessorCount; };
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; return hipSuccess; }
 
@@ -249,7 +329,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p 
 // scheduling hints have no meaning on the host
 #define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
-#define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) do { if ((n) >= 32) usleep(50); } while (0)   // long sleeps = spin-waits on another process
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
 
 // ---- math that hipcc provides as builtins -------------------------------------------------------

@@ -46,8 +46,8 @@ def _worker(rank, world, port, per, ret, schedules=False, axis="weights"):
     lib = simlib.load_sim()
     native.use_library(lib)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    for transport in ("staged", None):                    # None = what a job gets by default: the one-call step
-        ag = _make_agent(lib, per, schedules)
+    for transport in ("staged", None, "ipc"):             # None = what a gloo job gets by default: the one-call step over
+        ag = _make_agent(lib, per, schedules)             # torch.distributed call-backs; "ipc": over the single-hop transport
         shard_envelope_agent(ag, dist, axis=axis, transport=transport)
         comm = ag._shard.comm
         assert (comm is None) == (transport == "staged"), ag._shard.transport
@@ -56,8 +56,12 @@ def _worker(rank, world, port, per, ret, schedules=False, axis="weights"):
             ag.global_step += 1
         calls = None
         if comm is not None:
-            assert comm.transport == "torch" and comm.world == world and comm.rank == rank
-            calls = dict(comm.calls)
+            assert comm.transport == (transport or "torch") and comm.world == world and comm.rank == rank
+            if transport == "ipc":
+                comm.check()                              # no bounded wait ran out
+                dist.barrier()                            # nobody unmaps a region a peer may still read
+            else:
+                calls = dict(comm.calls)
             comm.close()
         ret[(rank, transport or "one-call")] = (
             ag.q_net.flat.clone().numpy(), float(ag.last_loss()),
@@ -72,7 +76,10 @@ def test_sharded_update_equals_single_process(per, schedules, world, axis):
     """``schedules``: several steps with ``homotopy_decay_steps`` / ``epsilon_decay_steps`` set -- the sharded step must run
     the same tail as ``Envelope.update`` (envelope.py:336-355), or the auxiliary loss never turns on under sharding.
     Both code paths of the rank step are run at world > 1: the one-call step (the production path; its collectives go through
-    the pluggable transport of ``morl_comm``) must equal the staged one BIT FOR BIT and the unsharded step to 1e-5."""
+    the pluggable transport of ``morl_comm``) must equal the staged one BIT FOR BIT and the unsharded step to 1e-5.  Third leg:
+    the one-call step over the SINGLE-HOP transport (``morl_comm_ipc_*``: direct writes into peer-mapped memory -- POSIX shared
+    memory between the processes of this test, hipIpc between GPUs); its all-reduce sums in rank order, so it equals the
+    unsharded step to 1e-5 and keeps the replicas bit-identical."""
     import simlib
     import morl_baselines_amd.native as native
     lib = simlib.load_sim()
@@ -99,7 +106,7 @@ def test_sharded_update_equals_single_process(per, schedules, world, axis):
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
-    for path in ("staged", "one-call"):
+    for path in ("staged", "one-call", "ipc"):
         p0, l0, t0, lam0, eps0, calls0 = ret[(0, path)]
         for r in range(1, world):                                       # (world 4: one weight per rank, four slab parts)
             p1, l1, t1, lam1, eps1, _ = ret[(r, path)]
@@ -246,6 +253,53 @@ def test_custom_transport_failure_is_a_status_not_a_crash():
         assert lib.lib.morl_comm_init_custom(None, 0, 1, None, None, None) != 0
     finally:
         native.use_library(None)
+
+
+def _ipc_missing_peer_worker(rank, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import time
+    import torch.distributed as dist
+    import simlib
+    from morl_baselines_amd.distributed import NativeComm
+    lib = simlib.load_sim()
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    comm = NativeComm(lib, dist, "cpu", transport="ipc", max_allreduce=1000, max_allgather=64)
+    buf = th.full((1000,), float(rank + 1))
+    comm.allreduce(buf)                                     # both ranks: 1 + 2
+    ok = bool((buf == 3.0).all())
+    comm.check()
+    msg = None
+    if rank == 0:                                            # rank 1 never joins the second all-reduce
+        t0 = time.time()
+        comm.allreduce(buf)
+        try:
+            comm.check()
+        except RuntimeError as e:
+            msg = str(e)
+        ret["waited"] = time.time() - t0
+    dist.barrier()
+    ret[rank] = (ok, msg)
+    comm.close()
+    dist.destroy_process_group()
+
+
+def test_single_hop_transport_bounded_wait_reports_a_missing_peer():
+    """``morl_comm_ipc_*``: an all-reduce over shared regions gives the sum on every rank; a peer that never arrives costs the
+    waiting rank its time limit and an error from ``morl_comm_check`` -- not a hang."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ipc_missing_peer_worker, args=(r, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret[0][0] and ret[1][0]
+    assert ret[0][1] is not None and "did not arrive" in ret[0][1] and ret[1][1] is None
+    assert 2.0 <= ret["waited"] <= 30.0
 
 
 def test_one_call_sharded_step_rejects_bad_arguments():
@@ -536,8 +590,9 @@ def test_data_parallel_capql_over_rccl_single_rank():
 
 
 # ---- world > 1 ON THE MI355X through the production rank step: several ranks share the one GPU of the test box ----------------
-# RCCL refuses two ranks on one device ("duplicate GPU"), so the ranks' collectives go through the pluggable transport of
-# morl_comm (torch.distributed over gloo, device tensors): everything else -- morl_envelope_step_sharded / _batch_sharded, the
+# RCCL refuses two ranks on one device ("duplicate GPU"), so the ranks' collectives go through the other two transports of
+# morl_comm -- torch.distributed over gloo (host-staged call-backs) and the single-hop hipIpc transport (peer-mapped regions,
+# direct writes: the same-device mapping here, xGMI peers on a multi-GPU node): everything else -- morl_envelope_step_sharded / _batch_sharded, the
 # gfx950 kernels, the side-stream all-gather beside the training forward, the gathered-slab layout read in place, the PER update
 # behind the all-reduce -- is what a multi-GPU job runs.  Replicas must stay bit-identical and equal the unsharded step.
 def _shared_gpu_worker(rank, world, port, per, axis, ret):
@@ -551,18 +606,23 @@ def _shared_gpu_worker(rank, world, port, per, axis, ret):
     th.cuda.set_device(dev)
     lib = native.load_library()
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ag = _make_agent(lib, per, schedules=True, dev=dev, arch=(256, 256, 256), B=64, W=16)
-    shard_envelope_agent(ag, dist, axis=axis)
-    comm = ag._shard.comm
-    assert comm is not None and comm.transport == "torch" and comm.world == world
     n = 4
-    for _ in range(n):
-        ag.update()
-        ag.global_step += 1
-    th.cuda.synchronize()
-    ret[rank] = (ag.q_net.flat.clone().cpu().numpy(), float(ag.last_loss()),
-                 ag.replay_buffer.tree_dev.clone().cpu().numpy() if per else None, dict(comm.calls))
-    dist.barrier()
+    for transport in (None, "ipc"):           # torch.distributed call-backs (gloo, host-staged) / single-hop hipIpc transport
+        ag = _make_agent(lib, per, schedules=True, dev=dev, arch=(256, 256, 256), B=64, W=16)
+        shard_envelope_agent(ag, dist, axis=axis, transport=transport)
+        comm = ag._shard.comm
+        assert comm is not None and comm.transport == (transport or "torch") and comm.world == world
+        for _ in range(n):
+            ag.update()
+            ag.global_step += 1
+        th.cuda.synchronize()
+        if transport == "ipc":
+            comm.check()                      # no bounded wait ran out
+        ret[(rank, transport or "torch")] = (ag.q_net.flat.clone().cpu().numpy(), float(ag.last_loss()),
+                                             ag.replay_buffer.tree_dev.clone().cpu().numpy() if per else None,
+                                             dict(comm.calls) if transport is None else None)
+        dist.barrier()
+        comm.close()
     dist.destroy_process_group()
 
 
@@ -594,14 +654,16 @@ def test_one_call_rank_step_at_world_gt_1_on_one_shared_gpu(per, world, axis):
                 q.kill()
             pytest.fail("a rank of the shared-GPU job did not finish")
         assert p.exitcode == 0
-    p0, l0, t0, calls = ret[0]
-    assert calls == {"allgather": n if axis == "weights" else 0, "allreduce": n}
-    for r in range(1, world):
-        p1, l1, t1, _ = ret[r]
-        assert np.array_equal(p0, p1) and l0 == l1                        # replicas bit-identical
+    for transport in ("torch", "ipc"):
+        p0, l0, t0, calls = ret[(0, transport)]
+        if transport == "torch":
+            assert calls == {"allgather": n if axis == "weights" else 0, "allreduce": n}
+        for r in range(1, world):
+            p1, l1, t1, _ = ret[(r, transport)]
+            assert np.array_equal(p0, p1) and l0 == l1                    # replicas bit-identical
+            if per:
+                assert np.array_equal(t0, t1)
+        assert abs(l0 - want_loss) <= 1e-5 * abs(want_loss), transport    # == the unsharded step up to fp32 summation order
+        assert np.abs(p0 - want).max() <= 0.02 * 3e-4 * n, transport
         if per:
-            assert np.array_equal(t0, t1)
-    assert abs(l0 - want_loss) <= 1e-5 * abs(want_loss)                   # == the unsharded step up to fp32 summation order
-    assert np.abs(p0 - want).max() <= 0.02 * 3e-4 * n
-    if per:
-        np.testing.assert_allclose(t0[0], want_tree[0], rtol=1e-5)
+            np.testing.assert_allclose(t0[0], want_tree[0], rtol=1e-5)
