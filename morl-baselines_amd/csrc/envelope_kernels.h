@@ -44,8 +44,10 @@ __global__ __launch_bounds__(256) void build_input_kernel(const float* __restric
 // The Qo[b] slab (W*A*R floats) and the weight vectors are staged in LDS once and shared by the W rows of this
 // transition.  Lane <-> TD row i; the waves of the workgroup split the (j, a) candidates and read each candidate's R values
 // as LDS broadcasts, so the arg-max loop has no cross-lane traffic at all; the per-wave partial winners of a row are merged
-// through LDS in candidate order, lowest index winning ties (a shuffle / ballot reduction over the candidates was measured
-// slower here: with 64 rows per transition the lanes are better spent on rows).
+// through LDS in candidate order, lowest index winning ties.  The shuffle form north_star names (lanes <-> candidates, a wave
+// butterfly carrying (value, index): argmax_mode 1, MORL_TD_SHFL=1) is kept and was A/B-measured on MI355X in round 3
+// (profiles/r03_argmax_ab.json): 16.6 us against 13.0 us for this form at W = 64 x A = 6, 52.5 against 51.5 us at the weak-scaled
+// W = 512 -- with 64 rows per transition the lanes are better spent on rows (DESIGN.md section 4 says the same).
 // diag_only restricts j to i (DDQN target, envelope.py:442-463).
 // HBM-bound and tiny: reads 2*B*W*A*R*4 bytes once.
 // ----------------------------------------------------------------------------------------------

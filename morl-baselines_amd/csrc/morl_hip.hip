@@ -561,7 +561,8 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
         Chain16Multi m16{};
         const int tiles = chain16_fill(m16, chains, n);
         hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
-    } else if (c->chain_sched) hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
+    } else if (td) hipLaunchKernelGGL(mlp_chain2_td_kernel, dim3(S), dim3(CH_THREADS), 0, s, m);
+    else if (c->chain_sched) hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
     else hipLaunchKernelGGL(mlp_chain2_kernel<0>, dim3(S), dim3(CH_THREADS), 0, s, m);
     LAUNCH_CHECK("mlp_chain2");
     return timing_close(c, slot, s);
