@@ -220,7 +220,7 @@ def _self_spawn(n: int, argv, result_out) -> int:
     127.0.0.1) and pass rank 0's JSON line through to the real stdout."""
     import subprocess
     have = th.cuda.device_count()
-    if have < n:
+    if have < n and "--shared-gpu" not in argv:
         raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible on this node")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
@@ -319,7 +319,7 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", 
     agent.q_net.ctx.set_timing(False)
     gpu_ms = e0.elapsed_time(e1)
     if dist is not None:
-        t = th.tensor([wall], device=dev, dtype=th.float64)
+        t = th.tensor([wall], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=th.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     res = {"wall": wall, "host_enqueue_ms_per_step": t_enq * 1e3 / steps, "gpu_ms_per_step_events": gpu_ms / steps,
@@ -396,6 +396,11 @@ def main():
                          "weights per rank: all-gather of Q(w) + all-reduce, the north_star's description); auto = the "
                          "strong-scaled job is measured on BOTH and the faster one is the headline, the weak-scaled one runs "
                          "on the weight axis (the one that grows)")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="FUNCTIONAL check of the N > 1 code path on a one-GPU box: the N ranks all run on cuda:0 (gloo process "
+                         "group; collectives over the single-hop hipIpc transport, MORL_COMM=ipc, unless MORL_COMM says "
+                         "otherwise -- RCCL refuses duplicate devices).  The line is labelled: its timings describe N processes "
+                         "sharing one chip, not a multi-GPU job")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the weight-sharded step (RCCL collectives) even with one rank (path check on a 1-GPU box)")
     a = ap.parse_args()
@@ -409,6 +414,9 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not th.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    if a.shared_gpu:
+        local_rank = 0                                    # every rank on the one GPU of the box
+        os.environ.setdefault("MORL_COMM", "ipc")
     th.cuda.set_device(local_rank)
     dev = th.device("cuda", local_rank)
     dist = None
@@ -416,8 +424,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        print(f"[bench] rank {rank}/{world} on {dev}: RCCL nranks={dist.get_world_size()}", file=sys.stderr, flush=True)
+        if a.shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        print(f"[bench] rank {rank}/{world} on {dev}: {dist.get_backend()} nranks={dist.get_world_size()}", file=sys.stderr, flush=True)
     sharded = dist is not None
 
     if a.weights % world:
@@ -436,7 +447,7 @@ def main():
             traceback.print_exc()
             res = {"error": f"{type(exc).__name__}: {exc}"}
         if dist is not None and world > 1:
-            bad = th.tensor([1 if "error" in res else 0], device=dev)
+            bad = th.tensor([1 if "error" in res else 0], device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
             if int(bad.item()) and "error" not in res:
                 res = {"error": "another rank failed"}
@@ -538,6 +549,9 @@ def main():
             # what one rank of an N-rank job takes when run ALONE (bench.py --force-shard --emulate-world N, profiles/): the
             # ceiling of strong scaling before any collective costs a microsecond -- nobody should read >= 6x into this record
             out["config"]["strong_scaling_ceiling_emulated"] = EMULATED_CEILING
+        if a.shared_gpu and world > 1:
+            out["shared_gpu"] = (f"FUNCTIONAL record, not a multi-GPU measurement: the {world} ranks of this job shared ONE MI355X "
+                                 "(gloo process group); value / ms_per_step describe that")
         if a.force_shard and a.emulate_world > 1 and world == 1:
             share = (f"{B // a.emulate_world} transitions x {W_head} weights" if head_axis == "batch"
                      else f"{B} transitions x {W_head // a.emulate_world} weights")
