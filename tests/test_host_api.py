@@ -342,3 +342,75 @@ def test_priority_update_larger_than_one_launch(be, monkeypatch):
     for lvl in range(len(tree.nodes)):
         np.testing.assert_array_equal(got.nodes[lvl][:len(tree.nodes[lvl])], tree.nodes[lvl])
     assert buf.min_priority == float(max(1e-5, pr.max()))
+
+
+# ---- round-2 advisor findings, held by tests ---------------------------------------------------------------------------------
+def test_pinned_ring_grows_once_and_serves_smaller_batches_from_a_prefix(be):
+    """``ops.HostRing``: a buffer that alternates between batch sizes (GPI-PD's real / model mix) keeps ONE ring sized for the
+    largest batch -- no re-creation (the pinned block of a dropped ring could be recycled under a kernel still reading it) --
+    and the gathers stay right."""
+    lib, dev = be
+    D, A, R = 5, 4, 3
+    buf = rp.ReplayBuffer((D,), 1, rew_dim=R, max_size=64, action_dtype=np.uint8, device=dev, lib=lib)
+    _fill(buf, 64, D, A, R)
+    rings = []
+    for k, B in enumerate((8, 24, 8, 16, 24, 3)):
+        np.random.seed(100 + k)
+        obs, act, rew, nobs, done, idx = buf.sample(B, to_tensor=True)
+        np.random.seed(100 + k)
+        want = np.random.choice(64, B, replace=True)
+        assert np.array_equal(idx.cpu().numpy(), want) and np.array_equal(obs.cpu().numpy(), buf.obs[want])
+        rings.append(buf.__dict__["_idx_ring"])
+    assert rings[0] is not rings[1]                                    # 8 -> 24: outgrown once (the old ring retired safely)
+    assert all(r is rings[1] for r in rings[1:]) and rings[1].capacity == 24
+
+
+def test_sharded_steps_refuse_bad_per_arguments_before_the_first_launch(be):
+    """A PER batch beyond the tree kernel's 1 024 entries, or missing Adam state, is refused at ENTRY of the one-call rank
+    steps: round 2 found them out after the all-reduce, with the parameters already stepped on every rank."""
+    lib, dev = be
+    from morl_baselines_amd import ops
+    from morl_baselines_amd.distributed import NativeComm
+    ag, env = _make_agent(lib, dev, per=True)
+    _fill(ag.replay_buffer, 100, env.D, env.A, env.R)
+    comm = NativeComm(lib, None, dev, loopback=True)
+    ctx, P = ag.q_net.ctx, ag.q_net.ctx.n_params
+    B, W = 2048, 1
+    ag.q_net.ensure_capacity(B, W)
+    ctx = ag.q_net.ctx
+    gx = th.zeros(P + 1 + B, device=dev)
+    z = lambda *s, dt=th.float32: th.zeros(*s, dtype=dt, device=dev)
+    w = th.full((W, env.R), 1.0 / env.R, device=dev)
+    before = ag.q_net.flat.clone()
+    per = ag.replay_buffer.per_update_args(z(B, dt=th.int64), 0.6)
+    with pytest.raises(RuntimeError, match="PER update inside the step"):
+        ops.envelope_step_batch_sharded(ctx, comm.handle, ag.q_net.flat, ag.target_q_net.flat, gx, ag._exp_avg, ag._exp_avg_sq,
+                                        z(B, env.D), z(B, env.D), z(B, dt=th.int32), z(B, env.R), z(B), w, B, 0, gamma=0.99,
+                                        lr=1e-3, adam_step=1, max_grad_norm=1.0, per=per)
+    with pytest.raises(RuntimeError, match="PER update inside the step"):
+        ops.envelope_update(ctx, ag.q_net.flat, ag.target_q_net.flat, gx[:P], ag._exp_avg, ag._exp_avg_sq, z(B, env.D), z(B, env.D),
+                            z(B, dt=th.int32), z(B, env.R), z(B), w, gamma=0.99, lr=1e-3, adam_step=1, max_grad_norm=1.0, per=per)
+    assert th.equal(before, ag.q_net.flat)                              # nothing ran
+    comm.close()
+
+
+def test_shadow_weights_of_a_skipped_step_are_not_reused(be):
+    """``sample(prepare=...)`` makes the K-major shadow copies for the step that follows.  If that step never runs and the
+    parameters are then written in place (here: a Polyak copy into the online net), the next forward must not stream the stale
+    copies: only the gradient step directly behind ``prepare`` may consume them."""
+    lib, dev = be
+    from morl_baselines_amd import ops
+    ag, env = _make_agent(lib, dev, per=False)
+    _fill(ag.replay_buffer, 100, env.D, env.A, env.R)
+    ag.replay_buffer.sample(16, to_tensor=True, prepare=(ag.q_net.ctx, ag.q_net.flat, ag.target_q_net.flat))   # step skipped
+    new = (ag.q_net.flat * 0.5 + 0.01).clone()
+    ops.polyak(lib, new, ag.q_net.flat, 1.0)                             # in-place write behind the library's back
+    obs = th.tensor(np.random.default_rng(0).standard_normal((4, env.D)).astype(np.float32)).to(dev)
+    w = th.tensor([[0.3, 0.7]], dtype=th.float32).to(dev)
+    got = ops.qnet_forward(ag.q_net.ctx, ag.q_net.flat, obs, w).cpu()
+    ps, off = [], 0
+    for (wo, (o, i), bo, n) in ag.q_net.ctx.layer_slices():
+        ps += [new[wo:wo + o * i].view(o, i).cpu(), new[bo:bo + n].cpu()]
+    want = orc.qnet_forward(ps, obs.cpu(), w.cpu().expand(4, -1), env.A, env.R)
+    assert float((got.view(-1) - want.reshape(-1)).abs().max()) <= 1e-5 * float(want.abs().max())
+    ag.q_net.ctx.invalidate_shadows()                                    # (the explicit form is a no-op afterwards)
