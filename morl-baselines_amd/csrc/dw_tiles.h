@@ -227,7 +227,14 @@ __device__ __forceinline__ void dw2_tile(const Dw2Problem& g, int tile_m, int ti
             const int col = n0 + wcol + TNW * i;
             float* dst = C + (size_t)row * g.ldc + col;
             if (TNW == 2) {
-                if (g.c_vec2 && col + 1 < g.N) *reinterpret_cast<float2*>(dst) = make_float2(acc[a][0][r], acc[a][TNW - 1][r]);
+                if (g.c_vec2 == 2 && col + 1 < g.N) {
+                    // non-temporal: the slab is written once and read once by the reduction; keep it from filling the L2s with
+                    // dirty lines that the end of the launch has to flush (A/B: MORL_DW_NT)
+                    typedef float dw2_v2f __attribute__((ext_vector_type(2)));
+                    dw2_v2f v2;
+                    v2.x = acc[a][0][r]; v2.y = acc[a][TNW - 1][r];
+                    __builtin_nontemporal_store(v2, reinterpret_cast<dw2_v2f*>(dst));
+                } else if (g.c_vec2 && col + 1 < g.N) *reinterpret_cast<float2*>(dst) = make_float2(acc[a][0][r], acc[a][TNW - 1][r]);
                 else {
                     if (col < g.N) dst[0] = acc[a][0][r];
                     if (col + 1 < g.N) dst[1] = acc[a][TNW - 1][r];

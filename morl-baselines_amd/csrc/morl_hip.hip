@@ -683,6 +683,22 @@ extern "C" int morl_ctx_set_timing(morl_ctx* c, int every) {
     c->timing_step = 0;
     c->timing = false;
     c->ev_used = 0;
+    // the first event pairs are made HERE, not lazily inside the region the caller is about to time (a pair costs ~10 us of host
+    // time to create; a 20-step run used to create its 20 pairs one per step)
+    if (every != 0) {
+        static const unsigned ev_flags = [] {
+            const char* e = getenv("MORL_EV_FLAGS");   // (tuning)
+            return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)hipEventDisableSystemFence;
+        }();
+        while (c->ev_start.size() < 64) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreateWithFlags(&e0, ev_flags));
+            HIP_TRY(hipEventCreateWithFlags(&e1, ev_flags));
+            c->ev_start.push_back(e0);
+            c->ev_stop.push_back(e1);
+            c->ev_kind.push_back(0);
+        }
+    }
     return MORL_OK;
 }
 
@@ -1085,6 +1101,8 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             q.gcols = q.ldg;                 // (pad columns of dq / x0 are written as zeros by their producers)
             q.hcols = q.ldh;
             q.c_vec2 = ((((uintptr_t)q.C) & 7u) == 0 && (q.ldc & 1) == 0 && (c->P & 1) == 0) ? 1 : 0;
+            static const int dw_nt = [] { const char* e = getenv("MORL_DW_NT"); return e ? atoi(e) : 0; }();   // (A/B)
+            if (q.c_vec2 && dw_nt) q.c_vec2 = 2;
             unit_tiles += (double)q.tiles_m * q.tiles_n * lay_cost[q.layout] / 4.0;
         }
         int target = 2 * c->num_cus;
