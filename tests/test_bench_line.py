@@ -1,0 +1,59 @@
+"""bench.py's line assembly without a GPU: the roofline arithmetic (algorithmic flop of the bracketed launches over their mean
+duration, against the fp32-MFMA peak of MI355X_MICROARCH.md), the per-kernel split, the committed PMC traffic figure, and the
+constants the contract names.  The measurement itself needs the MI355X (`-m gpu` and the driver run it)."""
+import importlib.util
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_algorithmic_work_matches_survey_8d(bench):
+    assert bench.MACS_ROW == 210176 and bench.FWD_FLOP_ROW == 420352
+    rows = 256 * 64
+    # (the line's whole-step figure counts the backward-dX pass without the first layer, which has no dX: 3.414e10)
+    assert rows * (4 * bench.FWD_FLOP_ROW + bench.BWD_DX_FLOP_ROW) == 34141634560
+    assert 5 * rows * bench.FWD_FLOP_ROW == pytest.approx(3.4435e10, rel=1e-4)   # SURVEY: 5 x 16 384 x 420 352
+    assert bench.PEAK_FP32_MFMA_TFLOPS == 157.3
+
+
+def test_roofline_record_arithmetic(bench):
+    rows = 256 * 64
+    # one step's launches: forward x3 (one launch) 185 us, backward 67 us, weight gradients 70 us, each bracketed 7 times
+    res = {"n_chain": 14, "chain_ms": 7 * 0.185 + 7 * 0.067, "timed_steps": 20, "launches_per_step": 2, "timing_mode": -1,
+           "fwd_launches_per_step": 1, "kinds": {"forward": (7, 7 * 0.185), "backward": (7, 7 * 0.067), "dw": (6, 6 * 0.070)}}
+    r = bench._roofline(res, rows)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    flop_launch = rows * (3 * bench.FWD_FLOP_ROW + bench.BWD_DX_FLOP_ROW) / 2
+    assert r["algorithmic_flop_per_launch"] == pytest.approx(flop_launch)
+    assert r["achieved"] == pytest.approx(flop_launch / (0.126e-3) / 1e12, rel=1e-9)
+    assert r["frac"] == pytest.approx(r["achieved"] / 157.3) and 0.0 < r["frac"] < 1.0
+    pk = r["per_kernel"]
+    assert pk["forward"]["achieved"] == pytest.approx(rows * 3 * bench.FWD_FLOP_ROW / 185e-6 / 1e12)
+    assert pk["backward"]["achieved"] == pytest.approx(rows * bench.BWD_DX_FLOP_ROW / 67e-6 / 1e12)
+    assert pk["dw"]["achieved"] == pytest.approx(rows * bench.FWD_FLOP_ROW / 70e-6 / 1e12)
+    assert all(0.0 < v["frac"] < 1.0 for v in pk.values())
+    # traffic: HBM bytes per chain launch of the newest committed PMC summary (profiles/), labelled as a constant of the repo
+    assert r["traffic"] == pytest.approx(bench.measured_chain_traffic())
+    assert 50e6 < r["traffic"] < 200e6 and "committed profile" in r["traffic_source"]
+
+
+def test_contract_constants(bench):
+    c = bench.EMULATED_CEILING
+    assert set(c["batch_axis"]) == set(c["weight_axis"]) == {"2", "4", "8"}
+    assert all(1.0 < v < 8.0 for v in list(c["batch_axis"].values()) + list(c["weight_axis"].values()))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "256" in base["metric"] and "64" in base["metric"]            # the line's metric is BASELINE.json's
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"metric": "Envelope-Q TD updates/sec (batch x weights x obj = 256 x 64 x 3)"' in src
+    assert '"vs_baseline": None' in src and '"dtype": "f32"' in src and '"data": "synthetic"' in src
