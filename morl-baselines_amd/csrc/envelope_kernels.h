@@ -83,6 +83,8 @@ struct EnvelopeTdArgs {
     int fma_scal;           // 1: scalarise with an fma chain  fma(w_r, q_r, ...fma(w_1, q_1, w_0 * q_0))  -- what torch's unbatched
                             // einsum("r,bar->ba") of Envelope.max_action (envelope.py:389-402) evaluates to -- instead of
                             // separately rounded products and sums (the batched einsum of the TD target)
+    float* zero_ptr;        // optional: zero_ptr[k] = 0 for k in [0, zero_n) outside [keep_lo, keep_hi) -- the batch-sharded step's
+    int zero_n, keep_lo, keep_hi;   // "the other ranks' priorities are zeros" (one memset launch less per rank step)
     int bmajor;             // internal row order of q_main / dq: 0 = row i * B + b (reference order, envelope.py:284-291),
                             // 1 = row b * WI + i (what the layer-fused engines use: the rows of a transition are contiguous, so a
                             // backward tile needs one or two slabs, chain_td.h).  target / pref / ac stay in reference order
@@ -315,6 +317,9 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
         }
     }
     if (p.priority_clear && ig == 0 && threadIdx.x == 0) p.priority_clear[b] = 0.f;
+    if (p.zero_ptr)
+        for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < p.zero_n; k += (int)(gridDim.x * blockDim.x))
+            if (k < p.keep_lo || k >= p.keep_hi) p.zero_ptr[k] = 0.f;
     if (p.loss_part && threadIdx.x == 0) {
         p.loss_part[(size_t)blockIdx.x * 2 + 0] = s_red[0][0];
         p.loss_part[(size_t)blockIdx.x * 2 + 1] = s_red[0][1];

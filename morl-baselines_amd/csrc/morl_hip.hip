@@ -190,6 +190,8 @@ struct morl_ctx {
     std::vector<hipEvent_t> ev_start, ev_stop;
     std::vector<int> ev_kind;            // MORL_TIMED_* of each recorded launch
     int last_B = 0, last_WI = 0;         // shape of the last training forward (morl_ctx_debug_hidden)
+    float* td_zero_ptr = nullptr;        // one-shot request of the batch-sharded step to the next TD launch: zero this range ...
+    int td_zero_n = 0, td_keep_lo = 0, td_keep_hi = 0;   // ... except [keep_lo, keep_hi) (the rank's own priorities)
     int main_rows = -1;                  // rows of a hoisted training forward (morl_envelope_main_forward), -1 = none
     // shadow copies made by morl_envelope_prepare for exactly these parameter buffers; consumed (one-shot) by the step's first
     // library entry, dropped by every optimiser step of the library
@@ -1035,6 +1037,8 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         p.B = B; p.W = W; p.A = A; p.R = R; p.ldq = c->ldq;
         p.WI = WI; p.i_offset = i_offset;
         p.bmajor = bmajor;
+        p.zero_ptr = c->td_zero_ptr; p.zero_n = c->td_zero_n; p.keep_lo = c->td_keep_lo; p.keep_hi = c->td_keep_hi;
+        c->td_zero_ptr = nullptr;
         p.diag_only = cfg->envelope ? 0 : 1;
         p.gamma = cfg->gamma;
         const float lam = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
@@ -1549,7 +1553,13 @@ extern "C" int morl_envelope_step_batch_sharded(morl_ctx* c, morl_comm* comm, fl
     if (world == parts && rank != b_offset / B) return fail(MORL_ERR_ARG, "rank %d does not own the transitions from %d on", rank, b_offset);
     hipStream_t s = (hipStream_t)stream;
     float* prio = grads_x + n_params + 1;
-    if (parts > 1) HIP_TRY(hipMemsetAsync(prio, 0, (size_t)B_total * sizeof(float), s));   // the other ranks' transitions: zeros
+    // the other ranks' transitions: zeros -- written by the step's TD launch (one memset launch less); the TD stage inside the
+    // backward chain (MORL_TD_FUSED=1) has no such hook, so that path keeps the fill
+    if (parts > 1) {
+        const bool td_kernel = !(c->use_fused && c->td_fused && !chain_rows_take_16((long long)B * W));
+        if (td_kernel) { c->td_zero_ptr = prio; c->td_zero_n = B_total; c->td_keep_lo = b_offset; c->td_keep_hi = b_offset + B; }
+        else HIP_TRY(hipMemsetAsync(prio, 0, (size_t)B_total * sizeof(float), s));
+    }
     morl_update_cfg local = *cfg;
     local.apply_step = 0;
     local.per_tree = nullptr;                                  // priorities are complete only after the all-reduce
@@ -1559,9 +1569,10 @@ extern "C" int morl_envelope_step_batch_sharded(morl_ctx* c, morl_comm* comm, fl
     morl_update_out out = {};
     out.loss = grads_x + n_params;
     out.priority = prio + b_offset;
-    if ((rc = morl_envelope_update(c, params_online, params_target, grads_x, exp_avg, exp_avg_sq, obs, next_obs, actions, rewards,
-                                   dones, weights, B, W, &local, &out, stream)))
-        return rc;
+    rc = morl_envelope_update(c, params_online, params_target, grads_x, exp_avg, exp_avg_sq, obs, next_obs, actions, rewards, dones,
+                              weights, B, W, &local, &out, stream);
+    c->td_zero_ptr = nullptr;                                  // (one-shot: never left behind by a call that failed early)
+    if (rc) return rc;
     if ((rc = morl_allreduce_grads(comm, grads_x, n_params + 1 + B_total, stream))) return rc;
     (void)max_norm;
     if (cfg->per_tree) {
