@@ -332,6 +332,83 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", 
     return res
 
 
+def collective_microbench(dist, dev, world, n_allreduce, n_allgather, iters=20):
+    """The step's two collectives alone, over every transport that comes up on this job -- RCCL inside the library and the
+    single-hop transport over peer-mapped memory (morl_comm_ipc_*): microseconds per call of the all-reduce of
+    [gradient | loss | priorities] and of the all-gather of Q(w), max over the ranks.  Every rank calls this; a transport
+    that fails to come up anywhere is skipped by ALL ranks together, and the single-hop waits are bounded, so the worst case is
+    a few seconds and an "error" entry -- never a hang."""
+    from morl_baselines_amd.distributed import NativeComm
+    from morl_baselines_amd.native import load_library
+    lib = load_library()
+    on_dev = dist.get_backend() == "nccl"
+    side = dev if on_dev else th.device("cpu")
+    out = {"allreduce_floats": n_allreduce, "allgather_floats_per_rank": n_allgather, "iters": iters}
+    for name in (("rccl", "ipc") if on_dev else ("ipc",)):
+        comm, err = None, None
+        try:
+            comm = NativeComm(lib, dist, dev, transport=name, max_allreduce=n_allreduce, max_allgather=n_allgather)
+        except Exception as exc:                       # (the ipc set-up raises on every rank together; RCCL: agreed below)
+            err = f"{type(exc).__name__}: {exc}"
+        ok = th.tensor([0 if comm is None else 1], device=side)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            if comm is not None:
+                comm.close()
+            out[name] = {"error": err or "unavailable on another rank"}
+            continue
+        rec = {}
+        buf = th.full((n_allreduce,), 1e-3, device=dev)
+        send = th.full((n_allgather,), float(dist.get_rank()), device=dev)
+        recv = th.zeros(world * n_allgather, device=dev)
+        # every rank runs the SAME sequence of torch.distributed calls whatever fails locally: a failure is a flag that rides in
+        # the all-reduce of the timing, and all ranks leave the loop together
+        for what in ("allreduce", "allgather"):
+            def call():
+                if what == "allreduce":
+                    comm.allreduce(buf)
+                else:
+                    comm.allgather_begin(send, recv)
+                    comm.wait(recv)
+            bad, us, why = 0.0, 0.0, None
+            try:
+                for _ in range(3):
+                    call()
+                th.cuda.synchronize()
+            except Exception as exc:
+                bad, why = 1.0, f"{type(exc).__name__}: {exc}"
+            f = th.tensor([bad], dtype=th.float64, device=side)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)       # (also the barrier) nobody enters the timed loop unless everybody does
+            bad = max(bad, float(f.item()))
+            if not bad:
+                try:
+                    if what == "allreduce":
+                        buf.fill_(1e-3)
+                    e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(iters):
+                        call()
+                    e1.record()
+                    th.cuda.synchronize()
+                    us = e0.elapsed_time(e1) * 1e3 / iters
+                    if name == "ipc":
+                        comm.check()
+                except Exception as exc:
+                    bad, why = 1.0, f"{type(exc).__name__}: {exc}"
+            t = th.tensor([us, bad], dtype=th.float64, device=side)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if float(t[1].item()) > 0:
+                rec["error"] = why or "failed on another rank"
+                break
+            rec[what + "_us"] = float(t[0].item())
+        if "error" not in rec:
+            rec["allgather_correct"] = bool((recv.view(world, -1)[:, 0].cpu() == th.arange(world, dtype=th.float32)).all())
+        out[name] = rec
+        dist.barrier()
+        comm.close()
+    return out
+
+
 def _roofline(res, rows_rank):
     """Dominant kernel = mlp_chain (per step and rank: the forward passes -- one launch of three chains, or the slabs launch +
     the hoisted training forward of a sharded step -- and the backward-dX launch): algorithmic flop of the timed launches
@@ -402,6 +479,9 @@ def main():
                          "group; collectives over the single-hop hipIpc transport, MORL_COMM=ipc, unless MORL_COMM says "
                          "otherwise -- RCCL refuses duplicate devices).  The line is labelled: its timings describe N processes "
                          "sharing one chip, not a multi-GPU job")
+    ap.add_argument("--no-collective-microbench", action="store_true",
+                    help="N > 1: skip the side record that times the step's two collectives alone over RCCL and over the "
+                         "single-hop transport (bounded: a few seconds at worst)")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the weight-sharded step (RCCL collectives) even with one rank (path check on a 1-GPU box)")
     a = ap.parse_args()
@@ -478,6 +558,15 @@ def main():
             no_ramp = job(a.weights, None, ramp=False)
         strong["single"] = job(a.weights, None)
 
+    coll = None
+    if world > 1 and not a.no_collective_microbench:
+        # the A/B SURVEY 8(e) asks for: the same two messages over RCCL's ring / tree and over single-hop direct writes
+        n_params = 36 * 256 + 3 * 257 * 256 + 257 * A * R       # P of the flagship net
+        try:
+            coll = collective_microbench(dist, dev, world, n_params + 1 + B, 2 * B * (a.weights // world) * A * R)
+        except Exception as exc:
+            coll = {"error": f"{type(exc).__name__}: {exc}"}
+
     if rank == 0:
         def record(res, W, scaling):
             if "error" in res:
@@ -550,6 +639,10 @@ def main():
             # what one rank of an N-rank job takes when run ALONE (bench.py --force-shard --emulate-world N, profiles/): the
             # ceiling of strong scaling before any collective costs a microsecond -- nobody should read >= 6x into this record
             out["config"]["strong_scaling_ceiling_emulated"] = EMULATED_CEILING
+        if coll is not None:
+            out["collectives_alone"] = dict(coll, note="microseconds per call, max over the ranks, HIP events around 20 back-to-back "
+                                                       "calls; rccl = RCCL inside libmorl_hip.so, ipc = single-hop direct writes over "
+                                                       "peer-mapped memory (MORL_COMM=ipc selects it for the step)")
         if a.shared_gpu and world > 1:
             out["shared_gpu"] = (f"FUNCTIONAL record, not a multi-GPU measurement: the {world} ranks of this job shared ONE MI355X "
                                  "(gloo process group); value / ms_per_step describe that")

@@ -298,6 +298,19 @@ __device__ __forceinline__ void ipc_wait(IpcHeader* mine, int world, int phase, 
     __syncthreads();
 }
 
+// grid-strided copy of `len` floats, 16 bytes at a time when both ends allow it (slots and chunks are multiples of 4 floats; the
+// caller's buffers usually are 16-byte aligned)
+__device__ __forceinline__ void ipc_copy(float* __restrict__ dst, const float* __restrict__ src, long long len) {
+    const long long t = (long long)blockIdx.x * IPC_THREADS + threadIdx.x, stride = (long long)gridDim.x * IPC_THREADS;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0) {
+        const long long n4 = len >> 2;
+        for (long long e = t; e < n4; e += stride) reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(src)[e];
+        for (long long e = (n4 << 2) + t; e < len; e += stride) dst[e] = src[e];
+    } else {
+        for (long long e = t; e < len; e += stride) dst[e] = src[e];
+    }
+}
+
 // push: blockIdx.y = destination rank j; floats [src_start(j), +len(j)) of `src` -> P.base[j] + dst_off + rank * slot_cap.
 // all-gather: every destination gets the same `count` floats; reduce-scatter: destination j gets chunk j.
 __global__ __launch_bounds__(IPC_THREADS) void ipc_push_kernel(IpcPeers P, IpcGeom g, const float* __restrict__ src, long long count,
@@ -307,8 +320,7 @@ __global__ __launch_bounds__(IPC_THREADS) void ipc_push_kernel(IpcPeers P, IpcGe
     const long long start = scatter ? (j * chunk < count ? j * chunk : count) : 0;
     const long long len = scatter ? (count - start < chunk ? count - start : chunk) : count;
     float* dst = P.base[j] + dst_off + (long long)g.rank * slot_cap;
-    const float* s = src + start;
-    for (long long e = (long long)blockIdx.x * IPC_THREADS + threadIdx.x; e < len; e += (long long)gridDim.x * IPC_THREADS) dst[e] = s[e];
+    ipc_copy(dst, src + start, len);
     ipc_finish_and_signal(P, g, phase, epoch, ticket, gridDim.x * gridDim.y);
 }
 
@@ -317,9 +329,7 @@ __global__ __launch_bounds__(IPC_THREADS) void ipc_collect_kernel(IpcPeers P, Ip
     float* mine = P.base[g.rank];
     ipc_wait(ipc_hdr(mine), g.world, IPC_PH_AG, epoch);
     const float* gather = mine + g.gather_off;
-    for (int r = 0; r < g.world; ++r)
-        for (long long e = (long long)blockIdx.x * IPC_THREADS + threadIdx.x; e < count; e += (long long)gridDim.x * IPC_THREADS)
-            recv[(long long)r * count + e] = gather[(long long)r * g.ag_cap + e];
+    for (int r = 0; r < g.world; ++r) ipc_copy(recv + (long long)r * count, gather + (long long)r * g.ag_cap, count);
 }
 
 __global__ __launch_bounds__(IPC_THREADS) void ipc_reduce_kernel(IpcPeers P, IpcGeom g, float* __restrict__ buf, long long count,
@@ -346,9 +356,7 @@ __global__ __launch_bounds__(IPC_THREADS) void ipc_pull_kernel(IpcPeers P, IpcGe
     if (j == g.rank) return;
     const long long start = j * chunk < count ? j * chunk : count;
     const long long len = count - start < chunk ? count - start : chunk;
-    const float* src = P.base[j] + g.outbox_off;
-    for (long long e = (long long)blockIdx.x * IPC_THREADS + threadIdx.x; e < len; e += (long long)gridDim.x * IPC_THREADS)
-        buf[start + e] = src[e];
+    ipc_copy(buf + start, P.base[j] + g.outbox_off, len);
 }
 
 struct IpcState {
@@ -386,11 +394,11 @@ int ipc_allgather(void* user, const float* send, float* recv, int64_t count, voi
     if (!st || !st->connected) return fail(MORL_ERR_STATE, "ipc communicator is not connected");
     if (count > st->max_ag) return fail(MORL_ERR_STATE, "all-gather of %lld floats per rank, the region holds %lld", (long long)count, st->max_ag);
     const unsigned epoch = ++st->epoch_ag;
-    const int gx = (int)std::max<long long>(1, std::min<long long>(32, (count + IPC_THREADS * 4 - 1) / (IPC_THREADS * 4)));
+    const int gx = (int)std::max<long long>(1, std::min<long long>(128, (count + IPC_THREADS * 4 - 1) / (IPC_THREADS * 4)));
     hipLaunchKernelGGL(ipc_push_kernel, dim3(gx, st->geom.world), dim3(IPC_THREADS), 0, (hipStream_t)stream, st->peers, st->geom, send,
                        (long long)count, 0ll, 0, st->geom.gather_off, st->geom.ag_cap, (int)IPC_PH_AG, epoch, st->tickets + 0);
     LAUNCH_CHECK("ipc_push(all-gather)");
-    const int gc = (int)std::max<long long>(1, std::min<long long>(64, (count + IPC_THREADS * 2 - 1) / (IPC_THREADS * 2)));
+    const int gc = (int)std::max<long long>(1, std::min<long long>(256, (count + IPC_THREADS * 4 - 1) / (IPC_THREADS * 4)));
     hipLaunchKernelGGL(ipc_collect_kernel, dim3(gc), dim3(IPC_THREADS), 0, (hipStream_t)stream, st->peers, st->geom, recv, (long long)count,
                        epoch);
     LAUNCH_CHECK("ipc_collect");

@@ -99,20 +99,35 @@ class NativeComm:
 
     def _bind_ipc(self, dist, group, handle, max_allreduce: int, max_allgather: int) -> None:
         """The single-hop transport (``morl_comm_ipc_*``): this rank's shared region, the world's 64-byte handles exchanged
-        through ``torch.distributed`` (the side channel), the peers mapped."""
+        through ``torch.distributed`` (the side channel), the peers mapped.  Every step of the set-up is collective-safe: a rank
+        whose local part fails still takes part in the exchange and in the final agreement, and then ALL ranks raise together
+        (nobody is left waiting in a barrier for a rank that has already given up)."""
         if max_allreduce < 1:
             raise ValueError("the ipc transport needs the size of the largest all-reduce (floats)")
+        on_dev = dist.get_backend(group) == "nccl"
+        side = self.device if on_dev else th.device("cpu")
         mine = th.zeros(64, dtype=th.uint8)
+        err = None
         with (th.cuda.device(self.device) if self.device.type == "cuda" else __import__("contextlib").nullcontext()):
-            self.lib.check(self.lib.lib.morl_comm_ipc_create(C.byref(handle), self.rank, self.world, int(max_allreduce),
-                                                             int(max_allgather), C.c_void_p(mine.data_ptr())))
-            self.handle = handle.value
-            on_dev = dist.get_backend(group) == "nccl"
-            every = th.zeros(64 * self.world, dtype=th.uint8, device=self.device if on_dev else "cpu")
-            dist.all_gather_into_tensor(every, mine.to(every.device), group=group)
+            try:
+                self.lib.check(self.lib.lib.morl_comm_ipc_create(C.byref(handle), self.rank, self.world, int(max_allreduce),
+                                                                 int(max_allgather), C.c_void_p(mine.data_ptr())))
+                self.handle = handle.value
+            except RuntimeError as exc:
+                err = exc
+            every = th.zeros(64 * self.world, dtype=th.uint8, device=side)
+            dist.all_gather_into_tensor(every, mine.to(side), group=group)
             every = every.cpu().contiguous()
-            self.lib.check(self.lib.lib.morl_comm_ipc_connect(self.handle, C.c_void_p(every.data_ptr())))
-        dist.barrier(group=group)            # nobody pushes before everybody has mapped everybody
+            if err is None:
+                try:
+                    self.lib.check(self.lib.lib.morl_comm_ipc_connect(self.handle, C.c_void_p(every.data_ptr())))
+                except RuntimeError as exc:
+                    err = exc
+        ok = th.tensor([0 if err is not None else 1], device=side)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)      # also the barrier: nobody pushes before everybody has mapped
+        if int(ok.item()) != 1:
+            self.close()
+            raise RuntimeError(f"single-hop transport unavailable on at least one rank (this rank: {err})")
 
     def check(self) -> None:
         """Raises if a bounded wait of the single-hop collectives ran out (a peer never arrived); synchronises the device."""
