@@ -12,6 +12,10 @@ rank: one all-reduce); both figures are in the line (``strong_scaling_axes``), t
 ``config.shard_axis`` names it.  The weak-scaled job (64 weights per GPU, W = 64*N) is measured right after and reported as
 the clearly labelled sub-record ``weak_scaling`` (``--scaling weak`` makes it the headline).
 
+At N > 1 the line also carries ``collectives_alone`` (the step's two messages timed by themselves over RCCL and over the single-hop
+transport).  ``--gpus N --shared-gpu`` runs the same N > 1 branch with all ranks on cuda:0 (a FUNCTIONAL check of the code path on
+a one-GPU box, labelled as such in the line).
+
 One "step" = one ``Envelope.update()`` gradient step (``envelope.py:267-367``) of the HIP agent on the synthetic
 workload of BASELINE.md section 3: obs dim 32, 3 objectives, 6 actions, net [256]*4, batch 256 x 64 sampled weights
 (16 384 TD rows = 49 152 scalar TD errors per step), replay buffer pre-filled with 20 000 seeded transitions, PER on
