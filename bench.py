@@ -296,7 +296,7 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", 
         step()
     th.cuda.synchronize()
     kinds0 = agent.q_net.ctx.read_timing_kinds()
-    launches_per_step = kinds0["forward"][0] + kinds0["backward"][0]       # chain launches of one step
+    launches_per_step = kinds0["forward"][0] + kinds0["forward2"][0] + kinds0["backward"][0]       # chain launches of one step
     if dist is not None:
         dist.barrier()
         th.cuda.synchronize()
@@ -320,8 +320,10 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", 
         th.cuda.synchronize()
     wall = time.perf_counter() - t0
     kinds = agent.q_net.ctx.read_timing_kinds()
-    n_chain, chain_ms = kinds["forward"][0] + kinds["backward"][0], kinds["forward"][1] + kinds["backward"][1]
+    chain_kinds = ("forward", "forward2", "backward")
+    n_chain, chain_ms = sum(kinds[k][0] for k in chain_kinds), sum(kinds[k][1] for k in chain_kinds)
     agent.q_net.ctx.set_timing(False)
+    lazy_rows = agent.q_net.ctx.lazy_target_rows(agent.q_net.flat)      # distinct (b, j*) pairs of the LAST step (0: eager)
     gpu_ms = e0.elapsed_time(e1)
     if dist is not None:
         t = th.tensor([wall], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=th.float64)
@@ -331,6 +333,7 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", 
            "n_chain": n_chain, "chain_ms": chain_ms, "timed_steps": (len(range(0, steps, timing_every)) if timing_every > 0 else steps if timing_every == -1 else 0),
            "launches_per_step": launches_per_step, "timing_mode": timing_every, "kinds": kinds,
            "fwd_launches_per_step": kinds0["forward"][0], "transport": transport, "axis": axis if sharded else None,
+           "lazy_target_rows": lazy_rows,
            "loss": agent.last_loss(), "engine": agent.q_net.ctx.engine, "W": W, "B": B}
     del agent
     return res
@@ -418,18 +421,22 @@ def _roofline(res, rows_rank):
     the hoisted training forward of a sharded step -- and the backward-dX launch): algorithmic flop of the timed launches
     over their summed HIP-event duration."""
     n_chain, chain_ms, timed_steps = res["n_chain"], res["chain_ms"], res["timed_steps"]
-    chain_flop_step = rows_rank * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW)
+    # algorithmic flop of ONE launch of each kind (this rank's rows): the three-pass forward launch (or the launches of a sharded
+    # step), the two-pass forward launch of a lazily evaluated step, the backward-dX launch, the weight-gradient launch
+    flop_kind = {"forward": rows_rank * 3 * FWD_FLOP_ROW / max(1, res.get("fwd_launches_per_step") or 1),
+                 "forward2": rows_rank * 2 * FWD_FLOP_ROW, "backward": rows_rank * BWD_DX_FLOP_ROW, "dw": rows_rank * FWD_FLOP_ROW}
+    kinds = res.get("kinds") or {}
+    chain_flop = sum(flop_kind[k] * kinds[k][0] for k in ("forward", "forward2", "backward") if k in kinds)
     launches_per_step = res.get("launches_per_step") or (n_chain / timed_steps if timed_steps else 0)
-    flop_per_launch = chain_flop_step / launches_per_step if launches_per_step else float("nan")
+    flop_per_launch = chain_flop / n_chain if n_chain else float("nan")
     avg_launch_s = (chain_ms * 1e-3 / n_chain) if n_chain else float("nan")
-    achieved = flop_per_launch / avg_launch_s / 1e12 if n_chain else float("nan")
+    achieved = chain_flop / (chain_ms * 1e-3) / 1e12 if n_chain else float("nan")
     traffic = measured_chain_traffic()
     # the three GEMM kernels of the step one by one (the launches of a kind that were bracketed; algorithmic flop of this rank's
     # rows over their mean duration): forward = the step's forward launch(es) together, 3 passes
     per_kernel = {}
-    flop_kind = {"forward": rows_rank * 3 * FWD_FLOP_ROW / max(1, res.get("fwd_launches_per_step") or 1),
-                 "backward": rows_rank * BWD_DX_FLOP_ROW, "dw": rows_rank * FWD_FLOP_ROW}
-    name_kind = {"forward": "mlp_chain forward (3 passes)", "backward": "mlp_chain backward-dX", "dw": "dw_tiles (dW, db)"}
+    name_kind = {"forward": "mlp_chain forward (3 passes)", "forward2": "mlp_chain forward (2 passes: online next-state + training)",
+                 "backward": "mlp_chain backward-dX", "dw": "dw_tiles (dW, db)"}
     for k, (n_k, ms_k) in (res.get("kinds") or {}).items():
         if n_k:
             us = ms_k * 1e3 / n_k
@@ -584,7 +591,11 @@ def main():
                     "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
                     "gpu_ms_per_step_events": res["gpu_ms_per_step_events"], "last_loss": res["loss"],
                     "roofline": _roofline(res, rows_step // parts),
-                    "whole_step_algorithmic_tflops": rows_step * (4 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) / (ms * 1e-3) / 1e12}
+                    "lazy_target_rows_last_step": res.get("lazy_target_rows"),
+                    "whole_step_algorithmic_tflops": rows_step * (4 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) / (ms * 1e-3) / 1e12,
+                    "whole_step_executed_tflops": ((rows_step * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) +
+                                                    parts * res["lazy_target_rows"] * FWD_FLOP_ROW) if res.get("lazy_target_rows")
+                                                   else rows_step * (4 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW)) / (ms * 1e-3) / 1e12}
 
         single = world == 1 and not a.force_shard
         scaling = "single" if world == 1 else a.scaling        # (one GPU: neither weak nor strong -- nothing is split)
@@ -629,8 +640,16 @@ def main():
             "gpu_ms_per_step_events": h["gpu_ms_per_step_events"],
             "host_enqueue_ms_per_step": h["host_enqueue_ms_per_step"],
             "last_loss": h["last_loss"],
-            "roofline": dict(h["roofline"], whole_step_algorithmic_tflops=h["whole_step_algorithmic_tflops"]),
+            "roofline": dict(h["roofline"], whole_step_algorithmic_tflops=h["whole_step_algorithmic_tflops"],
+                             whole_step_executed_tflops=h["whole_step_executed_tflops"]),
+            "lazy_target_rows_last_step": h["lazy_target_rows_last_step"],
         }
+        if h["lazy_target_rows_last_step"]:
+            out["config"]["target_evaluation"] = (
+                f"lazy: the target network is evaluated after the arg-max, on the {h['lazy_target_rows_last_step']} distinct "
+                f"(transition, weight) pairs the TD rows of the last step selected (of {B * W_head // parts} per rank) -- same values "
+                "as the full target slab; whole_step_algorithmic_tflops counts SURVEY 8(d)'s five full passes, "
+                "whole_step_executed_tflops what ran; MORL_LAZY_TARGETS=0 evaluates the slab eagerly")
         if no_ramp is not None and "error" not in no_ramp:
             out["ms_per_step_no_ramp"] = no_ramp["wall"] * 1e3 / a.steps
         if world > 1 or a.force_shard:

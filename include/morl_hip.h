@@ -126,10 +126,11 @@ int morl_ctx_read_timing(morl_ctx* ctx, int* n_launches, double* total_ms);
  * (the step's three passes, or the slabs / training-forward launches of a sharded step), the backward-dX chain launch and the
  * weight-gradient launch (dw_tiles; bracketed too, so in the rotating mode the three take turns).  morl_ctx_read_timing returns
  * the two chain kinds summed.  Either call clears the record. */
-#define MORL_TIMED_FORWARD 0
+#define MORL_TIMED_FORWARD 0     /* three passes in the launch (or the launches of a sharded step) */
 #define MORL_TIMED_BACKWARD 1
 #define MORL_TIMED_DW 2
-#define MORL_TIMED_KINDS 3
+#define MORL_TIMED_FORWARD2 3    /* the two-pass forward launch of a lazily evaluated step (online next-state + training pass) */
+#define MORL_TIMED_KINDS 4
 int morl_ctx_read_timing_kinds(morl_ctx* ctx, int* n_launches, double* total_ms);
 /* Parity-test aid: out [rows][dims[layer]] <- the post-ReLU activations of hidden layer `layer` (1 .. n_layers - 1) that the last
  * training forward on this context saved for the weight-gradient GEMM; out > 0 is the ReLU mask its backward pass applied.
@@ -168,6 +169,16 @@ int morl_envelope_prepare(morl_ctx* ctx, const float* params_online, const float
                           int64_t capacity, int B, int D, int R, int action_dim, float* obs, float* next_obs, float* rewards,
                           float* dones, float* actions_f, int32_t* actions_i, int64_t* idx_out, const float* aux_src,
                           float* aux_dst, int aux_floats, void* stream);
+/* Lazy target evaluation (default on; MORL_LAZY_TARGETS=0): envelope_target (envelope.py:404-440) evaluates the TARGET network on
+ * every (s'_b, w_j) row, but a TD row (i, b) only reads it at its own arg-max (j*, a*) -- and the W rows of a transition agree on a
+ * handful of j* (1 546 distinct (b, j*) pairs of 16 384 at the flagship shape).  morl_envelope_update on the layer-fused engine
+ * therefore runs: forward launch with the online next-state pass and the training pass -> arg-max over the online slab -> the
+ * distinct (b, j*) pairs compacted -> the target network on THOSE rows (16-row tiles, device-side row count) -> TD target / loss
+ * gradient.  Same values as the eager form (a row's Q does not depend on which rows share its tile); the eager form runs when the
+ * caller asks for out->q_target_next, for the DDQN target, in the weight-sharded step and on the per-layer engine.
+ * _set_lazy_targets returns the previous setting; _lazy_target_rows the pair count of the last lazy step (synchronises `stream`). */
+int morl_ctx_set_lazy_targets(morl_ctx* ctx, int enable);
+int morl_ctx_lazy_target_rows(morl_ctx* ctx, int* rows, void* stream);
 /* The shadow copies made by morl_envelope_prepare are consumed ONLY by the gradient step that directly follows it
  * (morl_envelope_update / morl_envelope_slabs / the one-call sharded steps); every other entry point re-makes its copies.  A
  * caller that writes the parameter buffers in place between prepare and that step (morl_polyak, load_state_dict, copy_) calls

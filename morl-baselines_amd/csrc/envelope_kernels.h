@@ -83,6 +83,16 @@ struct EnvelopeTdArgs {
     int fma_scal;           // 1: scalarise with an fma chain  fma(w_r, q_r, ...fma(w_1, q_1, w_0 * q_0))  -- what torch's unbatched
                             // einsum("r,bar->ba") of Envelope.max_action (envelope.py:389-402) evaluates to -- instead of
                             // separately rounded products and sums (the batched einsum of the TD target)
+    // Lazy target evaluation (morl_envelope_update's default on the layer-fused engines): a TD row only ever reads the target
+    // network at ITS arg-max (j*, a*), and the rows of a transition agree on a handful of j* (1 546 distinct (b, j*) pairs of
+    // 16 384 at the flagship shape), so the target network is evaluated AFTER the arg-max, on the distinct pairs only.
+    //   phase 1  arg-max only: best_io[row] = flattened (j*, a*); need[b * W + j*] = 1          (qt, q_main unused)
+    //   phase 2  TD only:      best_io read back; the target row of (b, j) is qt + slot[b * W + j] * A * R (compact rows)
+    //   phase 0  both in one launch from full slabs (the weight-sharded step, the per-layer engine, parity outputs)
+    int phase;
+    int32_t* best_io;       // [rows] internal row order (see bmajor)
+    unsigned char* need;    // [B * W] flags, cleared by the compaction kernel
+    const int32_t* slot;    // [B * W] compact row of pair (b, j), phase 2
     float* zero_ptr;        // optional: zero_ptr[k] = 0 for k in [0, zero_n) outside [keep_lo, keep_hi) -- the batch-sharded step's
     int zero_n, keep_lo, keep_hi;   // "the other ranks' priorities are zeros" (one memset launch less per rank step)
     int bmajor;             // internal row order of q_main / dq: 0 = row i * B + b (reference order, envelope.py:284-291),
@@ -158,12 +168,13 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
     const bool train = p.q_main != nullptr;
     const int act = train ? p.actions[b] : 0;
     const int pf = p.part_floats > 0 ? p.part_floats : slab;
-    for (int e = (int)threadIdx.x; e < slab; e += (int)blockDim.x) {
-        const int g = e / pf;
-        const size_t off = (size_t)g * (size_t)p.part_stride + (size_t)b * pf + (size_t)(e - g * pf);
-        s_qo[e] = p.qo[off];
-        s_qt[e] = p.qt[off];
-    }
+    if (p.phase != 2)
+        for (int e = (int)threadIdx.x; e < slab; e += (int)blockDim.x) {
+            const int g = e / pf;
+            const size_t off = (size_t)g * (size_t)p.part_stride + (size_t)b * pf + (size_t)(e - g * pf);
+            s_qo[e] = p.qo[off];
+            if (p.phase == 0) s_qt[e] = p.qt[off];
+        }
     for (int e = (int)threadIdx.x; e < nI * R; e += (int)blockDim.x) {
         s_w[e] = generic ? p.row_weights[(size_t)b * R + e] : p.weights[e];
         if (train) {
@@ -187,7 +198,9 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
 #pragma unroll
         for (int r = 0; r < MORL_MAX_OBJ; ++r) wi[r] = (live && r < R) ? s_w[i * R + r] : 0.f;
         const int n_c = p.diag_only ? A : W * A;
-        if (p.argmax_mode == 1) {
+        if (p.phase == 2) {
+            // the arg-max was taken by an earlier launch (phase 1)
+        } else if (p.argmax_mode == 1) {
             // ---- shuffle form: wave q owns the rows ib + q, ib + q + nw, ...; its lanes stride the (j, a) candidates of ONE
             // row (LDS reads at a stride of R words: conflict-free for the odd R = 3, two-way for even R), keep their own first
             // maximum, and a six-stage butterfly over (value, index) leaves the row's first maximum in every lane
@@ -239,16 +252,27 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
         __syncthreads();
         }
         if (wave == 0 && live) {
-            // merge the slices in candidate order: strictly greater replaces, so the first maximum wins
-            float bv = s_pv[0][lane];
-            int bc = s_pc[0][lane];
-            for (int q = 1; q < nw; ++q) {
-                const float v = s_pv[q][lane];
-                const int cc = s_pc[q][lane];
-                if (cc != 0x7fffffff && (bc == 0x7fffffff || v > bv)) { bv = v; bc = cc; }
+            const size_t irow = p.bmajor ? (size_t)b * nI + i : (size_t)i * p.B + b;     // internal row of (i, b)
+            int bc;
+            if (p.phase == 2) {
+                bc = p.best_io[irow];
+            } else {
+                // merge the slices in candidate order: strictly greater replaces, so the first maximum wins
+                float bv = s_pv[0][lane];
+                bc = s_pc[0][lane];
+                for (int q = 1; q < nw; ++q) {
+                    const float v = s_pv[q][lane];
+                    const int cc = s_pc[q][lane];
+                    if (cc != 0x7fffffff && (bc == 0x7fffffff || v > bv)) { bv = v; bc = cc; }
+                }
             }
             s_best[i] = bc;
-            const float* qt = s_qt + (size_t)bc * R;
+            if (p.phase == 1) {
+                p.best_io[irow] = bc;
+                p.need[(size_t)b * W + bc / A] = 1;      // (several rows may mark the same pair: same value, benign)
+            } else {
+            const float* qt = (p.phase == 2) ? p.qt + ((size_t)p.slot[(size_t)b * W + bc / A] * A + (bc % A)) * R
+                                             : s_qt + (size_t)bc * R;
             float td[MORL_MAX_OBJ];
             float wq = 0.f, wtq = 0.f;
 #pragma unroll
@@ -284,9 +308,11 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
                     p.priority[b] = fabsf(pr);
                 }
             }
+            }
         }
         __syncthreads();
     }
+    if (p.phase == 1) return;            // (uniform: the arg-max launch writes nothing else)
     // loss partials: only wave 0 accumulated; butterfly sum over its lanes (fixed order)
     if (wave == 0) {
         acc_mse = wave_sum(acc_mse);
@@ -324,6 +350,57 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
         p.loss_part[(size_t)blockIdx.x * 2 + 0] = s_red[0][0];
         p.loss_part[(size_t)blockIdx.x * 2 + 1] = s_red[0][1];
     }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Lazy target evaluation, step 2 of 4: the flags the arg-max launch left in need[b * W + j] -> the list of distinct pairs in
+// ascending order (pairs[k] = b * W + j), the inverse map (slot[b * W + j] = k), their number; the flags are cleared for the
+// next step.  One workgroup: 16 384 flags are four rounds of a 1 024-thread two-level scan.
+// ----------------------------------------------------------------------------------------------
+constexpr int ENV_COMPACT_THREADS = 1024;
+
+__global__ __launch_bounds__(ENV_COMPACT_THREADS) void envelope_compact_kernel(unsigned char* __restrict__ need, int n_flags,
+                                                                               int32_t* __restrict__ pairs, int32_t* __restrict__ slot,
+                                                                               int32_t* __restrict__ count) {
+    __shared__ int s_cnt[ENV_COMPACT_THREADS];
+    __shared__ int s_wave[ENV_COMPACT_THREADS / kWave + 1];
+    const int tid = (int)threadIdx.x;
+    constexpr int PER = 4;
+    int base = 0;
+    for (int c0 = 0; c0 < n_flags; c0 += ENV_COMPACT_THREADS * PER) {
+        int f[PER], mine = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = c0 + tid * PER + u;
+            f[u] = (idx < n_flags) ? (need[idx] != 0) : 0;
+            mine += f[u];
+        }
+        s_cnt[tid] = mine;
+        __syncthreads();
+        if (tid < ENV_COMPACT_THREADS / kWave) {                   // one thread per wave-sized group: its total
+            int t = 0;
+            for (int k = 0; k < kWave; ++k) t += s_cnt[tid * kWave + k];
+            s_wave[tid] = t;
+        }
+        __syncthreads();
+        int off = base;
+        for (int g = 0; g < tid / kWave; ++g) off += s_wave[g];
+        for (int k = (tid / kWave) * kWave; k < tid; ++k) off += s_cnt[k];
+        int total = 0;
+        for (int g = 0; g < ENV_COMPACT_THREADS / kWave; ++g) total += s_wave[g];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int idx = c0 + tid * PER + u;
+            if (idx < n_flags) {
+                slot[idx] = f[u] ? off : -1;
+                if (f[u]) { pairs[off] = idx; ++off; }
+                need[idx] = 0;
+            }
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) *count = base;
 }
 
 }  // namespace morl

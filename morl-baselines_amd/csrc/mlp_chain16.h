@@ -116,6 +116,7 @@ template <bool K4>
 __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, float* sAct, int g) {
     constexpr int N_PIECES = 4;                       // 16 rows x 64 quads / 256 threads
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_id();
+    const int n_rows = p.rows_dev ? min(p.rows, *p.rows_dev) : p.rows;        // (device-side count: in_mode 3)
     const int kq = lane >> 4, j = lane & 15;
     const int col0 = wave * 64 + 4 * j;               // first of this lane's four physical output columns (wide steps)
 
@@ -127,17 +128,21 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
 
     // ---- input tile -> sAct[m][k], zero-padded to the columns the first step multiplies --------------------------------
     {
-        const int K0 = (p.in_mode == 0) ? (p.D + p.R) : p.K0;
+        const bool cat_mode = p.in_mode == 0 || p.in_mode == 3;
+        const int K0 = cat_mode ? (p.D + p.R) : p.K0;
         const int K0pad = first_wide ? min(CH_MAXW, (K0 + 63) & ~63) : CH_MAXW;
         const int m = tid & 15, q = tid >> 4;          // 16 threads per row, 16 columns each
         const int row = row0 + m;
+        const bool row_ok = row < n_rows;
         int b = row, w = row;
         if (p.in_mode == 0) {
             if (p.row_order == 0) { b = row / p.W; w = row - b * p.W; }
             else if (p.row_order == 1) { w = row / p.B; b = row - w * p.B; }
+        } else if (p.in_mode == 3) {
+            const int flat = row_ok ? p.pairs[row] : 0;
+            b = flat / p.W; w = flat - b * p.W;
         }
-        const bool row_ok = row < p.rows;
-        const float* src_a = (p.in_mode == 0) ? p.obs + (size_t)b * p.D
+        const float* src_a = cat_mode ? p.obs + (size_t)b * p.D
                                               : p.src + (p.nb > 1 ? (g / p.src_div) * p.sSrc : 0) + (size_t)row * p.ldsrc;
         const float* src_w = p.weights + (size_t)w * p.R;
         const int kb = q * 16;
@@ -148,7 +153,7 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
                 const int k = kb + u;
                 float x = 0.f;
                 if (row_ok && k < K0) {
-                    if (p.in_mode == 0) x = (k < p.D) ? src_a[k] : src_w[k - p.D];
+                    if (cat_mode) x = (k < p.D) ? src_a[k] : src_w[k - p.D];
                     else x = src_a[k];
                 }
                 v[u] = x;
@@ -257,7 +262,7 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
             }
             if (st.bits_out != nullptr) reinterpret_cast<unsigned short*>(st.bits_out)[bits_idx] = (unsigned short)bits_w;
             do_copy = st.out != nullptr;
-            if (do_copy) cdst = c2_copy_dst(st.out + g * st.sOut, st.ldout, N, p.rows, row0, tid);
+            if (do_copy) cdst = c2_copy_dst(st.out + g * st.sOut, st.ldout, N, n_rows, row0, tid);
         } else {
             // ======================= narrow step: split-K over the four waves ==================================
             f32x4 hacc[2];
@@ -309,7 +314,7 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
                 const int r = 2 * (wave & 1) + q;
                 const int m = kq * 4 + r;
                 const int row = row0 + m;
-                const bool ok = n < N && row < p.rows;
+                const bool ok = n < N && row < n_rows;
                 float v = red[q] + bias;
                 if (st.relu) v = fmaxf(v, 0.f);
                 if (st.mask != nullptr) v = (ok && st.mask[(size_t)row * st.ldmask + n] > 0.f) ? v : 0.f;
@@ -343,6 +348,7 @@ static __global__ __launch_bounds__(CH_THREADS, 4) void mlp_chain16_kernel(Chain
     int lt = b - m.tile_start[q], g = 0;
     const int tpn = (m.p[q].rows + C16_TM - 1) / C16_TM;          // tiles per network
     if (m.p[q].nb > 1) { g = lt / tpn; lt -= g * tpn; }
+    if (m.p[q].rows_dev != nullptr && lt * C16_TM >= *m.p[q].rows_dev) return;      // (workgroup-uniform)
     if (m.p[q].fast == 1) mlp_chain16_body<true>(m.p[q], lt * C16_TM, sAct, g);
     else mlp_chain16_body<false>(m.p[q], lt * C16_TM, sAct, g);
 }

@@ -190,6 +190,18 @@ struct morl_ctx {
     std::vector<hipEvent_t> ev_start, ev_stop;
     std::vector<int> ev_kind;            // MORL_TIMED_* of each recorded launch
     int last_B = 0, last_WI = 0;         // shape of the last training forward (morl_ctx_debug_hidden)
+    // lazy target evaluation (envelope_kernels.h, EnvelopeTdArgs::phase): scratch + the one-shot hand-over from
+    // morl_envelope_update to update_core
+    bool lazy_targets = true;            // MORL_LAZY_TARGETS=0 / morl_ctx_set_lazy_targets: evaluate the whole target slab instead
+    int32_t* lz_best = nullptr;          // [max_rows] flattened (j*, a*) per TD row
+    unsigned char* lz_need = nullptr;    // [max_rows] pair flags (kept zero between steps by the compaction kernel)
+    int32_t* lz_slot = nullptr;          // [max_rows] pair -> compact row
+    int32_t* lz_pairs = nullptr;         // [max_rows] compact row -> pair
+    int32_t* lz_count = nullptr;         // [1] distinct pairs of the last step
+    int timing_kind_override = -1;       // MORL_TIMED_* of the next bracketed chain launch (-1: by its arguments)
+    bool lz_now = false;                 // this step runs lazily: the three below are what the target launch needs
+    const float* lz_params_target = nullptr;
+    const float* lz_next_obs = nullptr;
     float* td_zero_ptr = nullptr;        // one-shot request of the batch-sharded step to the next TD launch: zero this range ...
     int td_zero_n = 0, td_keep_lo = 0, td_keep_hi = 0;   // ... except [keep_lo, keep_hi) (the rank's own priorities)
     int main_rows = -1;                  // rows of a hoisted training forward (morl_envelope_main_forward), -1 = none
@@ -245,6 +257,11 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     }
     if (c->sumsq_part) (void)hipFree(c->sumsq_part);
     if (c->loss_part) (void)hipFree(c->loss_part);
+    if (c->lz_best) (void)hipFree(c->lz_best);
+    if (c->lz_need) (void)hipFree(c->lz_need);
+    if (c->lz_slot) (void)hipFree(c->lz_slot);
+    if (c->lz_pairs) (void)hipFree(c->lz_pairs);
+    if (c->lz_count) (void)hipFree(c->lz_count);
     for (hipEvent_t e : c->ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_stop) (void)hipEventDestroy(e);
     for (int l = 0; l < MORL_MAX_LAYERS; ++l)
@@ -359,6 +376,16 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     }
     for (int l = 1; l < c->L; ++l) ALLOC(relu_bits[l], ((size_t)c->max_rows + 63) / 64 * CH_THREADS);
     ALLOC(zeros, 16);
+    ALLOC(lz_best, rows);
+    ALLOC(lz_need, rows);
+    ALLOC(lz_slot, rows);
+    ALLOC(lz_pairs, rows);
+    ALLOC(lz_count, 4);
+    if (hipMemset(c->lz_need, 0, rows) != hipSuccess || hipMemset(c->lz_count, 0, 16) != hipSuccess) {
+        morl_ctx_destroy(c);
+        return fail(MORL_ERR_HIP, "hipMemset failed");
+    }
+    if (const char* e = getenv("MORL_LAZY_TARGETS")) c->lazy_targets = atoi(e) != 0;
     ALLOC(cu_tickets, C2_CU_SLOTS);
     if (hipMemsetAsync(c->cu_tickets, 0, C2_CU_SLOTS * sizeof(unsigned int), nullptr) != hipSuccess) { morl_ctx_destroy(c); return fail(MORL_ERR_HIP, "zero-fill failed"); }
     {
@@ -553,7 +580,8 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
     m.stagger = c->chain_stagger;
     m.cu_tickets = c->cu_tickets;
     // (backward chain: the one whose input is the TD kernel's dLoss/dQ)
-    const int kind = (chains[0].in_mode == 2 || (chains[0].in_mode == 1 && chains[0].src == c->dq)) ? MORL_TIMED_BACKWARD
+    const int kind = c->timing_kind_override >= 0 ? c->timing_kind_override
+                     : (chains[0].in_mode == 2 || (chains[0].in_mode == 1 && chains[0].src == c->dq)) ? MORL_TIMED_BACKWARD
                                                                                                        : MORL_TIMED_FORWARD;
     int slot = -1, rc_t;
     if ((rc_t = timing_open(c, kind, s, &slot))) return rc_t;
@@ -742,8 +770,8 @@ extern "C" int morl_ctx_read_timing(morl_ctx* c, int* n_launches, double* total_
     double ms[MORL_TIMED_KINDS];
     const int rc = morl_ctx_read_timing_kinds(c, n, ms);
     if (rc) return rc;
-    *n_launches = n[MORL_TIMED_FORWARD] + n[MORL_TIMED_BACKWARD];
-    *total_ms = ms[MORL_TIMED_FORWARD] + ms[MORL_TIMED_BACKWARD];
+    *n_launches = n[MORL_TIMED_FORWARD] + n[MORL_TIMED_FORWARD2] + n[MORL_TIMED_BACKWARD];
+    *total_ms = ms[MORL_TIMED_FORWARD] + ms[MORL_TIMED_FORWARD2] + ms[MORL_TIMED_BACKWARD];
     return MORL_OK;
 }
 
@@ -831,6 +859,23 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
     LAUNCH_CHECK("step_prologue");
     c->fresh_online = params_online;
     c->fresh_target = params_target;
+    return MORL_OK;
+}
+
+extern "C" int morl_ctx_set_lazy_targets(morl_ctx* c, int enable) {
+    if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
+    const int was = c->lazy_targets ? 1 : 0;
+    c->lazy_targets = enable != 0;
+    return was;
+}
+
+// distinct (transition, weight) pairs whose target row the LAST lazily evaluated step computed (0 if none ran); synchronises
+extern "C" int morl_ctx_lazy_target_rows(morl_ctx* c, int* rows, void* stream) {
+    if (!c || !rows) return fail(MORL_ERR_ARG, "NULL argument");
+    int32_t n = 0;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(&n, c->lz_count, sizeof(n), hipMemcpyDeviceToHost));
+    *rows = (int)n;
     return MORL_OK;
 }
 
@@ -1002,7 +1047,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     // (chain_td.h: every tile computes the dLoss/dQ rows it is about to propagate); otherwise envelope_td_kernel runs in front
     // of the backward pass: one lane per TD row of a transition, 64 rows per workgroup pass
     const float lam_td = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
-    const bool td_in_chain = c->use_fused && c->td_fused && L >= 2 && !chain_rows_take_16(rows) &&
+    const bool td_in_chain = !c->lz_now && c->use_fused && c->td_fused && L >= 2 && !chain_rows_take_16(rows) &&
                              ctd_slab_ok((long long)W * A * R, WI, C2_TM * C2_LDK);
     int td_groups = std::max(1, std::min(4, (WI + 63) / 64));
     int n_loss = B * td_groups;
@@ -1027,6 +1072,8 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         n_loss = (rows + 15) / 16;
     } else
     {
+        const bool lazy = c->lz_now;
+        c->lz_now = false;
         EnvelopeTdArgs p{};
     p.argmax_mode = td_argmax_mode();
         p.qo = qo; p.qt = qt; p.weights = weights_i; p.q_main = c->qm;
@@ -1054,6 +1101,32 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         const long long n_cand = cfg->envelope ? (long long)W * A : A;
         int td_waves = n_cand >= 256 ? 16 : (n_cand >= 64 ? 8 : 4);
         if (const char* e = getenv("MORL_TD_WAVES")) td_waves = std::max(1, std::min(ENV_MAX_WAVES, atoi(e)));
+        if (lazy) {
+            // 1. arg-max on the online slab: best (j*, a*) per TD row, the needed (b, j*) pairs flagged
+            EnvelopeTdArgs a1 = p;
+            a1.phase = 1; a1.best_io = c->lz_best; a1.need = c->lz_need;
+            a1.zero_ptr = nullptr;
+            hipLaunchKernelGGL(envelope_td_kernel, dim3(B * td_groups), dim3(64 * td_waves), 0, s, a1);
+            LAUNCH_CHECK("envelope_argmax");
+            // 2. the distinct pairs, in ascending order, and the inverse map
+            hipLaunchKernelGGL(envelope_compact_kernel, dim3(1), dim3(ENV_COMPACT_THREADS), 0, s, c->lz_need, B * W, c->lz_pairs,
+                               c->lz_slot, c->lz_count);
+            LAUNCH_CHECK("envelope_compact");
+            // 3. the target network on those rows only: 16-row tiles sized for the worst case, tiles beyond the count exit at once
+            {
+                ChainArgs t = make_forward_chain(c, c->lz_params_target, c->wt_target, c->lz_next_obs, weights_i, B, W, 0, B * W, false,
+                                                 c->qt, A * R);
+                t.in_mode = 3;
+                t.rows_dev = c->lz_count;
+                t.pairs = c->lz_pairs;
+                Chain16Multi m16{};
+                const int tiles = chain16_fill(m16, &t, 1);
+                hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
+                LAUNCH_CHECK("mlp_chain16(lazy targets)");
+            }
+            // 4. TD target, loss gradient, priorities from the compact target rows
+            p.phase = 2; p.best_io = c->lz_best; p.slot = c->lz_slot; p.qt = c->qt;
+        }
         hipLaunchKernelGGL(envelope_td_kernel, dim3(B * td_groups), dim3(64 * td_waves), 0, s, p);
         LAUNCH_CHECK("envelope_td");
     }
@@ -1343,7 +1416,21 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
                                                       c->ldq, true);
             main_chain.x0_out = c->x0m;      // layer-0 input of the dW GEMM, written by the pass that assembles it anyway
             main_chain.ldx0 = c->ld0;
-            if ((rc = chain_forward_x3(
+            // Lazy target evaluation: the target network is only ever read at a TD row's arg-max (j*, a*), and the rows of a
+            // transition agree on a handful of j* -- so this launch carries the online next-state pass and the training pass only,
+            // the arg-max runs on the online slab, and the target network is evaluated afterwards on the distinct (b, j*) pairs
+            // (update_core; 1 546 of 16 384 rows at the flagship shape).  Not when the caller asks for the whole target slab.
+            c->lz_now = c->lazy_targets && cfg->envelope && W >= 2 && !out->q_target_next;
+            if (c->lz_now) {
+                const ChainArgs two[2] = {
+                    make_forward_chain(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR), main_chain};
+                c->timing_kind_override = MORL_TIMED_FORWARD2;
+                rc = chain_forward_multi(c, two, 2, s);
+                c->timing_kind_override = -1;
+                if (rc) { c->lz_now = false; return rc; }
+                c->lz_params_target = params_target;
+                c->lz_next_obs = next_obs;
+            } else if ((rc = chain_forward_x3(
                      c, make_forward_chain(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR),
                      make_forward_chain(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR),
                      main_chain, s)))

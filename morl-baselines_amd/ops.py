@@ -43,6 +43,16 @@ class QNetContext:
         -1: one launch of every step, the launches of a step taking turns)."""
         self.lib.check(self.lib.lib.morl_ctx_set_timing(self.handle, int(every)))
 
+    def set_lazy_targets(self, enable: bool) -> bool:
+        """Lazy target evaluation of ``envelope_update`` on this context (``morl_ctx_set_lazy_targets``); returns the old setting."""
+        return bool(self.lib.lib.morl_ctx_set_lazy_targets(self.handle, int(bool(enable))))
+
+    def lazy_target_rows(self, like: th.Tensor) -> int:
+        """Distinct (transition, weight) pairs the last lazily evaluated step ran the target network on (synchronises)."""
+        n = C.c_int(0)
+        self.lib.check(self.lib.lib.morl_ctx_lazy_target_rows(self.handle, C.byref(n), self.lib.stream_of(like)))
+        return n.value
+
     def invalidate_shadows(self) -> None:
         """Drop the K-major shadow copies a ``sample(prepare=...)`` launch made (``morl_ctx_invalidate_shadows``): for callers
         that write the parameter buffers in place between that launch and the step it prepared."""
@@ -63,9 +73,9 @@ class QNetContext:
 
     def read_timing_kinds(self):
         """{"forward" | "backward" | "dw": (launches, summed ms)} of the bracketed launches; synchronises, clears the record."""
-        n, ms = (C.c_int * 3)(), (C.c_double * 3)()
+        n, ms = (C.c_int * 4)(), (C.c_double * 4)()
         self.lib.check(self.lib.lib.morl_ctx_read_timing_kinds(self.handle, n, ms))
-        return {k: (n[i], ms[i]) for i, k in enumerate(("forward", "backward", "dw"))}
+        return {k: (n[i], ms[i]) for i, k in enumerate(("forward", "backward", "dw", "forward2"))}
 
     def layer_slices(self):
         """[(w_offset, (out, in), b_offset, out)] of the flat parameter layout."""
@@ -338,7 +348,8 @@ def envelope_update(ctx: QNetContext, params_online: th.Tensor, params_target: t
         res["pref"] = th.empty((W * B,), dtype=th.int32, device=dev)
         res["ac"] = th.empty((W * B,), dtype=th.int32, device=dev)
         res["q_online_next"] = th.empty((B, W, A, R), dtype=th.float32, device=dev)
-        res["q_target_next"] = th.empty((B, W, A, R), dtype=th.float32, device=dev)
+        if debug != "lazy":          # (asking for the whole target slab makes the step evaluate it eagerly: include/morl_hip.h)
+            res["q_target_next"] = th.empty((B, W, A, R), dtype=th.float32, device=dev)
         res["q_values"] = th.empty((W * B, A, R), dtype=th.float32, device=dev)
     cfg = UpdateCfg(gamma=gamma, homotopy_lambda=homotopy_lambda,
                     max_grad_norm=-1.0 if max_grad_norm is None else float(max_grad_norm), lr=lr, beta1=beta1,

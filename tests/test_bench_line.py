@@ -37,6 +37,12 @@ def test_roofline_record_arithmetic(bench):
     flop_launch = rows * (3 * bench.FWD_FLOP_ROW + bench.BWD_DX_FLOP_ROW) / 2
     assert r["algorithmic_flop_per_launch"] == pytest.approx(flop_launch)
     assert r["achieved"] == pytest.approx(flop_launch / (0.126e-3) / 1e12, rel=1e-9)
+    # a lazily evaluated step: the forward launch carries two passes, and is priced as two
+    res2 = dict(res, kinds={"forward2": (7, 7 * 0.124), "backward": (7, 7 * 0.067), "dw": (6, 6 * 0.070)},
+                n_chain=14, chain_ms=7 * 0.124 + 7 * 0.067)
+    r2 = bench._roofline(res2, rows)
+    assert r2["achieved"] == pytest.approx(rows * (2 * bench.FWD_FLOP_ROW + bench.BWD_DX_FLOP_ROW) / 2 / (0.0955e-3) / 1e12, rel=1e-9)
+    assert r2["per_kernel"]["forward2"]["achieved"] == pytest.approx(rows * 2 * bench.FWD_FLOP_ROW / 124e-6 / 1e12)
     assert r["frac"] == pytest.approx(r["achieved"] / 157.3) and 0.0 < r["frac"] < 1.0
     pk = r["per_kernel"]
     assert pk["forward"]["achieved"] == pytest.approx(rows * 3 * bench.FWD_FLOP_ROW / 185e-6 / 1e12)

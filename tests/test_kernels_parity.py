@@ -439,3 +439,49 @@ def test_greedy_actions_follow_the_fma_chain(be):
         s = f32(q[..., r] * wd[:, None, r] + s)                                           # one rounding: an fma
     assert np.array_equal(ac, s.argmax(1))
     ctx.close()
+
+
+@pytest.mark.parametrize("c", [c for c in CASES if c.envelope] +
+                         [__import__("cases").Case("ragged", B=37, W=5, D=9, A=4, R=3, arch=(48, 40), homotopy_lambda=0.2, seed=21)],
+                         ids=lambda c: c.name)
+def test_lazy_target_evaluation_equals_the_eager_one(be, c):
+    """``morl_envelope_update`` evaluates the TARGET network lazily by default: arg-max over the online slab first, then the target
+    network on the distinct (transition, weight) pairs the TD rows actually selected (``envelope.py:429-439`` only ever gathers
+    those).  Same targets, indices, priorities, gradients and stepped parameters, bit for bit at sizes where both forms run the
+    same tiling (the emulator's), and the row count it reports is exactly the number of distinct selected pairs."""
+    lib, dev, is_sim = be
+    inp = make_inputs(c)
+    ctx_rows = {}
+
+    def run(debug):
+        ctx = ops.QNetContext(c.D, c.R, c.A, c.arch, c.B, c.W, lib=lib)
+        t = dict(po=flat(inp["online"]).to(dev), pt=flat(inp["target"]).to(dev), m=flat(inp["exp_avg"]).to(dev),
+                 v=flat(inp["exp_avg_sq"]).to(dev))
+        t["g"] = th.zeros_like(t["po"])
+        res = ops.envelope_update(ctx, t["po"], t["pt"], t["g"], t["m"], t["v"], th.tensor(inp["obs"]).to(dev),
+                                  th.tensor(inp["next_obs"]).to(dev), th.tensor(inp["actions"].astype(np.int32).reshape(-1)).to(dev),
+                                  th.tensor(inp["rewards"]).to(dev), th.tensor(inp["dones"]).reshape(-1).to(dev),
+                                  th.tensor(inp["sampled_w"]).float().to(dev), gamma=c.gamma, lr=c.lr, adam_step=c.step,
+                                  max_grad_norm=c.max_grad_norm, homotopy_lambda=c.homotopy_lambda, envelope=True, debug=debug)
+        ctx_rows[debug] = ctx.lazy_target_rows(t["po"])
+        ctx_rows["engine"] = ctx.engine
+        ctx.close()
+        return res, t
+    eager, te = run(True)
+    lazy, tl = run("lazy")
+    assert ctx_rows[True] == 0                                         # the whole slab was asked for: evaluated eagerly
+    pref = lazy["pref"].cpu().long().view(c.W, c.B)                    # [i][b] -> j*
+    distinct = sum(len(set(pref[:, b].tolist())) for b in range(c.B))
+    if ctx_rows["engine"] > 0:                                         # (the per-layer engine of the narrowest nets stays eager)
+        assert ctx_rows["lazy"] == distinct and 1 <= distinct <= c.B * c.W
+    else:
+        assert ctx_rows["lazy"] == 0
+    for k in ("target", "pref", "ac", "priority", "q_values", "q_online_next"):
+        if is_sim:
+            assert th.equal(eager[k].cpu(), lazy[k].cpu()), k
+        else:                                                          # (GPU: the two forms may run different row tilings)
+            assert relmax(lazy[k], eager[k]) <= (0 if k in ("pref", "ac") else 1e-5), k
+    if is_sim:
+        assert th.equal(te["g"], tl["g"]) and th.equal(te["po"], tl["po"]) and eager["loss"].item() == lazy["loss"].item()
+    else:
+        assert relmax(tl["g"], te["g"]) <= 5e-6 and abs(eager["loss"].item() - lazy["loss"].item()) <= 1e-6 * abs(eager["loss"].item())
