@@ -332,7 +332,7 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", 
     res = {"wall": wall, "host_enqueue_ms_per_step": t_enq * 1e3 / steps, "gpu_ms_per_step_events": gpu_ms / steps,
            "n_chain": n_chain, "chain_ms": chain_ms, "timed_steps": (len(range(0, steps, timing_every)) if timing_every > 0 else steps if timing_every == -1 else 0),
            "launches_per_step": launches_per_step, "timing_mode": timing_every, "kinds": kinds,
-           "fwd_launches_per_step": kinds0["forward"][0], "transport": transport, "axis": axis if sharded else None,
+           "fwd_launches_per_step": kinds0["forward"][0], "fwd2_launches_per_step": kinds0["forward2"][0], "transport": transport, "axis": axis if sharded else None,
            "lazy_target_rows": lazy_rows,
            "loss": agent.last_loss(), "engine": agent.q_net.ctx.engine, "W": W, "B": B}
     del agent
@@ -424,7 +424,7 @@ def _roofline(res, rows_rank):
     # algorithmic flop of ONE launch of each kind (this rank's rows): the three-pass forward launch (or the launches of a sharded
     # step), the two-pass forward launch of a lazily evaluated step, the backward-dX launch, the weight-gradient launch
     flop_kind = {"forward": rows_rank * 3 * FWD_FLOP_ROW / max(1, res.get("fwd_launches_per_step") or 1),
-                 "forward2": rows_rank * 2 * FWD_FLOP_ROW, "backward": rows_rank * BWD_DX_FLOP_ROW, "dw": rows_rank * FWD_FLOP_ROW}
+                 "forward2": rows_rank * 2 * FWD_FLOP_ROW / max(1, res.get("fwd2_launches_per_step") or 1), "backward": rows_rank * BWD_DX_FLOP_ROW, "dw": rows_rank * FWD_FLOP_ROW}
     kinds = res.get("kinds") or {}
     chain_flop = sum(flop_kind[k] * kinds[k][0] for k in ("forward", "forward2", "backward") if k in kinds)
     launches_per_step = res.get("launches_per_step") or (n_chain / timed_steps if timed_steps else 0)

@@ -86,13 +86,23 @@ struct EnvelopeTdArgs {
     // Lazy target evaluation (morl_envelope_update's default on the layer-fused engines): a TD row only ever reads the target
     // network at ITS arg-max (j*, a*), and the rows of a transition agree on a handful of j* (1 546 distinct (b, j*) pairs of
     // 16 384 at the flagship shape), so the target network is evaluated AFTER the arg-max, on the distinct pairs only.
-    //   phase 1  arg-max only: best_io[row] = flattened (j*, a*); need[b * W + j*] = 1          (qt, q_main unused)
-    //   phase 2  TD only:      best_io read back; the target row of (b, j) is qt + slot[b * W + j] * A * R (compact rows)
+    //   phase 1  arg-max only: best_io[row] = flattened (j*, a*); the distinct (b, j*) of the workgroup's rows get compact target
+    //            rows and every TD row learns its own (qt, q_main unused)
+    //   phase 2  TD only:      best_io read back; the target vector of TD row `row` is qt + (row_slot[row] * A + a*) * R
     //   phase 0  both in one launch from full slabs (the weight-sharded step, the per-layer engine, parity outputs)
     int phase;
     int32_t* best_io;       // [rows] internal row order (see bmajor)
-    unsigned char* need;    // [B * W] flags, cleared by the compaction kernel
-    const int32_t* slot;    // [B * W] compact row of pair (b, j), phase 2
+    // phase 1: the rows of a workgroup find their distinct j* through LDS (the lowest TD row selecting a weight owns it) and one
+    // lane takes that many compact rows from the step's counter -- ONE returning global atomic per workgroup pass.  (A version
+    // that also deduplicated through global memory, an atomicExch on a per-pair epoch tag, cost the launch 12.3 us instead of
+    // 5.7: two dependent device-scope round trips per workgroup.)  The ORDER of the compact rows varies from run to run; the
+    // values do not -- every row of the 16-row chain is computed independently of its position.  Workgroups that share a
+    // transition (i_groups > 1) may each list the same pair: evaluated twice, same value.  count[epoch & 1] is this step's
+    // counter, the other one is zeroed for the next step; nothing else needs clearing
+    int32_t* pairs_out;     // [rows] compact row -> b * W + j
+    int32_t* row_slot;      // [rows] TD row (internal order) -> compact row (written by phase 1, read by phase 2)
+    int32_t* count;         // [2]
+    int epoch;              // >= 1
     float* zero_ptr;        // optional: zero_ptr[k] = 0 for k in [0, zero_n) outside [keep_lo, keep_hi) -- the batch-sharded step's
     int zero_n, keep_lo, keep_hi;   // "the other ranks' priorities are zeros" (one memset launch less per rank step)
     int bmajor;             // internal row order of q_main / dq: 0 = row i * B + b (reference order, envelope.py:284-291),
@@ -144,16 +154,47 @@ __device__ __forceinline__ void env_scan(const float* q0, const float (&wi)[MORL
     }
 }
 
+// LDS of one workgroup, sized for the launch at hand (offsets in 4-byte words).  With every array at its maximum (two 9 216-float
+// slabs ...) a workgroup took 119 KB -- ONE per CU, so the 512 workgroups of the flagship step ran in two rounds; sized for its
+// 576-float slabs it takes 9 KB and all of them are resident at once.
+struct EnvTdLds {
+    int qo, qt, w, qm, tgt, g, best, mark, slot, pv, pc, total;
+};
+__host__ __device__ inline EnvTdLds env_td_lds(const EnvelopeTdArgs& p, int waves) {
+    auto al = [](int n) { return (n + 3) & ~3; };
+    const int slab = p.W * p.A * p.R;
+    const int nI = p.row_weights != nullptr ? 1 : (p.WI > 0 ? p.WI : p.W);
+    EnvTdLds l;
+    int o = 0;
+    l.qo = o;   o += p.phase != 2 ? al(slab) : 0;
+    l.qt = o;   o += p.phase == 0 ? al(slab) : 0;
+    l.w = o;    o += al(nI * p.R);
+    l.qm = o;   o += al(nI * p.R);
+    l.tgt = o;  o += al(nI * p.R);
+    l.g = o;    o += al(nI * p.R);
+    l.best = o; o += al(nI);
+    l.mark = o; o += p.phase == 1 ? al(p.W) : 0;
+    l.slot = o; o += p.phase == 1 ? al(p.W) : 0;
+    l.pv = o;   o += p.phase != 2 ? waves * kWave : 0;
+    l.pc = o;   o += p.phase != 2 ? waves * kWave : 0;
+    l.total = o;
+    return l;
+}
+
 __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(EnvelopeTdArgs p) {
-    __shared__ float s_qo[ENV_MAX_SLAB];
-    __shared__ float s_qt[ENV_MAX_SLAB];
-    __shared__ float s_w[ENV_MAX_WR];
-    __shared__ float s_qm[ENV_MAX_WR];    // Q_online(s_b, w_i)[action_b][r]
-    __shared__ float s_tgt[ENV_MAX_WR];   // selected target vectors
-    __shared__ float s_g[ENV_MAX_WR];     // dLoss/dQ of the taken action
-    __shared__ int s_best[ENV_MAX_WR];    // flattened (j*, a*)
-    __shared__ float s_pv[ENV_MAX_WAVES][kWave];   // per-wave partial maxima of the 64 rows in flight ...
-    __shared__ int s_pc[ENV_MAX_WAVES][kWave];     // ... and their candidate indices
+    HIP_DYNAMIC_SHARED(float, lds)
+    const EnvTdLds lo = env_td_lds(p, (int)(blockDim.x >> 6));
+    float* const s_qo = lds + lo.qo;
+    float* const s_qt = lds + lo.qt;
+    float* const s_w = lds + lo.w;
+    float* const s_qm = lds + lo.qm;      // Q_online(s_b, w_i)[action_b][r]
+    float* const s_tgt = lds + lo.tgt;    // selected target vectors
+    float* const s_g = lds + lo.g;        // dLoss/dQ of the taken action
+    int* const s_best = reinterpret_cast<int*>(lds + lo.best);    // flattened (j*, a*)
+    int* const s_mark = reinterpret_cast<int*>(lds + lo.mark);    // phase 1, [W]: lowest TD row of this workgroup that selected weight j
+    int* const s_slot = reinterpret_cast<int*>(lds + lo.slot);    // phase 1, [W]: compact target row of (b, j)
+    float (*const s_pv)[kWave] = reinterpret_cast<float (*)[kWave]>(lds + lo.pv);   // per-wave partial maxima of the 64 rows in flight ...
+    int (*const s_pc)[kWave] = reinterpret_cast<int (*)[kWave]>(lds + lo.pc);       // ... and their candidate indices
     __shared__ double s_red[4][2];
     const int nw = (int)(blockDim.x >> 6);
     const int ig_n = p.i_groups > 0 ? p.i_groups : 1;
@@ -168,12 +209,22 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
     const bool train = p.q_main != nullptr;
     const int act = train ? p.actions[b] : 0;
     const int pf = p.part_floats > 0 ? p.part_floats : slab;
+    if (p.phase == 1)
+        for (int e = (int)threadIdx.x; e < W; e += (int)blockDim.x) s_mark[e] = 0x7fffffff;
     if (p.phase != 2)
         for (int e = (int)threadIdx.x; e < slab; e += (int)blockDim.x) {
             const int g = e / pf;
             const size_t off = (size_t)g * (size_t)p.part_stride + (size_t)b * pf + (size_t)(e - g * pf);
             s_qo[e] = p.qo[off];
             if (p.phase == 0) s_qt[e] = p.qt[off];
+        }
+    if (p.phase == 2)       // (best (j*, a*), compact target row) -> target vector: two dependent loads, one TD row per thread,
+        for (int i = i_lo + (int)threadIdx.x; i < i_hi; i += (int)blockDim.x) {      // under the staging loads below
+            const size_t irow = p.bmajor ? (size_t)b * nI + i : (size_t)i * p.B + b;
+            const int bc = p.best_io[irow];
+            const float* qt = p.qt + ((size_t)p.row_slot[irow] * A + (bc % A)) * R;
+            s_best[i] = bc;
+            for (int r = 0; r < R; ++r) s_tgt[i * R + r] = qt[r];
         }
     for (int e = (int)threadIdx.x; e < nI * R; e += (int)blockDim.x) {
         s_w[e] = generic ? p.row_weights[(size_t)b * R + e] : p.weights[e];
@@ -255,7 +306,7 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
             const size_t irow = p.bmajor ? (size_t)b * nI + i : (size_t)i * p.B + b;     // internal row of (i, b)
             int bc;
             if (p.phase == 2) {
-                bc = p.best_io[irow];
+                bc = s_best[i];
             } else {
                 // merge the slices in candidate order: strictly greater replaces, so the first maximum wins
                 float bv = s_pv[0][lane];
@@ -269,10 +320,8 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
             s_best[i] = bc;
             if (p.phase == 1) {
                 p.best_io[irow] = bc;
-                p.need[(size_t)b * W + bc / A] = 1;      // (several rows may mark the same pair: same value, benign)
             } else {
-            const float* qt = (p.phase == 2) ? p.qt + ((size_t)p.slot[(size_t)b * W + bc / A] * A + (bc % A)) * R
-                                             : s_qt + (size_t)bc * R;
+            const float* qt = (p.phase == 2) ? s_tgt + (size_t)i * R : s_qt + (size_t)bc * R;
             float td[MORL_MAX_OBJ];
             float wq = 0.f, wtq = 0.f;
 #pragma unroll
@@ -310,9 +359,35 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
             }
             }
         }
+        if (p.phase == 1) {
+            // distinct j* of this pass: the lowest TD row selecting a weight owns it (s_mark), the owners take consecutive compact rows
+            const int jsel = (wave == 0 && live) ? s_best[i] / A : 0;
+            if (wave == 0 && live) atomicMin(&s_mark[jsel], i);
+            __syncthreads();
+            if (wave == 0) {
+                const bool first = live && s_mark[jsel] == i;
+                const unsigned long long won = __ballot(first);
+                if (won != 0ull) {
+                    const int leader = __ffsll(won) - 1;
+                    int base = 0;
+                    if (lane == leader) base = atomicAdd(p.count + (p.epoch & 1), __popcll(won));
+                    base = __shfl(base, leader);
+                    if (first) {
+                        const int k = base + __popcll(won & ((1ull << lane) - 1ull));
+                        p.pairs_out[k] = b * W + jsel;
+                        s_slot[jsel] = k;
+                    }
+                }
+            }
+            __syncthreads();
+            if (wave == 0 && live) p.row_slot[p.bmajor ? (size_t)b * nI + i : (size_t)i * p.B + b] = s_slot[jsel];
+        }
         __syncthreads();
     }
-    if (p.phase == 1) return;            // (uniform: the arg-max launch writes nothing else)
+    if (p.phase == 1) {                  // (uniform: the arg-max launch writes nothing else)
+        if (blockIdx.x == 0 && threadIdx.x == 0) p.count[(p.epoch + 1) & 1] = 0;
+        return;
+    }
     // loss partials: only wave 0 accumulated; butterfly sum over its lanes (fixed order)
     if (wave == 0) {
         acc_mse = wave_sum(acc_mse);
@@ -350,57 +425,6 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
         p.loss_part[(size_t)blockIdx.x * 2 + 0] = s_red[0][0];
         p.loss_part[(size_t)blockIdx.x * 2 + 1] = s_red[0][1];
     }
-}
-
-// ----------------------------------------------------------------------------------------------
-// Lazy target evaluation, step 2 of 4: the flags the arg-max launch left in need[b * W + j] -> the list of distinct pairs in
-// ascending order (pairs[k] = b * W + j), the inverse map (slot[b * W + j] = k), their number; the flags are cleared for the
-// next step.  One workgroup: 16 384 flags are four rounds of a 1 024-thread two-level scan.
-// ----------------------------------------------------------------------------------------------
-constexpr int ENV_COMPACT_THREADS = 1024;
-
-__global__ __launch_bounds__(ENV_COMPACT_THREADS) void envelope_compact_kernel(unsigned char* __restrict__ need, int n_flags,
-                                                                               int32_t* __restrict__ pairs, int32_t* __restrict__ slot,
-                                                                               int32_t* __restrict__ count) {
-    __shared__ int s_cnt[ENV_COMPACT_THREADS];
-    __shared__ int s_wave[ENV_COMPACT_THREADS / kWave + 1];
-    const int tid = (int)threadIdx.x;
-    constexpr int PER = 4;
-    int base = 0;
-    for (int c0 = 0; c0 < n_flags; c0 += ENV_COMPACT_THREADS * PER) {
-        int f[PER], mine = 0;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int idx = c0 + tid * PER + u;
-            f[u] = (idx < n_flags) ? (need[idx] != 0) : 0;
-            mine += f[u];
-        }
-        s_cnt[tid] = mine;
-        __syncthreads();
-        if (tid < ENV_COMPACT_THREADS / kWave) {                   // one thread per wave-sized group: its total
-            int t = 0;
-            for (int k = 0; k < kWave; ++k) t += s_cnt[tid * kWave + k];
-            s_wave[tid] = t;
-        }
-        __syncthreads();
-        int off = base;
-        for (int g = 0; g < tid / kWave; ++g) off += s_wave[g];
-        for (int k = (tid / kWave) * kWave; k < tid; ++k) off += s_cnt[k];
-        int total = 0;
-        for (int g = 0; g < ENV_COMPACT_THREADS / kWave; ++g) total += s_wave[g];
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int idx = c0 + tid * PER + u;
-            if (idx < n_flags) {
-                slot[idx] = f[u] ? off : -1;
-                if (f[u]) { pairs[off] = idx; ++off; }
-                need[idx] = 0;
-            }
-        }
-        base += total;
-        __syncthreads();
-    }
-    if (tid == 0) *count = base;
 }
 
 }  // namespace morl

@@ -194,10 +194,10 @@ struct morl_ctx {
     // morl_envelope_update to update_core
     bool lazy_targets = true;            // MORL_LAZY_TARGETS=0 / morl_ctx_set_lazy_targets: evaluate the whole target slab instead
     int32_t* lz_best = nullptr;          // [max_rows] flattened (j*, a*) per TD row
-    unsigned char* lz_need = nullptr;    // [max_rows] pair flags (kept zero between steps by the compaction kernel)
-    int32_t* lz_slot = nullptr;          // [max_rows] pair -> compact row
+    int lz_epoch = 0;                    // lazily evaluated steps so far (its parity picks the counter)
+    int32_t* lz_slot = nullptr;          // [max_rows] TD row -> compact row
     int32_t* lz_pairs = nullptr;         // [max_rows] compact row -> pair
-    int32_t* lz_count = nullptr;         // [1] distinct pairs of the last step
+    int32_t* lz_count = nullptr;         // [2] distinct pairs of the steps of even / odd epoch
     int timing_kind_override = -1;       // MORL_TIMED_* of the next bracketed chain launch (-1: by its arguments)
     bool lz_now = false;                 // this step runs lazily: the three below are what the target launch needs
     const float* lz_params_target = nullptr;
@@ -258,7 +258,6 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     if (c->sumsq_part) (void)hipFree(c->sumsq_part);
     if (c->loss_part) (void)hipFree(c->loss_part);
     if (c->lz_best) (void)hipFree(c->lz_best);
-    if (c->lz_need) (void)hipFree(c->lz_need);
     if (c->lz_slot) (void)hipFree(c->lz_slot);
     if (c->lz_pairs) (void)hipFree(c->lz_pairs);
     if (c->lz_count) (void)hipFree(c->lz_count);
@@ -377,11 +376,10 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     for (int l = 1; l < c->L; ++l) ALLOC(relu_bits[l], ((size_t)c->max_rows + 63) / 64 * CH_THREADS);
     ALLOC(zeros, 16);
     ALLOC(lz_best, rows);
-    ALLOC(lz_need, rows);
     ALLOC(lz_slot, rows);
     ALLOC(lz_pairs, rows);
     ALLOC(lz_count, 4);
-    if (hipMemset(c->lz_need, 0, rows) != hipSuccess || hipMemset(c->lz_count, 0, 16) != hipSuccess) {
+    if (hipMemset(c->lz_count, 0, 16) != hipSuccess) {
         morl_ctx_destroy(c);
         return fail(MORL_ERR_HIP, "hipMemset failed");
     }
@@ -516,6 +514,19 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
     return MORL_OK;
 }
 
+// envelope_td_kernel with its LDS sized for this launch (env_td_lds); beyond the 64 KB a launch gets by default the limit is raised once
+static int launch_envelope_td(const EnvelopeTdArgs& p, int blocks, int waves, hipStream_t s, const char* what) {
+    const size_t bytes = (size_t)env_td_lds(p, waves).total * 4;
+    if (bytes > 64 * 1024) {
+        static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(envelope_td_kernel),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        if (raised != hipSuccess) return fail(MORL_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(raised));
+    }
+    hipLaunchKernelGGL(envelope_td_kernel, dim3(blocks), dim3(64 * waves), bytes, s, p);
+    LAUNCH_CHECK(what);
+    return MORL_OK;
+}
+
 // arg-max form of envelope_td_kernel: 0 = lanes <-> TD rows, candidates as LDS broadcasts (default); 1 = lanes <-> candidates, wave
 // butterfly over (value, index).  MORL_TD_SHFL=1 selects the shuffle form (A/B measurements); both give
 // bit-identical indices (tests/test_kernels_parity.py runs the tie tests under both).
@@ -557,9 +568,8 @@ static int timing_close(morl_ctx* c, int slot, hipStream_t s) {
 }
 
 // ---- second-generation chain (mlp_chain2.h): one persistent launch of 2 workgroups per CU over all units --------------
-static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s, const ChainTd* td = nullptr) {
-    Chain2Multi m{};
-    if (td) m.td = *td;
+// the persistent schedule of `n` chains over S workgroups (0: two per CU); returns S
+static int chain2_fill(morl_ctx* c, Chain2Multi& m, const ChainArgs* chains, int n, int S) {
     m.n = n;
     int units = 0;
     for (int q = 0; q < n; ++q) {
@@ -568,8 +578,10 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
         units += std::max(1, chains[q].nb) * ((chains[q].rows + 63) / 64);
     }
     for (int q = n; q <= CH_MAX_MULTI; ++q) m.unit_start[q] = units;
-    int S = 2 * c->num_cus;
-    if (const char* e = getenv("MORL_CHAIN_SLOTS")) S = std::max(1, atoi(e));   // (tuning)
+    if (S <= 0) {
+        S = 2 * c->num_cus;
+        if (const char* e = getenv("MORL_CHAIN_SLOTS")) S = std::max(1, atoi(e));   // (tuning)
+    }
     // small jobs: no more slots than half units, so that every slot has work
     S = std::max(1, std::min(S, 2 * units));
     m.full_rounds = units / S;
@@ -579,6 +591,13 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
     if (c->fused_tm == 64) m.tail_halves = 0;
     m.stagger = c->chain_stagger;
     m.cu_tickets = c->cu_tickets;
+    return S;
+}
+
+static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s, const ChainTd* td = nullptr) {
+    Chain2Multi m{};
+    if (td) m.td = *td;
+    const int S = chain2_fill(c, m, chains, n, 0);
     // (backward chain: the one whose input is the TD kernel's dLoss/dQ)
     const int kind = c->timing_kind_override >= 0 ? c->timing_kind_override
                      : (chains[0].in_mode == 2 || (chains[0].in_mode == 1 && chains[0].src == c->dq)) ? MORL_TIMED_BACKWARD
@@ -874,7 +893,7 @@ extern "C" int morl_ctx_lazy_target_rows(morl_ctx* c, int* rows, void* stream) {
     if (!c || !rows) return fail(MORL_ERR_ARG, "NULL argument");
     int32_t n = 0;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    HIP_TRY(hipMemcpy(&n, c->lz_count, sizeof(n), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&n, c->lz_count + (c->lz_epoch & 1), sizeof(n), hipMemcpyDeviceToHost));
     *rows = (int)n;
     return MORL_OK;
 }
@@ -962,9 +981,7 @@ extern "C" int morl_envelope_reduce(const float* qo, const float* qt, const floa
     p.qo = qo; p.qt = qt; p.weights = weights;
     p.target = target; p.pref = pref; p.ac = ac;
     p.B = B; p.W = W; p.A = A; p.R = R; p.diag_only = diag_only;
-    hipLaunchKernelGGL(envelope_td_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
-    LAUNCH_CHECK("envelope_td(reduce)");
-    return MORL_OK;
+    return launch_envelope_td(p, B, 4, (hipStream_t)stream, "envelope_td(reduce)");
 }
 
 extern "C" int morl_envelope_reduce_rows(const float* qo, const float* qt, const float* row_weights, int n_rows, int W,
@@ -978,9 +995,7 @@ extern "C" int morl_envelope_reduce_rows(const float* qo, const float* qt, const
     p.qo = qo; p.qt = qt; p.row_weights = row_weights;
     p.target = target; p.pref = pref; p.ac = ac;
     p.B = n_rows; p.W = W; p.A = A; p.R = R;
-    hipLaunchKernelGGL(envelope_td_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, p);
-    LAUNCH_CHECK("envelope_td(reduce_rows)");
-    return MORL_OK;
+    return launch_envelope_td(p, n_rows, 4, (hipStream_t)stream, "envelope_td(reduce_rows)");
 }
 
 extern "C" int morl_envelope_greedy_actions(morl_ctx* c, const float* params, const float* obs, const float* w, int n,
@@ -1005,9 +1020,7 @@ extern "C" int morl_envelope_greedy_actions(morl_ctx* c, const float* params, co
     p.target = nullptr; p.pref = nullptr; p.ac = actions_out;
     p.B = n; p.W = 1; p.A = A; p.R = R;
     p.fma_scal = 1;
-    hipLaunchKernelGGL(envelope_td_kernel, dim3(n), dim3(256), 0, s, p);
-    LAUNCH_CHECK("envelope_td(greedy_actions)");
-    return MORL_OK;
+    return launch_envelope_td(p, n, 4, s, "envelope_td(greedy_actions)");
 }
 
 // ---- one gradient step, in three stages so that a weight-sharded job can put its collectives between them ----------
@@ -1102,33 +1115,32 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         int td_waves = n_cand >= 256 ? 16 : (n_cand >= 64 ? 8 : 4);
         if (const char* e = getenv("MORL_TD_WAVES")) td_waves = std::max(1, std::min(ENV_MAX_WAVES, atoi(e)));
         if (lazy) {
-            // 1. arg-max on the online slab: best (j*, a*) per TD row, the needed (b, j*) pairs flagged
+            // 1. arg-max on the online slab: best (j*, a*) per TD row; every (b, j*) pair selected gets a compact target row
+            c->lz_epoch = (c->lz_epoch & 0x3fffffff) + 1;
             EnvelopeTdArgs a1 = p;
-            a1.phase = 1; a1.best_io = c->lz_best; a1.need = c->lz_need;
+            a1.phase = 1; a1.best_io = c->lz_best;
+            a1.pairs_out = c->lz_pairs; a1.row_slot = c->lz_slot; a1.count = c->lz_count; a1.epoch = c->lz_epoch;
             a1.zero_ptr = nullptr;
-            hipLaunchKernelGGL(envelope_td_kernel, dim3(B * td_groups), dim3(64 * td_waves), 0, s, a1);
-            LAUNCH_CHECK("envelope_argmax");
-            // 2. the distinct pairs, in ascending order, and the inverse map
-            hipLaunchKernelGGL(envelope_compact_kernel, dim3(1), dim3(ENV_COMPACT_THREADS), 0, s, c->lz_need, B * W, c->lz_pairs,
-                               c->lz_slot, c->lz_count);
-            LAUNCH_CHECK("envelope_compact");
-            // 3. the target network on those rows only: 16-row tiles sized for the worst case, tiles beyond the count exit at once
+            if ((rc = launch_envelope_td(a1, B * td_groups, td_waves, s, "envelope_argmax"))) return rc;
+            // 2. the target network on those rows only: 16-row tiles sized for the worst case, tiles beyond the count exit at once.
+            //    (Measured and dropped: the same tiles as extra workgroups of the training pass's launch, large tiles one per CU --
+            //    a CU with a 64-row tile is already MFMA-bound, the 16-row tile on top made that launch 93 us instead of 70 and the
+            //    step 0.343 ms instead of 0.3375: profiles/r03_lazy_targets_ab.json)
             {
                 ChainArgs t = make_forward_chain(c, c->lz_params_target, c->wt_target, c->lz_next_obs, weights_i, B, W, 0, B * W, false,
                                                  c->qt, A * R);
                 t.in_mode = 3;
-                t.rows_dev = c->lz_count;
+                t.rows_dev = c->lz_count + (c->lz_epoch & 1);
                 t.pairs = c->lz_pairs;
                 Chain16Multi m16{};
                 const int tiles = chain16_fill(m16, &t, 1);
                 hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
                 LAUNCH_CHECK("mlp_chain16(lazy targets)");
             }
-            // 4. TD target, loss gradient, priorities from the compact target rows
-            p.phase = 2; p.best_io = c->lz_best; p.slot = c->lz_slot; p.qt = c->qt;
+            // 3. TD target, loss gradient, priorities from the compact target rows
+            p.phase = 2; p.best_io = c->lz_best; p.row_slot = c->lz_slot; p.qt = c->qt;
         }
-        hipLaunchKernelGGL(envelope_td_kernel, dim3(B * td_groups), dim3(64 * td_waves), 0, s, p);
-        LAUNCH_CHECK("envelope_td");
+        if ((rc = launch_envelope_td(p, B * td_groups, td_waves, s, "envelope_td"))) return rc;
     }
     // backward through the hidden layers: g[l-1] = (g[l] @ W_l) * (h[l] > 0)
     if (c->use_fused) {
@@ -1420,7 +1432,10 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
             // transition agree on a handful of j* -- so this launch carries the online next-state pass and the training pass only,
             // the arg-max runs on the online slab, and the target network is evaluated afterwards on the distinct (b, j*) pairs
             // (update_core; 1 546 of 16 384 rows at the flagship shape).  Not when the caller asks for the whole target slab.
-            c->lz_now = c->lazy_targets && cfg->envelope && W >= 2 && !out->q_target_next;
+            // Small steps are latency-bound: one more chain launch and a second TD launch cost them more than the target pass
+            // they drop (2 048 rows: 0.181 ms lazily, 0.149 eagerly; 8 192 rows: 0.255 against 0.262; MORL_LAZY_MIN_ROWS overrides)
+            static const long long lazy_min_rows = [] { const char* e = getenv("MORL_LAZY_MIN_ROWS"); return e ? atoll(e) : 8192ll; }();
+            c->lz_now = c->lazy_targets && cfg->envelope && W >= 2 && !out->q_target_next && rows >= lazy_min_rows;
             if (c->lz_now) {
                 const ChainArgs two[2] = {
                     make_forward_chain(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR), main_chain};

@@ -10,6 +10,13 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.pa
         sys.path.insert(0, p)
 
 
+# The library evaluates the target network lazily only for steps on the large row tiles (> 8 192 TD rows): smaller, latency-bound
+# steps are faster eagerly.  The suite's cases are almost all small, so it lowers the threshold to zero -- every Envelope step of
+# the fixtures, traces and agents then runs the lazy path (on the emulator and on the GPU); the eager path keeps its coverage
+# through the lazy-vs-eager test, the sharded steps and tests/test_chain_tilings.py's MORL_LAZY_TARGETS=0 leg.
+os.environ.setdefault("MORL_LAZY_MIN_ROWS", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -182,8 +182,15 @@ CollOut wave_collective(const CollIn& in, void (*fn)(const CollIn*, CollOut*, in
 
 static inline void __syncthreads() { hipsim::block_barrier(); }
 
+// dynamic LDS: one buffer of a CU's 160 KB (workgroups run one after another); the launch's byte count is checked against it
+namespace hipsim { alignas(16) static unsigned char dyn_lds[160 * 1024]; }
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipsim::dyn_lds);
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+
 template <typename K, typename... Args>
-static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t dyn_bytes, hipStream_t, Args... args) {
+    if (dyn_bytes > sizeof(hipsim::dyn_lds)) { std::fprintf(stderr, "hipsim: %zu bytes of dynamic LDS\n", dyn_bytes); std::abort(); }
     hipsim::run_grid(grid, block, [&]() { kernel(args...); });
 }
 
@@ -237,6 +244,7 @@ static inline void __builtin_amdgcn_wave_barrier() { hipsim::CollIn in{}; in.u =
 static inline unsigned long long __ballot(int p) { hipsim::CollIn in{}; in.i = p != 0; return hipsim::wave_collective(in, hipsim::fn_ballot).u; }
 static inline int __all(int p) { return __ballot(!p) == 0ull; }
 static inline int __any(int p) { return __ballot(p) != 0ull; }
+static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
@@ -325,7 +333,11 @@ static inline void __builtin_amdgcn_raw_buffer_store_b128(hipsim_v4u v, __amdgpu
         if (off + 4 * d + 4 <= r.num_records) { unsigned x = v[d]; std::memcpy((char*)r.base + off + 4 * d, &x, 4); }
 }
 static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }   // hardware identity registers: one CU on the host
+// (work-items of a process run one at a time: plain read-modify-write)
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
+static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 // scheduling hints have no meaning on the host
 #define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)

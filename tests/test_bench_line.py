@@ -43,6 +43,12 @@ def test_roofline_record_arithmetic(bench):
     r2 = bench._roofline(res2, rows)
     assert r2["achieved"] == pytest.approx(rows * (2 * bench.FWD_FLOP_ROW + bench.BWD_DX_FLOP_ROW) / 2 / (0.0955e-3) / 1e12, rel=1e-9)
     assert r2["per_kernel"]["forward2"]["achieved"] == pytest.approx(rows * 2 * bench.FWD_FLOP_ROW / 124e-6 / 1e12)
+    # ... or as two launches of one pass each (the second also carries the target rows, not counted)
+    res3 = dict(res, fwd2_launches_per_step=2, kinds={"forward2": (14, 7 * 0.140), "backward": (7, 7 * 0.067), "dw": (6, 6 * 0.070)},
+                n_chain=21, chain_ms=7 * 0.140 + 7 * 0.067)
+    r3 = bench._roofline(res3, rows)
+    assert r3["per_kernel"]["forward2"]["achieved"] == pytest.approx(rows * bench.FWD_FLOP_ROW / 70e-6 / 1e12)
+    assert r3["achieved"] == pytest.approx(rows * (2 * bench.FWD_FLOP_ROW + bench.BWD_DX_FLOP_ROW) / (0.207e-3) / 1e12, rel=1e-9)
     assert r["frac"] == pytest.approx(r["achieved"] / 157.3) and 0.0 < r["frac"] < 1.0
     pk = r["per_kernel"]
     assert pk["forward"]["achieved"] == pytest.approx(rows * 3 * bench.FWD_FLOP_ROW / 185e-6 / 1e12)

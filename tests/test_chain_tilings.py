@@ -47,6 +47,29 @@ def test_large_tile_chain_passes_the_shape_sweep_on_the_gpu():
     assert " passed" in r.stdout
 
 
+def test_lazy_targets_with_large_tiles_forced():
+    """Lazy target evaluation with the forward passes on the 64 / 32-row tiles (as at the flagship size on the GPU; the lazily
+    evaluated rows always take the 16-row ones) must equal the eager evaluation."""
+    env = dict(os.environ, MORL_CHAIN16="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_parity.py"), "-x", "-q", "-m", "not gpu",
+                        "-k", "lazy_target_evaluation and (ragged or small_homotopy or dup_weights)", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_eager_target_evaluation_on_the_gpu():
+    """The fixtures, traces and lazy-vs-eager tests run lazily by default; here the same assertions with MORL_LAZY_TARGETS=0."""
+    env = dict(os.environ, MORL_LAZY_TARGETS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_parity.py"),
+                        os.path.join(ROOT, "tests", "test_flagship_golden.py"), os.path.join(ROOT, "tests", "test_train_traces.py"),
+                        "-x", "-q", "-m", "gpu", "-k", "golden or trace", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_shuffle_argmax_form_passes_the_same_parity_tests():
     """``envelope_td_kernel`` has two arg-max forms -- lanes <-> TD rows with the candidates read as LDS broadcasts (default) and
     lanes <-> candidates with a wave butterfly over (value, index) (``MORL_TD_SHFL=1``, the form north_star names).  Indices are

@@ -476,12 +476,15 @@ def test_lazy_target_evaluation_equals_the_eager_one(be, c):
         assert ctx_rows["lazy"] == distinct and 1 <= distinct <= c.B * c.W
     else:
         assert ctx_rows["lazy"] == 0
+    # bit for bit where both forms run the 16-row tiles; with the large tiles forced (tests/test_chain_tilings.py) the eager target
+    # slab comes from 64 / 32-row tiles and the lazy rows from 16-row ones, as on the GPU at the flagship size
+    exact = is_sim and os.environ.get("MORL_CHAIN16") != "0"
     for k in ("target", "pref", "ac", "priority", "q_values", "q_online_next"):
-        if is_sim:
+        if exact:
             assert th.equal(eager[k].cpu(), lazy[k].cpu()), k
         else:                                                          # (GPU: the two forms may run different row tilings)
             assert relmax(lazy[k], eager[k]) <= (0 if k in ("pref", "ac") else 1e-5), k
-    if is_sim:
+    if exact:
         assert th.equal(te["g"], tl["g"]) and th.equal(te["po"], tl["po"]) and eager["loss"].item() == lazy["loss"].item()
     else:
         assert relmax(tl["g"], te["g"]) <= 5e-6 and abs(eager["loss"].item() - lazy["loss"].item()) <= 1e-6 * abs(eager["loss"].item())

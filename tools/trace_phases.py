@@ -1,0 +1,23 @@
+"""Per-position kernel durations of the Envelope step from a rocprofv3 kernel trace: groups the morl:: kernels by their position
+inside one step (the step_prologue launch opens a step) and prints the mean duration of each position over the steps seen."""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+steps, cur = [], None
+for r in rows:
+    n = r["Kernel_Name"]
+    if "morl::" not in n: continue
+    if "step_prologue" in n:
+        cur = []; steps.append(cur)
+    if cur is not None:
+        cur.append((n.split("(")[0].replace("void ", "")[:40], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+steps = [s for s in steps[5:-1]]
+L = collections.Counter(len(s) for s in steps).most_common(1)[0][0]
+steps = [s for s in steps if len(s) == L]
+print(f"{len(steps)} steps of {L} launches")
+for k in range(L):
+    d = [s[k][1] for s in steps]
+    gap = [(s[k][2] - s[k - 1][3]) / 1e3 for s in steps] if k else [0.0]
+    print(f"{k:2d} {steps[0][k][0]:40s} {sum(d) / len(d):8.2f} us   gap before {sum(gap) / len(gap):6.2f} us")
+tot = [(s[-1][3] - s[0][2]) / 1e3 for s in steps]
+print(f"first start -> last end: {sum(tot) / len(tot):.1f} us")
