@@ -154,47 +154,24 @@ __device__ __forceinline__ void env_scan(const float* q0, const float (&wi)[MORL
     }
 }
 
-// LDS of one workgroup, sized for the launch at hand (offsets in 4-byte words).  With every array at its maximum (two 9 216-float
-// slabs ...) a workgroup took 119 KB -- ONE per CU, so the 512 workgroups of the flagship step ran in two rounds; sized for its
-// 576-float slabs it takes 9 KB and all of them are resident at once.
-struct EnvTdLds {
-    int qo, qt, w, qm, tgt, g, best, mark, slot, pv, pc, total;
-};
-__host__ __device__ inline EnvTdLds env_td_lds(const EnvelopeTdArgs& p, int waves) {
-    auto al = [](int n) { return (n + 3) & ~3; };
-    const int slab = p.W * p.A * p.R;
-    const int nI = p.row_weights != nullptr ? 1 : (p.WI > 0 ? p.WI : p.W);
-    EnvTdLds l;
-    int o = 0;
-    l.qo = o;   o += p.phase != 2 ? al(slab) : 0;
-    l.qt = o;   o += p.phase == 0 ? al(slab) : 0;
-    l.w = o;    o += al(nI * p.R);
-    l.qm = o;   o += al(nI * p.R);
-    l.tgt = o;  o += al(nI * p.R);
-    l.g = o;    o += al(nI * p.R);
-    l.best = o; o += al(nI);
-    l.mark = o; o += p.phase == 1 ? al(p.W) : 0;
-    l.slot = o; o += p.phase == 1 ? al(p.W) : 0;
-    l.pv = o;   o += p.phase != 2 ? waves * kWave : 0;
-    l.pc = o;   o += p.phase != 2 ? waves * kWave : 0;
-    l.total = o;
-    return l;
-}
-
+// PHASE: EnvelopeTdArgs::phase as a compile-time constant -- the arg-max-only and TD-only launches of a lazily evaluated step do
+// not carry each other's code, registers and LDS (nor does the one-launch form: with the three in one body it ran 10.7 us instead
+// of 9.4 at the flagship shape).  (Also measured: the LDS sized per launch instead of for the largest slab -- 9 KB instead of
+// 119 KB, every workgroup resident at once instead of one per CU in two rounds -- was 1 us SLOWER per launch; the kernel is
+// bound by each workgroup's own chain of latencies, not by residency.)
+template <int PHASE>
 __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(EnvelopeTdArgs p) {
-    HIP_DYNAMIC_SHARED(float, lds)
-    const EnvTdLds lo = env_td_lds(p, (int)(blockDim.x >> 6));
-    float* const s_qo = lds + lo.qo;
-    float* const s_qt = lds + lo.qt;
-    float* const s_w = lds + lo.w;
-    float* const s_qm = lds + lo.qm;      // Q_online(s_b, w_i)[action_b][r]
-    float* const s_tgt = lds + lo.tgt;    // selected target vectors
-    float* const s_g = lds + lo.g;        // dLoss/dQ of the taken action
-    int* const s_best = reinterpret_cast<int*>(lds + lo.best);    // flattened (j*, a*)
-    int* const s_mark = reinterpret_cast<int*>(lds + lo.mark);    // phase 1, [W]: lowest TD row of this workgroup that selected weight j
-    int* const s_slot = reinterpret_cast<int*>(lds + lo.slot);    // phase 1, [W]: compact target row of (b, j)
-    float (*const s_pv)[kWave] = reinterpret_cast<float (*)[kWave]>(lds + lo.pv);   // per-wave partial maxima of the 64 rows in flight ...
-    int (*const s_pc)[kWave] = reinterpret_cast<int (*)[kWave]>(lds + lo.pc);       // ... and their candidate indices
+    __shared__ float s_qo[PHASE != 2 ? ENV_MAX_SLAB : 4];
+    __shared__ float s_qt[PHASE == 0 ? ENV_MAX_SLAB : 4];
+    __shared__ float s_w[ENV_MAX_WR];
+    __shared__ float s_qm[ENV_MAX_WR];    // Q_online(s_b, w_i)[action_b][r]
+    __shared__ float s_tgt[ENV_MAX_WR];   // selected target vectors
+    __shared__ float s_g[ENV_MAX_WR];     // dLoss/dQ of the taken action
+    __shared__ int s_best[ENV_MAX_WR];    // flattened (j*, a*)
+    __shared__ int s_mark[PHASE == 1 ? ENV_MAX_WR / 2 : 4];    // [W] (W * R <= ENV_MAX_WR, R >= 2): lowest TD row of this workgroup that selected weight j
+    __shared__ int s_slot[PHASE == 1 ? ENV_MAX_WR / 2 : 4];    // [W]: compact target row of (b, j)
+    __shared__ float s_pv[ENV_MAX_WAVES][kWave];   // per-wave partial maxima of the 64 rows in flight ...
+    __shared__ int s_pc[ENV_MAX_WAVES][kWave];     // ... and their candidate indices
     __shared__ double s_red[4][2];
     const int nw = (int)(blockDim.x >> 6);
     const int ig_n = p.i_groups > 0 ? p.i_groups : 1;
@@ -209,16 +186,16 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
     const bool train = p.q_main != nullptr;
     const int act = train ? p.actions[b] : 0;
     const int pf = p.part_floats > 0 ? p.part_floats : slab;
-    if (p.phase == 1)
+    if (PHASE == 1)
         for (int e = (int)threadIdx.x; e < W; e += (int)blockDim.x) s_mark[e] = 0x7fffffff;
-    if (p.phase != 2)
+    if (PHASE != 2)
         for (int e = (int)threadIdx.x; e < slab; e += (int)blockDim.x) {
             const int g = e / pf;
             const size_t off = (size_t)g * (size_t)p.part_stride + (size_t)b * pf + (size_t)(e - g * pf);
             s_qo[e] = p.qo[off];
-            if (p.phase == 0) s_qt[e] = p.qt[off];
+            if (PHASE == 0) s_qt[e] = p.qt[off];
         }
-    if (p.phase == 2)       // (best (j*, a*), compact target row) -> target vector: two dependent loads, one TD row per thread,
+    if (PHASE == 2)       // (best (j*, a*), compact target row) -> target vector: two dependent loads, one TD row per thread,
         for (int i = i_lo + (int)threadIdx.x; i < i_hi; i += (int)blockDim.x) {      // under the staging loads below
             const size_t irow = p.bmajor ? (size_t)b * nI + i : (size_t)i * p.B + b;
             const int bc = p.best_io[irow];
@@ -249,7 +226,7 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
 #pragma unroll
         for (int r = 0; r < MORL_MAX_OBJ; ++r) wi[r] = (live && r < R) ? s_w[i * R + r] : 0.f;
         const int n_c = p.diag_only ? A : W * A;
-        if (p.phase == 2) {
+        if (PHASE == 2) {
             // the arg-max was taken by an earlier launch (phase 1)
         } else if (p.argmax_mode == 1) {
             // ---- shuffle form: wave q owns the rows ib + q, ib + q + nw, ...; its lanes stride the (j, a) candidates of ONE
@@ -305,7 +282,7 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
         if (wave == 0 && live) {
             const size_t irow = p.bmajor ? (size_t)b * nI + i : (size_t)i * p.B + b;     // internal row of (i, b)
             int bc;
-            if (p.phase == 2) {
+            if (PHASE == 2) {
                 bc = s_best[i];
             } else {
                 // merge the slices in candidate order: strictly greater replaces, so the first maximum wins
@@ -318,10 +295,10 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
                 }
             }
             s_best[i] = bc;
-            if (p.phase == 1) {
+            if (PHASE == 1) {
                 p.best_io[irow] = bc;
             } else {
-            const float* qt = (p.phase == 2) ? s_tgt + (size_t)i * R : s_qt + (size_t)bc * R;
+            const float* qt = (PHASE == 2) ? s_tgt + (size_t)i * R : s_qt + (size_t)bc * R;
             float td[MORL_MAX_OBJ];
             float wq = 0.f, wtq = 0.f;
 #pragma unroll
@@ -359,7 +336,7 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
             }
             }
         }
-        if (p.phase == 1) {
+        if (PHASE == 1) {
             // distinct j* of this pass: the lowest TD row selecting a weight owns it (s_mark), the owners take consecutive compact rows
             const int jsel = (wave == 0 && live) ? s_best[i] / A : 0;
             if (wave == 0 && live) atomicMin(&s_mark[jsel], i);
@@ -384,7 +361,7 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
         }
         __syncthreads();
     }
-    if (p.phase == 1) {                  // (uniform: the arg-max launch writes nothing else)
+    if (PHASE == 1) {                  // (uniform: the arg-max launch writes nothing else)
         if (blockIdx.x == 0 && threadIdx.x == 0) p.count[(p.epoch + 1) & 1] = 0;
         return;
     }

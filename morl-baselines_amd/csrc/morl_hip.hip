@@ -514,15 +514,11 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
     return MORL_OK;
 }
 
-// envelope_td_kernel with its LDS sized for this launch (env_td_lds); beyond the 64 KB a launch gets by default the limit is raised once
+// envelope_td_kernel<p.phase>
 static int launch_envelope_td(const EnvelopeTdArgs& p, int blocks, int waves, hipStream_t s, const char* what) {
-    const size_t bytes = (size_t)env_td_lds(p, waves).total * 4;
-    if (bytes > 64 * 1024) {
-        static const hipError_t raised = hipFuncSetAttribute(reinterpret_cast<const void*>(envelope_td_kernel),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        if (raised != hipSuccess) return fail(MORL_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS): %s", hipGetErrorString(raised));
-    }
-    hipLaunchKernelGGL(envelope_td_kernel, dim3(blocks), dim3(64 * waves), bytes, s, p);
+    if (p.phase == 1) hipLaunchKernelGGL(envelope_td_kernel<1>, dim3(blocks), dim3(64 * waves), 0, s, p);
+    else if (p.phase == 2) hipLaunchKernelGGL(envelope_td_kernel<2>, dim3(blocks), dim3(64 * waves), 0, s, p);
+    else hipLaunchKernelGGL(envelope_td_kernel<0>, dim3(blocks), dim3(64 * waves), 0, s, p);
     LAUNCH_CHECK(what);
     return MORL_OK;
 }

@@ -182,15 +182,8 @@ CollOut wave_collective(const CollIn& in, void (*fn)(const CollIn*, CollOut*, in
 
 static inline void __syncthreads() { hipsim::block_barrier(); }
 
-// dynamic LDS: one buffer of a CU's 160 KB (workgroups run one after another); the launch's byte count is checked against it
-namespace hipsim { alignas(16) static unsigned char dyn_lds[160 * 1024]; }
-#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipsim::dyn_lds);
-enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
-static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
-
 template <typename K, typename... Args>
-static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t dyn_bytes, hipStream_t, Args... args) {
-    if (dyn_bytes > sizeof(hipsim::dyn_lds)) { std::fprintf(stderr, "hipsim: %zu bytes of dynamic LDS\n", dyn_bytes); std::abort(); }
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
     hipsim::run_grid(grid, block, [&]() { kernel(args...); });
 }
 
