@@ -172,11 +172,14 @@ int morl_envelope_prepare(morl_ctx* ctx, const float* params_online, const float
 /* Lazy target evaluation (default on; MORL_LAZY_TARGETS=0): envelope_target (envelope.py:404-440) evaluates the TARGET network on
  * every (s'_b, w_j) row, but a TD row (i, b) only reads it at its own arg-max (j*, a*) -- and the W rows of a transition agree on a
  * handful of j* (1 546 distinct (b, j*) pairs of 16 384 at the flagship shape).  morl_envelope_update on the layer-fused engine
- * therefore runs: forward launch with the online next-state pass and the training pass -> arg-max over the online slab -> the
- * distinct (b, j*) pairs compacted -> the target network on THOSE rows (16-row tiles, device-side row count) -> TD target / loss
- * gradient.  Same values as the eager form (a row's Q does not depend on which rows share its tile); the eager form runs when the
- * caller asks for out->q_target_next, for the DDQN target, in the weight-sharded step and on the per-layer engine.
- * _set_lazy_targets returns the previous setting; _lazy_target_rows the pair count of the last lazy step (synchronises `stream`). */
+ * therefore runs: forward launch with the online next-state pass and the training pass -> arg-max over the online slab, the
+ * distinct (b, j*) pairs taking compact rows in the same launch -> the target network on THOSE rows (16-row tiles, device-side
+ * row count) -> TD target / loss gradient.  Same values as the eager form (a row's Q does not depend on which rows share its
+ * tile); the eager form runs when the caller asks for out->q_target_next, for the DDQN target, in the weight-sharded step, on the
+ * per-layer engine and for steps of fewer than 8 192 TD rows (latency-bound: measured slower lazily; MORL_LAZY_MIN_ROWS overrides).
+ * _set_lazy_targets returns the previous setting; _lazy_target_rows the rows the last lazy step evaluated -- its distinct pairs
+ * (with more than 64 weight vectors a transition's TD rows span several workgroups, and a pair selected from two of them is
+ * listed, and evaluated, once per workgroup); 0 if the last step ran eagerly.  Synchronises `stream`. */
 int morl_ctx_set_lazy_targets(morl_ctx* ctx, int enable);
 int morl_ctx_lazy_target_rows(morl_ctx* ctx, int* rows, void* stream);
 /* The shadow copies made by morl_envelope_prepare are consumed ONLY by the gradient step that directly follows it

@@ -195,6 +195,7 @@ struct morl_ctx {
     bool lazy_targets = true;            // MORL_LAZY_TARGETS=0 / morl_ctx_set_lazy_targets: evaluate the whole target slab instead
     int32_t* lz_best = nullptr;          // [max_rows] flattened (j*, a*) per TD row
     int lz_epoch = 0;                    // lazily evaluated steps so far (its parity picks the counter)
+    bool lz_last = false;                // the last morl_envelope_update ran lazily
     int32_t* lz_slot = nullptr;          // [max_rows] TD row -> compact row
     int32_t* lz_pairs = nullptr;         // [max_rows] compact row -> pair
     int32_t* lz_count = nullptr;         // [2] distinct pairs of the steps of even / odd epoch
@@ -884,10 +885,11 @@ extern "C" int morl_ctx_set_lazy_targets(morl_ctx* c, int enable) {
     return was;
 }
 
-// distinct (transition, weight) pairs whose target row the LAST lazily evaluated step computed (0 if none ran); synchronises
+// target rows the last morl_envelope_update evaluated lazily (its distinct (transition, weight) pairs; 0: it ran eagerly); synchronises
 extern "C" int morl_ctx_lazy_target_rows(morl_ctx* c, int* rows, void* stream) {
     if (!c || !rows) return fail(MORL_ERR_ARG, "NULL argument");
     int32_t n = 0;
+    if (!c->lz_last) { *rows = 0; return MORL_OK; }
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     HIP_TRY(hipMemcpy(&n, c->lz_count + (c->lz_epoch & 1), sizeof(n), hipMemcpyDeviceToHost));
     *rows = (int)n;
@@ -1411,6 +1413,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     const int rows = B * W, AR = A * R;
     static const morl_update_out no_out = {};
     if (!out) out = &no_out;
+    c->lz_last = false;
     timing_begin_step(c);
 
     // stage A: no-grad next-state slabs Qo, Qt [B][W][A][R] (B*W distinct rows instead of the reference's W^2*B)
@@ -1432,6 +1435,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
             // they drop (2 048 rows: 0.181 ms lazily, 0.149 eagerly; 8 192 rows: 0.255 against 0.262; MORL_LAZY_MIN_ROWS overrides)
             static const long long lazy_min_rows = [] { const char* e = getenv("MORL_LAZY_MIN_ROWS"); return e ? atoll(e) : 8192ll; }();
             c->lz_now = c->lazy_targets && cfg->envelope && W >= 2 && !out->q_target_next && rows >= lazy_min_rows;
+            c->lz_last = c->lz_now;
             if (c->lz_now) {
                 const ChainArgs two[2] = {
                     make_forward_chain(c, params_online, c->wt_online, next_obs, weights, B, W, 0, rows, false, c->qo, AR), main_chain};
