@@ -20,6 +20,7 @@
 #include "mlp_chain.h"
 #include "mlp_chain2.h"
 #include "mlp_chain16.h"
+#include "mlp_chain4.h"
 #include "dw_wave.h"
 #include "dw_tiles.h"
 #include "optim_kernels.h"
@@ -1130,10 +1131,17 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
                 t.in_mode = 3;
                 t.rows_dev = c->lz_count + (c->lz_epoch & 1);
                 t.pairs = c->lz_pairs;
-                Chain16Multi m16{};
-                const int tiles = chain16_fill(m16, &t, 1);
-                hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
-                LAUNCH_CHECK("mlp_chain16(lazy targets)");
+                static const bool few_rows = [] { const char* e = getenv("MORL_CHAIN4"); return e ? atoi(e) != 0 : true; }();   // (A/B)
+                if (few_rows && chain4_ok(t)) {
+                    // 8-row tiles (mlp_chain4.h): twice the workgroups, half the MFMA time per CU and layer
+                    hipLaunchKernelGGL(mlp_chain4_kernel, dim3((B * W + C4_TM - 1) / C4_TM), dim3(CH_THREADS), 0, s, t);
+                    LAUNCH_CHECK("mlp_chain4(lazy targets)");
+                } else {
+                    Chain16Multi m16{};
+                    const int tiles = chain16_fill(m16, &t, 1);
+                    hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
+                    LAUNCH_CHECK("mlp_chain16(lazy targets)");
+                }
             }
             // 3. TD target, loss gradient, priorities from the compact target rows
             p.phase = 2; p.best_io = c->lz_best; p.row_slot = c->lz_slot; p.qt = c->qt;

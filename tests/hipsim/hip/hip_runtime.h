@@ -276,6 +276,31 @@ static inline hipsim_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b
     return d;
 }
 
+// 16 blocks of 4x4x1: block b = lane / 4; lane 4b + i supplies A_b[i] and B_b[i]; register r of lane 4b + j is D_b[r][j].
+// cbsz = 4: the A operand of block `abid` is broadcast to all sixteen blocks (cbsz = 0: every block its own)
+namespace hipsim {
+static void fn_mfma_4x4x1(const CollIn* in, CollOut* out, int n) {
+    if (n != 64) { std::fprintf(stderr, "hipsim: MFMA needs a full wave (got %d lanes)\n", n); std::abort(); }
+    const int cbsz = in[0].i >> 8, abid = in[0].i & 255;
+    if (cbsz != 0 && cbsz != 4) { std::fprintf(stderr, "hipsim: mfma 4x4x1 cbsz %d not emulated\n", cbsz); std::abort(); }
+    for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < 4; ++r) {
+            const int a_lane = (cbsz == 4 ? 4 * abid : (l & ~3)) + r;
+            out[l].f[r] = std::fmaf(in[a_lane].f[0], in[l].f[1], in[l].f[2 + r]);
+        }
+}
+}  // namespace hipsim
+static inline hipsim_f32x4 __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, hipsim_f32x4 c, int cbsz, int abid, int) {
+    hipsim::CollIn in{};
+    in.i = (cbsz << 8) | abid;
+    in.f[0] = a; in.f[1] = b;
+    for (int r = 0; r < 4; ++r) in.f[2 + r] = c[r];
+    hipsim::CollOut o = hipsim::wave_collective(in, hipsim::fn_mfma_4x4x1);
+    hipsim_f32x4 d;
+    for (int r = 0; r < 4; ++r) d[r] = o.f[r];
+    return d;
+}
+
 // LDS-DMA: lane l copies `size` bytes from its own global address to (first lane's LDS pointer) + l*size
 namespace hipsim {
 static void fn_first_ptr(const CollIn* in, CollOut* out, int n) { for (int l = 0; l < n; ++l) out[l].u = in[0].u; }
