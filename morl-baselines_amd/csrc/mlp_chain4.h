@@ -256,6 +256,8 @@ static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain4_kernel(ChainA
     mlp_chain4_body(p, row0, n_rows, flat, sAct, sRed);
 }
 
+constexpr int C4_MAX_ROWS = 2048;           // (general forward chains: one tile per CU at most; the lazy target rows always take these tiles)
+
 // Host side: can this chain run on the 8-row tiles?
 inline bool chain4_ok(const ChainArgs& a) {
     if (a.fast != 1 || a.n_steps < 1 || a.nb > 1 || a.x0_out != nullptr) return false;

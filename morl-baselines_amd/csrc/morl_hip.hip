@@ -603,7 +603,12 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
     int slot = -1, rc_t;
     if ((rc_t = timing_open(c, kind, s, &slot))) return rc_t;
     static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
-    if (small_rows && chain16_wanted(chains, n)) {
+    static const bool few_rows = [] { const char* e = getenv("MORL_CHAIN4"); return e ? atoi(e) != 0 : true; }();
+    if (small_rows && few_rows && n == 1 && !td && chains[0].rows <= C4_MAX_ROWS && chain4_ok(chains[0])) {
+        // one no-grad forward chain over at most a tile per CU (acting, evaluation, greedy actions): 8-row tiles (mlp_chain4.h),
+        // bit-identical rows to the 16-row tiles at two thirds of their latency
+        hipLaunchKernelGGL(mlp_chain4_kernel, dim3((chains[0].rows + C4_TM - 1) / C4_TM), dim3(CH_THREADS), 0, s, chains[0]);
+    } else if (small_rows && chain16_wanted(chains, n)) {
         // few rows (small batches, shards of a strong-scaled job): 16-row tiles, one workgroup each (mlp_chain16.h)
         Chain16Multi m16{};
         const int tiles = chain16_fill(m16, chains, n);
