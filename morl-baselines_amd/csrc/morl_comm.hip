@@ -252,7 +252,8 @@ namespace {
 
 constexpr int IPC_MAX_WORLD = 8;
 constexpr int IPC_THREADS = 256;
-constexpr long long IPC_TIMEOUT_TICKS = 300000000ll;       // wall_clock64() ticks at 100 MHz: 3 s
+constexpr long long IPC_TIMEOUT_TICKS = 300000000ll;       // wall_clock64() ticks at 100 MHz: 3 s (MORL_IPC_TIMEOUT_MS overrides: ranks
+                                                            // that SHARE a device, as in the tests, wait on each other's time slices)
 enum { IPC_PH_AG = 0, IPC_PH_RS = 1, IPC_PH_AR = 2 };
 
 struct IpcHeader {                                  // at the start of every rank's region
@@ -264,6 +265,7 @@ struct IpcPeers { float* base[IPC_MAX_WORLD]; };    // every rank's region as ma
 struct IpcGeom {
     long long inbox_off, outbox_off, gather_off;    // float offsets from the region base
     long long chunk_cap, ag_cap;                    // floats per inbox slot / per gather slot
+    long long timeout_ticks;                        // bound of every wait
     int rank, world;
 };
 
@@ -287,12 +289,12 @@ __device__ __forceinline__ void ipc_finish_and_signal(const IpcPeers& P, const I
 }
 
 // the workgroup waits until every rank has signalled `epoch` for `phase` in MY header (bounded)
-__device__ __forceinline__ void ipc_wait(IpcHeader* mine, int world, int phase, unsigned epoch) {
+__device__ __forceinline__ void ipc_wait(IpcHeader* mine, int world, int phase, unsigned epoch, long long timeout_ticks) {
     if ((int)threadIdx.x < world) {
         const long long t0 = wall_clock64();
         while ((int)(__hip_atomic_load(&mine->flag[phase][threadIdx.x][0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
             __builtin_amdgcn_s_sleep(63);
-            if (wall_clock64() - t0 > IPC_TIMEOUT_TICKS) { mine->error = 1u + (unsigned)phase; break; }
+            if (wall_clock64() - t0 > timeout_ticks) { mine->error = 1u + (unsigned)phase; break; }
         }
     }
     __syncthreads();
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(IPC_THREADS) void ipc_push_kernel(IpcPeers P, IpcGe
 __global__ __launch_bounds__(IPC_THREADS) void ipc_collect_kernel(IpcPeers P, IpcGeom g, float* __restrict__ recv, long long count,
                                                                   unsigned epoch) {
     float* mine = P.base[g.rank];
-    ipc_wait(ipc_hdr(mine), g.world, IPC_PH_AG, epoch);
+    ipc_wait(ipc_hdr(mine), g.world, IPC_PH_AG, epoch, g.timeout_ticks);
     const float* gather = mine + g.gather_off;
     for (int r = 0; r < g.world; ++r) ipc_copy(recv + (long long)r * count, gather + (long long)r * g.ag_cap, count);
 }
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(IPC_THREADS) void ipc_collect_kernel(IpcPeers P, Ip
 __global__ __launch_bounds__(IPC_THREADS) void ipc_reduce_kernel(IpcPeers P, IpcGeom g, float* __restrict__ buf, long long count,
                                                                  long long chunk, unsigned epoch, unsigned* ticket) {
     float* mine = P.base[g.rank];
-    ipc_wait(ipc_hdr(mine), g.world, IPC_PH_RS, epoch);
+    ipc_wait(ipc_hdr(mine), g.world, IPC_PH_RS, epoch, g.timeout_ticks);
     const long long start = g.rank * chunk < count ? g.rank * chunk : count;
     const long long len = count - start < chunk ? count - start : chunk;
     const float* inbox = mine + g.inbox_off;
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(IPC_THREADS) void ipc_reduce_kernel(IpcPeers P, Ipc
 
 __global__ __launch_bounds__(IPC_THREADS) void ipc_pull_kernel(IpcPeers P, IpcGeom g, float* __restrict__ buf, long long count,
                                                                long long chunk, unsigned epoch) {
-    ipc_wait(ipc_hdr(P.base[g.rank]), g.world, IPC_PH_AR, epoch);
+    ipc_wait(ipc_hdr(P.base[g.rank]), g.world, IPC_PH_AR, epoch, g.timeout_ticks);
     const int j = (int)blockIdx.y;
     if (j == g.rank) return;
     const long long start = j * chunk < count ? j * chunk : count;
@@ -441,6 +443,8 @@ extern "C" int morl_comm_ipc_create(morl_comm** out, int rank, int world, int64_
     st->max_ar = max_allreduce_floats; st->max_ag = max_allgather_floats;
     IpcGeom& g = st->geom;
     g.rank = rank; g.world = world;
+    g.timeout_ticks = IPC_TIMEOUT_TICKS;
+    if (const char* e = getenv("MORL_IPC_TIMEOUT_MS")) g.timeout_ticks = std::max(1ll, atoll(e)) * 100000ll;
     g.chunk_cap = round4((max_allreduce_floats + world - 1) / world);
     g.ag_cap = round4(std::max<int64_t>(max_allgather_floats, 4));
     g.inbox_off = (long long)(sizeof(IpcHeader) / sizeof(float));

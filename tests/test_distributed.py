@@ -596,6 +596,9 @@ def test_data_parallel_capql_over_rccl_single_rank():
 # gfx950 kernels, the side-stream all-gather beside the training forward, the gathered-slab layout read in place, the PER update
 # behind the all-reduce -- is what a multi-GPU job runs.  Replicas must stay bit-identical and equal the unsharded step.
 def _shared_gpu_worker(rank, world, port, per, axis, ret):
+    # the ranks SHARE one device here: a rank's spin-wait competes with the peer it waits for (and with their first-call set-up)
+    # for the same CUs and time slices, so the single-hop transport's 3 s bound -- ample between GPUs -- gets 30 s
+    os.environ["MORL_IPC_TIMEOUT_MS"] = "30000"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]

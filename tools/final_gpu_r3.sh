@@ -3,7 +3,7 @@ set -x
 R=$PWD
 O=gpurun_out/final_r3
 mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -6 > $O/gpu_tests.log
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -80 > $O/gpu_tests.log
 timeout 200 python __graft_entry__.py --smoke > $O/smoke.log 2>&1
 timeout 300 python bench.py > $O/bench_per_on.json 2> $O/bench_per_on.err
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_like.json 2>/dev/null
