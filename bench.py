@@ -45,9 +45,9 @@ BWD_DX_FLOP_ROW = 2 * (A * R * 256 + 3 * 256 * 256)               # dX chain (no
 PEAK_FP32_MFMA_TFLOPS = 157.3                                     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 # One rank of an N-rank strong-scaled job run alone on one MI355X (--force-shard --emulate-world N; profiles/r02_bench_emulated_
 # rank_of_*.json): single-GPU step time / that rank's step time = what N GPUs could reach if the collectives were free.
-EMULATED_CEILING = {"source": "profiles/r03_bench_emulated_rank_of_{2,4,8}.json (batch axis: 0.256 / 0.174 / 0.143 ms against 0.357), "
-                              "profiles/r02_*_weight_axis.json (weight axis); one rank run alone on a 1-GPU box",
-                    "batch_axis": {"2": 1.40, "4": 2.06, "8": 2.50}, "weight_axis": {"2": 1.35, "4": 1.85, "8": 2.05},
+EMULATED_CEILING = {"source": "profiles/r03_bench_emulated_rank_of_{2,4,8}.json (batch axis: 0.242 / 0.172 / 0.148 ms against 0.325), "
+                              "profiles/r02_*_weight_axis.json (weight axis: 0.264 / 0.194 / 0.175 ms); one rank run alone on a 1-GPU box",
+                    "batch_axis": {"2": 1.34, "4": 1.89, "8": 2.20}, "weight_axis": {"2": 1.23, "4": 1.68, "8": 1.86},
                     "note": "upper bounds BEFORE any collective latency; the >= 6x of north_star is only reachable in the weak "
                             "reading (W grows with N), which is a different workload from the metric"}
 
