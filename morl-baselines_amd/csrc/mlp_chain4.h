@@ -261,7 +261,7 @@ constexpr int C4_MAX_ROWS = 2048;           // (general forward chains: one tile
 // Host side: can this chain run on the 8-row tiles?
 inline bool chain4_ok(const ChainArgs& a) {
     if (a.fast != 1 || a.n_steps < 1 || a.nb > 1 || a.x0_out != nullptr) return false;
-    if (!(a.in_mode == 0 || a.in_mode == 1 || a.in_mode == 3)) return false;
+    if (!(a.in_mode == 0 || a.in_mode == 3)) return false;          // (a dense input matrix, in_mode 1, is handled by the body but has no caller yet)
     if (!(a.step[0].N > 32)) return false;
     for (int s = 0; s < a.n_steps; ++s) {
         const ChainStep& st = a.step[s];
