@@ -45,7 +45,7 @@ struct ChainArgs {
     int rows;
     // input assembly
     int in_mode;            // 0: cat(obs[b], weights[k]) with row -> (b, k) by row_order ; 1: dense matrix src[rows][ldsrc] ;
-                            // 3 (mlp_chain16 only): cat(obs[b], weights[j]) of the listed pairs, see rows_dev / pairs ;
+                            // 3 (mlp_chain16 / mlp_chain4 only): cat(obs[b], weights[j]) of the listed pairs, see rows_dev / pairs ;
                             // 2 (mlp_chain2 only): the rows are dLoss/dQ of a gradient step, computed by the tile itself (chain_td.h)
     const float* obs;       // [B][D]
     const float* weights;   // [W][R]  (row_order 2: [rows][R], paired with obs rows)
@@ -58,8 +58,8 @@ struct ChainArgs {
     int nb;                 // mlp_chain2: networks batched in this chain (0 / 1: one); unit u -> network u / units_per_net
     long long sSrc;         //   floats between the input matrices (in_mode 1) of consecutive input groups
     int src_div;            //   networks per input group (twin critics share their input rows)
-    // mlp_chain16, in_mode 3 (the lazily evaluated target rows of an Envelope step): row r is the pair pairs[r] = b * W + j, i.e.
-    // cat(obs[b], weights[j]); the row count is whatever the compaction kernel left in *rows_dev (rows = the upper bound the
+    // mlp_chain16 / mlp_chain4, in_mode 3 (the lazily evaluated target rows of an Envelope step): row r is the pair pairs[r] =
+    // b * W + j, i.e. cat(obs[b], weights[j]); the row count is what the arg-max launch left in *rows_dev (rows = the upper bound the
     // grid was sized for: tiles beyond the count exit at once)
     const int* rows_dev;
     const int32_t* pairs;
