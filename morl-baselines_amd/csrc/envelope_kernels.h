@@ -168,8 +168,8 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
     __shared__ float s_tgt[ENV_MAX_WR];   // selected target vectors
     __shared__ float s_g[ENV_MAX_WR];     // dLoss/dQ of the taken action
     __shared__ int s_best[ENV_MAX_WR];    // flattened (j*, a*)
-    __shared__ int s_mark[PHASE == 1 ? ENV_MAX_WR / 2 : 4];    // [W] (W * R <= ENV_MAX_WR, R >= 2): lowest TD row of this workgroup that selected weight j
-    __shared__ int s_slot[PHASE == 1 ? ENV_MAX_WR / 2 : 4];    // [W]: compact target row of (b, j)
+    __shared__ int s_mark[PHASE == 1 ? ENV_MAX_WR : 4];        // [W] (W * R <= ENV_MAX_WR): lowest TD row of this workgroup that selected weight j
+    __shared__ int s_slot[PHASE == 1 ? ENV_MAX_WR : 4];        // [W]: compact target row of (b, j)
     __shared__ float s_pv[ENV_MAX_WAVES][kWave];   // per-wave partial maxima of the 64 rows in flight ...
     __shared__ int s_pc[ENV_MAX_WAVES][kWave];     // ... and their candidate indices
     __shared__ double s_red[4][2];
