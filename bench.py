@@ -301,11 +301,12 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", 
         dist.barrier()
         th.cuda.synchronize()
     # chain launches are event-timed on the library's stream.  An event record costs ~3.5 us of stream time (four records
-    # around the two chain launches of a step: +14 us = 4 %), so short runs (the driver's --steps 20) bracket ONE launch per
-    # step, the launches of a step taking turns, and long runs bracket all launches of every 4th step.
-    timing_every = int(os.environ.get("MORL_BENCH_TIMING", -1 if steps <= 50 else 4))
+    # around the two chain launches of a step: +14 us = 4 %), so short runs (the driver's --steps 20) bracket ONE launch on
+    # every second step, the launches of a step taking turns (a 5 + 20 run: 10 launches, 3 - 4 of each kind; bracketing one on
+    # EVERY step cost the step ~5 us: 0.332 ms against 0.325 unbracketed), and long runs all launches of every 8th step.
+    timing_every = int(os.environ.get("MORL_BENCH_TIMING", (-2 if steps >= 12 else -1) if steps <= 50 else 8))
     if not launches_per_step:
-        timing_every = 1 if timing_every == -1 else timing_every
+        timing_every = 1 if timing_every < 0 else timing_every
     agent.q_net.ctx.set_timing(timing_every)
     e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -330,7 +331,8 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     res = {"wall": wall, "host_enqueue_ms_per_step": t_enq * 1e3 / steps, "gpu_ms_per_step_events": gpu_ms / steps,
-           "n_chain": n_chain, "chain_ms": chain_ms, "timed_steps": (len(range(0, steps, timing_every)) if timing_every > 0 else steps if timing_every == -1 else 0),
+           "n_chain": n_chain, "chain_ms": chain_ms, "timed_steps": (len(range(0, steps, timing_every)) if timing_every > 0 else steps if timing_every == -1
+                                                                  else (steps + 1) // 2 if timing_every == -2 else 0),
            "launches_per_step": launches_per_step, "timing_mode": timing_every, "kinds": kinds,
            "fwd_launches_per_step": kinds0["forward"][0], "fwd2_launches_per_step": kinds0["forward2"][0], "transport": transport, "axis": axis if sharded else None,
            "lazy_target_rows": lazy_rows,

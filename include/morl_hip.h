@@ -117,7 +117,7 @@ int morl_ctx_set_dw_mode(morl_ctx* ctx, int mode);
 /* Per-launch timing of the dominant kernel (the layer-fused MLP chain): every = n > 0 brackets the chain launches of every
  * n-th Envelope step (counted from this call; the first one is timed) with HIP event pairs on the caller's stream, 0 turns it
  * off, -1 brackets ONE chain launch of every step (the launches of a step take turns, so that every kind of launch is sampled
- * equally often at a quarter of the event records).  An event record costs a few microseconds of stream time, so sampling keeps the measurement from perturbing the step
+ * equally often at a quarter of the event records), -2 the same on every second step.  An event record costs a few microseconds of stream time, so sampling keeps the measurement from perturbing the step
  * it measures.  morl_ctx_read_timing blocks until the recorded launches have finished, returns their number and summed
  * duration (ms) and clears the record.  Used by bench.py for the roofline figure. */
 int morl_ctx_set_timing(morl_ctx* ctx, int every);

@@ -728,7 +728,7 @@ extern "C" int morl_ctx_set_dw_mode(morl_ctx* c, int mode) {
 
 extern "C" int morl_ctx_set_timing(morl_ctx* c, int every) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
-    if (every < -1) return fail(MORL_ERR_ARG, "every < -1");
+    if (every < -2) return fail(MORL_ERR_ARG, "every < -2");
     c->timing_every = every;
     c->timing_idx = c->timing_prev_launches = 0;
     c->timing_rotate = -1;
@@ -756,11 +756,13 @@ extern "C" int morl_ctx_set_timing(morl_ctx* c, int every) {
 
 // called at the first library entry of an Envelope step (morl_envelope_update, or morl_envelope_slabs of a sharded step)
 static void timing_begin_step(morl_ctx* c) {
-    if (c->timing_every == -1) {
-        // every step, one launch: the launches of a step take turns (two event records instead of two per launch)
-        c->timing = true;
+    if (c->timing_every == -1 || c->timing_every == -2) {
+        // every step (-1) or every second one (-2), one launch: the launches of a step take turns (two event records instead of
+        // two per launch)
+        const long long period = c->timing_every == -2 ? 2 : 1;
         if (c->timing_idx > 0) c->timing_prev_launches = c->timing_idx;
-        c->timing_rotate = c->timing_prev_launches > 0 ? (int)(c->timing_step % c->timing_prev_launches) : 0;
+        c->timing = (c->timing_step % period) == 0;
+        c->timing_rotate = c->timing_prev_launches > 0 ? (int)((c->timing_step / period) % c->timing_prev_launches) : 0;
     } else {
         c->timing = c->timing_every > 0 && (c->timing_step % c->timing_every) == 0;
         c->timing_rotate = -1;

@@ -167,7 +167,8 @@ def test_envelope_update_matches_oracle(be, per):
 
 
 def test_chain_launch_timing_modes(be):
-    """morl_ctx_set_timing: every step (n = 1), every n-th step, one launch per step taking turns (-1), off (0)."""
+    """morl_ctx_set_timing: every step (n = 1), every n-th step, one launch per step taking turns (-1), the same on every second
+    step (-2), off (0)."""
     lib, dev = be
     env = ToyEnv()
     ag = envmod.Envelope(env, net_arch=[64, 64], batch_size=16, num_sample_w=4, buffer_size=512, per=False, learning_starts=20,
@@ -187,18 +188,19 @@ def test_chain_launch_timing_modes(be):
     ag.update()
     n_chain, ms_chain = ctx.read_timing()                    # the two chain kinds only
     assert n_chain == chain_per_step and ms_chain >= 0.0
-    for every, steps, want in ((1, 3, 3 * per_step), (2, 4, 2 * per_step), (-1, 2 * per_step, 2 * per_step), (0, 2, 0)):
+    for every, steps, want in ((1, 3, 3 * per_step), (2, 4, 2 * per_step), (-1, 2 * per_step, 2 * per_step),
+                               (-2, 4 * per_step, 2 * per_step), (0, 2, 0)):
         ctx.set_timing(every)
         for _ in range(steps):
             ag.update()
         got = ctx.read_timing_kinds()
         assert sum(n for n, _ in got.values()) == want and all(ms >= 0.0 for _, ms in got.values())
-        if every == -1:                                      # taking turns: every launch site sampled equally often
+        if every < 0:                                        # taking turns: every launch site sampled equally often
             assert got["backward"][0] == 2 and got["dw"][0] == 2 and got["forward"][0] + got["forward2"][0] == 2 * fwd
     assert ctx.read_timing() == (0, 0.0)                    # reading clears the record
     ctx.set_timing(0)
     with pytest.raises(Exception):
-        ctx.set_timing(-2)
+        ctx.set_timing(-3)
 
 
 def test_envelope_train_save_load(be, tmp_path):
