@@ -151,3 +151,52 @@ def test_td_stage_inside_the_backward_chain_equals_the_separate_kernel():
 def test_td_stage_inside_the_backward_chain_equals_the_separate_kernel_on_the_gpu():
     _run_td_fused_snippet("gpu", {"MORL_CHAIN16": "0"})
     _run_td_fused_snippet("gpu", {})              # by size: only the 12 288-row case takes the fused stage
+
+
+_CHAIN4_SNIPPET = r"""
+import hashlib, os, sys
+import numpy as np, torch as th
+ROOT = sys.argv[1]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import morl_baselines_amd.ops as ops
+if sys.argv[2] == "gpu":
+    from morl_baselines_amd.native import load_library
+    lib, dev = load_library(), th.device("cuda:0")
+else:
+    import simlib
+    lib, dev = simlib.load_sim(), th.device("cpu")
+h = hashlib.sha256()
+g = th.Generator().manual_seed(5)
+# (rows, obs, objectives, actions, arch): ragged against the 8- and 16-row tiles, one to four hidden layers, narrow and wide heads
+shapes = [(1, 7, 3, 6, (256,)), (8, 7, 3, 6, (256, 256)), (9, 5, 2, 3, (256, 256)), (23, 32, 3, 6, (256, 256, 256, 256)),
+          (40, 11, 4, 12, (256, 256, 256)), (70, 3, 2, 2, (256,))]
+if sys.argv[2] == "gpu":
+    shapes += [(1355, 32, 3, 6, (256, 256, 256, 256)), (2048, 32, 3, 6, (256, 256, 256, 256))]
+for rows, D, R, A, arch in shapes:
+    ctx = ops.QNetContext(D, R, A, arch, rows, 1, lib=lib)
+    p = (th.randn(ctx.n_params, generator=g) * 0.08).to(dev)
+    obs, w = th.randn(rows, D, generator=g).to(dev), th.rand(rows, R, generator=g).to(dev)
+    q = ops.qnet_forward_rows(ctx, p, obs, w)
+    assert th.isfinite(q).all()
+    h.update(q.cpu().numpy().tobytes())
+    ctx.close()
+print("CHAIN4_DIGEST", h.hexdigest())
+"""
+
+
+def _chain4_digest(mode, extra_env):
+    r = subprocess.run([sys.executable, "-c", _CHAIN4_SNIPPET, ROOT, mode], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, **extra_env), cwd=ROOT)
+    assert r.returncode == 0 and "CHAIN4_DIGEST" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout.split("CHAIN4_DIGEST")[1].split()[0]
+
+
+def test_eight_row_tiles_give_the_bits_of_the_sixteen_row_tiles():
+    """``mlp_chain4.h`` (8-row tiles on the 16-block 4x4x1 MFMA) takes every eligible no-grad forward chain of at most 2 048 rows;
+    its contraction order is the one of ``mlp_chain16.h``, so the outputs must be the same BITS with the variant switched off."""
+    assert _chain4_digest("sim", {}) == _chain4_digest("sim", {"MORL_CHAIN4": "0"})
+
+
+@pytest.mark.gpu
+def test_eight_row_tiles_give_the_bits_of_the_sixteen_row_tiles_on_the_gpu():
+    assert _chain4_digest("gpu", {}) == _chain4_digest("gpu", {"MORL_CHAIN4": "0"})
