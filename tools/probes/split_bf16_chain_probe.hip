@@ -56,8 +56,15 @@ __device__ __forceinline__ f32x16 six(const bf16x8 (&a)[3], const bf16x8 (&b)[3]
     return c;
 }
 
+// MODE 0: the pass.  Decomposition runs (wrong results, timing only): 1 = operand traffic and epilogue without the MFMAs,
+// 2 = MFMAs and operand traffic with a trivial epilogue (hi part stored three times, no splitting), 3 = MFMAs only (operands
+// loaded once per layer, trivial epilogue)
+// 4 = like 3 with the six products of the four accumulators interleaved (no two consecutive MFMAs share an accumulator)
+__device__ long long g_clk[4];          // [0..1] shader cycles, [2..3] 100 MHz wall clock, first workgroup
+template <int MODE>
 __global__ __launch_bounds__(THREADS, 1) void chain_split_bf16(Net net, const float* __restrict__ x, float* __restrict__ q) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[0] = __builtin_readcyclecounter(); g_clk[2] = wall_clock64(); }
     unsigned short* act[3] = {lds, lds + TM * LDA, lds + 2 * TM * LDA};      // hi / mid / lo, [TM][LDA]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * TM;
@@ -71,6 +78,8 @@ __global__ __launch_bounds__(THREADS, 1) void chain_split_bf16(Net net, const fl
     }
     __syncthreads();
     const int rl = lane & 31, kg = lane >> 5;                  // operand row / column within a 32-tile, k-group (8 indices) of a 16-step
+    bf16x8 bA[2][3];                                           // first weight set of a layer: fetched before the previous layer's epilogue
+    bool have_bA = false;
     for (int s = 0; s < L; ++s) {
         const Layer& ly = net.l[s];
         const int steps = ly.kpad >> 4;
@@ -102,11 +111,36 @@ __global__ __launch_bounds__(THREADS, 1) void chain_split_bf16(Net net, const fl
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct)
-                    if (ct < n_ct) acc[rt][ct] = six(a[rt], b[ct], acc[rt][ct]);
+                    if (ct < n_ct) {
+                        if (MODE == 4) continue;
+                        if (MODE == 1) acc[rt][ct][0] += (float)a[rt][0][0] + (float)b[ct][0][0] + (float)a[rt][1][1] + (float)b[ct][1][1] + (float)a[rt][2][2] + (float)b[ct][2][2];
+                        else acc[rt][ct] = six(b[ct], a[rt], acc[rt][ct]);      // weights are the A operand: D[feature][batch row]
+                    }
         };
-        bf16x8 bA[2][3], bB[2][3], aA[2][3], aB[2][3];
-        load_b(bA, s_lo);
+        bf16x8 bB[2][3], aA[2][3], aB[2][3];
+        if (!have_bA) load_b(bA, s_lo);
         load_a(aA, s_lo);
+        // this layer's bias quads (wide layers), in flight under the MFMA loop
+        float4 bias_q[2][4];
+        if (wide)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) bias_q[ct][g4] = *reinterpret_cast<const float4*>(ly.bias + col_base + ct * 32 + 8 * g4 + 4 * kg);
+        if (MODE == 3) {
+            for (int st = s_lo; st < s_hi; ++st) mul(aA, bA);
+        } else if (MODE == 4) {
+            constexpr int pa[6] = {2, 1, 0, 1, 0, 0}, pb[6] = {0, 1, 2, 0, 1, 0};
+            for (int st = s_lo; st < s_hi; ++st) {
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+                            if (ct < n_ct) acc[rt][ct] = mfma_bf(bA[ct][pb[p]], aA[rt][pa[p]], acc[rt][ct]);
+            }
+        } else
         for (int st = s_lo; st < s_hi; st += 2) {
             const int s1 = min(st + 1, s_hi - 1), s2 = min(st + 2, s_hi - 1);
             load_b(bB, s1);
@@ -116,6 +150,20 @@ __global__ __launch_bounds__(THREADS, 1) void chain_split_bf16(Net net, const fl
             load_a(aA, s2);
             if (st + 1 < s_hi) mul(aB, bB);
         }
+        have_bA = false;
+        if (MODE != 3 && MODE != 4 && s + 1 < L) {
+            // the next layer's first weight set rides under this layer's epilogue and barriers
+            const Layer& nl = net.l[s + 1];
+            const bool nwide = nl.npad > 32;
+            const int nsteps = nl.kpad >> 4;
+            const int n_lo = nwide ? 0 : (nsteps * wave) / 4, ncb = nwide ? wave * 64 : 0;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bA[ct][p] = *reinterpret_cast<const bf16x8*>(nl.w[p] + ((size_t)(n_lo * 2 + kg) * nl.npad + ncb + ((nwide && ct == 1) ? 32 : 0) + rl) * 8);
+            have_bA = true;
+        }
         __syncthreads();                // every wave is past its last read of the activations
         if (!wide) {
             // split-K partials through LDS (the activation buffer is free): [wave][64 rows][32 cols] fp32
@@ -124,8 +172,8 @@ __global__ __launch_bounds__(THREADS, 1) void chain_split_bf16(Net net, const fl
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                    red[(wave * TM + m) * 32 + rl] = acc[rt][0][r];
+                    const int n = (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    red[(wave * TM + rt * 32 + rl) * 32 + n] = acc[rt][0][r];
                 }
             __syncthreads();
             for (int e = tid; e < TM * 32; e += THREADS) {
@@ -138,25 +186,52 @@ __global__ __launch_bounds__(THREADS, 1) void chain_split_bf16(Net net, const fl
                 if (n < N_OUT) q[(size_t)(row0 + m) * N_OUT + n] = v;       // (last layer of this probe)
             }
         } else {
+            // lane = batch row, registers = features: the four registers of a group are four CONSECUTIVE features -> one 8-byte LDS
+            // store per split part and group (the first version, lane = feature, issued 192 two-byte stores per lane and layer:
+            // 24 of its 51 us)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
-                    const int col = col_base + ct * 32 + rl;
-                    const float bias = ly.bias[col];
+                    const int m = rt * 32 + rl;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                        float v = acc[rt][ct][r] + bias;
-                        if (ly.relu) v = fmaxf(v, 0.f);
-                        unsigned short h, md, lo;
-                        split3(v, h, md, lo);
-                        act[0][m * LDA + col] = h; act[1][m * LDA + col] = md; act[2][m * LDA + col] = lo;
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int f0 = col_base + ct * 32 + 8 * g4 + 4 * kg;
+                        const float4 bias = bias_q[ct][g4];
+                        const float bv[4] = {bias.x, bias.y, bias.z, bias.w};
+                        unsigned short h[4], md[4], lo[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            float v = acc[rt][ct][4 * g4 + u] + bv[u];
+                            if (ly.relu) v = fmaxf(v, 0.f);
+                            if (MODE >= 2) { h[u] = md[u] = lo[u] = (unsigned short)(__float_as_uint(v) >> 16); }
+                            else split3(v, h[u], md[u], lo[u]);
+                        }
+                        *reinterpret_cast<uint2*>(act[0] + m * LDA + f0) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+                        *reinterpret_cast<uint2*>(act[1] + m * LDA + f0) = make_uint2(md[0] | ((unsigned)md[1] << 16), md[2] | ((unsigned)md[3] << 16));
+                        *reinterpret_cast<uint2*>(act[2] + m * LDA + f0) = make_uint2(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16));
                     }
                 }
         }
         __syncthreads();
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[1] = __builtin_readcyclecounter(); g_clk[3] = wall_clock64(); }
+}
+
+// pure issue-rate check of the instruction: NACC independent accumulators per wave, `blocks` workgroups of 4 waves
+template <int NACC>
+__global__ __launch_bounds__(THREADS) void mfma_rate(float* out, int iters) {
+    f32x16 acc[NACC];
+    for (int a = 0; a < NACC; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    bf16x8 x, y;
+    for (int e = 0; e < 8; ++e) { x[e] = (__bf16)(0.001f * (threadIdx.x + e)); y[e] = (__bf16)(0.002f * (threadIdx.x % 13 + e)); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 24; ++u) acc[u % NACC] = mfma_bf(x, y, acc[u % NACC]);
+    }
+    float sum = 0.f;
+    for (int a = 0; a < NACC; ++a) for (int r = 0; r < 16; ++r) sum += acc[a][r];
+    out[blockIdx.x * THREADS + threadIdx.x] = sum;
 }
 
 static unsigned short h_f2bf(float x) { unsigned u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
@@ -211,18 +286,58 @@ int main() {
     CK(hipMalloc(&dq, (size_t)ROWS * N_OUT * 4));
     CK(hipMemcpy(dx, X.data(), X.size() * 4, hipMemcpyHostToDevice));
     const size_t lds_bytes = (size_t)3 * TM * LDA * 2;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_split_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(chain_split_bf16, dim3(ROWS / TM), dim3(THREADS), lds_bytes, 0, net, dx, dq);
-    CK(hipDeviceSynchronize());
-    CK(hipEventRecord(e0));
     const int reps = 50;
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(chain_split_bf16, dim3(ROWS / TM), dim3(THREADS), lds_bytes, 0, net, dx, dq);
-    CK(hipEventRecord(e1));
-    CK(hipEventSynchronize(e1));
     float ms = 0;
-    CK(hipEventElapsedTime(&ms, e0, e1));
+    auto time_mode = [&](auto kernel, const char* what) -> int {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kernel, dim3(ROWS / TM), dim3(THREADS), lds_bytes, 0, net, dx, dq);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kernel, dim3(ROWS / TM), dim3(THREADS), lds_bytes, 0, net, dx, dq);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float t = 0;
+        CK(hipEventElapsedTime(&t, e0, e1));
+        long long clk[4];
+        CK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof(clk)));
+        printf("  %-78s %6.1f us   (first workgroup: %.2f GHz shader clock over its %.1f us)\n", what, t * 1e3 / reps,
+               (double)(clk[1] - clk[0]) / ((double)(clk[3] - clk[2]) * 10.0), (double)(clk[3] - clk[2]) / 100.0);
+        ms = t;
+        return 0;
+    };
+    {   // issue rate of v_mfma_f32_32x32x16_bf16 from one and from two waves per SIMD
+        float* dr;
+        CK(hipMalloc(&dr, (size_t)1024 * THREADS * 4));
+        auto rate = [&](auto kernel, int blocks, const char* what) -> int {
+            const int iters = 512;
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), 0, 0, dr, iters);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), 0, 0, dr, iters);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float t = 0;
+            CK(hipEventElapsedTime(&t, e0, e1));
+            const double n = 24.0 * iters;
+            printf("  %-60s %6.2f ns per MFMA per wave, %7.1f TFLOP/s (bf16) chip-wide\n", what, t * 1e6 / n,
+                   (double)blocks * 4 * n * 32768.0 / (t * 1e-3) / 1e12);
+            return 0;
+        };
+        printf("v_mfma_f32_32x32x16_bf16 issue rate:\n");
+        if (rate(mfma_rate<4>, 256, "4 accumulators, 1 wave per SIMD (256 workgroups)")) return 1;
+        if (rate(mfma_rate<4>, 512, "4 accumulators, 2 waves per SIMD (512 workgroups)")) return 1;
+        if (rate(mfma_rate<2>, 512, "2 accumulators, 2 waves per SIMD")) return 1;
+        if (rate(mfma_rate<4>, 1024, "4 accumulators, 4 waves per SIMD (1024 workgroups)")) return 1;
+    }
+    printf("decomposition (timing only, results of these three are not the forward pass):\n");
+    if (time_mode(chain_split_bf16<1>, "operand traffic + epilogue, no MFMAs")) return 1;
+    if (time_mode(chain_split_bf16<2>, "MFMAs + operand traffic, trivial epilogue (no splitting)")) return 1;
+    if (time_mode(chain_split_bf16<3>, "MFMAs only (operands loaded once per layer, trivial epilogue)")) return 1;
+    if (time_mode(chain_split_bf16<4>, "MFMAs only, the products of the four accumulators interleaved")) return 1;
+    printf("the pass:\n");
+    if (time_mode(chain_split_bf16<0>, "six-product forward pass")) return 1;
     std::vector<float> Q((size_t)ROWS * N_OUT);
     CK(hipMemcpy(Q.data(), dq, Q.size() * 4, hipMemcpyDeviceToHost));
     // float64 and float32 forwards of 256 sampled rows on the host
