@@ -31,7 +31,7 @@ extern "C" {
 
 #define MORL_MAX_LAYERS 8   /* linear layers per network */
 #define MORL_MAX_OBJ 8      /* reward dimension R */
-#define MORL_ABI_VERSION 10
+#define MORL_ABI_VERSION 11
 
 typedef enum morl_status {
     MORL_OK = 0,
@@ -177,7 +177,8 @@ int morl_envelope_prepare(morl_ctx* ctx, const float* params_online, const float
  * row count) -> TD target / loss gradient.  Same values as the eager form (a row's Q does not depend on which rows share its
  * tile); the eager form runs when the caller asks for out->q_target_next, for the DDQN target, in the weight-sharded step, on the
  * per-layer engine and for steps of fewer than 8 192 TD rows (latency-bound: measured slower lazily; MORL_LAZY_MIN_ROWS overrides).
- * _set_lazy_targets returns the previous setting; _lazy_target_rows the rows the last lazy step evaluated -- its distinct pairs
+ * _set_lazy_targets: 0 always eager, 1 (default) lazy from that row count on, 2 lazy at every size (what smoke() and the small
+ * fixtures use to put the default pipeline of large steps under the oracle); returns the previous setting; _lazy_target_rows the rows the last lazy step evaluated -- its distinct pairs
  * (with more than 64 weight vectors a transition's TD rows span several workgroups, and a pair selected from two of them is
  * listed, and evaluated, once per workgroup); 0 if the last step ran eagerly.  Synchronises `stream`. */
 int morl_ctx_set_lazy_targets(morl_ctx* ctx, int enable);
@@ -292,12 +293,17 @@ int morl_comm_init_custom(morl_comm** out, int rank, int world, morl_allgather_f
  * push + collect, all-reduce = push (reduce-scatter) + reduce in rank order + pull (csrc/morl_comm.hip).  Two-phase set-up, at most
  * 8 ranks: _create allocates this rank's shared region (sized for all-reduces of max_allreduce_floats and all-gathers of
  * max_allgather_floats per rank) and returns its 64-byte handle; the caller all-gathers the world's handles through any side
- * channel; _connect maps the peers.  Waits are bounded (3 s): morl_comm_check reports a peer that never arrived. */
+ * channel; _connect maps the peers.  Waits are bounded (3 s).  A wait that runs out is never silent: it sets an error word that (a)
+ * the clip + Adam launch of the one-call sharded steps reads on the device -- the optimiser state and the PER tree are left alone
+ * for that step --, (b) morl_comm_poll reads through a host-mapped mirror WITHOUT synchronising (call it before every step) and (c)
+ * morl_comm_check reads after a device synchronisation.  The region is fine-grained (uncached) device memory; if that cannot be
+ * allocated _create fails (no fall-back to coarse-grained memory, where a peer's writes need not be visible to a running kernel). */
 #define MORL_COMM_IPC_HANDLE_BYTES 64
 int morl_comm_ipc_create(morl_comm** out, int rank, int world, int64_t max_allreduce_floats, int64_t max_allgather_floats,
                          void* handle_out);
 int morl_comm_ipc_connect(morl_comm* comm, const void* all_handles);
 int morl_comm_check(morl_comm* comm);
+int morl_comm_poll(morl_comm* comm);
 int morl_comm_destroy(morl_comm* comm);
 int morl_comm_size(const morl_comm* comm, int* rank, int* world);
 int morl_allgather_q_begin(morl_comm* comm, const float* send, float* recv, int64_t count_per_rank, void* stream);

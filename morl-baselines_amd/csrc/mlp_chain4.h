@@ -271,6 +271,9 @@ inline bool chain4_ok(const ChainArgs& a) {
         if (st.N <= 32 && (st.Bt == nullptr || (st.K & 3) != 0 || (st.ldbt & 3) != 0 || (reinterpret_cast<uintptr_t>(st.Bt) & 15) != 0)) return false;
         if (st.K > CH_MAXW || st.N > CH_MAXW) return false;
         if (st.N <= 32 && !(a.step[s - 1].N > 32)) return false;            // a narrow step's operand is fetched by the wide step in front of it
+        // a narrow step is the LAST one: a wide step behind it would contract over a whole ring turn (128 columns) of which the
+        // narrow step only rewrote / zeroed the first 64 -- stale LDS times zero weights, i.e. NaN if the stale value is Inf
+        if (st.N <= 32 && s + 1 < a.n_steps) return false;
     }
     return true;
 }

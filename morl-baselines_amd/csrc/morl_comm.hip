@@ -266,6 +266,8 @@ struct IpcGeom {
     long long inbox_off, outbox_off, gather_off;    // float offsets from the region base
     long long chunk_cap, ag_cap;                    // floats per inbox slot / per gather slot
     long long timeout_ticks;                        // bound of every wait
+    unsigned int* host_err;                         // mirror of IpcHeader::error in mapped host memory: the host reads it WITHOUT
+                                                    // synchronising (morl_comm_poll)
     int rank, world;
 };
 
@@ -289,12 +291,19 @@ __device__ __forceinline__ void ipc_finish_and_signal(const IpcPeers& P, const I
 }
 
 // the workgroup waits until every rank has signalled `epoch` for `phase` in MY header (bounded)
-__device__ __forceinline__ void ipc_wait(IpcHeader* mine, int world, int phase, unsigned epoch, long long timeout_ticks) {
+// A wait that runs out is NOT silent: the error word (device copy: the sharded steps' clip + Adam launch reads it and leaves the
+// optimiser state alone -- morl_host::comm_error_word; host mirror: morl_comm_poll, no synchronisation) says which phase.
+__device__ __forceinline__ void ipc_wait(IpcHeader* mine, int world, int phase, unsigned epoch, long long timeout_ticks,
+                                         unsigned int* host_err) {
     if ((int)threadIdx.x < world) {
         const long long t0 = wall_clock64();
         while ((int)(__hip_atomic_load(&mine->flag[phase][threadIdx.x][0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
             __builtin_amdgcn_s_sleep(63);
-            if (wall_clock64() - t0 > timeout_ticks) { mine->error = 1u + (unsigned)phase; break; }
+            if (wall_clock64() - t0 > timeout_ticks) {
+                __hip_atomic_store(&mine->error, 1u + (unsigned)phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (host_err != nullptr) __hip_atomic_store(host_err, 1u + (unsigned)phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
         }
     }
     __syncthreads();
@@ -329,15 +338,18 @@ __global__ __launch_bounds__(IPC_THREADS) void ipc_push_kernel(IpcPeers P, IpcGe
 __global__ __launch_bounds__(IPC_THREADS) void ipc_collect_kernel(IpcPeers P, IpcGeom g, float* __restrict__ recv, long long count,
                                                                   unsigned epoch) {
     float* mine = P.base[g.rank];
-    ipc_wait(ipc_hdr(mine), g.world, IPC_PH_AG, epoch, g.timeout_ticks);
-    const float* gather = mine + g.gather_off;
+    ipc_wait(ipc_hdr(mine), g.world, IPC_PH_AG, epoch, g.timeout_ticks, g.host_err);
+    // the gather area is double-buffered by the parity of the epoch: a fast peer's push of call N + 1 must not land in the slots this
+    // rank is still copying out for call N (peers are at most one call apart: nobody passes collect N + 1 before this rank has
+    // pushed N + 1, which its stream orders behind this kernel)
+    const float* gather = mine + g.gather_off + (long long)(epoch & 1u) * g.world * g.ag_cap;
     for (int r = 0; r < g.world; ++r) ipc_copy(recv + (long long)r * count, gather + (long long)r * g.ag_cap, count);
 }
 
 __global__ __launch_bounds__(IPC_THREADS) void ipc_reduce_kernel(IpcPeers P, IpcGeom g, float* __restrict__ buf, long long count,
                                                                  long long chunk, unsigned epoch, unsigned* ticket) {
     float* mine = P.base[g.rank];
-    ipc_wait(ipc_hdr(mine), g.world, IPC_PH_RS, epoch, g.timeout_ticks);
+    ipc_wait(ipc_hdr(mine), g.world, IPC_PH_RS, epoch, g.timeout_ticks, g.host_err);
     const long long start = g.rank * chunk < count ? g.rank * chunk : count;
     const long long len = count - start < chunk ? count - start : chunk;
     const float* inbox = mine + g.inbox_off;
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(IPC_THREADS) void ipc_reduce_kernel(IpcPeers P, Ipc
 
 __global__ __launch_bounds__(IPC_THREADS) void ipc_pull_kernel(IpcPeers P, IpcGeom g, float* __restrict__ buf, long long count,
                                                                long long chunk, unsigned epoch) {
-    ipc_wait(ipc_hdr(P.base[g.rank]), g.world, IPC_PH_AR, epoch, g.timeout_ticks);
+    ipc_wait(ipc_hdr(P.base[g.rank]), g.world, IPC_PH_AR, epoch, g.timeout_ticks, g.host_err);
     const int j = (int)blockIdx.y;
     if (j == g.rank) return;
     const long long start = j * chunk < count ? j * chunk : count;
@@ -366,6 +378,7 @@ struct IpcState {
     IpcGeom geom{};
     void* region = nullptr;
     size_t region_bytes = 0;
+    unsigned int* host_err = nullptr;     // host address of the mapped error word (IpcGeom::host_err is its device address)
     bool opened[IPC_MAX_WORLD] = {};
     unsigned* tickets = nullptr;          // [2] device counters of the last-workgroup pattern
     unsigned epoch_ag = 0, epoch_ar = 0;
@@ -398,7 +411,8 @@ int ipc_allgather(void* user, const float* send, float* recv, int64_t count, voi
     const unsigned epoch = ++st->epoch_ag;
     const int gx = (int)std::max<long long>(1, std::min<long long>(128, (count + IPC_THREADS * 4 - 1) / (IPC_THREADS * 4)));
     hipLaunchKernelGGL(ipc_push_kernel, dim3(gx, st->geom.world), dim3(IPC_THREADS), 0, (hipStream_t)stream, st->peers, st->geom, send,
-                       (long long)count, 0ll, 0, st->geom.gather_off, st->geom.ag_cap, (int)IPC_PH_AG, epoch, st->tickets + 0);
+                       (long long)count, 0ll, 0, st->geom.gather_off + (long long)(epoch & 1u) * st->geom.world * st->geom.ag_cap, st->geom.ag_cap,
+                       (int)IPC_PH_AG, epoch, st->tickets + 0);
     LAUNCH_CHECK("ipc_push(all-gather)");
     const int gc = (int)std::max<long long>(1, std::min<long long>(256, (count + IPC_THREADS * 4 - 1) / (IPC_THREADS * 4)));
     hipLaunchKernelGGL(ipc_collect_kernel, dim3(gc), dim3(IPC_THREADS), 0, (hipStream_t)stream, st->peers, st->geom, recv, (long long)count,
@@ -450,21 +464,39 @@ extern "C" int morl_comm_ipc_create(morl_comm** out, int rank, int world, int64_
     g.inbox_off = (long long)(sizeof(IpcHeader) / sizeof(float));
     g.outbox_off = g.inbox_off + (long long)world * g.chunk_cap;
     g.gather_off = g.outbox_off + g.chunk_cap;
-    st->region_bytes = (size_t)(g.gather_off + (long long)world * g.ag_cap) * sizeof(float);
-    // fine-grained (uncached) device memory: a peer's writes must become visible to a kernel that is already running
+    st->region_bytes = (size_t)(g.gather_off + 2ll * world * g.ag_cap) * sizeof(float);       // (two gather areas: epoch parity)
+    // fine-grained (uncached) device memory: a peer's writes must become visible to a kernel that is already running.  Ordinary
+    // (coarse-grained) memory gives no such guarantee, so there is no fall-back to it: without this allocation the transport is
+    // unavailable and the caller takes another one (distributed.make_comm)
     if (hipExtMallocWithFlags(&st->region, st->region_bytes, hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
-        st->region = nullptr;
-        if (hipMalloc(&st->region, st->region_bytes) != hipSuccess) { delete c; delete st; return fail(MORL_ERR_ALLOC, "hipMalloc(%zu) failed", st->region_bytes); }
+        delete c; delete st;
+        return fail(MORL_ERR_ALLOC, "hipExtMallocWithFlags(%zu bytes, uncached) failed: no fine-grained device memory for the shared region", st->region_bytes);
+    }
+    {
+        void* h_err = nullptr;
+        if (hipHostMalloc(&h_err, 64, hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(st->region); delete c; delete st;
+            return fail(MORL_ERR_ALLOC, "hipHostMalloc(mapped) of the error word failed");
+        }
+        std::memset(h_err, 0, 64);
+        st->host_err = (unsigned int*)h_err;
+        void* d_err = nullptr;
+        if (hipHostGetDevicePointer(&d_err, h_err, 0) != hipSuccess) {
+            (void)hipHostFree(h_err); (void)hipFree(st->region); delete c; delete st;
+            return fail(MORL_ERR_HIP, "hipHostGetDevicePointer failed");
+        }
+        g.host_err = (unsigned int*)d_err;
     }
     if (hipMemset(st->region, 0, st->region_bytes) != hipSuccess || hipMalloc((void**)&st->tickets, 2 * sizeof(unsigned)) != hipSuccess ||
         hipMemset(st->tickets, 0, 2 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        (void)hipFree(st->region); delete c; delete st;
+        (void)hipFree(st->region); (void)hipHostFree(st->host_err); delete c; delete st;
         return fail(MORL_ERR_HIP, "setting up the shared region failed");
     }
     hipIpcMemHandle_t h;
     if (hipIpcGetMemHandle(&h, st->region) != hipSuccess) {
-        (void)hipFree(st->region); (void)hipFree(st->tickets); delete c; delete st;
+        (void)hipFree(st->region); (void)hipFree(st->tickets); (void)hipHostFree(st->host_err); delete c; delete st;
         return fail(MORL_ERR_HIP, "hipIpcGetMemHandle failed (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
     }
     static_assert(sizeof(hipIpcMemHandle_t) <= MORL_COMM_IPC_HANDLE_BYTES, "handle size");
@@ -495,6 +527,23 @@ extern "C" int morl_comm_ipc_connect(morl_comm* c, const void* all_handles) {
     return MORL_OK;
 }
 
+const unsigned int* morl_host::comm_error_word(const morl_comm* c) {
+    IpcState* st = c ? ipc_of(c) : nullptr;
+    return (st && st->region) ? &reinterpret_cast<const IpcHeader*>(st->region)->error : nullptr;
+}
+
+// the same verdict as morl_comm_check WITHOUT synchronising: reads the host mirror of the error word, i.e. what the collectives that
+// have EXECUTED so far found (cheap enough to call before every step; the training loops of distributed.py do)
+extern "C" int morl_comm_poll(morl_comm* c) {
+    if (!c) return fail(MORL_ERR_ARG, "comm is NULL");
+    IpcState* st = ipc_of(c);
+    if (!st || !st->host_err) return MORL_OK;
+    const unsigned e = __atomic_load_n(st->host_err, __ATOMIC_RELAXED);
+    if (e) return fail(MORL_ERR_STATE, "a peer did not arrive within the time limit (phase %u of the single-hop collectives); the step that "
+                                       "waited for it was NOT applied on this rank", e - 1);
+    return MORL_OK;
+}
+
 // 0 if no bounded wait of this rank's collectives has run out so far; synchronises the device
 extern "C" int morl_comm_check(morl_comm* c) {
     IpcState* st = c ? ipc_of(c) : nullptr;
@@ -521,5 +570,6 @@ static void ipc_release(morl_comm* c) {
         if (st->opened[j]) (void)hipIpcCloseMemHandle(st->peers.base[j]);
     if (st->region) (void)hipFree(st->region);
     if (st->tickets) (void)hipFree(st->tickets);
+    if (st->host_err) (void)hipHostFree(st->host_err);
     delete st;
 }

@@ -193,7 +193,8 @@ struct morl_ctx {
     int last_B = 0, last_WI = 0;         // shape of the last training forward (morl_ctx_debug_hidden)
     // lazy target evaluation (envelope_kernels.h, EnvelopeTdArgs::phase): scratch + the one-shot hand-over from
     // morl_envelope_update to update_core
-    bool lazy_targets = true;            // MORL_LAZY_TARGETS=0 / morl_ctx_set_lazy_targets: evaluate the whole target slab instead
+    int lazy_targets = 1;                // MORL_LAZY_TARGETS=0 / morl_ctx_set_lazy_targets: 0 evaluate the whole target slab instead,
+                                         // 1 lazily from MORL_LAZY_MIN_ROWS (8 192) TD rows on, 2 lazily at every size
     int32_t* lz_best = nullptr;          // [max_rows] flattened (j*, a*) per TD row
     int lz_epoch = 0;                    // lazily evaluated steps so far (its parity picks the counter)
     bool lz_last = false;                // the last morl_envelope_update ran lazily
@@ -206,6 +207,8 @@ struct morl_ctx {
     const float* lz_next_obs = nullptr;
     float* td_zero_ptr = nullptr;        // one-shot request of the batch-sharded step to the next TD launch: zero this range ...
     int td_zero_n = 0, td_keep_lo = 0, td_keep_hi = 0;   // ... except [keep_lo, keep_hi) (the rank's own priorities)
+    const unsigned int* skip_flag = nullptr;   // one-shot: the next clip + Adam launch leaves the optimiser state alone if this
+                                         // device word is non-zero (a timed-out collective of the single-hop transport)
     int main_rows = -1;                  // rows of a hoisted training forward (morl_envelope_main_forward), -1 = none
     // shadow copies made by morl_envelope_prepare for exactly these parameter buffers; consumed (one-shot) by the step's first
     // library entry, dropped by every optimiser step of the library
@@ -385,7 +388,7 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         morl_ctx_destroy(c);
         return fail(MORL_ERR_HIP, "hipMemset failed");
     }
-    if (const char* e = getenv("MORL_LAZY_TARGETS")) c->lazy_targets = atoi(e) != 0;
+    if (const char* e = getenv("MORL_LAZY_TARGETS")) c->lazy_targets = std::max(0, std::min(2, atoi(e)));
     ALLOC(cu_tickets, C2_CU_SLOTS);
     if (hipMemsetAsync(c->cu_tickets, 0, C2_CU_SLOTS * sizeof(unsigned int), nullptr) != hipSuccess) { morl_ctx_destroy(c); return fail(MORL_ERR_HIP, "zero-fill failed"); }
     {
@@ -888,8 +891,8 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
 
 extern "C" int morl_ctx_set_lazy_targets(morl_ctx* c, int enable) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
-    const int was = c->lazy_targets ? 1 : 0;
-    c->lazy_targets = enable != 0;
+    const int was = c->lazy_targets;
+    c->lazy_targets = std::max(0, std::min(2, enable));
     return was;
 }
 
@@ -1363,14 +1366,15 @@ static __global__ __launch_bounds__(ST_THREADS) void clip_adam_per_kernel(float*
                                                                     int n_part, float max_norm, float one_minus_b1, float b2,
                                                                     float one_minus_b2, float neg_step_size, float bc2_sqrt,
                                                                     float eps, int apply_step, float* __restrict__ grad_norm_out,
-                                                                    SumTreeUpdate per) {
+                                                                    SumTreeUpdate per, const unsigned int* __restrict__ skip_flag) {
     __shared__ __attribute__((aligned(8))) unsigned char lds[ST_LDS_BYTES];
     if (blockIdx.x + 1 == gridDim.x) {
+        if (skip_flag != nullptr && *skip_flag != 0u) return;     // (the summed priorities are garbage too: see clip_adam_body)
         sumtree_update_body(per, lds);
         return;
     }
     clip_adam_body(params, grads, exp_avg, exp_avg_sq, P, sumsq_part, n_part, max_norm, one_minus_b1, b2, one_minus_b2,
-                   neg_step_size, bc2_sqrt, eps, apply_step, grad_norm_out, (int)gridDim.x - 1);
+                   neg_step_size, bc2_sqrt, eps, apply_step, grad_norm_out, (int)gridDim.x - 1, skip_flag);
 }
 
 static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
@@ -1378,6 +1382,8 @@ static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_a
                           const SumTreeUpdate* per = nullptr) {
     c->wt_online_src = nullptr;          // the parameters change: any transposed copy is stale from here on
     c->fresh_online = c->fresh_target = nullptr;
+    const unsigned int* skip_flag = c->skip_flag;    // one-shot request of a sharded step (set right before this call)
+    c->skip_flag = nullptr;
     const int nblk = std::min(OPT_MAX_BLOCKS, stream_grid(c->P, OPT_THREADS));
     if (!have_partials) {
         hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)grads, 1, (long long)c->P,
@@ -1394,12 +1400,12 @@ static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_a
         hipLaunchKernelGGL(clip_adam_per_kernel, dim3(stream_grid(c->P, ST_THREADS) + 1), dim3(ST_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq,
                            (long long)c->P, (const double*)c->sumsq_part, nblk, cfg->max_grad_norm, (float)(1.0 - b1), (float)b2,
                            (float)(1.0 - b2), (float)(-step_size), (float)bc2_sqrt, (float)cfg->eps, cfg->apply_step,
-                           grad_norm_out, *per);
+                           grad_norm_out, *per, skip_flag);
     else
         hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq,
                            (long long)c->P, (const double*)c->sumsq_part, nblk, cfg->max_grad_norm, (float)(1.0 - b1), (float)b2,
                            (float)(1.0 - b2), (float)(-step_size), (float)bc2_sqrt, (float)cfg->eps, cfg->apply_step,
-                           grad_norm_out);
+                           grad_norm_out, skip_flag);
     LAUNCH_CHECK("clip_adam");
     return MORL_OK;
 }
@@ -1449,7 +1455,8 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
             // Small steps are latency-bound: one more chain launch and a second TD launch cost them more than the target pass
             // they drop (2 048 rows: 0.181 ms lazily, 0.149 eagerly; 8 192 rows: 0.255 against 0.262; MORL_LAZY_MIN_ROWS overrides)
             static const long long lazy_min_rows = [] { const char* e = getenv("MORL_LAZY_MIN_ROWS"); return e ? atoll(e) : 8192ll; }();
-            c->lz_now = c->lazy_targets && cfg->envelope && W >= 2 && !out->q_target_next && rows >= lazy_min_rows;
+            c->lz_now = c->lazy_targets && cfg->envelope && W >= 2 && !out->q_target_next &&
+                        (c->lazy_targets == 2 || rows >= lazy_min_rows);
             c->lz_last = c->lz_now;
             if (c->lz_now) {
                 const ChainArgs two[2] = {
@@ -1637,6 +1644,7 @@ extern "C" int morl_envelope_step_sharded(morl_ctx* c, morl_comm* comm, float* p
                                          i_offset, W_local, slab_all, slab_all + half, &shard, &out, stream)))
         return rc;
     if ((rc = morl_allreduce_grads(comm, grads_x, n_params + 1 + B, stream))) return rc;
+    c->skip_flag = morl_host::comm_error_word(comm);
     if (cfg->per_tree) {
         SumTreeUpdate u{};
         u.tree = cfg->per_tree; u.idx = cfg->per_idx; u.raw = grads_x + n_params + 1; u.running_max = cfg->per_running_max;
@@ -1692,6 +1700,7 @@ extern "C" int morl_envelope_step_batch_sharded(morl_ctx* c, morl_comm* comm, fl
     if (rc) return rc;
     if ((rc = morl_allreduce_grads(comm, grads_x, n_params + 1 + B_total, stream))) return rc;
     (void)max_norm;
+    c->skip_flag = morl_host::comm_error_word(comm);
     if (cfg->per_tree) {
         SumTreeUpdate u{};
         u.tree = cfg->per_tree; u.idx = cfg->per_idx; u.raw = prio; u.running_max = cfg->per_running_max;

@@ -37,6 +37,10 @@ inline int dmalloc(void** p, size_t bytes) {
     return MORL_OK;
 }
 
+// device address of the word a communicator's bounded waits set when one runs out (single-hop transport), or NULL for a transport
+// that reports its failures at the call (defined in morl_comm.hip; the sharded steps hand it to their clip + Adam launch)
+const unsigned int* comm_error_word(const morl_comm* c);
+
 }  // namespace morl_host
 
 #define HIP_TRY(expr)                                                                                              \

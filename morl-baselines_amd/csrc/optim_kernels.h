@@ -77,7 +77,12 @@ __device__ __forceinline__ void clip_adam_body(float* __restrict__ params, float
                                                float* __restrict__ exp_avg_sq, long long P, const double* __restrict__ sumsq_part,
                                                int n_part, float max_norm, float one_minus_b1, float b2, float one_minus_b2,
                                                float neg_step_size, float bc2_sqrt, float eps, int apply_step,
-                                               float* __restrict__ grad_norm_out, int nblk) {
+                                               float* __restrict__ grad_norm_out, int nblk,
+                                               const unsigned int* __restrict__ skip_flag = nullptr) {
+    // skip_flag (the sharded steps over the single-hop transport): non-zero = a bounded wait of the collectives that produced
+    // `grads` ran out (a peer never arrived, morl_comm.hip) -- the sums are garbage, so the optimiser must not move; the host finds
+    // the same word through morl_comm_poll / morl_comm_check and raises
+    if (skip_flag != nullptr && *skip_flag != 0u) apply_step = 0;
     double t = 0.0;
     for (int e = lane_id(); e < n_part; e += kWave) t += sumsq_part[e];
     t = wave_sum(t);
@@ -108,9 +113,10 @@ static __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(float* __
                                                                 float max_norm, float one_minus_b1, float b2,
                                                                 float one_minus_b2, float neg_step_size,
                                                                 float bc2_sqrt, float eps, int apply_step,
-                                                                float* __restrict__ grad_norm_out) {
+                                                                float* __restrict__ grad_norm_out,
+                                                                const unsigned int* __restrict__ skip_flag) {
     clip_adam_body(params, grads, exp_avg, exp_avg_sq, P, sumsq_part, n_part, max_norm, one_minus_b1, b2, one_minus_b2,
-                   neg_step_size, bc2_sqrt, eps, apply_step, grad_norm_out, (int)gridDim.x);
+                   neg_step_size, bc2_sqrt, eps, apply_step, grad_norm_out, (int)gridDim.x, skip_flag);
 }
 
 // polyak_update (common/networks.py:120-139): tau == 1 -> copy, else t = t*(1-tau) + tau*p

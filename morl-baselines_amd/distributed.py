@@ -88,14 +88,38 @@ class NativeComm:
             return
         if transport != "rccl":
             raise ValueError("transport must be 'rccl', 'ipc' or 'torch'")
+        # Collective-safe id exchange: a rank whose local part fails (rank 0: no RCCL to make an id with; any rank: the communicator
+        # refused) still takes part in EVERY collective of the set-up -- the broadcast carries a status byte next to the id, and
+        # all ranks agree on the outcome through a MIN all-reduce BEFORE anybody calls ncclCommInitRank (which blocks until every
+        # rank has called it) and again after it -- and then all ranks raise together.  make_comm turns that into a common fall-back.
+        err = None
+        msg = th.zeros(129, dtype=th.uint8)
         if self.rank == 0:
-            lib.check(lib.lib.morl_comm_unique_id(C.c_void_p(ident.data_ptr())))
-        ident = ident.to(self.device)
-        dist.broadcast(ident, src=0, group=group)
-        ident = ident.cpu()
+            try:
+                lib.check(lib.lib.morl_comm_unique_id(C.c_void_p(ident.data_ptr())))
+                msg[:128] = ident
+                msg[128] = 1
+            except RuntimeError as exc:
+                err = exc
+        msg = msg.to(self.device)
+        dist.broadcast(msg, src=0, group=group)
+        msg = msg.cpu()
+        have_id = th.tensor([int(msg[128].item())], device=self.device)
+        dist.all_reduce(have_id, op=dist.ReduceOp.MIN, group=group)
+        if int(have_id.item()) != 1:
+            raise RuntimeError(f"RCCL unique id unavailable on rank 0 (this rank: {err})")
+        ident = msg[:128].contiguous()
         with th.cuda.device(self.device):
-            lib.check(lib.lib.morl_comm_init(C.byref(handle), C.c_void_p(ident.data_ptr()), self.rank, self.world))
-        self.handle = handle.value
+            try:
+                lib.check(lib.lib.morl_comm_init(C.byref(handle), C.c_void_p(ident.data_ptr()), self.rank, self.world))
+                self.handle = handle.value
+            except RuntimeError as exc:
+                err = exc
+        ok = th.tensor([0 if err is not None else 1], device=self.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) != 1:
+            self.close()
+            raise RuntimeError(f"RCCL communicator unavailable on at least one rank (this rank: {err})")
 
     def _bind_ipc(self, dist, group, handle, max_allreduce: int, max_allgather: int) -> None:
         """The single-hop transport (``morl_comm_ipc_*``): this rank's shared region, the world's 64-byte handles exchanged
@@ -132,6 +156,12 @@ class NativeComm:
     def check(self) -> None:
         """Raises if a bounded wait of the single-hop collectives ran out (a peer never arrived); synchronises the device."""
         self.lib.check(self.lib.lib.morl_comm_check(self.handle))
+
+    def poll(self) -> None:
+        """The same verdict over the collectives that have EXECUTED so far, without synchronising (``morl_comm_poll``: a host-mapped
+        mirror of the error word).  The sharded training loops call it before every step: a late peer is an exception at most one
+        step later, and the step that waited for it was not applied (the clip + Adam launch reads the same word on the device)."""
+        self.lib.check(self.lib.lib.morl_comm_poll(self.handle))
 
     def _bind_torch(self, dist, group, handle) -> None:
         from .native import ALLGATHER_FN, ALLREDUCE_FN
@@ -225,6 +255,8 @@ def make_comm(lib, dist, device, group=None, transport=None, max_allreduce=0, ma
     instead of dying.  Returns (NativeComm or None for the staged path, name of the transport in use)."""
     import sys
     want = transport or {"native": "rccl"}.get(os.environ.get("MORL_COMM", ""), os.environ.get("MORL_COMM") or None)
+    if want is not None and want not in ("rccl", "ipc", "torch", "staged"):
+        raise ValueError(f"unknown transport {want!r} (MORL_COMM / transport=): expected 'rccl' ('native'), 'ipc', 'torch' or 'staged'")
     if want == "staged":
         return None, "staged (torch.distributed between library calls)"
     can_rccl = dist.get_backend(group) == "nccl" and lib.is_device_build
@@ -236,17 +268,12 @@ def make_comm(lib, dist, device, group=None, transport=None, max_allreduce=0, ma
     if want == "rccl":
         if not can_rccl:
             raise ValueError("transport 'rccl' needs an RCCL ('nccl') process group and the gfx950 build")
-        comm, err = None, None
+        # (NativeComm's RCCL set-up is collective-safe: it either succeeds on every rank or raises on every rank, after the
+        # ranks have agreed on the outcome -- so the fall-back below is taken by all of them or by none)
         try:
-            comm = NativeComm(lib, dist, device, group, transport="rccl")
+            return NativeComm(lib, dist, device, group, transport="rccl"), "rccl (inside libmorl_hip.so)"
         except RuntimeError as exc:
             err = exc
-        ok = th.tensor([0 if comm is None else 1], device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok.item()) == 1:
-            return comm, "rccl (inside libmorl_hip.so)"
-        if comm is not None:
-            comm.close()
         print(f"[morl_comm] rank {dist.get_rank(group)}: RCCL inside the library unavailable ({err}); every rank falls back to "
               "the torch.distributed transport", file=sys.stderr, flush=True)
         want = "torch (fallback: morl_comm_init failed)"
@@ -347,6 +374,8 @@ def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=N
         B = self.batch_size
         if B != B0:
             raise ValueError("batch_size changed after shard_envelope_agent")
+        if comm is not None:
+            comm.poll()                                      # (a timed-out collective of an earlier step: raise, do not train on)
         for _ in range(self.gradient_updates):
             aux, sampled_w = self._draw_weights()
             b_obs, b_actions, b_rewards, b_next_obs, b_dones, b_inds = self.replay_buffer.sample(
@@ -426,6 +455,8 @@ def _shard_envelope_batch(agent: Envelope, dist, group, emulate, comm, world: in
         self._losses = []
         if self.batch_size != B0:
             raise ValueError("batch_size changed after shard_envelope_agent")
+        if comm is not None:
+            comm.poll()                                      # (a timed-out collective of an earlier step: raise, do not train on)
         W = self.num_sample_w
         for _ in range(self.gradient_updates):
             aux, sampled_w = self._draw_weights()

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
 
 MORL_MAX_LAYERS = 8
 MORL_MAX_OBJ = 8
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class NetDesc(C.Structure):
@@ -171,6 +171,7 @@ _SIGNATURES = {
     "morl_comm_ipc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     "morl_comm_ipc_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "morl_comm_check": (C.c_int, [C.c_void_p]),
+    "morl_comm_poll": (C.c_int, [C.c_void_p]),
     "morl_comm_destroy": (C.c_int, [C.c_void_p]),
     "morl_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "morl_allgather_q_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -43,9 +43,10 @@ class QNetContext:
         -1: one launch of every step, the launches of a step taking turns)."""
         self.lib.check(self.lib.lib.morl_ctx_set_timing(self.handle, int(every)))
 
-    def set_lazy_targets(self, enable: bool) -> bool:
-        """Lazy target evaluation of ``envelope_update`` on this context (``morl_ctx_set_lazy_targets``); returns the old setting."""
-        return bool(self.lib.lib.morl_ctx_set_lazy_targets(self.handle, int(bool(enable))))
+    def set_lazy_targets(self, enable) -> int:
+        """Lazy target evaluation of ``envelope_update`` on this context (``morl_ctx_set_lazy_targets``): 0 / False never, 1 / True
+        from 8 192 TD rows on (the default), 2 at every size; returns the old setting."""
+        return int(self.lib.lib.morl_ctx_set_lazy_targets(self.handle, int(enable)))
 
     def lazy_target_rows(self, like: th.Tensor) -> int:
         """Distinct (transition, weight) pairs the last lazily evaluated step ran the target network on (synchronises)."""
@@ -189,12 +190,10 @@ class HostRing:
             self.events[g] = evt
 
     def retire(self) -> None:
-        """Block until every kernel enqueued so far on the device's current stream (the readers of this ring's slots) has
-        finished; only then may the pinned block go back to the host allocator.  Rare path (a ring outgrown)."""
+        """Block until every kernel enqueued so far on the DEVICE (whatever stream read this ring's slots) has finished; only
+        then may the pinned block go back to the host allocator.  Rare path (a ring outgrown)."""
         if self.on_gpu and self.cur >= 0:
-            evt = th.cuda.Event()
-            evt.record(th.cuda.current_stream(self.device))
-            evt.synchronize()
+            th.cuda.synchronize(self.device)
 
 
 def sample_gather(lib: NativeLib, records: th.Tensor, B: int, D: int, R: int, action_dim: int = 1, int_actions: bool = True, *,

@@ -10,10 +10,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.pa
         sys.path.insert(0, p)
 
 
-# The library evaluates the target network lazily only for steps on the large row tiles (> 8 192 TD rows): smaller, latency-bound
-# steps are faster eagerly.  The suite's cases are almost all small, so it lowers the threshold to zero -- every Envelope step of
-# the fixtures, traces and agents then runs the lazy path (on the emulator and on the GPU); the eager path keeps its coverage
-# through the lazy-vs-eager test, the sharded steps and tests/test_chain_tilings.py's MORL_LAZY_TARGETS=0 leg.
+# The library evaluates the target network lazily only for steps of >= 8 192 TD rows (smaller, latency-bound steps are faster
+# eagerly).  The suite's cases are almost all small, so it lowers the threshold to zero: every Envelope step that does NOT ask for
+# the whole target slab then runs the lazy pipeline -- the agents, the training traces, and the ``lazy`` legs of the fixture tests
+# (tests/test_kernels_parity.py ``debug="lazy"``, tests/test_flagship_golden.py at both full sizes).  A step that asks for
+# ``q_target_next`` (``debug=True``: the ``eager`` legs of the same tests) is evaluated eagerly whatever this setting, as are DDQN
+# targets, the weight-sharded steps and everything under MORL_LAZY_TARGETS=0.
 os.environ.setdefault("MORL_LAZY_MIN_ROWS", "0")
 
 

@@ -63,6 +63,9 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+enum { hipHostMallocMapped = 2 };
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 typedef void* hipEvent_t;

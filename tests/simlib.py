@@ -24,16 +24,26 @@ def build_sim(force=False):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
         os.path.join(SIM_DIR, "hipsim.cpp"), os.path.join(SIM_DIR, "hip", "hip_runtime.h"),
         os.path.join(ROOT, "include", "morl_hip.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(s) <= os.path.getmtime(OUT) for s in srcs):
+    fresh = lambda: os.path.exists(OUT) and all(os.path.getmtime(s) <= os.path.getmtime(OUT) for s in srcs)
+    if not force and fresh():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [_clang(), "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off",
-           "-I", SIM_DIR, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           os.path.join(CSRC, "morl_hip.hip"), os.path.join(CSRC, "morl_ac.hip"), os.path.join(CSRC, "morl_comm.hip"),
-           os.path.join(SIM_DIR, "hipsim.cpp"), "-ldl", "-o", OUT]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("emulated build failed:\n" + r.stdout + r.stderr)
+    # one builder at a time (pytest-xdist workers and the spawned ranks of the gloo tests all come through here), and the library
+    # appears atomically: a process never loads a half-written file
+    import fcntl
+    with open(OUT + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and fresh():
+            return OUT
+        tmp = f"{OUT}.{os.getpid()}.tmp"
+        cmd = [_clang(), "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off",
+               "-I", SIM_DIR, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+               os.path.join(CSRC, "morl_hip.hip"), os.path.join(CSRC, "morl_ac.hip"), os.path.join(CSRC, "morl_comm.hip"),
+               os.path.join(SIM_DIR, "hipsim.cpp"), "-ldl", "-o", tmp]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("emulated build failed:\n" + r.stdout + r.stderr)
+        os.replace(tmp, OUT)
     return OUT
 
 

@@ -259,36 +259,59 @@ def test_custom_transport_failure_is_a_status_not_a_crash():
 def _ipc_missing_peer_worker(rank, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["MORL_IPC_TIMEOUT_MS"] = "1500"
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
     import time
     import torch.distributed as dist
     import simlib
+    import morl_baselines_amd.native as native
+    from morl_baselines_amd import ops
     from morl_baselines_amd.distributed import NativeComm
     lib = simlib.load_sim()
+    native.use_library(lib)
     dist.init_process_group("gloo", rank=rank, world_size=2)
-    comm = NativeComm(lib, dist, "cpu", transport="ipc", max_allreduce=1000, max_allgather=64)
+    ag = _make_agent(lib, per=False)                          # (rank 0 only uses it: the step whose peer never arrives)
+    P, B, W = ag.q_net.ctx.n_params, ag.batch_size, ag.num_sample_w
+    comm = NativeComm(lib, dist, "cpu", transport="ipc", max_allreduce=max(1000, P + 1 + B), max_allgather=64)
     buf = th.full((1000,), float(rank + 1))
     comm.allreduce(buf)                                     # both ranks: 1 + 2
     ok = bool((buf == 3.0).all())
     comm.check()
-    msg = None
-    if rank == 0:                                            # rank 1 never joins the second all-reduce
+    comm.poll()                                             # (the non-synchronising form of the same question)
+    msg, poll_msg, untouched = None, None, None
+    if rank == 0:                                            # rank 1 never joins the next collective: one rank's WHOLE step
         t0 = time.time()
-        comm.allreduce(buf)
+        D, R = ag.observation_dim, ag.reward_dim
+        gx = th.zeros(P + 1 + B)
+        half = B // 2
+        obs, nobs = th.randn(half, D), th.randn(half, D)
+        act, rew, done = th.zeros(half, dtype=th.int32), th.randn(half, R), th.zeros(half)
+        w = th.full((W, R), 1.0 / R)
+        before = (ag.q_net.flat.clone(), ag._exp_avg.clone(), ag._exp_avg_sq.clone())
+        ops.envelope_step_batch_sharded(ag.q_net.ctx, comm.handle, ag.q_net.flat, ag.target_q_net.flat, gx, ag._exp_avg, ag._exp_avg_sq,
+                                        obs, nobs, act, rew, done, w, B, 0, gamma=0.99, lr=1e-3, adam_step=1, max_grad_norm=1.0)
+        # the all-reduce inside that step waited for rank 1 until its time limit, summed garbage -- and the optimiser did NOT move
+        untouched = all(bool(th.equal(a, b)) for a, b in zip(before, (ag.q_net.flat, ag._exp_avg, ag._exp_avg_sq)))
+        try:
+            comm.poll()
+        except RuntimeError as e:
+            poll_msg = str(e)
         try:
             comm.check()
         except RuntimeError as e:
             msg = str(e)
         ret["waited"] = time.time() - t0
     dist.barrier()
-    ret[rank] = (ok, msg)
+    ret[rank] = (ok, msg, poll_msg, untouched)
     comm.close()
     dist.destroy_process_group()
 
 
 def test_single_hop_transport_bounded_wait_reports_a_missing_peer():
     """``morl_comm_ipc_*``: an all-reduce over shared regions gives the sum on every rank; a peer that never arrives costs the
-    waiting rank its time limit and an error from ``morl_comm_check`` -- not a hang."""
+    waiting rank its time limit and an error from ``morl_comm_check`` AND from the non-synchronising ``morl_comm_poll`` -- not a
+    hang -- and the one-call sharded step whose all-reduce timed out leaves parameters and Adam moments untouched (its clip + Adam
+    launch reads the error word on the device): a late peer is never a silently wrong optimiser step."""
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = 33500 + (os.getpid() % 2000)
@@ -300,7 +323,9 @@ def test_single_hop_transport_bounded_wait_reports_a_missing_peer():
         assert p.exitcode == 0
     assert ret[0][0] and ret[1][0]
     assert ret[0][1] is not None and "did not arrive" in ret[0][1] and ret[1][1] is None
-    assert 2.0 <= ret["waited"] <= 30.0
+    assert ret[0][2] is not None and "did not arrive" in ret[0][2] and "NOT applied" in ret[0][2]
+    assert ret[0][3] is True
+    assert 1.0 <= ret["waited"] <= 30.0
 
 
 def test_one_call_sharded_step_rejects_bad_arguments():

@@ -58,6 +58,13 @@ def run_update(lib, dev, c, inp, apply_step=True, debug=True, fused=None, dw_mod
                               apply_step=apply_step, debug=debug)
     if hidden:      # the ReLU decisions the device took (tests/flip_aware.py): post-ReLU activations of every hidden layer
         res["hidden"] = [ctx.debug_hidden(l, c.B * c.W, t["po"]).cpu() for l in range(1, len(c.arch) + 1)]
+    res["lazy_rows"] = ctx.lazy_target_rows(t["po"])
+    res["engine"] = ctx.engine                                        # 0: the per-layer engine took the net (never lazy)
+    if debug == "lazy":
+        # no target slab was requested (asking for it is what switches the step to the eager form, include/morl_hip.h); the oracle
+        # comparison of check_update needs one: a separate no-grad forward of the target network, row b * W + j like the slab
+        assert "q_target_next" not in res
+        res["q_target_next"] = ops.qnet_forward(ctx, t["pt"], t["nobs"], t["sw"], row_order=0).view(c.B, c.W, c.A, c.R)
     if dev.type == "cuda":
         th.cuda.synchronize()
     ctx.close()
@@ -111,23 +118,40 @@ def check_update(res, t, o, online, m, v, c, param_tol_frac=0.02, grad_tol=5e-5,
     assert float((t["po"].cpu() - flat(online)).abs().max()) <= param_tol_frac * c.lr
 
 
-@pytest.mark.parametrize("fused", [1, 2, 3, 0], ids=["fused_auto", "fused64", "fused32", "perlayer"])
+def _lazy_capable(c, engine_fused):
+    """Steps the library can evaluate lazily: envelope targets over >= 2 weights on the layer-fused engine with the row tile picked
+    per launch (morl_hip.hip, morl_envelope_update); tests/conftest.py lowers MORL_LAZY_MIN_ROWS to 0 so that small steps qualify."""
+    return c.envelope and c.W >= 2 and engine_fused == 1 and os.environ.get("MORL_LAZY_TARGETS") != "0"
+
+
+@pytest.mark.parametrize("fused", [1, 2, 3, 0, "lazy"], ids=["fused_auto", "fused64", "fused32", "perlayer", "fused_auto_lazy"])
 @pytest.mark.parametrize("c", CASES, ids=lambda c: c.name)
 def test_envelope_update_vs_oracle(be, c, fused):
+    """``debug=True`` asks for the whole target slab, which makes the step evaluate it EAGERLY; the ``lazy`` leg asks for
+    everything but that slab and so runs the default pipeline (arg-max, compact rows, target network on the selected rows)."""
     lib, dev, is_sim = be
     inp = make_inputs(c)
-    res, t = run_update(lib, dev, c, inp, fused=fused)
+    lazy = fused == "lazy"
+    res, t = run_update(lib, dev, c, inp, fused=1 if lazy else fused, debug="lazy" if lazy else True)
+    if lazy:
+        assert (res["lazy_rows"] > 0) == _lazy_capable(c, res["engine"])   # (nets the per-layer engine takes stay eager)
+    else:
+        assert res["lazy_rows"] == 0
     o, online, m, v = run_oracle(c, inp)
     check_update(res, t, o, online, m, v, c)
 
 
+@pytest.mark.parametrize("lazy", [False, True], ids=["eager", "lazy"])
 @pytest.mark.parametrize("c", CASES, ids=lambda c: c.name)
-def test_envelope_update_vs_reference_golden(be, c):
-    """Directly against what the unmodified reference produced (tests/golden/*.npz)."""
+def test_envelope_update_vs_reference_golden(be, c, lazy):
+    """Directly against what the unmodified reference produced (tests/golden/*.npz); ``lazy``: through the default pipeline (no
+    target slab requested)."""
     lib, dev, is_sim = be
     g = np.load(os.path.join(GOLD, f"envelope_{c.name}.npz"))
     inp = make_inputs(c)
-    res, t = run_update(lib, dev, c, inp)
+    res, t = run_update(lib, dev, c, inp, debug="lazy" if lazy else True)
+    if not lazy:
+        assert res["lazy_rows"] == 0
     assert abs(res["loss"].item() - float(g["loss"])) <= RTOL * abs(float(g["loss"]))
     if c.max_grad_norm is not None:
         assert abs(res["grad_norm"].item() - float(g["grad_norm"])) <= RTOL * float(g["grad_norm"])
