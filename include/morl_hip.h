@@ -182,6 +182,14 @@ int morl_envelope_prepare(morl_ctx* ctx, const float* params_online, const float
  * (with more than 64 weight vectors a transition's TD rows span several workgroups, and a pair selected from two of them is
  * listed, and evaluated, once per workgroup); 0 if the last step ran eagerly.  Synchronises `stream`. */
 int morl_ctx_set_lazy_targets(morl_ctx* ctx, int enable);
+/* Arithmetic of the big launches of morl_envelope_update (steps of >= 8 192 TD rows -- MORL_BF_MIN_ROWS -- on networks whose hidden
+ * layers are 256 wide, head <= 32 columns, input <= 64): by default the two ONLINE forward passes (QNet.forward, envelope.py:300,
+ * :420) and the dX half of the backward pass (:323) run on the bf16 matrix cores, every fp32 product evaluated as six products of
+ * three-way bf16 splits accumulated in fp32 (csrc/mlp_chain_bf.h: exact split of every finite fp32, fp32-class result: max
+ * |Q - Q_float64| 2.4e-7 against 2.3e-7 for the k-ordered fp32 chain) -- the f32-input MFMA runs at 1/16 of the bf16 rate.
+ * enable = 1 (or MORL_EXACT_F32=1) keeps every GEMM on the f32-input MFMA (rounds 1-3; the A/B leg).  The target network's rows,
+ * the weight gradients and every other entry point are f32-input MFMA in both settings.  Returns the previous setting. */
+int morl_ctx_set_exact_f32(morl_ctx* ctx, int enable);
 int morl_ctx_lazy_target_rows(morl_ctx* ctx, int* rows, void* stream);
 /* The shadow copies made by morl_envelope_prepare are consumed ONLY by the gradient step that directly follows it
  * (morl_envelope_update / morl_envelope_slabs / the one-call sharded steps); every other entry point re-makes its copies.  A

@@ -45,9 +45,9 @@ __global__ __launch_bounds__(256) void build_input_kernel(const float* __restric
 // transition.  Lane <-> TD row i; the waves of the workgroup split the (j, a) candidates and read each candidate's R values
 // as LDS broadcasts, so the arg-max loop has no cross-lane traffic at all; the per-wave partial winners of a row are merged
 // through LDS in candidate order, lowest index winning ties.  The shuffle form north_star names (lanes <-> candidates, a wave
-// butterfly carrying (value, index): argmax_mode 1, MORL_TD_SHFL=1) is kept and was A/B-measured on MI355X in round 3
-// (profiles/r03_argmax_ab.json): 16.6 us against 13.0 us for this form at W = 64 x A = 6, 52.5 against 51.5 us at the weak-scaled
-// W = 512 -- with 64 rows per transition the lanes are better spent on rows (DESIGN.md section 4 says the same).
+// butterfly carrying (value, index)) was built and A/B-measured on MI355X in round 3 (profiles/r03_argmax_ab.json): 16.6 us against
+// 13.0 us for this form at W = 64 x A = 6, 52.5 against 51.5 us at the weak-scaled W = 512 -- with 64 rows per transition the lanes
+// are better spent on rows; bit-identical indices, so the slower form was removed in round 4.
 // diag_only restricts j to i (DDQN target, envelope.py:442-463).
 // HBM-bound and tiny: reads 2*B*W*A*R*4 bytes once.
 // ----------------------------------------------------------------------------------------------
@@ -108,8 +108,6 @@ struct EnvelopeTdArgs {
     int bmajor;             // internal row order of q_main / dq: 0 = row i * B + b (reference order, envelope.py:284-291),
                             // 1 = row b * WI + i (what the layer-fused engines use: the rows of a transition are contiguous, so a
                             // backward tile needs one or two slabs, chain_td.h).  target / pref / ac stay in reference order
-    int argmax_mode;        // 0: lanes <-> TD rows, candidates as LDS broadcasts (default).  1: lanes <-> candidates, wave-level
-                            // butterfly arg-max carrying (value, index) -- the shuffle form north_star names; A/B in DESIGN.md 4
     int part_floats;        // 0: qo / qt are [B][W][A][R].  > 0: all-gathered layout, the slab of transition b is made of
     long long part_stride;  //    W*A*R / part_floats pieces of part_floats floats, piece g at  g * part_stride + b * part_floats
 };
@@ -228,37 +226,6 @@ __global__ __launch_bounds__(64 * ENV_MAX_WAVES) void envelope_td_kernel(Envelop
         const int n_c = p.diag_only ? A : W * A;
         if (PHASE == 2) {
             // the arg-max was taken by an earlier launch (phase 1)
-        } else if (p.argmax_mode == 1) {
-            // ---- shuffle form: wave q owns the rows ib + q, ib + q + nw, ...; its lanes stride the (j, a) candidates of ONE
-            // row (LDS reads at a stride of R words: conflict-free for the odd R = 3, two-way for even R), keep their own first
-            // maximum, and a six-stage butterfly over (value, index) leaves the row's first maximum in every lane
-            if (wave > 0) s_pc[wave][lane] = 0x7fffffff;                    // the merge below only sees slice 0
-            const int i_end = min(ib + kWave, i_hi);
-            for (int ii = ib + wave; ii < i_end; ii += nw) {
-                float wr[MORL_MAX_OBJ];
-#pragma unroll
-                for (int r = 0; r < MORL_MAX_OBJ; ++r) wr[r] = (r < R) ? s_w[ii * R + r] : 0.f;      // wave-uniform: broadcast
-                const int co = p.diag_only ? (ii + p.i_offset) * A : 0;
-                float bv = -INFINITY;
-                int bc = 0x7fffffff;
-                for (int cc = lane; cc < n_c; cc += kWave) {
-                    const float* q = s_qo + (size_t)(co + cc) * R;
-                    float sc = __fmul_rn(wr[0], q[0]);
-#pragma unroll
-                    for (int r = 1; r < MORL_MAX_OBJ; ++r)
-                        if (r < R) sc = p.fma_scal ? fmaf(q[r], wr[r], sc) : __fadd_rn(sc, __fmul_rn(wr[r], q[r]));
-                    if (sc > bv || bc == 0x7fffffff) { bv = sc; bc = co + cc; }
-                }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    const float ov = __shfl_xor(bv, off);
-                    const int oc = __shfl_xor(bc, off);
-                    // strictly greater wins; equal values: the lower candidate index (th.max / th.argmax: first maximum)
-                    if (oc != 0x7fffffff && (bc == 0x7fffffff || ov > bv || (ov == bv && oc < bc))) { bv = ov; bc = oc; }
-                }
-                if (lane == 0) { s_pv[0][ii - ib] = bv; s_pc[0][ii - ib] = bc; }
-            }
-            __syncthreads();
         } else {
         // candidate range of this wave: a quarter of (j, a) in index order (DDQN: of the A actions of slab j = i)
         const int c_off = (p.diag_only && live) ? (i + p.i_offset) * A : 0;     // per-lane base in DDQN mode

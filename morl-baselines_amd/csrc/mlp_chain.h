@@ -45,8 +45,7 @@ struct ChainArgs {
     int rows;
     // input assembly
     int in_mode;            // 0: cat(obs[b], weights[k]) with row -> (b, k) by row_order ; 1: dense matrix src[rows][ldsrc] ;
-                            // 3 (mlp_chain16 / mlp_chain4 only): cat(obs[b], weights[j]) of the listed pairs, see rows_dev / pairs ;
-                            // 2 (mlp_chain2 only): the rows are dLoss/dQ of a gradient step, computed by the tile itself (chain_td.h)
+                            // 3 (mlp_chain16 / mlp_chain4 only): cat(obs[b], weights[j]) of the listed pairs, see rows_dev / pairs
     const float* obs;       // [B][D]
     const float* weights;   // [W][R]  (row_order 2: [rows][R], paired with obs rows)
     int B, W, D, R, row_order;

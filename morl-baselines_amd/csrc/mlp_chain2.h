@@ -22,7 +22,6 @@
 //     staggers the two workgroups of a CU: one is in its MFMA loop while the other is in an epilogue.
 #pragma once
 #include "mlp_chain.h"
-#include "chain_td.h"
 
 namespace morl {
 
@@ -275,12 +274,8 @@ __device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& 
 // PROF (development probes only, tools/probes/chain2_probe.hip): wave 0 stamps s_memtime at the phase boundaries of the job
 #define C2_TICK() if (PROF) { if (n_tick < 24) ticks[n_tick] = clock64(); ++n_tick; }
 
-// TDSTAGE: the instantiation that can run the TD stage as its input stage (in_mode 2, chain_td.h).  A compile-time switch: with
-// the stage merely PRESENT in the one kernel every chain launch runs, its registers cost the hot loops 39 more spilled VGPRs
-// (scratch 92 -> 256 bytes per lane, +33 MB of HBM traffic per launch, ~3 us per step) although it never executed.
-template <int TM, int SCHED, int LD, bool PROF = false, bool TDSTAGE = false>
-__device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, float* sAct, long long* prof_out = nullptr,
-                                                int g = 0, const ChainTd* td = nullptr, ChainTdScratch* td_scratch = nullptr) {
+template <int TM, int SCHED, int LD, bool PROF = false>
+__device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, float* sAct, long long* prof_out = nullptr, int g = 0) {
     long long ticks[24];
     int n_tick = 0;
     C2_TICK()
@@ -299,14 +294,7 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
     else c2_load_narrow_k(bx, p.step[0], wave, i, h, g);
 
     // ---- input tile -> sAct[m][k], zero-padded to the columns the first step multiplies -------------------------------
-    if (TDSTAGE && p.in_mode == 2) {
-        // backward chain of a gradient step: the tile's dLoss/dQ rows are computed here (envelope arg-max, TD target, loss
-        // gradient: chain_td.h) instead of being read from a separate launch's output
-        if constexpr (TDSTAGE) {
-            const int K0pad = first_wide ? min(CH_MAXW, (p.K0 + 63) & ~63) : CH_MAXW;
-            chain_td_stage<TM>(*td, row0, p.rows, sAct, C2_LDK, K0pad, td_scratch);
-        }
-    } else {
+    {
         const int K0 = (p.in_mode == 0) ? (p.D + p.R) : p.K0;
         const int K0pad = first_wide ? min(CH_MAXW, (K0 + 63) & ~63) : CH_MAXW;
         const int m = tid & (TM - 1);
@@ -541,7 +529,6 @@ struct Chain2Multi {
                                         // (nb networks of a population): the two or four tiles of one network then share an
                                         // L2 and its weights are fetched from HBM once instead of once per tile
     long long* prof;                    // probes only: [gridDim.x][2][24] phase stamps
-    ChainTd td;                         // the chain with in_mode == 2 (a step's backward chain with the TD stage fused in)
 };
 constexpr int C2_CU_SLOTS = 8192;
 
@@ -558,8 +545,8 @@ __device__ __forceinline__ unsigned c2_cu_key() {
     return ((xcc & 15u) << 8) | ((hw >> 8) & 0xffu);
 }
 
-template <int SCHED, bool PROF, bool NMAJOR = false, bool TDSTAGE = false>
-__device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, float* sAct, ChainTdScratch* td_scratch = nullptr) {
+template <int SCHED, bool PROF, bool NMAJOR = false>
+__device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, float* sAct) {
     const int S = (int)gridDim.x;
     // (workgroup x runs on XCD x % 8)
     const int b = (m.xcd_contig && (S & 7) == 0) ? ((int)blockIdx.x & 7) * (S >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
@@ -597,21 +584,21 @@ __device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, floa
         long long* pout = (PROF && m.prof != nullptr) ? m.prof + ((size_t)b * 2 + (j > 0 ? 1 : 0)) * 24 : nullptr;
         if (NMAJOR) {        // (every chain of the launch streams its wide steps N-major: ChainArgs::fast == 2)
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 2, PROF, TDSTAGE>(m.p[q], row0, sAct, pout, g, &m.td, td_scratch);
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 2, PROF>(m.p[q], row0, sAct, pout, g);
             } else {
-                mlp_chain2_body<64, SCHED, 2, PROF, TDSTAGE>(m.p[q], row0, sAct, pout, g, &m.td, td_scratch);
+                mlp_chain2_body<64, SCHED, 2, PROF>(m.p[q], row0, sAct, pout, g);
             }
         } else if (m.p[q].fast) {
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 1, PROF, TDSTAGE>(m.p[q], row0, sAct, pout, g, &m.td, td_scratch);
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 1, PROF>(m.p[q], row0, sAct, pout, g);
             } else {
-                mlp_chain2_body<64, SCHED, 1, PROF, TDSTAGE>(m.p[q], row0, sAct, pout, g, &m.td, td_scratch);
+                mlp_chain2_body<64, SCHED, 1, PROF>(m.p[q], row0, sAct, pout, g);
             }
         } else {
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 0, PROF, TDSTAGE>(m.p[q], row0, sAct, pout, g, &m.td, td_scratch);
+                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 0, PROF>(m.p[q], row0, sAct, pout, g);
             } else {
-                mlp_chain2_body<64, SCHED, 0, PROF, TDSTAGE>(m.p[q], row0, sAct, pout, g, &m.td, td_scratch);
+                mlp_chain2_body<64, SCHED, 0, PROF>(m.p[q], row0, sAct, pout, g);
             }
         }
         __syncthreads();     // the tile buffer is free for the next job
@@ -623,13 +610,6 @@ __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain2_kernel(Chain2Multi m
     // (+8: the last group's look-ahead operand read of the last row runs 4 floats past the tile; the values are unused)
     __shared__ __attribute__((aligned(16))) float sAct[C2_TM * C2_LDK + 8];
     mlp_chain2_persistent<SCHED, false>(m, sAct);
-}
-
-// the same schedule for a gradient step's backward chain with the TD stage as its input stage (MORL_TD_FUSED=1; chain_td.h)
-static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain2_td_kernel(Chain2Multi m) {
-    __shared__ __attribute__((aligned(16))) float sAct[C2_TM * C2_LDK + 8];
-    __shared__ ChainTdScratch td_scratch;          // 5.6 KB: with the tile buffer two workgroups still share a CU's 160 KB
-    mlp_chain2_persistent<1, false, false, true>(m, sAct, &td_scratch);
 }
 
 // the same schedule with the N-major weight stream (forward passes that read the nn.Linear matrices as they are: morl_ac.hip)

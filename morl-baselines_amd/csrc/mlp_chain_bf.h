@@ -1,0 +1,457 @@
+// Layer-fused MLP chain on the bf16 matrix cores with fp32-class accuracy (gfx950, wave64): every fp32 GEMM of a chain is
+// evaluated as SIX products of three-way bf16 splits,
+//
+//     a = a_hi + a_mid + a_lo  (8 + 8 + 8 significand bits, each part the round-to-nearest bf16 of what the parts before it left),
+//     a * b ~ a_lo*b_hi + a_mid*b_mid + a_hi*b_lo + a_mid*b_hi + a_hi*b_mid + a_hi*b_hi        (all terms >= 2^-16 of |a*b|),
+//
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  bf16 keeps fp32's exponent, so the split is exact for every finite fp32 value
+// (no range assumption: gradients of 1e-9 split as well as activations of 1e3); the dropped terms are <= 3 * 2^-24 of |a*b|, the
+// class of an fp32 multiply's own rounding.  Measured on MI355X (tools/probes): max |Q - Q_float64| 2.4e-7 against 2.3e-7 for the
+// k-ordered fp32 chain of mlp_chain2.h, at 6/16 of its matrix-core time (the f32-input MFMA runs at the VECTOR rate, 1/16 of bf16).
+//
+// Replaces, for the Envelope step's big launches (morl_hip.hip): QNet.forward of the online next-state pass and of the training
+// pass (envelope.py:300, :420; common/networks.py:10-48) and the dX half of loss.backward() (envelope.py:323).
+//
+// Layout, chosen so that ACTIVATIONS NEVER LEAVE THE REGISTERS between layers:
+//   * a wave owns 16 rows through the whole chain and computes the TRANSPOSED product D^T[feature][row] = W[feature][k] x^T[k][row]
+//     per 16-feature tile: A operand = weights (lane (n, q): feature 16t + n, eight contraction slots of group q), B operand =
+//     activations (lane (m, q): row m, the same eight slots), D: lane (m, q) holds features 16t + 4q + 0..3 of row m.
+//   * which contraction index a slot stands for is free as long as A and B agree, so the slots of a hidden layer's k-step s are
+//     DEFINED as what the lane already holds: slot (q, e) <-> feature 32s + 16(e >> 2) + 4q + (e & 3) = register e & 3 of tile
+//     2s + (e >> 2).  The epilogue (bias is the accumulator's initial value; ReLU; split; pack) is lane-local: no LDS, no barrier,
+//     no shuffle between layers.  The weights are laid out to match, once per step, by bf_split_kernel.
+//   * weights are the shared operand: the four waves of a workgroup (64 rows) read them from LDS, staged ONCE per workgroup by
+//     LDS-DMA (global_load_lds, 16 bytes per lane) through a ring of three 24 KB stages that runs ahead across layer boundaries
+//     (the whole chain's weights are one linear stream of 1 KB fragment blocks in consumption order: block = one (k-step, tile,
+//     split part), lane l's 16 bytes at offset 16 l -- the ds_read_b128 of a fragment is 1 KB contiguous, conflict-free).
+//     One s_barrier per stage (48 MFMAs per wave); counted vmcnt, never 0 in the loop.
+//   * two workgroups per CU (77 KB of LDS, <= 256 VGPRs): one's barriers and epilogues fall into the other's MFMA phases.
+// Per row and layer: 2*K*N flop algorithmic, 6x that on the bf16 pipe; HBM bytes = the chain's inputs and outputs only (saved
+// activations / gradients of the training passes are written once, fp32, from the accumulators).
+#pragma once
+#include "mlp_chain.h"
+
+namespace morl {
+
+constexpr int BF_ROWS_WAVE = 16;                 // rows a wave carries
+constexpr int BF_TM = 64;                        // rows per workgroup (4 waves)
+constexpr int BF_BLOCK = 1024;                   // bytes of one fragment block: 64 lanes x 8 bf16
+constexpr int BF_STAGE_BLOCKS = 24;              // blocks per ring stage (24 KB): half a k-step of a 256-wide layer
+constexpr int BF_STAGE_BYTES = BF_STAGE_BLOCKS * BF_BLOCK;
+constexpr int BF_RING = 3;                       // stages resident: one being multiplied, two in flight
+constexpr int BF_DMA_PER_WAVE = BF_STAGE_BLOCKS / 4;   // LDS-DMA instructions a wave issues per stage
+constexpr int BF_MAX_STEPS = MORL_MAX_LAYERS;
+constexpr int BF_WIDE = 256;                     // columns of every wide step
+
+typedef unsigned int bf_u32x4 __attribute__((ext_vector_type(4)));      // eight bf16
+typedef __bf16 bf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float bf_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf_bf16x2 __attribute__((ext_vector_type(2)));
+
+// One step (dense layer) of a chain.  Wide steps have N = 256 columns (16 tiles); the narrow last step (the Q head) N <= 32.
+struct BfStep {
+    const float* bias;                     // [N] fp32, or NULL (backward chain: no bias)
+    float* out;                            // or NULL: fp32 copy of this step's output, [rows][ldout] (saved h_l / g_l; the head: Q)
+    unsigned long long* bits_out;          // or NULL: (output > 0) of a wide step, one 64-bit word per lane: word[(row / 16) * 64 + lane],
+    const unsigned long long* bits_in;     //          bit 4 * tile + r <-> feature 16 * tile + 4 * (lane >> 4) + r of row (lane & 15);
+                                           // bits_in: the output is kept where the bit is set (ReLU backward)
+    int N, K;                              // real columns / contraction length
+    int ldout;
+    int relu;
+};
+
+struct BfChain {
+    const unsigned char* stream;           // split weights of the whole chain in consumption order (bf_split_kernel)
+    BfStep step[BF_MAX_STEPS];
+    int n_steps;                           // first step wide with k0_steps k-steps, then wide steps of 8 k-steps, then (head) one narrow step
+    int k0_steps;                          // 1 or 2: k-steps (32 contraction indices each) of the first step, natural order
+    int head;                              // 1: the last step is narrow
+    int n_stages;                          // ring stages of the stream
+    int rows;
+    // input rows (as ChainArgs): 0 cat(obs[b], weights[i]) with row -> (b, i) by row_order; 1 dense src[rows][ldsrc], K0 columns
+    int in_mode;
+    const float* obs;
+    const float* weights;
+    int B, W, D, R, row_order;
+    const float* src;
+    int ldsrc, K0;
+    float* x0_out;                         // in_mode 0, or NULL: the assembled rows also go to HBM as [rows][ldx0] (zero padded)
+    int ldx0;
+};
+
+constexpr int BF_MAX_MULTI = 2;
+struct BfMulti {
+    BfChain c[BF_MAX_MULTI];
+    int tile_start[BF_MAX_MULTI + 1];      // 64-row tiles of chain q: [tile_start[q], tile_start[q + 1])
+    int n;
+};
+
+// ---- three-way split ---------------------------------------------------------------------------------------------------------
+// two fp32 -> packed pair of round-to-nearest-even bf16 (v_cvt_pk_bf16_f32): a in the low half, b in the high half
+__device__ __forceinline__ unsigned bf_pack2(float a, float b) {
+    const bf_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf_bf16x2));
+}
+__device__ __forceinline__ float bf_low(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf_high(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// (a, b) -> hi / mid / lo pairs; the two subtractions are exact (the difference of an fp32 and its bf16 rounding fits fp32)
+__device__ __forceinline__ void bf_split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = bf_pack2(a, b);
+    const float ra = a - bf_low(hi), rb = b - bf_high(hi);
+    mid = bf_pack2(ra, rb);
+    lo = bf_pack2(ra - bf_low(mid), rb - bf_high(mid));
+}
+
+__device__ __forceinline__ f32x4 bf_mfma(const bf_u32x4& w, const bf_u32x4& x, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf_bf16x8, w), __builtin_bit_cast(bf_bf16x8, x), c, 0, 0, 0);
+}
+
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima)
+#define BF_VMCNT(N) __builtin_amdgcn_s_waitcnt((((N) & 15) | (((N) >> 4) << 14) | (7 << 4) | (15 << 8)))
+// s_waitcnt vmcnt(N) lgkmcnt(0): the stage boundary -- besides the DMA group, every LDS read this wave has issued has RETURNED (the
+// scheduler moves the last fragment reads of a stage up to the barrier; the buffer they read is the one the DMA issued right after
+// the barrier overwrites)
+#define BF_VMCNT_LDS0(N) __builtin_amdgcn_s_waitcnt((((N) & 15) | (((N) >> 4) << 14) | (7 << 4) | (0 << 8)))
+
+// ---- the weight ring ------------------------------------------------------------------------------------------------------------
+struct BfRing {
+    __amdgpu_buffer_rsrc_t rsrc;   // the whole stream
+    int voff;                      // this lane's byte offset inside a stage: wave * 6 KB + lane * 16
+    unsigned char* lds;            // ring base (workgroup)
+    int t;                         // stage the workgroup multiplies next
+    int buf;                       // t % 3
+    int n_stages;
+    int wave;
+};
+
+// LDS-DMA of this wave's share of stage `st` (clamped to the stream's last stage: the issue count per stage is static) into `buf`:
+// buffer_load_dwordx4 ... lds, 1 KB per instruction (lane l's 16 bytes land at M0 + offset + 16 l; the instruction offset counts on
+// both sides).  The MUBUF form, not global_load_lds: a pending FLAT-encoded LDS access makes hipcc's wait insertion treat every LDS
+// counter as unordered -- each fragment read was then waited for with lgkmcnt(0) instead of a counted wait.
+__device__ __forceinline__ void bf_ring_issue(const BfRing& r, int st, int buf) {
+    const int s = st < r.n_stages ? st : r.n_stages - 1;
+    const int soff = s * BF_STAGE_BYTES;
+    unsigned char* l = r.lds + buf * BF_STAGE_BYTES + r.wave * (BF_DMA_PER_WAVE * BF_BLOCK);
+    // (instruction offsets are 12-bit immediates: pieces 4 and 5 go through the scalar offset / M0)
+    __attribute__((address_space(3))) void* l0 = (__attribute__((address_space(3))) void*)l;
+    __attribute__((address_space(3))) void* l1 = (__attribute__((address_space(3))) void*)(l + 4 * BF_BLOCK);
+    static_assert(BF_DMA_PER_WAVE == 6, "six pieces per wave and stage");
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, l0, 16, r.voff, soff, 0 * BF_BLOCK, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, l0, 16, r.voff, soff, 1 * BF_BLOCK, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, l0, 16, r.voff, soff, 2 * BF_BLOCK, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, l0, 16, r.voff, soff, 3 * BF_BLOCK, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, l1, 16, r.voff, soff + 4 * BF_BLOCK, 0 * BF_BLOCK, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, l1, 16, r.voff, soff + 4 * BF_BLOCK, 1 * BF_BLOCK, 0);
+}
+
+// Entry of stage r.t: my share of it has landed (EXTRA = vector-memory instructions this lane issued AFTER the DMA group of the
+// stage following it -- epilogue stores -- which retire in issue order behind the group waited for); after the barrier everybody's
+// has, and everybody is done reading the stage before it, whose buffer takes the stage two ahead.  Returns the stage's LDS base.
+template <int EXTRA>
+__device__ __forceinline__ const unsigned char* bf_stage_begin(BfRing& r) {
+    BF_VMCNT_LDS0(BF_DMA_PER_WAVE + EXTRA);
+    __builtin_amdgcn_s_barrier();
+    const int free_buf = r.buf == 0 ? 2 : r.buf - 1;
+    bf_ring_issue(r, r.t + 2, free_buf);
+    const unsigned char* base = r.lds + r.buf * BF_STAGE_BYTES;
+    r.buf = r.buf == 2 ? 0 : r.buf + 1;
+    ++r.t;
+    return base;
+}
+
+// the three split parts of the fragment of local tile `t` of a stage (blocks 3t .. 3t + 2), lane's 16 bytes each
+__device__ __forceinline__ void bf_frag_load(bf_u32x4 (&f)[3], const unsigned char* lane_base, int t) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) f[p] = *reinterpret_cast<const bf_u32x4*>(lane_base + (3 * t + p) * BF_BLOCK);
+}
+
+// The six products of a tile pair, smallest first (lo*hi, mid*mid, hi*lo, mid*hi, hi*mid, hi*hi: w part, x part), the two tiles
+// alternating so that no two consecutive MFMAs share an accumulator (a dependent v_mfma_f32_16x16x32_bf16 waits for its predecessor's
+// last pass).  READ: the fragment reads of the NEXT pair ride along, one per product step, twelve MFMAs (>= 192 cycles) ahead of
+// their first use.  The order is PINNED with sched_barrier: left alone, hipcc clusters the MFMAs of one accumulator and sinks
+// every ds_read next to its first use (waiting for it on the spot).
+#define BF_PIN() __builtin_amdgcn_sched_barrier(0)
+template <bool READ>
+__device__ __forceinline__ void bf_six_pair(f32x4& c0, f32x4& c1, const bf_u32x4 (&w0)[3], const bf_u32x4 (&w1)[3], const bf_u32x4 (&x)[3],
+                                            bf_u32x4 (&n0)[3], bf_u32x4 (&n1)[3], const unsigned char* next_base) {
+    constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        if (READ) {          // in the order the next pair consumes them: lo parts first (the wait before its first MFMA is a counted one)
+            const int pl = 2 - (p >> 1);
+            if ((p & 1) == 0) n0[pl] = *reinterpret_cast<const bf_u32x4*>(next_base + pl * BF_BLOCK);
+            else n1[pl] = *reinterpret_cast<const bf_u32x4*>(next_base + (3 + pl) * BF_BLOCK);
+        }
+        c0 = bf_mfma(w0[pw[p]], x[px[p]], c0);
+        c1 = bf_mfma(w1[pw[p]], x[px[p]], c1);
+        BF_PIN();
+    }
+}
+
+// One wide step (256 columns = 16 tiles) over KSTEPS k-steps: two stages per k-step (tiles 0-7, 8-15), per stage four tile pairs.
+// acc[T][r] += sum_k W[16T + 4q + r][k] * x[k]  for this lane's row;   EXTRA0: see bf_stage_begin, applies to the first two stages
+template <int KSTEPS, int EXTRA0>
+__device__ __forceinline__ void bf_wide_step(f32x4 (&acc)[16], const bf_u32x4 (&x)[8][3], BfRing& ring, int lane) {
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            BF_PIN();
+            const unsigned char* base = ((s == 0) ? bf_stage_begin<EXTRA0>(ring) : bf_stage_begin<0>(ring)) + lane * 16;
+            bf_u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int pl = 2; pl >= 0; --pl) {       // (consumption order, pinned: the first MFMAs wait for the first two reads only)
+                fa[0][pl] = *reinterpret_cast<const bf_u32x4*>(base + pl * BF_BLOCK);
+                fa[1][pl] = *reinterpret_cast<const bf_u32x4*>(base + (3 + pl) * BF_BLOCK);
+                BF_PIN();
+            }
+            const int T = 8 * hf;
+            bf_six_pair<true>(acc[T + 0], acc[T + 1], fa[0], fa[1], x[s], fb[0], fb[1], base + 6 * BF_BLOCK);
+            bf_six_pair<true>(acc[T + 2], acc[T + 3], fb[0], fb[1], x[s], fa[0], fa[1], base + 12 * BF_BLOCK);
+            bf_six_pair<true>(acc[T + 4], acc[T + 5], fa[0], fa[1], x[s], fb[0], fb[1], base + 18 * BF_BLOCK);
+            bf_six_pair<false>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
+        }
+    }
+}
+
+// The narrow last step (N <= 32: NT tiles) over 8 k-steps: 24 / (3 NT) k-steps per stage.
+template <int NT, int EXTRA0>
+__device__ __forceinline__ void bf_head_step(f32x4 (&acc)[2], const bf_u32x4 (&x)[8][3], BfRing& ring, int lane) {
+    constexpr int KS_PER_STAGE = BF_STAGE_BLOCKS / (3 * NT);
+    constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int s0 = 0; s0 < 8; s0 += KS_PER_STAGE) {
+        BF_PIN();
+        const unsigned char* base = bf_stage_begin<EXTRA0>(ring) + lane * 16;       // (one or two stages: both behind the epilogue's stores)
+        bf_u32x4 f[KS_PER_STAGE][NT][3];
+#pragma unroll
+        for (int ks = 0; ks < KS_PER_STAGE; ++ks)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bf_frag_load(f[ks][t], base, ks * NT + t);
+        BF_PIN();
+        // (one tile: its products are a dependent chain per k-step; the k-steps of the stage alternate instead)
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int ks = 0; ks < KS_PER_STAGE; ++ks)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = bf_mfma(f[ks][t][pw[p]], x[s0 + ks][px[p]], acc[t]);
+    }
+}
+
+// accumulators of a step start from its bias (LDS copy, [256] floats per step; zeros for a step without bias)
+template <int NTILES>
+__device__ __forceinline__ void bf_acc_init(f32x4 (&acc)[NTILES], const float* bias_lds, int q) {
+#pragma unroll
+    for (int T = 0; T < NTILES; ++T) acc[T] = *reinterpret_cast<const f32x4*>(bias_lds + 16 * T + 4 * q);
+}
+
+// Epilogue of a wide step, lane-local: (ReLU | mask bits) -> fp32 copy to HBM -> sign bits -> split into the next step's B operand.
+// Vector-memory instructions issued per lane when SAVE: 16 row stores (+ 1 word of bits) -- BF_SAVE_VMEM, counted by the waits.
+constexpr int BF_SAVE_VMEM = 17;
+template <bool SAVE>
+__device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x4 (&x)[8][3], const BfStep& st, int row, bool row_ok,
+                                                 size_t bits_idx, int q) {
+    unsigned long long keep = ~0ull, pos = 0ull;
+    if (SAVE && st.bits_in != nullptr) keep = st.bits_in[bits_idx];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int T = 2 * s + (e >> 2), r = e & 3;
+            float a = acc[T][r];
+            if (st.relu) a = fmaxf(a, 0.f);
+            if (SAVE) {
+                a = ((keep >> (4 * T + r)) & 1ull) ? a : 0.f;
+                if (a > 0.f) pos |= 1ull << (4 * T + r);
+            }
+            v[e] = a;
+        }
+        if (SAVE && st.out != nullptr && row_ok) {
+            float* o = st.out + (size_t)row * st.ldout + 32 * s + 4 * q;
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(o + 16) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bf_split2(v[2 * u], v[2 * u + 1], hi[u], mid[u], lo[u]);
+        x[s][0] = bf_u32x4{hi[0], hi[1], hi[2], hi[3]};
+        x[s][1] = bf_u32x4{mid[0], mid[1], mid[2], mid[3]};
+        x[s][2] = bf_u32x4{lo[0], lo[1], lo[2], lo[3]};
+    }
+    if (SAVE && st.bits_out != nullptr) st.bits_out[bits_idx] = pos;
+}
+
+// ---- one 64-row tile through a whole chain ----------------------------------------------------------------------------------------
+// K0S: k-steps of the first step (1 or 2); SAVE: the chain writes per-step outputs / sign bits (training forward, backward) -- a
+// compile-time switch because the counted waits depend on the stores issued.
+template <int K0S, bool SAVE>
+__device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsigned char* ring_lds, float* bias_lds) {
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, q = lane >> 4;
+    const int row = row0 + 16 * wave + m;
+    const bool row_ok = row < p.rows;
+    const size_t bits_idx = (size_t)((row0 >> 4) + wave) * 64 + lane;
+
+    BfRing ring;
+    ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.stream, 0, p.n_stages * BF_STAGE_BYTES, 0x00020000);
+    ring.voff = wave * (BF_DMA_PER_WAVE * BF_BLOCK) + lane * 16;
+    ring.lds = ring_lds;
+    ring.t = 0; ring.buf = 0; ring.n_stages = p.n_stages; ring.wave = wave;
+    // the stream starts before the input rows are assembled
+    bf_ring_issue(ring, 0, 0);
+    bf_ring_issue(ring, 1, 1);
+    // biases -> LDS, [step][256] (zeros beyond a step's columns and for steps without bias); visible after the first stage's barrier
+    for (int e = tid; e < p.n_steps * BF_WIDE; e += 256) {
+        const int s = e >> 8, n = e & 255;
+        const BfStep& st = p.step[s];
+        bias_lds[e] = (st.bias != nullptr && n < st.N) ? st.bias[n] : 0.f;
+    }
+
+    // ---- input rows: natural contraction order, slot (q, e) of k-step s <-> column 32 s + 8 q + e -------------------------------
+    bf_u32x4 x[8][3];
+    {
+        int b = row, w = row;
+        if (p.in_mode == 0) {
+            if (p.row_order == 0) { b = row / p.W; w = row - b * p.W; }
+            else if (p.row_order == 1) { w = row / p.B; b = row - w * p.B; }
+        }
+        const int K0 = (p.in_mode == 0) ? p.D + p.R : p.K0;
+        const float* src_a = (p.in_mode == 0) ? p.obs + (size_t)b * p.D : p.src + (size_t)row * p.ldsrc;
+        const float* src_w = (p.in_mode == 0) ? p.weights + (size_t)w * p.R : nullptr;
+#pragma unroll
+        for (int s = 0; s < K0S; ++s) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 32 * s + 8 * q + e;
+                float a = 0.f;
+                if (row_ok && k < K0) {
+                    if (p.in_mode == 0) a = (k < p.D) ? src_a[k] : src_w[k - p.D];
+                    else a = src_a[k];
+                }
+                v[e] = a;
+            }
+            if (p.x0_out != nullptr && row_ok) {
+                const int k = 32 * s + 8 * q;
+                float* o = p.x0_out + (size_t)row * p.ldx0 + k;
+                if (k < p.ldx0) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);            // (ldx0 is a multiple of 4)
+                if (k + 4 < p.ldx0) *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bf_split2(v[2 * u], v[2 * u + 1], hi[u], mid[u], lo[u]);
+            x[s][0] = bf_u32x4{hi[0], hi[1], hi[2], hi[3]};
+            x[s][1] = bf_u32x4{mid[0], mid[1], mid[2], mid[3]};
+            x[s][2] = bf_u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+    }
+    // everything this lane loaded or stored so far has to be out of the way of the counted waits: drain once, before the loop
+    // (the two DMA groups in flight are waited for here too -- the only vmcnt(0) of the kernel, at its very start)
+    BF_VMCNT(0);
+    __syncthreads();                     // the bias copy is complete before the first accumulator takes its bias
+
+    f32x4 acc[16];
+    const int n_wide = p.n_steps - (p.head ? 1 : 0);
+    // ---- first step ---------------------------------------------------------------------------------------------------------------
+    bf_acc_init<16>(acc, bias_lds, q);
+    bf_wide_step<K0S, 0>(acc, x, ring, lane);
+    bf_wide_epilogue<SAVE>(acc, x, p.step[0], row, row_ok, bits_idx, q);
+    // ---- the 256 x 256 steps --------------------------------------------------------------------------------------------------------
+    for (int s = 1; s < n_wide; ++s) {
+        bf_acc_init<16>(acc, bias_lds + s * BF_WIDE, q);
+        bf_wide_step<8, SAVE ? BF_SAVE_VMEM : 0>(acc, x, ring, lane);
+        bf_wide_epilogue<SAVE>(acc, x, p.step[s], row, row_ok, bits_idx, q);
+    }
+    // ---- the head -----------------------------------------------------------------------------------------------------------------
+    if (p.head) {
+        const BfStep& st = p.step[p.n_steps - 1];
+        f32x4 hacc[2];
+        bf_acc_init<2>(hacc, bias_lds + (p.n_steps - 1) * BF_WIDE, q);
+        if (st.N > 16) bf_head_step<2, SAVE ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
+        else bf_head_step<1, SAVE ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
+        if (st.out != nullptr && row_ok) {
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 16 * T + 4 * q + r;
+                    if (n < st.N) st.out[(size_t)row * st.ldout + n] = hacc[T][r];
+                    else if (n < st.ldout) st.out[(size_t)row * st.ldout + n] = 0.f;          // (pad columns of a padded Q buffer)
+                }
+        }
+    }
+    // nothing of this workgroup may still be in flight into LDS when the next workgroup of the CU takes the allocation
+    BF_VMCNT(0);
+}
+
+constexpr int BF_LDS_BYTES = BF_RING * BF_STAGE_BYTES + BF_MAX_STEPS * BF_WIDE * 4;
+
+// grid: one workgroup per 64-row tile over the launch's chains; two workgroups per CU
+__global__ __launch_bounds__(256, 2) void mlp_chain_bf_kernel(BfMulti m) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BF_LDS_BYTES];
+    const int tile = (int)blockIdx.x;
+    int qn = 0;
+    while (qn + 1 < m.n && tile >= m.tile_start[qn + 1]) ++qn;
+    const BfChain& p = m.c[qn];
+    const int row0 = (tile - m.tile_start[qn]) * BF_TM;
+    float* bias_lds = reinterpret_cast<float*>(lds + BF_RING * BF_STAGE_BYTES);
+    const bool save = p.step[0].out != nullptr || p.step[0].bits_out != nullptr || p.step[0].bits_in != nullptr;
+    if (p.k0_steps == 1) {
+        if (save) bf_chain_body<1, true>(p, row0, lds, bias_lds);
+        else bf_chain_body<1, false>(p, row0, lds, bias_lds);
+    } else {
+        if (save) bf_chain_body<2, true>(p, row0, lds, bias_lds);
+        else bf_chain_body<2, false>(p, row0, lds, bias_lds);
+    }
+}
+
+// ---- the weight stream: split + fragment order, once per optimiser step ---------------------------------------------------------
+// One job = one chain step's matrix M[n][k] (n: output feature, k: contraction index) given as base + n * sn + k * sk (forward:
+// nn.Linear.weight [out][in], sn = in, sk = 1; backward: the transposed view, sn = 1, sk = in) of N x K real elements, written
+// as ksteps * ntiles * 3 blocks from block `block0` on; natural = 1: slot (q, e) of k-step s <-> k = 32 s + 8 q + e (the first step,
+// fed from memory), 0: <-> k = 32 s + 16 (e >> 2) + 4 q + (e & 3) (fed from the registers of the step before).
+struct BfSplitJob {
+    const float* base;
+    long long sn, sk;
+    int N, K, ksteps, ntiles, natural, block0;
+};
+constexpr int BF_MAX_JOBS = 2 * BF_MAX_STEPS;
+struct BfSplitArgs {
+    BfSplitJob job[BF_MAX_JOBS];
+    int unit_start[BF_MAX_JOBS + 1];       // (k-step, tile) units of job j: [unit_start[j], unit_start[j + 1])
+    int n;
+};
+
+// one thread per (k-step, tile, lane): eight weights -> three 16-byte fragments; `unit0` = first unit of this call's grid
+__device__ __forceinline__ void bf_split_body(const BfSplitArgs& a, unsigned char* __restrict__ stream, long long gtid) {
+    const int unit = (int)(gtid >> 6), lane = (int)(gtid & 63);
+    if (unit >= a.unit_start[a.n]) return;
+    int j = 0;
+    while (j + 1 < a.n && unit >= a.unit_start[j + 1]) ++j;
+    const BfSplitJob& jb = a.job[j];
+    const int u = unit - a.unit_start[j];
+    const int s = u / jb.ntiles, t = u - s * jb.ntiles;
+    const int n = 16 * t + (lane & 15), q = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = jb.natural ? 32 * s + 8 * q + e : 32 * s + 16 * (e >> 2) + 4 * q + (e & 3);
+        v[e] = (n < jb.N && k < jb.K) ? jb.base[(long long)n * jb.sn + (long long)k * jb.sk] : 0.f;
+    }
+    unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) bf_split2(v[2 * w], v[2 * w + 1], hi[w], mid[w], lo[w]);
+    unsigned char* dst = stream + ((size_t)jb.block0 + (size_t)u * 3) * BF_BLOCK + lane * 16;
+    *reinterpret_cast<bf_u32x4*>(dst) = bf_u32x4{hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<bf_u32x4*>(dst + BF_BLOCK) = bf_u32x4{mid[0], mid[1], mid[2], mid[3]};
+    *reinterpret_cast<bf_u32x4*>(dst + 2 * BF_BLOCK) = bf_u32x4{lo[0], lo[1], lo[2], lo[3]};
+}
+
+__global__ __launch_bounds__(256) void bf_split_kernel(BfSplitArgs a, unsigned char* __restrict__ stream) {
+    bf_split_body(a, stream, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+}  // namespace morl

@@ -21,7 +21,7 @@
 #include "mlp_chain2.h"
 #include "mlp_chain16.h"
 #include "mlp_chain4.h"
-#include "dw_wave.h"
+#include "mlp_chain_bf.h"
 #include "dw_tiles.h"
 #include "optim_kernels.h"
 #include "replay_kernels.h"
@@ -83,18 +83,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_grouped_tn_kernel(GemmGroup
     gemm_tile<false, false, EPI_STORE>(g, local / g.tiles_n, local % g.tiles_n, split);
 }
 
-// same work, double-buffered LDS tiles, two workgroups per CU (see gemm_tile_tn_db)
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_grouped_tn_db_kernel(GemmGroup grp) {
-    const int n_tiles = grp.tile_start[grp.n];
-    const int logical = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int split = logical / n_tiles, id = logical % n_tiles;
-    int q = 0;
-    while (q + 1 < grp.n && id >= grp.tile_start[q + 1]) ++q;
-    const int local = id - grp.tile_start[q];
-    const GemmProblem& g = grp.p[q];
-    gemm_tile_tn_db(g, local / g.tiles_n, local % g.tiles_n, split);
-}
-
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst,
                                                         int ldd, long long rows, int cols) {
     const long long total = rows * cols;
@@ -125,13 +113,15 @@ __global__ __launch_bounds__(256) void copy_rows_bmajor_kernel(const float* __re
 // half of round 2 ran as two launches (and, before that, as five).
 __global__ __launch_bounds__(256) void step_prologue_kernel(SampleGatherArgs sg, int sg_blocks, const float* __restrict__ params,
                                                             float* __restrict__ wt, const float* __restrict__ params2,
-                                                            float* __restrict__ wt2, ShadowArgs sh) {
+                                                            float* __restrict__ wt2, ShadowArgs sh, int sh_nets, BfSplitArgs bf,
+                                                            unsigned char* __restrict__ bf_stream) {
     __shared__ float tile[SH_T * (SH_T + 1)];
     const int b = (int)blockIdx.x;
     if (b < sg_blocks) { sample_gather_body(sg, b, sg_blocks); return; }
     const int t = b - sg_blocks;
     if (t < sh.tiles) shadow_tiles_body(params, wt, sh, t, sh.tiles, tile);
-    else shadow_tiles_body(params2, wt2, sh, t - sh.tiles, sh.tiles, tile);
+    else if (t < sh_nets * sh.tiles) shadow_tiles_body(params2, wt2, sh, t - sh.tiles, sh.tiles, tile);
+    else bf_split_body(bf, bf_stream, (long long)(t - sh_nets * sh.tiles) * 256 + threadIdx.x);     // (split-bf16 weight stream: mlp_chain_bf.h)
 }
 
 }  // namespace morl
@@ -173,11 +163,8 @@ struct morl_ctx {
     bool k4 = false;                         // every wide chain step has 256 columns: constant-stride weight stream over the K4
                                              // layout (mlp_chain2.h: c2_load_fast); ChainArgs::fast of this context's chains
     int ldn[MORL_MAX_LAYERS];
-    int dw_mode = 3;         // weight-gradient engine: 3 balanced wave-layout tiles (dw_tiles.h); older engines kept for A/B
-                             // runs: 0 wave-level tiles (dw_wave.h), 1 double-buffered LDS tiles,
-                             // 2 single-buffered LDS tiles (the per-layer engine's)
-    bool dw_wave_ok = false; // wave-level dW kernel usable (all operand row strides even)
-    int dw_wave_tiles = 0;
+    int dw_mode = 3;         // weight-gradient engine: 3 balanced wave-layout tiles (dw_tiles.h: 16-byte aligned operand rows);
+                             // 2 the per-layer engine's LDS tiles as one grouped split-K launch (any shape: the fall-back)
     bool fused_ok = false;   // architecture fits the fused engine
     bool use_fused = false;  // fused_ok and not disabled by morl_ctx_set_fused
     unsigned long long* relu_bits[MORL_MAX_LAYERS] = {};  // [l]: (h[l] > 0) packed by the 64-row forward tiling
@@ -207,6 +194,15 @@ struct morl_ctx {
     const float* lz_next_obs = nullptr;
     float* td_zero_ptr = nullptr;        // one-shot request of the batch-sharded step to the next TD launch: zero this range ...
     int td_zero_n = 0, td_keep_lo = 0, td_keep_hi = 0;   // ... except [keep_lo, keep_hi) (the rank's own priorities)
+    // split-bf16 chain (mlp_chain_bf.h): the online network's weights as fragment-ordered bf16 triples, forward stream then backward
+    // stream, re-made once per optimiser step (by morl_envelope_prepare's launch, or by the step itself)
+    bool bf_ok = false;                  // the architecture fits: hidden layers of 256, head <= 32 columns, input <= 64
+    int bf_mode = 1;                     // 0: MORL_EXACT_F32=1 / morl_ctx_set_exact_f32 -- every GEMM on the f32-input MFMA (rounds 1-3)
+    long long bf_min_rows = 8192;        // steps of fewer TD rows stay on the fp32 chains (latency-bound; MORL_BF_MIN_ROWS)
+    unsigned char* bf_stream = nullptr;
+    int bf_fwd_blocks = 0, bf_bwd_blocks = 0, bf_k0_steps = 0, bf_head_tiles = 0;
+    const float* fresh_bf = nullptr;     // parameters the streams were split from by this step's morl_envelope_prepare (one-shot)
+    bool bits_bf = false;                // the last training forward left its sign bits in mlp_chain_bf.h's lane layout
     const unsigned int* skip_flag = nullptr;   // one-shot: the next clip + Adam launch leaves the optimiser state alone if this
                                          // device word is non-zero (a timed-out collective of the single-hop transport)
     int main_rows = -1;                  // rows of a hoisted training forward (morl_envelope_main_forward), -1 = none
@@ -217,8 +213,6 @@ struct morl_ctx {
     const float* wt_online_src = nullptr;   // parameters wt_online was transposed from by this step's morl_envelope_slabs
                                          // (cleared by every optimiser step of the library)
     size_t ev_used = 0;
-    bool td_fused = false;   // MORL_TD_FUSED=1: large steps run the TD stage inside the backward chain's launch (chain_td.h) --
-                             // measured break-even against envelope_td_kernel in front of it, so off by default
     int chain_stagger = 3;   // mlp_chain2: job-order staggering of co-resident workgroups (Chain2Multi::stagger)
     unsigned int* cu_tickets = nullptr;
     int chain_sched = 1;     // mlp_chain2: instruction interleave pinned with sched_group_barrier (0: hipcc's own schedule)
@@ -274,6 +268,7 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     if (c->cu_tickets) (void)hipFree(c->cu_tickets);
     if (c->wt_online) (void)hipFree(c->wt_online);
     if (c->wt_target) (void)hipFree(c->wt_target);
+    if (c->bf_stream) (void)hipFree(c->bf_stream);
     delete c;
     return MORL_OK;
 }
@@ -364,19 +359,12 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         if (l >= 1 && net->dims[l] <= 32 && (net->dims[l + 1] & 3)) c->fused_ok = false;   // backward narrow step: K = dims[l+1]
     }
     if (const char* e = getenv("MORL_CHAIN_SCHED")) c->chain_sched = atoi(e) ? 1 : 0;
-    if (const char* e = getenv("MORL_TD_FUSED")) c->td_fused = atoi(e) != 0;      // (A/B runs)
     if (const char* e = getenv("MORL_CHAIN_STAGGER")) c->chain_stagger = std::max(0, std::min(3, atoi(e)));
     {
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             c->num_cus = prop.multiProcessorCount;
-    }
-    c->dw_wave_ok = true;
-    c->dw_wave_tiles = 0;
-    for (int l = 0; l < c->L; ++l) {
-        if (l >= 1 && (net->dims[l] & 1)) c->dw_wave_ok = false;
-        c->dw_wave_tiles += ((net->dims[l + 1] + DW_TILE - 1) / DW_TILE) * ((net->dims[l] + DW_TILE - 1) / DW_TILE);
     }
     for (int l = 1; l < c->L; ++l) ALLOC(relu_bits[l], ((size_t)c->max_rows + 63) / 64 * CH_THREADS);
     ALLOC(zeros, 16);
@@ -399,6 +387,18 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     ALLOC(wt_online, c->wt_count + 4);   // (+4: an 8-byte operand load may touch one float past the last row)
     ALLOC(wt_target, c->wt_count + 4);
     c->use_fused = c->fused_ok;
+    // split-bf16 chain: first step <= 64 inputs (1 or 2 k-steps of 32), every hidden layer 256 wide, head <= 32 columns
+    c->bf_ok = c->fused_ok && c->L >= 2 && c->L <= BF_MAX_STEPS && net->dims[0] <= 64 && net->dims[c->L] <= 32 && (c->ld0 & 3) == 0;
+    for (int l = 1; l < c->L; ++l) c->bf_ok = c->bf_ok && net->dims[l] == BF_WIDE;
+    if (c->bf_ok) {
+        c->bf_k0_steps = (net->dims[0] + 31) / 32;
+        c->bf_head_tiles = (net->dims[c->L] + 15) / 16;
+        c->bf_fwd_blocks = c->bf_k0_steps * 48 + (c->L - 2) * 384 + 8 * c->bf_head_tiles * 3;
+        c->bf_bwd_blocks = 48 + (c->L - 2) * 384;
+        ALLOC(bf_stream, (size_t)(c->bf_fwd_blocks + c->bf_bwd_blocks) * BF_BLOCK);
+    }
+    if (const char* e = getenv("MORL_EXACT_F32")) c->bf_mode = atoi(e) != 0 ? 0 : 1;
+    if (const char* e = getenv("MORL_BF_MIN_ROWS")) c->bf_min_rows = atoll(e);
 #undef ALLOC
     *out = c;
     return MORL_OK;
@@ -506,17 +506,141 @@ static ShadowArgs shadow_args(morl_ctx* c) {
 // the parameter pointer, which does not change when the parameters do (morl_polyak, load_state_dict, copy_ write in place), so
 // every other entry point (morl_qnet_forward, greedy actions, a skipped step's successor) refreshes unconditionally and drops
 // the flags; morl_ctx_invalidate_shadows drops them explicitly.
+static int bf_split_launch(morl_ctx* c, const float* params, hipStream_t s);
 static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipStream_t s, const float* params2 = nullptr,
                               float* wt2 = nullptr, bool step_entry = false) {
     // already made by this step's morl_envelope_prepare for exactly these buffers?  (one-shot)
-    const bool have = step_entry && (wt == c->wt_online && c->fresh_online == params) &&
-                      (params2 == nullptr || (wt2 == c->wt_target && c->fresh_target == params2));
-    c->fresh_online = c->fresh_target = nullptr;
-    if (have) return MORL_OK;
+    const bool have1 = step_entry && wt == c->wt_online && c->fresh_online == params;
+    const bool have2 = params2 == nullptr || (step_entry && wt2 == c->wt_target && c->fresh_target == params2);
+    c->fresh_online = c->fresh_target = c->fresh_bf = nullptr;
+    if (have1 && have2) return MORL_OK;
     const ShadowArgs t = shadow_args(c);
-    hipLaunchKernelGGL(shadow_weights_kernel, dim3(t.tiles, params2 ? 2 : 1), dim3(256), 0, s, params, wt, params2, wt2, t);
+    if (have1)          // (the prologue made the split-bf16 streams instead of the online copy, or only the target copy is stale)
+        hipLaunchKernelGGL(shadow_weights_kernel, dim3(t.tiles, 1), dim3(256), 0, s, params2, wt2, (const float*)nullptr, (float*)nullptr, t);
+    else
+        hipLaunchKernelGGL(shadow_weights_kernel, dim3(t.tiles, (params2 && !have2) ? 2 : 1), dim3(256), 0, s, params, wt, params2, wt2, t);
     LAUNCH_CHECK("shadow_weights");
     return MORL_OK;
+}
+
+// what a gradient step on the bf16 matrix cores streams: the online network's split weights + the K-major copy of the TARGET network
+// (its rows run on the fp32 few-row tiles, or its whole slab on the fp32 chain when the caller asks for it)
+static int refresh_bf_step(morl_ctx* c, const float* params_online, const float* params_target, hipStream_t s) {
+    const bool have_bf = c->fresh_bf == params_online, have_t = c->fresh_target == params_target;
+    c->fresh_online = c->fresh_target = c->fresh_bf = nullptr;
+    c->wt_online_src = nullptr;
+    int rc;
+    if (!have_bf && (rc = bf_split_launch(c, params_online, s))) return rc;
+    if (!have_t) {
+        const ShadowArgs t = shadow_args(c);
+        hipLaunchKernelGGL(shadow_weights_kernel, dim3(t.tiles, 1), dim3(256), 0, s, params_target, c->wt_target, (const float*)nullptr,
+                           (float*)nullptr, t);
+        LAUNCH_CHECK("shadow_weights(target)");
+    }
+    return MORL_OK;
+}
+
+// ---- split-bf16 chain (mlp_chain_bf.h) ------------------------------------------------------------------------------------------
+// does a gradient step over `rows` TD rows run its two online forward passes and its backward pass on the bf16 matrix cores?
+static bool bf_wanted(const morl_ctx* c, long long rows) {
+    return c->bf_ok && c->bf_mode != 0 && c->use_fused && c->fused_tm == 0 && rows >= c->bf_min_rows;
+}
+
+// the split jobs of the online network: forward stream (blocks [0, bf_fwd_blocks)) then backward stream
+static BfSplitArgs bf_split_args(const morl_ctx* c, const float* params) {
+    BfSplitArgs a{};
+    const morl_net_desc& n = c->net;
+    const int L = c->L;
+    int j = 0, units = 0, block = 0;
+    auto add = [&](const float* base, long long sn, long long sk, int N, int K, int ksteps, int ntiles, int natural) {
+        BfSplitJob& jb = a.job[j];
+        jb.base = base; jb.sn = sn; jb.sk = sk; jb.N = N; jb.K = K; jb.ksteps = ksteps; jb.ntiles = ntiles; jb.natural = natural;
+        jb.block0 = block;
+        a.unit_start[j++] = units;
+        units += ksteps * ntiles;
+        block += ksteps * ntiles * 3;
+    };
+    // forward: M[n][k] = W_l[n][k] (nn.Linear.weight [out][in])
+    for (int l = 0; l < L; ++l) {
+        const bool head = (l == L - 1);
+        add(params + c->offW[l], n.dims[l], 1, n.dims[l + 1], n.dims[l], l == 0 ? c->bf_k0_steps : 8, head ? c->bf_head_tiles : 16, l == 0 ? 1 : 0);
+    }
+    // backward: step k <-> layer l = L - 1 - k: g_{l-1} = g_l W_l, i.e. M[n = i][k = o] = W_l[o][i]
+    for (int l = L - 1; l >= 1; --l)
+        add(params + c->offW[l], 1, n.dims[l], n.dims[l], n.dims[l + 1], l == L - 1 ? 1 : 8, 16, l == L - 1 ? 1 : 0);
+    a.unit_start[j] = units;
+    a.n = j;
+    return a;
+}
+
+static int bf_split_launch(morl_ctx* c, const float* params, hipStream_t s) {
+    const BfSplitArgs a = bf_split_args(c, params);
+    const int blocks = (a.unit_start[a.n] * 64 + 255) / 256;
+    hipLaunchKernelGGL(bf_split_kernel, dim3(blocks), dim3(256), 0, s, a, c->bf_stream);
+    LAUNCH_CHECK("bf_split");
+    return MORL_OK;
+}
+
+// forward chain over rows assembled from (obs, weights), row b * W + i; save => hidden activations to ctx->h[], sign bits, x0
+static BfChain bf_forward_chain(morl_ctx* c, const float* params, const float* obs, const float* weights, int B, int W, int rows,
+                                bool save, float* q_out, int ldq_out) {
+    BfChain a{};
+    const int L = c->L;
+    a.stream = c->bf_stream;
+    a.n_steps = L; a.k0_steps = c->bf_k0_steps; a.head = 1;
+    a.n_stages = c->bf_fwd_blocks / BF_STAGE_BLOCKS;
+    a.rows = rows;
+    a.in_mode = 0; a.obs = obs; a.weights = weights;
+    a.B = B; a.W = W; a.D = c->net.obs_dim; a.R = c->net.reward_dim; a.row_order = 0;
+    for (int l = 0; l < L; ++l) {
+        BfStep& st = a.step[l];
+        const bool last = (l == L - 1);
+        st.bias = params + c->offB[l];
+        st.N = c->net.dims[l + 1]; st.K = c->net.dims[l];
+        st.relu = last ? 0 : 1;
+        if (last) { st.out = q_out; st.ldout = ldq_out; }
+        else if (save) { st.out = c->h[l + 1]; st.ldout = c->net.dims[l + 1]; st.bits_out = c->relu_bits[l + 1]; }
+    }
+    if (save) { a.x0_out = c->x0m; a.ldx0 = c->ld0; }
+    return a;
+}
+
+// backward chain: g[L-1] = dq -> g[l-1] = (g[l] W_l) * (h[l] > 0), every g[l-1] written to ctx->g[] for the weight gradients
+static BfChain bf_backward_chain(morl_ctx* c, int rows) {
+    BfChain a{};
+    const int L = c->L;
+    a.stream = c->bf_stream + (size_t)c->bf_fwd_blocks * BF_BLOCK;
+    a.n_steps = L - 1; a.k0_steps = 1; a.head = 0;
+    a.n_stages = c->bf_bwd_blocks / BF_STAGE_BLOCKS;
+    a.rows = rows;
+    a.in_mode = 1; a.src = c->dq; a.ldsrc = c->ldq; a.K0 = c->net.dims[L];
+    for (int l = L - 1, k = 0; l >= 1; --l, ++k) {
+        BfStep& st = a.step[k];
+        st.N = c->net.dims[l]; st.K = c->net.dims[l + 1];
+        st.relu = 0;
+        st.bits_in = c->relu_bits[l];
+        st.out = c->g[l - 1]; st.ldout = c->net.dims[l];
+    }
+    return a;
+}
+
+static int timing_open(morl_ctx* c, int kind, hipStream_t s, int* slot);
+static int timing_close(morl_ctx* c, int slot, hipStream_t s);
+static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStream_t s) {
+    BfMulti m{};
+    m.n = n;
+    int tiles = 0;
+    for (int q = 0; q < n; ++q) {
+        m.c[q] = chains[q];
+        m.tile_start[q] = tiles;
+        tiles += (chains[q].rows + BF_TM - 1) / BF_TM;
+    }
+    for (int q = n; q <= BF_MAX_MULTI; ++q) m.tile_start[q] = tiles;
+    int slot = -1, rc;
+    if ((rc = timing_open(c, kind, s, &slot))) return rc;
+    hipLaunchKernelGGL(mlp_chain_bf_kernel, dim3(tiles), dim3(256), 0, s, m);
+    LAUNCH_CHECK("mlp_chain_bf");
+    return timing_close(c, slot, s);
 }
 
 // envelope_td_kernel<p.phase>
@@ -526,14 +650,6 @@ static int launch_envelope_td(const EnvelopeTdArgs& p, int blocks, int waves, hi
     else hipLaunchKernelGGL(envelope_td_kernel<0>, dim3(blocks), dim3(64 * waves), 0, s, p);
     LAUNCH_CHECK(what);
     return MORL_OK;
-}
-
-// arg-max form of envelope_td_kernel: 0 = lanes <-> TD rows, candidates as LDS broadcasts (default); 1 = lanes <-> candidates, wave
-// butterfly over (value, index).  MORL_TD_SHFL=1 selects the shuffle form (A/B measurements); both give
-// bit-identical indices (tests/test_kernels_parity.py runs the tie tests under both).
-static int td_argmax_mode() {
-    static const int mode = [] { const char* e = getenv("MORL_TD_SHFL"); return e ? (atoi(e) != 0 ? 1 : 0) : 0; }();
-    return mode;
 }
 
 // ---- optional event brackets around the GEMM launches of a step (bench.py's roofline figures) --------------------------------
@@ -595,19 +711,18 @@ static int chain2_fill(morl_ctx* c, Chain2Multi& m, const ChainArgs* chains, int
     return S;
 }
 
-static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s, const ChainTd* td = nullptr) {
+static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s) {
     Chain2Multi m{};
-    if (td) m.td = *td;
     const int S = chain2_fill(c, m, chains, n, 0);
     // (backward chain: the one whose input is the TD kernel's dLoss/dQ)
     const int kind = c->timing_kind_override >= 0 ? c->timing_kind_override
-                     : (chains[0].in_mode == 2 || (chains[0].in_mode == 1 && chains[0].src == c->dq)) ? MORL_TIMED_BACKWARD
+                     : (chains[0].in_mode == 1 && chains[0].src == c->dq) ? MORL_TIMED_BACKWARD
                                                                                                        : MORL_TIMED_FORWARD;
     int slot = -1, rc_t;
     if ((rc_t = timing_open(c, kind, s, &slot))) return rc_t;
     static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
     static const bool few_rows = [] { const char* e = getenv("MORL_CHAIN4"); return e ? atoi(e) != 0 : true; }();
-    if (small_rows && few_rows && n == 1 && !td && chains[0].rows <= C4_MAX_ROWS && chain4_ok(chains[0])) {
+    if (small_rows && few_rows && n == 1 && chains[0].rows <= C4_MAX_ROWS && chain4_ok(chains[0])) {
         // one no-grad forward chain over at most a tile per CU (acting, evaluation, greedy actions): 8-row tiles (mlp_chain4.h),
         // bit-identical rows to the 16-row tiles at two thirds of their latency
         hipLaunchKernelGGL(mlp_chain4_kernel, dim3((chains[0].rows + C4_TM - 1) / C4_TM), dim3(CH_THREADS), 0, s, chains[0]);
@@ -616,14 +731,13 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
         Chain16Multi m16{};
         const int tiles = chain16_fill(m16, chains, n);
         hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
-    } else if (td) hipLaunchKernelGGL(mlp_chain2_td_kernel, dim3(S), dim3(CH_THREADS), 0, s, m);
-    else if (c->chain_sched) hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
+    } else if (c->chain_sched) hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
     else hipLaunchKernelGGL(mlp_chain2_kernel<0>, dim3(S), dim3(CH_THREADS), 0, s, m);
     LAUNCH_CHECK("mlp_chain2");
     return timing_close(c, slot, s);
 }
 
-static int launch_chain(morl_ctx* c, const ChainArgs& a, hipStream_t s, const ChainTd* td = nullptr) { return chain2_launch(c, &a, 1, s, td); }
+static int launch_chain(morl_ctx* c, const ChainArgs& a, hipStream_t s) { return chain2_launch(c, &a, 1, s); }
 
 // forward chain over rows assembled on the fly from (obs, weights); save => hidden activations to ctx->h[]
 static ChainArgs make_forward_chain(morl_ctx* c, const float* params, const float* wt, const float* obs,
@@ -674,15 +788,14 @@ static int chain_forward_x3(morl_ctx* c, const ChainArgs& a0, const ChainArgs& a
 static int chain_forward_multi(morl_ctx* c, const ChainArgs* chains, int n, hipStream_t s) { return chain2_launch(c, chains, n, s); }
 
 // backward chain: g[L-1] = dq  ->  g[l-1] = (g[l] @ W_l) * (h[l] > 0), every g[l-1] written to ctx->g[]
-// `td`: the TD stage runs inside this launch (in_mode 2, chain_td.h) instead of envelope_td_kernel in front of it
-static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_t s, const ChainTd* td = nullptr) {
+static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_t s) {
     const int L = c->L;
     if (L < 2) return MORL_OK;
     int rc_chain;
     ChainArgs a{};
     a.n_steps = L - 1;
     a.rows = rows;
-    a.in_mode = td ? 2 : 1;
+    a.in_mode = 1;
     a.fast = c->k4 ? 1 : 0;
     a.src = c->dq; a.ldsrc = c->ldq; a.K0 = c->net.dims[L];
     for (int l = L - 1, k = 0; l >= 1; --l, ++k) {
@@ -700,7 +813,7 @@ static int chain_backward(morl_ctx* c, const float* params, int rows, hipStream_
         st.out = c->g[l - 1];
         st.ldout = c->net.dims[l];
     }
-    if ((rc_chain = launch_chain(c, a, s, td))) return rc_chain;
+    if ((rc_chain = launch_chain(c, a, s))) return rc_chain;
     return MORL_OK;
 }
 
@@ -721,11 +834,8 @@ extern "C" int morl_ctx_set_fused(morl_ctx* c, int enable) {
 
 extern "C" int morl_ctx_set_dw_mode(morl_ctx* c, int mode) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
-    // low decimal digit: dW engine (0, 1, 2); tens digit: row tile of the three-pass forward launch (0: 64, 1: 32)
-    const int dw = mode % 10, mt = mode / 10;
-    if (dw < 0 || dw > 3 || mt < 0 || mt > 1) return fail(MORL_ERR_ARG, "bad tuning mode %d", mode);
-    c->dw_mode = dw;
-    (void)mt;
+    if (mode != 2 && mode != 3) return fail(MORL_ERR_ARG, "weight-gradient engine %d: 3 (dw_tiles.h, default) or 2 (generic LDS tiles)", mode);
+    c->dw_mode = mode;
     return MORL_OK;
 }
 
@@ -881,12 +991,35 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
         return MORL_OK;
     }
     const ShadowArgs sh = shadow_args(c);
+    // what the step that follows will stream: on the bf16 matrix cores (a step of B x max_weights rows qualifies) the online
+    // network's split weights + the target network's K-major copy; on the fp32 chains the K-major copies of both.  A guess about
+    // the step's weight count that turns out wrong costs that step a launch of its own, nothing else (refresh_*).
+    if (bf_wanted(c, (long long)B * c->max_weights)) {
+        const BfSplitArgs bf = bf_split_args(c, params_online);
+        const int bf_blocks = (bf.unit_start[bf.n] * 64 + 255) / 256;
+        hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks + sh.tiles + bf_blocks), dim3(256), 0, (hipStream_t)stream, a, blocks,
+                           params_target, c->wt_target, (const float*)nullptr, (float*)nullptr, sh, 1, bf, c->bf_stream);
+        LAUNCH_CHECK("step_prologue");
+        c->fresh_online = nullptr;
+        c->fresh_target = params_target;
+        c->fresh_bf = params_online;
+        return MORL_OK;
+    }
     hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks + 2 * sh.tiles), dim3(256), 0, (hipStream_t)stream, a, blocks, params_online,
-                       c->wt_online, params_target, c->wt_target, sh);
+                       c->wt_online, params_target, c->wt_target, sh, 2, BfSplitArgs{}, (unsigned char*)nullptr);
     LAUNCH_CHECK("step_prologue");
     c->fresh_online = params_online;
     c->fresh_target = params_target;
+    c->fresh_bf = nullptr;
     return MORL_OK;
+}
+
+extern "C" int morl_ctx_set_exact_f32(morl_ctx* c, int enable) {
+    if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
+    const int was = c->bf_mode == 0 ? 1 : 0;
+    c->bf_mode = enable ? 0 : 1;
+    c->fresh_online = c->fresh_target = c->fresh_bf = nullptr;
+    return was;
 }
 
 extern "C" int morl_ctx_set_lazy_targets(morl_ctx* c, int enable) {
@@ -909,7 +1042,7 @@ extern "C" int morl_ctx_lazy_target_rows(morl_ctx* c, int* rows, void* stream) {
 
 extern "C" int morl_ctx_invalidate_shadows(morl_ctx* c) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
-    c->fresh_online = c->fresh_target = nullptr;
+    c->fresh_online = c->fresh_target = c->fresh_bf = nullptr;
     c->wt_online_src = nullptr;
     return MORL_OK;
 }
@@ -986,7 +1119,6 @@ extern "C" int morl_envelope_reduce(const float* qo, const float* qt, const floa
     if ((long long)W * A * R > ENV_MAX_SLAB || W * R > ENV_MAX_WR)
         return fail(MORL_ERR_ARG, "W*A*R=%lld exceeds the LDS slab (%d floats)", (long long)W * A * R, ENV_MAX_SLAB);
     EnvelopeTdArgs p{};
-    p.argmax_mode = td_argmax_mode();
     p.qo = qo; p.qt = qt; p.weights = weights;
     p.target = target; p.pref = pref; p.ac = ac;
     p.B = B; p.W = W; p.A = A; p.R = R; p.diag_only = diag_only;
@@ -1000,7 +1132,6 @@ extern "C" int morl_envelope_reduce_rows(const float* qo, const float* qt, const
     if ((long long)W * A * R > ENV_MAX_SLAB || W * R > ENV_MAX_WR)
         return fail(MORL_ERR_ARG, "W*A*R=%lld exceeds the LDS slab (%d floats)", (long long)W * A * R, ENV_MAX_SLAB);
     EnvelopeTdArgs p{};
-    p.argmax_mode = td_argmax_mode();
     p.qo = qo; p.qt = qt; p.row_weights = row_weights;
     p.target = target; p.pref = pref; p.ac = ac;
     p.B = n_rows; p.W = W; p.A = A; p.R = R;
@@ -1024,7 +1155,6 @@ extern "C" int morl_envelope_greedy_actions(morl_ctx* c, const float* params, co
         if ((rc = net_forward(c, params, c->x0n, n, false, c->qo, A * R, s))) return rc;
     }
     EnvelopeTdArgs p{};
-    p.argmax_mode = td_argmax_mode();
     p.qo = c->qo; p.qt = c->qo; p.row_weights = w;
     p.target = nullptr; p.pref = nullptr; p.ac = actions_out;
     p.B = n; p.W = 1; p.A = A; p.R = R;
@@ -1061,43 +1191,20 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         if (c->use_fused) {
             if ((rc = chain_forward(c, params_online, c->wt_online, obs, weights_i, B, WI, main_ro, rows, true, c->qm, c->ldq, s))) return rc;
             c->bits_valid = true;   // (the layer-fused forward always emits the sign bits)
+            c->bits_bf = false;
         } else {
             if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
         }
     }
-    // envelope arg-max + TD target + dLoss/dQ.  Large steps on the layer-fused engine run it INSIDE the backward chain's launch
-    // (chain_td.h: every tile computes the dLoss/dQ rows it is about to propagate); otherwise envelope_td_kernel runs in front
-    // of the backward pass: one lane per TD row of a transition, 64 rows per workgroup pass
-    const float lam_td = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
-    const bool td_in_chain = !c->lz_now && c->use_fused && c->td_fused && L >= 2 && !chain_rows_take_16(rows) &&
-                             ctd_slab_ok((long long)W * A * R, WI, C2_TM * C2_LDK);
+    // envelope arg-max + TD target + dLoss/dQ: envelope_td_kernel in front of the backward pass, one lane per TD row of a
+    // transition, 64 rows per workgroup pass.  (The same stage INSIDE the backward chain's launch was built and measured in round 3:
+    // break-even; removed in round 4.)
     int td_groups = std::max(1, std::min(4, (WI + 63) / 64));
     int n_loss = B * td_groups;
-    ChainTd ctd{};
-    if (td_in_chain) {
-        ctd.qo = qo; ctd.qt = qt; ctd.weights = weights_i; ctd.q_main = c->qm;
-        ctd.actions = actions; ctd.rewards = rewards; ctd.dones = dones;
-        ctd.dq = c->dq; ctd.loss_part = c->loss_part;
-        ctd.priority = (i_offset == 0) ? out->priority : nullptr;
-        ctd.priority_clear = (i_offset != 0) ? out->priority : nullptr;
-        ctd.target = out->target; ctd.pref = out->pref; ctd.ac = out->ac;
-        ctd.B = B; ctd.W = W; ctd.A = A; ctd.R = R; ctd.ldq = c->ldq;
-        ctd.WI = WI; ctd.i_offset = i_offset;
-        ctd.diag_only = cfg->envelope ? 0 : 1;
-        ctd.gamma = cfg->gamma;
-        ctd.c_mse = (float)((1.0 - (double)lam_td) * 2.0 / ((double)rows_total * R));
-        ctd.c_aux = (float)((double)lam_td * 2.0 / (double)rows_total);
-        if (cfg->slab_parts > 1) {
-            ctd.part_floats = (W / cfg->slab_parts) * A * R;
-            ctd.part_stride = 2ll * B * ctd.part_floats;
-        }
-        n_loss = (rows + 15) / 16;
-    } else
     {
         const bool lazy = c->lz_now;
         c->lz_now = false;
         EnvelopeTdArgs p{};
-    p.argmax_mode = td_argmax_mode();
         p.qo = qo; p.qt = qt; p.weights = weights_i; p.q_main = c->qm;
         p.actions = actions; p.rewards = rewards; p.dones = dones;
         p.target = out->target; p.pref = out->pref; p.ac = out->ac;
@@ -1159,8 +1266,12 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         if ((rc = launch_envelope_td(p, B * td_groups, td_waves, s, "envelope_td"))) return rc;
     }
     // backward through the hidden layers: g[l-1] = (g[l] @ W_l) * (h[l] > 0)
-    if (c->use_fused) {
-        if ((rc = chain_backward(c, params_online, rows, s, td_in_chain ? &ctd : nullptr))) return rc;
+    if (c->use_fused && c->bits_bf && L >= 2) {
+        // (the training forward ran on the bf16 matrix cores and left its sign bits in that kernel's lane layout)
+        const BfChain bwd = bf_backward_chain(c, rows);
+        if ((rc = bf_launch(c, &bwd, 1, MORL_TIMED_BACKWARD, s))) return rc;
+    } else if (c->use_fused) {
+        if ((rc = chain_backward(c, params_online, rows, s))) return rc;
     } else
         for (int l = L - 1; l >= 1; --l) {
             GemmProblem g{};
@@ -1252,38 +1363,9 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         hipLaunchKernelGGL(dw_tiles_kernel, dim3(jobs + extra), dim3(DW2_THREADS), 0, s, a);
         LAUNCH_CHECK("dw_tiles");
         if ((rc = timing_close(c, tslot, s))) return rc;
-    } else if (c->dw_wave_ok && c->use_fused && c->dw_mode == 0) {
-        // wave-level tiles (dw_wave.h): aim at one wave per SIMD over the whole chip
-        splits = std::max(1, std::min(c->max_splits, (4 * c->num_cus + c->dw_wave_tiles / 2) / c->dw_wave_tiles));
-        int kps = round_up((rows + splits - 1) / splits, DW_CHUNK);
-        splits = (rows + kps - 1) / kps;
-        DwArgs a{};
-        a.n = L;
-        a.rows = rows;
-        a.k_per_split = kps;
-        a.slab_stride = c->P;
-        int t = 0;
-        for (int l = 0; l < L; ++l) {
-            DwProblem& q = a.p[l];
-            q.G = c->g[l];
-            q.ldg = (l == L - 1) ? c->ldq : n.dims[l + 1];
-            q.H = (l == 0) ? c->x0m : c->h[l];
-            q.ldh = (l == 0) ? c->ld0 : n.dims[l];
-            q.C = c->slabs + c->offW[l];
-            q.ldc = n.dims[l];
-            q.bias = c->slabs + c->offB[l];
-            q.M = n.dims[l + 1]; q.N = n.dims[l];
-            q.tiles_n = (q.N + DW_TILE - 1) / DW_TILE;
-            a.tile_start[l] = t;
-            t += ((q.M + DW_TILE - 1) / DW_TILE) * q.tiles_n;
-        }
-        a.tile_start[L] = t;
-        hipLaunchKernelGGL(dw_wave_kernel, dim3(t, splits), dim3(64), 0, s, a);
-        LAUNCH_CHECK("dw_wave");
     } else {
-    const bool db = (c->dw_mode == 1 || c->dw_mode == 3);
-    // double-buffered tiles run two workgroups per CU: twice as many, half as long row slices
-    splits = std::max(1, std::min(c->max_splits, ((db ? 2 : 1) * c->num_cus + c->dw_tiles - 1) / c->dw_tiles));
+    // the generic engine (operand rows that are not 16-byte aligned, or morl_ctx_set_dw_mode(ctx, 2)): one workgroup per CU
+    splits = std::max(1, std::min(c->max_splits, (c->num_cus + c->dw_tiles - 1) / c->dw_tiles));
     if (const char* e = getenv("MORL_DW_SPLITS")) splits = std::max(1, std::min(c->max_splits, atoi(e)));   // (tuning)
     int kps = round_up((rows + splits - 1) / splits, GEMM_BK);
     splits = (rows + kps - 1) / kps;
@@ -1312,8 +1394,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             t += g.tiles_m * g.tiles_n;
         }
         grp.tile_start[L] = t;
-        if (db) hipLaunchKernelGGL(gemm_grouped_tn_db_kernel, dim3(t * splits), dim3(GEMM_THREADS), 0, s, grp);
-        else hipLaunchKernelGGL(gemm_grouped_tn_kernel, dim3(t * splits), dim3(GEMM_THREADS), 0, s, grp);
+        hipLaunchKernelGGL(gemm_grouped_tn_kernel, dim3(t * splits), dim3(GEMM_THREADS), 0, s, grp);
         LAUNCH_CHECK("gemm_grouped_dw");
     }
     }
@@ -1381,7 +1462,7 @@ static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_a
                           const morl_update_cfg* cfg, float* grad_norm_out, bool have_partials, hipStream_t s,
                           const SumTreeUpdate* per = nullptr) {
     c->wt_online_src = nullptr;          // the parameters change: any transposed copy is stale from here on
-    c->fresh_online = c->fresh_target = nullptr;
+    c->fresh_online = c->fresh_target = c->fresh_bf = nullptr;
     const unsigned int* skip_flag = c->skip_flag;    // one-shot request of a sharded step (set right before this call)
     c->skip_flag = nullptr;
     const int nblk = std::min(OPT_MAX_BLOCKS, stream_grid(c->P, OPT_THREADS));
@@ -1439,8 +1520,26 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
 
     // stage A: no-grad next-state slabs Qo, Qt [B][W][A][R] (B*W distinct rows instead of the reference's W^2*B)
     bool main_done = false;
-    if (c->use_fused) {
+    const bool use_bf = bf_wanted(c, rows);
+    static const long long lazy_min_rows = [] { const char* e = getenv("MORL_LAZY_MIN_ROWS"); return e ? atoll(e) : 8192ll; }();
+    if (use_bf) {
+        // The two ONLINE passes (next-state slab, training pass) on the bf16 matrix cores as six split-bf16 products each
+        // (mlp_chain_bf.h: fp32-class accuracy at 6/16 of the f32-input MFMA's time), one launch.  The TARGET network stays on the
+        // exact fp32 tiles: its selected rows (lazy evaluation, the default) or, when the caller asks for the whole slab, its pass.
+        if ((rc = refresh_bf_step(c, params_online, params_target, s))) return rc;
+        c->lz_now = c->lazy_targets && cfg->envelope && W >= 2 && !out->q_target_next && (c->lazy_targets == 2 || rows >= lazy_min_rows);
+        c->lz_last = c->lz_now;
+        const BfChain two[2] = {bf_forward_chain(c, params_online, next_obs, weights, B, W, rows, false, c->qo, AR),
+                                bf_forward_chain(c, params_online, obs, weights, B, W, rows, true, c->qm, c->ldq)};
+        if ((rc = bf_launch(c, two, 2, MORL_TIMED_FORWARD2, s))) { c->lz_now = false; return rc; }
+        if (c->lz_now) { c->lz_params_target = params_target; c->lz_next_obs = next_obs; }
+        else if ((rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
+        main_done = true;
+        c->bits_valid = true;
+        c->bits_bf = true;
+    } else if (c->use_fused) {
         // layer-fused passes: activations stay in LDS; rows assembled from (obs, weights) inside the kernel
+        c->bits_bf = false;
         if ((rc = refresh_transposed(c, params_online, c->wt_online, s, params_target, c->wt_target, true))) return rc;
         if (c->fused_tm == 0) {
             // one launch for the three forward passes: 3 x rows/64 workgroups -> 2 resident per CU
@@ -1454,7 +1553,6 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
             // (update_core; 1 546 of 16 384 rows at the flagship shape).  Not when the caller asks for the whole target slab.
             // Small steps are latency-bound: one more chain launch and a second TD launch cost them more than the target pass
             // they drop (2 048 rows: 0.181 ms lazily, 0.149 eagerly; 8 192 rows: 0.255 against 0.262; MORL_LAZY_MIN_ROWS overrides)
-            static const long long lazy_min_rows = [] { const char* e = getenv("MORL_LAZY_MIN_ROWS"); return e ? atoll(e) : 8192ll; }();
             c->lz_now = c->lazy_targets && cfg->envelope && W >= 2 && !out->q_target_next &&
                         (c->lazy_targets == 2 || rows >= lazy_min_rows);
             c->lz_last = c->lz_now;
@@ -1586,6 +1684,7 @@ extern "C" int morl_envelope_main_forward(morl_ctx* c, const float* params_onlin
         one.ldx0 = c->ld0;
         if ((rc = chain_forward_multi(c, &one, 1, s))) return rc;
         c->bits_valid = true;
+        c->bits_bf = false;
     } else {
         if ((rc = build_input(obs, weights_local, c->x0m, B, W_local, c->net.obs_dim, c->net.reward_dim, c->ld0, 1, s))) return rc;
         c->bits_valid = false;
@@ -1678,13 +1777,8 @@ extern "C" int morl_envelope_step_batch_sharded(morl_ctx* c, morl_comm* comm, fl
     if (world == parts && rank != b_offset / B) return fail(MORL_ERR_ARG, "rank %d does not own the transitions from %d on", rank, b_offset);
     hipStream_t s = (hipStream_t)stream;
     float* prio = grads_x + n_params + 1;
-    // the other ranks' transitions: zeros -- written by the step's TD launch (one memset launch less); the TD stage inside the
-    // backward chain (MORL_TD_FUSED=1) has no such hook, so that path keeps the fill
-    if (parts > 1) {
-        const bool td_kernel = !(c->use_fused && c->td_fused && !chain_rows_take_16((long long)B * W));
-        if (td_kernel) { c->td_zero_ptr = prio; c->td_zero_n = B_total; c->td_keep_lo = b_offset; c->td_keep_hi = b_offset + B; }
-        else HIP_TRY(hipMemsetAsync(prio, 0, (size_t)B_total * sizeof(float), s));
-    }
+    // the other ranks' transitions: zeros -- written by the step's TD launch (one memset launch less)
+    if (parts > 1) { c->td_zero_ptr = prio; c->td_zero_n = B_total; c->td_keep_lo = b_offset; c->td_keep_hi = b_offset + B; }
     morl_update_cfg local = *cfg;
     local.apply_step = 0;
     local.per_tree = nullptr;                                  // priorities are complete only after the all-reduce

@@ -34,8 +34,8 @@ class QNetContext:
         self.fused = self.engine > 0
 
     def set_dw_mode(self, mode: int) -> None:
-        """Weight-gradient engine: 0 wave-level tiles, 1 double-buffered LDS tiles, 2 single-buffered, 3 balanced per-problem
-        wave layouts with a three-stage operand pipeline (``dw_tiles.h``; default)."""
+        """Weight-gradient engine: 3 balanced per-problem wave layouts with a three-stage operand pipeline (``dw_tiles.h``; default),
+        2 the per-layer engine's LDS tiles as one grouped launch (the fall-back for operand rows that are not 16-byte aligned)."""
         self.lib.check(self.lib.lib.morl_ctx_set_dw_mode(self.handle, int(mode)))
 
     def set_timing(self, every: int) -> None:
@@ -47,6 +47,12 @@ class QNetContext:
         """Lazy target evaluation of ``envelope_update`` on this context (``morl_ctx_set_lazy_targets``): 0 / False never, 1 / True
         from 8 192 TD rows on (the default), 2 at every size; returns the old setting."""
         return int(self.lib.lib.morl_ctx_set_lazy_targets(self.handle, int(enable)))
+
+    def set_exact_f32(self, enable: bool) -> bool:
+        """True: every GEMM of ``envelope_update`` on the f32-input MFMA (the arithmetic of rounds 1-3); False (default): the two
+        online forward passes and the dX backward pass of large steps as six split-bf16 products on the bf16 matrix cores
+        (``morl_ctx_set_exact_f32``, csrc/mlp_chain_bf.h).  Returns the old setting."""
+        return bool(self.lib.lib.morl_ctx_set_exact_f32(self.handle, int(bool(enable))))
 
     def lazy_target_rows(self, like: th.Tensor) -> int:
         """Distinct (transition, weight) pairs the last lazily evaluated step ran the target network on (synchronises)."""

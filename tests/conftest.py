@@ -17,6 +17,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.pa
 # ``q_target_next`` (``debug=True``: the ``eager`` legs of the same tests) is evaluated eagerly whatever this setting, as are DDQN
 # targets, the weight-sharded steps and everything under MORL_LAZY_TARGETS=0.
 os.environ.setdefault("MORL_LAZY_MIN_ROWS", "0")
+# Same for the split-bf16 chain (csrc/mlp_chain_bf.h: the two online forward passes and the dX backward pass of steps of >= 8 192 TD
+# rows on 256-wide networks): with the threshold at zero every fixture / agent whose network qualifies (flagship_b32w8, wide_pick,
+# both full-size cases, the shape sweep's all-256 nets) runs it, on the emulator and on the GPU; tests/test_chain_tilings.py re-runs
+# the fixtures with MORL_EXACT_F32=1 (every GEMM on the f32-input MFMA).
+os.environ.setdefault("MORL_BF_MIN_ROWS", "0")
 
 
 def pytest_configure(config):

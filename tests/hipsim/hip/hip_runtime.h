@@ -304,6 +304,42 @@ static inline hipsim_f32x4 __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, 
     return d;
 }
 
+// v_mfma_f32_16x16x32_bf16: A lane l = row l & 15, eight k of group l >> 4; B lane l = column l & 15, the same eight k;
+// D lane l: column l & 15, rows 4 (l >> 4) + r.  Products of bf16 are exact in fp32; the sum is formed in double and rounded once
+// (the hardware's internal order is not specified; results agree with it to fp32 rounding)
+namespace hipsim {
+// CollIn::f[0..3] = C, the 32 bytes from f[4] on = the lane's eight A and eight B values (bf16)
+static void fn_mfma_bf16_16x16x32(const CollIn* in, CollOut* out, int n) {
+    if (n != 64) { std::fprintf(stderr, "hipsim: MFMA needs a full wave (got %d lanes)\n", n); std::abort(); }
+    auto val = [&](int lane, int which, int e) {
+        unsigned short h;
+        std::memcpy(&h, reinterpret_cast<const char*>(&in[lane].f[4]) + 16 * which + 2 * e, 2);
+        unsigned u = (unsigned)h << 16; float x; std::memcpy(&x, &u, 4); return (double)x;
+    };
+    for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * (l >> 4) + r, col = l & 15;
+            double acc = in[l].f[r];
+            for (int g = 0; g < 4; ++g)
+                for (int e = 0; e < 8; ++e) acc += val(row + 16 * g, 0, e) * val(col + 16 * g, 1, e);
+            out[l].f[r] = (float)acc;
+        }
+}
+}  // namespace hipsim
+typedef __bf16 hipsim_bf16x8 __attribute__((ext_vector_type(8)));
+static inline hipsim_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hipsim_bf16x8 a, hipsim_bf16x8 b, hipsim_f32x4 c, int, int, int) {
+    hipsim::CollIn in{};
+    for (int r = 0; r < 4; ++r) in.f[r] = c[r];
+    std::memcpy(reinterpret_cast<char*>(&in.f[4]), &a, 16);
+    std::memcpy(reinterpret_cast<char*>(&in.f[4]) + 16, &b, 16);
+    hipsim::CollOut o = hipsim::wave_collective(in, hipsim::fn_mfma_bf16_16x16x32);
+    hipsim_f32x4 d;
+    for (int r = 0; r < 4; ++r) d[r] = o.f[r];
+    return d;
+}
+static inline void __builtin_amdgcn_s_barrier() { hipsim::block_barrier(); }
+#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
+
 // LDS-DMA: lane l copies `size` bytes from its own global address to (first lane's LDS pointer) + l*size
 namespace hipsim {
 static void fn_first_ptr(const CollIn* in, CollOut* out, int n) { for (int l = 0; l < n; ++l) out[l].u = in[0].u; }
@@ -322,6 +358,21 @@ struct hipsim_rsrc { const char* base; long long num_records; };
 typedef hipsim_rsrc __amdgpu_buffer_rsrc_t;
 static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num_records, int) {
     return hipsim_rsrc{(const char*)p, (long long)num_records};
+}
+// buffer_load ... lds: lane l copies `size` bytes from base + voffset + soffset + offset (range-checked: zeros beyond the buffer) to
+// (first lane's LDS pointer) + offset + l * size
+static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(__amdgpu_buffer_rsrc_t r, __attribute__((address_space(3))) void* dst,
+                                                            unsigned size, int voffset, int soffset, int offset, int) {
+    hipsim::CollIn in{};
+    in.u = (unsigned long long)(uintptr_t)dst;
+    char* base = (char*)(uintptr_t)hipsim::wave_collective(in, hipsim::fn_first_ptr).u;
+    const long long off = (long long)(unsigned)voffset + soffset + offset;
+    char* d = base + offset + (size_t)hipsim::cur->lane * size;
+    for (unsigned b = 0; b < size; b += 4) {
+        unsigned x = 0u;
+        if (off + b + 4 <= r.num_records) std::memcpy(&x, r.base + off + b, 4);
+        std::memcpy(d + b, &x, 4);
+    }
 }
 typedef unsigned int hipsim_v2u __attribute__((vector_size(8)));
 static inline hipsim_v2u __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {

@@ -170,7 +170,7 @@ def test_envelope_update_vs_reference_golden(be, c, lazy):
     np.testing.assert_allclose(pr, g["priority_final"], rtol=1e-4)
 
 
-@pytest.mark.parametrize("dw_mode", [0, 1, 2, 3])     # 3 (dw_tiles.h) is the default; the others are the kept alternates
+@pytest.mark.parametrize("dw_mode", [2, 3])     # 3 (dw_tiles.h) is the default, 2 the generic fall-back for unaligned operand rows
 def test_weight_gradient_engines_agree_with_oracle(be, dw_mode):
     lib, dev, _ = be
     c = [c for c in CASES if c.name == "flagship_b32w8"][0]

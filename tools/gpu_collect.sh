@@ -1,0 +1,42 @@
+#!/bin/bash
+# One parametrised GPU collection script (replaces the per-trip scripts of rounds 1-3).  Run from the repo root on the GPU box:
+#   tools/gpu_collect.sh <out-tag> <stage> [<stage> ...]
+# stages: tests-quick | tests-all | smoke | bench | bench-exact | bench-driver | bench-w32 | prof-env | prof-env-exact | prof-w32 |
+#         bench-ac | prof-ac | emu8 | pmc | fronts
+# Everything lands under gpurun_out/<out-tag>/ (merged back by gpurun); large traces are deleted, the stats CSVs kept.
+set -x
+R=$PWD
+TAG=$1; shift
+O=gpurun_out/$TAG
+mkdir -p $O
+B="--no-cpu-baseline --no-ramp-record"
+prof() {   # prof <name> <command...>: rocprofv3 kernel stats of the command (run from /tmp as the guide prescribes)
+    local name=$1; shift
+    (cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_$name -- "$@" > /dev/null 2>&1)
+    python tools/trace_phases.py $(find $O/prof_$name -name "*kernel_trace.csv" | head -1) > $O/step_timeline_$name.txt 2>&1 || true
+    find $O/prof_$name -name "*kernel_trace.csv" -delete; find $O/prof_$name -name "*agent_info.csv" -delete
+}
+for st in "$@"; do
+case $st in
+tests-quick) timeout 1500 python -m pytest tests/test_flagship_golden.py tests/test_kernels_parity.py -m gpu -q -x -p no:cacheprovider -s 2>&1 | tail -60 > $O/gpu_tests_quick.log; tail -5 $O/gpu_tests_quick.log ;;
+tests-all)   timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -80 > $O/gpu_tests.log; tail -5 $O/gpu_tests.log ;;
+smoke)       timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -3 $O/smoke.log ;;
+bench)       timeout 300 python bench.py --steps 200 --warmup 20 $B > $O/bench_200.json 2> $O/bench_200.err; cut -c1-400 $O/bench_200.json ;;
+bench-exact) MORL_EXACT_F32=1 timeout 300 python bench.py --steps 200 --warmup 20 $B > $O/bench_exact_f32_200.json 2>/dev/null; cut -c1-400 $O/bench_exact_f32_200.json ;;
+bench-driver) timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_like.json 2> $O/bench_driver_like.err; cut -c1-400 $O/bench_driver_like.json ;;
+bench-w32)   timeout 300 python bench.py --weights 32 --steps 200 --warmup 20 $B > $O/bench_w32.json 2>/dev/null; cut -c1-300 $O/bench_w32.json
+             MORL_EXACT_F32=1 timeout 300 python bench.py --weights 32 --steps 200 --warmup 20 $B > $O/bench_w32_exact_f32.json 2>/dev/null; cut -c1-300 $O/bench_w32_exact_f32.json ;;
+prof-env)    prof env python $R/bench.py --steps 80 --warmup 10 $B ;;
+prof-env-exact) MORL_EXACT_F32=1 prof env_exact_f32 python $R/bench.py --steps 80 --warmup 10 $B ;;
+prof-w32)    prof w32 python $R/bench.py --weights 32 --steps 80 --warmup 10 $B ;;
+bench-ac)    for w in capql mosac gpipd gpi ens; do timeout 300 python bench_ac.py --workload $w > $O/bench_ac_$w.json 2>/dev/null; cut -c1-200 $O/bench_ac_$w.json; done
+             timeout 300 python bench_ac.py --workload morld --pop 64 > $O/bench_ac_morld64.json 2>/dev/null ;;
+prof-ac)     for w in capql gpi; do prof $w python $R/bench_ac.py --workload $w --steps 60 --no-cpu-baseline; done ;;
+emu8)        timeout 300 python bench.py --gpus 1 --force-shard --emulate-world 8 $B > $O/bench_emulated_rank_of_8.json 2>/dev/null; cut -c1-300 $O/bench_emulated_rank_of_8.json ;;
+pmc)         (cd /tmp && export TMPDIR=/tmp && timeout 900 python $R/tools/pmc_summary.py $R/$O/pmc_summary.json > $R/$O/pmc_summary.txt 2>&1); tail -25 $O/pmc_summary.txt ;;
+fronts)      for n in 1024 16384 65536; do timeout 300 python bench_front.py --workload pareto --n $n > $O/bench_front_pareto_$n.json 2>/dev/null; done
+             for r in 2 3 4; do timeout 300 python bench_front.py --workload hv --r $r > $O/bench_front_hv_r$r.json 2>/dev/null; done ;;
+*) echo "unknown stage $st" ;;
+esac
+done
+for f in $O/prof_*/*/*kernel_stats.csv $O/prof_*/*kernel_stats.csv; do [ -f "$f" ] && { echo "== $f"; head -14 "$f" | cut -c1-160; }; done
