@@ -34,12 +34,11 @@
 namespace morl {
 
 constexpr int BF_ROWS_WAVE = 16;                 // rows a wave carries
-constexpr int BF_TM = 64;                        // rows per workgroup (4 waves)
+constexpr int BF_TM = 64;                        // rows per workgroup of the 4-wave form (the 2-wave form: 32)
 constexpr int BF_BLOCK = 1024;                   // bytes of one fragment block: 64 lanes x 8 bf16
 constexpr int BF_STAGE_BLOCKS = 24;              // blocks per ring stage (24 KB): half a k-step of a 256-wide layer
 constexpr int BF_STAGE_BYTES = BF_STAGE_BLOCKS * BF_BLOCK;
 constexpr int BF_RING = 3;                       // stages resident: one being multiplied, two in flight
-constexpr int BF_DMA_PER_WAVE = BF_STAGE_BLOCKS / 4;   // LDS-DMA instructions a wave issues per stage
 constexpr int BF_MAX_STEPS = MORL_MAX_LAYERS;
 constexpr int BF_WIDE = 256;                     // columns of every wide step
 
@@ -116,7 +115,7 @@ __device__ __forceinline__ f32x4 bf_mfma(const bf_u32x4& w, const bf_u32x4& x, f
 // ---- the weight ring ------------------------------------------------------------------------------------------------------------
 struct BfRing {
     __amdgpu_buffer_rsrc_t rsrc;   // the whole stream
-    int voff;                      // this lane's byte offset inside a stage: wave * 6 KB + lane * 16
+    int voff;                      // this lane's byte offset inside a stage: wave * (24 / NW) KB + lane * 16
     unsigned char* lds;            // ring base (workgroup)
     int t;                         // stage the workgroup multiplies next
     int buf;                       // t % 3
@@ -124,35 +123,45 @@ struct BfRing {
     int wave;
 };
 
-// LDS-DMA of this wave's share of stage `st` (clamped to the stream's last stage: the issue count per stage is static) into `buf`:
-// buffer_load_dwordx4 ... lds, 1 KB per instruction (lane l's 16 bytes land at M0 + offset + 16 l; the instruction offset counts on
-// both sides).  The MUBUF form, not global_load_lds: a pending FLAT-encoded LDS access makes hipcc's wait insertion treat every LDS
-// counter as unordered -- each fragment read was then waited for with lgkmcnt(0) instead of a counted wait.
+// LDS-DMA of this wave's share (24 / NW blocks) of stage `st` (clamped to the stream's last stage: the issue count per stage is
+// static) into `buf`: buffer_load_dwordx4 ... lds, 1 KB per instruction (lane l's 16 bytes land at M0 + offset + 16 l; the
+// instruction offset counts on both sides).  The MUBUF form, not global_load_lds: a pending FLAT-encoded LDS access makes hipcc's
+// wait insertion treat every LDS counter as unordered -- each fragment read was then waited for with lgkmcnt(0) instead of a
+// counted wait.
+template <int NW>
 __device__ __forceinline__ void bf_ring_issue(const BfRing& r, int st, int buf) {
+    constexpr int DPW = BF_STAGE_BLOCKS / NW;
+    static_assert(DPW == 6 || DPW == 12, "four or two waves per workgroup");
     const int s = st < r.n_stages ? st : r.n_stages - 1;
     const int soff = s * BF_STAGE_BYTES;
-    unsigned char* l = r.lds + buf * BF_STAGE_BYTES + r.wave * (BF_DMA_PER_WAVE * BF_BLOCK);
-    // (instruction offsets are 12-bit immediates: pieces 4 and 5 go through the scalar offset / M0)
-    __attribute__((address_space(3))) void* l0 = (__attribute__((address_space(3))) void*)l;
-    __attribute__((address_space(3))) void* l1 = (__attribute__((address_space(3))) void*)(l + 4 * BF_BLOCK);
-    static_assert(BF_DMA_PER_WAVE == 6, "six pieces per wave and stage");
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, l0, 16, r.voff, soff, 0 * BF_BLOCK, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, l0, 16, r.voff, soff, 1 * BF_BLOCK, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, l0, 16, r.voff, soff, 2 * BF_BLOCK, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, l0, 16, r.voff, soff, 3 * BF_BLOCK, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, l1, 16, r.voff, soff + 4 * BF_BLOCK, 0 * BF_BLOCK, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, l1, 16, r.voff, soff + 4 * BF_BLOCK, 1 * BF_BLOCK, 0);
+    unsigned char* l = r.lds + buf * BF_STAGE_BYTES + r.wave * (DPW * BF_BLOCK);
+    // (instruction offsets are 12-bit immediates: every group of four pieces goes through the scalar offset / M0)
+#define BF_DMA4(G, N)                                                                                                              \
+    {                                                                                                                              \
+        __attribute__((address_space(3))) void* lg = (__attribute__((address_space(3))) void*)(l + (G) * 4 * BF_BLOCK);            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, lg, 16, r.voff, soff + (G) * 4 * BF_BLOCK, 0 * BF_BLOCK, 0);              \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, lg, 16, r.voff, soff + (G) * 4 * BF_BLOCK, 1 * BF_BLOCK, 0);              \
+        if ((N) > 2) {                                                                                                             \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, lg, 16, r.voff, soff + (G) * 4 * BF_BLOCK, 2 * BF_BLOCK, 0);          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, lg, 16, r.voff, soff + (G) * 4 * BF_BLOCK, 3 * BF_BLOCK, 0);          \
+        }                                                                                                                          \
+    }
+    BF_DMA4(0, 4)
+    if (DPW == 6) BF_DMA4(1, 2)
+    else { BF_DMA4(1, 4) BF_DMA4(2, 4) }
+#undef BF_DMA4
 }
 
 // Entry of stage r.t: my share of it has landed (EXTRA = vector-memory instructions this lane issued AFTER the DMA group of the
-// stage following it -- epilogue stores -- which retire in issue order behind the group waited for); after the barrier everybody's
-// has, and everybody is done reading the stage before it, whose buffer takes the stage two ahead.  Returns the stage's LDS base.
-template <int EXTRA>
+// stage following it -- epilogue stores -- which retire in issue order behind the group waited for) and every LDS read this wave
+// has issued has returned; after the barrier everybody's share has landed and everybody is done reading the stage before it, whose
+// buffer takes the stage two ahead.  Returns the stage's LDS base.
+template <int NW, int EXTRA>
 __device__ __forceinline__ const unsigned char* bf_stage_begin(BfRing& r) {
-    BF_VMCNT_LDS0(BF_DMA_PER_WAVE + EXTRA);
+    BF_VMCNT_LDS0(BF_STAGE_BLOCKS / NW + EXTRA);
     __builtin_amdgcn_s_barrier();
     const int free_buf = r.buf == 0 ? 2 : r.buf - 1;
-    bf_ring_issue(r, r.t + 2, free_buf);
+    bf_ring_issue<NW>(r, r.t + 2, free_buf);
     const unsigned char* base = r.lds + r.buf * BF_STAGE_BYTES;
     r.buf = r.buf == 2 ? 0 : r.buf + 1;
     ++r.t;
@@ -189,40 +198,50 @@ __device__ __forceinline__ void bf_six_pair(f32x4& c0, f32x4& c1, const bf_u32x4
 }
 
 // One wide step (256 columns = 16 tiles) over KSTEPS k-steps: two stages per k-step (tiles 0-7, 8-15), per stage four tile pairs.
-// acc[T][r] += sum_k W[16T + 4q + r][k] * x[k]  for this lane's row;   EXTRA0: see bf_stage_begin, applies to the first two stages
-template <int KSTEPS, int EXTRA0>
+// acc[T][r] += sum_k W[16T + 4q + r][k] * x[k]  for this lane's row.  The pipeline runs ACROSS the stage boundaries: the entry of
+// stage i + 1 (wait, barrier, DMA issue) sits in front of the LAST pair of stage i, whose twelve MFMAs then cover the LDS latency of
+// stage i + 1's first fragments -- its own fragments are all in registers by then, so the buffer of stage i is free for the DMA the
+// entry issues.  EXTRA0: see bf_stage_begin, applies to the step's first two stages.
+template <int NW, int KSTEPS, int EXTRA0>
 __device__ __forceinline__ void bf_wide_step(f32x4 (&acc)[16], const bf_u32x4 (&x)[8][3], BfRing& ring, int lane) {
+    bf_u32x4 fa[2][3], fb[2][3];
+    BF_PIN();
+    const unsigned char* base = bf_stage_begin<NW, EXTRA0>(ring) + lane * 16;
+#pragma unroll
+    for (int pl = 2; pl >= 0; --pl) {       // (consumption order, pinned: the first MFMAs wait for the first two reads only)
+        fa[0][pl] = *reinterpret_cast<const bf_u32x4*>(base + pl * BF_BLOCK);
+        fa[1][pl] = *reinterpret_cast<const bf_u32x4*>(base + (3 + pl) * BF_BLOCK);
+        BF_PIN();
+    }
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            BF_PIN();
-            const unsigned char* base = ((s == 0) ? bf_stage_begin<EXTRA0>(ring) : bf_stage_begin<0>(ring)) + lane * 16;
-            bf_u32x4 fa[2][3], fb[2][3];
-#pragma unroll
-            for (int pl = 2; pl >= 0; --pl) {       // (consumption order, pinned: the first MFMAs wait for the first two reads only)
-                fa[0][pl] = *reinterpret_cast<const bf_u32x4*>(base + pl * BF_BLOCK);
-                fa[1][pl] = *reinterpret_cast<const bf_u32x4*>(base + (3 + pl) * BF_BLOCK);
-                BF_PIN();
-            }
             const int T = 8 * hf;
+            const bool last = (s == KSTEPS - 1) && (hf == 1);
             bf_six_pair<true>(acc[T + 0], acc[T + 1], fa[0], fa[1], x[s], fb[0], fb[1], base + 6 * BF_BLOCK);
             bf_six_pair<true>(acc[T + 2], acc[T + 3], fb[0], fb[1], x[s], fa[0], fa[1], base + 12 * BF_BLOCK);
             bf_six_pair<true>(acc[T + 4], acc[T + 5], fa[0], fa[1], x[s], fb[0], fb[1], base + 18 * BF_BLOCK);
-            bf_six_pair<false>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
+            if (!last) {
+                base = ((s == 0 && hf == 0) ? bf_stage_begin<NW, EXTRA0>(ring) : bf_stage_begin<NW, 0>(ring)) + lane * 16;
+                BF_PIN();
+                bf_six_pair<true>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
+            } else {
+                bf_six_pair<false>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
+            }
         }
     }
 }
 
 // The narrow last step (N <= 32: NT tiles) over 8 k-steps: 24 / (3 NT) k-steps per stage.
-template <int NT, int EXTRA0>
+template <int NW, int NT, int EXTRA0>
 __device__ __forceinline__ void bf_head_step(f32x4 (&acc)[2], const bf_u32x4 (&x)[8][3], BfRing& ring, int lane) {
     constexpr int KS_PER_STAGE = BF_STAGE_BLOCKS / (3 * NT);
     constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
     for (int s0 = 0; s0 < 8; s0 += KS_PER_STAGE) {
         BF_PIN();
-        const unsigned char* base = bf_stage_begin<EXTRA0>(ring) + lane * 16;       // (one or two stages: both behind the epilogue's stores)
+        const unsigned char* base = bf_stage_begin<NW, EXTRA0>(ring) + lane * 16;       // (one or two stages: both behind the epilogue's stores)
         bf_u32x4 f[KS_PER_STAGE][NT][3];
 #pragma unroll
         for (int ks = 0; ks < KS_PER_STAGE; ++ks)
@@ -286,25 +305,25 @@ __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x
 // ---- one 64-row tile through a whole chain ----------------------------------------------------------------------------------------
 // K0S: k-steps of the first step (1 or 2); SAVE: the chain writes per-step outputs / sign bits (training forward, backward) -- a
 // compile-time switch because the counted waits depend on the stores issued.
-template <int K0S, bool SAVE>
+template <int NW, int K0S, bool SAVE>
 __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsigned char* ring_lds, float* bias_lds) {
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int row = row0 + 16 * wave + m;
     const bool row_ok = row < p.rows;
-    const size_t bits_idx = (size_t)((row0 >> 4) + wave) * 64 + lane;
+    const size_t bits_idx = (size_t)((row0 >> 4) + wave) * 64 + lane;        // (the same word whichever tile size carried the row)
 
     BfRing ring;
     ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.stream, 0, p.n_stages * BF_STAGE_BYTES, 0x00020000);
-    ring.voff = wave * (BF_DMA_PER_WAVE * BF_BLOCK) + lane * 16;
+    ring.voff = wave * ((BF_STAGE_BLOCKS / NW) * BF_BLOCK) + lane * 16;
     ring.lds = ring_lds;
     ring.t = 0; ring.buf = 0; ring.n_stages = p.n_stages; ring.wave = wave;
     // the stream starts before the input rows are assembled
-    bf_ring_issue(ring, 0, 0);
-    bf_ring_issue(ring, 1, 1);
+    bf_ring_issue<NW>(ring, 0, 0);
+    bf_ring_issue<NW>(ring, 1, 1);
     // biases -> LDS, [step][256] (zeros beyond a step's columns and for steps without bias); visible after the first stage's barrier
-    for (int e = tid; e < p.n_steps * BF_WIDE; e += 256) {
+    for (int e = tid; e < p.n_steps * BF_WIDE; e += 64 * NW) {
         const int s = e >> 8, n = e & 255;
         const BfStep& st = p.step[s];
         bias_lds[e] = (st.bias != nullptr && n < st.N) ? st.bias[n] : 0.f;
@@ -357,12 +376,12 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     const int n_wide = p.n_steps - (p.head ? 1 : 0);
     // ---- first step ---------------------------------------------------------------------------------------------------------------
     bf_acc_init<16>(acc, bias_lds, q);
-    bf_wide_step<K0S, 0>(acc, x, ring, lane);
+    bf_wide_step<NW, K0S, 0>(acc, x, ring, lane);
     bf_wide_epilogue<SAVE>(acc, x, p.step[0], row, row_ok, bits_idx, q);
     // ---- the 256 x 256 steps --------------------------------------------------------------------------------------------------------
     for (int s = 1; s < n_wide; ++s) {
         bf_acc_init<16>(acc, bias_lds + s * BF_WIDE, q);
-        bf_wide_step<8, SAVE ? BF_SAVE_VMEM : 0>(acc, x, ring, lane);
+        bf_wide_step<NW, 8, SAVE ? BF_SAVE_VMEM : 0>(acc, x, ring, lane);
         bf_wide_epilogue<SAVE>(acc, x, p.step[s], row, row_ok, bits_idx, q);
     }
     // ---- the head -----------------------------------------------------------------------------------------------------------------
@@ -370,8 +389,8 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
         const BfStep& st = p.step[p.n_steps - 1];
         f32x4 hacc[2];
         bf_acc_init<2>(hacc, bias_lds + (p.n_steps - 1) * BF_WIDE, q);
-        if (st.N > 16) bf_head_step<2, SAVE ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
-        else bf_head_step<1, SAVE ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
+        if (st.N > 16) bf_head_step<NW, 2, SAVE ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
+        else bf_head_step<NW, 1, SAVE ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
         if (st.out != nullptr && row_ok) {
 #pragma unroll
             for (int T = 0; T < 2; ++T)
@@ -389,23 +408,35 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
 
 constexpr int BF_LDS_BYTES = BF_RING * BF_STAGE_BYTES + BF_MAX_STEPS * BF_WIDE * 4;
 
-// grid: one workgroup per 64-row tile over the launch's chains; two workgroups per CU
-__global__ __launch_bounds__(256, 2) void mlp_chain_bf_kernel(BfMulti m) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[BF_LDS_BYTES];
+// grid: one workgroup per (16 NW)-row tile over the launch's chains; two workgroups per CU.  NW = 4 (64-row tiles) when that fills
+// the chip twice over (the two forward passes of a step: 512 tiles); NW = 2 (32-row tiles, 128 work-items) for launches of fewer
+// tiles (the backward chain: 256 64-row tiles would leave ONE workgroup per CU, nothing to cover its barriers and epilogues)
+template <int NW>
+__device__ __forceinline__ void mlp_chain_bf_entry(const BfMulti& m, unsigned char* lds) {
     const int tile = (int)blockIdx.x;
     int qn = 0;
     while (qn + 1 < m.n && tile >= m.tile_start[qn + 1]) ++qn;
     const BfChain& p = m.c[qn];
-    const int row0 = (tile - m.tile_start[qn]) * BF_TM;
+    const int row0 = (tile - m.tile_start[qn]) * (16 * NW);
     float* bias_lds = reinterpret_cast<float*>(lds + BF_RING * BF_STAGE_BYTES);
     const bool save = p.step[0].out != nullptr || p.step[0].bits_out != nullptr || p.step[0].bits_in != nullptr;
     if (p.k0_steps == 1) {
-        if (save) bf_chain_body<1, true>(p, row0, lds, bias_lds);
-        else bf_chain_body<1, false>(p, row0, lds, bias_lds);
+        if (save) bf_chain_body<NW, 1, true>(p, row0, lds, bias_lds);
+        else bf_chain_body<NW, 1, false>(p, row0, lds, bias_lds);
     } else {
-        if (save) bf_chain_body<2, true>(p, row0, lds, bias_lds);
-        else bf_chain_body<2, false>(p, row0, lds, bias_lds);
+        if (save) bf_chain_body<NW, 2, true>(p, row0, lds, bias_lds);
+        else bf_chain_body<NW, 2, false>(p, row0, lds, bias_lds);
     }
+}
+
+__global__ __launch_bounds__(256, 2) void mlp_chain_bf_kernel(BfMulti m) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BF_LDS_BYTES];
+    mlp_chain_bf_entry<4>(m, lds);
+}
+
+__global__ __launch_bounds__(128, 1) void mlp_chain_bf32_kernel(BfMulti m) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BF_LDS_BYTES];
+    mlp_chain_bf_entry<2>(m, lds);
 }
 
 // ---- the weight stream: split + fragment order, once per optimiser step ---------------------------------------------------------

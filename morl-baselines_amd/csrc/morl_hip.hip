@@ -629,16 +629,23 @@ static int timing_close(morl_ctx* c, int slot, hipStream_t s);
 static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStream_t s) {
     BfMulti m{};
     m.n = n;
+    long long tiles64 = 0;
+    for (int q = 0; q < n; ++q) tiles64 += (chains[q].rows + BF_TM - 1) / BF_TM;
+    // 64-row tiles (4 waves) when they give every CU its two workgroups, else 32-row tiles (2 waves): MORL_BF_TILE=64 / 32 forces
+    static const int forced = [] { const char* e = getenv("MORL_BF_TILE"); return e ? atoi(e) : 0; }();      // (tuning)
+    const bool small = forced ? forced == 32 : tiles64 < 2ll * c->num_cus;
+    const int tm = small ? 32 : BF_TM;
     int tiles = 0;
     for (int q = 0; q < n; ++q) {
         m.c[q] = chains[q];
         m.tile_start[q] = tiles;
-        tiles += (chains[q].rows + BF_TM - 1) / BF_TM;
+        tiles += (chains[q].rows + tm - 1) / tm;
     }
     for (int q = n; q <= BF_MAX_MULTI; ++q) m.tile_start[q] = tiles;
     int slot = -1, rc;
     if ((rc = timing_open(c, kind, s, &slot))) return rc;
-    hipLaunchKernelGGL(mlp_chain_bf_kernel, dim3(tiles), dim3(256), 0, s, m);
+    if (small) hipLaunchKernelGGL(mlp_chain_bf32_kernel, dim3(tiles), dim3(128), 0, s, m);
+    else hipLaunchKernelGGL(mlp_chain_bf_kernel, dim3(tiles), dim3(256), 0, s, m);
     LAUNCH_CHECK("mlp_chain_bf");
     return timing_close(c, slot, s);
 }

@@ -20,6 +20,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMAND = [os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]
 PASSES = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
           "sq": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"]}
+# a second SQ pass (optional: a counter name this rocprofv3 does not know fails the pass, which is then skipped): where the waves'
+# cycles go -- parked at s_waitcnt / s_barrier (WAIT_ANY), issue-stalled (WAIT_INST_ANY), issuing (ACTIVE_INST_ANY); LDS activity
+EXTRA_PASSES = {"sq2": ["SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_LDS_IDX_ACTIVE",
+                        "SQ_WAVE_CYCLES", "SQ_INSTS_VALU"]}
 
 
 def run_pass(name, counters, outdir):
@@ -65,6 +69,12 @@ def main():
         COMMAND = [os.path.join(ROOT, sys.argv[2]), *sys.argv[3:]]
     work = os.path.join(os.environ.get("TMPDIR", "/tmp"), "pmc_passes")
     res = {n: run_pass(n, c, work) for n, c in PASSES.items()}
+    for n, c in EXTRA_PASSES.items():
+        try:
+            res[n] = run_pass(n, c, work)
+        except Exception as exc:                       # (unknown counter, slot overflow: the summary goes on without it)
+            print(f"[pmc_summary] optional pass {n} skipped: {exc}", file=sys.stderr)
+            res[n] = {}
     avg_ns = run_trace(work)
     kernels = {}
     for k in sorted(res["fetch"]):
@@ -85,7 +95,7 @@ def main():
                       "effective_clock_ghz": (sq["GRBM_GUI_ACTIVE"] / 8.0 / avg_ns[k]) if avg_ns.get(k) else None,
                       "avg_launch_ns_in_counter_pass": s.get("avg_ns_in_pass"),
                       "effective_clock_ghz_in_counter_pass": (sq["GRBM_GUI_ACTIVE"] / 8.0 / s["avg_ns_in_pass"]) if s.get("avg_ns_in_pass") else None,
-                      "sq": sq}
+                      "sq": sq, "sq2": {c: v for c, v in res.get("sq2", {}).get(k, {}).items() if c != "launches"}}
     json.dump({"note": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "command": "python " + " ".join([os.path.relpath(COMMAND[0], ROOT)] + COMMAND[1:]), "kernels": kernels}, open(out_path, "w"), indent=1)
     for k, v in kernels.items():
         print(f"{k:45s} launches {v['launches']:4d}  HBM {v['hbm_bytes'] / 1e6:9.2f} MB  mfma_busy {v['mfma_busy_frac']:.3f}")
