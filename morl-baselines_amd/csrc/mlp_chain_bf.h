@@ -180,26 +180,38 @@ __device__ __forceinline__ void bf_frag_load(bf_u32x4 (&f)[3], const unsigned ch
 // their first use.  The order is PINNED with sched_barrier: left alone, hipcc clusters the MFMAs of one accumulator and sinks
 // every ds_read next to its first use (waiting for it on the spot).
 #define BF_PIN() __builtin_amdgcn_sched_barrier(0)
-template <bool READ>
-__device__ __forceinline__ void bf_six_pair(f32x4& c0, f32x4& c1, const bf_u32x4 (&w0)[3], const bf_u32x4 (&w1)[3], const bf_u32x4 (&x)[3],
+// product steps [P0, P1) of a pair; READ: fragment k of the next pair (k = 0..5 in consumption order: lo, lo, mid, mid, hi, hi) is
+// read in front of product step rd[k] (steps outside [P0, P1) read nothing)
+template <int P0, int P1, bool READ, int R0 = 0, int R1 = 1, int R2 = 2, int R3 = 3, int R4 = 4, int R5 = 5>
+__device__ __forceinline__ void bf_six_part(f32x4& c0, f32x4& c1, const bf_u32x4 (&w0)[3], const bf_u32x4 (&w1)[3], const bf_u32x4 (&x)[3],
                                             bf_u32x4 (&n0)[3], bf_u32x4 (&n1)[3], const unsigned char* next_base) {
     constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};
+    constexpr int rd[6] = {R0, R1, R2, R3, R4, R5};
 #pragma unroll
-    for (int p = 0; p < 6; ++p) {
-        if (READ) {          // in the order the next pair consumes them: lo parts first (the wait before its first MFMA is a counted one)
-            const int pl = 2 - (p >> 1);
-            if ((p & 1) == 0) n0[pl] = *reinterpret_cast<const bf_u32x4*>(next_base + pl * BF_BLOCK);
-            else n1[pl] = *reinterpret_cast<const bf_u32x4*>(next_base + (3 + pl) * BF_BLOCK);
+    for (int p = P0; p < P1; ++p) {
+        if (READ) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (rd[k] == p) {
+                    const int pl = 2 - (k >> 1);
+                    if ((k & 1) == 0) n0[pl] = *reinterpret_cast<const bf_u32x4*>(next_base + pl * BF_BLOCK);
+                    else n1[pl] = *reinterpret_cast<const bf_u32x4*>(next_base + (3 + pl) * BF_BLOCK);
+                }
         }
         c0 = bf_mfma(w0[pw[p]], x[px[p]], c0);
         c1 = bf_mfma(w1[pw[p]], x[px[p]], c1);
         BF_PIN();
     }
 }
+template <bool READ>
+__device__ __forceinline__ void bf_six_pair(f32x4& c0, f32x4& c1, const bf_u32x4 (&w0)[3], const bf_u32x4 (&w1)[3], const bf_u32x4 (&x)[3],
+                                            bf_u32x4 (&n0)[3], bf_u32x4 (&n1)[3], const unsigned char* next_base) {
+    bf_six_part<0, 6, READ>(c0, c1, w0, w1, x, n0, n1, next_base);
+}
 
 // One wide step (256 columns = 16 tiles) over KSTEPS k-steps: two stages per k-step (tiles 0-7, 8-15), per stage four tile pairs.
 // acc[T][r] += sum_k W[16T + 4q + r][k] * x[k]  for this lane's row.  The pipeline runs ACROSS the stage boundaries: the entry of
-// stage i + 1 (wait, barrier, DMA issue) sits in front of the LAST pair of stage i, whose twelve MFMAs then cover the LDS latency of
+// stage i + 1 (wait, barrier, DMA issue) sits INSIDE the last pair of stage i, whose remaining MFMAs then cover the LDS latency of
 // stage i + 1's first fragments -- its own fragments are all in registers by then, so the buffer of stage i is free for the DMA the
 // entry issues.  EXTRA0: see bf_stage_begin, applies to the step's first two stages.
 template <int NW, int KSTEPS, int EXTRA0>
@@ -223,9 +235,13 @@ __device__ __forceinline__ void bf_wide_step(f32x4 (&acc)[16], const bf_u32x4 (&
             bf_six_pair<true>(acc[T + 2], acc[T + 3], fb[0], fb[1], x[s], fa[0], fa[1], base + 12 * BF_BLOCK);
             bf_six_pair<true>(acc[T + 4], acc[T + 5], fa[0], fa[1], x[s], fb[0], fb[1], base + 18 * BF_BLOCK);
             if (!last) {
+                // two product steps first: by the time the wave reaches the stage entry's wait, this pair's own fragments (read
+                // during the pair before) have long returned -- then the entry, then the other four steps with the next stage's first
+                // fragments riding along (2, 2, 1, 1)
+                bf_six_part<0, 2, false>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
                 base = ((s == 0 && hf == 0) ? bf_stage_begin<NW, EXTRA0>(ring) : bf_stage_begin<NW, 0>(ring)) + lane * 16;
                 BF_PIN();
-                bf_six_pair<true>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
+                bf_six_part<2, 6, true, 2, 2, 3, 3, 4, 5>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
             } else {
                 bf_six_pair<false>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
             }
@@ -267,12 +283,20 @@ __device__ __forceinline__ void bf_acc_init(f32x4 (&acc)[NTILES], const float* b
 
 // Epilogue of a wide step, lane-local: (ReLU | mask bits) -> fp32 copy to HBM -> sign bits -> split into the next step's B operand.
 // Vector-memory instructions issued per lane when SAVE: 16 row stores (+ 1 word of bits) -- BF_SAVE_VMEM, counted by the waits.
+// `keep`: the step's mask word (bits_in), loaded by the caller at the START of the step -- a load inside the epilogue would be waited
+// for with vmcnt(0), i.e. behind both weight stages in flight (the first version did: one drained ring per layer).
 constexpr int BF_SAVE_VMEM = 17;
+// ReLU as ONE instruction: max on the bit patterns as signed integers (positive floats are positive integers, everything with the
+// sign bit set -- negative values, -0 -- is a negative integer); fmaxf(a, 0) costs a second v_max (IEEE NaN quieting)
+__device__ __forceinline__ float bf_relu(float a) {
+    const int u = __builtin_bit_cast(int, a);
+    return __builtin_bit_cast(float, u > 0 ? u : 0);
+}
+
 template <bool SAVE>
 __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x4 (&x)[8][3], const BfStep& st, int row, bool row_ok,
-                                                 size_t bits_idx, int q) {
-    unsigned long long keep = ~0ull, pos = 0ull;
-    if (SAVE && st.bits_in != nullptr) keep = st.bits_in[bits_idx];
+                                                 size_t bits_idx, int q, unsigned long long keep) {
+    unsigned long long pos = 0ull;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         float v[8];
@@ -280,7 +304,7 @@ __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x
         for (int e = 0; e < 8; ++e) {
             const int T = 2 * s + (e >> 2), r = e & 3;
             float a = acc[T][r];
-            if (st.relu) a = fmaxf(a, 0.f);
+            if (st.relu) a = bf_relu(a);
             if (SAVE) {
                 a = ((keep >> (4 * T + r)) & 1ull) ? a : 0.f;
                 if (a > 0.f) pos |= 1ull << (4 * T + r);
@@ -367,6 +391,8 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
             x[s][2] = bf_u32x4{lo[0], lo[1], lo[2], lo[3]};
         }
     }
+    unsigned long long keep = ~0ull;     // the first step's mask word (backward chain)
+    if (SAVE && p.step[0].bits_in != nullptr) keep = p.step[0].bits_in[bits_idx];
     // everything this lane loaded or stored so far has to be out of the way of the counted waits: drain once, before the loop
     // (the two DMA groups in flight are waited for here too -- the only vmcnt(0) of the kernel, at its very start)
     BF_VMCNT(0);
@@ -377,12 +403,16 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     // ---- first step ---------------------------------------------------------------------------------------------------------------
     bf_acc_init<16>(acc, bias_lds, q);
     bf_wide_step<NW, K0S, 0>(acc, x, ring, lane);
-    bf_wide_epilogue<SAVE>(acc, x, p.step[0], row, row_ok, bits_idx, q);
+    bf_wide_epilogue<SAVE>(acc, x, p.step[0], row, row_ok, bits_idx, q, keep);
     // ---- the 256 x 256 steps --------------------------------------------------------------------------------------------------------
     for (int s = 1; s < n_wide; ++s) {
+        // this step's mask word: ONE more vector-memory instruction behind the epilogue's stores, in front of this step's DMA groups
+        // -- retired (in issue order) long before the epilogue reads it, counted by the first two stage waits like the stores
+        keep = ~0ull;
+        if (SAVE && p.step[s].bits_in != nullptr) keep = p.step[s].bits_in[bits_idx];
         bf_acc_init<16>(acc, bias_lds + s * BF_WIDE, q);
-        bf_wide_step<NW, 8, SAVE ? BF_SAVE_VMEM : 0>(acc, x, ring, lane);
-        bf_wide_epilogue<SAVE>(acc, x, p.step[s], row, row_ok, bits_idx, q);
+        bf_wide_step<NW, 8, SAVE ? BF_SAVE_VMEM + 1 : 0>(acc, x, ring, lane);
+        bf_wide_epilogue<SAVE>(acc, x, p.step[s], row, row_ok, bits_idx, q, keep);
     }
     // ---- the head -----------------------------------------------------------------------------------------------------------------
     if (p.head) {

@@ -202,6 +202,12 @@ struct morl_ctx {
     unsigned char* bf_stream = nullptr;
     int bf_fwd_blocks = 0, bf_bwd_blocks = 0, bf_k0_steps = 0, bf_head_tiles = 0;
     const float* fresh_bf = nullptr;     // parameters the streams were split from by this step's morl_envelope_prepare (one-shot)
+    // tail overlap (MORL_TAIL_STREAM): the arg-max and the target rows of a lazily evaluated step run on a side stream BESIDE the
+    // training forward (they need the online next-state slab only, it needs neither)
+    int tail_stream = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool lz_phase1_done = false;         // one-shot: update_core's TD stage starts at phase 2
     bool bits_bf = false;                // the last training forward left its sign bits in mlp_chain_bf.h's lane layout
     const unsigned int* skip_flag = nullptr;   // one-shot: the next clip + Adam launch leaves the optimiser state alone if this
                                          // device word is non-zero (a timed-out collective of the single-hop transport)
@@ -269,6 +275,9 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     if (c->wt_online) (void)hipFree(c->wt_online);
     if (c->wt_target) (void)hipFree(c->wt_target);
     if (c->bf_stream) (void)hipFree(c->bf_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
     return MORL_OK;
 }
@@ -399,6 +408,7 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     }
     if (const char* e = getenv("MORL_EXACT_F32")) c->bf_mode = atoi(e) != 0 ? 0 : 1;
     if (const char* e = getenv("MORL_BF_MIN_ROWS")) c->bf_min_rows = atoll(e);
+    if (const char* e = getenv("MORL_TAIL_STREAM")) c->tail_stream = atoi(e);
 #undef ALLOC
     *out = c;
     return MORL_OK;
@@ -1169,6 +1179,69 @@ extern "C" int morl_envelope_greedy_actions(morl_ctx* c, const float* params, co
     return launch_envelope_td(p, n, 4, s, "envelope_td(greedy_actions)");
 }
 
+// the argument block of envelope_td_kernel for the TD rows of `WI` scalarisation vectors against slabs over `W` candidates
+static EnvelopeTdArgs td_args(morl_ctx* c, const morl_update_cfg* cfg, const morl_update_out* out, const int32_t* actions,
+                              const float* rewards, const float* dones, const float* weights_i, int WI, const float* qo, const float* qt,
+                              int W, int i_offset, long long rows_total, int B, int* td_waves_out) {
+    const int R = c->net.reward_dim, A = c->net.n_actions;
+    EnvelopeTdArgs p{};
+    p.qo = qo; p.qt = qt; p.weights = weights_i; p.q_main = c->qm;
+    p.actions = actions; p.rewards = rewards; p.dones = dones;
+    p.target = out->target; p.pref = out->pref; p.ac = out->ac;
+    p.dq = c->dq; p.loss_part = c->loss_part; p.priority = (i_offset == 0) ? out->priority : nullptr;
+    p.priority_clear = (i_offset != 0) ? out->priority : nullptr;
+    p.B = B; p.W = W; p.A = A; p.R = R; p.ldq = c->ldq;
+    p.WI = WI; p.i_offset = i_offset;
+    p.bmajor = c->use_fused ? 1 : 0;
+    p.diag_only = cfg->envelope ? 0 : 1;
+    p.gamma = cfg->gamma;
+    const float lam = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
+    p.c_mse = (float)((1.0 - (double)lam) * 2.0 / ((double)rows_total * R));
+    p.c_aux = (float)((double)lam * 2.0 / (double)rows_total);
+    p.i_groups = std::max(1, std::min(4, (WI + 63) / 64));
+    if (cfg->slab_parts > 1) {      // all-gathered slabs read in place: [G][2][B][W/G][A][R]
+        p.part_floats = (W / cfg->slab_parts) * A * R;
+        p.part_stride = 2ll * B * p.part_floats;
+    }
+    // waves per workgroup ~ candidates per TD row: 4 at the single-GPU 64 x 6, up to 16 when a sharded job reduces over
+    // all gathered weights (MORL_TD_WAVES overrides, for tuning)
+    const long long n_cand = cfg->envelope ? (long long)W * A : A;
+    int td_waves = n_cand >= 256 ? 16 : (n_cand >= 64 ? 8 : 4);
+    if (const char* e = getenv("MORL_TD_WAVES")) td_waves = std::max(1, std::min(ENV_MAX_WAVES, atoi(e)));
+    *td_waves_out = td_waves;
+    return p;
+}
+
+// Lazy target evaluation, the part that needs the ONLINE next-state slab only: (1) arg-max, every selected (b, j*) pair takes a
+// compact target row; (2) the target network on those rows -- few-row tiles sized for the worst case, tiles beyond the count exit
+// at once.  (Measured and dropped in round 3: the same tiles as extra workgroups of the training pass's launch.)
+static int lazy_phase1(morl_ctx* c, const EnvelopeTdArgs& p, int td_waves, hipStream_t s) {
+    int rc;
+    c->lz_epoch = (c->lz_epoch & 0x3fffffff) + 1;
+    EnvelopeTdArgs a1 = p;
+    a1.phase = 1; a1.best_io = c->lz_best;
+    a1.pairs_out = c->lz_pairs; a1.row_slot = c->lz_slot; a1.count = c->lz_count; a1.epoch = c->lz_epoch;
+    a1.zero_ptr = nullptr;
+    if ((rc = launch_envelope_td(a1, p.B * p.i_groups, td_waves, s, "envelope_argmax"))) return rc;
+    ChainArgs t = make_forward_chain(c, c->lz_params_target, c->wt_target, c->lz_next_obs, p.weights, p.B, p.W, 0, p.B * p.W, false,
+                                     c->qt, p.A * p.R);
+    t.in_mode = 3;
+    t.rows_dev = c->lz_count + (c->lz_epoch & 1);
+    t.pairs = c->lz_pairs;
+    static const bool few_rows = [] { const char* e = getenv("MORL_CHAIN4"); return e ? atoi(e) != 0 : true; }();   // (A/B)
+    if (few_rows && chain4_ok(t)) {
+        // 8-row tiles (mlp_chain4.h): twice the workgroups, half the MFMA time per CU and layer
+        hipLaunchKernelGGL(mlp_chain4_kernel, dim3((p.B * p.W + C4_TM - 1) / C4_TM), dim3(CH_THREADS), 0, s, t);
+        LAUNCH_CHECK("mlp_chain4(lazy targets)");
+    } else {
+        Chain16Multi m16{};
+        const int tiles = chain16_fill(m16, &t, 1);
+        hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
+        LAUNCH_CHECK("mlp_chain16(lazy targets)");
+    }
+    return MORL_OK;
+}
+
 // ---- one gradient step, in three stages so that a weight-sharded job can put its collectives between them ----------
 // stage B: TD rows of `WI` scalarisation vectors (weights_i) against slabs over all `W` candidates:
 //          training forward (unless the caller already ran it), envelope arg-max + TD, backward, weight gradients.
@@ -1211,62 +1284,16 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     {
         const bool lazy = c->lz_now;
         c->lz_now = false;
-        EnvelopeTdArgs p{};
-        p.qo = qo; p.qt = qt; p.weights = weights_i; p.q_main = c->qm;
-        p.actions = actions; p.rewards = rewards; p.dones = dones;
-        p.target = out->target; p.pref = out->pref; p.ac = out->ac;
-        p.dq = c->dq; p.loss_part = c->loss_part; p.priority = (i_offset == 0) ? out->priority : nullptr;
-        p.priority_clear = (i_offset != 0) ? out->priority : nullptr;
-        p.B = B; p.W = W; p.A = A; p.R = R; p.ldq = c->ldq;
-        p.WI = WI; p.i_offset = i_offset;
-        p.bmajor = bmajor;
+        int td_waves = 0;
+        EnvelopeTdArgs p = td_args(c, cfg, out, actions, rewards, dones, weights_i, WI, qo, qt, W, i_offset, rows_total, B, &td_waves);
         p.zero_ptr = c->td_zero_ptr; p.zero_n = c->td_zero_n; p.keep_lo = c->td_keep_lo; p.keep_hi = c->td_keep_hi;
         c->td_zero_ptr = nullptr;
-        p.diag_only = cfg->envelope ? 0 : 1;
-        p.gamma = cfg->gamma;
-        const float lam = cfg->homotopy_lambda > 0.f ? cfg->homotopy_lambda : 0.f;
-        p.c_mse = (float)((1.0 - (double)lam) * 2.0 / ((double)rows_total * R));
-        p.c_aux = (float)((double)lam * 2.0 / (double)rows_total);
-        p.i_groups = td_groups;
-        if (cfg->slab_parts > 1) {      // all-gathered slabs read in place: [G][2][B][W/G][A][R]
-            p.part_floats = (W / cfg->slab_parts) * A * R;
-            p.part_stride = 2ll * B * p.part_floats;
-        }
-        // waves per workgroup ~ candidates per TD row: 4 at the single-GPU 64 x 6, up to 16 when a sharded job reduces over
-        // all gathered weights (MORL_TD_WAVES overrides, for tuning)
-        const long long n_cand = cfg->envelope ? (long long)W * A : A;
-        int td_waves = n_cand >= 256 ? 16 : (n_cand >= 64 ? 8 : 4);
-        if (const char* e = getenv("MORL_TD_WAVES")) td_waves = std::max(1, std::min(ENV_MAX_WAVES, atoi(e)));
         if (lazy) {
-            // 1. arg-max on the online slab: best (j*, a*) per TD row; every (b, j*) pair selected gets a compact target row
-            c->lz_epoch = (c->lz_epoch & 0x3fffffff) + 1;
-            EnvelopeTdArgs a1 = p;
-            a1.phase = 1; a1.best_io = c->lz_best;
-            a1.pairs_out = c->lz_pairs; a1.row_slot = c->lz_slot; a1.count = c->lz_count; a1.epoch = c->lz_epoch;
-            a1.zero_ptr = nullptr;
-            if ((rc = launch_envelope_td(a1, B * td_groups, td_waves, s, "envelope_argmax"))) return rc;
-            // 2. the target network on those rows only: 16-row tiles sized for the worst case, tiles beyond the count exit at once.
-            //    (Measured and dropped: the same tiles as extra workgroups of the training pass's launch, large tiles one per CU --
-            //    a CU with a 64-row tile is already MFMA-bound, the 16-row tile on top made that launch 93 us instead of 70 and the
-            //    step 0.343 ms instead of 0.3375: profiles/r03_lazy_targets_ab.json)
-            {
-                ChainArgs t = make_forward_chain(c, c->lz_params_target, c->wt_target, c->lz_next_obs, weights_i, B, W, 0, B * W, false,
-                                                 c->qt, A * R);
-                t.in_mode = 3;
-                t.rows_dev = c->lz_count + (c->lz_epoch & 1);
-                t.pairs = c->lz_pairs;
-                static const bool few_rows = [] { const char* e = getenv("MORL_CHAIN4"); return e ? atoi(e) != 0 : true; }();   // (A/B)
-                if (few_rows && chain4_ok(t)) {
-                    // 8-row tiles (mlp_chain4.h): twice the workgroups, half the MFMA time per CU and layer
-                    hipLaunchKernelGGL(mlp_chain4_kernel, dim3((B * W + C4_TM - 1) / C4_TM), dim3(CH_THREADS), 0, s, t);
-                    LAUNCH_CHECK("mlp_chain4(lazy targets)");
-                } else {
-                    Chain16Multi m16{};
-                    const int tiles = chain16_fill(m16, &t, 1);
-                    hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
-                    LAUNCH_CHECK("mlp_chain16(lazy targets)");
-                }
-            }
+            // 1. + 2. arg-max on the online slab, the target network on the selected rows -- unless morl_envelope_update already
+            //    ran them on the side stream, beside the training forward
+            const bool done = c->lz_phase1_done;
+            c->lz_phase1_done = false;
+            if (!done && (rc = lazy_phase1(c, p, td_waves, s))) return rc;
             // 3. TD target, loss gradient, priorities from the compact target rows
             p.phase = 2; p.best_io = c->lz_best; p.row_slot = c->lz_slot; p.qt = c->qt;
         }
@@ -1538,9 +1565,30 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         c->lz_last = c->lz_now;
         const BfChain two[2] = {bf_forward_chain(c, params_online, next_obs, weights, B, W, rows, false, c->qo, AR),
                                 bf_forward_chain(c, params_online, obs, weights, B, W, rows, true, c->qm, c->ldq)};
-        if ((rc = bf_launch(c, two, 2, MORL_TIMED_FORWARD2, s))) { c->lz_now = false; return rc; }
         if (c->lz_now) { c->lz_params_target = params_target; c->lz_next_obs = next_obs; }
-        else if ((rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
+        if (c->lz_now && c->tail_stream) {
+            // Tail overlap: the online next-state pass alone, then the arg-max and the target rows on a side stream BESIDE the
+            // training forward -- they need that slab only, the training forward needs neither; the TD launch joins them.
+            if (!c->side) {
+                HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            if ((rc = bf_launch(c, &two[0], 1, MORL_TIMED_FORWARD2, s))) { c->lz_now = false; return rc; }
+            HIP_TRY(hipEventRecord(c->ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+            int td_waves = 0;
+            const long long rows_total_ = cfg->rows_total > 0 ? (long long)cfg->rows_total : (long long)rows;
+            const EnvelopeTdArgs p1 = td_args(c, cfg, out, actions, rewards, dones, weights, W, c->qo, c->qt, W, 0, rows_total_, B, &td_waves);
+            if ((rc = lazy_phase1(c, p1, td_waves, c->side))) { c->lz_now = false; return rc; }
+            HIP_TRY(hipEventRecord(c->ev_join, c->side));
+            if ((rc = bf_launch(c, &two[1], 1, MORL_TIMED_FORWARD2, s))) { c->lz_now = false; return rc; }
+            HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+            c->lz_phase1_done = true;
+        } else {
+            if ((rc = bf_launch(c, two, 2, MORL_TIMED_FORWARD2, s))) { c->lz_now = false; return rc; }
+            if (!c->lz_now && (rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
+        }
         main_done = true;
         c->bits_valid = true;
         c->bits_bf = true;
