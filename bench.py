@@ -43,6 +43,9 @@ MACS_ROW = (D + R) * 256 + 3 * 256 * 256 + 256 * A * R           # 210 176 MACs 
 FWD_FLOP_ROW = 2 * MACS_ROW                                       # 420 352
 BWD_DX_FLOP_ROW = 2 * (A * R * 256 + 3 * 256 * 256)               # dX chain (no dX for layer 0): 402 432
 PEAK_FP32_MFMA_TFLOPS = 157.3                                     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0                                    # MI355X_MICROARCH.md: dense bf16 MFMA (no 2:1 sparsity)
+BF16_PRODUCTS = 6                                                 # split-bf16 products per fp32 product (csrc/mlp_chain_bf.h)
+ALGORITHMIC_BYTES_STEP = 7.7e6                                    # batch + parameters + Adam state + outputs of one step
 # One rank of an N-rank strong-scaled job run alone on one MI355X (--force-shard --emulate-world N; profiles/r02_bench_emulated_
 # rank_of_*.json): single-GPU step time / that rank's step time = what N GPUs could reach if the collectives were free.
 EMULATED_CEILING = {"source": "profiles/r03_bench_emulated_rank_of_{2,4,8}.json (batch axis: 0.242 / 0.172 / 0.148 ms against 0.325), "
@@ -187,21 +190,39 @@ def _physical_cores():
         return None
 
 
-def measured_chain_traffic():
-    """HBM bytes per mlp_chain launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected as
-    MI355X_MICROARCH.md prescribes; profiles/*_pmc_summary.json).  PMC counters cannot be read from inside this
-    process, so the figure is the one measured offline on this same command; None if no summary is committed."""
+def committed_pmc():
+    """The newest committed rocprofv3 PMC summary (profiles/r*_pmc_summary.json: FETCH_SIZE x2 + WRITE_SIZE per launch and kernel,
+    collected as MI355X_MICROARCH.md prescribes by tools/pmc_summary.py on this same command).  PMC counters cannot be read from
+    inside this process, so these figures are constants of the repository, not of this run; None if no summary is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
-        return None
+        return None, None
     try:
-        ks = json.load(open(files[-1]))["kernels"]
-        sel = [v for k, v in ks.items() if k.startswith("morl::mlp_chain")]
-        n = sum(v["launches"] for v in sel)
-        return sum(v["hbm_bytes"] * v["launches"] for v in sel) / n if n else None
+        return json.load(open(files[-1]))["kernels"], os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
+
+
+def traffic_fields(bf16):
+    """roofline.traffic = the DOMINANT kernel's own HBM bytes per launch (the chain kernel: mlp_chain_bf when the step ran on the
+    bf16 matrix cores -- its forward launch --, else mlp_chain2); step_hbm_bytes = the sum over the step's kernels."""
+    ks, src = committed_pmc()
+    if not ks:
+        return {"traffic": None, "traffic_source": None}
+    name = "morl::mlp_chain_bf_kernel" if bf16 else "morl::mlp_chain2_kernel"
+    dom = next((v for k, v in ks.items() if k.startswith(name)), None)
+    step = sum(v["hbm_bytes"] for k, v in ks.items() if k.startswith("morl::") and "sumtree_set" not in k and "polyak" not in k)
+    return {"traffic": dom["hbm_bytes"] if dom else None,
+            "traffic_kernel": name if dom else None,
+            "traffic_unit": "HBM bytes per launch of the dominant kernel (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE)",
+            "traffic_source": f"committed profile {src} (PMC counters cannot be read in-process): a constant of the repository, "
+                              "not of this run",
+            "step_hbm_bytes": step, "algorithmic_bytes": ALGORITHMIC_BYTES_STEP,
+            "step_hbm_over_algorithmic": step / ALGORITHMIC_BYTES_STEP,
+            "step_hbm_note": "sum over the step's kernels of the same summary; SURVEY 8(d)'s 7.7 MB is the figure of a fully fused "
+                             "forward + backward that keeps 117 MB of activations on chip -- here they are written once and read "
+                             "once by the weight-gradient launch"}
 
 
 def _claim_stdout():
@@ -335,7 +356,7 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", 
                                                                   else (steps + 1) // 2 if timing_every == -2 else 0),
            "launches_per_step": launches_per_step, "timing_mode": timing_every, "kinds": kinds,
            "fwd_launches_per_step": kinds0["forward"][0], "fwd2_launches_per_step": kinds0["forward2"][0], "transport": transport, "axis": axis if sharded else None,
-           "lazy_target_rows": lazy_rows,
+           "lazy_target_rows": lazy_rows, "bf16": agent.q_net.ctx.last_step_bf16(),
            "loss": agent.last_loss(), "engine": agent.q_net.ctx.engine, "W": W, "B": B}
     del agent
     return res
@@ -419,10 +440,12 @@ def collective_microbench(dist, dev, world, n_allreduce, n_allgather, iters=20):
 
 
 def _roofline(res, rows_rank):
-    """Dominant kernel = mlp_chain (per step and rank: the forward passes -- one launch of three chains, or the slabs launch +
-    the hoisted training forward of a sharded step -- and the backward-dX launch): algorithmic flop of the timed launches
-    over their summed HIP-event duration."""
+    """Dominant kernel = the layer-fused chain (per step and rank: the launch with the online forward passes and the backward-dX
+    launch): algorithmic flop of the timed launches over their summed HIP-event duration.  When the step ran on the bf16 matrix
+    cores every fp32 product is six bf16 products: ``achieved`` / ``frac`` then price the SIX-fold flop against the dense bf16 peak,
+    and ``fp32_equivalent_tflops`` is the algorithmic rate (what the same work would be called on the f32-input MFMA)."""
     n_chain, chain_ms, timed_steps = res["n_chain"], res["chain_ms"], res["timed_steps"]
+    bf16 = bool(res.get("bf16"))
     # algorithmic flop of ONE launch of each kind (this rank's rows): the three-pass forward launch (or the launches of a sharded
     # step), the two-pass forward launch of a lazily evaluated step, the backward-dX launch, the weight-gradient launch
     flop_kind = {"forward": rows_rank * 3 * FWD_FLOP_ROW / max(1, res.get("fwd_launches_per_step") or 1),
@@ -432,30 +455,79 @@ def _roofline(res, rows_rank):
     launches_per_step = res.get("launches_per_step") or (n_chain / timed_steps if timed_steps else 0)
     flop_per_launch = chain_flop / n_chain if n_chain else float("nan")
     avg_launch_s = (chain_ms * 1e-3 / n_chain) if n_chain else float("nan")
-    achieved = chain_flop / (chain_ms * 1e-3) / 1e12 if n_chain else float("nan")
-    traffic = measured_chain_traffic()
+    fp32_eq = chain_flop / (chain_ms * 1e-3) / 1e12 if n_chain else float("nan")
+    mult, peak = (BF16_PRODUCTS, PEAK_BF16_MFMA_TFLOPS) if bf16 else (1, PEAK_FP32_MFMA_TFLOPS)
+    achieved = fp32_eq * mult
     # the three GEMM kernels of the step one by one (the launches of a kind that were bracketed; algorithmic flop of this rank's
-    # rows over their mean duration): forward = the step's forward launch(es) together, 3 passes
+    # rows over their mean duration)
     per_kernel = {}
-    name_kind = {"forward": "mlp_chain forward (3 passes)", "forward2": "mlp_chain forward (2 passes: online next-state + training)",
-                 "backward": "mlp_chain backward-dX", "dw": "dw_tiles (dW, db)"}
-    for k, (n_k, ms_k) in (res.get("kinds") or {}).items():
+    chain_name = "mlp_chain_bf (split-bf16, 6 products)" if bf16 else "mlp_chain2 (f32-input MFMA)"
+    name_kind = {"forward": chain_name + " forward (3 passes)", "forward2": chain_name + " forward (2 passes: online next-state + training)",
+                 "backward": chain_name + " backward-dX", "dw": "dw_tiles (dW, db; f32-input MFMA)"}
+    for k, (n_k, ms_k) in kinds.items():
         if n_k:
             us = ms_k * 1e3 / n_k
             tf = flop_kind[k] / (us * 1e-6) / 1e12
+            on_bf = bf16 and k != "dw"
             per_kernel[k] = {"kernel": name_kind[k], "launches_timed": n_k, "avg_launch_us": us,
-                             "algorithmic_flop_per_launch": flop_kind[k], "achieved": tf, "frac": tf / PEAK_FP32_MFMA_TFLOPS}
-    return {"bound": "mfma", "kernel": "mlp_chain (layer-fused Q-net forward / backward-dX)", "per_kernel": per_kernel,
-            "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/)",
-            "traffic_source": "committed profile (profiles/*_pmc_summary.json: PMC counters cannot be read in-process); "
-                              "constant of the repo, not of this run" if traffic is not None else None,
-            "launches_timed": n_chain, "timed_steps": timed_steps, "launches_per_step": launches_per_step,
-            "timing": ("one launch per step, taking turns" if res.get("timing_mode") == -1 else
-                       "all launches of every %d-th step" % res.get("timing_mode", 0)),
-            "avg_launch_us": avg_launch_s * 1e6,
-            "algorithmic_flop_per_launch": flop_per_launch}
+                             "algorithmic_flop_per_launch": flop_kind[k], "fp32_equivalent_tflops": tf,
+                             "achieved": tf * (BF16_PRODUCTS if on_bf else 1), "peak": PEAK_BF16_MFMA_TFLOPS if on_bf else PEAK_FP32_MFMA_TFLOPS,
+                             "frac": tf * (BF16_PRODUCTS if on_bf else 1) / (PEAK_BF16_MFMA_TFLOPS if on_bf else PEAK_FP32_MFMA_TFLOPS)}
+    out = {"bound": "mfma",
+           "kernel": ("mlp_chain_bf (layer-fused Q-net forward / backward-dX, six split-bf16 products per fp32 product on "
+                      "v_mfma_f32_16x16x32_bf16)" if bf16 else "mlp_chain2 (layer-fused Q-net forward / backward-dX, f32-input MFMA)"),
+           "per_kernel": per_kernel, "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+           "peak_source": ("MI355X_MICROARCH.md: dense bf16 MFMA 2.5 PFLOP/s (no sparsity); executed flop = 6 x algorithmic" if bf16
+                           else "MI355X_MICROARCH.md: f32-input MFMA 157.3 TFLOP/s"),
+           "fp32_equivalent_tflops": fp32_eq, "frac_of_fp32_mfma_peak": fp32_eq / PEAK_FP32_MFMA_TFLOPS,
+           "launches_timed": n_chain, "timed_steps": timed_steps, "launches_per_step": launches_per_step,
+           "timing": ("one launch per step, taking turns" if res.get("timing_mode") == -1 else
+                      "one launch of every second step, taking turns" if res.get("timing_mode") == -2 else
+                      "all launches of every %d-th step" % res.get("timing_mode", 0)),
+           "avg_launch_us": avg_launch_s * 1e6,
+           "algorithmic_flop_per_launch": flop_per_launch}
+    out.update(traffic_fields(bf16))
+    return out
+
+
+def one_step_parity(dev):
+    """bench.py checks what it times: ONE gradient step at the metric's full shape (256 x 64 x 3, the seeded inputs of the reference
+    fixture tests/golden/envelope_flagship_full.npz) through the library's DEFAULT pipeline (lazy targets, bf16 matrix cores when
+    enabled) against the oracle on the host -- loss and gradient norm to 1e-5.  Part of the cpu_baseline leg (the only place the
+    benchmark may touch oracle/)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import envelope_oracle as orc
+    from cases import FLAGSHIP as c, make_inputs
+    import morl_baselines_amd.ops as ops
+    inp = make_inputs(c)
+    flat = lambda ps: th.cat([th.as_tensor(p).reshape(-1) for p in ps])
+    ctx = ops.QNetContext(c.D, c.R, c.A, c.arch, c.B, c.W)
+    po, pt = flat(inp["online"]).to(dev), flat(inp["target"]).to(dev)
+    m, v, g = flat(inp["exp_avg"]).to(dev), flat(inp["exp_avg_sq"]).to(dev), th.zeros_like(po)
+    res = ops.envelope_update(ctx, po, pt, g, m, v, th.tensor(inp["obs"]).to(dev), th.tensor(inp["next_obs"]).to(dev),
+                              th.tensor(inp["actions"].astype(np.int32).reshape(-1)).to(dev), th.tensor(inp["rewards"]).to(dev),
+                              th.tensor(inp["dones"]).reshape(-1).to(dev), th.tensor(inp["sampled_w"]).float().to(dev),
+                              gamma=c.gamma, lr=c.lr, adam_step=c.step, max_grad_norm=c.max_grad_norm)
+    lazy_rows, bf16 = ctx.lazy_target_rows(po), ctx.last_step_bf16()
+    th.cuda.synchronize()
+    nt = th.get_num_threads()
+    th.set_num_threads(max(1, min(32, (os.cpu_count() or 4) // 4)))
+    o = orc.envelope_update([th.tensor(a) for a in inp["online"]], [th.tensor(a) for a in inp["target"]],
+                            [th.tensor(a) for a in inp["exp_avg"]], [th.tensor(a) for a in inp["exp_avg_sq"]], c.step,
+                            tuple(th.tensor(inp[k]) for k in ("obs", "actions", "rewards", "next_obs", "dones")),
+                            th.tensor(inp["sampled_w"]).float(), n_actions=c.A, reward_dim=c.R, gamma=c.gamma, lr=c.lr,
+                            max_grad_norm=c.max_grad_norm, dedup=True, apply_step=False)
+    th.set_num_threads(nt)
+    rel_l = abs(res["loss"].item() - o["loss"].item()) / abs(o["loss"].item())
+    rel_g = abs(res["grad_norm"].item() - o["grad_norm"].item()) / abs(o["grad_norm"].item())
+    ctx.close()
+    out = {"shape": f"B={c.B} x W={c.W} x R={c.R} (fixture inputs of tests/golden/envelope_{c.name}.npz)", "loss_hip": res["loss"].item(),
+           "loss_oracle": o["loss"].item(), "loss_rel": rel_l, "grad_norm_rel": rel_g, "lazy_target_rows": lazy_rows, "bf16_matrix_cores": bf16,
+           "tolerance": 1e-5, "ok": bool(rel_l <= 1e-5 and rel_g <= 1e-5)}
+    if not out["ok"]:
+        raise SystemExit(f"bench.py: the timed pipeline disagrees with the oracle on one step: {out}")
+    return out
 
 
 def main():
@@ -594,6 +666,7 @@ def main():
                     "gpu_ms_per_step_events": res["gpu_ms_per_step_events"], "last_loss": res["loss"],
                     "roofline": _roofline(res, rows_step // parts),
                     "lazy_target_rows_last_step": res.get("lazy_target_rows"),
+                    "bf16": bool(res.get("bf16")),
                     "whole_step_algorithmic_tflops": rows_step * (4 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) / (ms * 1e-3) / 1e12,
                     "whole_step_executed_tflops": ((rows_step * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) +
                                                     parts * res["lazy_target_rows"] * FWD_FLOP_ROW) if res.get("lazy_target_rows")
@@ -621,7 +694,8 @@ def main():
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ("f32 (6 x bf16 split products, fp32 accumulate: online forward passes + dX backward; f32-input MFMA: target "
+                      "rows, dW)" if h["bf16"] else "f32"),
             "data": "synthetic",
             "config": {"workload": f"Envelope.update(): B={B} x W={W_head} x R={R}, obs {D}, {A} actions, net {ARCH}, "
                                    f"PER {'on' if a.per else 'off'}, buffer 20k seeded transitions (BASELINE.md s3)",
@@ -635,6 +709,9 @@ def main():
                        "shard_axis": head_axis,
                        "transport": head_res.get("transport"),
                        "engine": head_res["engine"],
+                       "arithmetic": ("online forward passes and dX backward on the bf16 matrix cores as six split-bf16 products per "
+                                      "fp32 product (csrc/mlp_chain_bf.h, fp32-class accuracy); MORL_EXACT_F32=1 keeps every GEMM on the "
+                                      "f32-input MFMA" if h["bf16"] else "every GEMM on the f32-input MFMA (exact fp32 fma chains)"),
                        "setup": "0.5 s device clock ramp (dummy GEMMs) before the warm-up steps; ms_per_step_no_ramp is the same "
                                 "run shape without it"},
             "updates_per_s": h["updates_per_s"],
@@ -642,8 +719,12 @@ def main():
             "gpu_ms_per_step_events": h["gpu_ms_per_step_events"],
             "host_enqueue_ms_per_step": h["host_enqueue_ms_per_step"],
             "last_loss": h["last_loss"],
+            # whole-step fractions are fp32-EQUIVALENT rates over the f32-input MFMA peak (the one common yardstick of a step that
+            # mixes both instruction families); algorithmic = SURVEY 8(d)'s five full passes, executed = what ran (lazy targets)
             "roofline": dict(h["roofline"], whole_step_algorithmic_tflops=h["whole_step_algorithmic_tflops"],
-                             whole_step_executed_tflops=h["whole_step_executed_tflops"]),
+                             whole_step_executed_tflops=h["whole_step_executed_tflops"],
+                             whole_step_frac_algorithmic=h["whole_step_algorithmic_tflops"] / PEAK_FP32_MFMA_TFLOPS,
+                             whole_step_frac_executed=h["whole_step_executed_tflops"] / PEAK_FP32_MFMA_TFLOPS),
             "lazy_target_rows_last_step": h["lazy_target_rows_last_step"],
         }
         if h["lazy_target_rows_last_step"]:
@@ -681,6 +762,7 @@ def main():
                                        note=f"sub-record, NOT the headline: weak scaling, W = {a.weights * world} sampled weights in "
                                             f"total ({a.weights} per GPU; weight axis sharded), same steps / warm-up")
         if not a.no_cpu_baseline and world == 1:
+            out["one_step_parity"] = one_step_parity(dev)
             cb = cpu_baseline(B, W_head, bool(a.per))
             out["cpu_baseline"] = cb
             total = out["value"] / cb["value"]

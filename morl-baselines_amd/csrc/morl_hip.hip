@@ -202,12 +202,6 @@ struct morl_ctx {
     unsigned char* bf_stream = nullptr;
     int bf_fwd_blocks = 0, bf_bwd_blocks = 0, bf_k0_steps = 0, bf_head_tiles = 0;
     const float* fresh_bf = nullptr;     // parameters the streams were split from by this step's morl_envelope_prepare (one-shot)
-    // tail overlap (MORL_TAIL_STREAM): the arg-max and the target rows of a lazily evaluated step run on a side stream BESIDE the
-    // training forward (they need the online next-state slab only, it needs neither)
-    int tail_stream = 0;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool lz_phase1_done = false;         // one-shot: update_core's TD stage starts at phase 2
     bool bits_bf = false;                // the last training forward left its sign bits in mlp_chain_bf.h's lane layout
     const unsigned int* skip_flag = nullptr;   // one-shot: the next clip + Adam launch leaves the optimiser state alone if this
                                          // device word is non-zero (a timed-out collective of the single-hop transport)
@@ -275,9 +269,6 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     if (c->wt_online) (void)hipFree(c->wt_online);
     if (c->wt_target) (void)hipFree(c->wt_target);
     if (c->bf_stream) (void)hipFree(c->bf_stream);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
     return MORL_OK;
 }
@@ -408,7 +399,6 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     }
     if (const char* e = getenv("MORL_EXACT_F32")) c->bf_mode = atoi(e) != 0 ? 0 : 1;
     if (const char* e = getenv("MORL_BF_MIN_ROWS")) c->bf_min_rows = atoll(e);
-    if (const char* e = getenv("MORL_TAIL_STREAM")) c->tail_stream = atoi(e);
 #undef ALLOC
     *out = c;
     return MORL_OK;
@@ -1031,6 +1021,13 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
     return MORL_OK;
 }
 
+// 1 if the last morl_envelope_update on this context ran its online forward passes and its dX backward pass as split-bf16 products
+// (mlp_chain_bf.h), 0 if on the f32-input MFMA
+extern "C" int morl_ctx_last_step_bf16(morl_ctx* c) {
+    if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
+    return c->bits_bf ? 1 : 0;
+}
+
 extern "C" int morl_ctx_set_exact_f32(morl_ctx* c, int enable) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     const int was = c->bf_mode == 0 ? 1 : 0;
@@ -1289,11 +1286,8 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         p.zero_ptr = c->td_zero_ptr; p.zero_n = c->td_zero_n; p.keep_lo = c->td_keep_lo; p.keep_hi = c->td_keep_hi;
         c->td_zero_ptr = nullptr;
         if (lazy) {
-            // 1. + 2. arg-max on the online slab, the target network on the selected rows -- unless morl_envelope_update already
-            //    ran them on the side stream, beside the training forward
-            const bool done = c->lz_phase1_done;
-            c->lz_phase1_done = false;
-            if (!done && (rc = lazy_phase1(c, p, td_waves, s))) return rc;
+            // 1. + 2. arg-max on the online slab, the target network on the selected rows
+            if ((rc = lazy_phase1(c, p, td_waves, s))) return rc;
             // 3. TD target, loss gradient, priorities from the compact target rows
             p.phase = 2; p.best_io = c->lz_best; p.row_slot = c->lz_slot; p.qt = c->qt;
         }
@@ -1566,26 +1560,11 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         const BfChain two[2] = {bf_forward_chain(c, params_online, next_obs, weights, B, W, rows, false, c->qo, AR),
                                 bf_forward_chain(c, params_online, obs, weights, B, W, rows, true, c->qm, c->ldq)};
         if (c->lz_now) { c->lz_params_target = params_target; c->lz_next_obs = next_obs; }
-        if (c->lz_now && c->tail_stream) {
-            // Tail overlap: the online next-state pass alone, then the arg-max and the target rows on a side stream BESIDE the
-            // training forward -- they need that slab only, the training forward needs neither; the TD launch joins them.
-            if (!c->side) {
-                HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-            }
-            if ((rc = bf_launch(c, &two[0], 1, MORL_TIMED_FORWARD2, s))) { c->lz_now = false; return rc; }
-            HIP_TRY(hipEventRecord(c->ev_fork, s));
-            HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-            int td_waves = 0;
-            const long long rows_total_ = cfg->rows_total > 0 ? (long long)cfg->rows_total : (long long)rows;
-            const EnvelopeTdArgs p1 = td_args(c, cfg, out, actions, rewards, dones, weights, W, c->qo, c->qt, W, 0, rows_total_, B, &td_waves);
-            if ((rc = lazy_phase1(c, p1, td_waves, c->side))) { c->lz_now = false; return rc; }
-            HIP_TRY(hipEventRecord(c->ev_join, c->side));
-            if ((rc = bf_launch(c, &two[1], 1, MORL_TIMED_FORWARD2, s))) { c->lz_now = false; return rc; }
-            HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
-            c->lz_phase1_done = true;
-        } else {
+        {
+            // (Measured and dropped in round 4: the online next-state pass alone, then arg-max + target rows on a side stream BESIDE
+            // the training forward -- the two workgroups of a bf16 chain launch hold all 160 KB of a CU's LDS, so the arg-max
+            // workgroups could not become resident beside them: 53 us instead of 10, the step 0.288 ms instead of 0.248;
+            // profiles/r04_tail_stream_ab.txt)
             if ((rc = bf_launch(c, two, 2, MORL_TIMED_FORWARD2, s))) { c->lz_now = false; return rc; }
             if (!c->lz_now && (rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
         }

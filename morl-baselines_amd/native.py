@@ -142,6 +142,7 @@ _SIGNATURES = {
     "morl_ctx_invalidate_shadows": (C.c_int, [C.c_void_p]),
     "morl_ctx_set_lazy_targets": (C.c_int, [C.c_void_p, C.c_int]),
     "morl_ctx_set_exact_f32": (C.c_int, [C.c_void_p, C.c_int]),
+    "morl_ctx_last_step_bf16": (C.c_int, [C.c_void_p]),
     "morl_ctx_lazy_target_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "morl_ctx_debug_hidden": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "morl_host_device_pointer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

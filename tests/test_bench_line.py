@@ -55,9 +55,25 @@ def test_roofline_record_arithmetic(bench):
     assert pk["backward"]["achieved"] == pytest.approx(rows * bench.BWD_DX_FLOP_ROW / 67e-6 / 1e12)
     assert pk["dw"]["achieved"] == pytest.approx(rows * bench.FWD_FLOP_ROW / 70e-6 / 1e12)
     assert all(0.0 < v["frac"] < 1.0 for v in pk.values())
-    # traffic: HBM bytes per chain launch of the newest committed PMC summary (profiles/), labelled as a constant of the repo
-    assert r["traffic"] == pytest.approx(bench.measured_chain_traffic())
-    assert 50e6 < r["traffic"] < 200e6 and "committed profile" in r["traffic_source"]
+    assert r["fp32_equivalent_tflops"] == pytest.approx(r["achieved"]) and r["frac_of_fp32_mfma_peak"] == pytest.approx(r["frac"])
+    # the same launches on the bf16 matrix cores (six split-bf16 products per fp32 product): the executed flop is six-fold, the peak
+    # the dense bf16 one, and the algorithmic rate is reported beside it
+    rb = bench._roofline(dict(res2, bf16=True, kinds={"forward2": (7, 7 * 0.071), "backward": (7, 7 * 0.043), "dw": (6, 6 * 0.070)},
+                              chain_ms=7 * 0.071 + 7 * 0.043), rows)
+    eq = rows * (2 * bench.FWD_FLOP_ROW + bench.BWD_DX_FLOP_ROW) / 2 / (0.057e-3) / 1e12
+    assert rb["peak"] == 2500.0 and rb["fp32_equivalent_tflops"] == pytest.approx(eq, rel=1e-9)
+    assert rb["achieved"] == pytest.approx(6 * eq, rel=1e-9) and rb["frac"] == pytest.approx(6 * eq / 2500.0, rel=1e-9)
+    assert rb["per_kernel"]["dw"]["peak"] == 157.3 and rb["per_kernel"]["forward2"]["peak"] == 2500.0
+    assert rb["per_kernel"]["forward2"]["achieved"] == pytest.approx(6 * rows * 2 * bench.FWD_FLOP_ROW / 71e-6 / 1e12)
+    assert "bf16" in rb["kernel"] and 0.0 < rb["frac"] < 1.0
+    # traffic: HBM bytes per launch of the DOMINANT kernel (its own figure, not an average over kernels) of the newest committed PMC
+    # summary (profiles/), labelled as a constant of the repository; the step's total and its ratio to SURVEY 8(d)'s 7.7 MB beside it
+    ks, src = bench.committed_pmc()
+    assert src.startswith("profiles/") and rb["traffic"] == pytest.approx(ks["morl::mlp_chain_bf_kernel"]["hbm_bytes"])
+    assert 50e6 < rb["traffic"] < 200e6 and "committed profile" in rb["traffic_source"]
+    assert rb["step_hbm_bytes"] == pytest.approx(sum(v["hbm_bytes"] for k, v in ks.items()
+                                                      if k.startswith("morl::") and "sumtree_set" not in k and "polyak" not in k))
+    assert rb["algorithmic_bytes"] == 7.7e6 and rb["step_hbm_over_algorithmic"] == pytest.approx(rb["step_hbm_bytes"] / 7.7e6)
 
 
 def test_contract_constants(bench):
@@ -68,4 +84,6 @@ def test_contract_constants(bench):
     assert "256" in base["metric"] and "64" in base["metric"]            # the line's metric is BASELINE.json's
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"metric": "Envelope-Q TD updates/sec (batch x weights x obj = 256 x 64 x 3)"' in src
-    assert '"vs_baseline": None' in src and '"dtype": "f32"' in src and '"data": "synthetic"' in src
+    assert '"vs_baseline": None' in src and '"data": "synthetic"' in src
+    assert 'else "f32")' in src and "6 x bf16 split products" in src      # dtype: the arithmetic type, spelled out for the split path
+    assert bench.PEAK_BF16_MFMA_TFLOPS == 2500.0 and bench.BF16_PRODUCTS == 6
