@@ -1,0 +1,226 @@
+// Weight gradients of one backward pass on the bf16 matrix cores with fp32-class accuracy (gfx950, wave64): one launch, split-K
+// over the batch rows, every fp32 product evaluated as six products of three-way bf16 splits (see mlp_chain_bf.h for the arithmetic),
+//
+//   dW_l[o][i] = sum_rows g_l[row][o] * h_l[row][i]        db_l[o] = sum_rows g_l[row][o]        (the dW / db half of loss.backward(),
+//                                                                                                 envelope.py:323)
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16 inside a row slice, slices summed in a fixed order by grad_reduce_ranges_kernel
+// (dw_tiles.h) exactly like the fp32 engine's.  Both operands are fp32 in HBM (what the forward / backward chains saved); a
+// workgroup splits its slices ON THE FLY:
+//   * 512 work-items = 8 waves, one workgroup per CU.  A job = (problem, group of output rows, row slice); per 32-row chunk the
+//     workgroup turns a 32 x (16 TG) block of g and a 32 x (16 TH) block of h into MFMA fragments: work-item (column quad, row octet)
+//     loads 8 x 16 bytes (branch-free buffer loads: rows beyond the slice and columns beyond the matrix read as zeros), splits its 32
+//     values and writes each column's eight rows as one 16-byte fragment lane per split part -- fragment block = (operand tile, part):
+//     1 KB, lane (column, octet) at 16 (column + 16 octet), so the MFMA phase's ds_read_b128 is 1 KB contiguous, conflict-free.
+//     db rides along: the g items keep running column sums (combined over the four octets in a fixed order at the end).
+//   * TG + TH <= 24 tiles = 72 KB per chunk, double-buffered (144 KB): chunk c is multiplied while chunk c + 1 is split and written
+//     and chunk c + 2 is in flight from memory; ONE barrier per chunk (96 MFMAs per wave).
+//   * a wave owns up to 2 x 8 output tiles of 16 x 16 (64 accumulator registers); which ones depends on the problem's shape (Layout):
+//     256 x 256 layers: two groups of 128 output rows, wave (w >> 1, w & 1) -> rows 32 (w >> 1).., columns 128 (w & 1)..;
+//     a narrow input (the first layer, in <= 128): all 256 output rows in one group, wave w -> rows 32 w.., all columns;
+//     a narrow output (the Q head, out <= 32): wave w -> all rows, columns 32 w...
+//     Row slices are sized by the MFMAs a chunk costs the busiest wave, so every job of the launch carries the same matrix-core work.
+// Roofline: 6 x (2 * rows * out * in) flop per layer on the bf16 pipe; HBM bytes = both operands once or twice (an operand block is
+// shared by the row groups / column halves of its layer) + the split-K slabs.
+#pragma once
+#include "dw_tiles.h"
+#include "mlp_chain_bf.h"
+
+namespace morl {
+
+constexpr int DWB_THREADS = 512;
+constexpr int DWB_BK = 32;                       // rows per chunk = one MFMA k-step
+constexpr int DWB_MAX_TILES = 24;                // operand tiles (g + h) per chunk: 72 KB
+constexpr int DWB_BUF_BYTES = DWB_MAX_TILES * 3 * BF_BLOCK;
+constexpr int DWB_LDS_BYTES = 2 * DWB_BUF_BYTES;
+
+struct DwbProblem {
+    const float* G;   // [rows][ldg]  dLoss/dz_l          (output index contiguous)
+    const float* H;   // [rows][ldh]  layer input          (input index contiguous)
+    float* C;         // slab 0 of dW_l, row-major [M][ldc]
+    float* colsum;    // slab 0 of db_l [M]
+    int M, N;         // out, in
+    int ldg, ldh, ldc;
+    int gcols, hcols; // loadable columns of G / H: multiples of 4, pad columns are zeros
+    int layout;       // 0: groups of 128 output rows x all (<= 256) columns; 1: all (<= 256) output rows x <= 128 columns; 2: <= 32 rows x <= 256 columns
+    int groups;       // output-row groups (layout 0: ceil(M / 128), else 1)
+    int tg, th;       // operand tiles of a chunk: g (16 output rows each) and h (16 input columns each)
+    int k_per_split, splits;
+    int job_start;    // job = job_start + split * groups + group
+};
+
+struct DwbArgs {
+    DwbProblem p[MORL_MAX_LAYERS];
+    int n, rows, jobs;
+    long long slab_stride;     // floats between split slabs
+    SumTreeUpdate per;         // per.tree != NULL: one extra workgroup (block `jobs`) applies the step's PER priority update (as dw_tiles.h)
+};
+
+// this wave's output tiles: rows 16 (ot0 + a), a < n_ot <= 2; columns 16 (it0 + b), b < n_it <= 8 -- tile indices INSIDE the chunk's
+// operand blocks (g tile / h tile numbers)
+struct DwbWave { int ot0, n_ot, it0, n_it; };
+__device__ __forceinline__ DwbWave dwb_wave_map(const DwbProblem& g, int wave) {
+    DwbWave m;
+    if (g.layout == 0) { m.ot0 = 2 * (wave >> 1); m.n_ot = min(2, g.tg - m.ot0); m.it0 = 8 * (wave & 1); m.n_it = min(8, g.th - m.it0); }
+    else if (g.layout == 1) { m.ot0 = 2 * wave; m.n_ot = min(2, g.tg - m.ot0); m.it0 = 0; m.n_it = g.th; }
+    else { m.ot0 = 0; m.n_ot = g.tg; m.it0 = 2 * wave; m.n_it = min(2, g.th - m.it0); }
+    m.n_ot = max(0, m.n_ot); m.n_it = max(0, m.n_it);
+    return m;
+}
+
+// the 8 x 16 bytes of one split item: rows k0 + 8 octet + e of four consecutive columns
+struct DwbStage { float4 v[8]; };
+
+__device__ __forceinline__ void dwb_load(DwbStage& s, __amdgpu_buffer_rsrc_t rsrc, int base_off, int ld, int k0) {
+    // (base_off = byte offset of (row 8 octet, column) or DW2_OOB for an idle item / a column beyond the matrix; the row goes
+    // through the VECTOR offset: the hardware's range check does not see the scalar one)
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        s.v[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base_off + (k0 + e) * ld * 4, 0, 0));
+}
+
+// split the item's four columns (8 rows each) and write them as fragment lanes of `buf`: column j -> tile (col / 16), lane (col % 16) + 16 octet
+__device__ __forceinline__ void dwb_split_store(const DwbStage& s, unsigned char* lane_dst) {
+    // lane_dst = buf + ((tile * 3) * 64 + (col0 % 16) + 16 octet) * 16: the four columns are four consecutive lanes of one tile
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float c[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c[e] = (j == 0) ? s.v[e].x : (j == 1) ? s.v[e].y : (j == 2) ? s.v[e].z : s.v[e].w;
+        unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bf_split2(c[2 * u], c[2 * u + 1], hi[u], mid[u], lo[u]);
+        *reinterpret_cast<bf_u32x4*>(lane_dst + j * 16) = bf_u32x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<bf_u32x4*>(lane_dst + BF_BLOCK + j * 16) = bf_u32x4{mid[0], mid[1], mid[2], mid[3]};
+        *reinterpret_cast<bf_u32x4*>(lane_dst + 2 * BF_BLOCK + j * 16) = bf_u32x4{lo[0], lo[1], lo[2], lo[3]};
+    }
+}
+
+__device__ __forceinline__ void dwb_job(const DwbProblem& g, int group, int split, int rows, long long slab_stride, unsigned char* lds) {
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kbeg = split * g.k_per_split;
+    const int kend = min(rows, kbeg + g.k_per_split);
+    const int m0 = (g.layout == 0) ? group * 128 : 0;          // first output row of this job's g block
+    const DwbWave wm = dwb_wave_map(g, wave);
+
+    // ---- this work-item's split item: column quad cq of the concatenated [g block | h block] columns, row octet oct ---------------
+    const int nq = 4 * (g.tg + g.th);                          // column quads of a chunk (<= 96)
+    const int cq = tid % nq, oct = tid / nq;                   // (items beyond 4 octets idle: 512 work-items, <= 384 items)
+    const bool item = oct < 4;
+    const bool is_g = cq < 4 * g.tg;
+    const int col_local = 4 * (is_g ? cq : cq - 4 * g.tg);     // first column inside the operand block
+    const int col = is_g ? m0 + col_local : col_local;         // ... inside the matrix
+    const int ld = is_g ? g.ldg : g.ldh;
+    const bool col_ok = item && col < (is_g ? g.gcols : g.hcols) && (!is_g || col_local < 16 * g.tg);
+    // rows [0, kend) of the operand: everything beyond this split's slice reads as zero
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(is_g ? g.G : g.H), 0, kend * ld * 4, 0x00020000);
+    const int base_off = col_ok ? (8 * oct * ld + col) * 4 : DW2_OOB;
+    const int tile = (is_g ? 0 : g.tg) + (col_local >> 4);
+    const int dst_off = ((tile * 3) * 64 + (col_local & 15) + 16 * oct) * 16;
+
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};                      // running column sums of this item's g columns (db)
+
+    DwbStage st;
+    // prologue: chunk 0 split into buffer 0, chunk 1 in flight
+    dwb_load(st, rsrc, base_off, ld, kbeg);
+    if (item) {
+        if (is_g) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { csum[0] += st.v[e].x; csum[1] += st.v[e].y; csum[2] += st.v[e].z; csum[3] += st.v[e].w; }
+        }
+        dwb_split_store(st, lds + dst_off);
+    }
+    dwb_load(st, rsrc, base_off, ld, kbeg + DWB_BK);
+    __syncthreads();
+
+    const unsigned char* frag_lane = lds + lane * 16;
+    for (int k0 = kbeg, c = 0; k0 < kend; k0 += DWB_BK, ++c) {
+        const unsigned char* cur = frag_lane + (c & 1) * DWB_BUF_BYTES;
+        unsigned char* nxt = lds + ((c & 1) ^ 1) * DWB_BUF_BYTES;
+        // A fragments (g tiles of this wave): once per chunk
+        bf_u32x4 fa[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                fa[a][pl] = (a < wm.n_ot) ? *reinterpret_cast<const bf_u32x4*>(cur + ((wm.ot0 + a) * 3 + pl) * BF_BLOCK) : bf_u32x4{0u, 0u, 0u, 0u};
+        const unsigned char* hb = cur + (g.tg + wm.it0) * 3 * BF_BLOCK;
+        bf_u32x4 fb[2][3];
+        if (wm.n_it > 0) bf_frag_load(fb[0], hb, 0);
+        const bool more = k0 + DWB_BK < kend;                  // chunk c + 1 exists: it is in `st`, goes to the other buffer
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (b < wm.n_it) {
+                if (b + 1 < wm.n_it) bf_frag_load(fb[(b + 1) & 1], hb, b + 1);
+                // D[o][i] += g^T[o][k] h[k][i]: A = the g fragment (lane = output row), B = the h fragment (lane = input column)
+                constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+                for (int p = 0; p < 6; ++p) {
+                    acc[0][b] = bf_mfma(fa[0][pw[p]], fb[b & 1][px[p]], acc[0][b]);
+                    if (wm.n_ot > 1) acc[1][b] = bf_mfma(fa[1][pw[p]], fb[b & 1][px[p]], acc[1][b]);
+                }
+            }
+            // the split of chunk c + 1 rides under the first tiles' MFMAs, the loads of chunk c + 2 behind it
+            if (b == 1 && more && item) {
+                if (is_g) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { csum[0] += st.v[e].x; csum[1] += st.v[e].y; csum[2] += st.v[e].z; csum[3] += st.v[e].w; }
+                }
+                dwb_split_store(st, nxt + dst_off);
+            }
+            if (b == 1) dwb_load(st, rsrc, base_off, ld, k0 + 2 * DWB_BK);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: slab tiles; D register r of lane (i, q) of tile (a, b) is row 16 (ot0 + a) + 4 q + r, column 16 (it0 + b) + i --------
+    float* __restrict__ C = g.C + (size_t)split * slab_stride;
+    const int li = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (a < wm.n_ot && b < wm.n_it) {
+                const int colc = 16 * (wm.it0 + b) + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + 16 * (wm.ot0 + a) + 4 * q + r;
+                    if (row < g.M && colc < g.N) C[(size_t)row * g.ldc + colc] = acc[a][b][r];
+                }
+            }
+        }
+    // db: the four octets of a g column, in octet order (the operand buffers are free: the loop ended with a barrier)
+    if (g.colsum != nullptr) {
+        float* scr = reinterpret_cast<float*>(lds);            // [4 octets][16 tg columns]
+        if (item && is_g) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) scr[oct * 256 + col_local + j] = csum[j];
+        }
+        __syncthreads();
+        if (tid < 16 * g.tg && m0 + tid < g.M)
+            g.colsum[(size_t)split * slab_stride + m0 + tid] = ((scr[tid] + scr[256 + tid]) + scr[512 + tid]) + scr[768 + tid];
+    }
+}
+
+__global__ __launch_bounds__(DWB_THREADS) void dw_bf_kernel(DwbArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[DWB_LDS_BYTES];
+    static_assert(DWB_LDS_BYTES >= ST_LDS_BYTES, "the tree update borrows the operand buffers as scratch");
+    if ((int)blockIdx.x >= a.jobs) {
+        // (the tree update is written for ST_THREADS work-items; the surplus of this launch's 512 idles)
+        if ((int)blockIdx.x == a.jobs && a.per.tree != nullptr) sumtree_update_body(a.per, lds);
+        return;
+    }
+    const int job = (int)blockIdx.x;
+    int q = 0;
+    while (q + 1 < a.n && job >= a.p[q + 1].job_start) ++q;
+    const DwbProblem& g = a.p[q];
+    const int local = job - g.job_start;
+    dwb_job(g, local % g.groups, local / g.groups, a.rows, a.slab_stride, lds);
+}
+
+}  // namespace morl

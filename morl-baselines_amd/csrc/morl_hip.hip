@@ -23,6 +23,7 @@
 #include "mlp_chain4.h"
 #include "mlp_chain_bf.h"
 #include "dw_tiles.h"
+#include "dw_bf.h"
 #include "optim_kernels.h"
 #include "replay_kernels.h"
 #include "pareto_kernels.h"
@@ -1320,7 +1321,78 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     Dw2Ranges ranges{};
     bool dw2_ok = (c->ld0 & 3) == 0 && (c->ldq & 3) == 0;      // dw_tiles.h streams 16-byte pieces of 16-byte aligned rows
     for (int l = 1; l < L; ++l) dw2_ok = dw2_ok && (n.dims[l] & 3) == 0;
-    if (c->dw_mode == 3 && dw2_ok) {
+    // the step runs on the bf16 matrix cores (its forward / backward chains did): the weight gradients too, as six split-bf16
+    // products per fp32 product (dw_bf.h) -- when every problem fits one of that kernel's three layouts
+    bool dwb_ok = c->bits_bf && c->bf_mode == 1 && dw2_ok && c->dw_mode == 3;
+    for (int l = 0; l < L && dwb_ok; ++l) {
+        const int M = n.dims[l + 1], N = n.dims[l];
+        if (!(M <= 256 && N <= 256 && (M <= 32 || N <= 128 || (M > 32 && N > 128)))) dwb_ok = false;
+    }
+    static const bool dwb_env = [] { const char* e = getenv("MORL_DW_BF16"); return e ? atoi(e) != 0 : true; }();      // (A/B)
+    if (dwb_ok && dwb_env) {
+        DwbArgs a{};
+        a.n = L;
+        a.rows = rows;
+        a.slab_stride = c->P;
+        double cost_rows = 0.0;
+        int cost[MORL_MAX_LAYERS];
+        for (int l = 0; l < L; ++l) {
+            DwbProblem& q = a.p[l];
+            q.G = c->g[l];
+            q.ldg = (l == L - 1) ? c->ldq : n.dims[l + 1];
+            q.H = (l == 0) ? c->x0m : c->h[l];
+            q.ldh = (l == 0) ? c->ld0 : n.dims[l];
+            q.C = c->slabs + c->offW[l];
+            q.ldc = n.dims[l];
+            q.colsum = c->slabs + c->offB[l];
+            q.M = n.dims[l + 1]; q.N = n.dims[l];
+            q.gcols = q.ldg; q.hcols = q.ldh;      // (pad columns of dq / x0 are written as zeros by their producers)
+            const int th = (q.N + 15) / 16;
+            if (q.M <= 32) { q.layout = 2; q.groups = 1; q.tg = (q.M + 15) / 16; q.th = th; cost[l] = q.tg * std::min(2, th) * 6; }
+            else if (q.N <= 128) { q.layout = 1; q.groups = 1; q.tg = (q.M + 15) / 16; q.th = th; cost[l] = 2 * th * 6; }
+            else { q.layout = 0; q.groups = (q.M + 127) / 128; q.tg = std::min(8, (q.M + 15) / 16); q.th = th; cost[l] = 2 * std::min(8, th) * 6; }
+            cost_rows += (double)q.groups * rows * cost[l] / 96.0;
+        }
+        int target = c->num_cus;                   // one 512-work-item workgroup per CU (144 KB of LDS)
+        if (const char* e = getenv("MORL_DW_JOBS")) target = std::max(1, atoi(e));     // (tuning)
+        int base = round_up(std::max(1, (int)std::ceil(cost_rows / (double)target)), DWB_BK);
+        for (;;) {      // the split count of every problem must fit the slab buffer
+            bool ok = true;
+            for (int l = 0; l < L; ++l) {
+                const int kps = round_up((int)((long long)base * 96 / cost[l]), DWB_BK);
+                if ((rows + kps - 1) / kps > c->max_splits) ok = false;
+            }
+            if (ok) break;
+            base += DWB_BK;
+        }
+        int jobs = 0, r = 0;
+        splits = 0;
+        for (int l = 0; l < L; ++l) {
+            DwbProblem& q = a.p[l];
+            q.k_per_split = round_up((int)((long long)base * 96 / cost[l]), DWB_BK);
+            q.splits = (rows + q.k_per_split - 1) / q.k_per_split;
+            q.job_start = jobs;
+            jobs += q.splits * q.groups;
+            splits = std::max(splits, q.splits);
+            ranges.end[r] = c->offB[l];                                   ranges.splits[r++] = q.splits;   // W_l
+            ranges.end[r] = c->offB[l] + n.dims[l + 1];                   ranges.splits[r++] = q.splits;   // b_l
+        }
+        ranges.n = r;
+        a.jobs = jobs;
+        int extra = 0;
+        if (cfg->per_tree && i_offset == 0 && out->priority && B <= ST_MAX_B) {     // the step's PER update rides along
+            a.per.tree = cfg->per_tree; a.per.idx = cfg->per_idx; a.per.raw = out->priority;
+            a.per.running_max = cfg->per_running_max; a.per.pr_out = nullptr;
+            a.per.n_levels = cfg->per_levels; a.per.B = B; a.per.alpha = cfg->per_alpha;
+            extra = 1;
+            per_done = true;
+        }
+        int tslot = -1;
+        if ((rc = timing_open(c, MORL_TIMED_DW, s, &tslot))) return rc;
+        hipLaunchKernelGGL(dw_bf_kernel, dim3(jobs + extra), dim3(DWB_THREADS), 0, s, a);
+        LAUNCH_CHECK("dw_bf");
+        if ((rc = timing_close(c, tslot, s))) return rc;
+    } else if (c->dw_mode == 3 && dw2_ok) {
         // dw_tiles.h: per-problem wave layout; a layout with fewer MFMAs per contraction step gets longer row slices so that
         // every workgroup carries the same matrix-core work, and the whole launch is one round of ~2 workgroups per CU
         Dw2Args a{};
