@@ -6,7 +6,7 @@
 // accumulated in fp32 by v_mfma_f32_16x16x32_bf16 inside a row slice, slices summed in a fixed order by grad_reduce_ranges_kernel
 // (dw_tiles.h) exactly like the fp32 engine's.  Both operands are fp32 in HBM (what the forward / backward chains saved); a
 // workgroup splits its slices ON THE FLY:
-//   * 512 work-items = 8 waves, one workgroup per CU.  A job = (problem, group of output rows, row slice); per 32-row chunk the
+//   * 512 work-items = 8 waves, one workgroup per CU (whole waves split g, the others h: wave-uniform buffer descriptors).  A job = (problem, group of output rows, row slice); per 32-row chunk the
 //     workgroup turns a 32 x (16 TG) block of g and a 32 x (16 TH) block of h into MFMA fragments: work-item (column quad, row octet)
 //     loads 8 x 16 bytes (branch-free buffer loads: rows beyond the slice and columns beyond the matrix read as zeros), splits its 32
 //     values and writes each column's eight rows as one 16-byte fragment lane per split part -- fragment block = (operand tile, part):
@@ -67,6 +67,11 @@ __device__ __forceinline__ DwbWave dwb_wave_map(const DwbProblem& g, int wave) {
     return m;
 }
 
+// chunk boundary: this wave's fragment writes have landed in LDS (lgkmcnt(0)), then the workgroup barrier -- NOT __syncthreads(),
+// whose release fence also waits for the vector-memory counter, i.e. for the operand loads of the chunk after next that are
+// meant to stay in flight across the barrier
+#define DWB_BARRIER() do { __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8)); __builtin_amdgcn_s_barrier(); } while (0)
+
 // the 8 x 16 bytes of one split item: rows k0 + 8 octet + e of four consecutive columns
 struct DwbStage { float4 v[8]; };
 
@@ -103,15 +108,19 @@ __device__ __forceinline__ void dwb_job(const DwbProblem& g, int group, int spli
     const int m0 = (g.layout == 0) ? group * 128 : 0;          // first output row of this job's g block
     const DwbWave wm = dwb_wave_map(g, wave);
 
-    // ---- this work-item's split item: column quad cq of the concatenated [g block | h block] columns, row octet oct ---------------
-    const int nq = 4 * (g.tg + g.th);                          // column quads of a chunk (<= 96)
-    const int cq = tid % nq, oct = tid / nq;                   // (items beyond 4 octets idle: 512 work-items, <= 384 items)
-    const bool item = oct < 4;
-    const bool is_g = cq < 4 * g.tg;
-    const int col_local = 4 * (is_g ? cq : cq - 4 * g.tg);     // first column inside the operand block
+    // ---- this work-item's split item: (column quad, row octet) of the g block or of the h block.  Whole WAVES belong to one
+    // operand (g items: waves [0, wg), h items from wave wg on), so the operand's buffer descriptor is wave-uniform -- chosen per
+    // LANE it made hipcc wrap every load into a waterfall loop (a v_readfirstlane loop over the descriptors present in the wave)
+    const int wg = (16 * g.tg + 63) >> 6;                      // waves that split g (tg <= 16 -> <= 4; h: th <= 16 -> <= 4)
+    const bool is_g = wave < wg;                               // (wave-uniform)
+    const int local = (wave - (is_g ? 0 : wg)) * 64 + lane;    // item index inside the operand
+    const int nq = 4 * (is_g ? g.tg : g.th);                   // column quads of the operand block
+    const int cq = local % nq, oct = local / nq;
+    const bool item = oct < 4;                                 // (a partial last wave, and the waves beyond both operands, idle)
+    const int col_local = 4 * cq;                              // first column inside the operand block
     const int col = is_g ? m0 + col_local : col_local;         // ... inside the matrix
     const int ld = is_g ? g.ldg : g.ldh;
-    const bool col_ok = item && col < (is_g ? g.gcols : g.hcols) && (!is_g || col_local < 16 * g.tg);
+    const bool col_ok = item && col < (is_g ? g.gcols : g.hcols);
     // rows [0, kend) of the operand: everything beyond this split's slice reads as zero
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(is_g ? g.G : g.H), 0, kend * ld * 4, 0x00020000);
     const int base_off = col_ok ? (8 * oct * ld + col) * 4 : DW2_OOB;
@@ -136,7 +145,7 @@ __device__ __forceinline__ void dwb_job(const DwbProblem& g, int group, int spli
         dwb_split_store(st, lds + dst_off);
     }
     dwb_load(st, rsrc, base_off, ld, kbeg + DWB_BK);
-    __syncthreads();
+    DWB_BARRIER();
 
     const unsigned char* frag_lane = lds + lane * 16;
     for (int k0 = kbeg, c = 0; k0 < kend; k0 += DWB_BK, ++c) {
@@ -175,7 +184,7 @@ __device__ __forceinline__ void dwb_job(const DwbProblem& g, int group, int spli
             }
             if (b == 1) dwb_load(st, rsrc, base_off, ld, k0 + 2 * DWB_BK);
         }
-        __syncthreads();
+        DWB_BARRIER();
     }
 
     // ---- epilogue: slab tiles; D register r of lane (i, q) of tile (a, b) is row 16 (ot0 + a) + 4 q + r, column 16 (it0 + b) + i --------
