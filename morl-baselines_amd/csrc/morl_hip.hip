@@ -1328,7 +1328,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         const int M = n.dims[l + 1], N = n.dims[l];
         if (!(M <= 256 && N <= 256 && (M <= 32 || N <= 128 || (M > 32 && N > 128)))) dwb_ok = false;
     }
-    static const bool dwb_env = [] { const char* e = getenv("MORL_DW_BF16"); return e ? atoi(e) != 0 : true; }();      // (A/B)
+    static const bool dwb_env = [] { const char* e = getenv("MORL_DW_BF16"); return e ? atoi(e) != 0 : false; }();     // (off until it wins)
     if (dwb_ok && dwb_env) {
         DwbArgs a{};
         a.n = L;
