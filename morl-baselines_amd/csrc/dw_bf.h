@@ -6,8 +6,11 @@
 // accumulated in fp32 by v_mfma_f32_16x16x32_bf16 inside a row slice, slices summed in a fixed order by grad_reduce_ranges_kernel
 // (dw_tiles.h) exactly like the fp32 engine's.  Both operands are fp32 in HBM (what the forward / backward chains saved); a
 // workgroup splits its slices ON THE FLY:
-//   * 512 work-items = 8 waves, one workgroup per CU (whole waves split g, the others h: wave-uniform buffer descriptors).  A job = (problem, group of output rows, row slice); per 32-row chunk the
-//     workgroup turns a 32 x (16 TG) block of g and a 32 x (16 TH) block of h into MFMA fragments: work-item (column quad, row octet)
+//   * 512 work-items = 8 waves, one workgroup per CU, SPECIALISED: waves 4-7 are producers (loads, split, fragment writes, db:
+//     vector ALU only), waves 0-3 consumers (fragment reads + MFMAs only) -- one of each per SIMD, so the split of chunk c + 1 runs on
+//     the vector ALU while chunk c is on the matrix pipe.  (The first version gave every wave both jobs and a run-time tile count:
+//     a branch around every MFMA and the split serialised in front of them -- 143 us against the fp32 engine's 69.)
+//     A job = (problem, group of output rows, row slice); per 32-row chunk the producers turn a 32 x (16 TG) block of g and a 32 x (16 TH) block of h into MFMA fragments: work-item (column quad, row octet)
 //     loads 8 x 16 bytes (branch-free buffer loads: rows beyond the slice and columns beyond the matrix read as zeros), splits its 32
 //     values and writes each column's eight rows as one 16-byte fragment lane per split part -- fragment block = (operand tile, part):
 //     1 KB, lane (column, octet) at 16 (column + 16 octet), so the MFMA phase's ds_read_b128 is 1 KB contiguous, conflict-free.
@@ -55,18 +58,6 @@ struct DwbArgs {
     SumTreeUpdate per;         // per.tree != NULL: one extra workgroup (block `jobs`) applies the step's PER priority update (as dw_tiles.h)
 };
 
-// this wave's output tiles: rows 16 (ot0 + a), a < n_ot <= 2; columns 16 (it0 + b), b < n_it <= 8 -- tile indices INSIDE the chunk's
-// operand blocks (g tile / h tile numbers)
-struct DwbWave { int ot0, n_ot, it0, n_it; };
-__device__ __forceinline__ DwbWave dwb_wave_map(const DwbProblem& g, int wave) {
-    DwbWave m;
-    if (g.layout == 0) { m.ot0 = 2 * (wave >> 1); m.n_ot = min(2, g.tg - m.ot0); m.it0 = 8 * (wave & 1); m.n_it = min(8, g.th - m.it0); }
-    else if (g.layout == 1) { m.ot0 = 2 * wave; m.n_ot = min(2, g.tg - m.ot0); m.it0 = 0; m.n_it = g.th; }
-    else { m.ot0 = 0; m.n_ot = g.tg; m.it0 = 2 * wave; m.n_it = min(2, g.th - m.it0); }
-    m.n_ot = max(0, m.n_ot); m.n_it = max(0, m.n_it);
-    return m;
-}
-
 // chunk boundary: this wave's fragment writes have landed in LDS (lgkmcnt(0)), then the workgroup barrier -- NOT __syncthreads(),
 // whose release fence also waits for the vector-memory counter, i.e. for the operand loads of the chunk after next that are
 // meant to stay in flight across the barrier
@@ -83,7 +74,7 @@ __device__ __forceinline__ void dwb_load(DwbStage& s, __amdgpu_buffer_rsrc_t rsr
         s.v[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base_off + (k0 + e) * ld * 4, 0, 0));
 }
 
-// split the item's four columns (8 rows each) and write them as fragment lanes of `buf`: column j -> tile (col / 16), lane (col % 16) + 16 octet
+// split the item's four columns (8 rows each) and write them as fragment lanes: column j -> lane (col % 16) + 16 octet of its tile
 __device__ __forceinline__ void dwb_split_store(const DwbStage& s, unsigned char* lane_dst) {
     // lane_dst = buf + ((tile * 3) * 64 + (col0 % 16) + 16 octet) * 16: the four columns are four consecutive lanes of one tile
 #pragma unroll
@@ -100,89 +91,113 @@ __device__ __forceinline__ void dwb_split_store(const DwbStage& s, unsigned char
     }
 }
 
+// one operand's split item of a producer work-item: (column quad cq, row octet oct) of the operand block, or idle
+struct DwbItem {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int base_off, ld, dst_off;
+    bool live;
+};
+__device__ __forceinline__ DwbItem dwb_item(const float* mat, int ld, int cols, int col0, int tiles, int tile0, int ptid, int kend) {
+    DwbItem it;
+    const int nq = 4 * tiles;                      // column quads of the operand block
+    const int cq = ptid % nq, oct = ptid / nq;
+    it.live = tiles > 0 && oct < 4;
+    const int col_local = 4 * cq;
+    const bool col_ok = it.live && col0 + col_local < cols;
+    it.ld = ld;
+    // rows [0, kend) of the operand: everything beyond this split's slice reads as zero
+    it.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)mat, 0, kend * ld * 4, 0x00020000);
+    it.base_off = col_ok ? (8 * oct * ld + col0 + col_local) * 4 : DW2_OOB;
+    it.dst_off = (((tile0 + (col_local >> 4)) * 3) * 64 + (col_local & 15) + 16 * oct) * 16;
+    return it;
+}
+
+// PRODUCER waves (4 .. 7, 256 work-items): per chunk each work-item splits at most one g item and one h item.
+// CONSUMER waves (0 .. 3): N_OT x N_IT output tiles each, every MFMA unconditional (tile counts are compile-time; operand tiles
+// beyond the matrix are zeros the producers wrote), the N_OT accumulators of an input tile alternating.
+template <int N_OT, int N_IT>
 __device__ __forceinline__ void dwb_job(const DwbProblem& g, int group, int split, int rows, long long slab_stride, unsigned char* lds) {
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kbeg = split * g.k_per_split;
     const int kend = min(rows, kbeg + g.k_per_split);
     const int m0 = (g.layout == 0) ? group * 128 : 0;          // first output row of this job's g block
-    const DwbWave wm = dwb_wave_map(g, wave);
+    const bool producer = wave >= 4;
 
-    // ---- this work-item's split item: (column quad, row octet) of the g block or of the h block.  Whole WAVES belong to one
-    // operand (g items: waves [0, wg), h items from wave wg on), so the operand's buffer descriptor is wave-uniform -- chosen per
-    // LANE it made hipcc wrap every load into a waterfall loop (a v_readfirstlane loop over the descriptors present in the wave)
-    const int wg = (16 * g.tg + 63) >> 6;                      // waves that split g (tg <= 16 -> <= 4; h: th <= 16 -> <= 4)
-    const bool is_g = wave < wg;                               // (wave-uniform)
-    const int local = (wave - (is_g ? 0 : wg)) * 64 + lane;    // item index inside the operand
-    const int nq = 4 * (is_g ? g.tg : g.th);                   // column quads of the operand block
-    const int cq = local % nq, oct = local / nq;
-    const bool item = oct < 4;                                 // (a partial last wave, and the waves beyond both operands, idle)
-    const int col_local = 4 * cq;                              // first column inside the operand block
-    const int col = is_g ? m0 + col_local : col_local;         // ... inside the matrix
-    const int ld = is_g ? g.ldg : g.ldh;
-    const bool col_ok = item && col < (is_g ? g.gcols : g.hcols);
-    // rows [0, kend) of the operand: everything beyond this split's slice reads as zero
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(is_g ? g.G : g.H), 0, kend * ld * 4, 0x00020000);
-    const int base_off = col_ok ? (8 * oct * ld + col) * 4 : DW2_OOB;
-    const int tile = (is_g ? 0 : g.tg) + (col_local >> 4);
-    const int dst_off = ((tile * 3) * 64 + (col_local & 15) + 16 * oct) * 16;
-
-    f32x4 acc[2][8];
+    if (producer) {
+        const int ptid = tid - 256;
+        const DwbItem ig = dwb_item(g.G, g.ldg, g.gcols, m0, g.tg, 0, ptid, kend);
+        const DwbItem ih = dwb_item(g.H, g.ldh, g.hcols, 0, g.th, g.tg, ptid, kend);
+        float csum[4] = {0.f, 0.f, 0.f, 0.f};                  // running column sums of this item's g columns (db)
+        DwbStage sg, sh;
+        auto put = [&](unsigned char* buf) {
+            if (ig.live) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};                      // running column sums of this item's g columns (db)
-
-    DwbStage st;
-    // prologue: chunk 0 split into buffer 0, chunk 1 in flight
-    dwb_load(st, rsrc, base_off, ld, kbeg);
-    if (item) {
-        if (is_g) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { csum[0] += st.v[e].x; csum[1] += st.v[e].y; csum[2] += st.v[e].z; csum[3] += st.v[e].w; }
+                for (int e = 0; e < 8; ++e) { csum[0] += sg.v[e].x; csum[1] += sg.v[e].y; csum[2] += sg.v[e].z; csum[3] += sg.v[e].w; }
+                dwb_split_store(sg, buf + ig.dst_off);
+            }
+            if (ih.live) dwb_split_store(sh, buf + ih.dst_off);
+        };
+        // prologue: chunk 0 split into buffer 0, chunk 1 in flight
+        dwb_load(sg, ig.rsrc, ig.base_off, ig.ld, kbeg);
+        dwb_load(sh, ih.rsrc, ih.base_off, ih.ld, kbeg);
+        put(lds);
+        dwb_load(sg, ig.rsrc, ig.base_off, ig.ld, kbeg + DWB_BK);
+        dwb_load(sh, ih.rsrc, ih.base_off, ih.ld, kbeg + DWB_BK);
+        DWB_BARRIER();
+        for (int k0 = kbeg, c = 0; k0 < kend; k0 += DWB_BK, ++c) {
+            // chunk c is being multiplied out of buffer c & 1; chunk c + 1 (in the registers) goes to the other one, chunk c + 2 into
+            // flight behind it
+            if (k0 + DWB_BK < kend) put(lds + ((c & 1) ^ 1) * DWB_BUF_BYTES);
+            dwb_load(sg, ig.rsrc, ig.base_off, ig.ld, k0 + 2 * DWB_BK);
+            dwb_load(sh, ih.rsrc, ih.base_off, ih.ld, k0 + 2 * DWB_BK);
+            DWB_BARRIER();
         }
-        dwb_split_store(st, lds + dst_off);
+        // db: the four octets of a g column, in octet order (the operand buffers are free: the loop ended with a barrier)
+        float* scr = reinterpret_cast<float*>(lds);            // [4 octets][256 columns]
+        if (g.colsum != nullptr && ig.live) {
+            const int nq = 4 * g.tg, cq = ptid % nq, oct = ptid / nq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) scr[oct * 256 + 4 * cq + j] = csum[j];
+        }
+        __syncthreads();
+        if (g.colsum != nullptr && ptid < 16 * g.tg && m0 + ptid < g.M)
+            g.colsum[(size_t)split * slab_stride + m0 + ptid] = ((scr[ptid] + scr[256 + ptid]) + scr[512 + ptid]) + scr[768 + ptid];
+        return;
     }
-    dwb_load(st, rsrc, base_off, ld, kbeg + DWB_BK);
-    DWB_BARRIER();
 
+    // ---- consumer: output tiles rows 16 (ot0 + a), columns 16 (it0 + b) ------------------------------------------------------------
+    int ot0, it0;
+    if (g.layout == 0) { ot0 = 4 * (wave >> 1); it0 = 8 * (wave & 1); }          // 128 x 256: 2 x 2 waves of 64 x 128
+    else if (g.layout == 1) { ot0 = 4 * wave; it0 = 0; }                          // 256 x 64: 4 x 1 waves of 64 x 64
+    else { ot0 = 0; it0 = 4 * wave; }                                            // 32 x 256: 1 x 4 waves of 32 x 64
+    f32x4 acc[N_OT][N_IT];
+#pragma unroll
+    for (int a = 0; a < N_OT; ++a)
+#pragma unroll
+        for (int b = 0; b < N_IT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    DWB_BARRIER();                                             // (the producers' prologue)
     const unsigned char* frag_lane = lds + lane * 16;
+    constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};
     for (int k0 = kbeg, c = 0; k0 < kend; k0 += DWB_BK, ++c) {
         const unsigned char* cur = frag_lane + (c & 1) * DWB_BUF_BYTES;
-        unsigned char* nxt = lds + ((c & 1) ^ 1) * DWB_BUF_BYTES;
-        // A fragments (g tiles of this wave): once per chunk
-        bf_u32x4 fa[2][3];
+        const unsigned char* hb = cur + (g.tg + it0) * 3 * BF_BLOCK;
+        // A fragments (the wave's g tiles): once per chunk; B fragments (h tiles): one tile ahead
+        bf_u32x4 fa[N_OT][3], fb[2][3];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < N_OT; ++a) bf_frag_load(fa[a], cur + (ot0 + a) * 3 * BF_BLOCK, 0);
+        bf_frag_load(fb[0], hb, 0);
+        BF_PIN();
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                fa[a][pl] = (a < wm.n_ot) ? *reinterpret_cast<const bf_u32x4*>(cur + ((wm.ot0 + a) * 3 + pl) * BF_BLOCK) : bf_u32x4{0u, 0u, 0u, 0u};
-        const unsigned char* hb = cur + (g.tg + wm.it0) * 3 * BF_BLOCK;
-        bf_u32x4 fb[2][3];
-        if (wm.n_it > 0) bf_frag_load(fb[0], hb, 0);
-        const bool more = k0 + DWB_BK < kend;                  // chunk c + 1 exists: it is in `st`, goes to the other buffer
+        for (int b = 0; b < N_IT; ++b) {
+            // D[o][i] += g^T[o][k] h[k][i]: A = the g fragment (lane = output row), B = the h fragment (lane = input column)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            if (b < wm.n_it) {
-                if (b + 1 < wm.n_it) bf_frag_load(fb[(b + 1) & 1], hb, b + 1);
-                // D[o][i] += g^T[o][k] h[k][i]: A = the g fragment (lane = output row), B = the h fragment (lane = input column)
-                constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};
+            for (int p = 0; p < 6; ++p) {
+                if (b + 1 < N_IT && p < 3) fb[(b + 1) & 1][2 - p] = *reinterpret_cast<const bf_u32x4*>(hb + (3 * (b + 1) + 2 - p) * BF_BLOCK);
 #pragma unroll
-                for (int p = 0; p < 6; ++p) {
-                    acc[0][b] = bf_mfma(fa[0][pw[p]], fb[b & 1][px[p]], acc[0][b]);
-                    if (wm.n_ot > 1) acc[1][b] = bf_mfma(fa[1][pw[p]], fb[b & 1][px[p]], acc[1][b]);
-                }
+                for (int a = 0; a < N_OT; ++a) acc[a][b] = bf_mfma(fa[a][pw[p]], fb[b & 1][px[p]], acc[a][b]);
+                BF_PIN();
             }
-            // the split of chunk c + 1 rides under the first tiles' MFMAs, the loads of chunk c + 2 behind it
-            if (b == 1 && more && item) {
-                if (is_g) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { csum[0] += st.v[e].x; csum[1] += st.v[e].y; csum[2] += st.v[e].z; csum[3] += st.v[e].w; }
-                }
-                dwb_split_store(st, nxt + dst_off);
-            }
-            if (b == 1) dwb_load(st, rsrc, base_off, ld, k0 + 2 * DWB_BK);
         }
         DWB_BARRIER();
     }
@@ -191,29 +206,17 @@ __device__ __forceinline__ void dwb_job(const DwbProblem& g, int group, int spli
     float* __restrict__ C = g.C + (size_t)split * slab_stride;
     const int li = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < N_OT; ++a)
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            if (a < wm.n_ot && b < wm.n_it) {
-                const int colc = 16 * (wm.it0 + b) + li;
+        for (int b = 0; b < N_IT; ++b) {
+            const int colc = 16 * (it0 + b) + li;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = m0 + 16 * (wm.ot0 + a) + 4 * q + r;
-                    if (row < g.M && colc < g.N) C[(size_t)row * g.ldc + colc] = acc[a][b][r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + 16 * (ot0 + a) + 4 * q + r;
+                if (row < g.M && colc < g.N) C[(size_t)row * g.ldc + colc] = acc[a][b][r];
             }
         }
-    // db: the four octets of a g column, in octet order (the operand buffers are free: the loop ended with a barrier)
-    if (g.colsum != nullptr) {
-        float* scr = reinterpret_cast<float*>(lds);            // [4 octets][16 tg columns]
-        if (item && is_g) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) scr[oct * 256 + col_local + j] = csum[j];
-        }
-        __syncthreads();
-        if (tid < 16 * g.tg && m0 + tid < g.M)
-            g.colsum[(size_t)split * slab_stride + m0 + tid] = ((scr[tid] + scr[256 + tid]) + scr[512 + tid]) + scr[768 + tid];
-    }
+    __syncthreads();                                           // (pairs with the producers' db barrier)
 }
 
 __global__ __launch_bounds__(DWB_THREADS) void dw_bf_kernel(DwbArgs a) {
@@ -229,7 +232,9 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf_kernel(DwbArgs a) {
     while (q + 1 < a.n && job >= a.p[q + 1].job_start) ++q;
     const DwbProblem& g = a.p[q];
     const int local = job - g.job_start;
-    dwb_job(g, local % g.groups, local / g.groups, a.rows, a.slab_stride, lds);
+    if (g.layout == 0) dwb_job<4, 8>(g, local % g.groups, local / g.groups, a.rows, a.slab_stride, lds);
+    else if (g.layout == 1) dwb_job<4, 4>(g, 0, local, a.rows, a.slab_stride, lds);
+    else dwb_job<2, 4>(g, 0, local, a.rows, a.slab_stride, lds);
 }
 
 }  // namespace morl

@@ -224,7 +224,7 @@ static int g_ac_gemm_mode = 0;      // 0 auto, 1 always LDS tiles, 2 always wave
 static bool use_wave_tiles(long long tiles128) {
     if (g_ac_gemm_mode == 1) return false;
     if (g_ac_gemm_mode == 2) return true;
-    static const long long below = [] { const char* e = getenv("MORL_AC_WAVE_TILES_BELOW"); return e ? atoll(e) : 128ll; }();   // (tuning)
+    constexpr long long below = 128;
     return tiles128 < below;
 }
 
@@ -265,8 +265,8 @@ extern "C" int morl_ac_set_gemm_mode(int mode) {
 // 16-row tiles of mlp_chain16.h CAPQL 0.197 -> 0.164, MOSAC 0.342 -> 0.276, GPI-PD continuous 0.261 -> 0.250.  (With 32-row
 // tiles the fused pass LOSES: a pass is then 4-8 workgroups whose tiles carry a whole 256 x 256 layer each, 23 us per pass
 // against 3 x 8 us for the wave-tile GEMMs that spread a layer over 32 workgroups -- CAPQL 0.214, MOSAC 0.367.)
-// MORL_AC_CHAIN=0 restores the per-layer engines.
-static const bool g_ac_chain = [] { const char* e = getenv("MORL_AC_CHAIN"); return e ? atoi(e) != 0 : true; }();
+// (the per-layer engines stay for networks the chain does not take: LayerNorm / Dropout, widths beyond 256)
+static constexpr bool g_ac_chain = true;
 
 static bool chain_shape_ok(const Mlp& m) {
     if (!g_ac_chain || m.ln || m.L < 2 || m.L > MORL_MAX_LAYERS) return false;
@@ -326,7 +326,7 @@ static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
     m.tail_units = units - m.tail_base;
     m.tail_halves = (2 * m.tail_units <= S) ? 1 : 0;
     m.stagger = 1;
-    static const bool xcd_env = [] { const char* e = getenv("MORL_AC_XCD_CONTIG"); return e ? atoi(e) != 0 : true; }();   // (tuning)
+    constexpr bool xcd_env = true;
     for (int q = 0; q < n; ++q) m.xcd_contig |= (xcd_env && chains[q].nb > 1) ? 1 : 0;
     if (chains[0].fast == 2) hipLaunchKernelGGL(mlp_chain2_n_kernel, dim3(S), dim3(CH_THREADS), 0, s, m);
     else hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
@@ -757,7 +757,7 @@ static int sacd_update(morl_ac_ctx* c, const morl_ac_state* st, const morl_ac_ba
     // K-major shadow copies for the forward GEMMs (single learners / small populations; see morl_ac_update)
     int widest = 0;
     for (int l = 1; l < Q.L; ++l) widest = std::max(widest, Q.dims[l]);
-    static const bool shadow_env = [] { const char* e = getenv("MORL_AC_SHADOW"); return e ? atoi(e) != 0 : true; }();
+    constexpr bool shadow_env = true;
     // (a population whose every pass runs on the 32 / 64-row chain needs none: N-major weight stream, see chain_nmajor)
     const bool nmajor = chain_nmajor(Q, rows, c->QG) && chain_nmajor(P, rows, PG);
     const bool use_wt = shadow_env && !nmajor &&
@@ -919,7 +919,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     }
 
     // ---- K-major shadow copies of every parameter set this update reads in a forward pass (one launch) -----------------------
-    static const bool shadow_env = [] { const char* e = getenv("MORL_AC_SHADOW"); return e ? atoi(e) != 0 : true; }();
+    constexpr bool shadow_env = true;
     // only where the wave-tile engine runs the layers (single learners, small populations): the LDS-tiled engine of a large
     // population stages 128 x 32 chunks either way and measured slower with the K-major weights (1.70 vs 1.27 ms at 64 learners)
     int widest = 0;

@@ -216,7 +216,6 @@ struct morl_ctx {
     size_t ev_used = 0;
     int chain_stagger = 3;   // mlp_chain2: job-order staggering of co-resident workgroups (Chain2Multi::stagger)
     unsigned int* cu_tickets = nullptr;
-    int chain_sched = 1;     // mlp_chain2: instruction interleave pinned with sched_group_barrier (0: hipcc's own schedule)
     int fused_tm = 0;        // 0: pick the row tile per launch (>= 2 workgroups per CU when possible), else 64 / 32
     int num_cus = 256;
 };
@@ -359,8 +358,6 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         if (net->dims[l + 1] <= 32 && (net->dims[l] & 3)) c->fused_ok = false;            // forward narrow step: K = dims[l]
         if (l >= 1 && net->dims[l] <= 32 && (net->dims[l + 1] & 3)) c->fused_ok = false;   // backward narrow step: K = dims[l+1]
     }
-    if (const char* e = getenv("MORL_CHAIN_SCHED")) c->chain_sched = atoi(e) ? 1 : 0;
-    if (const char* e = getenv("MORL_CHAIN_STAGGER")) c->chain_stagger = std::max(0, std::min(3, atoi(e)));
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -671,10 +668,7 @@ static int timing_open(morl_ctx* c, int kind, hipStream_t s, int* slot) {
         // no system-scope fence at the record: the fence is not part of the kernel, delays the launch behind it (a
         // bracketed chain launch measured 128.9 us with it, 126.4 us without; rocprofv3's kernel trace says 124.7 us)
         // and costs the step 2 us per record
-        static const unsigned ev_flags = [] {
-            const char* e = getenv("MORL_EV_FLAGS");   // (tuning)
-            return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)hipEventDisableSystemFence;
-        }();
+        const unsigned ev_flags = (unsigned)hipEventDisableSystemFence;
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreateWithFlags(&e0, ev_flags));
         HIP_TRY(hipEventCreateWithFlags(&e1, ev_flags));
@@ -703,10 +697,7 @@ static int chain2_fill(morl_ctx* c, Chain2Multi& m, const ChainArgs* chains, int
         units += std::max(1, chains[q].nb) * ((chains[q].rows + 63) / 64);
     }
     for (int q = n; q <= CH_MAX_MULTI; ++q) m.unit_start[q] = units;
-    if (S <= 0) {
-        S = 2 * c->num_cus;
-        if (const char* e = getenv("MORL_CHAIN_SLOTS")) S = std::max(1, atoi(e));   // (tuning)
-    }
+    if (S <= 0) S = 2 * c->num_cus;      // (measured: 1 / 1.5 / 3 / 4 workgroups per CU are all slower, profiles/r03_knob_sweeps.json)
     // small jobs: no more slots than half units, so that every slot has work
     S = std::max(1, std::min(S, 2 * units));
     m.full_rounds = units / S;
@@ -739,8 +730,7 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
         Chain16Multi m16{};
         const int tiles = chain16_fill(m16, chains, n);
         hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
-    } else if (c->chain_sched) hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
-    else hipLaunchKernelGGL(mlp_chain2_kernel<0>, dim3(S), dim3(CH_THREADS), 0, s, m);
+    } else hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
     LAUNCH_CHECK("mlp_chain2");
     return timing_close(c, slot, s);
 }
@@ -859,10 +849,7 @@ extern "C" int morl_ctx_set_timing(morl_ctx* c, int every) {
     // the first event pairs are made HERE, not lazily inside the region the caller is about to time (a pair costs ~10 us of host
     // time to create; a 20-step run used to create its 20 pairs one per step)
     if (every != 0) {
-        static const unsigned ev_flags = [] {
-            const char* e = getenv("MORL_EV_FLAGS");   // (tuning)
-            return e ? (unsigned)strtoul(e, nullptr, 0) : (unsigned)hipEventDisableSystemFence;
-        }();
+        const unsigned ev_flags = (unsigned)hipEventDisableSystemFence;
         while (c->ev_start.size() < 64) {
             hipEvent_t e0, e1;
             HIP_TRY(hipEventCreateWithFlags(&e0, ev_flags));
@@ -1202,10 +1189,9 @@ static EnvelopeTdArgs td_args(morl_ctx* c, const morl_update_cfg* cfg, const mor
         p.part_stride = 2ll * B * p.part_floats;
     }
     // waves per workgroup ~ candidates per TD row: 4 at the single-GPU 64 x 6, up to 16 when a sharded job reduces over
-    // all gathered weights (MORL_TD_WAVES overrides, for tuning)
+    // all gathered weights
     const long long n_cand = cfg->envelope ? (long long)W * A : A;
-    int td_waves = n_cand >= 256 ? 16 : (n_cand >= 64 ? 8 : 4);
-    if (const char* e = getenv("MORL_TD_WAVES")) td_waves = std::max(1, std::min(ENV_MAX_WAVES, atoi(e)));
+    const int td_waves = n_cand >= 256 ? 16 : (n_cand >= 64 ? 8 : 4);
     *td_waves_out = td_waves;
     return p;
 }
@@ -1326,7 +1312,8 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     bool dwb_ok = c->bits_bf && c->bf_mode == 1 && dw2_ok && c->dw_mode == 3;
     for (int l = 0; l < L && dwb_ok; ++l) {
         const int M = n.dims[l + 1], N = n.dims[l];
-        if (!(M <= 256 && N <= 256 && (M <= 32 || N <= 128 || (M > 32 && N > 128)))) dwb_ok = false;
+        // layouts of dw_bf.h: a narrow output (<= 32 rows), a narrow input (<= 64 columns), or groups of 128 rows x <= 256 columns
+        if (!(M <= 256 && N <= 256 && (M <= 32 || N <= 64 || M > 32))) dwb_ok = false;
     }
     static const bool dwb_env = [] { const char* e = getenv("MORL_DW_BF16"); return e ? atoi(e) != 0 : false; }();     // (off until it wins)
     if (dwb_ok && dwb_env) {
@@ -1347,19 +1334,19 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             q.colsum = c->slabs + c->offB[l];
             q.M = n.dims[l + 1]; q.N = n.dims[l];
             q.gcols = q.ldg; q.hcols = q.ldh;      // (pad columns of dq / x0 are written as zeros by their producers)
-            const int th = (q.N + 15) / 16;
-            if (q.M <= 32) { q.layout = 2; q.groups = 1; q.tg = (q.M + 15) / 16; q.th = th; cost[l] = q.tg * std::min(2, th) * 6; }
-            else if (q.N <= 128) { q.layout = 1; q.groups = 1; q.tg = (q.M + 15) / 16; q.th = th; cost[l] = 2 * th * 6; }
-            else { q.layout = 0; q.groups = (q.M + 127) / 128; q.tg = std::min(8, (q.M + 15) / 16); q.th = th; cost[l] = 2 * std::min(8, th) * 6; }
-            cost_rows += (double)q.groups * rows * cost[l] / 96.0;
+            // operand tiles per chunk are the kernel's compile-time shapes (tiles beyond the matrix are zero fragments); cost = MFMAs
+            // of a consumer wave per chunk
+            if (q.M <= 32) { q.layout = 2; q.groups = 1; q.tg = 2; q.th = 16; cost[l] = 2 * 4 * 6; }
+            else if (q.N <= 64) { q.layout = 1; q.groups = 1; q.tg = 16; q.th = 4; cost[l] = 4 * 4 * 6; }
+            else { q.layout = 0; q.groups = (q.M + 127) / 128; q.tg = 8; q.th = 16; cost[l] = 4 * 8 * 6; }
+            cost_rows += (double)q.groups * rows * cost[l] / 192.0;
         }
         int target = c->num_cus;                   // one 512-work-item workgroup per CU (144 KB of LDS)
-        if (const char* e = getenv("MORL_DW_JOBS")) target = std::max(1, atoi(e));     // (tuning)
         int base = round_up(std::max(1, (int)std::ceil(cost_rows / (double)target)), DWB_BK);
         for (;;) {      // the split count of every problem must fit the slab buffer
             bool ok = true;
             for (int l = 0; l < L; ++l) {
-                const int kps = round_up((int)((long long)base * 96 / cost[l]), DWB_BK);
+                const int kps = round_up((int)((long long)base * 192 / cost[l]), DWB_BK);
                 if ((rows + kps - 1) / kps > c->max_splits) ok = false;
             }
             if (ok) break;
@@ -1369,7 +1356,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         splits = 0;
         for (int l = 0; l < L; ++l) {
             DwbProblem& q = a.p[l];
-            q.k_per_split = round_up((int)((long long)base * 96 / cost[l]), DWB_BK);
+            q.k_per_split = round_up((int)((long long)base * 192 / cost[l]), DWB_BK);
             q.splits = (rows + q.k_per_split - 1) / q.k_per_split;
             q.job_start = jobs;
             jobs += q.splits * q.groups;
@@ -1417,8 +1404,6 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             q.gcols = q.ldg;                 // (pad columns of dq / x0 are written as zeros by their producers)
             q.hcols = q.ldh;
             q.c_vec2 = ((((uintptr_t)q.C) & 7u) == 0 && (q.ldc & 1) == 0 && (c->P & 1) == 0) ? 1 : 0;
-            static const int dw_nt = [] { const char* e = getenv("MORL_DW_NT"); return e ? atoi(e) : 0; }();   // (A/B)
-            if (q.c_vec2 && dw_nt) q.c_vec2 = 2;
             unit_tiles += (double)q.tiles_m * q.tiles_n * lay_cost[q.layout] / 4.0;
         }
         int target = 2 * c->num_cus;
@@ -1457,7 +1442,6 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             per_done = true;
         }
         a.stagger = 0;
-        if (const char* e = getenv("MORL_DW_STAGGER")) a.stagger = std::max(0, atoi(e));     // (tuning)
         int tslot = -1;
         if ((rc = timing_open(c, MORL_TIMED_DW, s, &tslot))) return rc;
         hipLaunchKernelGGL(dw_tiles_kernel, dim3(jobs + extra), dim3(DW2_THREADS), 0, s, a);
@@ -1466,7 +1450,6 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     } else {
     // the generic engine (operand rows that are not 16-byte aligned, or morl_ctx_set_dw_mode(ctx, 2)): one workgroup per CU
     splits = std::max(1, std::min(c->max_splits, (c->num_cus + c->dw_tiles - 1) / c->dw_tiles));
-    if (const char* e = getenv("MORL_DW_SPLITS")) splits = std::max(1, std::min(c->max_splits, atoi(e)));   // (tuning)
     int kps = round_up((rows + splits - 1) / splits, GEMM_BK);
     splits = (rows + kps - 1) / kps;
     {
@@ -1690,7 +1673,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     // The PER tree update (17 us of serial levels) rides as an extra workgroup of a longer launch: the weight gradients when they
     // take longer than it does, the clip + Adam launch for small steps (<= 4 096 rows: the weight-gradient launch would wait for
     // it -- 37 instead of 20 us at 256 x 8)
-    static const int per_adam_rows = [] { const char* e = getenv("MORL_PER_ADAM_ROWS"); return e ? atoi(e) : 4096; }();   // (tuning)
+    constexpr int per_adam_rows = 4096;
     const bool per_with_adam = cfg->per_tree && out->priority && B <= ST_MAX_B && rows <= per_adam_rows && c->dw_mode == 3;
     morl_update_cfg core_cfg = *cfg;
     if (per_with_adam) core_cfg.per_tree = nullptr;
@@ -1833,10 +1816,8 @@ extern "C" int morl_envelope_step_sharded(morl_ctx* c, morl_comm* comm, float* p
     float* recv = (world == parts) ? slab_all : slab_all + (size_t)(i_offset / W_local) * 2 * half;
     if ((rc = morl_envelope_slabs(c, params_online, params_target, next_obs, w_loc, B, W_local, slab_local, stream))) return rc;
     if ((rc = morl_allgather_q_begin(comm, slab_local, recv, 2 * half, stream))) return rc;
-    static const bool no_overlap = [] { const char* e = getenv("MORL_COMM_NO_OVERLAP"); return e && atoi(e) != 0; }();   // (diagnostics)
-    if (no_overlap && (rc = morl_comm_wait(comm, stream))) return rc;
     if ((rc = morl_envelope_main_forward(c, params_online, obs, w_loc, B, W_local, stream))) return rc;   // beside the exchange
-    if (!no_overlap && (rc = morl_comm_wait(comm, stream))) return rc;
+    if ((rc = morl_comm_wait(comm, stream))) return rc;
     morl_update_cfg shard = *cfg;
     shard.apply_step = 0;
     shard.main_forward_done = 1;
