@@ -129,29 +129,39 @@ __device__ __forceinline__ void dwb_job(const DwbProblem& g, int group, int spli
         const DwbItem ig = dwb_item(g.G, g.ldg, g.gcols, m0, g.tg, 0, ptid, kend);
         const DwbItem ih = dwb_item(g.H, g.ldh, g.hcols, 0, g.th, g.tg, ptid, kend);
         float csum[4] = {0.f, 0.f, 0.f, 0.f};                  // running column sums of this item's g columns (db)
-        DwbStage sg, sh;
-        auto put = [&](unsigned char* buf) {
+        // two register stages: chunk c + 1 waits in one to be split while chunk c + 2 is in flight into the other -- a chunk is ~1.5 us
+        // of matrix-core time, a loaded HBM round trip about as long: with ONE stage (the first producer/consumer version) every chunk
+        // waited for its operands and the launch ran at the memory LATENCY (96 us)
+        DwbStage sg[2], sh[2];
+        auto put = [&](const DwbStage& a, const DwbStage& b, unsigned char* buf) {
             if (ig.live) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { csum[0] += sg.v[e].x; csum[1] += sg.v[e].y; csum[2] += sg.v[e].z; csum[3] += sg.v[e].w; }
-                dwb_split_store(sg, buf + ig.dst_off);
+                for (int e = 0; e < 8; ++e) { csum[0] += a.v[e].x; csum[1] += a.v[e].y; csum[2] += a.v[e].z; csum[3] += a.v[e].w; }
+                dwb_split_store(a, buf + ig.dst_off);
             }
-            if (ih.live) dwb_split_store(sh, buf + ih.dst_off);
+            if (ih.live) dwb_split_store(b, buf + ih.dst_off);
         };
-        // prologue: chunk 0 split into buffer 0, chunk 1 in flight
-        dwb_load(sg, ig.rsrc, ig.base_off, ig.ld, kbeg);
-        dwb_load(sh, ih.rsrc, ih.base_off, ih.ld, kbeg);
-        put(lds);
-        dwb_load(sg, ig.rsrc, ig.base_off, ig.ld, kbeg + DWB_BK);
-        dwb_load(sh, ih.rsrc, ih.base_off, ih.ld, kbeg + DWB_BK);
+        auto load = [&](DwbStage& a, DwbStage& b, int k0) {
+            dwb_load(a, ig.rsrc, ig.base_off, ig.ld, k0);
+            dwb_load(b, ih.rsrc, ih.base_off, ih.ld, k0);
+        };
+        // prologue: chunk 0 split into buffer 0, chunks 1 and 2 in flight
+        load(sg[0], sh[0], kbeg);
+        load(sg[1], sh[1], kbeg + DWB_BK);
+        put(sg[0], sh[0], lds);
+        load(sg[0], sh[0], kbeg + 2 * DWB_BK);
         DWB_BARRIER();
-        for (int k0 = kbeg, c = 0; k0 < kend; k0 += DWB_BK, ++c) {
-            // chunk c is being multiplied out of buffer c & 1; chunk c + 1 (in the registers) goes to the other one, chunk c + 2 into
-            // flight behind it
-            if (k0 + DWB_BK < kend) put(lds + ((c & 1) ^ 1) * DWB_BUF_BYTES);
-            dwb_load(sg, ig.rsrc, ig.base_off, ig.ld, k0 + 2 * DWB_BK);
-            dwb_load(sh, ih.rsrc, ih.base_off, ih.ld, k0 + 2 * DWB_BK);
+        // iteration c: chunk c is being multiplied out of buffer c & 1; chunk c + 1 (stage (c + 1) & 1) goes to the other buffer,
+        // chunk c + 3 into flight behind it (into the stage just emptied); chunk c + 2 stays in flight across the barrier
+        for (int k0 = kbeg, c = 0; k0 < kend; k0 += 2 * DWB_BK, c += 2) {
+            if (k0 + DWB_BK < kend) put(sg[1], sh[1], lds + DWB_BUF_BYTES);
+            load(sg[1], sh[1], k0 + 3 * DWB_BK);
             DWB_BARRIER();
+            if (k0 + DWB_BK < kend) {
+                if (k0 + 2 * DWB_BK < kend) put(sg[0], sh[0], lds);
+                load(sg[0], sh[0], k0 + 4 * DWB_BK);
+                DWB_BARRIER();
+            }
         }
         // db: the four octets of a g column, in octet order (the operand buffers are free: the loop ended with a barrier)
         float* scr = reinterpret_cast<float*>(lds);            // [4 octets][256 columns]

@@ -1334,11 +1334,14 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             q.colsum = c->slabs + c->offB[l];
             q.M = n.dims[l + 1]; q.N = n.dims[l];
             q.gcols = q.ldg; q.hcols = q.ldh;      // (pad columns of dq / x0 are written as zeros by their producers)
-            // operand tiles per chunk are the kernel's compile-time shapes (tiles beyond the matrix are zero fragments); cost = MFMAs
-            // of a consumer wave per chunk
-            if (q.M <= 32) { q.layout = 2; q.groups = 1; q.tg = 2; q.th = 16; cost[l] = 2 * 4 * 6; }
-            else if (q.N <= 64) { q.layout = 1; q.groups = 1; q.tg = 16; q.th = 4; cost[l] = 4 * 4 * 6; }
-            else { q.layout = 0; q.groups = (q.M + 127) / 128; q.tg = 8; q.th = 16; cost[l] = 4 * 8 * 6; }
+            // operand tiles per chunk are the kernel's compile-time shapes (tiles beyond the matrix are zero fragments).  Jobs are
+            // balanced by their CHUNK count, not by their MFMAs: a chunk costs a 256 x 256 layer's job 192 MFMAs per consumer wave
+            // (1.5 us) and the narrow problems 96 / 48, but no chunk is shorter than the producers' load -> split -> write turn-around
+            // -- sized by MFMAs, the head's 56-chunk jobs set the launch's duration (96 us)
+            if (q.M <= 32) { q.layout = 2; q.groups = 1; q.tg = 2; q.th = 16; }
+            else if (q.N <= 64) { q.layout = 1; q.groups = 1; q.tg = 16; q.th = 4; }
+            else { q.layout = 0; q.groups = (q.M + 127) / 128; q.tg = 8; q.th = 16; }
+            cost[l] = 192;
             cost_rows += (double)q.groups * rows * cost[l] / 192.0;
         }
         int target = c->num_cus;                   // one 512-work-item workgroup per CU (144 KB of LDS)
