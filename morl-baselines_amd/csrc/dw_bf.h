@@ -237,7 +237,9 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf_kernel(DwbArgs a) {
         if ((int)blockIdx.x == a.jobs && a.per.tree != nullptr) sumtree_update_body(a.per, lds);
         return;
     }
-    const int job = (int)blockIdx.x;
+    // consecutive jobs = the output-row groups of one row slice, which read the same slice of h_l: keep them on one XCD's L2 (the
+    // dispatcher places block b on XCD b % 8)
+    const int job = xcd_remap((int)blockIdx.x, a.jobs);
     int q = 0;
     while (q + 1 < a.n && job >= a.p[q + 1].job_start) ++q;
     const DwbProblem& g = a.p[q];

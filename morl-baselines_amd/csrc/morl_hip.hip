@@ -1315,7 +1315,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         // layouts of dw_bf.h: a narrow output (<= 32 rows), a narrow input (<= 64 columns), or groups of 128 rows x <= 256 columns
         if (!(M <= 256 && N <= 256 && (M <= 32 || N <= 64 || M > 32))) dwb_ok = false;
     }
-    static const bool dwb_env = [] { const char* e = getenv("MORL_DW_BF16"); return e ? atoi(e) != 0 : false; }();     // (off until it wins)
+    static const bool dwb_env = [] { const char* e = getenv("MORL_DW_BF16"); return e ? atoi(e) != 0 : true; }();      // (A/B: 0 = dw_tiles.h)
     if (dwb_ok && dwb_env) {
         DwbArgs a{};
         a.n = L;
