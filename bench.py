@@ -211,6 +211,8 @@ def traffic_fields(bf16):
     if not ks:
         return {"traffic": None, "traffic_source": None}
     name = "morl::mlp_chain_bf_kernel" if bf16 else "morl::mlp_chain2_kernel"
+    if not any(k.startswith(name) for k in ks):          # (the committed summary is of the other arithmetic: say nothing rather than mix)
+        return {"traffic": None, "traffic_source": f"{src} holds no {name} launches"}
     dom = next((v for k, v in ks.items() if k.startswith(name)), None)
     step = sum(v["hbm_bytes"] for k, v in ks.items() if k.startswith("morl::") and "sumtree_set" not in k and "polyak" not in k)
     return {"traffic": dom["hbm_bytes"] if dom else None,
@@ -445,7 +447,8 @@ def _roofline(res, rows_rank):
     cores every fp32 product is six bf16 products: ``achieved`` / ``frac`` then price the SIX-fold flop against the dense bf16 peak,
     and ``fp32_equivalent_tflops`` is the algorithmic rate (what the same work would be called on the f32-input MFMA)."""
     n_chain, chain_ms, timed_steps = res["n_chain"], res["chain_ms"], res["timed_steps"]
-    bf16 = bool(res.get("bf16"))
+    bf16 = bool(int(res.get("bf16") or 0) & 1)
+    dw_bf16 = bool(int(res.get("bf16") or 0) & 2)
     # algorithmic flop of ONE launch of each kind (this rank's rows): the three-pass forward launch (or the launches of a sharded
     # step), the two-pass forward launch of a lazily evaluated step, the backward-dX launch, the weight-gradient launch
     flop_kind = {"forward": rows_rank * 3 * FWD_FLOP_ROW / max(1, res.get("fwd_launches_per_step") or 1),
@@ -463,12 +466,13 @@ def _roofline(res, rows_rank):
     per_kernel = {}
     chain_name = "mlp_chain_bf (split-bf16, 6 products)" if bf16 else "mlp_chain2 (f32-input MFMA)"
     name_kind = {"forward": chain_name + " forward (3 passes)", "forward2": chain_name + " forward (2 passes: online next-state + training)",
-                 "backward": chain_name + " backward-dX", "dw": "dw_tiles (dW, db; f32-input MFMA)"}
+                 "backward": chain_name + " backward-dX",
+                 "dw": "dw_bf (dW, db; split-bf16, 6 products)" if dw_bf16 else "dw_tiles (dW, db; f32-input MFMA)"}
     for k, (n_k, ms_k) in kinds.items():
         if n_k:
             us = ms_k * 1e3 / n_k
             tf = flop_kind[k] / (us * 1e-6) / 1e12
-            on_bf = bf16 and k != "dw"
+            on_bf = dw_bf16 if k == "dw" else bf16
             per_kernel[k] = {"kernel": name_kind[k], "launches_timed": n_k, "avg_launch_us": us,
                              "algorithmic_flop_per_launch": flop_kind[k], "fp32_equivalent_tflops": tf,
                              "achieved": tf * (BF16_PRODUCTS if on_bf else 1), "peak": PEAK_BF16_MFMA_TFLOPS if on_bf else PEAK_FP32_MFMA_TFLOPS,
@@ -666,7 +670,7 @@ def main():
                     "gpu_ms_per_step_events": res["gpu_ms_per_step_events"], "last_loss": res["loss"],
                     "roofline": _roofline(res, rows_step // parts),
                     "lazy_target_rows_last_step": res.get("lazy_target_rows"),
-                    "bf16": bool(res.get("bf16")),
+                    "bf16": int(res.get("bf16") or 0),
                     "whole_step_algorithmic_tflops": rows_step * (4 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) / (ms * 1e-3) / 1e12,
                     "whole_step_executed_tflops": ((rows_step * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) +
                                                     parts * res["lazy_target_rows"] * FWD_FLOP_ROW) if res.get("lazy_target_rows")
@@ -694,8 +698,8 @@ def main():
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": ("f32 (6 x bf16 split products, fp32 accumulate: online forward passes + dX backward; f32-input MFMA: target "
-                      "rows, dW)" if h["bf16"] else "f32"),
+            "dtype": ("f32 (6 x bf16 split products, fp32 accumulate: online forward passes, dX backward" +
+                      (", dW; f32-input MFMA: target rows)" if h["bf16"] & 2 else "; f32-input MFMA: target rows, dW)") if h["bf16"] & 1 else "f32"),
             "data": "synthetic",
             "config": {"workload": f"Envelope.update(): B={B} x W={W_head} x R={R}, obs {D}, {A} actions, net {ARCH}, "
                                    f"PER {'on' if a.per else 'off'}, buffer 20k seeded transitions (BASELINE.md s3)",
@@ -709,9 +713,10 @@ def main():
                        "shard_axis": head_axis,
                        "transport": head_res.get("transport"),
                        "engine": head_res["engine"],
-                       "arithmetic": ("online forward passes and dX backward on the bf16 matrix cores as six split-bf16 products per "
-                                      "fp32 product (csrc/mlp_chain_bf.h, fp32-class accuracy); MORL_EXACT_F32=1 keeps every GEMM on the "
-                                      "f32-input MFMA" if h["bf16"] else "every GEMM on the f32-input MFMA (exact fp32 fma chains)"),
+                       "arithmetic": ("online forward passes, dX backward" + (" and weight gradients" if h["bf16"] & 2 else "") +
+                                      " on the bf16 matrix cores as six split-bf16 products per fp32 product (csrc/mlp_chain_bf.h, "
+                                      "dw_bf.h: fp32-class accuracy); MORL_EXACT_F32=1 keeps every GEMM on the f32-input MFMA"
+                                      if h["bf16"] & 1 else "every GEMM on the f32-input MFMA (exact fp32 fma chains)"),
                        "setup": "0.5 s device clock ramp (dummy GEMMs) before the warm-up steps; ms_per_step_no_ramp is the same "
                                 "run shape without it"},
             "updates_per_s": h["updates_per_s"],

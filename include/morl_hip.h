@@ -190,8 +190,8 @@ int morl_ctx_set_lazy_targets(morl_ctx* ctx, int enable);
  * enable = 1 (or MORL_EXACT_F32=1) keeps every GEMM on the f32-input MFMA (rounds 1-3; the A/B leg).  The target network's rows,
  * the weight gradients and every other entry point are f32-input MFMA in both settings.  Returns the previous setting. */
 int morl_ctx_set_exact_f32(morl_ctx* ctx, int enable);
-/* 1 if the last morl_envelope_update on this context took the split-bf16 path, 0 if it ran on the f32-input MFMA (what bench.py
- * prices its roofline against) */
+/* What the last morl_envelope_update on this context ran on (what bench.py prices its roofline against): bit 0 = forward passes and
+ * dX backward as split-bf16 products, bit 1 = the weight gradients too; 0 = everything on the f32-input MFMA */
 int morl_ctx_last_step_bf16(morl_ctx* ctx);
 int morl_ctx_lazy_target_rows(morl_ctx* ctx, int* rows, void* stream);
 /* The shadow copies made by morl_envelope_prepare are consumed ONLY by the gradient step that directly follows it

@@ -282,7 +282,9 @@ __device__ __forceinline__ void bf_acc_init(f32x4 (&acc)[NTILES], const float* b
 }
 
 // Epilogue of a wide step, lane-local: (ReLU | mask bits) -> fp32 copy to HBM -> sign bits -> split into the next step's B operand.
-// Vector-memory instructions issued per lane when SAVE: 16 row stores (+ 1 word of bits) -- BF_SAVE_VMEM, counted by the waits.
+// Vector-memory instructions a wave issues per epilogue when MODE != 0: 16 row stores + 1 (the sign-bit word's store of the training
+// forward, or the NEXT step's mask-word load of the backward chain) -- BF_SAVE_VMEM, counted by the next layer's first two waits.
+// (A wave whose 16 rows all lie beyond the chain's rows issues none of them and so waits for too little: its results are discarded.)
 // `keep`: the step's mask word (bits_in), loaded by the caller at the START of the step -- a load inside the epilogue would be waited
 // for with vmcnt(0), i.e. behind both weight stages in flight (the first version did: one drained ring per layer).
 constexpr int BF_SAVE_VMEM = 17;
@@ -293,25 +295,36 @@ __device__ __forceinline__ float bf_relu(float a) {
     return __builtin_bit_cast(float, u > 0 ? u : 0);
 }
 
-template <bool SAVE>
+// MODE: 0 no-grad forward (nothing leaves but the next operand), 1 training forward (fp32 copy + sign bits out), 2 backward (mask
+// word in, fp32 copy out) -- compile-time, so that neither chain carries the other's bit arithmetic (two to three vector
+// instructions per value: a sixth of the epilogue).
+template <int MODE>
 __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x4 (&x)[8][3], const BfStep& st, int row, bool row_ok,
                                                  size_t bits_idx, int q, unsigned long long keep) {
-    unsigned long long pos = 0ull;
+    unsigned pos_lo = 0u, pos_hi = 0u;
+    const int keep_lo = (int)(unsigned)keep, keep_hi = (int)(unsigned)(keep >> 32);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int T = 2 * s + (e >> 2), r = e & 3;
+            const int T = 2 * s + (e >> 2), r = e & 3, k = 4 * T + r;
             float a = acc[T][r];
-            if (st.relu) a = bf_relu(a);
-            if (SAVE) {
-                a = ((keep >> (4 * T + r)) & 1ull) ? a : 0.f;
-                if (a > 0.f) pos |= 1ull << (4 * T + r);
+            if (MODE != 2 && st.relu) a = bf_relu(a);
+            if (MODE == 2) {
+                // a &= -(bit k of keep): the sign-extended one-bit field is the AND mask (v_bfe_i32 + v_and)
+                const int m = ((k < 32 ? keep_lo : keep_hi) << (31 - (k & 31))) >> 31;
+                a = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & m);
+            }
+            if (MODE == 1) {
+                // after the ReLU the bit pattern is 0 or a positive integer: min(u, 1) is the sign bit (v_min_u32 + v_lshl_or)
+                const unsigned u = __builtin_bit_cast(unsigned, a);
+                const unsigned bit = u < 1u ? u : 1u;
+                if (k < 32) pos_lo |= bit << k; else pos_hi |= bit << (k - 32);
             }
             v[e] = a;
         }
-        if (SAVE && st.out != nullptr && row_ok) {
+        if (MODE != 0 && st.out != nullptr && row_ok) {
             float* o = st.out + (size_t)row * st.ldout + 32 * s + 4 * q;
             *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(o + 16) = make_float4(v[4], v[5], v[6], v[7]);
@@ -323,13 +336,13 @@ __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x
         x[s][1] = bf_u32x4{mid[0], mid[1], mid[2], mid[3]};
         x[s][2] = bf_u32x4{lo[0], lo[1], lo[2], lo[3]};
     }
-    if (SAVE && st.bits_out != nullptr) st.bits_out[bits_idx] = pos;
+    if (MODE == 1 && st.bits_out != nullptr) st.bits_out[bits_idx] = ((unsigned long long)pos_hi << 32) | pos_lo;
 }
 
 // ---- one 64-row tile through a whole chain ----------------------------------------------------------------------------------------
-// K0S: k-steps of the first step (1 or 2); SAVE: the chain writes per-step outputs / sign bits (training forward, backward) -- a
-// compile-time switch because the counted waits depend on the stores issued.
-template <int NW, int K0S, bool SAVE>
+// K0S: k-steps of the first step (1 or 2); MODE: see bf_wide_epilogue -- the chain writes per-step outputs (1, 2) and sign bits (1) or
+// reads mask words (2); compile-time also because the counted waits depend on the stores issued.
+template <int NW, int K0S, int MODE>
 __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsigned char* ring_lds, float* bias_lds) {
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -392,7 +405,7 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
         }
     }
     unsigned long long keep = ~0ull;     // the first step's mask word (backward chain)
-    if (SAVE && p.step[0].bits_in != nullptr) keep = p.step[0].bits_in[bits_idx];
+    if (MODE == 2 && p.step[0].bits_in != nullptr) keep = p.step[0].bits_in[bits_idx];
     // everything this lane loaded or stored so far has to be out of the way of the counted waits: drain once, before the loop
     // (the two DMA groups in flight are waited for here too -- the only vmcnt(0) of the kernel, at its very start)
     BF_VMCNT(0);
@@ -403,24 +416,24 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     // ---- first step ---------------------------------------------------------------------------------------------------------------
     bf_acc_init<16>(acc, bias_lds, q);
     bf_wide_step<NW, K0S, 0>(acc, x, ring, lane);
-    bf_wide_epilogue<SAVE>(acc, x, p.step[0], row, row_ok, bits_idx, q, keep);
+    bf_wide_epilogue<MODE>(acc, x, p.step[0], row, row_ok, bits_idx, q, keep);
     // ---- the 256 x 256 steps --------------------------------------------------------------------------------------------------------
     for (int s = 1; s < n_wide; ++s) {
-        // this step's mask word: ONE more vector-memory instruction behind the epilogue's stores, in front of this step's DMA groups
-        // -- retired (in issue order) long before the epilogue reads it, counted by the first two stage waits like the stores
+        // this step's mask word: the seventeenth vector-memory instruction behind the previous epilogue's sixteen stores, in front of
+        // this step's DMA groups -- retired (in issue order) long before the epilogue reads it
         keep = ~0ull;
-        if (SAVE && p.step[s].bits_in != nullptr) keep = p.step[s].bits_in[bits_idx];
+        if (MODE == 2 && p.step[s].bits_in != nullptr) keep = p.step[s].bits_in[bits_idx];
         bf_acc_init<16>(acc, bias_lds + s * BF_WIDE, q);
-        bf_wide_step<NW, 8, SAVE ? BF_SAVE_VMEM + 1 : 0>(acc, x, ring, lane);
-        bf_wide_epilogue<SAVE>(acc, x, p.step[s], row, row_ok, bits_idx, q, keep);
+        bf_wide_step<NW, 8, MODE != 0 ? BF_SAVE_VMEM : 0>(acc, x, ring, lane);
+        bf_wide_epilogue<MODE>(acc, x, p.step[s], row, row_ok, bits_idx, q, keep);
     }
     // ---- the head -----------------------------------------------------------------------------------------------------------------
     if (p.head) {
         const BfStep& st = p.step[p.n_steps - 1];
         f32x4 hacc[2];
         bf_acc_init<2>(hacc, bias_lds + (p.n_steps - 1) * BF_WIDE, q);
-        if (st.N > 16) bf_head_step<NW, 2, SAVE ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
-        else bf_head_step<NW, 1, SAVE ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
+        if (st.N > 16) bf_head_step<NW, 2, MODE != 0 ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
+        else bf_head_step<NW, 1, MODE != 0 ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
         if (st.out != nullptr && row_ok) {
 #pragma unroll
             for (int T = 0; T < 2; ++T)
@@ -449,13 +462,15 @@ __device__ __forceinline__ void mlp_chain_bf_entry(const BfMulti& m, unsigned ch
     const BfChain& p = m.c[qn];
     const int row0 = (tile - m.tile_start[qn]) * (16 * NW);
     float* bias_lds = reinterpret_cast<float*>(lds + BF_RING * BF_STAGE_BYTES);
-    const bool save = p.step[0].out != nullptr || p.step[0].bits_out != nullptr || p.step[0].bits_in != nullptr;
+    const int mode = p.step[0].bits_in != nullptr ? 2 : (p.step[0].out != nullptr || p.step[0].bits_out != nullptr) ? 1 : 0;
     if (p.k0_steps == 1) {
-        if (save) bf_chain_body<NW, 1, true>(p, row0, lds, bias_lds);
-        else bf_chain_body<NW, 1, false>(p, row0, lds, bias_lds);
+        if (mode == 2) bf_chain_body<NW, 1, 2>(p, row0, lds, bias_lds);
+        else if (mode == 1) bf_chain_body<NW, 1, 1>(p, row0, lds, bias_lds);
+        else bf_chain_body<NW, 1, 0>(p, row0, lds, bias_lds);
     } else {
-        if (save) bf_chain_body<NW, 2, true>(p, row0, lds, bias_lds);
-        else bf_chain_body<NW, 2, false>(p, row0, lds, bias_lds);
+        if (mode == 2) bf_chain_body<NW, 2, 2>(p, row0, lds, bias_lds);
+        else if (mode == 1) bf_chain_body<NW, 2, 1>(p, row0, lds, bias_lds);
+        else bf_chain_body<NW, 2, 0>(p, row0, lds, bias_lds);
     }
 }
 

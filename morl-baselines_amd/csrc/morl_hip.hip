@@ -203,6 +203,7 @@ struct morl_ctx {
     unsigned char* bf_stream = nullptr;
     int bf_fwd_blocks = 0, bf_bwd_blocks = 0, bf_k0_steps = 0, bf_head_tiles = 0;
     const float* fresh_bf = nullptr;     // parameters the streams were split from by this step's morl_envelope_prepare (one-shot)
+    bool dw_bf_last = false;             // the last step's weight gradients ran on dw_bf.h
     bool bits_bf = false;                // the last training forward left its sign bits in mlp_chain_bf.h's lane layout
     const unsigned int* skip_flag = nullptr;   // one-shot: the next clip + Adam launch leaves the optimiser state alone if this
                                          // device word is non-zero (a timed-out collective of the single-hop transport)
@@ -1009,11 +1010,11 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
     return MORL_OK;
 }
 
-// 1 if the last morl_envelope_update on this context ran its online forward passes and its dX backward pass as split-bf16 products
-// (mlp_chain_bf.h), 0 if on the f32-input MFMA
+// bit 0: the last morl_envelope_update on this context ran its online forward passes and its dX backward pass as split-bf16
+// products (mlp_chain_bf.h); bit 1: its weight gradients too (dw_bf.h); 0: everything on the f32-input MFMA
 extern "C" int morl_ctx_last_step_bf16(morl_ctx* c) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
-    return c->bits_bf ? 1 : 0;
+    return (c->bits_bf ? 1 : 0) | (c->dw_bf_last ? 2 : 0);
 }
 
 extern "C" int morl_ctx_set_exact_f32(morl_ctx* c, int enable) {
@@ -1316,6 +1317,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         if (!(M <= 256 && N <= 256 && (M <= 32 || N <= 64 || M > 32))) dwb_ok = false;
     }
     static const bool dwb_env = [] { const char* e = getenv("MORL_DW_BF16"); return e ? atoi(e) != 0 : true; }();      // (A/B: 0 = dw_tiles.h)
+    c->dw_bf_last = dwb_ok && dwb_env;
     if (dwb_ok && dwb_env) {
         DwbArgs a{};
         a.n = L;

@@ -54,9 +54,10 @@ class QNetContext:
         (``morl_ctx_set_exact_f32``, csrc/mlp_chain_bf.h).  Returns the old setting."""
         return bool(self.lib.lib.morl_ctx_set_exact_f32(self.handle, int(bool(enable))))
 
-    def last_step_bf16(self) -> bool:
-        """Did the last ``envelope_update`` on this context run its online passes / dX backward as split-bf16 products?"""
-        return bool(self.lib.lib.morl_ctx_last_step_bf16(self.handle))
+    def last_step_bf16(self) -> int:
+        """What the last ``envelope_update`` on this context ran as split-bf16 products: bit 0 the online passes + dX backward, bit 1
+        the weight gradients; 0 = everything on the f32-input MFMA."""
+        return int(self.lib.lib.morl_ctx_last_step_bf16(self.handle))
 
     def lazy_target_rows(self, like: th.Tensor) -> int:
         """Distinct (transition, weight) pairs the last lazily evaluated step ran the target network on (synchronises)."""

@@ -58,7 +58,7 @@ def test_roofline_record_arithmetic(bench):
     assert r["fp32_equivalent_tflops"] == pytest.approx(r["achieved"]) and r["frac_of_fp32_mfma_peak"] == pytest.approx(r["frac"])
     # the same launches on the bf16 matrix cores (six split-bf16 products per fp32 product): the executed flop is six-fold, the peak
     # the dense bf16 one, and the algorithmic rate is reported beside it
-    rb = bench._roofline(dict(res2, bf16=True, kinds={"forward2": (7, 7 * 0.071), "backward": (7, 7 * 0.043), "dw": (6, 6 * 0.070)},
+    rb = bench._roofline(dict(res2, bf16=1, kinds={"forward2": (7, 7 * 0.071), "backward": (7, 7 * 0.043), "dw": (6, 6 * 0.070)},
                               chain_ms=7 * 0.071 + 7 * 0.043), rows)
     eq = rows * (2 * bench.FWD_FLOP_ROW + bench.BWD_DX_FLOP_ROW) / 2 / (0.057e-3) / 1e12
     assert rb["peak"] == 2500.0 and rb["fp32_equivalent_tflops"] == pytest.approx(eq, rel=1e-9)
@@ -66,6 +66,10 @@ def test_roofline_record_arithmetic(bench):
     assert rb["per_kernel"]["dw"]["peak"] == 157.3 and rb["per_kernel"]["forward2"]["peak"] == 2500.0
     assert rb["per_kernel"]["forward2"]["achieved"] == pytest.approx(6 * rows * 2 * bench.FWD_FLOP_ROW / 71e-6 / 1e12)
     assert "bf16" in rb["kernel"] and 0.0 < rb["frac"] < 1.0
+    rb3 = bench._roofline(dict(res2, bf16=3, kinds={"forward2": (7, 7 * 0.071), "backward": (7, 7 * 0.043), "dw": (6, 6 * 0.056)},
+                               chain_ms=7 * 0.071 + 7 * 0.043), rows)          # ... and the weight gradients too (dw_bf.h)
+    assert rb3["per_kernel"]["dw"]["peak"] == 2500.0
+    assert rb3["per_kernel"]["dw"]["achieved"] == pytest.approx(6 * rows * bench.FWD_FLOP_ROW / 56e-6 / 1e12)
     # traffic: HBM bytes per launch of the DOMINANT kernel (its own figure, not an average over kernels) of the newest committed PMC
     # summary (profiles/), labelled as a constant of the repository; the step's total and its ratio to SURVEY 8(d)'s 7.7 MB beside it
     ks, src = bench.committed_pmc()
