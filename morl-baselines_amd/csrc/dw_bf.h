@@ -10,9 +10,10 @@
 //     vector ALU only), waves 0-3 consumers (fragment reads + MFMAs only) -- one of each per SIMD, so the split of chunk c + 1 runs on
 //     the vector ALU while chunk c is on the matrix pipe.  (The first version gave every wave both jobs and a run-time tile count:
 //     a branch around every MFMA and the split serialised in front of them -- 143 us against the fp32 engine's 69.)
-//     A job = (problem, group of output rows, row slice); per 32-row chunk the producers turn a 32 x (16 TG) block of g and a 32 x (16 TH) block of h into MFMA fragments: work-item (column quad, row octet)
-//     loads 8 x 16 bytes (branch-free buffer loads: rows beyond the slice and columns beyond the matrix read as zeros), splits its 32
-//     values and writes each column's eight rows as one 16-byte fragment lane per split part -- fragment block = (operand tile, part):
+//     A job = (problem, group of output rows, row slice); per 32-row chunk the producers turn a 32 x (16 TG) block of g and a
+//     32 x (16 TH) block of h into MFMA fragments: a work-item takes up to three (column pair, row octet) items, loads 8 x 8 bytes each
+//     (branch-free buffer loads: rows beyond the slice and columns beyond the matrix read as zeros), splits the 16 values and
+//     writes each column's eight rows as one 16-byte fragment lane per split part -- fragment block = (operand tile, part):
 //     1 KB, lane (column, octet) at 16 (column + 16 octet), so the MFMA phase's ds_read_b128 is 1 KB contiguous, conflict-free.
 //     db rides along: the g items keep running column sums (combined over the four octets in a fixed order at the end).
 //   * TG + TH <= 24 tiles = 72 KB per chunk, double-buffered (144 KB): chunk c is multiplied while chunk c + 1 is split and written
@@ -63,25 +64,55 @@ struct DwbArgs {
 // meant to stay in flight across the barrier
 #define DWB_BARRIER() do { __builtin_amdgcn_s_waitcnt(15 | (3 << 14) | (7 << 4) | (0 << 8)); __builtin_amdgcn_s_barrier(); } while (0)
 
-// the 8 x 16 bytes of one split item: rows k0 + 8 octet + e of four consecutive columns
-struct DwbStage { float4 v[8]; };
+// the 8 x 8 bytes of one split item: rows k0 + 8 octet + e of TWO consecutive columns
+struct DwbStage { float2 v[8]; };
 
-__device__ __forceinline__ void dwb_load(DwbStage& s, __amdgpu_buffer_rsrc_t rsrc, int base_off, int ld, int k0) {
-    // (base_off = byte offset of (row 8 octet, column) or DW2_OOB for an idle item / a column beyond the matrix; the row goes
-    // through the VECTOR offset: the hardware's range check does not see the scalar one)
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-        s.v[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, base_off + (k0 + e) * ld * 4, 0, 0));
+// one split item of a producer work-item: (column pair cp, row octet oct) of the g block or of the h block, or idle.  A chunk has
+// 32 (TG + TH) <= 768 items = at most three per producer work-item (slot k: items [256 k, 256 k + 256)); the g items come first and
+// 32 TG is a multiple of 64, so every (slot, wave) belongs to ONE operand and its buffer descriptor is wave-uniform (chosen per LANE
+// it made hipcc wrap every load into a waterfall loop).  Column PAIRS, not quads: three items per work-item for the 24-tile
+// chunk of a 256 x 256 layer -- every producer wave carries the same work (with quads waves 4, 5 had two items and 6, 7 one) --
+// and the eight lanes of a ds_write_b128 group then cover eight different bank quads (quads: 2-way conflicts on every write).
+struct DwbItem {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int base_off, ld, dst_off;
+    bool live, is_g;
+};
+__device__ __forceinline__ DwbItem dwb_item(const DwbProblem& g, int m0, int slot, int pwave, int lane, int kend) {
+    DwbItem it;
+    const int first = (slot * 4 + pwave) * 64;                 // first item of this (slot, wave)
+    const int n_g = 32 * g.tg, n_h = 32 * g.th;
+    it.is_g = first < n_g;                                     // (wave-uniform)
+    const int local = first + lane - (it.is_g ? 0 : n_g);      // item index inside the operand
+    const int npairs = 8 * (it.is_g ? g.tg : g.th);            // column pairs of the operand block
+    const int cp = local % npairs, oct = local / npairs;
+    it.live = local < (it.is_g ? n_g : n_h);
+    const int col_local = 2 * cp;
+    const int col = (it.is_g ? m0 : 0) + col_local;
+    it.ld = it.is_g ? g.ldg : g.ldh;
+    const bool col_ok = it.live && col < (it.is_g ? g.gcols : g.hcols);     // (column counts are even: pairs are in or out as a whole)
+    // rows [0, kend) of the operand: everything beyond this split's slice reads as zero
+    it.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(it.is_g ? g.G : g.H), 0, kend * it.ld * 4, 0x00020000);
+    it.base_off = col_ok ? (8 * oct * it.ld + col) * 4 : DW2_OOB;
+    const int tile = (it.is_g ? 0 : g.tg) + (col_local >> 4);
+    it.dst_off = ((tile * 3) * 64 + (col_local & 15) + 16 * oct) * 16;
+    return it;
 }
 
-// split the item's four columns (8 rows each) and write them as fragment lanes: column j -> lane (col % 16) + 16 octet of its tile
-__device__ __forceinline__ void dwb_split_store(const DwbStage& s, unsigned char* lane_dst) {
-    // lane_dst = buf + ((tile * 3) * 64 + (col0 % 16) + 16 octet) * 16: the four columns are four consecutive lanes of one tile
+__device__ __forceinline__ void dwb_load(DwbStage& s, const DwbItem& it, int k0) {
+    // (the row goes through the VECTOR offset: the hardware's range check does not see the scalar one)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int e = 0; e < 8; ++e)
+        s.v[e] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(it.rsrc, it.base_off + (k0 + e) * it.ld * 4, 0, 0));
+}
+
+// split the item's two columns (8 rows each) and write them as fragment lanes: column j -> lane (col % 16) + 16 octet of its tile
+__device__ __forceinline__ void dwb_split_store(const DwbStage& s, unsigned char* lane_dst) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
         float c[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) c[e] = (j == 0) ? s.v[e].x : (j == 1) ? s.v[e].y : (j == 2) ? s.v[e].z : s.v[e].w;
+        for (int e = 0; e < 8; ++e) c[e] = (j == 0) ? s.v[e].x : s.v[e].y;
         unsigned hi[4], mid[4], lo[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) bf_split2(c[2 * u], c[2 * u + 1], hi[u], mid[u], lo[u]);
@@ -91,28 +122,7 @@ __device__ __forceinline__ void dwb_split_store(const DwbStage& s, unsigned char
     }
 }
 
-// one operand's split item of a producer work-item: (column quad cq, row octet oct) of the operand block, or idle
-struct DwbItem {
-    __amdgpu_buffer_rsrc_t rsrc;
-    int base_off, ld, dst_off;
-    bool live;
-};
-__device__ __forceinline__ DwbItem dwb_item(const float* mat, int ld, int cols, int col0, int tiles, int tile0, int ptid, int kend) {
-    DwbItem it;
-    const int nq = 4 * tiles;                      // column quads of the operand block
-    const int cq = ptid % nq, oct = ptid / nq;
-    it.live = tiles > 0 && oct < 4;
-    const int col_local = 4 * cq;
-    const bool col_ok = it.live && col0 + col_local < cols;
-    it.ld = ld;
-    // rows [0, kend) of the operand: everything beyond this split's slice reads as zero
-    it.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)mat, 0, kend * ld * 4, 0x00020000);
-    it.base_off = col_ok ? (8 * oct * ld + col0 + col_local) * 4 : DW2_OOB;
-    it.dst_off = (((tile0 + (col_local >> 4)) * 3) * 64 + (col_local & 15) + 16 * oct) * 16;
-    return it;
-}
-
-// PRODUCER waves (4 .. 7, 256 work-items): per chunk each work-item splits at most one g item and one h item.
+// PRODUCER waves (4 .. 7, 256 work-items): per chunk each work-item splits up to three items.
 // CONSUMER waves (0 .. 3): N_OT x N_IT output tiles each, every MFMA unconditional (tile counts are compile-time; operand tiles
 // beyond the matrix are zeros the producers wrote), the N_OT accumulators of an input tile alternating.
 template <int N_OT, int N_IT>
@@ -125,52 +135,62 @@ __device__ __forceinline__ void dwb_job(const DwbProblem& g, int group, int spli
     const bool producer = wave >= 4;
 
     if (producer) {
-        const int ptid = tid - 256;
-        const DwbItem ig = dwb_item(g.G, g.ldg, g.gcols, m0, g.tg, 0, ptid, kend);
-        const DwbItem ih = dwb_item(g.H, g.ldh, g.hcols, 0, g.th, g.tg, ptid, kend);
-        float csum[4] = {0.f, 0.f, 0.f, 0.f};                  // running column sums of this item's g columns (db)
-        // two register stages: chunk c + 1 waits in one to be split while chunk c + 2 is in flight into the other -- a chunk is ~1.5 us
-        // of matrix-core time, a loaded HBM round trip about as long: with ONE stage (the first producer/consumer version) every chunk
-        // waited for its operands and the launch ran at the memory LATENCY (96 us)
-        DwbStage sg[2], sh[2];
-        auto put = [&](const DwbStage& a, const DwbStage& b, unsigned char* buf) {
-            if (ig.live) {
+        const int pwave = wave - 4;
+        DwbItem it[3];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { csum[0] += a.v[e].x; csum[1] += a.v[e].y; csum[2] += a.v[e].z; csum[3] += a.v[e].w; }
-                dwb_split_store(a, buf + ig.dst_off);
-            }
-            if (ih.live) dwb_split_store(b, buf + ih.dst_off);
+        for (int k = 0; k < 3; ++k) it[k] = dwb_item(g, m0, k, pwave, lane, kend);
+        float csum[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // running column sums of this work-item's g columns (db)
+        // two register stages: chunk c + 1 waits in one to be split while chunk c + 2 is in flight into the other -- a chunk is ~1.5 us
+        // of matrix-core time, a loaded HBM round trip about as long: with ONE stage (the first producer / consumer version) every
+        // chunk waited for its operands and the launch ran at the memory LATENCY (96 us)
+        DwbStage st[2][3];
+        auto put = [&](int sidx, unsigned char* buf) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (it[k].live) {
+                    if (it[k].is_g) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { csum[k][0] += st[sidx][k].v[e].x; csum[k][1] += st[sidx][k].v[e].y; }
+                    }
+                    dwb_split_store(st[sidx][k], buf + it[k].dst_off);
+                }
         };
-        auto load = [&](DwbStage& a, DwbStage& b, int k0) {
-            dwb_load(a, ig.rsrc, ig.base_off, ig.ld, k0);
-            dwb_load(b, ih.rsrc, ih.base_off, ih.ld, k0);
+        auto load = [&](int sidx, int k0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dwb_load(st[sidx][k], it[k], k0);
         };
         // prologue: chunk 0 split into buffer 0, chunks 1 and 2 in flight
-        load(sg[0], sh[0], kbeg);
-        load(sg[1], sh[1], kbeg + DWB_BK);
-        put(sg[0], sh[0], lds);
-        load(sg[0], sh[0], kbeg + 2 * DWB_BK);
+        load(0, kbeg);
+        load(1, kbeg + DWB_BK);
+        put(0, lds);
+        load(0, kbeg + 2 * DWB_BK);
         DWB_BARRIER();
         // iteration c: chunk c is being multiplied out of buffer c & 1; chunk c + 1 (stage (c + 1) & 1) goes to the other buffer,
         // chunk c + 3 into flight behind it (into the stage just emptied); chunk c + 2 stays in flight across the barrier
-        for (int k0 = kbeg, c = 0; k0 < kend; k0 += 2 * DWB_BK, c += 2) {
-            if (k0 + DWB_BK < kend) put(sg[1], sh[1], lds + DWB_BUF_BYTES);
-            load(sg[1], sh[1], k0 + 3 * DWB_BK);
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * DWB_BK) {
+            if (k0 + DWB_BK < kend) put(1, lds + DWB_BUF_BYTES);
+            load(1, k0 + 3 * DWB_BK);
             DWB_BARRIER();
             if (k0 + DWB_BK < kend) {
-                if (k0 + 2 * DWB_BK < kend) put(sg[0], sh[0], lds);
-                load(sg[0], sh[0], k0 + 4 * DWB_BK);
+                if (k0 + 2 * DWB_BK < kend) put(0, lds);
+                load(0, k0 + 4 * DWB_BK);
                 DWB_BARRIER();
             }
         }
         // db: the four octets of a g column, in octet order (the operand buffers are free: the loop ended with a barrier)
         float* scr = reinterpret_cast<float*>(lds);            // [4 octets][256 columns]
-        if (g.colsum != nullptr && ig.live) {
-            const int nq = 4 * g.tg, cq = ptid % nq, oct = ptid / nq;
+        if (g.colsum != nullptr) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) scr[oct * 256 + 4 * cq + j] = csum[j];
+            for (int k = 0; k < 3; ++k)
+                if (it[k].live && it[k].is_g) {
+                    const int local = (k * 4 + pwave) * 64 + lane, npairs = 8 * g.tg;
+                    const int cp = local % npairs, oct = local / npairs;
+                    scr[oct * 256 + 2 * cp] = csum[k][0];
+                    scr[oct * 256 + 2 * cp + 1] = csum[k][1];
+                }
         }
         __syncthreads();
+        const int ptid = tid - 256;
         if (g.colsum != nullptr && ptid < 16 * g.tg && m0 + ptid < g.M)
             g.colsum[(size_t)split * slab_stride + m0 + ptid] = ((scr[ptid] + scr[256 + ptid]) + scr[512 + ptid]) + scr[768 + ptid];
         return;
