@@ -93,12 +93,34 @@ __device__ __forceinline__ unsigned bf_pack2(float a, float b) {
 }
 __device__ __forceinline__ float bf_low(unsigned p) { return __builtin_bit_cast(float, p << 16); }
 __device__ __forceinline__ float bf_high(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// x - y / x + y as ONE scalar instruction each, out of the SLP vectoriser's reach: it pairs neighbouring fp32 operations into
+// v_pk_add_f32, which issues at 24.5 cycles beside a wave that keeps the SIMD's matrix pipe busy -- every plain vector instruction
+// (v_sub_f32, v_cvt_pk_bf16_f32, v_and_b32 ...) at 9.7 -- and wants its operands in register PAIRS (a v_mov per operand on top).
+// Measured by tools/probes/valu_mfma_probe.hip; the split code below runs beside MFMAs in every kernel that uses it.
+__device__ __forceinline__ float bf_sub(float x, float y) {
+#ifdef HIPSIM_EMULATED
+    return x - y;
+#else
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#endif
+}
+__device__ __forceinline__ float bf_add(float x, float y) {
+#ifdef HIPSIM_EMULATED
+    return x + y;
+#else
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#endif
+}
 // (a, b) -> hi / mid / lo pairs; the two subtractions are exact (the difference of an fp32 and its bf16 rounding fits fp32)
 __device__ __forceinline__ void bf_split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
     hi = bf_pack2(a, b);
-    const float ra = a - bf_low(hi), rb = b - bf_high(hi);
+    const float ra = bf_sub(a, bf_low(hi)), rb = bf_sub(b, bf_high(hi));
     mid = bf_pack2(ra, rb);
-    lo = bf_pack2(ra - bf_low(mid), rb - bf_high(mid));
+    lo = bf_pack2(bf_sub(ra, bf_low(mid)), bf_sub(rb, bf_high(mid)));
 }
 
 __device__ __forceinline__ f32x4 bf_mfma(const bf_u32x4& w, const bf_u32x4& x, f32x4 c) {
