@@ -1311,11 +1311,6 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     // the step runs on the bf16 matrix cores (its forward / backward chains did): the weight gradients too, as six split-bf16
     // products per fp32 product (dw_bf.h) -- when every problem fits one of that kernel's three layouts
     bool dwb_ok = c->bits_bf && c->bf_mode == 1 && dw2_ok && c->dw_mode == 3;
-    for (int l = 0; l < L && dwb_ok; ++l) {
-        const int M = n.dims[l + 1], N = n.dims[l];
-        // layouts of dw_bf.h: a narrow output (<= 32 rows), a narrow input (<= 64 columns), or groups of 128 rows x <= 256 columns
-        if (!(M <= 256 && N <= 256 && (M <= 32 || N <= 64 || M > 32))) dwb_ok = false;
-    }
     static const bool dwb_env = [] { const char* e = getenv("MORL_DW_BF16"); return e ? atoi(e) != 0 : true; }();      // (A/B: 0 = dw_tiles.h)
     c->dw_bf_last = dwb_ok && dwb_env;
     if (dwb_ok && dwb_env) {
@@ -1323,8 +1318,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         a.n = L;
         a.rows = rows;
         a.slab_stride = c->P;
-        double cost_rows = 0.0;
-        int cost[MORL_MAX_LAYERS];
+        long long units = 0;                        // (output group, input group) pairs over all problems: each costs `rows` rows of chunks
         for (int l = 0; l < L; ++l) {
             DwbProblem& q = a.p[l];
             q.G = c->g[l];
@@ -1336,35 +1330,25 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             q.colsum = c->slabs + c->offB[l];
             q.M = n.dims[l + 1]; q.N = n.dims[l];
             q.gcols = q.ldg; q.hcols = q.ldh;      // (pad columns of dq / x0 are written as zeros by their producers)
-            // operand tiles per chunk are the kernel's compile-time shapes (tiles beyond the matrix are zero fragments).  Jobs are
-            // balanced by their CHUNK count, not by their MFMAs: a chunk costs a 256 x 256 layer's job 192 MFMAs per consumer wave
-            // (1.5 us) and the narrow problems 96 / 48, but no chunk is shorter than the producers' load -> split -> write turn-around
-            // -- sized by MFMAs, the head's 56-chunk jobs set the launch's duration (96 us)
-            if (q.M <= 32) { q.layout = 2; q.groups = 1; q.tg = 2; q.th = 16; }
-            else if (q.N <= 64) { q.layout = 1; q.groups = 1; q.tg = 16; q.th = 4; }
-            else { q.layout = 0; q.groups = (q.M + 127) / 128; q.tg = 8; q.th = 16; }
-            cost[l] = 192;
-            cost_rows += (double)q.groups * rows * cost[l] / 192.0;
+            // the kernel's three compile-time shapes (operand tiles beyond the matrix are zero fragments): a narrow output (the Q
+            // head), a narrow input (the first layer), or 128 x 128 blocks.  Jobs are balanced by their CHUNK count, not by their
+            // MFMAs: no chunk is shorter than the producers' load -> split -> write turn-around
+            q.shape = (q.M <= 32) ? 2 : (q.N <= 64) ? 1 : 0;
+            q.mgroups = (q.M + 16 * DWB_TG[q.shape] - 1) / (16 * DWB_TG[q.shape]);
+            q.ngroups = (q.N + 16 * DWB_TH[q.shape] - 1) / (16 * DWB_TH[q.shape]);
+            units += (long long)q.mgroups * q.ngroups;
         }
-        int target = c->num_cus;                   // one 512-work-item workgroup per CU (144 KB of LDS)
-        int base = round_up(std::max(1, (int)std::ceil(cost_rows / (double)target)), DWB_BK);
-        for (;;) {      // the split count of every problem must fit the slab buffer
-            bool ok = true;
-            for (int l = 0; l < L; ++l) {
-                const int kps = round_up((int)((long long)base * 192 / cost[l]), DWB_BK);
-                if ((rows + kps - 1) / kps > c->max_splits) ok = false;
-            }
-            if (ok) break;
-            base += DWB_BK;
-        }
+        const int target = c->num_cus;              // one 768-work-item workgroup per CU (96 KB of LDS, 3 waves per SIMD)
+        int base = round_up(std::max(1, (int)((units * rows + target - 1) / target)), DWB_BK);
+        while ((rows + base - 1) / base > c->max_splits) base += DWB_BK;       // the split count must fit the slab buffer
         int jobs = 0, r = 0;
         splits = 0;
         for (int l = 0; l < L; ++l) {
             DwbProblem& q = a.p[l];
-            q.k_per_split = round_up((int)((long long)base * 192 / cost[l]), DWB_BK);
-            q.splits = (rows + q.k_per_split - 1) / q.k_per_split;
+            q.k_per_split = base;
+            q.splits = (rows + base - 1) / base;
             q.job_start = jobs;
-            jobs += q.splits * q.groups;
+            jobs += q.splits * q.mgroups * q.ngroups;
             splits = std::max(splits, q.splits);
             ranges.end[r] = c->offB[l];                                   ranges.splits[r++] = q.splits;   // W_l
             ranges.end[r] = c->offB[l] + n.dims[l + 1];                   ranges.splits[r++] = q.splits;   // b_l

@@ -28,7 +28,7 @@ int main() {
     }
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
-    for (int target : {cus, cus - 1, cus / 2, 2 * cus}) {
+    for (int target : {cus, cus - 1, 2 * cus}) {
         DwbArgs a{};
         a.n = L; a.rows = rows; a.slab_stride = P;
         double cost_rows = 0;
@@ -37,10 +37,10 @@ int main() {
             q.G = G[l]; q.ldg = ldg[l]; q.H = H[l]; q.ldh = ldh[l];
             q.C = slabs + offW[l]; q.ldc = dims[l]; q.colsum = slabs + offB[l];
             q.M = dims[l + 1]; q.N = dims[l]; q.gcols = q.ldg; q.hcols = q.ldh;
-            if (q.M <= 32) { q.layout = 2; q.groups = 1; q.tg = 2; q.th = 16; }
-            else if (q.N <= 64) { q.layout = 1; q.groups = 1; q.tg = 16; q.th = 4; }
-            else { q.layout = 0; q.groups = (q.M + 127) / 128; q.tg = 8; q.th = 16; }
-            cost_rows += (double)q.groups * rows;
+            q.shape = (q.M <= 32) ? 2 : (q.N <= 64) ? 1 : 0;
+            q.mgroups = (q.M + 16 * DWB_TG[q.shape] - 1) / (16 * DWB_TG[q.shape]);
+            q.ngroups = (q.N + 16 * DWB_TH[q.shape] - 1) / (16 * DWB_TH[q.shape]);
+            cost_rows += (double)q.mgroups * q.ngroups * rows;
         }
         const int base = (std::max(1, (int)std::ceil(cost_rows / target)) + 31) / 32 * 32;
         int jobs = 0;
@@ -48,7 +48,7 @@ int main() {
             DwbProblem& q = a.p[l];
             q.k_per_split = base; q.splits = (rows + base - 1) / base;
             if (q.splits > 64) { printf("too many splits\n"); return 1; }
-            q.job_start = jobs; jobs += q.splits * q.groups;
+            q.job_start = jobs; jobs += q.splits * q.mgroups * q.ngroups;
         }
         a.jobs = jobs;
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -72,27 +72,25 @@ int main() {
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             { float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("  instrumented launch: %.1f us\n", ms * 1e3); }
             std::vector<long long> hp((size_t)jobs * DWB_PROF_SLOTS); CK(hipMemcpy(hp.data(), prof, hp.size() * 8, hipMemcpyDeviceToHost));
-            long long w0 = hp[6], w1 = 0;
-            for (int j = 0; j < jobs; ++j) { w0 = std::min(w0, hp[(size_t)j * DWB_PROF_SLOTS + 6]); w1 = std::max(w1, hp[(size_t)j * DWB_PROF_SLOTS + 7]); }
+            long long w0 = hp[48], w1 = 0;
+            for (int j = 0; j < jobs; ++j) { w0 = std::min(w0, hp[(size_t)j * DWB_PROF_SLOTS + 48]); w1 = std::max(w1, hp[(size_t)j * DWB_PROF_SLOTS + 49]); }
             printf("  first job start -> last job end: %.1f us (100 MHz wall clock)\n", (double)(w1 - w0) / 100.0);
             for (int l = 0; l < L; ++l) {
                 const DwbProblem& q = a.p[l];
-                const int nj = q.splits * q.groups;
+                const int nj = q.splits * q.mgroups * q.ngroups;
                 double s[DWB_PROF_SLOTS] = {0};
-                double st_min = 1e18, st_max = 0, en_min = 1e18, en_max = 0;
+                double en_min = 1e18, en_max = 0;
                 for (int j = 0; j < nj; ++j) {
                     const long long* r = &hp[(size_t)(q.job_start + j) * DWB_PROF_SLOTS];
                     for (int k = 0; k < DWB_PROF_SLOTS; ++k) s[k] += (double)r[k] / nj;
-                    st_min = std::min(st_min, (double)(r[6] - w0)); st_max = std::max(st_max, (double)(r[6] - w0));
-                    en_min = std::min(en_min, (double)(r[7] - w0)); en_max = std::max(en_max, (double)(r[7] - w0));
+                    en_min = std::min(en_min, (double)(r[49] - w0)); en_max = std::max(en_max, (double)(r[49] - w0));
                 }
                 const int chunks = q.k_per_split / 32;
-                printf("  problem %d layout %d: %d jobs x %d chunks; start %.1f..%.1f us, end %.1f..%.1f us\n", l, q.layout, nj, chunks,
-                       st_min / 100, st_max / 100, en_min / 100, en_max / 100);
-                printf("    consumer wave 0: first barrier %.0f | per chunk: fragment reads %.0f  mfma loop %.0f  barrier %.0f | epilogue %.0f\n",
-                       s[0], s[1] / chunks, s[2] / chunks, s[3] / chunks, s[4]);
-                printf("    producer wave 4: prologue %.0f | per chunk: operand wait %.0f  split+write %.0f  load issue %.0f  barrier %.0f | db %.0f\n",
-                       s[8], s[9] / chunks, s[10] / chunks, s[11] / chunks, s[12] / chunks, s[13]);
+                printf("  problem %d shape %d: %d jobs x %d chunks; end %.1f..%.1f us; per wave: prologue | per chunk work, barrier wait | epilogue (cycles)\n",
+                       l, q.shape, nj, chunks, en_min / 100, en_max / 100);
+                for (int w = 0; w < 12; ++w)
+                    printf("    wave %2d (%s): %6.0f | %5.0f %5.0f | %6.0f\n", w, w < 4 ? "consumer" : "producer", s[4 * w], s[4 * w + 1] / chunks,
+                           s[4 * w + 2] / chunks, s[4 * w + 3]);
             }
             a.prof = nullptr;
             CK(hipFree(prof));
