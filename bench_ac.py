@@ -187,6 +187,44 @@ def bench_gpi(a):
                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                         "note": "algorithmic GEMM flop of the update / wall time (launch-latency-bound workload)"},
            "algorithmic_flop_per_step": flop}
+    # the reference's default configuration: prioritised replay, 20 gradient updates per environment step -- ONE library entry
+    # (morl_gpi_update_n_per: per iteration tree descent + gather, update, max(|gtd|, min) ** alpha back into the tree)
+    from morl_baselines_amd.replay import PrioritizedReplayBuffer
+    G = 20
+    buf = PrioritizedReplayBuffer((D,), 1, rew_dim=R, max_size=32768, action_dtype=np.int32, device=dev)
+    rng = np.random.default_rng(0)
+    buf.add_batch(rng.standard_normal((20000, D)).astype(np.float32), rng.integers(0, A, (20000, 1)).astype(np.int32),
+                  rng.standard_normal((20000, R)).astype(np.float32), rng.standard_normal((20000, D)).astype(np.float32),
+                  (rng.random((20000, 1)) < 0.05).astype(np.float32))
+    sc = (th.empty(rows, D, device=dev), th.empty(rows, dtype=th.int32, device=dev), th.empty(rows, R, device=dev),
+          th.empty(rows, D, device=dev), th.empty(rows, device=dev))
+
+    def per_step():
+        items = []
+        for _ in range(G):
+            st["n"] += 1
+            items.append(dict(obs=sc[0], actions=sc[1], rewards=sc[2], next_obs=sc[3], dones=sc[4], w=w, sampled_w=sw,
+                              adam_step=st["n"], gpi_pd=True, n_per=B, dropout_seed=st["n"],
+                              want=("critic_loss", "td_error", "gtd_error")))
+        eng.update_n_per(items, buffer=buf, u01=np.random.random_sample((G, B)), doubled=True, use_gtd=True, alpha=0.6,
+                         min_priority=0.01)
+
+    for _ in range(3):
+        per_step()
+    th.cuda.synchronize()
+    n_loops = max(3, a.steps // G)
+    enq, t0 = [], time.perf_counter()
+    for _ in range(n_loops):
+        t1 = time.perf_counter()
+        per_step()
+        enq.append(time.perf_counter() - t1)
+    th.cuda.synchronize()
+    loop_ms = (time.perf_counter() - t0) * 1e3 / n_loops
+    out["per_loop"] = {"what": f"GPIPD.update() with per=True: {G} gradient updates per environment step through ONE library "
+                               "entry (morl_gpi_update_n_per: per iteration sum-tree descent + gather, update, priorities "
+                               "back into the tree); buffer of 20 000 transitions",
+                       "ms_per_env_step": loop_ms, "ms_per_update": loop_ms / G,
+                       "host_enqueue_ms_per_env_step": float(np.median(enq)) * 1e3, "library_entries_per_env_step": 1}
     if not a.no_cpu_baseline:
         import gpi_oracle as go
         from ac_oracle import clone

@@ -31,7 +31,7 @@ extern "C" {
 
 #define MORL_MAX_LAYERS 8   /* linear layers per network */
 #define MORL_MAX_OBJ 8      /* reward dimension R */
-#define MORL_ABI_VERSION 11
+#define MORL_ABI_VERSION 12
 
 typedef enum morl_status {
     MORL_OK = 0,
@@ -383,6 +383,10 @@ int morl_expected_utility(const double* front, int N, int R, const double* weigh
 int morl_sumtree_sample(const double* tree, int n_levels, const double* u01, int B, int64_t* idx, void* stream);
 int morl_sumtree_set(double* tree, int n_levels, const int64_t* ptr, const double* value, int n,
                      double* running_max, void* stream);
+/* priority = max(raw, clamp_min) ** alpha (GPIPD.update: priority.clip(min=self.min_priority) ** self.alpha,
+ * multi_policy/gpi_pd/gpi_pd.py:507-526), then as morl_sumtree_update */
+int morl_sumtree_update_clamped(double* tree, int n_levels, const int64_t* idx, const float* raw, int B, double alpha,
+                                double clamp_min, double* running_max, double* pr_out, void* stream);
 int morl_sumtree_update(double* tree, int n_levels, const int64_t* idx, const float* raw, int B, double alpha,
                         double* running_max, double* pr_out, void* stream);
 
@@ -625,6 +629,30 @@ int morl_gpi_update(morl_gpi_ctx* ctx, float* q, const float* q_target, float* e
  * morl_gpi_update on batches[k] / cfgs[k] -> outs[k] (outs may be NULL).  See morl_ac_update_n. */
 int morl_gpi_update_n(morl_gpi_ctx* ctx, float* q, const float* q_target, float* exp_avg, float* exp_avg_sq, int n,
                       const morl_gpi_batch* batches, const morl_gpi_cfg* cfgs, const morl_gpi_out* outs, void* stream);
+/* The same loop with prioritised replay (GPIPD's default, gpi_pd.py:416-420 + 507-526): iteration k samples B transitions
+ * through the sum tree with the unit uniforms u01[k][.] (drawn by the host in the reference's order), gathers them into the
+ * buffers batches[k] points to (rows [0, B), and again as rows [B, 2 B) when `doubled`: len(weight_support) > 1; the host has
+ * filled batches[k].w / sampled_w), runs morl_gpi_update, and writes priority = max(|td|, min_priority) ** alpha of the B
+ * transitions back into the tree -- what iteration k + 1 samples through.  outs[k] must carry td_error (or gtd_error when
+ * use_gtd); idx [n][B] receives the sampled indices.  Record layout / capacity / D / R / action_dim as morl_sample_gather. */
+typedef struct morl_gpi_per {
+    double* tree;
+    double* running_max;
+    const double* u01;                 /* [n][B], device or mapped pinned host */
+    const float* records;
+    int64_t* idx;                      /* [n][B] out */
+    int64_t capacity;
+    int32_t n_levels, record_floats, D, R, action_dim, B;
+    int32_t doubled, use_gtd;
+    float alpha, min_priority;
+} morl_gpi_per;
+int morl_gpi_update_n_per(morl_gpi_ctx* ctx, float* q, const float* q_target, float* exp_avg, float* exp_avg_sq, int n,
+                          const morl_gpi_per* per, const morl_gpi_batch* batches, const morl_gpi_cfg* cfgs,
+                          const morl_gpi_out* outs, void* stream);
+/* the continuous-action learner's loop (gpi_pd_continuous_action.py:373-417) the same way: float actions, priority =
+ * max(outs[k].priority, min_priority) ** alpha; one learner (batches[k].active <= 1); use_gtd is ignored */
+int morl_ac_update_n_per(morl_ac_ctx* ctx, const morl_ac_state* st, int n, const morl_gpi_per* per, const morl_ac_batch* batches,
+                         const morl_ac_cfg* cfgs, const morl_ac_out* outs, void* stream);
 /* Q(obs_row, w_row) of `n_nets` consecutive nets starting at `params`, eval mode (no dropout):
  * q_out [n_nets][rows][A*R].  w_per_row = 0: one weight vector for every row. */
 int morl_gpi_q_forward(morl_gpi_ctx* ctx, const float* params, int n_nets, const float* obs, const float* w,

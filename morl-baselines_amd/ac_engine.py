@@ -275,6 +275,43 @@ class ACEngine:
         self.lib.check(self.lib.lib.morl_ac_update_n(self._h, C.byref(st), n, bs, cs, os_, self.lib.stream_of(self.q)))
         return results
 
+    def update_n_per(self, items: Sequence[dict], *, buffer, u01: np.ndarray, doubled: bool, alpha: float, min_priority: float,
+                     want: Sequence[str] = ("critic_loss", "policy_loss", "priority")):
+        """``morl_ac_update_n_per``: the loop with prioritised replay in ONE library entry (one learner): iteration k samples
+        ``buffer`` through its sum tree with the unit uniforms ``u01[k]``, gathers the transitions into the batch tensors of
+        ``items[k]`` (scratch the caller allocated; w / noise filled), updates, and writes max(priority, min_priority) ** alpha
+        back into the tree.  Returns (output dicts, sampled indices [n][B])."""
+        from .native import GPIPer
+        n = len(items)
+        u01 = np.ascontiguousarray(u01, dtype=np.float64).reshape(n, -1)
+        B = u01.shape[1]
+        buffer.flush()
+        bs, cs, os_ = (ACBatch * n)(), (ACCfg * n)(), (ACOut * n)()
+        results, keep = [], []
+        for k, it in enumerate(items):
+            it = dict(it)
+            cfg = it.pop("cfg")
+            obs = self._f32(it.pop("obs"), "obs")
+            b, o, res, kp = self._pack(cfg, obs, self.pop, it.get("actions"), it.get("rewards"), it.get("next_obs"), it.get("dones"),
+                                       it.get("w"), it.get("eps_next"), it.get("eps_pi"), it.get("eps_alpha"), it.get("drop_masks"),
+                                       it.get("want", want))
+            bs[k], cs[k], os_[k] = b, cfg, o
+            results.append(res)
+            keep.append(kp)
+        dev = self.q.device
+        u_dev = th.as_tensor(u01).to(dev)
+        idx = th.empty((n, B), dtype=th.int64, device=dev)
+        per = GPIPer()
+        per.tree, per.running_max, per.u01 = buffer.tree_dev.data_ptr(), buffer.running_max.data_ptr(), u_dev.data_ptr()
+        per.records, per.idx = buffer.records.data_ptr(), idx.data_ptr()
+        per.capacity, per.record_floats = buffer.records.shape[0], buffer.records.shape[1]
+        per.n_levels, per.D, per.R, per.action_dim, per.B = buffer.n_levels, buffer._D, buffer._R, buffer._Ad, B
+        per.doubled, per.use_gtd, per.alpha, per.min_priority = int(doubled), 0, float(alpha), float(min_priority)
+        st = self._state(0)
+        self.lib.check(self.lib.lib.morl_ac_update_n_per(self._h, C.byref(st), n, C.byref(per), bs, cs, os_,
+                                                         self.lib.stream_of(self.q)))
+        return results, idx
+
     def policy_forward(self, obs, w=None, *, eps=None, use_target=False, cfg: Optional[ACCfg] = None,
                        want_logp=False):
         obs = self._f32(obs, "obs")

@@ -46,6 +46,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             # product and sum separately, as torch's einsum does); FMAs are written explicitly as fmaf()
             "-ffp-contract=off",
             "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    if os.environ.get("MORL_BF_PROF"):     # development build: phase stamps in the split-bf16 chain kernels (mlp_chain_bf.h)
+        base.append("-DBF_PROF")
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "morl_hip.h")]

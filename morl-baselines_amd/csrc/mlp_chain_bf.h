@@ -83,7 +83,17 @@ struct BfMulti {
     BfChain c[BF_MAX_MULTI];
     int tile_start[BF_MAX_MULTI + 1];      // 64-row tiles of chain q: [tile_start[q], tile_start[q + 1])
     int n;
+    long long* prof;                       // development builds only (-DBF_PROF, MORL_BF_PROF=1 python build.py): [tile][wave][BF_PROF_SLOTS]
 };
+// Phase stamps of a development build: s_memtime sums per wave -- 0 prologue (input rows, biases, first weight stages), 1 / 2 first
+// step's MFMA loop / epilogue, 3 / 4 the 256 x 256 steps' MFMA loops / epilogues, 5 head + drain, 6 of which waiting at stage
+// entries (counted wait + barrier), 7 of which issuing the weight DMA, 8 first stamp, 9 last stamp
+constexpr int BF_PROF_SLOTS = 10;
+#ifdef BF_PROF
+#define BF_T(q) { const long long t_ = clock64(); pt[q] += t_ - tp_; tp_ = t_; }
+#else
+#define BF_T(q)
+#endif
 
 // ---- three-way split ---------------------------------------------------------------------------------------------------------
 // two fp32 -> packed pair of round-to-nearest-even bf16 (v_cvt_pk_bf16_f32): a in the low half, b in the high half
@@ -143,6 +153,9 @@ struct BfRing {
     int buf;                       // t % 3
     int n_stages;
     int wave;
+#ifdef BF_PROF
+    long long t_entry, t_dma;
+#endif
 };
 
 // LDS-DMA of this wave's share (24 / NW blocks) of stage `st` (clamped to the stream's last stage: the issue count per stage is
@@ -180,10 +193,19 @@ __device__ __forceinline__ void bf_ring_issue(const BfRing& r, int st, int buf) 
 // buffer takes the stage two ahead.  Returns the stage's LDS base.
 template <int NW, int EXTRA>
 __device__ __forceinline__ const unsigned char* bf_stage_begin(BfRing& r) {
+#ifdef BF_PROF
+    const long long t0_ = clock64();
+#endif
     BF_VMCNT_LDS0(BF_STAGE_BLOCKS / NW + EXTRA);
     __builtin_amdgcn_s_barrier();
+#ifdef BF_PROF
+    const long long t1_ = clock64();
+#endif
     const int free_buf = r.buf == 0 ? 2 : r.buf - 1;
     bf_ring_issue<NW>(r, r.t + 2, free_buf);
+#ifdef BF_PROF
+    r.t_entry += t1_ - t0_; r.t_dma += clock64() - t1_;
+#endif
     const unsigned char* base = r.lds + r.buf * BF_STAGE_BYTES;
     r.buf = r.buf == 2 ? 0 : r.buf + 1;
     ++r.t;
@@ -365,7 +387,11 @@ __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x
 // K0S: k-steps of the first step (1 or 2); MODE: see bf_wide_epilogue -- the chain writes per-step outputs (1, 2) and sign bits (1) or
 // reads mask words (2); compile-time also because the counted waits depend on the stores issued.
 template <int NW, int K0S, int MODE>
-__device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsigned char* ring_lds, float* bias_lds) {
+__device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsigned char* ring_lds, float* bias_lds, long long* prof) {
+#ifdef BF_PROF
+    long long pt[6] = {0, 0, 0, 0, 0, 0}, tp_ = clock64();
+    const long long tstart_ = tp_;
+#endif
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
@@ -378,15 +404,27 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     ring.voff = wave * ((BF_STAGE_BLOCKS / NW) * BF_BLOCK) + lane * 16;
     ring.lds = ring_lds;
     ring.t = 0; ring.buf = 0; ring.n_stages = p.n_stages; ring.wave = wave;
+#ifdef BF_PROF
+    ring.t_entry = 0; ring.t_dma = 0;
+#endif
     // the stream starts before the input rows are assembled
     bf_ring_issue<NW>(ring, 0, 0);
     bf_ring_issue<NW>(ring, 1, 1);
-    // biases -> LDS, [step][256] (zeros beyond a step's columns and for steps without bias); visible after the first stage's barrier
-    for (int e = tid; e < p.n_steps * BF_WIDE; e += 64 * NW) {
-        const int s = e >> 8, n = e & 255;
-        const BfStep& st = p.step[s];
-        bias_lds[e] = (st.bias != nullptr && n < st.N) ? st.bias[n] : 0.f;
-    }
+    // biases -> registers, [step][256] (zeros beyond a step's columns and for steps without bias): every load issued here, in one go
+    // -- compile-time step indices: as a loop over (step, column) every iteration read the step's pointer and width from the
+    // argument block per LANE and waited for each of its three dependent loads with vmcnt(0), i.e. also for the weight stages just
+    // put in flight: 30 serialised round trips, a tenth of the launch -- and written to LDS behind the input rows' loads
+    constexpr int BPT = BF_WIDE / (64 * NW);        // columns per work-item per step
+    float bv[BF_MAX_STEPS][BPT];
+#pragma unroll
+    for (int s = 0; s < BF_MAX_STEPS; ++s)
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) {
+            const int n = tid + j * 64 * NW;
+            float b = 0.f;
+            if (s < p.n_steps && p.step[s].bias != nullptr && n < p.step[s].N) b = p.step[s].bias[n];
+            bv[s][j] = b;
+        }
 
     // ---- input rows: natural contraction order, slot (q, e) of k-step s <-> column 32 s + 8 q + e -------------------------------
     bf_u32x4 x[8][3];
@@ -428,6 +466,11 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     }
     unsigned long long keep = ~0ull;     // the first step's mask word (backward chain)
     if (MODE == 2 && p.step[0].bits_in != nullptr) keep = p.step[0].bits_in[bits_idx];
+#pragma unroll
+    for (int s = 0; s < BF_MAX_STEPS; ++s)
+#pragma unroll
+        for (int j = 0; j < BPT; ++j)
+            if (s < p.n_steps) bias_lds[s * BF_WIDE + tid + j * 64 * NW] = bv[s][j];
     // everything this lane loaded or stored so far has to be out of the way of the counted waits: drain once, before the loop
     // (the two DMA groups in flight are waited for here too -- the only vmcnt(0) of the kernel, at its very start)
     BF_VMCNT(0);
@@ -436,9 +479,12 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     f32x4 acc[16];
     const int n_wide = p.n_steps - (p.head ? 1 : 0);
     // ---- first step ---------------------------------------------------------------------------------------------------------------
+    BF_T(0)
     bf_acc_init<16>(acc, bias_lds, q);
     bf_wide_step<NW, K0S, 0>(acc, x, ring, lane);
+    BF_T(1)
     bf_wide_epilogue<MODE>(acc, x, p.step[0], row, row_ok, bits_idx, q, keep);
+    BF_T(2)
     // ---- the 256 x 256 steps --------------------------------------------------------------------------------------------------------
     for (int s = 1; s < n_wide; ++s) {
         // this step's mask word: the seventeenth vector-memory instruction behind the previous epilogue's sixteen stores, in front of
@@ -447,7 +493,9 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
         if (MODE == 2 && p.step[s].bits_in != nullptr) keep = p.step[s].bits_in[bits_idx];
         bf_acc_init<16>(acc, bias_lds + s * BF_WIDE, q);
         bf_wide_step<NW, 8, MODE != 0 ? BF_SAVE_VMEM : 0>(acc, x, ring, lane);
+        BF_T(3)
         bf_wide_epilogue<MODE>(acc, x, p.step[s], row, row_ok, bits_idx, q, keep);
+        BF_T(4)
     }
     // ---- the head -----------------------------------------------------------------------------------------------------------------
     if (p.head) {
@@ -469,6 +517,14 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     }
     // nothing of this workgroup may still be in flight into LDS when the next workgroup of the CU takes the allocation
     BF_VMCNT(0);
+    BF_T(5)
+#ifdef BF_PROF
+    if (prof != nullptr && lane == 0) {
+        long long* o = prof + ((size_t)blockIdx.x * NW + wave) * BF_PROF_SLOTS;
+        for (int i = 0; i < 6; ++i) o[i] = pt[i];
+        o[6] = ring.t_entry; o[7] = ring.t_dma; o[8] = tstart_; o[9] = tp_;
+    }
+#endif
 }
 
 constexpr int BF_LDS_BYTES = BF_RING * BF_STAGE_BYTES + BF_MAX_STEPS * BF_WIDE * 4;
@@ -486,13 +542,13 @@ __device__ __forceinline__ void mlp_chain_bf_entry(const BfMulti& m, unsigned ch
     float* bias_lds = reinterpret_cast<float*>(lds + BF_RING * BF_STAGE_BYTES);
     const int mode = p.step[0].bits_in != nullptr ? 2 : (p.step[0].out != nullptr || p.step[0].bits_out != nullptr) ? 1 : 0;
     if (p.k0_steps == 1) {
-        if (mode == 2) bf_chain_body<NW, 1, 2>(p, row0, lds, bias_lds);
-        else if (mode == 1) bf_chain_body<NW, 1, 1>(p, row0, lds, bias_lds);
-        else bf_chain_body<NW, 1, 0>(p, row0, lds, bias_lds);
+        if (mode == 2) bf_chain_body<NW, 1, 2>(p, row0, lds, bias_lds, m.prof);
+        else if (mode == 1) bf_chain_body<NW, 1, 1>(p, row0, lds, bias_lds, m.prof);
+        else bf_chain_body<NW, 1, 0>(p, row0, lds, bias_lds, m.prof);
     } else {
-        if (mode == 2) bf_chain_body<NW, 2, 2>(p, row0, lds, bias_lds);
-        else if (mode == 1) bf_chain_body<NW, 2, 1>(p, row0, lds, bias_lds);
-        else bf_chain_body<NW, 2, 0>(p, row0, lds, bias_lds);
+        if (mode == 2) bf_chain_body<NW, 2, 2>(p, row0, lds, bias_lds, m.prof);
+        else if (mode == 1) bf_chain_body<NW, 2, 1>(p, row0, lds, bias_lds, m.prof);
+        else bf_chain_body<NW, 2, 0>(p, row0, lds, bias_lds, m.prof);
     }
 }
 

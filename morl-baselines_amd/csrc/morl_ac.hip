@@ -1772,6 +1772,43 @@ extern "C" int morl_ac_update_n(morl_ac_ctx* c, const morl_ac_state* st, int n, 
     return MORL_OK;
 }
 
+// The same loop with prioritised replay for the TD3-style learner of GPI-PD with continuous actions
+// (gpi_pd_continuous_action.py:373-417): see morl_gpi_update_n_per.
+extern "C" int morl_ac_update_n_per(morl_ac_ctx* c, const morl_ac_state* st, int n, const morl_gpi_per* per, const morl_ac_batch* batches,
+                                    const morl_ac_cfg* cfgs, const morl_ac_out* outs, void* stream) {
+    if (!c || !st || !per || !batches || !cfgs || !outs) return fail(MORL_ERR_ARG, "NULL argument");
+    if (n < 1) return fail(MORL_ERR_ARG, "n = %d updates", n);
+    if (!per->tree || !per->running_max || !per->u01 || !per->records || !per->idx) return fail(MORL_ERR_ARG, "NULL field of morl_gpi_per");
+    const int B = per->B;
+    if (B < 1) return fail(MORL_ERR_ARG, "B = %d", B);
+    const int copies = per->doubled ? 2 : 1;
+    for (int k = 0; k < n; ++k) {
+        const morl_ac_batch& b = batches[k];
+        if (b.rows != copies * B) return fail(MORL_ERR_ARG, "update %d: %d rows for %d sampled transitions x %d", k, b.rows, B, copies);
+        if (b.active > 1) return fail(MORL_ERR_ARG, "update %d: one learner per prioritised loop", k);
+        if (cfgs[k].n_per != B) return fail(MORL_ERR_ARG, "update %d: n_per %d != B %d", k, cfgs[k].n_per, B);
+        if (!outs[k].priority) return fail(MORL_ERR_ARG, "update %d: the priority output is needed", k);
+        int64_t* idx = per->idx + (size_t)k * B;
+        int rc = MORL_OK;
+        for (int cp = 0; cp < copies && !rc; ++cp)
+            rc = morl_sample_gather(cp == 0 ? per->tree : nullptr, per->n_levels, cp == 0 ? per->u01 + (size_t)k * B : nullptr,
+                                    cp == 0 ? nullptr : idx, per->records, per->record_floats, per->capacity, B, per->D, per->R,
+                                    per->action_dim, (float*)b.obs + (size_t)cp * B * per->D, (float*)b.next_obs + (size_t)cp * B * per->D,
+                                    (float*)b.rewards + (size_t)cp * B * per->R, (float*)b.dones + (size_t)cp * B,
+                                    (float*)b.actions + (size_t)cp * B * per->action_dim, nullptr, cp == 0 ? idx : nullptr, nullptr,
+                                    nullptr, 0, stream);
+        if (!rc) rc = morl_ac_update(c, st, batches + k, cfgs + k, outs + k, stream);
+        if (!rc) rc = morl_sumtree_update_clamped(per->tree, per->n_levels, idx, outs[k].priority, B, per->alpha, per->min_priority,
+                                                  per->running_max, nullptr, stream);
+        if (rc) {
+            char msg[400];
+            snprintf(msg, sizeof(msg), "%s", morl_last_error());
+            return fail(rc, "update %d of %d: %s", k, n, msg);
+        }
+    }
+    return MORL_OK;
+}
+
 extern "C" int morl_gpi_update_n(morl_gpi_ctx* c, float* q, const float* q_target, float* exp_avg, float* exp_avg_sq, int n,
                                  const morl_gpi_batch* batches, const morl_gpi_cfg* cfgs, const morl_gpi_out* outs, void* stream) {
     if (!c || !batches || !cfgs) return fail(MORL_ERR_ARG, "NULL argument");
@@ -1782,6 +1819,45 @@ extern "C" int morl_gpi_update_n(morl_gpi_ctx* c, float* q, const float* q_targe
                                        b.rows, b.sampled_w, b.K, b.drop_masks, cfgs + k, outs ? outs + k : nullptr, stream);
         if (rc) {
             char msg[400];
+            snprintf(msg, sizeof(msg), "%s", morl_last_error());
+            return fail(rc, "update %d of %d: %s", k, n, msg);
+        }
+    }
+    return MORL_OK;
+}
+
+// GPIPD.update's loop WITH prioritised replay (the reference's default): every iteration samples through the tree the iteration
+// before it wrote.  Per iteration: descent + gather (morl_sample_gather) -> morl_gpi_update -> priorities = max(|td|, min) ** alpha
+// -> tree (morl_sumtree_update_clamped), all enqueued here.
+extern "C" int morl_gpi_update_n_per(morl_gpi_ctx* c, float* q, const float* q_target, float* exp_avg, float* exp_avg_sq, int n,
+                                     const morl_gpi_per* per, const morl_gpi_batch* batches, const morl_gpi_cfg* cfgs,
+                                     const morl_gpi_out* outs, void* stream) {
+    if (!c || !per || !batches || !cfgs || !outs) return fail(MORL_ERR_ARG, "NULL argument");
+    if (n < 1) return fail(MORL_ERR_ARG, "n = %d updates", n);
+    if (!per->tree || !per->running_max || !per->u01 || !per->records || !per->idx) return fail(MORL_ERR_ARG, "NULL field of morl_gpi_per");
+    const int B = per->B;
+    if (B < 1) return fail(MORL_ERR_ARG, "B = %d", B);
+    const int copies = per->doubled ? 2 : 1;
+    for (int k = 0; k < n; ++k) {
+        const morl_gpi_batch& b = batches[k];
+        char msg[400];
+        if (b.rows != copies * B) return fail(MORL_ERR_ARG, "update %d: %d rows for %d sampled transitions x %d", k, b.rows, B, copies);
+        if (cfgs[k].n_per != B) return fail(MORL_ERR_ARG, "update %d: n_per %d != B %d", k, cfgs[k].n_per, B);
+        const float* raw = per->use_gtd ? outs[k].gtd_error : outs[k].td_error;
+        if (!raw) return fail(MORL_ERR_ARG, "update %d: the %s output is needed for the priorities", k, per->use_gtd ? "gtd_error" : "td_error");
+        int64_t* idx = per->idx + (size_t)k * B;
+        int rc = MORL_OK;
+        for (int cp = 0; cp < copies && !rc; ++cp)      // (the second copy re-reads the indices the first one wrote)
+            rc = morl_sample_gather(cp == 0 ? per->tree : nullptr, per->n_levels, cp == 0 ? per->u01 + (size_t)k * B : nullptr,
+                                    cp == 0 ? nullptr : idx, per->records, per->record_floats, per->capacity, B, per->D, per->R,
+                                    per->action_dim, (float*)b.obs + (size_t)cp * B * per->D, (float*)b.next_obs + (size_t)cp * B * per->D,
+                                    (float*)b.rewards + (size_t)cp * B * per->R, (float*)b.dones + (size_t)cp * B, nullptr,
+                                    (int32_t*)b.actions + (size_t)cp * B * per->action_dim, cp == 0 ? idx : nullptr, nullptr, nullptr, 0, stream);
+        if (!rc) rc = morl_gpi_update(c, q, q_target, exp_avg, exp_avg_sq, b.obs, b.actions, b.rewards, b.next_obs, b.dones, b.w,
+                                      b.rows, b.sampled_w, b.K, b.drop_masks, cfgs + k, outs + k, stream);
+        if (!rc) rc = morl_sumtree_update_clamped(per->tree, per->n_levels, idx, raw, B, per->alpha, per->min_priority,
+                                                  per->running_max, nullptr, stream);
+        if (rc) {
             snprintf(msg, sizeof(msg), "%s", morl_last_error());
             return fail(rc, "update %d of %d: %s", k, n, msg);
         }

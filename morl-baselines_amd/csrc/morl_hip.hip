@@ -641,11 +641,34 @@ static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStr
         tiles += (chains[q].rows + tm - 1) / tm;
     }
     for (int q = n; q <= BF_MAX_MULTI; ++q) m.tile_start[q] = tiles;
+#ifdef BF_PROF
+    // development build: every 50th pair of launches prints the per-wave phase sums (see BF_PROF_SLOTS)
+    static long long* prof_dev = nullptr;
+    static int prof_calls = 0;
+    const bool prof_now = (++prof_calls % 50) <= 1;
+    if (!prof_dev) hipMalloc(&prof_dev, (size_t)4096 * 4 * BF_PROF_SLOTS * 8);
+    m.prof = prof_dev;
+    if (prof_now) hipStreamSynchronize(s);
+#endif
     int slot = -1, rc;
     if ((rc = timing_open(c, kind, s, &slot))) return rc;
     if (small) hipLaunchKernelGGL(mlp_chain_bf32_kernel, dim3(tiles), dim3(128), 0, s, m);
     else hipLaunchKernelGGL(mlp_chain_bf_kernel, dim3(tiles), dim3(256), 0, s, m);
     LAUNCH_CHECK("mlp_chain_bf");
+#ifdef BF_PROF
+    if (prof_now && tiles <= 4096) {
+        hipStreamSynchronize(s);
+        const int nw = small ? 2 : 4;
+        std::vector<long long> h((size_t)tiles * nw * BF_PROF_SLOTS);
+        hipMemcpy(h.data(), prof_dev, h.size() * 8, hipMemcpyDeviceToHost);
+        double a[BF_PROF_SLOTS] = {0};
+        for (int w = 0; w < tiles * nw; ++w)
+            for (int i = 0; i < BF_PROF_SLOTS; ++i) a[i] += (double)h[(size_t)w * BF_PROF_SLOTS + i] / (tiles * nw);
+        fprintf(stderr, "[bf_prof] %d tiles x %d waves, %s: prologue %.0f | step 0: mfma loop %.0f epilogue %.0f | wide steps: mfma loops %.0f epilogues %.0f | "
+                "head + drain %.0f | of which stage-entry waits %.0f, DMA issue %.0f | total %.0f cycles per wave\n",
+                tiles, nw, chains[0].step[0].bits_in ? "backward" : "forward", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[9] - a[8]);
+    }
+#endif
     return timing_close(c, slot, s);
 }
 
@@ -2006,5 +2029,19 @@ extern "C" int morl_sumtree_update(double* tree, int n_levels, const int64_t* id
     u.n_levels = n_levels; u.B = B; u.alpha = (float)alpha;
     hipLaunchKernelGGL(sumtree_update_kernel, dim3(1), dim3(ST_THREADS), 0, (hipStream_t)stream, u);
     LAUNCH_CHECK("sumtree_update");
+    return MORL_OK;
+}
+
+extern "C" int morl_sumtree_update_clamped(double* tree, int n_levels, const int64_t* idx, const float* raw, int B,
+                                           double alpha, double clamp_min, double* running_max, double* pr_out, void* stream) {
+    if (!tree || !idx || !raw || !running_max) return fail(MORL_ERR_ARG, "NULL array");
+    if (n_levels < 1 || n_levels > 40) return fail(MORL_ERR_ARG, "bad n_levels");
+    if (B < 1 || B > ST_MAX_B) return fail(MORL_ERR_ARG, "B=%d outside [1,%d]", B, ST_MAX_B);
+    if (!(alpha >= 0.0) || !(clamp_min > 0.0)) return fail(MORL_ERR_ARG, "alpha %g must be >= 0 and clamp_min %g > 0", alpha, clamp_min);
+    SumTreeUpdate u{};
+    u.tree = tree; u.idx = idx; u.raw = raw; u.running_max = running_max; u.pr_out = pr_out;
+    u.n_levels = n_levels; u.B = B; u.alpha = (float)alpha; u.clamp_min = (float)clamp_min;
+    hipLaunchKernelGGL(sumtree_update_kernel, dim3(1), dim3(ST_THREADS), 0, (hipStream_t)stream, u);
+    LAUNCH_CHECK("sumtree_update_clamped");
     return MORL_OK;
 }

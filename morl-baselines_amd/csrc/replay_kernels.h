@@ -220,6 +220,7 @@ struct SumTreeUpdate {
     double* pr_out;          // or NULL
     int n_levels, B;
     float alpha;
+    float clamp_min;         // > 0 (with alpha >= 0): priority = max(raw, clamp_min) ** alpha (GPIPD.update, gpi_pd.py:507-526)
 };
 
 // The update as a workgroup-level routine (any block size that is a multiple of 64; `lds` = ST_LDS_BYTES of scratch, 8-byte
@@ -237,8 +238,9 @@ __device__ __forceinline__ void sumtree_update_body(const SumTreeUpdate& a, void
     const float rmax = (float)(*a.running_max);
     float lmax = -INFINITY;
     for (int k = tid; k < B; k += nt) {
-        // alpha < 0: raw already is the priority (plain PrioritizedReplayBuffer.update_priorities)
-        const float p = (a.alpha < 0.f) ? a.raw[k] : powf(__fadd_rn(a.raw[k], rmax), a.alpha);
+        // alpha < 0: raw already is the priority (plain PrioritizedReplayBuffer.update_priorities); clamp_min > 0: the GPI-PD form
+        const float p = (a.alpha < 0.f) ? a.raw[k] : (a.clamp_min > 0.f) ? powf(fmaxf(a.raw[k], a.clamp_min), a.alpha)
+                                                                          : powf(__fadd_rn(a.raw[k], rmax), a.alpha);
         s_pr[k] = p;
         if (a.pr_out) a.pr_out[k] = (double)p;
         lmax = fmaxf(lmax, p);

@@ -8,7 +8,7 @@ import numpy as np
 import torch as th
 
 from . import native
-from .native import GPIBatch, GPICfg, GPIDesc, GPIOut, NativeLib
+from .native import GPIBatch, GPICfg, GPIDesc, GPIOut, GPIPer, NativeLib
 
 
 class GPIEngine:
@@ -131,6 +131,36 @@ class GPIEngine:
             self._h, self.q.data_ptr(), self.q_target.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), n, bs, cs,
             os_, self.lib.stream_of(self.q)))
         return [p[3] for p in packed]
+
+    def update_n_per(self, items: Sequence[dict], *, buffer, u01: np.ndarray, doubled: bool, use_gtd: bool, alpha: float,
+                     min_priority: float):
+        """``morl_gpi_update_n_per``: the same loop with prioritised replay in ONE library entry -- iteration k samples
+        ``buffer`` (a device ``PrioritizedReplayBuffer``) through its sum tree with the unit uniforms ``u01[k]``, gathers the
+        transitions into the batch tensors of ``items[k]`` (obs / actions / rewards / next_obs / dones: scratch the caller
+        allocated, B or 2 B rows; w / sampled_w filled), updates, and writes max(|td|, min_priority) ** alpha back into the
+        tree.  Returns (output dicts, sampled indices [n][B])."""
+        n = len(items)
+        u01 = np.ascontiguousarray(u01, dtype=np.float64).reshape(n, -1)
+        B = u01.shape[1]
+        buffer.flush()
+        packed = [self._pack(**kw) for kw in items]
+        bs, cs, os_ = (GPIBatch * n)(), (GPICfg * n)(), (GPIOut * n)()
+        for k, (b, cfg, out, _res, _keep) in enumerate(packed):
+            bs[k], cs[k], os_[k] = b, cfg, out
+        dev = self.q.device
+        u_dev = th.as_tensor(u01).to(dev)
+        idx = th.empty((n, B), dtype=th.int64, device=dev)
+        per = GPIPer()
+        per.tree, per.running_max, per.u01 = buffer.tree_dev.data_ptr(), buffer.running_max.data_ptr(), u_dev.data_ptr()
+        per.records, per.idx = buffer.records.data_ptr(), idx.data_ptr()
+        per.capacity, per.record_floats = buffer.records.shape[0], buffer.records.shape[1]
+        per.n_levels, per.D, per.R, per.action_dim, per.B = buffer.n_levels, buffer._D, buffer._R, buffer._Ad, B
+        per.doubled, per.use_gtd, per.alpha, per.min_priority = int(doubled), int(use_gtd), float(alpha), float(min_priority)
+        self.lib.check_device(buffer.tree_dev, buffer.running_max, buffer.records)
+        self.lib.check(self.lib.lib.morl_gpi_update_n_per(
+            self._h, self.q.data_ptr(), self.q_target.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), n,
+            C.byref(per), bs, cs, os_, self.lib.stream_of(self.q)))
+        return [p[3] for p in packed], idx
 
     def q_forward(self, obs, w, *, nets: int = 1, target: bool = False) -> th.Tensor:
         """Q(obs_row, w) of the first ``nets`` ensemble members, eval mode: (nets, rows, A, R).  ``w``: (R,) or (rows, R)."""

@@ -202,24 +202,51 @@ class GPIPD(MOPolicy, MOAgent):
         self._last_rollout = {"imagined": added, "uncertainty_mean": float(unc.mean())}
 
     # -- the hot path (gpi_pd.py:416-562) --------------------------------------------------------------------------------------
+    per_one_entry_enabled = True      # False: one sample / update / update_priorities entry per iteration (the A/B of the tests)
+
     def update(self, weight: th.Tensor):
         e = self.engine
         dev = e.q.device
         weight = th.as_tensor(weight).to(dev, th.float32).reshape(-1)
         critic_losses, priority, gpriority, deferred = [], None, None, []
-        for g in range(self.gradient_updates if self.global_step >= self.dynamics_rollout_starts else 1):
-            batch = self._sample_batch_experiences()
-            s_obs, s_actions, s_rewards, s_next_obs, s_dones = batch[:5]
-            idxes = batch[5] if self.per else None
-            B = s_obs.size(0)
-            n_per = idxes.numel() if idxes is not None else B      # the imagined rows of a Dyna batch carry no priority
-            if len(self.weight_support) > 1:
-                s_obs, s_rewards, s_next_obs, s_dones = (x.reshape(B, -1).repeat(2, 1) for x in
-                                                         (s_obs, s_rewards, s_next_obs, s_dones))
-                s_actions = s_actions.reshape(-1).repeat(2)
+        n_updates = self.gradient_updates if self.global_step >= self.dynamics_rollout_starts else 1
+        real_only = not self.dyna or self.global_step < self.dynamics_rollout_starts or len(self.dynamics_buffer) == 0
+        per_one_entry = self.per_one_entry_enabled and self.per and real_only and self.replay_buffer._int_actions and \
+            self.replay_buffer._Ad == 1
+        B = self.batch_size
+        doubled = len(self.weight_support) > 1
+        if per_one_entry:
+            # the whole loop as ONE library entry (morl_gpi_update_n_per): the host draws what the reference's loop draws, in its
+            # order per generator (numpy: the B unit uniforms of each PrioritizedReplayBuffer.sample; random: choices / sample) --
+            # none of it depends on what the device computes -- and the device samples, updates and re-prioritises per iteration
+            rows = 2 * B if doubled else B
+            sc = self.__dict__.get("_per_scratch")
+            if sc is None or sc[0].shape[0] != rows:
+                D, R = self.replay_buffer._D, self.replay_buffer._R
+                sc = (th.empty((rows, D), dtype=th.float32, device=dev), th.empty((rows,), dtype=th.int32, device=dev),
+                      th.empty((rows, R), dtype=th.float32, device=dev), th.empty((rows, D), dtype=th.float32, device=dev),
+                      th.empty((rows,), dtype=th.float32, device=dev))
+                self._per_scratch = sc
+            u01 = np.empty((n_updates, B), dtype=np.float64)
+        for g in range(n_updates):
+            if per_one_entry:
+                u01[g] = np.random.random_sample(B)
+                s_obs, s_actions, s_rewards, s_next_obs, s_dones = sc
+                idxes, n_per = True, B
+            else:
+                batch = self._sample_batch_experiences()
+                s_obs, s_actions, s_rewards, s_next_obs, s_dones = batch[:5]
+                idxes = batch[5] if self.per else None
+                B = s_obs.size(0)
+                n_per = idxes.numel() if idxes is not None else B      # the imagined rows of a Dyna batch carry no priority
+            if doubled:
+                if not per_one_entry:
+                    s_obs, s_rewards, s_next_obs, s_dones = (x.reshape(B, -1).repeat(2, 1) for x in
+                                                             (s_obs, s_rewards, s_next_obs, s_dones))
+                    s_actions = s_actions.reshape(-1).repeat(2)
                 w = th.vstack([weight.expand(B, -1)] + random.choices(self.weight_support, k=B))
             else:
-                w = weight.repeat(s_obs.size(0), 1)
+                w = weight.repeat(B, 1)
             if len(self.weight_support) > 5:
                 sampled_w = th.stack([weight] + random.sample(self.weight_support, k=4))
             else:
@@ -232,7 +259,7 @@ class GPIPD(MOPolicy, MOAgent):
                       sampled_w=sampled_w, gamma=self.gamma, lr=self.learning_rate, adam_step=self._adam_step,
                       min_priority=self.min_priority, max_grad_norm=self.max_grad_norm, gpi_pd=self.gpi_pd,
                       n_per=(n_per if (self.per or self.gpi_pd) else 0), dropout_seed=self._drop_seed, want=want)
-            if idxes is None:
+            if idxes is None or per_one_entry:
                 # no prioritised replay: iteration g + 1 does not sample through what iteration g wrote, so the whole loop is
                 # drawn first and submitted as ONE library entry below (morl_gpi_update_n)
                 deferred.append(kw)
@@ -246,7 +273,12 @@ class GPIPD(MOPolicy, MOAgent):
                 priority = out["td_error"].clamp(min=self.min_priority).pow(self.alpha)
             self.replay_buffer.update_priorities(idxes, gpriority if self.gpi_pd else priority)
         if deferred:
-            outs = [e.update(**deferred[0])] if len(deferred) == 1 else e.update_n(deferred)
+            if per_one_entry:
+                outs, self._last_per_idx = e.update_n_per(deferred, buffer=self.replay_buffer, u01=u01, doubled=doubled,
+                                                          use_gtd=self.gpi_pd, alpha=self.alpha, min_priority=self.min_priority)
+                priority = outs[-1]["td_error"].clamp(min=self.min_priority).pow(self.alpha)
+            else:
+                outs = [e.update(**deferred[0])] if len(deferred) == 1 else e.update_n(deferred)
             self._out = outs[-1]
             critic_losses += [o["critic_loss"] for o in outs]
             if self.gpi_pd:

@@ -230,23 +230,48 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
                        "dynamics/uncertainty_min": unc.min(), "global_step": self.global_step})
 
     # -- the hot path (gpi_pd_continuous_action.py:373-452) ---------------------------------------------------------------
+    per_one_entry_enabled = True      # False: one sample / update / update_priorities entry per iteration (the A/B of the tests)
+
     def update(self, weight: th.Tensor):
         e = self.engine
         dev = e.q.device
         weight = as_f32(weight, dev).reshape(-1)
         priority, deferred = None, []
-        for _ in range(self.gradient_updates):
-            batch = self._sample_batch_experiences()
-            s_obs, s_actions, s_rewards, s_next_obs, s_dones = batch[:5]
-            idxes = batch[5] if self.per else None
-            B = s_obs.size(0)
-            n_per = idxes.numel() if idxes is not None else B      # the imagined rows of a Dyna batch carry no priority
-            if len(self.weight_support) > 1:
-                s_obs, s_actions, s_rewards, s_next_obs, s_dones = (x.repeat(2, 1) for x in
-                                                                    (s_obs, s_actions, s_rewards, s_next_obs, s_dones))
+        real_only = not self.dyna or self.global_step < self.dynamics_rollout_starts or len(self.dynamics_buffer) == 0
+        per_one_entry = self.per_one_entry_enabled and self.per and real_only and not self.replay_buffer._int_actions
+        B = self.batch_size
+        doubled = len(self.weight_support) > 1
+        if per_one_entry:
+            # the whole loop as ONE library entry (morl_ac_update_n_per): the host draws what the reference's loop draws, in its
+            # order per generator (numpy: the B unit uniforms of each PrioritizedReplayBuffer.sample; random: choices; torch: the
+            # target noise) -- none of it depends on what the device computes
+            rows = 2 * B if doubled else B
+            sc = self.__dict__.get("_per_scratch")
+            if sc is None or sc[0].shape[0] != rows:
+                D, R, Ad = self.replay_buffer._D, self.replay_buffer._R, self.replay_buffer._Ad
+                sc = (th.empty((rows, D), dtype=th.float32, device=dev), th.empty((rows, Ad), dtype=th.float32, device=dev),
+                      th.empty((rows, R), dtype=th.float32, device=dev), th.empty((rows, D), dtype=th.float32, device=dev),
+                      th.empty((rows, 1), dtype=th.float32, device=dev))
+                self._per_scratch = sc
+            u01 = np.empty((self.gradient_updates, B), dtype=np.float64)
+        for g in range(self.gradient_updates):
+            if per_one_entry:
+                u01[g] = np.random.random_sample(B)
+                s_obs, s_actions, s_rewards, s_next_obs, s_dones = sc
+                idxes, n_per = True, B
+            else:
+                batch = self._sample_batch_experiences()
+                s_obs, s_actions, s_rewards, s_next_obs, s_dones = batch[:5]
+                idxes = batch[5] if self.per else None
+                B = s_obs.size(0)
+                n_per = idxes.numel() if idxes is not None else B      # the imagined rows of a Dyna batch carry no priority
+            if doubled:
+                if not per_one_entry:
+                    s_obs, s_actions, s_rewards, s_next_obs, s_dones = (x.repeat(2, 1) for x in
+                                                                        (s_obs, s_actions, s_rewards, s_next_obs, s_dones))
                 w = th.vstack([weight.expand(B, -1)] + random.choices(self.weight_support, k=B))
             else:
-                w = weight.repeat(s_obs.size(0), 1)
+                w = weight.repeat(B, 1)
             rows = s_obs.size(0)
             do_policy = self._n_updates % self.delay_policy_update == 0
             self._q_step += 1
@@ -262,7 +287,7 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
             kw = dict(obs=s_obs, actions=s_actions, rewards=s_rewards, next_obs=s_next_obs, dones=s_dones.reshape(-1), w=w,
                       eps_next=noise, want=want)
             self._n_updates += 1
-            if not self.per:
+            if not self.per or per_one_entry:
                 # no prioritised replay: nothing of iteration g feeds the sampling of iteration g + 1 -- the loop is drawn first
                 # and submitted as ONE library entry below (morl_ac_update_n)
                 deferred.append(dict(kw, cfg=cfg))
@@ -272,7 +297,11 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
             priority = out["priority"][0].clamp(min=self.min_priority).pow(self.alpha)
             self.replay_buffer.update_priorities(idxes, priority)
         if deferred:
-            if len(deferred) == 1:
+            if per_one_entry:
+                outs, self._last_per_idx = e.update_n_per(deferred, buffer=self.replay_buffer, u01=u01, doubled=doubled,
+                                                          alpha=self.alpha, min_priority=self.min_priority)
+                priority = outs[-1]["priority"][0].clamp(min=self.min_priority).pow(self.alpha)
+            elif len(deferred) == 1:
                 kw = deferred[0]
                 outs = [e.update(kw.pop("cfg"), **kw)]
             else:

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
 
 MORL_MAX_LAYERS = 8
 MORL_MAX_OBJ = 8
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class NetDesc(C.Structure):
@@ -100,6 +100,13 @@ class GPICfg(C.Structure):
 class GPIBatch(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("obs", "actions", "rewards", "next_obs", "dones", "w", "sampled_w", "drop_masks")] + \
                [("rows", C.c_int32), ("K", C.c_int32)]
+
+
+class GPIPer(C.Structure):
+    """``morl_gpi_per`` (the prioritised-replay side of ``morl_gpi_update_n_per``)."""
+    _fields_ = [(n, C.c_void_p) for n in ("tree", "running_max", "u01", "records", "idx")] + [("capacity", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("n_levels", "record_floats", "D", "R", "action_dim", "B", "doubled", "use_gtd")] + \
+               [("alpha", C.c_float), ("min_priority", C.c_float)]
 
 
 GPI_OUT_FIELDS = ("critic_loss", "td_error", "gtd_error", "target_q", "target_q_envelope", "grads", "grad_norm")
@@ -190,6 +197,8 @@ _SIGNATURES = {
     "morl_sumtree_set": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "morl_sumtree_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    "morl_sumtree_update_clamped": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "morl_ens_param_count": (C.c_int64, [C.POINTER(EnsDesc)]),
     "morl_ens_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(EnsDesc)]),
     "morl_ens_destroy": (C.c_int, [C.c_void_p]),
@@ -224,6 +233,10 @@ _SIGNATURES = {
                                    C.POINTER(ACOut), C.c_void_p]),
     "morl_gpi_update_n": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.POINTER(GPIBatch), C.POINTER(GPICfg), C.POINTER(GPIOut),
                                                         C.c_void_p]),
+    "morl_gpi_update_n_per": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.POINTER(GPIPer), C.POINTER(GPIBatch), C.POINTER(GPICfg),
+                                        C.POINTER(GPIOut), C.c_void_p]),
+    "morl_ac_update_n_per": (C.c_int, [C.c_void_p, C.POINTER(ACState), C.c_int, C.POINTER(GPIPer), C.POINTER(ACBatch), C.POINTER(ACCfg),
+                                       C.POINTER(ACOut), C.c_void_p]),
     "morl_ac_policy_forward": (C.c_int, [C.c_void_p, C.POINTER(ACState), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                          C.c_void_p, C.c_int, C.POINTER(ACCfg), C.c_void_p, C.c_void_p, C.c_void_p]),
     "morl_ac_q_forward": (C.c_int, [C.c_void_p, C.POINTER(ACState), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

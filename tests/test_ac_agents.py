@@ -505,3 +505,36 @@ def test_gpi_eval_with_64_weight_support(be):
         # the device's own best value is the oracle's (guards against a near-tie flipping the index silently)
         got_rows = (np.abs(acts.numpy() - a[None]).max(1) < 1e-4).nonzero()[0]
         assert got_rows.size >= 1 and abs(float(sc[:, got_rows[0]].max()) - best) <= 1e-5 * max(1.0, abs(best))
+
+
+@pytest.mark.parametrize("n_support", [3, 1])
+def test_prioritised_loop_in_one_call_equals_sequential_updates(be, n_support):
+    """GPI-PD with continuous actions, ``per=True`` (the reference's default): the ``gradient_updates`` loop goes through ONE
+    library entry (``morl_ac_update_n_per``: per iteration tree descent + gather, TD3 update, priorities back into the tree) and
+    takes exactly the steps of one sample / update / ``update_priorities`` round per iteration
+    (gpi_pd_continuous_action.py:373-417).  Parameters and optimiser state to the last bit, the tree to 1e-6 (torch's pow on the
+    sequential path, the device's powf inside the tree-update launch on the other)."""
+    lib, dev = be
+    support = [np.array([1.0, 0.0], np.float32), np.array([0.0, 1.0], np.float32), np.array([0.4, 0.6], np.float32)][:n_support]
+    runs = []
+    for one_entry in (True, False):
+        env = BoxEnv(D=5, Ad=2, low=-2.0, high=1.0)
+        th.manual_seed(0)
+        ag = GPILSContinuousAction(env, net_arch=[32, 32], batch_size=8, buffer_size=128, gradient_updates=5, per=True,
+                                   log=False, seed=0, device=dev, lib=lib)
+        ag.per_one_entry_enabled = one_entry
+        fill_buffer(ag.replay_buffer, 60, 5, 2, 2, low=-2.0, high=1.0)
+        ag.set_weight_support(support)
+        np.random.seed(2); random.seed(2); th.manual_seed(2)
+        for _ in range(2):
+            ag.update(th.tensor([0.7, 0.3]))
+        e, b = ag.engine, ag.replay_buffer
+        b.flush()
+        runs.append((e.q.clone().cpu(), e.pol.clone().cpu(), e.q_target.clone().cpu(), e.q_exp_avg.clone().cpu(),
+                     b.tree_dev.clone().cpu(), b.running_max.clone().cpu(), np.random.random_sample(), random.random()))
+    a, s = runs
+    for k in range(4):
+        assert th.equal(a[k], s[k]), k
+    for k in (4, 5):
+        assert th.allclose(a[k], s[k], rtol=1e-6, atol=0.0), k
+    assert a[6] == s[6] and a[7] == s[7]

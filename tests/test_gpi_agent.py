@@ -165,3 +165,48 @@ def test_gradient_updates_loop_in_one_call_equals_sequential_updates(be):
         runs.append((e.q.clone().cpu(), e.exp_avg.clone().cpu(), ag.last_loss(), ag._adam_step))
     a, b = runs
     assert th.equal(a[0], b[0]) and th.equal(a[1], b[1]) and a[2] == b[2] and a[3] == b[3] == 3
+
+
+@pytest.mark.parametrize("gpi_pd, n_support", [(True, 3), (False, 3), (True, 1), (True, 7)])
+def test_prioritised_loop_in_one_call_equals_sequential_updates(be, gpi_pd, n_support):
+    """With prioritised replay (the reference's default) the loop goes through ``morl_gpi_update_n_per``: the host pre-draws the
+    uniforms / weight choices in the reference's order, the device samples through the tree, updates and re-prioritises per
+    iteration.  Same parameters, optimiser state, tree, running maximum and sampled indices as one ``update`` call per
+    iteration (sample -> morl_gpi_update -> update_priorities) (gpi_pd.py:416-420, 507-526).  Parameters and optimiser state to
+    the last bit (the same transitions were sampled); the tree to 1e-6: the sequential path raises the priorities to ``alpha``
+    with torch's pow, the one-entry path with the device's powf inside the tree-update launch."""
+    lib, dev = be
+    D, A, R = 9, 4, 2
+    rng = np.random.default_rng(3)
+    support = [np.array([1.0, 0.0], np.float32), np.array([0.0, 1.0], np.float32)] + \
+        [rng.dirichlet(np.ones(2)).astype(np.float32) for _ in range(5)]
+    support = support[:n_support]
+    runs = []
+    for one_entry in (True, False):
+        env = momdp.TreasureLine(0)
+        th.manual_seed(0)
+        ag = GPIPD(env, net_arch=[32, 32, 32], batch_size=8, buffer_size=128, learning_starts=10, gradient_updates=4,
+                   dyna=False, per=True, gpi_pd=gpi_pd, drop_rate=0.01, log=False, seed=0, device=dev, lib=lib)
+        ag.per_one_entry_enabled = one_entry
+        fill(ag.replay_buffer, 50, D, A, R)
+        ag.set_weight_support(support)
+        ag.global_step = ag.dynamics_rollout_starts + 7          # past the single-update phase; not a target-sync step
+        np.random.seed(5); random.seed(5)
+        idx_log = []
+        for _ in range(2):
+            ag.update(th.tensor([0.5, 0.5]))
+            if one_entry:
+                idx_log.append(ag._last_per_idx.cpu().clone())
+        e, b = ag.engine, ag.replay_buffer
+        b.flush()
+        runs.append((e.q.clone().cpu(), e.exp_avg.clone().cpu(), e.exp_avg_sq.clone().cpu(), b.tree_dev.clone().cpu(),
+                     b.running_max.clone().cpu(), ag.last_loss(), ag._adam_step, np.random.random_sample(), random.random(),
+                     idx_log))
+    a, s = runs
+    assert a[6] == s[6] == 8
+    for k in range(3):
+        assert th.equal(a[k], s[k]), k
+    for k in (3, 4):
+        assert th.allclose(a[k], s[k], rtol=1e-6, atol=0.0), k
+    assert a[5] == s[5] and a[7] == s[7] and a[8] == s[8]       # (both generators left where the sequential loop leaves them)
+    assert len(a[9]) == 2 and a[9][0].shape == (4, 8) and int(a[9][0].min()) >= 0 and int(a[9][0].max()) < 50
