@@ -1341,7 +1341,6 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         a.n = L;
         a.rows = rows;
         a.slab_stride = c->P;
-        long long units = 0;                        // (output group, input group) pairs over all problems: each costs `rows` rows of chunks
         for (int l = 0; l < L; ++l) {
             DwbProblem& q = a.p[l];
             q.G = c->g[l];
@@ -1354,22 +1353,40 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             q.M = n.dims[l + 1]; q.N = n.dims[l];
             q.gcols = q.ldg; q.hcols = q.ldh;      // (pad columns of dq / x0 are written as zeros by their producers)
             // the kernel's three compile-time shapes (operand tiles beyond the matrix are zero fragments): a narrow output (the Q
-            // head), a narrow input (the first layer), or 128 x 128 blocks.  Jobs are balanced by their CHUNK count, not by their
-            // MFMAs: no chunk is shorter than the producers' load -> split -> write turn-around
+            // head), a narrow input (the first layer), or 128 x 128 blocks
             q.shape = (q.M <= 32) ? 2 : (q.N <= 64) ? 1 : 0;
             q.mgroups = (q.M + 16 * DWB_TG[q.shape] - 1) / (16 * DWB_TG[q.shape]);
             q.ngroups = (q.N + 16 * DWB_TH[q.shape] - 1) / (16 * DWB_TH[q.shape]);
-            units += (long long)q.mgroups * q.ngroups;
         }
-        const int target = c->num_cus;              // one 768-work-item workgroup per CU (96 KB of LDS, 3 waves per SIMD)
-        int base = round_up(std::max(1, (int)((units * rows + target - 1) / target)), DWB_BK);
-        while ((rows + base - 1) / base > c->max_splits) base += DWB_BK;       // the split count must fit the slab buffer
-        int jobs = 0, r = 0;
+        const bool per_rides = cfg->per_tree && i_offset == 0 && out->priority && B <= ST_MAX_B;
+        // One 768-work-item workgroup per CU (96 KB of LDS, 3 waves per SIMD), ONE round: row slices sized so that every job costs
+        // the same and there are at most as many jobs as CUs -- one CU fewer when the step's PER tree update rides along as an extra
+        // workgroup: it is 17 us of serial tree levels, hidden only if it starts with the jobs (as block 257 of 256 it started when
+        // the first job ended: + 6.7 us).  Cost of a 32-row chunk by shape (cycles, profiles/r04_dw_bf_probe.txt): 2 630 / 2 080 /
+        // 2 100 -- the producers' load -> split -> write turn-around bounds all three, the 128 x 128 shape also waits for its 96
+        // MFMAs per consumer -- i.e. 5 : 4 : 4.
+        static const int shape_cost[3] = {5, 4, 4};
+        const int target = std::max(1, c->num_cus - (per_rides ? 1 : 0));
+        const int chunks_total = (rows + DWB_BK - 1) / DWB_BK;
+        int jobs = 0;
+        for (int budget = 5;; ++budget) {           // cost budget of a job, in fifths of a 128 x 128 chunk
+            jobs = 0;
+            bool fits = true;
+            for (int l = 0; l < L; ++l) {
+                DwbProblem& q = a.p[l];
+                const int k = std::max(1, budget / shape_cost[q.shape]);          // chunks per job
+                q.k_per_split = k * DWB_BK;
+                q.splits = (chunks_total + k - 1) / k;
+                if (q.splits > c->max_splits) fits = false;
+                jobs += q.splits * q.mgroups * q.ngroups;
+            }
+            if ((fits && jobs <= target) || budget >= 5 * chunks_total) break;   // (one job per (problem, group): nothing left to merge)
+        }
+        int r = 0;
+        jobs = 0;
         splits = 0;
         for (int l = 0; l < L; ++l) {
             DwbProblem& q = a.p[l];
-            q.k_per_split = base;
-            q.splits = (rows + base - 1) / base;
             q.job_start = jobs;
             jobs += q.splits * q.mgroups * q.ngroups;
             splits = std::max(splits, q.splits);
@@ -1379,7 +1396,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         ranges.n = r;
         a.jobs = jobs;
         int extra = 0;
-        if (cfg->per_tree && i_offset == 0 && out->priority && B <= ST_MAX_B) {     // the step's PER update rides along
+        if (per_rides) {                            // the step's PER update rides along
             a.per.tree = cfg->per_tree; a.per.idx = cfg->per_idx; a.per.raw = out->priority;
             a.per.running_max = cfg->per_running_max; a.per.pr_out = nullptr;
             a.per.n_levels = cfg->per_levels; a.per.B = B; a.per.alpha = cfg->per_alpha;
