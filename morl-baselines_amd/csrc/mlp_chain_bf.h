@@ -153,6 +153,8 @@ struct BfRing {
     int buf;                       // t % 3
     int n_stages;
     int wave;
+    int dma_soff;                  // the DMA group a wide stage's entry left to its MFMA steps (bf_ring_piece): byte offset of the
+    unsigned char* dma_lds;        //   stage in the stream, this wave's share of the LDS buffer it goes to
 #ifdef BF_PROF
     long long t_entry, t_dma;
 #endif
@@ -185,6 +187,41 @@ __device__ __forceinline__ void bf_ring_issue(const BfRing& r, int st, int buf) 
     if (DPW == 6) BF_DMA4(1, 2)
     else { BF_DMA4(1, 4) BF_DMA4(2, 4) }
 #undef BF_DMA4
+}
+
+// One 1 KB piece (0 .. 24 / NW - 1) of the group set up by bf_stage_enter: issued BETWEEN the MFMAs of the stage (one piece behind
+// a product step's two MFMAs), where its ~25 - 45 issue cycles run under the matrix pipe's 32 -- all of a group in one burst
+// right behind the barrier was a seventh of a wave's time in the backward chain (one wave per SIMD: nobody else to feed the pipe).
+template <int NW, int PIECE>
+__device__ __forceinline__ void bf_ring_piece(const BfRing& r) {
+    constexpr int DPW = BF_STAGE_BLOCKS / NW;
+    if (PIECE >= 0 && PIECE < DPW) {
+        constexpr int G = (PIECE < 0 ? 0 : PIECE) / 4, J = (PIECE < 0 ? 0 : PIECE) % 4;
+        __attribute__((address_space(3))) void* lg = (__attribute__((address_space(3))) void*)(r.dma_lds + G * 4 * BF_BLOCK);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r.rsrc, lg, 16, r.voff, r.dma_soff + G * 4 * BF_BLOCK, J * BF_BLOCK, 0);
+    }
+}
+
+// Entry of a WIDE stage: as bf_stage_begin, but the DMA group of the stage two ahead is only set up here; the stage's product steps
+// issue its pieces (every one of them before the next entry, so the counted waits see the same issue order).
+template <int NW, int EXTRA>
+__device__ __forceinline__ const unsigned char* bf_stage_enter(BfRing& r) {
+#ifdef BF_PROF
+    const long long t0_ = clock64();
+#endif
+    BF_VMCNT_LDS0(BF_STAGE_BLOCKS / NW + EXTRA);
+    __builtin_amdgcn_s_barrier();
+#ifdef BF_PROF
+    r.t_entry += clock64() - t0_;
+#endif
+    const int free_buf = r.buf == 0 ? 2 : r.buf - 1;
+    const int st = r.t + 2 < r.n_stages ? r.t + 2 : r.n_stages - 1;       // (clamped: the issue count per stage is static)
+    r.dma_soff = st * BF_STAGE_BYTES;
+    r.dma_lds = r.lds + free_buf * BF_STAGE_BYTES + r.wave * ((BF_STAGE_BLOCKS / NW) * BF_BLOCK);
+    const unsigned char* base = r.lds + r.buf * BF_STAGE_BYTES;
+    r.buf = r.buf == 2 ? 0 : r.buf + 1;
+    ++r.t;
+    return base;
 }
 
 // Entry of stage r.t: my share of it has landed (EXTRA = vector-memory instructions this lane issued AFTER the DMA group of the
@@ -226,9 +263,11 @@ __device__ __forceinline__ void bf_frag_load(bf_u32x4 (&f)[3], const unsigned ch
 #define BF_PIN() __builtin_amdgcn_sched_barrier(0)
 // product steps [P0, P1) of a pair; READ: fragment k of the next pair (k = 0..5 in consumption order: lo, lo, mid, mid, hi, hi) is
 // read in front of product step rd[k] (steps outside [P0, P1) read nothing)
-template <int P0, int P1, bool READ, int R0 = 0, int R1 = 1, int R2 = 2, int R3 = 3, int R4 = 4, int R5 = 5>
+// NW / DMA0: product step p also issues piece DMA0 + (p - P0) of the weight group its stage's entry set up (DMA0 < 0: none).
+template <int P0, int P1, bool READ, int R0 = 0, int R1 = 1, int R2 = 2, int R3 = 3, int R4 = 4, int R5 = 5, int NW = 4, int DMA0 = -1>
 __device__ __forceinline__ void bf_six_part(f32x4& c0, f32x4& c1, const bf_u32x4 (&w0)[3], const bf_u32x4 (&w1)[3], const bf_u32x4 (&x)[3],
-                                            bf_u32x4 (&n0)[3], bf_u32x4 (&n1)[3], const unsigned char* next_base) {
+                                            bf_u32x4 (&n0)[3], bf_u32x4 (&n1)[3], const unsigned char* next_base,
+                                            const BfRing* ring = nullptr) {
     constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};
     constexpr int rd[6] = {R0, R1, R2, R3, R4, R5};
 #pragma unroll
@@ -244,13 +283,23 @@ __device__ __forceinline__ void bf_six_part(f32x4& c0, f32x4& c1, const bf_u32x4
         }
         c0 = bf_mfma(w0[pw[p]], x[px[p]], c0);
         c1 = bf_mfma(w1[pw[p]], x[px[p]], c1);
+        if (DMA0 >= 0) {
+            // (compile-time piece index: the instruction's offset field is an immediate)
+            if (p - P0 == 0) bf_ring_piece<NW, DMA0>(*ring);
+            if (p - P0 == 1) bf_ring_piece<NW, DMA0 < 0 ? -1 : DMA0 + 1>(*ring);
+            if (p - P0 == 2) bf_ring_piece<NW, DMA0 < 0 ? -1 : DMA0 + 2>(*ring);
+            if (p - P0 == 3) bf_ring_piece<NW, DMA0 < 0 ? -1 : DMA0 + 3>(*ring);
+            if (p - P0 == 4) bf_ring_piece<NW, DMA0 < 0 ? -1 : DMA0 + 4>(*ring);
+            if (p - P0 == 5) bf_ring_piece<NW, DMA0 < 0 ? -1 : DMA0 + 5>(*ring);
+        }
         BF_PIN();
     }
 }
-template <bool READ>
+template <bool READ, int NW = 4, int DMA0 = -1>
 __device__ __forceinline__ void bf_six_pair(f32x4& c0, f32x4& c1, const bf_u32x4 (&w0)[3], const bf_u32x4 (&w1)[3], const bf_u32x4 (&x)[3],
-                                            bf_u32x4 (&n0)[3], bf_u32x4 (&n1)[3], const unsigned char* next_base) {
-    bf_six_part<0, 6, READ>(c0, c1, w0, w1, x, n0, n1, next_base);
+                                            bf_u32x4 (&n0)[3], bf_u32x4 (&n1)[3], const unsigned char* next_base,
+                                            const BfRing* ring = nullptr) {
+    bf_six_part<0, 6, READ, 0, 1, 2, 3, 4, 5, NW, DMA0>(c0, c1, w0, w1, x, n0, n1, next_base, ring);
 }
 
 // One wide step (256 columns = 16 tiles) over KSTEPS k-steps: two stages per k-step (tiles 0-7, 8-15), per stage four tile pairs.
@@ -262,7 +311,7 @@ template <int NW, int KSTEPS, int EXTRA0>
 __device__ __forceinline__ void bf_wide_step(f32x4 (&acc)[16], const bf_u32x4 (&x)[8][3], BfRing& ring, int lane) {
     bf_u32x4 fa[2][3], fb[2][3];
     BF_PIN();
-    const unsigned char* base = bf_stage_begin<NW, EXTRA0>(ring) + lane * 16;
+    const unsigned char* base = bf_stage_enter<NW, EXTRA0>(ring) + lane * 16;
 #pragma unroll
     for (int pl = 2; pl >= 0; --pl) {       // (consumption order, pinned: the first MFMAs wait for the first two reads only)
         fa[0][pl] = *reinterpret_cast<const bf_u32x4*>(base + pl * BF_BLOCK);
@@ -275,17 +324,24 @@ __device__ __forceinline__ void bf_wide_step(f32x4 (&acc)[16], const bf_u32x4 (&
         for (int hf = 0; hf < 2; ++hf) {
             const int T = 8 * hf;
             const bool last = (s == KSTEPS - 1) && (hf == 1);
-            bf_six_pair<true>(acc[T + 0], acc[T + 1], fa[0], fa[1], x[s], fb[0], fb[1], base + 6 * BF_BLOCK);
-            bf_six_pair<true>(acc[T + 2], acc[T + 3], fb[0], fb[1], x[s], fa[0], fa[1], base + 12 * BF_BLOCK);
+            // the weight group this stage's entry set up goes out one piece per product step: from piece 0 when the entry was the
+            // step's first (in front of the stage), from piece 4 when it sat inside the previous stage's last pair (pieces 0 - 3 there)
+            if (s == 0 && hf == 0) {
+                bf_six_pair<true, NW, 0>(acc[T + 0], acc[T + 1], fa[0], fa[1], x[s], fb[0], fb[1], base + 6 * BF_BLOCK, &ring);
+                bf_six_pair<true, NW, 6>(acc[T + 2], acc[T + 3], fb[0], fb[1], x[s], fa[0], fa[1], base + 12 * BF_BLOCK, &ring);
+            } else {
+                bf_six_pair<true, NW, 4>(acc[T + 0], acc[T + 1], fa[0], fa[1], x[s], fb[0], fb[1], base + 6 * BF_BLOCK, &ring);
+                bf_six_pair<true, NW, 10>(acc[T + 2], acc[T + 3], fb[0], fb[1], x[s], fa[0], fa[1], base + 12 * BF_BLOCK, &ring);
+            }
             bf_six_pair<true>(acc[T + 4], acc[T + 5], fa[0], fa[1], x[s], fb[0], fb[1], base + 18 * BF_BLOCK);
             if (!last) {
                 // two product steps first: by the time the wave reaches the stage entry's wait, this pair's own fragments (read
                 // during the pair before) have long returned -- then the entry, then the other four steps with the next stage's first
-                // fragments riding along (2, 2, 1, 1)
+                // fragments riding along (2, 2, 1, 1) and the first four pieces of the group the entry set up
                 bf_six_part<0, 2, false>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
-                base = ((s == 0 && hf == 0) ? bf_stage_begin<NW, EXTRA0>(ring) : bf_stage_begin<NW, 0>(ring)) + lane * 16;
+                base = ((s == 0 && hf == 0) ? bf_stage_enter<NW, EXTRA0>(ring) : bf_stage_enter<NW, 0>(ring)) + lane * 16;
                 BF_PIN();
-                bf_six_part<2, 6, true, 2, 2, 3, 3, 4, 5>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
+                bf_six_part<2, 6, true, 2, 2, 3, 3, 4, 5, NW, 0>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base, &ring);
             } else {
                 bf_six_pair<false>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
             }
