@@ -45,6 +45,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             # rounding contract: a*b+c is never fused behind our back (the envelope scalarisation must round every
             # product and sum separately, as torch's einsum does); FMAs are written explicitly as fmaf()
             "-ffp-contract=off",
+            # A kernel reads its by-value argument block in place (scalar loads from the kernarg segment) only if instcombine can
+            # prove the block's local copy is never written -- a walk over the copy's users that gives up after 300 of them.  The
+            # split-bf16 chain kernels (six instantiations of the chain body over one argument block) are past that: without this
+            # the block is copied to SCRATCH memory at kernel entry and read from there (1.1 KB per work-item, 1.8 x the time).
+            # tests/test_build_flags.py holds the kernels to zero scratch.
+            "-mllvm", "-instcombine-max-copied-from-constant-users=4000",
             "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     if os.environ.get("MORL_BF_PROF"):     # development build: phase stamps in the split-bf16 chain kernels (mlp_chain_bf.h)
         base.append("-DBF_PROF")

@@ -152,6 +152,98 @@ __device__ __forceinline__ void env_scan(const float* q0, const float (&wi)[MORL
     }
 }
 
+// The arg-max stage (phase 1 of envelope_td_kernel) of ONE transition for a caller whose workgroup already holds the transition's
+// online slab in LDS -- the no-grad pass of the split-bf16 forward chain when its row tile IS the transition's W rows
+// (mlp_chain_bf.h): the launch of envelope_td_kernel<1> (10 us of latencies between the forward passes and the target rows)
+// becomes ~1 500 cycles at the end of workgroups that are resident anyway.  Same mapping -- lane <-> TD row i (W <= 64), the
+// caller's NW waves <-> slices of the (j, a) candidates --, same env_scan, same merge order, same compaction: best_io / row_slot
+// are bit-identical to the separate launch's, pairs_out up to the order of the compact rows (which varies from run to run there
+// too).  Every work-item of the workgroup calls it; W scalarisation vectors, i_groups = 1, the slab in [W][A][R] order.
+struct EnvArgmaxLds {
+    float* qo;      // [W * A * R]   filled by the caller (no barrier needed before the call)
+    float* w;       // [W * R]
+    float* pv;      // [NW][64]
+    int* pc;        // [NW][64]
+    int* mark;      // [W]
+    int* slot;      // [W]
+    int* best;      // [W]
+};
+// (the arguments as scalars, not as the EnvelopeTdArgs they come from: handed on as a struct out of another kernel's argument
+// block, hipcc copied that whole block to scratch memory -- 1.2 KB per work-item, both chain kernels 1.8 x slower)
+struct EnvArgmaxArgs {
+    const float* weights;
+    int32_t* best_io;
+    int32_t* pairs_out;
+    int32_t* row_slot;
+    int32_t* count;
+    int epoch, B, W, A, R, diag_only, i_offset, fma_scal, bmajor;
+};
+template <int NW>
+__device__ __forceinline__ void envelope_argmax_tile(const float* weights, int32_t* best_io, int32_t* pairs_out, int32_t* row_slot,
+                                                     int32_t* count, int epoch, int nB, int W, int A, int R, int diag_only,
+                                                     int i_offset, int fma_scal, int bmajor, int b, const EnvArgmaxLds L) {
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < W; e += 64 * NW) L.mark[e] = 0x7fffffff;
+    for (int e = tid; e < W * R; e += 64 * NW) L.w[e] = weights[e];
+    __syncthreads();
+    const int i = lane;
+    const bool live = i < W;
+    float wi[MORL_MAX_OBJ];
+#pragma unroll
+    for (int r = 0; r < MORL_MAX_OBJ; ++r) wi[r] = (live && r < R) ? L.w[i * R + r] : 0.f;
+    const int n_c = diag_only ? A : W * A;
+    const int c_off = (diag_only && live) ? (i + i_offset) * A : 0;
+    const int q_lo = (int)(((long long)n_c * wave) / NW), q_hi = (int)(((long long)n_c * (wave + 1)) / NW);
+    float best = -INFINITY;
+    int best_c = 0x7fffffff;
+    const float* qb = L.qo + (size_t)c_off * R;
+    switch (fma_scal ? R + MORL_MAX_OBJ : R) {
+#define MORL_TD_CASE(r) case r: env_scan<r, false>(qb, wi, q_lo, q_hi, c_off, best, best_c); break; \
+                        case r + MORL_MAX_OBJ: env_scan<r, true>(qb, wi, q_lo, q_hi, c_off, best, best_c); break;
+        MORL_TD_CASE(1) MORL_TD_CASE(2) MORL_TD_CASE(3) MORL_TD_CASE(4)
+        MORL_TD_CASE(5) MORL_TD_CASE(6) MORL_TD_CASE(7) MORL_TD_CASE(8)
+#undef MORL_TD_CASE
+        default: break;
+    }
+    if (live) { L.pv[wave * 64 + i] = best; L.pc[wave * 64 + i] = best_c; }
+    __syncthreads();
+    int jsel = 0;
+    if (wave == 0 && live) {
+        // merge the slices in candidate order: strictly greater replaces, so the first maximum wins
+        float bv = L.pv[lane];
+        int bc = L.pc[lane];
+        for (int q = 1; q < NW; ++q) {
+            const float v = L.pv[q * 64 + lane];
+            const int cc = L.pc[q * 64 + lane];
+            if (cc != 0x7fffffff && (bc == 0x7fffffff || v > bv)) { bv = v; bc = cc; }
+        }
+        L.best[i] = bc;
+        best_io[bmajor ? (size_t)b * W + i : (size_t)i * nB + b] = bc;
+        // distinct j* of the transition: the lowest TD row selecting a weight owns it, the owners take consecutive compact rows
+        jsel = bc / A;
+        atomicMin(&L.mark[jsel], i);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const bool first = live && L.mark[jsel] == i;
+        const unsigned long long won = __ballot(first);
+        if (won != 0ull) {
+            const int leader = __ffsll(won) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(count + (epoch & 1), __popcll(won));
+            base = __shfl(base, leader);
+            if (first) {
+                const int k = base + __popcll(won & ((1ull << lane) - 1ull));
+                pairs_out[k] = b * W + jsel;
+                L.slot[jsel] = k;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && live) row_slot[bmajor ? (size_t)b * W + i : (size_t)i * nB + b] = L.slot[jsel];
+    if (b == 0 && tid == 0) count[(epoch + 1) & 1] = 0;
+}
+
 // PHASE: EnvelopeTdArgs::phase as a compile-time constant -- the arg-max-only and TD-only launches of a lazily evaluated step do
 // not carry each other's code, registers and LDS (nor does the one-launch form: with the three in one body it ran 10.7 us instead
 // of 9.4 at the flagship shape).  (Also measured: the LDS sized per launch instead of for the largest slab -- 9 KB instead of

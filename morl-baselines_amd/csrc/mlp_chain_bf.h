@@ -30,6 +30,7 @@
 // activations / gradients of the training passes are written once, fp32, from the accumulators).
 #pragma once
 #include "mlp_chain.h"
+#include "envelope_kernels.h"
 
 namespace morl {
 
@@ -76,6 +77,9 @@ struct BfChain {
     int ldsrc, K0;
     float* x0_out;                         // in_mode 0, or NULL: the assembled rows also go to HBM as [rows][ldx0] (zero padded)
     int ldx0;
+    int amax;                              // 1: the head's output is the online next-state slab of an Envelope step whose row tiles are
+                                           //    whole transitions (tile rows == W): the workgroup also takes the arg-max of its
+                                           //    transition (BfMulti::td, envelope_argmax_tile) -- no separate arg-max launch
 };
 
 constexpr int BF_MAX_MULTI = 2;
@@ -83,6 +87,7 @@ struct BfMulti {
     BfChain c[BF_MAX_MULTI];
     int tile_start[BF_MAX_MULTI + 1];      // 64-row tiles of chain q: [tile_start[q], tile_start[q + 1])
     int n;
+    EnvArgmaxArgs td;                      // arguments of the arg-max stage for the chain with amax = 1
     long long* prof;                       // development builds only (-DBF_PROF, MORL_BF_PROF=1 python build.py): [tile][wave][BF_PROF_SLOTS]
 };
 // Phase stamps of a development build: s_memtime sums per wave -- 0 prologue (input rows, biases, first weight stages), 1 / 2 first
@@ -443,7 +448,9 @@ __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x
 // K0S: k-steps of the first step (1 or 2); MODE: see bf_wide_epilogue -- the chain writes per-step outputs (1, 2) and sign bits (1) or
 // reads mask words (2); compile-time also because the counted waits depend on the stores issued.
 template <int NW, int K0S, int MODE>
-__device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsigned char* ring_lds, float* bias_lds, long long* prof) {
+__device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsigned char* ring_lds, float* bias_lds, long long* prof,
+                                              const float* am_w, int32_t* am_best, int32_t* am_pairs, int32_t* am_slot,
+                                              int32_t* am_count, int am_epoch, int am_B, int am_W, int am_A, int am_R, int am_flags) {
 #ifdef BF_PROF
     long long pt[6] = {0, 0, 0, 0, 0, 0}, tp_ = clock64();
     const long long tstart_ = tp_;
@@ -554,9 +561,9 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
         BF_T(4)
     }
     // ---- the head -----------------------------------------------------------------------------------------------------------------
+    f32x4 hacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     if (p.head) {
         const BfStep& st = p.step[p.n_steps - 1];
-        f32x4 hacc[2];
         bf_acc_init<2>(hacc, bias_lds + (p.n_steps - 1) * BF_WIDE, q);
         if (st.N > 16) bf_head_step<NW, 2, MODE != 0 ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
         else bf_head_step<NW, 1, MODE != 0 ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
@@ -573,6 +580,29 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     }
     // nothing of this workgroup may still be in flight into LDS when the next workgroup of the CU takes the allocation
     BF_VMCNT(0);
+    if (MODE == 0 && p.amax) {
+        // The tile is one transition (rows b * W + j, j = 0 .. W - 1 = 16 NW - 1) and the head's accumulators are its online slab
+        // Q(s'_b, a, w_j): arg-max of the transition's W TD rows here, from LDS (the ring is drained: its first stages are free)
+        __syncthreads();
+        const int AR = p.step[p.n_steps - 1].N;
+        EnvArgmaxLds L;
+        L.qo = reinterpret_cast<float*>(ring_lds);
+        L.w = L.qo + 16 * NW * 32;                              // (AR <= 32)
+        L.pv = L.w + 16 * NW * MORL_MAX_OBJ;
+        L.pc = reinterpret_cast<int*>(L.pv + NW * 64);
+        L.mark = L.pc + NW * 64;
+        L.slot = L.mark + 64;
+        L.best = L.slot + 64;
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 16 * T + 4 * q + r;
+                if (n < AR) L.qo[(16 * wave + m) * AR + n] = hacc[T][r];
+            }
+        envelope_argmax_tile<NW>(am_w, am_best, am_pairs, am_slot, am_count, am_epoch, am_B, am_W, am_A, am_R, am_flags & 1, 0,
+                                 (am_flags >> 1) & 1, (am_flags >> 2) & 1, row0 / (16 * NW), L);
+    }
     BF_T(5)
 #ifdef BF_PROF
     if (prof != nullptr && lane == 0) {
@@ -596,15 +626,19 @@ __device__ __forceinline__ void mlp_chain_bf_entry(const BfMulti& m, unsigned ch
     const BfChain& p = m.c[qn];
     const int row0 = (tile - m.tile_start[qn]) * (16 * NW);
     float* bias_lds = reinterpret_cast<float*>(lds + BF_RING * BF_STAGE_BYTES);
+    // (the arg-max arguments as scalars read HERE: a reference to the argument block handed into the chain body made hipcc copy
+    // the whole block to scratch memory, 1.1 KB per work-item)
+#define BF_AM m.td.weights, m.td.best_io, m.td.pairs_out, m.td.row_slot, m.td.count, m.td.epoch, m.td.B, m.td.W, m.td.A, m.td.R, \
+              (m.td.diag_only | (m.td.fma_scal << 1) | (m.td.bmajor << 2))
     const int mode = p.step[0].bits_in != nullptr ? 2 : (p.step[0].out != nullptr || p.step[0].bits_out != nullptr) ? 1 : 0;
     if (p.k0_steps == 1) {
-        if (mode == 2) bf_chain_body<NW, 1, 2>(p, row0, lds, bias_lds, m.prof);
-        else if (mode == 1) bf_chain_body<NW, 1, 1>(p, row0, lds, bias_lds, m.prof);
-        else bf_chain_body<NW, 1, 0>(p, row0, lds, bias_lds, m.prof);
+        if (mode == 2) bf_chain_body<NW, 1, 2>(p, row0, lds, bias_lds, m.prof, BF_AM);
+        else if (mode == 1) bf_chain_body<NW, 1, 1>(p, row0, lds, bias_lds, m.prof, BF_AM);
+        else bf_chain_body<NW, 1, 0>(p, row0, lds, bias_lds, m.prof, BF_AM);
     } else {
-        if (mode == 2) bf_chain_body<NW, 2, 2>(p, row0, lds, bias_lds, m.prof);
-        else if (mode == 1) bf_chain_body<NW, 2, 1>(p, row0, lds, bias_lds, m.prof);
-        else bf_chain_body<NW, 2, 0>(p, row0, lds, bias_lds, m.prof);
+        if (mode == 2) bf_chain_body<NW, 2, 2>(p, row0, lds, bias_lds, m.prof, BF_AM);
+        else if (mode == 1) bf_chain_body<NW, 2, 1>(p, row0, lds, bias_lds, m.prof, BF_AM);
+        else bf_chain_body<NW, 2, 0>(p, row0, lds, bias_lds, m.prof, BF_AM);
     }
 }
 

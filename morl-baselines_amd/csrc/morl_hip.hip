@@ -190,6 +190,7 @@ struct morl_ctx {
     int32_t* lz_pairs = nullptr;         // [max_rows] compact row -> pair
     int32_t* lz_count = nullptr;         // [2] distinct pairs of the steps of even / odd epoch
     int timing_kind_override = -1;       // MORL_TIMED_* of the next bracketed chain launch (-1: by its arguments)
+    bool lz_argmax_done = false;         // one-shot: this step's forward launch took the arg-max (mlp_chain_bf.h, BfChain::amax)
     bool lz_now = false;                 // this step runs lazily: the three below are what the target launch needs
     const float* lz_params_target = nullptr;
     const float* lz_next_obs = nullptr;
@@ -625,15 +626,26 @@ static BfChain bf_backward_chain(morl_ctx* c, int rows) {
 
 static int timing_open(morl_ctx* c, int kind, hipStream_t s, int* slot);
 static int timing_close(morl_ctx* c, int slot, hipStream_t s);
-static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStream_t s) {
-    BfMulti m{};
-    m.n = n;
+// row tile of a bf16 chain launch: 64-row tiles (4 waves) when they give every CU its two workgroups, else 32-row tiles (2 waves):
+// MORL_BF_TILE=64 / 32 forces
+static int bf_tile_rows(morl_ctx* c, const BfChain* chains, int n) {
     long long tiles64 = 0;
     for (int q = 0; q < n; ++q) tiles64 += (chains[q].rows + BF_TM - 1) / BF_TM;
-    // 64-row tiles (4 waves) when they give every CU its two workgroups, else 32-row tiles (2 waves): MORL_BF_TILE=64 / 32 forces
     static const int forced = [] { const char* e = getenv("MORL_BF_TILE"); return e ? atoi(e) : 0; }();      // (tuning)
     const bool small = forced ? forced == 32 : tiles64 < 2ll * c->num_cus;
-    const int tm = small ? 32 : BF_TM;
+    return small ? 32 : BF_TM;
+}
+
+static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStream_t s, const EnvelopeTdArgs* td = nullptr) {
+    BfMulti m{};
+    m.n = n;
+    const int tm = bf_tile_rows(c, chains, n);
+    const bool small = tm == 32;
+    if (td) {
+        m.td.weights = td->weights; m.td.best_io = td->best_io; m.td.pairs_out = td->pairs_out; m.td.row_slot = td->row_slot;
+        m.td.count = td->count; m.td.epoch = td->epoch; m.td.B = td->B; m.td.W = td->W; m.td.A = td->A; m.td.R = td->R;
+        m.td.diag_only = td->diag_only; m.td.i_offset = td->i_offset; m.td.fma_scal = td->fma_scal; m.td.bmajor = td->bmajor;
+    }
     int tiles = 0;
     for (int q = 0; q < n; ++q) {
         m.c[q] = chains[q];
@@ -1223,14 +1235,25 @@ static EnvelopeTdArgs td_args(morl_ctx* c, const morl_update_cfg* cfg, const mor
 // Lazy target evaluation, the part that needs the ONLINE next-state slab only: (1) arg-max, every selected (b, j*) pair takes a
 // compact target row; (2) the target network on those rows -- few-row tiles sized for the worst case, tiles beyond the count exit
 // at once.  (Measured and dropped in round 3: the same tiles as extra workgroups of the training pass's launch.)
-static int lazy_phase1(morl_ctx* c, const EnvelopeTdArgs& p, int td_waves, hipStream_t s) {
-    int rc;
+// the arg-max stage's arguments of a lazily evaluated step (starts the step's epoch: its parity picks the pair counter)
+static EnvelopeTdArgs lazy_argmax_args(morl_ctx* c, const EnvelopeTdArgs& p) {
     c->lz_epoch = (c->lz_epoch & 0x3fffffff) + 1;
     EnvelopeTdArgs a1 = p;
     a1.phase = 1; a1.best_io = c->lz_best;
     a1.pairs_out = c->lz_pairs; a1.row_slot = c->lz_slot; a1.count = c->lz_count; a1.epoch = c->lz_epoch;
     a1.zero_ptr = nullptr;
-    if ((rc = launch_envelope_td(a1, p.B * p.i_groups, td_waves, s, "envelope_argmax"))) return rc;
+    return a1;
+}
+
+static int lazy_phase1(morl_ctx* c, const EnvelopeTdArgs& p, int td_waves, hipStream_t s) {
+    int rc;
+    // (the arg-max may already have been taken at the end of the forward launch: morl_envelope_update, BfChain::amax)
+    const bool argmax_done = c->lz_argmax_done;
+    c->lz_argmax_done = false;
+    if (!argmax_done) {
+        const EnvelopeTdArgs a1 = lazy_argmax_args(c, p);
+        if ((rc = launch_envelope_td(a1, p.B * p.i_groups, td_waves, s, "envelope_argmax"))) return rc;
+    }
     ChainArgs t = make_forward_chain(c, c->lz_params_target, c->wt_target, c->lz_next_obs, p.weights, p.B, p.W, 0, p.B * p.W, false,
                                      c->qt, p.A * p.R);
     t.in_mode = 3;
@@ -1645,11 +1668,23 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
                                 bf_forward_chain(c, params_online, obs, weights, B, W, rows, true, c->qm, c->ldq)};
         if (c->lz_now) { c->lz_params_target = params_target; c->lz_next_obs = next_obs; }
         {
-            // (Measured and dropped in round 4: the online next-state pass alone, then arg-max + target rows on a side stream BESIDE
-            // the training forward -- the two workgroups of a bf16 chain launch hold all 160 KB of a CU's LDS, so the arg-max
-            // workgroups could not become resident beside them: 53 us instead of 10, the step 0.288 ms instead of 0.248;
-            // profiles/r04_tail_stream_ab.txt)
-            if ((rc = bf_launch(c, two, 2, MORL_TIMED_FORWARD2, s))) { c->lz_now = false; return rc; }
+            // (Measured and dropped in round 4, twice: the online next-state pass alone, then arg-max + target rows on a side stream
+            // BESIDE the training forward: profiles/r04_tail_stream_ab.txt)
+            // When a row tile of the launch is exactly one transition's W rows, the workgroups of the next-state pass take their
+            // transition's arg-max themselves, from the head's accumulators (envelope_argmax_tile): no arg-max launch
+            BfChain fwd[2] = {two[0], two[1]};
+            EnvelopeTdArgs amax_args{};
+            static const bool fuse_env = [] { const char* e = getenv("MORL_ARGMAX_IN_CHAIN"); return e ? atoi(e) != 0 : true; }();   // (A/B)
+            const bool fuse = fuse_env && c->lz_now && W == bf_tile_rows(c, two, 2) && cfg->slab_parts <= 1 && R <= MORL_MAX_OBJ;
+            if (fuse) {
+                int td_waves = 0;
+                const long long rows_total_ = cfg->rows_total > 0 ? (long long)cfg->rows_total : (long long)rows;
+                const EnvelopeTdArgs p1 = td_args(c, cfg, out, actions, rewards, dones, weights, W, c->qo, c->qt, W, 0, rows_total_, B, &td_waves);
+                amax_args = lazy_argmax_args(c, p1);
+                fwd[0].amax = 1;
+            }
+            if ((rc = bf_launch(c, fwd, 2, MORL_TIMED_FORWARD2, s, fuse ? &amax_args : nullptr))) { c->lz_now = false; return rc; }
+            c->lz_argmax_done = fuse;
             if (!c->lz_now && (rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
         }
         main_done = true;

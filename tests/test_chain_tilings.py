@@ -141,3 +141,64 @@ def test_eight_row_tiles_give_the_bits_of_the_sixteen_row_tiles():
 @pytest.mark.gpu
 def test_eight_row_tiles_give_the_bits_of_the_sixteen_row_tiles_on_the_gpu():
     assert _chain4_digest("gpu", {}) == _chain4_digest("gpu", {"MORL_CHAIN4": "0"})
+
+
+_ARGMAX_SNIPPET = r"""
+import hashlib, os, sys
+import numpy as np, torch as th
+ROOT = sys.argv[1]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import morl_baselines_amd.ops as ops
+if sys.argv[2] == "gpu":
+    from morl_baselines_amd.native import load_library
+    lib, dev = load_library(), th.device("cuda:0")
+else:
+    import simlib
+    lib, dev = simlib.load_sim(), th.device("cpu")
+h = hashlib.sha256()
+g = th.Generator().manual_seed(11)
+# (B, W, obs, objectives, actions, arch): a row tile of the forward launch is one transition's W rows (32-row tiles: W = 32; on the
+# GPU also the flagship's 64-row tiles) -- and one case where it is not (W = 16: the separate launch either way)
+cases = [(3, 32, 7, 3, 6, (256, 256)), (2, 32, 5, 2, 4, (256,)), (3, 16, 7, 3, 6, (256, 256))]
+if sys.argv[2] == "gpu":
+    cases += [(256, 64, 32, 3, 6, (256, 256, 256, 256)), (256, 32, 7, 3, 6, (256, 256, 256, 256))]
+rows_seen = []
+for B, W, D, R, A, arch in cases:
+    ctx = ops.QNetContext(D, R, A, arch, B, W, lib=lib)
+    ctx.set_lazy_targets(2)
+    P = ctx.n_params
+    po = (th.randn(P, generator=g) * 0.1).to(dev); pt = (th.randn(P, generator=g) * 0.1).to(dev)
+    obs, nobs = th.randn(B, D, generator=g).to(dev), th.randn(B, D, generator=g).to(dev)
+    act = th.randint(0, A, (B,), generator=g).to(th.int32).to(dev)
+    rew, done = th.randn(B, R, generator=g).to(dev), (th.rand(B, generator=g) < 0.2).float().to(dev)
+    w = th.rand(W, R, generator=g); w = (w / w.sum(1, keepdim=True)).to(dev)
+    grads, m, v = th.zeros(P, device=dev), th.zeros(P, device=dev), th.zeros(P, device=dev)
+    out = ops.envelope_update(ctx, po, pt, grads, m, v, obs, nobs, act, rew, done, w, gamma=0.98, lr=3e-4, adam_step=1,
+                              max_grad_norm=1.0, homotopy_lambda=0.3, debug="lazy")
+    for k in ("pref", "ac", "target", "loss", "priority"):
+        h.update(out[k].cpu().numpy().tobytes())
+    h.update(grads.cpu().numpy().tobytes()); h.update(po.cpu().numpy().tobytes())
+    rows_seen.append(ctx.lazy_target_rows(po))
+    ctx.close()
+print("ARGMAX_DIGEST", h.hexdigest(), rows_seen)
+"""
+
+
+def _argmax_digest(mode, extra_env):
+    r = subprocess.run([sys.executable, "-c", _ARGMAX_SNIPPET, ROOT, mode], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, MORL_BF_MIN_ROWS="0", MORL_LAZY_MIN_ROWS="0", **extra_env), cwd=ROOT)
+    assert r.returncode == 0 and "ARGMAX_DIGEST" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout.split("ARGMAX_DIGEST")[1].strip()
+
+
+def test_argmax_inside_the_forward_launch_gives_the_bits_of_the_separate_launch():
+    """When a row tile of the split-bf16 forward launch is one transition's W rows, its workgroups take the transition's arg-max
+    themselves (``envelope_argmax_tile`` from the head's accumulators, no ``envelope_td_kernel<1>`` launch).  Indices, targets,
+    loss, priorities, gradients and stepped parameters must be the bits of the step with the separate launch
+    (``MORL_ARGMAX_IN_CHAIN=0``), and the same number of target rows must have been evaluated."""
+    assert _argmax_digest("sim", {}) == _argmax_digest("sim", {"MORL_ARGMAX_IN_CHAIN": "0"})
+
+
+@pytest.mark.gpu
+def test_argmax_inside_the_forward_launch_gives_the_bits_of_the_separate_launch_on_the_gpu():
+    assert _argmax_digest("gpu", {}) == _argmax_digest("gpu", {"MORL_ARGMAX_IN_CHAIN": "0"})
