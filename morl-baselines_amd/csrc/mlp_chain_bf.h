@@ -389,7 +389,6 @@ __device__ __forceinline__ void bf_acc_init(f32x4 (&acc)[NTILES], const float* b
 // Epilogue of a wide step, lane-local: (ReLU | mask bits) -> fp32 copy to HBM -> sign bits -> split into the next step's B operand.
 // Vector-memory instructions a wave issues per epilogue when MODE != 0: 16 row stores + 1 (the sign-bit word's store of the training
 // forward, or the NEXT step's mask-word load of the backward chain) -- BF_SAVE_VMEM, counted by the next layer's first two waits.
-// (A wave whose 16 rows all lie beyond the chain's rows issues none of them and so waits for too little: its results are discarded.)
 // `keep`: the step's mask word (bits_in), loaded by the caller at the START of the step -- a load inside the epilogue would be waited
 // for with vmcnt(0), i.e. behind both weight stages in flight (the first version did: one drained ring per layer).
 constexpr int BF_SAVE_VMEM = 17;
@@ -404,9 +403,11 @@ __device__ __forceinline__ float bf_relu(float a) {
 // word in, fp32 copy out) -- compile-time, so that neither chain carries the other's bit arithmetic (two to three vector
 // instructions per value: a sixth of the epilogue).
 template <int MODE>
-__device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x4 (&x)[8][3], const BfStep& st, int row, bool row_ok,
+__device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x4 (&x)[8][3], const BfStep& st, int rows, int row, bool row_ok,
                                                  size_t bits_idx, int q, unsigned long long keep) {
     unsigned pos_lo = 0u, pos_hi = 0u;
+    const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)st.out, 0, (MODE != 0 && st.out != nullptr) ? rows * st.ldout * 4 : 0, 0x00020000);
     const int keep_lo = (int)(unsigned)keep, keep_hi = (int)(unsigned)(keep >> 32);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -429,10 +430,18 @@ __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x
             }
             v[e] = a;
         }
-        if (MODE != 0 && st.out != nullptr && row_ok) {
-            float* o = st.out + (size_t)row * st.ldout + 32 * s + 4 * q;
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(o + 16) = make_float4(v[4], v[5], v[6], v[7]);
+        if (MODE != 0) {
+            // BUFFER stores with an out-of-range offset for rows beyond the chain (and for a step without a copy: an empty range):
+            // issued by every wave whatever its rows.  A wave that skipped them would see fewer vector-memory instructions in flight
+            // than BF_SAVE_VMEM says, wait for too little at the next stage entry -- and the other waves read ITS share of the stage
+            // after the barrier.
+            const int voff = row_ok ? (row * st.ldout + 32 * s + 4 * q) * 4 : CH_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(bf_u32x4{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
+                                                            __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])},
+                                                   orsrc, voff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(bf_u32x4{__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]),
+                                                            __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7])},
+                                                   orsrc, voff + 64, 0, 0);
         }
         unsigned hi[4], mid[4], lo[4];
 #pragma unroll
@@ -546,7 +555,7 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     bf_acc_init<16>(acc, bias_lds, q);
     bf_wide_step<NW, K0S, 0>(acc, x, ring, lane);
     BF_T(1)
-    bf_wide_epilogue<MODE>(acc, x, p.step[0], row, row_ok, bits_idx, q, keep);
+    bf_wide_epilogue<MODE>(acc, x, p.step[0], p.rows, row, row_ok, bits_idx, q, keep);
     BF_T(2)
     // ---- the 256 x 256 steps --------------------------------------------------------------------------------------------------------
     for (int s = 1; s < n_wide; ++s) {
@@ -557,7 +566,7 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
         bf_acc_init<16>(acc, bias_lds + s * BF_WIDE, q);
         bf_wide_step<NW, 8, MODE != 0 ? BF_SAVE_VMEM : 0>(acc, x, ring, lane);
         BF_T(3)
-        bf_wide_epilogue<MODE>(acc, x, p.step[s], row, row_ok, bits_idx, q, keep);
+        bf_wide_epilogue<MODE>(acc, x, p.step[s], p.rows, row, row_ok, bits_idx, q, keep);
         BF_T(4)
     }
     // ---- the head -----------------------------------------------------------------------------------------------------------------
