@@ -158,7 +158,9 @@ __device__ __forceinline__ void env_scan(const float* q0, const float (&wi)[MORL
 // becomes ~1 500 cycles at the end of workgroups that are resident anyway.  Same mapping -- lane <-> TD row i (W <= 64), the
 // caller's NW waves <-> slices of the (j, a) candidates --, same env_scan, same merge order, same compaction: best_io / row_slot
 // are bit-identical to the separate launch's, pairs_out up to the order of the compact rows (which varies from run to run there
-// too).  Every work-item of the workgroup calls it; W scalarisation vectors, i_groups = 1, the slab in [W][A][R] order.
+// too).  Every work-item of the workgroup calls it; W scalarisation vectors, i_groups = 1, the slab in [W][A][R] order.  A row tile
+// may hold several whole transitions (64 rows = two transitions of 32 weights ...): the workgroup's waves then form `sub`-groups of NW
+// waves, one per transition, each with its own LDS regions; all of them run this code side by side (the barriers are the workgroup's).
 struct EnvArgmaxLds {
     float* qo;      // [W * A * R]   filled by the caller (no barrier needed before the call)
     float* w;       // [W * R]
@@ -181,13 +183,13 @@ struct EnvArgmaxArgs {
 template <int NW>
 __device__ __forceinline__ void envelope_argmax_tile(const float* weights, int32_t* best_io, int32_t* pairs_out, int32_t* row_slot,
                                                      int32_t* count, int epoch, int nB, int W, int A, int R, int diag_only,
-                                                     int i_offset, int fma_scal, int bmajor, int b, const EnvArgmaxLds L) {
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                     int i_offset, int fma_scal, int bmajor, int b, const EnvArgmaxLds L, int sub = 0) {
+    const int tid = (int)threadIdx.x - sub * 64 * NW, lane = tid & 63, wave = tid >> 6;     // (inside this transition's wave group)
     for (int e = tid; e < W; e += 64 * NW) L.mark[e] = 0x7fffffff;
     for (int e = tid; e < W * R; e += 64 * NW) L.w[e] = weights[e];
     __syncthreads();
     const int i = lane;
-    const bool live = i < W;
+    const bool live = i < W && b < nB;          // (a tile's last transitions may lie beyond the batch: they only keep the barriers company)
     float wi[MORL_MAX_OBJ];
 #pragma unroll
     for (int r = 0; r < MORL_MAX_OBJ; ++r) wi[r] = (live && r < R) ? L.w[i * R + r] : 0.f;

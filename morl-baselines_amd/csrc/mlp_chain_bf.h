@@ -78,8 +78,8 @@ struct BfChain {
     float* x0_out;                         // in_mode 0, or NULL: the assembled rows also go to HBM as [rows][ldx0] (zero padded)
     int ldx0;
     int amax;                              // 1: the head's output is the online next-state slab of an Envelope step whose row tiles are
-                                           //    whole transitions (tile rows == W): the workgroup also takes the arg-max of its
-                                           //    transition (BfMulti::td, envelope_argmax_tile) -- no separate arg-max launch
+                                           //    whole transitions (tile rows = W, 2 W or 4 W): the workgroup also takes the arg-max of its
+                                           //    transitions (BfMulti::td, envelope_argmax_tile) -- no separate arg-max launch
 };
 
 constexpr int BF_MAX_MULTI = 2;
@@ -590,27 +590,37 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     // nothing of this workgroup may still be in flight into LDS when the next workgroup of the CU takes the allocation
     BF_VMCNT(0);
     if (MODE == 0 && p.amax) {
-        // The tile is one transition (rows b * W + j, j = 0 .. W - 1 = 16 NW - 1) and the head's accumulators are its online slab
-        // Q(s'_b, a, w_j): arg-max of the transition's W TD rows here, from LDS (the ring is drained: its first stages are free)
+        // The tile is 1, 2 or 4 whole transitions (rows b * W + j, j = 0 .. W - 1; W = 16 NW, 8 NW or 4 NW) and the head's
+        // accumulators are their online slabs Q(s'_b, a, w_j): arg-max of each transition's W TD rows here, from LDS (the ring is
+        // drained: its first stages are free), the waves of a transition working as one group
         __syncthreads();
         const int AR = p.step[p.n_steps - 1].N;
+        const int wpt = am_W >> 4;                              // waves per transition
+        const int sub = wave / wpt;
+        float* region = reinterpret_cast<float*>(ring_lds) + sub * (am_W * 32 + am_W * MORL_MAX_OBJ + 2 * 4 * 64 + 3 * 64);
         EnvArgmaxLds L;
-        L.qo = reinterpret_cast<float*>(ring_lds);
-        L.w = L.qo + 16 * NW * 32;                              // (AR <= 32)
-        L.pv = L.w + 16 * NW * MORL_MAX_OBJ;
-        L.pc = reinterpret_cast<int*>(L.pv + NW * 64);
-        L.mark = L.pc + NW * 64;
+        L.qo = region;
+        L.w = L.qo + am_W * 32;                                 // (AR <= 32)
+        L.pv = L.w + am_W * MORL_MAX_OBJ;
+        L.pc = reinterpret_cast<int*>(L.pv + 4 * 64);
+        L.mark = L.pc + 4 * 64;
         L.slot = L.mark + 64;
         L.best = L.slot + 64;
+        const int j = 16 * wave + m - sub * am_W;               // this lane's row inside its transition
 #pragma unroll
         for (int T = 0; T < 2; ++T)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = 16 * T + 4 * q + r;
-                if (n < AR) L.qo[(16 * wave + m) * AR + n] = hacc[T][r];
+                if (n < AR) L.qo[j * AR + n] = hacc[T][r];
             }
-        envelope_argmax_tile<NW>(am_w, am_best, am_pairs, am_slot, am_count, am_epoch, am_B, am_W, am_A, am_R, am_flags & 1, 0,
-                                 (am_flags >> 1) & 1, (am_flags >> 2) & 1, row0 / (16 * NW), L);
+        const int b = row0 / am_W + sub;
+#define BF_AMAX(NWS) envelope_argmax_tile<NWS>(am_w, am_best, am_pairs, am_slot, am_count, am_epoch, am_B, am_W, am_A, am_R, am_flags & 1, 0, \
+                                               (am_flags >> 1) & 1, (am_flags >> 2) & 1, b, L, sub)
+        if (wpt == NW) BF_AMAX(NW);
+        else if (NW >= 2 && wpt * 2 == NW) BF_AMAX((NW >= 2 ? NW / 2 : 1));
+        else BF_AMAX((NW >= 4 ? NW / 4 : 1));
+#undef BF_AMAX
     }
     BF_T(5)
 #ifdef BF_PROF

@@ -626,13 +626,14 @@ static BfChain bf_backward_chain(morl_ctx* c, int rows) {
 
 static int timing_open(morl_ctx* c, int kind, hipStream_t s, int* slot);
 static int timing_close(morl_ctx* c, int slot, hipStream_t s);
-// row tile of a bf16 chain launch: 64-row tiles (4 waves) when they give every CU its two workgroups, else 32-row tiles (2 waves):
-// MORL_BF_TILE=64 / 32 forces
+// row tile of a bf16 chain launch: 64-row tiles (4 waves) when there is at least one for every CU, else 32-row tiles (2 waves).
+// (Round 4 first asked for TWO 64-row workgroups per CU; one 4-wave workgroup per CU stages the weight stream into LDS once
+// where two 2-wave ones stage it twice: the flagship's backward launch 41.9 -> 39 us.)  MORL_BF_TILE=64 / 32 forces
 static int bf_tile_rows(morl_ctx* c, const BfChain* chains, int n) {
     long long tiles64 = 0;
     for (int q = 0; q < n; ++q) tiles64 += (chains[q].rows + BF_TM - 1) / BF_TM;
     static const int forced = [] { const char* e = getenv("MORL_BF_TILE"); return e ? atoi(e) : 0; }();      // (tuning)
-    const bool small = forced ? forced == 32 : tiles64 < 2ll * c->num_cus;
+    const bool small = forced ? forced == 32 : tiles64 < (long long)c->num_cus;
     return small ? 32 : BF_TM;
 }
 
@@ -1670,12 +1671,14 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         {
             // (Measured and dropped in round 4, twice: the online next-state pass alone, then arg-max + target rows on a side stream
             // BESIDE the training forward: profiles/r04_tail_stream_ab.txt)
-            // When a row tile of the launch is exactly one transition's W rows, the workgroups of the next-state pass take their
-            // transition's arg-max themselves, from the head's accumulators (envelope_argmax_tile): no arg-max launch
+            // When a row tile of the launch is one, two or four whole transitions (W rows each), the workgroups of the next-state pass
+            // take their transitions' arg-max themselves, from the head's accumulators (envelope_argmax_tile): no arg-max launch
             BfChain fwd[2] = {two[0], two[1]};
             EnvelopeTdArgs amax_args{};
             static const bool fuse_env = [] { const char* e = getenv("MORL_ARGMAX_IN_CHAIN"); return e ? atoi(e) != 0 : true; }();   // (A/B)
-            const bool fuse = fuse_env && c->lz_now && W == bf_tile_rows(c, two, 2) && cfg->slab_parts <= 1 && R <= MORL_MAX_OBJ;
+            const int tile_rows = bf_tile_rows(c, two, 2);
+            const bool fuse = fuse_env && c->lz_now && (W == tile_rows || 2 * W == tile_rows || (4 * W == tile_rows && tile_rows == 64)) &&
+                              cfg->slab_parts <= 1 && R <= MORL_MAX_OBJ;
             if (fuse) {
                 int td_waves = 0;
                 const long long rows_total_ = cfg->rows_total > 0 ? (long long)cfg->rows_total : (long long)rows;

@@ -158,10 +158,11 @@ else:
 h = hashlib.sha256()
 g = th.Generator().manual_seed(11)
 # (B, W, obs, objectives, actions, arch): a row tile of the forward launch is one transition's W rows (32-row tiles: W = 32; on the
-# GPU also the flagship's 64-row tiles) -- and one case where it is not (W = 16: the separate launch either way)
-cases = [(3, 32, 7, 3, 6, (256, 256)), (2, 32, 5, 2, 4, (256,)), (3, 16, 7, 3, 6, (256, 256))]
+# GPU also the flagship's 64-row tiles), two whole transitions (W = 16, with a last tile that is half empty: B odd) -- and one case
+# where it is neither (W = 8: the separate launch either way)
+cases = [(3, 32, 7, 3, 6, (256, 256)), (2, 32, 5, 2, 4, (256,)), (3, 16, 7, 3, 6, (256, 256)), (5, 16, 7, 3, 6, (256,)), (3, 8, 7, 3, 6, (256,))]
 if sys.argv[2] == "gpu":
-    cases += [(256, 64, 32, 3, 6, (256, 256, 256, 256)), (256, 32, 7, 3, 6, (256, 256, 256, 256))]
+    cases += [(256, 64, 32, 3, 6, (256, 256, 256, 256)), (256, 32, 7, 3, 6, (256, 256, 256, 256)), (255, 16, 7, 3, 6, (256, 256, 256, 256))]
 rows_seen = []
 for B, W, D, R, A, arch in cases:
     ctx = ops.QNetContext(D, R, A, arch, B, W, lib=lib)
