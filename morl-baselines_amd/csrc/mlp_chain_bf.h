@@ -68,7 +68,8 @@ struct BfChain {
     int head;                              // 1: the last step is narrow
     int n_stages;                          // ring stages of the stream
     int rows;
-    // input rows (as ChainArgs): 0 cat(obs[b], weights[i]) with row -> (b, i) by row_order; 1 dense src[rows][ldsrc], K0 columns
+    // input rows (as ChainArgs): 0 cat(obs[b], weights[i]) with row -> (b, i) by row_order; 1 dense src[rows][ldsrc], K0 columns;
+    // 2 (backward chain): dLoss/dQ of TD row `row`, computed here (BfMulti::tdb), K0 = A * R columns
     int in_mode;
     const float* obs;
     const float* weights;
@@ -82,12 +83,33 @@ struct BfChain {
                                            //    transitions (BfMulti::td, envelope_argmax_tile) -- no separate arg-max launch
 };
 
+// The TD stage of a lazily evaluated Envelope step (envelope_td_kernel<2>: target from the compact target rows, TD error, loss
+// gradient wrt Q, loss partials, priorities) taken over by the BACKWARD chain's workgroups: BfChain::in_mode = 2, the chain's input row
+// (dLoss/dQ of its TD row) is computed where it is needed instead of by a launch in front (6 us of latencies).  Row tiles are whole
+// transitions; same arithmetic, same summation order of the loss partials as the kernel (tests/test_chain_tilings.py holds the bits).
+struct BfTdArgs {
+    const int32_t* best_io;     // [rows] flattened (j*, a*) per TD row (row = b * W + i)
+    const int32_t* row_slot;    // [rows] compact target row of the TD row's (b, j*)
+    const float* qt;            // compact target rows [slots][A][R]
+    const float* q_main;        // [rows][ldq] Q_online(s_b, w_i)
+    const int32_t* actions;     // [B]
+    const float* rewards;       // [B][R]
+    const float* dones;         // [B]
+    const float* weights;       // [W][R]
+    float* dq;                  // [rows][ldq] out: dLoss/dQ (the head's weight gradients read it)
+    double* loss_part;          // [B][2] out
+    float* priority;            // [B] out, or NULL
+    int B, W, A, R, ldq;
+    float gamma, c_mse, c_aux;
+};
+
 constexpr int BF_MAX_MULTI = 2;
 struct BfMulti {
     BfChain c[BF_MAX_MULTI];
     int tile_start[BF_MAX_MULTI + 1];      // 64-row tiles of chain q: [tile_start[q], tile_start[q + 1])
     int n;
     EnvArgmaxArgs td;                      // arguments of the arg-max stage for the chain with amax = 1
+    BfTdArgs tdb;                          // arguments of the TD stage for the chain with in_mode = 2
     long long* prof;                       // development builds only (-DBF_PROF, MORL_BF_PROF=1 python build.py): [tile][wave][BF_PROF_SLOTS]
 };
 // Phase stamps of a development build: s_memtime sums per wave -- 0 prologue (input rows, biases, first weight stages), 1 / 2 first
@@ -459,7 +481,8 @@ __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x
 template <int NW, int K0S, int MODE>
 __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsigned char* ring_lds, float* bias_lds, long long* prof,
                                               const float* am_w, int32_t* am_best, int32_t* am_pairs, int32_t* am_slot,
-                                              int32_t* am_count, int am_epoch, int am_B, int am_W, int am_A, int am_R, int am_flags) {
+                                              int32_t* am_count, int am_epoch, int am_B, int am_W, int am_A, int am_R, int am_flags,
+                                              const BfTdArgs& tdb) {
 #ifdef BF_PROF
     long long pt[6] = {0, 0, 0, 0, 0, 0}, tp_ = clock64();
     const long long tstart_ = tp_;
@@ -509,6 +532,59 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
         const int K0 = (p.in_mode == 0) ? p.D + p.R : p.K0;
         const float* src_a = (p.in_mode == 0) ? p.obs + (size_t)b * p.D : p.src + (size_t)row * p.ldsrc;
         const float* src_w = (p.in_mode == 0) ? p.weights + (size_t)w * p.R : nullptr;
+        // ---- in_mode 2: the TD stage of this lane's TD row (envelope_td_kernel<2>'s arithmetic, operation for operation) ---------------
+        float tdg[MORL_MAX_OBJ];
+        int td_act = -1;
+        if (MODE == 2 && K0S == 1 && p.in_mode == 2) {
+            const BfTdArgs& t = tdb;
+            const int W = t.W, A = t.A, R = t.R;
+            const int tb = row / W, ti = row - tb * W;
+            double m2 = 0.0, a2 = 0.0;
+            float prv = 0.f;
+#pragma unroll
+            for (int r = 0; r < MORL_MAX_OBJ; ++r) tdg[r] = 0.f;
+            if (row_ok) {
+                const int bc = t.best_io[row];
+                const float* qt = t.qt + ((size_t)t.row_slot[row] * A + (bc % A)) * R;
+                td_act = t.actions[tb];
+                const float* qm = t.q_main + (size_t)row * t.ldq + td_act * R;
+                const float ndg = __fmul_rn(__fsub_rn(1.0f, t.dones[tb]), t.gamma);      // (1 - d) * gamma
+                float td[MORL_MAX_OBJ], wi[MORL_MAX_OBJ];
+                float wq = 0.f, wtq = 0.f;
+#pragma unroll
+                for (int r = 0; r < MORL_MAX_OBJ; ++r) {
+                    td[r] = 0.f; wi[r] = 0.f;
+                    if (r < R) {
+                        wi[r] = t.weights[ti * R + r];
+                        const float tq = __fadd_rn(t.rewards[(size_t)tb * R + r], __fmul_rn(ndg, qt[r]));
+                        const float qv = qm[r];
+                        td[r] = __fsub_rn(qv, tq);
+                        wq = (r == 0) ? __fmul_rn(qv, wi[0]) : __fadd_rn(wq, __fmul_rn(qv, wi[r]));
+                        wtq = (r == 0) ? __fmul_rn(tq, wi[0]) : __fadd_rn(wtq, __fmul_rn(tq, wi[r]));
+                    }
+                }
+                const float daux = __fsub_rn(wq, wtq);
+#pragma unroll
+                for (int r = 0; r < MORL_MAX_OBJ; ++r)
+                    if (r < R) {
+                        tdg[r] = t.c_mse * td[r] + t.c_aux * daux * wi[r];
+                        m2 += (double)td[r] * (double)td[r];
+                    }
+                a2 = (double)daux * (double)daux;
+                prv = __fmul_rn(td[0], wi[0]);
+#pragma unroll
+                for (int r = 1; r < MORL_MAX_OBJ; ++r)
+                    if (r < R) prv = __fadd_rn(prv, __fmul_rn(td[r], wi[r]));
+                if (ti == 0 && q == 0 && t.priority != nullptr) t.priority[tb] = fabsf(prv);
+            }
+            // loss partials: one (sum td^2, (wQ - wTQ)^2) pair per row into LDS (ring buffer 2 is not in flight yet), summed per
+            // transition behind the barrier below in the kernel's order (lane <-> TD row, wave_sum)
+            if (q == 0) {
+                double* sl = reinterpret_cast<double*>(ring_lds + 2 * BF_STAGE_BYTES);
+                sl[(16 * wave + m) * 2 + 0] = m2;
+                sl[(16 * wave + m) * 2 + 1] = a2;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < K0S; ++s) {
             float v[8];
@@ -516,11 +592,24 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
             for (int e = 0; e < 8; ++e) {
                 const int k = 32 * s + 8 * q + e;
                 float a = 0.f;
-                if (row_ok && k < K0) {
+                if (MODE == 2 && K0S == 1 && p.in_mode == 2) {
+                    // column k = action * R + objective of dLoss/dQ: the row's gradient at the taken action, zero elsewhere
+                    const int R = tdb.R, ka = k / R, kr = k - ka * R;
+#pragma unroll
+                    for (int r = 0; r < MORL_MAX_OBJ; ++r)
+                        if (r == kr && ka == td_act && k < tdb.A * R) a = tdg[r];
+                } else if (row_ok && k < K0) {
                     if (p.in_mode == 0) a = (k < p.D) ? src_a[k] : src_w[k - p.D];
                     else a = src_a[k];
                 }
                 v[e] = a;
+            }
+            if (MODE == 2 && K0S == 1 && p.in_mode == 2 && row_ok) {
+                // the row of dLoss/dQ also goes to HBM, pad columns as zeros: the head's weight gradients read it (ldq is a multiple of 4)
+                const int k = 8 * q;
+                float* o = tdb.dq + (size_t)row * tdb.ldq + k;
+                if (k < tdb.ldq) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                if (k + 4 < tdb.ldq) *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
             if (p.x0_out != nullptr && row_ok) {
                 const int k = 32 * s + 8 * q;
@@ -547,6 +636,19 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     // (the two DMA groups in flight are waited for here too -- the only vmcnt(0) of the kernel, at its very start)
     BF_VMCNT(0);
     __syncthreads();                     // the bias copy is complete before the first accumulator takes its bias
+    if (MODE == 2 && K0S == 1 && p.in_mode == 2) {
+        // loss partials of this tile's transitions: the first wave of each transition's wave group, lane <-> TD row
+        const int wpt = tdb.W >> 4;                             // waves per transition (W = 16, 32 or 64)
+        if (wave % wpt == 0) {
+            const double* sl = reinterpret_cast<const double*>(ring_lds + 2 * BF_STAGE_BYTES);
+            const int tb = row0 / tdb.W + wave / wpt;
+            const bool live = lane < tdb.W && tb < tdb.B;
+            double s0 = live ? sl[(16 * wave + lane) * 2 + 0] : 0.0, s1 = live ? sl[(16 * wave + lane) * 2 + 1] : 0.0;
+            s0 = wave_sum(s0);
+            s1 = wave_sum(s1);
+            if (lane == 0 && tb < tdb.B) { tdb.loss_part[(size_t)tb * 2 + 0] = s0; tdb.loss_part[(size_t)tb * 2 + 1] = s1; }
+        }
+    }
 
     f32x4 acc[16];
     const int n_wide = p.n_steps - (p.head ? 1 : 0);
@@ -648,7 +750,7 @@ __device__ __forceinline__ void mlp_chain_bf_entry(const BfMulti& m, unsigned ch
     // (the arg-max arguments as scalars read HERE: a reference to the argument block handed into the chain body made hipcc copy
     // the whole block to scratch memory, 1.1 KB per work-item)
 #define BF_AM m.td.weights, m.td.best_io, m.td.pairs_out, m.td.row_slot, m.td.count, m.td.epoch, m.td.B, m.td.W, m.td.A, m.td.R, \
-              (m.td.diag_only | (m.td.fma_scal << 1) | (m.td.bmajor << 2))
+              (m.td.diag_only | (m.td.fma_scal << 1) | (m.td.bmajor << 2)), m.tdb
     const int mode = p.step[0].bits_in != nullptr ? 2 : (p.step[0].out != nullptr || p.step[0].bits_out != nullptr) ? 1 : 0;
     if (p.k0_steps == 1) {
         if (mode == 2) bf_chain_body<NW, 1, 2>(p, row0, lds, bias_lds, m.prof, BF_AM);

@@ -191,6 +191,7 @@ struct morl_ctx {
     int32_t* lz_count = nullptr;         // [2] distinct pairs of the steps of even / odd epoch
     int timing_kind_override = -1;       // MORL_TIMED_* of the next bracketed chain launch (-1: by its arguments)
     bool lz_argmax_done = false;         // one-shot: this step's forward launch took the arg-max (mlp_chain_bf.h, BfChain::amax)
+    bool td_in_chain_done = false;       // one-shot inside update_core: the backward chain's launch took the TD stage
     bool lz_now = false;                 // this step runs lazily: the three below are what the target launch needs
     const float* lz_params_target = nullptr;
     const float* lz_next_obs = nullptr;
@@ -637,11 +638,13 @@ static int bf_tile_rows(morl_ctx* c, const BfChain* chains, int n) {
     return small ? 32 : BF_TM;
 }
 
-static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStream_t s, const EnvelopeTdArgs* td = nullptr) {
+static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStream_t s, const EnvelopeTdArgs* td = nullptr,
+                     const BfTdArgs* tdb = nullptr) {
     BfMulti m{};
     m.n = n;
     const int tm = bf_tile_rows(c, chains, n);
     const bool small = tm == 32;
+    if (tdb) m.tdb = *tdb;
     if (td) {
         m.td.weights = td->weights; m.td.best_io = td->best_io; m.td.pairs_out = td->pairs_out; m.td.row_slot = td->row_slot;
         m.td.count = td->count; m.td.epoch = td->epoch; m.td.B = td->B; m.td.W = td->W; m.td.A = td->A; m.td.R = td->R;
@@ -1320,16 +1323,38 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
         EnvelopeTdArgs p = td_args(c, cfg, out, actions, rewards, dones, weights_i, WI, qo, qt, W, i_offset, rows_total, B, &td_waves);
         p.zero_ptr = c->td_zero_ptr; p.zero_n = c->td_zero_n; p.keep_lo = c->td_keep_lo; p.keep_hi = c->td_keep_hi;
         c->td_zero_ptr = nullptr;
+        bool td_in_chain = false;
         if (lazy) {
             // 1. + 2. arg-max on the online slab, the target network on the selected rows
             if ((rc = lazy_phase1(c, p, td_waves, s))) return rc;
             // 3. TD target, loss gradient, priorities from the compact target rows
             p.phase = 2; p.best_io = c->lz_best; p.row_slot = c->lz_slot; p.qt = c->qt;
+            // ... by the backward chain's own workgroups when their row tiles are whole transitions and nobody asked for the parity
+            // outputs (mlp_chain_bf.h, BfTdArgs): no TD launch
+            static const bool td_env = [] { const char* e = getenv("MORL_TD_IN_CHAIN"); return e ? atoi(e) != 0 : true; }();   // (A/B)
+            if (td_env && c->use_fused && c->bits_bf && L >= 2 && bmajor && WI == W && i_offset == 0 && td_groups == 1 && !p.target && !p.pref &&
+                !p.ac && !p.zero_ptr && !p.priority_clear && p.part_floats == 0 && !p.diag_only && p.q_main != nullptr && (c->ldq & 3) == 0) {
+                const BfChain probe = bf_backward_chain(c, rows);
+                const int tr = bf_tile_rows(c, &probe, 1);
+                td_in_chain = (W == tr || 2 * W == tr || (4 * W == tr && tr == 64)) && (W & 15) == 0;
+            }
         }
-        if ((rc = launch_envelope_td(p, B * td_groups, td_waves, s, "envelope_td"))) return rc;
+        if (!td_in_chain && (rc = launch_envelope_td(p, B * td_groups, td_waves, s, "envelope_td"))) return rc;
+        if (td_in_chain) {
+            BfChain bwd = bf_backward_chain(c, rows);
+            bwd.in_mode = 2;
+            BfTdArgs t{};
+            t.best_io = p.best_io; t.row_slot = p.row_slot; t.qt = p.qt; t.q_main = p.q_main; t.actions = p.actions; t.rewards = p.rewards;
+            t.dones = p.dones; t.weights = p.weights; t.dq = p.dq; t.loss_part = p.loss_part; t.priority = p.priority;
+            t.B = B; t.W = W; t.A = p.A; t.R = p.R; t.ldq = p.ldq; t.gamma = p.gamma; t.c_mse = p.c_mse; t.c_aux = p.c_aux;
+            if ((rc = bf_launch(c, &bwd, 1, MORL_TIMED_BACKWARD, s, nullptr, &t))) return rc;
+            c->td_in_chain_done = true;
+        }
     }
     // backward through the hidden layers: g[l-1] = (g[l] @ W_l) * (h[l] > 0)
-    if (c->use_fused && c->bits_bf && L >= 2) {
+    if (c->td_in_chain_done) {
+        c->td_in_chain_done = false;         // (the backward chain has run: it took the TD stage with it)
+    } else if (c->use_fused && c->bits_bf && L >= 2) {
         // (the training forward ran on the bf16 matrix cores and left its sign bits in that kernel's lane layout)
         const BfChain bwd = bf_backward_chain(c, rows);
         if ((rc = bf_launch(c, &bwd, 1, MORL_TIMED_BACKWARD, s))) return rc;

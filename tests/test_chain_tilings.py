@@ -180,6 +180,12 @@ for B, W, D, R, A, arch in cases:
         h.update(out[k].cpu().numpy().tobytes())
     h.update(grads.cpu().numpy().tobytes()); h.update(po.cpu().numpy().tobytes())
     rows_seen.append(ctx.lazy_target_rows(po))
+    # the same step as the agents issue it -- no parity outputs requested: the TD stage may then run inside the backward launch
+    out2 = ops.envelope_update(ctx, po, pt, grads, m, v, obs, nobs, act, rew, done, w, gamma=0.98, lr=3e-4, adam_step=2,
+                               max_grad_norm=1.0, homotopy_lambda=0.3)
+    for k in ("loss", "grad_norm", "priority"):
+        h.update(out2[k].cpu().numpy().tobytes())
+    h.update(grads.cpu().numpy().tobytes()); h.update(po.cpu().numpy().tobytes()); h.update(m.cpu().numpy().tobytes())
     ctx.close()
 print("ARGMAX_DIGEST", h.hexdigest(), rows_seen)
 """
@@ -203,3 +209,16 @@ def test_argmax_inside_the_forward_launch_gives_the_bits_of_the_separate_launch(
 @pytest.mark.gpu
 def test_argmax_inside_the_forward_launch_gives_the_bits_of_the_separate_launch_on_the_gpu():
     assert _argmax_digest("gpu", {}) == _argmax_digest("gpu", {"MORL_ARGMAX_IN_CHAIN": "0"})
+
+
+def test_td_stage_inside_the_backward_launch_gives_the_bits_of_the_separate_launch():
+    """Likewise the TD stage (target from the compact target rows, TD error, dLoss/dQ, loss partials, priorities): when the row
+    tiles of the split-bf16 backward launch are whole transitions and no parity outputs are requested, its workgroups compute their
+    rows' dLoss/dQ themselves (``BfTdArgs``, no ``envelope_td_kernel<2>`` launch).  Same loss, priorities, gradients, parameters and
+    optimiser state, to the last bit, as with ``MORL_TD_IN_CHAIN=0``."""
+    assert _argmax_digest("sim", {}) == _argmax_digest("sim", {"MORL_TD_IN_CHAIN": "0"})
+
+
+@pytest.mark.gpu
+def test_td_stage_inside_the_backward_launch_gives_the_bits_of_the_separate_launch_on_the_gpu():
+    assert _argmax_digest("gpu", {}) == _argmax_digest("gpu", {"MORL_TD_IN_CHAIN": "0"})
