@@ -108,6 +108,68 @@ __global__ __launch_bounds__(256) void gemm_wave4_grouped_tn_batched_kernel(Gemm
     gemm_wave4_tile<false, false, EPI_STORE>(g, local / g.tiles_n, local % g.tiles_n);
 }
 
+// the same launch with the optimiser step in the epilogue (gemm_wave.h: AdamTile): net z of the batch is learner z /
+// nets_per_learner, whose device-resident step counter (or the host's step number) gives the bias corrections
+struct AdamFuse {
+    float* params; float* exp_avg; float* exp_avg_sq;   // [nets][P]
+    float* wt;                  // [nets][P] K-major shadow copies, or NULL
+    float* target;              // [nets][P] Polyak targets, or NULL
+    long long offB[MORL_MAX_LAYERS];   // bias blocks (the weight blocks are grp.p[l].C - the gradient base)
+    long long offW[MORL_MAX_LAYERS];
+    const int* steps;           // [learners] or NULL
+    const float* corr;          // [learners][2] bias-correction scalars left by an earlier kernel of the update, or NULL
+    int step_add, nets_per_learner;
+    double lr, b1, b2;
+    float eps, tau;
+    // when this is the last launch of the update that depends on the device-resident step counters (it reads `corr`, not them):
+    // their advance, by the first workgroup of each learner
+    int* adv_q; int* adv_p;
+    int adv_p_by;
+    // parameters whose gradients are NOT tiles of this launch (LayerNorm gains / shifts: ac_ln_grad_kernel left them in `grads`
+    // before the dX pass last read the parameters): stepped element-wise by one extra workgroup per net
+    const float* grads;         // [nets][P]
+    long long extra_off[MORL_MAX_LAYERS];
+    int extra_len[MORL_MAX_LAYERS];
+    int n_extra;
+};
+
+__global__ __launch_bounds__(256) void gemm_wave4_grouped_tn_batched_adam_kernel(GemmGroupBatched grp, AdamFuse f) {
+    const int id = (int)blockIdx.x, z = (int)blockIdx.z;
+    int q = 0;
+    while (q + 1 < grp.n && id >= grp.tile_start[q + 1]) ++q;
+    const int local = id - grp.tile_start[q];
+    GemmProblem g = grp.p[q];
+    g.A += (long long)z * grp.sA[q];
+    g.B += (long long)(z / grp.b_div[q]) * grp.sB[q];
+    const long long net = (long long)z * grp.sC;
+    AdamTile ad;
+    ad.params = f.params + net; ad.exp_avg = f.exp_avg + net; ad.exp_avg_sq = f.exp_avg_sq + net;
+    ad.wt = f.wt ? f.wt + net : nullptr;
+    ad.target = f.target ? f.target + net : nullptr;
+    ad.offW = f.offW[q]; ad.offB = f.offB[q];
+    if (id == 0 && threadIdx.x == 0 && f.corr && z % f.nets_per_learner == 0) {
+        if (f.adv_q) f.adv_q[z / f.nets_per_learner] += 1;
+        if (f.adv_p) f.adv_p[z / f.nets_per_learner] += f.adv_p_by;
+    }
+    ad.corr = f.corr ? f.corr + 2 * (z / f.nets_per_learner) : nullptr;
+    ad.step = f.corr ? 1 : max(1, (f.steps ? f.steps[z / f.nets_per_learner] : 0) + f.step_add);
+    ad.lr = f.lr; ad.b1 = f.b1; ad.b2 = f.b2; ad.eps = f.eps; ad.tau = f.tau;
+    if (id >= grp.tile_start[grp.n]) {              // (workgroup-uniform) the extra workgroup of this net
+        AdamScalars c;
+        if (ad.corr != nullptr) {
+            c.neg_step_size = ad.corr[0]; c.bc2_sqrt = ad.corr[1];
+            c.one_minus_b1 = (float)(1.0 - f.b1); c.b2 = (float)f.b2; c.one_minus_b2 = (float)(1.0 - f.b2); c.eps = f.eps;
+        } else {
+            c = adam_scalars(ad.step, f.lr, f.b1, f.b2, f.eps);
+        }
+        for (int x = 0; x < f.n_extra; ++x)
+            for (int e = (int)threadIdx.x; e < f.extra_len[x]; e += (int)blockDim.x)
+                adam_tile_apply(ad, c, f.extra_off[x] + e, f.extra_off[x] + e, f.grads[net + f.extra_off[x] + e]);
+        return;
+    }
+    gemm_wave4_tile<false, false, EPI_STORE, true>(g, local / g.tiles_n, local % g.tiles_n, &ad);
+}
+
 __global__ __launch_bounds__(256) void gemm_wave_grouped_tn_batched_kernel(GemmGroupBatched grp) {
     const int id = (int)blockIdx.x * 4 + wave_id(), z = (int)blockIdx.z;
     if (id >= grp.tile_start[grp.n]) return;
@@ -138,10 +200,9 @@ struct ConcatArgs {
     int rows, G;
 };
 
-__device__ __forceinline__ void ac_concat_body(const ConcatArgs& a) {
+__device__ __forceinline__ void ac_concat_body(const ConcatArgs& a, int bx, int nbx) {
     const long long total = (long long)a.G * a.rows * a.ld;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
+    for (long long e = (long long)bx * blockDim.x + threadIdx.x; e < total; e += (long long)nbx * blockDim.x) {
         const int c = (int)(e % a.ld);
         const long long gr = e / a.ld;
         const int row = (int)(gr % a.rows), g = (int)(gr / a.rows);
@@ -159,16 +220,16 @@ __device__ __forceinline__ void ac_concat_body(const ConcatArgs& a) {
     }
 }
 
-__global__ __launch_bounds__(256) void ac_concat_kernel(ConcatArgs a) { ac_concat_body(a); }
+__global__ __launch_bounds__(256) void ac_concat_kernel(ConcatArgs a) { ac_concat_body(a, (int)blockIdx.x, (int)gridDim.x); }
 
 // all network inputs of one update in a single launch (blockIdx.y = destination matrix)
 struct ConcatMulti {
-    ConcatArgs c[4];
+    ConcatArgs c[5];
     int n;
 };
 
 __global__ __launch_bounds__(256) void ac_concat_multi_kernel(ConcatMulti m) {
-    if ((int)blockIdx.y < m.n) ac_concat_body(m.c[blockIdx.y]);
+    if ((int)blockIdx.y < m.n) ac_concat_body(m.c[blockIdx.y], (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -407,7 +468,7 @@ struct HeadArgs {
     float policy_noise, noise_clip;
 };
 
-__global__ __launch_bounds__(256) void ac_head_fwd_kernel(HeadArgs a) {
+__device__ __forceinline__ void ac_head_fwd_body(const HeadArgs& a) {
     const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
     if (e >= a.G * a.rows) return;
     const int g = e / a.rows, row = e % a.rows;
@@ -462,6 +523,10 @@ __global__ __launch_bounds__(256) void ac_head_fwd_kernel(HeadArgs a) {
         a.logp[(long long)g * a.rows + row] = lp;
     }
 }
+
+__global__ __launch_bounds__(256) void ac_head_fwd_kernel(HeadArgs a) { ac_head_fwd_body(a); }
+// a' ~ pi(s') and a ~ pi(s) of one update (both actors' pre-activations come out of the same chain launch): blockIdx.y picks
+__global__ __launch_bounds__(256) void ac_head_fwd_pair_kernel(HeadArgs a, HeadArgs b) { ac_head_fwd_body(blockIdx.y == 0 ? a : b); }
 
 struct HeadBwdArgs {
     const float* dx_q;        // [G*nq][cap][ld_qin]  dLoss / d(critic input); the action columns start at col0
@@ -536,6 +601,22 @@ __device__ __forceinline__ double ac_block_sum(double v, double* s_red) {
 //   MOSAC mosac...:436-450   scalarised: t = r.w + (1-d) * gamma * (min_n (Qt_n.w) - alpha * logp'); loss = sum_n mse
 //   TD3   gpi_pd_c...:395-415  n* = argmin_n (Qt_n . w_row); target = r + (1-d) * gamma * Qt_n*; PER |q_0 - t| * 0.05 . w
 // ---------------------------------------------------------------------------------------------------------------------
+// The bias-correction scalars of the Adam step that follows (two fp64 pow()s per learner), computed by an otherwise idle thread
+// of the loss kernel in front of the backward pass, for the optimiser step inside the weight-gradient launch (AdamFuse::corr)
+struct AdamCorrOut {
+    float* out;               // [G][2] or NULL
+    const int* steps;         // [G] or NULL
+    int step_add;
+    double lr, b1, b2;
+};
+__device__ __forceinline__ void adam_corr_write(const AdamCorrOut& a, int g) {
+    if (a.out != nullptr && threadIdx.x == blockDim.x - 1) {
+        const AdamScalars c = adam_scalars(max(1, (a.steps ? a.steps[g] : 0) + a.step_add), a.lr, a.b1, a.b2, 0.f);
+        a.out[2 * g] = c.neg_step_size;
+        a.out[2 * g + 1] = c.bc2_sqrt;
+    }
+}
+
 struct CriticArgs {
     const float* tq;          // [G*nq][cap][ldo]  target critics at (s', a')
     const float* q;           // [G*nq][cap][ldo]  critics at (s, a)
@@ -556,11 +637,13 @@ struct CriticArgs {
     int n_per;
     int rows, R, nq, algo;
     float gamma;
+    AdamCorrOut corr;
 };
 
 __global__ __launch_bounds__(256) void ac_critic_kernel(CriticArgs a) {
     __shared__ double s_red[4];
     const int g = (int)blockIdx.x;
+    adam_corr_write(a.corr, g);
     const float alpha = (a.algo == MORL_AC_TD3) ? 0.f : ac_alpha(a.log_alpha, a.alpha_const, g);
     double part[4] = {0.0, 0.0, 0.0, 0.0};                  // per-critic squared-error sums (nq <= 4)
     for (int row = (int)threadIdx.x; row < a.rows; row += (int)blockDim.x) {
@@ -657,11 +740,13 @@ struct ActorLossArgs {
     float alpha_const;
     float* loss_out;          // [G] or NULL
     int rows, R, nq, algo;
+    AdamCorrOut corr;
 };
 
 __global__ __launch_bounds__(256) void ac_actor_loss_kernel(ActorLossArgs a) {
     __shared__ double s_red[4];
     const int g = (int)blockIdx.x;
+    adam_corr_write(a.corr, g);
     const float alpha = (a.algo == MORL_AC_TD3) ? 0.f : ac_alpha(a.log_alpha, a.alpha_const, g);
     double s_lp = 0.0, s_q = 0.0;
     const float inv_rows = 1.f / (float)a.rows;
@@ -723,7 +808,8 @@ __global__ void ac_alpha_prepare_kernel(const float* log_alpha, float alpha_cons
 __global__ __launch_bounds__(256) void ac_alpha_step_kernel(float* log_alpha, float* m_, float* v_, const float* logp,
                                                             int rows, float target_entropy, const int* steps,
                                                             int step_add, double lr, double db1, double db2, float eps,
-                                                            float* alpha_loss_out) {
+                                                            float* alpha_loss_out, int* adv_q = nullptr, int* adv_p = nullptr,
+                                                            int adv_p_by = 0) {
     __shared__ double s_red[4];
     const int g = (int)blockIdx.x;
     double s = 0.0;
@@ -732,6 +818,9 @@ __global__ __launch_bounds__(256) void ac_alpha_step_kernel(float* log_alpha, fl
     const double tot = ac_block_sum(s, s_red);
     if (threadIdx.x == 0) {
         const int t = max(1, (steps ? steps[g] : 0) + step_add);
+        // (the last reader of the update's step counters advances them: see AdamFuse::adv_q)
+        if (adv_q) adv_q[g] += 1;
+        if (adv_p) adv_p[g] += adv_p_by;
         const float neg_step_size = (float)(-(lr / (1.0 - pow(db1, (double)t))));
         const float bc2_sqrt = (float)sqrt(1.0 - pow(db2, (double)t));
         const float one_minus_b1 = (float)(1.0 - db1), b2 = (float)db2, one_minus_b2 = (float)(1.0 - db2);
@@ -1005,15 +1094,26 @@ __device__ __forceinline__ void mlp_transpose_tile(const MlpLayout& t, const flo
 
 // Small totals (a single learner: 0.15 M parameters per set): one element per thread, scattered stores -- 7 us against the 9 us
 // the tiled form needs for its two phases; the tiled form takes over where the scatter's bandwidth matters.
-__global__ __launch_bounds__(256) void ac_transpose_scatter_kernel(TransposeMulti a) {
-    const int q = (int)blockIdx.z;
+__device__ __forceinline__ void ac_transpose_scatter_body(const TransposeMulti& a, int q, int bx, int nbx) {
     if (q >= a.n) return;
     const MlpLayout& t = a.lay[q];
     const long long total = t.P * a.nets[q];
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    for (long long e = (long long)bx * blockDim.x + threadIdx.x; e < total; e += (long long)nbx * blockDim.x) {
         const long long net = e / t.P, p = e - net * t.P;
         a.dst[q][net * t.P + mlp_transposed_index(t, p)] = a.src[q][e];
     }
+}
+__global__ __launch_bounds__(256) void ac_transpose_scatter_kernel(TransposeMulti a) {
+    ac_transpose_scatter_body(a, (int)blockIdx.z, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The two independent preparations at the start of a single learner's update in ONE launch (each is a few microseconds of work
+// behind a launch boundary of its own): workgroups [0, cx * m.n) assemble the network inputs, the rest scatter the K-major shadow
+// copies of the parameter sets.
+__global__ __launch_bounds__(256) void ac_inputs_shadows_kernel(ConcatMulti m, TransposeMulti tm, int cx, int tx) {
+    const int b = (int)blockIdx.x;
+    if (b < cx * m.n) ac_concat_body(m.c[b / cx], b % cx, cx);
+    else ac_transpose_scatter_body(tm, (b - cx * m.n) / tx, (b - cx * m.n) % tx, tx);
 }
 
 // grid (max over the sets of tiles + 1, max nets, sets)
@@ -1036,22 +1136,20 @@ __global__ __launch_bounds__(256) void ac_adam_kernel(float* __restrict__ params
     // were most of the kernel: 58 us for the 9 M critic parameters of a 64-learner population, ~1 TB/s)
     __shared__ float s_corr[2];
     if (threadIdx.x == 0) {
-        const int t = max(1, (steps ? steps[g] : 0) + step_add);
-        s_corr[0] = (float)(-(lr / (1.0 - pow(b1, (double)t))));
-        s_corr[1] = (float)sqrt(1.0 - pow(b2, (double)t));
+        const AdamScalars c0 = adam_scalars(max(1, (steps ? steps[g] : 0) + step_add), lr, b1, b2, eps);
+        s_corr[0] = c0.neg_step_size;
+        s_corr[1] = c0.bc2_sqrt;
     }
     __syncthreads();
-    const float neg_step_size = s_corr[0];
-    const float bc2_sqrt = s_corr[1];
-    const float one_minus_b1 = (float)(1.0 - b1), fb2 = (float)b2, one_minus_b2 = (float)(1.0 - b2);
+    AdamScalars c;
+    c.neg_step_size = s_corr[0];
+    c.bc2_sqrt = s_corr[1];
+    c.one_minus_b1 = (float)(1.0 - b1); c.b2 = (float)b2; c.one_minus_b2 = (float)(1.0 - b2); c.eps = eps;
     const long long base = (long long)g * seg;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < seg; p += (long long)gridDim.x * blockDim.x) {
         const float gr = grads[base + p];
         float m = exp_avg[base + p], v = exp_avg_sq[base + p];
-        m = fmaf(one_minus_b1, __fsub_rn(gr, m), m);
-        v = __fadd_rn(__fmul_rn(v, fb2), __fmul_rn(__fmul_rn(one_minus_b2, gr), gr));
-        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), bc2_sqrt), eps);
-        const float np_ = __fadd_rn(params[base + p], __fmul_rn(neg_step_size, __fdiv_rn(m, denom)));
+        const float np_ = adam_element(c, params[base + p], gr, m, v);
         params[base + p] = np_;
         exp_avg[base + p] = m;
         exp_avg_sq[base + p] = v;

@@ -200,10 +200,58 @@ __device__ __forceinline__ void panel_transpose(float (&v)[WG4_CHUNK / 2], const
     }
 }
 
-template <bool A_KC, bool B_KC, int EPI>
-__device__ __forceinline__ void gemm_wave4_tile(const GemmProblem& g, int tile_m, int tile_n) {
-    __shared__ float s_red[3][16][64];
-    __shared__ float s_col[3][32];
+// The Adam step of ONE parameter as torch's single-tensor implementation evaluates it (torch/optim/adam.py: exp_avg.lerp_,
+// exp_avg_sq.mul_().addcmul_(), denom = sqrt / bias_correction2_sqrt + eps, addcdiv_ with -lr / bias_correction1): every
+// optimiser kernel of the actor-critic rows goes through this one function, so a fused and a separate step give the same bits.
+struct AdamScalars {
+    float neg_step_size, bc2_sqrt, one_minus_b1, b2, one_minus_b2, eps;
+};
+__device__ __forceinline__ float adam_element(const AdamScalars& c, float p, float gr, float& m, float& v) {
+    m = fmaf(c.one_minus_b1, __fsub_rn(gr, m), m);
+    v = __fadd_rn(__fmul_rn(v, c.b2), __fmul_rn(__fmul_rn(c.one_minus_b2, gr), gr));
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), c.bc2_sqrt), c.eps);
+    return __fadd_rn(p, __fmul_rn(c.neg_step_size, __fdiv_rn(m, denom)));
+}
+__device__ __forceinline__ AdamScalars adam_scalars(int t, double lr, double b1, double b2, float eps) {
+    AdamScalars c;
+    c.neg_step_size = (float)(-(lr / (1.0 - pow(b1, (double)t))));
+    c.bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)t));
+    c.one_minus_b1 = (float)(1.0 - b1); c.b2 = (float)b2; c.one_minus_b2 = (float)(1.0 - b2); c.eps = eps;
+    return c;
+}
+
+// Adam in the epilogue of a weight-gradient tile (gemm_wave4_tile<..., ADAM = true>): the tile's sums ARE the finished gradient
+// entries (the four waves split the batch rows inside the workgroup, no split over workgroups), so the step, the K-major shadow
+// copy the forward chains stream and the Polyak average of the target net are applied where the gradient is produced -- the
+// gradient itself never goes to memory.  Pointers are those of this net's flat parameter block.
+struct AdamTile {
+    float* params; float* exp_avg; float* exp_avg_sq;
+    float* wt;              // K-major shadow copy of this net, or NULL
+    float* target;          // Polyak target of this net, or NULL
+    long long offW, offB;   // this layer's weight block ([M][N] dense, nn.Linear layout) and bias block
+    const float* corr;      // {-lr / bias_correction1, sqrt(bias_correction2)} of this learner, left by an earlier kernel of the
+                            // update (the two fp64 pow()s are ~2 us of one wave: not in this epilogue), or NULL: from `step`
+    int step;               // Adam step number of this update (>= 1)
+    double lr, b1, b2;
+    float eps, tau;
+};
+__device__ __forceinline__ void adam_tile_apply(const AdamTile& a, const AdamScalars& c, long long e, long long e_t, float gr) {
+    float m = a.exp_avg[e], v = a.exp_avg_sq[e];
+    const float np_ = adam_element(c, a.params[e], gr, m, v);
+    a.params[e] = np_;
+    a.exp_avg[e] = m;
+    a.exp_avg_sq[e] = v;
+    if (a.wt != nullptr) a.wt[e_t] = np_;
+    if (a.target != nullptr) {
+        if (a.tau == 1.0f) a.target[e] = np_;
+        else a.target[e] = __fadd_rn(__fmul_rn(a.target[e], 1.0f - a.tau), __fmul_rn(a.tau, np_));
+    }
+}
+
+template <bool A_KC, bool B_KC, int EPI, bool ADAM = false>
+__device__ __forceinline__ void gemm_wave4_tile(const GemmProblem& g, int tile_m, int tile_n, const AdamTile* ad = nullptr) {
+    __shared__ float s_red[ADAM ? 4 : 3][16][64];
+    __shared__ float s_col[ADAM ? 4 : 3][32];
     __shared__ __attribute__((aligned(16))) float s_panel[(A_KC || B_KC) ? 4 : 1][(A_KC || B_KC) ? 32 * WG4_PITCH : 4];
     const int lane = lane_id(), wave = wave_id();
     const int h = lane >> 5, i = lane & 31;
@@ -231,6 +279,36 @@ __device__ __forceinline__ void gemm_wave4_tile(const GemmProblem& g, int tile_m
             acc = mfma32(a[s], b[s], acc);
             if (do_colsum) { const float odd = __shfl_xor(a[s], 32); colsum += a[s]; colsum += odd; }
         }
+    }
+    if constexpr (ADAM) {
+        // every wave leaves its partial tile in LDS and finishes a quarter of the entries: the sums in the wave order of the plain
+        // epilogue below -- ((wave 0 + wave 1) + wave 2) + wave 3 --, then the optimiser step of those entries (three loads, the
+        // step, up to five stores per entry: spread over the four waves instead of serial in one)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_red[wave][r][lane] = acc[r];
+        if (do_colsum && h == 0) s_col[wave][i] = colsum;
+        __syncthreads();
+        AdamScalars c;
+        if (ad->corr != nullptr) {
+            c.neg_step_size = ad->corr[0]; c.bc2_sqrt = ad->corr[1];
+            c.one_minus_b1 = (float)(1.0 - ad->b1); c.b2 = (float)ad->b2; c.one_minus_b2 = (float)(1.0 - ad->b2); c.eps = ad->eps;
+        } else {
+            c = adam_scalars(ad->step, ad->lr, ad->b1, ad->b2, ad->eps);
+        }
+        const int col = n0 + i;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * wave + rr;
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float gr = ((s_red[0][r][lane] + s_red[1][r][lane]) + s_red[2][r][lane]) + s_red[3][r][lane];
+            if (row < g.M && col < g.N)
+                adam_tile_apply(*ad, c, ad->offW + (long long)row * g.N + col, ad->offW + (long long)col * g.M + row, gr);
+        }
+        if (do_colsum && wave == 3 && h == 0 && m0 + i < g.M) {
+            const long long e = ad->offB + m0 + i;
+            adam_tile_apply(*ad, c, e, e, ((s_col[0][i] + s_col[1][i]) + s_col[2][i]) + s_col[3][i]);
+        }
+        return;
     }
     if (wave > 0) {
 #pragma unroll

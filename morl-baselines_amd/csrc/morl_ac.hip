@@ -77,11 +77,15 @@ struct morl_ac_ctx {
     float* act = nullptr;                        // [PG][cap][Ad]
     float* logp_next = nullptr;                  // [PG][cap]
     float* logp_pi = nullptr;
+    float* act_pi = nullptr;                     // [PG][cap][Ad] (a ~ pi(s) when its head runs next to pi(s')'s)
+    float* xq_b = nullptr;                       // tq_b.x as allocated; xq_pi: the critics' input rows (s, pi(s), w) of the actor phase
+    float* xq_pi = nullptr;                      //   when pi(s) is sampled before the critic phase has finished with (s, a, w)
     float* save_y = nullptr;                     // [PG][cap][Ad]
     float* save_std = nullptr;
     float* gq = nullptr;                         // [QG][Pq]
     float* gp = nullptr;                         // [PG][Pp]
     float* alpha_dev = nullptr;                  // [PG]
+    float* adam_corr = nullptr;                  // [2][PG][2] bias-correction scalars of the critics' / the actor's fused Adam step
     // K-major shadow copies of the weight matrices used by the forward GEMMs of an update (ac_kernels.h: MlpLayout)
     float* wt_q = nullptr;                       // [QG][Pq]
     float* wt_qt = nullptr;                      // [QG][Pq]  target critics
@@ -200,16 +204,18 @@ extern "C" int morl_ac_create(morl_ac_ctx** out, const morl_ac_desc* d) {
         (rc = alloc_tape(c->allocs, c->q, c->tq_b, c->QG, c->PG, c->cap, post)) ||
         (rc = alloc_tape(c->allocs, c->pol, c->tp_a, c->PG, c->PG, c->cap, false)) ||
         (rc = alloc_tape(c->allocs, c->pol, c->tp_b, c->PG, c->PG, c->cap, false)) ||
-        (rc = alloc_f(c, &c->act, c->PG * cap * Ad)) || (rc = alloc_f(c, &c->logp_next, c->PG * cap)) ||
+        (rc = alloc_f(c, &c->act, c->PG * cap * Ad)) || (rc = alloc_f(c, &c->act_pi, c->PG * cap * Ad)) ||
+        (rc = alloc_f(c, &c->xq_pi, c->PG * cap * (size_t)q.ld[0])) || (rc = alloc_f(c, &c->logp_next, c->PG * cap)) ||
         (rc = alloc_f(c, &c->logp_pi, c->PG * cap)) || (rc = alloc_f(c, &c->save_y, c->PG * cap * Ad)) ||
         (rc = alloc_f(c, &c->save_std, c->PG * cap * Ad)) || (rc = alloc_f(c, &c->gq, (size_t)c->QG * q.P)) ||
-        (rc = alloc_f(c, &c->gp, (size_t)c->PG * p.P)) || (rc = alloc_f(c, &c->alpha_dev, c->PG)) ||
+        (rc = alloc_f(c, &c->gp, (size_t)c->PG * p.P)) || (rc = alloc_f(c, &c->alpha_dev, c->PG)) || (rc = alloc_f(c, &c->adam_corr, (size_t)4 * c->PG)) ||
         (rc = alloc_f(c, &c->wt_q, (size_t)c->QG * q.P)) || (rc = alloc_f(c, &c->wt_qt, (size_t)c->QG * q.P)) ||
         (rc = alloc_f(c, &c->wt_pol, (size_t)c->PG * p.P)) || (rc = alloc_f(c, &c->wt_polt, (size_t)c->PG * p.P))) {
         morl_ac_destroy(c);
         return rc;
     }
     if (hipDeviceSynchronize() != hipSuccess) { morl_ac_destroy(c); return fail(MORL_ERR_HIP, "workspace init failed"); }
+    c->xq_b = c->tq_b.x;
     *out = c;
     return MORL_OK;
 }
@@ -478,9 +484,13 @@ static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape&
 
 // backward of the same pass: t.g[L-1] holds dLoss/d(out).  grads ([G][P], fully overwritten) may be NULL (no parameter
 // gradients wanted); need_dx -> t.dx = dLoss/d(input rows).  `dropped` = the forward ran with train-mode dropout.
+// fuse / fused: the caller offers the optimiser step of these gradients (AdamFuse with everything but the layer offsets filled
+// in); *fused says whether the weight-gradient launch took it -- it does when it runs on the split-K wave tiles (single learners
+// and small populations), where a workgroup's tile holds finished gradient entries; otherwise `grads` is written as usual
 static int mlp_backward(const Mlp& m, const float* params, int64_t pstride, Tape& t, int rows, int x_div,
                         bool dropped, float* grads, bool need_dx, hipStream_t s, int64_t grad_stride = -1,
-                        const float* wt = nullptr) {
+                        const float* wt = nullptr, const AdamFuse* fuse = nullptr, bool* fused = nullptr) {
+    if (fused) *fused = false;
     const long long cap = t.cap;
     if (grad_stride < 0) grad_stride = m.P;      // floats between the gradient blocks of consecutive nets
     // dX chain in one launch when the forward was the layer-fused one (its ReLU sign bits are in the tape): g[L-1] -> ... ->
@@ -606,7 +616,16 @@ static int mlp_backward(const Mlp& m, const float* params, int64_t pstride, Tape
                 tiles += g.tiles_m * g.tiles_n;
             }
             grp.tile_start[m.L] = tiles;
-            if (rows > 32)
+            if (rows > 32 && fuse && fused && grad_stride == m.P) {
+                AdamFuse f = *fuse;
+                for (int l = 0; l < m.L; ++l) { f.offW[l] = m.offW[l]; f.offB[l] = m.offB[l]; }
+                f.grads = grads;
+                if (m.ln)
+                    for (int l = 0; l < m.L - 1; ++l) { f.extra_off[f.n_extra] = m.offG[l]; f.extra_len[f.n_extra++] = 2 * m.dims[l + 1]; }
+                hipLaunchKernelGGL(gemm_wave4_grouped_tn_batched_adam_kernel, dim3(tiles + (f.n_extra ? 1 : 0), 1, t.G), dim3(256), 0, s,
+                                   grp, f);
+                *fused = true;
+            } else if (rows > 32)
                 hipLaunchKernelGGL(gemm_wave4_grouped_tn_batched_kernel, dim3(tiles, 1, t.G), dim3(256), 0, s, grp);
             else
                 hipLaunchKernelGGL(gemm_wave_grouped_tn_batched_kernel, dim3((tiles + 3) / 4, 1, t.G), dim3(256), 0, s, grp);
@@ -700,9 +719,8 @@ static int polyak(const float* src, float* dst, long long n, float tau, hipStrea
     return MORL_OK;
 }
 
-static int head_forward(morl_ac_ctx* c, Tape& tp, int rows, const float* eps, const morl_ac_state* st,
-                        const morl_ac_cfg* cfg, float* action, float* logp, bool save, hipStream_t s,
-                        Tape* qin = nullptr) {
+static HeadArgs head_args(morl_ac_ctx* c, Tape& tp, int rows, const float* eps, const morl_ac_state* st,
+                          const morl_ac_cfg* cfg, float* action, float* logp, bool save, Tape* qin = nullptr) {
     HeadArgs a{};
     a.head = tp.out;
     a.head_gstride = (long long)c->cap * c->pol.ld[c->pol.L];
@@ -718,6 +736,12 @@ static int head_forward(morl_ac_ctx* c, Tape& tp, int rows, const float* eps, co
     a.rows = rows; a.Ad = c->d.act_dim; a.G = c->PG; a.algo = c->d.algo;
     a.policy_noise = cfg ? cfg->policy_noise : 0.f;
     a.noise_clip = cfg ? cfg->noise_clip : 0.f;
+    return a;
+}
+static int head_forward(morl_ac_ctx* c, Tape& tp, int rows, const float* eps, const morl_ac_state* st,
+                        const morl_ac_cfg* cfg, float* action, float* logp, bool save, hipStream_t s,
+                        Tape* qin = nullptr) {
+    const HeadArgs a = head_args(c, tp, rows, eps, st, cfg, action, logp, save, qin);
     hipLaunchKernelGGL(ac_head_fwd_kernel, dim3((c->PG * rows + 255) / 256), dim3(256), 0, s, a);
     LAUNCH_CHECK("ac_head_fwd");
     return MORL_OK;
@@ -893,6 +917,12 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
     if (algo == MORL_AC_SACD) return sacd_update(c, st, bt, cfg, out, PG, s);
 
     // ---- every network input of the update in one launch: policy at s' / s, critics at (s', .) / (s, a) -----------------------
+    // a ~ pi(s) of the actor phase's first iteration is sampled next to a' ~ pi(s') (one head launch instead of two): it then needs
+    // critic input rows of its own, the critic phase is not done with (s, a, w)
+    static const bool heads_env = [] { const char* e = getenv("MORL_AC_HEADS_PAIRED"); return e ? atoi(e) != 0 : true; }();   // (A/B)
+    const bool heads_early = heads_env && cfg->do_policy != 0;
+    c->tq_b.x = c->xq_b;
+    ConcatMulti m{};
     {
         auto fill = [&](ConcatArgs& a, float* dst, int ld, const float* s0, int w0, const float* s1, int w1, const float* s2, int w2) {
             const float* src[3] = {s0, s1, s2};
@@ -907,16 +937,17 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
             a.n_src = n;
             a.dst = dst; a.ld = ld; a.dst_gstride = (long long)c->cap * ld; a.rows = rows; a.G = PG;
         };
-        ConcatMulti m{};
         m.n = 4;
         fill(m.c[0], c->tp_a.x, P.ld[0], bt->next_obs, D, w_rows, wR, nullptr, 0);
         fill(m.c[1], c->tq_a.x, Q.ld[0], bt->next_obs, D, nullptr, Ad, w_rows, wR);      // a' is written by the head kernel
         fill(m.c[2], c->tq_b.x, Q.ld[0], bt->obs, D, bt->actions, Ad, w_rows, wR);
         fill(m.c[3], c->tp_b.x, P.ld[0], bt->obs, D, w_rows, wR, nullptr, 0);
-        const long long biggest = (long long)PG * rows * Q.ld[0];
-        hipLaunchKernelGGL(ac_concat_multi_kernel, dim3(stream_grid(biggest, 256, 512), 4), dim3(256), 0, s, m);
-        LAUNCH_CHECK("ac_inputs");
+        if (heads_early) {       // the actor phase's critic input rows (s, pi(s), w): pi(s) is written by the paired head launch
+            m.n = 5;
+            fill(m.c[4], c->xq_pi, Q.ld[0], bt->obs, D, nullptr, Ad, w_rows, wR);
+        }
     }
+    const int concat_bx = stream_grid((long long)PG * rows * Q.ld[0], 256, 512);
 
     // ---- K-major shadow copies of every parameter set this update reads in a forward pass (one launch) -----------------------
     constexpr bool shadow_env = true;
@@ -944,7 +975,22 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
             tm.nets[tm.n] = is_q ? QG : PG;
             ++tm.n;
         }
-        if ((rc = launch_transposes(tm, s))) return rc;
+        // a single learner: the shadow copies are scattered by extra workgroups of the input-assembly launch
+        long long longest = 0;
+        for (int k = 0; k < tm.n; ++k) longest = std::max(longest, tm.lay[k].P * tm.nets[k]);
+        static const long long scatter_max = [] { const char* e = getenv("MORL_AC_SCATTER_MAX"); return e ? atoll(e) : (1ll << 20); }();
+        if (tm.n >= 1 && longest >= 1 && longest <= scatter_max) {
+            const int tx = stream_grid(longest, 256, 1024);
+            hipLaunchKernelGGL(ac_inputs_shadows_kernel, dim3(concat_bx * m.n + tx * tm.n), dim3(256), 0, s, m, tm, concat_bx, tx);
+            LAUNCH_CHECK("ac_inputs_shadows");
+        } else {
+            hipLaunchKernelGGL(ac_concat_multi_kernel, dim3(concat_bx, m.n), dim3(256), 0, s, m);
+            LAUNCH_CHECK("ac_inputs");
+            if ((rc = launch_transposes(tm, s))) return rc;
+        }
+    } else {
+        hipLaunchKernelGGL(ac_concat_multi_kernel, dim3(concat_bx, m.n), dim3(256), 0, s, m);
+        LAUNCH_CHECK("ac_inputs");
     }
 
     // ---- critic phase: a' ~ pi(s'), target critics at (s', a'), critics at (s, a), TD loss, backward, Adam --------------
@@ -954,14 +1000,30 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                           pi_s_early ? st->pol : nullptr, pi_s_early ? &c->tp_b : nullptr, &nodrop,
                           algo == MORL_AC_TD3 ? WT(c->wt_polt) : WT(c->wt_pol), pi_s_early ? WT(c->wt_pol) : nullptr)))
         return rc;
-    if ((rc = head_forward(c, c->tp_a, rows, bt->eps_next, st, cfg, c->act, c->logp_next, false, s, &c->tq_a))) return rc;
+    if (heads_early) {
+        const HeadArgs h_next = head_args(c, c->tp_a, rows, bt->eps_next, st, cfg, c->act, c->logp_next, false, &c->tq_a);
+        Tape xpi = c->tq_b;
+        xpi.x = c->xq_pi;
+        const HeadArgs h_pi = head_args(c, c->tp_b, rows, (algo == MORL_AC_TD3) ? nullptr : bt->eps_pi, st, cfg, c->act_pi,
+                                        c->logp_pi, true, &xpi);
+        hipLaunchKernelGGL(ac_head_fwd_pair_kernel, dim3((c->PG * rows + 255) / 256, 2), dim3(256), 0, s, h_next, h_pi);
+        LAUNCH_CHECK("ac_head_fwd_pair");
+    } else if ((rc = head_forward(c, c->tp_a, rows, bt->eps_next, st, cfg, c->act, c->logp_next, false, s, &c->tq_a))) return rc;
     {
         // target critics at (s', a') and online critics at (s, a): independent passes, one launch per layer
         const DropSpec d0 = dropspec(0), d1 = dropspec(1);
         if ((rc = mlp_forward(Q, st->q_target, Q.P, c->tq_a, rows, nq, d0, s, st->q, &c->tq_b, &d1, WT(c->wt_qt), WT(c->wt_q)))) return rc;
     }
+    // the optimiser step (+ the K-major shadow copy, + the Polyak average of the target critics, which nothing reads before the
+    // next update) rides in the weight-gradient launch when nobody asks for the gradients themselves
+    static const bool adam_in_dw = [] { const char* e = getenv("MORL_AC_ADAM_IN_DW"); return e ? atoi(e) != 0 : true; }();   // (A/B)
+    static const long long scatter_max = [] { const char* e = getenv("MORL_AC_SCATTER_MAX"); return e ? atoll(e) : (1ll << 20); }();
+    const bool may_fuse = adam_in_dw && !cfg->grad_hook;
+    const bool offer_q = may_fuse && !out->q_grads && (!use_wt || (long long)QG * Q.P <= scatter_max);
+    const bool offer_p = may_fuse && !out->pol_grads && (!use_wt || (long long)PG * P.P <= scatter_max);
     {
         CriticArgs a{};
+        if (offer_q) a.corr = AdamCorrOut{c->adam_corr, st->q_steps, st->q_steps ? 1 : cfg->q_step, cfg->q_lr, cfg->beta1, cfg->beta2};
         a.tq = c->tq_a.out; a.q = c->tq_b.out; a.dq = c->tq_b.g[Q.L - 1];
         a.gstride = q_gs; a.ldo = (int)q_ldo;
         a.logp_next = c->logp_next; a.rewards = bt->rewards; a.dones = bt->dones;
@@ -974,7 +1036,21 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
         hipLaunchKernelGGL(ac_critic_kernel, dim3(c->PG), dim3(256), 0, s, a);
         LAUNCH_CHECK("ac_critic");
     }
-    if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_b, rows, nq, Q.drop > 0.f, c->gq, false, s, -1, WT(c->wt_q)))) return rc;
+    bool q_fused = false, q_target_fused = false, steps_advanced = false;
+    {
+        AdamFuse f{};
+        f.corr = c->adam_corr;
+        if (!cfg->do_policy) f.adv_q = st->q_steps;          // nothing behind this launch reads the counter
+        f.params = st->q; f.exp_avg = st->q_exp_avg; f.exp_avg_sq = st->q_exp_avg_sq;
+        f.wt = WT(c->wt_q);
+        f.target = cfg->do_target ? st->q_target : nullptr;
+        f.steps = st->q_steps; f.step_add = st->q_steps ? 1 : cfg->q_step; f.nets_per_learner = nq;
+        f.lr = cfg->q_lr; f.b1 = cfg->beta1; f.b2 = cfg->beta2; f.eps = (float)cfg->eps; f.tau = cfg->tau;
+        if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_b, rows, nq, Q.drop > 0.f, c->gq, false, s, -1, WT(c->wt_q),
+                               offer_q ? &f : nullptr, &q_fused))) return rc;
+        q_target_fused = q_fused && cfg->do_target;
+        steps_advanced = q_fused && !cfg->do_policy;
+    }
     if (out->q_grads)
         HIP_TRY(hipMemcpyAsync(out->q_grads, c->gq, (size_t)c->QG * Q.P * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (cfg->grad_hook) {
@@ -983,8 +1059,8 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
             return fail(MORL_ERR_STATE, "grad_hook failed on the critic gradients");
         HIP_TRY(hipMemcpyAsync(c->gq, out->q_grads, (size_t)c->QG * Q.P * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    if ((rc = adam(st->q, c->gq, st->q_exp_avg, st->q_exp_avg_sq, (long long)nq * Q.P, PG, cfg->q_lr, st->q_steps,
-                   st->q_steps ? 1 : cfg->q_step, cfg, s, WT(c->wt_q), &Q))) return rc;
+    if (!q_fused && (rc = adam(st->q, c->gq, st->q_exp_avg, st->q_exp_avg_sq, (long long)nq * Q.P, PG, cfg->q_lr, st->q_steps,
+                               st->q_steps ? 1 : cfg->q_step, cfg, s, WT(c->wt_q), &Q))) return rc;
 
     // ---- actor phase ---------------------------------------------------------------------------------------------------
     if (cfg->do_policy) {
@@ -997,10 +1073,14 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
             const bool trunk_current = (it == 0 && pi_s_early) || (it > 0 && autotune && algo == MORL_AC_MOSAC);
             if (!trunk_current && (rc = mlp_forward(P, st->pol, P.P, c->tp_b, rows, 1, nodrop, s, nullptr, nullptr, nullptr, WT(c->wt_pol))))
                 return rc;
-            if ((rc = head_forward(c, c->tp_b, rows, eps_pi, st, cfg, c->act, c->logp_pi, true, s, &c->tq_b))) return rc;
+            if (it == 0 && heads_early) c->tq_b.x = c->xq_pi;     // (restored at the start of the next update)
+            else if ((rc = head_forward(c, c->tp_b, rows, eps_pi, st, cfg, c->act, c->logp_pi, true, s, &c->tq_b))) return rc;
             if ((rc = mlp_forward(Q, st->q, Q.P, c->tq_b, rows, nq, dropspec(2), s, nullptr, nullptr, nullptr, WT(c->wt_q)))) return rc;
             {
                 ActorLossArgs a{};
+                if (offer_p)
+                    a.corr = AdamCorrOut{c->adam_corr + 2 * c->PG, st->pol_steps, (st->pol_steps ? 1 : cfg->policy_step) + it,
+                                         cfg->policy_lr, cfg->beta1, cfg->beta2};
                 a.q = c->tq_b.out; a.dq = c->tq_b.g[Q.L - 1];
                 a.gstride = q_gs; a.ldo = (int)q_ldo;
                 a.logp = c->logp_pi; a.w = bt->w; a.w_per_row = c->w_input ? 1 : 0;
@@ -1023,7 +1103,21 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                 hipLaunchKernelGGL(ac_head_bwd_kernel, dim3((c->PG * rows + 255) / 256), dim3(256), 0, s, a);
                 LAUNCH_CHECK("ac_head_bwd");
             }
-            if ((rc = mlp_backward(P, st->pol, P.P, c->tp_b, rows, 1, false, c->gp, false, s, -1, WT(c->wt_pol)))) return rc;
+            bool p_fused = false;
+            {
+                AdamFuse f{};
+                f.params = st->pol; f.exp_avg = st->pol_exp_avg; f.exp_avg_sq = st->pol_exp_avg_sq;
+                f.wt = WT(c->wt_pol);
+                f.target = (algo == MORL_AC_TD3) ? st->pol_target : nullptr;
+                f.steps = st->pol_steps; f.step_add = (st->pol_steps ? 1 : cfg->policy_step) + it; f.nets_per_learner = 1;
+                f.lr = cfg->policy_lr; f.b1 = cfg->beta1; f.b2 = cfg->beta2; f.eps = (float)cfg->eps; f.tau = cfg->tau;
+                f.corr = c->adam_corr + 2 * c->PG;
+                const bool last_reader = (it == iters - 1) && !autotune;       // (with a learnt alpha: its step kernel below)
+                if (last_reader) { f.adv_q = st->q_steps; f.adv_p = st->pol_steps; f.adv_p_by = iters; }
+                if ((rc = mlp_backward(P, st->pol, P.P, c->tp_b, rows, 1, false, c->gp, false, s, -1, WT(c->wt_pol),
+                                       offer_p ? &f : nullptr, &p_fused))) return rc;
+                if (p_fused && last_reader) steps_advanced = true;
+            }
             if (out->pol_grads)
                 HIP_TRY(hipMemcpyAsync(out->pol_grads, c->gp, (size_t)c->PG * P.P * sizeof(float), hipMemcpyDeviceToDevice, s));
             if (cfg->grad_hook) {
@@ -1031,8 +1125,8 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                     return fail(MORL_ERR_STATE, "grad_hook failed on the actor gradients");
                 HIP_TRY(hipMemcpyAsync(c->gp, out->pol_grads, (size_t)c->PG * P.P * sizeof(float), hipMemcpyDeviceToDevice, s));
             }
-            if ((rc = adam(st->pol, c->gp, st->pol_exp_avg, st->pol_exp_avg_sq, P.P, PG, cfg->policy_lr, st->pol_steps,
-                           (st->pol_steps ? 1 : cfg->policy_step) + it, cfg, s, WT(c->wt_pol), &P))) return rc;
+            if (!p_fused && (rc = adam(st->pol, c->gp, st->pol_exp_avg, st->pol_exp_avg_sq, P.P, PG, cfg->policy_lr, st->pol_steps,
+                                       (st->pol_steps ? 1 : cfg->policy_step) + it, cfg, s, WT(c->wt_pol), &P))) return rc;
             if (autotune) {
                 // log-prob of a fresh sample under the UPDATED actor (mosac_continuous_action.py:467-468)
                 const float* eps_al = bt->eps_alpha + (long long)it * c->PG * rows * Ad;
@@ -1041,17 +1135,20 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                 hipLaunchKernelGGL(ac_alpha_step_kernel, dim3(c->PG), dim3(256), 0, s, st->log_alpha, st->log_alpha_exp_avg,
                                    st->log_alpha_exp_avg_sq, (const float*)c->logp_pi, rows, cfg->target_entropy,
                                    (const int*)st->pol_steps, (st->pol_steps ? 1 : cfg->policy_step) + it, cfg->alpha_lr,
-                                   cfg->beta1, cfg->beta2, (float)cfg->eps, out->alpha_loss);
+                                   cfg->beta1, cfg->beta2, (float)cfg->eps, out->alpha_loss,
+                                   it == iters - 1 ? st->q_steps : nullptr, it == iters - 1 ? st->pol_steps : nullptr, iters);
                 LAUNCH_CHECK("ac_alpha_step");
+                if (it == iters - 1) steps_advanced = true;
             }
-            if (algo == MORL_AC_TD3)
+            if (algo == MORL_AC_TD3 && !p_fused)
                 if ((rc = polyak(st->pol, st->pol_target, (long long)c->PG * P.P, cfg->tau, s))) return rc;
         }
     }
+    c->tq_b.x = c->xq_b;
     {
-        int32_t* qs = st->q_steps;
-        int32_t* ps = cfg->do_policy ? st->pol_steps : nullptr;
-        if (cfg->do_target) {
+        int32_t* qs = steps_advanced ? nullptr : st->q_steps;
+        int32_t* ps = (cfg->do_policy && !steps_advanced) ? st->pol_steps : nullptr;
+        if (cfg->do_target && !q_target_fused) {
             const long long n = (long long)c->QG * Q.P;
             hipLaunchKernelGGL(ac_polyak_advance_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, s, (const float*)st->q,
                                st->q_target, n, cfg->tau, 1.0f - cfg->tau, qs, ps, PG, iters);

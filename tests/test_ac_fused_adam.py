@@ -1,0 +1,72 @@
+"""The optimiser step inside the weight-gradient launch of the actor-critic updates (``gemm_wave4_grouped_tn_batched_adam_kernel``,
+``csrc/gemm_wave.h: AdamTile``) against the separate ``ac_adam_kernel`` / Polyak launches (``MORL_AC_ADAM_IN_DW=0``): same
+function per element, so parameters, Adam moments, target networks and losses must agree to the last bit over consecutive updates
+(the second update reads everything the first one's fused step wrote, the actor phase reads the shadow copy it scattered).
+The switch is read once per process, hence the sub-processes."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SNIPPET = r"""
+import dataclasses, hashlib, os, sys
+import numpy as np, torch as th
+ROOT = sys.argv[1]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "oracle")]
+from cases_ac import AC_CASES, make_inputs
+import test_ac_kernels_parity as T
+if sys.argv[2] == "gpu":
+    from morl_baselines_amd.native import load_library
+    lib, dev = load_library(), th.device("cuda:0")
+else:
+    import simlib
+    lib, dev = simlib.load_sim(), th.device("cpu")
+by_name = {c.name: c for c in AC_CASES}
+# more than 32 batch rows: the weight-gradient launch then runs on the split-K wave tiles, the form that can take the step
+cases = [dataclasses.replace(by_name["capql_small"], B=40), dataclasses.replace(by_name["mosac_small"], B=48),
+         dataclasses.replace(by_name["mosac_noauto_odd"], B=36, global_step=100),
+         dataclasses.replace(by_name["gpipd_nopolicy_plain"], B=40, n_updates=2),
+         # LayerNorm + Dropout critics (the reference's GPI-PD default): the gains / shifts are stepped by the launch's extra workgroup
+         dataclasses.replace(by_name["gpipd_small"], B=40), by_name["gpipd_support_per"]]
+if sys.argv[2] == "gpu":
+    cases += [by_name["capql_cheetah"], by_name["mosac_hopper"], by_name["gpipd_hopper"], dataclasses.replace(by_name["gpipd_nopolicy_plain"], B=128, arch=(256, 256), n_updates=2)]
+h = hashlib.sha256()
+for c in cases:
+    inp = make_inputs(c)
+    eng = T.build_engine(c, inp, lib, dev)
+    for it in range(2):
+        res = T.run_engine(c, inp, eng, ["critic_loss", "policy_loss"])
+        for k in sorted(res):
+            h.update(res[k].cpu().numpy().tobytes())
+        for name in ("q", "q_target", "q_exp_avg", "q_exp_avg_sq", "pol", "pol_exp_avg", "pol_exp_avg_sq", "pol_target", "log_alpha"):
+            t = getattr(eng, name, None)
+            if t is not None:
+                h.update(t.cpu().numpy().tobytes())
+print("AC_DIGEST", h.hexdigest())
+"""
+
+
+def _digest(mode, extra_env):
+    r = subprocess.run([sys.executable, "-c", _SNIPPET, ROOT, mode], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, **extra_env), cwd=ROOT)
+    assert r.returncode == 0 and "AC_DIGEST" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout.split("AC_DIGEST")[1].strip()
+
+
+def test_adam_inside_the_weight_gradient_launch_gives_the_bits_of_the_separate_launches():
+    assert _digest("sim", {}) == _digest("sim", {"MORL_AC_ADAM_IN_DW": "0"})
+
+
+def test_paired_policy_heads_give_the_bits_of_the_separate_launches():
+    """a ~ pi(s) sampled next to a' ~ pi(s') (``ac_head_fwd_pair_kernel``, critic input rows of its own for the actor phase) against
+    one head launch per phase (``MORL_AC_HEADS_PAIRED=0``)."""
+    assert _digest("sim", {}) == _digest("sim", {"MORL_AC_HEADS_PAIRED": "0", "MORL_AC_ADAM_IN_DW": "0"})
+
+
+@pytest.mark.gpu
+def test_adam_inside_the_weight_gradient_launch_gives_the_bits_of_the_separate_launches_on_the_gpu():
+    assert _digest("gpu", {}) == _digest("gpu", {"MORL_AC_ADAM_IN_DW": "0"})
+    assert _digest("gpu", {}) == _digest("gpu", {"MORL_AC_HEADS_PAIRED": "0"})
