@@ -54,6 +54,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     if os.environ.get("MORL_BF_PROF"):     # development build: phase stamps in the split-bf16 chain kernels (mlp_chain_bf.h)
         base.append("-DBF_PROF")
+    if os.environ.get("MORL_C16_PROF"):    # development build: phase stamps in the 16-row chain kernel (mlp_chain16.h)
+        base.append("-DC16_PROF")
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "morl_hip.h")]

@@ -120,8 +120,17 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
     const int kq = lane >> 4, j = lane & 15;
     const int col0 = wave * 64 + 4 * j;               // first of this lane's four physical output columns (wide steps)
 
+#ifdef C16_PROF
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tp_ = clock64();
+    const long long tstart_ = tp_;
+#define C16_T(q) { const long long t_ = clock64(); pt[q] += t_ - tp_; tp_ = t_; }
+#else
+#define C16_T(q)
+#endif
     C16BSet bx, by;
     const bool first_wide = p.step[0].N > 32;
+    bool narrow_ready = !first_wide;          // the narrow step's operand is already in bx
     C16Desc dcur = c16_desc_t<K4>(p.step[0], wave, j, kq, g);
     if (first_wide) c16_load_t<K4>(bx, dcur, 0);
     else c16_load_narrow(bx, p.step[0], wave, j, kq, g);
@@ -171,6 +180,7 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
         }
     }
     __syncthreads();
+    C16_T(0)
 
     bool do_copy = false;
     C2CopyDst cdst = c2_copy_dst(sAct, 0, 0, 0, 0, tid);
@@ -191,6 +201,18 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
                 for (int r = 0; r < 4; ++r) acc[ct][r] = 0.f;
             const int n_pairs = (K + 63) >> 6;          // K is treated as padded to a multiple of 64 with zero rows
             c16_load_t<K4>(by, dcur, CH_BK);
+            // what the epilogue needs from memory is requested before the contraction, not behind its barrier (phase stamps of a
+            // -DC16_PROF build: 1 500 of a step's 3 300 epilogue cycles were these two loads' latency)
+            float bias[4] = {0.f, 0.f, 0.f, 0.f};
+            if (st.bias != nullptr) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    if (col0 + ct < N) bias[ct] = st.bias[g * st.sW + col0 + ct];
+            }
+            // 16-bit words: same bytes per row as the 64-bit words of the 32 / 64-row tilings
+            const size_t bits_idx = ((size_t)g * st.sBits) * 4 + (size_t)(row0 >> 4) * CH_THREADS + tid;
+            unsigned int bits_w = 0u, bits_r = 0u;
+            if (st.bits_in != nullptr) bits_r = reinterpret_cast<const unsigned short*>(st.bits_in)[bits_idx];
             const float* pa = sAct + j * C2_LDK + 4 * kq;
             const C16Desc dnext = c16_desc_t<K4>(nxt, wave, j, kq, g);
             float4 an, ac = *reinterpret_cast<const float4*>(pa);
@@ -221,7 +243,8 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
     }
                 C16_GROUP(bx, 0, k0 + 16)
                 C16_GROUP(bx, 1, k0 + 32)
-                c16_load_t<K4>(bx, dx, more ? k0 + 64 : 0);
+                if (!more && feed_next && !nxt_wide) c16_load_narrow(bx, nxt, wave, j, kq, g);    // a narrow step's operand
+                else c16_load_t<K4>(bx, dx, more ? k0 + 64 : 0);
                 C16_GROUP(by, 0, k0 + 48)
                 // (the last group's look-ahead read stays inside the buffer: column k0 + 64 + 15 <= 271 -> see the kernel's array)
                 C16_GROUP(by, 1, k0 + 64)
@@ -231,20 +254,13 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
             }
             if (do_copy)
                 for (; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cdst, piece);
+            narrow_ready = feed_next && !nxt_wide;
             dcur = dnext;
+            C16_T(K > 64 ? 2 : 1)
             __syncthreads();     // every wave is past its last read of sAct
+            C16_T(3)
 
             // ---- epilogue ---------------------------------------------------------------------------------
-            float bias[4] = {0.f, 0.f, 0.f, 0.f};
-            if (st.bias != nullptr) {
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    if (col0 + ct < N) bias[ct] = st.bias[g * st.sW + col0 + ct];
-            }
-            unsigned int bits_w = 0u, bits_r = 0u;
-            // 16-bit words: same bytes per row as the 64-bit words of the 32 / 64-row tilings
-            const size_t bits_idx = ((size_t)g * st.sBits) * 4 + (size_t)(row0 >> 4) * CH_THREADS + tid;
-            if (st.bits_in != nullptr) bits_r = reinterpret_cast<const unsigned short*>(st.bits_in)[bits_idx];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v[4];
@@ -270,7 +286,12 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hacc[ct][r] = 0.f;
-            if (s > 0) c16_load_narrow(bx, st, wave, j, kq, g);
+            if (!narrow_ready) c16_load_narrow(bx, st, wave, j, kq, g);       // (a narrow step behind a narrow step)
+            narrow_ready = false;
+            // (the bias this step's output needs: requested before the contraction and its two barriers)
+            const int ct = wave >> 1;
+            const int n = 16 * ct + j;
+            const float bias = (st.bias != nullptr && n < N) ? st.bias[g * st.sW + n] : 0.f;
             if (do_copy)
                 for (int piece = 0; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cdst, piece);
             const float* pa = sAct + j * C2_LDK + wave * 64 + 4 * kq;
@@ -295,7 +316,6 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
             dcur = dnext;
             __syncthreads();
             // thread (wave, lane): column tile ct = wave >> 1, registers 2 * (wave & 1) + {0, 1} -- sums the four partials in wave order
-            const int ct = wave >> 1;
             float red[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -307,8 +327,6 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
                 red[q] = v;
             }
             if (feed_next) __syncthreads();
-            const int n = 16 * ct + j;
-            const float bias = (st.bias != nullptr && n < N) ? st.bias[g * st.sW + n] : 0.f;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int r = 2 * (wave & 1) + q;
@@ -325,11 +343,22 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
             if (feed_next)      // the next step reads K' = N <= 32 padded to 64 columns: columns [32, 64) must be zero too
                 for (int e = tid; e < 32 * C16_TM; e += CH_THREADS) sAct[(e >> 5) * C2_LDK + 32 + (e & 31)] = 0.f;
             do_copy = false;
+            C16_T(5)
         }
         __syncthreads();
+        C16_T(4)
     }
     if (do_copy)
         for (int piece = 0; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cdst, piece);
+    C16_T(6)
+#ifdef C16_PROF
+    if (p.prof != nullptr && lane == 0) {
+        long long* o = p.prof + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = pt[i];
+        o[7] = tp_ - tstart_;
+    }
+#endif
+#undef C16_T
 }
 
 // One workgroup per 16-row tile; tiles are numbered chain after chain, network after network.
@@ -339,7 +368,7 @@ struct Chain16Multi {
     int n;
 };
 
-static __global__ __launch_bounds__(CH_THREADS, 4) void mlp_chain16_kernel(Chain16Multi m) {
+static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain16_kernel(Chain16Multi m) {
     // (+16: the last group's look-ahead operand read of the last row runs up to 12 floats past the tile; the values are unused)
     __shared__ __attribute__((aligned(16))) float sAct[C16_TM * C2_LDK + 16];
     const int b = (int)blockIdx.x;

@@ -313,8 +313,28 @@ static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
                 if (chains[q].step[l].N > 32 && !chains[q].step[l].Bmat) return fail(MORL_ERR_STATE, "ac_chain_launch: 16-row chain without a K-major operand");
         Chain16Multi m16{};
         const int tiles = chain16_fill(m16, chains, n);
+#ifdef C16_PROF
+        // development build (-DC16_PROF): per-wave phase cycle sums of the launches of two updates, printed once
+        static long long* prof_dev = nullptr;
+        static int launch_no = 0;
+        if (!prof_dev) hipMalloc(&prof_dev, (size_t)1024 * 4 * 8 * 8);
+        for (int q = 0; q < n; ++q) m16.p[q].prof = prof_dev;
+#endif
         hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
         LAUNCH_CHECK("ac_chain16");
+#ifdef C16_PROF
+        if (++launch_no > 600 && launch_no <= 612 && tiles <= 1024) {
+            hipStreamSynchronize(s);
+            std::vector<long long> h((size_t)tiles * 4 * 8);
+            hipMemcpy(h.data(), prof_dev, h.size() * 8, hipMemcpyDeviceToHost);
+            double a[8] = {0};
+            for (size_t w = 0; w < (size_t)tiles * 4; ++w)
+                for (int i = 0; i < 8; ++i) a[i] += (double)h[w * 8 + i] / (tiles * 4);
+            fprintf(stderr, "C16_PROF launch %d: %d tiles, steps %d; clock64 cycles per wave: input %.0f | first-step mfma %.0f | wide mfma %.0f | "
+                            "barrier %.0f | epilogue+sync %.0f | narrow %.0f | final copy %.0f | total %.0f\n",
+                    launch_no, tiles, chains[0].n_steps, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+        }
+#endif
         return MORL_OK;
     }
     Chain2Multi m{};

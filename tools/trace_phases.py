@@ -1,17 +1,21 @@
-"""Per-position kernel durations of the Envelope step from a rocprofv3 kernel trace: groups the morl:: kernels by their position
-inside one step (the step_prologue launch opens a step) and prints the mean duration of each position over the steps seen."""
+"""Per-position kernel durations of one update from a rocprofv3 kernel trace: groups the morl:: kernels by their position inside
+one step (the launch whose name contains argv[2] opens a step: default step_prologue, the Envelope step; ac_inputs for the
+actor-critic updates) and prints the mean duration of each position over the steps seen."""
 import csv, sys, collections
+OPENER = sys.argv[2] if len(sys.argv) > 2 else "step_prologue"
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 steps, cur = [], None
 for r in rows:
     n = r["Kernel_Name"]
     if "morl::" not in n: continue
-    if "step_prologue" in n:
+    if OPENER in n:
         cur = []; steps.append(cur)
     if cur is not None:
         cur.append((n.split("(")[0].replace("void ", "")[:40], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 steps = [s for s in steps[5:-1]]
+if not steps:
+    sys.exit(f"no launch named *{OPENER}* opens a step in this trace")
 L = collections.Counter(len(s) for s in steps).most_common(1)[0][0]
 steps = [s for s in steps if len(s) == L]
 print(f"{len(steps)} steps of {L} launches")
