@@ -32,7 +32,7 @@ prof-w32)    prof w32 python $R/bench.py --weights 32 --steps 80 --warmup 10 $B 
 bench-ac)    for w in capql mosac gpipd gpi ens; do timeout 300 python bench_ac.py --workload $w > $O/bench_ac_$w.json 2>/dev/null; cut -c1-200 $O/bench_ac_$w.json; done
              timeout 300 python bench_ac.py --workload morld --pop 64 > $O/bench_ac_morld64.json 2>/dev/null ;;
 prof-ac)     OPENER=ac_inputs prof capql python $R/bench_ac.py --workload capql --steps 60 --no-cpu-baseline
-             OPENER=gpi_expand prof gpi python $R/bench_ac.py --workload gpi --steps 60 --no-cpu-baseline ;;
+             OPENER=ac_transpose_scatter prof gpi python $R/bench_ac.py --workload gpi --steps 60 --no-cpu-baseline ;;
 emu8)        timeout 300 python bench.py --gpus 1 --force-shard --emulate-world 8 $B > $O/bench_emulated_rank_of_8.json 2>/dev/null; cut -c1-300 $O/bench_emulated_rank_of_8.json ;;
 pmc)         (cd /tmp && export TMPDIR=/tmp && timeout 900 python $R/tools/pmc_summary.py $R/$O/pmc_summary.json > $R/$O/pmc_summary.txt 2>&1); tail -25 $O/pmc_summary.txt ;;
 fronts)      for n in 1024 16384 65536; do timeout 300 python bench_front.py --workload pareto --n $n > $O/bench_front_pareto_$n.json 2>/dev/null; done
