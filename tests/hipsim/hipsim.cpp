@@ -68,7 +68,10 @@ CollOut wave_collective(const CollIn& in, void (*fn)(const CollIn*, CollOut*, in
     return w.out[lane];
 }
 
+static long long g_launches = 0;      // kernel launches since the library was loaded (tests count the launches of an update)
+
 void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
+    ++g_launches;
     const int nthreads = (int)(block.x * block.y * block.z);
     cur_block_dim = block;
     cur_grid_dim = grid;
@@ -115,3 +118,6 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
     cur = nullptr;
 }
 }  // namespace hipsim
+
+// test hook: how many kernels the emulated library has launched so far (the product library has no such symbol)
+extern "C" long long hipsim_launch_count() { return hipsim::g_launches; }

@@ -1,0 +1,71 @@
+"""How many kernels one update launches -- counted by the emulator (``hipsim_launch_count``), for the fused and the separate forms.
+The bit-equality A/B tests (test_chain_tilings.py, test_ac_fused_adam.py) would also pass if a fusion silently stopped applying
+(both legs would then run the separate launches); this test fails instead.  The switches are read once per process."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SNIPPET = r"""
+import dataclasses, os, sys, ctypes
+import numpy as np, torch as th
+ROOT = sys.argv[1]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "oracle")]
+import simlib
+import morl_baselines_amd.ops as ops
+lib, dev = simlib.load_sim(), th.device("cpu")
+count = lib.lib.hipsim_launch_count
+count.restype = ctypes.c_longlong
+out = {}
+# one Envelope step as the agents issue it (no parity outputs), row tiles = whole transitions
+g = th.Generator().manual_seed(5)
+B, W, D, R, A, arch = 3, 32, 7, 3, 6, (256, 256)
+ctx = ops.QNetContext(D, R, A, arch, B, W, lib=lib)
+ctx.set_lazy_targets(2)
+P = ctx.n_params
+po = (th.randn(P, generator=g) * 0.1); pt = (th.randn(P, generator=g) * 0.1)
+obs, nobs = th.randn(B, D, generator=g), th.randn(B, D, generator=g)
+act = th.randint(0, A, (B,), generator=g).to(th.int32)
+rew, done = th.randn(B, R, generator=g), (th.rand(B, generator=g) < 0.2).float()
+w = th.rand(W, R, generator=g); w = w / w.sum(1, keepdim=True)
+grads, m, v = th.zeros(P), th.zeros(P), th.zeros(P)
+kw = dict(gamma=0.98, lr=3e-4, max_grad_norm=1.0, homotopy_lambda=0.3)
+ops.envelope_update(ctx, po, pt, grads, m, v, obs, nobs, act, rew, done, w, adam_step=1, **kw)
+c0 = count()
+ops.envelope_update(ctx, po, pt, grads, m, v, obs, nobs, act, rew, done, w, adam_step=2, **kw)
+out["envelope"] = count() - c0
+ctx.close()
+from cases_ac import AC_CASES, make_inputs
+import test_ac_kernels_parity as T
+by_name = {c.name: c for c in AC_CASES}
+for name, c in (("capql", dataclasses.replace(by_name["capql_small"], B=40)), ("mosac", dataclasses.replace(by_name["mosac_small"], B=48))):
+    inp = make_inputs(c)
+    eng = T.build_engine(c, inp, lib, dev)
+    T.run_engine(c, inp, eng, ["critic_loss", "policy_loss"])
+    c0 = count()
+    T.run_engine(c, inp, eng, ["critic_loss", "policy_loss"])
+    out[name] = count() - c0
+print("LAUNCHES", out)
+"""
+
+
+def _launches(extra_env):
+    r = subprocess.run([sys.executable, "-c", _SNIPPET, ROOT], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, MORL_BF_MIN_ROWS="0", MORL_LAZY_MIN_ROWS="0", **extra_env), cwd=ROOT)
+    assert r.returncode == 0 and "LAUNCHES" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    return eval(r.stdout.split("LAUNCHES")[1].strip())
+
+
+def test_launches_per_update_with_and_without_the_fused_stages():
+    fused = _launches({})
+    # ops.envelope_update (lazy targets, split-bf16 chains, row tiles = whole transitions): the seven launches of DESIGN.md section 4 --
+    # weight shadows / splits, forward + arg-max, target rows, backward + TD stage, weight gradients, slab reduction, clip + Adam --
+    # and one more: called directly (no sampling launch in front that also prepares the weights) the entry prepares them itself
+    assert fused == {"envelope": 8, "capql": 13, "mosac": 26}, fused
+    assert _launches({"MORL_ARGMAX_IN_CHAIN": "0"})["envelope"] == fused["envelope"] + 1
+    assert _launches({"MORL_TD_IN_CHAIN": "0"})["envelope"] == fused["envelope"] + 1
+    # CAPQL: two Adam launches and the Polyak / counter launch fold into the two weight-gradient launches
+    sep = _launches({"MORL_AC_ADAM_IN_DW": "0"})
+    assert sep["capql"] == fused["capql"] + 3 and sep["mosac"] > fused["mosac"], sep
+    assert _launches({"MORL_AC_HEADS_PAIRED": "0"})["capql"] == fused["capql"] + 1
