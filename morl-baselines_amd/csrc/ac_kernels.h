@@ -546,10 +546,9 @@ struct HeadBwdArgs {
     int rows, Ad, G, algo;
 };
 
-__global__ __launch_bounds__(256) void ac_head_bwd_kernel(HeadBwdArgs a) {
-    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
-    if (e >= a.G * a.rows) return;
-    const int g = e / a.rows, row = e % a.rows;
+// one (learner, batch row): writes the row of dhead; `v` (optional) also receives its first 16 entries -- the input row of the
+// actor's backward chain when the chain's input stage calls this itself (HeadBwdHook)
+__device__ __forceinline__ void ac_head_bwd_row(const HeadBwdArgs& a, int g, int row, float* v) {
     const long long o = ((long long)g * a.rows + row) * a.Ad;
     const float* __restrict__ hd = a.head + (long long)g * a.head_gstride + (long long)row * a.ldh;
     float* __restrict__ dh = a.dhead + (long long)g * a.head_gstride + (long long)row * a.ldh;
@@ -565,10 +564,16 @@ __global__ __launch_bounds__(256) void ac_head_bwd_kernel(HeadBwdArgs a) {
         const float y = a.save_y[o + j];
         const float one_m = 1.f - y * y;
         const float sc = a.scale[j];
-        if (a.algo == MORL_AC_TD3) { dh[j] = dA * sc * one_m; continue; }
+        if (a.algo == MORL_AC_TD3) {
+            const float d = dA * sc * one_m;
+            dh[j] = d;
+            if (v != nullptr && j < 16) v[j] = d;
+            continue;
+        }
         const float sd = a.save_std[o + j], ep = a.eps[o + j];
         const float du = dA * sc * one_m + dlogp * (2.f * y * sc * one_m) / (sc * one_m + 1e-6f);
         dh[j] = du;                                         // the Gaussian term's two paths to the mean cancel exactly
+        if (v != nullptr && j < 16) v[j] = du;
         const float t = ep * sd;                            // x - mean
         const float var = sd * sd;
         const float dstd = du * ep + dlogp * (-t * ep / var + (t * t) / (var * sd) - 1.f / sd);
@@ -578,8 +583,15 @@ __global__ __launch_bounds__(256) void ac_head_bwd_kernel(HeadBwdArgs a) {
         if (a.algo == MORL_AC_CAPQL) draw = (raw >= -20.f && raw <= 2.f) ? dls : 0.f;
         else { const float th_ = tanhf(raw); draw = dls * 3.5f * (1.f - th_ * th_); }
         dh[a.Ad + j] = draw;
+        if (v != nullptr && a.Ad + j < 16) v[a.Ad + j] = draw;
     }
     for (int j = ((a.algo == MORL_AC_TD3) ? a.Ad : 2 * a.Ad); j < a.ldh; ++j) dh[j] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void ac_head_bwd_kernel(HeadBwdArgs a) {
+    const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (e >= a.G * a.rows) return;
+    ac_head_bwd_row(a, e / a.rows, e % a.rows, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

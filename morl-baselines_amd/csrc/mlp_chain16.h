@@ -111,9 +111,16 @@ __device__ __forceinline__ void c16_load_narrow(C16BSet& s, const ChainStep& st,
 
 __device__ __forceinline__ float c16_elem(const float4& v, int t) { return t == 0 ? v.x : t == 1 ? v.y : t == 2 ? v.z : v.w; }
 
+// Input rows computed by the chain's own input stage (ChainArgs::in_mode == 4) instead of read from a matrix an extra launch wrote:
+// hook(g, row, v) fills the row's first 16 entries (and keeps whatever copy other kernels need).  The default has none.
+struct C16NoHook {
+    static constexpr bool active = false;
+    __device__ __forceinline__ void operator()(int, int, float (&)[16]) const {}
+};
+
 // one 16-row tile (rows [row0, row0 + 16) of network g) through the whole chain; K4: the weight layout of ChainArgs::fast == 1
-template <bool K4>
-__device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, float* sAct, int g) {
+template <bool K4, class Hook = C16NoHook>
+__device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, float* sAct, int g, const Hook& hook = Hook()) {
     constexpr int N_PIECES = 4;                       // 16 rows x 64 quads / 256 threads
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_id();
     const int n_rows = p.rows_dev ? min(p.rows, *p.rows_dev) : p.rows;        // (device-side count: in_mode 3)
@@ -155,6 +162,16 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
                                               : p.src + (p.nb > 1 ? (g / p.src_div) * p.sSrc : 0) + (size_t)row * p.ldsrc;
         const float* src_w = p.weights + (size_t)w * p.R;
         const int kb = q * 16;
+        bool hooked = false;
+        float hv[16];
+        if constexpr (Hook::active) {
+            if (p.in_mode == 4) {                      // (K0 <= 16: the row's entries are the first column block's)
+                hooked = true;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) hv[u] = 0.f;
+                if (q == 0 && row_ok) hook(g, row, hv);
+            }
+        }
         if (kb < K0pad) {
             float v[16];
 #pragma unroll
@@ -163,6 +180,7 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
                 float x = 0.f;
                 if (row_ok && k < K0) {
                     if (cat_mode) x = (k < p.D) ? src_a[k] : src_w[k - p.D];
+                    else if (hooked) x = (q == 0) ? hv[u] : 0.f;
                     else x = src_a[k];
                 }
                 v[u] = x;

@@ -292,7 +292,24 @@ static bool ac_rows_take_chain16(long long rows_x_nets) {
     static const long long limit = [] { const char* e = getenv("MORL_CHAIN16_MAX_ROWS"); return e ? atoll(e) : AC_C16_MAX_ROWS; }();   // (tuning)
     return small_rows && rows_x_nets <= limit;
 }
-static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
+// The actor's backward chain with the policy head's backward pass in its input stage (ChainArgs::in_mode == 4): each tile computes
+// its 16 rows of dLoss/d(head pre-activations) itself (ac_head_bwd_row: the function the separate ac_head_bwd_kernel runs) -- one
+// launch and one first-touch round trip fewer per actor step.
+struct HeadBwdHook {
+    static constexpr bool active = true;
+    HeadBwdArgs a;
+    __device__ __forceinline__ void operator()(int g, int row, float (&v)[16]) const { ac_head_bwd_row(a, g, row, v); }
+};
+static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain16_headbwd_kernel(Chain16Multi m, HeadBwdArgs hb) {
+    __shared__ __attribute__((aligned(16))) float sAct[C16_TM * C2_LDK + 16];
+    const ChainArgs& p = m.p[0];                                 // (one chain: the actor's backward pass)
+    int lt = (int)blockIdx.x, g = 0;
+    const int tpn = (p.rows + C16_TM - 1) / C16_TM;              // tiles per network
+    if (p.nb > 1) { g = lt / tpn; lt -= g * tpn; }
+    mlp_chain16_body<false, HeadBwdHook>(p, lt * C16_TM, sAct, g, HeadBwdHook{hb});
+}
+
+static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s, const HeadBwdArgs* head_bwd = nullptr) {
     static const int num_cus = [] {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -320,7 +337,8 @@ static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
         if (!prof_dev) hipMalloc(&prof_dev, (size_t)1024 * 4 * 8 * 8);
         for (int q = 0; q < n; ++q) m16.p[q].prof = prof_dev;
 #endif
-        hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
+        if (head_bwd) hipLaunchKernelGGL(mlp_chain16_headbwd_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16, *head_bwd);
+        else hipLaunchKernelGGL(mlp_chain16_kernel, dim3(tiles), dim3(CH_THREADS), 0, s, m16);
         LAUNCH_CHECK("ac_chain16");
 #ifdef C16_PROF
         if (++launch_no > 600 && launch_no <= 612 && tiles <= 1024) {
@@ -337,6 +355,7 @@ static int ac_chain_launch(const ChainArgs* chains, int n, hipStream_t s) {
 #endif
         return MORL_OK;
     }
+    if (head_bwd) return fail(MORL_ERR_STATE, "ac_chain_launch: the head's backward pass rides on the 16-row tiles only");
     Chain2Multi m{};
     m.n = n;
     int units = 0;
@@ -509,8 +528,20 @@ static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape&
 // and small populations), where a workgroup's tile holds finished gradient entries; otherwise `grads` is written as usual
 static int mlp_backward(const Mlp& m, const float* params, int64_t pstride, Tape& t, int rows, int x_div,
                         bool dropped, float* grads, bool need_dx, hipStream_t s, int64_t grad_stride = -1,
-                        const float* wt = nullptr, const AdamFuse* fuse = nullptr, bool* fused = nullptr) {
+                        const float* wt = nullptr, const AdamFuse* fuse = nullptr, bool* fused = nullptr,
+                        const HeadBwdArgs* head_bwd = nullptr) {
     if (fused) *fused = false;
+    // head_bwd: t.g[L-1] is still to be computed from the critics' dLoss/d(action) (the actor's head).  In the chain's input stage
+    // when the pass runs as a 16-row chain and a row's entries fit one column block; by its own launch otherwise
+    static const bool head_in_chain = [] { const char* e = getenv("MORL_AC_HEADBWD_IN_CHAIN"); return e ? atoi(e) != 0 : true; }();   // (A/B)
+    bool head_pending = head_bwd != nullptr;
+    const bool head_rides = head_pending && head_in_chain && t.bits_valid && chain_shape_ok(m) && !(dropped && m.drop > 0.f) &&
+                            m.dims[m.L] <= 16 && m.L - 1 >= 1 && ac_rows_take_chain16((long long)rows * t.G);
+    if (head_pending && !head_rides) {
+        hipLaunchKernelGGL(ac_head_bwd_kernel, dim3((head_bwd->G * rows + 255) / 256), dim3(256), 0, s, *head_bwd);
+        LAUNCH_CHECK("ac_head_bwd");
+        head_pending = false;
+    }
     const long long cap = t.cap;
     if (grad_stride < 0) grad_stride = m.P;      // floats between the gradient blocks of consecutive nets
     // dX chain in one launch when the forward was the layer-fused one (its ReLU sign bits are in the tape): g[L-1] -> ... ->
@@ -523,7 +554,7 @@ static int mlp_backward(const Mlp& m, const float* params, int64_t pstride, Tape
         if (m.L - 1 >= last_l) {
             ChainArgs a{};
             a.rows = rows;
-            a.in_mode = 1;
+            a.in_mode = head_pending ? 4 : 1;
             a.src = t.g[m.L - 1]; a.ldsrc = m.ld[m.L]; a.K0 = m.dims[m.L];
             a.nb = t.G; a.sSrc = cap * m.ld[m.L]; a.src_div = 1;
             a.fast = 0;
@@ -544,11 +575,13 @@ static int mlp_backward(const Mlp& m, const float* params, int64_t pstride, Tape
                 st.sOut = cap * m.ld[l];
             }
             a.n_steps = k;
-            int rc = ac_chain_launch(&a, 1, s);
+            int rc = ac_chain_launch(&a, 1, s, head_pending ? head_bwd : nullptr);
             if (rc) return rc;
+            head_pending = false;
             chain_down_to = last_l;
         }
     }
+    if (head_pending) return fail(MORL_ERR_STATE, "mlp_backward: the head's backward pass was left to a chain that did not run");
     for (int l = m.L - 1; l >= 0; --l) {
         if (l == 0 && !need_dx) break;
         if (chain_down_to >= 0 && l >= chain_down_to) continue;
@@ -1111,6 +1144,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                 LAUNCH_CHECK("ac_actor_loss");
             }
             if ((rc = mlp_backward(Q, st->q, Q.P, c->tq_b, rows, nq, Q.drop > 0.f, nullptr, true, s, -1, WT(c->wt_q)))) return rc;
+            HeadBwdArgs hb{};
             {
                 HeadBwdArgs a{};
                 a.dx_q = c->tq_b.dx; a.dxq_gstride = (long long)c->cap * Q.ld[0];
@@ -1120,8 +1154,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                 a.scale = st->action_scale; a.log_alpha = la; a.alpha_const = cfg->alpha;
                 a.dhead = c->tp_b.g[P.L - 1];
                 a.rows = rows; a.Ad = Ad; a.G = c->PG; a.algo = algo;
-                hipLaunchKernelGGL(ac_head_bwd_kernel, dim3((c->PG * rows + 255) / 256), dim3(256), 0, s, a);
-                LAUNCH_CHECK("ac_head_bwd");
+                hb = a;
             }
             bool p_fused = false;
             {
@@ -1135,7 +1168,7 @@ extern "C" int morl_ac_update(morl_ac_ctx* c, const morl_ac_state* st, const mor
                 const bool last_reader = (it == iters - 1) && !autotune;       // (with a learnt alpha: its step kernel below)
                 if (last_reader) { f.adv_q = st->q_steps; f.adv_p = st->pol_steps; f.adv_p_by = iters; }
                 if ((rc = mlp_backward(P, st->pol, P.P, c->tp_b, rows, 1, false, c->gp, false, s, -1, WT(c->wt_pol),
-                                       offer_p ? &f : nullptr, &p_fused))) return rc;
+                                       offer_p ? &f : nullptr, &p_fused, &hb))) return rc;
                 if (p_fused && last_reader) steps_advanced = true;
             }
             if (out->pol_grads)

@@ -66,7 +66,14 @@ def test_paired_policy_heads_give_the_bits_of_the_separate_launches():
     assert _digest("sim", {}) == _digest("sim", {"MORL_AC_HEADS_PAIRED": "0", "MORL_AC_ADAM_IN_DW": "0"})
 
 
+def test_head_backward_inside_the_actor_chain_gives_the_bits_of_the_separate_launch():
+    """dLoss/d(head pre-activations) computed by the input stage of the actor's backward chain (``mlp_chain16_headbwd_kernel``,
+    the same ``ac_head_bwd_row``) against ``ac_head_bwd_kernel`` as its own launch (``MORL_AC_HEADBWD_IN_CHAIN=0``)."""
+    assert _digest("sim", {}) == _digest("sim", {"MORL_AC_HEADBWD_IN_CHAIN": "0"})
+
+
 @pytest.mark.gpu
 def test_adam_inside_the_weight_gradient_launch_gives_the_bits_of_the_separate_launches_on_the_gpu():
     assert _digest("gpu", {}) == _digest("gpu", {"MORL_AC_ADAM_IN_DW": "0"})
     assert _digest("gpu", {}) == _digest("gpu", {"MORL_AC_HEADS_PAIRED": "0"})
+    assert _digest("gpu", {}) == _digest("gpu", {"MORL_AC_HEADBWD_IN_CHAIN": "0"})

@@ -62,10 +62,11 @@ def test_launches_per_update_with_and_without_the_fused_stages():
     # ops.envelope_update (lazy targets, split-bf16 chains, row tiles = whole transitions): the seven launches of DESIGN.md section 4 --
     # weight shadows / splits, forward + arg-max, target rows, backward + TD stage, weight gradients, slab reduction, clip + Adam --
     # and one more: called directly (no sampling launch in front that also prepares the weights) the entry prepares them itself
-    assert fused == {"envelope": 8, "capql": 13, "mosac": 26}, fused
+    assert fused == {"envelope": 8, "capql": 12, "mosac": 24}, fused
     assert _launches({"MORL_ARGMAX_IN_CHAIN": "0"})["envelope"] == fused["envelope"] + 1
     assert _launches({"MORL_TD_IN_CHAIN": "0"})["envelope"] == fused["envelope"] + 1
     # CAPQL: two Adam launches and the Polyak / counter launch fold into the two weight-gradient launches
     sep = _launches({"MORL_AC_ADAM_IN_DW": "0"})
     assert sep["capql"] == fused["capql"] + 3 and sep["mosac"] > fused["mosac"], sep
     assert _launches({"MORL_AC_HEADS_PAIRED": "0"})["capql"] == fused["capql"] + 1
+    assert _launches({"MORL_AC_HEADBWD_IN_CHAIN": "0"})["capql"] == fused["capql"] + 1
