@@ -33,7 +33,47 @@ cases = [dataclasses.replace(by_name["capql_small"], B=40), dataclasses.replace(
          dataclasses.replace(by_name["gpipd_small"], B=40), by_name["gpipd_support_per"]]
 if sys.argv[2] == "gpu":
     cases += [by_name["capql_cheetah"], by_name["mosac_hopper"], by_name["gpipd_hopper"], dataclasses.replace(by_name["gpipd_nopolicy_plain"], B=128, arch=(256, 256), n_updates=2)]
+# the head's backward pass rides in the chain up to 16 head outputs (8 action dimensions): the boundary and the first case beyond it
+cases += [dataclasses.replace(by_name["capql_small"], Ad=8, B=40, seed=41), dataclasses.replace(by_name["capql_small"], Ad=9, B=40, seed=42)]
 h = hashlib.sha256()
+# a small population (three learners in one call, more than 32 rows each): learner-indexed step counters, bias corrections and
+# counter advance of the fused optimiser step
+c = dataclasses.replace(by_name["capql_small"], B=40)
+inps = [make_inputs(dataclasses.replace(c, seed=c.seed + 100 * k)) for k in range(3)]
+import functools
+_plain = T.ACEngine
+T.ACEngine = functools.partial(_plain, device_steps=True)       # device-resident Adam step counters, as the MORL/D population keeps them
+pop = T.build_engine(c, inps, lib, dev)
+T.ACEngine = _plain
+assert pop.q_steps is not None
+stack = lambda key: np.stack([np.asarray(i[key]) for i in inps])
+for it in range(2):
+    cfg = pop.make_cfg(gamma=c.gamma, tau=c.tau, alpha=c.alpha, q_lr=c.lr, policy_lr=c.lr, q_step=c.step, policy_step=c.step)
+    res = pop.update(cfg, obs=stack("obs"), actions=stack("actions"), rewards=stack("rewards"), next_obs=stack("next_obs"),
+                     dones=stack("dones"), w=stack("w"), eps_next=stack("eps_next"), eps_pi=np.stack([i["eps_pi"][0] for i in inps]))
+    for k in sorted(res):
+        h.update(res[k].cpu().numpy().tobytes())
+    for name in ("q", "q_target", "q_exp_avg", "q_exp_avg_sq", "pol", "pol_exp_avg", "pol_exp_avg_sq", "q_steps", "pol_steps"):
+        h.update(getattr(pop, name).cpu().numpy().tobytes())
+    assert pop.q_steps.cpu().tolist() == [it + 1] * 3 and pop.pol_steps.cpu().tolist() == [it + 1] * 3
+# ... and a MOSAC population with a learnt entropy coefficient: there the alpha step is the last reader of the counters
+c = dataclasses.replace(by_name["mosac_small"], B=48)
+inps = [make_inputs(dataclasses.replace(c, seed=c.seed + 100 * k)) for k in range(2)]
+T.ACEngine = functools.partial(_plain, device_steps=True)
+pop = T.build_engine(c, inps, lib, dev)
+T.ACEngine = _plain
+for it in range(2):
+    cfg = pop.make_cfg(gamma=c.gamma, tau=c.tau, alpha=c.alpha, q_lr=c.q_lr, policy_lr=c.lr, alpha_lr=c.q_lr, q_step=c.step,
+                       policy_step=c.step, do_policy=True, policy_iters=c.policy_freq, autotune=c.autotune, target_entropy=-float(c.Ad))
+    res = pop.update(cfg, obs=stack("obs"), actions=stack("actions"), rewards=stack("rewards"), next_obs=stack("next_obs"),
+                     dones=stack("dones"), w=stack("weights"), eps_next=stack("eps_next"),
+                     eps_pi=np.stack([np.stack([i["eps_pi"][k] for i in inps]) for k in range(c.policy_freq)]),
+                     eps_alpha=np.stack([np.stack([i["eps_alpha"][k] for i in inps]) for k in range(c.policy_freq)]))
+    for k in sorted(res):
+        h.update(res[k].cpu().numpy().tobytes())
+    for name in ("q", "q_target", "q_exp_avg_sq", "pol", "pol_exp_avg", "log_alpha", "q_steps", "pol_steps"):
+        h.update(getattr(pop, name).cpu().numpy().tobytes())
+    assert pop.q_steps.cpu().tolist() == [it + 1] * 2 and pop.pol_steps.cpu().tolist() == [(it + 1) * c.policy_freq] * 2, (pop.q_steps, pop.pol_steps)
 for c in cases:
     inp = make_inputs(c)
     eng = T.build_engine(c, inp, lib, dev)
