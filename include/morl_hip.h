@@ -31,7 +31,7 @@ extern "C" {
 
 #define MORL_MAX_LAYERS 8   /* linear layers per network */
 #define MORL_MAX_OBJ 8      /* reward dimension R */
-#define MORL_ABI_VERSION 12
+#define MORL_ABI_VERSION 13
 
 typedef enum morl_status {
     MORL_OK = 0,
@@ -244,6 +244,45 @@ int morl_envelope_update(morl_ctx* ctx, float* params_online, const float* param
                          float* exp_avg, float* exp_avg_sq, const float* obs, const float* next_obs,
                          const int32_t* actions, const float* rewards, const float* dones, const float* weights,
                          int B, int W, const morl_update_cfg* cfg, const morl_update_out* out, void* stream);
+
+/* ---- Envelope.update's whole loop in ONE library entry: `for g in range(self.gradient_updates)` of envelope.py:269-334 -----
+ * Everything of a step that does not change from one call to the next lives in a block the caller fills once and keeps
+ * (device pointers of the agent's persistent buffers, the replay store, the batch tensors the gather writes and the update reads);
+ * a call then only carries what the host draws per iteration -- in the reference's order per generator: the B unit uniforms of
+ * PrioritizedReplayBuffer.sample (prioritized_buffer.py:40; `u01` [n][B] doubles) or the B indices of ReplayBuffer.sample
+ * (buffer.py:82; `idx_in` [n][B] int64) and the W x R sampled weights (envelope.py:279-283; `w_src` [n][W*R] floats), all
+ * DEVICE-VISIBLE addresses (device memory or mapped pinned host memory, read in place by the gather launch) -- plus the index of
+ * the first Adam step and the current homotopy weight.  Iteration k = morl_envelope_prepare (tree descent / index read + record
+ * gather + the w copy + the step's weight copies) then morl_envelope_update with adam_step0 + k; with a tree, iteration k + 1
+ * samples through the priorities iteration k wrote (envelope.py:329-334), exactly as n separate rounds would.
+ * loss_out [n], grad_norm_out [n] or NULL, priority_out [B] (|td . w| of the LAST iteration; needed when io->tree != NULL). */
+typedef struct morl_step_io {
+    float* params_online;        /* flat [P], updated in place */
+    const float* params_target;  /* flat [P] */
+    float* grads;                /* flat [P] */
+    float* exp_avg;              /* flat [P] */
+    float* exp_avg_sq;           /* flat [P] */
+    double* tree;                /* PER sum tree (levels concatenated root-first), or NULL: uniform replay */
+    double* running_max;         /* [1] (with tree) */
+    const float* records;        /* [capacity][record_floats] AoS replay records: obs | next_obs | reward | done | action */
+    int64_t capacity;
+    float* obs;                  /* [B][D]   batch tensors: written by the gather, read by the update */
+    float* next_obs;             /* [B][D] */
+    float* rewards;              /* [B][R] */
+    float* dones;                /* [B] */
+    int32_t* actions;            /* [B] */
+    int64_t* idx;                /* [B] sampled indices (output) */
+    float* weights;              /* [W][R] the step's sampled weights (device copy of w_src's current slice) */
+    int32_t n_levels;            /* of the tree */
+    int32_t record_floats;
+    int32_t D, R;
+    int32_t B, W;
+    morl_update_cfg cfg;         /* gamma, max_grad_norm, lr, beta1, beta2, eps, envelope, per_alpha; the per-iteration fields
+                                  * (adam_step, homotopy_lambda, apply_step, per_* pointers, rows_total) are set by the entry */
+} morl_step_io;
+int morl_envelope_update_n(morl_ctx* ctx, const morl_step_io* io, int n, const double* u01, const int64_t* idx_in,
+                           const float* w_src, int adam_step0, float homotopy_lambda, float* loss_out, float* grad_norm_out,
+                           float* priority_out, void* stream);
 
 /* ---- weight-axis sharding of the same step (no counterpart in the reference, which is single-device) ------------
  * A rank that owns the TD rows of weights [i_offset, i_offset + W_local) of W_total:

@@ -285,6 +285,14 @@ class ACEngine:
         n = len(items)
         u01 = np.ascontiguousarray(u01, dtype=np.float64).reshape(n, -1)
         B = u01.shape[1]
+        # the library gathers records straight into the batch tensors: the buffer must live where the engine does and hold what
+        # this engine's batches hold (a mismatch would be out-of-bounds gather writes, not an exception)
+        self.lib.check_device(buffer.tree_dev, buffer.running_max, buffer.records)
+        if buffer._Ad != self.Ad or buffer._int_actions or buffer._D != self.D or buffer._R != self.R:
+            raise ValueError(f"update_n_per: the buffer holds (obs {buffer._D}, reward {buffer._R}, "
+                             f"{'int' if buffer._int_actions else 'float'} actions {buffer._Ad}), the engine "
+                             f"(obs {self.D}, reward {self.R}, float actions {self.Ad})")
+        copies = 2 if doubled else 1
         buffer.flush()
         bs, cs, os_ = (ACBatch * n)(), (ACCfg * n)(), (ACOut * n)()
         results, keep = [], []
@@ -292,6 +300,8 @@ class ACEngine:
             it = dict(it)
             cfg = it.pop("cfg")
             obs = self._f32(it.pop("obs"), "obs")
+            if obs.numel() != copies * B * self.D:
+                raise ValueError(f"update_n_per: update {k} has {obs.numel() // self.D} rows, {copies} x {B} sampled transitions expected")
             b, o, res, kp = self._pack(cfg, obs, self.pop, it.get("actions"), it.get("rewards"), it.get("next_obs"), it.get("dones"),
                                        it.get("w"), it.get("eps_next"), it.get("eps_pi"), it.get("eps_alpha"), it.get("drop_masks"),
                                        it.get("want", want))

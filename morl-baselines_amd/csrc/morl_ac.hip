@@ -1931,6 +1931,10 @@ extern "C" int morl_ac_update_n_per(morl_ac_ctx* c, const morl_ac_state* st, int
     if (!per->tree || !per->running_max || !per->u01 || !per->records || !per->idx) return fail(MORL_ERR_ARG, "NULL field of morl_gpi_per");
     const int B = per->B;
     if (B < 1) return fail(MORL_ERR_ARG, "B = %d", B);
+    // (refused HERE, before the first launch: morl_sumtree_update_clamped would only notice after iteration 0's gather and
+    // optimiser step were enqueued, and leave the caller with a half-taken loop)
+    if (B > morl_host::TREE_UPDATE_MAX) return fail(MORL_ERR_ARG, "prioritised loop: B=%d > %d entries of one tree-update launch (run one sample / update / "
+                                  "update_priorities round per iteration instead)", B, morl_host::TREE_UPDATE_MAX);
     const int copies = per->doubled ? 2 : 1;
     for (int k = 0; k < n; ++k) {
         const morl_ac_batch& b = batches[k];
@@ -1987,6 +1991,10 @@ extern "C" int morl_gpi_update_n_per(morl_gpi_ctx* c, float* q, const float* q_t
     if (!per->tree || !per->running_max || !per->u01 || !per->records || !per->idx) return fail(MORL_ERR_ARG, "NULL field of morl_gpi_per");
     const int B = per->B;
     if (B < 1) return fail(MORL_ERR_ARG, "B = %d", B);
+    // (refused HERE, before the first launch: morl_sumtree_update_clamped would only notice after iteration 0's gather and
+    // optimiser step were enqueued, and leave the caller with a half-taken loop)
+    if (B > morl_host::TREE_UPDATE_MAX) return fail(MORL_ERR_ARG, "prioritised loop: B=%d > %d entries of one tree-update launch (run one sample / update / "
+                                  "update_priorities round per iteration instead)", B, morl_host::TREE_UPDATE_MAX);
     const int copies = per->doubled ? 2 : 1;
     for (int k = 0; k < n; ++k) {
         const morl_gpi_batch& b = batches[k];

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(SampleGatherArgs sg,
 }
 
 }  // namespace morl
+static_assert(ST_MAX_B == morl_host::TREE_UPDATE_MAX, "morl_host.h's TREE_UPDATE_MAX mirrors ST_MAX_B");
 
 // ------------------------------------------------------------------------------------------------
 // context
@@ -179,6 +180,7 @@ struct morl_ctx {
     std::vector<hipEvent_t> ev_start, ev_stop;
     std::vector<int> ev_kind;            // MORL_TIMED_* of each recorded launch
     int last_B = 0, last_WI = 0;         // shape of the last training forward (morl_ctx_debug_hidden)
+    int last_step_W = 0;                 // weights of the last morl_envelope_update (what morl_envelope_prepare expects of the next)
     // lazy target evaluation (envelope_kernels.h, EnvelopeTdArgs::phase): scratch + the one-shot hand-over from
     // morl_envelope_update to update_core
     int lazy_targets = 1;                // MORL_LAZY_TARGETS=0 / morl_ctx_set_lazy_targets: 0 evaluate the whole target slab instead,
@@ -867,6 +869,8 @@ extern "C" int morl_ctx_set_fused(morl_ctx* c, int enable) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     c->use_fused = enable && c->fused_ok;
     c->fused_tm = (enable == 2) ? 64 : (enable == 3) ? 32 : 0;
+    c->bits_bf = false;              // (what the last step of the OTHER engine left behind says nothing about the next one)
+    c->dw_bf_last = false;
     return c->use_fused ? (enable >= 1 && enable <= 3 ? enable : 1) : 0;
 }
 
@@ -1029,7 +1033,8 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
     // what the step that follows will stream: on the bf16 matrix cores (a step of B x max_weights rows qualifies) the online
     // network's split weights + the target network's K-major copy; on the fp32 chains the K-major copies of both.  A guess about
     // the step's weight count that turns out wrong costs that step a launch of its own, nothing else (refresh_*).
-    if (bf_wanted(c, (long long)B * c->max_weights)) {
+    // (the step's weight count is not an argument here: the last step's, or the context's capacity before the first one)
+    if (bf_wanted(c, (long long)B * (c->last_step_W > 0 ? c->last_step_W : c->max_weights))) {
         const BfSplitArgs bf = bf_split_args(c, params_online);
         const int bf_blocks = (bf.unit_start[bf.n] * 64 + 255) / 256;
         hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks + sh.tiles + bf_blocks), dim3(256), 0, (hipStream_t)stream, a, blocks,
@@ -1309,6 +1314,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             c->bits_bf = false;
         } else {
             if ((rc = net_forward(c, params_online, c->x0m, rows, true, c->qm, c->ldq, s))) return rc;
+            c->bits_bf = false;     // (the per-layer engine: no sign bits at all -- and its weight gradients stay on the exact engines)
         }
     }
     // envelope arg-max + TD target + dLoss/dQ: envelope_td_kernel in front of the backward pass, one lane per TD row of a
@@ -1382,7 +1388,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     for (int l = 1; l < L; ++l) dw2_ok = dw2_ok && (n.dims[l] & 3) == 0;
     // the step runs on the bf16 matrix cores (its forward / backward chains did): the weight gradients too, as six split-bf16
     // products per fp32 product (dw_bf.h) -- when every problem fits one of that kernel's three layouts
-    bool dwb_ok = c->bits_bf && c->bf_mode == 1 && dw2_ok && c->dw_mode == 3;
+    bool dwb_ok = c->use_fused && c->bits_bf && c->bf_mode == 1 && dw2_ok && c->dw_mode == 3;
     static const bool dwb_env = [] { const char* e = getenv("MORL_DW_BF16"); return e ? atoi(e) != 0 : true; }();      // (A/B: 0 = dw_tiles.h)
     c->dw_bf_last = dwb_ok && dwb_env;
     if (dwb_ok && dwb_env) {
@@ -1677,6 +1683,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     static const morl_update_out no_out = {};
     if (!out) out = &no_out;
     c->lz_last = false;
+    c->last_step_W = W;
     timing_begin_step(c);
 
     // stage A: no-grad next-state slabs Qo, Qt [B][W][A][R] (B*W distinct rows instead of the reference's W^2*B)
@@ -1758,6 +1765,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
             if ((rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
         }
     } else {
+        c->bits_bf = false;          // (per-layer engine, the A/B oracle of the fused ones: nothing of it runs as split-bf16 products)
         if ((rc = build_input(next_obs, weights, c->x0n, B, W, D, R, c->ld0, 0, s))) return rc;
         if ((rc = net_forward(c, params_online, c->x0n, rows, false, c->qo, AR, s))) return rc;
         if ((rc = net_forward(c, params_target, c->x0n, rows, false, c->qt, AR, s))) return rc;
@@ -1787,6 +1795,56 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     // optional debug / parity outputs
     if (out->q_online_next) HIP_TRY(hipMemcpyAsync(out->q_online_next, c->qo, (size_t)rows * AR * 4, hipMemcpyDeviceToDevice, s));
     if (out->q_target_next) HIP_TRY(hipMemcpyAsync(out->q_target_next, c->qt, (size_t)rows * AR * 4, hipMemcpyDeviceToDevice, s));
+    return MORL_OK;
+}
+
+// Envelope.update's loop (envelope.py:269-334) in one entry: see include/morl_hip.h.  Everything that can be refused is refused
+// before the first launch of the first iteration.
+extern "C" int morl_envelope_update_n(morl_ctx* c, const morl_step_io* io, int n, const double* u01, const int64_t* idx_in,
+                                      const float* w_src, int adam_step0, float homotopy_lambda, float* loss_out, float* grad_norm_out,
+                                      float* priority_out, void* stream) {
+    if (!c || !io) return fail(MORL_ERR_ARG, "NULL argument");
+    if (n < 1) return fail(MORL_ERR_ARG, "n = %d updates", n);
+    int rc = check_bw(c, io->B, io->W);
+    if (rc) return rc;
+    if (!io->params_online || !io->params_target || !io->grads || !io->exp_avg || !io->exp_avg_sq || !io->records || !io->obs ||
+        !io->next_obs || !io->rewards || !io->dones || !io->actions || !io->idx || !io->weights)
+        return fail(MORL_ERR_ARG, "NULL field of morl_step_io");
+    if (!w_src || !loss_out) return fail(MORL_ERR_ARG, "w_src / loss_out is NULL");
+    if (io->tree ? (!u01 || !io->running_max || !priority_out) : !idx_in)
+        return fail(MORL_ERR_ARG, io->tree ? "prioritised replay needs u01, running_max and priority_out" : "uniform replay needs idx_in");
+    if (io->tree && (io->n_levels < 1 || io->n_levels > 40)) return fail(MORL_ERR_ARG, "n_levels = %d", io->n_levels);
+    if (io->tree && io->B > ST_MAX_B) return fail(MORL_ERR_ARG, "PER update inside the step: B=%d > %d", io->B, ST_MAX_B);
+    if (io->D != c->net.obs_dim || io->R != c->net.reward_dim)
+        return fail(MORL_ERR_ARG, "records of (obs %d, reward %d), the network takes (%d, %d)", io->D, io->R, c->net.obs_dim, c->net.reward_dim);
+    if (adam_step0 < 1) return fail(MORL_ERR_ARG, "adam_step0 must be >= 1");
+    const int B = io->B, W = io->W, WR = W * io->R;
+    for (int k = 0; k < n; ++k) {
+        rc = morl_envelope_prepare(c, io->params_online, io->params_target, io->tree, io->n_levels, io->tree ? u01 + (size_t)k * B : nullptr,
+                                   io->tree ? nullptr : idx_in + (size_t)k * B, io->records, io->record_floats, io->capacity, B, io->D,
+                                   io->R, 1, io->obs, io->next_obs, io->rewards, io->dones, nullptr, io->actions, io->idx,
+                                   w_src + (size_t)k * WR, io->weights, WR, stream);
+        if (!rc) {
+            morl_update_cfg cfg = io->cfg;
+            cfg.adam_step = adam_step0 + k;
+            cfg.homotopy_lambda = homotopy_lambda;
+            cfg.apply_step = 1;
+            cfg.main_forward_done = 0; cfg.slab_parts = 0; cfg.rows_total = 0;
+            cfg.per_tree = io->tree; cfg.per_idx = io->tree ? io->idx : nullptr; cfg.per_running_max = io->tree ? io->running_max : nullptr;
+            cfg.per_levels = io->n_levels;
+            morl_update_out out = {};
+            out.loss = loss_out + k;
+            out.grad_norm = grad_norm_out ? grad_norm_out + k : nullptr;
+            out.priority = priority_out;
+            rc = morl_envelope_update(c, io->params_online, io->params_target, io->grads, io->exp_avg, io->exp_avg_sq, io->obs, io->next_obs,
+                                      io->actions, io->rewards, io->dones, io->weights, B, W, &cfg, &out, stream);
+        }
+        if (rc) {
+            char msg[400];
+            snprintf(msg, sizeof(msg), "%s", morl_last_error());
+            return fail(rc, "update %d of %d: %s", k, n, msg);
+        }
+    }
     return MORL_OK;
 }
 

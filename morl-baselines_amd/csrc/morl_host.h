@@ -22,6 +22,9 @@ inline int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// entries one sum-tree update launch holds (ST_MAX_B of replay_kernels.h; asserted equal in morl_hip.hip)
+constexpr int TREE_UPDATE_MAX = 1024;
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 inline int vec_ok(const void* p, int ld) { return (((uintptr_t)p & 15u) == 0 && (ld & 3) == 0) ? 1 : 0; }

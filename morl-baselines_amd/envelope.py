@@ -29,8 +29,8 @@ def random_weights(dim: int, n: int = 1, dist: str = "dirichlet", seed=None, rng
     if rng is None:
         rng = np.random.default_rng(seed)
     if dist == "gaussian":
-        w = rng.standard_normal((n, dim))
-        w = np.abs(w) / np.linalg.norm(w, ord=1, axis=1, keepdims=True)
+        w = np.abs(rng.standard_normal((n, dim)))
+        w = w / np.add.reduce(w, axis=1, keepdims=True)     # (= np.linalg.norm(w, ord=1, axis=1, keepdims=True): the same reduction)
     elif dist == "dirichlet":
         w = rng.dirichlet(np.ones(dim), n)
     else:
@@ -243,8 +243,91 @@ class Envelope(MOPolicy, MOAgent):
         slot[:] = random_weights(dim=R, n=W, dist="gaussian", rng=self.np_random).reshape(-1)   # float64 -> fp32 (.float())
         return (ptr, self._w_dev), self._w_dev
 
+    def _step_block(self, n: int):
+        """The persistent argument block of ``morl_envelope_update_n`` (``native.StepIO``) with the tensors it points at: the batch
+        the gather launch writes and the update reads, the device copy of the sampled weights, the loss / norm / priority outputs.
+        Built once, rebuilt when anything it captured changes (batch size, weight count, a re-bound buffer, a loaded replay
+        buffer, a hyper-parameter); ``None`` when the replay buffer is not one of ``replay.py``'s device-mirrored ones."""
+        buf = self.replay_buffer
+        if not isinstance(buf, ReplayBuffer) or buf._Ad != 1 or not buf._int_actions:
+            return None
+        key = (self.batch_size, self.num_sample_w, self.q_net.flat.data_ptr(), self.target_q_net.flat.data_ptr(),
+               self._grads.data_ptr(), self._exp_avg.data_ptr(), self._exp_avg_sq.data_ptr(), id(buf), buf.records.data_ptr(),
+               self.gamma, self.learning_rate, self.max_grad_norm, self.envelope, self.per_alpha, self.q_net.ctx.handle)
+        st = self.__dict__.get("_step_state")
+        if st is not None and st.key == key and st.n_alloc >= n:
+            return st
+        import ctypes as C
+        import types
+        from .native import StepIO
+        B, W, R, D, dev = self.batch_size, self.num_sample_w, self.reward_dim, self.observation_dim, self.device
+        self.lib.check_device(self.q_net.flat, self.target_q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq, buf.records)
+        per = isinstance(buf, PrioritizedReplayBuffer)
+        st = types.SimpleNamespace(key=key, n_alloc=max(n, 1), per=per)
+        f32 = dict(dtype=th.float32, device=dev)
+        st.obs, st.next_obs = th.empty((B, D), **f32), th.empty((B, D), **f32)
+        st.rewards, st.dones = th.empty((B, R), **f32), th.empty((B, 1), **f32)
+        st.actions = th.empty((B,), dtype=th.int32, device=dev)
+        st.idx = th.empty((B,), dtype=th.int64, device=dev)
+        st.weights = th.zeros((W, R), **f32)
+        st.loss, st.grad_norm = th.zeros((st.n_alloc,), **f32), th.zeros((st.n_alloc,), **f32)
+        st.priority = th.zeros((B,), **f32)
+        st.loss_views = [st.loss[k] for k in range(st.n_alloc)]
+        st.outs = [{"loss": st.loss[k], "grad_norm": st.grad_norm[k], "priority": st.priority} for k in range(st.n_alloc)]
+        io = StepIO()
+        io.params_online, io.params_target = self.q_net.flat.data_ptr(), self.target_q_net.flat.data_ptr()
+        io.grads, io.exp_avg, io.exp_avg_sq = self._grads.data_ptr(), self._exp_avg.data_ptr(), self._exp_avg_sq.data_ptr()
+        if per:
+            self.lib.check_device(buf.tree_dev, buf.running_max)
+            io.tree, io.running_max, io.n_levels = buf.tree_dev.data_ptr(), buf.running_max.data_ptr(), buf.n_levels
+        io.records, io.capacity, io.record_floats = buf.records.data_ptr(), buf.records.shape[0], buf.records.shape[1]
+        io.obs, io.next_obs, io.rewards, io.dones = (t.data_ptr() for t in (st.obs, st.next_obs, st.rewards, st.dones))
+        io.actions, io.idx, io.weights = st.actions.data_ptr(), st.idx.data_ptr(), st.weights.data_ptr()
+        io.D, io.R, io.B, io.W = D, R, B, W
+        io.cfg = ops._update_cfg(self.gamma, self.learning_rate, 1, self.max_grad_norm, 0.0, self.envelope, 0.9, 0.999, 1e-8, True)
+        io.cfg.per_alpha = float(self.per_alpha)
+        st.io, st.io_ref = io, C.byref(io)
+        st.loss_ptr, st.gn_ptr, st.prio_ptr = st.loss.data_ptr(), st.grad_norm.data_ptr(), st.priority.data_ptr()
+        st.fn = self.lib.lib.morl_envelope_update_n
+        self._step_state = st
+        return st
+
     def update(self):
-        """``envelope.py:267-367``; one C call per gradient step, no host synchronisation."""
+        """``envelope.py:267-367``: the whole ``gradient_updates`` loop is ONE library call (``morl_envelope_update_n``), nothing is
+        synchronised with the host.  The host only draws what the reference draws -- per generator in the reference's order: the
+        batch's uniforms / indices from the global numpy RNG (``prioritized_buffer.py:40`` / ``buffer.py:82``), the sampled
+        weights from ``self.np_random`` (``:279-283``) -- into pinned slots the gather launches read in place."""
+        n = self.gradient_updates
+        self.q_net.ensure_capacity(self.batch_size, self.num_sample_w)
+        st = self._step_block(n)
+        if st is None:
+            return self._update_by_calls()
+        W, R = self.num_sample_w, self.reward_dim
+        WR = W * R
+        ring = self._w_ring = ops.HostRing.fit(self.__dict__.get("_w_ring"), self.lib, self.device, n * WR, th.float32)
+        slot, w_ptr = ring.next(n * WR)
+        if n == 1:
+            slot[:] = random_weights(dim=R, n=W, dist="gaussian", rng=self.np_random).reshape(-1)    # float64 -> fp32 (.float())
+        else:
+            for k in range(n):
+                slot[k * WR:(k + 1) * WR] = random_weights(dim=R, n=W, dist="gaussian", rng=self.np_random).reshape(-1)
+        u_ptr, i_ptr = self.replay_buffer.draw_batches(self.batch_size, n)
+        a0 = self._adam_step + 1
+        self._adam_step += n
+        rc = st.fn(self.q_net.ctx.handle, st.io_ref, n, u_ptr, i_ptr, w_ptr, a0, float(self.homotopy_lambda), st.loss_ptr, st.gn_ptr,
+                   st.prio_ptr, self.lib.stream_of(st.loss))
+        if rc:
+            self._adam_step -= n
+            self.lib.check(rc)
+        ring.mark_used()
+        self.replay_buffer.mark_drawn()
+        self._losses = st.loss_views[:n]
+        self._out = st.outs[n - 1]
+        self._finish_update(st.priority if st.per else None)
+
+    def _update_by_calls(self):
+        """The same loop as one ``sample`` + one ``morl_envelope_update`` call per iteration (foreign replay buffers; the A/B leg of
+        the tests: bit-identical to ``update``)."""
         self._losses = []
         priority = None
         self.q_net.ensure_capacity(self.batch_size, self.num_sample_w)

@@ -211,8 +211,10 @@ class GPIPD(MOPolicy, MOAgent):
         critic_losses, priority, gpriority, deferred = [], None, None, []
         n_updates = self.gradient_updates if self.global_step >= self.dynamics_rollout_starts else 1
         real_only = not self.dyna or self.global_step < self.dynamics_rollout_starts or len(self.dynamics_buffer) == 0
+        # (one tree-update launch holds ST_MAX_B = 1 024 entries: larger batches keep the per-iteration rounds, whose
+        # update_priorities splits the update into blocks)
         per_one_entry = self.per_one_entry_enabled and self.per and real_only and self.replay_buffer._int_actions and \
-            self.replay_buffer._Ad == 1
+            self.replay_buffer._Ad == 1 and self.batch_size <= self.replay_buffer.TREE_BLOCK
         B = self.batch_size
         doubled = len(self.weight_support) > 1
         if per_one_entry:

@@ -238,7 +238,10 @@ class GPIPDContinuousAction(MOAgent, MOPolicy):
         weight = as_f32(weight, dev).reshape(-1)
         priority, deferred = None, []
         real_only = not self.dyna or self.global_step < self.dynamics_rollout_starts or len(self.dynamics_buffer) == 0
-        per_one_entry = self.per_one_entry_enabled and self.per and real_only and not self.replay_buffer._int_actions
+        # (one tree-update launch holds ST_MAX_B = 1 024 entries: larger batches keep the per-iteration rounds, whose
+        # update_priorities splits the update into blocks)
+        per_one_entry = self.per_one_entry_enabled and self.per and real_only and not self.replay_buffer._int_actions and \
+            self.batch_size <= self.replay_buffer.TREE_BLOCK
         B = self.batch_size
         doubled = len(self.weight_support) > 1
         if per_one_entry:

@@ -16,7 +16,7 @@ DEFAULT_LIB = os.path.join(PKG, "lib", "libmorl_hip.so")
 
 MORL_MAX_LAYERS = 8
 MORL_MAX_OBJ = 8
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class NetDesc(C.Structure):
@@ -36,6 +36,14 @@ class UpdateCfg(C.Structure):
 class UpdateOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("loss", "grad_norm", "priority", "target", "pref", "ac", "q_online_next",
                                           "q_target_next", "q_values")]
+
+
+class StepIO(C.Structure):
+    """``morl_step_io``: the persistent argument block of ``morl_envelope_update_n``."""
+    _fields_ = [(n, C.c_void_p) for n in ("params_online", "params_target", "grads", "exp_avg", "exp_avg_sq", "tree", "running_max",
+                                          "records")] + [("capacity", C.c_int64)] + \
+               [(n, C.c_void_p) for n in ("obs", "next_obs", "rewards", "dones", "actions", "idx", "weights")] + \
+               [(n, C.c_int32) for n in ("n_levels", "record_floats", "D", "R", "B", "W")] + [("cfg", UpdateCfg)]
 
 
 class ACDesc(C.Structure):
@@ -164,6 +172,8 @@ _SIGNATURES = {
     "morl_envelope_greedy_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "morl_envelope_update": (C.c_int, [C.c_void_p] * 12 + [C.c_int, C.c_int, C.POINTER(UpdateCfg),
                                                            C.POINTER(UpdateOut), C.c_void_p]),
+    "morl_envelope_update_n": (C.c_int, [C.c_void_p, C.POINTER(StepIO), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "morl_envelope_slabs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p]),
     "morl_envelope_main_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

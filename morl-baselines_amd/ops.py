@@ -182,13 +182,19 @@ class HostRing:
             count = max(count, ring.capacity)
         return HostRing(lib, device, count, dtype)
 
+    waited_s = 0.0        # (class-wide) host time spent blocked on the device in ``next`` -- back-pressure, not host work: a host
+                          # that enqueues faster than the device executes runs into the ring a lap later (bench.py subtracts it)
+
     def next(self, count: Optional[int] = None):
         """(numpy view to fill -- the first ``count`` elements of the slot --, device-side address of the slot)."""
         self.cur = (self.cur + 1) % len(self.dev_ptrs)
         if self.cur % self.group == 0:
             evt = self.events[self.cur // self.group]
-            if evt is not None:
+            if evt is not None and not evt.query():
+                import time
+                t0 = time.perf_counter()
                 evt.synchronize()
+                HostRing.waited_s += time.perf_counter() - t0
         view = self.np[self.cur]
         return (view if count is None or count == self.capacity else view[:count]), self.dev_ptrs[self.cur]
 

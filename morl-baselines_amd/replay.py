@@ -176,6 +176,22 @@ class ReplayBuffer:
             act = act.view(-1, 1)
         return obs, act, rew, nobs, done, idx
 
+    def draw_batches(self, batch_size: int, n: int = 1):
+        """The host side of ``n`` consecutive ``sample(batch_size, to_tensor=True)`` calls for ``morl_envelope_update_n``: the
+        indices of ``buffer.py:82`` drawn from the global numpy RNG in call order, staged in one pinned slot that the library's
+        gather launches read in place.  Returns (address of the unit uniforms -- None here --, address of the [n][B] indices);
+        call ``mark_drawn()`` once the entry that reads them has been enqueued."""
+        self.flush()
+        B = int(batch_size)
+        ring = self._draw_ring = self._ring("_idx_ring", n * B, th.int64)
+        slot, ptr = ring.next(n * B)
+        for k in range(n):
+            slot[k * B:(k + 1) * B] = np.random.choice(self.size, B, replace=True)
+        return None, ptr
+
+    def mark_drawn(self) -> None:
+        self._draw_ring.mark_used()
+
     def sample(self, batch_size, replace=True, use_cer=False, to_tensor=False, device=None, aux=None, prepare=None):
         """``buffer.py:68-96``: host index selection on the global numpy RNG, device gather when ``to_tensor``.
         ``aux`` = (device-visible source address, device tensor): copied along by the gather launch (``ops.sample_gather``)."""
@@ -207,7 +223,7 @@ class ReplayBuffer:
         self.flush()
         st = {k: v for k, v in self.__dict__.items()
               if k not in ("records", "lib", "_stage", "_stage_np", "_stage_evt", "tree_dev", "running_max", "_idx_ring",
-                           "_u_ring")}
+                           "_u_ring", "_draw_ring")}
         st["device"] = str(self.device)
         return st
 
@@ -292,6 +308,21 @@ class PrioritizedReplayBuffer(ReplayBuffer):
         self.flush()
         u = th.as_tensor(np.random.random_sample(batch_size)).to(self.device, non_blocking=True)
         return ops.sumtree_sample(self.lib, self.tree_dev, self.n_levels, u)
+
+    def draw_batches(self, batch_size: int, n: int = 1):
+        """See ``ReplayBuffer.draw_batches``: here the B unit uniforms of every ``SumTree.sample`` (``prioritized_buffer.py:40``,
+        the stream ``np.random.uniform`` consumes), [n][B] doubles; the descents run on the device, iteration k + 1 through the
+        priorities iteration k wrote.  Returns (address of the uniforms, None)."""
+        self.flush()
+        B = int(batch_size)
+        ring = self._draw_ring = self._ring("_u_ring", n * B, th.float64)
+        slot, ptr = ring.next(n * B)
+        if n == 1:
+            slot[:] = np.random.random_sample(B)
+        else:
+            for k in range(n):
+                slot[k * B:(k + 1) * B] = np.random.random_sample(B)
+        return ptr, None
 
     def sample(self, batch_size, to_tensor=False, device=None, aux=None, prepare=None):
         """``prioritized_buffer.py:149-185``.  ``to_tensor``: uniforms from the global numpy RNG (the stream

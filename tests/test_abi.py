@@ -30,7 +30,7 @@ def test_header_symbols_exported_by_the_gfx950_library():
         assert hasattr(lib, n), f"{n} declared in include/morl_hip.h but not exported"
     lib.morl_abi_version.restype = ctypes.c_int
     from morl_baselines_amd.native import ABI_VERSION
-    assert lib.morl_abi_version() == ABI_VERSION == 12
+    assert lib.morl_abi_version() == ABI_VERSION == 13
     assert lib.morl_is_device_build() == 1
 
 

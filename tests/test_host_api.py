@@ -417,3 +417,56 @@ def test_shadow_weights_of_a_skipped_step_are_not_reused(be):
     want = orc.qnet_forward(ps, obs.cpu(), w.cpu().expand(4, -1), env.A, env.R)
     assert float((got.view(-1) - want.reshape(-1)).abs().max()) <= 1e-5 * float(want.abs().max())
     ag.q_net.ctx.invalidate_shadows()                                    # (the explicit form is a no-op afterwards)
+
+
+@pytest.mark.parametrize("per", [False, True])
+def test_update_loop_in_one_entry_equals_one_call_per_iteration(be, per):
+    """``Envelope.update`` = ``morl_envelope_update_n`` (the whole ``gradient_updates`` loop, sampling included, in ONE library
+    call on a persistent argument block) against ``_update_by_calls`` (one ``sample`` + one ``morl_envelope_update`` per iteration):
+    same host RNG streams, parameters / Adam state / losses / sum tree / sampled indices equal to the last bit, over several
+    calls (the block is reused) and after a change that must rebuild it (``gradient_updates`` grows)."""
+    lib, dev = be
+    runs = []
+    for fast in (True, False):
+        ag, env = _make_agent(lib, dev, per, gradient_updates=3)
+        _fill(ag.replay_buffer, 200, env.D, env.A, env.R)
+        ag.global_step = 21
+        losses = []
+        for call in range(4):
+            if call == 2:
+                ag.gradient_updates = 5
+            (ag.update if fast else ag._update_by_calls)()
+            losses += [float(x) for x in ag._losses]
+            ag.global_step += 1
+        assert len(losses) == 3 + 3 + 5 + 5 and ag._adam_step == 16
+        if fast:
+            assert ag._step_state.n_alloc == 5
+        runs.append((ag.q_net.flat.clone().cpu(), ag._exp_avg.clone().cpu(), ag._exp_avg_sq.clone().cpu(), losses,
+                     ag.replay_buffer.tree_dev.clone().cpu() if per else None, float(ag._out["grad_norm"]),
+                     ag._out["priority"].clone().cpu() if per else None, np.random.random_sample(), ag.np_random.random()))
+    a, b = runs
+    assert th.equal(a[0], b[0]) and th.equal(a[1], b[1]) and th.equal(a[2], b[2])
+    assert a[3] == b[3] and a[5] == b[5]
+    assert a[7] == b[7] and a[8] == b[8]                     # both host generators were consumed identically
+    if per:
+        assert th.equal(a[4], b[4]) and th.equal(a[6], b[6])
+
+
+def test_update_entry_refuses_bad_blocks_before_the_first_launch(be):
+    """``morl_envelope_update_n`` validates the whole block up front: a refused call leaves parameters, Adam step and RNG-independent
+    state untouched (the agent rewinds its step counter)."""
+    lib, dev = be
+    ag, env = _make_agent(lib, dev, per=True)
+    _fill(ag.replay_buffer, 100, env.D, env.A, env.R)
+    ag.global_step = 21
+    ag.update()
+    before = ag.q_net.flat.clone()
+    st = ag._step_state
+    keep = st.io.n_levels
+    st.io.n_levels = 0                                       # (a corrupted block)
+    with pytest.raises(RuntimeError, match="n_levels"):
+        ag.update()
+    st.io.n_levels = keep
+    assert ag._adam_step == 1 and th.equal(ag.q_net.flat, before)
+    ag.update()
+    assert ag._adam_step == 2 and not th.equal(ag.q_net.flat, before)

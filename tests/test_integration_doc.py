@@ -22,7 +22,7 @@ DOC = os.path.join(ROOT, "INTEGRATION.md")
 HEADER = os.path.join(ROOT, "include", "morl_hip.h")
 
 # ctypes class name <-> header struct, for every struct that crosses the boundary
-STRUCTS = {"NetDesc": "morl_net_desc", "UpdateCfg": "morl_update_cfg", "UpdateOut": "morl_update_out",
+STRUCTS = {"NetDesc": "morl_net_desc", "UpdateCfg": "morl_update_cfg", "UpdateOut": "morl_update_out", "StepIO": "morl_step_io",
            "ACDesc": "morl_ac_desc", "ACCfg": "morl_ac_cfg", "ACState": "morl_ac_state", "ACBatch": "morl_ac_batch",
            "ACOut": "morl_ac_out", "GPIDesc": "morl_gpi_desc", "GPICfg": "morl_gpi_cfg", "GPIOut": "morl_gpi_out", "GPIBatch": "morl_gpi_batch", "GPIPer": "morl_gpi_per",
            "EnsDesc": "morl_ens_desc", "EnsCfg": "morl_ens_cfg"}
