@@ -494,41 +494,92 @@ def _roofline(res, rows_rank):
     return out
 
 
-def one_step_parity(dev):
+def one_step_parity(dev, case=None, lib=None):
     """bench.py checks what it times: ONE gradient step at the metric's full shape (256 x 64 x 3, the seeded inputs of the reference
     fixture tests/golden/envelope_flagship_full.npz) through the library's DEFAULT pipeline (lazy targets, bf16 matrix cores when
-    enabled) against the oracle on the host -- loss and gradient norm to 1e-5.  Part of the cpu_baseline leg (the only place the
-    benchmark may touch oracle/)."""
+    enabled, the PER tree update inside the step) against the oracle on the host:
+      * loss and gradient norm to 1e-5;
+      * the B priorities |td . w| within the tolerance the 1e-5 contract on Q implies ((1 + gamma) * 1e-5 * max|Q|: w is
+        L1-normalised), the PER sum tree's root equal to what the oracle's tree (prioritized_buffer.py:69-82, 187-195) makes of
+        the device's own priorities (to 3e-7: the device's powf may differ from numpy's fp32 power by an ulp);
+      * the envelope arg-max of all 16 384 TD rows (a second step from the same state that asks for the indices): every row that
+        differs from the oracle's must be a near-tie -- runner-up within 4e-7 of the maximum --, and no more rows may differ than
+        have such a runner-up (counted from the oracle's own slab).
+    Part of the cpu_baseline leg (the only place the benchmark may touch oracle/); a pipeline that disagrees prints no line."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import envelope_oracle as orc
-    from cases import FLAGSHIP as c, make_inputs
+    from cases import FLAGSHIP, make_inputs
     import morl_baselines_amd.ops as ops
+    c = case or FLAGSHIP                  # (tests/test_bench_line.py runs the same checks on a small fixture through the emulator)
     inp = make_inputs(c)
     flat = lambda ps: th.cat([th.as_tensor(p).reshape(-1) for p in ps])
-    ctx = ops.QNetContext(c.D, c.R, c.A, c.arch, c.B, c.W)
-    po, pt = flat(inp["online"]).to(dev), flat(inp["target"]).to(dev)
-    m, v, g = flat(inp["exp_avg"]).to(dev), flat(inp["exp_avg_sq"]).to(dev), th.zeros_like(po)
-    res = ops.envelope_update(ctx, po, pt, g, m, v, th.tensor(inp["obs"]).to(dev), th.tensor(inp["next_obs"]).to(dev),
-                              th.tensor(inp["actions"].astype(np.int32).reshape(-1)).to(dev), th.tensor(inp["rewards"]).to(dev),
-                              th.tensor(inp["dones"]).reshape(-1).to(dev), th.tensor(inp["sampled_w"]).float().to(dev),
-                              gamma=c.gamma, lr=c.lr, adam_step=c.step, max_grad_norm=c.max_grad_norm)
+    ctx = ops.QNetContext(c.D, c.R, c.A, c.arch, c.B, c.W, lib=lib)
+    lib = ctx.lib
+    batch = (th.tensor(inp["obs"]).to(dev), th.tensor(inp["next_obs"]).to(dev),
+             th.tensor(inp["actions"].astype(np.int32).reshape(-1)).to(dev), th.tensor(inp["rewards"]).to(dev),
+             th.tensor(inp["dones"]).reshape(-1).to(dev), th.tensor(inp["sampled_w"]).float().to(dev))
+
+    def state():
+        po, pt = flat(inp["online"]).to(dev), flat(inp["target"]).to(dev)
+        return po, pt, th.zeros_like(po), flat(inp["exp_avg"]).to(dev), flat(inp["exp_avg_sq"]).to(dev)
+
+    # (1) the default pipeline, the step's PER update included: a tree of B leaves at the running maximum, transition b <-> leaf b
+    RMAX, ALPHA = 0.125, 0.6
+    n_levels = int(np.ceil(np.log2(c.B))) + 1
+    tree = th.zeros(2 ** n_levels - 1, dtype=th.float64, device=dev)
+    rmax = th.tensor([RMAX], dtype=th.float64, device=dev)
+    idx = th.arange(c.B, dtype=th.int64, device=dev)
+    ops.sumtree_set(lib, tree, n_levels, idx, None, rmax)
+    po, pt, g, m, v = state()
+    res = ops.envelope_update(ctx, po, pt, g, m, v, *batch, gamma=c.gamma, lr=c.lr, adam_step=c.step, max_grad_norm=c.max_grad_norm,
+                              per=(tree, n_levels, idx, ALPHA, rmax))
     lazy_rows, bf16 = ctx.lazy_target_rows(po), ctx.last_step_bf16()
-    th.cuda.synchronize()
+    # (2) the same step again from the same state, asking for the arg-max indices (still lazily evaluated)
+    po2, pt2, g2, m2, v2 = state()
+    res2 = ops.envelope_update(ctx, po2, pt2, g2, m2, v2, *batch, gamma=c.gamma, lr=c.lr, adam_step=c.step,
+                               max_grad_norm=c.max_grad_norm, debug="lazy")
+    if th.device(dev).type == "cuda":
+        th.cuda.synchronize()
     nt = th.get_num_threads()
     th.set_num_threads(max(1, min(32, (os.cpu_count() or 4) // 4)))
+    sw = th.tensor(inp["sampled_w"]).float()
     o = orc.envelope_update([th.tensor(a) for a in inp["online"]], [th.tensor(a) for a in inp["target"]],
                             [th.tensor(a) for a in inp["exp_avg"]], [th.tensor(a) for a in inp["exp_avg_sq"]], c.step,
                             tuple(th.tensor(inp[k]) for k in ("obs", "actions", "rewards", "next_obs", "dones")),
-                            th.tensor(inp["sampled_w"]).float(), n_actions=c.A, reward_dim=c.R, gamma=c.gamma, lr=c.lr,
+                            sw, n_actions=c.A, reward_dim=c.R, gamma=c.gamma, lr=c.lr,
                             max_grad_norm=c.max_grad_norm, dedup=True, apply_step=False)
     th.set_num_threads(nt)
     rel_l = abs(res["loss"].item() - o["loss"].item()) / abs(o["loss"].item())
     rel_g = abs(res["grad_norm"].item() - o["grad_norm"].item()) / abs(o["grad_norm"].item())
+    # priorities and the tree
+    raw_dev = res["priority"].cpu().numpy()
+    raw_ref = o["priority_raw"].numpy().astype(np.float64)
+    qmax = max(1.0, float(o["q_values"].abs().max()), float(o["target"].abs().max()))
+    prio_tol = (1.0 + c.gamma) * 1e-5 * qmax
+    prio_err = float(np.abs(raw_dev.astype(np.float64) - raw_ref).max())
+    host_tree = orc.SumTree(c.B)
+    host_tree.batch_set(np.arange(c.B), np.full(c.B, RMAX))
+    pr = (raw_dev + np.float32(RMAX)) ** np.float32(ALPHA)                 # envelope.py:333 in numpy's fp32, as the reference does
+    host_tree.batch_set(np.arange(c.B), pr.astype(np.float64))
+    root_dev, root_host = float(tree[0].item()), float(host_tree.nodes[0][0])
+    root_rel = abs(root_dev - root_host) / root_host
+    # arg-max rows
+    pref_d, ac_d = res2["pref"].cpu().long(), res2["ac"].cpu().long()
+    mism = ((pref_d != o["pref"].reshape(-1).long()) | (ac_d != o["ac"].reshape(-1).long())).nonzero().flatten()
+    s_all = th.einsum("ir,bjar->ibja", sw.double(), o["qo"].double().view(c.B, c.W, c.A, c.R)).reshape(c.W, c.B, c.W * c.A)
+    top2 = s_all.topk(2, dim=-1).values
+    at_risk = (((top2[..., 0] - top2[..., 1]) / top2[..., 0].abs().clamp(min=1.0)) <= 4e-7).reshape(-1)
+    flips_ok = mism.numel() <= int(at_risk.sum()) and bool(at_risk[mism].all())
     ctx.close()
     out = {"shape": f"B={c.B} x W={c.W} x R={c.R} (fixture inputs of tests/golden/envelope_{c.name}.npz)", "loss_hip": res["loss"].item(),
            "loss_oracle": o["loss"].item(), "loss_rel": rel_l, "grad_norm_rel": rel_g, "lazy_target_rows": lazy_rows, "bf16_matrix_cores": bf16,
-           "tolerance": 1e-5, "ok": bool(rel_l <= 1e-5 and rel_g <= 1e-5)}
+           "tolerance": 1e-5,
+           "priority_max_abs_err": prio_err, "priority_tolerance": prio_tol,
+           "per_tree_root": root_dev, "per_tree_root_rel_err_given_device_priorities": root_rel,
+           "argmax_rows": c.B * c.W, "argmax_rows_differing": int(mism.numel()), "argmax_rows_with_a_near_tie": int(at_risk.sum()),
+           "argmax_near_tie": 4e-7,
+           "ok": bool(rel_l <= 1e-5 and rel_g <= 1e-5 and prio_err <= prio_tol and root_rel <= 3e-7 and flips_ok)}
     if not out["ok"]:
         raise SystemExit(f"bench.py: the timed pipeline disagrees with the oracle on one step: {out}")
     return out

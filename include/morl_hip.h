@@ -191,7 +191,11 @@ int morl_ctx_set_lazy_targets(morl_ctx* ctx, int enable);
  * the weight gradients and every other entry point are f32-input MFMA in both settings.  Returns the previous setting. */
 int morl_ctx_set_exact_f32(morl_ctx* ctx, int enable);
 /* What the last morl_envelope_update on this context ran on (what bench.py prices its roofline against): bit 0 = forward passes and
- * dX backward as split-bf16 products, bit 1 = the weight gradients too; 0 = everything on the f32-input MFMA */
+ * dX backward as split-bf16 products, bit 1 = the weight gradients too; 0 = everything on the f32-input MFMA.  Bit 2: its lazily
+ * evaluated target rows ran on the 64-row f32 tiles instead of the 8-row ones -- the adaptive fall-back for batches whose TD
+ * rows select many (transition, weight) pairs: the launch of lazily evaluated step e is sized by the pair count step e - 4
+ * reported (more than MORL_LAZY_BIG_ROWS = 4 096 -> large tiles; same compact rows, same values), so a worst-case batch (every
+ * TD row its own pair) costs what the eager target pass costs, not a 16 384-row pass through 8-row tiles. */
 int morl_ctx_last_step_bf16(morl_ctx* ctx);
 int morl_ctx_lazy_target_rows(morl_ctx* ctx, int* rows, void* stream);
 /* The shadow copies made by morl_envelope_prepare are consumed ONLY by the gradient step that directly follows it

@@ -45,7 +45,7 @@ struct ChainArgs {
     int rows;
     // input assembly
     int in_mode;            // 0: cat(obs[b], weights[k]) with row -> (b, k) by row_order ; 1: dense matrix src[rows][ldsrc] ;
-                            // 3 (mlp_chain16 / mlp_chain4 only): cat(obs[b], weights[j]) of the listed pairs, see rows_dev / pairs
+                            // 3 (mlp_chain2 / mlp_chain16 / mlp_chain4): cat(obs[b], weights[j]) of the listed pairs, see rows_dev / pairs
     const float* obs;       // [B][D]
     const float* weights;   // [W][R]  (row_order 2: [rows][R], paired with obs rows)
     int B, W, D, R, row_order;
@@ -57,11 +57,15 @@ struct ChainArgs {
     int nb;                 // mlp_chain2: networks batched in this chain (0 / 1: one); unit u -> network u / units_per_net
     long long sSrc;         //   floats between the input matrices (in_mode 1) of consecutive input groups
     int src_div;            //   networks per input group (twin critics share their input rows)
-    // mlp_chain16 / mlp_chain4, in_mode 3 (the lazily evaluated target rows of an Envelope step): row r is the pair pairs[r] =
+    // in_mode 3 (the lazily evaluated target rows of an Envelope step): row r is the pair pairs[r] =
     // b * W + j, i.e. cat(obs[b], weights[j]); the row count is what the arg-max launch left in *rows_dev (rows = the upper bound the
     // grid was sized for: tiles beyond the count exit at once)
     const int* rows_dev;
     const int32_t* pairs;
+    // in_mode 3: workgroup 0 also reports the count to the host -- *count_mirror = (count_tag << 32) | count, one 8-byte store into
+    // host-mapped memory (morl_ctx::lz_mirror: the library sizes the NEXT steps' target launch by what earlier steps selected)
+    unsigned long long* count_mirror;
+    unsigned int count_tag;
     int fast;               // mlp_chain2: every wide step has ldb == 256 and kpad a multiple of 64 (constant-stride weight stream)
 };
 

@@ -395,6 +395,8 @@ static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain16_kernel(Chain
     int lt = b - m.tile_start[q], g = 0;
     const int tpn = (m.p[q].rows + C16_TM - 1) / C16_TM;          // tiles per network
     if (m.p[q].nb > 1) { g = lt / tpn; lt -= g * tpn; }
+    if (b == 0 && threadIdx.x == 0 && m.p[q].rows_dev != nullptr && m.p[q].count_mirror != nullptr)      // (see ChainArgs::count_mirror)
+        *m.p[q].count_mirror = ((unsigned long long)m.p[q].count_tag << 32) | (unsigned int)*m.p[q].rows_dev;
     if (m.p[q].rows_dev != nullptr && lt * C16_TM >= *m.p[q].rows_dev) return;      // (workgroup-uniform)
     if (m.p[q].fast == 1) mlp_chain16_body<true>(m.p[q], lt * C16_TM, sAct, g);
     else mlp_chain16_body<false>(m.p[q], lt * C16_TM, sAct, g);

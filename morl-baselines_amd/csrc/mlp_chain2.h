@@ -275,7 +275,9 @@ __device__ __forceinline__ void c2_wide_loop(f32x16 (&acc)[TM / 32][2], C2BSet& 
 #define C2_TICK() if (PROF) { if (n_tick < 24) ticks[n_tick] = clock64(); ++n_tick; }
 
 template <int TM, int SCHED, int LD, bool PROF = false>
-__device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, float* sAct, long long* prof_out = nullptr, int g = 0) {
+__device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, float* sAct, long long* prof_out = nullptr, int g = 0,
+                                                int n_rows_dev = -1) {
+    const int n_rows = n_rows_dev >= 0 ? n_rows_dev : p.rows;      // (in_mode 3: the device-side count of the listed pairs)
     long long ticks[24];
     int n_tick = 0;
     C2_TICK()
@@ -295,20 +297,24 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
 
     // ---- input tile -> sAct[m][k], zero-padded to the columns the first step multiplies -------------------------------
     {
-        const int K0 = (p.in_mode == 0) ? (p.D + p.R) : p.K0;
+        const bool cat_mode = p.in_mode == 0 || p.in_mode == 3;
+        const int K0 = cat_mode ? (p.D + p.R) : p.K0;
         const int K0pad = first_wide ? min(CH_MAXW, (K0 + 63) & ~63) : CH_MAXW;
         const int m = tid & (TM - 1);
         constexpr int TPR = CH_THREADS / TM;           // threads per row
         const int q = tid / TM;
         const int row = row0 + m;
+        const bool row_ok = row < n_rows;
         int b = row, w = row;
         if (p.in_mode == 0) {
             if (p.row_order == 0) { b = row / p.W; w = row - b * p.W; }
             else if (p.row_order == 1) { w = row / p.B; b = row - w * p.B; }
+        } else if (p.in_mode == 3) {                   // row r of the compact list is the pair pairs[r] = b * W + j
+            const int flat = min(max(row_ok ? p.pairs[row] : 0, 0), p.B * p.W - 1);
+            b = flat / p.W; w = flat - b * p.W;
         }
-        const bool row_ok = row < p.rows;
-        const float* src_a = (p.in_mode == 0) ? p.obs + (size_t)b * p.D
-                                              : p.src + (p.nb > 1 ? (g / p.src_div) * p.sSrc : 0) + (size_t)row * p.ldsrc;
+        const float* src_a = cat_mode ? p.obs + (size_t)b * p.D
+                                      : p.src + (p.nb > 1 ? (g / p.src_div) * p.sSrc : 0) + (size_t)row * p.ldsrc;
         const float* src_w = p.weights + (size_t)w * p.R;
         for (int kb = q * 16; kb < K0pad; kb += TPR * 16) {
             float v[16];
@@ -317,7 +323,7 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
                 const int k = kb + u;
                 float x = 0.f;
                 if (row_ok && k < K0) {
-                    if (p.in_mode == 0) x = (k < p.D) ? src_a[k] : src_w[k - p.D];
+                    if (cat_mode) x = (k < p.D) ? src_a[k] : src_w[k - p.D];
                     else x = src_a[k];
                 }
                 v[u] = x;
@@ -418,7 +424,7 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
                     reinterpret_cast<unsigned int*>(st.bits_out)[2 * bits_idx + ((row0 >> 5) & 1)] = (unsigned int)bits_w;
             }
             do_copy = st.out != nullptr;
-            if (do_copy) cdst = c2_copy_dst(st.out + g * st.sOut, st.ldout, N, p.rows, row0, tid);
+            if (do_copy) cdst = c2_copy_dst(st.out + g * st.sOut, st.ldout, N, n_rows, row0, tid);
         } else {
             // ======================= narrow step (Q head): split-K over the four waves ========================
             // bx holds Bt[i][64w + 8c + 4h + 0..3] (c = 0..7): wave w contracts k in [64w, 64w + 64) for output column i
@@ -484,7 +490,7 @@ __device__ __forceinline__ void mlp_chain2_body(const ChainArgs& p, int row0, fl
                     const int r = wave * 4 + q;
                     const int m = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const int row = row0 + m;
-                    const bool ok = n < N && row < p.rows;
+                    const bool ok = n < N && row < n_rows;
                     float v = red[tm][q] + bias;
                     if (st.relu) v = fmaxf(v, 0.f);
                     if (st.mask != nullptr) v = (ok && st.mask[(size_t)row * st.ldmask + n] > 0.f) ? v : 0.f;
@@ -581,24 +587,34 @@ __device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, floa
         int lu = unit - m.unit_start[q], g = 0;                  // batched chain: unit -> (network, row tile)
         if (m.p[q].nb > 1) { const int upn = (m.p[q].rows + 63) >> 6; g = lu / upn; lu -= g * upn; }
         const int row0 = lu * 64 + (half > 0 ? 32 : 0);
+        // in_mode 3 (the lazily evaluated target rows of a step that selected MANY pairs): the row count is on the device; units
+        // beyond it have nothing to do (workgroup-uniform), workgroup 0 reports the count to the host
+        int nrd = -1;
+        if (m.p[q].rows_dev != nullptr) {
+            nrd = min(m.p[q].rows, *m.p[q].rows_dev);
+            if (b == 0 && j == 0 && threadIdx.x == 0 && m.p[q].count_mirror != nullptr)
+                *m.p[q].count_mirror = ((unsigned long long)m.p[q].count_tag << 32) | (unsigned int)*m.p[q].rows_dev;
+            if (row0 >= nrd) continue;
+        }
+        const int rows_q = nrd >= 0 ? nrd : m.p[q].rows;
         long long* pout = (PROF && m.prof != nullptr) ? m.prof + ((size_t)b * 2 + (j > 0 ? 1 : 0)) * 24 : nullptr;
         if (NMAJOR) {        // (every chain of the launch streams its wide steps N-major: ChainArgs::fast == 2)
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 2, PROF>(m.p[q], row0, sAct, pout, g);
+                if (row0 < rows_q) mlp_chain2_body<32, SCHED, 2, PROF>(m.p[q], row0, sAct, pout, g, nrd);
             } else {
-                mlp_chain2_body<64, SCHED, 2, PROF>(m.p[q], row0, sAct, pout, g);
+                mlp_chain2_body<64, SCHED, 2, PROF>(m.p[q], row0, sAct, pout, g, nrd);
             }
         } else if (m.p[q].fast) {
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 1, PROF>(m.p[q], row0, sAct, pout, g);
+                if (row0 < rows_q) mlp_chain2_body<32, SCHED, 1, PROF>(m.p[q], row0, sAct, pout, g, nrd);
             } else {
-                mlp_chain2_body<64, SCHED, 1, PROF>(m.p[q], row0, sAct, pout, g);
+                mlp_chain2_body<64, SCHED, 1, PROF>(m.p[q], row0, sAct, pout, g, nrd);
             }
         } else {
             if (half >= 0) {
-                if (row0 < m.p[q].rows) mlp_chain2_body<32, SCHED, 0, PROF>(m.p[q], row0, sAct, pout, g);
+                if (row0 < rows_q) mlp_chain2_body<32, SCHED, 0, PROF>(m.p[q], row0, sAct, pout, g, nrd);
             } else {
-                mlp_chain2_body<64, SCHED, 0, PROF>(m.p[q], row0, sAct, pout, g);
+                mlp_chain2_body<64, SCHED, 0, PROF>(m.p[q], row0, sAct, pout, g, nrd);
             }
         }
         __syncthreads();     // the tile buffer is free for the next job

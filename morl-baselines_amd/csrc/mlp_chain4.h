@@ -251,6 +251,8 @@ static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain4_kernel(ChainA
     const int n_pairs = p.B * p.W;
     int flat = (p.in_mode == 3) ? p.pairs[min(row0 + ((int)threadIdx.x >> 5), p.rows - 1)] : 0;
     const int n_rows = p.rows_dev ? min(p.rows, *p.rows_dev) : p.rows;        // (device-side count: in_mode 3)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.rows_dev != nullptr && p.count_mirror != nullptr)     // (see ChainArgs::count_mirror)
+        *p.count_mirror = ((unsigned long long)p.count_tag << 32) | (unsigned int)*p.rows_dev;
     if (row0 >= n_rows) return;                                               // (workgroup-uniform)
     flat = min(max(flat, 0), n_pairs - 1);
     mlp_chain4_body(p, row0, n_rows, flat, sAct, sRed);

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <chrono>
 #include <vector>
 
 #include "morl_hip.h"
@@ -131,6 +132,9 @@ static_assert(ST_MAX_B == morl_host::TREE_UPDATE_MAX, "morl_host.h's TREE_UPDATE
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
+constexpr int LZ_SLOTS = 16;        // mirror slots (a power of two > LZ_LAG)
+constexpr int LZ_LAG = 4;           // the target launch of lazily evaluated step e is sized by the count of step e - LZ_LAG
+
 struct morl_ctx {
     morl_net_desc net;
     int L;
@@ -191,6 +195,16 @@ struct morl_ctx {
     int32_t* lz_slot = nullptr;          // [max_rows] TD row -> compact row
     int32_t* lz_pairs = nullptr;         // [max_rows] compact row -> pair
     int32_t* lz_count = nullptr;         // [2] distinct pairs of the steps of even / odd epoch
+    // Adaptive sizing of the target launch.  The 8-row tiles are the right tool for the FEW rows a step normally selects (1 161 - 1 828
+    // of 16 384 at the flagship shape) and the wrong one for a batch whose TD rows select (nearly) all B * W pairs -- there the
+    // 64-row tiles of the f32 chain are, on the same compact rows.  Which one a step launches is decided on the host from the count
+    // an EARLIER lazily evaluated step reported (LZ_LAG steps back: the host may run that far ahead of the device without waiting),
+    // read from a host-mapped mirror the target launch's workgroup 0 writes: slot epoch % LZ_SLOTS = (epoch << 32) | count.  The
+    // decision is a function of that count alone, so a run is reproducible whatever the host / device timing.
+    unsigned long long* lz_mirror = nullptr;       // host-mapped, LZ_SLOTS entries
+    unsigned long long* lz_mirror_dev = nullptr;   // its device address
+    long long lz_big_rows = 4096;                  // counts above this take the large tiles (MORL_LAZY_BIG_ROWS)
+    int lz_last_big = 0;                           // what the last lazily evaluated step launched
     int timing_kind_override = -1;       // MORL_TIMED_* of the next bracketed chain launch (-1: by its arguments)
     bool lz_argmax_done = false;         // one-shot: this step's forward launch took the arg-max (mlp_chain_bf.h, BfChain::amax)
     bool td_in_chain_done = false;       // one-shot inside update_core: the backward chain's launch took the TD stage
@@ -274,6 +288,7 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     if (c->wt_online) (void)hipFree(c->wt_online);
     if (c->wt_target) (void)hipFree(c->wt_target);
     if (c->bf_stream) (void)hipFree(c->bf_stream);
+    if (c->lz_mirror) (void)hipHostFree(c->lz_mirror);
     delete c;
     return MORL_OK;
 }
@@ -380,6 +395,20 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         return fail(MORL_ERR_HIP, "hipMemset failed");
     }
     if (const char* e = getenv("MORL_LAZY_TARGETS")) c->lazy_targets = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("MORL_LAZY_BIG_ROWS")) c->lz_big_rows = atoll(e);
+    {
+        void* hm = nullptr;
+        void* dm = nullptr;
+        if (hipHostMalloc(&hm, LZ_SLOTS * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&dm, hm, 0) != hipSuccess) {
+            if (hm) (void)hipHostFree(hm);
+            morl_ctx_destroy(c);
+            return fail(MORL_ERR_ALLOC, "host-mapped count mirror: hipHostMalloc failed");
+        }
+        c->lz_mirror = (unsigned long long*)hm;
+        c->lz_mirror_dev = (unsigned long long*)dm;
+        for (int i = 0; i < LZ_SLOTS; ++i) c->lz_mirror[i] = 0ull;
+    }
     ALLOC(cu_tickets, C2_CU_SLOTS);
     if (hipMemsetAsync(c->cu_tickets, 0, C2_CU_SLOTS * sizeof(unsigned int), nullptr) != hipSuccess) { morl_ctx_destroy(c); return fail(MORL_ERR_HIP, "zero-fill failed"); }
     {
@@ -1055,10 +1084,11 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
 }
 
 // bit 0: the last morl_envelope_update on this context ran its online forward passes and its dX backward pass as split-bf16
-// products (mlp_chain_bf.h); bit 1: its weight gradients too (dw_bf.h); 0: everything on the f32-input MFMA
+// products (mlp_chain_bf.h); bit 1: its weight gradients too (dw_bf.h); bit 2: its lazily evaluated target rows took the large
+// f32 tiles (an earlier step had selected more than MORL_LAZY_BIG_ROWS pairs); 0: everything on the f32-input MFMA
 extern "C" int morl_ctx_last_step_bf16(morl_ctx* c) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
-    return (c->bits_bf ? 1 : 0) | (c->dw_bf_last ? 2 : 0);
+    return (c->bits_bf ? 1 : 0) | (c->dw_bf_last ? 2 : 0) | ((c->lz_last && c->lz_last_big) ? 4 : 0);
 }
 
 extern "C" int morl_ctx_set_exact_f32(morl_ctx* c, int enable) {
@@ -1254,6 +1284,30 @@ static EnvelopeTdArgs lazy_argmax_args(morl_ctx* c, const EnvelopeTdArgs& p) {
     return a1;
 }
 
+// did the lazily evaluated step LZ_LAG epochs before the current one select more than lz_big_rows pairs?  Waits (bounded) for that
+// step's target launch to have started -- the host is then at most LZ_LAG steps ahead of the device, which it normally is not.
+static int chain2_fill(morl_ctx* c, Chain2Multi& m, const ChainArgs* chains, int n, int S);
+static bool lazy_count_was_big(morl_ctx* c) {
+    const long long e = (long long)c->lz_epoch - LZ_LAG;
+    if (e < 1 || !c->lz_mirror || c->lz_big_rows <= 0) return false;
+    volatile unsigned long long* slot = c->lz_mirror + (e & (LZ_SLOTS - 1));
+    unsigned long long v = *slot;
+    if ((unsigned int)(v >> 32) != (unsigned int)e) {
+        // (not there yet: the device is more than LZ_LAG steps behind.  ~2 s bound: a step whose target launch never ran -- an error
+        // return between the arg-max and it -- must not hang its successors; they fall back to the small tiles.)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            v = *slot;
+            if ((unsigned int)(v >> 32) == (unsigned int)e) break;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return false;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    return (long long)(unsigned int)(v & 0xffffffffull) > c->lz_big_rows;
+}
+
 static int lazy_phase1(morl_ctx* c, const EnvelopeTdArgs& p, int td_waves, hipStream_t s) {
     int rc;
     // (the arg-max may already have been taken at the end of the forward launch: morl_envelope_update, BfChain::amax)
@@ -1268,8 +1322,17 @@ static int lazy_phase1(morl_ctx* c, const EnvelopeTdArgs& p, int td_waves, hipSt
     t.in_mode = 3;
     t.rows_dev = c->lz_count + (c->lz_epoch & 1);
     t.pairs = c->lz_pairs;
+    t.count_mirror = c->lz_mirror_dev + (c->lz_epoch & (LZ_SLOTS - 1));
+    t.count_tag = (unsigned int)c->lz_epoch;
     static const bool few_rows = [] { const char* e = getenv("MORL_CHAIN4"); return e ? atoi(e) != 0 : true; }();   // (A/B)
-    if (few_rows && chain4_ok(t)) {
+    // many pairs LZ_LAG steps ago (an adversarial batch: every TD row its own pair): the same compact rows on the 64-row f32 tiles
+    c->lz_last_big = lazy_count_was_big(c) ? 1 : 0;
+    if (c->lz_last_big) {
+        Chain2Multi m{};
+        const int S = chain2_fill(c, m, &t, 1, 0);
+        hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
+        LAUNCH_CHECK("mlp_chain2(lazy targets, many rows)");
+    } else if (few_rows && chain4_ok(t)) {
         // 8-row tiles (mlp_chain4.h): twice the workgroups, half the MFMA time per CU and layer
         hipLaunchKernelGGL(mlp_chain4_kernel, dim3((p.B * p.W + C4_TM - 1) / C4_TM), dim3(CH_THREADS), 0, s, t);
         LAUNCH_CHECK("mlp_chain4(lazy targets)");

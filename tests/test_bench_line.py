@@ -91,3 +91,37 @@ def test_contract_constants(bench):
     assert '"vs_baseline": None' in src and '"data": "synthetic"' in src
     assert 'else "f32")' in src and "6 x bf16 split products" in src      # dtype: the arithmetic type, spelled out for the split path
     assert bench.PEAK_BF16_MFMA_TFLOPS == 2500.0 and bench.BF16_PRODUCTS == 6
+
+
+def test_one_step_parity_checks_priorities_tree_and_argmax(bench):
+    """``bench.py::one_step_parity`` (the check the benchmark runs on what it times, at the metric's shape on the GPU) on the small
+    flagship fixture through the emulator: loss, gradient norm, priorities, the PER tree's root and the arg-max rows all pass, the
+    record carries the figures, and a pipeline that disagrees is refused (a corrupted priority fails it)."""
+    import sys
+    sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+    import torch as th
+    import simlib
+    from cases import CASES
+    lib = simlib.load_sim()
+    c = [c for c in CASES if c.name == "flagship_b32w8"][0]
+    rec = bench.one_step_parity(th.device("cpu"), case=c, lib=lib)
+    assert rec["ok"] and rec["loss_rel"] <= 1e-5 and rec["grad_norm_rel"] <= 1e-5
+    assert rec["priority_max_abs_err"] <= rec["priority_tolerance"] < 1e-4
+    # (the tree arithmetic is exact; powf may differ from numpy's fp32 power by an ulp: tests/test_kernels_parity.py::test_sumtree_trace_bit_exact)
+    assert rec["per_tree_root_rel_err_given_device_priorities"] <= 3e-7 and rec["per_tree_root"] > 0
+    assert rec["argmax_rows"] == c.B * c.W and rec["argmax_rows_differing"] <= rec["argmax_rows_with_a_near_tie"]
+    assert rec["lazy_target_rows"] > 0                       # the default pipeline: lazily evaluated targets
+    import morl_baselines_amd.ops as ops
+    real = ops.envelope_update
+
+    def corrupted(*a, **kw):
+        res = real(*a, **kw)
+        if kw.get("per") is not None:
+            res["priority"].mul_(1.01)
+        return res
+    ops.envelope_update = corrupted
+    try:
+        with pytest.raises(SystemExit, match="disagrees with the oracle"):
+            bench.one_step_parity(th.device("cpu"), case=c, lib=lib)
+    finally:
+        ops.envelope_update = real

@@ -117,23 +117,39 @@ def test_argmax_indices_match_reference_up_to_one_ulp_ties(run):
             json.dump({"case": c.name, "td_rows": c.B * c.W, "flips": int(mism.numel())}, fh)
     except OSError:
         pass
-    # observed on MI355X in round 2: 1 of 16 384 (256 x 64) and 0 of 8 192 (256 x 32) -- profiles/r02_near_tie_flips_*.json; a
-    # handful is what ~1e-7 of GEMM rounding can produce among 16 384 x 384 candidates, hundreds would be an error
-    assert mism.numel() <= 8
+    # How many rows MAY flip is derived, not chosen: the device's Q and torch-CPU's agree to Q_TOL = 2e-7 of max(1, |s|) per
+    # scalarised value (two fp32 GEMM chains against float64: 2.4e-7 and 2.3e-7 at |Q| ~ 1, profiles/r03_split_bf16_probe.txt;
+    # w is L1-normalised, so a scalarised value inherits the bound of the Q entries), hence a row can only flip if its best and
+    # second-best candidates are closer than 2 * Q_TOL.  The rows AT RISK are counted from the data (float64 scalarisation of the
+    # device's own slab) and every flip must be one of them; observed on MI355X: 1 - 2 flips at 256 x 64, 0 at 256 x 32
+    # (profiles/r0*_near_tie_flips_*.json)
+    Q_TOL = 2e-7
+    s_all = th.einsum("ir,bjar->ibja", sw.double(), qo.double()).reshape(c.W, c.B, c.W * c.A)      # [i][b][(j, a)]
+    top2 = s_all.topk(2, dim=-1).values
+    gap = (top2[..., 0] - top2[..., 1]) / top2[..., 0].abs().clamp(min=1.0)
+    at_risk = (gap <= 2 * Q_TOL).reshape(-1)                               # TD row i * B + b
+    print(f"[near-tie flips] {c.name}: {int(at_risk.sum())} TD rows have a runner-up within {2 * Q_TOL:.0e} of their maximum")
+    assert mism.numel() <= int(at_risk.sum()), "more arg-max rows differ from the reference than have a near-tie to flip on"
+    assert bool(at_risk[mism].all())
     for r in mism.tolist():                                               # every mismatch is a near-tie
         i, b = r // c.B, r % c.B
         s = (sw[i].double() * qo[b].double()).sum(-1)                     # (W, A) scalarised values
         mine = s[res["pref"][r].item(), res["ac"][r].item()]
         ref = s[pref_ref[r].item(), ac_ref[r].item()]
-        assert abs(float(mine - ref)) <= 4e-7 * max(1.0, abs(float(ref)))
+        assert abs(float(mine - ref)) <= 2 * Q_TOL * max(1.0, abs(float(ref)))
 
 
 def test_targets_params_and_priorities_match_reference(run):
     c, inp, res, t, sw, g = run
     got, want = res["target"].cpu()[::16], th.tensor(g["target"])
     rel = (got - want).abs().max(1).values / want.abs().max()
-    # rows whose arg-max agrees differ only by GEMM rounding (1e-5); the few near-tie index flips select another slab row
-    assert (rel > 1e-5).float().mean().item() <= 0.004
+    # EVERY stored row whose arg-max agrees with the reference's is within the 1e-5 contract (GEMM rounding only); a row whose
+    # index flipped on a near-tie (test_argmax_indices_...: each one shown to be a tie within 4e-7) selects another slab row and
+    # is exempt -- those rows are identified, not budgeted
+    same = ((res["pref"].cpu().long() == th.tensor(g["pref"].astype(np.int64))) &
+            (res["ac"].cpu().long() == th.tensor(g["ac"].astype(np.int64))))[::16]
+    assert bool((rel[same] <= 1e-5).all()), f"{int((rel[same] > 1e-5).sum())} target rows with the reference's arg-max are off by > 1e-5"
+    assert int((~same).sum()) <= 8
     # (1) the device against the oracle re-run under the device's OWN discrete decisions (ReLU masks, selected targets): the
     #     tight contract -- gradients 5e-5 of the largest entry, parameters within the bound Adam derives from that; every mask
     #     difference is asserted to sit within 1e-6 of a zero pre-activation (tests/flip_aware.py)
@@ -163,8 +179,35 @@ def test_targets_params_and_priorities_match_reference(run):
         assert bool(((gr[sl][::s] - th.tensor(g[f"grad_{i}"])).abs() <= fa.GRAD_TOL * gmax + moved_g[sl][::s]).all())
         assert bool(((po[sl][::s] - th.tensor(g[f"param_after_{i}"])).abs().double() <= (bound_p[sl] + moved_p[sl].double())[::s] + 1e-12).all())
         off += n
+    # Priorities (envelope.py:330-334): x_b = |td_b . w_0|, priority = (x_b + 0.125) ** 0.6.
+    # (1) the kernel's arithmetic, exactly: x_b recomputed on the host in fp32 from the device's OWN Q(s_b, w_0), selected target
+    #     vector, reward and done flag, same operations in the same order -- bit for bit
+    w0 = sw[0].numpy().astype(np.float32)
+    act = inp["actions"].reshape(-1).astype(np.int64)
+    qv = res["q_values"].cpu().numpy().reshape(c.W, c.B, c.A, c.R)[0][np.arange(c.B), act]            # TD row 0 * B + b
+    tgt0 = res["target"].cpu().numpy().reshape(c.W, c.B, c.R)[0]
+    ndg = ((np.float32(1.0) - inp["dones"].reshape(-1).astype(np.float32)) * np.float32(c.gamma)).astype(np.float32)
+    tq = (inp["rewards"].astype(np.float32) + (ndg[:, None] * tgt0).astype(np.float32)).astype(np.float32)
+    td = (qv - tq).astype(np.float32)
+    x = (td[:, 0] * w0[0]).astype(np.float32)
+    for r in range(1, c.R):
+        x = (x + (td[:, r] * w0[r]).astype(np.float32)).astype(np.float32)
+    assert np.array_equal(np.abs(x), res["priority"].cpu().numpy()), "priority is not the fp32 |td . w| of the device's own Q and target"
+    # (2) against the reference's fixture, with the tolerance DERIVED from the 1e-5 contract on Q: |dx| <= sum_r w_0r (|dq_r| +
+    #     (1 - done) gamma |dqt_r|) <= (1 + gamma) * 1e-5 * max|Q| (w is L1-normalised), and d(priority) = 0.6 (x + 0.125) ** -0.4 dx
+    #     -- plus 4 ulp of the fp32 power itself.  (Observed: ~2e-6 relative; the bound is 1.4e-5 .. 3e-4 depending on x.)
     pr = (res["priority"].cpu().numpy() + np.float32(0.125)) ** np.float32(0.6)
-    np.testing.assert_allclose(pr, g["priority_final"], rtol=2e-4)
+    want_pr = g["priority_final"].astype(np.float64)
+    qmax = max(float(np.abs(qv).max()), float(np.abs(tgt0).max()), 1.0)
+    x_ref = want_pr ** (1.0 / 0.6) - 0.125
+    tol = 0.6 * (np.minimum(x_ref, np.abs(x).astype(np.float64)).clip(min=0.0) + 0.125) ** -0.4 * (1.0 + c.gamma) * 1e-5 * qmax + 4 * 6e-8 * want_pr
+    err = np.abs(pr.astype(np.float64) - want_pr)
+    print(f"[priorities] {c.name}: max err / derived tolerance {float((err / tol).max()):.3g}, max rel err {float((err / want_pr).max()):.3g}")
+    # (a TD row of weight 0 whose arg-max flipped on a near-tie selects another target vector: exempt, and identified -- TD rows
+    # 0 .. B-1 of the pref / ac comparison)
+    flipped0 = ((res["pref"].cpu().long() != th.tensor(g["pref"].astype(np.int64))) |
+                (res["ac"].cpu().long() != th.tensor(g["ac"].astype(np.int64))))[:c.B].numpy()
+    assert bool((err <= tol)[~flipped0].all()) and int(flipped0.sum()) <= 2
 
 
 def test_size_independent_properties(run):
