@@ -46,13 +46,23 @@ PEAK_FP32_MFMA_TFLOPS = 157.3                                     # MI355X_MICRO
 PEAK_BF16_MFMA_TFLOPS = 2500.0                                    # MI355X_MICROARCH.md: dense bf16 MFMA (no 2:1 sparsity)
 BF16_PRODUCTS = 6                                                 # split-bf16 products per fp32 product (csrc/mlp_chain_bf.h)
 ALGORITHMIC_BYTES_STEP = 7.7e6                                    # batch + parameters + Adam state + outputs of one step
-# One rank of an N-rank strong-scaled job run alone on one MI355X (--force-shard --emulate-world N; profiles/r02_bench_emulated_
-# rank_of_*.json): single-GPU step time / that rank's step time = what N GPUs could reach if the collectives were free.
-EMULATED_CEILING = {"source": "profiles/r03_bench_emulated_rank_of_{2,4,8}.json (batch axis: 0.242 / 0.172 / 0.148 ms against 0.325), "
-                              "profiles/r02_*_weight_axis.json (weight axis: 0.264 / 0.194 / 0.175 ms); one rank run alone on a 1-GPU box",
-                    "batch_axis": {"2": 1.34, "4": 1.89, "8": 2.20}, "weight_axis": {"2": 1.23, "4": 1.68, "8": 1.86},
-                    "note": "upper bounds BEFORE any collective latency; the >= 6x of north_star is only reachable in the weak "
-                            "reading (W grows with N), which is a different workload from the metric"}
+def emulated_ceiling():
+    """One rank of an N-rank strong-scaled job run alone on one MI355X (--force-shard --emulate-world N): single-GPU step time / that
+    rank's step time = what N GPUs could reach if the collectives were free.  Read from the newest committed summary
+    (profiles/r*_emulated_ceiling.json, written by tools/emulated_ceiling.py from the bench lines of the same build) -- a constant of
+    the repository, not of this run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_emulated_ceiling.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+    except Exception:
+        return None
+    d["source"] = os.path.relpath(files[-1], ROOT)
+    d.setdefault("note", "upper bounds BEFORE any collective latency; the >= 6x of north_star is only reachable in the weak reading "
+                         "(W grows with N), which is a different workload from the metric")
+    return d
 
 
 class _Space:
@@ -227,6 +237,36 @@ def traffic_fields(bf16):
                              "once by the weight-gradient launch"}
 
 
+def _sync(dev):
+    if th.device(dev).type == "cuda":
+        th.cuda.synchronize()
+
+
+class _Stopwatch:
+    """Elapsed milliseconds between two points of the device's stream (HIP events), or of the host clock on the emulated build
+    (``--cpu-emulator``: launches execute synchronously there)."""
+
+    def __init__(self, dev):
+        self.cuda = th.device(dev).type == "cuda"
+        if self.cuda:
+            self.e0, self.e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+
+    def start(self):
+        if self.cuda:
+            self.e0.record()
+        else:
+            self.t0 = time.perf_counter()
+
+    def stop(self):
+        if self.cuda:
+            self.e1.record()
+        else:
+            self.t1 = time.perf_counter()
+
+    def ms(self):
+        return self.e0.elapsed_time(self.e1) if self.cuda else (self.t1 - self.t0) * 1e3
+
+
 def _claim_stdout():
     """stdout must carry exactly ONE line, rank 0's JSON: C libraries (RCCL prints a version banner to stdout, flushed
     at exit, i.e. after the JSON) and the other ranks are moved to stderr; the result is written to the saved descriptor."""
@@ -248,7 +288,7 @@ def _self_spawn(n: int, argv, result_out) -> int:
     127.0.0.1) and pass rank 0's JSON line through to the real stdout."""
     import subprocess
     have = th.cuda.device_count()
-    if have < n and "--shared-gpu" not in argv:
+    if have < n and "--shared-gpu" not in argv and "--cpu-emulator" not in argv:
         raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible on this node")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
@@ -296,33 +336,35 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", 
                      engine=a.engine)
     if a.dw_mode is not None:
         agent.q_net.ctx.set_dw_mode(a.dw_mode)
-    fill_buffer(agent.replay_buffer, 20_000, seed=0)
+    fill_buffer(agent.replay_buffer, a.buffer_fill, seed=0)
     agent.global_step = 1001
     if sharded:
         from morl_baselines_amd.distributed import shard_envelope_agent
         emu = (a.emulate_world, 0) if (a.emulate_world > 1 and world == 1) else None
         # batch axis: every rank runs the unsharded pipeline on B/N transitions, one all-reduce (the strong-scaled job);
         # weight axis: W/N weights per rank, all-gather of Q(w) + all-reduce (the weak-scaled job, whose weight axis grows)
-        shard_envelope_agent(agent, dist, emulate=emu, axis=axis)
+        shard_envelope_agent(agent, dist, emulate=emu, axis=axis, transport=None if a.transport == "auto" else a.transport)
     transport = getattr(getattr(agent, "_shard", None), "transport", None)
+    comm = getattr(getattr(agent, "_shard", None), "comm", None)
+    comm_ranks = comm.size()[1] if comm is not None else None       # what the library's communicator itself reports (morl_comm_size)
 
     def step():
         agent.update()
         agent.global_step += 1
 
-    if ramp:
+    if ramp and dev.type == "cuda":
         _clock_ramp(dev)
     for _ in range(max(warmup - 1, 0)):
         step()
     agent.q_net.ctx.set_timing(1)                    # the last warm-up step counts the chain launches of a step
     if warmup > 0:
         step()
-    th.cuda.synchronize()
+    _sync(dev)
     kinds0 = agent.q_net.ctx.read_timing_kinds()
     launches_per_step = kinds0["forward"][0] + kinds0["forward2"][0] + kinds0["backward"][0]       # chain launches of one step
     if dist is not None:
         dist.barrier()
-        th.cuda.synchronize()
+        _sync(dev)
     # chain launches are event-timed on the library's stream.  An event record costs ~3.5 us of stream time (four records
     # around the two chain launches of a step: +14 us = 4 %), so short runs (the driver's --steps 20) bracket ONE launch on
     # every second step, the launches of a step taking turns (a 5 + 20 run: 10 launches, 3 - 4 of each kind; bracketing one on
@@ -331,33 +373,39 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", 
     if not launches_per_step:
         timing_every = 1 if timing_every < 0 else timing_every
     agent.q_net.ctx.set_timing(timing_every)
-    e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+    from morl_baselines_amd.ops import HostRing
+    sw = _Stopwatch(dev)
+    waited0 = HostRing.waited_s + agent.q_net.ctx.backpressure_seconds()
     t0 = time.perf_counter()
-    e0.record()
+    sw.start()
     for _ in range(steps):
         step()
-    e1.record()
-    t_enq = time.perf_counter() - t0                 # host time to enqueue the timed steps (no synchronisation inside)
-    th.cuda.synchronize()
+    sw.stop()
+    t_enq = time.perf_counter() - t0                 # host time to enqueue the timed steps (no synchronisation inside) ...
+    t_back = HostRing.waited_s + agent.q_net.ctx.backpressure_seconds() - waited0     # ... of which blocked on the device: a host that
+    # enqueues faster than the device executes is throttled to the device's pace -- by the library (the target launch of a lazily
+    # evaluated step is sized by the pair count of eight steps back) or a lap later by the pinned rings: back-pressure, not host work
+    _sync(dev)
     if dist is not None:
         dist.barrier()
-        th.cuda.synchronize()
+        _sync(dev)
     wall = time.perf_counter() - t0
     kinds = agent.q_net.ctx.read_timing_kinds()
     chain_kinds = ("forward", "forward2", "backward")
     n_chain, chain_ms = sum(kinds[k][0] for k in chain_kinds), sum(kinds[k][1] for k in chain_kinds)
     agent.q_net.ctx.set_timing(False)
     lazy_rows = agent.q_net.ctx.lazy_target_rows(agent.q_net.flat)      # distinct (b, j*) pairs of the LAST step (0: eager)
-    gpu_ms = e0.elapsed_time(e1)
+    gpu_ms = sw.ms()
     if dist is not None:
         t = th.tensor([wall], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=th.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-    res = {"wall": wall, "host_enqueue_ms_per_step": t_enq * 1e3 / steps, "gpu_ms_per_step_events": gpu_ms / steps,
+    res = {"wall": wall, "host_enqueue_ms_per_step": (t_enq - t_back) * 1e3 / steps, "host_backpressure_ms_per_step": t_back * 1e3 / steps,
+           "gpu_ms_per_step_events": gpu_ms / steps,
            "n_chain": n_chain, "chain_ms": chain_ms, "timed_steps": (len(range(0, steps, timing_every)) if timing_every > 0 else steps if timing_every == -1
                                                                   else (steps + 1) // 2 if timing_every == -2 else 0),
            "launches_per_step": launches_per_step, "timing_mode": timing_every, "kinds": kinds,
-           "fwd_launches_per_step": kinds0["forward"][0], "fwd2_launches_per_step": kinds0["forward2"][0], "transport": transport, "axis": axis if sharded else None,
+           "fwd_launches_per_step": kinds0["forward"][0], "fwd2_launches_per_step": kinds0["forward2"][0], "transport": transport, "comm_ranks": comm_ranks, "axis": axis if sharded else None,
            "lazy_target_rows": lazy_rows, "bf16": agent.q_net.ctx.last_step_bf16(),
            "loss": agent.last_loss(), "engine": agent.q_net.ctx.engine, "W": W, "B": B}
     del agent
@@ -406,7 +454,7 @@ def collective_microbench(dist, dev, world, n_allreduce, n_allgather, iters=20):
             try:
                 for _ in range(3):
                     call()
-                th.cuda.synchronize()
+                _sync(dev)
             except Exception as exc:
                 bad, why = 1.0, f"{type(exc).__name__}: {exc}"
             f = th.tensor([bad], dtype=th.float64, device=side)
@@ -416,13 +464,13 @@ def collective_microbench(dist, dev, world, n_allreduce, n_allgather, iters=20):
                 try:
                     if what == "allreduce":
                         buf.fill_(1e-3)
-                    e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
-                    e0.record()
+                    sw = _Stopwatch(dev)
+                    sw.start()
                     for _ in range(iters):
                         call()
-                    e1.record()
-                    th.cuda.synchronize()
-                    us = e0.elapsed_time(e1) * 1e3 / iters
+                    sw.stop()
+                    _sync(dev)
+                    us = sw.ms() * 1e3 / iters
                     if name == "ipc":
                         comm.check()
                 except Exception as exc:
@@ -447,6 +495,8 @@ def _roofline(res, rows_rank):
     cores every fp32 product is six bf16 products: ``achieved`` / ``frac`` then price the SIX-fold flop against the dense bf16 peak,
     and ``fp32_equivalent_tflops`` is the algorithmic rate (what the same work would be called on the f32-input MFMA)."""
     n_chain, chain_ms, timed_steps = res["n_chain"], res["chain_ms"], res["timed_steps"]
+    if chain_ms <= 0.0:          # (no usable event timings: the emulated build's events do not measure anything)
+        n_chain = 0
     bf16 = bool(int(res.get("bf16") or 0) & 1)
     dw_bf16 = bool(int(res.get("bf16") or 0) & 2)
     # algorithmic flop of ONE launch of each kind (this rank's rows): the three-pass forward launch (or the launches of a sharded
@@ -469,7 +519,7 @@ def _roofline(res, rows_rank):
                  "backward": chain_name + " backward-dX",
                  "dw": "dw_bf (dW, db; split-bf16, 6 products)" if dw_bf16 else "dw_tiles (dW, db; f32-input MFMA)"}
     for k, (n_k, ms_k) in kinds.items():
-        if n_k:
+        if n_k and ms_k > 0.0:
             us = ms_k * 1e3 / n_k
             tf = flop_kind[k] / (us * 1e-6) / 1e12
             on_bf = dw_bf16 if k == "dw" else bf16
@@ -622,6 +672,15 @@ def main():
     ap.add_argument("--no-collective-microbench", action="store_true",
                     help="N > 1: skip the side record that times the step's two collectives alone over RCCL and over the "
                          "single-hop transport (bounded: a few seconds at worst)")
+    ap.add_argument("--transport", choices=["auto", "rccl", "ipc", "torch", "staged"], default="auto",
+                    help="collectives of the N > 1 rank steps: auto = MORL_COMM, else RCCL inside libmorl_hip.so on an RCCL process group "
+                         "(falling back, on every rank together, to the torch.distributed call-backs); staged = the library calls of a "
+                         "rank step one by one with torch.distributed between them")
+    ap.add_argument("--buffer-fill", type=int, default=20_000, help="seeded transitions in the replay buffer (BASELINE.md s3: 20 000)")
+    ap.add_argument("--cpu-emulator", action="store_true",
+                    help="FUNCTIONAL check without a GPU (the CPU test-suite's end-to-end run of this script): the ranks run the "
+                         "host-emulated kernel library (MORL_HIP_LIB must point at tests/hipsim's build) on CPU tensors over gloo. "
+                         "Its timings mean nothing and the line says so; never the product path")
     ap.add_argument("--force-shard", action="store_true",
                     help="run the weight-sharded step (RCCL collectives) even with one rank (path check on a 1-GPU box)")
     a = ap.parse_args()
@@ -633,19 +692,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if not th.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
-    if a.shared_gpu:
-        local_rank = 0                                    # every rank on the one GPU of the box
-        os.environ.setdefault("MORL_COMM", "ipc")
-    th.cuda.set_device(local_rank)
-    dev = th.device("cuda", local_rank)
+    if a.cpu_emulator:
+        from morl_baselines_amd.native import load_library
+        if load_library().is_device_build:
+            raise SystemExit("--cpu-emulator needs MORL_HIP_LIB to point at the host-emulated test build (tests/hipsim)")
+        th.set_num_threads(1)
+        dev = th.device("cpu")
+    else:
+        if not th.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+        if a.shared_gpu:
+            local_rank = 0                                    # every rank on the one GPU of the box
+            os.environ.setdefault("MORL_COMM", "ipc")
+        th.cuda.set_device(local_rank)
+        dev = th.device("cuda", local_rank)
     dist = None
     if world > 1 or a.force_shard:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if a.shared_gpu:
+        if a.shared_gpu or a.cpu_emulator:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -703,7 +769,10 @@ def main():
         # the A/B SURVEY 8(e) asks for: the same two messages over RCCL's ring / tree and over single-hop direct writes
         n_params = 36 * 256 + 3 * 257 * 256 + 257 * A * R       # P of the flagship net
         try:
-            coll = collective_microbench(dist, dev, world, n_params + 1 + B, 2 * B * (a.weights // world) * A * R)
+            # (the weight-sharded step's all-gather: both slabs, or the online one alone when it evaluates its targets lazily)
+            w_res = strong.get("weights") or weak or {}
+            nets = 1 if (w_res.get("lazy_target_rows") or 0) > 0 else 2
+            coll = collective_microbench(dist, dev, world, n_params + 1 + B, nets * B * (a.weights // world) * A * R)
         except Exception as exc:
             coll = {"error": f"{type(exc).__name__}: {exc}"}
 
@@ -713,19 +782,25 @@ def main():
                 return dict(res)
             rows_step = B * W                             # TD rows per gradient step of the whole job
             ms = res["wall"] * 1e3 / a.steps
-            return {"value": rows_step * a.steps / res["wall"], "unit": "TD-updates/s", "ms_per_step": ms,
+            # (an EMULATED record times one rank of the job run alone: everything below then describes that rank's rows, not the job's)
+            emulated = a.force_shard and a.emulate_world > 1 and world == 1
+            rows_timed = rows_step // parts if emulated else rows_step
+            lazy_all = (1 if emulated else parts) * (res.get("lazy_target_rows") or 0)
+            return {"value": rows_timed * a.steps / res["wall"], "unit": "TD-updates/s", "ms_per_step": ms,
                     "scaling": scaling, "weights": W, "weights_per_gpu": W // world, "shard_axis": res.get("axis"),
                     "transport": res.get("transport"),
                     "updates_per_s": a.steps / res["wall"],
                     "host_enqueue_ms_per_step": res["host_enqueue_ms_per_step"],
+                    "host_backpressure_ms_per_step": res.get("host_backpressure_ms_per_step", 0.0),
                     "gpu_ms_per_step_events": res["gpu_ms_per_step_events"], "last_loss": res["loss"],
                     "roofline": _roofline(res, rows_step // parts),
                     "lazy_target_rows_last_step": res.get("lazy_target_rows"),
                     "bf16": int(res.get("bf16") or 0),
-                    "whole_step_algorithmic_tflops": rows_step * (4 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) / (ms * 1e-3) / 1e12,
-                    "whole_step_executed_tflops": ((rows_step * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) +
-                                                    parts * res["lazy_target_rows"] * FWD_FLOP_ROW) if res.get("lazy_target_rows")
-                                                   else rows_step * (4 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW)) / (ms * 1e-3) / 1e12}
+                    "rows_timed": rows_timed,
+                    "whole_step_algorithmic_tflops": rows_timed * (4 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) / (ms * 1e-3) / 1e12,
+                    "whole_step_executed_tflops": ((rows_timed * (3 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW) + lazy_all * FWD_FLOP_ROW)
+                                                   if res.get("lazy_target_rows")
+                                                   else rows_timed * (4 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW)) / (ms * 1e-3) / 1e12}
 
         single = world == 1 and not a.force_shard
         scaling = "single" if world == 1 else a.scaling        # (one GPU: neither weak nor strong -- nothing is split)
@@ -763,6 +838,10 @@ def main():
                            "all-gather of Q(w), all-reduce of gradient | loss | priorities)"),
                        "shard_axis": head_axis,
                        "transport": head_res.get("transport"),
+                       # ranks the step's communicator ran over, as the library reports them (morl_comm_size); rccl_ranks: the same
+                       # when that communicator is RCCL inside libmorl_hip.so (ncclCommCount), null for every other transport
+                       "comm_ranks": head_res.get("comm_ranks"),
+                       "rccl_ranks": head_res.get("comm_ranks") if str(head_res.get("transport") or "").startswith("rccl") else None,
                        "engine": head_res["engine"],
                        "arithmetic": ("online forward passes, dX backward" + (" and weight gradients" if h["bf16"] & 2 else "") +
                                       " on the bf16 matrix cores as six split-bf16 products per fp32 product (csrc/mlp_chain_bf.h, "
@@ -774,6 +853,9 @@ def main():
             "scalar_td_per_s": h["value"] * R,
             "gpu_ms_per_step_events": h["gpu_ms_per_step_events"],
             "host_enqueue_ms_per_step": h["host_enqueue_ms_per_step"],
+            "host_backpressure_ms_per_step": h["host_backpressure_ms_per_step"],
+            "host_enqueue_note": "host time to enqueue a step (Python + ctypes + launches), the time blocked on the device excluded: a host "
+                                 "that runs ahead waits in the pinned rings a lap later (host_backpressure_ms_per_step)",
             "last_loss": h["last_loss"],
             # whole-step fractions are fp32-EQUIVALENT rates over the f32-input MFMA peak (the one common yardstick of a step that
             # mixes both instruction families); algorithmic = SURVEY 8(d)'s five full passes, executed = what ran (lazy targets)
@@ -800,11 +882,14 @@ def main():
                 for ax, r in strong.items()}
             # what one rank of an N-rank job takes when run ALONE (bench.py --force-shard --emulate-world N, profiles/): the
             # ceiling of strong scaling before any collective costs a microsecond -- nobody should read >= 6x into this record
-            out["config"]["strong_scaling_ceiling_emulated"] = EMULATED_CEILING
+            out["config"]["strong_scaling_ceiling_emulated"] = emulated_ceiling()
         if coll is not None:
             out["collectives_alone"] = dict(coll, note="microseconds per call, max over the ranks, HIP events around 20 back-to-back "
                                                        "calls; rccl = RCCL inside libmorl_hip.so, ipc = single-hop direct writes over "
                                                        "peer-mapped memory (MORL_COMM=ipc selects it for the step)")
+        if a.cpu_emulator:
+            out["cpu_emulator"] = ("FUNCTIONAL record, not a measurement: the ranks ran the host-emulated kernel library on CPU tensors "
+                                   "(gloo); every timing in this line describes the emulator")
         if a.shared_gpu and world > 1:
             out["shared_gpu"] = (f"FUNCTIONAL record, not a multi-GPU measurement: the {world} ranks of this job shared ONE MI355X "
                                  "(gloo process group); value / ms_per_step describe that")
@@ -812,7 +897,7 @@ def main():
             share = (f"{B // a.emulate_world} transitions x {W_head} weights" if head_axis == "batch"
                      else f"{B} transitions x {W_head // a.emulate_world} weights")
             out["emulated"] = (f"NOT a job throughput: the step of rank 0 of a {a.emulate_world}-rank job ({share}) run alone on "
-                               "one GPU; value / ms_per_step describe that rank")
+                               "one GPU; value / ms_per_step / the whole_step_* rates describe that rank's rows")
         if world > 1 and a.scaling == "strong" and weak is not None:
             out["weak_scaling"] = dict(record(weak, a.weights * world, "weak"),
                                        note=f"sub-record, NOT the headline: weak scaling, W = {a.weights * world} sampled weights in "
@@ -827,7 +912,15 @@ def main():
             out["speedup_factors"] = {"total": total, "algorithmic_dedup": algo, "hardware": total / algo,
                                       "note": "total = GPU / CPU-as-written; algorithmic_dedup = CPU(B*W-row targets) / "
                                               "CPU(as written, W^2*B rows); hardware = GPU / CPU(B*W-row targets)"}
-        print(json.dumps(out), file=result_out, flush=True)
+        def finite(x):           # (strict JSON: a figure that could not be measured is null, not NaN)
+            if isinstance(x, float) and x != x:
+                return None
+            if isinstance(x, dict):
+                return {k: finite(v) for k, v in x.items()}
+            if isinstance(x, (list, tuple)):
+                return [finite(v) for v in x]
+            return x
+        print(json.dumps(finite(out)), file=result_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

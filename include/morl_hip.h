@@ -83,6 +83,13 @@ typedef struct morl_update_cfg {
     /* batch-axis sharding (a rank updates on its B transitions of a larger batch): the TD rows of the whole job, by which
      * the loss and its gradient are normalised.  0 => B * W (this call is the whole batch). */
     int64_t rows_total;
+    /* morl_envelope_update_shard only -- lazy target evaluation of the weight-sharded step (envelope.py:422-439: the arg-max reads
+     * the ONLINE slab alone, the target network only at each TD row's (j*, a*)): both non-NULL => qo_all is the all-gathered
+     * ONLINE slab [G][B][W_total/G][A][R] (morl_envelope_slab_online of every rank; parts B*(W_total/G)*A*R floats apart when
+     * slab_parts = G > 1), qt_all is ignored, and the rank evaluates the target network itself on the distinct (transition,
+     * weight) pairs its own TD rows selected -- any of the W_total weights -- from shard_next_obs [B][D] and weights_all. */
+    const float* shard_params_target;
+    const float* shard_next_obs;
 } morl_update_cfg;
 
 /* Optional device outputs of morl_envelope_update (any may be NULL). */
@@ -193,10 +200,13 @@ int morl_ctx_set_exact_f32(morl_ctx* ctx, int enable);
 /* What the last morl_envelope_update on this context ran on (what bench.py prices its roofline against): bit 0 = forward passes and
  * dX backward as split-bf16 products, bit 1 = the weight gradients too; 0 = everything on the f32-input MFMA.  Bit 2: its lazily
  * evaluated target rows ran on the 64-row f32 tiles instead of the 8-row ones -- the adaptive fall-back for batches whose TD
- * rows select many (transition, weight) pairs: the launch of lazily evaluated step e is sized by the pair count step e - 4
- * reported (more than MORL_LAZY_BIG_ROWS = 4 096 -> large tiles; same compact rows, same values), so a worst-case batch (every
- * TD row its own pair) costs what the eager target pass costs, not a 16 384-row pass through 8-row tiles. */
+ * rows select many (transition, weight) pairs: the launch of lazily evaluated step e is sized by the pair count step e - 8
+ * reported (more than MORL_LAZY_BIG_ROWS = 6 144 -> large tiles; same compact rows, same values), so a worst-case batch (every
+ * TD row its own pair) costs what the eager target pass costs, not a 16 384-row pass through 8-row tiles.  Reading that count
+ * makes the host wait when it is more than 8 lazily evaluated steps ahead of the device (it is then throttled to the device's
+ * pace, as by any bounded queue); morl_ctx_backpressure_seconds returns the host time spent so. */
 int morl_ctx_last_step_bf16(morl_ctx* ctx);
+int morl_ctx_backpressure_seconds(morl_ctx* ctx, double* seconds);
 int morl_ctx_lazy_target_rows(morl_ctx* ctx, int* rows, void* stream);
 /* The shadow copies made by morl_envelope_prepare are consumed ONLY by the gradient step that directly follows it
  * (morl_envelope_update / morl_envelope_slabs / the one-call sharded steps); every other entry point re-makes its copies.  A
@@ -310,6 +320,14 @@ int morl_envelope_slabs(morl_ctx* ctx, const float* params_online, const float* 
  * morl_envelope_update ran in between; a caller that rewrites the parameters itself between the two calls must not rely on that.) */
 int morl_envelope_main_forward(morl_ctx* ctx, const float* params_online, const float* obs, const float* weights_local,
                                int B, int W_local, void* stream);
+/* The lazily evaluated form of step 1: the ONLINE network's slab only, slab_out [B][W_local][A][R] -- half the all-gather, no
+ * target pass; params_target: the same launch makes the weight copy the target rows of morl_envelope_update_shard(cfg->
+ * shard_params_target) stream.  morl_ctx_shard_lazy tells whether the one-call step (morl_envelope_step_sharded) of B x W_local
+ * rows per rank takes this form (the same rule as the unsharded step: from MORL_LAZY_MIN_ROWS = 8 192 rows on, envelope targets
+ * only, morl_ctx_set_lazy_targets) -- a staged caller asks it to stay bit-identical to the one-call step. */
+int morl_envelope_slab_online(morl_ctx* ctx, const float* params_online, const float* params_target, const float* next_obs,
+                              const float* weights_local, int B, int W_local, float* slab_out, void* stream);
+int morl_ctx_shard_lazy(morl_ctx* ctx, int B, int W_local, int envelope);
 int morl_envelope_update_shard(morl_ctx* ctx, const float* params_online, float* grads, const float* obs,
                                const int32_t* actions, const float* rewards, const float* dones,
                                const float* weights_all, int B, int W_total, int i_offset, int W_local,

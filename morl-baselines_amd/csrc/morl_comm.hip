@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <new>
@@ -37,10 +38,20 @@ constexpr int kNcclFloat32 = 7, kNcclSum = 0;     // ncclDataType_t / ncclRedOp_
 Rccl& rccl() {
     static Rccl r = [] {
         Rccl q;
+        // MORL_RCCL_LIB: this RCCL build and no other (a site's own build; the fake one of tests/test_distributed.py, which fails on
+        // a chosen rank to exercise the ranks' agreement on a common fall-back)
+        if (const char* own = getenv("MORL_RCCL_LIB")) {
+            q.handle = dlopen(own, RTLD_NOW | RTLD_LOCAL);
+            if (!q.handle) {
+                const char* e = dlerror();
+                snprintf(q.why, sizeof(q.why), "MORL_RCCL_LIB=%s: %s", own, e ? e : "dlopen failed");
+                return q;
+            }
+        }
         const char* names[] = {"librccl.so.1", "librccl.so"};
         for (const char* n : names) {                              // an instance that is already mapped first
-            q.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
             if (q.handle) break;
+            q.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         }
         if (!q.handle) {
             const char* more[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -87,6 +98,7 @@ struct morl_comm {
     void* user = nullptr;
     bool custom = false;                 // the caller's call-backs: their return codes are not ours
     int rank = 0, world = 1;
+    int nccl_count = -1;                 // ncclCommCount of an RCCL communicator: the rank count RCCL itself computes with
     hipStream_t side = nullptr;          // the all-gather runs here, beside the training forward on the caller's stream
     hipEvent_t ready = nullptr, done = nullptr;
 };
@@ -156,8 +168,14 @@ extern "C" int morl_comm_init(morl_comm** out, const void* unique_id, int rank, 
         // RCCL's own view of the job, for the log of a multi-GPU run (the rank count the library computes with, not the launcher's)
         int n = -1;
         if (r->CommCount) (void)r->CommCount(c->nccl, &n);
+        c->nccl_count = n;
         fprintf(stderr, "[morl_comm] rank %d: RCCL communicator of %d rank(s) (ncclCommCount), asked for %d\n", rank, n, world);
         fflush(stderr);
+        if (n > 0 && n != world) {
+            (void)r->CommDestroy(c->nccl);
+            delete c;
+            return fail(MORL_ERR_STATE, "RCCL reports a communicator of %d rank(s), %d were asked for", n, world);
+        }
     } else {
         c->allgather = loop_allgather; c->allreduce = loop_allreduce;
     }
@@ -196,7 +214,9 @@ extern "C" int morl_comm_destroy(morl_comm* c) {
 extern "C" int morl_comm_size(const morl_comm* c, int* rank, int* world) {
     if (!c) return fail(MORL_ERR_ARG, "comm is NULL");
     if (rank) *rank = c->rank;
-    if (world) *world = c->world;
+    // (an RCCL communicator answers with RCCL's own count -- ncclCommCount --, so that a multi-GPU benchmark line can state how many
+    // ranks the library's collectives really ran over: bench.py config.rccl_ranks)
+    if (world) *world = (c->nccl && c->nccl_count > 0) ? c->nccl_count : c->world;
     return MORL_OK;
 }
 

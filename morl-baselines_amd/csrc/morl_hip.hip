@@ -132,8 +132,8 @@ static_assert(ST_MAX_B == morl_host::TREE_UPDATE_MAX, "morl_host.h's TREE_UPDATE
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
-constexpr int LZ_SLOTS = 16;        // mirror slots (a power of two > LZ_LAG)
-constexpr int LZ_LAG = 4;           // the target launch of lazily evaluated step e is sized by the count of step e - LZ_LAG
+constexpr int LZ_SLOTS = 32;        // mirror slots (a power of two > LZ_LAG)
+constexpr int LZ_LAG = 8;           // the target launch of lazily evaluated step e is sized by the count of step e - LZ_LAG
 
 struct morl_ctx {
     morl_net_desc net;
@@ -203,7 +203,10 @@ struct morl_ctx {
     // decision is a function of that count alone, so a run is reproducible whatever the host / device timing.
     unsigned long long* lz_mirror = nullptr;       // host-mapped, LZ_SLOTS entries
     unsigned long long* lz_mirror_dev = nullptr;   // its device address
-    long long lz_big_rows = 4096;                  // counts above this take the large tiles (MORL_LAZY_BIG_ROWS)
+    long long lz_big_rows = 6144;                  // counts above this take the large tiles (MORL_LAZY_BIG_ROWS; the measured cross-over
+                                                   // at the flagship shape: profiles/r05_lazy_target_rows_sweep.json)
+    double host_wait_s = 0.0;                      // host time spent waiting for a count (the device more than LZ_LAG steps behind):
+                                                   // back-pressure, not host work (morl_ctx_backpressure_seconds)
     int lz_last_big = 0;                           // what the last lazily evaluated step launched
     int timing_kind_override = -1;       // MORL_TIMED_* of the next bracketed chain launch (-1: by its arguments)
     bool lz_argmax_done = false;         // one-shot: this step's forward launch took the arg-max (mlp_chain_bf.h, BfChain::amax)
@@ -211,6 +214,7 @@ struct morl_ctx {
     bool lz_now = false;                 // this step runs lazily: the three below are what the target launch needs
     const float* lz_params_target = nullptr;
     const float* lz_next_obs = nullptr;
+    const float* lz_weights_all = nullptr;   // a weight-sharded step: the job's W_total weight vectors (the selected pairs' j* range over all of them)
     float* td_zero_ptr = nullptr;        // one-shot request of the batch-sharded step to the next TD launch: zero this range ...
     int td_zero_n = 0, td_keep_lo = 0, td_keep_hi = 0;   // ... except [keep_lo, keep_hi) (the rank's own priorities)
     // split-bf16 chain (mlp_chain_bf.h): the online network's weights as fragment-ordered bf16 triples, forward stream then backward
@@ -230,6 +234,8 @@ struct morl_ctx {
     // library entry, dropped by every optimiser step of the library
     const float* fresh_online = nullptr;
     const float* fresh_target = nullptr;
+    const float* bf_stream_src = nullptr;   // parameters the split-bf16 streams were made from by this step's morl_envelope_slab_online
+                                         // (one-shot for morl_envelope_main_forward; cleared by every optimiser step of the library)
     const float* wt_online_src = nullptr;   // parameters wt_online was transposed from by this step's morl_envelope_slabs
                                          // (cleared by every optimiser step of the library)
     size_t ev_used = 0;
@@ -1117,10 +1123,19 @@ extern "C" int morl_ctx_lazy_target_rows(morl_ctx* c, int* rows, void* stream) {
     return MORL_OK;
 }
 
+// host seconds this context has spent blocked on the device so far (lazy_count_was_big): a caller that measures its own enqueue
+// cost subtracts it
+extern "C" int morl_ctx_backpressure_seconds(morl_ctx* c, double* seconds) {
+    if (!c || !seconds) return fail(MORL_ERR_ARG, "NULL argument");
+    *seconds = c->host_wait_s;
+    return MORL_OK;
+}
+
 extern "C" int morl_ctx_invalidate_shadows(morl_ctx* c) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     c->fresh_online = c->fresh_target = c->fresh_bf = nullptr;
     c->wt_online_src = nullptr;
+    c->bf_stream_src = nullptr;
     return MORL_OK;
 }
 
@@ -1259,9 +1274,9 @@ static EnvelopeTdArgs td_args(morl_ctx* c, const morl_update_cfg* cfg, const mor
     p.c_mse = (float)((1.0 - (double)lam) * 2.0 / ((double)rows_total * R));
     p.c_aux = (float)((double)lam * 2.0 / (double)rows_total);
     p.i_groups = std::max(1, std::min(4, (WI + 63) / 64));
-    if (cfg->slab_parts > 1) {      // all-gathered slabs read in place: [G][2][B][W/G][A][R]
+    if (cfg->slab_parts > 1) {      // all-gathered slabs read in place: [G][2][B][W/G][A][R] -- or, lazily evaluated, [G][B][W/G][A][R]
         p.part_floats = (W / cfg->slab_parts) * A * R;
-        p.part_stride = 2ll * B * p.part_floats;
+        p.part_stride = (cfg->shard_params_target ? 1ll : 2ll) * B * p.part_floats;
     }
     // waves per workgroup ~ candidates per TD row: 4 at the single-GPU 64 x 6, up to 16 when a sharded job reduces over
     // all gathered weights
@@ -1296,14 +1311,17 @@ static bool lazy_count_was_big(morl_ctx* c) {
         // (not there yet: the device is more than LZ_LAG steps behind.  ~2 s bound: a step whose target launch never ran -- an error
         // return between the arg-max and it -- must not hang its successors; they fall back to the small tiles.)
         const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
         for (;;) {
             v = *slot;
-            if ((unsigned int)(v >> 32) == (unsigned int)e) break;
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return false;
+            if ((unsigned int)(v >> 32) == (unsigned int)e) { seen = true; break; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
         }
+        c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (!seen) return false;
     }
     return (long long)(unsigned int)(v & 0xffffffffull) > c->lz_big_rows;
 }
@@ -1317,7 +1335,11 @@ static int lazy_phase1(morl_ctx* c, const EnvelopeTdArgs& p, int td_waves, hipSt
         const EnvelopeTdArgs a1 = lazy_argmax_args(c, p);
         if ((rc = launch_envelope_td(a1, p.B * p.i_groups, td_waves, s, "envelope_argmax"))) return rc;
     }
-    ChainArgs t = make_forward_chain(c, c->lz_params_target, c->wt_target, c->lz_next_obs, p.weights, p.B, p.W, 0, p.B * p.W, false,
+    // (compact rows: at most one per TD row of this call -- a shard's rows select among ALL W candidates but own B * WI rows)
+    const int wi = p.WI > 0 ? p.WI : p.W;
+    const float* w_all = c->lz_weights_all ? c->lz_weights_all : p.weights;
+    c->lz_weights_all = nullptr;
+    ChainArgs t = make_forward_chain(c, c->lz_params_target, c->wt_target, c->lz_next_obs, w_all, p.B, p.W, 0, p.B * wi, false,
                                      c->qt, p.A * p.R);
     t.in_mode = 3;
     t.rows_dev = c->lz_count + (c->lz_epoch & 1);
@@ -1334,7 +1356,7 @@ static int lazy_phase1(morl_ctx* c, const EnvelopeTdArgs& p, int td_waves, hipSt
         LAUNCH_CHECK("mlp_chain2(lazy targets, many rows)");
     } else if (few_rows && chain4_ok(t)) {
         // 8-row tiles (mlp_chain4.h): twice the workgroups, half the MFMA time per CU and layer
-        hipLaunchKernelGGL(mlp_chain4_kernel, dim3((p.B * p.W + C4_TM - 1) / C4_TM), dim3(CH_THREADS), 0, s, t);
+        hipLaunchKernelGGL(mlp_chain4_kernel, dim3((p.B * wi + C4_TM - 1) / C4_TM), dim3(CH_THREADS), 0, s, t);
         LAUNCH_CHECK("mlp_chain4(lazy targets)");
     } else {
         Chain16Multi m16{};
@@ -1692,6 +1714,7 @@ static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_a
                           const morl_update_cfg* cfg, float* grad_norm_out, bool have_partials, hipStream_t s,
                           const SumTreeUpdate* per = nullptr) {
     c->wt_online_src = nullptr;          // the parameters change: any transposed copy is stale from here on
+    c->bf_stream_src = nullptr;
     c->fresh_online = c->fresh_target = c->fresh_bf = nullptr;
     const unsigned int* skip_flag = c->skip_flag;    // one-shot request of a sharded step (set right before this call)
     c->skip_flag = nullptr;
@@ -1938,9 +1961,60 @@ extern "C" int morl_envelope_update_shard(morl_ctx* c, const float* params_onlin
         return fail(MORL_ERR_STATE, "main_forward_done: morl_envelope_main_forward was not run for %d rows", B * W_local);
     if (!fwd_done && c->use_fused && (rc = refresh_transposed(c, params_online, c->wt_online, s))) return rc;
     c->main_rows = -1;
-    return update_core(c, params_online, grads, obs, actions, rewards, dones,
-                       weights_all + (size_t)i_offset * c->net.reward_dim, W_local, qo_all, qt_all, W_total, i_offset,
-                       (long long)B * W_total, B, cfg, out, fwd_done, nullptr, nullptr, s);
+    // lazily evaluated: arg-max on the gathered ONLINE slab, the target network on the pairs this rank's TD rows selected
+    c->lz_now = false;
+    c->lz_last = false;
+    if (cfg->shard_params_target && cfg->shard_next_obs) {
+        if (!cfg->envelope) return fail(MORL_ERR_ARG, "lazy target evaluation is for envelope targets (cfg->envelope = 1)");
+        if (!c->use_fused) return fail(MORL_ERR_STATE, "lazy target evaluation needs the layer-fused engine");
+        c->lz_now = c->lz_last = true;
+        c->lz_params_target = cfg->shard_params_target;
+        c->lz_next_obs = cfg->shard_next_obs;
+        c->lz_weights_all = weights_all;
+    }
+    rc = update_core(c, params_online, grads, obs, actions, rewards, dones,
+                     weights_all + (size_t)i_offset * c->net.reward_dim, W_local, qo_all, qt_all, W_total, i_offset,
+                     (long long)B * W_total, B, cfg, out, fwd_done, nullptr, nullptr, s);
+    c->lz_now = false;
+    c->lz_weights_all = nullptr;
+    return rc;
+}
+
+// does the one-call weight-sharded step of B x W_local rows per rank evaluate its targets lazily?  (the unsharded step's rule)
+static bool shard_lazy(const morl_ctx* c, int B, int W_local, int envelope) {
+    static const long long lazy_min_rows = [] { const char* e = getenv("MORL_LAZY_MIN_ROWS"); return e ? atoll(e) : 8192ll; }();
+    return c->use_fused && c->lazy_targets && envelope && (c->lazy_targets == 2 || (long long)B * W_local >= lazy_min_rows);
+}
+
+extern "C" int morl_ctx_shard_lazy(morl_ctx* c, int B, int W_local, int envelope) {
+    if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
+    return shard_lazy(c, B, W_local, envelope) ? 1 : 0;
+}
+
+extern "C" int morl_envelope_slab_online(morl_ctx* c, const float* params_online, const float* params_target, const float* next_obs,
+                                         const float* weights_local, int B, int W_local, float* slab_out, void* stream) {
+    int rc = check_bw(c, B, W_local);
+    if (rc) return rc;
+    if (!params_online || !params_target || !next_obs || !weights_local || !slab_out) return fail(MORL_ERR_ARG, "NULL array");
+    if (!c->use_fused) return fail(MORL_ERR_STATE, "morl_envelope_slab_online needs the layer-fused engine");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = B * W_local, AR = c->net.n_actions * c->net.reward_dim;
+    timing_begin_step(c);
+    c->last_step_W = W_local;
+    if (bf_wanted(c, rows)) {
+        // the rank's share is large enough for the bf16 matrix cores: split weight streams of the online network (+ the target's
+        // K-major copy for the target rows), the next-state pass as one split-bf16 chain; the training pass and the backward follow
+        if ((rc = refresh_bf_step(c, params_online, params_target, s))) return rc;
+        c->wt_online_src = nullptr;
+        c->bf_stream_src = params_online;
+        const BfChain one = bf_forward_chain(c, params_online, next_obs, weights_local, B, W_local, rows, false, slab_out, AR);
+        return bf_launch(c, &one, 1, MORL_TIMED_FORWARD, s);
+    }
+    c->bf_stream_src = nullptr;
+    if ((rc = refresh_transposed(c, params_online, c->wt_online, s, params_target, c->wt_target, true))) return rc;
+    c->wt_online_src = params_online;
+    const ChainArgs one = make_forward_chain(c, params_online, c->wt_online, next_obs, weights_local, B, W_local, 0, rows, false, slab_out, AR);
+    return chain_forward_multi(c, &one, 1, s);
 }
 
 extern "C" int morl_envelope_slabs(morl_ctx* c, const float* params_online, const float* params_target, const float* next_obs,
@@ -1974,7 +2048,16 @@ extern "C" int morl_envelope_main_forward(morl_ctx* c, const float* params_onlin
     if (!params_online || !obs || !weights_local) return fail(MORL_ERR_ARG, "NULL array");
     hipStream_t s = (hipStream_t)stream;
     const int rows = B * W_local;
-    if (c->use_fused) {
+    if (c->use_fused && bf_wanted(c, rows) && c->bf_stream_src == params_online) {
+        // the split weight streams this step's morl_envelope_slab_online made are current: the training pass on the bf16 matrix cores
+        // (the backward chain and the weight gradients follow it there: update_core looks at bits_bf)
+        c->bf_stream_src = nullptr;
+        const BfChain one = bf_forward_chain(c, params_online, obs, weights_local, B, W_local, rows, true, c->qm, c->ldq);
+        if ((rc = bf_launch(c, &one, 1, MORL_TIMED_FORWARD, s))) return rc;
+        c->bits_valid = true;
+        c->bits_bf = true;
+    } else if (c->use_fused) {
+        c->bf_stream_src = nullptr;
         // exactly the third pass of the unsharded step's fused launch: activations and ReLU sign bits saved in the context,
         // the layer-0 input of the dW GEMM written from the kernel's own input assembly
         // the K-major copy made by this step's morl_envelope_slabs is still current unless an optimiser step intervened
@@ -2026,9 +2109,16 @@ extern "C" int morl_envelope_step_sharded(morl_ctx* c, morl_comm* comm, float* p
     const int R = c->net.reward_dim, AR = c->net.n_actions * R;
     const int64_t half = (int64_t)B * W_local * AR;            // one network's slab of one rank
     const float* w_loc = weights_all + (size_t)i_offset * R;
-    float* recv = (world == parts) ? slab_all : slab_all + (size_t)(i_offset / W_local) * 2 * half;
-    if ((rc = morl_envelope_slabs(c, params_online, params_target, next_obs, w_loc, B, W_local, slab_local, stream))) return rc;
-    if ((rc = morl_allgather_q_begin(comm, slab_local, recv, 2 * half, stream))) return rc;
+    // Lazily evaluated (the unsharded step's rule applied to the rank's rows): only Q_online(s', w_j) is exchanged -- half the
+    // all-gather --, the arg-max of the rank's TD rows runs over all gathered candidates, and the rank evaluates the target network
+    // on the pairs those rows selected (envelope.py:422-439).  slab_local / slab_all are used as [B][W_local][A][R] / [G][...].
+    const bool lazy = shard_lazy(c, B, W_local, cfg->envelope);
+    const int64_t part = lazy ? half : 2 * half;
+    float* recv = (world == parts) ? slab_all : slab_all + (size_t)(i_offset / W_local) * part;
+    if (lazy) rc = morl_envelope_slab_online(c, params_online, params_target, next_obs, w_loc, B, W_local, slab_local, stream);
+    else rc = morl_envelope_slabs(c, params_online, params_target, next_obs, w_loc, B, W_local, slab_local, stream);
+    if (rc) return rc;
+    if ((rc = morl_allgather_q_begin(comm, slab_local, recv, part, stream))) return rc;
     if ((rc = morl_envelope_main_forward(c, params_online, obs, w_loc, B, W_local, stream))) return rc;   // beside the exchange
     if ((rc = morl_comm_wait(comm, stream))) return rc;
     morl_update_cfg shard = *cfg;
@@ -2036,6 +2126,8 @@ extern "C" int morl_envelope_step_sharded(morl_ctx* c, morl_comm* comm, float* p
     shard.main_forward_done = 1;
     shard.slab_parts = parts;
     shard.per_tree = nullptr;                                  // priorities are complete only after the all-reduce
+    shard.shard_params_target = lazy ? params_target : nullptr;
+    shard.shard_next_obs = lazy ? next_obs : nullptr;
     morl_update_out out = {};
     out.loss = grads_x + n_params;
     out.priority = grads_x + n_params + 1;

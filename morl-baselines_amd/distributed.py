@@ -109,7 +109,7 @@ class NativeComm:
         if int(have_id.item()) != 1:
             raise RuntimeError(f"RCCL unique id unavailable on rank 0 (this rank: {err})")
         ident = msg[:128].contiguous()
-        with th.cuda.device(self.device):
+        with (th.cuda.device(self.device) if self.device.type == "cuda" else __import__("contextlib").nullcontext()):
             try:
                 lib.check(lib.lib.morl_comm_init(C.byref(handle), C.c_void_p(ident.data_ptr()), self.rank, self.world))
                 self.handle = handle.value
@@ -228,6 +228,12 @@ class NativeComm:
             self.lib.check(self.lib.lib.morl_comm_init_custom(C.byref(handle), self.rank, self.world,
                                                               C.cast(self._cbs[0], C.c_void_p), C.cast(self._cbs[1], C.c_void_p), None))
         self.handle = handle.value
+
+    def size(self):
+        """(rank, world) as the LIBRARY's communicator reports them (``morl_comm_size``; over RCCL the world is ``ncclCommCount``)."""
+        r, w = C.c_int(-1), C.c_int(-1)
+        self.lib.check(self.lib.lib.morl_comm_size(self.handle, C.byref(r), C.byref(w)))
+        return r.value, w.value
 
     def allgather_begin(self, send: th.Tensor, recv: th.Tensor) -> None:
         self.lib.check(self.lib.lib.morl_allgather_q_begin(self.handle, send.data_ptr(), recv.data_ptr(), send.numel(),
@@ -398,20 +404,31 @@ def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=N
             else:
                 # the same stages one by one, the collectives through torch.distributed (gloo in the CPU tests)
                 w_loc = sampled_w[i0:i0 + Wl].contiguous()
-                # 1. local slabs [2][B][Wl][A][R]: both networks in one launch pair
-                loc = ops.envelope_slabs(ctx, self.q_net.flat, self.target_q_net.flat, b_next_obs, w_loc, out=slab_loc)
-                # 2. one all-gather -> [G][2][B][Wl][A][R], read in place by the TD kernel; while it is in flight ...
-                work = dist.all_gather_into_tensor(slab_recv.view(-1), loc.view(-1), group=group, async_op=True)
+                lazy = ops.shard_lazy(ctx, B, Wl, self.envelope)          # (the form the one-call step takes at this size)
+                if lazy:
+                    # 1. the ONLINE slab only [B][Wl][A][R]; 2. all-gather -> [G][B][Wl][A][R] (half the message)
+                    half = B * Wl * A * R
+                    loc = ops.envelope_slab_online(ctx, self.q_net.flat, self.target_q_net.flat, b_next_obs, w_loc,
+                                                   slab_loc.view(-1))[:half]
+                    recv = slab_all.view(-1)[:world * half] if emulate is None else slab_all.view(-1)[rank * half:(rank + 1) * half]
+                    work = dist.all_gather_into_tensor(recv, loc, group=group, async_op=True)
+                else:
+                    # 1. local slabs [2][B][Wl][A][R]: both networks in one launch pair
+                    loc = ops.envelope_slabs(ctx, self.q_net.flat, self.target_q_net.flat, b_next_obs, w_loc, out=slab_loc)
+                    # 2. one all-gather -> [G][2][B][Wl][A][R], read in place by the TD kernel; while it is in flight ...
+                    work = dist.all_gather_into_tensor(slab_recv.view(-1), loc.view(-1), group=group, async_op=True)
                 # ... the training forward of this rank's rows runs (it does not need the slabs)
                 ops.envelope_main_forward(ctx, self.q_net.flat, b_obs, w_loc)
                 work.wait()
                 # 3. this rank's TD rows: arg-max over ALL gathered candidates, TD, backward (priorities: written by the
-                #    rank that owns weight 0, zeroed by the others)
+                #    rank that owns weight 0, zeroed by the others); lazily evaluated: the target network on the selected pairs
                 outs = {"loss": gx[P], "priority": gx[P + 1:]}
+                flat_all = slab_all.view(-1)
                 ops.envelope_update_shard(ctx, self.q_net.flat, self._grads, b_obs, actions, b_rewards, b_dones.reshape(-1),
-                                          sampled_w, i0, Wl, slab_all[0, 0], slab_all[0, 1], gamma=self.gamma,
-                                          homotopy_lambda=float(self.homotopy_lambda), envelope=self.envelope, outputs=outs,
-                                          main_forward_done=True, slab_parts=world)
+                                          sampled_w, i0, Wl, flat_all if lazy else slab_all[0, 0], flat_all if lazy else slab_all[0, 1],
+                                          gamma=self.gamma, homotopy_lambda=float(self.homotopy_lambda), envelope=self.envelope,
+                                          outputs=outs, main_forward_done=True, slab_parts=world,
+                                          lazy=(self.target_q_net.flat, b_next_obs) if lazy else None)
                 # 4. one all-reduce: flat gradient + loss + priorities
                 dist.all_reduce(gx, op=dist.ReduceOp.SUM, group=group)
                 # 5. identical optimiser step everywhere

@@ -30,7 +30,8 @@ class UpdateCfg(C.Structure):
                 ("adam_step", C.c_int32), ("envelope", C.c_int32), ("apply_step", C.c_int32),
                 ("main_forward_done", C.c_int32), ("slab_parts", C.c_int32),
                 ("per_tree", C.c_void_p), ("per_idx", C.c_void_p), ("per_running_max", C.c_void_p),
-                ("per_levels", C.c_int32), ("per_alpha", C.c_float), ("rows_total", C.c_int64)]
+                ("per_levels", C.c_int32), ("per_alpha", C.c_float), ("rows_total", C.c_int64),
+                ("shard_params_target", C.c_void_p), ("shard_next_obs", C.c_void_p)]
 
 
 class UpdateOut(C.Structure):
@@ -158,6 +159,7 @@ _SIGNATURES = {
     "morl_ctx_set_lazy_targets": (C.c_int, [C.c_void_p, C.c_int]),
     "morl_ctx_set_exact_f32": (C.c_int, [C.c_void_p, C.c_int]),
     "morl_ctx_last_step_bf16": (C.c_int, [C.c_void_p]),
+    "morl_ctx_backpressure_seconds": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "morl_ctx_lazy_target_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "morl_ctx_debug_hidden": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "morl_host_device_pointer": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -177,6 +179,9 @@ _SIGNATURES = {
     "morl_envelope_slabs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p]),
     "morl_envelope_main_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "morl_envelope_slab_online": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p]),
+    "morl_ctx_shard_lazy": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "morl_envelope_update_shard": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p,
                                                                                  C.POINTER(UpdateCfg), C.POINTER(UpdateOut),
                                                                                  C.c_void_p]),

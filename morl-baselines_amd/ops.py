@@ -59,6 +59,13 @@ class QNetContext:
         the weight gradients; 0 = everything on the f32-input MFMA."""
         return int(self.lib.lib.morl_ctx_last_step_bf16(self.handle))
 
+    def backpressure_seconds(self) -> float:
+        """Host time this context has spent waiting for the device (``morl_ctx_backpressure_seconds``: the adaptive sizing of the lazily
+        evaluated target launch reads the pair count of eight steps back)."""
+        t = C.c_double(0.0)
+        self.lib.check(self.lib.lib.morl_ctx_backpressure_seconds(self.handle, C.byref(t)))
+        return t.value
+
     def lazy_target_rows(self, like: th.Tensor) -> int:
         """Distinct (transition, weight) pairs the last lazily evaluated step ran the target network on (synchronises)."""
         n = C.c_int(0)
@@ -411,6 +418,28 @@ def envelope_slabs(ctx: QNetContext, params_online: th.Tensor, params_target: th
     return out
 
 
+def envelope_slab_online(ctx: QNetContext, params_online: th.Tensor, params_target: th.Tensor, next_obs: th.Tensor,
+                         weights_local: th.Tensor, out: th.Tensor) -> th.Tensor:
+    """This rank's ONLINE next-state slab [B][W_local][A][R] only (``morl_envelope_slab_online``: the lazily evaluated form of the
+    weight-sharded step -- half the all-gather, no target pass); ``out``: at least B * W_local * A * R floats, written from its start."""
+    lib = ctx.lib
+    for t, n in ((params_online, "params_online"), (params_target, "params_target"), (next_obs, "next_obs"),
+                 (weights_local, "weights_local"), (out, "out")):
+        _chk(t, th.float32, n)
+    B, Wl = next_obs.shape[0], weights_local.shape[0]
+    if out.numel() < B * Wl * ctx.n_actions * ctx.reward_dim:
+        raise ValueError("out is too small for the online slab")
+    lib.check_device(params_online, params_target, next_obs, weights_local, out)
+    lib.check(lib.lib.morl_envelope_slab_online(ctx.handle, _ptr(params_online), _ptr(params_target), _ptr(next_obs),
+                                                _ptr(weights_local), B, Wl, _ptr(out), lib.stream_of(next_obs)))
+    return out
+
+
+def shard_lazy(ctx: QNetContext, B: int, w_local: int, envelope: bool = True) -> bool:
+    """Does the one-call weight-sharded step of B x w_local rows per rank evaluate its targets lazily (``morl_ctx_shard_lazy``)?"""
+    return bool(ctx.lib.lib.morl_ctx_shard_lazy(ctx.handle, int(B), int(w_local), int(bool(envelope))))
+
+
 def envelope_main_forward(ctx: QNetContext, params_online: th.Tensor, obs: th.Tensor, weights_local: th.Tensor) -> None:
     """Hoisted training forward of this rank's TD rows (``morl_envelope_main_forward``): independent of the gathered
     slabs, so it can run while the all-gather is in flight."""
@@ -427,7 +456,7 @@ def envelope_update_shard(ctx: QNetContext, params_online: th.Tensor, grads: th.
                           i_offset: int, w_local: int, qo_all: th.Tensor, qt_all: th.Tensor, *, gamma: float,
                           homotopy_lambda: float = 0.0, envelope: bool = True,
                           outputs: Optional[Dict[str, th.Tensor]] = None, main_forward_done: bool = False,
-                          slab_parts: int = 0) -> Dict[str, th.Tensor]:
+                          slab_parts: int = 0, lazy=None) -> Dict[str, th.Tensor]:
     """Stage B of a weight-sharded Envelope step (see include/morl_hip.h): this rank's TD rows against the gathered
     slabs; leaves the unclipped, globally normalised gradient contribution in ``grads``.  ``slab_parts`` = G > 1:
     ``qo_all`` / ``qt_all`` are views of part 0 inside the all-gathered buffer [G][2][B][W/G][A][R] (read in place)."""
@@ -446,6 +475,11 @@ def envelope_update_shard(ctx: QNetContext, params_online: th.Tensor, grads: th.
         res["priority"] = th.zeros((B,), dtype=th.float32, device=dev)
     cfg = _update_cfg(gamma, 0.0, 1, None, homotopy_lambda, envelope, 0.9, 0.999, 1e-8, False)
     cfg.main_forward_done, cfg.slab_parts = int(bool(main_forward_done)), int(slab_parts)
+    if lazy is not None:          # (params_target, next_obs): qo_all is the gathered ONLINE slab, the target rows are evaluated here
+        p_target, next_obs = lazy
+        _chk(p_target, th.float32, "params_target"); _chk(next_obs, th.float32, "next_obs")
+        lib.check_device(p_target, next_obs)
+        cfg.shard_params_target, cfg.shard_next_obs = _ptr(p_target), _ptr(next_obs)
     out = UpdateOut(**{k: _ptr(res.get(k)) for k, _ in UpdateOut._fields_})
     lib.check(lib.lib.morl_envelope_update_shard(
         ctx.handle, _ptr(params_online), _ptr(grads), _ptr(obs), _ptr(actions), _ptr(rewards), _ptr(dones),

@@ -32,7 +32,7 @@ def _make_agent(lib, per, schedules=False, dev=th.device("cpu"), arch=(32, 32), 
 
 
 
-def _tensor_slices(n_params, D=6, R=2, A=3, archs=((32, 32), (256, 256, 256))):
+def _tensor_slices(n_params, D=6, R=2, A=3, archs=((32, 32), (64, 64), (256, 256, 256))):
     """[(start, end)] of every weight matrix / bias vector in the flat parameter buffer of the ToyEnv agents this file builds
     (layout of ``QNetContext.layer_slices``: W_l then b_l, layer after layer), the architecture told by the parameter count."""
     for arch in archs:
@@ -61,7 +61,7 @@ def _same_training(p, want, n_steps, lr=3e-4):
     return d.max() <= lr * n_steps and np.mean(tight) >= 0.99 and per_tensor
 
 
-def _worker(rank, world, port, per, ret, schedules=False, axis="weights"):
+def _worker(rank, world, port, per, ret, schedules=False, axis="weights", arch=(32, 32)):
     """One rank of a gloo job.  The sharded agent is run TWICE from identical seeds: through the staged path (seven library
     calls, the collectives issued by ``torch.distributed`` between them) and through the production path -- ONE library call
     per step (``morl_envelope_step_sharded`` / ``_batch_sharded``) whose collectives are the communicator's transport, here
@@ -78,7 +78,7 @@ def _worker(rank, world, port, per, ret, schedules=False, axis="weights"):
     native.use_library(lib)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     for transport in ("staged", None, "ipc"):             # None = what a gloo job gets by default: the one-call step over
-        ag = _make_agent(lib, per, schedules)             # torch.distributed call-backs; "ipc": over the single-hop transport
+        ag = _make_agent(lib, per, schedules, arch=arch)  # torch.distributed call-backs; "ipc": over the single-hop transport
         shard_envelope_agent(ag, dist, axis=axis, transport=transport)
         comm = ag._shard.comm
         assert (comm is None) == (transport == "staged"), ag._shard.transport
@@ -94,6 +94,11 @@ def _worker(rank, world, port, per, ret, schedules=False, axis="weights"):
             else:
                 calls = dict(comm.calls)
             comm.close()
+        if axis == "weights" and ag.q_net.ctx.fused:
+            # the layer-fused engine evaluates the weight-sharded step's targets LAZILY (tests/conftest.py: MORL_LAZY_MIN_ROWS=0): only the
+            # online slab was exchanged, the rank ran the target network on the pairs its own TD rows selected
+            n_lazy = ag.q_net.ctx.lazy_target_rows(ag.q_net.flat)
+            assert 0 < n_lazy <= ag.batch_size * ag._shard.Wl, n_lazy
         ret[(rank, transport or "one-call")] = (
             ag.q_net.flat.clone().numpy(), float(ag.last_loss()),
             ag.replay_buffer.tree_dev.clone().numpy() if per else None,
@@ -102,10 +107,14 @@ def _worker(rank, world, port, per, ret, schedules=False, axis="weights"):
 
 
 @pytest.mark.parametrize("axis", ["weights", "batch"])
-@pytest.mark.parametrize("per,schedules,world", [(False, False, 2), (True, False, 2), (True, True, 2), (True, False, 4)])
-def test_sharded_update_equals_single_process(per, schedules, world, axis):
+@pytest.mark.parametrize("per,schedules,world,arch", [(False, False, 2, (32, 32)), (True, False, 2, (32, 32)), (True, True, 2, (32, 32)),
+                                                      (True, False, 4, (32, 32)), (True, False, 2, (64, 64))],
+                         ids=["plain", "per", "per-schedules", "per-world4", "per-fused-lazy"])
+def test_sharded_update_equals_single_process(per, schedules, world, axis, arch):
     """``schedules``: several steps with ``homotopy_decay_steps`` / ``epsilon_decay_steps`` set -- the sharded step must run
     the same tail as ``Envelope.update`` (envelope.py:336-355), or the auxiliary loss never turns on under sharding.
+    ``arch`` (64, 64) takes the layer-fused engine, whose weight-sharded step is LAZILY evaluated (all-gather of the online slab only,
+    the target network on the pairs the rank's own TD rows selected): asserted in the workers.
     Both code paths of the rank step are run at world > 1: the one-call step (the production path; its collectives go through
     the pluggable transport of ``morl_comm``) must equal the staged one BIT FOR BIT and the unsharded step to 1e-5.  Third leg:
     the one-call step over the SINGLE-HOP transport (``morl_comm_ipc_*``: direct writes into peer-mapped memory -- POSIX shared
@@ -117,7 +126,8 @@ def test_sharded_update_equals_single_process(per, schedules, world, axis):
     native.use_library(lib)
     n_steps = N_STEPS[schedules]
     try:
-        ref = _make_agent(lib, per, schedules)
+        ref = _make_agent(lib, per, schedules, arch=arch)
+        assert ref.q_net.ctx.fused == (arch == (64, 64))
         for _ in range(n_steps):
             ref.update()
             ref.global_step += 1
@@ -130,8 +140,8 @@ def test_sharded_update_equals_single_process(per, schedules, world, axis):
         assert 0.0 < want_lam <= 1.0 and want_eps < 0.5            # the schedules actually moved
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 29500 + (os.getpid() % 2000) + 7 * int(schedules) + 13 * (world - 2) + 31 * int(axis == "batch") + 3 * int(per)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, per, ret, schedules, axis)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + 7 * int(schedules) + 13 * (world - 2) + 31 * int(axis == "batch") + 3 * int(per) + 61 * int(arch != (32, 32))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per, ret, schedules, axis, arch)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -231,10 +241,12 @@ def test_one_call_sharded_step_equals_the_staged_one(per):
     lib = simlib.load_sim()
     native.use_library(lib)
     try:
-        for emulate, axis in ((None, "weights"), ((2, 1), "weights"), (None, "batch"), ((2, 1), "batch"), ((4, 2), "batch")):
+        for emulate, axis, arch in ((None, "weights", (32, 32)), ((2, 1), "weights", (32, 32)), (None, "batch", (32, 32)),
+                                    ((2, 1), "batch", (32, 32)), ((4, 2), "batch", (32, 32)), (None, "weights", (64, 64)),
+                                    ((2, 1), "weights", (64, 64)), ((2, 0), "batch", (64, 64))):
             runs = []
             for one_call in (False, True, None):
-                ag = _make_agent(lib, per, schedules=True)
+                ag = _make_agent(lib, per, schedules=True, arch=arch)
                 if one_call is not None:
                     comm = NativeComm(lib, None, "cpu", loopback=True) if one_call else None
                     shard_envelope_agent(ag, _OneRank(), emulate=emulate, comm=comm, axis=axis)
@@ -242,6 +254,11 @@ def test_one_call_sharded_step_equals_the_staged_one(per):
                 for _ in range(3):
                     ag.update()
                     ag.global_step += 1
+                if one_call is not None and axis == "weights" and arch == (64, 64):
+                    # the layer-fused engine: the weight-sharded step evaluated its targets LAZILY (tests/conftest.py:
+                    # MORL_LAZY_MIN_ROWS=0) -- only the online slab exchanged, the target network on the selected pairs
+                    n_lazy = ag.q_net.ctx.lazy_target_rows(ag.q_net.flat)
+                    assert ag.q_net.ctx.fused and 0 < n_lazy <= ag.batch_size * ag._shard.Wl, n_lazy
                 runs.append((ag.q_net.flat.clone().numpy(), ag.last_loss(),
                              ag.replay_buffer.tree_dev.clone().numpy() if per else None, float(ag.homotopy_lambda)))
             staged, fused, plain = runs
@@ -735,3 +752,132 @@ def test_one_call_rank_step_at_world_gt_1_on_one_shared_gpu(per, world, axis):
         assert _same_training(p0, want, n), transport
         if per:
             np.testing.assert_allclose(t0[0], want_tree[0], rtol=1e-5)
+
+
+def test_weight_sharded_step_on_the_bf16_lazy_pipeline():
+    """The weight-sharded rank step on the pipeline ``bench.py`` times on one GPU: 256-wide network -> the rank's online slab, its
+    training pass, the dX backward and the weight gradients as split-bf16 products (``morl_envelope_slab_online`` /
+    ``morl_envelope_main_forward`` on ``mlp_chain_bf``), targets lazily evaluated after the all-gather of the ONLINE slab.
+    Staged == one-call bit for bit (whole weight axis on one rank, and one rank of two run alone); the whole-axis run equals the
+    unsharded agent (same arithmetic, other summation order) to 1e-5."""
+    import simlib
+    import morl_baselines_amd.native as native
+    from morl_baselines_amd.distributed import NativeComm, shard_envelope_agent
+    lib = simlib.load_sim()
+    native.use_library(lib)
+    try:
+        for emulate in (None, (2, 1)):
+            runs = []
+            for one_call in (False, True, None):
+                ag = _make_agent(lib, True, schedules=False, arch=(256, 256), B=8, W=8)
+                if one_call is not None:
+                    comm = NativeComm(lib, None, "cpu", loopback=True) if one_call else None
+                    shard_envelope_agent(ag, _OneRank(), emulate=emulate, comm=comm, axis="weights")
+                for _ in range(2):
+                    ag.update()
+                    ag.global_step += 1
+                ctx = ag.q_net.ctx
+                assert ctx.last_step_bf16() & 3 == 3                                  # chains and weight gradients on the bf16 cores
+                assert ctx.lazy_target_rows(ag.q_net.flat) > 0
+                runs.append((ag.q_net.flat.clone().numpy(), ag.last_loss(), ag.replay_buffer.tree_dev.clone().numpy()))
+            staged, fused, plain = runs
+            assert np.array_equal(staged[0], fused[0]) and staged[1] == fused[1] and np.array_equal(staged[2], fused[2])
+            if emulate is None:
+                assert abs(fused[1] - plain[1]) <= 1e-5 * abs(plain[1])
+                d = np.abs(fused[0] - plain[0])
+                assert d.max() <= 3e-4 * 2 and np.mean(d <= 0.02 * 3e-4 * 2) >= 0.99
+    finally:
+        native.use_library(None)
+
+
+# ---- RCCL set-up without a second GPU: the ranks' agreement, against a fake librccl (tests/fake_rccl) ---------------------------
+def _build_fake_rccl():
+    import subprocess
+    src = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.c")
+    out = os.path.join(ROOT, "tests", "fake_rccl", "_build", "librccl_fake.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        tmp = f"{out}.{os.getpid()}.tmp"
+        subprocess.run(["gcc", "-shared", "-fPIC", "-O1", src, "-o", tmp], check=True)
+        os.replace(tmp, out)
+    return out
+
+
+class _AsRccl:
+    """``torch.distributed`` (gloo underneath) that calls itself an RCCL process group -- what ``make_comm`` asks before it tries RCCL."""
+
+    def __init__(self, dist):
+        self._d = dist
+
+    def get_backend(self, group=None):
+        return "nccl"
+
+    def __getattr__(self, k):
+        return getattr(self._d, k)
+
+
+def _fake_rccl_worker(rank, world, port, fake, scenario, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MORL_RCCL_LIB"] = fake
+    kind, k = scenario
+    if kind == "id":
+        os.environ["FAKE_RCCL_FAIL_ID"] = "1"
+    elif kind == "init":
+        os.environ["FAKE_RCCL_FAIL_INIT_RANK"] = str(k)
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import types
+    import torch.distributed as dist
+    import simlib
+    from morl_baselines_amd.distributed import NativeComm, make_comm
+    lib = simlib.load_sim()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # (1) the RCCL communicator itself: comes up on every rank, or raises on EVERY rank -- after all of them took part in every
+    #     collective of the set-up (a rank that raised early would leave the others in a broadcast / all-reduce forever)
+    try:
+        c = NativeComm(lib, dist, "cpu", transport="rccl")
+        got = ("up",) + c.size()
+        c.close()
+    except RuntimeError as exc:
+        got = ("raised", str(exc))
+    dist.barrier()
+    # (2) make_comm: RCCL when it came up everywhere, else ALL ranks fall back to the torch.distributed transport together
+    as_device = types.SimpleNamespace(lib=lib.lib, is_device_build=True, check=lib.check, check_device=lib.check_device,
+                                      stream_of=lib.stream_of)
+    comm, name = make_comm(as_device, _AsRccl(dist), "cpu")
+    ret[rank] = (got, comm.transport, name, comm.size())
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", [("none", -1), ("id", 0), ("init", 0), ("init", 1), ("init", 2)],
+                         ids=["rccl-comes-up", "no-unique-id", "init-fails-on-rank0", "init-fails-on-rank1", "init-fails-on-rank2"])
+def test_rccl_setup_agreement_on_every_rank_ordering(scenario):
+    """``NativeComm(transport="rccl")`` / ``make_comm`` at world 3 over gloo with a fake librccl (``MORL_RCCL_LIB``) whose
+    ``ncclGetUniqueId`` / ``ncclCommInitRank`` fail where the scenario says.  Whatever rank fails: nobody hangs, every rank reaches
+    the same verdict, ``make_comm`` returns RCCL on all ranks or the torch.distributed fall-back on all ranks, and a communicator
+    that came up reports the world RCCL itself counted (``morl_comm_size`` -> ``ncclCommCount``: bench.py's ``config.rccl_ranks``)."""
+    fake = _build_fake_rccl()
+    world = 3
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 35500 + (os.getpid() % 2000) + 7 * ["none", "id", "init"].index(scenario[0]) + max(scenario[1], 0)
+    procs = [ctx.Process(target=_fake_rccl_worker, args=(r, world, port, fake, scenario, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        if p.is_alive():
+            p.kill()
+            pytest.fail("a rank hung in the RCCL set-up")
+        assert p.exitcode == 0
+    ok = scenario[0] == "none"
+    for r in range(world):
+        got, transport, name, size = ret[r]
+        if ok:
+            assert got == ("up", r, world)
+            assert transport == "rccl" and name.startswith("rccl") and size == (r, world)
+        else:
+            assert got[0] == "raised" and ("unavailable" in got[1])
+            assert transport == "torch" and "fallback" in name and size == (r, world)
