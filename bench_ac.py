@@ -354,6 +354,70 @@ def _claim_stdout():
     return real
 
 
+def bench_morld_contexts(a, D, Ad, R, pop, rows, shp):
+    """``MORLD(devices=[...])``'s hot path (``__update_others``, morld.py:423-433) with the population split over ``a.devices`` contexts
+    of ONE process: context g holds pop / G learners in its own ACEngine on GPU min(g, visible - 1); a step enqueues every context's
+    update (independent learners: no exchange), the step ends when all devices are done."""
+    from morl_baselines_amd.ac_engine import ALGO_MOSAC, ACEngine
+    G = a.devices
+    if pop % G:
+        raise SystemExit(f"--pop {pop} must be divisible by --devices {G}")
+    visible = th.cuda.device_count()
+    devs = [th.device("cuda", min(g, visible - 1)) for g in range(G)]
+    iters, ctxs = 2, []
+    for g, dev in enumerate(devs):
+        n = pop // G
+        with th.cuda.device(dev):
+            eng = ACEngine(ALGO_MOSAC, D, Ad, R, ARCH, action_low=-1.0, action_high=1.0, max_rows=rows, population=n, device=dev,
+                           device_steps=True)
+            gen = th.Generator(device=dev).manual_seed(g)
+            rnd = lambda *s_, gen=gen, dev=dev: th.randn(*s_, generator=gen, device=dev)  # noqa: E731
+            with th.no_grad():
+                eng.q.copy_(rnd(*eng.q.shape) * 0.05)
+                eng.pol.copy_(rnd(*eng.pol.shape) * 0.05)
+                eng.q_target.copy_(eng.q)
+            data = dict(obs=rnd(n, rows, D), next_obs=rnd(n, rows, D), actions=th.tanh(rnd(n, rows, Ad)), rewards=rnd(n, rows, R),
+                        dones=(th.rand(n, rows, generator=gen, device=dev) < 0.05).float(),
+                        w=th.softmax(rnd(n, 1, R), dim=-1).contiguous())
+        ctxs.append((dev, eng, data, n))
+
+    def step():
+        for dev, eng, data, n in ctxs:
+            with th.cuda.device(dev):
+                cfg = eng.make_cfg(q_lr=1e-3, policy_iters=iters, autotune=True, target_entropy=-float(Ad))
+                eps = th.randn((1 + 2 * iters, n, rows, Ad), dtype=th.float32, device=dev)
+                eng.update(cfg, eps_next=eps[0], eps_pi=eps[1:1 + iters], eps_alpha=eps[1 + iters:], want=("critic_loss",), **data)
+
+    sync = lambda: [th.cuda.synchronize(d) for d in set(devs)]  # noqa: E731
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    wall = time.perf_counter() - t0
+    ms = wall * 1e3 / a.steps
+    flop = update_flop("morld", D, Ad, R, rows, iters) * pop
+    tf = flop / (ms * 1e-3) / 1e12
+    distinct = len(set(devs))
+    out = {"metric": "actor-critic learner updates/sec", "value": pop * a.steps / wall, "unit": "learner-updates/s",
+           "rows_per_s": pop * rows * a.steps / wall, "n_gpus": distinct, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"morld: {pop} learners x batch {B} ({rows} rows), net {ARCH}, shapes of {shp['env']}; one pass of "
+                                  f"MORLD.__update_others per step, the population split over {G} device contexts of one process",
+                      "population": pop, "contexts": G, "learners_per_context": pop // G, "distinct_gpus": distinct,
+                      "parallelism": f"{G} contexts (one ACEngine each) on {distinct} GPU(s); independent learners, no data-path collective",
+                      "measured": (f"all {G} contexts on their own GPU" if distinct == G else
+                                   f"FUNCTIONAL beyond {distinct} GPU(s): this box shows {visible}, so {G - distinct + 1} contexts share "
+                                   "a device -- the multi-GPU figure is UNMEASURED")},
+           "roofline": {"bound": "mfma", "kernel": "gemm_batched (exact-fp32 MFMA layers of all nets / learners)", "achieved": tf,
+                        "peak": PEAK_FP32_MFMA_TFLOPS * distinct, "unit": "TFLOP/s", "frac": tf / (PEAK_FP32_MFMA_TFLOPS * distinct),
+                        "traffic": None},
+           "algorithmic_flop_per_step": flop}
+    print(json.dumps(out), file=RESULT_OUT, flush=True)
+
+
 def main():
     global RESULT_OUT
     RESULT_OUT = _claim_stdout()
@@ -365,6 +429,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-mode", type=int, default=0, help="0 auto, 1 LDS tiles, 2 wave tiles (morl_ac_set_gemm_mode)")
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--devices", type=int, default=1,
+                    help="morld in ONE process: the population split over this many device contexts (MORLD(devices=[...]): pop / N "
+                         "learners per ACEngine, one context per visible GPU -- all on cuda:0 when the box has fewer, and the record "
+                         "says how many distinct GPUs it really used)")
     ap.add_argument("--force-dp", action="store_true",
                     help="capql on ONE rank through the data-parallel path (gradient hook + RCCL all-reduce with itself)")
     a = ap.parse_args()
@@ -401,6 +469,10 @@ def main():
         pop = pop // world                       # this rank's learners
     algo = {"capql": ALGO_CAPQL, "mosac": ALGO_MOSAC, "morld": ALGO_MOSAC, "gpipd": ALGO_TD3}[wl]
     rows = 2 * B if wl == "gpipd" else B
+    if a.devices > 1:
+        if wl != "morld" or world > 1:
+            raise SystemExit("--devices N is the single-process MORL/D population over N device contexts")
+        return bench_morld_contexts(a, D, Ad, R, pop, rows, shp)
     eng = ACEngine(algo, D, Ad, R, ARCH, action_low=-1.0, action_high=1.0, max_rows=rows, population=pop, device=dev,
                    q_layer_norm=(wl == "gpipd"), q_drop_rate=(0.01 if wl == "gpipd" else 0.0), device_steps=True)
     eng.lib.check(eng.lib.lib.morl_ac_set_gemm_mode(a.gemm_mode))

@@ -76,7 +76,9 @@ class Policy:
 
 
 class MORLD(MOAgent):
-    """MORL/D (Felten et al., JAIR 2024) with MOSAC sub-problem learners on one MI355X."""
+    """MORL/D (Felten et al., JAIR 2024) with MOSAC sub-problem learners on one MI355X, or -- ``devices=[...]`` -- with the population
+    split over several device contexts (BASELINE config 5: 64 decomposition weights over the 8 MI355X of a node; ``morld.py:423-433``
+    updates the sub-problems independently, so the split needs no exchange: SURVEY 8(e) "replicas only")."""
 
     def __init__(self, env, scalarization_method: str = "ws", evaluation_mode: str = "ser", policy_name: str = "MOSAC",
                  policy_args: dict = {}, gamma: float = 0.995, pop_size: int = 6, seed: int = 42,
@@ -86,7 +88,8 @@ class MORLD(MOAgent):
                  weight_init_method: str = "uniform", weight_adaptation_method: Optional[str] = None,
                  project_name: str = "MORL-Baselines", experiment_name: str = "MORL-D",
                  wandb_entity: Optional[str] = None, log: bool = True, device: Union[th.device, str] = "auto",
-                 weights: Optional[np.ndarray] = None, lib: Optional[NativeLib] = None):
+                 weights: Optional[np.ndarray] = None, lib: Optional[NativeLib] = None,
+                 devices: Optional[List[Union[th.device, str]]] = None):
         self.env = env
         super().__init__(self.env, device, seed=seed)
         self.gamma, self.seed = gamma, seed
@@ -123,30 +126,49 @@ class MORLD(MOAgent):
         self.project_name, self.experiment_name, self.log = project_name, experiment_name, log
         self.policy_name, self.policy_args = policy_name, dict(policy_args)
         self.lib = lib or load_library()
-        # ---- one engine for the whole population; members are slices of it ------------------------------------------------
+        # ---- one engine per device context for its share of the population; members are slices of it ----------------------
+        # ``devices`` = G contexts (BASELINE config 5: the 64 sub-problems over the 8 MI355X of a node): member i lives in context
+        # g = i * G // pop_size -- contiguous shares of pop_size / G learners, each an ACEngine(population = share) on its device.
+        # The sub-problems are independent (morld.py:423-433 updates them one after the other), so nothing is exchanged between
+        # the contexts during updates: every device's launches are enqueued on its own stream and run side by side; the host only
+        # merges the members' evaluations into the ParetoArchive (and copies a neighbour's actor across devices in _share).  One
+        # context (the default: ``device``) is the single population engine of before; G contexts on ONE device give the same
+        # learners bit for bit (tests/test_ac_agents.py).
         a = self.policy_args
         arch = a.get("net_arch", [256, 256])
         self.batch_size = a.get("batch_size", 128)
         D = int(np.prod(env.observation_space.shape))
         self.discrete = policy_name == "MOSACDiscrete"
-        if self.discrete:
-            self.engine = ACEngine(ALGO_SACD, D, int(env.action_space.n), self.reward_dim, arch, action_low=0.0,
-                                   action_high=1.0, max_rows=self.batch_size, population=pop_size, device=self.device,
-                                   lib=self.lib, device_steps=True)
-        else:
-            Ad = int(np.prod(env.action_space.shape))
-            self.engine = ACEngine(ALGO_MOSAC, D, Ad, self.reward_dim, arch, action_low=np.asarray(env.action_space.low),
-                                   action_high=np.asarray(env.action_space.high), max_rows=self.batch_size,
-                                   population=pop_size, device=self.device, lib=self.lib, device_steps=True)
+        self.devices = [th.device(d) for d in devices] if devices else [th.device(self.device)]
+        G = len(self.devices)
+        if G > pop_size:
+            raise ValueError(f"{G} device contexts for a population of {pop_size}")
+        bounds = [k * pop_size // G for k in range(G + 1)]
+        self._where = [None] * pop_size                  # member id -> (context, index inside its engine)
+        self.engines = []
+        for g, dev in enumerate(self.devices):
+            n_g = bounds[g + 1] - bounds[g]
+            for k in range(n_g):
+                self._where[bounds[g] + k] = (g, k)
+            if self.discrete:
+                eng = ACEngine(ALGO_SACD, D, int(env.action_space.n), self.reward_dim, arch, action_low=0.0, action_high=1.0,
+                               max_rows=self.batch_size, population=n_g, device=dev, lib=self.lib, device_steps=True)
+            else:
+                Ad = int(np.prod(env.action_space.shape))
+                eng = ACEngine(ALGO_MOSAC, D, Ad, self.reward_dim, arch, action_low=np.asarray(env.action_space.low),
+                               action_high=np.asarray(env.action_space.high), max_rows=self.batch_size, population=n_g,
+                               device=dev, lib=self.lib, device_steps=True)
+            self.engines.append(eng)
+        self.engine = self.engines[0]                    # (the whole population when there is one context)
         learner = MOSACDiscrete if self.discrete else MOSAC
         self.current_policy = 0
         self.population = [
             Policy(id=i, weights=w,
                    wrapped=learner(id=i, env=self.env, weights=w, scalarization=th.matmul, gamma=gamma, log=self.log,
-                                   seed=self.seed, parent_rng=self.np_random, device=self.device, lib=self.lib,
-                                   engine=self.engine.member(i), **self.policy_args))
+                                   seed=self.seed, parent_rng=self.np_random, device=self.devices[self._where[i][0]], lib=self.lib,
+                                   engine=self.engines[self._where[i][0]].member(self._where[i][1]), **self.policy_args))
             for i, w in enumerate(self.weights)]
-        self.archive = ParetoArchive()
+        self.archive = ParetoArchive(lib=self.lib, device=self.devices[0] if self.lib.is_device_build else None)
         self._update_neighborhoods()
         if self.log:
             self.setup_wandb(project_name=self.project_name, experiment_name=self.experiment_name, entity=wandb_entity)
@@ -160,7 +182,8 @@ class MORLD(MOAgent):
                 "shared_buffer": self.shared_buffer, "update_passes": self.update_passes, "transfer": self.transfer,
                 "weight_init_method": self.weight_init_method, "weight_adapt_method": self.weight_adaptation_method,
                 "delta_adapt": self.delta, "project_name": self.project_name, "experiment_name": self.experiment_name,
-                "seed": self.seed, "log": self.log, "device": self.device, "policy_name": self.policy_name,
+                "seed": self.seed, "log": self.log, "device": self.device, "devices": [str(d) for d in self.devices],
+                "policy_name": self.policy_name,
                 **self.population[0].wrapped.get_config(), **self.policy_args}
 
     # -- population plumbing (morld.py:245-330) ---------------------------------------------------------------------------
@@ -219,12 +242,15 @@ class MORLD(MOAgent):
         """``morld.py`` ``__share``: copy the trained actor to not-yet-trained neighbours (first sweep only)."""
         if self.transfer and self.iteration == 0:
             src = last_trained.id
+            gs, ks = self._where[src]
             for n in self.neighborhoods[src]:
                 if n > src:
-                    self.engine.pol[n].copy_(self.engine.pol[src])
-                    self.engine.pol_exp_avg[n].zero_()            # the reference re-creates the neighbour's optimiser
-                    self.engine.pol_exp_avg_sq[n].zero_()
-                    self.engine.pol_steps[n] = 0
+                    gn, kn = self._where[n]
+                    en = self.engines[gn]
+                    en.pol[kn].copy_(self.engines[gs].pol[ks])    # (across devices when the neighbour lives in another context)
+                    en.pol_exp_avg[kn].zero_()                    # the reference re-creates the neighbour's optimiser
+                    en.pol_exp_avg_sq[kn].zero_()
+                    en.pol_steps[kn] = 0
                     self.population[n].wrapped._p_step = 0
 
     def _adapt_weights(self, evals: List[np.ndarray]):
@@ -262,19 +288,28 @@ class MORLD(MOAgent):
             if k == len(ids) or ids[k] != ids[k - 1] + 1:
                 runs.append(ids[start:k])
                 start = k
-        e = self.engine
+        e0 = self.engines[0]
         ref = members[0].wrapped
+
+        def pieces(run):
+            """A run of consecutive member ids cut at the context boundaries: (context, ids, offset inside the run)."""
+            out, a0 = [], 0
+            for k in range(1, len(run) + 1):
+                if k == len(run) or self._where[run[k]][0] != self._where[run[a0]][0]:
+                    out.append((self._where[run[a0]][0], run[a0:k], a0))
+                    a0 = k
+            return out
+
         for _ in range(self.update_passes):
             batches = {p.id: p.wrapped.update_inputs() for p in members}      # population order: reference RNG stream
             for run in runs:
                 n, B = len(run), ref.batch_size
-                stack = lambda k_: th.stack([batches[i][k_] for i in run])  # noqa: E731
                 cfg = ref.make_cfg()
-                w = th.stack([self.population[i].wrapped.weights_tensor for i in run])
-                if self.discrete:
-                    e.update(cfg, obs=stack(0), actions=stack(1), rewards=stack(2), next_obs=stack(3), dones=stack(4), w=w,
-                             want=(), first=run[0], count=n)
-                else:
+                eps = None
+                if not self.discrete:
+                    # the run's noise is drawn ONCE, in population order, on the first context's device -- whatever the number of
+                    # contexts, the learners see the draws a single population engine would have handed them
+                    e = e0
                     pf = ref.policy_freq
                     if noise_device(e.q.device).type == "cpu":
                         # host generator: one call per tensor in the order of the reference's sequential updates (learner by
@@ -291,9 +326,20 @@ class MORLD(MOAgent):
                         eps = eps.to(e.q.device)
                     else:
                         eps = randn((1 + 2 * pf, n, B, e.Ad), e.q.device)
-                    e.update(cfg, obs=stack(0), actions=stack(1), rewards=stack(2), next_obs=stack(3), dones=stack(4), w=w,
-                             eps_next=eps[0], eps_pi=eps[1:1 + ref.policy_freq], eps_alpha=eps[1 + ref.policy_freq:],
-                             want=(), first=run[0], count=n)
+                for g, ids, off in pieces(run):
+                    e = self.engines[g]
+                    stack = lambda k_: th.stack([batches[i][k_] for i in ids])  # noqa: E731
+                    w = th.stack([self.population[i].wrapped.weights_tensor for i in ids])
+                    first, m = self._where[ids[0]][1], len(ids)
+                    if self.discrete:
+                        e.update(cfg, obs=stack(0), actions=stack(1), rewards=stack(2), next_obs=stack(3), dones=stack(4), w=w,
+                                 want=(), first=first, count=m)
+                    else:
+                        ep = eps[:, off:off + m].to(e.q.device) if (len(self.engines) > 1) else eps
+                        pf = ref.policy_freq
+                        e.update(cfg, obs=stack(0), actions=stack(1), rewards=stack(2), next_obs=stack(3), dones=stack(4), w=w,
+                                 eps_next=ep[0].contiguous(), eps_pi=ep[1:1 + pf].contiguous(), eps_alpha=ep[1 + pf:].contiguous(),
+                                 want=(), first=first, count=m)
                 for i in run:
                     self.population[i].wrapped.note_update(True if self.discrete else bool(cfg.do_policy))
 

@@ -360,6 +360,65 @@ def test_morld_population_update(be):
     assert got == [(0.0, 1.0), (0.6, 0.6), (1.0, 0.0)]
 
 
+@pytest.mark.parametrize("contexts,pop", [(2, 5), (3, 6)])
+def test_morld_population_over_device_contexts_equals_one_population(be, contexts, pop):
+    """``MORLD(devices=[...])`` (BASELINE config 5: the population split over the GPUs of a node): G contexts on ONE device give the
+    learners of the single population engine bit for bit -- parameters, targets, Adam moments, step counters, entropy coefficients --
+    through ``__update_others`` (``morld.py:423-433``) with a member skipped in the middle of a context, and ``_share``'s actor
+    transfer across a context boundary; the archive merges the members' evaluations on the host."""
+    lib, dev = be
+    env = BoxEnv(D=4, Ad=2)
+
+    def make(devices):
+        th.manual_seed(0)
+        np.random.seed(0)
+        random.seed(0)
+        if dev.type == "cuda":
+            th.cuda.manual_seed(0)
+        algo = MORLD(env, pop_size=pop, policy_args=dict(net_arch=[16, 16], batch_size=8, buffer_size=64), update_passes=2,
+                     shared_buffer=False, exchange_every=10, log=False, seed=3, device=dev, lib=lib, devices=devices,
+                     sharing_mechanism=["transfer"])
+        for k, p in enumerate(algo.population):
+            fill_buffer(p.wrapped.get_buffer(), 30, 4, 2, 2, seed=k)
+            p.wrapped.global_step = 10
+        return algo
+
+    one, many = make(None), make([dev] * contexts)
+    assert len(one.engines) == 1 and len(many.engines) == contexts
+    assert sum(e.pop for e in many.engines) == pop and [g for g, _ in many._where] == sorted(g for g, _ in many._where)
+    assert many.population[pop - 1].wrapped.engine.q.data_ptr() == many.engines[-1].q[many._where[pop - 1][1]].data_ptr()
+
+    def state(algo):
+        out = {}
+        for k in ("q", "q_target", "q_exp_avg", "q_exp_avg_sq", "pol", "pol_exp_avg", "pol_exp_avg_sq", "log_alpha", "q_steps", "pol_steps"):
+            out[k] = th.cat([getattr(e, k).reshape(e.pop, -1).cpu() for e in algo.engines])
+        return out
+
+    a0, b0 = state(one), state(many)
+    assert all(th.equal(a0[k], b0[k]) for k in a0)                       # the members initialise their own slices: same start
+    snap = rng_snapshot(dev)                                             # both runs consume the same host / device generators
+    one._update_others(one.population[1])
+    rng_restore(snap, dev)
+    many._update_others(many.population[1])
+    if dev.type == "cuda":
+        th.cuda.synchronize()
+    a1, b1 = state(one), state(many)
+    for k in a1:
+        assert th.equal(a1[k], b1[k]), k
+    assert not th.equal(a1["q"], a0["q"]) and a1["q_steps"].reshape(-1).tolist() == [2, 0] + [2] * (pop - 2)
+    # actor transfer across the boundary between two contexts
+    src = many._where.index((1, 0)) - 1                                  # last member of context 0 ...
+    for algo in (one, many):
+        algo.neighborhoods[src] = [src + 1]                              # ... hands its actor to the first member of context 1
+        algo._share(algo.population[src])
+    a2, b2 = state(one), state(many)
+    assert all(th.equal(a2[k], b2[k]) for k in a2) and th.equal(b2["pol"][src + 1], b2["pol"][src])
+    for k, ev in enumerate([[1.0, 0.0], [0.0, 1.0], [0.4, 0.4], [0.6, 0.6]]):
+        many.archive.add(many.population[k], np.array(ev))
+    assert sorted(tuple(np.round(x, 3)) for x in many.archive.evaluations) == [(0.0, 1.0), (0.6, 0.6), (1.0, 0.0)]
+    assert many.get_config()["devices"] == [str(dev)] * contexts
+
+
 def test_simplex_lattice_weights():
     for dim, n in ((2, 6), (3, 6), (3, 64), (4, 10)):
         w = simplex_lattice_weights(dim, n)
