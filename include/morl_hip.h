@@ -182,14 +182,15 @@ int morl_envelope_prepare(morl_ctx* ctx, const float* params_online, const float
  * therefore runs: forward launch with the online next-state pass and the training pass -> arg-max over the online slab, the
  * distinct (b, j*) pairs taking compact rows in the same launch -> the target network on THOSE rows (16-row tiles, device-side
  * row count) -> TD target / loss gradient.  Same values as the eager form (a row's Q does not depend on which rows share its
- * tile); the eager form runs when the caller asks for out->q_target_next, for the DDQN target, in the weight-sharded step, on the
- * per-layer engine and for steps of fewer than 8 192 TD rows (latency-bound: measured slower lazily; MORL_LAZY_MIN_ROWS overrides).
+ * tile); the eager form runs when the caller asks for out->q_target_next, for the DDQN target, on the
+ * per-layer engine and for small steps (latency-bound: measured slower lazily): fewer than 4 096 TD rows on the bf16 matrix cores, 8 192
+ * on the f32 chains and in the weight-sharded rank step (MORL_LAZY_MIN_ROWS overrides).
  * _set_lazy_targets: 0 always eager, 1 (default) lazy from that row count on, 2 lazy at every size (what smoke() and the small
  * fixtures use to put the default pipeline of large steps under the oracle); returns the previous setting; _lazy_target_rows the rows the last lazy step evaluated -- its distinct pairs
  * (with more than 64 weight vectors a transition's TD rows span several workgroups, and a pair selected from two of them is
  * listed, and evaluated, once per workgroup); 0 if the last step ran eagerly.  Synchronises `stream`. */
 int morl_ctx_set_lazy_targets(morl_ctx* ctx, int enable);
-/* Arithmetic of the big launches of morl_envelope_update (steps of >= 8 192 TD rows -- MORL_BF_MIN_ROWS -- on networks whose hidden
+/* Arithmetic of the big launches of morl_envelope_update (steps of >= 4 096 TD rows, a weight-sharded rank's from 8 192 -- MORL_BF_MIN_ROWS -- on networks whose hidden
  * layers are 256 wide, head <= 32 columns, input <= 64): by default the two ONLINE forward passes (QNet.forward, envelope.py:300,
  * :420) and the dX half of the backward pass (:323) run on the bf16 matrix cores, every fp32 product evaluated as six products of
  * three-way bf16 splits accumulated in fp32 (csrc/mlp_chain_bf.h: exact split of every finite fp32, fp32-class result: max

@@ -396,7 +396,19 @@ struct LnGradArgs {
 
 constexpr int COLRED_WAVES = 16;
 
-__global__ __launch_bounds__(64 * COLRED_WAVES) void ac_ln_grad_kernel(LnGradArgs a) {
+__device__ __forceinline__ void ac_ln_grad_body(const LnGradArgs& a);
+__global__ __launch_bounds__(64 * COLRED_WAVES) void ac_ln_grad_kernel(LnGradArgs a) { ac_ln_grad_body(a); }
+// every hidden layer of a network in one launch (blockIdx.z = layer): the layer-fused backward of a LayerNorm net (mlp_chain16.h)
+// leaves all the layers' dLoss/dh behind at once
+struct LnGradMulti {
+    LnGradArgs a[MORL_MAX_LAYERS];
+    int n;
+};
+__global__ __launch_bounds__(64 * COLRED_WAVES) void ac_ln_grad_multi_kernel(LnGradMulti m) {
+    if ((int)blockIdx.z < m.n && (int)blockIdx.x * 64 < m.a[blockIdx.z].N) ac_ln_grad_body(m.a[blockIdx.z]);
+}
+
+__device__ __forceinline__ void ac_ln_grad_body(const LnGradArgs& a) {
     __shared__ float s_g[COLRED_WAVES][64], s_b[COLRED_WAVES][64];
     const int lane = lane_id(), wave = wave_id();
     const int c = (int)blockIdx.x * 64 + lane, g = (int)blockIdx.y;

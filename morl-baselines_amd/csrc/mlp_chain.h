@@ -69,6 +69,37 @@ struct ChainArgs {
     int fast;               // mlp_chain2: every wide step has ldb == 256 and kpad a multiple of 64 (constant-stride weight stream)
 };
 
+// Post-op of a hidden layer of a LayerNorm / Dropout network (common/networks.py:10-48: Linear -> [Dropout] -> [LayerNorm] -> ReLU)
+// carried by the 16-row chain (mlp_chain16.h, ChainPostSet): what ac_post_fwd_kernel / ac_post_bwd_kernel of ac_kernels.h do in
+// launches of their own, on the tile's rows while they are in LDS.  A 16-row tile holds WHOLE rows (<= 256 columns), so the row
+// statistics are one wave's work: wave w takes rows 4w .. 4w+3, lane <-> columns lane + 64 j -- the very arithmetic, in the very
+// order, of the per-layer kernels (bit-identical given the same Linear output).
+//   forward  (mode 1): z = Linear output (in LDS) -> keep mask, dropped z, mean / rstd, xhat -> HBM (what the backward needs),
+//                      h = relu(xhat * gamma + beta) -> LDS (the next step's input; the chain's deferred copy takes it to st.out)
+//   backward (mode 2): dh = dLoss/dh (in LDS, the dX step's output) -> HBM copy for the LayerNorm affine gradients
+//                      (ac_ln_grad_kernel reads dh, h, xhat), dz = LN' / Dropout' of relu'(dh) -> LDS (next step's input, st.out)
+struct ChainPost {
+    float* xhat;              // [G][cap][ld]  forward: out; backward: in
+    float* rstd;              // [G][cap]
+    uint8_t* mask;            // [G][cap][N] keep flags, or NULL (no dropout in this pass)
+    const uint8_t* ext_mask;  // forward: explicit keep flags [G][rows][N] (parity tests) or NULL -> counter-based RNG
+    const float* gamma;       // params + offset of the layer's LayerNorm weight (beta follows at +N), or NULL (no LayerNorm)
+    const float* h;           // backward: [G][cap][ld] the forward's post-ReLU activation
+    float* dh_out;            // backward: [G][cap][ld] copy of dLoss/dh, or NULL
+    unsigned long long seed;  // forward, counter-based RNG
+    long long gstride;        // floats between the nets' rows in xhat / h / dh_out (cap * ld)
+    int ld;                   // row stride of xhat / h / dh_out
+    int active;               // 0: this step has no post-op (the output layer; a backward chain's last step)
+    int drop;                 // dropout active in this pass
+};
+struct ChainPostSet {
+    ChainPost st[MORL_MAX_LAYERS];
+    long long pstride;        // floats between the nets' parameters
+    long long ext_gstride;    // bytes between the nets' explicit masks
+    int cap;                  // row capacity of the tape (stride of rstd / mask)
+    float drop_p, inv_keep;
+};
+
 constexpr int CH_OOB = 0x40000000;   // byte offset beyond any matrix (forces the out-of-range zero of a buffer access)
 constexpr int CH_MAX_MULTI = 3;      // independent chains per launch (the three forward passes of an Envelope step)
 

@@ -118,9 +118,130 @@ struct C16NoHook {
     __device__ __forceinline__ void operator()(int, int, float (&)[16]) const {}
 };
 
+// ---- the post-op stages of LayerNorm / Dropout networks (ChainPost of mlp_chain.h) on the tile's rows in LDS ------------------
+// splitmix64 finaliser -> uniform in [0, 1): ac_kernels.h's ac_uniform (same bits: the keep masks of the per-layer path)
+__device__ __forceinline__ float c16_uniform(unsigned long long seed, unsigned long long idx) {
+    unsigned long long x = seed + idx * 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (float)(x >> 40) * (1.0f / 16777216.0f);
+}
+
+constexpr int C16_POSTJ = CH_MAXW / 64;      // columns per lane: lane + 64 j
+
+// forward: wave w, rows 4w .. 4w+3 -- ac_post_fwd_body's arithmetic on sAct[m][0 .. N)
+__device__ __forceinline__ void c16_post_fwd(const ChainPostSet& ps, const ChainPost& a, float* sAct, int row0, int n_rows, int N, int g) {
+    const int lane = lane_id(), wave = wave_id();
+    const float* __restrict__ gam = a.gamma ? a.gamma + (long long)g * ps.pstride : nullptr;
+    for (int q = 0; q < 4; ++q) {
+        const int m = wave * 4 + q, row = row0 + m;
+        if (row >= n_rows) continue;                                   // (wave-uniform)
+        float* zr = sAct + m * C2_LDK;
+        float* __restrict__ xh_out = a.xhat + (long long)g * a.gstride + (long long)row * a.ld;
+        float v[C16_POSTJ];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < C16_POSTJ; ++j) {
+            const int c = lane + 64 * j;
+            float x = 0.f;
+            if (c < N) {
+                x = zr[c];
+                if (a.drop) {
+                    bool keep;
+                    if (a.ext_mask) keep = a.ext_mask[(long long)g * ps.ext_gstride + (long long)row * N + c] != 0;
+                    else keep = c16_uniform(a.seed, ((unsigned long long)g * ps.cap + row) * N + c) >= ps.drop_p;
+                    a.mask[((long long)g * ps.cap + row) * N + c] = keep ? 1 : 0;
+                    x = keep ? x * ps.inv_keep : 0.f;
+                }
+                sum += x;
+            }
+            v[j] = x;
+        }
+        if (!gam) {                                                    // Dropout only (its backward needs the keep mask and h, nothing else)
+#pragma unroll
+            for (int j = 0; j < C16_POSTJ; ++j) {
+                const int c = lane + 64 * j;
+                if (c < N) zr[c] = fmaxf(v[j], 0.f);
+            }
+            continue;
+        }
+        const float mean = wave_sum(sum) / (float)N;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < C16_POSTJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < N) { const float d = v[j] - mean; sq += d * d; }
+        }
+        const float var = wave_sum(sq) / (float)N;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        if (lane == 0) a.rstd[(long long)g * ps.cap + row] = rstd;
+        const float* __restrict__ bet = gam + N;
+#pragma unroll
+        for (int j = 0; j < C16_POSTJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < N) {
+                const float xh = (v[j] - mean) * rstd;
+                xh_out[c] = xh;
+                zr[c] = fmaxf(xh * gam[c] + bet[c], 0.f);
+            }
+        }
+    }
+}
+
+// backward: ac_post_bwd_kernel's arithmetic on sAct[m][0 .. N) = dLoss/dh -> dLoss/dz; dLoss/dh also goes to a.dh_out
+__device__ __forceinline__ void c16_post_bwd(const ChainPostSet& ps, const ChainPost& a, float* sAct, int row0, int n_rows, int N, int g) {
+    const int lane = lane_id(), wave = wave_id();
+    const float* __restrict__ gam = a.gamma ? a.gamma + (long long)g * ps.pstride : nullptr;
+    for (int q = 0; q < 4; ++q) {
+        const int m = wave * 4 + q, row = row0 + m;
+        if (row >= n_rows) continue;
+        float* dr = sAct + m * C2_LDK;
+        const long long base = (long long)g * a.gstride + (long long)row * a.ld;
+        float dxh[C16_POSTJ], xh[C16_POSTJ];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < C16_POSTJ; ++j) {
+            const int c = lane + 64 * j;
+            float t = 0.f, x = 0.f;
+            if (c < N) {
+                const float d = dr[c];
+                if (a.dh_out) a.dh_out[base + c] = d;
+                t = (a.h[base + c] > 0.f) ? d : 0.f;                   // ReLU
+                if (gam) {
+                    x = a.xhat[base + c];
+                    t *= gam[c];
+                    s1 += t;
+                    s2 += t * x;
+                }
+            }
+            dxh[j] = t;
+            xh[j] = x;
+        }
+        float m1 = 0.f, m2 = 0.f, rstd = 1.f;
+        if (gam) {
+            m1 = wave_sum(s1) / (float)N;
+            m2 = wave_sum(s2) / (float)N;
+            rstd = a.rstd[(long long)g * ps.cap + row];
+        }
+#pragma unroll
+        for (int j = 0; j < C16_POSTJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < N) {
+                float t = dxh[j];
+                if (gam) t = rstd * (t - m1 - xh[j] * m2);
+                if (a.drop) t = a.mask[((long long)g * ps.cap + row) * N + c] ? t * ps.inv_keep : 0.f;
+                dr[c] = t;
+            }
+        }
+    }
+}
+
 // one 16-row tile (rows [row0, row0 + 16) of network g) through the whole chain; K4: the weight layout of ChainArgs::fast == 1
-template <bool K4, class Hook = C16NoHook>
-__device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, float* sAct, int g, const Hook& hook = Hook()) {
+// POST: 0 plain; 1 / 2: the hidden steps of a LayerNorm / Dropout network carry their post-op (forward / backward: `ps`)
+template <bool K4, class Hook = C16NoHook, int POST = 0>
+__device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, float* sAct, int g, const Hook& hook = Hook(),
+                                                const ChainPostSet* ps = nullptr) {
     constexpr int N_PIECES = 4;                       // 16 rows x 64 quads / 256 threads
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_id();
     const int n_rows = p.rows_dev ? min(p.rows, *p.rows_dev) : p.rows;        // (device-side count: in_mode 3)
@@ -364,6 +485,15 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
             C16_T(5)
         }
         __syncthreads();
+        if constexpr (POST != 0) {
+            // the step's output rows are complete in LDS: their post-op, then the same barrier again (the next step's operand reads,
+            // and the deferred copy to st.out, see what the post-op left)
+            if (ps->st[s].active && N > 32) {
+                if (POST == 1) c16_post_fwd(*ps, ps->st[s], sAct, row0, n_rows, N, g);
+                else c16_post_bwd(*ps, ps->st[s], sAct, row0, n_rows, N, g);
+                __syncthreads();
+            }
+        }
         C16_T(4)
     }
     if (do_copy)
@@ -400,6 +530,27 @@ static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain16_kernel(Chain
     if (m.p[q].rows_dev != nullptr && lt * C16_TM >= *m.p[q].rows_dev) return;      // (workgroup-uniform)
     if (m.p[q].fast == 1) mlp_chain16_body<true>(m.p[q], lt * C16_TM, sAct, g);
     else mlp_chain16_body<false>(m.p[q], lt * C16_TM, sAct, g);
+}
+
+// the same launch for LayerNorm / Dropout networks: chain q's hidden steps carry their post-op (one ChainPostSet per chain; at most
+// two chains: paired forward passes)
+struct Chain16PostMulti {
+    ChainArgs p[2];
+    ChainPostSet ps[2];
+    int tile_start[3];
+    int n;
+};
+
+template <int POST>
+static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain16_post_kernel(Chain16PostMulti m) {
+    __shared__ __attribute__((aligned(16))) float sAct[C16_TM * C2_LDK + 16];
+    const int b = (int)blockIdx.x;
+    const int q = (m.n > 1 && b >= m.tile_start[1]) ? 1 : 0;
+    int lt = b - m.tile_start[q], g = 0;
+    const int tpn = (m.p[q].rows + C16_TM - 1) / C16_TM;          // tiles per network
+    if (m.p[q].nb > 1) { g = lt / tpn; lt -= g * tpn; }
+    if (m.p[q].fast == 1) mlp_chain16_body<true, C16NoHook, POST>(m.p[q], lt * C16_TM, sAct, g, C16NoHook(), &m.ps[q]);
+    else mlp_chain16_body<false, C16NoHook, POST>(m.p[q], lt * C16_TM, sAct, g, C16NoHook(), &m.ps[q]);
 }
 
 // Host side: which launches take the 16-row tiles, and the tile table.  The choice must be the same for a forward pass and

@@ -58,6 +58,8 @@ struct Tape {
     float* zx[MORL_MAX_LAYERS] = {};             // Linear output -> xhat (LayerNorm / Dropout nets only)
     float* rstd[MORL_MAX_LAYERS] = {};
     uint8_t* mask[MORL_MAX_LAYERS] = {};
+    float* dh[MORL_MAX_LAYERS] = {};             // dLoss/dh of the hidden layers as the layer-fused backward of a LayerNorm net leaves
+                                                 // it for ac_ln_grad_kernel (the per-layer path reads it from g[] before the post-op)
     float* out = nullptr;                        // [G][cap][ld[L]]
     float* g[MORL_MAX_LAYERS] = {};              // dLoss/dz of every linear layer
     float* dx = nullptr;                         // [G][cap][ld0]
@@ -122,6 +124,7 @@ static int alloc_tape(std::vector<void*>& c, const Mlp& m, Tape& t, int G, int x
             }
             if (post) {
                 if ((rc = alloc_f(c, &t.zx[l], n))) return rc;
+                if (m.ln && (rc = alloc_f(c, &t.dh[l], n))) return rc;
                 if ((rc = alloc_f(c, &t.rstd[l], (size_t)G * cap))) return rc;
                 float* mk = nullptr;
                 if ((rc = alloc_f(c, &mk, ((size_t)G * cap * m.dims[l + 1] + 3) / 4))) return rc;
@@ -421,6 +424,21 @@ static ChainArgs ac_forward_chain(const Mlp& m, const float* params, const float
     return a;
 }
 
+// ---- LayerNorm / Dropout networks on the 16-row chain (mlp_chain16.h: mlp_chain16_post_kernel) ------------------------------------
+// The hidden layers' post-ops (Dropout -> LayerNorm -> ReLU, common/networks.py:10-48) run on the tile's rows in LDS, so a pass is ONE
+// launch instead of a GEMM + a post-op (+ a LayerNorm-gradient) launch per layer: GPI-PD's critics (gpi_pd.py:41-76,
+// gpi_pd_continuous_action.py:60-73).  MORL_AC_LN_CHAIN: bit 0 forward passes, bit 1 backward passes (default 3; 0 = the per-layer
+// launches, the A/B leg of tests/test_ln_chain.py).
+static const int g_ac_ln_chain = [] { const char* e = getenv("MORL_AC_LN_CHAIN"); return e ? atoi(e) : 3; }();
+static bool chain_post_ok(const Mlp& m, long long rows_x_nets) {
+    if (!g_ac_chain || !(m.ln || m.drop > 0.f) || m.L < 2 || m.L > MORL_MAX_LAYERS) return false;
+    if (m.dims[0] > CH_MAXW) return false;
+    for (int l = 1; l < m.L; ++l)
+        if (m.dims[l] > CH_MAXW || m.dims[l] <= 32 || (m.dims[l] & 3)) return false;
+    if (m.dims[m.L] > CH_MAXW || (m.dims[m.L] > 32 && (m.dims[m.L] & 3))) return false;
+    return ac_rows_take_chain16(rows_x_nets);          // (the post-op stages exist on the 16-row tiles only)
+}
+
 struct DropSpec {
     bool active = false;              // train-mode dropout
     const uint8_t* ext = nullptr;     // explicit masks of this phase: [G][per_net bytes]
@@ -449,6 +467,46 @@ static int mlp_forward(const Mlp& m, const float* params, int64_t pstride, Tape&
         if (rc) return rc;
         t.bits_valid = true;
         if (t2) t2->bits_valid = true;
+        return MORL_OK;
+    }
+    // LayerNorm / Dropout networks with a K-major shadow copy, few enough rows for the 16-row tiles: the whole pass (both passes of
+    // a pair) as ONE chain launch whose hidden steps carry their post-op (mlp_chain16.h: c16_post_fwd)
+    if ((g_ac_ln_chain & 1) && wt != nullptr && chain_post_ok(m, (long long)rows * t.G)) {
+        Chain16PostMulti pm{};
+        pm.n = t2 ? 2 : 1;
+        int tiles = 0;
+        for (int pass = 0; pass < pm.n; ++pass) {
+            Tape& tt = pass ? *t2 : t;
+            const DropSpec& dd = pass ? *ds2 : ds;
+            const float* pp = pass ? params2 : params;
+            ChainArgs ch = ac_forward_chain(m, pp, pass ? wt2 : wt, pstride, tt, rows, x_div);
+            ChainPostSet& ps = pm.ps[pass];
+            const bool drop = dd.active && m.drop > 0.f;
+            ps.pstride = pstride; ps.ext_gstride = dd.ext_net_bytes; ps.cap = tt.cap;
+            ps.drop_p = m.drop; ps.inv_keep = 1.0f / (1.0f - m.drop);
+            int64_t ext_off = 0;
+            for (int l = 0; l < m.L - 1; ++l) {
+                ChainStep& st = ch.step[l];
+                st.relu = 0;                       // (the post-op applies it, after Dropout / LayerNorm)
+                st.bits_out = nullptr;             // (the backward of these nets reads h, not sign bits)
+                ChainPost& a = ps.st[l];
+                a.active = (m.ln || drop) ? 1 : 0;
+                if (!a.active) { st.relu = 1; continue; }
+                a.xhat = tt.zx[l]; a.rstd = tt.rstd[l]; a.mask = drop ? tt.mask[l] : nullptr;
+                a.ext_mask = (drop && dd.ext) ? dd.ext + ext_off : nullptr;
+                a.gamma = m.ln ? pp + m.offG[l] : nullptr;
+                a.seed = dd.seed * 0x100000001B3ull + (unsigned long long)(l + 1) * 0x9E3779B97F4A7C15ull;
+                a.gstride = cap * m.ld[l + 1]; a.ld = m.ld[l + 1];
+                a.drop = drop ? 1 : 0;
+                ext_off += (int64_t)rows * m.dims[l + 1];
+            }
+            pm.p[pass] = ch;
+            pm.tile_start[pass] = tiles;
+            tiles += std::max(1, ch.nb) * ((ch.rows + C16_TM - 1) / C16_TM);
+        }
+        for (int q = pm.n; q <= 2; ++q) pm.tile_start[q] = tiles;
+        hipLaunchKernelGGL(mlp_chain16_post_kernel<1>, dim3(tiles), dim3(CH_THREADS), 0, s, pm);
+        LAUNCH_CHECK("ac_chain16_post_fwd");
         return MORL_OK;
     }
     int64_t ext_off = 0;
@@ -582,6 +640,71 @@ static int mlp_backward(const Mlp& m, const float* params, int64_t pstride, Tape
         }
     }
     if (head_pending) return fail(MORL_ERR_STATE, "mlp_backward: the head's backward pass was left to a chain that did not run");
+    // LayerNorm / Dropout networks: the dX steps with the hidden layers' post-op derivatives between them as ONE chain launch
+    // (mlp_chain16.h: c16_post_bwd), then the LayerNorm affine gradients of all layers in one launch (from the dLoss/dh copies
+    // the chain left in t.dh[])
+    if ((g_ac_ln_chain & 2) && chain_post_ok(m, (long long)rows * t.G) && (!m.ln || !grads || t.dh[0] != nullptr) && m.L - 1 >= 1) {
+        const bool drop = dropped && m.drop > 0.f;
+        const int last_l = need_dx ? 0 : 1;
+        Chain16PostMulti pm{};
+        pm.n = 1;
+        ChainArgs& a = pm.p[0];
+        a.rows = rows;
+        a.in_mode = 1;
+        a.src = t.g[m.L - 1]; a.ldsrc = m.ld[m.L]; a.K0 = m.dims[m.L];
+        a.nb = t.G; a.sSrc = cap * m.ld[m.L]; a.src_div = 1;
+        a.fast = 0;
+        ChainPostSet& ps = pm.ps[0];
+        ps.pstride = pstride; ps.cap = t.cap; ps.drop_p = m.drop; ps.inv_keep = 1.0f / (1.0f - m.drop);
+        int k = 0;
+        for (int l = m.L - 1; l >= last_l; --l, ++k) {
+            ChainStep& st = a.step[k];
+            st.Bmat = params + m.offW[l];          // [out][in]: K-major for g_l @ W_l
+            st.ldb = m.dims[l];
+            st.Bt = wt ? wt + m.offW[l] : nullptr;
+            st.ldbt = m.dims[l + 1];
+            st.K = m.dims[l + 1];
+            st.N = m.dims[l];
+            st.sW = pstride;
+            st.out = (l == 0) ? t.dx : t.g[l - 1];
+            st.ldout = m.ld[l];
+            st.sOut = cap * m.ld[l];
+            ChainPost& po = ps.st[k];
+            po.active = (l > 0 && (m.ln || drop)) ? 1 : 0;
+            if (l > 0 && !po.active) return fail(MORL_ERR_STATE, "mlp_backward: post-op chain on a layer without a post-op");
+            if (po.active) {
+                const int hl = l - 1;              // hidden layer whose post-op is differentiated
+                po.xhat = t.zx[hl]; po.rstd = t.rstd[hl]; po.mask = drop ? t.mask[hl] : nullptr; po.h = t.h[hl];
+                po.gamma = m.ln ? params + m.offG[hl] : nullptr;
+                po.dh_out = (m.ln && grads) ? t.dh[hl] : nullptr;
+                po.gstride = cap * m.ld[l]; po.ld = m.ld[l];
+                po.drop = drop ? 1 : 0;
+            }
+        }
+        a.n_steps = k;
+        pm.tile_start[0] = 0;
+        const int tiles = std::max(1, a.nb) * ((rows + C16_TM - 1) / C16_TM);
+        pm.tile_start[1] = pm.tile_start[2] = tiles;
+        if (m.dims[0] <= 32 && need_dx && !wt) return fail(MORL_ERR_STATE, "mlp_backward: a narrow first layer needs the K-major shadow copy");
+        hipLaunchKernelGGL(mlp_chain16_post_kernel<2>, dim3(tiles), dim3(CH_THREADS), 0, s, pm);
+        LAUNCH_CHECK("ac_chain16_post_bwd");
+        if (m.ln && grads) {
+            LnGradMulti lg{};
+            lg.n = m.L - 1;
+            int max_n = 0;
+            for (int hl = 0; hl < m.L - 1; ++hl) {
+                LnGradArgs& q = lg.a[hl];
+                q.d = t.dh[hl]; q.h = t.h[hl]; q.xhat = t.zx[hl];
+                q.dgamma = grads + m.offG[hl];
+                q.pstride = grad_stride; q.gstride = cap * m.ld[hl + 1];
+                q.N = m.dims[hl + 1]; q.ld = m.ld[hl + 1]; q.rows = rows;
+                max_n = std::max(max_n, q.N);
+            }
+            hipLaunchKernelGGL(ac_ln_grad_multi_kernel, dim3((max_n + 63) / 64, t.G, lg.n), dim3(64 * COLRED_WAVES), 0, s, lg);
+            LAUNCH_CHECK("ac_ln_grad_multi");
+        }
+        chain_down_to = last_l;
+    }
     for (int l = m.L - 1; l >= 0; --l) {
         if (l == 0 && !need_dx) break;
         if (chain_down_to >= 0 && l >= chain_down_to) continue;

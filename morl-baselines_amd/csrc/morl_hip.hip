@@ -221,7 +221,12 @@ struct morl_ctx {
     // stream, re-made once per optimiser step (by morl_envelope_prepare's launch, or by the step itself)
     bool bf_ok = false;                  // the architecture fits: hidden layers of 256, head <= 32 columns, input <= 64
     int bf_mode = 1;                     // 0: MORL_EXACT_F32=1 / morl_ctx_set_exact_f32 -- every GEMM on the f32-input MFMA (rounds 1-3)
-    long long bf_min_rows = 8192;        // steps of fewer TD rows stay on the fp32 chains (latency-bound; MORL_BF_MIN_ROWS)
+    long long bf_min_rows = 4096;        // steps of fewer TD rows stay on the fp32 chains (latency-bound; MORL_BF_MIN_ROWS).  The
+                                         // unsharded step (and a batch-sharded rank's) from 4 096 rows on -- 64 transitions x 64 weights:
+                                         // 0.1766 -> 0.1694 ms --, the weight-sharded rank step from 8 192 (its slab, training pass
+                                         // and target rows are separate launches: 0.2094 -> 0.2206 ms at 4 096;
+                                         // profiles/r05_rank_step_thresholds_ab.json)
+    bool bf_min_rows_env = false;        // MORL_BF_MIN_ROWS given: one threshold for every step
     unsigned char* bf_stream = nullptr;
     int bf_fwd_blocks = 0, bf_bwd_blocks = 0, bf_k0_steps = 0, bf_head_tiles = 0;
     const float* fresh_bf = nullptr;     // parameters the streams were split from by this step's morl_envelope_prepare (one-shot)
@@ -436,7 +441,7 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         ALLOC(bf_stream, (size_t)(c->bf_fwd_blocks + c->bf_bwd_blocks) * BF_BLOCK);
     }
     if (const char* e = getenv("MORL_EXACT_F32")) c->bf_mode = atoi(e) != 0 ? 0 : 1;
-    if (const char* e = getenv("MORL_BF_MIN_ROWS")) c->bf_min_rows = atoll(e);
+    if (const char* e = getenv("MORL_BF_MIN_ROWS")) { c->bf_min_rows = atoll(e); c->bf_min_rows_env = true; }
 #undef ALLOC
     *out = c;
     return MORL_OK;
@@ -580,8 +585,9 @@ static int refresh_bf_step(morl_ctx* c, const float* params_online, const float*
 
 // ---- split-bf16 chain (mlp_chain_bf.h) ------------------------------------------------------------------------------------------
 // does a gradient step over `rows` TD rows run its two online forward passes and its backward pass on the bf16 matrix cores?
-static bool bf_wanted(const morl_ctx* c, long long rows) {
-    return c->bf_ok && c->bf_mode != 0 && c->use_fused && c->fused_tm == 0 && rows >= c->bf_min_rows;
+static bool bf_wanted(const morl_ctx* c, long long rows, bool weight_shard = false) {
+    const long long min_rows = (weight_shard && !c->bf_min_rows_env) ? std::max(c->bf_min_rows, 8192ll) : c->bf_min_rows;
+    return c->bf_ok && c->bf_mode != 0 && c->use_fused && c->fused_tm == 0 && rows >= min_rows;
 }
 
 // the split jobs of the online network: forward stream (blocks [0, bf_fwd_blocks)) then backward stream
@@ -1775,7 +1781,10 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     // stage A: no-grad next-state slabs Qo, Qt [B][W][A][R] (B*W distinct rows instead of the reference's W^2*B)
     bool main_done = false;
     const bool use_bf = bf_wanted(c, rows);
-    static const long long lazy_min_rows = [] { const char* e = getenv("MORL_LAZY_MIN_ROWS"); return e ? atoll(e) : 8192ll; }();
+    // lazily from 4 096 TD rows on when the step runs on the bf16 matrix cores, from 8 192 on the f32 chains (measured there in round 3:
+    // 8 192 rows 0.255 ms lazily against 0.262 eagerly, 2 048 rows 0.181 against 0.149); MORL_LAZY_MIN_ROWS: one threshold for both
+    static const long long lazy_env = [] { const char* e = getenv("MORL_LAZY_MIN_ROWS"); return e ? atoll(e) : -1ll; }();
+    const long long lazy_min_rows = lazy_env >= 0 ? lazy_env : (use_bf ? 4096ll : 8192ll);
     if (use_bf) {
         // The two ONLINE passes (next-state slab, training pass) on the bf16 matrix cores as six split-bf16 products each
         // (mlp_chain_bf.h: fp32-class accuracy at 6/16 of the f32-input MFMA's time), one launch.  The TARGET network stays on the
@@ -2001,7 +2010,7 @@ extern "C" int morl_envelope_slab_online(morl_ctx* c, const float* params_online
     const int rows = B * W_local, AR = c->net.n_actions * c->net.reward_dim;
     timing_begin_step(c);
     c->last_step_W = W_local;
-    if (bf_wanted(c, rows)) {
+    if (bf_wanted(c, rows, true)) {
         // the rank's share is large enough for the bf16 matrix cores: split weight streams of the online network (+ the target's
         // K-major copy for the target rows), the next-state pass as one split-bf16 chain; the training pass and the backward follow
         if ((rc = refresh_bf_step(c, params_online, params_target, s))) return rc;
@@ -2048,7 +2057,7 @@ extern "C" int morl_envelope_main_forward(morl_ctx* c, const float* params_onlin
     if (!params_online || !obs || !weights_local) return fail(MORL_ERR_ARG, "NULL array");
     hipStream_t s = (hipStream_t)stream;
     const int rows = B * W_local;
-    if (c->use_fused && bf_wanted(c, rows) && c->bf_stream_src == params_online) {
+    if (c->use_fused && bf_wanted(c, rows, true) && c->bf_stream_src == params_online) {
         // the split weight streams this step's morl_envelope_slab_online made are current: the training pass on the bf16 matrix cores
         // (the backward chain and the weight gradients follow it there: update_core looks at bits_bf)
         c->bf_stream_src = nullptr;
