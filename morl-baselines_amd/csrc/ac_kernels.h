@@ -242,7 +242,8 @@ struct PostArgs {
     float* z;                 // [G][..][ld]  in: Linear output; out: xhat (LayerNorm) or the dropped-out z
     float* h;                 // [G][..][ld]  out: post-ReLU activation
     float* rstd;              // [G][cap]
-    uint8_t* mask;            // [G][cap][N] keep flags (written when dropout is active)
+    unsigned long long* mask; // [G][cap][ceil(N / 64)] keep bits (written when dropout is active): bit l of word j <-> column 64 j + l
+                              // -- one wave ballot and ONE 8-byte store per 64 columns (bytes: 16 store instructions per lane and row)
     const uint8_t* ext_mask;  // explicit keep flags [G][rows][N] (parity tests) or NULL -> counter-based RNG
     long long ext_gstride;
     const float* gamma;       // params + offset of this layer's LayerNorm weight; beta follows at +N
@@ -255,12 +256,19 @@ struct PostArgs {
     unsigned long long seed;
 };
 
+// counter-based uniform in [0, 1) for the Dropout keep masks: element `idx` of the stream `seed` (one stream per update, pass and
+// layer).  32-bit arithmetic throughout -- three v_mul_lo_u32 per element: the splitmix64 finaliser of rounds 1-4 (three 64-bit
+// multiplies = a dozen quarter-rate instructions) was 8.5 of the 54 us of a LayerNorm / Dropout chain launch on MI355X
+// (profiles/r05_ln_chain_post_costs.txt).  Two rounds of a multiply-xorshift mixer (Wellons' lowbias32 constants) over the counter
+// Weyl-stepped into the seed; the reference draws its masks from torch's generator (nn.Dropout), so only the statistics matter --
+// and that every kernel computing a mask uses THIS function (mlp_chain16.h's post-op stage does).
 __device__ __forceinline__ float ac_uniform(unsigned long long seed, unsigned long long idx) {
-    unsigned long long x = seed + idx * 0x9E3779B97F4A7C15ull;      // splitmix64 finaliser
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    return (float)(x >> 40) * (1.0f / 16777216.0f);
+    unsigned int x = (unsigned int)idx * 0x9E3779B9u + (unsigned int)seed;
+    x ^= (unsigned int)(seed >> 32);
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
 __device__ __forceinline__ void ac_post_fwd_body(const PostArgs& a) {
@@ -275,16 +283,21 @@ __device__ __forceinline__ void ac_post_fwd_body(const PostArgs& a) {
     for (int j = 0; j < POST_MAXJ; ++j) {
         const int c = lane + 64 * j;
         float x = 0.f;
+        bool kept = false;
         if (c < a.N) {
             x = z[c];
             if (a.drop) {
                 bool keep;
                 if (a.ext_mask) keep = a.ext_mask[(long long)g * a.ext_gstride + (long long)row * a.N + c] != 0;
                 else keep = ac_uniform(a.seed, ((unsigned long long)g * a.cap + row) * a.N + c) >= a.drop_p;
-                a.mask[((long long)g * a.cap + row) * a.N + c] = keep ? 1 : 0;
+                kept = keep;
                 x = keep ? x * a.inv_keep : 0.f;
             }
             sum += x;
+        }
+        if (a.drop && 64 * j < a.N) {                    // (wave-uniform: the row exists, this 64-column block too)
+            const unsigned long long bits = __ballot(kept);
+            if (lane == 0) a.mask[((long long)g * a.cap + row) * ((a.N + 63) >> 6) + j] = bits;
         }
         v[j] = x;
     }
@@ -328,7 +341,7 @@ struct PostBwdArgs {
     const float* h;
     const float* xhat;
     const float* rstd;
-    const uint8_t* mask;
+    const unsigned long long* mask;      // keep bits, see PostArgs::mask
     const float* gamma;
     long long pstride, gstride;
     int cap, N, ld, rows;
@@ -374,7 +387,7 @@ __global__ __launch_bounds__(256) void ac_post_bwd_kernel(PostBwdArgs a) {
         if (c < a.N) {
             float t = dxh[j];
             if (a.ln) t = rstd * (t - m1 - xh[j] * m2);
-            if (a.drop) t = a.mask[((long long)g * a.cap + row) * a.N + c] ? t * a.inv_keep : 0.f;
+            if (a.drop) t = ((a.mask[((long long)g * a.cap + row) * ((a.N + 63) >> 6) + j] >> lane) & 1ull) ? t * a.inv_keep : 0.f;
             d[c] = t;
         }
     }

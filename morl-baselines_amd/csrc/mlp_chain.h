@@ -81,7 +81,7 @@ struct ChainArgs {
 struct ChainPost {
     float* xhat;              // [G][cap][ld]  forward: out; backward: in
     float* rstd;              // [G][cap]
-    uint8_t* mask;            // [G][cap][N] keep flags, or NULL (no dropout in this pass)
+    unsigned long long* mask; // [G][cap][ceil(N / 64)] keep bits (PostArgs::mask of ac_kernels.h), or NULL (no dropout in this pass)
     const uint8_t* ext_mask;  // forward: explicit keep flags [G][rows][N] (parity tests) or NULL -> counter-based RNG
     const float* gamma;       // params + offset of the layer's LayerNorm weight (beta follows at +N), or NULL (no LayerNorm)
     const float* h;           // backward: [G][cap][ld] the forward's post-ReLU activation

@@ -119,71 +119,119 @@ struct C16NoHook {
 };
 
 // ---- the post-op stages of LayerNorm / Dropout networks (ChainPost of mlp_chain.h) on the tile's rows in LDS ------------------
-// splitmix64 finaliser -> uniform in [0, 1): ac_kernels.h's ac_uniform (same bits: the keep masks of the per-layer path)
+// ac_kernels.h's ac_uniform (same bits: the keep masks of the per-layer path), repeated here because this header is also compiled
+// into the Envelope translation unit, which does not see ac_kernels.h
 __device__ __forceinline__ float c16_uniform(unsigned long long seed, unsigned long long idx) {
-    unsigned long long x = seed + idx * 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    return (float)(x >> 40) * (1.0f / 16777216.0f);
+    unsigned int x = (unsigned int)idx * 0x9E3779B9u + (unsigned int)seed;
+    x ^= (unsigned int)(seed >> 32);
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 
 constexpr int C16_POSTJ = CH_MAXW / 64;      // columns per lane: lane + 64 j
+
+// A wave's four rows are processed SIDE BY SIDE (every load, hash and shuffle of the four rows issued before the first is consumed):
+// the per-row work is a chain of latencies (LDS / L2 round trips, six dependent cross-lane shuffles per sum), and a tile has four
+// waves, not the hundreds a launch of its own hides them behind -- row after row the stage cost 10+ us per layer on MI355X, the
+// whole pass more than the launches it replaced.  Each row's arithmetic, and its order, is ac_post_fwd_body's / ac_post_bwd_kernel's.
+__device__ __forceinline__ void c16_wave_sum4(float (&v)[4]) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = __shfl_xor(v[q], off);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += o[q];
+    }
+}
 
 // forward: wave w, rows 4w .. 4w+3 -- ac_post_fwd_body's arithmetic on sAct[m][0 .. N)
 __device__ __forceinline__ void c16_post_fwd(const ChainPostSet& ps, const ChainPost& a, float* sAct, int row0, int n_rows, int N, int g) {
     const int lane = lane_id(), wave = wave_id();
     const float* __restrict__ gam = a.gamma ? a.gamma + (long long)g * ps.pstride : nullptr;
+    float gm[C16_POSTJ], bt[C16_POSTJ];
+#pragma unroll
+    for (int j = 0; j < C16_POSTJ; ++j) {
+        const int c = lane + 64 * j;
+        gm[j] = (gam && c < N) ? gam[c] : 0.f;
+        bt[j] = (gam && c < N) ? gam[N + c] : 0.f;
+    }
+    float v[4][C16_POSTJ], sum[4];
+    bool live[4];
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int m = wave * 4 + q, row = row0 + m;
-        if (row >= n_rows) continue;                                   // (wave-uniform)
-        float* zr = sAct + m * C2_LDK;
-        float* __restrict__ xh_out = a.xhat + (long long)g * a.gstride + (long long)row * a.ld;
-        float v[C16_POSTJ];
-        float sum = 0.f;
+        live[q] = row < n_rows;                                        // (wave-uniform)
+        const float* zr = sAct + m * C2_LDK;
+        sum[q] = 0.f;
+        // element index of (row, column 0) in the keep-mask / RNG stream: ((g * cap + row) * N + c)
+        const unsigned long long e0 = ((unsigned long long)g * ps.cap + row) * (unsigned long long)N;
 #pragma unroll
         for (int j = 0; j < C16_POSTJ; ++j) {
             const int c = lane + 64 * j;
             float x = 0.f;
-            if (c < N) {
+            bool kept = false;
+            if (live[q] && c < N) {
                 x = zr[c];
                 if (a.drop) {
                     bool keep;
                     if (a.ext_mask) keep = a.ext_mask[(long long)g * ps.ext_gstride + (long long)row * N + c] != 0;
-                    else keep = c16_uniform(a.seed, ((unsigned long long)g * ps.cap + row) * N + c) >= ps.drop_p;
-                    a.mask[((long long)g * ps.cap + row) * N + c] = keep ? 1 : 0;
+                    else keep = c16_uniform(a.seed, e0 + c) >= ps.drop_p;
+                    kept = keep;
                     x = keep ? x * ps.inv_keep : 0.f;
                 }
-                sum += x;
+                sum[q] += x;
             }
-            v[j] = x;
+            if (a.drop && live[q] && 64 * j < N) {           // (wave-uniform)
+                const unsigned long long bits = __ballot(kept);
+                if (lane == 0) a.mask[((long long)g * ps.cap + row) * ((N + 63) >> 6) + j] = bits;
+            }
+            v[q][j] = x;
         }
-        if (!gam) {                                                    // Dropout only (its backward needs the keep mask and h, nothing else)
+    }
+    if (!gam) {                                                        // Dropout only (its backward needs the keep mask and h, nothing else)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float* zr = sAct + (wave * 4 + q) * C2_LDK;
 #pragma unroll
             for (int j = 0; j < C16_POSTJ; ++j) {
                 const int c = lane + 64 * j;
-                if (c < N) zr[c] = fmaxf(v[j], 0.f);
+                if (live[q] && c < N) zr[c] = fmaxf(v[q][j], 0.f);
             }
-            continue;
         }
-        const float mean = wave_sum(sum) / (float)N;
-        float sq = 0.f;
+        return;
+    }
+    c16_wave_sum4(sum);
+    float mean[4], sq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        mean[q] = sum[q] / (float)N;
+        sq[q] = 0.f;
 #pragma unroll
         for (int j = 0; j < C16_POSTJ; ++j) {
             const int c = lane + 64 * j;
-            if (c < N) { const float d = v[j] - mean; sq += d * d; }
+            if (c < N) { const float d = v[q][j] - mean[q]; sq[q] += d * d; }
         }
-        const float var = wave_sum(sq) / (float)N;
+    }
+    c16_wave_sum4(sq);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = wave * 4 + q, row = row0 + m;
+        if (!live[q]) continue;
+        const float var = sq[q] / (float)N;
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
         if (lane == 0) a.rstd[(long long)g * ps.cap + row] = rstd;
-        const float* __restrict__ bet = gam + N;
+        float* zr = sAct + m * C2_LDK;
+        float* __restrict__ xh_out = a.xhat + (long long)g * a.gstride + (long long)row * a.ld;
 #pragma unroll
         for (int j = 0; j < C16_POSTJ; ++j) {
             const int c = lane + 64 * j;
             if (c < N) {
-                const float xh = (v[j] - mean) * rstd;
+                const float xh = (v[q][j] - mean[q]) * rstd;
                 xh_out[c] = xh;
-                zr[c] = fmaxf(xh * gam[c] + bet[c], 0.f);
+                zr[c] = fmaxf(xh * gm[j] + bt[j], 0.f);
             }
         }
     }
@@ -193,44 +241,69 @@ __device__ __forceinline__ void c16_post_fwd(const ChainPostSet& ps, const Chain
 __device__ __forceinline__ void c16_post_bwd(const ChainPostSet& ps, const ChainPost& a, float* sAct, int row0, int n_rows, int N, int g) {
     const int lane = lane_id(), wave = wave_id();
     const float* __restrict__ gam = a.gamma ? a.gamma + (long long)g * ps.pstride : nullptr;
+    float gm[C16_POSTJ];
+#pragma unroll
+    for (int j = 0; j < C16_POSTJ; ++j) {
+        const int c = lane + 64 * j;
+        gm[j] = (gam && c < N) ? gam[c] : 0.f;
+    }
+    float dxh[4][C16_POSTJ], xh[4][C16_POSTJ], s1[4], s2[4], rs[4];
+    unsigned keepbits[4];
+    bool live[4];
+    // every global load of the four rows first (h, xhat, keep flags, rstd), then the arithmetic
+    float hv[4][C16_POSTJ];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = row0 + wave * 4 + q;
+        live[q] = row < n_rows;
+        const long long base = (long long)g * a.gstride + (long long)(live[q] ? row : row0) * a.ld;
+        keepbits[q] = 0u;
+        rs[q] = (gam && live[q]) ? a.rstd[(long long)g * ps.cap + row] : 1.f;
+#pragma unroll
+        for (int j = 0; j < C16_POSTJ; ++j) {
+            const int c = lane + 64 * j;
+            const bool ok = live[q] && c < N;
+            hv[q][j] = ok ? a.h[base + c] : 0.f;
+            xh[q][j] = (ok && gam) ? a.xhat[base + c] : 0.f;
+            if (ok && a.drop && ((a.mask[((long long)g * ps.cap + row) * ((N + 63) >> 6) + j] >> lane) & 1ull)) keepbits[q] |= 1u << j;
+        }
+    }
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int m = wave * 4 + q, row = row0 + m;
-        if (row >= n_rows) continue;
-        float* dr = sAct + m * C2_LDK;
+        const float* dr = sAct + m * C2_LDK;
         const long long base = (long long)g * a.gstride + (long long)row * a.ld;
-        float dxh[C16_POSTJ], xh[C16_POSTJ];
-        float s1 = 0.f, s2 = 0.f;
+        s1[q] = 0.f; s2[q] = 0.f;
 #pragma unroll
         for (int j = 0; j < C16_POSTJ; ++j) {
             const int c = lane + 64 * j;
-            float t = 0.f, x = 0.f;
-            if (c < N) {
+            float t = 0.f;
+            if (live[q] && c < N) {
                 const float d = dr[c];
                 if (a.dh_out) a.dh_out[base + c] = d;
-                t = (a.h[base + c] > 0.f) ? d : 0.f;                   // ReLU
+                t = (hv[q][j] > 0.f) ? d : 0.f;                        // ReLU
                 if (gam) {
-                    x = a.xhat[base + c];
-                    t *= gam[c];
-                    s1 += t;
-                    s2 += t * x;
+                    t *= gm[j];
+                    s1[q] += t;
+                    s2[q] += t * xh[q][j];
                 }
             }
-            dxh[j] = t;
-            xh[j] = x;
+            dxh[q][j] = t;
         }
-        float m1 = 0.f, m2 = 0.f, rstd = 1.f;
-        if (gam) {
-            m1 = wave_sum(s1) / (float)N;
-            m2 = wave_sum(s2) / (float)N;
-            rstd = a.rstd[(long long)g * ps.cap + row];
-        }
+    }
+    if (gam) { c16_wave_sum4(s1); c16_wave_sum4(s2); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!live[q]) continue;
+        float* dr = sAct + (wave * 4 + q) * C2_LDK;
+        const float m1 = s1[q] / (float)N, m2 = s2[q] / (float)N;
 #pragma unroll
         for (int j = 0; j < C16_POSTJ; ++j) {
             const int c = lane + 64 * j;
             if (c < N) {
-                float t = dxh[j];
-                if (gam) t = rstd * (t - m1 - xh[j] * m2);
-                if (a.drop) t = a.mask[((long long)g * ps.cap + row) * N + c] ? t * ps.inv_keep : 0.f;
+                float t = dxh[q][j];
+                if (gam) t = rs[q] * (t - m1 - xh[q][j] * m2);
+                if (a.drop) t = ((keepbits[q] >> j) & 1u) ? t * ps.inv_keep : 0.f;
                 dr[c] = t;
             }
         }

@@ -57,7 +57,7 @@ struct Tape {
     float* h[MORL_MAX_LAYERS] = {};              // post-ReLU activations of the hidden layers
     float* zx[MORL_MAX_LAYERS] = {};             // Linear output -> xhat (LayerNorm / Dropout nets only)
     float* rstd[MORL_MAX_LAYERS] = {};
-    uint8_t* mask[MORL_MAX_LAYERS] = {};
+    unsigned long long* mask[MORL_MAX_LAYERS] = {};      // Dropout keep bits, [G][cap][ceil(N / 64)] words per hidden layer
     float* dh[MORL_MAX_LAYERS] = {};             // dLoss/dh of the hidden layers as the layer-fused backward of a LayerNorm net leaves
                                                  // it for ac_ln_grad_kernel (the per-layer path reads it from g[] before the post-op)
     float* out = nullptr;                        // [G][cap][ld[L]]
@@ -127,8 +127,8 @@ static int alloc_tape(std::vector<void*>& c, const Mlp& m, Tape& t, int G, int x
                 if (m.ln && (rc = alloc_f(c, &t.dh[l], n))) return rc;
                 if ((rc = alloc_f(c, &t.rstd[l], (size_t)G * cap))) return rc;
                 float* mk = nullptr;
-                if ((rc = alloc_f(c, &mk, ((size_t)G * cap * m.dims[l + 1] + 3) / 4))) return rc;
-                t.mask[l] = reinterpret_cast<uint8_t*>(mk);
+                if ((rc = alloc_f(c, &mk, (size_t)G * cap * ((m.dims[l + 1] + 63) / 64) * 2 + 2))) return rc;
+                t.mask[l] = reinterpret_cast<unsigned long long*>(((uintptr_t)mk + 7) & ~(uintptr_t)7);
             }
         }
     }
@@ -427,9 +427,12 @@ static ChainArgs ac_forward_chain(const Mlp& m, const float* params, const float
 // ---- LayerNorm / Dropout networks on the 16-row chain (mlp_chain16.h: mlp_chain16_post_kernel) ------------------------------------
 // The hidden layers' post-ops (Dropout -> LayerNorm -> ReLU, common/networks.py:10-48) run on the tile's rows in LDS, so a pass is ONE
 // launch instead of a GEMM + a post-op (+ a LayerNorm-gradient) launch per layer: GPI-PD's critics (gpi_pd.py:41-76,
-// gpi_pd_continuous_action.py:60-73).  MORL_AC_LN_CHAIN: bit 0 forward passes, bit 1 backward passes (default 3; 0 = the per-layer
-// launches, the A/B leg of tests/test_ln_chain.py).
-static const int g_ac_ln_chain = [] { const char* e = getenv("MORL_AC_LN_CHAIN"); return e ? atoi(e) : 3; }();
+// gpi_pd_continuous_action.py:60-73).  MORL_AC_LN_CHAIN: bit 0 forward passes, bit 1 backward passes; 0 = the per-layer launches.
+// Default 1 -- measured on MI355X (profiles/r05_ln_chain_ab.json): the FORWARD chain wins (GPI-PD discrete 0.2845 -> 0.2639 ms per
+// update, continuous 0.2243 -> 0.2194), the backward chain does not (its four 256-wide dX steps and three post-op stages are one
+// serial 73 us chain on 16 - 32 workgroups where the per-layer launches spread each step over the chip: 0.2845 -> 0.3010): built,
+// held to the same fixtures (tests/test_ln_chain.py runs both), not the default.
+static const int g_ac_ln_chain = [] { const char* e = getenv("MORL_AC_LN_CHAIN"); return e ? atoi(e) : 1; }();
 static bool chain_post_ok(const Mlp& m, long long rows_x_nets) {
     if (!g_ac_chain || !(m.ln || m.drop > 0.f) || m.L < 2 || m.L > MORL_MAX_LAYERS) return false;
     if (m.dims[0] > CH_MAXW) return false;
