@@ -1,8 +1,8 @@
 #!/bin/bash
 # One parametrised GPU collection script (replaces the per-trip scripts of rounds 1-3).  Run from the repo root on the GPU box:
 #   tools/gpu_collect.sh <out-tag> <stage> [<stage> ...]
-# stages: tests-quick | tests-all | smoke | bench | bench-exact | bench-driver | bench-w32 | prof-env | prof-env-exact | prof-w32 |
-#         bench-ac | prof-ac | emu8 | pmc | fronts
+# stages: tests-quick | tests-all | smoke | bench | bench-exact | bench-eager | bench-driver | bench-w32 | prof-env | prof-env-exact | prof-w32 |
+#         bench-ac | prof-ac | emu8 | emu-all | host-prof | morld-ctx | lazy-sweep | pmc | fronts
 # Everything lands under gpurun_out/<out-tag>/ (merged back by gpurun); large traces are deleted, the stats CSVs kept.
 set -x
 R=$PWD
@@ -34,6 +34,16 @@ bench-ac)    for w in capql mosac gpipd gpi ens; do timeout 300 python bench_ac.
 prof-ac)     OPENER=ac_inputs prof capql python $R/bench_ac.py --workload capql --steps 60 --no-cpu-baseline
              OPENER=ac_transpose_scatter prof gpi python $R/bench_ac.py --workload gpi --steps 60 --no-cpu-baseline ;;
 emu8)        timeout 300 python bench.py --gpus 1 --force-shard --emulate-world 8 $B > $O/bench_emulated_rank_of_8.json 2>/dev/null; cut -c1-300 $O/bench_emulated_rank_of_8.json ;;
+emu-all)     # one rank of a 2 / 4 / 8-rank strong-scaled job run alone, both axes -> the strong-scaling ceiling (tools/emulated_ceiling.py)
+             timeout 300 python bench.py --steps 200 --warmup 20 $B > $O/single.json 2>/dev/null
+             for n in 2 4 8; do for ax in batch weights; do
+               timeout 200 python bench.py --gpus 1 --force-shard --emulate-world $n --shard-axis $ax --steps 100 --warmup 20 $B > $O/emu${n}_${ax}.json 2>/dev/null
+             done; done
+             python tools/emulated_ceiling.py $O/single.json $O $O/emulated_ceiling.json | cut -c1-400 ;;
+bench-eager) MORL_LAZY_TARGETS=0 timeout 300 python bench.py --steps 200 --warmup 20 $B > $O/bench_eager_targets_200.json 2>/dev/null; cut -c1-300 $O/bench_eager_targets_200.json ;;
+host-prof)   timeout 300 python tools/host_profile.py --steps 300 > $O/host_profile_single.txt 2>&1; head -8 $O/host_profile_single.txt ;;
+morld-ctx)   timeout 300 python bench_ac.py --workload morld --pop 64 --devices 2 --no-cpu-baseline > $O/bench_ac_morld64_2ctx.json 2>/dev/null; cut -c1-300 $O/bench_ac_morld64_2ctx.json ;;
+lazy-sweep)  timeout 300 python tools/lazy_sweep.py > $O/lazy_sweep.json 2> $O/lazy_sweep.err; tail -3 $O/lazy_sweep.err ;;
 pmc)         (cd /tmp && export TMPDIR=/tmp && timeout 900 python $R/tools/pmc_summary.py $R/$O/pmc_summary.json > $R/$O/pmc_summary.txt 2>&1); tail -25 $O/pmc_summary.txt ;;
 fronts)      for n in 1024 16384 65536; do timeout 300 python bench_front.py --workload pareto --n $n > $O/bench_front_pareto_$n.json 2>/dev/null; done
              for r in 2 3 4; do timeout 300 python bench_front.py --workload hv --r $r > $O/bench_front_hv_r$r.json 2>/dev/null; done ;;
