@@ -224,7 +224,12 @@ def traffic_fields(bf16):
     if not any(k.startswith(name) for k in ks):          # (the committed summary is of the other arithmetic: say nothing rather than mix)
         return {"traffic": None, "traffic_source": f"{src} holds no {name} launches"}
     dom = next((v for k, v in ks.items() if k.startswith(name)), None)
-    step = sum(v["hbm_bytes"] for k, v in ks.items() if k.startswith("morl::") and "sumtree_set" not in k and "polyak" not in k)
+    # per STEP: a kernel's per-launch average times its launches per step (the chain kernel runs twice: forward and backward-dX --
+    # the figure of rounds 1-4 counted every kernel once and so left one chain launch out: 280 MB instead of 366 MB)
+    steps = max((v.get("launches", 1) for k, v in ks.items() if "step_prologue" in k), default=0) or \
+        min(v.get("launches", 1) for k, v in ks.items() if k.startswith("morl::") and "sumtree_set" not in k)
+    step = sum(v["hbm_bytes"] * v.get("launches", steps) / steps for k, v in ks.items()
+               if k.startswith("morl::") and "sumtree_set" not in k and "polyak" not in k)
     return {"traffic": dom["hbm_bytes"] if dom else None,
             "traffic_kernel": name if dom else None,
             "traffic_unit": "HBM bytes per launch of the dominant kernel (rocprofv3 PMC: FETCH_SIZE x 2 + WRITE_SIZE)",

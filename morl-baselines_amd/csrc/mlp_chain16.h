@@ -639,8 +639,7 @@ inline bool chain16_wanted(const ChainArgs* chains, int n, long long max_rows = 
         const long long r = (long long)chains[q].rows * (chains[q].nb > 1 ? chains[q].nb : 1);
         most = r > most ? r : most;
     }
-    static const long long env_limit = [] { const char* e = getenv("MORL_CHAIN16_MAX_ROWS"); return e ? atoll(e) : -1ll; }();   // (tuning)
-    return most <= (env_limit >= 0 ? env_limit : max_rows);
+    return most <= max_rows;
 }
 
 inline int chain16_fill(Chain16Multi& m, const ChainArgs* chains, int n) {

@@ -288,11 +288,11 @@ static bool chain_shape_ok(const Mlp& m) {
 
 constexpr long long AC_C16_MAX_ROWS = 4096;     // row count up to which a chain of these three-layer nets takes the 16-row tiles
 // ONE decision for "does a chain of this many rows (x networks) run on the 16-row tiles": ac_chain_launch (which kernel) and
-// chain_nmajor (does the pass have K-major shadow weights at all) both ask here, so the MORL_CHAIN16_MAX_ROWS tuning variable
+// chain_nmajor (does the pass have K-major shadow weights at all) both ask here, so that the two
 // cannot make them disagree (an N-major chain has no shadow copy for the 16-row kernel to stream)
 static bool ac_rows_take_chain16(long long rows_x_nets) {
     static const bool small_rows = [] { const char* e = getenv("MORL_CHAIN16"); return e ? atoi(e) != 0 : true; }();
-    static const long long limit = [] { const char* e = getenv("MORL_CHAIN16_MAX_ROWS"); return e ? atoll(e) : AC_C16_MAX_ROWS; }();   // (tuning)
+    constexpr long long limit = AC_C16_MAX_ROWS;
     return small_rows && rows_x_nets <= limit;
 }
 // The actor's backward chain with the policy head's backward pass in its input stage (ChainArgs::in_mode == 4): each tile computes

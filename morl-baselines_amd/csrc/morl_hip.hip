@@ -672,12 +672,11 @@ static int timing_open(morl_ctx* c, int kind, hipStream_t s, int* slot);
 static int timing_close(morl_ctx* c, int slot, hipStream_t s);
 // row tile of a bf16 chain launch: 64-row tiles (4 waves) when there is at least one for every CU, else 32-row tiles (2 waves).
 // (Round 4 first asked for TWO 64-row workgroups per CU; one 4-wave workgroup per CU stages the weight stream into LDS once
-// where two 2-wave ones stage it twice: the flagship's backward launch 41.9 -> 39 us.)  MORL_BF_TILE=64 / 32 forces
+// where two 2-wave ones stage it twice: the flagship's backward launch 41.9 -> 39 us.)
 static int bf_tile_rows(morl_ctx* c, const BfChain* chains, int n) {
     long long tiles64 = 0;
     for (int q = 0; q < n; ++q) tiles64 += (chains[q].rows + BF_TM - 1) / BF_TM;
-    static const int forced = [] { const char* e = getenv("MORL_BF_TILE"); return e ? atoi(e) : 0; }();      // (tuning)
-    const bool small = forced ? forced == 32 : tiles64 < (long long)c->num_cus;
+    const bool small = tiles64 < (long long)c->num_cus;
     return small ? 32 : BF_TM;
 }
 
@@ -1480,7 +1479,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
     // the step runs on the bf16 matrix cores (its forward / backward chains did): the weight gradients too, as six split-bf16
     // products per fp32 product (dw_bf.h) -- when every problem fits one of that kernel's three layouts
     bool dwb_ok = c->use_fused && c->bits_bf && c->bf_mode == 1 && dw2_ok && c->dw_mode == 3;
-    static const bool dwb_env = [] { const char* e = getenv("MORL_DW_BF16"); return e ? atoi(e) != 0 : true; }();      // (A/B: 0 = dw_tiles.h)
+    constexpr bool dwb_env = true;      // (the A/B against dw_tiles.h is morl_ctx_set_exact_f32 / MORL_EXACT_F32=1: profiles/r04_dw_bf_versions.txt)
     c->dw_bf_last = dwb_ok && dwb_env;
     if (dwb_ok && dwb_env) {
         DwbArgs a{};
@@ -1582,7 +1581,6 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
             unit_tiles += (double)q.tiles_m * q.tiles_n * lay_cost[q.layout] / 4.0;
         }
         int target = 2 * c->num_cus;
-        if (const char* e = getenv("MORL_DW_JOBS")) target = std::max(1, atoi(e));     // (tuning)
         // base slice of the 2x2 layout: unit_tiles * rows / base ~ target jobs, a multiple of the 32-row chunk
         int base = round_up(std::max(1, (int)std::ceil(unit_tiles * rows / (double)target)), DW2_BK);
         for (;;) {      // the split count of every problem must fit the slab buffer

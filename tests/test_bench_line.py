@@ -75,8 +75,10 @@ def test_roofline_record_arithmetic(bench):
     ks, src = bench.committed_pmc()
     assert src.startswith("profiles/") and rb["traffic"] == pytest.approx(ks["morl::mlp_chain_bf_kernel"]["hbm_bytes"])
     assert 50e6 < rb["traffic"] < 200e6 and "committed profile" in rb["traffic_source"]
-    assert rb["step_hbm_bytes"] == pytest.approx(sum(v["hbm_bytes"] for k, v in ks.items()
+    n_steps = max(v["launches"] for k, v in ks.items() if "step_prologue" in k)
+    assert rb["step_hbm_bytes"] == pytest.approx(sum(v["hbm_bytes"] * v["launches"] / n_steps for k, v in ks.items()
                                                       if k.startswith("morl::") and "sumtree_set" not in k and "polyak" not in k))
+    assert ks["morl::mlp_chain_bf_kernel"]["launches"] == 2 * n_steps            # (forward and backward-dX: both counted)
     assert rb["algorithmic_bytes"] == 7.7e6 and rb["step_hbm_over_algorithmic"] == pytest.approx(rb["step_hbm_bytes"] / 7.7e6)
 
 
