@@ -1307,7 +1307,8 @@ static EnvelopeTdArgs lazy_argmax_args(morl_ctx* c, const EnvelopeTdArgs& p) {
 // did the lazily evaluated step LZ_LAG epochs before the current one select more than lz_big_rows pairs?  Waits (bounded) for that
 // step's target launch to have started -- the host is then at most LZ_LAG steps ahead of the device, which it normally is not.
 static int chain2_fill(morl_ctx* c, Chain2Multi& m, const ChainArgs* chains, int n, int S);
-static bool lazy_count_was_big(morl_ctx* c) {
+static bool lazy_count_was_big(morl_ctx* c, long long* count_out = nullptr) {
+    if (count_out) *count_out = -1;
     const long long e = (long long)c->lz_epoch - LZ_LAG;
     if (e < 1 || !c->lz_mirror || c->lz_big_rows <= 0) return false;
     volatile unsigned long long* slot = c->lz_mirror + (e & (LZ_SLOTS - 1));
@@ -1326,8 +1327,16 @@ static bool lazy_count_was_big(morl_ctx* c) {
 #endif
         }
         c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (!seen) return false;
+        if (!seen) {
+            // never reported: the stream of that step is not making progress while this call is in flight (a caller that parks its
+            // streams behind events of its own, a step that failed between the arg-max and the target launch).  One bounded wait is
+            // the price; the context then stops asking and keeps the small tiles (correct at any count, slow only in the worst case)
+            fprintf(stderr, "[morl] lazy target rows: the pair count of step %lld was never reported; adaptive tile sizing is off for this context\n", e);
+            c->lz_big_rows = 0;
+            return false;
+        }
     }
+    if (count_out) *count_out = (long long)(unsigned int)(v & 0xffffffffull);
     return (long long)(unsigned int)(v & 0xffffffffull) > c->lz_big_rows;
 }
 
@@ -1361,6 +1370,8 @@ static int lazy_phase1(morl_ctx* c, const EnvelopeTdArgs& p, int td_waves, hipSt
         LAUNCH_CHECK("mlp_chain2(lazy targets, many rows)");
     } else if (few_rows && chain4_ok(t)) {
         // 8-row tiles (mlp_chain4.h): twice the workgroups, half the MFMA time per CU and layer
+        // (sized for the worst case -- every TD row its own pair --, tiles beyond the count exit at once.  A grid fitted to the count an
+        // earlier step reported, the kernel walking further tiles itself, changed nothing: 24.9 us either way, profiles/r05_target_grid_ab.txt)
         hipLaunchKernelGGL(mlp_chain4_kernel, dim3((p.B * wi + C4_TM - 1) / C4_TM), dim3(CH_THREADS), 0, s, t);
         LAUNCH_CHECK("mlp_chain4(lazy targets)");
     } else {
