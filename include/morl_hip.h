@@ -412,6 +412,16 @@ int morl_envelope_step_batch_sharded(morl_ctx* ctx, morl_comm* comm, float* para
                                      const float* weights, int B, int B_total, int b_offset, int W,
                                      const morl_update_cfg* cfg, void* stream);
 
+/* One rank's WHOLE sharded Envelope.update iteration in one entry, sampling included: morl_envelope_prepare (tree descent /
+ * index read + record gather + the w copy + the step's weight copies, into io's batch tensors) followed by
+ * morl_envelope_step_batch_sharded (axis 0: this rank keeps transitions [offset, offset + share) of io->B) or
+ * morl_envelope_step_sharded (axis 1: weights [offset, offset + share) of io->W; slab_local / slab_all as there).  `io` is the
+ * persistent block of morl_envelope_update_n with io->grads = grads_x = [P gradient | 1 loss | io->B priorities] (the buffer the
+ * all-reduce sums); u01 / idx_in / w_src as there, for one iteration.  What the sharded agents of distributed.py call per step. */
+int morl_envelope_rank_step(morl_ctx* ctx, morl_comm* comm, const morl_step_io* io, int axis, int offset, int share,
+                            const double* u01, const int64_t* idx_in, const float* w_src, int adam_step, float homotopy_lambda,
+                            float* slab_local, float* slab_all, void* stream);
+
 /* ---- polyak_update: common/networks.py:120-139 ------------------------------------------------- */
 int morl_polyak(const float* src, float* dst, float tau, int64_t n, void* stream);
 

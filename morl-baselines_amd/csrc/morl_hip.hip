@@ -2214,6 +2214,49 @@ extern "C" int morl_envelope_step_batch_sharded(morl_ctx* c, morl_comm* comm, fl
     return morl_clip_adam(c, params_online, grads_x, exp_avg, exp_avg_sq, cfg, nullptr, stream);
 }
 
+// One rank's sharded iteration with its sampling in one entry (include/morl_hip.h)
+extern "C" int morl_envelope_rank_step(morl_ctx* c, morl_comm* comm, const morl_step_io* io, int axis, int offset, int share,
+                                       const double* u01, const int64_t* idx_in, const float* w_src, int adam_step, float homotopy_lambda,
+                                       float* slab_local, float* slab_all, void* stream) {
+    if (!c || !comm || !io) return fail(MORL_ERR_ARG, "NULL argument");
+    if (axis != 0 && axis != 1) return fail(MORL_ERR_ARG, "axis %d (0: batch, 1: weights)", axis);
+    if (!io->params_online || !io->params_target || !io->grads || !io->exp_avg || !io->exp_avg_sq || !io->records || !io->obs ||
+        !io->next_obs || !io->rewards || !io->dones || !io->actions || !io->idx || !io->weights)
+        return fail(MORL_ERR_ARG, "NULL field of morl_step_io");
+    if (!w_src) return fail(MORL_ERR_ARG, "w_src is NULL");
+    if (io->tree ? (!u01 || !io->running_max) : !idx_in)
+        return fail(MORL_ERR_ARG, io->tree ? "prioritised replay needs u01 and running_max" : "uniform replay needs idx_in");
+    if (io->tree && (io->n_levels < 1 || io->n_levels > 40)) return fail(MORL_ERR_ARG, "n_levels = %d", io->n_levels);
+    if (io->D != c->net.obs_dim || io->R != c->net.reward_dim)
+        return fail(MORL_ERR_ARG, "records of (obs %d, reward %d), the network takes (%d, %d)", io->D, io->R, c->net.obs_dim, c->net.reward_dim);
+    const int B = io->B, W = io->W, D = io->D, R = io->R;
+    if (share < 1 || offset < 0 || offset + share > (axis == 0 ? B : W))
+        return fail(MORL_ERR_ARG, "bad shard [%d, %d) of %d", offset, offset + share, axis == 0 ? B : W);
+    if (axis == 1 && (!slab_local || !slab_all)) return fail(MORL_ERR_ARG, "the weight axis needs the slab buffers");
+    int rc = check_bw(c, axis == 0 ? share : B, axis == 0 ? W : share);
+    if (rc) return rc;
+    if ((rc = morl_envelope_prepare(c, io->params_online, io->params_target, io->tree, io->n_levels, io->tree ? u01 : nullptr,
+                                    io->tree ? nullptr : idx_in, io->records, io->record_floats, io->capacity, B, D, R, 1, io->obs,
+                                    io->next_obs, io->rewards, io->dones, nullptr, io->actions, io->idx, w_src, io->weights, W * R, stream)))
+        return rc;
+    morl_update_cfg cfg = io->cfg;
+    cfg.adam_step = adam_step;
+    cfg.homotopy_lambda = homotopy_lambda;
+    cfg.apply_step = 1;
+    cfg.main_forward_done = 0; cfg.slab_parts = 0; cfg.rows_total = 0;
+    cfg.shard_params_target = nullptr; cfg.shard_next_obs = nullptr;
+    cfg.per_tree = io->tree; cfg.per_idx = io->tree ? io->idx : nullptr; cfg.per_running_max = io->tree ? io->running_max : nullptr;
+    cfg.per_levels = io->n_levels;
+    if (axis == 0)
+        return morl_envelope_step_batch_sharded(c, comm, io->params_online, io->params_target, io->grads, c->P, io->exp_avg, io->exp_avg_sq,
+                                                io->obs + (size_t)offset * D, io->next_obs + (size_t)offset * D, io->actions + offset,
+                                                io->rewards + (size_t)offset * R, io->dones + offset, io->weights, share, B, offset, W, &cfg,
+                                                stream);
+    return morl_envelope_step_sharded(c, comm, io->params_online, io->params_target, io->grads, c->P, io->exp_avg, io->exp_avg_sq, io->obs,
+                                      io->next_obs, io->actions, io->rewards, io->dones, io->weights, B, W, offset, share, slab_local, slab_all,
+                                      &cfg, stream);
+}
+
 // clip_grad_norm_ + Adam on flat buffers (envelope.py:324-326) -- stage C on its own, for gradients that were
 // all-reduced between the stages.
 extern "C" int morl_clip_adam(morl_ctx* c, float* params, float* grads, float* exp_avg, float* exp_avg_sq,

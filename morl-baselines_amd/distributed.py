@@ -330,6 +330,32 @@ def shard_capql_agent(agent, dist, group=None):
     return agent
 
 
+def _rank_step(agent: Envelope, comm, axis: int, offset: int, share: int, slab_loc=None, slab_all=None) -> bool:
+    """One sharded iteration of ``agent`` as ONE library entry (``morl_envelope_rank_step``: sampling + the rank step on the agent's
+    persistent argument block): the host draws what the reference draws (batch uniforms / indices from the global numpy RNG, the
+    sampled weights from ``agent.np_random``) into pinned slots and makes one call.  False: the agent's replay buffer is not one
+    of ``replay.py``'s (the caller then takes the call-by-call path)."""
+    st = agent._step_block(1)
+    if st is None:
+        return False
+    W, R = agent.num_sample_w, agent.reward_dim
+    ring = agent._w_ring = ops.HostRing.fit(agent.__dict__.get("_w_ring"), agent.lib, agent.device, W * R, th.float32)
+    slot, w_ptr = ring.next(W * R)
+    slot[:] = random_weights(dim=R, n=W, dist="gaussian", rng=agent.np_random).reshape(-1)
+    u_ptr, i_ptr = agent.replay_buffer.draw_batches(agent.batch_size, 1)
+    agent._adam_step += 1
+    rc = agent.lib.lib.morl_envelope_rank_step(
+        agent.q_net.ctx.handle, comm.handle, st.io_ref, axis, offset, share, u_ptr, i_ptr, w_ptr, agent._adam_step,
+        float(agent.homotopy_lambda), None if slab_loc is None else slab_loc.data_ptr(), None if slab_all is None else slab_all.data_ptr(),
+        agent.lib.stream_of(st.loss))
+    if rc:
+        agent._adam_step -= 1
+        agent.lib.check(rc)
+    ring.mark_used()
+    agent.replay_buffer.mark_drawn()
+    return True
+
+
 def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=None, axis: str = "weights",
                          transport=None) -> Envelope:
     """Replace ``agent.update`` with the sharded step.  ``dist`` is ``torch.distributed`` (already initialised).
@@ -383,6 +409,14 @@ def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=N
         if comm is not None:
             comm.poll()                                      # (a timed-out collective of an earlier step: raise, do not train on)
         for _ in range(self.gradient_updates):
+            gx = self._grads_x
+            if comm is not None and _rank_step(self, comm, 1, i0, Wl, slab_loc, slab_all):
+                # (sampling + the whole step of this rank: ONE library entry, morl_envelope_rank_step)
+                loss = gx[P] if self.gradient_updates == 1 else gx[P].clone()
+                pr = gx[P + 1:]
+                self._out = {"loss": loss, "priority": pr}
+                self._losses.append(loss)
+                continue
             aux, sampled_w = self._draw_weights()
             b_obs, b_actions, b_rewards, b_next_obs, b_dones, b_inds = self.replay_buffer.sample(
                 B, to_tensor=True, device=self.device, aux=aux,
@@ -390,7 +424,6 @@ def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=N
             self._w_ring.mark_used()
             ctx = self.q_net.ctx
             self._adam_step += 1
-            gx = self._grads_x
             actions = b_actions.reshape(-1).to(th.int32)
             if comm is not None:
                 # the whole step of this rank in one library call (RCCL inside libmorl_hip.so): slabs -> all-gather beside
@@ -476,6 +509,14 @@ def _shard_envelope_batch(agent: Envelope, dist, group, emulate, comm, world: in
             comm.poll()                                      # (a timed-out collective of an earlier step: raise, do not train on)
         W = self.num_sample_w
         for _ in range(self.gradient_updates):
+            gx = self._grads_x
+            if comm is not None and _rank_step(self, comm, 0, b0, Bl):
+                # (sampling + the whole step of this rank: ONE library entry, morl_envelope_rank_step)
+                loss = gx[P] if self.gradient_updates == 1 else gx[P].clone()
+                pr = gx[P + 1:]
+                self._out = {"loss": loss, "priority": pr}
+                self._losses.append(loss)
+                continue
             aux, sampled_w = self._draw_weights()
             b_obs, b_actions, b_rewards, b_next_obs, b_dones, b_inds = self.replay_buffer.sample(
                 B0, to_tensor=True, device=self.device, aux=aux,
@@ -483,7 +524,6 @@ def _shard_envelope_batch(agent: Envelope, dist, group, emulate, comm, world: in
             self._w_ring.mark_used()
             ctx = self.q_net.ctx
             self._adam_step += 1
-            gx = self._grads_x
             sl = slice(b0, b0 + Bl)                      # this rank's transitions (row slices of contiguous tensors: views)
             actions = b_actions.reshape(-1).to(th.int32)[sl]
             obs, nobs, rew, done = b_obs[sl], b_next_obs[sl], b_rewards[sl], b_dones.reshape(-1)[sl]

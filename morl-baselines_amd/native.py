@@ -189,6 +189,8 @@ _SIGNATURES = {
                                    [C.c_void_p, C.c_void_p, C.POINTER(UpdateCfg), C.c_void_p]),
     "morl_envelope_step_batch_sharded": (C.c_int, [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 8 + [C.c_int] * 4 +
                                          [C.POINTER(UpdateCfg), C.c_void_p]),
+    "morl_envelope_rank_step": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(StepIO), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "morl_comm_unique_id": (C.c_int, [C.c_void_p]),
     "morl_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int]),
     "morl_comm_init_custom": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
