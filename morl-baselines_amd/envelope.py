@@ -299,7 +299,10 @@ class Envelope(MOPolicy, MOAgent):
         weights from ``self.np_random`` (``:279-283``) -- into pinned slots the gather launches read in place."""
         n = self.gradient_updates
         self.q_net.ensure_capacity(self.batch_size, self.num_sample_w)
-        st = self._step_block(n)
+        # (a prioritised batch larger than one tree-update launch holds -- 1 024 entries -- takes the call-by-call path, whose
+        # priority update goes through update_priorities' ascending blocks)
+        big_per = self.per and self.batch_size > PrioritizedReplayBuffer.TREE_BLOCK
+        st = None if big_per else self._step_block(n)
         if st is None:
             return self._update_by_calls()
         W, R = self.num_sample_w, self.reward_dim
@@ -331,6 +334,7 @@ class Envelope(MOPolicy, MOAgent):
         self._losses = []
         priority = None
         self.q_net.ensure_capacity(self.batch_size, self.num_sample_w)
+        in_step = self.per and self.batch_size <= PrioritizedReplayBuffer.TREE_BLOCK
         for _ in range(self.gradient_updates):
             aux, sampled_w = self._draw_weights()
             b_obs, b_actions, b_rewards, b_next_obs, b_dones, b_inds = self.__sample_batch_experiences(aux)
@@ -341,10 +345,16 @@ class Envelope(MOPolicy, MOAgent):
                 b_obs, b_next_obs, b_actions.reshape(-1).to(th.int32), b_rewards, b_dones.reshape(-1), sampled_w,
                 gamma=self.gamma, lr=self.learning_rate, adam_step=self._adam_step, max_grad_norm=self.max_grad_norm,
                 homotopy_lambda=float(self.homotopy_lambda), envelope=self.envelope, outputs=None,
-                per=self.replay_buffer.per_update_args(b_inds, self.per_alpha) if self.per else None)
+                per=self.replay_buffer.per_update_args(b_inds, self.per_alpha) if in_step else None)
             self._losses.append(self._out["loss"])
             if self.per:
                 priority = self._out["priority"]      # (the sum tree was updated inside the step: envelope.py:329-334)
+                if not in_step:
+                    # envelope.py:329-334 for a batch of more than 1 024 transitions: priority = (|td . w| + min_priority) ** alpha
+                    # with the running maximum as it stood BEFORE this update (fp32, as numpy evaluates it), then update_priorities
+                    # (ascending blocks: the tree of one batch_set, bit for bit)
+                    rmax = self.replay_buffer.running_max.to(th.float32)
+                    self.replay_buffer.update_priorities(b_inds, (priority + rmax).pow(th.tensor(self.per_alpha, dtype=th.float32, device=priority.device)))
 
         self._finish_update(priority)
 

@@ -470,3 +470,43 @@ def test_update_entry_refuses_bad_blocks_before_the_first_launch(be):
     assert ag._adam_step == 1 and th.equal(ag.q_net.flat, before)
     ag.update()
     assert ag._adam_step == 2 and not th.equal(ag.q_net.flat, before)
+
+
+def test_prioritised_batch_larger_than_one_tree_update_launch(be):
+    """``Envelope.update`` with prioritised replay and a batch of more than 1 024 transitions (one tree-update launch holds 1 024;
+    the reference has no such limit, ``envelope.py:329-334``): the step runs without the in-step tree update and the priorities go
+    through ``update_priorities``' ascending blocks -- the tree is what ONE ``SumTree.batch_set`` of the reference makes of the same
+    priorities, bit for bit, and the running maximum follows ``prioritized_buffer.py:194``."""
+    lib, dev = be
+    env = ToyEnv()
+    th.manual_seed(0)
+    np.random.seed(0)
+    B = 1100
+    ag = envmod.Envelope(env, net_arch=[32, 32], batch_size=B, num_sample_w=2, buffer_size=2048, per=True, learning_starts=0,
+                         log=False, seed=0, device=dev, lib=lib)
+    _fill(ag.replay_buffer, 1500, env.D, env.A, env.R)
+    ag.global_step = 21
+    buf = ag.replay_buffer
+    buf.flush()
+    tree0 = buf.tree_dev.clone().cpu().numpy()
+    rmax0 = float(buf.running_max.item())
+    st_np = np.random.get_state()
+    idx = buf.sample_indices(B).cpu().numpy()                              # what update() is about to draw (the tree is untouched)
+    np.random.set_state(st_np)
+    ag.update()
+    assert ag._adam_step == 1 and np.isfinite(ag.last_loss())
+    raw = ag._out["priority"].detach().cpu()
+    pr = (raw + th.tensor(rmax0, dtype=th.float32)).pow(th.tensor(0.6, dtype=th.float32)).numpy()
+    want = orc.SumTree(buf.max_size)
+    off = 0
+    for l, nodes in enumerate(want.nodes):
+        nodes[:] = tree0[off:off + len(nodes)]
+        off += len(nodes)
+    want.batch_set(idx, pr.astype(np.float64))
+    got = buf.tree_dev.cpu().numpy()
+    off = 0
+    for l, nodes in enumerate(want.nodes):
+        assert np.array_equal(got[off:off + len(nodes)], nodes), l
+        off += len(nodes)
+    assert float(buf.running_max.item()) == max(rmax0, float(pr.max()))
+    assert len(np.unique(idx)) < B                                          # (duplicates among the sampled leaves: first occurrence wins)
