@@ -126,6 +126,6 @@ def test_one_step_parity_checks_priorities_tree_and_argmax(bench):
     ops.envelope_update = corrupted
     try:
         with pytest.raises(SystemExit, match="disagrees with the oracle"):
-            bench.one_step_parity(th.device("cpu"), case=c, lib=lib)
+            bench.one_step_parity(th.device("cpu"), case=[k for k in CASES if k.name == "tiny_mse"][0], lib=lib)      # (any shape will do)
     finally:
         ops.envelope_update = real

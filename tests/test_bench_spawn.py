@@ -19,6 +19,8 @@ def _run(transport):
     env.pop("MORL_COMM", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-emulator", "--transport", transport, "--steps", "2",
            "--warmup", "1", "--batch", "8", "--weights", "4", "--buffer-fill", "200"]
+    if transport != "staged":          # (the second leg is about the communicator the line reports: no sub-record, no side record again)
+        cmd += ["--no-sub-record", "--no-collective-microbench"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -45,11 +47,14 @@ def test_bench_two_ranks_end_to_end_on_the_emulator(transport):
     else:
         assert "torch" in d["config"]["transport"] and d["config"]["comm_ranks"] == 2
     assert d["config"]["rccl_ranks"] is None                   # (gloo: RCCL never came up, and the line says so)
+    assert d["config"]["strong_scaling_ceiling_emulated"]["source"].startswith("profiles/")
+    if transport != "staged":
+        assert "weak_scaling" not in d and "collectives_alone" not in d
+        return
     # the weak-scaled sub-record (weight axis grown to 4 * 2) and the collectives alone (single-hop transport over shared memory)
     w = d["weak_scaling"]
     assert "error" not in w and w["weights"] == 8 and w["weights_per_gpu"] == 4 and w["scaling"] == "weak"
     c = d["collectives_alone"]
     assert "ipc" in c and "error" not in c["ipc"], c
     assert c["ipc"]["allreduce_us"] > 0 and c["ipc"]["allgather_us"] > 0 and c["ipc"]["allgather_correct"] is True
-    assert d["config"]["strong_scaling_ceiling_emulated"]["source"].startswith("profiles/")
     assert "[bench] rank 0/2" in err and "[bench] rank 1/2" in err

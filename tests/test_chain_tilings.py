@@ -77,7 +77,8 @@ def test_exact_f32_arithmetic_passes_the_same_parity_tests():
     MFMA, the arithmetic of rounds 1-3."""
     env = dict(os.environ, MORL_EXACT_F32="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_parity.py"), "-x", "-q", "-m", "not gpu",
-                        "-k", "flagship_b32w8 or wide_pick", "-p", "no:cacheprovider"],
+                        "-k", "(flagship_b32w8 or wide_pick) and (reference_golden or fused_auto or lazy_target_evaluation)", "-p",
+                        "no:cacheprovider"],          # (the emulator leg: the fixture + oracle + lazy-vs-eager cases; the GPU leg below runs them all)
                        capture_output=True, text=True, timeout=2400, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
