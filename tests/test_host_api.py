@@ -495,8 +495,9 @@ def test_prioritised_batch_larger_than_one_tree_update_launch(be):
     np.random.set_state(st_np)
     ag.update()
     assert ag._adam_step == 1 and np.isfinite(ag.last_loss())
-    raw = ag._out["priority"].detach().cpu()
-    pr = (raw + th.tensor(rmax0, dtype=th.float32)).pow(th.tensor(0.6, dtype=th.float32)).numpy()
+    raw = ag._out["priority"].detach()                       # (the power on the device that took it: a device's powf may differ from
+    pr = (raw + th.tensor(rmax0, dtype=th.float32, device=raw.device)).pow(          # the host's by an ulp; the TREE arithmetic is what is exact)
+        th.tensor(0.6, dtype=th.float32, device=raw.device)).cpu().numpy()
     want = orc.SumTree(buf.max_size)
     off = 0
     for l, nodes in enumerate(want.nodes):
