@@ -253,6 +253,7 @@ class Envelope(MOPolicy, MOAgent):
             return None
         key = (self.batch_size, self.num_sample_w, self.q_net.flat.data_ptr(), self.target_q_net.flat.data_ptr(),
                self._grads.data_ptr(), self._exp_avg.data_ptr(), self._exp_avg_sq.data_ptr(), id(buf), buf.records.data_ptr(),
+               buf.tree_dev.data_ptr() if hasattr(buf, "tree_dev") else 0,
                self.gamma, self.learning_rate, self.max_grad_norm, self.envelope, self.per_alpha, self.q_net.ctx.handle)
         st = self.__dict__.get("_step_state")
         if st is not None and st.key == key and st.n_alloc >= n:
@@ -263,7 +264,9 @@ class Envelope(MOPolicy, MOAgent):
         B, W, R, D, dev = self.batch_size, self.num_sample_w, self.reward_dim, self.observation_dim, self.device
         self.lib.check_device(self.q_net.flat, self.target_q_net.flat, self._grads, self._exp_avg, self._exp_avg_sq, buf.records)
         per = isinstance(buf, PrioritizedReplayBuffer)
-        st = types.SimpleNamespace(key=key, n_alloc=max(n, 1), per=per)
+        # (st.buf: the block holds raw addresses of the buffer's tensors -- the reference keeps the buffer, and with it the identity
+        # id(buf) in the key, alive for as long as the block is)
+        st = types.SimpleNamespace(key=key, n_alloc=max(n, 1), per=per, buf=buf)
         f32 = dict(dtype=th.float32, device=dev)
         st.obs, st.next_obs = th.empty((B, D), **f32), th.empty((B, D), **f32)
         st.rewards, st.dones = th.empty((B, R), **f32), th.empty((B, 1), **f32)
