@@ -567,6 +567,11 @@ __device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, floa
         __syncthreads();
         tail_first = (s_ticket & 1u) != 0;
     }
+    // (in_mode 3: workgroup 0 reports the device-side row count to the host, whatever jobs it goes on to take -- ChainArgs::count_mirror)
+    if (b == 0 && threadIdx.x == 0)
+        for (int q = 0; q < m.n; ++q)
+            if (m.p[q].rows_dev != nullptr && m.p[q].count_mirror != nullptr)
+                *m.p[q].count_mirror = ((unsigned long long)m.p[q].count_tag << 32) | (unsigned int)*m.p[q].rows_dev;
     // jobs of this workgroup: `full_rounds` whole units and at most one tail job (every condition below is workgroup-uniform)
     for (int j = 0; j <= m.full_rounds; ++j) {
         const bool is_tail = tail_first ? (j == 0) : (j == m.full_rounds);
@@ -592,8 +597,6 @@ __device__ __forceinline__ void mlp_chain2_persistent(const Chain2Multi& m, floa
         int nrd = -1;
         if (m.p[q].rows_dev != nullptr) {
             nrd = min(m.p[q].rows, *m.p[q].rows_dev);
-            if (b == 0 && j == 0 && threadIdx.x == 0 && m.p[q].count_mirror != nullptr)
-                *m.p[q].count_mirror = ((unsigned long long)m.p[q].count_tag << 32) | (unsigned int)*m.p[q].rows_dev;
             if (row0 >= nrd) continue;
         }
         const int rows_q = nrd >= 0 ? nrd : m.p[q].rows;

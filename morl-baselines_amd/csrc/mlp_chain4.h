@@ -31,6 +31,7 @@ constexpr int C4_LDK = CH_MAXW + 8;         // activation row stride = 8 banks m
 constexpr int C4_CHUNK = 2;                 // 16-groups per register set of B (32 contraction indices)
 constexpr int C4_RING = 4;                  // register sets: the weight stream runs three sets ahead of the MFMAs
 static_assert(4 % C4_CHUNK == 0 && C4_RING >= 4 / C4_CHUNK, "a narrow step's 64-deep operand must fit the ring");
+static_assert(C4_TM * 32 <= CH_THREADS, "a narrow step's outputs (8 rows x at most 32 columns): one per thread");
 
 // A operand: lane l holds A[row l & 3][k0 + (l >> 2)] -- block j = l >> 2 of the 16 carries contraction index k0 + j -- and the
 // instruction's block broadcast (cbsz = 4: one block's A for all sixteen, abid = which) picks the index: ONE LDS dword per lane
@@ -44,9 +45,7 @@ struct C4BSet {
 };
 
 // K4 layout (mlp_chain2.h): element (k, n) at ((k >> 2) * 256 + n) * 4 + (k & 3); k4-rows beyond the matrix read as zeros
-__device__ __forceinline__ void c4_load(C4BSet& s, const ChainStep& st, int col, int chunk) {
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)st.Bmat, 0, (st.kpad > st.K ? st.kpad : st.K) * 256 * 4, 0x00020000);
+__device__ __forceinline__ void c4_load(C4BSet& s, __amdgpu_buffer_rsrc_t rsrc, int col, int chunk) {
 #pragma unroll
     for (int q = 0; q < 4 * C4_CHUNK; ++q)
         s.v[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, col * 16, (4 * C4_CHUNK * chunk + q) * 256 * 16, 0));
@@ -64,13 +63,40 @@ __device__ __forceinline__ int c4_chunks(const ChainStep& st) {
 // The weight stream: the 32-deep chunks of consecutive wide steps in order.  Streaming a 256 x 256 layer into one CU takes as
 // long as its MFMAs (64 B / clk against 8 rows x 256 x 256 MACs); with ONE set in flight every chunk also paid the L2 latency
 // (24 us for the flagship chain instead of 28 on 16-row tiles: still latency); three sets ahead hide it.
-struct C4Stream {
-    int step, chunk, end;       // next chunk to load; step == end: exhausted (end: first step that is not wide, or n_steps)
+//
+// Every call issues its eight loads UNCONDITIONALLY -- past the last wide step from a zero-sized buffer (zeros, no memory access)
+// -- and the descriptor of a step (base, size, chunk count: scalar loads from the argument block) is fetched one whole step ahead.
+// (Round 5: with the loads under `if (stream not exhausted)` the compiler's wait-count pass has to assume the branch not taken
+// and drained the whole ring -- s_waitcnt vmcnt(7..0) instead of vmcnt(23..16) -- once per turn of the ring, and the per-chunk
+// descriptor fetch stalled the wave's issue for a scalar-cache round trip in front of every chunk.)
+struct C4Desc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int n_chunks;
 };
+__device__ __forceinline__ C4Desc c4_desc(const ChainArgs& p, int s, int end) {
+    const bool live = s < end;                          // (workgroup-uniform)
+    const ChainStep& st = p.step[live ? s : 0];
+    C4Desc d;
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st.Bmat, 0, live ? (st.kpad > st.K ? st.kpad : st.K) * 256 * 4 : 0, 0x00020000);
+    d.n_chunks = live ? c4_chunks(st) : (1 << 30);
+    return d;
+}
+struct C4Stream {
+    C4Desc cur, nxt;
+    int step, chunk, end;       // next chunk to load; step >= end: exhausted (end: first step that is not wide, or n_steps)
+};
+__device__ __forceinline__ void c4_stream_begin(C4Stream& w, const ChainArgs& p, int n_wide) {
+    w.step = 0; w.chunk = 0; w.end = n_wide;
+    w.cur = c4_desc(p, 0, n_wide);
+    w.nxt = c4_desc(p, 1, n_wide);
+}
 __device__ __forceinline__ void c4_stream_load(C4BSet& s, C4Stream& w, const ChainArgs& p, int col) {
-    if (w.step >= w.end) return;                        // (workgroup-uniform)
-    c4_load(s, p.step[w.step], col, w.chunk);
-    if (++w.chunk >= c4_chunks(p.step[w.step])) { ++w.step; w.chunk = 0; }
+    c4_load(s, w.cur.rsrc, col, w.chunk);
+    if (++w.chunk >= w.cur.n_chunks) {                  // (workgroup-uniform)
+        w.cur = w.nxt;
+        ++w.step; w.chunk = 0;
+        w.nxt = c4_desc(p, w.step + 1, w.end);
+    }
 }
 
 // one 16-group: the 16 steps in mlp_chain16.h's order (t outer, kq inner: index 4 kq + t)
@@ -89,9 +115,18 @@ __device__ __forceinline__ void c4_compute(const C4BSet& b, const float* pa, int
     for (int g = 0; g < C4_CHUNK; ++g) {
         float a[C4_RG];
 #pragma unroll
+#if defined(C4_PROBE) && C4_PROBE == 3
+        for (int rg = 0; rg < C4_RG; ++rg) a[rg] = __builtin_bit_cast(float, (int)(0x3f800000 + k0 + rg));
+#else
         for (int rg = 0; rg < C4_RG; ++rg) a[rg] = pa[rg * 4 * C4_LDK + k0 + 16 * g];
+#endif
         const float4 bq[4] = {b.v[4 * g + 0], b.v[4 * g + 1], b.v[4 * g + 2], b.v[4 * g + 3]};
+#if defined(C4_PROBE) && C4_PROBE == 2
+#pragma unroll
+        for (int rg = 0; rg < C4_RG; ++rg) acc[rg][0] += a[rg] * (bq[0].x + bq[1].y + bq[2].z + bq[3].w);
+#else
         c4_group_steps<0, 0>(bq, a, acc);
+#endif
     }
 }
 
@@ -107,29 +142,93 @@ __device__ __forceinline__ void c4_wide_chunks(C4BSet (&ring)[C4_RING], C4Stream
     }
 }
 
-// rows [row0, row0 + 8) of the chain; sAct: two activation buffers of C4_TM x C4_LDK floats, sRed: 4 x C4_TM x 32 floats.
-// `flat`: in_mode 3, the pair of this thread's input row (loaded by the caller next to the row count)
-__device__ __forceinline__ void mlp_chain4_body(const ChainArgs& p, int row0, int n_rows, int flat, float* sAct, float* sRed) {
+constexpr int C4_NAR_LD = 68;               // floats per lane of a narrow step's staged operand (= 4 banks mod 32: the b128 reads are conflict-free)
+struct C4Shared {
+    float act[2 * C4_TM * C4_LDK];          // two activation buffers
+    float red[4 * C4_TM * 32];              // a narrow step's four partial tiles
+    float bias[MORL_MAX_LAYERS * CH_MAXW];  // bias[s][column] of the wide steps (zeros beyond N)
+    float nar[4 * 32 * C4_NAR_LD];          // nar[wave][lane < N][k - 64 wave]: a narrow last step's operand rows
+};
+
+// One wide step of a tile: the MFMA loop over the step's chunks (the stream running ahead into the next wide step), bias / ReLU,
+// the result into the other activation buffer (`feed`) and / or HBM.  The bias comes from LDS (staged by the prologue): a global
+// load here would sit at the tail of the weight stream's queue -- loads return in order, so waiting for it drains the stream and
+// adds its own round trip, once per layer (round 5: 3.5 - 4.4 us per 256 x 256 layer against 1.8 us of stream).
+__device__ __forceinline__ void c4_wide_step(const ChainArgs& p, int s, bool feed, C4BSet (&ring)[C4_RING], C4Stream& w, int col,
+                                             const float* cur, float* nxt, const float* sBias, int row0, int n_rows) {
+    const int lane = lane_id();
+    const ChainStep& st = p.step[s];
+    const int N = st.N;
+    const float* pa = cur + (lane & 3) * C4_LDK + (lane >> 2);
+    f32x4 acc[C4_RG];
+#pragma unroll
+    for (int rg = 0; rg < C4_RG; ++rg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[rg][r] = 0.f;
+    const int n_chunks = c4_chunks(st);
+    const bool relu = st.relu != 0;             // (the scalar fields the epilogue needs: fetched in front of the MFMA loop)
+    float* const outp = st.out;
+    const int ldout = st.ldout;
+    c4_wide_chunks(ring, w, p, col, pa, n_chunks, acc);
+    const float bias = sBias[s * CH_MAXW + col];
+#pragma unroll
+    for (int rg = 0; rg < C4_RG; ++rg)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = acc[rg][r] + bias;
+            if (relu) x = fmaxf(x, 0.f);
+            x = (col < N) ? x : 0.f;
+            const int m = rg * 4 + r;
+            if (feed) nxt[m * C4_LDK + col] = x;
+            if (outp != nullptr && col < N && row0 + m < n_rows) outp[(size_t)(row0 + m) * ldout + col] = x;
+        }
+}
+
+// rows [row0, row0 + 8) of the chain.  `flat`: in_mode 3, the pair of this thread's input row (loaded by the caller next to the
+// row count).
+//
+// Everything a tile needs besides the weight stream is fetched by the PROLOGUE, in front of the stream's first sets -- the input
+// columns (their addresses hang off the pair, itself the end of a dependent chain of fetches: argument block -> list -> pair),
+// every wide step's bias, a narrow last step's operand rows and bias -- and parked in LDS / registers; from there on the only
+// vector-memory traffic is the stream, which then never drains before the chain's end.
+__device__ __forceinline__ void mlp_chain4_body(const ChainArgs& p, int row0, int n_rows, int flat, C4Shared& sh) {
     const int tid = (int)threadIdx.x, lane = lane_id(), wave = wave_id();
     const int col = wave * 64 + lane;
-    float* cur = sAct;
-    float* nxt = sAct + C4_TM * C4_LDK;
+    float* cur = sh.act;
+    float* nxt = sh.act + C4_TM * C4_LDK;
 
-    C4BSet ring[C4_RING];
-    C4Stream w;
-    w.step = 0; w.chunk = 0; w.end = 0;
-    while (w.end < p.n_steps && c4_wide(p.step[w.end])) ++w.end;       // (the first step is wide: host guarantee)
+#ifdef C4_PROF
+    long long pt[12];
+    int pti = 0;
+#define C4_T() { if (pti < 12) pt[pti++] = wall_clock64(); }
+#else
+#define C4_T()
+#endif
+    C4_T()
+    // ---- prologue fetches: straight-line code -----------------------------------------------------------------------------
+    // No branch depends on a scalar field in here: every optional fetch is a buffer load whose descriptor's size says whether
+    // (and for which lanes) it touches memory, so the scalar fields of all eight step descriptors arrive in ONE batch of scalar
+    // loads -- the first form tested each pointer / count in turn, a scalar-cache round trip and a branch per vector load (45 of
+    // them in a row: 5 us from kernel entry to the first MFMA).
+    // chain4_ok(): step 0 is wide, a narrow step can only be the last one; steps beyond n_steps count as absent
+    int stN[MORL_MAX_LAYERS];
+    int n_wide = 0;
 #pragma unroll
-    for (int u = 0; u < C4_RING - 1; ++u) c4_stream_load(ring[u], w, p, col);
+    for (int s = 0; s < MORL_MAX_LAYERS; ++s) {
+        stN[s] = (s < p.n_steps) ? p.step[s].N : 0;
+        n_wide += (stN[s] > 32) ? 1 : 0;
+    }
+    const bool narrow_last = n_wide < p.n_steps;
 
-    // ---- input tile -> cur[m][k], zero-padded to the first step's contraction length -------------------------------------
+    const bool cat_mode = p.in_mode == 0 || p.in_mode == 3;
+    const int K0 = cat_mode ? (p.D + p.R) : p.K0;
+    const int in_m = tid >> 5, in_q = tid & 31;          // 32 threads per input row
+    const float* src_a;
+    const float* src_w;
+    bool row_ok;
     {
-        const bool cat_mode = p.in_mode == 0 || p.in_mode == 3;
-        const int K0 = cat_mode ? (p.D + p.R) : p.K0;
-        const int K0pad = min(CH_MAXW, c4_chunks(p.step[0]) * 16 * C4_CHUNK);     // what the first step's chunks read
-        const int m = tid >> 5, q = tid & 31;          // 32 threads per row
-        const int row = row0 + m;
-        const bool row_ok = row < n_rows;
+        const int row = row0 + in_m;
+        row_ok = row < n_rows;
         int b = row, wj = row;
         if (p.in_mode == 0) {
             if (p.row_order == 0) { b = row / p.W; wj = row - b * p.W; }
@@ -138,114 +237,142 @@ __device__ __forceinline__ void mlp_chain4_body(const ChainArgs& p, int row0, in
             const int f = row_ok ? flat : 0;
             b = f / p.W; wj = f - b * p.W;
         }
-        const float* src_a = cat_mode ? p.obs + (size_t)b * p.D : p.src + (size_t)row * p.ldsrc;
-        const float* src_w = p.weights + (size_t)wj * p.R;
-        for (int k = q; k < K0pad; k += 32) {
-            float x = 0.f;
-            if (row_ok && k < K0) x = cat_mode ? ((k < p.D) ? src_a[k] : src_w[k - p.D]) : src_a[k];
-            cur[m * C4_LDK + k] = x;
+        src_a = cat_mode ? p.obs + (size_t)b * p.D : p.src + (size_t)row * p.ldsrc;
+        src_w = p.weights + (size_t)wj * p.R;
+    }
+    auto in_elem = [&](int k) -> float {
+        float x = 0.f;
+        if (row_ok && k < K0) x = cat_mode ? ((k < p.D) ? src_a[k] : src_w[k - p.D]) : src_a[k];
+        return x;
+    };
+    const float x0 = in_elem(in_q), x1 = in_elem(in_q + 32);
+    float bias_w[MORL_MAX_LAYERS];
+#pragma unroll
+    for (int s = 0; s < MORL_MAX_LAYERS; ++s) {
+        const float* bp = p.step[s].bias;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)bp, 0, (bp != nullptr && stN[s] > 32) ? stN[s] * 4 : 0, 0x00020000);
+        bias_w[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, col * 4, 0, 0));       // zero beyond N / without a bias
+    }
+    // a narrow last step (N <= 32 outputs): lane l < N of wave w contracts k in [64w, 64w + 64) with row l of the N-major operand
+    float4 nar[16];
+    float nbias;
+    int nN;
+    {
+        const ChainStep& ns = p.step[min(n_wide, MORL_MAX_LAYERS - 1)];
+        nN = narrow_last ? max(ns.N, 1) : 1;
+        constexpr int OOR = 0x40000000;              // beyond any descriptor's size: the load returns zeros
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)ns.Bt, 0, narrow_last ? nN * ns.ldbt * 4 : 0, 0x00020000);
+        const int lim = ns.K - wave * 64;            // K is a multiple of 4
+        const int voff = (lane * ns.ldbt + wave * 64) * 4;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            nar[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, (4 * q < lim) ? voff + 16 * q : OOR, 0, 0));
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc((void*)ns.bias, 0, (narrow_last && ns.bias != nullptr) ? nN * 4 : 0, 0x00020000);
+        nbias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rn, (tid < C4_TM * nN) ? (tid % nN) * 4 : OOR, 0, 0));
+    }
+
+    C4BSet ring[C4_RING];
+    C4Stream w;
+    c4_stream_begin(w, p, n_wide);
+#pragma unroll
+    for (int u = 0; u < C4_RING - 1; ++u) c4_stream_load(ring[u], w, p, col);
+
+    // ---- park them: input tile -> cur[m][k], zero-padded to the first step's contraction length; biases; the narrow operand ----
+    {
+        const int K0pad = min(CH_MAXW, c4_chunks(p.step[0]) * 16 * C4_CHUNK);     // what the first step's chunks read: >= 128
+        cur[in_m * C4_LDK + in_q] = x0;
+        cur[in_m * C4_LDK + in_q + 32] = x1;
+        if (K0 > 64) {                                   // (workgroup-uniform; the wait for these loads drains the ring)
+            for (int k = in_q + 64; k < K0pad; k += 32) cur[in_m * C4_LDK + k] = in_elem(k);
+        } else {
+            for (int k = in_q + 64; k < K0pad; k += 32) cur[in_m * C4_LDK + k] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < MORL_MAX_LAYERS; ++s)
+            sh.bias[s * CH_MAXW + col] = bias_w[s];                               // (read back by this very thread)
+        if (narrow_last && lane < 32) {
+            float* d = sh.nar + (wave * 32 + lane) * C4_NAR_LD;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) *reinterpret_cast<float4*>(d + 4 * q) = nar[q];
         }
     }
     __syncthreads();
+    C4_T()
 
-    for (int s = 0; s < p.n_steps; ++s) {
-        const ChainStep& st = p.step[s];
-        const int K = st.K, N = st.N;
-        const bool feed_next = (s + 1 < p.n_steps);
-        const ChainStep& ns = p.step[feed_next ? s + 1 : s];
-        const bool nxt_narrow = feed_next && !c4_wide(ns);
+    // ---- the wide steps -----------------------------------------------------------------------------------------------------
+    for (int s = 0; s < n_wide; ++s) {
+        const bool feed = s + 1 < p.n_steps;
+        c4_wide_step(p, s, feed, ring, w, col, cur, nxt, sh.bias, row0, n_rows);
+        if (feed) __syncthreads();          // nxt complete, every wave past its last read of cur
+        C4_T()
+        float* t = cur; cur = nxt; nxt = t;
+    }
+
+    if (narrow_last) {
+        // ======================= narrow last step: split-K over the four waves ================================================
+        // wave w contracts k in [64w, 64w + 64) with the same instruction -- lane l < N is output column l, its operand row
+        // Bt[l][.] read N-major (staged in LDS by the prologue) -- i.e. the fma chains of mlp_chain16.h's narrow step (t outer /
+        // kq inner inside a 16-group); the four partial tiles are summed through LDS in wave order
+        const ChainStep& st = p.step[n_wide];
+        const int N = nN;
         const float* pa = cur + (lane & 3) * C4_LDK + (lane >> 2);
-
-        if (c4_wide(st)) {
-            // ======================= matrix-core path: 4 rows x 64 columns x 1 per instruction =============================
+        const int n_out = C4_TM * N;               // <= CH_THREADS: one output per thread
+        const int o_m = tid / N, o_n = tid - o_m * N;
+        const bool relu = st.relu != 0;
+        float* const outp = st.out;
+        const int ldout = st.ldout;
+        {
+            C4BSet nb[4 / C4_CHUNK];
+            const float* d = sh.nar + (wave * 32 + (lane & 31)) * C4_NAR_LD;
+#pragma unroll
+            for (int h = 0; h < 4 / C4_CHUNK; ++h)
+#pragma unroll
+                for (int q = 0; q < 4 * C4_CHUNK; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(d + 16 * C4_CHUNK * h + 4 * q);
+                    nb[h].v[q] = (lane < 32) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             f32x4 acc[C4_RG];
 #pragma unroll
             for (int rg = 0; rg < C4_RG; ++rg)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[rg][r] = 0.f;
-            const int n_chunks = c4_chunks(st);
-            c4_wide_chunks(ring, w, p, col, pa, n_chunks, acc);
-            if (nxt_narrow) {
-                // the stream ends here (every set is free): the next step's N-major operand rows ride under the epilogue and the barrier
-                const float* pb = ns.Bt + (size_t)lane * ns.ldbt + wave * 64;
 #pragma unroll
-                for (int h = 0; h < 4 / C4_CHUNK; ++h)
-#pragma unroll
-                    for (int q = 0; q < 4 * C4_CHUNK; ++q) {
-                        const int ko = 16 * C4_CHUNK * h + 4 * q;
-                        ring[h].v[q] = (lane < ns.N && wave * 64 + ko < ns.K) ? *reinterpret_cast<const float4*>(pb + ko)
-                                                                              : make_float4(0.f, 0.f, 0.f, 0.f);       // K is a multiple of 4
-                    }
-            }
-            // ---- epilogue: bias, ReLU -> the other activation buffer (and / or HBM for a wide last step) ------------------
-            const float bias = (st.bias != nullptr && col < N) ? st.bias[col] : 0.f;
-#pragma unroll
-            for (int rg = 0; rg < C4_RG; ++rg)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[rg][r] + bias;
-                    if (st.relu) x = fmaxf(x, 0.f);
-                    x = (col < N) ? x : 0.f;
-                    const int m = rg * 4 + r;
-                    if (feed_next) nxt[m * C4_LDK + col] = x;
-                    if (st.out != nullptr && col < N && row0 + m < n_rows) st.out[(size_t)(row0 + m) * st.ldout + col] = x;
-                }
-        } else {
-            // ======================= narrow step: split-K over the four waves ================================================
-            // wave w contracts k in [64w, 64w + 64) with the same instruction -- lane l < N is output column l, its operand row
-            // Bt[l][.] read N-major (into the first sets of the ring, by the wide step in front) -- i.e. the fma chains of
-            // mlp_chain16.h's narrow step (t outer / kq inner inside a 16-group); the four partial tiles are summed through LDS
-            // in wave order
-            {
-                f32x4 acc[C4_RG];
+            for (int h = 0; h < 4 / C4_CHUNK; ++h) c4_compute(nb[h], pa, wave * 64 + 16 * C4_CHUNK * h, acc);
+            if (lane < N)
 #pragma unroll
                 for (int rg = 0; rg < C4_RG; ++rg)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[rg][r] = 0.f;
-#pragma unroll
-                for (int h = 0; h < 4 / C4_CHUNK; ++h) c4_compute(ring[h], pa, wave * 64 + 16 * C4_CHUNK * h, acc);
-                if (lane < N)
-#pragma unroll
-                    for (int rg = 0; rg < C4_RG; ++rg)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) sRed[wave * (C4_TM * 32) + (rg * 4 + r) * N + lane] = acc[rg][r];
-            }
-            const int n_out = C4_TM * N;
-            // a wide step behind this one: its stream starts over
-            w.step = s + 1; w.chunk = 0; w.end = s + 1;
-            while (w.end < p.n_steps && c4_wide(p.step[w.end])) ++w.end;
-#pragma unroll
-            for (int u = 0; u < C4_RING - 1; ++u) c4_stream_load(ring[u], w, p, col);
-            __syncthreads();
-            for (int o = tid; o < n_out; o += CH_THREADS) {
-                const int m = o / N, n = o - m * N;
-                float v = sRed[o];
-                v += sRed[1 * (C4_TM * 32) + o];
-                v += sRed[2 * (C4_TM * 32) + o];
-                v += sRed[3 * (C4_TM * 32) + o];
-                v += (st.bias != nullptr) ? st.bias[n] : 0.f;
-                if (st.relu) v = fmaxf(v, 0.f);
-                const bool ok = row0 + m < n_rows;
-                if (!ok) v = 0.f;
-                if (feed_next) nxt[m * C4_LDK + n] = v;
-                if (st.out != nullptr && ok) st.out[(size_t)(row0 + m) * st.ldout + n] = v;
-            }
-            if (feed_next)      // the next step reads K' = N <= 32 padded to 64 columns
-                for (int e = tid; e < C4_TM * 64; e += CH_THREADS) {
-                    const int m = e >> 6, k = e & 63;
-                    if (k >= N) nxt[m * C4_LDK + k] = 0.f;
-                }
+                    for (int r = 0; r < 4; ++r) sh.red[wave * (C4_TM * 32) + (rg * 4 + r) * N + lane] = acc[rg][r];
         }
-        __syncthreads();          // nxt complete, every wave past its last read of cur
-        float* t = cur; cur = nxt; nxt = t;
+        __syncthreads();
+        if (tid < n_out) {
+            float v = sh.red[tid];
+            v += sh.red[1 * (C4_TM * 32) + tid];
+            v += sh.red[2 * (C4_TM * 32) + tid];
+            v += sh.red[3 * (C4_TM * 32) + tid];
+            v += nbias;
+            if (relu) v = fmaxf(v, 0.f);
+            if (outp != nullptr && row0 + o_m < n_rows) outp[(size_t)(row0 + o_m) * ldout + o_n] = v;
+        }
+        C4_T()
     }
+#ifdef C4_PROF
+    if (p.prof != nullptr && tid == 0) {
+        long long* o = p.prof + (size_t)blockIdx.x * 16;
+        o[0] = pti;
+        for (int i = 0; i < pti; ++i) o[2 + i] = pt[i];
+    }
+#endif
+#undef C4_T
 }
 
 // One workgroup per 8-row tile of ONE chain (single network: nb <= 1)
 static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain4_kernel(ChainArgs p) {
-    __shared__ __attribute__((aligned(16))) float sAct[2 * C4_TM * C4_LDK];
-    __shared__ float sRed[4 * C4_TM * 32];
+    __shared__ __attribute__((aligned(16))) C4Shared sh;
     const int row0 = (int)blockIdx.x * C4_TM;
+#ifdef C4_PROF
+    if (p.prof != nullptr && threadIdx.x == 0) p.prof[16 * 4096 + 1 + blockIdx.x] = wall_clock64();      // kernel entry, before any argument is read
+#endif
     // the row count and this thread's pair are fetched together (a stale list entry is a pair of an earlier step: in range once
     // clamped; it is only used if the row turns out to exist)
     const int n_pairs = p.B * p.W;
@@ -255,7 +382,7 @@ static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain4_kernel(ChainA
         *p.count_mirror = ((unsigned long long)p.count_tag << 32) | (unsigned int)*p.rows_dev;
     if (row0 >= n_rows) return;                                               // (workgroup-uniform)
     flat = min(max(flat, 0), n_pairs - 1);
-    mlp_chain4_body(p, row0, n_rows, flat, sAct, sRed);
+    mlp_chain4_body(p, row0, n_rows, flat, sh);
 }
 
 constexpr int C4_MAX_ROWS = 2048;           // (general forward chains: one tile per CU at most; the lazy target rows always take these tiles)
