@@ -56,6 +56,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         base.append("-DBF_PROF")
     if os.environ.get("MORL_C16_PROF"):    # development build: phase stamps in the 16-row chain kernel (mlp_chain16.h)
         base.append("-DC16_PROF")
+    if os.environ.get("MORL_C4_PROF"):     # development build: wall-clock stamps in the 8-row chain kernel (mlp_chain4.h), printed by the library
+        base.append("-DC4_PROF")
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(ROOT, "include", "morl_hip.h")]

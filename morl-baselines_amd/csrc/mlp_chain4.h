@@ -8,8 +8,21 @@
 // block, a 4-row x 64-column outer-product step per instruction (K = 1, 8 cycles) -- one lane per column, the four rows in the
 // four accumulator registers.  A workgroup carries 8 rows (two independent accumulator sets per lane: the dependent-issue
 // latency of the instruction is hidden, and the weights a lane streams are used twice): 170 tiles on 170 CUs at the flagship
-// shape, 1.7 us of MFMA per layer and tile -- equal to what streaming a 256 x 256 layer from L2 into one CU costs at 64 B / clk,
-// which is the bound that remains; the stream runs three 32-deep register sets ahead of the MFMAs, across layer boundaries.
+// shape.  A 256 x 256 layer is 512 MFMAs per wave -- 2.4 us at the instruction's measured issue rate (4.7 ns with two or more
+// accumulators, profiles/r03_mfma_4x4x1_probe.txt) -- beside 1.8 us of weight stream (256 KB into one CU at 64 B / clk:
+// tools/probes/stream_probe.hip reaches 145 GB/s per CU with 8 or more loads in flight per lane); the stream runs three 32-deep
+// register sets ahead of the MFMAs, across layer boundaries.
+//
+// Round 5, from wall-clock stamps of one tile (-DC4_PROF, `MORL_C4_PROF=1 python build.py`; us after kernel entry, flagship chain
+// 35 -> 256 x 4 -> 18, before -> after): prologue to the first MFMA 3.6 -> 2.9, input step 2.4 -> 1.5, each 256 x 256 step
+// 3.5 - 4.4 -> 3.3 (MFMA loop 2.85, epilogue 0.36, barrier 0.1), head 1.8 -> 1.1; mlp_chain4_kernel 23.2 -> 18.7 us inside the
+// step.  What was wrong was not the MFMA loop: (1) the stream's loads stood under `if (stream not exhausted)`, so the compiler's
+// wait-count pass drained the ring once per turn; (2) every chunk fetched its step descriptor with scalar loads in the loop --
+// a scalar load's out-of-order return turns every LDS wait behind it into a full one; (3) each layer's bias was a global load
+// behind the stream (loads return in order: a drain plus a round trip per layer); (4) wide and narrow steps shared one loop body
+// and the ring went through register copies behind a full drain at every step boundary; (5) the prologue tested 45 optional
+// fetches one by one, a scalar round trip and a branch each.  What remains is the instruction's issue rate (the loops run at
+// 0.84 of it) and ~6 us of launch, argument, input and head latency around four layers.
 //
 //   wave w owns columns [64w, 64w + 64); lane l is column 64w + l and supplies B[k][64w + l]; lane l reads A[row = l & 3 (+ 4)]
 //   [k0 + (l >> 2)] from LDS, one dword per 16 contraction indices (block broadcast: see mfma4).  The contraction order inside
@@ -90,12 +103,14 @@ __device__ __forceinline__ void c4_stream_begin(C4Stream& w, const ChainArgs& p,
     w.cur = c4_desc(p, 0, n_wide);
     w.nxt = c4_desc(p, 1, n_wide);
 }
-__device__ __forceinline__ void c4_stream_load(C4BSet& s, C4Stream& w, const ChainArgs& p, int col) {
+// (no scalar fetch in here: a scalar load's out-of-order return makes every LDS wait behind it a full one -- the compiler can
+// no longer count -- and this sits inside the MFMA loop; `nxt` is refreshed once per step by c4_wide_step.  The stream runs three
+// chunks ahead and a step has at least four: it crosses exactly one step boundary per step.)
+__device__ __forceinline__ void c4_stream_load(C4BSet& s, C4Stream& w, int col) {
     c4_load(s, w.cur.rsrc, col, w.chunk);
     if (++w.chunk >= w.cur.n_chunks) {                  // (workgroup-uniform)
         w.cur = w.nxt;
         ++w.step; w.chunk = 0;
-        w.nxt = c4_desc(p, w.step + 1, w.end);
     }
 }
 
@@ -109,35 +124,49 @@ __device__ __forceinline__ void c4_group_steps(const float4 (&b)[4], const float
     else if constexpr (T < 3) c4_group_steps<T + 1, 0>(b, a, acc);
 }
 
-// one chunk: C4_CHUNK groups x 16 MFMA steps x C4_RG accumulator sets; pa: cur + (lane & 3) * C4_LDK + (lane >> 2)
-__device__ __forceinline__ void c4_compute(const C4BSet& b, const float* pa, int k0, f32x4 (&acc)[C4_RG]) {
+// The A values of one chunk: one LDS dword per lane, 16-group and row group; pa: cur + (lane & 3) * C4_LDK + (lane >> 2)
+struct C4A {
+    float v[C4_CHUNK][C4_RG];
+};
+__device__ __forceinline__ void c4_read_a(C4A& a, const float* pa, int k0) {
 #pragma unroll
-    for (int g = 0; g < C4_CHUNK; ++g) {
-        float a[C4_RG];
+    for (int g = 0; g < C4_CHUNK; ++g)
 #pragma unroll
-#if defined(C4_PROBE) && C4_PROBE == 3
-        for (int rg = 0; rg < C4_RG; ++rg) a[rg] = __builtin_bit_cast(float, (int)(0x3f800000 + k0 + rg));
-#else
-        for (int rg = 0; rg < C4_RG; ++rg) a[rg] = pa[rg * 4 * C4_LDK + k0 + 16 * g];
-#endif
-        const float4 bq[4] = {b.v[4 * g + 0], b.v[4 * g + 1], b.v[4 * g + 2], b.v[4 * g + 3]};
-#if defined(C4_PROBE) && C4_PROBE == 2
-#pragma unroll
-        for (int rg = 0; rg < C4_RG; ++rg) acc[rg][0] += a[rg] * (bq[0].x + bq[1].y + bq[2].z + bq[3].w);
-#else
-        c4_group_steps<0, 0>(bq, a, acc);
-#endif
-    }
+        for (int rg = 0; rg < C4_RG; ++rg) a.v[g][rg] = pa[rg * 4 * C4_LDK + k0 + 16 * g];
 }
 
+// one chunk: C4_CHUNK groups x 16 MFMA steps x C4_RG accumulator sets.  `a` holds this chunk's A values on entry and the NEXT
+// chunk's (k0 + 32 ..) on return: their LDS reads are issued in front of this chunk's MFMAs (read next to their use, every
+// chunk's 64 MFMAs waited for an LDS round trip first: 0.4 us of a 256 x 256 layer's 3.2).  Behind a step's last chunk the read
+// runs up to 32 + 15 floats past the row -- into the next row, buffer or array of C4Shared -- and is dropped.  The order -- this
+// segment's weight loads (the caller's), the next chunk's A reads, then the MFMAs -- is pinned: left alone the scheduler sinks
+// the loads into the MFMAs and the stream runs one set ahead instead of three.
+__device__ __forceinline__ void c4_compute(const C4BSet& b, const float* pa, int k0, f32x4 (&acc)[C4_RG], C4A& a) {
+    const C4A cur = a;
+    c4_read_a(a, pa, k0 + 16 * C4_CHUNK);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < C4_CHUNK; ++g) {
+        const float av[C4_RG] = {cur.v[g][0], cur.v[g][1]};
+        const float4 bq[4] = {b.v[4 * g + 0], b.v[4 * g + 1], b.v[4 * g + 2], b.v[4 * g + 3]};
+        c4_group_steps<0, 0>(bq, av, acc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+static_assert(C4_RG == 2, "c4_compute spells out the two row groups");
+
 // the chunks of one wide step (a multiple of C4_RING: its first chunk is in slot 0)
-__device__ __forceinline__ void c4_wide_chunks(C4BSet (&ring)[C4_RING], C4Stream& w, const ChainArgs& p, int col, const float* pa,
-                                               int n_chunks, f32x4 (&acc)[C4_RG]) {
+__device__ __forceinline__ void c4_wide_chunks(C4BSet (&ring)[C4_RING], C4Stream& w, int col, const float* pa,
+                                               int n_chunks, int k_live, f32x4 (&acc)[C4_RG]) {
+    C4A a;
+    c4_read_a(a, pa, 0);
     for (int ch = 0; ch < n_chunks; ch += C4_RING) {
 #pragma unroll
         for (int u = 0; u < C4_RING; ++u) {
-            c4_stream_load(ring[(u + C4_RING - 1) % C4_RING], w, p, col);       // the set consumed last is free
-            c4_compute(ring[u], pa, 16 * C4_CHUNK * (ch + u), acc);
+            c4_stream_load(ring[(u + C4_RING - 1) % C4_RING], w, col);       // the set consumed last is free
+            // (chunks that only pad the step to a whole turn of the ring -- K <= 64: the input step -- are loaded, as zeros from
+            // beyond the matrix, to keep the ring turning, but not multiplied)
+            if (16 * C4_CHUNK * (ch + u) < k_live) c4_compute(ring[u], pa, 16 * C4_CHUNK * (ch + u), acc, a);
         }
     }
 }
@@ -154,8 +183,17 @@ struct C4Shared {
 // the result into the other activation buffer (`feed`) and / or HBM.  The bias comes from LDS (staged by the prologue): a global
 // load here would sit at the tail of the weight stream's queue -- loads return in order, so waiting for it drains the stream and
 // adds its own round trip, once per layer (round 5: 3.5 - 4.4 us per 256 x 256 layer against 1.8 us of stream).
+#ifdef C4_PROF
+#define C4_PROF_PARAMS , long long (&pt)[40], int& pti
+#define C4_PROF_ARGS , pt, pti
+#define C4_T() { if (pti < 40) pt[pti++] = wall_clock64(); }
+#else
+#define C4_PROF_PARAMS
+#define C4_PROF_ARGS
+#define C4_T()
+#endif
 __device__ __forceinline__ void c4_wide_step(const ChainArgs& p, int s, bool feed, C4BSet (&ring)[C4_RING], C4Stream& w, int col,
-                                             const float* cur, float* nxt, const float* sBias, int row0, int n_rows) {
+                                             const float* cur, float* nxt, const float* sBias, int row0, int n_rows C4_PROF_PARAMS) {
     const int lane = lane_id();
     const ChainStep& st = p.step[s];
     const int N = st.N;
@@ -166,10 +204,13 @@ __device__ __forceinline__ void c4_wide_step(const ChainArgs& p, int s, bool fee
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[rg][r] = 0.f;
     const int n_chunks = c4_chunks(st);
+    w.nxt = c4_desc(p, s + 1, w.end);           // the step the stream moves on to during this one
     const bool relu = st.relu != 0;             // (the scalar fields the epilogue needs: fetched in front of the MFMA loop)
     float* const outp = st.out;
     const int ldout = st.ldout;
-    c4_wide_chunks(ring, w, p, col, pa, n_chunks, acc);
+    C4_T()
+    c4_wide_chunks(ring, w, col, pa, n_chunks, ((st.K + 63) >> 6) << 6, acc);
+    C4_T()
     const float bias = sBias[s * CH_MAXW + col];
 #pragma unroll
     for (int rg = 0; rg < C4_RG; ++rg)
@@ -198,11 +239,8 @@ __device__ __forceinline__ void mlp_chain4_body(const ChainArgs& p, int row0, in
     float* nxt = sh.act + C4_TM * C4_LDK;
 
 #ifdef C4_PROF
-    long long pt[12];
+    long long pt[40];
     int pti = 0;
-#define C4_T() { if (pti < 12) pt[pti++] = wall_clock64(); }
-#else
-#define C4_T()
 #endif
     C4_T()
     // ---- prologue fetches: straight-line code -----------------------------------------------------------------------------
@@ -275,7 +313,7 @@ __device__ __forceinline__ void mlp_chain4_body(const ChainArgs& p, int row0, in
     C4Stream w;
     c4_stream_begin(w, p, n_wide);
 #pragma unroll
-    for (int u = 0; u < C4_RING - 1; ++u) c4_stream_load(ring[u], w, p, col);
+    for (int u = 0; u < C4_RING - 1; ++u) c4_stream_load(ring[u], w, col);
 
     // ---- park them: input tile -> cur[m][k], zero-padded to the first step's contraction length; biases; the narrow operand ----
     {
@@ -302,7 +340,8 @@ __device__ __forceinline__ void mlp_chain4_body(const ChainArgs& p, int row0, in
     // ---- the wide steps -----------------------------------------------------------------------------------------------------
     for (int s = 0; s < n_wide; ++s) {
         const bool feed = s + 1 < p.n_steps;
-        c4_wide_step(p, s, feed, ring, w, col, cur, nxt, sh.bias, row0, n_rows);
+        c4_wide_step(p, s, feed, ring, w, col, cur, nxt, sh.bias, row0, n_rows C4_PROF_ARGS);
+        C4_T()
         if (feed) __syncthreads();          // nxt complete, every wave past its last read of cur
         C4_T()
         float* t = cur; cur = nxt; nxt = t;
@@ -336,8 +375,10 @@ __device__ __forceinline__ void mlp_chain4_body(const ChainArgs& p, int row0, in
             for (int rg = 0; rg < C4_RG; ++rg)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[rg][r] = 0.f;
+            C4A a;
+            c4_read_a(a, pa, wave * 64);
 #pragma unroll
-            for (int h = 0; h < 4 / C4_CHUNK; ++h) c4_compute(nb[h], pa, wave * 64 + 16 * C4_CHUNK * h, acc);
+            for (int h = 0; h < 4 / C4_CHUNK; ++h) c4_compute(nb[h], pa, wave * 64 + 16 * C4_CHUNK * h, acc, a);
             if (lane < N)
 #pragma unroll
                 for (int rg = 0; rg < C4_RG; ++rg)
@@ -358,20 +399,32 @@ __device__ __forceinline__ void mlp_chain4_body(const ChainArgs& p, int row0, in
     }
 #ifdef C4_PROF
     if (p.prof != nullptr && tid == 0) {
-        long long* o = p.prof + (size_t)blockIdx.x * 16;
+        long long* o = p.prof + (size_t)blockIdx.x * 48;
         o[0] = pti;
         for (int i = 0; i < pti; ++i) o[2 + i] = pt[i];
     }
 #endif
-#undef C4_T
 }
+#undef C4_T
+#undef C4_PROF_PARAMS
+#undef C4_PROF_ARGS
 
 // One workgroup per 8-row tile of ONE chain (single network: nb <= 1)
 static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain4_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) C4Shared sh;
     const int row0 = (int)blockIdx.x * C4_TM;
+#if defined(__AMDGCN__)
+    {   // the whole argument block (1 KB: sixteen lines of the scalar cache) in ONE round trip: the prologue reads it in several
+        // dependent batches, each of which otherwise pays its own first-touch misses
+        const __attribute__((address_space(4))) int* ka = (const __attribute__((address_space(4))) int*)__builtin_amdgcn_kernarg_segment_ptr();
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(ChainArgs) / 64); ++i) t |= ka[i * 16];
+        asm volatile("" ::"s"(t));
+    }
+#endif
 #ifdef C4_PROF
-    if (p.prof != nullptr && threadIdx.x == 0) p.prof[16 * 4096 + 1 + blockIdx.x] = wall_clock64();      // kernel entry, before any argument is read
+    if (p.prof != nullptr && threadIdx.x == 0) p.prof[48 * 4096 + 1 + blockIdx.x] = wall_clock64();      // kernel entry, before any argument is read
 #endif
     // the row count and this thread's pair are fetched together (a stale list entry is a pair of an earlier step: in range once
     // clamped; it is only used if the row turns out to exist)

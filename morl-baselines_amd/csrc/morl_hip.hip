@@ -810,7 +810,7 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
         // development build (-DC4_PROF): wall_clock64 stamps (10 ns) of every workgroup, printed for a few launches
         static long long* prof_dev = nullptr;
         static int launch_no = 0;
-        if (!prof_dev) hipMalloc(&prof_dev, (size_t)(16 * 4096 + 1 + 4096) * 8);
+        if (!prof_dev) hipMalloc(&prof_dev, (size_t)(48 * 4096 + 1 + 4096) * 8);
         ChainArgs c4a = chains[0];
         c4a.prof = prof_dev;
         hipLaunchKernelGGL(mlp_chain4_kernel, dim3((chains[0].rows + C4_TM - 1) / C4_TM), dim3(CH_THREADS), 0, s, c4a);
@@ -821,15 +821,15 @@ static int chain2_launch(morl_ctx* c, const ChainArgs* chains, int n, hipStream_
         if (++launch_no % 100 == 50) {
             const int tiles = (chains[0].rows + C4_TM - 1) / C4_TM;
             hipStreamSynchronize(s);
-            std::vector<long long> h((size_t)16 * 4096 + 1 + 4096);
+            std::vector<long long> h((size_t)48 * 4096 + 1 + 4096);
             hipMemcpy(h.data(), prof_dev, h.size() * 8, hipMemcpyDeviceToHost);
-            long long t_first = h[16 * 4096 + 1];
-            for (int b = 0; b < tiles; ++b) t_first = std::min(t_first, h[16 * 4096 + 1 + b]);
+            long long t_first = h[48 * 4096 + 1];
+            for (int b = 0; b < tiles; ++b) t_first = std::min(t_first, h[48 * 4096 + 1 + b]);
             for (int b : {0, tiles / 2, tiles - 1}) {
-                const long long* o = h.data() + (size_t)b * 16;
-                fprintf(stderr, "C4_PROF launch %d tile %d/%d: entry +%.2f us;", launch_no, b, tiles, (h[16 * 4096 + 1 + b] - t_first) * 0.01);
-                for (int i = 0; i < (int)o[0]; ++i) fprintf(stderr, " %.2f", (o[2 + i] - h[16 * 4096 + 1 + b]) * 0.01);
-                fprintf(stderr, " (us after entry: body start, input staged, after each step)\n");
+                const long long* o = h.data() + (size_t)b * 48;
+                fprintf(stderr, "C4_PROF launch %d tile %d/%d: entry +%.2f us;", launch_no, b, tiles, (h[48 * 4096 + 1 + b] - t_first) * 0.01);
+                for (int i = 0; i < (int)o[0]; ++i) fprintf(stderr, " %.2f", (o[2 + i] - h[48 * 4096 + 1 + b]) * 0.01);
+                fprintf(stderr, " (us after entry: body start, input staged, then per wide step: loop start, loop end, epilogue done, barrier passed; narrow step)\n");
             }
         }
 #endif

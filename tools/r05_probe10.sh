@@ -6,8 +6,8 @@ R=$PWD
 for v in new probe_old probe2 probe3; do
   if [ $v = new ]; then L=$R/morl-baselines_amd/lib/libmorl_hip.so; else L=$R/morl-baselines_amd/lib/$v/libmorl_hip.so; fi
   echo "== $v"
-  MORL_HIP_LIB=$L timeout 120 python tools/c4_rows.py 2>&1 | tail -4
-  (cd /tmp && MORL_HIP_LIB=$L timeout 200 rocprofv3 --kernel-trace --stats -d $R/$O/prof_$v -o p -- python $R/tools/c4_rows.py > /dev/null 2>&1)
+  MORL_HIP_LIB=$L timeout 120 python tools/chain4_rows.py 2>&1 | tail -4
+  (cd /tmp && MORL_HIP_LIB=$L timeout 200 rocprofv3 --kernel-trace --stats -d $R/$O/prof_$v -o p -- python $R/tools/chain4_rows.py > /dev/null 2>&1)
   python - <<PY
 import csv, glob
 for f in glob.glob("$R/$O/prof_$v/**/*kernel_stats.csv", recursive=True):

@@ -3,7 +3,7 @@ O=gpurun_out/r05_probe11
 mkdir -p $O
 R=$PWD
 echo "== phase stamps"
-MORL_HIP_LIB=$R/morl-baselines_amd/lib/probe_prof/libmorl_hip.so timeout 120 python tools/c4_rows.py 2>&1 | grep -v "^rows" | tee $O/c4_prof.txt | head -40
+MORL_HIP_LIB=$R/morl-baselines_amd/lib/probe_prof/libmorl_hip.so timeout 120 python tools/chain4_rows.py 2>&1 | grep -v "^rows" | tee $O/c4_prof.txt | head -40
 echo "== kernarg placement"
 for k in 0 1; do
   for i in 1 2; do

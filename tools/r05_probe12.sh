@@ -4,10 +4,10 @@ mkdir -p $O
 export TMPDIR=/tmp
 R=$PWD
 echo "== phase stamps"
-MORL_HIP_LIB=$R/morl-baselines_amd/lib/probe_prof/libmorl_hip.so timeout 120 python tools/c4_rows.py 2>&1 | grep "C4_PROF" | tee $O/c4_prof.txt | awk 'NR%3==1' | tail -6
+MORL_HIP_LIB=$R/morl-baselines_amd/lib/probe_prof/libmorl_hip.so timeout 120 python tools/chain4_rows.py 2>&1 | grep "C4_PROF" | tee $O/c4_prof.txt | awk 'NR%3==1' | tail -6
 for v in new probe_old; do
   if [ $v = new ]; then L=$R/morl-baselines_amd/lib/libmorl_hip.so; else L=$R/morl-baselines_amd/lib/$v/libmorl_hip.so; fi
-  (cd /tmp && MORL_HIP_LIB=$L timeout 200 rocprofv3 --kernel-trace --stats -d $R/$O/prof_$v -o p -- python $R/tools/c4_rows.py > /dev/null 2>&1)
+  (cd /tmp && MORL_HIP_LIB=$L timeout 200 rocprofv3 --kernel-trace --stats -d $R/$O/prof_$v -o p -- python $R/tools/chain4_rows.py > /dev/null 2>&1)
   for i in 1 2; do
     MORL_HIP_LIB=$L timeout 200 python bench.py --no-cpu-baseline --no-ramp-record --steps 200 --warmup 30 > $O/bench_${v}_$i.json 2>/dev/null
     python -c "
