@@ -38,10 +38,12 @@ struct C16Desc {
     int stride;        // bytes per k-row
 };
 
-__device__ __forceinline__ C16Desc c16_desc(const ChainStep& st, int wave, int j, int kq, int g) {
+// live == false: a zero-sized descriptor -- loads through it return zeros without touching memory (the stream's look-ahead past the
+// last wide step of a run, issued unconditionally: a load under a branch costs the MFMA loop its look-ahead, see mlp_chain16_body)
+__device__ __forceinline__ C16Desc c16_desc(const ChainStep& st, int wave, int j, int kq, int g, bool live = true) {
     C16Desc d;
     const int col = wave * 64 + 4 * j;
-    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bmat + g * st.sW), 0, (st.kpad > st.K ? st.kpad : st.K) * st.ldb * 4, 0x00020000);
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bmat + g * st.sW), 0, live ? (st.kpad > st.K ? st.kpad : st.K) * st.ldb * 4 : 0, 0x00020000);
     d.lane_off = (col < st.ldb) ? (4 * kq * st.ldb + col) * 4 : CH_OOB;
     d.stride = st.ldb * 4;
     return d;
@@ -60,10 +62,10 @@ __device__ __forceinline__ void c16_load_wide(C16BSet& s, const C16Desc& d, int 
 // ChainArgs::fast == 1 (the contexts whose wide steps all have 256 columns): the operand is in the K4 layout of mlp_chain2.h's
 // c2_load_fast -- element (k, n) at ((k >> 2) * 256 + n) * 4 + (k & 3).  The four k of a lane's group are 16 contiguous bytes
 // per column: four loads per group as before, one per COLUMN instead of one per k, the register set filled transposed.
-__device__ __forceinline__ C16Desc c16_desc_k4(const ChainStep& st, int wave, int j, int kq, int g) {
+__device__ __forceinline__ C16Desc c16_desc_k4(const ChainStep& st, int wave, int j, int kq, int g, bool live = true) {
     C16Desc d;
     const int col = wave * 64 + 4 * j;
-    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bmat + g * st.sW), 0, (st.kpad > st.K ? st.kpad : st.K) * 256 * 4, 0x00020000);
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bmat + g * st.sW), 0, live ? (st.kpad > st.K ? st.kpad : st.K) * 256 * 4 : 0, 0x00020000);
     d.lane_off = (kq * 256 + col) * 16;
     d.stride = 256 * 16;              // bytes per k4-row
     return d;
@@ -85,8 +87,8 @@ __device__ __forceinline__ void c16_load_k4(C16BSet& s, const C16Desc& d, int k0
 }
 
 template <bool K4>
-__device__ __forceinline__ C16Desc c16_desc_t(const ChainStep& st, int wave, int j, int kq, int g) {
-    return K4 ? c16_desc_k4(st, wave, j, kq, g) : c16_desc(st, wave, j, kq, g);
+__device__ __forceinline__ C16Desc c16_desc_t(const ChainStep& st, int wave, int j, int kq, int g, bool live = true) {
+    return K4 ? c16_desc_k4(st, wave, j, kq, g, live) : c16_desc(st, wave, j, kq, g, live);
 }
 template <bool K4>
 __device__ __forceinline__ void c16_load_t(C16BSet& s, const C16Desc& d, int k0) {
@@ -95,8 +97,9 @@ __device__ __forceinline__ void c16_load_t(C16BSet& s, const C16Desc& d, int k0)
 
 // narrow step: wave w contracts k in [64w, 64w + 64) = 4 groups of 16; lane (j = column within the tile, kq) loads
 // Bt[n][64w + 16c + 4kq .. +3] for the two column tiles n = j and n = 16 + j: v[2c + ct]
-__device__ __forceinline__ void c16_load_narrow(C16BSet& s, const ChainStep& st, int wave, int j, int kq, int g) {
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bt + g * st.sW), 0, st.N * st.ldbt * 4, 0x00020000);
+// (live == false: a zero-sized descriptor, eight loads that touch no memory -- see c16_desc)
+__device__ __forceinline__ void c16_load_narrow(C16BSet& s, const ChainStep& st, int wave, int j, int kq, int g, bool live = true) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(st.Bt + g * st.sW), 0, live ? st.N * st.ldbt * 4 : 0, 0x00020000);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int k = wave * 64 + 16 * c + 4 * kq;
@@ -329,12 +332,13 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
 #else
 #define C16_T(q)
 #endif
-    C16BSet bx, by;
+    // bx / by: the two sets of the wide steps' weight stream; bn: a narrow step's operand -- a set of its own, because what is
+    // loaded into a set behind one step and used in the next is, to the compiler, loaded in front of EVERY kind of next step:
+    // with the narrow operand in bx each pair of a wide step waited for all loads in flight before its last four MFMAs
+    C16BSet bx, by, bn;
     const bool first_wide = p.step[0].N > 32;
-    bool narrow_ready = !first_wide;          // the narrow step's operand is already in bx
+    bool narrow_ready = !first_wide;          // the narrow step's operand is already in bn
     C16Desc dcur = c16_desc_t<K4>(p.step[0], wave, j, kq, g);
-    if (first_wide) c16_load_t<K4>(bx, dcur, 0);
-    else c16_load_narrow(bx, p.step[0], wave, j, kq, g);
 
     // ---- input tile -> sAct[m][k], zero-padded to the columns the first step multiplies --------------------------------
     {
@@ -366,8 +370,10 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
                 if (q == 0 && row_ok) hook(g, row, hv);
             }
         }
-        if (kb < K0pad) {
-            float v[16];
+        // (the input rows' loads stand in front of the weight stream's first sets: the wait for them then leaves the sets in flight)
+        float v[16];
+        const bool in_live = kb < K0pad;
+        if (in_live) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const int k = kb + u;
@@ -379,6 +385,10 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
                 }
                 v[u] = x;
             }
+        }
+        if (first_wide) { c16_load_t<K4>(bx, dcur, 0); c16_load_t<K4>(by, dcur, CH_BK); }
+        else c16_load_narrow(bn, p.step[0], wave, j, kq, g);
+        if (in_live) {
 #pragma unroll
             for (int u = 0; u < 16; u += 4)
                 *reinterpret_cast<float4*>(sAct + m * C2_LDK + kb + u) = make_float4(v[u], v[u + 1], v[u + 2], v[u + 3]);
@@ -412,31 +422,48 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[ct][r] = 0.f;
             const int n_pairs = (K + 63) >> 6;          // K is treated as padded to a multiple of 64 with zero rows
-            c16_load_t<K4>(by, dcur, CH_BK);
+            // (both sets hold this step's first two chunks: the prologue, the wide step or the narrow step in front loaded them)
             // what the epilogue needs from memory is requested before the contraction, not behind its barrier (phase stamps of a
             // -DC16_PROF build: 1 500 of a step's 3 300 epilogue cycles were these two loads' latency)
-            float bias[4] = {0.f, 0.f, 0.f, 0.f};
-            if (st.bias != nullptr) {
+            // -- as range-checked buffer loads, NOT under `if (column exists)` / `if (pointer)`: a load under a branch in front of the
+            // MFMA loop is, to the compiler's wait-count pass, a load that may or may not stand between the weight stream's sets and
+            // their use, and the loop's waits came out as "all but two" (round 5)
+            float bias[4];
+            {
+                const float* bp = st.bias != nullptr ? st.bias + g * st.sW : nullptr;
+                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bp, 0, bp != nullptr ? N * 4 : 0, 0x00020000);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    if (col0 + ct < N) bias[ct] = st.bias[g * st.sW + col0 + ct];
+                for (int ct = 0; ct < 4; ++ct) bias[ct] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (col0 + ct) * 4, 0, 0));
             }
             // 16-bit words: same bytes per row as the 64-bit words of the 32 / 64-row tilings
             const size_t bits_idx = ((size_t)g * st.sBits) * 4 + (size_t)(row0 >> 4) * CH_THREADS + tid;
-            unsigned int bits_w = 0u, bits_r = 0u;
-            if (st.bits_in != nullptr) bits_r = reinterpret_cast<const unsigned short*>(st.bits_in)[bits_idx];
+            unsigned int bits_w = 0u, bits_r;
+            {
+                const unsigned short* wp = reinterpret_cast<const unsigned short*>(st.bits_in) + (st.bits_in != nullptr ? bits_idx - tid : 0);
+                const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, st.bits_in != nullptr ? CH_THREADS * 2 : 0, 0x00020000);
+                bits_r = (unsigned int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rw, tid * 2, 0, 0);
+            }
+            // a narrow step behind this one: its operand, requested HERE and not behind the loop -- its registers are free for the
+            // loop's temporaries otherwise, and the next wide step's loop then opens by waiting for loads younger than its own sets
+            narrow_ready = feed_next && !nxt_wide;
+            c16_load_narrow(bn, nxt, wave, j, kq, g, narrow_ready);
             const float* pa = sAct + j * C2_LDK + 4 * kq;
-            const C16Desc dnext = c16_desc_t<K4>(nxt, wave, j, kq, g);
+            // the stream behind this step: the next step's operand if that step is wide, nothing otherwise (a zero-sized descriptor).
+            // Inside the loop every reload is unconditional, from a descriptor picked with scalar selects, and nothing is fetched
+            // from the argument block: with the narrow step's operand loaded under a branch in here (round 4) the compiler's
+            // wait-count pass made the second set's MFMAs wait for the loads just issued into the first -- no look-ahead at all,
+            // 12 650 cycles for a 256 x 256 step of 8 192 MFMA cycles (profiles/r04_chain16_phases.txt).
+            const bool nxt_live = feed_next && nxt_wide;
+            const C16Desc dnext = c16_desc_t<K4>(nxt, wave, j, kq, g, nxt_live);
             float4 an, ac = *reinterpret_cast<const float4*>(pa);
             int piece = 0;
             for (int pr = 0; pr < n_pairs; ++pr) {
                 const int k0 = pr * 64;
                 const bool more = pr + 1 < n_pairs;
-                const bool from_next = !more && nxt_wide;
                 C16Desc dx;
-                dx.rsrc = from_next ? dnext.rsrc : dcur.rsrc;
-                dx.lane_off = from_next ? dnext.lane_off : dcur.lane_off;
-                dx.stride = from_next ? dnext.stride : dcur.stride;
+                dx.rsrc = more ? dcur.rsrc : dnext.rsrc;
+                dx.lane_off = more ? dcur.lane_off : dnext.lane_off;
+                dx.stride = more ? dcur.stride : dnext.stride;
 // one group = 16 contraction indices = 4 MFMA steps x 4 column tiles; the A quad of the NEXT group is read first
 #define C16_GROUP(SET, G, KNEXT)                                                      \
     {                                                                                 \
@@ -455,18 +482,22 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
     }
                 C16_GROUP(bx, 0, k0 + 16)
                 C16_GROUP(bx, 1, k0 + 32)
-                if (!more && feed_next && !nxt_wide) c16_load_narrow(bx, nxt, wave, j, kq, g);    // a narrow step's operand
-                else c16_load_t<K4>(bx, dx, more ? k0 + 64 : 0);
+                // (each reload is pinned where it stands: left alone the scheduler sinks both behind the pair's last MFMAs and the
+                // next iteration opens by waiting for all sixteen loads)
+                __builtin_amdgcn_sched_barrier(0);
+                c16_load_t<K4>(bx, dx, more ? k0 + 64 : 0);
+                __builtin_amdgcn_sched_barrier(0);
                 C16_GROUP(by, 0, k0 + 48)
                 // (the last group's look-ahead read stays inside the buffer: column k0 + 64 + 15 <= 271 -> see the kernel's array)
                 C16_GROUP(by, 1, k0 + 64)
-                c16_load_t<K4>(by, dcur, more ? k0 + 96 : CH_BK);
+                __builtin_amdgcn_sched_barrier(0);
+                c16_load_t<K4>(by, dx, more ? k0 + 96 : CH_BK);
+                __builtin_amdgcn_sched_barrier(0);
 #undef C16_GROUP
                 if (do_copy && piece < N_PIECES) { c2_copy_piece(sAct, cdst, piece); ++piece; }
             }
             if (do_copy)
                 for (; piece < N_PIECES; ++piece) c2_copy_piece(sAct, cdst, piece);
-            narrow_ready = feed_next && !nxt_wide;
             dcur = dnext;
             C16_T(K > 64 ? 2 : 1)
             __syncthreads();     // every wave is past its last read of sAct
@@ -498,7 +529,7 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hacc[ct][r] = 0.f;
-            if (!narrow_ready) c16_load_narrow(bx, st, wave, j, kq, g);       // (a narrow step behind a narrow step)
+            if (!narrow_ready) c16_load_narrow(bn, st, wave, j, kq, g);       // (a narrow step behind a narrow step)
             narrow_ready = false;
             // (the bias this step's output needs: requested before the contraction and its two barriers)
             const int ct = wave >> 1;
@@ -513,8 +544,8 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float av = c16_elem(a4, t);        // columns >= K of sAct: finite stale values times zero weights
-                    hacc[0] = mfma16(av, c16_elem(bx.v[2 * c], t), hacc[0]);
-                    hacc[1] = mfma16(av, c16_elem(bx.v[2 * c + 1], t), hacc[1]);
+                    hacc[0] = mfma16(av, c16_elem(bn.v[2 * c], t), hacc[0]);
+                    hacc[1] = mfma16(av, c16_elem(bn.v[2 * c + 1], t), hacc[1]);
                 }
             }
             __syncthreads();     // every wave is past its last read of sAct -> reuse it as the reduction scratch
@@ -523,8 +554,8 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) scr[((wave * 2 + ct) * 4 + r) * 64 + lane] = hacc[ct][r];
-            const C16Desc dnext = c16_desc_t<K4>(nxt, wave, j, kq, g);
-            if (nxt_wide) c16_load_t<K4>(bx, dnext, 0);
+            const C16Desc dnext = c16_desc_t<K4>(nxt, wave, j, kq, g, feed_next && nxt_wide);
+            if (feed_next && nxt_wide) { c16_load_t<K4>(bx, dnext, 0); c16_load_t<K4>(by, dnext, CH_BK); }
             dcur = dnext;
             __syncthreads();
             // thread (wave, lane): column tile ct = wave >> 1, registers 2 * (wave & 1) + {0, 1} -- sums the four partials in wave order

@@ -160,7 +160,15 @@ struct C2CopyDst {
 
 __device__ __forceinline__ C2CopyDst c2_copy_dst(float* out, int ldout, int n, int rows, int row0, int tid) {
     C2CopyDst d;
-    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, rows * ldout * 4, 0x00020000);
+    // The descriptor is workgroup-uniform, and the compiler must KNOW it (the network index in `out` comes out of an integer
+    // division, i.e. out of the vector ALU): a descriptor it takes for divergent is stored through a "waterfall" loop -- one pass
+    // per distinct value -- and a loop with a store in it inside the MFMA loop turns every wait for the weight stream into a
+    // wait for (nearly) all of it, since stores and loads share the counter (round 5: the 16-row chain's look-ahead was lost here).
+    const unsigned long long a = (unsigned long long)(uintptr_t)out;
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)a);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(a >> 32));
+    out = (float*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, __builtin_amdgcn_readfirstlane(rows * ldout * 4), 0x00020000);
     const int m = tid >> 6, c4 = (tid & 63) << 2;
     d.voff0 = (c4 < n) ? ((row0 + m) * ldout + c4) * 4 : CH_OOB;
     d.step = 4 * ldout * 4;

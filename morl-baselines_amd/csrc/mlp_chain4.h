@@ -413,16 +413,7 @@ __device__ __forceinline__ void mlp_chain4_body(const ChainArgs& p, int row0, in
 static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain4_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) C4Shared sh;
     const int row0 = (int)blockIdx.x * C4_TM;
-#if defined(__AMDGCN__)
-    {   // the whole argument block (1 KB: sixteen lines of the scalar cache) in ONE round trip: the prologue reads it in several
-        // dependent batches, each of which otherwise pays its own first-touch misses
-        const __attribute__((address_space(4))) int* ka = (const __attribute__((address_space(4))) int*)__builtin_amdgcn_kernarg_segment_ptr();
-        int t = 0;
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(ChainArgs) / 64); ++i) t |= ka[i * 16];
-        asm volatile("" ::"s"(t));
-    }
-#endif
+    kernarg_warm<sizeof(ChainArgs)>();       // (the prologue reads the block in several dependent batches)
 #ifdef C4_PROF
     if (p.prof != nullptr && threadIdx.x == 0) p.prof[48 * 4096 + 1 + blockIdx.x] = wall_clock64();      // kernel entry, before any argument is read
 #endif

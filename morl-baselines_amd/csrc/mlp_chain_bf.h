@@ -511,15 +511,18 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     // put in flight: 30 serialised round trips, a tenth of the launch -- and written to LDS behind the input rows' loads
     constexpr int BPT = BF_WIDE / (64 * NW);        // columns per work-item per step
     float bv[BF_MAX_STEPS][BPT];
+    // (round 5: as range-checked buffer loads -- a descriptor of N floats, or of none -- instead of loads under
+    // `if (step exists && has a bias && column < N)`: the tests read the argument block step by step, a scalar-cache round trip
+    // and a branch in front of every load)
 #pragma unroll
-    for (int s = 0; s < BF_MAX_STEPS; ++s)
+    for (int s = 0; s < BF_MAX_STEPS; ++s) {
+        const float* bp = p.step[s].bias;
+        const __amdgpu_buffer_rsrc_t rb =
+            __builtin_amdgcn_make_buffer_rsrc((void*)bp, 0, (s < p.n_steps && bp != nullptr) ? p.step[s].N * 4 : 0, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < BPT; ++j) {
-            const int n = tid + j * 64 * NW;
-            float b = 0.f;
-            if (s < p.n_steps && p.step[s].bias != nullptr && n < p.step[s].N) b = p.step[s].bias[n];
-            bv[s][j] = b;
-        }
+        for (int j = 0; j < BPT; ++j)
+            bv[s][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (tid + j * 64 * NW) * 4, 0, 0));
+    }
 
     // ---- input rows: natural contraction order, slot (q, e) of k-step s <-> column 32 s + 8 q + e -------------------------------
     bf_u32x4 x[8][3];
@@ -765,11 +768,13 @@ __device__ __forceinline__ void mlp_chain_bf_entry(const BfMulti& m, unsigned ch
 
 __global__ __launch_bounds__(256, 2) void mlp_chain_bf_kernel(BfMulti m) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[BF_LDS_BYTES];
+    kernarg_warm<sizeof(BfMulti)>();
     mlp_chain_bf_entry<4>(m, lds);
 }
 
 __global__ __launch_bounds__(128, 1) void mlp_chain_bf32_kernel(BfMulti m) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[BF_LDS_BYTES];
+    kernarg_warm<sizeof(BfMulti)>();
     mlp_chain_bf_entry<2>(m, lds);
 }
 

@@ -22,6 +22,21 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 // wave index as a scalar (SGPR) value so that wave-dependent loop bounds / branches stay scalar
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// The first BYTES of the kernel's argument block pulled into the scalar cache in (a few batches of) ONE round trip, at kernel
+// entry.  A kernel whose prologue reads a large by-value argument block in several DEPENDENT batches -- pointer, then what hangs
+// off it, branch, next pointer -- otherwise pays a first-touch miss of the scalar cache per batch (0.3 - 0.5 us each on MI355X;
+// the 8-row chain's prologue: 3.6 -> 2.9 us with this and branch-free fetches, profiles/r05_target_rows_phases.txt).
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+#if defined(__AMDGCN__)
+    const __attribute__((address_space(4))) int* ka = (const __attribute__((address_space(4))) int*)__builtin_amdgcn_kernarg_segment_ptr();
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < (BYTES + 63) / 64; ++i) t |= ka[i * 16];
+    asm volatile("" ::"s"(t));
+#endif
+}
+
 // Deterministic butterfly sums (same order on every run; all lanes end with the total).
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -384,6 +384,12 @@ static inline hipsim_v2u __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rs
 }
 
 
+static inline unsigned short __builtin_amdgcn_raw_buffer_load_b16(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    unsigned short x = 0;
+    const long long off = (long long)(unsigned)voffset + soffset;
+    if (off + 2 <= r.num_records) std::memcpy(&x, r.base + off, 2);
+    return x;
+}
 static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
     unsigned x = 0u;
     const long long off = (long long)(unsigned)voffset + soffset;
