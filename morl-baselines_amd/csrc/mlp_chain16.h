@@ -94,6 +94,26 @@ template <bool K4>
 __device__ __forceinline__ void c16_load_t(C16BSet& s, const C16Desc& d, int k0) {
     if (K4) c16_load_k4(s, d, k0); else c16_load_wide(s, d, k0);
 }
+// one 16-deep group (half a set: v[4 gq .. 4 gq + 3]) of the chunk at k0
+template <bool K4>
+__device__ __forceinline__ void c16_load_half(C16BSet& s, const C16Desc& d, int k0, int gq) {
+    if (K4) {
+        float4 q[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+            q[ct] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d.rsrc, d.lane_off + ct * 16,
+                                                                                      ((k0 >> 2) + 4 * gq) * d.stride, 0));
+        s.v[4 * gq + 0] = make_float4(q[0].x, q[1].x, q[2].x, q[3].x);
+        s.v[4 * gq + 1] = make_float4(q[0].y, q[1].y, q[2].y, q[3].y);
+        s.v[4 * gq + 2] = make_float4(q[0].z, q[1].z, q[2].z, q[3].z);
+        s.v[4 * gq + 3] = make_float4(q[0].w, q[1].w, q[2].w, q[3].w);
+    } else {
+        const int base = d.lane_off + k0 * d.stride;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            s.v[4 * gq + t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(d.rsrc, base + (16 * gq + t) * d.stride, 0, 0));
+    }
+}
 
 // narrow step: wave w contracts k in [64w, 64w + 64) = 4 groups of 16; lane (j = column within the tile, kq) loads
 // Bt[n][64w + 16c + 4kq .. +3] for the two column tiles n = j and n = 16 + j: v[2c + ct]
@@ -480,18 +500,27 @@ __device__ __forceinline__ void mlp_chain16_body(const ChainArgs& p, int row0, f
         C2_SGB(0x100, 1);                                                             \
         C2_SGB(0x008, 16);                                                            \
     }
+                // Each 16-deep half of a set is reloaded as soon as its group's MFMAs are issued -- three groups (1 500 MFMA cycles)
+                // ahead of its next use, where whole sets reloaded behind their second group were two ahead -- and pinned where it
+                // stands: left alone the scheduler sinks the loads behind the pair's last MFMAs and the next iteration opens by
+                // waiting for all sixteen.
+                const int kx = more ? k0 + 64 : 0, ky = more ? k0 + 96 : CH_BK;
                 C16_GROUP(bx, 0, k0 + 16)
-                C16_GROUP(bx, 1, k0 + 32)
-                // (each reload is pinned where it stands: left alone the scheduler sinks both behind the pair's last MFMAs and the
-                // next iteration opens by waiting for all sixteen loads)
                 __builtin_amdgcn_sched_barrier(0);
-                c16_load_t<K4>(bx, dx, more ? k0 + 64 : 0);
+                c16_load_half<K4>(bx, dx, kx, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                C16_GROUP(bx, 1, k0 + 32)
+                __builtin_amdgcn_sched_barrier(0);
+                c16_load_half<K4>(bx, dx, kx, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 C16_GROUP(by, 0, k0 + 48)
+                __builtin_amdgcn_sched_barrier(0);
+                c16_load_half<K4>(by, dx, ky, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 // (the last group's look-ahead read stays inside the buffer: column k0 + 64 + 15 <= 271 -> see the kernel's array)
                 C16_GROUP(by, 1, k0 + 64)
                 __builtin_amdgcn_sched_barrier(0);
-                c16_load_t<K4>(by, dx, more ? k0 + 96 : CH_BK);
+                c16_load_half<K4>(by, dx, ky, 1);
                 __builtin_amdgcn_sched_barrier(0);
 #undef C16_GROUP
                 if (do_copy && piece < N_PIECES) { c2_copy_piece(sAct, cdst, piece); ++piece; }
