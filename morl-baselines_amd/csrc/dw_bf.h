@@ -213,9 +213,10 @@ __device__ __forceinline__ void dwb_job(const DwbProblem& g, int mgroup, int ngr
                 dwb_split_store(st[sidx], buf + it.dst_off);
             }
         };
-        auto load = [&](int sidx, int k0) {
-            if (it.live) dwb_load(st[sidx], it, voff, k0);
-        };
+        // (unconditional: a wave without items has out-of-range offsets, a chunk beyond the slice a zero-sized descriptor -- neither
+        // touches memory.  Under `if (live)` / inside the odd-chunk branch the loads were, to the compiler's wait-count pass, loads
+        // that may or may not have been issued, and every split waited for ALL loads in flight: one chunk of look-ahead, not two.)
+        auto load = [&](int sidx, int k0) { dwb_load(st[sidx], it, voff, k0); };
         // prologue: chunk 0 split into buffer 0, chunks 1 and 2 in flight
         load(0, kbeg);
         load(1, kbeg + DWB_BK);
@@ -233,15 +234,14 @@ __device__ __forceinline__ void dwb_job(const DwbProblem& g, int mgroup, int ngr
             DWB_TICK(3)
             DWB_BARRIER();
             DWB_TICK(4)
-            if (k0 + DWB_BK < kend) {
-                if (PROF) { BF_VMCNT(8); DWB_TICK(1) }
-                if (k0 + 2 * DWB_BK < kend) put(0, lds);
-                DWB_TICK(2)
-                load(0, k0 + 4 * DWB_BK);
-                DWB_TICK(3)
-                DWB_BARRIER();
-                DWB_TICK(4)
-            }
+            const bool second = k0 + DWB_BK < kend;             // (an odd chunk count: the last iteration has no second half)
+            if (PROF && second) { BF_VMCNT(8); DWB_TICK(1) }
+            if (second && k0 + 2 * DWB_BK < kend) put(0, lds);
+            DWB_TICK(2)
+            load(0, k0 + 4 * DWB_BK);
+            DWB_TICK(3)
+            if (second) DWB_BARRIER();
+            DWB_TICK(4)
         }
         // db: the four octets of a g column, in octet order (the operand buffers are free: the loop ended with a barrier)
         float* scr = reinterpret_cast<float*>(lds);            // [4 octets][16 TG columns]
