@@ -110,8 +110,9 @@ else:
 h = hashlib.sha256()
 g = th.Generator().manual_seed(5)
 # (rows, obs, objectives, actions, arch): ragged against the 8- and 16-row tiles, one to four hidden layers, narrow and wide heads
+# (round 5: inputs wider than the 64 columns the prologue fetches ahead of the weight stream, a wide head behind one hidden layer)
 shapes = [(1, 7, 3, 6, (256,)), (8, 7, 3, 6, (256, 256)), (9, 5, 2, 3, (256, 256)), (23, 32, 3, 6, (256, 256, 256, 256)),
-          (40, 11, 4, 12, (256, 256, 256)), (70, 3, 2, 2, (256,))]
+          (40, 11, 4, 12, (256, 256, 256)), (70, 3, 2, 2, (256,)), (23, 70, 3, 6, (256, 256)), (9, 100, 4, 12, (256,))]
 if sys.argv[2] == "gpu":
     shapes += [(1355, 32, 3, 6, (256, 256, 256, 256)), (2048, 32, 3, 6, (256, 256, 256, 256))]
 for rows, D, R, A, arch in shapes:
