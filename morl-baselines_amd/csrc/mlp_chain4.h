@@ -43,7 +43,7 @@ constexpr int C4_LDK = CH_MAXW + 8;         // activation row stride = 8 banks m
                                             // conflict-free, one dword per lane
 constexpr int C4_CHUNK = 2;                 // 16-groups per register set of B (32 contraction indices)
 constexpr int C4_RING = 4;                  // register sets: the weight stream runs three sets ahead of the MFMAs
-static_assert(4 % C4_CHUNK == 0 && C4_RING >= 4 / C4_CHUNK, "a narrow step's 64-deep operand must fit the ring");
+static_assert(4 % C4_CHUNK == 0, "a narrow step's 64-deep operand (staged in LDS by the prologue) is consumed in whole chunks");
 static_assert(C4_TM * 32 <= CH_THREADS, "a narrow step's outputs (8 rows x at most 32 columns): one per thread");
 
 // A operand: lane l holds A[row l & 3][k0 + (l >> 2)] -- block j = l >> 2 of the 16 carries contraction index k0 + j -- and the
