@@ -344,6 +344,9 @@ __device__ __forceinline__ void dw_bf_body(const DwbArgs& a) {
     else if (g.shape == 1) dwb_job<1, PROF>(g, mg, ng, split, a.rows, a.slab_stride, lds, prof);
     else dwb_job<2, PROF>(g, mg, ng, split, a.rows, a.slab_stride, lds, prof);
 }
-__global__ __launch_bounds__(DWB_THREADS) void dw_bf_kernel(DwbArgs a) { dw_bf_body<false>(a); }
+__global__ __launch_bounds__(DWB_THREADS) void dw_bf_kernel(DwbArgs a) {
+    kernarg_warm<sizeof(DwbArgs)>();       // (a block finds its problem by walking the table: dependent fetches of the argument block)
+    dw_bf_body<false>(a);
+}
 
 }  // namespace morl
