@@ -655,6 +655,9 @@ static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain16_kernel(Chain
     const int b = (int)blockIdx.x;
     int q = 0;
     while (q + 1 < m.n && b >= m.tile_start[q + 1]) ++q;
+    // (this chain's share of the argument block into the scalar cache in one round trip: the body reads it step by step, each step's
+    // descriptors behind the previous step's barrier -- a chain of first-touch misses on a launch that is a chain of latencies anyway)
+    kernarg_warm_at<sizeof(ChainArgs), sizeof(Chain16Multi)>(q * (int)sizeof(ChainArgs));
     int lt = b - m.tile_start[q], g = 0;
     const int tpn = (m.p[q].rows + C16_TM - 1) / C16_TM;          // tiles per network
     if (m.p[q].nb > 1) { g = lt / tpn; lt -= g * tpn; }
@@ -679,6 +682,8 @@ static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain16_post_kernel(
     __shared__ __attribute__((aligned(16))) float sAct[C16_TM * C2_LDK + 16];
     const int b = (int)blockIdx.x;
     const int q = (m.n > 1 && b >= m.tile_start[1]) ? 1 : 0;
+    kernarg_warm_at<sizeof(ChainArgs), sizeof(Chain16PostMulti)>(q * (int)sizeof(ChainArgs));
+    kernarg_warm_at<sizeof(ChainPostSet), sizeof(Chain16PostMulti)>(2 * (int)sizeof(ChainArgs) + q * (int)sizeof(ChainPostSet));
     int lt = b - m.tile_start[q], g = 0;
     const int tpn = (m.p[q].rows + C16_TM - 1) / C16_TM;          // tiles per network
     if (m.p[q].nb > 1) { g = lt / tpn; lt -= g * tpn; }

@@ -306,6 +306,7 @@ struct HeadBwdHook {
 static __global__ __launch_bounds__(CH_THREADS, 2) void mlp_chain16_headbwd_kernel(Chain16Multi m, HeadBwdArgs hb) {
     __shared__ __attribute__((aligned(16))) float sAct[C16_TM * C2_LDK + 16];
     const ChainArgs& p = m.p[0];                                 // (one chain: the actor's backward pass)
+    kernarg_warm<sizeof(ChainArgs)>();
     int lt = (int)blockIdx.x, g = 0;
     const int tpn = (p.rows + C16_TM - 1) / C16_TM;              // tiles per network
     if (p.nb > 1) { g = lt / tpn; lt -= g * tpn; }

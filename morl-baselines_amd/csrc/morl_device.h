@@ -37,6 +37,25 @@ __device__ __forceinline__ void kernarg_warm() {
 #endif
 }
 
+// the same for BYTES at a (workgroup-uniform) byte offset of a TOTAL-byte block: the one chain of a multi-chain argument block a
+// workgroup reads (lines clamped to the block: nothing beyond the argument segment is touched)
+template <int BYTES, int TOTAL>
+__device__ __forceinline__ void kernarg_warm_at(int byte_offset) {
+#if defined(__AMDGCN__)
+    const __attribute__((address_space(4))) char* base = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int first = byte_offset & ~63, last = (TOTAL - 1) & ~63;
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < (BYTES + 126) / 64; ++i) {
+        const int off = min(first + 64 * i, last);
+        t |= *(const __attribute__((address_space(4))) int*)(base + off);
+    }
+    asm volatile("" ::"s"(t));
+#else
+    (void)byte_offset;
+#endif
+}
+
 // Deterministic butterfly sums (same order on every run; all lanes end with the total).
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
