@@ -63,6 +63,7 @@ struct GemmGroupBatched {
 };
 
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_grouped_tn_batched_kernel(GemmGroupBatched grp) {
+    kernarg_warm<sizeof(GemmGroupBatched)>();       // (the block finds its group / piece by walking the argument block: see morl_device.h)
     const int id = (int)blockIdx.x, z = (int)blockIdx.z;
     int q = 0;
     while (q + 1 < grp.n && id >= grp.tile_start[q + 1]) ++q;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void gemm_wave4_batched_kernel(GemmBatched b) 
 }
 
 __global__ __launch_bounds__(256) void gemm_wave4_grouped_tn_batched_kernel(GemmGroupBatched grp) {
+    kernarg_warm<sizeof(GemmGroupBatched)>();       // (the block finds its group / piece by walking the argument block: see morl_device.h)
     const int id = (int)blockIdx.x, z = (int)blockIdx.z;
     int q = 0;
     while (q + 1 < grp.n && id >= grp.tile_start[q + 1]) ++q;
@@ -134,6 +136,7 @@ struct AdamFuse {
 };
 
 __global__ __launch_bounds__(256) void gemm_wave4_grouped_tn_batched_adam_kernel(GemmGroupBatched grp, AdamFuse f) {
+    kernarg_warm<sizeof(GemmGroupBatched) + sizeof(AdamFuse)>();       // (the block finds its group / piece by walking the argument block: see morl_device.h)
     const int id = (int)blockIdx.x, z = (int)blockIdx.z;
     int q = 0;
     while (q + 1 < grp.n && id >= grp.tile_start[q + 1]) ++q;
@@ -171,6 +174,7 @@ __global__ __launch_bounds__(256) void gemm_wave4_grouped_tn_batched_adam_kernel
 }
 
 __global__ __launch_bounds__(256) void gemm_wave_grouped_tn_batched_kernel(GemmGroupBatched grp) {
+    kernarg_warm<sizeof(GemmGroupBatched)>();       // (the block finds its group / piece by walking the argument block: see morl_device.h)
     const int id = (int)blockIdx.x * 4 + wave_id(), z = (int)blockIdx.z;
     if (id >= grp.tile_start[grp.n]) return;
     int q = 0;
@@ -229,6 +233,7 @@ struct ConcatMulti {
 };
 
 __global__ __launch_bounds__(256) void ac_concat_multi_kernel(ConcatMulti m) {
+    kernarg_warm<sizeof(ConcatMulti)>();       // (the block finds its group / piece by walking the argument block: see morl_device.h)
     if ((int)blockIdx.y < m.n) ac_concat_body(m.c[blockIdx.y], (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -678,6 +683,7 @@ struct CriticArgs {
 };
 
 __global__ __launch_bounds__(256) void ac_critic_kernel(CriticArgs a) {
+    kernarg_warm<sizeof(CriticArgs)>();       // (the block finds its group / piece by walking the argument block: see morl_device.h)
     __shared__ double s_red[4];
     const int g = (int)blockIdx.x;
     adam_corr_write(a.corr, g);
@@ -781,6 +787,7 @@ struct ActorLossArgs {
 };
 
 __global__ __launch_bounds__(256) void ac_actor_loss_kernel(ActorLossArgs a) {
+    kernarg_warm<sizeof(ActorLossArgs)>();       // (the block finds its group / piece by walking the argument block: see morl_device.h)
     __shared__ double s_red[4];
     const int g = (int)blockIdx.x;
     adam_corr_write(a.corr, g);
@@ -922,6 +929,7 @@ struct SacdCriticArgs {
 };
 
 __global__ __launch_bounds__(256) void sacd_critic_kernel(SacdCriticArgs a) {
+    kernarg_warm<sizeof(SacdCriticArgs)>();       // (the block finds its group / piece by walking the argument block: see morl_device.h)
     __shared__ double s_red[4];
     const int g = (int)blockIdx.x;
     const float alpha = ac_alpha(a.log_alpha, a.alpha_const, g);
@@ -992,6 +1000,7 @@ struct SacdActorArgs {
 };
 
 __global__ __launch_bounds__(256) void sacd_actor_kernel(SacdActorArgs a) {
+    kernarg_warm<sizeof(SacdActorArgs)>();       // (the block finds its group / piece by walking the argument block: see morl_device.h)
     __shared__ double s_red[4];
     const int g = (int)blockIdx.x;
     const float alpha = ac_alpha(a.autotune ? a.log_alpha : nullptr, a.alpha_const, g);
@@ -1141,6 +1150,7 @@ __device__ __forceinline__ void ac_transpose_scatter_body(const TransposeMulti& 
     }
 }
 __global__ __launch_bounds__(256) void ac_transpose_scatter_kernel(TransposeMulti a) {
+    kernarg_warm<sizeof(TransposeMulti)>();       // (the block finds its group / piece by walking the argument block: see morl_device.h)
     ac_transpose_scatter_body(a, (int)blockIdx.z, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -1148,6 +1158,7 @@ __global__ __launch_bounds__(256) void ac_transpose_scatter_kernel(TransposeMult
 // behind a launch boundary of its own): workgroups [0, cx * m.n) assemble the network inputs, the rest scatter the K-major shadow
 // copies of the parameter sets.
 __global__ __launch_bounds__(256) void ac_inputs_shadows_kernel(ConcatMulti m, TransposeMulti tm, int cx, int tx) {
+    kernarg_warm<sizeof(ConcatMulti) + sizeof(TransposeMulti)>();       // (the block finds its group / piece by walking the argument block: see morl_device.h)
     const int b = (int)blockIdx.x;
     if (b < cx * m.n) ac_concat_body(m.c[b / cx], b % cx, cx);
     else ac_transpose_scatter_body(tm, (b - cx * m.n) / tx, (b - cx * m.n) % tx, tx);
@@ -1155,6 +1166,7 @@ __global__ __launch_bounds__(256) void ac_inputs_shadows_kernel(ConcatMulti m, T
 
 // grid (max over the sets of tiles + 1, max nets, sets)
 __global__ __launch_bounds__(256) void ac_transpose_multi_kernel(TransposeMulti a) {
+    kernarg_warm<sizeof(TransposeMulti)>();       // (the block finds its group / piece by walking the argument block: see morl_device.h)
     __shared__ float sT[TR_T][TR_T + 1];
     const int q = (int)blockIdx.z, net = (int)blockIdx.y;
     if (q >= a.n || net >= a.nets[q]) return;
