@@ -327,9 +327,10 @@ def _clock_ramp(dev, seconds=0.5):
     del x
 
 
-def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", ramp=True):
+def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", ramp=True, exact_f32=False):
     """Build the agent for a job of W sampled weights in total, run warm-up + `steps` timed Envelope.update() steps bracketed
-    by barrier + synchronize on both sides; returns the measurements (wall = max over ranks)."""
+    by barrier + synchronize on both sides; returns the measurements (wall = max over ranks).  exact_f32: every GEMM on the
+    f32-input MFMA (morl_ctx_set_exact_f32: the "no split trick" leg of the line)."""
     from morl_baselines_amd.envelope import Envelope
 
     th.manual_seed(0)
@@ -341,6 +342,8 @@ def run_job(a, dist, world, rank, dev, W, sharded, steps, warmup, axis="batch", 
                      engine=a.engine)
     if a.dw_mode is not None:
         agent.q_net.ctx.set_dw_mode(a.dw_mode)
+    if exact_f32:
+        agent.q_net.ctx.set_exact_f32(True)
     fill_buffer(agent.replay_buffer, a.buffer_fill, seed=0)
     agent.global_step = 1001
     if sharded:
@@ -549,6 +552,16 @@ def _roofline(res, rows_rank):
     return out
 
 
+def whole_step_bf16_frac(rows, ms, bf16):
+    """The step's EXECUTED matrix-core work over the dense bf16 peak: six bf16 products per fp32 product of the launches that ran on
+    the bf16 pipe (bit 0 of `bf16`: the two online forward passes and the dX backward; bit 1: the weight gradients too) over the
+    whole step's time, every non-GEMM microsecond included.  None for a step on the f32-input MFMA."""
+    if not (int(bf16 or 0) & 1) or ms <= 0.0:
+        return None
+    flop = rows * (2 * FWD_FLOP_ROW + BWD_DX_FLOP_ROW + (FWD_FLOP_ROW if int(bf16) & 2 else 0))
+    return BF16_PRODUCTS * flop / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
+
+
 def one_step_parity(dev, case=None, lib=None):
     """bench.py checks what it times: ONE gradient step at the metric's full shape (256 x 64 x 3, the seeded inputs of the reference
     fixture tests/golden/envelope_flagship_full.npz) through the library's DEFAULT pipeline (lazy targets, bf16 matrix cores when
@@ -660,6 +673,12 @@ def main():
     ap.add_argument("--no-sub-record", action="store_true")
     ap.add_argument("--no-ramp-record", action="store_true",
                     help="skip the extra un-ramped run of the single-GPU job (ms_per_step_no_ramp)")
+    ap.add_argument("--no-sustained-record", action="store_true",
+                    help="skip the long run of the single-GPU job (ms_per_step_sustained: >= 2 000 steps, the lazily selected row "
+                         "count at its long-run level)")
+    ap.add_argument("--sustained-steps", type=int, default=2000)
+    ap.add_argument("--no-exact-record", action="store_true",
+                    help="skip the run of the single-GPU job with every GEMM on the f32-input MFMA (exact_f32_ms_per_step)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="with --force-shard on one GPU: run the step of rank 0 of a job of this many ranks (its kernels, "
                          "launches, host work and message sizes; the other ranks' slabs are zeros) -- a measurement aid, "
@@ -730,10 +749,10 @@ def main():
     if sharded and B % parts:
         raise SystemExit(f"--batch {B} must be divisible by the number of ranks")
 
-    def job(W, axis, ramp=True):
+    def job(W, axis, ramp=True, steps=None, exact_f32=False):
         """One measured job; every rank must reach the same verdict, so a failure is agreed on through an all-reduce."""
         try:
-            res = run_job(a, dist, world, rank, dev, W, sharded, a.steps, a.warmup, axis, ramp)
+            res = run_job(a, dist, world, rank, dev, W, sharded, steps or a.steps, a.warmup, axis, ramp, exact_f32)
         except Exception as exc:
             import traceback
             traceback.print_exc()
@@ -749,7 +768,7 @@ def main():
     # BASELINE.json's north_star describes (W/N weights per rank: all-gather of Q(w) + all-reduce) and the batch axis (B/N
     # transitions per rank: one all-reduce) -- and both figures go into the line; the headline is the faster one and
     # config.shard_axis says which.  The WEAK-scaled job (64 weights per GPU, weight axis) is the labelled sub-record.
-    strong, weak, no_ramp = {}, None, None
+    strong, weak, no_ramp, sustained, exact = {}, None, None, None, None
     if sharded:
         axes = ["batch", "weights"] if a.shard_axis == "auto" else [a.shard_axis]
         if a.scaling == "weak":
@@ -768,6 +787,12 @@ def main():
             # procedure as written; the headline below runs behind the ramp and says so in config.setup
             no_ramp = job(a.weights, None, ramp=False)
         strong["single"] = job(a.weights, None)
+        if not a.no_sustained_record:
+            # the same job over a long run: the lazily selected row count grows over the first ~ 1 000 updates of a fresh agent
+            # (1 193 -> 1 749 of 16 384 at the flagship shape), so a 20-step line flatters the target rows' launch
+            sustained = job(a.weights, None, steps=max(a.sustained_steps, a.steps))
+        if not a.no_exact_record:
+            exact = job(a.weights, None, exact_f32=True)        # what the step costs without the split-bf16 products
 
     coll = None
     if world > 1 and not a.no_collective_microbench:
@@ -864,7 +889,8 @@ def main():
             "last_loss": h["last_loss"],
             # whole-step fractions are fp32-EQUIVALENT rates over the f32-input MFMA peak (the one common yardstick of a step that
             # mixes both instruction families); algorithmic = SURVEY 8(d)'s five full passes, executed = what ran (lazy targets)
-            "roofline": dict(h["roofline"], whole_step_algorithmic_tflops=h["whole_step_algorithmic_tflops"],
+            "roofline": dict(h["roofline"], frac_whole_step_bf16=whole_step_bf16_frac(h["rows_timed"], h["ms_per_step"], h["bf16"]),
+                             whole_step_algorithmic_tflops=h["whole_step_algorithmic_tflops"],
                              whole_step_executed_tflops=h["whole_step_executed_tflops"],
                              whole_step_frac_algorithmic=h["whole_step_algorithmic_tflops"] / PEAK_FP32_MFMA_TFLOPS,
                              whole_step_frac_executed=h["whole_step_executed_tflops"] / PEAK_FP32_MFMA_TFLOPS),
@@ -878,6 +904,19 @@ def main():
                 "whole_step_executed_tflops what ran; MORL_LAZY_TARGETS=0 evaluates the slab eagerly")
         if no_ramp is not None and "error" not in no_ramp:
             out["ms_per_step_no_ramp"] = no_ramp["wall"] * 1e3 / a.steps
+        if sustained is not None and "error" not in sustained:
+            n_s = max(a.sustained_steps, a.steps)
+            out["ms_per_step_sustained"] = sustained["wall"] * 1e3 / n_s
+            out["sustained"] = {"steps": n_s, "lazy_target_rows_last_step": sustained.get("lazy_target_rows"),
+                                "value": B * W_head * n_s / sustained["wall"],
+                                "frac_whole_step_bf16": whole_step_bf16_frac(B * W_head, sustained["wall"] * 1e3 / n_s, sustained.get("bf16")),
+                                "note": "the headline job over a long run (same agent set-up, warm-up and clock ramp): the lazily selected "
+                                        "target-row count at its long-run level"}
+        if exact is not None and "error" not in exact:
+            out["exact_f32_ms_per_step"] = exact["wall"] * 1e3 / a.steps
+            out["exact_f32"] = {"bf16": int(exact.get("bf16") or 0), "value": B * W_head * a.steps / exact["wall"],
+                                "note": "the headline job with every GEMM on the f32-input MFMA (morl_ctx_set_exact_f32 / MORL_EXACT_F32=1): "
+                                        "the cost of not using the six split-bf16 products"}
         if world > 1 or a.force_shard:
             # both partitions of the strong-scaled job, each labelled; the headline above is the faster one
             out["strong_scaling_axes"] = {

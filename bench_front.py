@@ -22,6 +22,12 @@ import numpy as np
 import torch as th
 
 
+# f64 compares a SIMD retires per clock (v_cmp_le_f64 / v_cmp_eq_f64 at 4 waves per SIMD: tools/probes/cmp64_probe.hip,
+# profiles/r06_cmp64_probe.txt) x 1 024 SIMDs x 2.4 GHz: the rate the Pareto kernel's compare instructions are priced against
+F64_CMP_LANES_PER_CLK_SIMD = 16.0
+PEAK_F64_COMPARES = F64_CMP_LANES_PER_CLK_SIMD * 1024 * 2.4e9
+
+
 def timed(fn, steps, warmup):
     for _ in range(warmup):
         fn()
@@ -62,15 +68,25 @@ def main():
         pts = th.from_numpy(x).to(dev)
         sec = timed(lambda: ops.pareto_mask(lib, pts, True), a.steps, a.warmup)
         kept = int(ops.pareto_mask(lib, pts, True).sum().item())
+        # the roofline leg: the same launch with its wave-uniform early exits switched off (bit 1 of the flag), so that it executes
+        # a KNOWN number of pair tests -- N^2, each R (<=, ==) compare pairs -- and the same mask
+        sec_all = timed(lambda: ops.pareto_mask(lib, pts, 3), a.steps, a.warmup)
+        assert bool((ops.pareto_mask(lib, pts, 3) == ops.pareto_mask(lib, pts, True)).all())
         pair_tests = float(N) * N
+        cmp_rate = 2.0 * R * pair_tests / sec_all
         out = {"metric": "Pareto prune candidates/sec", "value": N / sec, "unit": "candidates/s", "n_gpus": 1,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"get_non_pareto_dominated_inds on {N} candidates x {R} objectives (float64), "
                                       f"{kept} non-dominated, 2% duplicates"},
                "roofline": {"bound": "compare (f64 VALU)", "kernel": "pareto_mask_kernel",
-                            "achieved": pair_tests * R / sec / 1e12, "peak": None, "unit": "T objective-compares/s (upper "
-                            "bound: early exits skip part of the N^2 pairs)", "frac": None, "traffic": None,
+                            "achieved": cmp_rate / 1e12, "peak": PEAK_F64_COMPARES / 1e12, "unit": "T f64 compares/s",
+                            "frac": cmp_rate / PEAK_F64_COMPARES, "traffic": None,
+                            "executed": "2 R N^2 v_cmp_*_f64 lane-operations per launch with the early exits switched off "
+                                        f"({sec_all * 1e3:.4f} ms; {sec * 1e3:.4f} ms with them: ms_per_step / value)",
+                            "peak_source": f"{F64_CMP_LANES_PER_CLK_SIMD:g} f64 compares per clock and SIMD (tools/probes/cmp64_probe.hip, "
+                                           "profiles/r06_cmp64_probe.txt) x 1 024 SIMDs x 2.4 GHz",
+                            "early_exit_speedup": sec_all / sec,
                             "algorithmic_bytes_per_launch": N * R * 8 + N,
                             "note": "N*R*8 B in, N B out: every workgroup re-reads the candidate set from L2 (N*R*8 B per "
                                     "256 candidates); compare-bound, not HBM-bound"}}

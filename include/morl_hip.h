@@ -426,7 +426,9 @@ int morl_envelope_rank_step(morl_ctx* ctx, morl_comm* comm, const morl_step_io* 
 int morl_polyak(const float* src, float* dst, float tau, int64_t n, void* stream);
 
 /* ---- get_non_pareto_dominated_inds: common/pareto.py:34-57 --------------------------------------
- * points: device float64 [N][R]; mask_out: device uint8 [N] (1 = keep).  Bit-exact boolean result. */
+ * points: device float64 [N][R]; mask_out: device uint8 [N] (1 = keep).  Bit-exact boolean result.
+ * remove_duplicates: bit 0 as the reference's flag; bit 1 (measurement aid of bench_front.py): run without the wave-uniform
+ * early exits, i.e. execute all N^2 pair tests -- same mask. */
 int morl_pareto_mask(const double* points, int N, int R, int remove_duplicates, uint8_t* mask_out, void* stream);
 
 /* ---- front metrics: common/performance_indicators.py -------------------------------------------------------------

@@ -38,6 +38,10 @@ __global__ __launch_bounds__(PARETO_THREADS) void pareto_mask_kernel(const doubl
     double ci[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) ci[r] = valid ? pts[(size_t)i * R + r] : 0.0;
+    // bit 1 of `remove_duplicates` (bench_front.py's roofline leg only): no early exit -- every one of the N^2 pair tests is
+    // executed, so the launch's duration prices a KNOWN number of compares; the mask is the same
+    const bool exits = (remove_duplicates & 2) == 0;
+    remove_duplicates &= 1;
     bool dominated = !valid;      // found j with c_i <= c_j and c_i != c_j
     bool dup_before = false;      // found j < i with c_j == c_i
     const int jbeg = (int)blockIdx.y * chunk, jend = min(N, jbeg + chunk);
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(PARETO_THREADS) void pareto_mask_kernel(const doubl
             s_pts[e] = (e < nj * R) ? pts[(size_t)j0 * R + e] : __builtin_nan("");
         __syncthreads();
         // wave-uniform early exit: a dominated candidate is dropped regardless of duplicates
-        if (__ballot(!dominated) == 0ull) continue;
+        if (exits && __ballot(!dominated) == 0ull) continue;
         for (int j = 0; j < nj_pad; j += PARETO_UNROLL) {
             bool dom = false, dup = false;
 #pragma unroll
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(PARETO_THREADS) void pareto_mask_kernel(const doubl
             }
             dominated = dominated || dom;
             dup_before = dup_before || dup;
-            if ((j & 15) == 12 && __ballot(!dominated) == 0ull) break;
+            if (exits && (j & 15) == 12 && __ballot(!dominated) == 0ull) break;
         }
     }
     if (valid && (dominated || (remove_duplicates && dup_before))) mask[i] = 0;

@@ -350,6 +350,35 @@ def make_net_desc(obs_dim: int, reward_dim: int, n_actions: int, net_arch: Seque
     return d
 
 
+# Every MORL_* environment variable anything in this repository reads, with its default (INTEGRATION.md "Run-time switches" is the
+# same list with the reasons; tests/test_integration_doc.py holds the three -- this table, the document, the getenv sites -- together).
+# A MORL_* variable that is NOT here is a typo or a switch of another round: load_library() refuses to start with it set, because
+# a silently ignored switch is a benchmark run with the wrong pipeline.
+KNOWN_ENV = {
+    # library (read once per process by libmorl_hip.so)
+    "MORL_EXACT_F32": "0", "MORL_BF_MIN_ROWS": "4096 (weight-sharded rank step: 8192)", "MORL_LAZY_TARGETS": "1",
+    "MORL_ARGMAX_IN_CHAIN": "1", "MORL_TD_IN_CHAIN": "1", "MORL_LAZY_MIN_ROWS": "4096 / 8192", "MORL_LAZY_BIG_ROWS": "6144",
+    "MORL_AC_LN_CHAIN": "1", "MORL_CHAIN4": "1", "MORL_CHAIN16": "1", "MORL_AC_NMAJOR": "1", "MORL_AC_SCATTER_MAX": "1048576",
+    "MORL_AC_ADAM_IN_DW": "1", "MORL_AC_HEADS_PAIRED": "1", "MORL_AC_HEADBWD_IN_CHAIN": "1", "MORL_RCCL_LIB": "",
+    "MORL_IPC_TIMEOUT_MS": "3000",
+    # host side
+    "MORL_COMM": "rccl", "MORL_HIP_LIB": "morl-baselines_amd/lib/libmorl_hip.so", "MORL_HOST_NOISE": "0",
+    # measurement / test infrastructure
+    "MORL_BENCH_TIMING": "(by --steps)", "MORL_REFERENCE_ROOT": "/root/reference",
+    # build time (morl-baselines_amd/build.py)
+    "MORL_BF_PROF": "", "MORL_C16_PROF": "", "MORL_C4_PROF": "",
+}
+
+
+def check_environment(environ=None) -> None:
+    """Raise on a ``MORL_*`` environment variable nothing reads (see ``KNOWN_ENV``)."""
+    env = os.environ if environ is None else environ
+    unknown = sorted(k for k in env if k.startswith("MORL_") and k not in KNOWN_ENV)
+    if unknown:
+        raise RuntimeError(f"unknown environment variable(s) {', '.join(unknown)}: not a switch of this build "
+                           f"(known: {', '.join(sorted(KNOWN_ENV))}; INTEGRATION.md lists what each does)")
+
+
 _default: Optional[NativeLib] = None
 
 
@@ -363,6 +392,7 @@ def use_library(lib: Optional[NativeLib]) -> None:
 def load_library(path: Optional[str] = None) -> NativeLib:
     """Load (once) the gfx950 library.  Raises if it is absent -- there is deliberately no fallback."""
     global _default
+    check_environment()
     if path is not None:
         return NativeLib(path)
     if _default is None:

@@ -30,8 +30,10 @@ neural path, so the oracle is pinned instead against the reference
 executed in the build container: ``tests/golden/make_golden.py`` runs the unmodified
 ``Envelope.update()`` through ``oracle/ref_harness.py`` and commits inputs + outputs under
 ``tests/golden/``; ``tests/test_oracle_golden.py`` checks this file against them
-(bit-exact on CPU).  Pareto parity is pinned by the reference's ``tests/test_pruning.py``
-known-answer generators, restated in ``tests/test_pareto_oracle.py``.
+(bit-exact on CPU).  Pareto parity is pinned by masks the unmodified ``get_non_pareto_dominated_inds``
+produced -- on adversarial sets (``tests/golden/pareto_masks.npz``) and on the known-answer fronts of the
+reference's own ``tests/test_pruning.py`` at their full sizes (``tests/golden/pruning_known_fronts.npz``,
+made by ``tests/golden/make_golden_pruning.py``) -- in ``tests/test_oracle_golden.py``.
 """
 from __future__ import annotations
 

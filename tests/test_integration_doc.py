@@ -125,3 +125,26 @@ def test_every_exported_symbol_is_mapped_to_a_reference_call_site():
                and not re.search(r"`" + s.rsplit("_", 1)[0] + r"` / `_" + s.rsplit("_", 1)[1] + r"`", text)
                and not re.search(r"`_" + s.rsplit("_", 1)[1] + r"`", text)]
     assert not missing, f"INTEGRATION.md section 3 does not mention: {missing}"
+
+
+def test_environment_switches_are_one_list():
+    """every ``MORL_*`` environment variable the sources read is in ``native.KNOWN_ENV`` and in INTEGRATION.md's
+    table, nothing else is, and an unknown ``MORL_*`` variable is refused loudly instead of being ignored."""
+    sys.path.insert(0, ROOT)
+    import morl_baselines_amd.native as native
+    read = set()
+    pat = re.compile(r"""(?:getenv\(\s*|environ\.get\(\s*|environ\.setdefault\(\s*|environ\[\s*)["'](MORL_[A-Z0-9_]+)["']""")
+    files = [os.path.join(ROOT, f) for f in ("bench.py", "bench_ac.py", "bench_front.py", "__graft_entry__.py", "oracle/ref_harness.py")]
+    for top in ("morl-baselines_amd", "tools"):
+        for d, _, fs in os.walk(os.path.join(ROOT, top)):
+            files += [os.path.join(d, f) for f in fs if f.endswith((".py", ".hip", ".h"))]
+    for f in files:
+        read |= set(pat.findall(open(f, errors="ignore").read()))
+    assert read == set(native.KNOWN_ENV), (sorted(read - set(native.KNOWN_ENV)), sorted(set(native.KNOWN_ENV) - read))
+    doc = open(DOC).read()
+    section = doc[doc.index("## Run-time switches"):]
+    for name in native.KNOWN_ENV:
+        assert f"`{name}`" in section or f"`{name}=" in section, f"{name} is not in INTEGRATION.md's switch table"
+    native.check_environment({"MORL_EXACT_F32": "1", "HOME": "/"})
+    with pytest.raises(RuntimeError, match="MORL_EXACT_F23"):
+        native.check_environment({"MORL_EXACT_F23": "1"})

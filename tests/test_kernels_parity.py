@@ -309,6 +309,23 @@ def test_pareto_mask_adversarial_sets(be):
             assert np.array_equal(got, g[f"{name}__rd{int(rd)}"].astype(bool)), (name, rd)  # the reference's own mask
 
 
+def test_reference_pruning_known_fronts(be):
+    """``tests/test_pruning.py::test_small_pf`` / ``test_large_pf`` of the reference at their full sizes (100 + 500 x 2; 1 000 +
+    5 000 x 4 -- the large one on the GPU only: the emulator runs N^2 fibres): ``morl_pareto_mask`` equals the mask the unmodified
+    ``get_non_pareto_dominated_inds`` produced on the same points (tests/golden/pruning_known_fronts.npz), bit for bit, and the
+    kept set is the planted front -- the reference test's own assertion."""
+    lib, dev, is_sim = be
+    import morl_baselines_amd.pareto as par
+    g = np.load(os.path.join(GOLD, "pruning_known_fronts.npz"))
+    for name in ("small_pf",) if is_sim else ("small_pf", "large_pf"):
+        pts, n_nd = g[f"{name}__points"], int(g[f"{name}__n_nd"])
+        for rd in (True, False):
+            got = ops.pareto_mask(lib, th.tensor(pts, dtype=th.float64).to(dev), rd).cpu().numpy().astype(bool)
+            assert np.array_equal(got, g[f"{name}__mask_rd{int(rd)}"].astype(bool)), (name, rd)
+        kept = par.filter_pareto_dominated(pts, lib=lib, device=dev)
+        assert {tuple(v) for v in kept} == {tuple(v) for v in pts[:n_nd]}, name
+
+
 def test_pareto_mask_single_and_tile_edges(be):
     lib, dev, is_sim = be
     rng = np.random.default_rng(11)

@@ -72,6 +72,20 @@ def test_pareto_masks_match_reference():
             assert np.array_equal(got, want), (name, rd)
 
 
+def test_reference_pruning_known_fronts_oracle():
+    """The reference's own known-answer pruning tests at their OWN sizes (``tests/test_pruning.py:71-84, 98-110``: 100 + 500 x 2
+    and 1 000 + 5 000 x 4, seed 0; points and reference masks committed by tests/golden/make_golden_pruning.py): the oracle
+    reproduces the reference's mask bit for bit and keeps exactly the planted front."""
+    g = np.load(os.path.join(GOLD, "pruning_known_fronts.npz"))
+    for name in ("small_pf", "large_pf"):
+        pts, n_nd = g[f"{name}__points"], int(g[f"{name}__n_nd"])
+        for rd in (True, False):
+            got = orc.pareto_mask(pts, remove_duplicates=rd)
+            assert np.array_equal(got, g[f"{name}__mask_rd{int(rd)}"].astype(bool)), (name, rd)
+        kept = orc.filter_pareto(pts)
+        assert {tuple(v) for v in kept} == {tuple(v) for v in pts[:n_nd]}, name
+
+
 def test_sumtree_trace_matches_reference():
     g = np.load(os.path.join(GOLD, "per_trace.npz"))
     rng = np.random.default_rng(5)
