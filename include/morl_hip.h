@@ -205,7 +205,10 @@ int morl_ctx_set_exact_f32(morl_ctx* ctx, int enable);
  * reported (more than MORL_LAZY_BIG_ROWS = 6 144 -> large tiles; same compact rows, same values), so a worst-case batch (every
  * TD row its own pair) costs what the eager target pass costs, not a 16 384-row pass through 8-row tiles.  Reading that count
  * makes the host wait when it is more than 8 lazily evaluated steps ahead of the device (it is then throttled to the device's
- * pace, as by any bounded queue); morl_ctx_backpressure_seconds returns the host time spent so. */
+ * pace, as by any bounded queue); morl_ctx_backpressure_seconds returns the host time spent so.  That wait is bounded (2 s): a
+ * count that never arrives (a stream parked behind the caller's own events, a failed step) makes THAT step -- and the 32 after it,
+ * then the context asks again -- take the 8-row tiles: bit 3 = the last step was sized without its count, bit 4 = this happened
+ * at least once on this context (bench.py and the tests assert it did not). */
 int morl_ctx_last_step_bf16(morl_ctx* ctx);
 int morl_ctx_backpressure_seconds(morl_ctx* ctx, double* seconds);
 int morl_ctx_lazy_target_rows(morl_ctx* ctx, int* rows, void* stream);

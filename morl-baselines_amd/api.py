@@ -116,3 +116,16 @@ except Exception:  # pragma: no cover - exercised on boxes without the reference
         if w is None:
             return float(vec_return), float(disc_vec_return), vec_return, disc_vec_return
         return scalarization(w, vec_return), scalarization(w, disc_vec_return), vec_return, disc_vec_return
+
+
+def reference_method(module: str, cls: str, name: str):
+    """The reference's own (unbound) method ``module.cls.name`` when ``morl_baselines`` is importable, else None.  The host mirrors
+    hand their env-stepping loops to it -- ``Envelope.train`` is the reference's loop, unchanged, driving OUR ``act`` / ``update`` /
+    replay buffer -- and keep their own restatement only for machines without the reference (the GPU test box)."""
+    if not HAVE_REFERENCE_API:
+        return None
+    try:
+        import importlib
+        return getattr(getattr(importlib.import_module(module), cls), name)
+    except Exception:
+        return None

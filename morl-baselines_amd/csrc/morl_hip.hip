@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "morl_hip.h"
@@ -185,6 +186,8 @@ struct morl_ctx {
     std::vector<int> ev_kind;            // MORL_TIMED_* of each recorded launch
     int last_B = 0, last_WI = 0;         // shape of the last training forward (morl_ctx_debug_hidden)
     int last_step_W = 0;                 // weights of the last morl_envelope_update (what morl_envelope_prepare expects of the next)
+    long long prepare_rows = -1;         // one-shot, set by morl_envelope_rank_step: the TD rows THIS rank's step will run (prepare is
+    bool prepare_weight_shard = false;   //   handed the job's whole batch) and whether it is the weight-sharded step (its own threshold)
     // lazy target evaluation (envelope_kernels.h, EnvelopeTdArgs::phase): scratch + the one-shot hand-over from
     // morl_envelope_update to update_core
     int lazy_targets = 1;                // MORL_LAZY_TARGETS=0 / morl_ctx_set_lazy_targets: 0 evaluate the whole target slab instead,
@@ -208,6 +211,10 @@ struct morl_ctx {
     double host_wait_s = 0.0;                      // host time spent waiting for a count (the device more than LZ_LAG steps behind):
                                                    // back-pressure, not host work (morl_ctx_backpressure_seconds)
     int lz_last_big = 0;                           // what the last lazily evaluated step launched
+    bool lz_count_missed = false;                  // the last lazily evaluated step could not read the count it is sized by (bounded
+                                                   // wait ran out, or inside the re-arm window after one): it took the small tiles
+    long long lz_count_misses = 0;                 // bounded waits that ran out, ever
+    int lz_skip_until = 0;                         // epoch from which the count is asked for again
     int timing_kind_override = -1;       // MORL_TIMED_* of the next bracketed chain launch (-1: by its arguments)
     bool lz_argmax_done = false;         // one-shot: this step's forward launch took the arg-max (mlp_chain_bf.h, BfChain::amax)
     bool td_in_chain_done = false;       // one-shot inside update_core: the backward chain's launch took the TD stage
@@ -1100,7 +1107,10 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
     // network's split weights + the target network's K-major copy; on the fp32 chains the K-major copies of both.  A guess about
     // the step's weight count that turns out wrong costs that step a launch of its own, nothing else (refresh_*).
     // (the step's weight count is not an argument here: the last step's, or the context's capacity before the first one)
-    if (bf_wanted(c, (long long)B * (c->last_step_W > 0 ? c->last_step_W : c->max_weights))) {
+    const long long rows_next = c->prepare_rows >= 0 ? c->prepare_rows : (long long)B * (c->last_step_W > 0 ? c->last_step_W : c->max_weights);
+    const bool shard_next = c->prepare_rows >= 0 && c->prepare_weight_shard;
+    c->prepare_rows = -1;
+    if (bf_wanted(c, rows_next, shard_next)) {
         const BfSplitArgs bf = bf_split_args(c, params_online);
         const int bf_blocks = (bf.unit_start[bf.n] * 64 + 255) / 256;
         hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks + sh.tiles + bf_blocks), dim3(256), 0, (hipStream_t)stream, a, blocks,
@@ -1122,10 +1132,12 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
 
 // bit 0: the last morl_envelope_update on this context ran its online forward passes and its dX backward pass as split-bf16
 // products (mlp_chain_bf.h); bit 1: its weight gradients too (dw_bf.h); bit 2: its lazily evaluated target rows took the large
-// f32 tiles (an earlier step had selected more than MORL_LAZY_BIG_ROWS pairs); 0: everything on the f32-input MFMA
+// f32 tiles (an earlier step had selected more than MORL_LAZY_BIG_ROWS pairs); bit 3: its target launch was sized WITHOUT the count it
+// should have read (bounded wait ran out / re-arm window); bit 4: that has happened on this context; 0: everything on the f32-input MFMA
 extern "C" int morl_ctx_last_step_bf16(morl_ctx* c) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
-    return (c->bits_bf ? 1 : 0) | (c->dw_bf_last ? 2 : 0) | ((c->lz_last && c->lz_last_big) ? 4 : 0);
+    return (c->bits_bf ? 1 : 0) | (c->dw_bf_last ? 2 : 0) | ((c->lz_last && c->lz_last_big) ? 4 : 0) |
+           ((c->lz_last && c->lz_count_missed) ? 8 : 0) | (c->lz_count_misses > 0 ? 16 : 0);
 }
 
 extern "C" int morl_ctx_set_exact_f32(morl_ctx* c, int enable) {
@@ -1335,30 +1347,39 @@ static EnvelopeTdArgs lazy_argmax_args(morl_ctx* c, const EnvelopeTdArgs& p) {
 static int chain2_fill(morl_ctx* c, Chain2Multi& m, const ChainArgs* chains, int n, int S);
 static bool lazy_count_was_big(morl_ctx* c, long long* count_out = nullptr) {
     if (count_out) *count_out = -1;
+    c->lz_count_missed = false;
     const long long e = (long long)c->lz_epoch - LZ_LAG;
     if (e < 1 || !c->lz_mirror || c->lz_big_rows <= 0) return false;
+    if (c->lz_skip_until > c->lz_epoch) { c->lz_count_missed = true; return false; }      // (re-armed later, below)
     volatile unsigned long long* slot = c->lz_mirror + (e & (LZ_SLOTS - 1));
     unsigned long long v = *slot;
     if ((unsigned int)(v >> 32) != (unsigned int)e) {
         // (not there yet: the device is more than LZ_LAG steps behind.  ~2 s bound: a step whose target launch never ran -- an error
-        // return between the arg-max and it -- must not hang its successors; they fall back to the small tiles.)
+        // return between the arg-max and it -- must not hang its successors; they fall back to the small tiles.)  The ordinary case
+        // is a device a fraction of a step behind the bound: spin for that long, then give the core away between looks.
         const auto t0 = std::chrono::steady_clock::now();
         bool seen = false;
         for (;;) {
             v = *slot;
             if ((unsigned int)(v >> 32) == (unsigned int)e) { seen = true; break; }
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+            const auto waited = std::chrono::steady_clock::now() - t0;
+            if (waited > std::chrono::seconds(2)) break;
+            if (waited > std::chrono::microseconds(300)) std::this_thread::sleep_for(std::chrono::microseconds(50));
 #if defined(__x86_64__)
-            __builtin_ia32_pause();
+            else __builtin_ia32_pause();
 #endif
         }
         c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (!seen) {
             // never reported: the stream of that step is not making progress while this call is in flight (a caller that parks its
-            // streams behind events of its own, a step that failed between the arg-max and the target launch).  One bounded wait is
-            // the price; the context then stops asking and keeps the small tiles (correct at any count, slow only in the worst case)
-            fprintf(stderr, "[morl] lazy target rows: the pair count of step %lld was never reported; adaptive tile sizing is off for this context\n", e);
-            c->lz_big_rows = 0;
+            // streams behind events of its own, a step that failed between the arg-max and the target launch).  THIS step takes the
+            // small tiles (correct at any count, slow only in the worst case) and says so (bit 3 of morl_ctx_last_step_bf16); the
+            // context asks again after 4 LZ_LAG steps -- one bounded wait per 32 steps at worst, never a switch thrown for good.
+            fprintf(stderr, "[morl] lazy target rows: the pair count of step %lld was never reported; small tiles for the next %d steps\n",
+                    e, 4 * LZ_LAG);
+            c->lz_skip_until = c->lz_epoch + 4 * LZ_LAG;
+            c->lz_count_missed = true;
+            ++c->lz_count_misses;
             return false;
         }
     }
@@ -2069,6 +2090,7 @@ extern "C" int morl_envelope_slabs(morl_ctx* c, const float* params_online, cons
     hipStream_t s = (hipStream_t)stream;
     const int rows = B * W_local, AR = c->net.n_actions * c->net.reward_dim;
     timing_begin_step(c);
+    c->last_step_W = W_local;            // (what a staged caller's morl_envelope_prepare expects of its next step)
     float* qo = slabs_out;
     float* qt = slabs_out + (size_t)rows * AR;
     if (c->use_fused) {
@@ -2261,6 +2283,11 @@ extern "C" int morl_envelope_rank_step(morl_ctx* c, morl_comm* comm, const morl_
     if (axis == 1 && (!slab_local || !slab_all)) return fail(MORL_ERR_ARG, "the weight axis needs the slab buffers");
     int rc = check_bw(c, axis == 0 ? share : B, axis == 0 ? W : share);
     if (rc) return rc;
+    // (before anything is enqueued: the sharded steps update the PER tree inside their clip + Adam launch, one launch's worth of entries)
+    if (io->tree && B > ST_MAX_B) return fail(MORL_ERR_ARG, "PER update inside the rank step: B=%d > %d", B, ST_MAX_B);
+    // the prologue launch makes the weight copies of the engine THIS rank's rows will run on
+    c->prepare_rows = axis == 0 ? (long long)share * W : (long long)B * share;
+    c->prepare_weight_shard = axis == 1;
     if ((rc = morl_envelope_prepare(c, io->params_online, io->params_target, io->tree, io->n_levels, io->tree ? u01 : nullptr,
                                     io->tree ? nullptr : idx_in, io->records, io->record_floats, io->capacity, B, D, R, 1, io->obs,
                                     io->next_obs, io->rewards, io->dones, nullptr, io->actions, io->idx, w_src, io->weights, W * R, stream)))

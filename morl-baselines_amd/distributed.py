@@ -45,6 +45,7 @@ import torch as th
 
 from . import ops
 from .acnets import randn
+from .replay import PrioritizedReplayBuffer
 from .envelope import Envelope, random_weights
 
 
@@ -335,6 +336,10 @@ def _rank_step(agent: Envelope, comm, axis: int, offset: int, share: int, slab_l
     persistent argument block): the host draws what the reference draws (batch uniforms / indices from the global numpy RNG, the
     sampled weights from ``agent.np_random``) into pinned slots and makes one call.  False: the agent's replay buffer is not one
     of ``replay.py``'s (the caller then takes the call-by-call path)."""
+    if agent.per and agent.batch_size > PrioritizedReplayBuffer.TREE_BLOCK:
+        # (a prioritised batch larger than one tree-update launch holds: the staged path, whose priority update goes through
+        # update_priorities' ascending blocks -- as Envelope.update does for the unsharded agent)
+        return False
     st = agent._step_block(1)
     if st is None:
         return False
@@ -348,11 +353,11 @@ def _rank_step(agent: Envelope, comm, axis: int, offset: int, share: int, slab_l
         agent.q_net.ctx.handle, comm.handle, st.io_ref, axis, offset, share, u_ptr, i_ptr, w_ptr, agent._adam_step,
         float(agent.homotopy_lambda), None if slab_loc is None else slab_loc.data_ptr(), None if slab_all is None else slab_all.data_ptr(),
         agent.lib.stream_of(st.loss))
+    ring.mark_used()                 # (also on failure: what was enqueued before it still reads the pinned slots)
+    agent.replay_buffer.mark_drawn()
     if rc:
         agent._adam_step -= 1
         agent.lib.check(rc)
-    ring.mark_used()
-    agent.replay_buffer.mark_drawn()
     return True
 
 
@@ -408,6 +413,7 @@ def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=N
             raise ValueError("batch_size changed after shard_envelope_agent")
         if comm is not None:
             comm.poll()                                      # (a timed-out collective of an earlier step: raise, do not train on)
+        big_per = self.per and B > PrioritizedReplayBuffer.TREE_BLOCK
         for _ in range(self.gradient_updates):
             gx = self._grads_x
             if comm is not None and _rank_step(self, comm, 1, i0, Wl, slab_loc, slab_all):
@@ -433,7 +439,9 @@ def shard_envelope_agent(agent: Envelope, dist, group=None, emulate=None, comm=N
                     b_next_obs, actions, b_rewards, b_dones.reshape(-1), sampled_w, i0, Wl, slab_loc, slab_all,
                     gamma=self.gamma, lr=self.learning_rate, adam_step=self._adam_step, max_grad_norm=self.max_grad_norm,
                     homotopy_lambda=float(self.homotopy_lambda), envelope=self.envelope,
-                    per=self.replay_buffer.per_update_args(b_inds, self.per_alpha) if self.per else None)
+                    per=self.replay_buffer.per_update_args(b_inds, self.per_alpha) if (self.per and not big_per) else None)
+                if big_per:      # (more entries than the tree update inside the step holds: ascending blocks behind it)
+                    self.replay_buffer.update_priorities_from_td(b_inds, gx[P + 1:], self.per_alpha)
             else:
                 # the same stages one by one, the collectives through torch.distributed (gloo in the CPU tests)
                 w_loc = sampled_w[i0:i0 + Wl].contiguous()
@@ -508,6 +516,7 @@ def _shard_envelope_batch(agent: Envelope, dist, group, emulate, comm, world: in
         if comm is not None:
             comm.poll()                                      # (a timed-out collective of an earlier step: raise, do not train on)
         W = self.num_sample_w
+        big_per = self.per and B0 > PrioritizedReplayBuffer.TREE_BLOCK
         for _ in range(self.gradient_updates):
             gx = self._grads_x
             if comm is not None and _rank_step(self, comm, 0, b0, Bl):
@@ -527,13 +536,15 @@ def _shard_envelope_batch(agent: Envelope, dist, group, emulate, comm, world: in
             sl = slice(b0, b0 + Bl)                      # this rank's transitions (row slices of contiguous tensors: views)
             actions = b_actions.reshape(-1).to(th.int32)[sl]
             obs, nobs, rew, done = b_obs[sl], b_next_obs[sl], b_rewards[sl], b_dones.reshape(-1)[sl]
-            per = self.replay_buffer.per_update_args(b_inds, self.per_alpha) if self.per else None
+            per = self.replay_buffer.per_update_args(b_inds, self.per_alpha) if (self.per and not big_per) else None
             if comm is not None:
                 ops.envelope_step_batch_sharded(
                     ctx, comm.handle, self.q_net.flat, self.target_q_net.flat, gx, self._exp_avg, self._exp_avg_sq, obs, nobs,
                     actions, rew, done, sampled_w, B0, b0, gamma=self.gamma, lr=self.learning_rate, adam_step=self._adam_step,
                     max_grad_norm=self.max_grad_norm, homotopy_lambda=float(self.homotopy_lambda), envelope=self.envelope,
                     per=per)
+                if big_per:
+                    self.replay_buffer.update_priorities_from_td(b_inds, gx[P + 1:], self.per_alpha)
             else:
                 # the same stages through torch.distributed (gloo in the CPU tests): local gradients of the job's loss ...
                 gx[P + 1:].zero_()

@@ -10,6 +10,7 @@ synchronised with the host unless logging asks for a scalar.  There is no CPU fa
 from __future__ import annotations
 
 import os
+import re
 from typing import List, Optional, Union
 
 import numpy as np
@@ -18,7 +19,7 @@ import torch.optim as optim
 
 from . import ops
 from .evaluation import front_returns
-from .api import MOAgent, MOPolicy
+from .api import MOAgent, MOPolicy, reference_method
 from .native import NativeLib, load_library
 from .qnet import QNet
 from .replay import PrioritizedReplayBuffer, ReplayBuffer
@@ -322,11 +323,16 @@ class Envelope(MOPolicy, MOAgent):
         self._adam_step += n
         rc = st.fn(self.q_net.ctx.handle, st.io_ref, n, u_ptr, i_ptr, w_ptr, a0, float(self.homotopy_lambda), st.loss_ptr, st.gn_ptr,
                    st.prio_ptr, self.lib.stream_of(st.loss))
-        if rc:
-            self._adam_step -= n
-            self.lib.check(rc)
+        # (the pinned slots are handed out again only behind an event recorded NOW: kernels of the iterations that were enqueued
+        # before a failure still read them)
         ring.mark_used()
         self.replay_buffer.mark_drawn()
+        if rc:
+            # "update k of n: ...": k optimiser steps were enqueued before the failing iteration -- Adam's step count keeps them
+            msg = self.lib.lib.morl_last_error().decode()
+            m = re.match(r"update (\d+) of \d+:", msg)
+            self._adam_step -= n - (min(int(m.group(1)), n) if m else 0)
+            self.lib.check(rc)
         self._losses = st.loss_views[:n]
         self._out = st.outs[n - 1]
         self._finish_update(st.priority if st.per else None)
@@ -457,6 +463,18 @@ class Envelope(MOPolicy, MOAgent):
               total_episodes: Optional[int] = None, reset_num_timesteps: bool = True, eval_freq: int = 10000,
               num_eval_weights_for_front: int = 100, num_eval_episodes_for_front: int = 5,
               num_eval_weights_for_eval: int = 50, reset_learning_starts: bool = False, verbose: bool = False):
+        """``envelope.py:465-575``.  With ``morl_baselines`` importable this IS the reference's method (``api.reference_method``): its
+        loop calls this class's ``act`` / ``update`` / replay buffer, everything else is the reference's own code.  The loop below is
+        the restatement for machines without the reference (same draws from the same generators in the same order: the seeded traces
+        of tests/test_train_traces.py), plus one extension: a LIST of evaluation environments is rolled out in lock-step."""
+        ref_train = None if isinstance(eval_env, (list, tuple)) else reference_method(
+            "morl_baselines.multi_policy.envelope.envelope", "Envelope", "train")
+        if ref_train is not None:
+            return ref_train(self, total_timesteps, eval_env=eval_env, ref_point=ref_point, known_pareto_front=known_pareto_front,
+                             weight=weight, total_episodes=total_episodes, reset_num_timesteps=reset_num_timesteps, eval_freq=eval_freq,
+                             num_eval_weights_for_front=num_eval_weights_for_front, num_eval_episodes_for_front=num_eval_episodes_for_front,
+                             num_eval_weights_for_eval=num_eval_weights_for_eval, reset_learning_starts=reset_learning_starts,
+                             verbose=verbose)
         if eval_env is not None:
             assert ref_point is not None, "Reference point must be provided for the hypervolume computation."
         self.global_step = 0 if reset_num_timesteps else self.global_step

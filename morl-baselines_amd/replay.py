@@ -381,6 +381,11 @@ class PrioritizedReplayBuffer(ReplayBuffer):
     def update_priorities_from_td(self, idx: th.Tensor, raw_abs_td: th.Tensor, alpha: float) -> None:
         """Device-only path of ``envelope.py:329-334``: priority = (|td . w| + min_priority) ** alpha, then update."""
         self.flush()
+        if idx.numel() > self.TREE_BLOCK:
+            # more entries than one tree-update launch holds: the priorities here (every entry against the SAME running maximum, as
+            # envelope.py:332 reads min_priority once), the tree through update_priorities' ascending blocks
+            pr = (raw_abs_td.to(th.float32).reshape(-1) + self.running_max.to(th.float32)).pow(float(alpha))
+            return self.update_priorities(idx, pr)
         ops.sumtree_update(self.lib, self.tree_dev, self.n_levels, idx, raw_abs_td, float(alpha), self.running_max)
 
     def get_all_data(self, max_samples=None, to_tensor=False, device=None):

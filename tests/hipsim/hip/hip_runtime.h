@@ -167,7 +167,7 @@ struct LaneCtx {
     uint3 tid, bid;
     int lane, wave;
 };
-struct CollIn { float f[18]; double d; unsigned long long u; int i; };
+struct CollIn { float f[24]; double d; unsigned long long u; int i; };
 struct CollOut { float f[16]; double d; unsigned long long u; int i; };
 extern LaneCtx* cur;
 extern dim3 cur_block_dim, cur_grid_dim;
@@ -335,6 +335,36 @@ static inline hipsim_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hipsim_bf16x8
     hipsim::CollOut o = hipsim::wave_collective(in, hipsim::fn_mfma_bf16_16x16x32);
     hipsim_f32x4 d;
     for (int r = 0; r < 4; ++r) d[r] = o.f[r];
+    return d;
+}
+// v_mfma_f32_32x32x16_bf16: A lane l = row l & 31, eight k of group l >> 5; B lane l = column l & 31, the same eight k; D lane l:
+// column l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5).  CollIn::f[0..15] = C, then the lane's eight A and eight B values.
+namespace hipsim {
+static void fn_mfma_bf16_32x32x16(const CollIn* in, CollOut* out, int n) {
+    if (n != 64) { std::fprintf(stderr, "hipsim: MFMA needs a full wave (got %d lanes)\n", n); std::abort(); }
+    auto val = [&](int lane, int which, int e) {
+        unsigned short h;
+        std::memcpy(&h, reinterpret_cast<const char*>(&in[lane].f[16]) + 16 * which + 2 * e, 2);
+        unsigned u = (unsigned)h << 16; float x; std::memcpy(&x, &u, 4); return (double)x;
+    };
+    for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+            double acc = in[l].f[r];
+            for (int g = 0; g < 2; ++g)
+                for (int e = 0; e < 8; ++e) acc += val(row + 32 * g, 0, e) * val(col + 32 * g, 1, e);
+            out[l].f[r] = (float)acc;
+        }
+}
+}  // namespace hipsim
+static inline hipsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipsim_bf16x8 a, hipsim_bf16x8 b, hipsim_f32x16 c, int, int, int) {
+    hipsim::CollIn in{};
+    for (int r = 0; r < 16; ++r) in.f[r] = c[r];
+    std::memcpy(reinterpret_cast<char*>(&in.f[16]), &a, 16);
+    std::memcpy(reinterpret_cast<char*>(&in.f[16]) + 16, &b, 16);
+    hipsim::CollOut o = hipsim::wave_collective(in, hipsim::fn_mfma_bf16_32x32x16);
+    hipsim_f32x16 d;
+    for (int r = 0; r < 16; ++r) d[r] = o.f[r];
     return d;
 }
 static inline void __builtin_amdgcn_s_barrier() { hipsim::block_barrier(); }

@@ -61,7 +61,7 @@ def _same_training(p, want, n_steps, lr=3e-4):
     return d.max() <= lr * n_steps and np.mean(tight) >= 0.99 and per_tensor
 
 
-def _worker(rank, world, port, per, ret, schedules=False, axis="weights", arch=(32, 32)):
+def _worker(rank, world, port, per, ret, schedules=False, axis="weights", arch=(32, 32), W=4):
     """One rank of a gloo job.  The sharded agent is run TWICE from identical seeds: through the staged path (seven library
     calls, the collectives issued by ``torch.distributed`` between them) and through the production path -- ONE library call
     per step (``morl_envelope_step_sharded`` / ``_batch_sharded``) whose collectives are the communicator's transport, here
@@ -78,7 +78,7 @@ def _worker(rank, world, port, per, ret, schedules=False, axis="weights", arch=(
     native.use_library(lib)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     for transport in ("staged", None, "ipc"):             # None = what a gloo job gets by default: the one-call step over
-        ag = _make_agent(lib, per, schedules, arch=arch)  # torch.distributed call-backs; "ipc": over the single-hop transport
+        ag = _make_agent(lib, per, schedules, arch=arch, W=W)  # torch.distributed call-backs; "ipc": over the single-hop transport
         shard_envelope_agent(ag, dist, axis=axis, transport=transport)
         comm = ag._shard.comm
         assert (comm is None) == (transport == "staged"), ag._shard.transport
@@ -108,8 +108,9 @@ def _worker(rank, world, port, per, ret, schedules=False, axis="weights", arch=(
 
 @pytest.mark.parametrize("axis", ["weights", "batch"])
 @pytest.mark.parametrize("per,schedules,world,arch", [(False, False, 2, (32, 32)), (True, False, 2, (32, 32)), (True, True, 2, (32, 32)),
-                                                      (True, False, 4, (32, 32)), (True, False, 2, (64, 64))],
-                         ids=["plain", "per", "per-schedules", "per-world4", "per-fused-lazy"])
+                                                      (True, False, 4, (32, 32)), (True, False, 2, (64, 64)),
+                                                      (True, False, 8, (32, 32)), (True, False, 8, (64, 64))],
+                         ids=["plain", "per", "per-schedules", "per-world4", "per-fused-lazy", "per-world8", "per-world8-fused-lazy"])
 def test_sharded_update_equals_single_process(per, schedules, world, axis, arch):
     """``schedules``: several steps with ``homotopy_decay_steps`` / ``epsilon_decay_steps`` set -- the sharded step must run
     the same tail as ``Envelope.update`` (envelope.py:336-355), or the auxiliary loss never turns on under sharding.
@@ -119,14 +120,17 @@ def test_sharded_update_equals_single_process(per, schedules, world, axis, arch)
     the pluggable transport of ``morl_comm``) must equal the staged one BIT FOR BIT and the unsharded step to 1e-5.  Third leg:
     the one-call step over the SINGLE-HOP transport (``morl_comm_ipc_*``: direct writes into peer-mapped memory -- POSIX shared
     memory between the processes of this test, hipIpc between GPUs); its all-reduce sums in rank order, so it equals the
-    unsharded step to 1e-5 and keeps the replicas bit-identical."""
+    unsharded step to 1e-5 and keeps the replicas bit-identical.
+    World 8 is the shape of the driver's 8-GPU run taken to its end: ONE weight per rank (W = 8) on the weight axis, ONE transition
+    per rank (B = 8) on the batch axis, eight slab parts, eight-way collectives on all three transports."""
+    W = 8 if world == 8 else 4
     import simlib
     import morl_baselines_amd.native as native
     lib = simlib.load_sim()
     native.use_library(lib)
     n_steps = N_STEPS[schedules]
     try:
-        ref = _make_agent(lib, per, schedules, arch=arch)
+        ref = _make_agent(lib, per, schedules, arch=arch, W=W)
         assert ref.q_net.ctx.fused == (arch == (64, 64))
         for _ in range(n_steps):
             ref.update()
@@ -141,7 +145,7 @@ def test_sharded_update_equals_single_process(per, schedules, world, axis, arch)
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = 29500 + (os.getpid() % 2000) + 7 * int(schedules) + 13 * (world - 2) + 31 * int(axis == "batch") + 3 * int(per) + 61 * int(arch != (32, 32))
-    procs = [ctx.Process(target=_worker, args=(r, world, port, per, ret, schedules, axis, arch)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, per, ret, schedules, axis, arch, W)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -18,7 +18,13 @@ __global__ void k(long long* out, double seed, int iters) {
             if (KIND == 0) asm volatile("v_cmp_le_f64 vcc, %0, %1" :: "v"(a), "v"(b) : "vcc");
             if (KIND == 1) asm volatile("v_cmp_eq_f64 vcc, %0, %1" :: "v"(a), "v"(b) : "vcc");
             if (KIND == 2) asm volatile("v_cmp_le_f32 vcc, %0, %1" :: "v"(fa), "v"(fb) : "vcc");
-            if (KIND == 3) { asm volatile("v_cmp_le_f64 vcc, %0, %1\n s_and_b64 vcc, vcc, exec" :: "v"(a), "v"(b) : "vcc"); }
+            // (rotating scalar destinations: back-to-back compares of one wave do not queue behind each other's VCC write)
+            if (KIND == 3) {
+                if ((i & 3) == 0) asm volatile("v_cmp_le_f64 s[40:41], %0, %1" :: "v"(a), "v"(b) : "s40", "s41");
+                if ((i & 3) == 1) asm volatile("v_cmp_le_f64 s[42:43], %0, %1" :: "v"(a), "v"(b) : "s42", "s43");
+                if ((i & 3) == 2) asm volatile("v_cmp_le_f64 s[44:45], %0, %1" :: "v"(a), "v"(b) : "s44", "s45");
+                if ((i & 3) == 3) asm volatile("v_cmp_le_f64 s[46:47], %0, %1" :: "v"(a), "v"(b) : "s46", "s47");
+            }
         }
     }
     const long long t1 = clock64();
@@ -38,6 +44,6 @@ template <int KIND> int one(const char* name, long long* d) {
 }
 int main() {
     long long* d; CK(hipMalloc(&d, 64 * 8));
-    one<0>("v_cmp_le_f64", d); one<1>("v_cmp_eq_f64", d); one<2>("v_cmp_le_f32", d); one<3>("v_cmp_le_f64 + s_and_b64", d);
+    one<0>("v_cmp_le_f64", d); one<1>("v_cmp_eq_f64", d); one<2>("v_cmp_le_f32", d); one<3>("v_cmp_le_f64, 4 destinations", d);
     return 0;
 }
