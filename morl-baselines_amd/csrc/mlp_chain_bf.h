@@ -78,6 +78,12 @@ struct BfChain {
     int ldsrc, K0;
     float* x0_out;                         // in_mode 0, or NULL: the assembled rows also go to HBM as [rows][ldx0] (zero padded)
     int ldx0;
+    // mlp_chain_bfn.h only, in_mode 3 (the lazily evaluated target rows): row r is the pair pairs[r] = b * W + j, i.e.
+    // cat(obs[b], weights[j]); rows = the bound the grid was sized for, *rows_dev the count; count_mirror / count_tag as ChainArgs'
+    const int* rows_dev;
+    const int32_t* pairs;
+    unsigned long long* count_mirror;
+    unsigned int count_tag;
     int amax;                              // 1: the head's output is the online next-state slab of an Envelope step whose row tiles are
                                            //    whole transitions (tile rows = W, 2 W or 4 W): the workgroup also takes the arg-max of its
                                            //    transitions (BfMulti::td, envelope_argmax_tile) -- no separate arg-max launch
@@ -788,7 +794,7 @@ struct BfSplitJob {
     long long sn, sk;
     int N, K, ksteps, ntiles, natural, block0;
 };
-constexpr int BF_MAX_JOBS = 2 * BF_MAX_STEPS;
+constexpr int BF_MAX_JOBS = 3 * BF_MAX_STEPS;      // forward + backward stream of the online network, forward stream of the target network
 struct BfSplitArgs {
     BfSplitJob job[BF_MAX_JOBS];
     int unit_start[BF_MAX_JOBS + 1];       // (k-step, tile) units of job j: [unit_start[j], unit_start[j + 1])

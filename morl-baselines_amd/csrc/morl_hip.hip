@@ -26,6 +26,7 @@
 #include "mlp_chain_bf.h"
 #include "dw_tiles.h"
 #include "dw_bf.h"
+#include "mlp_chain_bfn.h"
 #include "optim_kernels.h"
 #include "replay_kernels.h"
 #include "pareto_kernels.h"
@@ -211,6 +212,7 @@ struct morl_ctx {
     double host_wait_s = 0.0;                      // host time spent waiting for a count (the device more than LZ_LAG steps behind):
                                                    // back-pressure, not host work (morl_ctx_backpressure_seconds)
     int lz_last_big = 0;                           // what the last lazily evaluated step launched
+    bool lz_last_bfn = false;                      // ... its target rows ran on the few-row split-bf16 chain (mlp_chain_bfn.h)
     bool lz_count_missed = false;                  // the last lazily evaluated step could not read the count it is sized by (bounded
                                                    // wait ran out, or inside the re-arm window after one): it took the small tiles
     long long lz_count_misses = 0;                 // bounded waits that ran out, ever
@@ -237,6 +239,15 @@ struct morl_ctx {
     unsigned char* bf_stream = nullptr;
     int bf_fwd_blocks = 0, bf_bwd_blocks = 0, bf_k0_steps = 0, bf_head_tiles = 0;
     const float* fresh_bf = nullptr;     // parameters the streams were split from by this step's morl_envelope_prepare (one-shot)
+    const float* fresh_bft = nullptr;    // TARGET parameters whose forward stream (third region of bf_stream) that launch also made:
+                                         // the lazily evaluated target rows then run on the few-row split-bf16 chain (mlp_chain_bfn.h)
+    long long bfn_max_rows = 4096;       // chain launches of at most this many rows (over their chains) take the few-row split-bf16 chain
+                                         // (mlp_chain_bfn.h: 16-row tiles, the waves split the output features); MORL_BFN_MAX_ROWS, 0 = never
+    bool bft_ready = false;              // this step: the target network's forward stream is current (set at the step's entry, dropped by its end)
+    int bfn_targets = 0;                 // MORL_BFN_TARGETS=1: the lazily evaluated target rows on the few-row split-bf16 chain instead of
+                                         // the 8-row f32 tiles (mlp_chain4.h).  Measured and NOT the default: a tile streams the whole network
+                                         // through ONE CU's 64 B/clk vector-memory path, and the split stream is 1.5 x the fp32 bytes --
+                                         // 22.7 us against 18.2 at the flagship shape (profiles/r06_target_rows_ab.json)
     bool dw_bf_last = false;             // the last step's weight gradients ran on dw_bf.h
     bool bits_bf = false;                // the last training forward left its sign bits in mlp_chain_bf.h's lane layout
     const unsigned int* skip_flag = nullptr;   // one-shot: the next clip + Adam launch leaves the optimiser state alone if this
@@ -445,9 +456,11 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
         c->bf_head_tiles = (net->dims[c->L] + 15) / 16;
         c->bf_fwd_blocks = c->bf_k0_steps * 48 + (c->L - 2) * 384 + 8 * c->bf_head_tiles * 3;
         c->bf_bwd_blocks = 48 + (c->L - 2) * 384;
-        ALLOC(bf_stream, (size_t)(c->bf_fwd_blocks + c->bf_bwd_blocks) * BF_BLOCK);
+        ALLOC(bf_stream, (size_t)(2 * c->bf_fwd_blocks + c->bf_bwd_blocks) * BF_BLOCK);      // online forward | online backward | target forward
     }
     if (const char* e = getenv("MORL_EXACT_F32")) c->bf_mode = atoi(e) != 0 ? 0 : 1;
+    if (const char* e = getenv("MORL_BFN_TARGETS")) c->bfn_targets = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("MORL_BFN_MAX_ROWS")) c->bfn_max_rows = atoll(e);
     if (const char* e = getenv("MORL_BF_MIN_ROWS")) { c->bf_min_rows = atoll(e); c->bf_min_rows_env = true; }
 #undef ALLOC
     *out = c;
@@ -562,7 +575,7 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
     // already made by this step's morl_envelope_prepare for exactly these buffers?  (one-shot)
     const bool have1 = step_entry && wt == c->wt_online && c->fresh_online == params;
     const bool have2 = params2 == nullptr || (step_entry && wt2 == c->wt_target && c->fresh_target == params2);
-    c->fresh_online = c->fresh_target = c->fresh_bf = nullptr;
+    c->fresh_online = c->fresh_target = c->fresh_bf = c->fresh_bft = nullptr; c->bft_ready = false;
     if (have1 && have2) return MORL_OK;
     const ShadowArgs t = shadow_args(c);
     if (have1)          // (the prologue made the split-bf16 streams instead of the online copy, or only the target copy is stale)
@@ -577,7 +590,9 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
 // (its rows run on the fp32 few-row tiles, or its whole slab on the fp32 chain when the caller asks for it)
 static int refresh_bf_step(morl_ctx* c, const float* params_online, const float* params_target, hipStream_t s) {
     const bool have_bf = c->fresh_bf == params_online, have_t = c->fresh_target == params_target;
-    c->fresh_online = c->fresh_target = c->fresh_bf = nullptr;
+    const bool have_bft = have_bf && c->fresh_bft == params_target;
+    c->fresh_online = c->fresh_target = c->fresh_bf = c->fresh_bft = nullptr; c->bft_ready = false;
+    c->bft_ready = have_bft;             // (this step's lazily evaluated target rows may take the target network's split stream)
     c->wt_online_src = nullptr;
     int rc;
     if (!have_bf && (rc = bf_split_launch(c, params_online, s))) return rc;
@@ -592,13 +607,19 @@ static int refresh_bf_step(morl_ctx* c, const float* params_online, const float*
 
 // ---- split-bf16 chain (mlp_chain_bf.h) ------------------------------------------------------------------------------------------
 // does a gradient step over `rows` TD rows run its two online forward passes and its backward pass on the bf16 matrix cores?
+// few rows: the split-bf16 chain in its few-row form (mlp_chain_bfn.h) -- a rank's share of a sharded step, small batches
+static bool bfn_few(const morl_ctx* c, long long rows) {
+    return c->bf_ok && c->bf_mode != 0 && c->use_fused && c->fused_tm == 0 && rows >= 1 && rows <= c->bfn_max_rows;
+}
 static bool bf_wanted(const morl_ctx* c, long long rows, bool weight_shard = false) {
     const long long min_rows = (weight_shard && !c->bf_min_rows_env) ? std::max(c->bf_min_rows, 8192ll) : c->bf_min_rows;
-    return c->bf_ok && c->bf_mode != 0 && c->use_fused && c->fused_tm == 0 && rows >= min_rows;
+    // (the few-row form serves the unsharded / batch-sharded step; the weight-sharded rank step below its threshold keeps the f32
+    // engines: its slab, training pass and TD rows are separate entries that were measured there)
+    return c->bf_ok && c->bf_mode != 0 && c->use_fused && c->fused_tm == 0 && (rows >= min_rows || (!weight_shard && bfn_few(c, rows)));
 }
 
 // the split jobs of the online network: forward stream (blocks [0, bf_fwd_blocks)) then backward stream
-static BfSplitArgs bf_split_args(const morl_ctx* c, const float* params) {
+static BfSplitArgs bf_split_args(const morl_ctx* c, const float* params, const float* params_target = nullptr) {
     BfSplitArgs a{};
     const morl_net_desc& n = c->net;
     const int L = c->L;
@@ -611,14 +632,23 @@ static BfSplitArgs bf_split_args(const morl_ctx* c, const float* params) {
         units += ksteps * ntiles;
         block += ksteps * ntiles * 3;
     };
-    // forward: M[n][k] = W_l[n][k] (nn.Linear.weight [out][in])
-    for (int l = 0; l < L; ++l) {
-        const bool head = (l == L - 1);
-        add(params + c->offW[l], n.dims[l], 1, n.dims[l + 1], n.dims[l], l == 0 ? c->bf_k0_steps : 8, head ? c->bf_head_tiles : 16, l == 0 ? 1 : 0);
+    if (params != nullptr) {
+        // forward: M[n][k] = W_l[n][k] (nn.Linear.weight [out][in])
+        for (int l = 0; l < L; ++l) {
+            const bool head = (l == L - 1);
+            add(params + c->offW[l], n.dims[l], 1, n.dims[l + 1], n.dims[l], l == 0 ? c->bf_k0_steps : 8, head ? c->bf_head_tiles : 16, l == 0 ? 1 : 0);
+        }
+        // backward: step k <-> layer l = L - 1 - k: g_{l-1} = g_l W_l, i.e. M[n = i][k = o] = W_l[o][i]
+        for (int l = L - 1; l >= 1; --l)
+            add(params + c->offW[l], 1, n.dims[l], n.dims[l], n.dims[l + 1], l == L - 1 ? 1 : 8, 16, l == L - 1 ? 1 : 0);
     }
-    // backward: step k <-> layer l = L - 1 - k: g_{l-1} = g_l W_l, i.e. M[n = i][k = o] = W_l[o][i]
-    for (int l = L - 1; l >= 1; --l)
-        add(params + c->offW[l], 1, n.dims[l], n.dims[l], n.dims[l + 1], l == L - 1 ? 1 : 8, 16, l == L - 1 ? 1 : 0);
+    block = c->bf_fwd_blocks + c->bf_bwd_blocks;
+    // the target network's forward stream, behind both streams of the online one (mlp_chain_bfn.h: the lazily evaluated target rows)
+    if (params_target != nullptr)
+        for (int l = 0; l < L; ++l) {
+            const bool head = (l == L - 1);
+            add(params_target + c->offW[l], n.dims[l], 1, n.dims[l + 1], n.dims[l], l == 0 ? c->bf_k0_steps : 8, head ? c->bf_head_tiles : 16, l == 0 ? 1 : 0);
+        }
     a.unit_start[j] = units;
     a.n = j;
     return a;
@@ -634,10 +664,11 @@ static int bf_split_launch(morl_ctx* c, const float* params, hipStream_t s) {
 
 // forward chain over rows assembled from (obs, weights), row b * W + i; save => hidden activations to ctx->h[], sign bits, x0
 static BfChain bf_forward_chain(morl_ctx* c, const float* params, const float* obs, const float* weights, int B, int W, int rows,
-                                bool save, float* q_out, int ldq_out) {
+                                bool save, float* q_out, int ldq_out, bool target_stream = false) {
     BfChain a{};
     const int L = c->L;
-    a.stream = c->bf_stream;
+    // (target_stream: `params` is the TARGET network, whose forward stream is the third region of bf_stream -- mlp_chain_bfn.h only)
+    a.stream = c->bf_stream + (target_stream ? (size_t)(c->bf_fwd_blocks + c->bf_bwd_blocks) * BF_BLOCK : 0);
     a.n_steps = L; a.k0_steps = c->bf_k0_steps; a.head = 1;
     a.n_stages = c->bf_fwd_blocks / BF_STAGE_BLOCKS;
     a.rows = rows;
@@ -680,8 +711,15 @@ static int timing_close(morl_ctx* c, int slot, hipStream_t s);
 // row tile of a bf16 chain launch: 64-row tiles (4 waves) when there is at least one for every CU, else 32-row tiles (2 waves).
 // (Round 4 first asked for TWO 64-row workgroups per CU; one 4-wave workgroup per CU stages the weight stream into LDS once
 // where two 2-wave ones stage it twice: the flagship's backward launch 41.9 -> 39 us.)
+constexpr int BF_TILE_FEW = 1;      // bf_tile_rows: the launch takes the few-row chain (mlp_chain_bfn.h), whose tiles are never whole transitions
 static int bf_tile_rows(morl_ctx* c, const BfChain* chains, int n) {
-    long long tiles64 = 0;
+    long long tiles64 = 0, rows_all = 0;
+    for (int q = 0; q < n; ++q) rows_all += chains[q].rows;
+    // the few-row form (32-row tiles whose waves split the output features, no in-chain arg-max / TD stage) while the LAUNCH has at most
+    // 4 096 rows over its chains, i.e. 128 tiles: measured per launch (profiles/r06_rank_step_bfn_ab.json) -- the two forward passes of
+    // 2 048 rows each 23.8 us against 36 on the 32-row tiles of mlp_chain_bf.h, the backward pass of 4 096 rows 22.2 against 34.3, but
+    // the two forward passes of 4 096 rows each 44.0 against 41.1
+    if (n <= BFN_MAX_MULTI && bfn_few(c, rows_all)) return BF_TILE_FEW;
     for (int q = 0; q < n; ++q) tiles64 += (chains[q].rows + BF_TM - 1) / BF_TM;
     const bool small = tiles64 < (long long)c->num_cus;
     return small ? 32 : BF_TM;
@@ -689,9 +727,31 @@ static int bf_tile_rows(morl_ctx* c, const BfChain* chains, int n) {
 
 static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStream_t s, const EnvelopeTdArgs* td = nullptr,
                      const BfTdArgs* tdb = nullptr) {
+    const int tm = bf_tile_rows(c, chains, n);
+    if (tm == BF_TILE_FEW) {
+        const int trows = BFN_TM;
+        if (td || tdb) return fail(MORL_ERR_STATE, "internal: the few-row chain takes no in-chain arg-max / TD stage");
+        BfnMulti f{};
+        f.n = n;
+        int tiles = 0;
+        for (int q = 0; q < n; ++q) {
+            f.c[q] = chains[q];
+            f.c[q].amax = 0;
+            f.tile_start[q] = tiles;
+            tiles += (chains[q].rows + trows - 1) / trows;
+            // which of the three streams the chain reads (their block counts bound the stream's descriptor)
+            const unsigned char* st = chains[q].stream;
+            f.n_blocks[q] = (st == c->bf_stream + (size_t)c->bf_fwd_blocks * BF_BLOCK) ? c->bf_bwd_blocks : c->bf_fwd_blocks;
+        }
+        for (int q = n; q <= BFN_MAX_MULTI; ++q) f.tile_start[q] = tiles;
+        int slot = -1, rc;
+        if ((rc = timing_open(c, kind, s, &slot))) return rc;
+        hipLaunchKernelGGL(mlp_chain_bfn_kernel, dim3(tiles), dim3(BFN_THREADS), 0, s, f);
+        LAUNCH_CHECK("mlp_chain_bfn");
+        return timing_close(c, slot, s);
+    }
     BfMulti m{};
     m.n = n;
-    const int tm = bf_tile_rows(c, chains, n);
     const bool small = tm == 32;
     if (tdb) m.tdb = *tdb;
     if (td) {
@@ -1111,7 +1171,8 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
     const bool shard_next = c->prepare_rows >= 0 && c->prepare_weight_shard;
     c->prepare_rows = -1;
     if (bf_wanted(c, rows_next, shard_next)) {
-        const BfSplitArgs bf = bf_split_args(c, params_online);
+        const bool bft = c->bfn_targets && c->lazy_targets != 0;       // (the target rows of a lazily evaluated step: mlp_chain_bfn.h)
+        const BfSplitArgs bf = bf_split_args(c, params_online, bft ? params_target : nullptr);
         const int bf_blocks = (bf.unit_start[bf.n] * 64 + 255) / 256;
         hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks + sh.tiles + bf_blocks), dim3(256), 0, (hipStream_t)stream, a, blocks,
                            params_target, c->wt_target, (const float*)nullptr, (float*)nullptr, sh, 1, bf, c->bf_stream);
@@ -1119,6 +1180,7 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
         c->fresh_online = nullptr;
         c->fresh_target = params_target;
         c->fresh_bf = params_online;
+        c->fresh_bft = bft ? params_target : nullptr;
         return MORL_OK;
     }
     hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks + 2 * sh.tiles), dim3(256), 0, (hipStream_t)stream, a, blocks, params_online,
@@ -1126,25 +1188,26 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
     LAUNCH_CHECK("step_prologue");
     c->fresh_online = params_online;
     c->fresh_target = params_target;
-    c->fresh_bf = nullptr;
+    c->fresh_bf = c->fresh_bft = nullptr;
     return MORL_OK;
 }
 
 // bit 0: the last morl_envelope_update on this context ran its online forward passes and its dX backward pass as split-bf16
 // products (mlp_chain_bf.h); bit 1: its weight gradients too (dw_bf.h); bit 2: its lazily evaluated target rows took the large
 // f32 tiles (an earlier step had selected more than MORL_LAZY_BIG_ROWS pairs); bit 3: its target launch was sized WITHOUT the count it
-// should have read (bounded wait ran out / re-arm window); bit 4: that has happened on this context; 0: everything on the f32-input MFMA
+// should have read (bounded wait ran out / re-arm window); bit 4: that has happened on this context; bit 5: its lazily evaluated target
+// rows ran on the few-row split-bf16 chain (mlp_chain_bfn.h) rather than the f32 tiles; 0: everything on the f32-input MFMA
 extern "C" int morl_ctx_last_step_bf16(morl_ctx* c) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     return (c->bits_bf ? 1 : 0) | (c->dw_bf_last ? 2 : 0) | ((c->lz_last && c->lz_last_big) ? 4 : 0) |
-           ((c->lz_last && c->lz_count_missed) ? 8 : 0) | (c->lz_count_misses > 0 ? 16 : 0);
+           ((c->lz_last && c->lz_count_missed) ? 8 : 0) | (c->lz_count_misses > 0 ? 16 : 0) | ((c->lz_last && c->lz_last_bfn) ? 32 : 0);
 }
 
 extern "C" int morl_ctx_set_exact_f32(morl_ctx* c, int enable) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     const int was = c->bf_mode == 0 ? 1 : 0;
     c->bf_mode = enable ? 0 : 1;
-    c->fresh_online = c->fresh_target = c->fresh_bf = nullptr;
+    c->fresh_online = c->fresh_target = c->fresh_bf = c->fresh_bft = nullptr; c->bft_ready = false;
     return was;
 }
 
@@ -1176,7 +1239,7 @@ extern "C" int morl_ctx_backpressure_seconds(morl_ctx* c, double* seconds) {
 
 extern "C" int morl_ctx_invalidate_shadows(morl_ctx* c) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
-    c->fresh_online = c->fresh_target = c->fresh_bf = nullptr;
+    c->fresh_online = c->fresh_target = c->fresh_bf = c->fresh_bft = nullptr; c->bft_ready = false;
     c->wt_online_src = nullptr;
     c->bf_stream_src = nullptr;
     return MORL_OK;
@@ -1410,7 +1473,35 @@ static int lazy_phase1(morl_ctx* c, const EnvelopeTdArgs& p, int td_waves, hipSt
     static const bool few_rows = [] { const char* e = getenv("MORL_CHAIN4"); return e ? atoi(e) != 0 : true; }();   // (A/B)
     // many pairs LZ_LAG steps ago (an adversarial batch: every TD row its own pair): the same compact rows on the 64-row f32 tiles
     c->lz_last_big = lazy_count_was_big(c) ? 1 : 0;
-    if (c->lz_last_big) {
+    const bool bfn = c->bft_ready && c->bfn_targets && c->bf_ok && c->bf_mode == 1 && !c->lz_last_big;
+    c->bft_ready = false;
+    c->lz_last_bfn = bfn;
+    if (bfn) {
+        // few-row split-bf16 chain on the target network's forward stream (mlp_chain_bfn.h): 16-row tiles, the four waves of a tile
+        // split every layer's output features -- the same six-product arithmetic as the step's online passes
+        BfnMulti m{};
+        BfChain& a = m.c[0];
+        a.stream = c->bf_stream + (size_t)(c->bf_fwd_blocks + c->bf_bwd_blocks) * BF_BLOCK;
+        a.n_steps = c->L; a.k0_steps = c->bf_k0_steps; a.head = 1;
+        a.n_stages = 0;
+        a.rows = p.B * wi;
+        a.in_mode = 3; a.obs = c->lz_next_obs; a.weights = w_all;
+        a.B = p.B; a.W = p.W; a.D = c->net.obs_dim; a.R = c->net.reward_dim; a.row_order = 0;
+        a.rows_dev = t.rows_dev; a.pairs = t.pairs; a.count_mirror = t.count_mirror; a.count_tag = t.count_tag;
+        for (int l = 0; l < c->L; ++l) {
+            BfStep& st = a.step[l];
+            st.bias = c->lz_params_target + c->offB[l];
+            st.N = c->net.dims[l + 1]; st.K = c->net.dims[l];
+            st.relu = (l == c->L - 1) ? 0 : 1;
+            if (l == c->L - 1) { st.out = c->qt; st.ldout = p.A * p.R; }
+        }
+        m.n = 1;
+        m.tile_start[0] = 0;
+        m.tile_start[1] = m.tile_start[2] = (a.rows + BFN_TM - 1) / BFN_TM;
+        m.n_blocks[0] = c->bf_fwd_blocks;
+        hipLaunchKernelGGL(mlp_chain_bfn_kernel, dim3(m.tile_start[1]), dim3(BFN_THREADS), 0, s, m);
+        LAUNCH_CHECK("mlp_chain_bfn(lazy targets)");
+    } else if (c->lz_last_big) {
         Chain2Multi m{};
         const int S = chain2_fill(c, m, &t, 1, 0);
         hipLaunchKernelGGL(mlp_chain2_kernel<1>, dim3(S), dim3(CH_THREADS), 0, s, m);
@@ -1490,7 +1581,7 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
                 !p.ac && !p.zero_ptr && !p.priority_clear && p.part_floats == 0 && !p.diag_only && p.q_main != nullptr && (c->ldq & 3) == 0) {
                 const BfChain probe = bf_backward_chain(c, rows);
                 const int tr = bf_tile_rows(c, &probe, 1);
-                td_in_chain = (W == tr || 2 * W == tr || (4 * W == tr && tr == 64)) && (W & 15) == 0;
+                td_in_chain = tr != BF_TILE_FEW && (W == tr || 2 * W == tr || (4 * W == tr && tr == 64)) && (W & 15) == 0;
             }
         }
         if (!td_in_chain && (rc = launch_envelope_td(p, B * td_groups, td_waves, s, "envelope_td"))) return rc;
@@ -1777,7 +1868,7 @@ static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_a
                           const SumTreeUpdate* per = nullptr) {
     c->wt_online_src = nullptr;          // the parameters change: any transposed copy is stale from here on
     c->bf_stream_src = nullptr;
-    c->fresh_online = c->fresh_target = c->fresh_bf = nullptr;
+    c->fresh_online = c->fresh_target = c->fresh_bf = c->fresh_bft = nullptr; c->bft_ready = false;
     const unsigned int* skip_flag = c->skip_flag;    // one-shot request of a sharded step (set right before this call)
     c->skip_flag = nullptr;
     const int nblk = std::min(OPT_MAX_BLOCKS, stream_grid(c->P, OPT_THREADS));
@@ -1848,6 +1939,13 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         if ((rc = refresh_bf_step(c, params_online, params_target, s))) return rc;
         c->lz_now = c->lazy_targets && cfg->envelope && W >= 2 && !out->q_target_next && (c->lazy_targets == 2 || rows >= lazy_min_rows);
         c->lz_last = c->lz_now;
+        if (c->lz_now && !c->bft_ready && c->bfn_targets) {
+            // (a caller that did not come through morl_envelope_prepare: the target network's forward stream for the few-row chain)
+            const BfSplitArgs a = bf_split_args(c, nullptr, params_target);
+            hipLaunchKernelGGL(bf_split_kernel, dim3((a.unit_start[a.n] * 64 + 255) / 256), dim3(256), 0, s, a, c->bf_stream);
+            LAUNCH_CHECK("bf_split(target)");
+            c->bft_ready = true;
+        }
         const BfChain two[2] = {bf_forward_chain(c, params_online, next_obs, weights, B, W, rows, false, c->qo, AR),
                                 bf_forward_chain(c, params_online, obs, weights, B, W, rows, true, c->qm, c->ldq)};
         if (c->lz_now) { c->lz_params_target = params_target; c->lz_next_obs = next_obs; }
@@ -1860,7 +1958,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
             EnvelopeTdArgs amax_args{};
             static const bool fuse_env = [] { const char* e = getenv("MORL_ARGMAX_IN_CHAIN"); return e ? atoi(e) != 0 : true; }();   // (A/B)
             const int tile_rows = bf_tile_rows(c, two, 2);
-            const bool fuse = fuse_env && c->lz_now && (W == tile_rows || 2 * W == tile_rows || (4 * W == tile_rows && tile_rows == 64)) &&
+            const bool fuse = fuse_env && c->lz_now && tile_rows != BF_TILE_FEW && (W == tile_rows || 2 * W == tile_rows || (4 * W == tile_rows && tile_rows == 64)) &&
                               cfg->slab_parts <= 1 && R <= MORL_MAX_OBJ;
             if (fuse) {
                 int td_waves = 0;

@@ -71,6 +71,33 @@ def test_eager_target_evaluation_on_the_gpu():
     assert " passed" in r.stdout
 
 
+def test_large_tile_split_bf16_chain_passes_the_same_parity_tests():
+    """Chain launches of at most 4 096 rows -- every case the emulator can afford -- take the few-row split-bf16 chain
+    (csrc/mlp_chain_bfn.h: 16-row tiles whose waves split the output features); the 64 / 32-row tiles of mlp_chain_bf.h, which carry the
+    flagship step on the GPU, are reached here with MORL_BFN_MAX_ROWS=0: the same fixture / oracle assertions, including the arg-max
+    inside the forward launch and the TD stage inside the backward launch, which only those tiles have."""
+    env = dict(os.environ, MORL_BFN_MAX_ROWS="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_parity.py"),
+                        os.path.join(ROOT, "tests", "test_flagship_golden.py"), "-x", "-q", "-m", "not gpu",
+                        "-k", "(flagship_b32w8 or wide_pick or flagship) and (reference_golden or lazy_target_evaluation or fused_auto or separate_launch)",
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+def test_target_rows_on_the_few_row_split_bf16_chain_pass_the_same_parity_tests():
+    """The lazily evaluated target rows of a bf16 step run on the 8-row f32 tiles of mlp_chain4.h; MORL_BFN_TARGETS=1 puts them on the
+    few-row split-bf16 chain (csrc/mlp_chain_bfn.h, in_mode 3: pair list, device-side row count, count mirror) -- measured slower on
+    the MI355X and therefore not the default, but a supported pipeline: the same fixture assertions, the lazy leg asserting through
+    bit 5 of ``morl_ctx_last_step_bf16`` that the rows did run there."""
+    env = dict(os.environ, MORL_BFN_TARGETS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_parity.py"), "-x", "-q", "-m", "not gpu",
+                        "-k", "(flagship_b32w8 or wide_pick) and (reference_golden or lazy_target_evaluation)", "-p",
+                        "no:cacheprovider"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_exact_f32_arithmetic_passes_the_same_parity_tests():
     """The suite runs qualifying networks (hidden layers of 256) through the split-bf16 chain (csrc/mlp_chain_bf.h; tests/conftest.py
     sets its row threshold to zero); here the same fixture / oracle assertions with MORL_EXACT_F32=1 -- every GEMM on the f32-input

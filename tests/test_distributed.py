@@ -855,18 +855,21 @@ def _fake_rccl_worker(rank, world, port, fake, scenario, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scenario", [("none", -1), ("id", 0), ("init", 0), ("init", 1), ("init", 2)],
-                         ids=["rccl-comes-up", "no-unique-id", "init-fails-on-rank0", "init-fails-on-rank1", "init-fails-on-rank2"])
+@pytest.mark.parametrize("scenario", [("none", -1), ("id", 0), ("init", 0), ("init", 1), ("init", 2),
+                                      ("none", -1, 8), ("init", 0, 8), ("init", 5, 8), ("init", 7, 8)],
+                         ids=["rccl-comes-up", "no-unique-id", "init-fails-on-rank0", "init-fails-on-rank1", "init-fails-on-rank2",
+                              "world8-rccl-comes-up", "world8-init-fails-on-rank0", "world8-init-fails-on-rank5", "world8-init-fails-on-rank7"])
 def test_rccl_setup_agreement_on_every_rank_ordering(scenario):
     """``NativeComm(transport="rccl")`` / ``make_comm`` at world 3 over gloo with a fake librccl (``MORL_RCCL_LIB``) whose
     ``ncclGetUniqueId`` / ``ncclCommInitRank`` fail where the scenario says.  Whatever rank fails: nobody hangs, every rank reaches
     the same verdict, ``make_comm`` returns RCCL on all ranks or the torch.distributed fall-back on all ranks, and a communicator
     that came up reports the world RCCL itself counted (``morl_comm_size`` -> ``ncclCommCount``: bench.py's ``config.rccl_ranks``)."""
     fake = _build_fake_rccl()
-    world = 3
+    world = scenario[2] if len(scenario) > 2 else 3         # (world 8: the driver's 8-GPU node -- the first real RCCL job is eight ranks)
+    scenario = scenario[:2]
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    port = 35500 + (os.getpid() % 2000) + 7 * ["none", "id", "init"].index(scenario[0]) + max(scenario[1], 0)
+    port = 35500 + (os.getpid() % 2000) + 7 * ["none", "id", "init"].index(scenario[0]) + max(scenario[1], 0) + 40 * (world - 3)
     procs = [ctx.Process(target=_fake_rccl_worker, args=(r, world, port, fake, scenario, ret)) for r in range(world)]
     for p in procs:
         p.start()

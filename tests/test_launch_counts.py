@@ -58,13 +58,19 @@ def _launches(extra_env):
 
 
 def test_launches_per_update_with_and_without_the_fused_stages():
-    fused = _launches({})
+    # (the Envelope step on the 64 / 32-row tiles of mlp_chain_bf.h, as at the flagship size on the GPU: MORL_BFN_MAX_ROWS=0 -- by size
+    # the emulator's steps take the few-row chain of mlp_chain_bfn.h, counted below)
+    big = {"MORL_BFN_MAX_ROWS": "0"}
+    fused = _launches(big)
     # ops.envelope_update (lazy targets, split-bf16 chains, row tiles = whole transitions): the seven launches of DESIGN.md section 4 --
     # weight shadows / splits, forward + arg-max, target rows, backward + TD stage, weight gradients, slab reduction, clip + Adam --
     # and one more: called directly (no sampling launch in front that also prepares the weights) the entry prepares them itself
     assert fused == {"envelope": 8, "capql": 12, "mosac": 24}, fused
-    assert _launches({"MORL_ARGMAX_IN_CHAIN": "0"})["envelope"] == fused["envelope"] + 1
-    assert _launches({"MORL_TD_IN_CHAIN": "0"})["envelope"] == fused["envelope"] + 1
+    assert _launches(dict(big, MORL_ARGMAX_IN_CHAIN="0"))["envelope"] == fused["envelope"] + 1
+    assert _launches(dict(big, MORL_TD_IN_CHAIN="0"))["envelope"] == fused["envelope"] + 1
+    # the few-row chain (a step of at most 4 096 rows): its 32-row tiles are not whole transitions, so the arg-max and the TD stage are
+    # launches of their own -- two more
+    assert _launches({})["envelope"] == fused["envelope"] + 2
     # CAPQL: two Adam launches and the Polyak / counter launch fold into the two weight-gradient launches
     sep = _launches({"MORL_AC_ADAM_IN_DW": "0"})
     assert sep["capql"] == fused["capql"] + 3 and sep["mosac"] > fused["mosac"], sep

@@ -17,7 +17,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the profiled command: bench.py by default, or `pmc_summary.py out.json <script under the repo root> <its arguments...>`
-COMMAND = [os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline"]
+COMMAND = [os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--no-ramp-record",
+           "--no-sustained-record", "--no-exact-record"]
 PASSES = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
           "sq": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"]}
 # a second SQ pass (optional: a counter name this rocprofv3 does not know fails the pass, which is then skipped): where the waves'
