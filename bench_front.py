@@ -22,9 +22,10 @@ import numpy as np
 import torch as th
 
 
-# f64 compares a SIMD retires per clock (v_cmp_le_f64 / v_cmp_eq_f64 at 4 waves per SIMD: tools/probes/cmp64_probe.hip,
-# profiles/r06_cmp64_probe.txt) x 1 024 SIMDs x 2.4 GHz: the rate the Pareto kernel's compare instructions are priced against
-F64_CMP_LANES_PER_CLK_SIMD = 16.0
+# f64 compares a SIMD retires per clock (v_cmp_le_f64 at 4 waves per SIMD issuing to rotating scalar destinations: 1.81 cycles per
+# wave-instruction = 35.3 lane-compares per clock; tools/probes/cmp64_probe.hip, profiles/r06_cmp64_probe.txt) x 1 024 SIMDs x 2.4 GHz:
+# the rate the Pareto kernel's compare instructions are priced against
+F64_CMP_LANES_PER_CLK_SIMD = 35.3
 PEAK_F64_COMPARES = F64_CMP_LANES_PER_CLK_SIMD * 1024 * 2.4e9
 
 

@@ -45,6 +45,7 @@ constexpr int BFN_XBUF_BYTES = BFN_XBLOCKS * BF_BLOCK;
 // four sub-tiles (64-row tiles: a barrier in front of the epilogue's writes and one behind them) -- 96 KB either way
 constexpr int BFN_LDS_BYTES = 2 * BFN_RT * BFN_XBUF_BYTES;
 static_assert(BFN_RT_MAX * BFN_XBUF_BYTES <= BFN_LDS_BYTES, "the 64-row form's single buffer fits the same allocation");
+constexpr int BFN_BIAS_BYTES = BF_MAX_STEPS * BF_WIDE * 4;   // every step's bias, [step][256] floats (zeros beyond a step's columns)
 constexpr int BFN_MAX_MULTI = 2;
 
 struct BfnMulti {
@@ -176,17 +177,13 @@ __device__ __forceinline__ void bfn_epilogue(const f32x4 (&acc)[4], const BfStep
     if (MODE == 1 && st.bits_out != nullptr && row_ok) reinterpret_cast<unsigned short*>(st.bits_out)[bits_idx * 4 + wave] = (unsigned short)pos;
 }
 
-// this wave's accumulators start from its tiles' biases (zeros beyond the step's columns / without a bias).  Requested a whole step
-// AHEAD (bfn_bias_load at the top of the step before): the vector-memory counter retires in issue order, so a bias loaded at the top of
-// ITS step would be waited for behind every weight group in flight -- the ring drained once per layer
-template <int NT>
-__device__ __forceinline__ void bfn_bias_load(f32x4 (&b)[4], const BfStep& st, bool live, int tile0, int q) {
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)st.bias, 0, (live && st.bias != nullptr) ? st.N * 4 : 0, 0x00020000);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (j < NT) b[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (16 * (tile0 + j) + 4 * q) * 4, 0, 0));
-        else b[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+// The biases of every step go to LDS ONCE, at the top of the kernel (one 4-byte buffer load per work-item and step, range-checked:
+// zeros beyond a step's columns / without a bias), in front of the weight stream -- the oldest loads the wave ever issues.  A bias
+// loaded at the top of its own step is waited for behind every weight group in flight (the counter retires in issue order: the ring
+// drained once per layer), and one loaded a step ahead is more than 63 loads old when it is used, which the compiler's wait insertion
+// answers with vmcnt(0) just the same; an accumulator's initial value then is an LDS read.
+__device__ __forceinline__ f32x4 bfn_bias_at(const float* bias_lds, int step, int tile, int q) {
+    return *reinterpret_cast<const f32x4*>(bias_lds + step * BF_WIDE + 16 * tile + 4 * q);
 }
 
 // ---- one 32-row tile (two sub-tiles) through a whole chain ------------------------------------------------------------------------
@@ -209,8 +206,15 @@ __device__ __forceinline__ void bfn_chain_body(const BfChain& p, int n_blocks, i
     cur.head0 = (cur.g_wide * 48 + 3 * wave) * BF_BLOCK;
     cur.head_stride = head_tiles * 3 * BF_BLOCK;
     cur.beyond = n_blocks * BF_BLOCK;
-    f32x4 bias0[4];
-    bfn_bias_load<4>(bias0, p.step[0], true, 4 * wave, q);          // (in front of the stream: older than every weight group)
+    float* bias_lds = reinterpret_cast<float*>(lds + BFN_LDS_BYTES);
+    float bv[BF_MAX_STEPS];
+#pragma unroll
+    for (int st = 0; st < BF_MAX_STEPS; ++st) {
+        const float* bp = p.step[st].bias;
+        const __amdgpu_buffer_rsrc_t rb =
+            __builtin_amdgcn_make_buffer_rsrc((void*)bp, 0, (st < p.n_steps && bp != nullptr) ? p.step[st].N * 4 : 0, 0x00020000);
+        bv[st] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, tid * 4, 0, 0));
+    }
     bf_u32x4 wr[BFN_DEPTH][4][3];
     bfn_issue<0>(wr, rsrc, voff, bfn_next_offset(cur));
     bfn_issue<1>(wr, rsrc, voff, bfn_next_offset(cur));
@@ -265,15 +269,16 @@ __device__ __forceinline__ void bfn_chain_body(const BfChain& p, int n_blocks, i
         if (K0S == 1) { x0[t][1][0] = x0[t][0][0]; x0[t][1][1] = x0[t][0][1]; x0[t][1][2] = x0[t][0][2]; }
     }
 
-    f32x4 acc[RT][4], bnext[4];
+    // the bias table (behind the input rows' loads, in front of the first product: the weight groups stay in flight across the barrier)
+#pragma unroll
+    for (int st = 0; st < BF_MAX_STEPS; ++st) bias_lds[st * BF_WIDE + tid] = bv[st];
+    BFN_BARRIER();
+    f32x4 acc[RT][4];
     // ---- first step ---------------------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = bias0[j];
-    // (the next step's biases: the second wide step's, or the head's for this wave's tile)
-    if (n_wide > 1) bfn_bias_load<4>(bnext, p.step[1], true, 4 * wave, q);
-    else bfn_bias_load<1>(bnext, p.step[p.n_steps - 1], p.head != 0, wave, q);
+        for (int j = 0; j < 4; ++j) acc[t][j] = bfn_bias_at(bias_lds, 0, 4 * wave + j, q);
     bfn_products<RT, 0, K0S, true, 4>(acc, wr, x0, nullptr, rsrc, voff, cur, lane);
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -288,9 +293,7 @@ __device__ __forceinline__ void bfn_chain_body(const BfChain& p, int n_blocks, i
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t][j] = bnext[j];
-        if (s + 1 < n_wide) bfn_bias_load<4>(bnext, p.step[s + 1], true, 4 * wave, q);
-        else bfn_bias_load<1>(bnext, p.step[p.n_steps - 1], p.head != 0, wave, q);
+            for (int j = 0; j < 4; ++j) acc[t][j] = bfn_bias_at(bias_lds, s, 4 * wave + j, q);
         if (phase == 0) bfn_products<RT, 0, 8, false, 4>(acc, wr, x0, xin, rsrc, voff, cur, lane);
         else if (phase == 1) bfn_products<RT, 1, 8, false, 4>(acc, wr, x0, xin, rsrc, voff, cur, lane);
         else bfn_products<RT, (BFN_DEPTH > 2 ? 2 : 0), 8, false, 4>(acc, wr, x0, xin, rsrc, voff, cur, lane);
@@ -306,7 +309,7 @@ __device__ __forceinline__ void bfn_chain_body(const BfChain& p, int n_blocks, i
         const BfStep& st = p.step[p.n_steps - 1];
         const unsigned char* xin = lds + (DB ? ((n_wide - 1) & 1) * RT * BFN_XBUF_BYTES : 0);
 #pragma unroll
-        for (int t = 0; t < RT; ++t) { acc[t][0] = bnext[0]; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int t = 0; t < RT; ++t) { acc[t][0] = bfn_bias_at(bias_lds, p.n_steps - 1, wave, q); acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         if (phase == 0) bfn_products<RT, 0, 8, false, 1>(acc, wr, x0, xin, rsrc, voff, cur, lane);
         else if (phase == 1) bfn_products<RT, 1, 8, false, 1>(acc, wr, x0, xin, rsrc, voff, cur, lane);
         else bfn_products<RT, (BFN_DEPTH > 2 ? 2 : 0), 8, false, 1>(acc, wr, x0, xin, rsrc, voff, cur, lane);
@@ -362,7 +365,7 @@ __device__ __forceinline__ void bfn_entry(const BfnMulti& m, unsigned char* lds)
 }
 
 __global__ __launch_bounds__(BFN_THREADS) void mlp_chain_bfn_kernel(BfnMulti m) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[BFN_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BFN_LDS_BYTES + BFN_BIAS_BYTES];
     kernarg_warm<sizeof(BfnMulti)>();
     bfn_entry<BFN_RT>(m, lds);
 }
