@@ -46,7 +46,7 @@ constexpr int BFN_XBUF_BYTES = BFN_XBLOCKS * BF_BLOCK;
 constexpr int BFN_LDS_BYTES = 2 * BFN_RT * BFN_XBUF_BYTES;
 static_assert(BFN_RT_MAX * BFN_XBUF_BYTES <= BFN_LDS_BYTES, "the 64-row form's single buffer fits the same allocation");
 constexpr int BFN_BIAS_BYTES = BF_MAX_STEPS * BF_WIDE * 4;   // every step's bias, [step][256] floats (zeros beyond a step's columns)
-constexpr int BFN_MAX_MULTI = 2;
+constexpr int BFN_MAX_MULTI = 3;                             // (the three forward passes of an eagerly evaluated few-row step)
 
 struct BfnMulti {
     BfChain c[BFN_MAX_MULTI];
@@ -346,32 +346,28 @@ __device__ __forceinline__ void bfn_dispatch(const BfChain& p, int n_blocks, int
     else bfn_chain_body<RT, K0S, 0>(p, n_blocks, row0, n_rows, lds);
 }
 
-// grid: one workgroup per (16 RT)-row tile over the launch's chains
-template <int RT>
-__device__ __forceinline__ void bfn_entry(const BfnMulti& m, unsigned char* lds) {
+// grid: one workgroup per 32-row tile over the launch's chains.  (The tile -> chain walk stands IN the kernel: handed on as a reference
+// through a helper, the argument block was re-read per use -- a constant ~4 us per launch.)
+__global__ __launch_bounds__(BFN_THREADS) void mlp_chain_bfn_kernel(BfnMulti m) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BFN_LDS_BYTES + BFN_BIAS_BYTES];
+    kernarg_warm<sizeof(BfnMulti)>();
     const int tile = (int)blockIdx.x;
     int qn = 0;
     while (qn + 1 < m.n && tile >= m.tile_start[qn + 1]) ++qn;
     const BfChain& p = m.c[qn];
-    const int row0 = (tile - m.tile_start[qn]) * (16 * RT);
+    const int row0 = (tile - m.tile_start[qn]) * BFN_TM;
     // in_mode 3 (the lazily evaluated target rows): the row count is what the arg-max launch left on the device; workgroup 0 reports it
     // to the host (ChainArgs::count_mirror of mlp_chain.h: the adaptive sizing of later steps' target launch)
     const int n_rows = p.rows_dev ? min(p.rows, *p.rows_dev) : p.rows;
     if (tile == m.tile_start[qn] && threadIdx.x == 0 && p.rows_dev != nullptr && p.count_mirror != nullptr)
         *p.count_mirror = ((unsigned long long)p.count_tag << 32) | (unsigned int)*p.rows_dev;
     if (row0 >= n_rows) return;
-    if (p.k0_steps == 1) bfn_dispatch<RT, 1>(p, m.n_blocks[qn], row0, n_rows, lds);
-    else bfn_dispatch<RT, 2>(p, m.n_blocks[qn], row0, n_rows, lds);
-}
-
-__global__ __launch_bounds__(BFN_THREADS) void mlp_chain_bfn_kernel(BfnMulti m) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[BFN_LDS_BYTES + BFN_BIAS_BYTES];
-    kernarg_warm<sizeof(BfnMulti)>();
-    bfn_entry<BFN_RT>(m, lds);
+    if (p.k0_steps == 1) bfn_dispatch<BFN_RT, 1>(p, m.n_blocks[qn], row0, n_rows, lds);
+    else bfn_dispatch<BFN_RT, 2>(p, m.n_blocks[qn], row0, n_rows, lds);
 }
 
 // (Measured and dropped in round 6: the same chain with FOUR sub-tiles per wave -- 64-row tiles, one activation buffer with a barrier
 // on either side of the epilogue's writes -- as the engine of the flagship step's big launches: 92.1 us against 70.3 for the two forward
-// passes, 45.1 against 41.8 for the backward pass; bfn_entry<BFN_RT_MAX> still compiles, nothing launches it.)
+// passes, 45.1 against 41.8 for the backward pass; bfn_dispatch<BFN_RT_MAX, ...> still compiles, nothing launches it.)
 
 }  // namespace morl

@@ -241,6 +241,8 @@ struct morl_ctx {
     const float* fresh_bf = nullptr;     // parameters the streams were split from by this step's morl_envelope_prepare (one-shot)
     const float* fresh_bft = nullptr;    // TARGET parameters whose forward stream (third region of bf_stream) that launch also made:
                                          // the lazily evaluated target rows then run on the few-row split-bf16 chain (mlp_chain_bfn.h)
+    int bfn_eager3 = 1;                  // MORL_BFN_EAGER3=0: the target pass of an eagerly evaluated few-row step as a launch of its own on the
+                                         // f32 tiles instead of a third chain of the few-row forward launch (A/B)
     long long bfn_max_rows = 4096;       // chain launches of at most this many rows (over their chains) take the few-row split-bf16 chain
                                          // (mlp_chain_bfn.h: 16-row tiles, the waves split the output features); MORL_BFN_MAX_ROWS, 0 = never
     bool bft_ready = false;              // this step: the target network's forward stream is current (set at the step's entry, dropped by its end)
@@ -461,6 +463,7 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     if (const char* e = getenv("MORL_EXACT_F32")) c->bf_mode = atoi(e) != 0 ? 0 : 1;
     if (const char* e = getenv("MORL_BFN_TARGETS")) c->bfn_targets = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BFN_MAX_ROWS")) c->bfn_max_rows = atoll(e);
+    if (const char* e = getenv("MORL_BFN_EAGER3")) c->bfn_eager3 = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BF_MIN_ROWS")) { c->bf_min_rows = atoll(e); c->bf_min_rows_env = true; }
 #undef ALLOC
     *out = c;
@@ -719,7 +722,10 @@ static int bf_tile_rows(morl_ctx* c, const BfChain* chains, int n) {
     // 4 096 rows over its chains, i.e. 128 tiles: measured per launch (profiles/r06_rank_step_bfn_ab.json) -- the two forward passes of
     // 2 048 rows each 23.8 us against 36 on the 32-row tiles of mlp_chain_bf.h, the backward pass of 4 096 rows 22.2 against 34.3, but
     // the two forward passes of 4 096 rows each 44.0 against 41.1
-    if (n <= BFN_MAX_MULTI && bfn_few(c, rows_all)) return BF_TILE_FEW;
+    if (n <= 2 && bfn_few(c, rows_all)) return BF_TILE_FEW;
+    // (three chains: the forward launch of an EAGERLY evaluated few-row step with the target network's pass riding along -- 3 x 2 048
+    // rows = 192 tiles, still one per CU)
+    if (n == 3 && c->bfn_eager3 && bfn_few(c, rows_all * 2 / 3)) return BF_TILE_FEW;
     for (int q = 0; q < n; ++q) tiles64 += (chains[q].rows + BF_TM - 1) / BF_TM;
     const bool small = tiles64 < (long long)c->num_cus;
     return small ? 32 : BF_TM;
@@ -1171,7 +1177,9 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
     const bool shard_next = c->prepare_rows >= 0 && c->prepare_weight_shard;
     c->prepare_rows = -1;
     if (bf_wanted(c, rows_next, shard_next)) {
-        const bool bft = c->bfn_targets && c->lazy_targets != 0;       // (the target rows of a lazily evaluated step: mlp_chain_bfn.h)
+        // the target network's forward stream too: for the target rows of a lazily evaluated step (MORL_BFN_TARGETS=1) or for the target
+        // pass of an eagerly evaluated few-row step, which rides in its forward launch (mlp_chain_bfn.h)
+        const bool bft = (c->bfn_targets && c->lazy_targets != 0) || (c->bfn_eager3 && bfn_few(c, 2 * rows_next));
         const BfSplitArgs bf = bf_split_args(c, params_online, bft ? params_target : nullptr);
         const int bf_blocks = (bf.unit_start[bf.n] * 64 + 255) / 256;
         hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks + sh.tiles + bf_blocks), dim3(256), 0, (hipStream_t)stream, a, blocks,
@@ -1195,12 +1203,12 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
 // bit 0: the last morl_envelope_update on this context ran its online forward passes and its dX backward pass as split-bf16
 // products (mlp_chain_bf.h); bit 1: its weight gradients too (dw_bf.h); bit 2: its lazily evaluated target rows took the large
 // f32 tiles (an earlier step had selected more than MORL_LAZY_BIG_ROWS pairs); bit 3: its target launch was sized WITHOUT the count it
-// should have read (bounded wait ran out / re-arm window); bit 4: that has happened on this context; bit 5: its lazily evaluated target
-// rows ran on the few-row split-bf16 chain (mlp_chain_bfn.h) rather than the f32 tiles; 0: everything on the f32-input MFMA
+// should have read (bounded wait ran out / re-arm window); bit 4: that has happened on this context; bit 5: its target network -- the lazily
+// evaluated rows, or the whole pass of an eagerly evaluated few-row step -- ran on the few-row split-bf16 chain (mlp_chain_bfn.h) rather than the f32 tiles; 0: everything on the f32-input MFMA
 extern "C" int morl_ctx_last_step_bf16(morl_ctx* c) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     return (c->bits_bf ? 1 : 0) | (c->dw_bf_last ? 2 : 0) | ((c->lz_last && c->lz_last_big) ? 4 : 0) |
-           ((c->lz_last && c->lz_count_missed) ? 8 : 0) | (c->lz_count_misses > 0 ? 16 : 0) | ((c->lz_last && c->lz_last_bfn) ? 32 : 0);
+           ((c->lz_last && c->lz_count_missed) ? 8 : 0) | (c->lz_count_misses > 0 ? 16 : 0) | (c->lz_last_bfn ? 32 : 0);
 }
 
 extern "C" int morl_ctx_set_exact_f32(morl_ctx* c, int enable) {
@@ -1922,6 +1930,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     static const morl_update_out no_out = {};
     if (!out) out = &no_out;
     c->lz_last = false;
+    c->lz_last_bfn = false;
     c->last_step_W = W;
     timing_begin_step(c);
 
@@ -1939,7 +1948,10 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         if ((rc = refresh_bf_step(c, params_online, params_target, s))) return rc;
         c->lz_now = c->lazy_targets && cfg->envelope && W >= 2 && !out->q_target_next && (c->lazy_targets == 2 || rows >= lazy_min_rows);
         c->lz_last = c->lz_now;
-        if (c->lz_now && !c->bft_ready && c->bfn_targets) {
+        // an eagerly evaluated FEW-ROW step (a rank's share of a sharded job, small batches): the target network's pass rides in the
+        // forward launch as a third few-row chain instead of a launch of its own on the f32 tiles
+        const bool few_eager = !c->lz_now && c->bfn_eager3 && bfn_few(c, 2ll * rows) && cfg->slab_parts <= 1;
+        if (((c->lz_now && c->bfn_targets) || few_eager) && !c->bft_ready) {
             // (a caller that did not come through morl_envelope_prepare: the target network's forward stream for the few-row chain)
             const BfSplitArgs a = bf_split_args(c, nullptr, params_target);
             hipLaunchKernelGGL(bf_split_kernel, dim3((a.unit_start[a.n] * 64 + 255) / 256), dim3(256), 0, s, a, c->bf_stream);
@@ -1967,9 +1979,16 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
                 amax_args = lazy_argmax_args(c, p1);
                 fwd[0].amax = 1;
             }
-            if ((rc = bf_launch(c, fwd, 2, MORL_TIMED_FORWARD2, s, fuse ? &amax_args : nullptr))) { c->lz_now = false; return rc; }
-            c->lz_argmax_done = fuse;
-            if (!c->lz_now && (rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
+            if (few_eager) {
+                const BfChain three[3] = {two[0], two[1], bf_forward_chain(c, params_target, next_obs, weights, B, W, rows, false, c->qt, AR, true)};
+                c->bft_ready = false;
+                c->lz_last_bfn = true;          // (bit 5 of morl_ctx_last_step_bf16: the target network ran on the few-row split-bf16 chain)
+                if ((rc = bf_launch(c, three, 3, MORL_TIMED_FORWARD, s))) return rc;
+            } else {
+                if ((rc = bf_launch(c, fwd, 2, MORL_TIMED_FORWARD2, s, fuse ? &amax_args : nullptr))) { c->lz_now = false; return rc; }
+                c->lz_argmax_done = fuse;
+                if (!c->lz_now && (rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
+            }
         }
         main_done = true;
         c->bits_valid = true;

@@ -85,6 +85,18 @@ def test_large_tile_split_bf16_chain_passes_the_same_parity_tests():
     assert " passed" in r.stdout
 
 
+def test_eager_few_row_step_with_its_target_pass_on_the_f32_tiles():
+    """An eagerly evaluated few-row step runs the target network's pass as a third chain of its few-row forward launch (bit 5 of
+    ``morl_ctx_last_step_bf16``); MORL_BFN_EAGER3=0 keeps that pass on the f32 tiles as a launch of its own -- the same fixture
+    assertions on that leg (eager and lazy then agree bit for bit again on the emulator, which the test asserts by itself)."""
+    env = dict(os.environ, MORL_BFN_EAGER3="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_parity.py"), "-x", "-q", "-m", "not gpu",
+                        "-k", "(flagship_b32w8 or wide_pick) and (reference_golden or lazy_target_evaluation)", "-p",
+                        "no:cacheprovider"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_target_rows_on_the_few_row_split_bf16_chain_pass_the_same_parity_tests():
     """The lazily evaluated target rows of a bf16 step run on the 8-row f32 tiles of mlp_chain4.h; MORL_BFN_TARGETS=1 puts them on the
     few-row split-bf16 chain (csrc/mlp_chain_bfn.h, in_mode 3: pair list, device-side row count, count mirror) -- measured slower on

@@ -535,11 +535,13 @@ def test_lazy_target_evaluation_equals_the_eager_one(be, c):
     # (mlp_chain_bfn.h, bit 5 of last_step_bf16) -- six split products like its online passes, fp32-class, not the eager slab's bits
     bits = ctx_rows[("bits", "lazy")]
     on_bfn = bool(bits & 32)
+    # (... or the EAGER step's target pass: a few-row step evaluates it as a third chain of its few-row forward launch)
+    eager_on_bfn = bool(ctx_rows[("bits", True)] & 32)
     if (bits & 1) and ctx_rows["lazy"] > 0 and os.environ.get("MORL_BFN_TARGETS") == "1":
         assert on_bfn, bits                                            # (asked for: tests/test_chain_tilings.py)
     if os.environ.get("MORL_BFN_TARGETS", "0") == "0" or os.environ.get("MORL_EXACT_F32") == "1":
         assert not on_bfn, bits
-    exact = is_sim and os.environ.get("MORL_CHAIN16") != "0" and not on_bfn
+    exact = is_sim and os.environ.get("MORL_CHAIN16") != "0" and not on_bfn and not eager_on_bfn
     for k in ("target", "pref", "ac", "priority", "q_values", "q_online_next"):
         if exact:
             assert th.equal(eager[k].cpu(), lazy[k].cpu()), k

@@ -4,11 +4,15 @@
 #   tools/rank_step_ab.sh OUTDIR
 out=$1; mkdir -p "$out"
 B="--no-cpu-baseline --no-ramp-record --no-sustained-record --no-exact-record --steps 100 --warmup 20"
-for n in 8 4 2; do for ax in batch weights; do for leg in r5 bfn; do
-  if [ $leg = r5 ]; then export MORL_BFN_MAX_ROWS=0; else unset MORL_BFN_MAX_ROWS; fi
+# legs: r5 = the round-5 engines; bfn2 = the few-row chain for the two online passes and the backward pass, the target pass of an eager step on
+# the f32 tiles (MORL_BFN_EAGER3=0); bfn = the default (the target pass rides as a third few-row chain)
+for n in 8 4 2; do for ax in batch weights; do for leg in r5 bfn2 bfn; do
+  unset MORL_BFN_MAX_ROWS MORL_BFN_EAGER3
+  if [ $leg = r5 ]; then export MORL_BFN_MAX_ROWS=0; fi
+  if [ $leg = bfn2 ]; then export MORL_BFN_EAGER3=0; fi
   timeout 200 python bench.py --gpus 1 --force-shard --emulate-world $n --shard-axis $ax $B > "$out/emu${n}_${ax}_$leg.json" 2> "$out/emu${n}_${ax}_$leg.err"
 done; done; done
-unset MORL_BFN_MAX_ROWS
+unset MORL_BFN_MAX_ROWS MORL_BFN_EAGER3
 python - "$out" <<'PY'
 import glob, json, os, sys
 res = {}
