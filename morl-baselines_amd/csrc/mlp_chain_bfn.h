@@ -3,16 +3,15 @@
 // share of a rank of an 8-rank job -- where mlp_chain_bf.h's 64-row tiles leave most of the chip idle and every tile is one wave's
 // serial chain per SIMD.
 //
-//   * tile = 32 rows (two 16-row sub-tiles), workgroup = 4 waves: the waves split the OUTPUT FEATURES of every wide (256-column) step,
-//     64 each (feature tiles 4 w .. 4 w + 3), and carry BOTH sub-tiles: every weight fragment a wave fetches feeds two MFMAs.  What
-//     sets the tile size is bytes, not the matrix pipe: a tile streams the whole network (1.27 MB of split weights) through one CU --
-//     64 B/clk, ~9.5 us -- and all tiles of a launch together through the L2 (measured with 16-row tiles: 256 tiles x 1.27 MB in
-//     19 us = 17 TB/s, the chip's L2 rate: profiles/r06_rank_step_bfn_ab.json); 32 rows halve the tiles, i.e. the L2 bytes, at the
-//     same per-CU time, and a 256 x 256 step is then 384 MFMAs per wave (6 144 matrix-pipe cycles, 2.6 us: under the stream);
+//   * tile = 16 or 32 rows, workgroup = 4 waves: the waves split the OUTPUT FEATURES of every wide (256-column) step, 64 each (feature
+//     tiles 4 w .. 4 w + 3) -- a 256 x 256 step is 192 MFMAs per wave and 16 rows instead of 768 on one wave (mlp_chain_bf.h with a 16-row
+//     tile).  What sets the tile size is bytes, not the matrix pipe: a tile streams the whole network (1.27 MB of split weights) through
+//     one CU -- ~115 GB/s with every CU pulling, 11 us -- so a launch takes 16-row tiles while that is at most a tile per CU (more CUs
+//     pull) and 32-row tiles beyond (two sub-tiles per wave: every fetched fragment feeds two MFMAs, half the tiles, half the L2 bytes);
 //   * weights straight from L2 into REGISTERS: a wave reads only its own 64 features' fragments (a quarter of the stream, no sharing
 //     between the waves, so nothing to stage in LDS, no barrier in the stream): the 12 fragment blocks of a k-step (4 tiles x 3 split
 //     parts, 12 KB contiguous in bf_split_kernel's order) as 12 coalesced 16-byte buffer loads, two k-steps resident (the one
-//     being multiplied and one in flight: 768 matrix-pipe cycles of cover), the stream running ahead ACROSS layer boundaries
+//     being multiplied and one in flight), the stream running ahead ACROSS layer boundaries
 //     (addresses do not depend on data; beyond the last block the descriptor's range check returns zeros: no branch in the stream);
 //   * activations exchanged through LDS once per layer: a wave's outputs ARE k-steps 2 w, 2 w + 1 of the next step's B operand in
 //     mlp_chain_bf.h's slot order (slot (q, e) <-> feature 32 s + 16 (e >> 2) + 4 q + (e & 3)): epilogue (bias as the accumulator's
@@ -28,7 +27,10 @@
 
 namespace morl {
 
-constexpr int BFN_RT = 2;                                    // 16-row sub-tiles a wave carries in the few-row form (32-row tiles)
+#ifndef BFN_PIN_
+#define BFN_PIN_ 1
+#endif
+constexpr int BFN_RT = 2;                                    // 16-row sub-tiles a wave carries: 1 or 2 (mlp_chain_bfn16_kernel / mlp_chain_bfn_kernel)
 constexpr int BFN_RT_MAX = 4;                                // ... and in the 64-row form (measured and dropped: see the end of this file)
 #ifndef BFN_DEPTH_
 #define BFN_DEPTH_ 2
@@ -44,7 +46,6 @@ constexpr int BFN_XBUF_BYTES = BFN_XBLOCKS * BF_BLOCK;
 // activations in LDS: two layers' worth of both sub-tiles, alternating (32-row tiles: one barrier per layer), or ONE layer's worth of
 // four sub-tiles (64-row tiles: a barrier in front of the epilogue's writes and one behind them) -- 96 KB either way
 constexpr int BFN_LDS_BYTES = 2 * BFN_RT * BFN_XBUF_BYTES;
-static_assert(BFN_RT_MAX * BFN_XBUF_BYTES <= BFN_LDS_BYTES, "the 64-row form's single buffer fits the same allocation");
 constexpr int BFN_BIAS_BYTES = BF_MAX_STEPS * BF_WIDE * 4;   // every step's bias, [step][256] floats (zeros beyond a step's columns)
 constexpr int BFN_MAX_MULTI = 3;                             // (the three forward passes of an eagerly evaluated few-row step)
 
@@ -128,12 +129,12 @@ __device__ __forceinline__ void bfn_products(f32x4 (&acc)[RT][4], bf_u32x4 (&wr)
         }
         // the slot's refill goes out HERE, behind its k-step's last product and in front of the next k-step's first: left to the
         // scheduler it drifted a k-step down the unrolled loop (one group of look-ahead instead of two)
-        BF_PIN();
+        if (BFN_PIN_) BF_PIN();
         const int off = bfn_next_offset(cur);
         if (slot == 0) bfn_issue<0>(wr, rsrc, voff, off);
         else if (slot == 1) bfn_issue<1>(wr, rsrc, voff, off);
         else bfn_issue<(BFN_DEPTH > 2 ? 2 : 0)>(wr, rsrc, voff, off);
-        BF_PIN();
+        if (BFN_PIN_) BF_PIN();
     }
 }
 
@@ -206,7 +207,7 @@ __device__ __forceinline__ void bfn_chain_body(const BfChain& p, int n_blocks, i
     cur.head0 = (cur.g_wide * 48 + 3 * wave) * BF_BLOCK;
     cur.head_stride = head_tiles * 3 * BF_BLOCK;
     cur.beyond = n_blocks * BF_BLOCK;
-    float* bias_lds = reinterpret_cast<float*>(lds + BFN_LDS_BYTES);
+    float* bias_lds = reinterpret_cast<float*>(lds + 2 * RT * BFN_XBUF_BYTES);
     float bv[BF_MAX_STEPS];
 #pragma unroll
     for (int st = 0; st < BF_MAX_STEPS; ++st) {
@@ -286,7 +287,7 @@ __device__ __forceinline__ void bfn_chain_body(const BfChain& p, int n_blocks, i
     BFN_BARRIER();
     int phase = K0S % BFN_DEPTH;
     // ---- the 256 x 256 steps --------------------------------------------------------------------------------------------------------
-    constexpr bool DB = RT <= BFN_RT;       // two alternating activation buffers, or one with a barrier on either side of the writes
+    constexpr bool DB = RT <= 2;       // two alternating activation buffers, or one with a barrier on either side of the writes
     for (int s = 1; s < n_wide; ++s) {
         const unsigned char* xin = lds + (DB ? ((s - 1) & 1) * RT * BFN_XBUF_BYTES : 0);
         unsigned char* xout = lds + (DB ? (s & 1) * RT * BFN_XBUF_BYTES : 0);
@@ -346,24 +347,34 @@ __device__ __forceinline__ void bfn_dispatch(const BfChain& p, int n_blocks, int
     else bfn_chain_body<RT, K0S, 0>(p, n_blocks, row0, n_rows, lds);
 }
 
-// grid: one workgroup per 32-row tile over the launch's chains.  (The tile -> chain walk stands IN the kernel: handed on as a reference
-// through a helper, the argument block was re-read per use -- a constant ~4 us per launch.)
-__global__ __launch_bounds__(BFN_THREADS) void mlp_chain_bfn_kernel(BfnMulti m) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[BFN_LDS_BYTES + BFN_BIAS_BYTES];
-    kernarg_warm<sizeof(BfnMulti)>();
+// grid: one workgroup per (16 RT)-row tile over the launch's chains.  Two instantiations: 16-row tiles (RT = 1) while the launch has at most
+// a tile per CU that way (more CUs pull the stream: the backward pass of 2 048 rows 19.6 us against 24.2), 32-row tiles (RT = 2) beyond
+// (the three forward passes of an eager step of 2 048 rows: 192 tiles, 29.8 us against 31.5 on 384 16-row tiles).
+template <int RT>
+__device__ __forceinline__ void bfn_kernel_body(const BfnMulti& m, unsigned char* lds) {
     const int tile = (int)blockIdx.x;
     int qn = 0;
     while (qn + 1 < m.n && tile >= m.tile_start[qn + 1]) ++qn;
     const BfChain& p = m.c[qn];
-    const int row0 = (tile - m.tile_start[qn]) * BFN_TM;
+    const int row0 = (tile - m.tile_start[qn]) * (16 * RT);
     // in_mode 3 (the lazily evaluated target rows): the row count is what the arg-max launch left on the device; workgroup 0 reports it
     // to the host (ChainArgs::count_mirror of mlp_chain.h: the adaptive sizing of later steps' target launch)
     const int n_rows = p.rows_dev ? min(p.rows, *p.rows_dev) : p.rows;
     if (tile == m.tile_start[qn] && threadIdx.x == 0 && p.rows_dev != nullptr && p.count_mirror != nullptr)
         *p.count_mirror = ((unsigned long long)p.count_tag << 32) | (unsigned int)*p.rows_dev;
     if (row0 >= n_rows) return;
-    if (p.k0_steps == 1) bfn_dispatch<BFN_RT, 1>(p, m.n_blocks[qn], row0, n_rows, lds);
-    else bfn_dispatch<BFN_RT, 2>(p, m.n_blocks[qn], row0, n_rows, lds);
+    if (p.k0_steps == 1) bfn_dispatch<RT, 1>(p, m.n_blocks[qn], row0, n_rows, lds);
+    else bfn_dispatch<RT, 2>(p, m.n_blocks[qn], row0, n_rows, lds);
+}
+__global__ __launch_bounds__(BFN_THREADS) void mlp_chain_bfn_kernel(BfnMulti m) {            // 32-row tiles
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * BFN_XBUF_BYTES + BFN_BIAS_BYTES];
+    kernarg_warm<sizeof(BfnMulti)>();
+    bfn_kernel_body<2>(m, lds);
+}
+__global__ __launch_bounds__(BFN_THREADS) void mlp_chain_bfn16_kernel(BfnMulti m) {          // 16-row tiles
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 1 * BFN_XBUF_BYTES + BFN_BIAS_BYTES];
+    kernarg_warm<sizeof(BfnMulti)>();
+    bfn_kernel_body<1>(m, lds);
 }
 
 // (Measured and dropped in round 6: the same chain with FOUR sub-tiles per wave -- 64-row tiles, one activation buffer with a barrier

@@ -735,7 +735,10 @@ static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStr
                      const BfTdArgs* tdb = nullptr) {
     const int tm = bf_tile_rows(c, chains, n);
     if (tm == BF_TILE_FEW) {
-        const int trows = BFN_TM;
+        // 16-row tiles while that is at most a tile per CU, 32-row tiles beyond (mlp_chain_bfn.h)
+        long long tiles16 = 0;
+        for (int q = 0; q < n; ++q) tiles16 += (chains[q].rows + 15) / 16;
+        const int trows = tiles16 <= (long long)c->num_cus ? 16 : BFN_TM;
         if (td || tdb) return fail(MORL_ERR_STATE, "internal: the few-row chain takes no in-chain arg-max / TD stage");
         BfnMulti f{};
         f.n = n;
@@ -752,7 +755,8 @@ static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStr
         for (int q = n; q <= BFN_MAX_MULTI; ++q) f.tile_start[q] = tiles;
         int slot = -1, rc;
         if ((rc = timing_open(c, kind, s, &slot))) return rc;
-        hipLaunchKernelGGL(mlp_chain_bfn_kernel, dim3(tiles), dim3(BFN_THREADS), 0, s, f);
+        if (trows == 16) hipLaunchKernelGGL(mlp_chain_bfn16_kernel, dim3(tiles), dim3(BFN_THREADS), 0, s, f);
+        else hipLaunchKernelGGL(mlp_chain_bfn_kernel, dim3(tiles), dim3(BFN_THREADS), 0, s, f);
         LAUNCH_CHECK("mlp_chain_bfn");
         return timing_close(c, slot, s);
     }
