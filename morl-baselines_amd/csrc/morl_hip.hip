@@ -249,7 +249,7 @@ struct morl_ctx {
     int bfn_targets = 0;                 // MORL_BFN_TARGETS=1: the lazily evaluated target rows on the few-row split-bf16 chain instead of
                                          // the 8-row f32 tiles (mlp_chain4.h).  Measured and NOT the default: a tile streams the whole network
                                          // through ONE CU's 64 B/clk vector-memory path, and the split stream is 1.5 x the fp32 bytes --
-                                         // 22.7 us against 18.2 at the flagship shape (profiles/r06_target_rows_ab.json)
+                                         // 20.6 us against 18.5 at the flagship shape (profiles/r06_target_rows_ab.json)
     bool dw_bf_last = false;             // the last step's weight gradients ran on dw_bf.h
     bool bits_bf = false;                // the last training forward left its sign bits in mlp_chain_bf.h's lane layout
     const unsigned int* skip_flag = nullptr;   // one-shot: the next clip + Adam launch leaves the optimiser state alone if this
@@ -1509,9 +1509,12 @@ static int lazy_phase1(morl_ctx* c, const EnvelopeTdArgs& p, int td_waves, hipSt
         }
         m.n = 1;
         m.tile_start[0] = 0;
-        m.tile_start[1] = m.tile_start[2] = (a.rows + BFN_TM - 1) / BFN_TM;
+        // (16-row tiles: the grid is sized for the worst case -- every TD row its own pair --, the tiles beyond the count exit at once;
+        // the rows a step really selects, 1 200 - 3 200, are at most a tile per CU that way)
+        m.tile_start[1] = m.tile_start[2] = (a.rows + 15) / 16;
+        for (int q = 2; q <= BFN_MAX_MULTI; ++q) m.tile_start[q] = m.tile_start[1];
         m.n_blocks[0] = c->bf_fwd_blocks;
-        hipLaunchKernelGGL(mlp_chain_bfn_kernel, dim3(m.tile_start[1]), dim3(BFN_THREADS), 0, s, m);
+        hipLaunchKernelGGL(mlp_chain_bfn16_kernel, dim3(m.tile_start[1]), dim3(BFN_THREADS), 0, s, m);
         LAUNCH_CHECK("mlp_chain_bfn(lazy targets)");
     } else if (c->lz_last_big) {
         Chain2Multi m{};
