@@ -178,6 +178,7 @@ struct morl_ctx {
     unsigned long long* relu_bits[MORL_MAX_LAYERS] = {};  // [l]: (h[l] > 0) packed by the 64-row forward tiling
     bool bits_valid = false;                               // written by the last training forward
     float* zeros = nullptr;  // 16 zero floats: target of the invalid elements of the chain's operand gathers
+    unsigned char* per_scratch = nullptr;   // ST_SCRATCH_BYTES: part 1 -> part 2 of a PER tree update split over two launches
     // optional per-launch timing of the dominant kernel (mlp_chain): HIP event pairs on the caller's stream
     bool timing = false;                 // chain launches of the current step are bracketed by events
     int timing_every = 0;                // 0 = off, n = every n-th Envelope step is timed (event records cost ~4 us of stream
@@ -315,6 +316,7 @@ extern "C" int morl_ctx_destroy(morl_ctx* c) {
     for (int l = 0; l < MORL_MAX_LAYERS; ++l)
         if (c->relu_bits[l]) (void)hipFree(c->relu_bits[l]);
     if (c->zeros) (void)hipFree(c->zeros);
+    if (c->per_scratch) (void)hipFree(c->per_scratch);
     if (c->cu_tickets) (void)hipFree(c->cu_tickets);
     if (c->wt_online) (void)hipFree(c->wt_online);
     if (c->wt_target) (void)hipFree(c->wt_target);
@@ -417,6 +419,7 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     }
     for (int l = 1; l < c->L; ++l) ALLOC(relu_bits[l], ((size_t)c->max_rows + 63) / 64 * CH_THREADS);
     ALLOC(zeros, 16);
+    ALLOC(per_scratch, ST_SCRATCH_BYTES);
     ALLOC(lz_best, rows);
     ALLOC(lz_slot, rows);
     ALLOC(lz_pairs, rows);
@@ -1861,17 +1864,48 @@ static int update_core(morl_ctx* c, const float* params_online, float* grads, co
 // are complete only after the all-reduce, so the update cannot ride in the weight-gradient launch as it does on one GPU;
 // its 17 us of serial tree levels run beside Adam's 7 instead of behind them)
 // (ST_THREADS = 1024 work-items per workgroup: the tree update walks its levels one wave per level)
+// the sum of squares of the (all-reduced) gradient with part 1 of the step's PER tree update as one extra workgroup
+static __global__ __launch_bounds__(OPT_THREADS) void grad_sumsq_per_kernel(const float* __restrict__ grads, long long P,
+                                                                     double* __restrict__ sumsq_part, SumTreeUpdate per,
+                                                                     void* __restrict__ per_scratch,
+                                                                     const unsigned int* __restrict__ skip_flag) {
+    __shared__ __attribute__((aligned(8))) unsigned char lds[ST_LDS_BYTES];
+    if (blockIdx.x + 1 == gridDim.x) {
+        if (skip_flag != nullptr && *skip_flag != 0u) return;     // (the summed priorities are garbage: see clip_adam_body)
+        sumtree_update_part1(per, lds, per_scratch);
+        return;
+    }
+    double ss = 0.0;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)(gridDim.x - 1) * blockDim.x) {
+        const float g = grads[p];
+        ss += (double)g * (double)g;
+    }
+    // (the partial of a block in grad_reduce_kernel's order: lanes, then waves)
+    double* s_red = reinterpret_cast<double*>(lds);
+    ss = wave_sum(ss);
+    if (lane_id() == 0) s_red[wave_id()] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < OPT_THREADS / 64; ++w) t += s_red[w];
+        sumsq_part[blockIdx.x] = t;
+    }
+}
+
 static __global__ __launch_bounds__(ST_THREADS) void clip_adam_per_kernel(float* __restrict__ params, float* __restrict__ grads,
                                                                     float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                                                     long long P, const double* __restrict__ sumsq_part,
                                                                     int n_part, float max_norm, float one_minus_b1, float b2,
                                                                     float one_minus_b2, float neg_step_size, float bc2_sqrt,
                                                                     float eps, int apply_step, float* __restrict__ grad_norm_out,
-                                                                    SumTreeUpdate per, const unsigned int* __restrict__ skip_flag) {
+                                                                    SumTreeUpdate per, const void* __restrict__ per_scratch,
+                                                                    const unsigned int* __restrict__ skip_flag) {
     __shared__ __attribute__((aligned(8))) unsigned char lds[ST_LDS_BYTES];
     if (blockIdx.x + 1 == gridDim.x) {
         if (skip_flag != nullptr && *skip_flag != 0u) return;     // (the summed priorities are garbage too: see clip_adam_body)
-        sumtree_update_body(per, lds);
+        // (per_scratch: part 1 ran as the extra workgroup of the launch in front -- grad_sumsq_per_kernel --, this is part 2)
+        if (per_scratch != nullptr) sumtree_update_part2(per, lds, per_scratch);
+        else sumtree_update_body(per, lds);
         return;
     }
     clip_adam_body(params, grads, exp_avg, exp_avg_sq, P, sumsq_part, n_part, max_norm, one_minus_b1, b2, one_minus_b2,
@@ -1887,7 +1921,14 @@ static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_a
     const unsigned int* skip_flag = c->skip_flag;    // one-shot request of a sharded step (set right before this call)
     c->skip_flag = nullptr;
     const int nblk = std::min(OPT_MAX_BLOCKS, stream_grid(c->P, OPT_THREADS));
-    if (!have_partials) {
+    // the PER tree update of a sharded step over BOTH launches that follow the all-reduce (replay_kernels.h: sumtree_update_part1 / 2)
+    static const bool per_split_env = [] { const char* e = getenv("MORL_PER_SPLIT"); return e ? atoi(e) != 0 : true; }();   // (A/B)
+    const bool per_split = per != nullptr && !have_partials && per_split_env && c->per_scratch != nullptr;
+    if (per_split) {
+        hipLaunchKernelGGL(grad_sumsq_per_kernel, dim3(nblk + 1), dim3(OPT_THREADS), 0, s, (const float*)grads, (long long)c->P, c->sumsq_part,
+                           *per, c->per_scratch, skip_flag);
+        LAUNCH_CHECK("grad_sumsq_per");
+    } else if (!have_partials) {
         hipLaunchKernelGGL(grad_reduce_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, (const float*)grads, 1, (long long)c->P,
                            grads, (long long)c->P, c->sumsq_part, (const double*)nullptr, 0, 0.0, 0.0, 0.f, (float*)nullptr);
         LAUNCH_CHECK("grad_sumsq");
@@ -1902,7 +1943,7 @@ static int clip_adam_step(morl_ctx* c, float* params, float* grads, float* exp_a
         hipLaunchKernelGGL(clip_adam_per_kernel, dim3(stream_grid(c->P, ST_THREADS) + 1), dim3(ST_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq,
                            (long long)c->P, (const double*)c->sumsq_part, nblk, cfg->max_grad_norm, (float)(1.0 - b1), (float)b2,
                            (float)(1.0 - b2), (float)(-step_size), (float)bc2_sqrt, (float)cfg->eps, cfg->apply_step,
-                           grad_norm_out, *per, skip_flag);
+                           grad_norm_out, *per, per_split ? (const void*)c->per_scratch : (const void*)nullptr, skip_flag);
     else
         hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq,
                            (long long)c->P, (const double*)c->sumsq_part, nblk, cfg->max_grad_norm, (float)(1.0 - b1), (float)b2,

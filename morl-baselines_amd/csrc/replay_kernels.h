@@ -226,7 +226,8 @@ struct SumTreeUpdate {
 // The update as a workgroup-level routine (any block size that is a multiple of 64; `lds` = ST_LDS_BYTES of scratch, 8-byte
 // aligned), so that it can run as its own launch or ride as an extra workgroup of another kernel of the step
 // (dw_tiles_kernel: the tree update only depends on the TD priorities and nothing of the backward pass depends on it).
-__device__ __forceinline__ void sumtree_update_body(const SumTreeUpdate& a, void* lds) {
+// part 1: priorities, running maximum, sort, leaf differences -- leaves s_diff / s_node in LDS (see the offsets below), synchronised
+__device__ __forceinline__ void sumtree_prepare(const SumTreeUpdate& a, void* lds) {
     long long* s_key = reinterpret_cast<long long*>(lds);   // (index << 11) | position -> ascending index, first position first
     double* s_diff = reinterpret_cast<double*>(s_key + ST_MAX_B);
     long long* s_node = reinterpret_cast<long long*>(s_diff + ST_MAX_B);
@@ -281,35 +282,90 @@ __device__ __forceinline__ void sumtree_update_body(const SumTreeUpdate& a, void
         s_diff[k] = first ? __dsub_rn((double)s_pr[(int)(s_key[k] & 2047)], tree[level_off(leaf_level) + id]) : 0.0;
     }
     __syncthreads();
-    // per level: the head of each run of equal ancestors adds that run's diffs in order (the np.add.at order).  Levels
-    // touch disjoint memory, so each wave takes its own levels and they proceed concurrently; the critical path is the
-    // root's single run of B sequential float64 adds, whose LDS reads do not depend on the running sum and pipeline.
-    const int lane = lane_id(), wave = wave_id(), n_waves = nt / 64;
-    for (int up = wave; up < n_levels; up += n_waves) {
-        const int l = leaf_level - up;
-        for (int k = lane; k < B; k += 64) {
-            const long long anc = s_node[k] >> up;
-            const bool head = (k == 0) || ((s_node[k - 1] >> up) != anc);
-            if (!head) continue;
-            int lo = k + 1, hi = B;                            // first index whose ancestor differs (binary search)
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if ((s_node[mid] >> up) == anc) lo = mid + 1; else hi = mid;
-            }
-            const int end = lo;
-            double acc = tree[level_off(l) + anc];
-            int e = k;
-            for (; e + 8 <= end; e += 8) {
-                double d[8];
+}
+
+// part 2: per level, the head of each run of equal ancestors adds that run's diffs in order (the np.add.at order).  Levels
+// touch disjoint memory, so each wave takes its own levels and they proceed concurrently; the critical path is the
+// root's single run of B sequential float64 adds, whose LDS reads do not depend on the running sum and pipeline.
+__device__ __forceinline__ void sumtree_levels(const SumTreeUpdate& a, const void* lds) {
+    const double* s_diff = reinterpret_cast<const double*>(reinterpret_cast<const long long*>(lds) + ST_MAX_B);
+    const long long* s_node = reinterpret_cast<const long long*>(s_diff + ST_MAX_B);
+    double* __restrict__ tree = a.tree;
+    const int n_levels = a.n_levels, B = a.B, leaf_level = n_levels - 1;
+    const int nt = (int)blockDim.x;
+    // (round 6: the (level, entry) pairs spread over ALL work-items, the root's level first -- one wave per level put the 256 run heads of
+    // the leaf level through 64 lanes four at a time, each a dependent global load -> add -> store, and gave two waves two levels: 12 us of
+    // the sharded step's clip + Adam launch.  A run is still summed by ONE work-item in entry order: the tree stays bit-exact.)
+    // Four pairs per work-item at a time: run boundaries of all four first (LDS), then their four tree loads back to back, then the adds
+    // and stores -- one global round trip per batch instead of one per run head.
+    const int tid = (int)threadIdx.x, items = n_levels * B;
+    constexpr int NB = 4;
+    for (int it0 = tid; it0 < items; it0 += NB * nt) {
+        bool head[NB];
+        int beg[NB], end[NB];
+        long long addr[NB];
+        double acc[NB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) d[u] = s_diff[e + u];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc = __dadd_rn(acc, d[u]);
+        for (int j = 0; j < NB; ++j) {
+            const int it = it0 + j * nt;
+            head[j] = false; beg[j] = 0; end[j] = 0; addr[j] = 0;
+            if (it < items) {
+                const int up = n_levels - 1 - it / B, k = it % B;
+                const long long anc = s_node[k] >> up;
+                head[j] = (k == 0) || ((s_node[k - 1] >> up) != anc);
+                if (head[j]) {
+                    int lo = k + 1, hi = B;                        // first index whose ancestor differs (binary search)
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if ((s_node[mid] >> up) == anc) lo = mid + 1; else hi = mid;
+                    }
+                    beg[j] = k; end[j] = lo;
+                    addr[j] = level_off(leaf_level - up) + anc;
+                }
             }
-            for (; e < end; ++e) acc = __dadd_rn(acc, s_diff[e]);
-            tree[level_off(l) + anc] = acc;
         }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = head[j] ? tree[addr[j]] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (head[j]) {
+                double x = acc[j];
+                int e = beg[j];
+                for (; e + 8 <= end[j]; e += 8) {
+                    double d[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) d[u] = s_diff[e + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x = __dadd_rn(x, d[u]);
+                }
+                for (; e < end[j]; ++e) x = __dadd_rn(x, s_diff[e]);
+                tree[addr[j]] = x;
+            }
     }
+}
+
+__device__ __forceinline__ void sumtree_update_body(const SumTreeUpdate& a, void* lds) {
+    sumtree_prepare(a, lds);
+    sumtree_levels(a, lds);
+}
+
+// The same update split over TWO launches (the sharded Envelope step: the priorities are complete only behind the all-reduce, where two
+// short launches follow -- the sum of squares of the reduced gradient, clip + Adam -- and one workgroup carrying all 17 us of the update
+// made the second of them 17 us long): part 1 as an extra workgroup of the first launch, its result (ST_MAX_B differences + node ids,
+// 16 KB) through device memory, part 2 as an extra workgroup of the second.  Same arithmetic in the same order: the tree stays bit-exact.
+constexpr int ST_SCRATCH_BYTES = 2 * ST_MAX_B * 8;
+__device__ __forceinline__ void sumtree_update_part1(const SumTreeUpdate& a, void* lds, void* scratch) {
+    sumtree_prepare(a, lds);
+    const long long* src = reinterpret_cast<const long long*>(lds) + ST_MAX_B;        // s_diff then s_node: 2 * ST_MAX_B eight-byte words
+    long long* dst = reinterpret_cast<long long*>(scratch);
+    for (int e = (int)threadIdx.x; e < 2 * ST_MAX_B; e += (int)blockDim.x) dst[e] = src[e];
+}
+__device__ __forceinline__ void sumtree_update_part2(const SumTreeUpdate& a, void* lds, const void* scratch) {
+    long long* dst = reinterpret_cast<long long*>(lds) + ST_MAX_B;
+    const long long* src = reinterpret_cast<const long long*>(scratch);
+    for (int e = (int)threadIdx.x; e < 2 * ST_MAX_B; e += (int)blockDim.x) dst[e] = src[e];
+    __syncthreads();
+    sumtree_levels(a, lds);
 }
 
 __global__ __launch_bounds__(ST_THREADS) void sumtree_update_kernel(SumTreeUpdate a) {
