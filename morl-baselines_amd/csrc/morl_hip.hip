@@ -27,6 +27,7 @@
 #include "dw_tiles.h"
 #include "dw_bf.h"
 #include "mlp_chain_bfn.h"
+#include "mlp_chain_bf2.h"
 #include "optim_kernels.h"
 #include "replay_kernels.h"
 #include "pareto_kernels.h"
@@ -213,6 +214,7 @@ struct morl_ctx {
     double host_wait_s = 0.0;                      // host time spent waiting for a count (the device more than LZ_LAG steps behind):
                                                    // back-pressure, not host work (morl_ctx_backpressure_seconds)
     int lz_last_big = 0;                           // what the last lazily evaluated step launched
+    bool last_dual = false;                        // the step's two online forward passes ran as tile pairs (mlp_chain_bf2.h)
     bool lz_last_bfn = false;                      // ... its target rows ran on the few-row split-bf16 chain (mlp_chain_bfn.h)
     bool lz_count_missed = false;                  // the last lazily evaluated step could not read the count it is sized by (bounded
                                                    // wait ran out, or inside the re-arm window after one): it took the small tiles
@@ -242,6 +244,8 @@ struct morl_ctx {
     const float* fresh_bf = nullptr;     // parameters the streams were split from by this step's morl_envelope_prepare (one-shot)
     const float* fresh_bft = nullptr;    // TARGET parameters whose forward stream (third region of bf_stream) that launch also made:
                                          // the lazily evaluated target rows then run on the few-row split-bf16 chain (mlp_chain_bfn.h)
+    int bf_dual = 0;                     // MORL_BF_DUAL=1: the two online forward passes as tile pairs sharing the weight fragments (mlp_chain_bf2.h)
+    int bf_dual_min_tiles = 0;           // MORL_BF_DUAL_MIN_TILES: ... from this many tile pairs on
     int bfn_eager3 = 1;                  // MORL_BFN_EAGER3=0: the target pass of an eagerly evaluated few-row step as a launch of its own on the
                                          // f32 tiles instead of a third chain of the few-row forward launch (A/B)
     long long bfn_max_rows = 4096;       // chain launches of at most this many rows (over their chains) take the few-row split-bf16 chain
@@ -466,6 +470,8 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     if (const char* e = getenv("MORL_EXACT_F32")) c->bf_mode = atoi(e) != 0 ? 0 : 1;
     if (const char* e = getenv("MORL_BFN_TARGETS")) c->bfn_targets = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BFN_MAX_ROWS")) c->bfn_max_rows = atoll(e);
+    if (const char* e = getenv("MORL_BF_DUAL")) c->bf_dual = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("MORL_BF_DUAL_MIN_TILES")) c->bf_dual_min_tiles = atoi(e);
     if (const char* e = getenv("MORL_BFN_EAGER3")) c->bfn_eager3 = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BF_MIN_ROWS")) { c->bf_min_rows = atoll(e); c->bf_min_rows_env = true; }
 #undef ALLOC
@@ -790,7 +796,17 @@ static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStr
 #endif
     int slot = -1, rc;
     if ((rc = timing_open(c, kind, s, &slot))) return rc;
-    if (small) hipLaunchKernelGGL(mlp_chain_bf32_kernel, dim3(tiles), dim3(128), 0, s, m);
+    // the two online passes of a step as pairs of tiles sharing every weight fragment (mlp_chain_bf2.h): a no-grad chain and a training
+    // chain over the same stream, the same number of rows, observation-and-weight input rows both
+    const bool dual = c->bf_dual && !small && n == 2 && !tdb && chains[0].stream == chains[1].stream && chains[0].rows == chains[1].rows &&
+                      chains[0].n_steps == chains[1].n_steps && chains[0].head && chains[1].head && chains[0].in_mode == 0 &&
+                      chains[1].in_mode == 0 && chains[0].step[0].out == nullptr && chains[0].step[0].bits_out == nullptr &&
+                      chains[0].step[0].bits_in == nullptr && chains[1].step[0].bits_in == nullptr && chains[0].x0_out == nullptr &&
+                      (chains[1].step[0].out != nullptr || chains[1].step[0].bits_out != nullptr) &&
+                      (long long)(tiles / 2) >= (long long)c->bf_dual_min_tiles;
+    if (dual) c->last_dual = true;
+    if (dual) hipLaunchKernelGGL(mlp_chain_bf2_kernel, dim3(tiles / 2), dim3(256), 0, s, m);
+    else if (small) hipLaunchKernelGGL(mlp_chain_bf32_kernel, dim3(tiles), dim3(128), 0, s, m);
     else hipLaunchKernelGGL(mlp_chain_bf_kernel, dim3(tiles), dim3(256), 0, s, m);
     LAUNCH_CHECK("mlp_chain_bf");
 #ifdef BF_PROF
@@ -1215,7 +1231,7 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
 extern "C" int morl_ctx_last_step_bf16(morl_ctx* c) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     return (c->bits_bf ? 1 : 0) | (c->dw_bf_last ? 2 : 0) | ((c->lz_last && c->lz_last_big) ? 4 : 0) |
-           ((c->lz_last && c->lz_count_missed) ? 8 : 0) | (c->lz_count_misses > 0 ? 16 : 0) | (c->lz_last_bfn ? 32 : 0);
+           ((c->lz_last && c->lz_count_missed) ? 8 : 0) | (c->lz_count_misses > 0 ? 16 : 0) | (c->lz_last_bfn ? 32 : 0) | (c->last_dual ? 64 : 0);
 }
 
 extern "C" int morl_ctx_set_exact_f32(morl_ctx* c, int enable) {
@@ -1979,6 +1995,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     if (!out) out = &no_out;
     c->lz_last = false;
     c->lz_last_bfn = false;
+    c->last_dual = false;
     c->last_step_W = W;
     timing_begin_step(c);
 

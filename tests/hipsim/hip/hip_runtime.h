@@ -160,7 +160,13 @@ static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_C
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 struct hipDeviceProp_t { int multiProcessorCount; };
-static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; return hipSuccess; }
+// (HIPSIM_CUS: a smaller chip, so that tilings chosen from the CU count -- the 64-row chain tiles, which want a tile per CU -- are reached
+// with row counts the emulator can afford)
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    const char* e = getenv("HIPSIM_CUS");
+    p->multiProcessorCount = (e && atoi(e) > 0) ? atoi(e) : 256;
+    return hipSuccess;
+}
 
 namespace hipsim {
 struct LaneCtx {

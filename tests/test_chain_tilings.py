@@ -204,7 +204,9 @@ g = th.Generator().manual_seed(11)
 cases = [(3, 32, 7, 3, 6, (256, 256)), (2, 32, 5, 2, 4, (256,)), (3, 16, 7, 3, 6, (256, 256)), (5, 16, 7, 3, 6, (256,)), (3, 8, 7, 3, 6, (256,))]
 if sys.argv[2] == "gpu":
     cases += [(256, 64, 32, 3, 6, (256, 256, 256, 256)), (256, 32, 7, 3, 6, (256, 256, 256, 256)), (255, 16, 7, 3, 6, (256, 256, 256, 256))]
-rows_seen = []
+if os.environ.get("TILING_CASES"):
+    cases = [cases[int(i)] for i in os.environ["TILING_CASES"].split(",")]
+rows_seen, dual_seen = [], []
 for B, W, D, R, A, arch in cases:
     ctx = ops.QNetContext(D, R, A, arch, B, W, lib=lib)
     ctx.set_lazy_targets(2)
@@ -221,6 +223,7 @@ for B, W, D, R, A, arch in cases:
         h.update(out[k].cpu().numpy().tobytes())
     h.update(grads.cpu().numpy().tobytes()); h.update(po.cpu().numpy().tobytes())
     rows_seen.append(ctx.lazy_target_rows(po))
+    dual_seen.append((ctx.last_step_bf16() >> 6) & 1)
     # the same step as the agents issue it -- no parity outputs requested: the TD stage may then run inside the backward launch
     out2 = ops.envelope_update(ctx, po, pt, grads, m, v, obs, nobs, act, rew, done, w, gamma=0.98, lr=3e-4, adam_step=2,
                                max_grad_norm=1.0, homotopy_lambda=0.3)
@@ -228,14 +231,18 @@ for B, W, D, R, A, arch in cases:
         h.update(out2[k].cpu().numpy().tobytes())
     h.update(grads.cpu().numpy().tobytes()); h.update(po.cpu().numpy().tobytes()); h.update(m.cpu().numpy().tobytes())
     ctx.close()
+print("DUAL_STEPS", sum(dual_seen))
 print("ARGMAX_DIGEST", h.hexdigest(), rows_seen)
 """
 
 
-def _argmax_digest(mode, extra_env):
+def _argmax_digest(mode, extra_env, dual_steps=None):
     r = subprocess.run([sys.executable, "-c", _ARGMAX_SNIPPET, ROOT, mode], capture_output=True, text=True, timeout=1500,
                        env=dict(os.environ, MORL_BF_MIN_ROWS="0", MORL_LAZY_MIN_ROWS="0", **extra_env), cwd=ROOT)
     assert r.returncode == 0 and "ARGMAX_DIGEST" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    if dual_steps is not None:
+        seen = int(r.stdout.split("DUAL_STEPS")[1].split()[0])
+        assert (seen > 0) == dual_steps, (seen, dual_steps)
     return r.stdout.split("ARGMAX_DIGEST")[1].strip()
 
 
@@ -263,3 +270,18 @@ def test_td_stage_inside_the_backward_launch_gives_the_bits_of_the_separate_laun
 @pytest.mark.gpu
 def test_td_stage_inside_the_backward_launch_gives_the_bits_of_the_separate_launch_on_the_gpu():
     assert _argmax_digest("gpu", {}) == _argmax_digest("gpu", {"MORL_TD_IN_CHAIN": "0"})
+
+
+def test_paired_forward_tiles_give_the_bits_of_the_separate_tiles():
+    """``MORL_BF_DUAL=1`` runs the two online forward passes of a step as PAIRS of 64-row tiles -- one of the next-state pass, one of the
+    training pass, sharing every weight fragment a wave reads (csrc/mlp_chain_bf2.h).  Every accumulator sees the products it sees in
+    mlp_chain_bf.h in the same order, so the step -- arg-max inside the launch, saves, sign bits, gradients, Adam -- is the same to the
+    last bit.  The emulated chip is shrunk to two CUs (``HIPSIM_CUS``) so that the 64-row tiles, which want a tile per CU, are chosen at
+    row counts the emulator can afford (ragged last tiles included)."""
+    base = {"HIPSIM_CUS": "2", "MORL_BFN_MAX_ROWS": "0", "TILING_CASES": "0,3"}
+    assert _argmax_digest("sim", base, dual_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_DUAL="1"), dual_steps=True)
+
+
+@pytest.mark.gpu
+def test_paired_forward_tiles_give_the_bits_of_the_separate_tiles_on_the_gpu():
+    assert _argmax_digest("gpu", {"MORL_BF_DUAL": "0"}, dual_steps=False) == _argmax_digest("gpu", {"MORL_BF_DUAL": "1"}, dual_steps=True)

@@ -51,6 +51,11 @@ fronts)      for n in 1024 16384 65536; do timeout 300 python bench_front.py --w
 rank-ab)     tools/rank_step_ab.sh $O/rank_ab > $O/rank_step_bfn_ab.txt 2>&1; cp $O/rank_ab/rank_step_bfn_ab.json $O/rank_step_bfn_ab.json; tail -12 $O/rank_step_bfn_ab.txt | cut -c1-200 ;;
 target-ab)   for rep in 1 2; do timeout 300 python bench.py --steps 300 --warmup 20 $B --no-sustained-record --no-exact-record > $O/target_ab_chain4_$rep.json 2>/dev/null
                MORL_BFN_TARGETS=1 timeout 300 python bench.py --steps 300 --warmup 20 $B --no-sustained-record --no-exact-record > $O/target_ab_bfn_$rep.json 2>/dev/null; done ;;
+dual-ab)     timeout 900 python -m pytest tests/test_chain_tilings.py -m gpu -q -x -p no:cacheprovider -k paired 2>&1 | tail -15 > $O/dual_test.log; tail -3 $O/dual_test.log
+             for rep in 1 2 3; do for d in 0 1; do
+               MORL_BF_DUAL=$d timeout 300 python bench.py --steps 300 --warmup 20 $B $S > $O/dual_ab_${d}_$rep.json 2>/dev/null
+               python -c "import json,sys; j=json.loads(open('$O/dual_ab_${d}_$rep.json').read()); print('dual=$d', j['ms_per_step'], {k: round(v['avg_launch_us'], 1) for k, v in j['roofline']['per_kernel'].items()})"
+             done; done ;;
 probes)      for p in planes_probe cmp64_probe valu_mfma_probe; do [ -x tools/probes/$p ] && timeout 200 tools/probes/$p > $O/$p.txt 2>&1; done; tail -4 $O/cmp64_probe.txt ;;
 *) echo "unknown stage $st" ;;
 esac
