@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmorl_hip.so")
 SOURCES = ["morl_hip.hip", "morl_ac.hip", "morl_comm.hip"]
-HEADERS = ["morl_device.h", "morl_host.h", "gemm_f32.h", "envelope_kernels.h", "mlp_chain.h", "mlp_chain2.h", "mlp_chain16.h", "mlp_chain4.h", "mlp_chain_bf.h", "mlp_chain_bfn.h", "mlp_chain_bf2.h", "dw_tiles.h", "dw_bf.h", "optim_kernels.h",
+HEADERS = ["morl_device.h", "morl_host.h", "gemm_f32.h", "envelope_kernels.h", "mlp_chain.h", "mlp_chain2.h", "mlp_chain16.h", "mlp_chain4.h", "mlp_chain_bf.h", "mlp_chain_bfn.h", "mlp_chain_bf2.h", "mlp_chain_bf_roll.h", "dw_tiles.h", "dw_bf.h", "optim_kernels.h",
            "replay_kernels.h", "pareto_kernels.h", "metrics_kernels.h", "ac_kernels.h", "gemm_wave.h", "gpi_kernels.h", "ens_kernels.h"]
 
 

@@ -481,10 +481,16 @@ __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x
     if (MODE == 1 && st.bits_out != nullptr) st.bits_out[bits_idx] = ((unsigned long long)pos_hi << 32) | pos_lo;
 }
 
+}  // namespace morl
+#include "mlp_chain_bf_roll.h"
+namespace morl {
+
 // ---- one 64-row tile through a whole chain ----------------------------------------------------------------------------------------
 // K0S: k-steps of the first step (1 or 2); MODE: see bf_wide_epilogue -- the chain writes per-step outputs (1, 2) and sign bits (1) or
 // reads mask words (2); compile-time also because the counted waits depend on the stores issued.
-template <int NW, int K0S, int MODE>
+// ROLL: the 256 x 256 steps behind the first one walk pair after pair with rolling epilogues (mlp_chain_bf_roll.h; the stream is then
+// pair-major: BfSplitJob::pair_major) -- the backward chain on 64-row tiles
+template <int NW, int K0S, int MODE, bool ROLL = false>
 __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsigned char* ring_lds, float* bias_lds, long long* prof,
                                               const float* am_w, int32_t* am_best, int32_t* am_pairs, int32_t* am_slot,
                                               int32_t* am_count, int am_epoch, int am_B, int am_W, int am_A, int am_R, int am_flags,
@@ -669,6 +675,41 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     bf_wide_epilogue<MODE>(acc, x, p.step[0], p.rows, row, row_ok, bits_idx, q, keep);
     BF_T(2)
     // ---- the 256 x 256 steps --------------------------------------------------------------------------------------------------------
+    if constexpr (ROLL) {
+        static_assert(!ROLL || (NW == 4 && MODE == 2), "rolling epilogues: the backward chain on 64-row tiles");
+        f32x4 cc[2][2];
+        bf_u32x4 y[8][3];
+        BfRollPend pend;
+        // the operand arrays swap roles from step to step (x -> y, y -> x, ...): no copies, and whichever array the register
+        // allocator keeps in accumulation registers is read from there by the MFMAs directly
+#define BF_ROLL_STEP(S, PEND, E01, A, B)                                                                                             \
+        {                                                                                                                            \
+            keep_prev = keep;                                                                                                        \
+            keep = ~0ull;                                                                                                            \
+            if (p.step[S].bits_in != nullptr) keep = p.step[S].bits_in[bits_idx];     /* (one vector-memory instruction: in E01) */  \
+            /* (both descriptors from the argument block, here: carried from step to step their pointers ended up in vector   */     \
+            /*  registers and every store of the pending pair ran a readfirstlane loop)                                        */     \
+            const BfRollOut prev_ = bf_roll_out(p.step[(S) > 1 ? (S) - 1 : 1], p.rows, row, row_ok, q, keep_prev);                   \
+            const BfRollOut cur_ = bf_roll_out(p.step[S], p.rows, row, row_ok, q, keep);                                             \
+            bf_roll_wide_step<MODE, PEND, E01>(cc, A, B, ring, lane, bias_lds + (S) * BF_WIDE, q, pend, prev_, cur_);                \
+            BF_T(3)                                                                                                                  \
+        }
+        unsigned long long keep_prev = ~0ull;
+        if (n_wide > 1) BF_ROLL_STEP(1, false, BF_SAVE_VMEM, x, y)
+        int s = 2;
+        for (; s + 1 < n_wide; s += 2) {
+            BF_ROLL_STEP(s, true, 3, y, x)
+            BF_ROLL_STEP(s + 1, true, 3, x, y)
+        }
+        if (s < n_wide) {
+            BF_ROLL_STEP(s, true, 3, y, x)
+            bf_roll_pair_epilogue<MODE>(7, pend, bf_roll_out(p.step[n_wide - 1], p.rows, row, row_ok, q, keep), cc[1][0], cc[1][1], x[7]);
+        } else if (n_wide > 1) {
+            bf_roll_pair_epilogue<MODE>(7, pend, bf_roll_out(p.step[n_wide - 1], p.rows, row, row_ok, q, keep), cc[1][0], cc[1][1], y[7]);
+        }
+        BF_T(4)
+#undef BF_ROLL_STEP
+    } else
     for (int s = 1; s < n_wide; ++s) {
         // this step's mask word: the seventeenth vector-memory instruction behind the previous epilogue's sixteen stores, in front of
         // this step's DMA groups -- retired (in issue order) long before the epilogue reads it
@@ -778,6 +819,17 @@ __global__ __launch_bounds__(256, 2) void mlp_chain_bf_kernel(BfMulti m) {
     mlp_chain_bf_entry<4>(m, lds);
 }
 
+// the backward chain on 64-row tiles with rolling epilogues (one workgroup per CU: ~300 registers per lane); its stream is pair-major
+__global__ __launch_bounds__(256, 1) void mlp_chain_bf_roll_kernel(BfMulti m) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BF_LDS_BYTES];
+    kernarg_warm<sizeof(BfMulti)>();
+    // (one chain, the backward one, whose first step is the 32-wide head transposed: the host launches nothing else here)
+    float* bias_lds = reinterpret_cast<float*>(lds + BF_RING * BF_STAGE_BYTES);
+    bf_chain_body<4, 1, 2, true>(m.c[0], (int)blockIdx.x * BF_TM, lds, bias_lds, m.prof, m.td.weights, m.td.best_io, m.td.pairs_out,
+                                 m.td.row_slot, m.td.count, m.td.epoch, m.td.B, m.td.W, m.td.A, m.td.R,
+                                 (m.td.diag_only | (m.td.fma_scal << 1) | (m.td.bmajor << 2)), m.tdb);
+}
+
 __global__ __launch_bounds__(128, 1) void mlp_chain_bf32_kernel(BfMulti m) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[BF_LDS_BYTES];
     kernarg_warm<sizeof(BfMulti)>();
@@ -793,6 +845,7 @@ struct BfSplitJob {
     const float* base;
     long long sn, sk;
     int N, K, ksteps, ntiles, natural, block0;
+    int pair_major;     // 8 k-steps x 16 tiles only: stage i of the job = k-steps 4 (i & 1) .. + 3 of tiles 2 (i >> 1), + 1 (mlp_chain_bf_roll.h)
 };
 constexpr int BF_MAX_JOBS = 3 * BF_MAX_STEPS;      // forward + backward stream of the online network, forward stream of the target network
 struct BfSplitArgs {
@@ -809,7 +862,12 @@ __device__ __forceinline__ void bf_split_body(const BfSplitArgs& a, unsigned cha
     while (j + 1 < a.n && unit >= a.unit_start[j + 1]) ++j;
     const BfSplitJob& jb = a.job[j];
     const int u = unit - a.unit_start[j];
-    const int s = u / jb.ntiles, t = u - s * jb.ntiles;
+    int s = u / jb.ntiles, t = u - s * jb.ntiles;
+    if (jb.pair_major) {
+        // unit u of the stream: stage u / 8 = (pair j = u / 16, half h = (u / 8) & 1), slot u % 8 = (k-step 4 h + slot / 2, tile 2 j + (slot & 1))
+        s = 4 * ((u >> 3) & 1) + ((u & 7) >> 1);
+        t = 2 * (u >> 4) + (u & 1);
+    }
     const int n = 16 * t + (lane & 15), q = lane >> 4;
     float v[8];
 #pragma unroll

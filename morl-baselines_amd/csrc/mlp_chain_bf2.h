@@ -155,24 +155,28 @@ __device__ __forceinline__ void bf2_input(const BfChain& p, int row, bool row_ok
 }
 
 // ---- one 64-row next-state tile + one 64-row training tile through the chain -------------------------------------------------------------
-// pn: the no-grad next-state chain (head -> the online slab; amax: arg-max of the tile's transitions), pt: the training chain (saves,
+// pn: the no-grad next-state chain (head -> the online slab; amax: arg-max of the tile's transitions), pc: the training chain (saves,
 // sign bits, x0_out, head -> Q).  Same stream, same steps' shapes and biases (the online network).
 template <int K0S>
-__device__ __forceinline__ void bf2_chain_body(const BfChain& pn, const BfChain& pt, int row0, unsigned char* ring_lds, float* bias_lds,
+__device__ __forceinline__ void bf2_chain_body(const BfChain& pn, const BfChain& pc, int row0, unsigned char* ring_lds, float* bias_lds,
                                                const float* am_w, int32_t* am_best, int32_t* am_pairs, int32_t* am_slot, int32_t* am_count,
-                                               int am_epoch, int am_B, int am_W, int am_A, int am_R, int am_flags) {
+                                               int am_epoch, int am_B, int am_W, int am_A, int am_R, int am_flags, long long* prof) {
+#ifdef BF_PROF
+    long long pt[6] = {0, 0, 0, 0, 0, 0}, tp_ = clock64();
+    const long long tstart_ = tp_;
+#endif
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, q = lane >> 4;
     const int row = row0 + 16 * wave + m;
-    const bool ok_n = row < pn.rows, ok_t = row < pt.rows;
+    const bool ok_n = row < pn.rows, ok_t = row < pc.rows;
     const size_t bits_idx = (size_t)((row0 >> 4) + wave) * 64 + lane;
 
     BfRing ring;
-    ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pt.stream, 0, pt.n_stages * BF_STAGE_BYTES, 0x00020000);
+    ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pc.stream, 0, pc.n_stages * BF_STAGE_BYTES, 0x00020000);
     ring.voff = wave * ((BF_STAGE_BLOCKS / 4) * BF_BLOCK) + lane * 16;
     ring.lds = ring_lds;
-    ring.t = 0; ring.buf = 0; ring.n_stages = pt.n_stages; ring.wave = wave;
+    ring.t = 0; ring.buf = 0; ring.n_stages = pc.n_stages; ring.wave = wave;
 #ifdef BF_PROF
     ring.t_entry = 0; ring.t_dma = 0;
 #endif
@@ -181,43 +185,48 @@ __device__ __forceinline__ void bf2_chain_body(const BfChain& pn, const BfChain&
     float bv[BF_MAX_STEPS];
 #pragma unroll
     for (int s = 0; s < BF_MAX_STEPS; ++s) {
-        const float* bp = pt.step[s].bias;
+        const float* bp = pc.step[s].bias;
         const __amdgpu_buffer_rsrc_t rb =
-            __builtin_amdgcn_make_buffer_rsrc((void*)bp, 0, (s < pt.n_steps && bp != nullptr) ? pt.step[s].N * 4 : 0, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void*)bp, 0, (s < pc.n_steps && bp != nullptr) ? pc.step[s].N * 4 : 0, 0x00020000);
         bv[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, tid * 4, 0, 0));
     }
     bf_u32x4 x[2][8][3];
     bf2_input<K0S>(pn, row, ok_n, q, x[0]);
-    bf2_input<K0S>(pt, row, ok_t, q, x[1]);
+    bf2_input<K0S>(pc, row, ok_t, q, x[1]);
 #pragma unroll
     for (int s = 0; s < BF_MAX_STEPS; ++s)
-        if (s < pt.n_steps) bias_lds[s * BF_WIDE + tid] = bv[s];
+        if (s < pc.n_steps) bias_lds[s * BF_WIDE + tid] = bv[s];
     BF_VMCNT(0);
     __syncthreads();
 
     f32x4 acc[2][16];
-    const int n_wide = pt.n_steps - 1;
+    const int n_wide = pc.n_steps - 1;
     // ---- first step ---------------------------------------------------------------------------------------------------------------
+    BF_T(0)
     bf_acc_init<16>(acc[0], bias_lds, q);
     bf_acc_init<16>(acc[1], bias_lds, q);
     bf2_wide_step<K0S, 0>(acc, x, ring, lane);
+    BF_T(1)
     bf_wide_epilogue<0>(acc[0], x[0], pn.step[0], pn.rows, row, ok_n, bits_idx, q, ~0ull);
-    bf_wide_epilogue<1>(acc[1], x[1], pt.step[0], pt.rows, row, ok_t, bits_idx, q, ~0ull);
+    bf_wide_epilogue<1>(acc[1], x[1], pc.step[0], pc.rows, row, ok_t, bits_idx, q, ~0ull);
+    BF_T(2)
     // ---- the 256 x 256 steps --------------------------------------------------------------------------------------------------------
     for (int s = 1; s < n_wide; ++s) {
         bf_acc_init<16>(acc[0], bias_lds + s * BF_WIDE, q);
         bf_acc_init<16>(acc[1], bias_lds + s * BF_WIDE, q);
         bf2_wide_step<8, BF_SAVE_VMEM>(acc, x, ring, lane);
+        BF_T(3)
         bf_wide_epilogue<0>(acc[0], x[0], pn.step[s], pn.rows, row, ok_n, bits_idx, q, ~0ull);
-        bf_wide_epilogue<1>(acc[1], x[1], pt.step[s], pt.rows, row, ok_t, bits_idx, q, ~0ull);
+        bf_wide_epilogue<1>(acc[1], x[1], pc.step[s], pc.rows, row, ok_t, bits_idx, q, ~0ull);
+        BF_T(4)
     }
     // ---- the head -----------------------------------------------------------------------------------------------------------------
     f32x4 hacc[2][2];
     {
         const BfStep& sn = pn.step[pn.n_steps - 1];
-        const BfStep& st = pt.step[pt.n_steps - 1];
-        bf_acc_init<2>(hacc[0], bias_lds + (pt.n_steps - 1) * BF_WIDE, q);
-        bf_acc_init<2>(hacc[1], bias_lds + (pt.n_steps - 1) * BF_WIDE, q);
+        const BfStep& st = pc.step[pc.n_steps - 1];
+        bf_acc_init<2>(hacc[0], bias_lds + (pc.n_steps - 1) * BF_WIDE, q);
+        bf_acc_init<2>(hacc[1], bias_lds + (pc.n_steps - 1) * BF_WIDE, q);
         if (st.N > 16) bf2_head_step<2, BF_SAVE_VMEM>(hacc, x, ring, lane);
         else bf2_head_step<1, BF_SAVE_VMEM>(hacc, x, ring, lane);
 #pragma unroll
@@ -268,6 +277,14 @@ __device__ __forceinline__ void bf2_chain_body(const BfChain& pn, const BfChain&
         else BF2_AMAX(1);
 #undef BF2_AMAX
     }
+    BF_T(5)
+#ifdef BF_PROF
+    if (prof != nullptr && lane == 0) {
+        long long* o = prof + ((size_t)blockIdx.x * 4 + wave) * BF_PROF_SLOTS;
+        for (int i = 0; i < 6; ++i) o[i] = pt[i];
+        o[6] = ring.t_entry; o[7] = ring.t_dma; o[8] = tstart_; o[9] = tp_;
+    }
+#endif
 }
 
 // grid: one workgroup per pair of 64-row tiles (tile t of the next-state chain m.c[0] and tile t of the training chain m.c[1])
@@ -277,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_bf2_kernel(BfMulti m) {
     const int row0 = (int)blockIdx.x * BF_TM;
     float* bias_lds = reinterpret_cast<float*>(lds + BF_RING * BF_STAGE_BYTES);
 #define BF2_AM m.td.weights, m.td.best_io, m.td.pairs_out, m.td.row_slot, m.td.count, m.td.epoch, m.td.B, m.td.W, m.td.A, m.td.R, \
-               (m.td.diag_only | (m.td.fma_scal << 1) | (m.td.bmajor << 2))
+               (m.td.diag_only | (m.td.fma_scal << 1) | (m.td.bmajor << 2)), m.prof
     if (m.c[1].k0_steps == 1) bf2_chain_body<1>(m.c[0], m.c[1], row0, lds, bias_lds, BF2_AM);
     else bf2_chain_body<2>(m.c[0], m.c[1], row0, lds, bias_lds, BF2_AM);
 #undef BF2_AM

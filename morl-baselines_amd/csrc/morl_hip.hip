@@ -244,6 +244,12 @@ struct morl_ctx {
     const float* fresh_bf = nullptr;     // parameters the streams were split from by this step's morl_envelope_prepare (one-shot)
     const float* fresh_bft = nullptr;    // TARGET parameters whose forward stream (third region of bf_stream) that launch also made:
                                          // the lazily evaluated target rows then run on the few-row split-bf16 chain (mlp_chain_bfn.h)
+    int bf_roll = 0;                     // MORL_BF_ROLL=1: the backward chain's 64-row launch walks its 256 x 256 steps pair after pair with rolling
+                                         //   epilogues (mlp_chain_bf_roll.h); its stream is then split pair-major
+    bool split_pair_major = false;       // ... what the NEXT split of the backward stream writes (bf_split_args)
+    bool bwd_pair_major = false;         // ... what the backward stream holds now
+    const float* bf_split_src = nullptr; // ... the parameters it was split from
+    bool last_roll = false;              // the last step's backward chain ran with rolling epilogues
     int bf_dual = 0;                     // MORL_BF_DUAL=1: the two online forward passes as tile pairs sharing the weight fragments (mlp_chain_bf2.h)
     int bf_dual_min_tiles = 0;           // MORL_BF_DUAL_MIN_TILES: ... from this many tile pairs on
     int bfn_eager3 = 1;                  // MORL_BFN_EAGER3=0: the target pass of an eagerly evaluated few-row step as a launch of its own on the
@@ -470,6 +476,7 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     if (const char* e = getenv("MORL_EXACT_F32")) c->bf_mode = atoi(e) != 0 ? 0 : 1;
     if (const char* e = getenv("MORL_BFN_TARGETS")) c->bfn_targets = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BFN_MAX_ROWS")) c->bfn_max_rows = atoll(e);
+    if (const char* e = getenv("MORL_BF_ROLL")) c->bf_roll = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BF_DUAL")) c->bf_dual = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BF_DUAL_MIN_TILES")) c->bf_dual_min_tiles = atoi(e);
     if (const char* e = getenv("MORL_BFN_EAGER3")) c->bfn_eager3 = atoi(e) != 0 ? 1 : 0;
@@ -600,14 +607,16 @@ static int refresh_transposed(morl_ctx* c, const float* params, float* wt, hipSt
 
 // what a gradient step on the bf16 matrix cores streams: the online network's split weights + the K-major copy of the TARGET network
 // (its rows run on the fp32 few-row tiles, or its whole slab on the fp32 chain when the caller asks for it)
-static int refresh_bf_step(morl_ctx* c, const float* params_online, const float* params_target, hipStream_t s) {
+static bool bf_roll_wanted(const morl_ctx* c, long long rows);
+static int bf_split_launch(morl_ctx* c, const float* params, hipStream_t s, bool pair_major);
+static int refresh_bf_step(morl_ctx* c, const float* params_online, const float* params_target, hipStream_t s, long long rows_bwd = 0) {
     const bool have_bf = c->fresh_bf == params_online, have_t = c->fresh_target == params_target;
     const bool have_bft = have_bf && c->fresh_bft == params_target;
     c->fresh_online = c->fresh_target = c->fresh_bf = c->fresh_bft = nullptr; c->bft_ready = false;
     c->bft_ready = have_bft;             // (this step's lazily evaluated target rows may take the target network's split stream)
     c->wt_online_src = nullptr;
     int rc;
-    if (!have_bf && (rc = bf_split_launch(c, params_online, s))) return rc;
+    if (!have_bf && (rc = bf_split_launch(c, params_online, s, bf_roll_wanted(c, rows_bwd)))) return rc;
     if (!have_t) {
         const ShadowArgs t = shadow_args(c);
         hipLaunchKernelGGL(shadow_weights_kernel, dim3(t.tiles, 1), dim3(256), 0, s, params_target, c->wt_target, (const float*)nullptr,
@@ -628,6 +637,11 @@ static bool bf_wanted(const morl_ctx* c, long long rows, bool weight_shard = fal
     // (the few-row form serves the unsharded / batch-sharded step; the weight-sharded rank step below its threshold keeps the f32
     // engines: its slab, training pass and TD rows are separate entries that were measured there)
     return c->bf_ok && c->bf_mode != 0 && c->use_fused && c->fused_tm == 0 && (rows >= min_rows || (!weight_shard && bfn_few(c, rows)));
+}
+
+// does the backward chain of a step over `rows` TD rows take the rolling-epilogue kernel (64-row tiles, a tile for every CU)?
+static bool bf_roll_wanted(const morl_ctx* c, long long rows) {
+    return c->bf_roll && rows > 0 && !bfn_few(c, rows) && (rows + BF_TM - 1) / BF_TM >= (long long)c->num_cus;
 }
 
 // the split jobs of the online network: forward stream (blocks [0, bf_fwd_blocks)) then backward stream
@@ -651,8 +665,10 @@ static BfSplitArgs bf_split_args(const morl_ctx* c, const float* params, const f
             add(params + c->offW[l], n.dims[l], 1, n.dims[l + 1], n.dims[l], l == 0 ? c->bf_k0_steps : 8, head ? c->bf_head_tiles : 16, l == 0 ? 1 : 0);
         }
         // backward: step k <-> layer l = L - 1 - k: g_{l-1} = g_l W_l, i.e. M[n = i][k = o] = W_l[o][i]
-        for (int l = L - 1; l >= 1; --l)
+        for (int l = L - 1; l >= 1; --l) {
             add(params + c->offW[l], 1, n.dims[l], n.dims[l], n.dims[l + 1], l == L - 1 ? 1 : 8, 16, l == L - 1 ? 1 : 0);
+            if (l != L - 1 && c->split_pair_major) a.job[j - 1].pair_major = 1;
+        }
     }
     block = c->bf_fwd_blocks + c->bf_bwd_blocks;
     // the target network's forward stream, behind both streams of the online one (mlp_chain_bfn.h: the lazily evaluated target rows)
@@ -666,8 +682,11 @@ static BfSplitArgs bf_split_args(const morl_ctx* c, const float* params, const f
     return a;
 }
 
-static int bf_split_launch(morl_ctx* c, const float* params, hipStream_t s) {
+static int bf_split_launch(morl_ctx* c, const float* params, hipStream_t s, bool pair_major) {
+    c->split_pair_major = pair_major;
     const BfSplitArgs a = bf_split_args(c, params);
+    c->bwd_pair_major = pair_major;
+    c->bf_split_src = params;
     const int blocks = (a.unit_start[a.n] * 64 + 255) / 256;
     hipLaunchKernelGGL(bf_split_kernel, dim3(blocks), dim3(256), 0, s, a, c->bf_stream);
     LAUNCH_CHECK("bf_split");
@@ -743,6 +762,15 @@ static int bf_tile_rows(morl_ctx* c, const BfChain* chains, int n) {
 static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStream_t s, const EnvelopeTdArgs* td = nullptr,
                      const BfTdArgs* tdb = nullptr) {
     const int tm = bf_tile_rows(c, chains, n);
+    // a backward chain whose stream was split pair-major (for the rolling-epilogue kernel) by a launch that guessed this step's rows
+    // wrong: the stream again, k-step-major
+    const bool backward = n == 1 && chains[0].step[0].bits_in != nullptr;
+    const bool roll = backward && c->bwd_pair_major && tm == BF_TM;
+    if (backward && c->bwd_pair_major && !roll) {
+        if (c->bf_split_src == nullptr) return fail(MORL_ERR_STATE, "internal: pair-major stream without its source");
+        int rc2;
+        if ((rc2 = bf_split_launch(c, c->bf_split_src, s, false))) return rc2;
+    }
     if (tm == BF_TILE_FEW) {
         // 16-row tiles while that is at most a tile per CU, 32-row tiles beyond (mlp_chain_bfn.h)
         long long tiles16 = 0;
@@ -805,7 +833,9 @@ static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStr
                       (chains[1].step[0].out != nullptr || chains[1].step[0].bits_out != nullptr) &&
                       (long long)(tiles / 2) >= (long long)c->bf_dual_min_tiles;
     if (dual) c->last_dual = true;
+    if (roll) c->last_roll = true;
     if (dual) hipLaunchKernelGGL(mlp_chain_bf2_kernel, dim3(tiles / 2), dim3(256), 0, s, m);
+    else if (roll) hipLaunchKernelGGL(mlp_chain_bf_roll_kernel, dim3(tiles), dim3(256), 0, s, m);
     else if (small) hipLaunchKernelGGL(mlp_chain_bf32_kernel, dim3(tiles), dim3(128), 0, s, m);
     else hipLaunchKernelGGL(mlp_chain_bf_kernel, dim3(tiles), dim3(256), 0, s, m);
     LAUNCH_CHECK("mlp_chain_bf");
@@ -813,6 +843,7 @@ static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStr
     if (prof_now && tiles <= 4096) {
         hipStreamSynchronize(s);
         const int nw = small ? 2 : 4;
+        if (dual) tiles /= 2;
         std::vector<long long> h((size_t)tiles * nw * BF_PROF_SLOTS);
         hipMemcpy(h.data(), prof_dev, h.size() * 8, hipMemcpyDeviceToHost);
         double a[BF_PROF_SLOTS] = {0};
@@ -1203,7 +1234,10 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
         // the target network's forward stream too: for the target rows of a lazily evaluated step (MORL_BFN_TARGETS=1) or for the target
         // pass of an eagerly evaluated few-row step, which rides in its forward launch (mlp_chain_bfn.h)
         const bool bft = (c->bfn_targets && c->lazy_targets != 0) || (c->bfn_eager3 && bfn_few(c, 2 * rows_next));
+        c->split_pair_major = bf_roll_wanted(c, rows_next);
         const BfSplitArgs bf = bf_split_args(c, params_online, bft ? params_target : nullptr);
+        c->bwd_pair_major = c->split_pair_major;
+        c->bf_split_src = params_online;
         const int bf_blocks = (bf.unit_start[bf.n] * 64 + 255) / 256;
         hipLaunchKernelGGL(step_prologue_kernel, dim3(blocks + sh.tiles + bf_blocks), dim3(256), 0, (hipStream_t)stream, a, blocks,
                            params_target, c->wt_target, (const float*)nullptr, (float*)nullptr, sh, 1, bf, c->bf_stream);
@@ -1231,7 +1265,7 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
 extern "C" int morl_ctx_last_step_bf16(morl_ctx* c) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     return (c->bits_bf ? 1 : 0) | (c->dw_bf_last ? 2 : 0) | ((c->lz_last && c->lz_last_big) ? 4 : 0) |
-           ((c->lz_last && c->lz_count_missed) ? 8 : 0) | (c->lz_count_misses > 0 ? 16 : 0) | (c->lz_last_bfn ? 32 : 0) | (c->last_dual ? 64 : 0);
+           ((c->lz_last && c->lz_count_missed) ? 8 : 0) | (c->lz_count_misses > 0 ? 16 : 0) | (c->lz_last_bfn ? 32 : 0) | (c->last_dual ? 64 : 0) | (c->last_roll ? 128 : 0);
 }
 
 extern "C" int morl_ctx_set_exact_f32(morl_ctx* c, int enable) {
@@ -1996,6 +2030,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     c->lz_last = false;
     c->lz_last_bfn = false;
     c->last_dual = false;
+    c->last_roll = false;
     c->last_step_W = W;
     timing_begin_step(c);
 
@@ -2010,7 +2045,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
         // The two ONLINE passes (next-state slab, training pass) on the bf16 matrix cores as six split-bf16 products each
         // (mlp_chain_bf.h: fp32-class accuracy at 6/16 of the f32-input MFMA's time), one launch.  The TARGET network stays on the
         // exact fp32 tiles: its selected rows (lazy evaluation, the default) or, when the caller asks for the whole slab, its pass.
-        if ((rc = refresh_bf_step(c, params_online, params_target, s))) return rc;
+        if ((rc = refresh_bf_step(c, params_online, params_target, s, rows))) return rc;
         c->lz_now = c->lazy_targets && cfg->envelope && W >= 2 && !out->q_target_next && (c->lazy_targets == 2 || rows >= lazy_min_rows);
         c->lz_last = c->lz_now;
         // an eagerly evaluated FEW-ROW step (a rank's share of a sharded job, small batches): the target network's pass rides in the

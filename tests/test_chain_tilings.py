@@ -204,9 +204,11 @@ g = th.Generator().manual_seed(11)
 cases = [(3, 32, 7, 3, 6, (256, 256)), (2, 32, 5, 2, 4, (256,)), (3, 16, 7, 3, 6, (256, 256)), (5, 16, 7, 3, 6, (256,)), (3, 8, 7, 3, 6, (256,))]
 if sys.argv[2] == "gpu":
     cases += [(256, 64, 32, 3, 6, (256, 256, 256, 256)), (256, 32, 7, 3, 6, (256, 256, 256, 256)), (255, 16, 7, 3, 6, (256, 256, 256, 256))]
+if os.environ.get("TILING_DEEP"):     # three hidden layers: the backward chain has two 256 x 256 steps (a rolling step entered with a pair pending)
+    cases = [(4, 32, 5, 2, 4, (256, 256, 256)), (5, 16, 7, 3, 6, (256, 256))]
 if os.environ.get("TILING_CASES"):
     cases = [cases[int(i)] for i in os.environ["TILING_CASES"].split(",")]
-rows_seen, dual_seen = [], []
+rows_seen, dual_seen, roll_seen = [], [], []
 for B, W, D, R, A, arch in cases:
     ctx = ops.QNetContext(D, R, A, arch, B, W, lib=lib)
     ctx.set_lazy_targets(2)
@@ -224,6 +226,7 @@ for B, W, D, R, A, arch in cases:
     h.update(grads.cpu().numpy().tobytes()); h.update(po.cpu().numpy().tobytes())
     rows_seen.append(ctx.lazy_target_rows(po))
     dual_seen.append((ctx.last_step_bf16() >> 6) & 1)
+    roll_seen.append((ctx.last_step_bf16() >> 7) & 1)
     # the same step as the agents issue it -- no parity outputs requested: the TD stage may then run inside the backward launch
     out2 = ops.envelope_update(ctx, po, pt, grads, m, v, obs, nobs, act, rew, done, w, gamma=0.98, lr=3e-4, adam_step=2,
                                max_grad_norm=1.0, homotopy_lambda=0.3)
@@ -232,17 +235,21 @@ for B, W, D, R, A, arch in cases:
     h.update(grads.cpu().numpy().tobytes()); h.update(po.cpu().numpy().tobytes()); h.update(m.cpu().numpy().tobytes())
     ctx.close()
 print("DUAL_STEPS", sum(dual_seen))
+print("ROLL_STEPS", sum(roll_seen))
 print("ARGMAX_DIGEST", h.hexdigest(), rows_seen)
 """
 
 
-def _argmax_digest(mode, extra_env, dual_steps=None):
+def _argmax_digest(mode, extra_env, dual_steps=None, roll_steps=None):
     r = subprocess.run([sys.executable, "-c", _ARGMAX_SNIPPET, ROOT, mode], capture_output=True, text=True, timeout=1500,
                        env=dict(os.environ, MORL_BF_MIN_ROWS="0", MORL_LAZY_MIN_ROWS="0", **extra_env), cwd=ROOT)
     assert r.returncode == 0 and "ARGMAX_DIGEST" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     if dual_steps is not None:
         seen = int(r.stdout.split("DUAL_STEPS")[1].split()[0])
         assert (seen > 0) == dual_steps, (seen, dual_steps)
+    if roll_steps is not None:
+        seen = int(r.stdout.split("ROLL_STEPS")[1].split()[0])
+        assert (seen > 0) == roll_steps, (seen, roll_steps)
     return r.stdout.split("ARGMAX_DIGEST")[1].strip()
 
 
@@ -285,3 +292,17 @@ def test_paired_forward_tiles_give_the_bits_of_the_separate_tiles():
 @pytest.mark.gpu
 def test_paired_forward_tiles_give_the_bits_of_the_separate_tiles_on_the_gpu():
     assert _argmax_digest("gpu", {"MORL_BF_DUAL": "0"}, dual_steps=False) == _argmax_digest("gpu", {"MORL_BF_DUAL": "1"}, dual_steps=True)
+
+
+def test_rolling_epilogues_give_the_bits_of_the_step_end_epilogues():
+    """``MORL_BF_ROLL=1``: the backward chain's 64-row launch walks every 256 x 256 step pair of feature tiles after pair (a pair-major
+    weight stream) and runs a finished pair's epilogue in slices between the MFMAs of the pair that follows (csrc/mlp_chain_bf_roll.h).
+    Every accumulator sees the products it sees in mlp_chain_bf.h, in the same order: gradients, optimiser state and priorities are the
+    same to the last bit.  Two hidden layers (one rolling step) and three (a rolling step entered with a pair pending), ragged tiles."""
+    base = {"HIPSIM_CUS": "2", "MORL_BFN_MAX_ROWS": "0", "TILING_DEEP": "1"}
+    assert _argmax_digest("sim", base, roll_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_ROLL="1"), roll_steps=True)
+
+
+@pytest.mark.gpu
+def test_rolling_epilogues_give_the_bits_of_the_step_end_epilogues_on_the_gpu():
+    assert _argmax_digest("gpu", {"MORL_BF_ROLL": "0"}, roll_steps=False) == _argmax_digest("gpu", {"MORL_BF_ROLL": "1"}, roll_steps=True)
