@@ -257,6 +257,54 @@ __device__ __forceinline__ const unsigned char* bf_stage_enter(BfRing& r) {
     return base;
 }
 
+// PRODUCER-WAVE form (round 6, the backward launch: mlp_chain_bf_pw_kernel).  A fifth wave of the workgroup issues every weight group --
+// all 24 pieces of a stage -- and waits for them; the four MFMA waves issue none.  Why: a 1 KB LDS-DMA instruction costs the wave that
+// issues it ~40 issue cycles, six per stage and wave were ~5 of the backward chain's 23 cycles per MFMA, and a wave's own instructions
+// do not run under its MFMAs (profiles/r06_mfma_same_wave_probe.txt) -- another wave's do.
+// entry of a stage for an MFMA wave: its own fragment reads have returned, then the workgroup's barrier (the producer arrives there
+// once the stage has landed)
+__device__ __forceinline__ const unsigned char* bf_stage_enter_pw(BfRing& r) {
+#ifdef BF_PROF
+    const long long t0_ = clock64();
+#endif
+    __builtin_amdgcn_s_waitcnt((0 << 8) | (7 << 4) | 15 | (3 << 14));     // lgkmcnt(0), vmcnt / expcnt untouched
+    __builtin_amdgcn_s_barrier();
+#ifdef BF_PROF
+    r.t_entry += clock64() - t0_;
+#endif
+    const unsigned char* base = r.lds + r.buf * BF_STAGE_BYTES;
+    r.buf = r.buf == 2 ? 0 : r.buf + 1;
+    ++r.t;
+    return base;
+}
+// the producer wave: stages 0 and 1 at once, then per stage entry -- stage t has landed (everything but the 24 pieces of stage t + 1),
+// barrier (the MFMA waves are done with stage t - 1), stage t + 2 into the buffer that became free.  `pre_barriers`: workgroup barriers
+// the MFMA waves pass before their first stage entry.
+__device__ __forceinline__ void bf_ring_producer(const unsigned char* stream, int n_stages, unsigned char* ring_lds, int lane, int pre_barriers) {
+    BfRing r;
+    r.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)stream, 0, n_stages * BF_STAGE_BYTES, 0x00020000);
+    r.lds = ring_lds;
+    r.n_stages = n_stages;
+    // (as one "wave of a one-wave workgroup": share = the whole stage, 24 pieces in two calls of the two-wave issue)
+    auto issue = [&](int st, int buf) {
+        r.wave = 0; r.voff = lane * 16;
+        bf_ring_issue<2>(r, st, buf);
+        r.wave = 1; r.voff = 12 * BF_BLOCK + lane * 16;
+        bf_ring_issue<2>(r, st, buf);
+    };
+    issue(0, 0);
+    issue(1, 1);
+    for (int b = 0; b < pre_barriers; ++b) __builtin_amdgcn_s_barrier();
+    int buf = 2;
+    for (int t = 0; t < n_stages; ++t) {
+        BF_VMCNT(BF_STAGE_BLOCKS);
+        __builtin_amdgcn_s_barrier();
+        issue(t + 2, buf);
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    BF_VMCNT(0);
+}
+
 // Entry of stage r.t: my share of it has landed (EXTRA = vector-memory instructions this lane issued AFTER the DMA group of the
 // stage following it -- epilogue stores -- which retire in issue order behind the group waited for) and every LDS read this wave
 // has issued has returned; after the barrier everybody's share has landed and everybody is done reading the stage before it, whose
@@ -340,11 +388,11 @@ __device__ __forceinline__ void bf_six_pair(f32x4& c0, f32x4& c1, const bf_u32x4
 // stage i + 1 (wait, barrier, DMA issue) sits INSIDE the last pair of stage i, whose remaining MFMAs then cover the LDS latency of
 // stage i + 1's first fragments -- its own fragments are all in registers by then, so the buffer of stage i is free for the DMA the
 // entry issues.  EXTRA0: see bf_stage_begin, applies to the step's first two stages.
-template <int NW, int KSTEPS, int EXTRA0>
+template <int NW, int KSTEPS, int EXTRA0, bool PW = false>
 __device__ __forceinline__ void bf_wide_step(f32x4 (&acc)[16], const bf_u32x4 (&x)[8][3], BfRing& ring, int lane) {
     bf_u32x4 fa[2][3], fb[2][3];
     BF_PIN();
-    const unsigned char* base = bf_stage_enter<NW, EXTRA0>(ring) + lane * 16;
+    const unsigned char* base = (PW ? bf_stage_enter_pw(ring) : bf_stage_enter<NW, EXTRA0>(ring)) + lane * 16;
 #pragma unroll
     for (int pl = 2; pl >= 0; --pl) {       // (consumption order, pinned: the first MFMAs wait for the first two reads only)
         fa[0][pl] = *reinterpret_cast<const bf_u32x4*>(base + pl * BF_BLOCK);
@@ -359,7 +407,10 @@ __device__ __forceinline__ void bf_wide_step(f32x4 (&acc)[16], const bf_u32x4 (&
             const bool last = (s == KSTEPS - 1) && (hf == 1);
             // the weight group this stage's entry set up goes out one piece per product step: from piece 0 when the entry was the
             // step's first (in front of the stage), from piece 4 when it sat inside the previous stage's last pair (pieces 0 - 3 there)
-            if (s == 0 && hf == 0) {
+            if (PW) {
+                bf_six_pair<true>(acc[T + 0], acc[T + 1], fa[0], fa[1], x[s], fb[0], fb[1], base + 6 * BF_BLOCK);
+                bf_six_pair<true>(acc[T + 2], acc[T + 3], fb[0], fb[1], x[s], fa[0], fa[1], base + 12 * BF_BLOCK);
+            } else if (s == 0 && hf == 0) {
                 bf_six_pair<true, NW, 0>(acc[T + 0], acc[T + 1], fa[0], fa[1], x[s], fb[0], fb[1], base + 6 * BF_BLOCK, &ring);
                 bf_six_pair<true, NW, 6>(acc[T + 2], acc[T + 3], fb[0], fb[1], x[s], fa[0], fa[1], base + 12 * BF_BLOCK, &ring);
             } else {
@@ -372,9 +423,10 @@ __device__ __forceinline__ void bf_wide_step(f32x4 (&acc)[16], const bf_u32x4 (&
                 // during the pair before) have long returned -- then the entry, then the other four steps with the next stage's first
                 // fragments riding along (2, 2, 1, 1) and the first four pieces of the group the entry set up
                 bf_six_part<0, 2, false>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
-                base = ((s == 0 && hf == 0) ? bf_stage_enter<NW, EXTRA0>(ring) : bf_stage_enter<NW, 0>(ring)) + lane * 16;
+                base = (PW ? bf_stage_enter_pw(ring) : (s == 0 && hf == 0) ? bf_stage_enter<NW, EXTRA0>(ring) : bf_stage_enter<NW, 0>(ring)) + lane * 16;
                 BF_PIN();
-                bf_six_part<2, 6, true, 2, 2, 3, 3, 4, 5, NW, 0>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base, &ring);
+                if (PW) bf_six_part<2, 6, true, 2, 2, 3, 3, 4, 5>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
+                else bf_six_part<2, 6, true, 2, 2, 3, 3, 4, 5, NW, 0>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base, &ring);
             } else {
                 bf_six_pair<false>(acc[T + 6], acc[T + 7], fb[0], fb[1], x[s], fa[0], fa[1], base);
             }
@@ -490,7 +542,8 @@ namespace morl {
 // reads mask words (2); compile-time also because the counted waits depend on the stores issued.
 // ROLL: the 256 x 256 steps behind the first one walk pair after pair with rolling epilogues (mlp_chain_bf_roll.h; the stream is then
 // pair-major: BfSplitJob::pair_major) -- the backward chain on 64-row tiles
-template <int NW, int K0S, int MODE, bool ROLL = false>
+// PW: a fifth wave issues the weight ring (bf_ring_producer) -- the backward chain on 64-row tiles, 320 work-items
+template <int NW, int K0S, int MODE, bool ROLL = false, bool PW = false>
 __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsigned char* ring_lds, float* bias_lds, long long* prof,
                                               const float* am_w, int32_t* am_best, int32_t* am_pairs, int32_t* am_slot,
                                               int32_t* am_count, int am_epoch, int am_B, int am_W, int am_A, int am_R, int am_flags,
@@ -501,6 +554,11 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
 #endif
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (PW && wave == NW) {
+        static_assert(!PW || (NW == 4 && MODE == 2 && !ROLL), "producer wave: the backward chain on 64-row tiles");
+        bf_ring_producer(p.stream, p.n_stages, ring_lds, lane, 1);       // (one barrier in front of the stage entries: the bias copy's)
+        return;
+    }
     const int m = lane & 15, q = lane >> 4;
     const int row = row0 + 16 * wave + m;
     const bool row_ok = row < p.rows;
@@ -515,8 +573,10 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     ring.t_entry = 0; ring.t_dma = 0;
 #endif
     // the stream starts before the input rows are assembled
-    bf_ring_issue<NW>(ring, 0, 0);
-    bf_ring_issue<NW>(ring, 1, 1);
+    if (!PW) {
+        bf_ring_issue<NW>(ring, 0, 0);
+        bf_ring_issue<NW>(ring, 1, 1);
+    }
     // biases -> registers, [step][256] (zeros beyond a step's columns and for steps without bias): every load issued here, in one go
     // -- compile-time step indices: as a loop over (step, column) every iteration read the step's pointer and width from the
     // argument block per LANE and waited for each of its three dependent loads with vmcnt(0), i.e. also for the weight stages just
@@ -670,7 +730,7 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     // ---- first step ---------------------------------------------------------------------------------------------------------------
     BF_T(0)
     bf_acc_init<16>(acc, bias_lds, q);
-    bf_wide_step<NW, K0S, 0>(acc, x, ring, lane);
+    bf_wide_step<NW, K0S, 0, PW>(acc, x, ring, lane);
     BF_T(1)
     bf_wide_epilogue<MODE>(acc, x, p.step[0], p.rows, row, row_ok, bits_idx, q, keep);
     BF_T(2)
@@ -716,7 +776,7 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
         keep = ~0ull;
         if (MODE == 2 && p.step[s].bits_in != nullptr) keep = p.step[s].bits_in[bits_idx];
         bf_acc_init<16>(acc, bias_lds + s * BF_WIDE, q);
-        bf_wide_step<NW, 8, MODE != 0 ? BF_SAVE_VMEM : 0>(acc, x, ring, lane);
+        bf_wide_step<NW, 8, MODE != 0 ? BF_SAVE_VMEM : 0, PW>(acc, x, ring, lane);
         BF_T(3)
         bf_wide_epilogue<MODE>(acc, x, p.step[s], p.rows, row, row_ok, bits_idx, q, keep);
         BF_T(4)
@@ -828,6 +888,16 @@ __global__ __launch_bounds__(256, 1) void mlp_chain_bf_roll_kernel(BfMulti m) {
     bf_chain_body<4, 1, 2, true>(m.c[0], (int)blockIdx.x * BF_TM, lds, bias_lds, m.prof, m.td.weights, m.td.best_io, m.td.pairs_out,
                                  m.td.row_slot, m.td.count, m.td.epoch, m.td.B, m.td.W, m.td.A, m.td.R,
                                  (m.td.diag_only | (m.td.fma_scal << 1) | (m.td.bmajor << 2)), m.tdb);
+}
+
+// the backward chain on 64-row tiles with a producer wave (320 work-items, one workgroup per CU)
+__global__ __launch_bounds__(320, 1) void mlp_chain_bf_pw_kernel(BfMulti m) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BF_LDS_BYTES];
+    kernarg_warm<sizeof(BfMulti)>();
+    float* bias_lds = reinterpret_cast<float*>(lds + BF_RING * BF_STAGE_BYTES);
+    bf_chain_body<4, 1, 2, false, true>(m.c[0], (int)blockIdx.x * BF_TM, lds, bias_lds, m.prof, m.td.weights, m.td.best_io, m.td.pairs_out,
+                                        m.td.row_slot, m.td.count, m.td.epoch, m.td.B, m.td.W, m.td.A, m.td.R,
+                                        (m.td.diag_only | (m.td.fma_scal << 1) | (m.td.bmajor << 2)), m.tdb);
 }
 
 __global__ __launch_bounds__(128, 1) void mlp_chain_bf32_kernel(BfMulti m) {

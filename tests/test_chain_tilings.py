@@ -208,7 +208,7 @@ if os.environ.get("TILING_DEEP"):     # three hidden layers: the backward chain 
     cases = [(4, 32, 5, 2, 4, (256, 256, 256)), (5, 16, 7, 3, 6, (256, 256))]
 if os.environ.get("TILING_CASES"):
     cases = [cases[int(i)] for i in os.environ["TILING_CASES"].split(",")]
-rows_seen, dual_seen, roll_seen = [], [], []
+rows_seen, dual_seen, roll_seen, pw_seen = [], [], [], []
 for B, W, D, R, A, arch in cases:
     ctx = ops.QNetContext(D, R, A, arch, B, W, lib=lib)
     ctx.set_lazy_targets(2)
@@ -227,6 +227,7 @@ for B, W, D, R, A, arch in cases:
     rows_seen.append(ctx.lazy_target_rows(po))
     dual_seen.append((ctx.last_step_bf16() >> 6) & 1)
     roll_seen.append((ctx.last_step_bf16() >> 7) & 1)
+    pw_seen.append((ctx.last_step_bf16() >> 8) & 1)
     # the same step as the agents issue it -- no parity outputs requested: the TD stage may then run inside the backward launch
     out2 = ops.envelope_update(ctx, po, pt, grads, m, v, obs, nobs, act, rew, done, w, gamma=0.98, lr=3e-4, adam_step=2,
                                max_grad_norm=1.0, homotopy_lambda=0.3)
@@ -236,11 +237,12 @@ for B, W, D, R, A, arch in cases:
     ctx.close()
 print("DUAL_STEPS", sum(dual_seen))
 print("ROLL_STEPS", sum(roll_seen))
+print("PW_STEPS", sum(pw_seen))
 print("ARGMAX_DIGEST", h.hexdigest(), rows_seen)
 """
 
 
-def _argmax_digest(mode, extra_env, dual_steps=None, roll_steps=None):
+def _argmax_digest(mode, extra_env, dual_steps=None, roll_steps=None, pw_steps=None):
     r = subprocess.run([sys.executable, "-c", _ARGMAX_SNIPPET, ROOT, mode], capture_output=True, text=True, timeout=1500,
                        env=dict(os.environ, MORL_BF_MIN_ROWS="0", MORL_LAZY_MIN_ROWS="0", **extra_env), cwd=ROOT)
     assert r.returncode == 0 and "ARGMAX_DIGEST" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
@@ -250,6 +252,9 @@ def _argmax_digest(mode, extra_env, dual_steps=None, roll_steps=None):
     if roll_steps is not None:
         seen = int(r.stdout.split("ROLL_STEPS")[1].split()[0])
         assert (seen > 0) == roll_steps, (seen, roll_steps)
+    if pw_steps is not None:
+        seen = int(r.stdout.split("PW_STEPS")[1].split()[0])
+        assert (seen > 0) == pw_steps, (seen, pw_steps)
     return r.stdout.split("ARGMAX_DIGEST")[1].strip()
 
 
@@ -306,3 +311,16 @@ def test_rolling_epilogues_give_the_bits_of_the_step_end_epilogues():
 @pytest.mark.gpu
 def test_rolling_epilogues_give_the_bits_of_the_step_end_epilogues_on_the_gpu():
     assert _argmax_digest("gpu", {"MORL_BF_ROLL": "0"}, roll_steps=False) == _argmax_digest("gpu", {"MORL_BF_ROLL": "1"}, roll_steps=True)
+
+
+def test_producer_wave_gives_the_bits_of_the_self_fed_chain():
+    """``MORL_BF_PW=1``: the backward chain's 64-row launch runs 320 work-items -- a fifth wave issues every piece of the weight ring and
+    waits for it, the four MFMA waves issue none (csrc/mlp_chain_bf.h: bf_ring_producer).  Same stream, same products, same order: the
+    same bits; what the test pins is the hand-over (barrier counts, buffer reuse) on ragged tiles and on two and three hidden layers."""
+    base = {"HIPSIM_CUS": "2", "MORL_BFN_MAX_ROWS": "0", "TILING_DEEP": "1"}
+    assert _argmax_digest("sim", dict(base, MORL_BF_PW="0"), pw_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_PW="1"), pw_steps=True)
+
+
+@pytest.mark.gpu
+def test_producer_wave_gives_the_bits_of_the_self_fed_chain_on_the_gpu():
+    assert _argmax_digest("gpu", {"MORL_BF_PW": "0"}, pw_steps=False) == _argmax_digest("gpu", {"MORL_BF_PW": "1"}, pw_steps=True)
