@@ -563,6 +563,11 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     const int row = row0 + 16 * wave + m;
     const bool row_ok = row < p.rows;
     const size_t bits_idx = (size_t)((row0 >> 4) + wave) * 64 + lane;        // (the same word whichever tile size carried the row)
+#if defined(BF_PRIO_T)
+    if (MODE == 1) __builtin_amdgcn_s_setprio(3);       // (development A/B: the training tiles of a forward launch before the no-grad tiles)
+#elif defined(BF_PRIO_N)
+    if (MODE == 0) __builtin_amdgcn_s_setprio(3);
+#endif
 
     BfRing ring;
     ring.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.stream, 0, p.n_stages * BF_STAGE_BYTES, 0x00020000);

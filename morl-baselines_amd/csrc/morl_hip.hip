@@ -861,6 +861,23 @@ static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStr
         fprintf(stderr, "[bf_prof] %d tiles x %d waves, %s: prologue %.0f | step 0: mfma loop %.0f epilogue %.0f | wide steps: mfma loops %.0f epilogues %.0f | "
                 "head + drain %.0f | of which stage-entry waits %.0f, DMA issue %.0f | total %.0f cycles per wave\n",
                 tiles, nw, chains[0].step[0].bits_in ? "backward" : "forward", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[9] - a[8]);
+        if (n == 2 && !dual) {
+            // the two chains of a forward launch apart (tile_start[1] = first tile of the second), start / end stamps relative to the launch's first
+            long long t0 = h[8];
+            for (int w = 0; w < tiles * nw; ++w) t0 = std::min(t0, h[(size_t)w * BF_PROF_SLOTS + 8]);
+            for (int qn = 0; qn < 2; ++qn) {
+                const int w0 = m.tile_start[qn] * nw, w1 = m.tile_start[qn + 1] * nw;
+                double b[BF_PROF_SLOTS] = {0}, st = 0, en = 0, en_max = 0;
+                for (int w = w0; w < w1; ++w) {
+                    for (int i = 0; i < BF_PROF_SLOTS; ++i) b[i] += (double)h[(size_t)w * BF_PROF_SLOTS + i] / (w1 - w0);
+                    st += (double)(h[(size_t)w * BF_PROF_SLOTS + 8] - t0) / (w1 - w0);
+                    en += (double)(h[(size_t)w * BF_PROF_SLOTS + 9] - t0) / (w1 - w0);
+                    en_max = std::max(en_max, (double)(h[(size_t)w * BF_PROF_SLOTS + 9] - t0));
+                }
+                fprintf(stderr, "[bf_prof]   chain %d: prologue %.0f | step 0 %.0f + %.0f | wide %.0f + %.0f | head + drain %.0f | entry waits %.0f | total %.0f | mean start %.0f, mean end %.0f, last end %.0f\n",
+                        qn, b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[9] - b[8], st, en, en_max);
+            }
+        }
     }
 #endif
     return timing_close(c, slot, s);
