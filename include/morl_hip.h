@@ -213,7 +213,8 @@ int morl_ctx_set_exact_f32(morl_ctx* ctx, int enable);
  * chain (mlp_chain_bfn.h: six split products, fp32-class) rather than on the f32 tiles; bit 6 = the two online forward passes ran as
  * pairs of 64-row tiles sharing every weight fragment (mlp_chain_bf2.h, MORL_BF_DUAL=1: the same bits as the separate tiles); bit 7 =
  * the backward chain ran with rolling epilogues over a pair-major stream (mlp_chain_bf_roll.h, MORL_BF_ROLL=1: the same bits); bit 8 =
- * the backward chain's weight ring was issued by a producer wave (mlp_chain_bf_pw_kernel: the default for one-round 64-row launches). */
+ * the backward chain's weight ring was issued by a producer wave (mlp_chain_bf_pw_kernel / mlp_chain_bf32_pw_kernel: the default for
+ * one-round 64-row launches and for 32-row launches); bit 9 = the forward launch's too (mlp_chain_bf_fwd_pw_kernel: one-round launches). */
 int morl_ctx_last_step_bf16(morl_ctx* ctx);
 int morl_ctx_backpressure_seconds(morl_ctx* ctx, double* seconds);
 int morl_ctx_lazy_target_rows(morl_ctx* ctx, int* rows, void* stream);

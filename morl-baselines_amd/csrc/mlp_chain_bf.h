@@ -435,14 +435,14 @@ __device__ __forceinline__ void bf_wide_step(f32x4 (&acc)[16], const bf_u32x4 (&
 }
 
 // The narrow last step (N <= 32: NT tiles) over 8 k-steps: 24 / (3 NT) k-steps per stage.
-template <int NW, int NT, int EXTRA0>
+template <int NW, int NT, int EXTRA0, bool PW = false>
 __device__ __forceinline__ void bf_head_step(f32x4 (&acc)[2], const bf_u32x4 (&x)[8][3], BfRing& ring, int lane) {
     constexpr int KS_PER_STAGE = BF_STAGE_BLOCKS / (3 * NT);
     constexpr int pw[6] = {2, 1, 0, 1, 0, 0}, px[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
     for (int s0 = 0; s0 < 8; s0 += KS_PER_STAGE) {
         BF_PIN();
-        const unsigned char* base = bf_stage_begin<NW, EXTRA0>(ring) + lane * 16;       // (one or two stages: both behind the epilogue's stores)
+        const unsigned char* base = (PW ? bf_stage_enter_pw(ring) : bf_stage_begin<NW, EXTRA0>(ring)) + lane * 16;       // (one or two stages: both behind the epilogue's stores)
         bf_u32x4 f[KS_PER_STAGE][NT][3];
 #pragma unroll
         for (int ks = 0; ks < KS_PER_STAGE; ++ks)
@@ -555,7 +555,7 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (PW && wave == NW) {
-        static_assert(!PW || (NW == 4 && MODE == 2 && !ROLL), "producer wave: the backward chain on 64-row tiles");
+        static_assert(!PW || !ROLL, "producer wave: not with rolling epilogues");
         bf_ring_producer(p.stream, p.n_stages, ring_lds, lane, 1);       // (one barrier in front of the stage entries: the bias copy's)
         return;
     }
@@ -791,8 +791,8 @@ __device__ __forceinline__ void bf_chain_body(const BfChain& p, int row0, unsign
     if (p.head) {
         const BfStep& st = p.step[p.n_steps - 1];
         bf_acc_init<2>(hacc, bias_lds + (p.n_steps - 1) * BF_WIDE, q);
-        if (st.N > 16) bf_head_step<NW, 2, MODE != 0 ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
-        else bf_head_step<NW, 1, MODE != 0 ? BF_SAVE_VMEM : 0>(hacc, x, ring, lane);
+        if (st.N > 16) bf_head_step<NW, 2, MODE != 0 ? BF_SAVE_VMEM : 0, PW>(hacc, x, ring, lane);
+        else bf_head_step<NW, 1, MODE != 0 ? BF_SAVE_VMEM : 0, PW>(hacc, x, ring, lane);
         if (st.out != nullptr && row_ok) {
 #pragma unroll
             for (int T = 0; T < 2; ++T)
@@ -854,7 +854,7 @@ constexpr int BF_LDS_BYTES = BF_RING * BF_STAGE_BYTES + BF_MAX_STEPS * BF_WIDE *
 // grid: one workgroup per (16 NW)-row tile over the launch's chains; two workgroups per CU.  NW = 4 (64-row tiles) when that fills
 // the chip twice over (the two forward passes of a step: 512 tiles); NW = 2 (32-row tiles, 128 work-items) for launches of fewer
 // tiles (the backward chain: 256 64-row tiles would leave ONE workgroup per CU, nothing to cover its barriers and epilogues)
-template <int NW>
+template <int NW, bool PW = false>
 __device__ __forceinline__ void mlp_chain_bf_entry(const BfMulti& m, unsigned char* lds) {
     const int tile = (int)blockIdx.x;
     int qn = 0;
@@ -868,13 +868,13 @@ __device__ __forceinline__ void mlp_chain_bf_entry(const BfMulti& m, unsigned ch
               (m.td.diag_only | (m.td.fma_scal << 1) | (m.td.bmajor << 2)), m.tdb
     const int mode = p.step[0].bits_in != nullptr ? 2 : (p.step[0].out != nullptr || p.step[0].bits_out != nullptr) ? 1 : 0;
     if (p.k0_steps == 1) {
-        if (mode == 2) bf_chain_body<NW, 1, 2>(p, row0, lds, bias_lds, m.prof, BF_AM);
-        else if (mode == 1) bf_chain_body<NW, 1, 1>(p, row0, lds, bias_lds, m.prof, BF_AM);
-        else bf_chain_body<NW, 1, 0>(p, row0, lds, bias_lds, m.prof, BF_AM);
+        if (mode == 2) bf_chain_body<NW, 1, 2, false, PW>(p, row0, lds, bias_lds, m.prof, BF_AM);
+        else if (mode == 1) bf_chain_body<NW, 1, 1, false, PW>(p, row0, lds, bias_lds, m.prof, BF_AM);
+        else bf_chain_body<NW, 1, 0, false, PW>(p, row0, lds, bias_lds, m.prof, BF_AM);
     } else {
-        if (mode == 2) bf_chain_body<NW, 2, 2>(p, row0, lds, bias_lds, m.prof, BF_AM);
-        else if (mode == 1) bf_chain_body<NW, 2, 1>(p, row0, lds, bias_lds, m.prof, BF_AM);
-        else bf_chain_body<NW, 2, 0>(p, row0, lds, bias_lds, m.prof, BF_AM);
+        if (mode == 2) bf_chain_body<NW, 2, 2, false, PW>(p, row0, lds, bias_lds, m.prof, BF_AM);
+        else if (mode == 1) bf_chain_body<NW, 2, 1, false, PW>(p, row0, lds, bias_lds, m.prof, BF_AM);
+        else bf_chain_body<NW, 2, 0, false, PW>(p, row0, lds, bias_lds, m.prof, BF_AM);
     }
 }
 
@@ -901,6 +901,33 @@ __global__ __launch_bounds__(320, 1) void mlp_chain_bf_pw_kernel(BfMulti m) {
     kernarg_warm<sizeof(BfMulti)>();
     float* bias_lds = reinterpret_cast<float*>(lds + BF_RING * BF_STAGE_BYTES);
     bf_chain_body<4, 1, 2, false, true>(m.c[0], (int)blockIdx.x * BF_TM, lds, bias_lds, m.prof, m.td.weights, m.td.best_io, m.td.pairs_out,
+                                        m.td.row_slot, m.td.count, m.td.epoch, m.td.B, m.td.W, m.td.A, m.td.R,
+                                        (m.td.diag_only | (m.td.fma_scal << 1) | (m.td.bmajor << 2)), m.tdb);
+}
+
+// the forward launch in its one-round form (at most a 64-row tile per CU: one workgroup per CU, one MFMA wave per SIMD) with the producer
+// wave: whichever chains the launch carries (no-grad with the arg-max at the end -- the producer has ended by then: a barrier waits for
+// the surviving waves --, training)
+__global__ __launch_bounds__(320, 1) void mlp_chain_bf_fwd_pw_kernel(BfMulti m) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BF_LDS_BYTES];
+    kernarg_warm<sizeof(BfMulti)>();
+    mlp_chain_bf_entry<4, true>(m, lds);
+}
+
+// ... the same on 32-row tiles (forward launches of fewer 64-row tiles than CUs: two MFMA waves + the producer)
+__global__ __launch_bounds__(192, 1) void mlp_chain_bf32_fwd_pw_kernel(BfMulti m) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BF_LDS_BYTES];
+    kernarg_warm<sizeof(BfMulti)>();
+    mlp_chain_bf_entry<2, true>(m, lds);
+}
+
+// ... and on 32-row tiles (launches of fewer 64-row tiles than CUs): two MFMA waves + the producer, 192 work-items -- here every MFMA
+// wave issued TWELVE pieces per stage
+__global__ __launch_bounds__(192, 1) void mlp_chain_bf32_pw_kernel(BfMulti m) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BF_LDS_BYTES];
+    kernarg_warm<sizeof(BfMulti)>();
+    float* bias_lds = reinterpret_cast<float*>(lds + BF_RING * BF_STAGE_BYTES);
+    bf_chain_body<2, 1, 2, false, true>(m.c[0], (int)blockIdx.x * 32, lds, bias_lds, m.prof, m.td.weights, m.td.best_io, m.td.pairs_out,
                                         m.td.row_slot, m.td.count, m.td.epoch, m.td.B, m.td.W, m.td.A, m.td.R,
                                         (m.td.diag_only | (m.td.fma_scal << 1) | (m.td.bmajor << 2)), m.tdb);
 }

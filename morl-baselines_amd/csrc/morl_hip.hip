@@ -252,7 +252,10 @@ struct morl_ctx {
     bool last_roll = false;              // the last step's backward chain ran with rolling epilogues
     int bf_pw = 1;                       // MORL_BF_PW=0: the backward chain's 64-row launch WITHOUT its producer wave (mlp_chain_bf_pw_kernel: a fifth wave
                                          //   issues the weight ring) -- the A/B leg; the producer form runs when the launch is one round of the chip
-    bool last_pw = false;
+    bool last_pw = false, last_fwd_pw = false;
+    int bf_pw_fwd32 = 1;                 // MORL_BF_PW_FWD32=0: ... NOT for forward launches on 32-row tiles (mlp_chain_bf32_fwd_pw_kernel)
+    int bf_pw_fwd = 1;                   // MORL_BF_PW_FWD=0: ... NOT for forward launches of one round (mlp_chain_bf_fwd_pw_kernel)
+    int bf_pw32 = 1;                     // MORL_BF_PW32=0: ... NOT on the 32-row tiles of launches with fewer 64-row tiles than CUs (mlp_chain_bf32_pw_kernel)
     int bf_dual = 0;                     // MORL_BF_DUAL=1: the two online forward passes as tile pairs sharing the weight fragments (mlp_chain_bf2.h)
     int bf_dual_min_tiles = 0;           // MORL_BF_DUAL_MIN_TILES: ... from this many tile pairs on
     int bfn_eager3 = 1;                  // MORL_BFN_EAGER3=0: the target pass of an eagerly evaluated few-row step as a launch of its own on the
@@ -480,6 +483,9 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     if (const char* e = getenv("MORL_BFN_TARGETS")) c->bfn_targets = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BFN_MAX_ROWS")) c->bfn_max_rows = atoll(e);
     if (const char* e = getenv("MORL_BF_PW")) c->bf_pw = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("MORL_BF_PW_FWD32")) c->bf_pw_fwd32 = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("MORL_BF_PW_FWD")) c->bf_pw_fwd = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("MORL_BF_PW32")) c->bf_pw32 = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BF_ROLL")) c->bf_roll = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BF_DUAL")) c->bf_dual = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BF_DUAL_MIN_TILES")) c->bf_dual_min_tiles = atoi(e);
@@ -839,11 +845,16 @@ static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStr
     if (dual) c->last_dual = true;
     // (one round: the producer form is one 320-work-item workgroup per CU; a launch of more tiles than CUs keeps the two co-resident
     // 256-work-item workgroups of mlp_chain_bf_kernel)
-    const bool pw = backward && !roll && c->bf_pw && tm == BF_TM && tiles <= c->num_cus;
+    const bool pw = backward && !roll && c->bf_pw && ((tm == BF_TM && tiles <= c->num_cus) || (small && c->bf_pw32));
+    const bool fwd_pw = !backward && !dual && !tdb && c->bf_pw_fwd && ((tm == BF_TM && tiles <= c->num_cus) || (small && c->bf_pw_fwd32));
+    if (fwd_pw) c->last_fwd_pw = true;
     if (roll) c->last_roll = true;
     if (pw) c->last_pw = true;
     if (dual) hipLaunchKernelGGL(mlp_chain_bf2_kernel, dim3(tiles / 2), dim3(256), 0, s, m);
     else if (roll) hipLaunchKernelGGL(mlp_chain_bf_roll_kernel, dim3(tiles), dim3(256), 0, s, m);
+    else if (fwd_pw && small) hipLaunchKernelGGL(mlp_chain_bf32_fwd_pw_kernel, dim3(tiles), dim3(192), 0, s, m);
+    else if (fwd_pw) hipLaunchKernelGGL(mlp_chain_bf_fwd_pw_kernel, dim3(tiles), dim3(320), 0, s, m);
+    else if (pw && small) hipLaunchKernelGGL(mlp_chain_bf32_pw_kernel, dim3(tiles), dim3(192), 0, s, m);
     else if (pw) hipLaunchKernelGGL(mlp_chain_bf_pw_kernel, dim3(tiles), dim3(320), 0, s, m);
     else if (small) hipLaunchKernelGGL(mlp_chain_bf32_kernel, dim3(tiles), dim3(128), 0, s, m);
     else hipLaunchKernelGGL(mlp_chain_bf_kernel, dim3(tiles), dim3(256), 0, s, m);
@@ -1291,7 +1302,7 @@ extern "C" int morl_envelope_prepare(morl_ctx* c, const float* params_online, co
 extern "C" int morl_ctx_last_step_bf16(morl_ctx* c) {
     if (!c) return fail(MORL_ERR_ARG, "ctx is NULL");
     return (c->bits_bf ? 1 : 0) | (c->dw_bf_last ? 2 : 0) | ((c->lz_last && c->lz_last_big) ? 4 : 0) |
-           ((c->lz_last && c->lz_count_missed) ? 8 : 0) | (c->lz_count_misses > 0 ? 16 : 0) | (c->lz_last_bfn ? 32 : 0) | (c->last_dual ? 64 : 0) | (c->last_roll ? 128 : 0) | (c->last_pw ? 256 : 0);
+           ((c->lz_last && c->lz_count_missed) ? 8 : 0) | (c->lz_count_misses > 0 ? 16 : 0) | (c->lz_last_bfn ? 32 : 0) | (c->last_dual ? 64 : 0) | (c->last_roll ? 128 : 0) | (c->last_pw ? 256 : 0) | (c->last_fwd_pw ? 512 : 0);
 }
 
 extern "C" int morl_ctx_set_exact_f32(morl_ctx* c, int enable) {
@@ -2058,6 +2069,7 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
     c->last_dual = false;
     c->last_roll = false;
     c->last_pw = false;
+    c->last_fwd_pw = false;
     c->last_step_W = W;
     timing_begin_step(c);
 

@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-HOT = ("mlp_chain_bf_kernel", "mlp_chain_bf32_kernel", "mlp_chain_bf2_kernel", "mlp_chain_bf_roll_kernel", "mlp_chain_bf_pw_kernel", "mlp_chain_bfn_kernel", "mlp_chain_bfn16_kernel", "dw_bf_kernel", "mlp_chain4_kernel", "mlp_chain16_kernel", "dw_tiles_kernel",
+HOT = ("mlp_chain_bf_kernel", "mlp_chain_bf32_kernel", "mlp_chain_bf2_kernel", "mlp_chain_bf_roll_kernel", "mlp_chain_bf_pw_kernel", "mlp_chain_bf32_pw_kernel", "mlp_chain_bf_fwd_pw_kernel", "mlp_chain_bf32_fwd_pw_kernel", "mlp_chain_bfn_kernel", "mlp_chain_bfn16_kernel", "dw_bf_kernel", "mlp_chain4_kernel", "mlp_chain16_kernel", "dw_tiles_kernel",
        "step_prologue_kernel", "clip_adam_kernel", "grad_reduce_ranges_kernel")
 
 

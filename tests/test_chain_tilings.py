@@ -208,7 +208,7 @@ if os.environ.get("TILING_DEEP"):     # three hidden layers: the backward chain 
     cases = [(4, 32, 5, 2, 4, (256, 256, 256)), (5, 16, 7, 3, 6, (256, 256))]
 if os.environ.get("TILING_CASES"):
     cases = [cases[int(i)] for i in os.environ["TILING_CASES"].split(",")]
-rows_seen, dual_seen, roll_seen, pw_seen = [], [], [], []
+rows_seen, dual_seen, roll_seen, pw_seen, fpw_seen = [], [], [], [], []
 for B, W, D, R, A, arch in cases:
     ctx = ops.QNetContext(D, R, A, arch, B, W, lib=lib)
     ctx.set_lazy_targets(2)
@@ -228,6 +228,7 @@ for B, W, D, R, A, arch in cases:
     dual_seen.append((ctx.last_step_bf16() >> 6) & 1)
     roll_seen.append((ctx.last_step_bf16() >> 7) & 1)
     pw_seen.append((ctx.last_step_bf16() >> 8) & 1)
+    fpw_seen.append((ctx.last_step_bf16() >> 9) & 1)
     # the same step as the agents issue it -- no parity outputs requested: the TD stage may then run inside the backward launch
     out2 = ops.envelope_update(ctx, po, pt, grads, m, v, obs, nobs, act, rew, done, w, gamma=0.98, lr=3e-4, adam_step=2,
                                max_grad_norm=1.0, homotopy_lambda=0.3)
@@ -238,11 +239,12 @@ for B, W, D, R, A, arch in cases:
 print("DUAL_STEPS", sum(dual_seen))
 print("ROLL_STEPS", sum(roll_seen))
 print("PW_STEPS", sum(pw_seen))
+print("FPW_STEPS", sum(fpw_seen))
 print("ARGMAX_DIGEST", h.hexdigest(), rows_seen)
 """
 
 
-def _argmax_digest(mode, extra_env, dual_steps=None, roll_steps=None, pw_steps=None):
+def _argmax_digest(mode, extra_env, dual_steps=None, roll_steps=None, pw_steps=None, fpw_steps=None):
     r = subprocess.run([sys.executable, "-c", _ARGMAX_SNIPPET, ROOT, mode], capture_output=True, text=True, timeout=1500,
                        env=dict(os.environ, MORL_BF_MIN_ROWS="0", MORL_LAZY_MIN_ROWS="0", **extra_env), cwd=ROOT)
     assert r.returncode == 0 and "ARGMAX_DIGEST" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
@@ -255,6 +257,9 @@ def _argmax_digest(mode, extra_env, dual_steps=None, roll_steps=None, pw_steps=N
     if pw_steps is not None:
         seen = int(r.stdout.split("PW_STEPS")[1].split()[0])
         assert (seen > 0) == pw_steps, (seen, pw_steps)
+    if fpw_steps is not None:
+        seen = int(r.stdout.split("FPW_STEPS")[1].split()[0])
+        assert (seen > 0) == fpw_steps, (seen, fpw_steps)
     return r.stdout.split("ARGMAX_DIGEST")[1].strip()
 
 
@@ -324,3 +329,42 @@ def test_producer_wave_gives_the_bits_of_the_self_fed_chain():
 @pytest.mark.gpu
 def test_producer_wave_gives_the_bits_of_the_self_fed_chain_on_the_gpu():
     assert _argmax_digest("gpu", {"MORL_BF_PW": "0"}, pw_steps=False) == _argmax_digest("gpu", {"MORL_BF_PW": "1"}, pw_steps=True)
+
+
+def test_producer_wave_on_32_row_tiles_gives_the_bits_of_the_self_fed_chain():
+    """``MORL_BF_PW32=1``: the producer wave also on the 32-row tiles that backward launches of fewer 64-row tiles than CUs take (192
+    work-items: two MFMA waves + the producer) -- every case the emulated 256-CU chip runs with ``MORL_BFN_MAX_ROWS=0``."""
+    base = {"MORL_BFN_MAX_ROWS": "0", "TILING_DEEP": "1"}
+    assert _argmax_digest("sim", dict(base, MORL_BF_PW32="0"), pw_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_PW32="1"), pw_steps=True)
+
+
+@pytest.mark.gpu
+def test_producer_wave_on_32_row_tiles_gives_the_bits_of_the_self_fed_chain_on_the_gpu():
+    # (the 256 x 64 case runs the 64-row producer form in both legs; 256 x 32 -- 8 192 rows -- is the 32-row launch)
+    assert _argmax_digest("gpu", {"MORL_BF_PW32": "0", "MORL_BF_PW": "1"}) == _argmax_digest("gpu", {"MORL_BF_PW32": "1", "MORL_BF_PW": "1"})
+
+
+def test_producer_wave_in_the_forward_launch_gives_the_bits_of_the_self_fed_chain():
+    """``MORL_BF_PW_FWD=1``: a forward launch of one round (at most a 64-row tile per CU: one workgroup per CU) with the producer wave --
+    no-grad chain with the arg-max at its end (the producer has ended by then) and training chain.  An emulated chip of four CUs: the
+    two chains' four tiles are one round."""
+    base = {"HIPSIM_CUS": "4", "MORL_BFN_MAX_ROWS": "0", "TILING_DEEP": "1"}
+    assert _argmax_digest("sim", dict(base, MORL_BF_PW_FWD="0"), fpw_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_PW_FWD="1"), fpw_steps=True)
+
+
+@pytest.mark.gpu
+def test_producer_wave_in_the_forward_launch_gives_the_bits_of_the_self_fed_chain_on_the_gpu():
+    # (256 x 32: the forward launch's 2 x 128 tiles are one round)
+    assert _argmax_digest("gpu", {"MORL_BF_PW_FWD": "0"}, fpw_steps=False) == _argmax_digest("gpu", {"MORL_BF_PW_FWD": "1"}, fpw_steps=True)
+
+
+def test_producer_wave_in_the_forward_launch_on_32_row_tiles_gives_the_bits_of_the_self_fed_chain():
+    """``MORL_BF_PW_FWD32=1``: ... and forward launches on 32-row tiles (192 work-items), the emulated 256-CU chip's choice for every case
+    here."""
+    base = {"MORL_BFN_MAX_ROWS": "0", "TILING_DEEP": "1"}
+    assert _argmax_digest("sim", dict(base, MORL_BF_PW_FWD32="0"), fpw_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_PW_FWD32="1"), fpw_steps=True)
+
+
+@pytest.mark.gpu
+def test_producer_wave_in_the_forward_launch_on_32_row_tiles_gives_the_bits_of_the_self_fed_chain_on_the_gpu():
+    assert _argmax_digest("gpu", {"MORL_BF_PW_FWD32": "0"}) == _argmax_digest("gpu", {"MORL_BF_PW_FWD32": "1"})
