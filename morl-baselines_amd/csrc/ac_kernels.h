@@ -265,11 +265,10 @@ struct PostArgs {
 // layer).  32-bit arithmetic throughout -- three v_mul_lo_u32 per element: the splitmix64 finaliser of rounds 1-4 (three 64-bit
 // multiplies = a dozen quarter-rate instructions) was 8.5 of the 54 us of a LayerNorm / Dropout chain launch on MI355X
 // (profiles/r05_ln_chain_post_costs.txt).  Two rounds of a multiply-xorshift mixer (Wellons' lowbias32 constants) over the counter
-// Weyl-stepped into the seed; the reference draws its masks from torch's generator (nn.Dropout), so only the statistics matter --
+// Weyl-stepped into the MIXED seed (morl_device.h: dropout_seed_mix -- both seed words hashed first); the reference draws its masks from torch's generator (nn.Dropout), so only the statistics matter --
 // and that every kernel computing a mask uses THIS function (mlp_chain16.h's post-op stage does).
 __device__ __forceinline__ float ac_uniform(unsigned long long seed, unsigned long long idx) {
-    unsigned int x = (unsigned int)idx * 0x9E3779B9u + (unsigned int)seed;
-    x ^= (unsigned int)(seed >> 32);
+    unsigned int x = (unsigned int)idx * 0x9E3779B9u + dropout_seed_mix(seed);
     x ^= x >> 16; x *= 0x7FEB352Du;
     x ^= x >> 15; x *= 0x846CA68Bu;
     x ^= x >> 16;

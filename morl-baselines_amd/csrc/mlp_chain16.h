@@ -145,8 +145,7 @@ struct C16NoHook {
 // ac_kernels.h's ac_uniform (same bits: the keep masks of the per-layer path), repeated here because this header is also compiled
 // into the Envelope translation unit, which does not see ac_kernels.h
 __device__ __forceinline__ float c16_uniform(unsigned long long seed, unsigned long long idx) {
-    unsigned int x = (unsigned int)idx * 0x9E3779B9u + (unsigned int)seed;
-    x ^= (unsigned int)(seed >> 32);
+    unsigned int x = (unsigned int)idx * 0x9E3779B9u + dropout_seed_mix(seed);
     x ^= x >> 16; x *= 0x7FEB352Du;
     x ^= x >> 15; x *= 0x846CA68Bu;
     x ^= x >> 16;

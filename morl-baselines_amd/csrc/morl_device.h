@@ -26,6 +26,21 @@ __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane
 // entry.  A kernel whose prologue reads a large by-value argument block in several DEPENDENT batches -- pointer, then what hangs
 // off it, branch, next pointer -- otherwise pays a first-touch miss of the scalar cache per batch (0.3 - 0.5 us each on MI355X;
 // the 8-row chain's prologue: 3.6 -> 2.9 us with this and branch-free fetches, profiles/r05_target_rows_phases.txt).
+// The 64-bit Dropout stream seed folded to the 32-bit state of the counter hash (ac_kernels.h: ac_uniform, mlp_chain16.h: c16_uniform):
+// both words through a hash round of their own BEFORE the counter's Weyl step is added (a plain xor of the words made every pair of seeds
+// with hi ^ lo equal share one stream).  Uniform per launch: the compiler keeps it in scalar registers, outside the element loops.
+__device__ __forceinline__ unsigned int dropout_seed_mix(unsigned long long seed) {
+    unsigned int s = (unsigned int)seed ^ 0x9E3779B9u;
+    s ^= s >> 16; s *= 0x7FEB352Du;
+    s ^= s >> 15; s *= 0x846CA68Bu;
+    s ^= s >> 16;
+    unsigned int h = (unsigned int)(seed >> 32) + 0x85EBCA6Bu;
+    h ^= h >> 16; h *= 0x2C1B3C6Du;
+    h ^= h >> 12; h *= 0x297A2D39u;
+    h ^= h >> 15;
+    return s + (h | 1u) * 0xC2B2AE35u;
+}
+
 template <int BYTES>
 __device__ __forceinline__ void kernarg_warm() {
 #if defined(__AMDGCN__)
