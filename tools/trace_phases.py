@@ -16,12 +16,19 @@ for r in rows:
 steps = [s for s in steps[5:-1]]
 if not steps:
     sys.exit(f"no launch named *{OPENER}* opens a step in this trace")
-L = collections.Counter(len(s) for s in steps).most_common(1)[0][0]
-steps = [s for s in steps if len(s) == L]
-print(f"{len(steps)} steps of {L} launches")
-for k in range(L):
-    d = [s[k][1] for s in steps]
-    gap = [(s[k][2] - s[k - 1][3]) / 1e3 for s in steps] if k else [0.0]
-    print(f"{k:2d} {steps[0][k][0]:40s} {sum(d) / len(d):8.2f} us   gap before {sum(gap) / len(gap):6.2f} us")
-tot = [(s[-1][3] - s[0][2]) / 1e3 for s in steps]
-print(f"first start -> last end: {sum(tot) / len(tot):.1f} us")
+import statistics
+# the step shapes seen (a bench run mixes them: e.g. the stand-alone updates and the iterations of the prioritised loop, which carry the
+# tree update and the next iteration's sampling); per position the MEDIAN duration and the mean gap without its largest twentieth -- a trace has the odd multi-hundred-microsecond host hiccup
+for L, cnt in collections.Counter(len(s) for s in steps).most_common(2):
+    if cnt < 5:
+        continue
+    sel = [s for s in steps if len(s) == L]
+    print(f"{len(sel)} steps of {L} launches (medians)")
+    for k in range(L):
+        d = [s[k][1] for s in sel]
+        gap = [(s[k][2] - s[k - 1][3]) / 1e3 for s in sel] if k else [0.0]
+        gap = sorted(gap)[:max(1, len(gap) - max(1, len(gap) // 20))]          # (mean without the largest twentieth: the hiccups)
+        print(f"{k:2d} {sel[0][k][0]:40s} {statistics.median(d):8.2f} us   gap before {sum(gap) / len(gap):6.2f} us")
+    tot = [(s[-1][3] - s[0][2]) / 1e3 for s in sel]
+    print(f"first start -> last end: {statistics.median(tot):.1f} us (median), kernels {sum(statistics.median([s[k][1] for s in sel]) for k in range(L)):.1f} us")
+    print()
