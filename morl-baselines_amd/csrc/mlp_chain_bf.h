@@ -472,6 +472,16 @@ __device__ __forceinline__ void bf_acc_init(f32x4 (&acc)[NTILES], const float* b
 // `keep`: the step's mask word (bits_in), loaded by the caller at the START of the step -- a load inside the epilogue would be waited
 // for with vmcnt(0), i.e. behind both weight stages in flight (the first version did: one drained ring per layer).
 constexpr int BF_SAVE_VMEM = 17;
+// -(bit `pos` of `word`): v_bfe_i32's sign-extended one-bit field
+__device__ __forceinline__ int bf_bit_mask(int word, int pos) {
+#if defined(HIPSIM_EMULATED) || defined(BF_SHIFT_MASK)        // (BF_SHIFT_MASK: the A/B build of profiles/r06_mask_bfe_ab.txt)
+    return (word << (31 - pos)) >> 31;
+#else
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(word), "s"(pos));
+    return m;
+#endif
+}
 // ReLU as ONE instruction: max on the bit patterns as signed integers (positive floats are positive integers, everything with the
 // sign bit set -- negative values, -0 -- is a negative integer); fmaxf(a, 0) costs a second v_max (IEEE NaN quieting)
 __device__ __forceinline__ float bf_relu(float a) {
@@ -499,8 +509,9 @@ __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x
             if (MODE != 2 && st.relu) a = bf_relu(a);
             if (MODE == 2) {
                 // a &= -(bit k of keep): the sign-extended one-bit field is the AND mask (v_bfe_i32 + v_and)
-                const int m = ((k < 32 ? keep_lo : keep_hi) << (31 - (k & 31))) >> 31;
-                a = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & m);
+                // (as the instruction: written with shifts -- or as __builtin_amdgcn_sbfe -- hipcc turns the pair into v_and / v_cmp /
+                // s_nop / v_cndmask: four issue slots a value where these are two)
+                a = __builtin_bit_cast(float, __builtin_bit_cast(int, a) & bf_bit_mask(k < 32 ? keep_lo : keep_hi, k & 31));
             }
             if (MODE == 1) {
                 // after the ReLU the bit pattern is 0 or a positive integer: min(u, 1) is the sign bit (v_min_u32 + v_lshl_or)

@@ -374,6 +374,15 @@ static inline hipsim_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipsim_bf16x
     return d;
 }
 static inline void __builtin_amdgcn_s_barrier() { hipsim::block_barrier(); }
+// v_bfe_i32: the sign-extended bit field [offset, offset + width) of src
+static inline int __builtin_amdgcn_sbfe(int src, unsigned offset, unsigned width) {
+    offset &= 31u; width &= 31u;
+    if (width == 0) return 0;
+    const unsigned u = (unsigned)src >> offset;
+    const unsigned m = width >= 32 ? 0xffffffffu : ((1u << width) - 1u);
+    const unsigned f = u & m;
+    return (f >> (width - 1)) & 1u ? (int)(f | ~m) : (int)f;
+}
 #define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
 
 // LDS-DMA: lane l copies `size` bytes from its own global address to (first lane's LDS pointer) + l*size
