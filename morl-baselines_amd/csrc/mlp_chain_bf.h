@@ -506,7 +506,9 @@ __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x
         for (int e = 0; e < 8; ++e) {
             const int T = 2 * s + (e >> 2), r = e & 3, k = 4 * T + r;
             float a = acc[T][r];
-            if (MODE != 2 && st.relu) a = bf_relu(a);
+            // (a wide step of a forward chain is a hidden layer: ReLU, always -- bf_launch refuses anything else; under the step's run-time
+            // flag every value cost a v_max AND a v_cndmask)
+            if (MODE != 2) a = bf_relu(a);
             if (MODE == 2) {
                 // a &= -(bit k of keep): the sign-extended one-bit field is the AND mask (v_bfe_i32 + v_and)
                 // (as the instruction: written with shifts -- or as __builtin_amdgcn_sbfe -- hipcc turns the pair into v_and / v_cmp /
@@ -526,6 +528,9 @@ __device__ __forceinline__ void bf_wide_epilogue(const f32x4 (&acc)[16], bf_u32x
             // issued by every wave whatever its rows.  A wave that skipped them would see fewer vector-memory instructions in flight
             // than BF_SAVE_VMEM says, wait for too little at the next stage entry -- and the other waves read ITS share of the stage
             // after the barrier.
+            // (the row offset per pair of stores, as written: hoisted out of the loop -- one multiply instead of a branch, a scalar load
+            // and a multiply per pair -- the forward launch took 71.5 us instead of 70.0 on one box, profiles/r06_epilogue_variants.txt:
+            // what the co-resident tiles do to each other moves with every such change)
             const int voff = row_ok ? (row * st.ldout + 32 * s + 4 * q) * 4 : CH_OOB;
             __builtin_amdgcn_raw_buffer_store_b128(bf_u32x4{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
                                                             __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3])},

@@ -818,6 +818,10 @@ static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStr
     }
     int tiles = 0;
     for (int q = 0; q < n; ++q) {
+        // (bf_wide_epilogue applies the ReLU of a forward chain's wide steps without asking: every step but the head is a hidden layer)
+        if (chains[q].step[0].bits_in == nullptr)
+            for (int l = 0; l + (chains[q].head ? 1 : 0) < chains[q].n_steps; ++l)
+                if (!chains[q].step[l].relu) return fail(MORL_ERR_STATE, "internal: a wide step of a forward split-bf16 chain without ReLU");
         m.c[q] = chains[q];
         m.tile_start[q] = tiles;
         tiles += (chains[q].rows + tm - 1) / tm;
