@@ -256,6 +256,8 @@ struct morl_ctx {
     int bf_pw_fwd32 = 1;                 // MORL_BF_PW_FWD32=0: ... NOT for forward launches on 32-row tiles (mlp_chain_bf32_fwd_pw_kernel)
     int bf_pw_fwd = 1;                   // MORL_BF_PW_FWD=0: ... NOT for forward launches of one round (mlp_chain_bf_fwd_pw_kernel)
     int bf_pw32 = 1;                     // MORL_BF_PW32=0: ... NOT on the 32-row tiles of launches with fewer 64-row tiles than CUs (mlp_chain_bf32_pw_kernel)
+    int bf_t_first = 1;                  // MORL_BF_T_FIRST: the training pass's tiles in front of the no-grad pass's in the forward launch's grid -- 1: in one-round
+                                         //   launches (default), 0: never, 2: always
     int bf_dual = 0;                     // MORL_BF_DUAL=1: the two online forward passes as tile pairs sharing the weight fragments (mlp_chain_bf2.h)
     int bf_dual_min_tiles = 0;           // MORL_BF_DUAL_MIN_TILES: ... from this many tile pairs on
     int bfn_eager3 = 1;                  // MORL_BFN_EAGER3=0: the target pass of an eagerly evaluated few-row step as a launch of its own on the
@@ -487,6 +489,7 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     if (const char* e = getenv("MORL_BF_PW_FWD")) c->bf_pw_fwd = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BF_PW32")) c->bf_pw32 = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BF_ROLL")) c->bf_roll = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("MORL_BF_T_FIRST")) c->bf_t_first = atoi(e);
     if (const char* e = getenv("MORL_BF_DUAL")) c->bf_dual = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BF_DUAL_MIN_TILES")) c->bf_dual_min_tiles = atoi(e);
     if (const char* e = getenv("MORL_BFN_EAGER3")) c->bfn_eager3 = atoi(e) != 0 ? 1 : 0;
@@ -2128,6 +2131,17 @@ extern "C" int morl_envelope_update(morl_ctx* c, float* params_online, const flo
                 c->lz_last_bfn = true;          // (bit 5 of morl_ctx_last_step_bf16: the target network ran on the few-row split-bf16 chain)
                 if ((rc = bf_launch(c, three, 3, MORL_TIMED_FORWARD, s))) return rc;
             } else {
+                // The training pass's tiles FIRST in the grid when the launch is one round (a tile per CU at most): they are the longer ones
+                // (saves, sign bits) and the second half of a grid starts a microsecond behind the first -- 46.0 -> 45.2 us at 256 x 32.
+                // NOT when two tiles share a CU (the flagship): the older workgroup wins the matrix pipe, and with the training tile as the
+                // older one the no-grad tile is starved and finishes alone -- 77.7 against 71.5 us (profiles/r06_forward_chains_apart.txt;
+                // MORL_BF_T_FIRST=0 / 2: never / always, the A/B legs)
+                {
+                    long long t64 = 0;
+                    for (int qn = 0; qn < 2; ++qn) t64 += (fwd[qn].rows + BF_TM - 1) / BF_TM;
+                    if (!c->bf_dual && (c->bf_t_first == 2 || (c->bf_t_first == 1 && tile_rows == BF_TM && t64 <= (long long)c->num_cus)))
+                        std::swap(fwd[0], fwd[1]);
+                }
                 if ((rc = bf_launch(c, fwd, 2, MORL_TIMED_FORWARD2, s, fuse ? &amax_args : nullptr))) { c->lz_now = false; return rc; }
                 c->lz_argmax_done = fuse;
                 if (!c->lz_now && (rc = chain_forward(c, params_target, c->wt_target, next_obs, weights, B, W, 0, rows, false, c->qt, AR, s))) return rc;
