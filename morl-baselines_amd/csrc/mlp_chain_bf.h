@@ -281,6 +281,8 @@ __device__ __forceinline__ const unsigned char* bf_stage_enter_pw(BfRing& r) {
 // barrier (the MFMA waves are done with stage t - 1), stage t + 2 into the buffer that became free.  `pre_barriers`: workgroup barriers
 // the MFMA waves pass before their first stage entry.
 __device__ __forceinline__ void bf_ring_producer(const unsigned char* stream, int n_stages, unsigned char* ring_lds, int lane, int pre_barriers) {
+    // (the producer at raised priority -- s_setprio 3 -- changes nothing in the backward launch and costs the one-round forward launch
+    // 0.9 us: profiles/r06_producer_wave_ab.json)
     BfRing r;
     r.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)stream, 0, n_stages * BF_STAGE_BYTES, 0x00020000);
     r.lds = ring_lds;
