@@ -250,16 +250,13 @@ struct morl_ctx {
     bool bwd_pair_major = false;         // ... what the backward stream holds now
     const float* bf_split_src = nullptr; // ... the parameters it was split from
     bool last_roll = false;              // the last step's backward chain ran with rolling epilogues
-    int bf_pw = 1;                       // MORL_BF_PW=0: the backward chain's 64-row launch WITHOUT its producer wave (mlp_chain_bf_pw_kernel: a fifth wave
-                                         //   issues the weight ring) -- the A/B leg; the producer form runs when the launch is one round of the chip
+    int bf_pw = 15;                      // MORL_BF_PW: which chain launches with one MFMA wave per SIMD get a PRODUCER wave issuing their weight ring (bit mask, default
+                                         //   all): 1 backward on 64-row tiles, one round (mlp_chain_bf_pw_kernel); 2 backward on 32-row tiles (mlp_chain_bf32_pw_kernel);
+                                         //   4 forward on 64-row tiles, one round (mlp_chain_bf_fwd_pw_kernel); 8 forward on 32-row tiles (mlp_chain_bf32_fwd_pw_kernel)
     bool last_pw = false, last_fwd_pw = false;
-    int bf_pw_fwd32 = 1;                 // MORL_BF_PW_FWD32=0: ... NOT for forward launches on 32-row tiles (mlp_chain_bf32_fwd_pw_kernel)
-    int bf_pw_fwd = 1;                   // MORL_BF_PW_FWD=0: ... NOT for forward launches of one round (mlp_chain_bf_fwd_pw_kernel)
-    int bf_pw32 = 1;                     // MORL_BF_PW32=0: ... NOT on the 32-row tiles of launches with fewer 64-row tiles than CUs (mlp_chain_bf32_pw_kernel)
     int bf_t_first = 1;                  // MORL_BF_T_FIRST: the training pass's tiles in front of the no-grad pass's in the forward launch's grid -- 1: in one-round
                                          //   launches (default), 0: never, 2: always
     int bf_dual = 0;                     // MORL_BF_DUAL=1: the two online forward passes as tile pairs sharing the weight fragments (mlp_chain_bf2.h)
-    int bf_dual_min_tiles = 0;           // MORL_BF_DUAL_MIN_TILES: ... from this many tile pairs on
     int bfn_eager3 = 1;                  // MORL_BFN_EAGER3=0: the target pass of an eagerly evaluated few-row step as a launch of its own on the
                                          // f32 tiles instead of a third chain of the few-row forward launch (A/B)
     long long bfn_max_rows = 4096;       // chain launches of at most this many rows (over their chains) take the few-row split-bf16 chain
@@ -484,14 +481,10 @@ extern "C" int morl_ctx_create(morl_ctx** out, const morl_net_desc* net, int max
     if (const char* e = getenv("MORL_EXACT_F32")) c->bf_mode = atoi(e) != 0 ? 0 : 1;
     if (const char* e = getenv("MORL_BFN_TARGETS")) c->bfn_targets = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BFN_MAX_ROWS")) c->bfn_max_rows = atoll(e);
-    if (const char* e = getenv("MORL_BF_PW")) c->bf_pw = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("MORL_BF_PW_FWD32")) c->bf_pw_fwd32 = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("MORL_BF_PW_FWD")) c->bf_pw_fwd = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("MORL_BF_PW32")) c->bf_pw32 = atoi(e) != 0 ? 1 : 0;
+    if (const char* e = getenv("MORL_BF_PW")) c->bf_pw = atoi(e);
     if (const char* e = getenv("MORL_BF_ROLL")) c->bf_roll = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BF_T_FIRST")) c->bf_t_first = atoi(e);
     if (const char* e = getenv("MORL_BF_DUAL")) c->bf_dual = atoi(e) != 0 ? 1 : 0;
-    if (const char* e = getenv("MORL_BF_DUAL_MIN_TILES")) c->bf_dual_min_tiles = atoi(e);
     if (const char* e = getenv("MORL_BFN_EAGER3")) c->bfn_eager3 = atoi(e) != 0 ? 1 : 0;
     if (const char* e = getenv("MORL_BF_MIN_ROWS")) { c->bf_min_rows = atoll(e); c->bf_min_rows_env = true; }
 #undef ALLOC
@@ -847,13 +840,12 @@ static int bf_launch(morl_ctx* c, const BfChain* chains, int n, int kind, hipStr
                       chains[0].n_steps == chains[1].n_steps && chains[0].head && chains[1].head && chains[0].in_mode == 0 &&
                       chains[1].in_mode == 0 && chains[0].step[0].out == nullptr && chains[0].step[0].bits_out == nullptr &&
                       chains[0].step[0].bits_in == nullptr && chains[1].step[0].bits_in == nullptr && chains[0].x0_out == nullptr &&
-                      (chains[1].step[0].out != nullptr || chains[1].step[0].bits_out != nullptr) &&
-                      (long long)(tiles / 2) >= (long long)c->bf_dual_min_tiles;
+                      (chains[1].step[0].out != nullptr || chains[1].step[0].bits_out != nullptr);
     if (dual) c->last_dual = true;
     // (one round: the producer form is one 320-work-item workgroup per CU; a launch of more tiles than CUs keeps the two co-resident
     // 256-work-item workgroups of mlp_chain_bf_kernel)
-    const bool pw = backward && !roll && c->bf_pw && ((tm == BF_TM && tiles <= c->num_cus) || (small && c->bf_pw32));
-    const bool fwd_pw = !backward && !dual && !tdb && c->bf_pw_fwd && ((tm == BF_TM && tiles <= c->num_cus) || (small && c->bf_pw_fwd32));
+    const bool pw = backward && !roll && (((c->bf_pw & 1) && tm == BF_TM && tiles <= c->num_cus) || ((c->bf_pw & 2) && small));
+    const bool fwd_pw = !backward && !dual && !tdb && (((c->bf_pw & 4) && tm == BF_TM && tiles <= c->num_cus) || ((c->bf_pw & 8) && small));
     if (fwd_pw) c->last_fwd_pw = true;
     if (roll) c->last_roll = true;
     if (pw) c->last_pw = true;

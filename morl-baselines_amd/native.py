@@ -360,7 +360,7 @@ KNOWN_ENV = {
     "MORL_ARGMAX_IN_CHAIN": "1", "MORL_TD_IN_CHAIN": "1", "MORL_LAZY_MIN_ROWS": "4096 / 8192", "MORL_LAZY_BIG_ROWS": "6144",
     "MORL_AC_LN_CHAIN": "1", "MORL_CHAIN4": "1", "MORL_CHAIN16": "1", "MORL_AC_NMAJOR": "1", "MORL_AC_SCATTER_MAX": "1048576",
     "MORL_AC_ADAM_IN_DW": "1", "MORL_AC_HEADS_PAIRED": "1", "MORL_AC_HEADBWD_IN_CHAIN": "1", "MORL_RCCL_LIB": "",
-    "MORL_IPC_TIMEOUT_MS": "3000", "MORL_BFN_TARGETS": "0", "MORL_BFN_MAX_ROWS": "4096", "MORL_BFN_EAGER3": "1", "MORL_PER_SPLIT": "1", "MORL_BF_DUAL": "0", "MORL_BF_T_FIRST": "1", "MORL_BF_DUAL_MIN_TILES": "0", "MORL_BF_ROLL": "0", "MORL_BF_PW": "1", "MORL_BF_PW32": "1", "MORL_BF_PW_FWD": "1", "MORL_BF_PW_FWD32": "1",
+    "MORL_IPC_TIMEOUT_MS": "3000", "MORL_BFN_TARGETS": "0", "MORL_BFN_MAX_ROWS": "4096", "MORL_BFN_EAGER3": "1", "MORL_PER_SPLIT": "1", "MORL_BF_DUAL": "0", "MORL_BF_T_FIRST": "1", "MORL_BF_ROLL": "0", "MORL_BF_PW": "15",
     # host side
     "MORL_COMM": "rccl", "MORL_HIP_LIB": "morl-baselines_amd/lib/libmorl_hip.so", "MORL_HOST_NOISE": "0",
     # measurement / test infrastructure

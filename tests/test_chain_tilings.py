@@ -319,52 +319,52 @@ def test_rolling_epilogues_give_the_bits_of_the_step_end_epilogues_on_the_gpu():
 
 
 def test_producer_wave_gives_the_bits_of_the_self_fed_chain():
-    """``MORL_BF_PW=1``: the backward chain's 64-row launch runs 320 work-items -- a fifth wave issues every piece of the weight ring and
+    """``MORL_BF_PW`` bit 0 (the mask's default is 15, every form on): the backward chain's 64-row launch runs 320 work-items -- a fifth wave issues every piece of the weight ring and
     waits for it, the four MFMA waves issue none (csrc/mlp_chain_bf.h: bf_ring_producer).  Same stream, same products, same order: the
     same bits; what the test pins is the hand-over (barrier counts, buffer reuse) on ragged tiles and on two and three hidden layers."""
     base = {"HIPSIM_CUS": "2", "MORL_BFN_MAX_ROWS": "0", "TILING_DEEP": "1"}
-    assert _argmax_digest("sim", dict(base, MORL_BF_PW="0"), pw_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_PW="1"), pw_steps=True)
+    assert _argmax_digest("sim", dict(base, MORL_BF_PW="14"), pw_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_PW="15"), pw_steps=True)
 
 
 @pytest.mark.gpu
 def test_producer_wave_gives_the_bits_of_the_self_fed_chain_on_the_gpu():
-    assert _argmax_digest("gpu", {"MORL_BF_PW": "0"}, pw_steps=False) == _argmax_digest("gpu", {"MORL_BF_PW": "1"}, pw_steps=True)
+    assert _argmax_digest("gpu", {"MORL_BF_PW": "0"}, pw_steps=False) == _argmax_digest("gpu", {"MORL_BF_PW": "15"}, pw_steps=True)
 
 
 def test_producer_wave_on_32_row_tiles_gives_the_bits_of_the_self_fed_chain():
-    """``MORL_BF_PW32=1``: the producer wave also on the 32-row tiles that backward launches of fewer 64-row tiles than CUs take (192
+    """``MORL_BF_PW`` bit 1: the producer wave also on the 32-row tiles that backward launches of fewer 64-row tiles than CUs take (192
     work-items: two MFMA waves + the producer) -- every case the emulated 256-CU chip runs with ``MORL_BFN_MAX_ROWS=0``."""
     base = {"MORL_BFN_MAX_ROWS": "0", "TILING_DEEP": "1"}
-    assert _argmax_digest("sim", dict(base, MORL_BF_PW32="0"), pw_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_PW32="1"), pw_steps=True)
+    assert _argmax_digest("sim", dict(base, MORL_BF_PW="13"), pw_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_PW="15"), pw_steps=True)
 
 
 @pytest.mark.gpu
 def test_producer_wave_on_32_row_tiles_gives_the_bits_of_the_self_fed_chain_on_the_gpu():
     # (the 256 x 64 case runs the 64-row producer form in both legs; 256 x 32 -- 8 192 rows -- is the 32-row launch)
-    assert _argmax_digest("gpu", {"MORL_BF_PW32": "0", "MORL_BF_PW": "1"}) == _argmax_digest("gpu", {"MORL_BF_PW32": "1", "MORL_BF_PW": "1"})
+    assert _argmax_digest("gpu", {"MORL_BF_PW": "13"}) == _argmax_digest("gpu", {"MORL_BF_PW": "15"})
 
 
 def test_producer_wave_in_the_forward_launch_gives_the_bits_of_the_self_fed_chain():
-    """``MORL_BF_PW_FWD=1``: a forward launch of one round (at most a 64-row tile per CU: one workgroup per CU) with the producer wave --
+    """``MORL_BF_PW`` bit 2: a forward launch of one round (at most a 64-row tile per CU: one workgroup per CU) with the producer wave --
     no-grad chain with the arg-max at its end (the producer has ended by then) and training chain.  An emulated chip of four CUs: the
     two chains' four tiles are one round."""
     base = {"HIPSIM_CUS": "4", "MORL_BFN_MAX_ROWS": "0", "TILING_DEEP": "1"}
-    assert _argmax_digest("sim", dict(base, MORL_BF_PW_FWD="0"), fpw_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_PW_FWD="1"), fpw_steps=True)
+    assert _argmax_digest("sim", dict(base, MORL_BF_PW="11"), fpw_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_PW="15"), fpw_steps=True)
 
 
 @pytest.mark.gpu
 def test_producer_wave_in_the_forward_launch_gives_the_bits_of_the_self_fed_chain_on_the_gpu():
     # (256 x 32: the forward launch's 2 x 128 tiles are one round)
-    assert _argmax_digest("gpu", {"MORL_BF_PW_FWD": "0"}, fpw_steps=False) == _argmax_digest("gpu", {"MORL_BF_PW_FWD": "1"}, fpw_steps=True)
+    assert _argmax_digest("gpu", {"MORL_BF_PW": "3"}, fpw_steps=False) == _argmax_digest("gpu", {"MORL_BF_PW": "15"}, fpw_steps=True)
 
 
 def test_producer_wave_in_the_forward_launch_on_32_row_tiles_gives_the_bits_of_the_self_fed_chain():
-    """``MORL_BF_PW_FWD32=1``: ... and forward launches on 32-row tiles (192 work-items), the emulated 256-CU chip's choice for every case
+    """``MORL_BF_PW`` bit 3: ... and forward launches on 32-row tiles (192 work-items), the emulated 256-CU chip's choice for every case
     here."""
     base = {"MORL_BFN_MAX_ROWS": "0", "TILING_DEEP": "1"}
-    assert _argmax_digest("sim", dict(base, MORL_BF_PW_FWD32="0"), fpw_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_PW_FWD32="1"), fpw_steps=True)
+    assert _argmax_digest("sim", dict(base, MORL_BF_PW="7"), fpw_steps=False) == _argmax_digest("sim", dict(base, MORL_BF_PW="15"), fpw_steps=True)
 
 
 @pytest.mark.gpu
 def test_producer_wave_in_the_forward_launch_on_32_row_tiles_gives_the_bits_of_the_self_fed_chain_on_the_gpu():
-    assert _argmax_digest("gpu", {"MORL_BF_PW_FWD32": "0"}) == _argmax_digest("gpu", {"MORL_BF_PW_FWD32": "1"})
+    assert _argmax_digest("gpu", {"MORL_BF_PW": "7"}) == _argmax_digest("gpu", {"MORL_BF_PW": "15"})

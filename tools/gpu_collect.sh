@@ -63,7 +63,7 @@ roll-ab)     timeout 900 python -m pytest tests/test_chain_tilings.py -m gpu -q 
              done; done ;;
 pw-ab)       timeout 600 python -m pytest tests/test_chain_tilings.py -m gpu -q -x -p no:cacheprovider -k producer_wave 2>&1 | tail -15 > $O/pw_test.log; tail -3 $O/pw_test.log
              for rep in 1 2 3; do for d in 0 1; do
-               MORL_BF_PW=$d timeout 300 python bench.py --steps 300 --warmup 20 $B $S > $O/pw_ab_${d}_$rep.json 2>/dev/null
+               MORL_BF_PW=$((14 + d)) timeout 300 python bench.py --steps 300 --warmup 20 $B $S > $O/pw_ab_${d}_$rep.json 2>/dev/null
                python -c "import json,sys; j=json.loads(open('$O/pw_ab_${d}_$rep.json').read()); print('pw=$d', j['ms_per_step'], {k: round(v['avg_launch_us'], 1) for k, v in j['roofline']['per_kernel'].items()})"
              done; done ;;
 probes)      for p in planes_probe cmp64_probe valu_mfma_probe; do [ -x tools/probes/$p ] && timeout 200 tools/probes/$p > $O/$p.txt 2>&1; done; tail -4 $O/cmp64_probe.txt ;;

@@ -3,7 +3,7 @@ parameters, Adam state and the last step's outputs -- run once per environment (
 the default environment) in fresh interpreters; the digests must agree.  A race in a hand-over (a weight stage read before it landed,
 a buffer reused too early) shows up as a different digest within a few hundred steps.
     python tools/soak_kernel_forms.py --steps 2000 --shape 256,64 - MORL_BF_PW=0
-    python tools/soak_kernel_forms.py --steps 2000 --shape 256,32 - MORL_BF_PW32=0,MORL_BF_PW_FWD=0"""
+    python tools/soak_kernel_forms.py --steps 2000 --shape 256,32 - MORL_BF_PW=0 MORL_BF_PW=5"""
 import hashlib, os, subprocess, sys
 
 SNIPPET = r"""
